@@ -1,0 +1,801 @@
+/*
+ * mc_oracle.c -- CPU ORACLE (test infrastructure, see mc_oracle.h).  Scalar restatement of the
+ * reference's kernels; every function cites the reference lines it follows.
+ *
+ * Build: see oracle/Makefile (gcc -O2 -fno-fast-math -ffp-contract=off -fopenmp).
+ * -ffp-contract=off keeps a*b+c as two roundings so results do not depend on the host ISA.
+ */
+#include "mc_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define AINLINE static inline __attribute__((always_inline))
+
+/* ------------------------------------------------------------------------------------------
+ * bf16  (include/metalchat/dtype.h:32-58: round-to-nearest-even on the float bits; NaN keeps a
+ * quiet bit; the host class flushes subnormals to zero, the device `bfloat(float)` conversion is
+ * plain RNE -- the two agree on every value the path produces, subnormal inputs are kept RNE here
+ * because that is what kernel code does).
+ * ------------------------------------------------------------------------------------------ */
+mco_bf16
+mco_f32_to_bf16(float f)
+{
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7f800000u) == 0x7f800000u && (u & 0x007fffffu)) {
+        return (mco_bf16)((u >> 16) | 0x40u); /* NaN stays NaN */
+    }
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (mco_bf16)(u >> 16);
+}
+
+float
+mco_bf16_to_f32(mco_bf16 b)
+{
+    uint32_t u = (uint32_t)b << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+AINLINE float
+ld(const int dt, const void* p, size_t i)
+{
+    if (dt == MCO_BF16) return mco_bf16_to_f32(((const mco_bf16*)p)[i]);
+    return ((const float*)p)[i];
+}
+
+AINLINE void
+st(const int dt, void* p, size_t i, float v)
+{
+    if (dt == MCO_BF16)
+        ((mco_bf16*)p)[i] = mco_f32_to_bf16(v);
+    else
+        ((float*)p)[i] = v;
+}
+
+/* round a float to T and back: the value a T-typed temporary would hold */
+AINLINE float
+rt(const int dt, float v)
+{
+    return dt == MCO_BF16 ? mco_bf16_to_f32(mco_f32_to_bf16(v)) : v;
+}
+
+/* kernel/tensor.h:84-88,115-122,146-156: at(i...) = data[sum(stride_d*i_d + offset_d)] */
+AINLINE size_t
+at1(const uint32_t* l, uint32_t i0)
+{
+    return (size_t)l[1] * i0 + l[2];
+}
+AINLINE size_t
+at2(const uint32_t* l, uint32_t i0, uint32_t i1)
+{
+    return ((size_t)l[2] * i0 + l[4]) + ((size_t)l[3] * i1 + l[5]);
+}
+AINLINE size_t
+at3(const uint32_t* l, uint32_t i0, uint32_t i1, uint32_t i2)
+{
+    return ((size_t)l[3] * i0 + l[6]) + ((size_t)l[4] * i1 + l[7]) + ((size_t)l[5] * i2 + l[8]);
+}
+
+/* correctly rounded float transcendental = the value `precise::f` is an approximation of */
+AINLINE float
+exp_precise(float x)
+{
+    return (float)exp((double)x);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * bmm  (kernel/bmm.metal:25-82).  C[b,m,n] = T(sum_k float(A[b,m,k]) * float(B[b,k,n])), fp32
+ * partial accumulated in increasing k (the 8x8 tiling only stages operands, the per-output
+ * accumulation order is k = 0..K-1).
+ * ------------------------------------------------------------------------------------------ */
+AINLINE void
+bmm_impl(const int dt, const uint32_t* ol, void* out, const uint32_t* al, const void* a,
+         const uint32_t* bl, const void* b)
+{
+    const uint32_t nb = al[0], M = al[1], K = al[2], N = bl[2];
+#pragma omp parallel for collapse(2) schedule(static)
+    for (uint32_t bi = 0; bi < nb; bi++) {
+        for (uint32_t n = 0; n < N; n++) {
+            for (uint32_t m = 0; m < M; m++) {
+                float partial = 0.0f;
+                for (uint32_t k = 0; k < K; k++) {
+                    partial += ld(dt, a, at3(al, bi, m, k)) * ld(dt, b, at3(bl, bi, k, n));
+                }
+                st(dt, out, at3(ol, bi, m, n), partial);
+            }
+        }
+    }
+}
+
+void
+mco_bmm(int dt, const uint32_t* ol, void* out, const uint32_t* al, const void* a,
+        const uint32_t* bl, const void* b)
+{
+    if (dt == MCO_BF16)
+        bmm_impl(MCO_BF16, ol, out, al, a, bl, b);
+    else
+        bmm_impl(MCO_F32, ol, out, al, a, bl, b);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * hadamard (kernel/mul.metal:13-48): out = in1 * in2 evaluated in T.
+ * ------------------------------------------------------------------------------------------ */
+void
+mco_hadamard(int dt, const uint32_t* ol, void* out, const uint32_t* al, const void* a,
+             const uint32_t* bl, const void* b)
+{
+    for (uint32_t i = 0; i < al[0]; i++)
+        for (uint32_t k = 0; k < al[1]; k++)
+            st(dt, out, at2(ol, i, k), ld(dt, a, at2(al, i, k)) * ld(dt, b, at2(bl, i, k)));
+}
+
+/* ------------------------------------------------------------------------------------------
+ * hadamard_broadcast (kernel/mul.metal:51-85) -- THE DEQUANTIZER:
+ *   out[i,j] = Output(in1[i,j]) * Output(in2[i % in2.size(0)])      (product evaluated in Output)
+ * ------------------------------------------------------------------------------------------ */
+void
+mco_hadamard_broadcast(int odt, int sdt, const uint32_t* ol, void* out, const uint32_t* il,
+                       const int8_t* in1, const uint32_t* sl, const void* in2)
+{
+    for (uint32_t i = 0; i < il[0]; i++) {
+        const float s = rt(odt, ld(sdt, in2, at1(sl, i % sl[0])));
+        for (uint32_t j = 0; j < il[1]; j++) {
+            const float q = rt(odt, (float)in1[at2(il, i, j)]);
+            st(odt, out, at2(ol, i, j), q * s);
+        }
+    }
+}
+
+/* scalar_mul (kernel/mul.metal:88-121): out = in * multiplier in T */
+void
+mco_scalar_mul(int dt, const uint32_t* ol, void* out, const uint32_t* il, const void* in,
+               const void* multiplier)
+{
+    const float m = ld(dt, multiplier, 0);
+    for (uint32_t i = 0; i < il[0]; i++)
+        for (uint32_t k = 0; k < il[1]; k++)
+            st(dt, out, at2(ol, i, k), ld(dt, in, at2(il, i, k)) * m);
+}
+
+/* simd_sum over a 32-lane group, restated as a butterfly (the hardware order is unspecified) */
+static float
+simd_sum32(float* v)
+{
+    for (int off = 16; off >= 1; off >>= 1)
+        for (int i = 0; i < off; i++) v[i] = v[i] + v[i + off];
+    return v[0];
+}
+
+/* two-level threadgroup reduction shared by rmsnorm and softmax
+ * (kernel/rmsnorm.metal:58-84, kernel/softmax.metal:50-75): per-thread partials -> simd_sum ->
+ * 32-slot threadgroup array -> simd_sum. */
+static float
+threadgroup_sum(const float* partial, uint32_t nthreads)
+{
+    float groups[32];
+    for (int g = 0; g < 32; g++) groups[g] = 0.0f;
+    for (uint32_t g = 0; g * 32 < nthreads; g++) {
+        float lanes[32];
+        for (uint32_t l = 0; l < 32; l++) {
+            uint32_t t = g * 32 + l;
+            lanes[l] = t < nthreads ? partial[t] : 0.0f;
+        }
+        groups[g] = simd_sum32(lanes);
+    }
+    return simd_sum32(groups);
+}
+
+static uint32_t
+ceil_div_u32(uint32_t a, uint32_t b)
+{
+    return (a + b - 1) / b;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * rmsnorm (kernel/rmsnorm.metal:28-98; launch maths include/metalchat/kernel/rmsnorm.h:40-45)
+ *   y = T((mu + w) * x * rsqrt(mean(x^2) + eps)), fp32 math.
+ * ------------------------------------------------------------------------------------------ */
+AINLINE void
+rmsnorm_impl(const int dt, const uint32_t* ol, void* out, const uint32_t* il, const void* in,
+             const uint32_t* wl, const void* w, float eps, float mu, uint32_t max_threads)
+{
+    const uint32_t rows = il[0], dim = il[1];
+    const uint32_t block = ceil_div_u32(dim, max_threads);
+    const uint32_t nthreads = ceil_div_u32(dim, block);
+    float* partial = (float*)malloc(sizeof(float) * nthreads);
+    for (uint32_t i = 0; i < rows; i++) {
+        for (uint32_t t = 0; t < nthreads; t++) {
+            float s = 0.0f;
+            for (uint32_t j = t * block; j < (t + 1) * block && j < dim; j++) {
+                float x = ld(dt, in, at2(il, i, j));
+                s += x * x;
+            }
+            partial[t] = s;
+        }
+        const float acc = threadgroup_sum(partial, nthreads);
+        const float mean_sq = acc / (float)dim;
+        const float inv = 1.0f / sqrtf(mean_sq + eps);
+        for (uint32_t j = 0; j < dim; j++) {
+            const float x = ld(dt, in, at2(il, i, j));
+            const float weight = mu + ld(dt, w, at1(wl, j));
+            st(dt, out, at2(ol, i, j), weight * x * inv);
+        }
+    }
+    free(partial);
+}
+
+void
+mco_rmsnorm(int dt, const uint32_t* ol, void* out, const uint32_t* il, const void* in,
+            const uint32_t* wl, const void* w, float eps, float mu, uint32_t max_threads)
+{
+    if (dt == MCO_BF16)
+        rmsnorm_impl(MCO_BF16, ol, out, il, in, wl, w, eps, mu, max_threads);
+    else
+        rmsnorm_impl(MCO_F32, ol, out, il, in, wl, w, eps, mu, max_threads);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * rope (kernel/rope.metal:29-63).  NOTE `head_dim` in the kernel is f_cos.size(1) = dim/2.
+ * PARITY UNPINNED: the reference has no test for the rotation kernel.
+ * ------------------------------------------------------------------------------------------ */
+void
+mco_rope(int dt, const uint32_t* ol, void* out, const uint32_t* il, const void* in,
+         const uint32_t* cl, const float* fcos, const uint32_t* sl, const float* fsin,
+         uint32_t batch_size, uint32_t n_head, uint32_t start_pos)
+{
+    const uint32_t rows = il[0], half = cl[1];
+    for (uint32_t i = 0; i < rows; i++) {
+        const uint32_t pos = i / (batch_size * n_head);
+        for (uint32_t k = 0; k < half; k++) {
+            const float x1 = ld(dt, in, at2(il, i, k));
+            const float x2 = ld(dt, in, at2(il, i, half + k));
+            const float c = fcos[at2(cl, start_pos + pos, k)];
+            const float s = fsin[at2(sl, start_pos + pos, k)];
+            st(dt, out, at2(ol, i, k), c * x1 - s * x2);
+            st(dt, out, at2(ol, i, half + k), s * x1 + c * x2);
+        }
+    }
+}
+
+/* one (cos, sin) pair exactly as rope_freqs computes it (kernel/rope.metal:94-99), with the
+ * `precise::` functions restated as correctly rounded float results */
+static void
+rope_angle(uint32_t pos, uint32_t j, uint32_t dim, float theta, float* c, float* s)
+{
+    const float e = 2.0f * (float)j / (float)dim;
+    const float freq = 1.0f / (float)pow((double)theta, (double)e);
+    const float angle = (float)pos * freq;
+    *c = (float)cos((double)angle);
+    *s = (float)sin((double)angle);
+}
+
+/* rope_freqs (kernel/rope.metal:77-102) */
+void
+mco_rope_freqs(const uint32_t* cl, float* fcos, const uint32_t* sl, float* fsin, uint32_t dim,
+               uint32_t start_pos, float theta)
+{
+    for (uint32_t i = 0; i < cl[0]; i++)
+        for (uint32_t j = 0; j < dim / 2; j++)
+            rope_angle(start_pos + i, j, dim, theta, &fcos[at2(cl, i, j)], &fsin[at2(sl, i, j)]);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * softmax (kernel/softmax.metal:24-88): exp(x) / sum(exp(x)) with NO max subtraction.
+ * ------------------------------------------------------------------------------------------ */
+AINLINE void
+softmax_impl(const int dt, const uint32_t* ol, void* out, const uint32_t* il, const void* in,
+             uint32_t max_threads)
+{
+    const uint32_t rows = il[0], dim = il[1];
+    const uint32_t block = ceil_div_u32(dim, max_threads);
+    const uint32_t nthreads = ceil_div_u32(dim, block);
+    float* partial = (float*)malloc(sizeof(float) * nthreads);
+    for (uint32_t i = 0; i < rows; i++) {
+        for (uint32_t t = 0; t < nthreads; t++) {
+            float s = 0.0f;
+            for (uint32_t j = t * block; j < (t + 1) * block && j < dim; j++)
+                s += exp_precise(ld(dt, in, at2(il, i, j)));
+            partial[t] = s;
+        }
+        const float exp_sum = 1.0f / threadgroup_sum(partial, nthreads);
+        for (uint32_t j = 0; j < dim; j++)
+            st(dt, out, at2(ol, i, j), exp_precise(ld(dt, in, at2(il, i, j))) * exp_sum);
+    }
+    free(partial);
+}
+
+void
+mco_softmax(int dt, const uint32_t* ol, void* out, const uint32_t* il, const void* in,
+            uint32_t max_threads)
+{
+    if (dt == MCO_BF16)
+        softmax_impl(MCO_BF16, ol, out, il, in, max_threads);
+    else
+        softmax_impl(MCO_F32, ol, out, il, in, max_threads);
+}
+
+/* embedding (kernel/embedding.metal:38-70): out[i,j,k] = w[in[i,j], k] */
+void
+mco_embedding(int dt, const uint32_t* ol, void* out, const uint32_t* il, const int32_t* in,
+              const uint32_t* wl, const void* w)
+{
+    const size_t esz = dt == MCO_BF16 ? 2 : 4;
+    for (uint32_t i = 0; i < il[0]; i++)
+        for (uint32_t j = 0; j < il[1]; j++) {
+            const uint32_t id = (uint32_t)in[at2(il, i, j)];
+            for (uint32_t k = 0; k < wl[1]; k++)
+                memcpy((char*)out + esz * at3(ol, i, j, k),
+                       (const char*)w + esz * at2(wl, id, k), esz);
+        }
+}
+
+/* copy (kernel/copy.metal:20-42) */
+void
+mco_copy(int dt, const uint32_t* ol, void* out, const uint32_t* il, const void* in)
+{
+    const size_t esz = dt == MCO_BF16 ? 2 : 4;
+    for (uint32_t i = 0; i < il[0]; i++)
+        for (uint32_t k = 0; k < il[1]; k++)
+            memcpy((char*)out + esz * at2(ol, i, k), (const char*)in + esz * at2(il, i, k), esz);
+}
+
+/* roll (kernel/roll.metal:23-49): out[k] = in[base + ((k/stride + shift) % size)*stride + k%stride] */
+void
+mco_roll(int dt, const uint32_t* ol, void* out, const uint32_t* il, const void* in,
+         uint32_t shift, uint32_t size, uint32_t stride)
+{
+    const size_t esz = dt == MCO_BF16 ? 2 : 4;
+    const uint32_t stride_size = size * stride;
+    for (uint32_t k = 0; k < il[0]; k++) {
+        const uint32_t base = (k / stride_size) * stride_size;
+        const uint32_t i = (k / stride + shift) % size;
+        const uint32_t j = k % stride;
+        const uint32_t m = base + i * stride + j;
+        memcpy((char*)out + esz * at1(ol, k), (const char*)in + esz * at1(il, m), esz);
+    }
+}
+
+/* add (kernel/arithmetic.metal:13-46) evaluated in T */
+void
+mco_add(int dt, const uint32_t* ol, void* out, const uint32_t* al, const void* a,
+        const uint32_t* bl, const void* b)
+{
+    for (uint32_t i = 0; i < al[0]; i++)
+        for (uint32_t k = 0; k < al[1]; k++)
+            st(dt, out, at2(ol, i, k), ld(dt, a, at2(al, i, k)) + ld(dt, b, at2(bl, i, k)));
+}
+
+/* add_broadcast (kernel/arithmetic.metal:49-85): out[i,j] = in1[i,j] + in2[j % n] */
+void
+mco_add_broadcast(int dt, const uint32_t* ol, void* out, const uint32_t* al, const void* a,
+                  const uint32_t* bl, const void* b)
+{
+    for (uint32_t i = 0; i < al[0]; i++)
+        for (uint32_t j = 0; j < al[1]; j++)
+            st(dt, out, at2(ol, i, j), ld(dt, a, at2(al, i, j)) + ld(dt, b, at1(bl, j % bl[0])));
+}
+
+/* silu (kernel/activation.metal:13-41): x / (T(1) + T(exp(-x))), every step a T value */
+AINLINE float
+silu_T(const int dt, float x)
+{
+    const float e = rt(dt, exp_precise(-x));
+    const float d = rt(dt, 1.0f + e);
+    return rt(dt, x / d);
+}
+
+void
+mco_silu(int dt, const uint32_t* ol, void* out, const uint32_t* il, const void* in)
+{
+    for (uint32_t i = 0; i < il[0]; i++)
+        for (uint32_t k = 0; k < il[1]; k++)
+            st(dt, out, at2(ol, i, k), silu_T(dt, ld(dt, in, at2(il, i, k))));
+}
+
+/* gelu (kernel/activation.metal:44-78): tanh approximation in fp32 */
+AINLINE float
+gelu_f(float x)
+{
+    const float beta = 1.41421356237309504880f * 1.12837916709551257390f * 0.5f;
+    const float kappa = 0.044715f;
+    const float x3 = x * x * x;
+    const float inner = beta * (x + kappa * x3);
+    return 0.5f * x * (1.0f + (float)tanh((double)inner));
+}
+
+void
+mco_gelu(int dt, const uint32_t* ol, void* out, const uint32_t* il, const void* in)
+{
+    for (uint32_t i = 0; i < il[0]; i++)
+        for (uint32_t k = 0; k < il[1]; k++)
+            st(dt, out, at2(ol, i, k), gelu_f(ld(dt, in, at2(il, i, k))));
+}
+
+/* ==========================================================================================
+ * Model-level restatement: one transform(token, start_pos) with len == 1.
+ *   nn::llama3::operator()        include/metalchat/nn/llama.h:113-134
+ *   nn::gemma3::operator()        include/metalchat/nn/gemma.h:110-137
+ *   nn::transformer::operator()   include/metalchat/nn/transformer.h:126-141
+ *   nn::attention::operator()     include/metalchat/nn/attention.h:161-206
+ *   nn::feed_forward::operator()  include/metalchat/nn/transformer.h:53-60
+ *   nn::sink_cache::update/copy   include/metalchat/nn/cache.h:133-216
+ *   nn::rope                      include/metalchat/nn/embedding.h:107-200
+ *   quantization::lora_linear     include/metalchat/quantization/lora.h:94-122
+ *   quantization::linear          include/metalchat/quantization/linear.h:45-55
+ * Every intermediate the reference materialises as a T tensor is rounded to T here.
+ * PARITY UNPINNED: the reference's integration tests assert nothing about logits.
+ * ========================================================================================== */
+struct mco_model {
+    mco_model_options opt;
+    mco_layer_weights* layers;
+    int32_t emb_kind;
+    const void* emb_weight;
+    const float* emb_scales;
+    const void* final_norm;
+    mco_linear output;
+    size_t esz;
+    int32_t pre_len;
+    /* per-layer KV caches [max_seq, n_kv, hd] of T, plus a scratch "new" buffer for the roll */
+    void** k_cache;
+    void** v_cache;
+    void* roll_tmp;
+    int32_t* end_pos;
+    /* activations (T stored as float after rounding) */
+    float* hidden_taps; /* (n_layers + 1) * dim */
+};
+
+static int g_threads = 0;
+void
+mco_set_num_threads(int n)
+{
+    g_threads = n;
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#endif
+}
+
+static int32_t
+bit_width_u32(uint32_t v)
+{
+    int32_t n = 0;
+    while (v) {
+        n++;
+        v >>= 1;
+    }
+    return n;
+}
+
+/* y[o] = T(sum_k x[k] * W[o,k]) for the three linear kinds; x and y hold T values as floats */
+static void
+linear_apply(const int dt, const mco_linear* L, const float* x, float* y)
+{
+    const int32_t out = L->out_features, in = L->in_features;
+    if (L->kind == 0) {
+#pragma omp parallel for schedule(static)
+        for (int32_t o = 0; o < out; o++) {
+            float partial = 0.0f;
+            if (dt == MCO_BF16) {
+                const mco_bf16* w = (const mco_bf16*)L->weight + (size_t)o * in;
+                for (int32_t k = 0; k < in; k++) partial += x[k] * mco_bf16_to_f32(w[k]);
+            } else {
+                const float* w = (const float*)L->weight + (size_t)o * in;
+                for (int32_t k = 0; k < in; k++) partial += x[k] * w[k];
+            }
+            y[o] = rt(dt, partial);
+        }
+    } else {
+        /* lora.h:105-117 / linear.h:50-54: Wd = T(q) * T(scale) evaluated in T (mul.metal:78-82),
+         * then bmm in fp32 (bmm.metal:54-67). kind 1: scale per (row, group); kind 2: per row. */
+        const int32_t G = L->kind == 1 ? L->group_size : in;
+        const int32_t ng = in / G;
+#pragma omp parallel for schedule(static)
+        for (int32_t o = 0; o < out; o++) {
+            const int8_t* q = (const int8_t*)L->weight + (size_t)o * in;
+            float partial = 0.0f;
+            for (int32_t g = 0; g < ng; g++) {
+                const float s = rt(dt, L->scales[(size_t)o * ng + g]);
+                for (int32_t k = g * G; k < (g + 1) * G; k++) {
+                    const float wd = rt(dt, (float)q[k] * s);
+                    partial += x[k] * wd;
+                }
+            }
+            y[o] = rt(dt, partial);
+        }
+        if (L->kind == 1 && L->lora_rank > 0) {
+            /* lora.h:119-121: result = output + mul(B(A(x)), scale) */
+            const int32_t r = L->lora_rank;
+            float* a = (float*)malloc(sizeof(float) * r);
+            for (int32_t i = 0; i < r; i++) {
+                float p = 0.0f;
+                for (int32_t k = 0; k < in; k++)
+                    p += x[k] * ld(dt, L->lora_a, (size_t)i * in + k);
+                a[i] = rt(dt, p);
+            }
+            const float sc = rt(dt, L->lora_scale);
+            for (int32_t o = 0; o < out; o++) {
+                float p = 0.0f;
+                for (int32_t i = 0; i < r; i++) p += a[i] * ld(dt, L->lora_b, (size_t)o * r + i);
+                const float b = rt(dt, p);
+                const float ad = rt(dt, b * sc);
+                y[o] = rt(dt, y[o] + ad);
+            }
+            free(a);
+        }
+    }
+}
+
+/* rmsnorm over one row held as floats (values already T), weights in T memory */
+static void
+rmsnorm_row(const int dt, const float* x, const void* w, int32_t dim, float eps, float mu,
+            float* y)
+{
+    const uint32_t max_threads = 1024;
+    const uint32_t block = ceil_div_u32((uint32_t)dim, max_threads);
+    const uint32_t nthreads = ceil_div_u32((uint32_t)dim, block);
+    float partial[1024];
+    for (uint32_t t = 0; t < nthreads; t++) {
+        float s = 0.0f;
+        for (uint32_t j = t * block; j < (t + 1) * block && j < (uint32_t)dim; j++)
+            s += x[j] * x[j];
+        partial[t] = s;
+    }
+    const float acc = threadgroup_sum(partial, nthreads);
+    const float inv = 1.0f / sqrtf(acc / (float)dim + eps);
+    for (int32_t j = 0; j < dim; j++) {
+        const float weight = mu + ld(dt, w, (size_t)j);
+        y[j] = rt(dt, weight * x[j] * inv);
+    }
+}
+
+mco_model*
+mco_model_create(const mco_model_options* opt, const mco_layer_weights* layers, int32_t emb_kind,
+                 const void* emb_weight, const float* emb_scales, const void* final_norm,
+                 const mco_linear* output)
+{
+    mco_model* m = (mco_model*)calloc(1, sizeof(mco_model));
+    m->opt = *opt;
+    m->layers = (mco_layer_weights*)malloc(sizeof(mco_layer_weights) * opt->n_layers);
+    memcpy(m->layers, layers, sizeof(mco_layer_weights) * opt->n_layers);
+    m->emb_kind = emb_kind;
+    m->emb_weight = emb_weight;
+    m->emb_scales = emb_scales;
+    m->final_norm = final_norm;
+    m->output = *output;
+    m->esz = opt->dtype == MCO_BF16 ? 2 : 4;
+    /* nn/cache.h:125-127: pre_len = bit_width(max_seq_len) - 1 */
+    m->pre_len = opt->sink_pre_len >= 0 ? opt->sink_pre_len
+                                        : bit_width_u32((uint32_t)opt->max_seq_len) - 1;
+    const size_t cache_bytes =
+        (size_t)opt->max_seq_len * opt->n_kv_heads * opt->head_dim * m->esz;
+    m->k_cache = (void**)malloc(sizeof(void*) * opt->n_layers);
+    m->v_cache = (void**)malloc(sizeof(void*) * opt->n_layers);
+    for (int32_t i = 0; i < opt->n_layers; i++) {
+        m->k_cache[i] = calloc(1, cache_bytes);
+        m->v_cache[i] = calloc(1, cache_bytes);
+    }
+    m->roll_tmp = malloc(cache_bytes);
+    m->end_pos = (int32_t*)calloc(opt->n_layers, sizeof(int32_t));
+    m->hidden_taps = (float*)calloc((size_t)(opt->n_layers + 1) * opt->dim, sizeof(float));
+    return m;
+}
+
+void
+mco_model_destroy(mco_model* m)
+{
+    if (!m) return;
+    for (int32_t i = 0; i < m->opt.n_layers; i++) {
+        free(m->k_cache[i]);
+        free(m->v_cache[i]);
+    }
+    free(m->k_cache);
+    free(m->v_cache);
+    free(m->roll_tmp);
+    free(m->end_pos);
+    free(m->hidden_taps);
+    free(m->layers);
+    free(m);
+}
+
+/* nn::sink_cache::copy (nn/cache.h:167-216) for len == 1.  `cache` is [max_seq, row] of T where
+ * row = n_kv*hd.  Returns end_pos (the length of the returned view).
+ * PARITY UNPINNED: no reference test reaches start_pos >= max_seq_len. */
+static int32_t
+sink_cache_update(mco_model* m, void* cache, const float* new_row, int32_t start_pos)
+{
+    const int dt = m->opt.dtype;
+    const int32_t cache_size = m->opt.max_seq_len;
+    const size_t row = (size_t)m->opt.n_kv_heads * m->opt.head_dim;
+    const size_t rb = row * m->esz;
+    const int32_t len = 1;
+    const int32_t pre = m->pre_len, post = cache_size - pre;
+    if (start_pos >= cache_size) {
+        char* src = (char*)cache;
+        char* dst = (char*)m->roll_tmp;
+        /* prefix copy (cache.h:189-193) */
+        memcpy(dst, src, (size_t)pre * rb);
+        /* roll(cache_post -> cache_new_post, shift=len, dim=1) (cache.h:195-199, roll.metal) */
+        for (int32_t p = 0; p < post; p++)
+            memcpy(dst + (size_t)(pre + p) * rb, src + (size_t)(pre + (p + len) % post) * rb, rb);
+        memcpy(src, dst, (size_t)cache_size * rb);
+        start_pos = cache_size - len;
+    }
+    for (size_t j = 0; j < row; j++) st(dt, cache, (size_t)start_pos * row + j, new_row[j]);
+    return start_pos + len;
+}
+
+int32_t
+mco_model_step(mco_model* m, int32_t token, int32_t start_pos, void* logits_out)
+{
+    const mco_model_options* o = &m->opt;
+    const int dt = o->dtype;
+    const int32_t dim = o->dim, H = o->n_heads, KV = o->n_kv_heads, hd = o->head_dim;
+    const int32_t n_rep = H / KV, half = hd / 2;
+    const float mu = o->family == 1 ? 1.0f : 0.0f;
+
+    float* x = (float*)malloc(sizeof(float) * dim);
+    float* hn = (float*)malloc(sizeof(float) * dim);
+    float* q = (float*)malloc(sizeof(float) * H * hd);
+    float* k = (float*)malloc(sizeof(float) * KV * hd);
+    float* v = (float*)malloc(sizeof(float) * KV * hd);
+    float* qr = (float*)malloc(sizeof(float) * H * hd);
+    float* kr = (float*)malloc(sizeof(float) * KV * hd);
+    float* att = (float*)malloc(sizeof(float) * H * hd);
+    float* proj = (float*)malloc(sizeof(float) * dim);
+    float* h1 = (float*)malloc(sizeof(float) * dim);
+    float* g1 = (float*)malloc(sizeof(float) * o->ffn_dim);
+    float* g3 = (float*)malloc(sizeof(float) * o->ffn_dim);
+    float* ff = (float*)malloc(sizeof(float) * dim);
+    float* scores = (float*)malloc(sizeof(float) * o->max_seq_len);
+    float* partial = (float*)malloc(sizeof(float) * 1024);
+    float* fcos = (float*)malloc(sizeof(float) * half * 2);
+    float* fsin = (float*)malloc(sizeof(float) * half * 2);
+
+    /* embedding (nn/embedding.h:82-86; quantization/lora.h:161-170 dequantises the table once) */
+    if (m->emb_kind == 0) {
+        for (int32_t j = 0; j < dim; j++) x[j] = ld(dt, m->emb_weight, (size_t)token * dim + j);
+    } else {
+        const int8_t* qw = (const int8_t*)m->emb_weight + (size_t)token * dim;
+        const float s = rt(dt, m->emb_scales[token]);
+        for (int32_t j = 0; j < dim; j++) x[j] = rt(dt, (float)qw[j] * s);
+    }
+    if (o->family == 1) { /* nn/gemma.h:115 */
+        const float sc = rt(dt, sqrtf((float)dim));
+        for (int32_t j = 0; j < dim; j++) x[j] = rt(dt, x[j] * sc);
+    }
+    memcpy(m->hidden_taps, x, sizeof(float) * dim);
+
+    /* rope tables for this position: table t = 0 global theta, 1 sliding theta */
+    for (int t = 0; t < 2; t++) {
+        const float theta = t == 0 ? o->rope_theta : o->rope_sliding_theta;
+        if (theta <= 0.0f) continue;
+        for (int32_t j = 0; j < half; j++)
+            rope_angle((uint32_t)start_pos, (uint32_t)j, (uint32_t)hd, theta, &fcos[t * half + j],
+                       &fsin[t * half + j]);
+    }
+    const float scale_T = rt(dt, o->attn_scale); /* attention.h:148 _M_scale(options.scale) is a T */
+
+    for (int32_t li = 0; li < o->n_layers; li++) {
+        const mco_layer_weights* L = &m->layers[li];
+        /* transformer.h:130 */
+        rmsnorm_row(dt, x, L->attention_norm, dim, o->norm_eps, mu, hn);
+        /* attention.h:170-172 */
+        linear_apply(dt, &L->wq, hn, q);
+        linear_apply(dt, &L->wk, hn, k);
+        linear_apply(dt, &L->wv, hn, v);
+        /* attention.h:174-175 (gemma q/k norm over head_dim) */
+        if (L->q_norm) {
+            for (int32_t h = 0; h < H; h++)
+                rmsnorm_row(dt, q + h * hd, L->q_norm, hd, o->norm_eps, mu, q + h * hd);
+            for (int32_t h = 0; h < KV; h++)
+                rmsnorm_row(dt, k + h * hd, L->k_norm, hd, o->norm_eps, mu, k + h * hd);
+        }
+        /* rope (rope.metal:49-59) */
+        const float* c = fcos + L->rope_table * half;
+        const float* s = fsin + L->rope_table * half;
+        for (int32_t h = 0; h < H; h++)
+            for (int32_t j = 0; j < half; j++) {
+                const float x1 = q[h * hd + j], x2 = q[h * hd + half + j];
+                qr[h * hd + j] = rt(dt, c[j] * x1 - s[j] * x2);
+                qr[h * hd + half + j] = rt(dt, s[j] * x1 + c[j] * x2);
+            }
+        for (int32_t h = 0; h < KV; h++)
+            for (int32_t j = 0; j < half; j++) {
+                const float x1 = k[h * hd + j], x2 = k[h * hd + half + j];
+                kr[h * hd + j] = rt(dt, c[j] * x1 - s[j] * x2);
+                kr[h * hd + half + j] = rt(dt, s[j] * x1 + c[j] * x2);
+            }
+        /* attention.h:177 */
+        const int32_t S = sink_cache_update(m, m->k_cache[li], kr, start_pos);
+        sink_cache_update(m, m->v_cache[li], v, start_pos);
+        m->end_pos[li] = S;
+        const size_t row = (size_t)KV * hd;
+        /* attention.h:179-203: repeat_kv is a pure copy, indexed here as kv = h / n_reps
+         * (functional/transform.h:20-90: repeat_interleave along the head dim) */
+        for (int32_t h = 0; h < H; h++) {
+            const int32_t kvh = h / n_rep;
+            for (int32_t sp = 0; sp < S; sp++) {
+                float p = 0.0f;
+                for (int32_t d = 0; d < hd; d++)
+                    p += qr[h * hd + d] * ld(dt, m->k_cache[li], (size_t)sp * row + kvh * hd + d);
+                const float sc = rt(dt, p);          /* bmm -> T */
+                scores[sp] = rt(dt, sc * scale_T);   /* scalar_mul in T */
+            }
+            /* softmax (softmax.metal) */
+            const uint32_t block = ceil_div_u32((uint32_t)S, 1024);
+            const uint32_t nthreads = ceil_div_u32((uint32_t)S, block);
+            for (uint32_t t = 0; t < nthreads; t++) {
+                float acc = 0.0f;
+                for (uint32_t j = t * block; j < (t + 1) * block && j < (uint32_t)S; j++)
+                    acc += exp_precise(scores[j]);
+                partial[t] = acc;
+            }
+            const float exp_sum = 1.0f / threadgroup_sum(partial, nthreads);
+            for (int32_t sp = 0; sp < S; sp++)
+                scores[sp] = rt(dt, exp_precise(scores[sp]) * exp_sum);
+            /* PV bmm */
+            for (int32_t d = 0; d < hd; d++) {
+                float p = 0.0f;
+                for (int32_t sp = 0; sp < S; sp++)
+                    p += scores[sp] * ld(dt, m->v_cache[li], (size_t)sp * row + kvh * hd + d);
+                att[h * hd + d] = rt(dt, p);
+            }
+        }
+        /* attention.h:205 */
+        linear_apply(dt, &L->wo, att, proj);
+        /* transformer.h:132-133 */
+        if (L->attention_post_norm)
+            rmsnorm_row(dt, proj, L->attention_post_norm, dim, o->norm_eps, mu, proj);
+        for (int32_t j = 0; j < dim; j++) h1[j] = rt(dt, x[j] + proj[j]);
+        /* transformer.h:135-139 */
+        rmsnorm_row(dt, h1, L->ffn_norm, dim, o->norm_eps, mu, hn);
+        linear_apply(dt, &L->w1, hn, g1);
+        linear_apply(dt, &L->w3, hn, g3);
+        for (int32_t j = 0; j < o->ffn_dim; j++) {
+            const float a = o->family == 1 ? rt(dt, gelu_f(g1[j])) : silu_T(dt, g1[j]);
+            g1[j] = rt(dt, a * g3[j]); /* hadamard in T */
+        }
+        linear_apply(dt, &L->w2, g1, ff);
+        if (L->ffn_post_norm) rmsnorm_row(dt, ff, L->ffn_post_norm, dim, o->norm_eps, mu, ff);
+        for (int32_t j = 0; j < dim; j++) x[j] = rt(dt, h1[j] + ff[j]);
+        memcpy(m->hidden_taps + (size_t)(li + 1) * dim, x, sizeof(float) * dim);
+    }
+
+    /* llama.h:128-133 */
+    rmsnorm_row(dt, x, m->final_norm, dim, o->norm_eps, mu, hn);
+    float* logits = (float*)malloc(sizeof(float) * o->vocab);
+    linear_apply(dt, &m->output, hn, logits);
+    int32_t best = 0;
+    for (int32_t i = 1; i < o->vocab; i++)
+        if (logits[i] > logits[best]) best = i;
+    if (logits_out)
+        for (int32_t i = 0; i < o->vocab; i++) st(dt, logits_out, (size_t)i, logits[i]);
+
+    free(logits);
+    free(x); free(hn); free(q); free(k); free(v); free(qr); free(kr); free(att); free(proj);
+    free(h1); free(g1); free(g3); free(ff); free(scores); free(partial); free(fcos); free(fsin);
+    return best;
+}
+
+void
+mco_model_get_hidden(const mco_model* m, int32_t layer, void* out)
+{
+    const float* src = m->hidden_taps + (size_t)(layer + 1) * m->opt.dim;
+    for (int32_t j = 0; j < m->opt.dim; j++) st(m->opt.dtype, out, (size_t)j, src[j]);
+}
+
+int32_t
+mco_model_get_kv(const mco_model* m, int32_t layer, void* keys_out, void* values_out)
+{
+    const size_t rb = (size_t)m->opt.n_kv_heads * m->opt.head_dim * m->esz;
+    const int32_t n = m->end_pos[layer];
+    memcpy(keys_out, m->k_cache[layer], (size_t)n * rb);
+    memcpy(values_out, m->v_cache[layer], (size_t)n * rb);
+    return n;
+}
