@@ -1,0 +1,274 @@
+#!/usr/bin/env python3
+"""Headline benchmark: single-stream (batch = 1) greedy decode tokens/s of int4 Llama-3-8B on
+MI355X, with the achieved HBM rate of the dominant kernel (the fused int4 GEMV) against the
+8 TB/s roofline and the CPU restatement of the reference timed beside it.
+
+  python bench.py --gpus N --steps K --warmup W          (N = 1 default)
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one generated token: embedding -> 32 x (rmsnorm, QKV GEMV, RoPE, sink-cache write,
+QK^T, softmax, PV, Wo, residual, rmsnorm, w1|w3 GEMV, SiLU*mul, w2 GEMV, residual) -> final norm
+-> output-head GEMV -> greedy argmax, exactly what the reference's transform(token, start_pos)
+does per token (include/metalchat/transformer.h:357-364).  Weights are synthetic (counter-based
+hash, generated on the device), the context is filled by really decoding up to
+seq_len - steps before the timed region, and the timed tokens end at position seq_len so the KV
+traffic is at its configured maximum.
+
+N > 1: the layers are pipelined over N GPUs (contiguous layer ranges, one RCCL send/recv of the
+hidden row per stage boundary and one 4-byte token hop back), one process per GPU.  At batch 1
+only one stage is busy at a time, so this buys capacity, not speed: scaling is "strong".
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+MODELS = {
+    # SURVEY.md section 8 shape table
+    "llama3-8b": dict(dim=4096, n_heads=32, n_kv_heads=8, head_dim=128, ffn_dim=14336, n_layers=32,
+                      vocab=128256, rope_theta=500000.0, norm_eps=1e-5),
+    "tinyllama-1.1b": dict(dim=2048, n_heads=32, n_kv_heads=4, head_dim=64, ffn_dim=5632,
+                           n_layers=22, vocab=32000, rope_theta=10000.0, norm_eps=1e-5),
+    "llama3-70b": dict(dim=8192, n_heads=64, n_kv_heads=8, head_dim=128, ffn_dim=28672,
+                       n_layers=80, vocab=128256, rope_theta=500000.0, norm_eps=1e-5),
+}
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=256)
+    p.add_argument("--warmup", type=int, default=32)
+    p.add_argument("--model", default="llama3-8b", choices=sorted(MODELS))
+    p.add_argument("--wbits", type=int, default=4, choices=[4, 8, 16])
+    p.add_argument("--group", type=int, default=128)
+    p.add_argument("--seq-len", type=int, default=2048)
+    p.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    p.add_argument("--qmode", default="exact", choices=["exact", "fast"])
+    p.add_argument("--no-graph", action="store_true")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-roofline", action="store_true")
+    p.add_argument("--seed", type=int, default=0x5EED)
+    return p.parse_args()
+
+
+def algorithmic_bytes(m, wbits, group, seq_len, tbytes):
+    """weights + scales of every linear + KV read + KV write + embedding row."""
+    L, dim, H, KV, hd, ffn, V = (m["n_layers"], m["dim"], m["n_heads"], m["n_kv_heads"],
+                                 m["head_dim"], m["ffn_dim"], m["vocab"])
+    p_mm = L * (dim * H * hd + 2 * dim * KV * hd + H * hd * dim + 3 * dim * ffn) + V * dim
+    sb = 0 if wbits == 16 else (2 if tbytes == 2 else 4)
+    w = p_mm * (wbits / 8.0 + (sb / group if sb else 0.0))
+    kv_read = 2 * L * KV * hd * seq_len * tbytes
+    kv_write = 2 * L * KV * hd * tbytes
+    return dict(weights=w, kv_read=kv_read, kv_write=kv_write, embed=dim * tbytes,
+                total=w + kv_read + kv_write + dim * tbytes, p_mm=p_mm)
+
+
+def cpu_baseline(args, m, tbytes):
+    """The oracle (CPU restatement of the reference op sequence) timed on this box's host cores on
+    a bounded sample: a 2-layer slice of the same shapes + the full output head, a few tokens,
+    scaled to the full depth.  kind = "port" (there is no reference CPU path to run)."""
+    import numpy as np
+
+    import modelgen as mg
+    from oracle import mc_oracle as mo
+
+    cores = os.cpu_count() or 1
+    mo.set_num_threads(cores)
+    sample_layers = 2
+    cfg = dict(m)
+    cfg.update(dtype=0 if args.dtype == "bf16" else 1, family=0, n_layers=sample_layers,
+               max_seq_len=64, attn_scale=float(1.0 / np.sqrt(m["head_dim"])))
+    quant = {4: "i4", 8: "i8", 16: None}[args.wbits]
+    t0 = time.time()
+    weights = mg.make_model(cfg, seed=1, quant=quant, group=args.group)
+    gen_s = time.time() - t0
+    om = mo.Model(cfg, weights)
+    tok = 1
+    om.step(tok, 0, want_logits=False)  # touch pages
+    n = 3
+    t0 = time.time()
+    for pos in range(1, 1 + n):
+        tok, _ = om.step(tok, pos, want_logits=False)
+    per_tok = (time.time() - t0) / n
+    om.close()
+    # time of the head alone ~ vocab*dim MACs vs layer MACs: split by parameter count
+    L = m["n_layers"]
+    p_layer = m["dim"] * (m["n_heads"] + 2 * m["n_kv_heads"]) * m["head_dim"] + \
+        m["n_heads"] * m["head_dim"] * m["dim"] + 3 * m["dim"] * m["ffn_dim"]
+    p_head = m["vocab"] * m["dim"]
+    t_layer = per_tok * p_layer / (sample_layers * p_layer + p_head)
+    t_head = per_tok * p_head / (sample_layers * p_layer + p_head)
+    full = L * t_layer + t_head
+    return dict(value=1.0 / full, unit="tokens/s", cores=cores, kind="port",
+                sample=f"{sample_layers}-layer slice of {args.model} + full output head, {n} tokens at "
+                       f"context <= 4, {per_tok:.2f} s/token measured, scaled to {L} layers "
+                       f"(weights generated in {gen_s:.0f} s, not timed)")
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with "
+                  f"--nproc-per-node {args.gpus}", file=sys.stderr)
+            sys.exit(2)
+    import numpy as np
+    import torch
+
+    import metalchat_amd as mc
+
+    if not torch.cuda.is_available():
+        print("bench.py: no GPU visible (there is no CPU fallback for the product path)", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+
+        dist = dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+
+    m = MODELS[args.model]
+    tbytes = 2 if args.dtype == "bf16" else 4
+    dtype = mc.BF16 if args.dtype == "bf16" else mc.F32
+    wfmt = {4: mc.WFMT_I4, 8: mc.WFMT_I8, 16: mc.WFMT_T}[args.wbits]
+    S, K, W = args.seq_len, args.steps, args.warmup
+    if K + W > S:
+        print("bench.py: steps + warmup must not exceed seq-len", file=sys.stderr)
+        sys.exit(2)
+
+    # queue on torch's current stream so RCCL hops are ordered against the kernels by torch
+    stream = torch.cuda.current_stream().cuda_stream if world > 1 else None
+    acc = mc.HardwareAccelerator(ordinal=local_rank, stream=stream)
+    L = m["n_layers"]
+    lb, le = rank * L // world, (rank + 1) * L // world
+    dec = mc.Decoder(acc, dtype=dtype, family=mc.FAMILY_LLAMA3, max_seq_len=S,
+                     attn_scale=float(1.0 / np.sqrt(m["head_dim"])), layer_begin=lb, layer_end=le,
+                     weight_format=wfmt, group_size=(args.group if args.wbits != 16 else 0),
+                     qmode=(mc.QMODE_FAST if args.qmode == "fast" else mc.QMODE_EXACT),
+                     use_graph=0 if (args.no_graph or world > 1) else 1, **m)
+    dec.init_synthetic(args.seed)
+
+    fill = S - K - W  # context decoded (untimed) before warm-up so the timed tokens end at S
+
+    def sync_all():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        acc.wait()
+
+    if world == 1:
+        tok = 1
+        if fill > 0:
+            tok = int(dec.generate(tok, 0, fill)[-1])
+        if W > 0:
+            tok = int(dec.generate(tok, fill, W)[-1])
+        sync_all()
+        t0 = time.perf_counter()
+        toks = dec.generate(tok, fill + W, K)
+        sync_all()
+        dt = time.perf_counter() - t0
+        tmax = dt
+    else:
+        class _Raw:  # expose a decoder-owned device buffer to torch (CUDA array interface)
+            def __init__(self, ptr, n, typestr):
+                self.__cuda_array_interface__ = dict(shape=(n,), typestr=typestr, data=(ptr, False),
+                                                     version=3)
+        tt = "<u2" if tbytes == 2 else "<f4"
+        h_out = torch.as_tensor(_Raw(dec.hidden_out_ptr(), m["dim"], tt), device=f"cuda:{local_rank}")
+        h_in = torch.as_tensor(_Raw(dec.hidden_in_ptr(), m["dim"], tt), device=f"cuda:{local_rank}")
+        tok_t = torch.zeros(1, dtype=torch.int32, device=f"cuda:{local_rank}")
+
+        def run(start, n, tok):
+            for i in range(n):
+                pos = start + i
+                if rank > 0:
+                    dist.recv(h_in, src=rank - 1)
+                nt = dec.step(tok if rank == 0 else -1, pos,
+                              hidden_in=dec.hidden_in_ptr() if rank > 0 else None,
+                              sync=(rank == world - 1))
+                if rank < world - 1:
+                    dist.send(h_out, dst=rank + 1)
+                # token hop back to the first stage
+                if rank == world - 1:
+                    tok_t.fill_(nt)
+                    dist.send(tok_t, dst=0)
+                elif rank == 0:
+                    dist.recv(tok_t, src=world - 1)
+                    tok = int(tok_t.item())
+            return tok
+
+        tok = 1
+        tok = run(0, fill, tok)
+        tok = run(fill, W, tok)
+        sync_all()
+        t0 = time.perf_counter()
+        tok = run(fill + W, K, tok)
+        sync_all()
+        dt = time.perf_counter() - t0
+        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        tmax = float(t.item())
+
+    ab = algorithmic_bytes(m, args.wbits, args.group, S, tbytes)
+    tok_s = K / tmax
+    out = {
+        "metric": "decode tokens/s (batch=1) + achieved HBM GB/s vs roofline, int4 Llama-3-8B",
+        "value": tok_s, "unit": "tokens/s", "n_gpus": world, "steps": K, "warmup": W,
+        "ms_per_step": 1e3 * tmax / K, "higher_is_better": True,
+        "scaling": "strong" if world > 1 else "weak", "vs_baseline": None,
+        "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"{args.model} int{args.wbits} (group={args.group}) batch=1 greedy decode, "
+                               f"seq_len={S}, {args.dtype} activations/KV, qmode={args.qmode}",
+                   "parallelism": "single GPU" if world == 1 else f"layer pipeline pp{world} (RCCL send/recv)",
+                   "hipgraph": bool(world == 1 and not args.no_graph)},
+        "whole_token": {"algorithmic_bytes": ab["total"], "achieved_GBs": ab["total"] * tok_s / 1e9,
+                        "frac_of_hbm_peak": ab["total"] * tok_s / 1e9 / HBM_PEAK_GBS},
+    }
+
+    if rank == 0 and world == 1 and not args.no_roofline:
+        # dominant kernel: the fused rmsnorm + w1|w3 int4 GEMV + SiLU*mul (81 % of the layer bytes
+        # are the three FFN matrices).  Launched for all layers back to back (different weights
+        # each launch, 1.9 GB >> the 256 MiB Infinity Cache) between two HIP events recorded on
+        # the queue's stream.
+        reps = 5
+        ms, by, ln = dec.time_gemv("w13", reps)
+        per = ms / (reps * ln)
+        achieved = by / ln / (per * 1e-3) / 1e9
+        ms_all, by_all, ln_all = dec.time_gemv("all", reps)
+        out["roofline"] = {
+            "bound": "hbm", "kernel": "mc_gemv (w1|w3 fused, per launch)", "achieved": achieved,
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "bytes_per_launch": by / ln, "avg_launch_us": per * 1e3,
+            "all_gemv": {"achieved": by_all * reps / (ms_all * 1e-3) / 1e9,
+                         "frac": by_all * reps / (ms_all * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "bytes_per_token": by_all, "ms_per_token": ms_all / reps,
+                         "launches_per_token": ln_all},
+        }
+    if rank == 0 and not args.no_cpu_baseline and world == 1:
+        out["cpu_baseline"] = cpu_baseline(args, m, tbytes)
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

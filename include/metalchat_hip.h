@@ -1,0 +1,259 @@
+/*
+ * metalchat_hip.h -- C ABI of the MI355X (gfx950) backend for metalchat's decode hot path.
+ *
+ * This is the drop-in boundary: plain C, opaque handles, pointers and sizes only.  It exports
+ * exactly what the reference's Metal seam binds for this path, one entry point per Metal call
+ * site, plus the fused decode pipeline that sits behind the same handles.  Reference citations
+ * are paths relative to the metalchat source tree (v1.2.1).
+ *
+ * Part 1 mirrors  metal::{device,library,kernel,buffer}   include/metalchat/metal.h:14-34
+ *                 src/metal.cc:21-84, src/metal_impl.h:19-120
+ *                 hardware_function_encoder / kernel_thread  include/metalchat/kernel_thread.h:57-294
+ *                 src/kernel_thread.cc:13-223
+ * Part 2 is the decode pipeline driven by nn::llama3 / nn::gemma3 / transformer<Layer>::transform
+ *                 include/metalchat/nn/llama.h:113-134, nn/gemma.h:110-137, transformer.h:357-364
+ *
+ * Error convention: every function that can fail returns an mc_status (0 = ok).  The message of
+ * the last failure on the calling thread is mc_last_error().  The C++ shim rethrows
+ * MC_ERR_INVALID_ARGUMENT as std::invalid_argument, MC_ERR_RUNTIME as std::runtime_error and
+ * MC_ERR_ALLOC as alloc_error with the same message text the reference uses
+ * (include/metalchat/tensor/expected.h:185-193, include/metalchat/allocator.h:20-34).
+ *
+ * There is NO CPU fallback anywhere behind this ABI: without a HIP device every entry point that
+ * needs one fails with MC_ERR_RUNTIME.
+ */
+#ifndef METALCHAT_HIP_H
+#define METALCHAT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int32_t mc_status;
+enum {
+    MC_OK = 0,
+    MC_ERR_INVALID_ARGUMENT = 1, /* std::invalid_argument */
+    MC_ERR_RUNTIME = 2,          /* std::runtime_error    */
+    MC_ERR_ALLOC = 3             /* alloc_error           */
+};
+
+const char* mc_last_error(void);
+/* "metalchat-hip <version> gfx950" */
+const char* mc_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Part 1 -- backend seam
+ * ------------------------------------------------------------------------------------------ */
+typedef struct mc_device mc_device;
+typedef struct mc_library mc_library;
+typedef struct mc_kernel mc_kernel;
+typedef struct mc_buffer mc_buffer;
+typedef struct mc_queue mc_queue;
+
+/* MTL::CreateSystemDefaultDevice -- src/metal.cc:51-55.  ordinal < 0 selects the current HIP
+ * device (LOCAL_RANK-aware callers pass their own ordinal). */
+mc_status mc_device_create(int32_t ordinal, mc_device** out);
+void mc_device_release(mc_device* dev);
+/* device->name() -- src/accelerator.cc:108-113 */
+const char* mc_device_name(const mc_device* dev);
+/* device->maxBufferLength() -- src/accelerator.cc:73-77 */
+size_t mc_device_max_buffer_size(const mc_device* dev);
+int32_t mc_device_ordinal(const mc_device* dev);
+int32_t mc_device_compute_units(const mc_device* dev);
+
+/* device->newLibrary(url) -- src/metal.cc:58-84.  `path` is a gfx950 code object (.hsaco).
+ * Failure message is "metal: library not found"-style: "hip: library not found" when the file
+ * is absent (test/test_accelerator.cc:15-21 expects the runtime_error). */
+mc_status mc_library_open(mc_device* dev, const char* path, mc_library** out);
+void mc_library_release(mc_library* lib);
+
+/* library->newFunction(name) + newComputePipelineState -- src/accelerator.cc:116-158.
+ * Name format {kernel}[_{block}]_{type}[_{type}...] with types bfloat,float,int32_t,int8_t
+ * (include/metalchat/accelerator.h:175-218, include/metalchat/dtype.h:83-118).
+ * Missing function -> MC_ERR_INVALID_ARGUMENT "hardware_accelerator: function <name> not found
+ * in a shader library". */
+mc_status mc_library_get_kernel(mc_library* lib, const char* name, mc_kernel** out);
+void mc_kernel_release(mc_kernel* k);
+const char* mc_kernel_name(const mc_kernel* k);
+/* pipeline->maxTotalThreadsPerThreadgroup() -- src/kernel.cc:75-79 */
+size_t mc_kernel_max_threads_per_group(const mc_kernel* k);
+
+/* device->newBuffer(bytes, Shared) / newBuffer(ptr, bytes, Shared) / newBuffer(ptr, bytes,
+ * Shared, nil) (no-copy) -- src/allocator.cc:127-173.  HBM-resident (hipMalloc); the no-copy
+ * form wraps an existing DEVICE pointer (for example torch-owned memory) without owning it. */
+mc_status mc_buffer_alloc(mc_device* dev, size_t bytes, mc_buffer** out);
+mc_status mc_buffer_alloc_copy(mc_device* dev, const void* host_src, size_t bytes, mc_buffer** out);
+mc_status mc_buffer_wrap_nocopy(mc_device* dev, void* device_ptr, size_t bytes, mc_buffer** out);
+void mc_buffer_release(mc_buffer* buf);
+/* buffer->contents() / buffer->length() -- src/metal.cc:21-32.  contents() is a DEVICE address:
+ * weights live in HBM, so the reference's "CPU dereferences the shared buffer" idiom becomes the
+ * explicit copies below ("Unified memory assumption"). */
+void* mc_buffer_contents(const mc_buffer* buf);
+size_t mc_buffer_length(const mc_buffer* buf);
+mc_status mc_buffer_upload(mc_buffer* buf, size_t offset, const void* host_src, size_t bytes);
+mc_status mc_buffer_download(const mc_buffer* buf, size_t offset, void* host_dst, size_t bytes);
+mc_status mc_buffer_fill_zero(mc_buffer* buf, size_t offset, size_t bytes);
+
+/* device->newCommandQueue() + commandBuffer + computeCommandEncoder -- src/kernel_thread.cc:23-32.
+ * One in-order HIP stream subsumes the MTL::Event chain of src/kernel_thread.cc:34-47,194 and
+ * the per-argument memoryBarrier of include/metalchat/kernel_thread.h:121-124.
+ * external_stream != NULL adopts a caller-owned hipStream_t (for example torch's current stream). */
+mc_status mc_queue_create(mc_device* dev, void* external_stream, mc_queue** out);
+void mc_queue_release(mc_queue* q);
+void* mc_queue_stream(const mc_queue* q);
+
+/* encoder->setComputePipelineState -- src/kernel_thread.cc:69-74.  Resets the argument index. */
+mc_status mc_encoder_set_kernel(mc_queue* q, mc_kernel* k);
+/* encoder->setBytes(data, size, index++) -- src/kernel_thread.cc:77-81.  The argument is placed at
+ * the next offset aligned to min(size, 4) rounded down to a power of two (tensor_layout<N> and
+ * 32-bit scalars: 4; a bfloat scalar: 2). */
+mc_status mc_encoder_set_bytes(mc_queue* q, const void* data, size_t size);
+/* encoder->setBuffer(buffer, offset, index++) -- src/kernel_thread.cc:84-88.  offset in BYTES. */
+mc_status mc_encoder_set_buffer(mc_queue* q, mc_buffer* buf, size_t byte_offset);
+/* encoder->memoryBarrier(resource) -- src/kernel_thread.cc:91-96.  A no-op on an in-order stream;
+ * kept so the reference's encode() sequence maps 1:1. */
+mc_status mc_encoder_memory_barrier(mc_queue* q, mc_buffer* buf);
+/* encoder->dispatchThreads(grid, group) -- src/kernel_thread.cc:105-120.  grid = TOTAL threads,
+ * group = threads per group; blocks = ceil(grid/group) per axis and kernels bounds-check, which is
+ * how Metal's non-uniform threadgroups behave.  Validation as include/metalchat/kernel.h:119-141:
+ * group.numel() <= max_threads and grid.numel() >= group.numel() else MC_ERR_INVALID_ARGUMENT. */
+mc_status mc_encoder_dispatch_threads(mc_queue* q, const size_t grid[3], const size_t group[3]);
+/* Same, with an explicit dynamic LDS size (fused kernels only). */
+mc_status mc_encoder_dispatch_threads_lds(mc_queue* q, const size_t grid[3], const size_t group[3],
+                                          size_t lds_bytes);
+/* commandBuffer->addCompletedHandler -- src/kernel_thread.cc:134-144.  The callback runs on a
+ * driver thread once everything submitted before it has completed; status != MC_OK carries a GPU
+ * execution error (the reference delivers it through the promise). */
+typedef void (*mc_completion_fn)(void* ctx, mc_status status);
+mc_status mc_queue_on_completed(mc_queue* q, mc_completion_fn fn, void* ctx);
+/* commandBuffer->commit() -- src/kernel_thread.cc:184-199.  Launches are asynchronous already;
+ * commit only flushes.  mc_queue_wait is future_tensor::wait (include/metalchat/tensor/future.h:235-253). */
+mc_status mc_queue_commit(mc_queue* q);
+mc_status mc_queue_wait(mc_queue* q);
+
+/* Timing of a region of the queue with HIP events recorded ON THE QUEUE'S STREAM (bench.py).
+ * begin/end record the events, elapsed synchronises on the end event. */
+mc_status mc_queue_timer_begin(mc_queue* q);
+mc_status mc_queue_timer_end(mc_queue* q);
+mc_status mc_queue_timer_elapsed_ms(mc_queue* q, float* ms);
+
+/* ------------------------------------------------------------------------------------------
+ * Part 2 -- fused decode pipeline (what nn::llama3::operator() does per token, behind the seam)
+ * ------------------------------------------------------------------------------------------ */
+enum { MC_DTYPE_BF16 = 0, MC_DTYPE_F32 = 1 };
+enum { MC_FAMILY_LLAMA3 = 0, MC_FAMILY_GEMMA3 = 1 };
+/* weight formats of a linear layer held in HBM */
+enum {
+    MC_WFMT_T = 0,   /* nn::linear: row-major [out,in] of T                                    */
+    MC_WFMT_I8 = 1,  /* int8 [out,in] + per-(row,group) scale  (quantization::lora_linear)      */
+    MC_WFMT_I4 = 2   /* packed int4 (two values per byte, offset-binary) + per-(row,group) scale */
+};
+/* quantised-GEMV arithmetic */
+enum {
+    MC_QMODE_EXACT = 0, /* Wd = T(T(q)*T(s)) materialised per weight exactly as
+                           hadamard_broadcast does (kernel/mul.metal:78-82), then fp32 dot        */
+    MC_QMODE_FAST = 1   /* y = sum_g s_g * sum_k q_k x_k : skips the per-weight rounding to T     */
+};
+
+typedef struct {
+    int32_t dtype;   /* activation / KV / norm-weight type T */
+    int32_t family;
+    int32_t dim, n_heads, n_kv_heads, head_dim, ffn_dim, n_layers, vocab, max_seq_len;
+    float rope_theta;
+    float rope_sliding_theta; /* gemma3: theta of the sliding layers, 0 otherwise */
+    int32_t sliding_stride;   /* gemma3: layer i is sliding iff (i+1) % stride != 0 */
+    float norm_eps;
+    float attn_scale;
+    int32_t sink_pre_len;     /* < 0: bit_width(max_seq_len) - 1 (include/metalchat/nn/cache.h:125-127) */
+    /* pipeline partition: this decoder owns layers [layer_begin, layer_end); the first stage
+     * owns the embedding, the last stage owns final norm + output head. */
+    int32_t layer_begin, layer_end;
+    int32_t weight_format;    /* MC_WFMT_* of the seven per-layer linears and the output head */
+    int32_t group_size;       /* quantisation group along `in` (per-row scale: group_size = 0)   */
+    int32_t qmode;            /* MC_QMODE_* */
+    int32_t use_graph;        /* capture one token step into a hipGraph and replay it */
+} mc_decoder_config;
+
+typedef struct mc_decoder mc_decoder;
+
+mc_status mc_decoder_create(mc_device* dev, mc_library* lib, mc_queue* q,
+                            const mc_decoder_config* cfg, mc_decoder** out);
+void mc_decoder_release(mc_decoder* d);
+
+/* Names of the per-layer tensors: "wq","wk","wv","wo","w1","w2","w3" (linears),
+ * "attention_norm","ffn_norm","q_norm","k_norm","attention_post_norm","ffn_post_norm" (T[n]).
+ * layer = -1 addresses the model-level tensors "tok_embeddings", "output" (linears) and "norm".
+ *
+ * mc_decoder_load_linear takes the REFERENCE-NATIVE host format and repacks it for HBM:
+ *   MC_WFMT_T : weight = T[out*in]
+ *   MC_WFMT_I8/I4 : weight = int8_t[out*in] (int4 range [-8,7] held one value per byte, as the
+ *                   reference loads it: include/metalchat/huggingface/llama.h:159-168),
+ *                   scales = float[out * in/group] (group 0: float[out])
+ * For "tok_embeddings" a quantised table is always kept as int8 + per-row scale
+ * (quantization::lora_embedding, include/metalchat/quantization/lora.h:133-175). */
+mc_status mc_decoder_load_linear(mc_decoder* d, int32_t layer, const char* name,
+                                 int32_t weight_format, int32_t out_features, int32_t in_features,
+                                 int32_t group_size, const void* weight, const float* scales);
+mc_status mc_decoder_load_vector(mc_decoder* d, int32_t layer, const char* name, int32_t n,
+                                 const void* data_T);
+/* Synthetic weights generated ON THE DEVICE from a counter-based hash (bench.py at full model
+ * sizes; tests regenerate any row on the host with mc_synth_* below and check it). */
+mc_status mc_decoder_init_synthetic(mc_decoder* d, uint64_t seed);
+
+/* transformer<Layer>::transform(token, start_pos) with len == 1 -- include/metalchat/transformer.h:357-364.
+ * Runs the layers this decoder owns.  First stage: `token` is embedded.  Other stages: the hidden
+ * row is read from hidden_in (device pointer, T[dim]).  Last stage: writes the greedy next token
+ * to *next_token (after a stream sync) when next_token != NULL.  Non-last stages leave the hidden
+ * row in the buffer returned by mc_decoder_hidden_out(). */
+mc_status mc_decoder_step(mc_decoder* d, int32_t token, int32_t start_pos, const void* hidden_in,
+                          int32_t* next_token);
+/* Enqueue `n` chained greedy steps entirely on the device (token feedback through HBM, one host
+ * sync at the end); tokens_out receives the n generated ids.  Single-stage decoders only. */
+mc_status mc_decoder_generate(mc_decoder* d, int32_t first_token, int32_t start_pos, int32_t n,
+                              int32_t* tokens_out);
+void* mc_decoder_hidden_out(mc_decoder* d);
+void* mc_decoder_hidden_in(mc_decoder* d);
+/* Debug / parity taps (synchronise the queue).  mc_decoder_set_taps(1) makes every step also
+ * copy the hidden row after the embedding and after each owned layer into a tap buffer. */
+mc_status mc_decoder_set_taps(mc_decoder* d, int32_t enable);
+mc_status mc_decoder_get_logits(mc_decoder* d, void* logits_T_vocab);
+mc_status mc_decoder_get_hidden(mc_decoder* d, int32_t layer, void* hidden_T_dim);
+/* Logical sink-cache view of `layer` after the last step, in the reference's layout
+ * [end_pos, n_kv_heads, head_dim] (include/metalchat/nn/cache.h:209-215); *n_valid = end_pos. */
+mc_status mc_decoder_export_kv(mc_decoder* d, int32_t layer, void* keys, void* values,
+                               int32_t* n_valid);
+/* Bytes of weights + scales this decoder streams per token (the roofline numerator). */
+size_t mc_decoder_weight_bytes(const mc_decoder* d);
+/* Per-kernel timing pass used by bench.py's roofline leg: runs the named fused GEMV of every
+ * owned layer back to back between two events on the queue's stream and returns the total
+ * milliseconds and the algorithmic bytes moved.  which: "qkv","wo","w13","w2","head","all". */
+mc_status mc_decoder_time_gemv(mc_decoder* d, const char* which, int32_t repeats, float* total_ms,
+                               double* bytes_per_pass, int32_t* launches_per_pass);
+
+/* Device addresses of a fused weight matrix as it lies in HBM: per layer "qkv" (wq|wk|wv rows),
+ * "wo", "w13" (w1/w3 rows interleaved), "w2"; layer -1: "output".  For kernel-level tests that
+ * drive mc_gemv_* through the encoder (wrap with mc_buffer_wrap_nocopy). */
+mc_status mc_decoder_weight_ptrs(mc_decoder* d, int32_t layer, const char* name, void** w,
+                                 void** scales, int32_t* rows, int32_t* in_features,
+                                 int32_t* ngroups);
+
+/* Host-side helpers shared by tests and the synthetic initialiser. */
+/* value in [-8,7] (bits = 4) or [-128,127] (bits = 8) of element (row, col) of matrix `matrix_id` */
+int32_t mc_synth_weight(uint64_t seed, uint32_t matrix_id, uint32_t row, uint32_t col, int32_t bits);
+/* scale of (row, group) : U(0.5,1.5) / (sqrt(in) * 2^(bits-1)) as float */
+float mc_synth_scale(uint64_t seed, uint32_t matrix_id, uint32_t row, uint32_t group,
+                     int32_t in_features, int32_t bits);
+/* T-typed synthetic values before rounding to T.  kind 0: U(0.5,1.5) (norm weights);
+ * kind 1: ~N(0,1)*0.02 (embedding rows); kind 2: U(-1,1)/sqrt(n) (plain T linear weights, n = in) */
+float mc_synth_value(uint64_t seed, uint32_t matrix_id, uint32_t index, int32_t kind, uint32_t n);
+/* Matrix ids of mc_decoder_init_synthetic: layer*16 + {0 wq, 1 wk, 2 wv, 3 wo, 4 w1, 5 w2, 6 w3,
+ * 8 attention_norm, 9 ffn_norm, 10 q_norm, 11 k_norm, 12 attention_post_norm, 13 ffn_post_norm};
+ * 0xFFFF0000 + {0 tok_embeddings, 1 output, 2 norm}. */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,16 @@
+"""metalchat_amd -- MI355X (gfx950) backend for metalchat's per-token decode hot path.
+
+The product is native: `lib/metalchat.hsaco` (hand-written HIP kernels) behind the C ABI in
+`include/metalchat_hip.h` (`lib/libmetalchat_hip.so`).  This Python package is only the ctypes
+harness that tests and bench.py use to drive that ABI; it mirrors the reference's class names
+(`hardware_accelerator`, `kernel_task`, `kernel_thread`, include/metalchat/{accelerator,kernel,
+kernel_thread}.h) so the parity tests read like the reference's own tests.
+
+There is no CPU fallback: if the shared library or a HIP device is missing every entry point
+raises.  Nothing in here imports the oracle.
+"""
+from .runtime import (  # noqa: F401
+    BF16, F32, WFMT_T, WFMT_I8, WFMT_I4, QMODE_EXACT, QMODE_FAST, FAMILY_LLAMA3, FAMILY_GEMMA3,
+    McError, HardwareAccelerator, Buffer, Kernel, KernelTask, Decoder, DecoderConfig, capi,
+    library_path, hsaco_path, layout, make_kernel_grid_2d,
+)

@@ -1,0 +1,1070 @@
+// Part 2 of include/metalchat_hip.h: the fused per-token decode pipeline.
+//
+// This is the host-side driver the reference spreads over header-only templates:
+//   nn::llama3::operator()        include/metalchat/nn/llama.h:113-134
+//   nn::gemma3::operator()        include/metalchat/nn/gemma.h:110-137
+//   nn::transformer::operator()   include/metalchat/nn/transformer.h:126-141
+//   nn::attention::operator()     include/metalchat/nn/attention.h:161-206
+//   nn::sink_cache / nn::rope     include/metalchat/nn/cache.h:96-232, nn/embedding.h:107-200
+//   transformer<Layer>::transform include/metalchat/transformer.h:357-364
+// Instead of ~1000 one-op launches and as many allocations per token it issues 8 launches per
+// layer on one in-order stream over a pre-allocated arena, keeps the token / position state in
+// HBM so successive steps chain without a host round trip, and (optionally) replays one captured
+// hipGraph per token.
+#include "backend_impl.h"
+#include "kernels/synth.h"
+
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+
+using namespace mcimpl;
+
+namespace {
+
+constexpr int PB = 256; // cache slots per attention workgroup (decode_kernels.hip)
+
+struct step_state_h {
+    int32_t token, pos, kv_len, write_slot, ring_base, step_index, rope_row, rolled;
+};
+
+struct linear_w {
+    int fmt = MC_WFMT_T;
+    int out = 0, in = 0, group = 0; // group 0 = one scale per row
+    void* w = nullptr;
+    void* scales = nullptr;
+    size_t w_bytes = 0, s_bytes = 0;
+    size_t row_bytes = 0;
+    int ngroups = 1;
+    bool allocated = false;
+};
+
+struct layer_w {
+    linear_w qkv, wo, w13, w2;
+    void* attention_norm = nullptr;
+    void* ffn_norm = nullptr;
+    void* q_norm = nullptr;
+    void* k_norm = nullptr;
+    void* attention_post_norm = nullptr;
+    void* ffn_post_norm = nullptr;
+    void* kc = nullptr;
+    void* vt = nullptr;
+    int rope_table = 0;
+};
+
+uint16_t
+f2bf_host(float f)
+{
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7f800000u) == 0x7f800000u && (u & 0x007fffffu)) return (uint16_t)((u >> 16) | 0x40u);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+float
+bf2f_host(uint16_t b)
+{
+    uint32_t u = (uint32_t)b << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+int
+bit_width(uint32_t v)
+{
+    int n = 0;
+    while (v) {
+        n++;
+        v >>= 1;
+    }
+    return n;
+}
+
+// kernel-argument packer: natural alignment of each argument, like the compiler's kernarg layout
+struct arg_pack {
+    std::vector<char> buf;
+    template <typename T> void
+    push(const T& v)
+    {
+        size_t off = (buf.size() + alignof(T) - 1) / alignof(T) * alignof(T);
+        buf.resize(off + sizeof(T));
+        memcpy(buf.data() + off, &v, sizeof(T));
+    }
+};
+template <typename... A> arg_pack
+pack(const A&... a)
+{
+    arg_pack p;
+    (p.push(a), ...);
+    return p;
+}
+
+} // namespace
+
+struct mc_decoder {
+    mc_decoder_config cfg;
+    mc_device* dev = nullptr;
+    mc_library* lib = nullptr;
+    mc_queue* q = nullptr;
+    hipStream_t stream = nullptr;
+    int tb = 2; // sizeof(T)
+    int pre_len = 0;
+    int nsplit = 1;
+    int n_own = 0;
+    bool first_stage = true, last_stage = true;
+    std::string tname; // "bfloat" / "float"
+
+    std::map<std::string, hipFunction_t> fns;
+    std::vector<layer_w> layers;
+    // embedding
+    int emb_fmt = MC_WFMT_T;
+    void* emb_table = nullptr;
+    float* emb_scales = nullptr;
+    linear_w output;
+    void* final_norm = nullptr;
+
+    // arena
+    void* hidden = nullptr;     // T[dim]   running hidden row (h)
+    void* hidden_in = nullptr;  // T[dim]   inbound row for non-first stages
+    void* qkv = nullptr;        // T[(H+2KV)*hd]
+    void* q_rot = nullptr;      // T[H*hd]
+    void* attn_out = nullptr;   // T[H*hd]
+    void* proj = nullptr;       // T[dim]   (gemma: pre-post-norm outputs)
+    void* gate = nullptr;       // T[ffn]
+    void* logits = nullptr;     // T[vocab]
+    float* expv = nullptr;      // [H][max_seq]
+    float* psum = nullptr;      // [H][nsplit]
+    float* opart = nullptr;     // [nsplit][H][hd]
+    void* taps = nullptr;       // T[(n_own+1)*dim]
+    step_state_h* state = nullptr;
+    int32_t* tokens_dev = nullptr;
+    int tokens_cap = 0;
+    float* rope_cos[2] = {nullptr, nullptr};
+    float* rope_sin[2] = {nullptr, nullptr};
+    int rope_rows = 0;
+    int rope_start = 0;
+    bool rope_valid = false;
+    int last_pos = -1;
+    bool want_taps = false;
+
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+
+    std::vector<void*> allocs;
+    int gemv_block = 256;
+    int gemv_wgs_per_cu = 2;
+
+    ~mc_decoder()
+    {
+        (void)hipSetDevice(dev->ordinal);
+        if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
+        if (graph) (void)hipGraphDestroy(graph);
+        for (void* p : allocs) (void)hipFree(p);
+    }
+
+    mc_status
+    alloc(void** p, size_t bytes, bool zero = true)
+    {
+        hipError_t e = hipMalloc(p, bytes ? bytes : 16);
+        if (e != hipSuccess)
+            return fail(MC_ERR_ALLOC, std::string("hardware_memory_allocator: failed to allocate ") +
+                                          std::to_string(bytes) + " bytes: " + hipGetErrorString(e));
+        allocs.push_back(*p);
+        if (zero) MC_HIP(hipMemsetAsync(*p, 0, bytes ? bytes : 16, stream));
+        return MC_OK;
+    }
+
+    mc_status
+    fn(const std::string& name, hipFunction_t* out)
+    {
+        auto it = fns.find(name);
+        if (it != fns.end()) {
+            *out = it->second;
+            return MC_OK;
+        }
+        hipFunction_t f = nullptr;
+        hipError_t e = hipModuleGetFunction(&f, lib->module, name.c_str());
+        if (e != hipSuccess || !f)
+            return fail(MC_ERR_INVALID_ARGUMENT, "hardware_accelerator: function " + name +
+                                                     " not found in a shader library");
+        fns[name] = f;
+        *out = f;
+        return MC_OK;
+    }
+
+    mc_status
+    launch(const std::string& name, unsigned gx, unsigned gy, unsigned gz, unsigned bx, unsigned lds,
+           arg_pack&& a)
+    {
+        hipFunction_t f;
+        mc_status s = fn(name, &f);
+        if (s != MC_OK) return s;
+        size_t n = a.buf.size();
+        void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, a.buf.data(), HIP_LAUNCH_PARAM_BUFFER_SIZE,
+                         &n, HIP_LAUNCH_PARAM_END};
+        hipError_t e = hipModuleLaunchKernel(f, gx, gy, gz, bx, 1, 1, lds, stream, nullptr, extra);
+        if (e != hipSuccess) return hip_fail(e, name.c_str());
+        return MC_OK;
+    }
+
+    // ---------------------------------------------------------------- weights
+    size_t
+    row_bytes(int fmt, int in) const
+    {
+        if (fmt == MC_WFMT_I4) return (size_t)in / 2;
+        if (fmt == MC_WFMT_I8) return (size_t)in;
+        return (size_t)in * tb;
+    }
+
+    mc_status
+    alloc_linear(linear_w& L, int fmt, int out, int in, int group)
+    {
+        if (L.allocated) {
+            if (L.fmt != fmt || L.in != in || L.group != group)
+                return fail(MC_ERR_INVALID_ARGUMENT,
+                            "decoder: matrices fused into one GEMV must share format, in_features "
+                            "and group size");
+            return MC_OK;
+        }
+        if (in % 32 != 0)
+            return fail(MC_ERR_INVALID_ARGUMENT, "decoder: in_features must be a multiple of 32");
+        if (fmt != MC_WFMT_T && group != 0 && (group % 32 != 0 || in % group != 0))
+            return fail(MC_ERR_INVALID_ARGUMENT,
+                        "decoder: group size must be a multiple of 32 that divides in_features");
+        L.fmt = fmt;
+        L.out = out;
+        L.in = in;
+        L.group = group;
+        L.ngroups = (fmt == MC_WFMT_T) ? 0 : (group ? in / group : 1);
+        L.row_bytes = row_bytes(fmt, in);
+        L.w_bytes = L.row_bytes * out;
+        L.s_bytes = (size_t)L.ngroups * out * (tb == 2 ? 2 : 4);
+        mc_status s = alloc(&L.w, L.w_bytes, false);
+        if (s != MC_OK) return s;
+        if (L.s_bytes) {
+            s = alloc(&L.scales, L.s_bytes, false);
+            if (s != MC_OK) return s;
+        }
+        L.allocated = true;
+        return MC_OK;
+    }
+
+    // repack `rows` reference-native rows into the fused buffer at destination rows
+    // dst_row0 + i*dst_stride
+    mc_status
+    upload_rows(linear_w& L, int dst_row0, int dst_stride, int rows, const void* weight,
+                const float* scales)
+    {
+        const int in = L.in;
+        std::vector<uint8_t> rowbuf(L.row_bytes);
+        std::vector<uint8_t> sbuf((size_t)L.ngroups * (tb == 2 ? 2 : 4));
+        // stage whole matrix when contiguous to cut the number of copies
+        const bool contiguous = dst_stride == 1;
+        std::vector<uint8_t> stage, sstage;
+        if (contiguous) {
+            stage.resize(L.row_bytes * rows);
+            sstage.resize(sbuf.size() * rows);
+        }
+        for (int r = 0; r < rows; r++) {
+            uint8_t* dst = contiguous ? stage.data() + (size_t)r * L.row_bytes : rowbuf.data();
+            if (L.fmt == MC_WFMT_T) {
+                memcpy(dst, (const char*)weight + (size_t)r * in * tb, (size_t)in * tb);
+            } else if (L.fmt == MC_WFMT_I8) {
+                memcpy(dst, (const int8_t*)weight + (size_t)r * in, in);
+            } else {
+                // I4: offset-binary nibbles, nibble p of each dword = weight {0,2,4,6,1,3,5,7}[p]
+                static const int perm[8] = {0, 2, 4, 6, 1, 3, 5, 7};
+                const int8_t* src = (const int8_t*)weight + (size_t)r * in;
+                uint32_t* d32 = reinterpret_cast<uint32_t*>(dst);
+                for (int c0 = 0; c0 < in; c0 += 8) {
+                    uint32_t v = 0;
+                    for (int p = 0; p < 8; p++) {
+                        const int q = src[c0 + perm[p]];
+                        if (q < -8 || q > 7)
+                            return fail(MC_ERR_INVALID_ARGUMENT,
+                                        "decoder: int4 weight outside [-8, 7]");
+                        v |= (uint32_t)(q + 8) << (4 * p);
+                    }
+                    d32[c0 / 8] = v;
+                }
+            }
+            if (L.ngroups) {
+                uint8_t* sd = contiguous ? sstage.data() + (size_t)r * sbuf.size() : sbuf.data();
+                for (int g = 0; g < L.ngroups; g++) {
+                    const float s = scales[(size_t)r * L.ngroups + g];
+                    if (tb == 2) reinterpret_cast<uint16_t*>(sd)[g] = f2bf_host(s);
+                    else reinterpret_cast<float*>(sd)[g] = s;
+                }
+            }
+            if (!contiguous) {
+                const size_t drow = (size_t)dst_row0 + (size_t)r * dst_stride;
+                MC_HIP(hipMemcpy((char*)L.w + drow * L.row_bytes, rowbuf.data(), L.row_bytes,
+                                 hipMemcpyHostToDevice));
+                if (L.ngroups)
+                    MC_HIP(hipMemcpy((char*)L.scales + drow * sbuf.size(), sbuf.data(), sbuf.size(),
+                                     hipMemcpyHostToDevice));
+            }
+        }
+        if (contiguous) {
+            MC_HIP(hipMemcpy((char*)L.w + (size_t)dst_row0 * L.row_bytes, stage.data(), stage.size(),
+                             hipMemcpyHostToDevice));
+            if (L.ngroups)
+                MC_HIP(hipMemcpy((char*)L.scales + (size_t)dst_row0 * sbuf.size(), sstage.data(),
+                                 sstage.size(), hipMemcpyHostToDevice));
+        }
+        return MC_OK;
+    }
+
+    // ---------------------------------------------------------------- launches
+    mc_status
+    gemv(const linear_w& L, int pro, int epi, const void* x, void* y, const void* res,
+         const void* norm_w, float mu)
+    {
+        std::string name = "mc_gemv_";
+        name += L.fmt == MC_WFMT_I4 ? "i4_" : (L.fmt == MC_WFMT_I8 ? "i8_" : "w_");
+        name += tname;
+        if (L.fmt == MC_WFMT_I4 && tb == 2 && cfg.qmode == MC_QMODE_FAST) name += "_fast";
+        name += "_p" + std::to_string(pro) + "_e" + std::to_string(epi);
+        const unsigned waves = gemv_block / 64;
+        const unsigned ng = (L.out + 3) / 4;
+        unsigned wgs = (ng + waves - 1) / waves;
+        const unsigned cap = (unsigned)(dev->prop.multiProcessorCount * gemv_wgs_per_cu);
+        if (wgs > cap) wgs = cap;
+        if (wgs == 0) wgs = 1;
+        const unsigned lds = (unsigned)((((size_t)L.in * tb + 15) & ~(size_t)15) + 64);
+        return launch(name, wgs, 1, 1, gemv_block, lds,
+                      pack(L.w, L.scales, x, y, res, norm_w, (uint32_t)L.out, (uint32_t)L.in,
+                           (uint32_t)L.group, cfg.norm_eps, mu));
+    }
+
+    mc_status
+    ensure_rope(int pos)
+    {
+        // nn::rope::operator() (include/metalchat/nn/embedding.h:190-198)
+        if (rope_valid && pos >= rope_start && pos < rope_start + rope_rows) return MC_OK;
+        rope_start = rope_valid ? pos : 0;
+        if (!rope_valid && pos >= rope_rows) rope_start = pos;
+        const unsigned half = cfg.head_dim / 2;
+        for (int t = 0; t < 2; t++) {
+            const float theta = t == 0 ? cfg.rope_theta : cfg.rope_sliding_theta;
+            if (!rope_cos[t]) continue;
+            mc_status s = launch("mc_rope_table", (half + 63) / 64, rope_rows, 1, 64, 0,
+                                 pack(rope_cos[t], rope_sin[t], (uint32_t)rope_rows,
+                                      (uint32_t)cfg.head_dim, (uint32_t)rope_start, theta));
+            if (s != MC_OK) return s;
+        }
+        rope_valid = true;
+        return MC_OK;
+    }
+
+    mc_status
+    run_layers(const void* x_in)
+    {
+        const int dim = cfg.dim, H = cfg.n_heads, KV = cfg.n_kv_heads, hd = cfg.head_dim;
+        const int n_rep = H / KV;
+        const float mu = cfg.family == MC_FAMILY_GEMMA3 ? 1.0f : 0.0f;
+        const bool gemma = cfg.family == MC_FAMILY_GEMMA3;
+        const float scale_T = tb == 2 ? bf2f_host(f2bf_host(cfg.attn_scale)) : cfg.attn_scale;
+        mc_status s;
+        const void* x = x_in; // current hidden row
+        for (int li = 0; li < n_own; li++) {
+            layer_w& L = layers[li];
+            // attention_norm + wq|wk|wv            (transformer.h:130, attention.h:170-172)
+            s = gemv(L.qkv, 1, 0, x, qkv, nullptr, L.attention_norm, mu);
+            if (s != MC_OK) return s;
+            // q/k norm, rope, cache write          (attention.h:174-177)
+            s = launch("mc_rope_kv_" + tname, H + 2 * KV, 1, 1, hd / 2, 0,
+                       pack(qkv, q_rot, L.kc, L.vt, rope_cos[L.rope_table], rope_sin[L.rope_table],
+                            L.q_norm, L.k_norm, state, (uint32_t)H, (uint32_t)KV, (uint32_t)hd,
+                            (uint32_t)cfg.max_seq_len, cfg.norm_eps, mu));
+            if (s != MC_OK) return s;
+            // scores, softmax denominators         (attention.h:195-200)
+            s = launch("mc_attn_scores_" + tname, nsplit, KV, 1, 256, 0,
+                       pack(q_rot, L.kc, expv, psum, (void*)nullptr, state, (uint32_t)n_rep,
+                            (uint32_t)hd, (uint32_t)cfg.max_seq_len, scale_T, (uint32_t)nsplit));
+            if (s != MC_OK) return s;
+            // P.V                                  (attention.h:202)
+            s = launch("mc_attn_pv_" + tname, nsplit, KV, 1, 256, 4 * 16 * hd * 4,
+                       pack(expv, psum, L.vt, opart, state, (uint32_t)n_rep, (uint32_t)hd,
+                            (uint32_t)cfg.max_seq_len, (uint32_t)nsplit, (uint32_t)H));
+            if (s != MC_OK) return s;
+            s = launch("mc_attn_reduce_" + tname, (H * hd + 255) / 256, 1, 1, 256, 0,
+                       pack(opart, attn_out, state, (uint32_t)(H * hd)));
+            if (s != MC_OK) return s;
+            // wo (+ post norm) + residual          (attention.h:205, transformer.h:132-133)
+            if (!gemma) {
+                s = gemv(L.wo, 0, 1, attn_out, hidden, x, nullptr, mu);
+                if (s != MC_OK) return s;
+            } else {
+                s = gemv(L.wo, 0, 0, attn_out, proj, nullptr, nullptr, mu);
+                if (s != MC_OK) return s;
+                s = launch("mc_rmsnorm_row_" + tname, 1, 1, 1, 1024, 0,
+                           pack(proj, L.attention_post_norm, x, hidden, (uint32_t)dim, cfg.norm_eps, mu));
+                if (s != MC_OK) return s;
+            }
+            // ffn_norm + w1|w3 + act*mul           (transformer.h:135-137, 53-59)
+            s = gemv(L.w13, 1, gemma ? 3 : 2, hidden, gate, nullptr, L.ffn_norm, mu);
+            if (s != MC_OK) return s;
+            // w2 (+ post norm) + residual          (transformer.h:59, 138-139)
+            if (!gemma) {
+                s = gemv(L.w2, 0, 1, gate, hidden, hidden, nullptr, mu);
+                if (s != MC_OK) return s;
+            } else {
+                s = gemv(L.w2, 0, 0, gate, proj, nullptr, nullptr, mu);
+                if (s != MC_OK) return s;
+                s = launch("mc_rmsnorm_row_" + tname, 1, 1, 1, 1024, 0,
+                           pack(proj, L.ffn_post_norm, hidden, hidden, (uint32_t)dim, cfg.norm_eps, mu));
+                if (s != MC_OK) return s;
+            }
+            x = hidden;
+            if (want_taps)
+                MC_HIP(hipMemcpyAsync((char*)taps + (size_t)(li + 1) * dim * tb, hidden,
+                                      (size_t)dim * tb, hipMemcpyDeviceToDevice, stream));
+        }
+        return MC_OK;
+    }
+
+    mc_status
+    run_embed()
+    {
+        const bool gemma = cfg.family == MC_FAMILY_GEMMA3;
+        float sc = std::sqrt((float)cfg.dim);
+        if (tb == 2) sc = bf2f_host(f2bf_host(sc));
+        const unsigned g = (cfg.dim + 255) / 256;
+        mc_status s;
+        if (emb_fmt == MC_WFMT_T)
+            s = launch("mc_embed_" + tname, g, 1, 1, 256, 0,
+                       pack(emb_table, hidden, state, (uint32_t)cfg.dim, sc, (int32_t)(gemma ? 1 : 0)));
+        else
+            s = launch("mc_embed_q8_" + tname, g, 1, 1, 256, 0,
+                       pack(emb_table, emb_scales, hidden, state, (uint32_t)cfg.dim, sc,
+                            (int32_t)(gemma ? 1 : 0)));
+        if (s != MC_OK) return s;
+        if (want_taps)
+            MC_HIP(hipMemcpyAsync(taps, hidden, (size_t)cfg.dim * tb, hipMemcpyDeviceToDevice, stream));
+        return MC_OK;
+    }
+
+    mc_status
+    run_head()
+    {
+        const float mu = cfg.family == MC_FAMILY_GEMMA3 ? 1.0f : 0.0f;
+        // final norm + output head (llama.h:128-133) + greedy pick
+        mc_status s = gemv(output, 1, 0, hidden, logits, nullptr, final_norm, mu);
+        if (s != MC_OK) return s;
+        return launch("mc_argmax_" + tname, 1, 1, 1, 1024, 0,
+                      pack(logits, (uint32_t)cfg.vocab, state, tokens_dev));
+    }
+
+    // everything one token needs after the state has been set
+    mc_status
+    run_token(const void* hidden_src)
+    {
+        mc_status s;
+        const void* x = hidden_src;
+        if (first_stage) {
+            s = run_embed();
+            if (s != MC_OK) return s;
+            x = hidden;
+        }
+        s = run_layers(x);
+        if (s != MC_OK) return s;
+        if (last_stage) {
+            if (n_own == 0 && !first_stage)
+                MC_HIP(hipMemcpyAsync(hidden, x, (size_t)cfg.dim * tb, hipMemcpyDeviceToDevice, stream));
+            s = run_head();
+            if (s != MC_OK) return s;
+        }
+        return MC_OK;
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+extern "C" {
+
+mc_status
+mc_decoder_create(mc_device* dev, mc_library* lib, mc_queue* q, const mc_decoder_config* cfg,
+                  mc_decoder** out)
+{
+    if (!dev || !lib || !q || !cfg || !out)
+        return fail(MC_ERR_INVALID_ARGUMENT, "mc_decoder_create: null argument");
+    const mc_decoder_config& c = *cfg;
+    if (c.n_heads % c.n_kv_heads != 0 || c.n_heads / c.n_kv_heads > 16)
+        return fail(MC_ERR_INVALID_ARGUMENT,
+                    "decoder: n_heads must be a multiple of n_kv_heads with at most 16 query heads "
+                    "per kv head");
+    if (c.head_dim != 32 && c.head_dim != 64 && c.head_dim != 128 && c.head_dim != 256)
+        return fail(MC_ERR_INVALID_ARGUMENT, "decoder: head_dim must be 32, 64, 128 or 256");
+    if (c.max_seq_len % 8 != 0 || c.max_seq_len < 8)
+        return fail(MC_ERR_INVALID_ARGUMENT, "decoder: max_seq_len must be a multiple of 8");
+    if (c.layer_begin < 0 || c.layer_end > c.n_layers || c.layer_begin > c.layer_end)
+        return fail(MC_ERR_INVALID_ARGUMENT, "decoder: bad layer range");
+    MC_HIP(hipSetDevice(dev->ordinal));
+
+    auto d = std::unique_ptr<mc_decoder>(new mc_decoder());
+    d->cfg = c;
+    d->dev = dev;
+    d->lib = lib;
+    d->q = q;
+    d->stream = q->stream;
+    d->tb = c.dtype == MC_DTYPE_BF16 ? 2 : 4;
+    d->tname = c.dtype == MC_DTYPE_BF16 ? "bfloat" : "float";
+    d->pre_len = c.sink_pre_len >= 0 ? c.sink_pre_len : bit_width((uint32_t)c.max_seq_len) - 1;
+    if (d->pre_len >= c.max_seq_len)
+        return fail(MC_ERR_INVALID_ARGUMENT, "decoder: sink prefix must be shorter than the cache");
+    d->nsplit = (c.max_seq_len + PB - 1) / PB;
+    d->n_own = c.layer_end - c.layer_begin;
+    d->first_stage = c.layer_begin == 0;
+    d->last_stage = c.layer_end == c.n_layers;
+    if (const char* e = getenv("MC_GEMV_BLOCK")) d->gemv_block = atoi(e);
+    if (const char* e = getenv("MC_GEMV_WGS_PER_CU")) d->gemv_wgs_per_cu = atoi(e);
+    if (d->gemv_block % 64 || d->gemv_block < 64 || d->gemv_block > 512) d->gemv_block = 256;
+    if (d->gemv_wgs_per_cu < 1) d->gemv_wgs_per_cu = 2;
+
+    const size_t tb = d->tb;
+    const int dim = c.dim, H = c.n_heads, KV = c.n_kv_heads, hd = c.head_dim;
+    mc_status s;
+#define A(ptr, bytes)                                   \
+    s = d->alloc((void**)&(ptr), (bytes));              \
+    if (s != MC_OK) return s;
+    A(d->hidden, dim * tb);
+    A(d->hidden_in, dim * tb);
+    A(d->qkv, (size_t)(H + 2 * KV) * hd * tb);
+    A(d->q_rot, (size_t)H * hd * tb);
+    A(d->attn_out, (size_t)H * hd * tb);
+    A(d->proj, dim * tb);
+    A(d->gate, (size_t)c.ffn_dim * tb);
+    A(d->logits, (size_t)c.vocab * tb);
+    A(d->expv, (size_t)H * c.max_seq_len * 4);
+    A(d->psum, (size_t)H * d->nsplit * 4);
+    A(d->opart, (size_t)d->nsplit * H * hd * 4);
+    A(d->taps, (size_t)(d->n_own + 1) * dim * tb);
+    A(d->state, sizeof(step_state_h));
+    d->tokens_cap = 1 << 16;
+    A(d->tokens_dev, (size_t)d->tokens_cap * 4);
+    d->rope_rows = 2 * c.max_seq_len; // nn/embedding.h:171: _M_seq_len(max_seq_len * 2)
+    A(d->rope_cos[0], (size_t)d->rope_rows * (hd / 2) * 4);
+    A(d->rope_sin[0], (size_t)d->rope_rows * (hd / 2) * 4);
+    if (c.family == MC_FAMILY_GEMMA3 && c.rope_sliding_theta > 0.0f) {
+        A(d->rope_cos[1], (size_t)d->rope_rows * (hd / 2) * 4);
+        A(d->rope_sin[1], (size_t)d->rope_rows * (hd / 2) * 4);
+    }
+    d->layers.resize(d->n_own);
+    for (int i = 0; i < d->n_own; i++) {
+        layer_w& L = d->layers[i];
+        const size_t cache_bytes = (size_t)KV * c.max_seq_len * hd * tb;
+        A(L.kc, cache_bytes);
+        A(L.vt, cache_bytes);
+        const int gi = c.layer_begin + i;
+        // nn/gemma.h:69-73: sliding iff (i + 1) % sliding_stride != 0
+        L.rope_table = (c.family == MC_FAMILY_GEMMA3 && c.sliding_stride > 0 &&
+                        ((gi + 1) % c.sliding_stride) != 0 && d->rope_cos[1])
+                           ? 1
+                           : 0;
+    }
+#undef A
+    MC_HIP(hipStreamSynchronize(d->stream));
+    *out = d.release();
+    return MC_OK;
+}
+
+void
+mc_decoder_release(mc_decoder* d)
+{
+    delete d;
+}
+
+static mc_status
+find_layer(mc_decoder* d, int32_t layer, layer_w** out)
+{
+    const int li = layer - d->cfg.layer_begin;
+    if (li < 0 || li >= d->n_own)
+        return fail(MC_ERR_INVALID_ARGUMENT, "decoder: layer is not owned by this stage");
+    *out = &d->layers[li];
+    return MC_OK;
+}
+
+mc_status
+mc_decoder_load_linear(mc_decoder* d, int32_t layer, const char* name, int32_t fmt,
+                       int32_t out_f, int32_t in_f, int32_t group, const void* weight,
+                       const float* scales)
+{
+    if (!d || !name || !weight) return fail(MC_ERR_INVALID_ARGUMENT, "mc_decoder_load_linear: null argument");
+    if (fmt != MC_WFMT_T && !scales)
+        return fail(MC_ERR_INVALID_ARGUMENT, "mc_decoder_load_linear: quantised weights need scales");
+    MC_HIP(hipSetDevice(d->dev->ordinal));
+    const mc_decoder_config& c = d->cfg;
+    const std::string n = name;
+    const int H = c.n_heads, KV = c.n_kv_heads, hd = c.head_dim;
+    mc_status s;
+    if (layer < 0) {
+        if (n == "tok_embeddings") {
+            if (out_f != c.vocab || in_f != c.dim)
+                return fail(MC_ERR_INVALID_ARGUMENT, "decoder: tok_embeddings shape mismatch");
+            if (fmt == MC_WFMT_T) {
+                d->emb_fmt = MC_WFMT_T;
+                s = d->alloc(&d->emb_table, (size_t)out_f * in_f * d->tb, false);
+                if (s != MC_OK) return s;
+                MC_HIP(hipMemcpy(d->emb_table, weight, (size_t)out_f * in_f * d->tb, hipMemcpyHostToDevice));
+            } else {
+                // lora_embedding: int8 + one f32 scale per row (quantization/lora.h:133-175)
+                d->emb_fmt = MC_WFMT_I8;
+                s = d->alloc(&d->emb_table, (size_t)out_f * in_f, false);
+                if (s != MC_OK) return s;
+                s = d->alloc((void**)&d->emb_scales, (size_t)out_f * 4, false);
+                if (s != MC_OK) return s;
+                MC_HIP(hipMemcpy(d->emb_table, weight, (size_t)out_f * in_f, hipMemcpyHostToDevice));
+                MC_HIP(hipMemcpy(d->emb_scales, scales, (size_t)out_f * 4, hipMemcpyHostToDevice));
+            }
+            return MC_OK;
+        }
+        if (n == "output") {
+            if (out_f != c.vocab || in_f != c.dim)
+                return fail(MC_ERR_INVALID_ARGUMENT, "decoder: output shape mismatch");
+            s = d->alloc_linear(d->output, fmt, out_f, in_f, group);
+            if (s != MC_OK) return s;
+            return d->upload_rows(d->output, 0, 1, out_f, weight, scales);
+        }
+        return fail(MC_ERR_INVALID_ARGUMENT, "decoder: unknown model-level linear '" + n + "'");
+    }
+    layer_w* L;
+    s = find_layer(d, layer, &L);
+    if (s != MC_OK) return s;
+    struct slot { linear_w* lin; int total, row0, stride, rows, in; };
+    slot sl{};
+    if (n == "wq") sl = {&L->qkv, (H + 2 * KV) * hd, 0, 1, H * hd, c.dim};
+    else if (n == "wk") sl = {&L->qkv, (H + 2 * KV) * hd, H * hd, 1, KV * hd, c.dim};
+    else if (n == "wv") sl = {&L->qkv, (H + 2 * KV) * hd, (H + KV) * hd, 1, KV * hd, c.dim};
+    else if (n == "wo") sl = {&L->wo, c.dim, 0, 1, c.dim, H * hd};
+    else if (n == "w1") sl = {&L->w13, 2 * c.ffn_dim, 0, 2, c.ffn_dim, c.dim};
+    else if (n == "w3") sl = {&L->w13, 2 * c.ffn_dim, 1, 2, c.ffn_dim, c.dim};
+    else if (n == "w2") sl = {&L->w2, c.dim, 0, 1, c.dim, c.ffn_dim};
+    else return fail(MC_ERR_INVALID_ARGUMENT, "decoder: unknown linear '" + n + "'");
+    if (out_f != sl.rows || in_f != sl.in)
+        return fail(MC_ERR_INVALID_ARGUMENT, "decoder: '" + n + "' shape mismatch");
+    s = d->alloc_linear(*sl.lin, fmt, sl.total, sl.in, group);
+    if (s != MC_OK) return s;
+    return d->upload_rows(*sl.lin, sl.row0, sl.stride, sl.rows, weight, scales);
+}
+
+mc_status
+mc_decoder_load_vector(mc_decoder* d, int32_t layer, const char* name, int32_t n, const void* data)
+{
+    if (!d || !name || !data) return fail(MC_ERR_INVALID_ARGUMENT, "mc_decoder_load_vector: null argument");
+    MC_HIP(hipSetDevice(d->dev->ordinal));
+    void** dst = nullptr;
+    const std::string nm = name;
+    int expect = d->cfg.dim;
+    if (layer < 0) {
+        if (nm == "norm") dst = &d->final_norm;
+        else return fail(MC_ERR_INVALID_ARGUMENT, "decoder: unknown model-level vector '" + nm + "'");
+    } else {
+        layer_w* L;
+        mc_status s = find_layer(d, layer, &L);
+        if (s != MC_OK) return s;
+        if (nm == "attention_norm") dst = &L->attention_norm;
+        else if (nm == "ffn_norm") dst = &L->ffn_norm;
+        else if (nm == "attention_post_norm") dst = &L->attention_post_norm;
+        else if (nm == "ffn_post_norm") dst = &L->ffn_post_norm;
+        else if (nm == "q_norm") { dst = &L->q_norm; expect = d->cfg.head_dim; }
+        else if (nm == "k_norm") { dst = &L->k_norm; expect = d->cfg.head_dim; }
+        else return fail(MC_ERR_INVALID_ARGUMENT, "decoder: unknown vector '" + nm + "'");
+    }
+    if (n != expect) return fail(MC_ERR_INVALID_ARGUMENT, "decoder: '" + nm + "' length mismatch");
+    if (!*dst) {
+        mc_status s = d->alloc(dst, (size_t)n * d->tb, false);
+        if (s != MC_OK) return s;
+    }
+    MC_HIP(hipMemcpy(*dst, data, (size_t)n * d->tb, hipMemcpyHostToDevice));
+    return MC_OK;
+}
+
+// matrix ids of the synthetic model: layer*16 + {0 wq,1 wk,2 wv,3 wo,4 w1,5 w2,6 w3,
+// 8 attention_norm, 9 ffn_norm, 10 q_norm, 11 k_norm, 12 attention_post_norm, 13 ffn_post_norm};
+// 0xFFFF0000 + {0 tok_embeddings, 1 output, 2 norm}
+mc_status
+mc_decoder_init_synthetic(mc_decoder* d, uint64_t seed)
+{
+    if (!d) return fail(MC_ERR_INVALID_ARGUMENT, "mc_decoder_init_synthetic: null argument");
+    MC_HIP(hipSetDevice(d->dev->ordinal));
+    const mc_decoder_config& c = d->cfg;
+    const int H = c.n_heads, KV = c.n_kv_heads, hd = c.head_dim;
+    const int fmt = c.weight_format;
+    const int bits = fmt == MC_WFMT_I4 ? 4 : 8;
+    const int group = c.group_size;
+    mc_status s;
+    auto fill_linear = [&](linear_w& L, int out, int in, uint32_t m0, uint32_t map, uint32_t n0,
+                           uint32_t n1) -> mc_status {
+        mc_status r = d->alloc_linear(L, fmt, out, in, group);
+        if (r != MC_OK) return r;
+        if (fmt == MC_WFMT_T) {
+            return d->launch("mc_synth_fill_T", 2048, 1, 1, 256, 0,
+                             pack(L.w, seed, m0, map, n0, n1, (uint32_t)out, (uint32_t)in, (int32_t)2,
+                                  (int32_t)d->tb));
+        }
+        r = d->launch("mc_synth_fill_q", 4096, 1, 1, 256, 0,
+                      pack(L.w, seed, m0, map, n0, n1, (uint32_t)out, (uint32_t)in, (int32_t)bits));
+        if (r != MC_OK) return r;
+        return d->launch("mc_synth_fill_scales", 1024, 1, 1, 256, 0,
+                         pack(L.scales, seed, m0, map, n0, n1, (uint32_t)out, (uint32_t)L.ngroups,
+                              (uint32_t)in, (int32_t)bits, (int32_t)(d->tb == 2 ? 2 : 4)));
+    };
+    auto fill_vec = [&](void** p, int n, uint32_t m) -> mc_status {
+        if (!*p) {
+            mc_status r = d->alloc(p, (size_t)n * d->tb, false);
+            if (r != MC_OK) return r;
+        }
+        return d->launch("mc_synth_fill_T", (n + 255) / 256, 1, 1, 256, 0,
+                         pack(*p, seed, m, (uint32_t)0, (uint32_t)0, (uint32_t)0, (uint32_t)1,
+                              (uint32_t)n, (int32_t)0, (int32_t)d->tb));
+    };
+    for (int i = 0; i < d->n_own; i++) {
+        layer_w& L = d->layers[i];
+        const uint32_t base = (uint32_t)(c.layer_begin + i) * 16;
+        s = fill_linear(L.qkv, (H + 2 * KV) * hd, c.dim, base + 0, 1, H * hd, KV * hd);
+        if (s != MC_OK) return s;
+        s = fill_linear(L.wo, c.dim, H * hd, base + 3, 0, 0, 0);
+        if (s != MC_OK) return s;
+        s = fill_linear(L.w13, 2 * c.ffn_dim, c.dim, base + 4, 2, 0, 0);
+        if (s != MC_OK) return s;
+        s = fill_linear(L.w2, c.dim, c.ffn_dim, base + 5, 0, 0, 0);
+        if (s != MC_OK) return s;
+        s = fill_vec(&L.attention_norm, c.dim, base + 8);
+        if (s != MC_OK) return s;
+        s = fill_vec(&L.ffn_norm, c.dim, base + 9);
+        if (s != MC_OK) return s;
+        if (c.family == MC_FAMILY_GEMMA3) {
+            s = fill_vec(&L.q_norm, hd, base + 10);
+            if (s != MC_OK) return s;
+            s = fill_vec(&L.k_norm, hd, base + 11);
+            if (s != MC_OK) return s;
+            s = fill_vec(&L.attention_post_norm, c.dim, base + 12);
+            if (s != MC_OK) return s;
+            s = fill_vec(&L.ffn_post_norm, c.dim, base + 13);
+            if (s != MC_OK) return s;
+        }
+    }
+    if (d->first_stage) {
+        d->emb_fmt = MC_WFMT_T;
+        if (!d->emb_table) {
+            s = d->alloc(&d->emb_table, (size_t)c.vocab * c.dim * d->tb, false);
+            if (s != MC_OK) return s;
+        }
+        s = d->launch("mc_synth_fill_T", 4096, 1, 1, 256, 0,
+                      pack(d->emb_table, seed, (uint32_t)0xFFFF0000u, (uint32_t)0, (uint32_t)0,
+                           (uint32_t)0, (uint32_t)c.vocab, (uint32_t)c.dim, (int32_t)1, (int32_t)d->tb));
+        if (s != MC_OK) return s;
+    }
+    if (d->last_stage) {
+        s = fill_linear(d->output, c.vocab, c.dim, 0xFFFF0001u, 0, 0, 0);
+        if (s != MC_OK) return s;
+        s = fill_vec(&d->final_norm, c.dim, 0xFFFF0002u);
+        if (s != MC_OK) return s;
+    }
+    MC_HIP(hipStreamSynchronize(d->stream));
+    return MC_OK;
+}
+
+static mc_status
+check_ready(mc_decoder* d)
+{
+    for (auto& L : d->layers)
+        if (!L.qkv.allocated || !L.wo.allocated || !L.w13.allocated || !L.w2.allocated ||
+            !L.attention_norm || !L.ffn_norm)
+            return fail(MC_ERR_RUNTIME, "decoder: layer weights are not loaded");
+    if (d->first_stage && !d->emb_table) return fail(MC_ERR_RUNTIME, "decoder: tok_embeddings not loaded");
+    if (d->last_stage && (!d->output.allocated || !d->final_norm))
+        return fail(MC_ERR_RUNTIME, "decoder: output head not loaded");
+    return MC_OK;
+}
+
+mc_status
+mc_decoder_step(mc_decoder* d, int32_t token, int32_t start_pos, const void* hidden_in,
+                int32_t* next_token)
+{
+    if (!d) return fail(MC_ERR_INVALID_ARGUMENT, "mc_decoder_step: null argument");
+    mc_status s = check_ready(d);
+    if (s != MC_OK) return s;
+    if (start_pos < 0) return fail(MC_ERR_INVALID_ARGUMENT, "decoder: negative start position");
+    if (!d->first_stage && !hidden_in)
+        return fail(MC_ERR_INVALID_ARGUMENT, "decoder: a non-first stage needs the inbound hidden row");
+    MC_HIP(hipSetDevice(d->dev->ordinal));
+    s = d->ensure_rope(start_pos);
+    if (s != MC_OK) return s;
+    s = d->launch("mc_step_set", 1, 1, 1, 64, 0,
+                  pack(d->state, token, start_pos, (int32_t)d->cfg.max_seq_len, (int32_t)d->pre_len,
+                       (int32_t)d->rope_start, (int32_t)(start_pos == 0 ? 1 : 0)));
+    if (s != MC_OK) return s;
+    s = d->run_token(d->first_stage ? nullptr : hidden_in);
+    if (s != MC_OK) return s;
+    d->last_pos = start_pos;
+    if (next_token && d->last_stage) {
+        MC_HIP(hipMemcpyAsync(next_token, &d->state->token, 4, hipMemcpyDeviceToHost, d->stream));
+        MC_HIP(hipStreamSynchronize(d->stream));
+    }
+    return MC_OK;
+}
+
+mc_status
+mc_decoder_generate(mc_decoder* d, int32_t first_token, int32_t start_pos, int32_t n,
+                    int32_t* tokens_out)
+{
+    if (!d || n <= 0) return fail(MC_ERR_INVALID_ARGUMENT, "mc_decoder_generate: bad argument");
+    if (!d->first_stage || !d->last_stage)
+        return fail(MC_ERR_INVALID_ARGUMENT, "mc_decoder_generate: single-stage decoders only");
+    if (n > d->tokens_cap) return fail(MC_ERR_INVALID_ARGUMENT, "mc_decoder_generate: n too large");
+    mc_status s = check_ready(d);
+    if (s != MC_OK) return s;
+    MC_HIP(hipSetDevice(d->dev->ordinal));
+    s = d->ensure_rope(start_pos);
+    if (s != MC_OK) return s;
+    s = d->launch("mc_step_set", 1, 1, 1, 64, 0,
+                  pack(d->state, first_token, start_pos, (int32_t)d->cfg.max_seq_len,
+                       (int32_t)d->pre_len, (int32_t)d->rope_start, (int32_t)(start_pos == 0 ? 1 : 0)));
+    if (s != MC_OK) return s;
+    // step_index restarts at 0 for every generate call
+    MC_HIP(hipMemsetAsync(&d->state->step_index, 0, 4, d->stream));
+    s = d->run_token(nullptr);
+    if (s != MC_OK) return s;
+    for (int i = 1; i < n; i++) {
+        const int pos = start_pos + i;
+        const int old_start = d->rope_start;
+        s = d->ensure_rope(pos);
+        if (s != MC_OK) return s;
+        const bool rope_moved = d->rope_start != old_start;
+        if (d->cfg.use_graph && !rope_moved) {
+            if (!d->graph_exec) {
+                MC_HIP(hipStreamBeginCapture(d->stream, hipStreamCaptureModeGlobal));
+                s = d->launch("mc_step_advance", 1, 1, 1, 64, 0,
+                              pack(d->state, (int32_t)d->cfg.max_seq_len, (int32_t)d->pre_len,
+                                   (int32_t)d->rope_start));
+                mc_status s2 = s == MC_OK ? d->run_token(nullptr) : s;
+                hipError_t e = hipStreamEndCapture(d->stream, &d->graph);
+                if (s2 != MC_OK) return s2;
+                if (e != hipSuccess) return hip_fail(e, "hipStreamEndCapture");
+                MC_HIP(hipGraphInstantiate(&d->graph_exec, d->graph, nullptr, nullptr, 0));
+            }
+            MC_HIP(hipGraphLaunch(d->graph_exec, d->stream));
+        } else {
+            if (rope_moved && d->graph_exec) {
+                // the captured advance kernel froze rope_start: drop the graph, it is re-captured
+                (void)hipGraphExecDestroy(d->graph_exec);
+                (void)hipGraphDestroy(d->graph);
+                d->graph_exec = nullptr;
+                d->graph = nullptr;
+            }
+            s = d->launch("mc_step_advance", 1, 1, 1, 64, 0,
+                          pack(d->state, (int32_t)d->cfg.max_seq_len, (int32_t)d->pre_len,
+                               (int32_t)d->rope_start));
+            if (s != MC_OK) return s;
+            s = d->run_token(nullptr);
+            if (s != MC_OK) return s;
+        }
+    }
+    d->last_pos = start_pos + n - 1;
+    if (tokens_out) {
+        MC_HIP(hipMemcpyAsync(tokens_out, d->tokens_dev, (size_t)n * 4, hipMemcpyDeviceToHost, d->stream));
+    }
+    MC_HIP(hipStreamSynchronize(d->stream));
+    return MC_OK;
+}
+
+void*
+mc_decoder_hidden_out(mc_decoder* d)
+{
+    return d->hidden;
+}
+
+void*
+mc_decoder_hidden_in(mc_decoder* d)
+{
+    return d->hidden_in;
+}
+
+mc_status
+mc_decoder_set_taps(mc_decoder* d, int32_t enable)
+{
+    d->want_taps = enable != 0;
+    return MC_OK;
+}
+
+mc_status
+mc_decoder_get_logits(mc_decoder* d, void* out)
+{
+    MC_HIP(hipSetDevice(d->dev->ordinal));
+    MC_HIP(hipStreamSynchronize(d->stream));
+    MC_HIP(hipMemcpy(out, d->logits, (size_t)d->cfg.vocab * d->tb, hipMemcpyDeviceToHost));
+    return MC_OK;
+}
+
+mc_status
+mc_decoder_get_hidden(mc_decoder* d, int32_t layer, void* out)
+{
+    // layer = global layer index, -1 = embedding output; only meaningful with taps enabled
+    const int li = layer - d->cfg.layer_begin + 1;
+    if (li < 0 || li > d->n_own) return fail(MC_ERR_INVALID_ARGUMENT, "decoder: tap out of range");
+    if (!d->want_taps) return fail(MC_ERR_RUNTIME, "decoder: taps are disabled (mc_decoder_set_taps)");
+    MC_HIP(hipSetDevice(d->dev->ordinal));
+    MC_HIP(hipStreamSynchronize(d->stream));
+    MC_HIP(hipMemcpy(out, (char*)d->taps + (size_t)li * d->cfg.dim * d->tb, (size_t)d->cfg.dim * d->tb,
+                     hipMemcpyDeviceToHost));
+    return MC_OK;
+}
+
+mc_status
+mc_decoder_export_kv(mc_decoder* d, int32_t layer, void* keys, void* values, int32_t* n_valid)
+{
+    layer_w* L;
+    mc_status s = find_layer(d, layer, &L);
+    if (s != MC_OK) return s;
+    MC_HIP(hipSetDevice(d->dev->ordinal));
+    const mc_decoder_config& c = d->cfg;
+    const size_t bytes = (size_t)c.max_seq_len * c.n_kv_heads * c.head_dim * d->tb;
+    void *kt = nullptr, *vtmp = nullptr;
+    MC_HIP(hipMalloc(&kt, bytes));
+    MC_HIP(hipMalloc(&vtmp, bytes));
+    s = d->launch("mc_kv_export_" + d->tname, 512, 1, 1, 256, 0,
+                  pack(L->kc, L->vt, kt, vtmp, d->state, (uint32_t)c.n_kv_heads, (uint32_t)c.head_dim,
+                       (uint32_t)c.max_seq_len, (uint32_t)d->pre_len));
+    step_state_h st{};
+    hipError_t e = hipStreamSynchronize(d->stream);
+    if (s == MC_OK && e == hipSuccess) {
+        e = hipMemcpy(&st, d->state, sizeof st, hipMemcpyDeviceToHost);
+        const size_t nb = (size_t)st.kv_len * c.n_kv_heads * c.head_dim * d->tb;
+        if (e == hipSuccess) e = hipMemcpy(keys, kt, nb, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(values, vtmp, nb, hipMemcpyDeviceToHost);
+        if (n_valid) *n_valid = st.kv_len;
+    }
+    (void)hipFree(kt);
+    (void)hipFree(vtmp);
+    if (s != MC_OK) return s;
+    if (e != hipSuccess) return hip_fail(e, "mc_decoder_export_kv");
+    return MC_OK;
+}
+
+static size_t
+linear_bytes(const linear_w& L)
+{
+    return L.allocated ? L.w_bytes + L.s_bytes : 0;
+}
+
+size_t
+mc_decoder_weight_bytes(const mc_decoder* d)
+{
+    size_t n = 0;
+    for (auto& L : d->layers) n += linear_bytes(L.qkv) + linear_bytes(L.wo) + linear_bytes(L.w13) + linear_bytes(L.w2);
+    if (d->last_stage) n += linear_bytes(d->output);
+    return n;
+}
+
+mc_status
+mc_decoder_time_gemv(mc_decoder* d, const char* which, int32_t repeats, float* total_ms,
+                     double* bytes_per_pass, int32_t* launches_per_pass)
+{
+    if (!d || !which || repeats <= 0)
+        return fail(MC_ERR_INVALID_ARGUMENT, "mc_decoder_time_gemv: bad argument");
+    mc_status s = check_ready(d);
+    if (s != MC_OK) return s;
+    MC_HIP(hipSetDevice(d->dev->ordinal));
+    const std::string w = which;
+    const float mu = d->cfg.family == MC_FAMILY_GEMMA3 ? 1.0f : 0.0f;
+    const bool gemma = d->cfg.family == MC_FAMILY_GEMMA3;
+    double bytes = 0;
+    int launches = 0;
+    auto pass = [&](bool count) -> mc_status {
+        mc_status r = MC_OK;
+        for (auto& L : d->layers) {
+            if (w == "qkv" || w == "all") {
+                r = d->gemv(L.qkv, 1, 0, d->hidden, d->qkv, nullptr, L.attention_norm, mu);
+                if (r != MC_OK) return r;
+                if (count) { bytes += linear_bytes(L.qkv); launches++; }
+            }
+            if (w == "wo" || w == "all") {
+                r = d->gemv(L.wo, 0, 0, d->attn_out, d->proj, nullptr, nullptr, mu);
+                if (r != MC_OK) return r;
+                if (count) { bytes += linear_bytes(L.wo); launches++; }
+            }
+            if (w == "w13" || w == "all") {
+                r = d->gemv(L.w13, 1, gemma ? 3 : 2, d->hidden, d->gate, nullptr, L.ffn_norm, mu);
+                if (r != MC_OK) return r;
+                if (count) { bytes += linear_bytes(L.w13); launches++; }
+            }
+            if (w == "w2" || w == "all") {
+                r = d->gemv(L.w2, 0, 0, d->gate, d->proj, nullptr, nullptr, mu);
+                if (r != MC_OK) return r;
+                if (count) { bytes += linear_bytes(L.w2); launches++; }
+            }
+        }
+        if ((w == "head" || w == "all") && d->last_stage) {
+            r = d->gemv(d->output, 1, 0, d->hidden, d->logits, nullptr, d->final_norm, mu);
+            if (r != MC_OK) return r;
+            if (count) { bytes += linear_bytes(d->output); launches++; }
+        }
+        return r;
+    };
+    s = pass(true); // warm-up + byte count
+    if (s != MC_OK) return s;
+    MC_HIP(hipEventRecord(d->q->t0, d->stream));
+    for (int i = 0; i < repeats; i++) {
+        s = pass(false);
+        if (s != MC_OK) return s;
+    }
+    MC_HIP(hipEventRecord(d->q->t1, d->stream));
+    MC_HIP(hipEventSynchronize(d->q->t1));
+    MC_HIP(hipEventElapsedTime(total_ms, d->q->t0, d->q->t1));
+    if (bytes_per_pass) *bytes_per_pass = bytes;
+    if (launches_per_pass) *launches_per_pass = launches;
+    return MC_OK;
+}
+
+// tests: direct access to the fused weight buffers ("qkv","wo","w13","w2" per layer, "output")
+mc_status
+mc_decoder_weight_ptrs(mc_decoder* d, int32_t layer, const char* name, void** w, void** scales,
+                       int32_t* rows, int32_t* in_features, int32_t* ngroups)
+{
+    const linear_w* L = nullptr;
+    const std::string n = name;
+    if (layer < 0) {
+        if (n == "output") L = &d->output;
+    } else {
+        layer_w* lw;
+        mc_status s = find_layer(d, layer, &lw);
+        if (s != MC_OK) return s;
+        if (n == "qkv") L = &lw->qkv;
+        else if (n == "wo") L = &lw->wo;
+        else if (n == "w13") L = &lw->w13;
+        else if (n == "w2") L = &lw->w2;
+    }
+    if (!L || !L->allocated) return fail(MC_ERR_INVALID_ARGUMENT, "decoder: no such fused weight '" + n + "'");
+    if (w) *w = L->w;
+    if (scales) *scales = L->scales;
+    if (rows) *rows = L->out;
+    if (in_features) *in_features = L->in;
+    if (ngroups) *ngroups = L->ngroups;
+    return MC_OK;
+}
+
+int32_t
+mc_synth_weight(uint64_t seed, uint32_t matrix_id, uint32_t row, uint32_t col, int32_t bits)
+{
+    return mcsynth::weight(seed, matrix_id, row, col, bits);
+}
+
+float
+mc_synth_scale(uint64_t seed, uint32_t matrix_id, uint32_t row, uint32_t group, int32_t in_features,
+               int32_t bits)
+{
+    return mcsynth::scale(seed, matrix_id, row, group, in_features, bits);
+}
+
+float
+mc_synth_value(uint64_t seed, uint32_t matrix_id, uint32_t index, int32_t kind, uint32_t n)
+{
+    return mcsynth::value(seed, matrix_id, index, kind, n ? n : 1);
+}
+
+} // extern "C"

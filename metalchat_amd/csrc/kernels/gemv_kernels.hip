@@ -1,0 +1,31 @@
+// extern "C" instantiations of the fused GEMV (gemv.h).  Name:
+//   mc_gemv_{i4|i8|w}_{bfloat|float}[_fast]_p{PRO}_e{EPI}
+//   PRO 0 = x as is, 1 = rmsnorm(x) on the way into LDS
+//   EPI 0 = store, 1 = residual add, 2 = silu(w1 x) * (w3 x), 3 = gelu(w1 x) * (w3 x)
+#include "gemv.h"
+
+using namespace mc;
+using namespace mc::gemv;
+
+#define MC_GEMV(NAME, WF, T, QM, PRO, EPI)                                                        \
+    extern "C" __global__ void __launch_bounds__(512)                                            \
+    NAME(const void* w, const void* scales, const void* x, void* y, const void* res,             \
+         const void* norm_w, uint32_t out_rows, uint32_t in, uint32_t group, float eps, float mu) \
+    {                                                                                             \
+        body<WF, T, QM, PRO, EPI, 4>(w, scales, x, y, res, norm_w, out_rows, in, group, eps, mu); \
+    }
+
+#define MC_GEMV_SET(PFX, WF, T, QM)            \
+    MC_GEMV(PFX##_p0_e0, WF, T, QM, 0, 0)      \
+    MC_GEMV(PFX##_p1_e0, WF, T, QM, 1, 0)      \
+    MC_GEMV(PFX##_p0_e1, WF, T, QM, 0, 1)      \
+    MC_GEMV(PFX##_p1_e2, WF, T, QM, 1, 2)      \
+    MC_GEMV(PFX##_p1_e3, WF, T, QM, 1, 3)
+
+MC_GEMV_SET(mc_gemv_i4_bfloat, WF_I4, BF, Q_EXACT)
+MC_GEMV_SET(mc_gemv_i4_bfloat_fast, WF_I4, BF, Q_FAST)
+MC_GEMV_SET(mc_gemv_i4_float, WF_I4, F32, Q_EXACT)
+MC_GEMV_SET(mc_gemv_i8_bfloat, WF_I8, BF, Q_EXACT)
+MC_GEMV_SET(mc_gemv_i8_float, WF_I8, F32, Q_EXACT)
+MC_GEMV_SET(mc_gemv_w_bfloat, WF_T, BF, Q_EXACT)
+MC_GEMV_SET(mc_gemv_w_float, WF_T, F32, Q_EXACT)

@@ -1,0 +1,444 @@
+"""ctypes harness over the C ABI (include/metalchat_hip.h).  See package docstring."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+BF16, F32 = 0, 1
+FAMILY_LLAMA3, FAMILY_GEMMA3 = 0, 1
+WFMT_T, WFMT_I8, WFMT_I4 = 0, 1, 2
+QMODE_EXACT, QMODE_FAST = 0, 1
+
+
+class McError(RuntimeError):
+    """status 1 -> std::invalid_argument, 2 -> std::runtime_error, 3 -> alloc_error."""
+
+    def __init__(self, status: int, message: str):
+        super().__init__(message)
+        self.status = status
+
+
+def library_path() -> str:
+    return os.path.join(HERE, "lib", "libmetalchat_hip.so")
+
+
+def hsaco_path() -> str:
+    return os.path.join(HERE, "lib", "metalchat.hsaco")
+
+
+class DecoderConfig(C.Structure):
+    _fields_ = [
+        ("dtype", C.c_int32), ("family", C.c_int32),
+        ("dim", C.c_int32), ("n_heads", C.c_int32), ("n_kv_heads", C.c_int32),
+        ("head_dim", C.c_int32), ("ffn_dim", C.c_int32), ("n_layers", C.c_int32),
+        ("vocab", C.c_int32), ("max_seq_len", C.c_int32),
+        ("rope_theta", C.c_float), ("rope_sliding_theta", C.c_float),
+        ("sliding_stride", C.c_int32), ("norm_eps", C.c_float), ("attn_scale", C.c_float),
+        ("sink_pre_len", C.c_int32), ("layer_begin", C.c_int32), ("layer_end", C.c_int32),
+        ("weight_format", C.c_int32), ("group_size", C.c_int32), ("qmode", C.c_int32),
+        ("use_graph", C.c_int32),
+    ]
+
+
+_lib = None
+
+
+def capi() -> C.CDLL:
+    """Loads libmetalchat_hip.so and declares every prototype of include/metalchat_hip.h."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise McError(2, f"hip: {path} is missing -- run `python -m metalchat_amd.build` "
+                         "(there is no CPU fallback)")
+    lib = C.CDLL(path)
+    vp, sz, i32, u32, u64, f32 = C.c_void_p, C.c_size_t, C.c_int32, C.c_uint32, C.c_uint64, C.c_float
+    pvp = C.POINTER(C.c_void_p)
+    P = {
+        "mc_last_error": (C.c_char_p, []),
+        "mc_version": (C.c_char_p, []),
+        "mc_device_create": (i32, [i32, pvp]),
+        "mc_device_release": (None, [vp]),
+        "mc_device_name": (C.c_char_p, [vp]),
+        "mc_device_max_buffer_size": (sz, [vp]),
+        "mc_device_ordinal": (i32, [vp]),
+        "mc_device_compute_units": (i32, [vp]),
+        "mc_library_open": (i32, [vp, C.c_char_p, pvp]),
+        "mc_library_release": (None, [vp]),
+        "mc_library_get_kernel": (i32, [vp, C.c_char_p, pvp]),
+        "mc_kernel_release": (None, [vp]),
+        "mc_kernel_name": (C.c_char_p, [vp]),
+        "mc_kernel_max_threads_per_group": (sz, [vp]),
+        "mc_buffer_alloc": (i32, [vp, sz, pvp]),
+        "mc_buffer_alloc_copy": (i32, [vp, vp, sz, pvp]),
+        "mc_buffer_wrap_nocopy": (i32, [vp, vp, sz, pvp]),
+        "mc_buffer_release": (None, [vp]),
+        "mc_buffer_contents": (vp, [vp]),
+        "mc_buffer_length": (sz, [vp]),
+        "mc_buffer_upload": (i32, [vp, sz, vp, sz]),
+        "mc_buffer_download": (i32, [vp, sz, vp, sz]),
+        "mc_buffer_fill_zero": (i32, [vp, sz, sz]),
+        "mc_queue_create": (i32, [vp, vp, pvp]),
+        "mc_queue_release": (None, [vp]),
+        "mc_queue_stream": (vp, [vp]),
+        "mc_encoder_set_kernel": (i32, [vp, vp]),
+        "mc_encoder_set_bytes": (i32, [vp, vp, sz]),
+        "mc_encoder_set_buffer": (i32, [vp, vp, sz]),
+        "mc_encoder_memory_barrier": (i32, [vp, vp]),
+        "mc_encoder_dispatch_threads": (i32, [vp, C.POINTER(sz), C.POINTER(sz)]),
+        "mc_encoder_dispatch_threads_lds": (i32, [vp, C.POINTER(sz), C.POINTER(sz), sz]),
+        "mc_queue_on_completed": (i32, [vp, vp, vp]),
+        "mc_queue_commit": (i32, [vp]),
+        "mc_queue_wait": (i32, [vp]),
+        "mc_queue_timer_begin": (i32, [vp]),
+        "mc_queue_timer_end": (i32, [vp]),
+        "mc_queue_timer_elapsed_ms": (i32, [vp, C.POINTER(f32)]),
+        "mc_decoder_create": (i32, [vp, vp, vp, C.POINTER(DecoderConfig), pvp]),
+        "mc_decoder_release": (None, [vp]),
+        "mc_decoder_load_linear": (i32, [vp, i32, C.c_char_p, i32, i32, i32, i32, vp, vp]),
+        "mc_decoder_load_vector": (i32, [vp, i32, C.c_char_p, i32, vp]),
+        "mc_decoder_init_synthetic": (i32, [vp, u64]),
+        "mc_decoder_step": (i32, [vp, i32, i32, vp, C.POINTER(i32)]),
+        "mc_decoder_generate": (i32, [vp, i32, i32, i32, C.POINTER(i32)]),
+        "mc_decoder_hidden_out": (vp, [vp]),
+        "mc_decoder_hidden_in": (vp, [vp]),
+        "mc_decoder_set_taps": (i32, [vp, i32]),
+        "mc_decoder_get_logits": (i32, [vp, vp]),
+        "mc_decoder_get_hidden": (i32, [vp, i32, vp]),
+        "mc_decoder_export_kv": (i32, [vp, i32, vp, vp, C.POINTER(i32)]),
+        "mc_decoder_weight_bytes": (sz, [vp]),
+        "mc_decoder_time_gemv": (i32, [vp, C.c_char_p, i32, C.POINTER(f32), C.POINTER(C.c_double),
+                                       C.POINTER(i32)]),
+        "mc_decoder_weight_ptrs": (i32, [vp, i32, C.c_char_p, pvp, pvp, C.POINTER(i32),
+                                         C.POINTER(i32), C.POINTER(i32)]),
+        "mc_synth_weight": (i32, [u64, u32, u32, u32, i32]),
+        "mc_synth_scale": (f32, [u64, u32, u32, u32, i32, i32]),
+        "mc_synth_value": (f32, [u64, u32, u32, i32, u32]),
+    }
+    for name, (res, args) in P.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    lib._prototypes = P
+    _lib = lib
+    return lib
+
+
+def _check(status: int):
+    if status != 0:
+        raise McError(status, capi().mc_last_error().decode())
+
+
+def _np_ptr(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def layout(sizes, strides=None, offsets=None) -> np.ndarray:
+    """tensor_layout<N>: 3N uint32 words {sizes, strides, offsets} (kernel/tensor.h:10-14)."""
+    sizes = list(sizes)
+    n = len(sizes)
+    if strides is None:
+        strides, acc = [0] * n, 1
+        for d in range(n - 1, -1, -1):
+            strides[d] = acc
+            acc *= sizes[d]
+    if offsets is None:
+        offsets = [0] * n
+    return np.array(list(sizes) + list(strides) + list(offsets), dtype=np.uint32)
+
+
+def make_kernel_grid_2d(num_rows: int, dim_size: int, max_threads: int):
+    """src/kernel.cc:13-37 -- returns (grid, thread) as 3-tuples of TOTAL threads / group size."""
+    if num_rows * dim_size <= max_threads:
+        return (dim_size, num_rows, 1), (dim_size, num_rows, 1)
+    if dim_size <= max_threads:
+        return (dim_size, num_rows, 1), (dim_size, 1, 1)
+    groups = (dim_size + max_threads - 1) // max_threads
+    return (max_threads * groups, num_rows, 1), (max_threads, 1, 1)
+
+
+class Buffer:
+    """metal::shared_buffer / hardware_memory_container (include/metalchat/container.h:641-700)."""
+
+    def __init__(self, acc: "HardwareAccelerator", handle, keep=None):
+        self.acc, self._h, self._keep = acc, handle, keep
+
+    @property
+    def nbytes(self) -> int:
+        return capi().mc_buffer_length(self._h)
+
+    @property
+    def device_ptr(self) -> int:
+        return capi().mc_buffer_contents(self._h)
+
+    def upload(self, a: np.ndarray, offset: int = 0):
+        a = np.ascontiguousarray(a)
+        _check(capi().mc_buffer_upload(self._h, offset, _np_ptr(a), a.nbytes))
+
+    def download(self, dtype, count: int, offset: int = 0) -> np.ndarray:
+        out = np.empty(count, dtype=dtype)
+        _check(capi().mc_buffer_download(self._h, offset, _np_ptr(out), out.nbytes))
+        return out
+
+    def release(self):
+        if self._h:
+            capi().mc_buffer_release(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+
+class Kernel:
+    """basic_kernel (include/metalchat/kernel.h:59-98)."""
+
+    def __init__(self, acc, handle, name):
+        self.acc, self._h, self.name = acc, handle, name
+
+    def max_threads_per_threadgroup(self) -> int:
+        return capi().mc_kernel_max_threads_per_group(self._h)
+
+
+class KernelTask:
+    """kernel_task (include/metalchat/kernel.h:101-298): positional arguments, then dispatch.
+    Arguments: a Buffer (optionally (Buffer, byte_offset)), a numpy uint32 layout array, or a
+    numpy scalar / 0-d array passed by value.  Tensor = layout then buffer, exactly as
+    hardware_function_encoder::encode (include/metalchat/kernel_thread.h:111-125)."""
+
+    def __init__(self, kernel: Kernel, grid, thread, args=(), lds_bytes: int = 0):
+        self.kernel, self.grid, self.thread, self.args, self.lds = kernel, grid, thread, list(args), lds_bytes
+
+    def bind_front(self, *front):
+        return KernelTask(self.kernel, self.grid, self.thread, list(front) + self.args, self.lds)
+
+    def bind_back(self, *back):
+        return KernelTask(self.kernel, self.grid, self.thread, self.args + list(back), self.lds)
+
+    def __call__(self):
+        lib, q = capi(), self.kernel.acc._queue
+        _check(lib.mc_encoder_set_kernel(q, self.kernel._h))
+        for a in self.args:
+            if a is None:
+                _check(lib.mc_encoder_set_buffer(q, None, 0))
+            elif isinstance(a, Buffer):
+                _check(lib.mc_encoder_set_buffer(q, a._h, 0))
+                _check(lib.mc_encoder_memory_barrier(q, a._h))
+            elif isinstance(a, tuple) and isinstance(a[0], Buffer):
+                _check(lib.mc_encoder_set_buffer(q, a[0]._h, a[1]))
+                _check(lib.mc_encoder_memory_barrier(q, a[0]._h))
+            else:
+                arr = np.ascontiguousarray(a)
+                _check(lib.mc_encoder_set_bytes(q, _np_ptr(arr), arr.nbytes))
+        g = (C.c_size_t * 3)(*self.grid)
+        t = (C.c_size_t * 3)(*self.thread)
+        _check(lib.mc_encoder_dispatch_threads_lds(q, g, t, self.lds))
+
+
+class HardwareAccelerator:
+    """hardware_accelerator (include/metalchat/accelerator.h:55-219, src/accelerator.cc:26-158):
+    device + shader library + kernel cache + the command queue."""
+
+    def __init__(self, path: str | None = None, ordinal: int = -1, stream: int | None = None):
+        lib = capi()
+        self._dev = C.c_void_p()
+        _check(lib.mc_device_create(ordinal, C.byref(self._dev)))
+        self._lib = C.c_void_p()
+        _check(lib.mc_library_open(self._dev, (path or hsaco_path()).encode(), C.byref(self._lib)))
+        self._queue = C.c_void_p()
+        _check(lib.mc_queue_create(self._dev, C.c_void_p(stream) if stream else None,
+                                   C.byref(self._queue)))
+        self._kernels: dict[str, Kernel] = {}
+
+    def name(self) -> str:
+        return capi().mc_device_name(self._dev).decode()
+
+    def max_buffer_size(self) -> int:
+        return capi().mc_device_max_buffer_size(self._dev)
+
+    def compute_units(self) -> int:
+        return capi().mc_device_compute_units(self._dev)
+
+    def load(self, name: str, *types) -> Kernel:
+        """load("rmsnorm", "bfloat") -> kernel "rmsnorm_bfloat" (accelerator.h:175-218)."""
+        full = "_".join([name, *[str(t) for t in types]])
+        if full not in self._kernels:
+            h = C.c_void_p()
+            _check(capi().mc_library_get_kernel(self._lib, full.encode(), C.byref(h)))
+            self._kernels[full] = Kernel(self, h, full)
+        return self._kernels[full]
+
+    def alloc(self, nbytes: int) -> Buffer:
+        h = C.c_void_p()
+        _check(capi().mc_buffer_alloc(self._dev, nbytes, C.byref(h)))
+        return Buffer(self, h)
+
+    def to_device(self, a: np.ndarray) -> Buffer:
+        a = np.ascontiguousarray(a)
+        h = C.c_void_p()
+        _check(capi().mc_buffer_alloc_copy(self._dev, _np_ptr(a), a.nbytes, C.byref(h)))
+        return Buffer(self, h)
+
+    def wrap(self, device_ptr: int, nbytes: int, keep=None) -> Buffer:
+        h = C.c_void_p()
+        _check(capi().mc_buffer_wrap_nocopy(self._dev, C.c_void_p(device_ptr), nbytes, C.byref(h)))
+        return Buffer(self, h, keep)
+
+    def wait(self):
+        _check(capi().mc_queue_wait(self._queue))
+
+    def timer_begin(self):
+        _check(capi().mc_queue_timer_begin(self._queue))
+
+    def timer_end_ms(self) -> float:
+        _check(capi().mc_queue_timer_end(self._queue))
+        ms = C.c_float()
+        _check(capi().mc_queue_timer_elapsed_ms(self._queue, C.byref(ms)))
+        return ms.value
+
+    def stream(self) -> int:
+        return capi().mc_queue_stream(self._queue)
+
+
+class Decoder:
+    """The fused decode pipeline (Part 2 of the C ABI): nn::llama3 / nn::gemma3 per-token step."""
+
+    def __init__(self, acc: HardwareAccelerator, **cfg):
+        self.acc = acc
+        c = DecoderConfig()
+        defaults = dict(family=FAMILY_LLAMA3, rope_sliding_theta=0.0, sliding_stride=0,
+                        sink_pre_len=-1, layer_begin=0, layer_end=cfg["n_layers"],
+                        weight_format=WFMT_T, group_size=0, qmode=QMODE_EXACT, use_graph=0)
+        defaults.update(cfg)
+        for k, _ in DecoderConfig._fields_:
+            setattr(c, k, defaults[k])
+        self.cfg = defaults
+        self._c = c
+        self._h = C.c_void_p()
+        _check(capi().mc_decoder_create(acc._dev, acc._lib, acc._queue, C.byref(c), C.byref(self._h)))
+        self.np_T = np.uint16 if defaults["dtype"] == BF16 else np.float32
+
+    # -- weights ------------------------------------------------------------------------------
+    def load_linear(self, layer: int, name: str, fmt: int, weight: np.ndarray, scales=None,
+                    group_size: int = 0):
+        weight = np.ascontiguousarray(weight)
+        out_f, in_f = weight.shape
+        sc = np.ascontiguousarray(scales, dtype=np.float32) if scales is not None else None
+        _check(capi().mc_decoder_load_linear(self._h, layer, name.encode(), fmt, out_f, in_f,
+                                             group_size, _np_ptr(weight),
+                                             _np_ptr(sc) if sc is not None else None))
+
+    def load_vector(self, layer: int, name: str, data: np.ndarray):
+        data = np.ascontiguousarray(data)
+        _check(capi().mc_decoder_load_vector(self._h, layer, name.encode(), data.size, _np_ptr(data)))
+
+    def load_model(self, weights: dict):
+        """weights: the dict produced by tests/modelgen.py (reference-native formats)."""
+        fmt_of = {0: WFMT_T, 1: None, 2: WFMT_I8}
+        lb, le = self.cfg["layer_begin"], self.cfg["layer_end"]
+        for li in range(lb, le):
+            lw = weights["layers"][li]
+            for n in ("wq", "wk", "wv", "wo", "w1", "w2", "w3"):
+                spec = lw[n]
+                if spec["kind"] == 0:
+                    self.load_linear(li, n, WFMT_T, spec["weight"])
+                else:
+                    self.load_linear(li, n, spec["hbm_format"], spec["weight"], spec["scales"],
+                                     spec.get("group_size", 0) if spec["kind"] == 1 else 0)
+            for n in ("attention_norm", "ffn_norm", "q_norm", "k_norm", "attention_post_norm",
+                      "ffn_post_norm"):
+                if lw.get(n) is not None:
+                    self.load_vector(li, n, lw[n])
+        if lb == 0:
+            e = weights["embedding"]
+            if e["kind"] == 0:
+                self.load_linear(-1, "tok_embeddings", WFMT_T, e["weight"])
+            else:
+                self.load_linear(-1, "tok_embeddings", WFMT_I8, e["weight"], e["scales"])
+        if le == self.cfg["n_layers"]:
+            o = weights["output"]
+            if o["kind"] == 0:
+                self.load_linear(-1, "output", WFMT_T, o["weight"])
+            else:
+                self.load_linear(-1, "output", o["hbm_format"], o["weight"], o["scales"],
+                                 o.get("group_size", 0) if o["kind"] == 1 else 0)
+            self.load_vector(-1, "norm", weights["final_norm"])
+
+    def init_synthetic(self, seed: int):
+        _check(capi().mc_decoder_init_synthetic(self._h, seed))
+
+    # -- stepping -----------------------------------------------------------------------------
+    def step(self, token: int, start_pos: int, hidden_in: int | None = None, sync: bool = True):
+        nt = C.c_int32(-1)
+        _check(capi().mc_decoder_step(self._h, token, start_pos,
+                                      C.c_void_p(hidden_in) if hidden_in else None,
+                                      C.byref(nt) if sync else None))
+        return nt.value
+
+    def generate(self, first_token: int, start_pos: int, n: int) -> np.ndarray:
+        out = np.zeros(n, dtype=np.int32)
+        _check(capi().mc_decoder_generate(self._h, first_token, start_pos, n,
+                                          out.ctypes.data_as(C.POINTER(C.c_int32))))
+        return out
+
+    def hidden_out_ptr(self) -> int:
+        return capi().mc_decoder_hidden_out(self._h)
+
+    def hidden_in_ptr(self) -> int:
+        return capi().mc_decoder_hidden_in(self._h)
+
+    def set_taps(self, enable: bool):
+        _check(capi().mc_decoder_set_taps(self._h, 1 if enable else 0))
+
+    def logits(self) -> np.ndarray:
+        out = np.empty(self.cfg["vocab"], dtype=self.np_T)
+        _check(capi().mc_decoder_get_logits(self._h, _np_ptr(out)))
+        return out
+
+    def hidden(self, layer: int) -> np.ndarray:
+        out = np.empty(self.cfg["dim"], dtype=self.np_T)
+        _check(capi().mc_decoder_get_hidden(self._h, layer, _np_ptr(out)))
+        return out
+
+    def export_kv(self, layer: int):
+        c = self.cfg
+        shape = (c["max_seq_len"], c["n_kv_heads"], c["head_dim"])
+        k = np.zeros(shape, dtype=self.np_T)
+        v = np.zeros(shape, dtype=self.np_T)
+        n = C.c_int32()
+        _check(capi().mc_decoder_export_kv(self._h, layer, _np_ptr(k), _np_ptr(v), C.byref(n)))
+        return k[: n.value], v[: n.value]
+
+    def weight_bytes(self) -> int:
+        return capi().mc_decoder_weight_bytes(self._h)
+
+    def time_gemv(self, which: str, repeats: int):
+        ms, by, ln = C.c_float(), C.c_double(), C.c_int32()
+        _check(capi().mc_decoder_time_gemv(self._h, which.encode(), repeats, C.byref(ms),
+                                           C.byref(by), C.byref(ln)))
+        return ms.value, by.value, ln.value
+
+    def weight_ptrs(self, layer: int, name: str):
+        w, s = C.c_void_p(), C.c_void_p()
+        rows, inf, ng = C.c_int32(), C.c_int32(), C.c_int32()
+        _check(capi().mc_decoder_weight_ptrs(self._h, layer, name.encode(), C.byref(w), C.byref(s),
+                                             C.byref(rows), C.byref(inf), C.byref(ng)))
+        return w.value, s.value, rows.value, inf.value, ng.value
+
+    def release(self):
+        if self._h:
+            capi().mc_decoder_release(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass

@@ -19,3 +19,13 @@ def oracle():
 
     mc_oracle.build()
     return mc_oracle
+
+
+@pytest.fixture(scope="session")
+def acc():
+    """One hardware_accelerator (device + code object + queue) for the whole GPU session."""
+    import metalchat_amd as mc
+    from metalchat_amd import build
+
+    build.build_all()
+    return mc.HardwareAccelerator()
