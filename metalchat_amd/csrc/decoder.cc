@@ -39,6 +39,7 @@ struct linear_w {
     size_t row_bytes = 0;
     int ngroups = 1;
     bool allocated = false;
+    std::vector<uint8_t> scales_host; // shadow of the quad-interleaved scale buffer (load path only)
 };
 
 struct layer_w {
@@ -157,6 +158,7 @@ struct mc_decoder {
     std::vector<void*> allocs;
     int gemv_block = 256;
     int gemv_wgs_per_cu = 2;
+    int dbg_variant = 0; // MC_GEMV_DBG=1 stream-only, 2 compute-only (tuning ablations)
 
     ~mc_decoder()
     {
@@ -232,9 +234,9 @@ struct mc_decoder {
         }
         if (in % 32 != 0)
             return fail(MC_ERR_INVALID_ARGUMENT, "decoder: in_features must be a multiple of 32");
-        if (fmt != MC_WFMT_T && group != 0 && (group % 32 != 0 || in % group != 0))
+        if (fmt != MC_WFMT_T && group != 0 && (group < 32 || (group & (group - 1)) != 0 || in % group != 0))
             return fail(MC_ERR_INVALID_ARGUMENT,
-                        "decoder: group size must be a multiple of 32 that divides in_features");
+                        "decoder: group size must be a power of two >= 32 that divides in_features");
         L.fmt = fmt;
         L.out = out;
         L.in = in;
@@ -242,7 +244,8 @@ struct mc_decoder {
         L.ngroups = (fmt == MC_WFMT_T) ? 0 : (group ? in / group : 1);
         L.row_bytes = row_bytes(fmt, in);
         L.w_bytes = L.row_bytes * out;
-        L.s_bytes = (size_t)L.ngroups * out * (tb == 2 ? 2 : 4);
+        // scales live in row quads [ceil(out/4)][ngroups][4] (gemv.h)
+        L.s_bytes = (size_t)L.ngroups * ((out + 3) / 4 * 4) * (tb == 2 ? 2 : 4);
         mc_status s = alloc(&L.w, L.w_bytes, false);
         if (s != MC_OK) return s;
         if (L.s_bytes) {
@@ -260,17 +263,13 @@ struct mc_decoder {
                 const float* scales)
     {
         const int in = L.in;
-        std::vector<uint8_t> rowbuf(L.row_bytes);
-        std::vector<uint8_t> sbuf((size_t)L.ngroups * (tb == 2 ? 2 : 4));
-        // stage whole matrix when contiguous to cut the number of copies
+        const size_t sb = tb == 2 ? 2 : 4;
         const bool contiguous = dst_stride == 1;
-        std::vector<uint8_t> stage, sstage;
-        if (contiguous) {
-            stage.resize(L.row_bytes * rows);
-            sstage.resize(sbuf.size() * rows);
-        }
+        std::vector<uint8_t> stage(L.row_bytes * (contiguous ? rows : 1));
+        // scales of the destination rows, scattered into the quad layout on the host first
+        std::vector<uint8_t> squad;
         for (int r = 0; r < rows; r++) {
-            uint8_t* dst = contiguous ? stage.data() + (size_t)r * L.row_bytes : rowbuf.data();
+            uint8_t* dst = contiguous ? stage.data() + (size_t)r * L.row_bytes : stage.data();
             if (L.fmt == MC_WFMT_T) {
                 memcpy(dst, (const char*)weight + (size_t)r * in * tb, (size_t)in * tb);
             } else if (L.fmt == MC_WFMT_I8) {
@@ -292,29 +291,34 @@ struct mc_decoder {
                     d32[c0 / 8] = v;
                 }
             }
-            if (L.ngroups) {
-                uint8_t* sd = contiguous ? sstage.data() + (size_t)r * sbuf.size() : sbuf.data();
-                for (int g = 0; g < L.ngroups; g++) {
-                    const float s = scales[(size_t)r * L.ngroups + g];
-                    if (tb == 2) reinterpret_cast<uint16_t*>(sd)[g] = f2bf_host(s);
-                    else reinterpret_cast<float*>(sd)[g] = s;
-                }
-            }
             if (!contiguous) {
                 const size_t drow = (size_t)dst_row0 + (size_t)r * dst_stride;
-                MC_HIP(hipMemcpy((char*)L.w + drow * L.row_bytes, rowbuf.data(), L.row_bytes,
+                MC_HIP(hipMemcpy((char*)L.w + drow * L.row_bytes, stage.data(), L.row_bytes,
                                  hipMemcpyHostToDevice));
-                if (L.ngroups)
-                    MC_HIP(hipMemcpy((char*)L.scales + drow * sbuf.size(), sbuf.data(), sbuf.size(),
-                                     hipMemcpyHostToDevice));
             }
         }
-        if (contiguous) {
+        if (contiguous)
             MC_HIP(hipMemcpy((char*)L.w + (size_t)dst_row0 * L.row_bytes, stage.data(), stage.size(),
                              hipMemcpyHostToDevice));
-            if (L.ngroups)
-                MC_HIP(hipMemcpy((char*)L.scales + (size_t)dst_row0 * sbuf.size(), sstage.data(),
-                                 sstage.size(), hipMemcpyHostToDevice));
+        if (L.ngroups) {
+            // element (row, g) of the quad layout sits at ((row/4)*ngroups + g)*4 + row%4.  Rows of
+            // different source matrices share quads (w1/w3), so the layout is edited in a host
+            // shadow of the whole scale buffer and the touched quad range is re-uploaded.
+            if (L.scales_host.size() != L.s_bytes) L.scales_host.assign(L.s_bytes, 0);
+            size_t lo = SIZE_MAX, hi = 0;
+            for (int r = 0; r < rows; r++) {
+                const size_t drow = (size_t)dst_row0 + (size_t)r * dst_stride;
+                for (int g = 0; g < L.ngroups; g++) {
+                    const float sc = scales[(size_t)r * L.ngroups + g];
+                    const size_t idx = ((drow / 4) * L.ngroups + g) * 4 + drow % 4;
+                    if (tb == 2) reinterpret_cast<uint16_t*>(L.scales_host.data())[idx] = f2bf_host(sc);
+                    else reinterpret_cast<float*>(L.scales_host.data())[idx] = sc;
+                }
+                const size_t q0 = (drow / 4) * L.ngroups * 4 * sb, q1 = q0 + (size_t)L.ngroups * 4 * sb;
+                lo = q0 < lo ? q0 : lo;
+                hi = q1 > hi ? q1 : hi;
+            }
+            MC_HIP(hipMemcpy((char*)L.scales + lo, L.scales_host.data() + lo, hi - lo, hipMemcpyHostToDevice));
         }
         return MC_OK;
     }
@@ -328,6 +332,8 @@ struct mc_decoder {
         name += L.fmt == MC_WFMT_I4 ? "i4_" : (L.fmt == MC_WFMT_I8 ? "i8_" : "w_");
         name += tname;
         if (L.fmt == MC_WFMT_I4 && tb == 2 && cfg.qmode == MC_QMODE_FAST) name += "_fast";
+        if (L.fmt == MC_WFMT_I4 && tb == 2 && dbg_variant && ((pro == 1 && epi == 2) || (pro == 0 && epi == 0)))
+            name += dbg_variant == 1 ? "_dbgstream" : "_dbgnoload";
         name += "_p" + std::to_string(pro) + "_e" + std::to_string(epi);
         const unsigned waves = gemv_block / 64;
         const unsigned ng = (L.out + 3) / 4;
@@ -335,7 +341,10 @@ struct mc_decoder {
         const unsigned cap = (unsigned)(dev->prop.multiProcessorCount * gemv_wgs_per_cu);
         if (wgs > cap) wgs = cap;
         if (wgs == 0) wgs = 1;
-        const unsigned lds = (unsigned)((((size_t)L.in * tb + 15) & ~(size_t)15) + 64);
+        // LDS: activation row zero-padded to whole chunks (64 lanes x 16 B of packed weights) + scratch
+        const unsigned kpl = L.fmt == MC_WFMT_I4 ? 32 : (L.fmt == MC_WFMT_I8 ? 16 : (tb == 2 ? 8 : 4));
+        const unsigned chunk = 64 * kpl;
+        const unsigned lds = (unsigned)((size_t)((L.in + chunk - 1) / chunk) * chunk * tb + 64);
         return launch(name, wgs, 1, 1, gemv_block, lds,
                       pack(L.w, L.scales, x, y, res, norm_w, (uint32_t)L.out, (uint32_t)L.in,
                            (uint32_t)L.group, cfg.norm_eps, mu));
@@ -522,6 +531,7 @@ mc_decoder_create(mc_device* dev, mc_library* lib, mc_queue* q, const mc_decoder
     d->last_stage = c.layer_end == c.n_layers;
     if (const char* e = getenv("MC_GEMV_BLOCK")) d->gemv_block = atoi(e);
     if (const char* e = getenv("MC_GEMV_WGS_PER_CU")) d->gemv_wgs_per_cu = atoi(e);
+    if (const char* e = getenv("MC_GEMV_DBG")) d->dbg_variant = atoi(e);
     if (d->gemv_block % 64 || d->gemv_block < 64 || d->gemv_block > 512) d->gemv_block = 256;
     if (d->gemv_wgs_per_cu < 1) d->gemv_wgs_per_cu = 2;
 

@@ -13,8 +13,10 @@
 //        (p, p+4) are the adjacent pair (2p, 2p+1) that one bf16 dot2 consumes.
 //   I8 : in bytes, two's complement, natural order.
 //   T  : in*sizeof(T) bytes.
-// scales: [out][in/group], bf16 when T = bfloat (the reference rounds the f32 scale to T before
-// the multiply, kernel/mul.metal:80-81, so nothing is lost), f32 when T = float.
+// scales: bf16 when T = bfloat (the reference rounds the f32 scale to T before the multiply,
+// kernel/mul.metal:80-81, so nothing is lost), f32 when T = float; laid out in ROW QUADS
+// [ceil(out/4)][in/group][4]: the four rows a wavefront dequantises together find their scales
+// for one group in 8 (bf16) or 16 (f32) contiguous bytes -- one load instead of four.
 //
 // Work split: one wavefront owns R consecutive rows at a time and walks K in "chunks" of
 // 64 lanes x 16 B (one fully coalesced 1 KiB global_load_dwordx4 per row and chunk).  The
@@ -30,7 +32,7 @@ namespace mc {
 namespace gemv {
 
 enum { WF_T = 0, WF_I8 = 1, WF_I4 = 2 };
-enum { Q_EXACT = 0, Q_FAST = 1 };
+enum { Q_EXACT = 0, Q_FAST = 1, Q_DBG_STREAM = 2, Q_DBG_NOLOAD = 3, Q_DBG_TL = 4 }; // 2..4: tuning aids
 enum { PRO_NONE = 0, PRO_RMSNORM = 1 };
 enum { EPI_STORE = 0, EPI_RESID = 1, EPI_SILU_MUL = 2, EPI_GELU_MUL = 3 };
 
@@ -133,6 +135,20 @@ template <int KPL> struct xregs<F32, KPL> {
 // ------------------------------------------------------------------------------------------
 constexpr uint32_t ONE = 0x3F800000u;
 
+// byte k of a dword -> float with ONE full-rate VOP1 instruction.  Written as asm because hipcc
+// turns (float)((v >> 8k) & 0xFF) on a nibble-masked value into v_bfe_u32 + v_cvt_f32_ubyte0.
+template <int K>
+__device__ __forceinline__ float
+ubyte_f32(uint32_t v)
+{
+    float d;
+    if (K == 0) asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(d) : "v"(v));
+    if (K == 1) asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(d) : "v"(v));
+    if (K == 2) asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(d) : "v"(v));
+    if (K == 3) asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(d) : "v"(v));
+    return d;
+}
+
 // (v & mask) | 1.0f in ONE instruction (v_and_or_b32 with the mask in an SGPR and the inline
 // constant 1.0): hipcc otherwise emits a v_and_b32 + v_or_b32 pair per nibble.
 __device__ __forceinline__ float
@@ -143,36 +159,41 @@ nib1(uint32_t v, uint32_t mask)
     return __uint_as_float(d);
 }
 
-// I4, T = bfloat, exact.  A nibble masked in place at mantissa bits [4j, 4j+3] under exponent 0
-// is the float M = 1 + n*2^(4j-23); with S_j = s*2^(23-4j) and C_j = -(2^(23-4j) + 8)*s the single
-// fused multiply-add fma(M, S_j, C_j) = (n - 8)*s = q*s with NO rounding (the exact product has
-// <= 12 significant bits, and C_j is representable for j in {2,3,4} because (2^(23-4j)+8)*m <
-// 2^24 for an 8-bit mantissa m).  v_cvt_pk_bf16_f32 then rounds two products to bf16 (RNE) --
-// bit for bit the reference's bfloat(bfloat(q) * bfloat(s)) -- and v_dot2c_f32_bf16 accumulates.
+// I4, T = bfloat, exact.  Per weight: v_cvt_f32_ubyteN (nibble -> float, full rate), one fma that
+// yields q*s with NO rounding, half a v_cvt_pk_bf16_f32 that rounds it to bf16 (RNE) -- bit for
+// bit the reference's bfloat(bfloat(q) * bfloat(s)) -- and half a v_dot2c_f32_bf16.  Measured
+// issue cost on gfx950 (tools/ubench): v_fma / v_cvt_f32_ubyte 2 cycles per wave-instruction,
+// v_and_or_b32 / v_cvt_pk_bf16_f32 / v_dot2c_f32_bf16 4 cycles.
 template <int QM>
 __device__ __forceinline__ void
 mac(float& acc, const uint4& w, float s, const xregs<BF, 32>& x, float xsum,
     fmt<WF_I4, BF>* = nullptr)
 {
     const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
-    if (QM == Q_EXACT) {
-        const float S2 = s * 32768.0f, S3 = s * 2048.0f, S4 = s * 128.0f;
-        const float C2 = -32776.0f * s, C3 = -2056.0f * s, C4 = -136.0f * s;
+    if (QM == Q_DBG_STREAM) {
+        acc += asf((w.x ^ w.y ^ w.z ^ w.w) & 0x3FFFFFFFu) * s;
+        return;
+    }
+    if (QM == Q_EXACT || QM == Q_DBG_NOLOAD || QM == Q_DBG_TL) {
+        // n = q + 8 in [0,15] converted with the full-rate v_cvt_f32_ubyteN; fma(n, s, -8 s) =
+        // q*s EXACTLY (n*s has <= 12 significant bits, -8 s is a power-of-two multiple of s).
+        const float c8 = -8.0f * s;
 #pragma unroll
         for (int d = 0; d < 4; d++) {
-            const uint32_t v = ws[d], lo = v << 8, hi = v >> 12;
-            const float p0 = __builtin_fmaf(nib1(lo, 0xF00u), S2, C2);
-            const float p1 = __builtin_fmaf(nib1(lo, 0xF000u), S3, C3);
-            const float p2 = __builtin_fmaf(nib1(v, 0xF00u), S2, C2);
-            const float p3 = __builtin_fmaf(nib1(v, 0xF000u), S3, C3);
-            const float p4 = __builtin_fmaf(nib1(v, 0xF0000u), S4, C4);
-            const float p5 = __builtin_fmaf(nib1(hi, 0xF00u), S2, C2);
-            const float p6 = __builtin_fmaf(nib1(hi, 0xF000u), S3, C3);
-            const float p7 = __builtin_fmaf(nib1(hi, 0xF0000u), S4, C4);
-            acc = dot2(pack_bf16x2(p0, p4), x.v[4 * d + 0], acc);
-            acc = dot2(pack_bf16x2(p1, p5), x.v[4 * d + 1], acc);
-            acc = dot2(pack_bf16x2(p2, p6), x.v[4 * d + 2], acc);
-            acc = dot2(pack_bf16x2(p3, p7), x.v[4 * d + 3], acc);
+            const uint32_t v = ws[d], lo = v & 0x0F0F0F0Fu, hi = (v >> 4) & 0x0F0F0F0Fu;
+            // nibble p holds weight {0,2,4,6,1,3,5,7}[p]; byte b of lo/hi = nibble 2b / 2b+1
+            const float p0 = __builtin_fmaf(ubyte_f32<0>(lo), s, c8);         // nibble 0 = weight 0
+            const float p1 = __builtin_fmaf(ubyte_f32<2>(lo), s, c8); // nibble 4 = weight 1
+            const float p2 = __builtin_fmaf(ubyte_f32<0>(hi), s, c8);         // nibble 1 = weight 2
+            const float p3 = __builtin_fmaf(ubyte_f32<2>(hi), s, c8); // nibble 5 = weight 3
+            const float p4 = __builtin_fmaf(ubyte_f32<1>(lo), s, c8);  // nibble 2 = weight 4
+            const float p5 = __builtin_fmaf(ubyte_f32<3>(lo), s, c8);           // nibble 6 = weight 5
+            const float p6 = __builtin_fmaf(ubyte_f32<1>(hi), s, c8);  // nibble 3 = weight 6
+            const float p7 = __builtin_fmaf(ubyte_f32<3>(hi), s, c8);           // nibble 7 = weight 7
+            acc = dot2(pack_bf16x2(p0, p1), x.v[4 * d + 0], acc);
+            acc = dot2(pack_bf16x2(p2, p3), x.v[4 * d + 1], acc);
+            acc = dot2(pack_bf16x2(p4, p5), x.v[4 * d + 2], acc);
+            acc = dot2(pack_bf16x2(p6, p7), x.v[4 * d + 3], acc);
         }
     } else {
         // FAST: (nibble | 0x4300) is the bf16 value 128 + n; sum (136 + q) x, fix the offset with
@@ -190,37 +211,34 @@ mac(float& acc, const uint4& w, float s, const xregs<BF, 32>& x, float xsum,
     }
 }
 
-// I4, T = float.  q*2^(4j-23) = M - K_j exactly, then ONE rounding in (q*2^(4j-23)) * (s*2^(23-4j))
-// = fl(float(q) * s), the reference's float(q) * float(s) (kernel/mul.metal:80-81, Output = float).
+// I4, T = float: Wd = fl(float(q) * s), the reference's float(q) * float(s)
+// (kernel/mul.metal:80-81 with Output = float).
 template <int QM>
 __device__ __forceinline__ void
 mac(float& acc, const uint4& w, float s, const xregs<F32, 32>& x, float xsum,
     fmt<WF_I4, F32>* = nullptr)
 {
     const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
-    const float S0 = s * 8388608.0f, S1 = s * 524288.0f, S2 = s * 32768.0f, S3 = s * 2048.0f,
-                S4 = s * 128.0f;
-    const float K0 = asf(ONE | 0x8u), K1 = asf(ONE | 0x80u), K2 = asf(ONE | 0x800u),
-                K3 = asf(ONE | 0x8000u), K4 = asf(ONE | 0x80000u);
+    const float c8 = -8.0f * s;
 #pragma unroll
     for (int d = 0; d < 4; d++) {
-        const uint32_t v = ws[d], hi = v >> 12;
-        const float p0 = (nib1(v, 0xFu) - K0) * S0;
-        const float p1 = (nib1(v, 0xF0u) - K1) * S1;
-        const float p2 = (nib1(v, 0xF00u) - K2) * S2;
-        const float p3 = (nib1(v, 0xF000u) - K3) * S3;
-        const float p4 = (nib1(v, 0xF0000u) - K4) * S4;
-        const float p5 = (nib1(hi, 0xF00u) - K2) * S2;
-        const float p6 = (nib1(hi, 0xF000u) - K3) * S3;
-        const float p7 = (nib1(hi, 0xF0000u) - K4) * S4;
-        // nibble p holds weight {0,2,4,6,1,3,5,7}[p]
+        const uint32_t v = ws[d], lo = v & 0x0F0F0F0Fu, hi = (v >> 4) & 0x0F0F0F0Fu;
+        // fma(n, s, -8 s) rounds the exact (n - 8) * s once = fl(float(q) * s)
+        const float p0 = __builtin_fmaf(ubyte_f32<0>(lo), s, c8);
+        const float p1 = __builtin_fmaf(ubyte_f32<2>(lo), s, c8);
+        const float p2 = __builtin_fmaf(ubyte_f32<0>(hi), s, c8);
+        const float p3 = __builtin_fmaf(ubyte_f32<2>(hi), s, c8);
+        const float p4 = __builtin_fmaf(ubyte_f32<1>(lo), s, c8);
+        const float p5 = __builtin_fmaf(ubyte_f32<3>(lo), s, c8);
+        const float p6 = __builtin_fmaf(ubyte_f32<1>(hi), s, c8);
+        const float p7 = __builtin_fmaf(ubyte_f32<3>(hi), s, c8);
         acc = __builtin_fmaf(p0, x.v[8 * d + 0], acc);
-        acc = __builtin_fmaf(p4, x.v[8 * d + 1], acc);
-        acc = __builtin_fmaf(p1, x.v[8 * d + 2], acc);
-        acc = __builtin_fmaf(p5, x.v[8 * d + 3], acc);
-        acc = __builtin_fmaf(p2, x.v[8 * d + 4], acc);
-        acc = __builtin_fmaf(p6, x.v[8 * d + 5], acc);
-        acc = __builtin_fmaf(p3, x.v[8 * d + 6], acc);
+        acc = __builtin_fmaf(p1, x.v[8 * d + 1], acc);
+        acc = __builtin_fmaf(p2, x.v[8 * d + 2], acc);
+        acc = __builtin_fmaf(p3, x.v[8 * d + 3], acc);
+        acc = __builtin_fmaf(p4, x.v[8 * d + 4], acc);
+        acc = __builtin_fmaf(p5, x.v[8 * d + 5], acc);
+        acc = __builtin_fmaf(p6, x.v[8 * d + 6], acc);
         acc = __builtin_fmaf(p7, x.v[8 * d + 7], acc);
     }
 }
@@ -302,9 +320,12 @@ gelu_f32(float x)
     return 0.5f * x * (1.0f + (float)tanh((double)inner));
 }
 
+// A tile as it comes out of memory: the scale stays RAW (bf16 bits or f32 bits) until the tile is
+// consumed -- converting it in the load path would make the compiler wait for that load (and, as
+// vector memory returns in order, for every older one) right after issuing it.
 template <int R> struct tile {
     uint4 w[R];
-    float s[R];
+    uint32_t s[R]; // bf16 scales: two per dword in s[0..R/2); f32 scales: one per dword
 };
 
 // ------------------------------------------------------------------------------------------
@@ -319,88 +340,213 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
     using F = fmt<WF, T>;
     using S = typename T::S;
     constexpr int KPL = F::KPL;
-    constexpr uint32_t CHUNK = 64 * KPL;
-    static_assert(EPI < EPI_SILU_MUL || (R % 2) == 0, "paired epilogues need an even R");
+    constexpr uint32_t CHUNK = 64 * KPL;         // weights per wavefront load
+    constexpr uint32_t CHUNK_BYTES = 64 * 16;    // = 1 KiB of packed weights
+    static_assert(R == 4, "tiles are four rows deep (scale quads, paired epilogues)");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* xs = smem;
-    float* red = reinterpret_cast<float*>(smem + (((size_t)in * T::bytes + 15) & ~(size_t)15));
-
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t nwaves = blockDim.x >> 6;
     const uint32_t nchunks = (in + CHUNK - 1) / CHUNK;
+    // LDS: the activation row, zero-padded to a whole number of chunks, then 16 floats of scratch
+    char* xs = smem;
+    float* red = reinterpret_cast<float*>(smem + (size_t)nchunks * CHUNK * T::bytes);
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    // Everything that is the same for the 64 lanes of a wavefront is kept in SGPRs: the wave index
+    // is made scalar here, so row / chunk cursors, row base addresses and tile liveness are SALU
+    // work and the per-lane address of a load is ONE v_min (the clamp) -- the first version spent
+    // ~240 VALU instructions per tile on 64-bit per-lane addressing, selects and masks.
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t nwaves = blockDim.x >> 6;
     const uint32_t ngroups = group ? in / group : 1;
-    const uint32_t geff = group ? group : in;
+    const uint32_t glog = group ? 31u - __builtin_clz(group) : 31u; // group is a power of two
     const uint32_t NG = (out_rows + R - 1) / R;
     const uint32_t stride = gridDim.x * nwaves;
     const size_t rowb = F::row_bytes(in);
+    const uint32_t rowb32 = (uint32_t)rowb;
     const char* wbase = static_cast<const char*>(wp);
+    const uint32_t lane16 = lane * 16;
 
-    tile<R> A, B;
+    unsigned long long tl0 = 0, tl1 = 0;
+    if (QM == Q_DBG_TL) tl0 = __builtin_amdgcn_s_memrealtime();
+    tile<R> t0, t1, t2; // register ring: two tiles in flight while one is dequantised
 
-    auto load = [&](tile<R>& t, uint32_t rg, uint32_t c) {
-        const uint32_t kbase = c * CHUNK + lane * KPL;
-        const bool active = kbase < in;
+    // Loads are UNCONDITIONAL straight-line code: hipcc only emits counted s_waitcnt vmcnt(N) --
+    // leaving the younger tiles in flight -- when no load sits behind a branch; one predicated
+    // load turns every wait into vmcnt(0) and the ring degenerates to one tile at a time.
+    // A lane past the end of a row (last chunk of a row that is not a multiple of the chunk) is
+    // clamped onto the row's last packet; its products meet the zero padding of the activation
+    // row.  A dead tile (ring slot past the wave's last tile) makes every lane read the same 16
+    // bytes at the buffer base, which the address coalescer folds into one request.
+    auto load = [&](tile<R>& t, uint32_t rg, uint32_t c, bool live) {
+        const uint32_t cbyte = c * CHUNK_BYTES;
+        const uint32_t remain = live ? rowb32 - cbyte : 16u; // bytes of the row from this chunk on
+        const uint32_t off = min(lane16, remain - 16u);      // v_min_u32 with a scalar operand
+        const uint32_t rg_l = live ? rg : 0u;
+        const char* base = wbase + (live ? (size_t)cbyte : (size_t)0);
 #pragma unroll
         for (int r = 0; r < R; r++) {
-            uint32_t row = rg * R + r;
+            uint32_t row = rg_l * R + r;
             row = row < out_rows ? row : out_rows - 1;
-            if (active) {
-                t.w[r] = *reinterpret_cast<const uint4*>(wbase + row * rowb +
-                                                         (size_t)kbase * F::BITS / 8);
-                if (WF != WF_T) {
-                    const size_t si = (size_t)row * ngroups + kbase / geff;
-                    t.s[r] = T::bytes == 2 ? bf2f(static_cast<const bf16_t*>(sp)[si])
-                                           : static_cast<const float*>(sp)[si];
-                } else {
-                    t.s[r] = 1.0f;
-                }
+            if (QM == Q_DBG_NOLOAD) {
+                t.w[r] = make_uint4(lane * 0x01010101u + off, rg, c * 0x11111111u, r);
+                t.s[r] = T::bytes == 2 ? 0x3F803F80u : 0x3F800000u;
             } else {
-                t.w[r] = make_uint4(0, 0, 0, 0);
-                t.s[r] = 0.0f;
+                t.w[r] = *reinterpret_cast<const uint4*>(base + (size_t)row * rowb + off);
+            }
+        }
+        if (WF != WF_T && QM != Q_DBG_NOLOAD) {
+            // weight index of the lane's packet -> group; scales are stored in row quads
+            const uint32_t k = (cbyte + off) * (8 / F::BITS == 0 ? 1 : 8 / F::BITS);
+            const uint32_t g = live ? (group ? k >> glog : 0u) : 0u;
+            const size_t si = ((size_t)rg_l * ngroups) * 4 + (size_t)g * 4;
+            if (T::bytes == 2) {
+                const uint2 q = *reinterpret_cast<const uint2*>(static_cast<const bf16_t*>(sp) + si);
+                t.s[0] = q.x;
+                t.s[1] = q.y;
+            } else {
+                const uint4 q = *reinterpret_cast<const uint4*>(static_cast<const float*>(sp) + si);
+                t.s[0] = q.x; t.s[1] = q.y; t.s[2] = q.z; t.s[3] = q.w;
             }
         }
     };
 
-    // first tile's weights are requested before the activation row is staged, so the HBM latency
-    // of the first packets overlaps the prologue
-    uint32_t rg = blockIdx.x * nwaves + wave, c = 0;
-    bool have = rg < NG;
-    if (have) load(A, rg, 0);
+    // Tile cursor (scalar): the wave walks (row group, chunk) pairs; row groups are dealt
+    // round-robin over all waves of the grid.  `ld` runs three tiles ahead of `cp`.
+    struct cursor {
+        uint32_t rg, c;
+    };
+    auto advance = [&](cursor& k) {
+        if (++k.c == nchunks) {
+            k.c = 0;
+            k.rg += stride;
+        }
+    };
+    const uint32_t first_rg = blockIdx.x * nwaves + wave;
+    cursor ld{first_rg, 0};
+    cursor cp = ld;
+    const uint32_t ntiles = first_rg < NG ? ((NG - first_rg + stride - 1) / stride) * nchunks : 0;
 
-    // ---- prologue: stage the activation row in LDS
+    // ---- prologue: stage the activation row in LDS (16 bytes per lane per access).
+    // Vector memory retires in issue order, so the L2-resident packets of the row (and of the
+    // norm weight) are REQUESTED FIRST, then the first weight tile (HBM latency) and only then is
+    // the row consumed: the counted wait for the row does not sit behind the weight stream.
+    // PRO_RMSNORM: kernel/rmsnorm.metal:52-95, y = T((mu + w) * x * rsqrt(mean(x^2) + eps)).
     {
-        const S* x = static_cast<const S*>(xp);
-        S* xd = reinterpret_cast<S*>(xs);
-        if (PRO == PRO_RMSNORM) {
-            // kernel/rmsnorm.metal:52-95 : y = T((mu + w) * x * rsqrt(mean(x^2) + eps))
-            const S* nw = static_cast<const S*>(normp);
-            float ss = 0.0f;
-            for (uint32_t j = tid; j < in; j += blockDim.x) {
-                const float v = T::ld(x[j]);
-                ss += v * v;
+        constexpr uint32_t EPV = 16 / T::bytes; // elements per 16-byte packet
+        constexpr int MAXP = PRO == PRO_RMSNORM ? 4 : 8;
+        const uint32_t npk = in / EPV;
+        const uint32_t npk_pad = nchunks * CHUNK / EPV;
+        const uint4* xg = static_cast<const uint4*>(xp);
+        const uint4* ng = static_cast<const uint4*>(normp);
+        uint4* xl = reinterpret_cast<uint4*>(xs);
+        const uint32_t bd = blockDim.x;
+        const bool fits = npk <= (uint32_t)MAXP * bd;
+        uint4 xr[MAXP], nr[MAXP];
+        if (fits) {
+#pragma unroll
+            for (int i = 0; i < MAXP; i++) {
+                const uint32_t p = tid + i * bd;
+                const uint32_t pc = p < npk ? p : npk - 1;
+                xr[i] = xg[pc];
+                if (PRO == PRO_RMSNORM) nr[i] = ng[pc];
             }
-            const float tot = block_sum(ss, red);
-            const float inv = 1.0f / sqrtf(tot / (float)in + eps);
-            for (uint32_t j = tid; j < in; j += blockDim.x) {
-                const float weight = mu + T::ld(nw[j]);
-                xd[j] = T::st(weight * T::ld(x[j]) * inv);
+        }
+        load(t0, ld.rg, ld.c, 0 < ntiles);
+        advance(ld);
+        if (fits) {
+#pragma unroll
+            for (int i = 0; i < MAXP; i++)
+                if (tid + i * bd >= npk) xr[i] = make_uint4(0, 0, 0, 0); // absent packets count as zero
+        }
+        // zero padding behind the row
+        for (uint32_t p = npk + tid; p < npk_pad; p += bd) xl[p] = make_uint4(0, 0, 0, 0);
+
+        auto sumsq = [&](const uint4& v) {
+            const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
+            float ss = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                if (T::bytes == 2) {
+                    const float a = asf(vv[i] << 16), b = asf(vv[i] & 0xFFFF0000u);
+                    ss += a * a;
+                    ss += b * b;
+                } else {
+                    const float a = asf(vv[i]);
+                    ss += a * a;
+                }
+            }
+            return ss;
+        };
+        auto normalise = [&](const uint4& v, const uint4& wv, float inv) {
+            const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
+            const uint32_t ww[4] = {wv.x, wv.y, wv.z, wv.w};
+            uint32_t o[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                if (T::bytes == 2) {
+                    const float a = (mu + asf(ww[i] << 16)) * asf(vv[i] << 16) * inv;
+                    const float b = (mu + asf(ww[i] & 0xFFFF0000u)) * asf(vv[i] & 0xFFFF0000u) * inv;
+                    o[i] = pack_bf16x2(a, b);
+                } else {
+                    o[i] = __float_as_uint((mu + asf(ww[i])) * asf(vv[i]) * inv);
+                }
+            }
+            return make_uint4(o[0], o[1], o[2], o[3]);
+        };
+
+        if (fits) {
+            if (PRO == PRO_RMSNORM) {
+                float ss = 0.0f;
+#pragma unroll
+                for (int i = 0; i < MAXP; i++) ss += sumsq(xr[i]);
+                const float tot = block_sum(ss, red);
+                const float inv = 1.0f / sqrtf(tot / (float)in + eps);
+#pragma unroll
+                for (int i = 0; i < MAXP; i++) {
+                    const uint32_t p = tid + i * bd;
+                    if (p < npk) xl[p] = normalise(xr[i], nr[i], inv);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < MAXP; i++) {
+                    const uint32_t p = tid + i * bd;
+                    if (p < npk) xl[p] = xr[i];
+                }
             }
         } else {
-            for (uint32_t j = tid; j < in; j += blockDim.x) xd[j] = x[j];
+            // rows too long for the register path (not reached by the shapes of SURVEY.md s.8 at
+            // 256+ threads): same arithmetic, row parked raw in LDS between the two passes
+            if (PRO == PRO_RMSNORM) {
+                float ss = 0.0f;
+                for (uint32_t p = tid; p < npk; p += bd) {
+                    const uint4 v = xg[p];
+                    xl[p] = v;
+                    ss += sumsq(v);
+                }
+                const float tot = block_sum(ss, red);
+                const float inv = 1.0f / sqrtf(tot / (float)in + eps);
+                for (uint32_t p = tid; p < npk; p += bd) xl[p] = normalise(xl[p], ng[p], inv);
+            } else {
+                for (uint32_t p = tid; p < npk; p += bd) xl[p] = xg[p];
+            }
         }
     }
     __syncthreads();
+    if (QM == Q_DBG_TL) tl1 = __builtin_amdgcn_s_memrealtime();
+    load(t1, ld.rg, ld.c, 1 < ntiles);
+    advance(ld);
+    load(t2, ld.rg, ld.c, 2 < ntiles);
+    advance(ld);
 
     float acc[R];
 #pragma unroll
     for (int r = 0; r < R; r++) acc[r] = 0.0f;
+    const uint32_t lane_x = lane * KPL * T::bytes; // byte offset of the lane's x slice in a chunk
 
     auto compute = [&](const tile<R>& t, uint32_t crg, uint32_t cc) {
-        const uint32_t kbase = cc * CHUNK + lane * KPL;
-        if (kbase < in) {
+        {
             xregs<T, KPL> x;
-            x.load(xs, kbase);
+            x.load(xs + (size_t)cc * CHUNK * T::bytes + lane_x, 0);
             float xsum = 0.0f;
             if (WF == WF_I4 && QM == Q_FAST && T::bytes == 2) {
 #pragma unroll
@@ -408,11 +554,15 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
                     xsum = dot2(reinterpret_cast<const uint32_t*>(x.v)[i], 0x3F803F80u, xsum);
             }
 #pragma unroll
-            for (int r = 0; r < R; r++)
-                mac<QM>(acc[r], t.w[r], t.s[r], x, xsum, static_cast<F*>(nullptr));
+            for (int r = 0; r < R; r++) {
+                const float sc = WF == WF_T ? 1.0f
+                                 : (T::bytes == 2 ? ((r & 1) ? asf(t.s[r >> 1] & 0xFFFF0000u) : asf(t.s[r >> 1] << 16))
+                                                  : asf(t.s[r]));
+                mac<QM>(acc[r], t.w[r], sc, x, xsum, static_cast<F*>(nullptr));
+            }
         }
         if (cc + 1 == nchunks) {
-            // ---- epilogue for row group crg
+            // ---- epilogue for row group crg (wave-uniform branch)
             float tot[R];
 #pragma unroll
             for (int r = 0; r < R; r++) {
@@ -421,45 +571,45 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
             }
             S* y = static_cast<S*>(yp);
             if (EPI == EPI_STORE || EPI == EPI_RESID) {
-#pragma unroll
-                for (int r = 0; r < R; r++) {
-                    const uint32_t row = crg * R + r;
-                    if (lane == r && row < out_rows) {
-                        float v = T::rt(tot[r]);
-                        if (EPI == EPI_RESID)
-                            v = T::ld(static_cast<const S*>(resp)[row]) + v; // add in T
-                        y[row] = T::st(v);
-                    }
+                // lane r finishes row r
+                const float mine = lane == 0 ? tot[0] : (lane == 1 ? tot[1] : (lane == 2 ? tot[2] : tot[3]));
+                const uint32_t row = crg * R + lane;
+                if (lane < (uint32_t)R && row < out_rows) {
+                    float v = T::rt(mine);
+                    if (EPI == EPI_RESID) v = T::ld(static_cast<const S*>(resp)[row]) + v; // add in T
+                    y[row] = T::st(v);
                 }
             } else {
-                // rows (2j, 2j+1) = (w1 row j, w3 row j): out[j] = T(act(T(w1 x)) * T(w3 x))
-#pragma unroll
-                for (int r = 0; r < R; r += 2) {
-                    const uint32_t row = crg * R + r;
-                    if (lane == r && row + 1 < out_rows) {
-                        const float a = T::rt(tot[r]), b = T::rt(tot[r + 1]);
-                        const float g = EPI == EPI_SILU_MUL ? silu_T<T>(a) : T::rt(gelu_f32(a));
-                        y[row / 2] = T::st(g * b);
-                    }
+                // rows (2j, 2j+1) = (w1 row j, w3 row j): out[j] = T(act(T(w1 x)) * T(w3 x));
+                // lane 0 finishes pair 0, lane 1 pair 1 (one activation evaluation per wave)
+                const float a = T::rt(lane == 0 ? tot[0] : tot[2]);
+                const float b = T::rt(lane == 0 ? tot[1] : tot[3]);
+                const uint32_t row = crg * R + 2 * lane;
+                if (lane < 2 && row + 1 < out_rows) {
+                    const float g = EPI == EPI_SILU_MUL ? silu_T<T>(a) : T::rt(gelu_f32(a));
+                    y[row / 2] = T::st(g * b);
                 }
             }
         }
     };
 
-    while (have) {
-        uint32_t rg2 = rg, c2 = c + 1;
-        if (c2 == nchunks) { c2 = 0; rg2 += stride; }
-        bool have2 = rg2 < NG;
-        if (have2) load(B, rg2, c2);
-        compute(A, rg, c);
-        rg = rg2; c = c2; have = have2;
-        if (!have) break;
-        rg2 = rg; c2 = c + 1;
-        if (c2 == nchunks) { c2 = 0; rg2 += stride; }
-        have2 = rg2 < NG;
-        if (have2) load(A, rg2, c2);
-        compute(B, rg, c);
-        rg = rg2; c = c2; have = have2;
+    // One loop, no drain phase: every step consumes the oldest ring slot (if that tile exists) and
+    // refills it with the tile three ahead (live or dead), so the loads stay unconditional and the
+    // compiler's s_waitcnt vmcnt(N) always leaves the two younger tiles in flight.
+    for (uint32_t i = 0; i < ntiles; i += 3) {
+        compute(t0, cp.rg, cp.c); advance(cp);
+        load(t0, ld.rg, ld.c, i + 3 < ntiles); advance(ld);
+        if (i + 1 < ntiles) { compute(t1, cp.rg, cp.c); advance(cp); }
+        load(t1, ld.rg, ld.c, i + 4 < ntiles); advance(ld);
+        if (i + 2 < ntiles) { compute(t2, cp.rg, cp.c); advance(cp); }
+        load(t2, ld.rg, ld.c, i + 5 < ntiles); advance(ld);
+    }
+    if (QM == Q_DBG_TL && lane == 0) {
+        // (epilogues of this variant never read `resp`: it carries the stamp buffer)
+        unsigned long long* tl = const_cast<unsigned long long*>(static_cast<const unsigned long long*>(resp));
+        const size_t o = ((size_t)blockIdx.x * nwaves + wave) * 4;
+        tl[o] = tl0; tl[o + 1] = tl1; tl[o + 2] = __builtin_amdgcn_s_memrealtime();
+        unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); tl[o + 3] = xcc;
     }
 }
 

@@ -29,3 +29,11 @@ MC_GEMV_SET(mc_gemv_i8_bfloat, WF_I8, BF, Q_EXACT)
 MC_GEMV_SET(mc_gemv_i8_float, WF_I8, F32, Q_EXACT)
 MC_GEMV_SET(mc_gemv_w_bfloat, WF_T, BF, Q_EXACT)
 MC_GEMV_SET(mc_gemv_w_float, WF_T, F32, Q_EXACT)
+
+// tuning ablations (not used by the product path): stream-only and compute-only variants
+MC_GEMV(mc_gemv_i4_bfloat_dbgstream_p1_e2, WF_I4, BF, Q_DBG_STREAM, 1, 2)
+MC_GEMV(mc_gemv_i4_bfloat_dbgnoload_p1_e2, WF_I4, BF, Q_DBG_NOLOAD, 1, 2)
+MC_GEMV(mc_gemv_i4_bfloat_dbgstream_p0_e0, WF_I4, BF, Q_DBG_STREAM, 0, 0)
+MC_GEMV(mc_gemv_i4_bfloat_dbgnoload_p0_e0, WF_I4, BF, Q_DBG_NOLOAD, 0, 0)
+MC_GEMV(mc_gemv_i4_bfloat_dbgtl_p1_e2, WF_I4, BF, Q_DBG_TL, 1, 2)
+MC_GEMV(mc_gemv_i4_bfloat_dbgtl_p0_e0, WF_I4, BF, Q_DBG_TL, 0, 0)

@@ -50,7 +50,7 @@ mc_synth_fill_q(uint32_t* w, uint64_t seed, uint32_t m0, uint32_t map, uint32_t 
     }
 }
 
-// scales [rows][ngroups], stored bf16 (sbytes 2) or f32 (sbytes 4)
+// scales in row quads [ceil(rows/4)][ngroups][4], stored bf16 (sbytes 2) or f32 (sbytes 4)
 extern "C" __global__ void
 mc_synth_fill_scales(void* s, uint64_t seed, uint32_t m0, uint32_t map, uint32_t n0, uint32_t n1,
                      uint32_t rows, uint32_t ngroups, uint32_t in, int32_t bits, int32_t sbytes)
@@ -62,8 +62,10 @@ mc_synth_fill_scales(void* s, uint64_t seed, uint32_t m0, uint32_t map, uint32_t
         uint32_t m, sr;
         map_row(map, m0, n0, n1, r, m, sr);
         const float v = mcsynth::scale(seed, m, sr, g, (int32_t)in, bits);
-        if (sbytes == 2) static_cast<bf16_t*>(s)[i] = f2bf(v);
-        else static_cast<float*>(s)[i] = v;
+        // row-quad layout of gemv.h: [ceil(rows/4)][ngroups][4]
+        const size_t o = ((size_t)(r / 4) * ngroups + g) * 4 + (r & 3);
+        if (sbytes == 2) static_cast<bf16_t*>(s)[o] = f2bf(v);
+        else static_cast<float*>(s)[o] = v;
     }
 }
 

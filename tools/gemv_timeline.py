@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Per-wave timeline of one fused GEMV launch (tuning aid): start / prologue done / end stamps
+from s_memrealtime (100 MHz)."""
+import json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import metalchat_amd as mc
+
+M = dict(dim=4096, n_heads=32, n_kv_heads=8, head_dim=128, ffn_dim=14336, n_layers=4, vocab=1024,
+         rope_theta=500000.0, norm_eps=1e-5)
+acc = mc.HardwareAccelerator()
+dec = mc.Decoder(acc, dtype=mc.BF16, max_seq_len=64, attn_scale=0.088, weight_format=mc.WFMT_I4,
+                 group_size=128, **M)
+dec.init_synthetic(1)
+cus = acc.compute_units()
+x = acc.to_device((np.random.default_rng(0).normal(0, 1, 14336).astype(np.float32).view(np.uint32) >> 16).astype(np.uint16))
+nw = acc.to_device(np.full(14336, 0x3F80, np.uint16))
+y = acc.alloc(2 * 28672)
+for which, kname in (("w13", "mc_gemv_i4_bfloat_dbgtl_p1_e2"), ("wo", "mc_gemv_i4_bfloat_dbgtl_p0_e0"),
+                     ("w2", "mc_gemv_i4_bfloat_dbgtl_p0_e0")):
+    for block, wgs_per_cu in ((256, 2), (256, 4)):
+        k = acc.load(kname)
+        waves = block // 64
+        for layer in (1, 2):
+            wptr, sptr, rows, inf, ng = dec.weight_ptrs(layer, which)
+            ngp = (rows + 3) // 4
+            wgs = min((ngp + waves - 1) // waves, cus * wgs_per_cu)
+            tl = acc.alloc(wgs * waves * 32)
+            lds = (inf + 2047) // 2048 * 2048 * 2 + 64
+            t = mc.KernelTask(k, (wgs * block, 1, 1), (block, 1, 1),
+                              [acc.wrap(wptr, 1 << 40), acc.wrap(sptr, 1 << 40), x, y, tl, nw,
+                               np.uint32(rows), np.uint32(inf), np.uint32(128), np.float32(1e-5), np.float32(0)],
+                              lds_bytes=lds)
+            acc.timer_begin(); t(); ms = acc.timer_end_ms()
+        st = tl.download(np.uint64, wgs * waves * 4).reshape(-1, 4).astype(np.int64)
+        t0 = st[:, 0].min()
+        start, pro, end = (st[:, 0] - t0) / 100.0, (st[:, 1] - st[:, 0]) / 100.0, (st[:, 2] - t0) / 100.0
+        body = (st[:, 2] - st[:, 1]) / 100.0
+        q = lambda a: [round(float(np.percentile(a, p)), 2) for p in (0, 50, 90, 100)]
+        print(json.dumps(dict(which=which, block=block, wgs=wgs, event_us=round(ms * 1e3, 2),
+                              start_us=q(start), prologue_us=q(pro), body_us=q(body), end_us=q(end),
+                              xcds=sorted(set(st[:, 3].tolist())))), flush=True)
