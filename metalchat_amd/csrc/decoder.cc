@@ -7,8 +7,8 @@
 //   nn::attention::operator()     include/metalchat/nn/attention.h:161-206
 //   nn::sink_cache / nn::rope     include/metalchat/nn/cache.h:96-232, nn/embedding.h:107-200
 //   transformer<Layer>::transform include/metalchat/transformer.h:357-364
-// Instead of ~1000 one-op launches and as many allocations per token it issues 8 launches per
-// layer on one in-order stream over a pre-allocated arena, keeps the token / position state in
+// Instead of ~1000 one-op launches and as many allocations per token it issues 6 launches per
+// layer (llama3) on one in-order stream over a pre-allocated arena, keeps the token / position state in
 // HBM so successive steps chain without a host round trip, and (optionally) replays one captured
 // hipGraph per token.
 #include "backend_impl.h"
@@ -24,7 +24,7 @@ using namespace mcimpl;
 
 namespace {
 
-constexpr int PB = 256; // cache slots per attention workgroup (decode_kernels.hip)
+constexpr int PB = 64; // cache slots per attention-scores workgroup (decode_kernels.hip)
 
 struct step_state_h {
     int32_t token, pos, kv_len, write_slot, ring_base, step_index, rope_row, rolled;
@@ -42,8 +42,20 @@ struct linear_w {
     std::vector<uint8_t> scales_host; // shadow of the quad-interleaved scale buffer (load path only)
 };
 
+// mirrors mc::gemv::qkv_epilogue (kernels/gemv.h)
+struct qkv_epilogue_h {
+    void* q_out;
+    void* kc;
+    void* vt;
+    const float* fcos;
+    const float* fsin;
+    const int32_t* state;
+    uint32_t H, KV, hd, max_seq;
+};
+
 struct layer_w {
     linear_w qkv, wo, w13, w2;
+    void* qkv_epi = nullptr; // device copy of qkv_epilogue_h
     void* attention_norm = nullptr;
     void* ffn_norm = nullptr;
     void* q_norm = nullptr;
@@ -139,7 +151,6 @@ struct mc_decoder {
     void* logits = nullptr;     // T[vocab]
     float* expv = nullptr;      // [H][max_seq]
     float* psum = nullptr;      // [H][nsplit]
-    float* opart = nullptr;     // [nsplit][H][hd]
     void* taps = nullptr;       // T[(n_own+1)*dim]
     step_state_h* state = nullptr;
     int32_t* tokens_dev = nullptr;
@@ -260,16 +271,23 @@ struct mc_decoder {
     // dst_row0 + i*dst_stride
     mc_status
     upload_rows(linear_w& L, int dst_row0, int dst_stride, int rows, const void* weight,
-                const float* scales)
+                const float* scales, int perm_hd = 0)
     {
+        // perm_hd != 0: the source is a q or k projection; natural row head*hd + j + e*hd/2 goes to
+        // packed row head*hd + 2j + e (rotation partners adjacent, gemv.h EPI_QKV_ROPE)
+        auto dest = [&](int r) -> size_t {
+            if (!perm_hd) return (size_t)dst_row0 + (size_t)r * dst_stride;
+            const int head = r / perm_hd, w = r % perm_hd, half = perm_hd / 2;
+            return (size_t)dst_row0 + (size_t)head * perm_hd + 2 * (w % half) + w / half;
+        };
         const int in = L.in;
         const size_t sb = tb == 2 ? 2 : 4;
-        const bool contiguous = dst_stride == 1;
+        const bool contiguous = dst_stride == 1; // destination rows form one block (maybe permuted)
         std::vector<uint8_t> stage(L.row_bytes * (contiguous ? rows : 1));
         // scales of the destination rows, scattered into the quad layout on the host first
         std::vector<uint8_t> squad;
         for (int r = 0; r < rows; r++) {
-            uint8_t* dst = contiguous ? stage.data() + (size_t)r * L.row_bytes : stage.data();
+            uint8_t* dst = contiguous ? stage.data() + (dest(r) - dst_row0) * L.row_bytes : stage.data();
             if (L.fmt == MC_WFMT_T) {
                 memcpy(dst, (const char*)weight + (size_t)r * in * tb, (size_t)in * tb);
             } else if (L.fmt == MC_WFMT_I8) {
@@ -292,7 +310,7 @@ struct mc_decoder {
                 }
             }
             if (!contiguous) {
-                const size_t drow = (size_t)dst_row0 + (size_t)r * dst_stride;
+                const size_t drow = dest(r);
                 MC_HIP(hipMemcpy((char*)L.w + drow * L.row_bytes, stage.data(), L.row_bytes,
                                  hipMemcpyHostToDevice));
             }
@@ -307,7 +325,7 @@ struct mc_decoder {
             if (L.scales_host.size() != L.s_bytes) L.scales_host.assign(L.s_bytes, 0);
             size_t lo = SIZE_MAX, hi = 0;
             for (int r = 0; r < rows; r++) {
-                const size_t drow = (size_t)dst_row0 + (size_t)r * dst_stride;
+                const size_t drow = dest(r);
                 for (int g = 0; g < L.ngroups; g++) {
                     const float sc = scales[(size_t)r * L.ngroups + g];
                     const size_t idx = ((drow / 4) * L.ngroups + g) * 4 + drow % 4;
@@ -382,27 +400,31 @@ struct mc_decoder {
         const void* x = x_in; // current hidden row
         for (int li = 0; li < n_own; li++) {
             layer_w& L = layers[li];
-            // attention_norm + wq|wk|wv            (transformer.h:130, attention.h:170-172)
-            s = gemv(L.qkv, 1, 0, x, qkv, nullptr, L.attention_norm, mu);
-            if (s != MC_OK) return s;
-            // q/k norm, rope, cache write          (attention.h:174-177)
-            s = launch("mc_rope_kv_" + tname, H + 2 * KV, 1, 1, hd / 2, 0,
-                       pack(qkv, q_rot, L.kc, L.vt, rope_cos[L.rope_table], rope_sin[L.rope_table],
-                            L.q_norm, L.k_norm, state, (uint32_t)H, (uint32_t)KV, (uint32_t)hd,
-                            (uint32_t)cfg.max_seq_len, cfg.norm_eps, mu));
-            if (s != MC_OK) return s;
+            if (!gemma) {
+                // attention_norm + wq|wk|wv + rope + cache write in ONE launch
+                // (transformer.h:130, attention.h:170-177)
+                s = gemv(L.qkv, 1, 4, x, qkv, L.qkv_epi, L.attention_norm, mu);
+                if (s != MC_OK) return s;
+            } else {
+                // gemma3 normalises q and k per head before the rotation (attention.h:174-175):
+                // that needs whole heads, so rope + cache write stay a launch of their own
+                s = gemv(L.qkv, 1, 0, x, qkv, nullptr, L.attention_norm, mu);
+                if (s != MC_OK) return s;
+                s = launch("mc_rope_kv_" + tname, H + 2 * KV, 1, 1, hd / 2, 0,
+                           pack(qkv, q_rot, L.kc, L.vt, rope_cos[L.rope_table], rope_sin[L.rope_table],
+                                L.q_norm, L.k_norm, state, (uint32_t)H, (uint32_t)KV, (uint32_t)hd,
+                                (uint32_t)cfg.max_seq_len, cfg.norm_eps, mu));
+                if (s != MC_OK) return s;
+            }
             // scores, softmax denominators         (attention.h:195-200)
             s = launch("mc_attn_scores_" + tname, nsplit, KV, 1, 256, 0,
                        pack(q_rot, L.kc, expv, psum, (void*)nullptr, state, (uint32_t)n_rep,
                             (uint32_t)hd, (uint32_t)cfg.max_seq_len, scale_T, (uint32_t)nsplit));
             if (s != MC_OK) return s;
-            // P.V                                  (attention.h:202)
-            s = launch("mc_attn_pv_" + tname, nsplit, KV, 1, 256, 4 * 16 * hd * 4,
-                       pack(expv, psum, L.vt, opart, state, (uint32_t)n_rep, (uint32_t)hd,
-                            (uint32_t)cfg.max_seq_len, (uint32_t)nsplit, (uint32_t)H));
-            if (s != MC_OK) return s;
-            s = launch("mc_attn_reduce_" + tname, (H * hd + 255) / 256, 1, 1, 256, 0,
-                       pack(opart, attn_out, state, (uint32_t)(H * hd)));
+            // softmax normalisation + P.V          (attention.h:200-203)
+            s = launch("mc_attn_pv_" + tname, hd / 16, KV, 1, 256, 0,
+                       pack(expv, psum, L.vt, attn_out, state, (uint32_t)n_rep, (uint32_t)hd,
+                            (uint32_t)cfg.max_seq_len, (uint32_t)nsplit));
             if (s != MC_OK) return s;
             // wo (+ post norm) + residual          (attention.h:205, transformer.h:132-133)
             if (!gemma) {
@@ -551,7 +573,6 @@ mc_decoder_create(mc_device* dev, mc_library* lib, mc_queue* q, const mc_decoder
     A(d->logits, (size_t)c.vocab * tb);
     A(d->expv, (size_t)H * c.max_seq_len * 4);
     A(d->psum, (size_t)H * d->nsplit * 4);
-    A(d->opart, (size_t)d->nsplit * H * hd * 4);
     A(d->taps, (size_t)(d->n_own + 1) * dim * tb);
     A(d->state, sizeof(step_state_h));
     d->tokens_cap = 1 << 16;
@@ -575,6 +596,12 @@ mc_decoder_create(mc_device* dev, mc_library* lib, mc_queue* q, const mc_decoder
                         ((gi + 1) % c.sliding_stride) != 0 && d->rope_cos[1])
                            ? 1
                            : 0;
+        qkv_epilogue_h e{d->q_rot, L.kc, L.vt, d->rope_cos[L.rope_table], d->rope_sin[L.rope_table],
+                         reinterpret_cast<const int32_t*>(d->state), (uint32_t)H, (uint32_t)KV,
+                         (uint32_t)hd, (uint32_t)c.max_seq_len};
+        A(L.qkv_epi, sizeof e);
+        MC_HIP(hipMemcpyAsync(L.qkv_epi, &e, sizeof e, hipMemcpyHostToDevice, d->stream));
+        MC_HIP(hipStreamSynchronize(d->stream)); // `e` is a stack temporary
     }
 #undef A
     MC_HIP(hipStreamSynchronize(d->stream));
@@ -644,21 +671,21 @@ mc_decoder_load_linear(mc_decoder* d, int32_t layer, const char* name, int32_t f
     layer_w* L;
     s = find_layer(d, layer, &L);
     if (s != MC_OK) return s;
-    struct slot { linear_w* lin; int total, row0, stride, rows, in; };
+    struct slot { linear_w* lin; int total, row0, stride, rows, in, perm; };
     slot sl{};
-    if (n == "wq") sl = {&L->qkv, (H + 2 * KV) * hd, 0, 1, H * hd, c.dim};
-    else if (n == "wk") sl = {&L->qkv, (H + 2 * KV) * hd, H * hd, 1, KV * hd, c.dim};
-    else if (n == "wv") sl = {&L->qkv, (H + 2 * KV) * hd, (H + KV) * hd, 1, KV * hd, c.dim};
-    else if (n == "wo") sl = {&L->wo, c.dim, 0, 1, c.dim, H * hd};
-    else if (n == "w1") sl = {&L->w13, 2 * c.ffn_dim, 0, 2, c.ffn_dim, c.dim};
-    else if (n == "w3") sl = {&L->w13, 2 * c.ffn_dim, 1, 2, c.ffn_dim, c.dim};
-    else if (n == "w2") sl = {&L->w2, c.dim, 0, 1, c.dim, c.ffn_dim};
+    if (n == "wq") sl = {&L->qkv, (H + 2 * KV) * hd, 0, 1, H * hd, c.dim, hd};
+    else if (n == "wk") sl = {&L->qkv, (H + 2 * KV) * hd, H * hd, 1, KV * hd, c.dim, hd};
+    else if (n == "wv") sl = {&L->qkv, (H + 2 * KV) * hd, (H + KV) * hd, 1, KV * hd, c.dim, 0};
+    else if (n == "wo") sl = {&L->wo, c.dim, 0, 1, c.dim, H * hd, 0};
+    else if (n == "w1") sl = {&L->w13, 2 * c.ffn_dim, 0, 2, c.ffn_dim, c.dim, 0};
+    else if (n == "w3") sl = {&L->w13, 2 * c.ffn_dim, 1, 2, c.ffn_dim, c.dim, 0};
+    else if (n == "w2") sl = {&L->w2, c.dim, 0, 1, c.dim, c.ffn_dim, 0};
     else return fail(MC_ERR_INVALID_ARGUMENT, "decoder: unknown linear '" + n + "'");
     if (out_f != sl.rows || in_f != sl.in)
         return fail(MC_ERR_INVALID_ARGUMENT, "decoder: '" + n + "' shape mismatch");
     s = d->alloc_linear(*sl.lin, fmt, sl.total, sl.in, group);
     if (s != MC_OK) return s;
-    return d->upload_rows(*sl.lin, sl.row0, sl.stride, sl.rows, weight, scales);
+    return d->upload_rows(*sl.lin, sl.row0, sl.stride, sl.rows, weight, scales, sl.perm);
 }
 
 mc_status
@@ -735,7 +762,7 @@ mc_decoder_init_synthetic(mc_decoder* d, uint64_t seed)
     for (int i = 0; i < d->n_own; i++) {
         layer_w& L = d->layers[i];
         const uint32_t base = (uint32_t)(c.layer_begin + i) * 16;
-        s = fill_linear(L.qkv, (H + 2 * KV) * hd, c.dim, base + 0, 1, H * hd, KV * hd);
+        s = fill_linear(L.qkv, (H + 2 * KV) * hd, c.dim, base + 0, 1u | ((uint32_t)hd << 8), H * hd, KV * hd);
         if (s != MC_OK) return s;
         s = fill_linear(L.wo, c.dim, H * hd, base + 3, 0, 0, 0);
         if (s != MC_OK) return s;
@@ -989,7 +1016,8 @@ mc_decoder_time_gemv(mc_decoder* d, const char* which, int32_t repeats, float* t
         mc_status r = MC_OK;
         for (auto& L : d->layers) {
             if (w == "qkv" || w == "all") {
-                r = d->gemv(L.qkv, 1, 0, d->hidden, d->qkv, nullptr, L.attention_norm, mu);
+                r = gemma ? d->gemv(L.qkv, 1, 0, d->hidden, d->qkv, nullptr, L.attention_norm, mu)
+                          : d->gemv(L.qkv, 1, 4, d->hidden, d->qkv, L.qkv_epi, L.attention_norm, mu);
                 if (r != MC_OK) return r;
                 if (count) { bytes += linear_bytes(L.qkv); launches++; }
             }

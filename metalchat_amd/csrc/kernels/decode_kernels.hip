@@ -160,8 +160,10 @@ rope_kv_body(const typename T::S* qkv, typename T::S* q_out, typename T::S* kc, 
         return;
     }
     const bool is_q = b < H;
-    const typename T::S* src = qkv + (size_t)b * hd; // q heads then k heads are contiguous
-    float x1 = T::ld(src[j]), x2 = T::ld(src[j + half]);
+    // q heads then k heads are contiguous; inside a head the fused GEMV stores the rotation
+    // partners adjacently (gemv.h EPI_QKV_ROPE): packed [2j] = natural [j], [2j+1] = natural [j+half]
+    const typename T::S* src = qkv + (size_t)b * hd;
+    float x1 = T::ld(src[2 * j]), x2 = T::ld(src[2 * j + 1]);
     const typename T::S* nw = is_q ? q_norm : k_norm;
     if (nw) {
         const float tot = block_sum(x1 * x1 + x2 * x2, red);
@@ -208,19 +210,62 @@ mc_rope_table(float* fcos, float* fsin, uint32_t rows, uint32_t dim, uint32_t st
 
 // ------------------------------------------------------------------------------------------
 // Decode attention, stage 1: scores.   grid (nsplit, n_kv), 256 threads (4 waves).
-// Workgroup (split, kv) owns cache slots [split*PB, split*PB + PB); wave w owns 16-slot tiles
-// w, w+4, w+8, w+12 of that range.  Per tile one MFMA chain computes the [16 heads x 16 slots]
-// block  Q_g . K^T  (rows >= n_rep are zero padding: the n_rep query heads that share kv head g
-// are the M dimension -- this is the GQA "repeat_kv" without the copies).
+// Workgroup (split, kv) owns cache slots [split*PB, split*PB + PB), one 16-slot MFMA tile per
+// wave.  Per tile one MFMA chain computes the [16 heads x 16 slots] block  Q_g . K^T  (rows
+// >= n_rep are zero padding: the n_rep query heads that share kv head g are the M dimension --
+// this is the GQA "repeat_kv" without the copies).
 //   s  = T(acc)            bmm result rounded to T          (attention.h:195, bmm.metal:80)
 //   s  = T(s * scale_T)    scalar_mul evaluated in T        (attention.h:196, mul.metal:117)
 //   e  = exp(s)            kept in fp32 for stage 2; per-(head, split) partial sums of e are
 //                          written in a fixed slot so the softmax denominator is deterministic.
+// After the MFMA the valid scores sit in the first n_rep/4 lane groups; they are dealt out so that
+// lane (c, col) finishes head 4m + c of slot col: with n_rep = 4 every lane evaluates ONE exp.
 // ------------------------------------------------------------------------------------------
-constexpr int PB = 256; // cache slots per workgroup
+constexpr int PB = 64; // cache slots per scores workgroup
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+// shared tail of both dtypes: acc = one 16x16 score tile of this wave
+template <typename T>
+__device__ __forceinline__ void
+scores_finish(const f32x4_t& acc, float* __restrict__ expv, float* __restrict__ psum,
+              typename T::S* __restrict__ scores_dbg, float (*wsum)[16], uint32_t S, uint32_t pos,
+              uint32_t kv, uint32_t n_rep, uint32_t max_seq, float scale, uint32_t nsplit,
+              uint32_t split)
+{
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t col = lane & 15, c = lane >> 4;
+    const uint32_t nm = (n_rep + 3) / 4;
+    for (uint32_t m = 0; m < nm; m++) {
+        const int src = (int)(m * 16 + col);
+        const float v0 = __shfl(acc[0], src, 64), v1 = __shfl(acc[1], src, 64);
+        const float v2 = __shfl(acc[2], src, 64), v3 = __shfl(acc[3], src, 64);
+        const float mine = c == 0 ? v0 : (c == 1 ? v1 : (c == 2 ? v2 : v3));
+        const uint32_t head = 4 * m + c;
+        float e = 0.0f;
+        if (head < n_rep && pos < S) {
+            float s = T::rt(mine);
+            s = T::rt(s * scale);
+            e = exp_precise(s);
+            const size_t o = (size_t)(kv * n_rep + head) * max_seq + pos;
+            expv[o] = e;
+            if (scores_dbg) scores_dbg[o] = T::st(s);
+        }
+        // sum over the 16 slots of the tile (lanes sharing c)
+        e += __shfl_xor(e, 1, 64);
+        e += __shfl_xor(e, 2, 64);
+        e += __shfl_xor(e, 4, 64);
+        e += __shfl_xor(e, 8, 64);
+        if (col == 0 && head < 16) wsum[wave][head] = e;
+    }
+    __syncthreads();
+    if (threadIdx.x < n_rep) {
+        const float tot = (wsum[0][threadIdx.x] + wsum[1][threadIdx.x]) +
+                          (wsum[2][threadIdx.x] + wsum[3][threadIdx.x]);
+        psum[(size_t)(kv * n_rep + threadIdx.x) * nsplit + split] = tot;
+    }
+}
 
 template <int HD>
 __device__ __forceinline__ void
@@ -237,7 +282,14 @@ attn_scores_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc,
     const uint32_t col = lane & 15, c = lane >> 4;
     constexpr int KS = HD / 32;
 
-    // A fragments: Q[head = col][d = ks*32 + c*8 + j]
+    // B fragments first (HBM): K[slot = pos][d = ks*32 + c*8 + j]
+    const uint32_t pos = p_begin + wave * 16 + col;
+    const uint32_t lp = pos < S ? pos : S - 1;
+    const bf16_t* kbase = kc + ((size_t)kv * max_seq + lp) * HD;
+    uint4 kb[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++) kb[ks] = *reinterpret_cast<const uint4*>(kbase + ks * 32 + c * 8);
+    // A fragments (L2): Q[head = col][d = ks*32 + c*8 + j]
     uint4 qa[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ks++) {
@@ -245,57 +297,12 @@ attn_scores_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc,
         if (col < n_rep)
             qa[ks] = *reinterpret_cast<const uint4*>(q + (size_t)(kv * n_rep + col) * HD + ks * 32 + c * 8);
     }
-    const bf16_t* kbase = kc + (size_t)kv * max_seq * HD;
-
-    uint4 kb[4][KS];
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int t = 0; t < 4; t++) {
-        uint32_t pos = p_begin + (wave + 4 * t) * 16 + col;
-        pos = pos < S ? pos : S - 1;
-#pragma unroll
-        for (int ks = 0; ks < KS; ks++)
-            kb[t][ks] = *reinterpret_cast<const uint4*>(kbase + (size_t)pos * HD + ks * 32 + c * 8);
-    }
-    float esum[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int t = 0; t < 4; t++) {
-        f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < KS; ks++)
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, qa[ks]),
-                                                          __builtin_bit_cast(bf16x8_t, kb[t][ks]),
-                                                          acc, 0, 0, 0);
-        const uint32_t pos = p_begin + (wave + 4 * t) * 16 + col;
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const uint32_t head = c * 4 + r; // D: row = (lane>>4)*4 + reg, col = lane & 15
-            if (head < n_rep && pos < S) {
-                float s = BF::rt(acc[r]);
-                s = BF::rt(s * scale);
-                const float e = exp_precise(s);
-                const size_t o = (size_t)(kv * n_rep + head) * max_seq + pos;
-                expv[o] = e;
-                if (scores_dbg) scores_dbg[o] = f2bf(s);
-                esum[r] += e;
-            }
-        }
-    }
-    // reduce over the 16 slots of a tile row (lanes sharing c), then over the 4 waves
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-        float v = esum[r];
-        v += __shfl_xor(v, 1, 64);
-        v += __shfl_xor(v, 2, 64);
-        v += __shfl_xor(v, 4, 64);
-        v += __shfl_xor(v, 8, 64);
-        if (col == 0) wsum[wave][c * 4 + r] = v;
-    }
-    __syncthreads();
-    if (threadIdx.x < n_rep) {
-        const float tot = (wsum[0][threadIdx.x] + wsum[1][threadIdx.x]) +
-                          (wsum[2][threadIdx.x] + wsum[3][threadIdx.x]);
-        psum[(size_t)(kv * n_rep + threadIdx.x) * nsplit + split] = tot;
-    }
+    for (int ks = 0; ks < KS; ks++)
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, qa[ks]),
+                                                      __builtin_bit_cast(bf16x8_t, kb[ks]), acc, 0, 0, 0);
+    scores_finish<BF>(acc, expv, psum, scores_dbg, wsum, S, pos, kv, n_rep, max_seq, scale, nsplit, split);
 }
 
 extern "C" __global__ void __launch_bounds__(256)
@@ -330,6 +337,12 @@ attn_scores_f32(const float* __restrict__ q, const float* __restrict__ kc,
     const uint32_t col = lane & 15, c = lane >> 4;
     constexpr int ST = HD / 16;
 
+    const uint32_t pos = p_begin + wave * 16 + col;
+    const uint32_t lp = pos < S ? pos : S - 1;
+    const float* kbase = kc + ((size_t)kv * max_seq + lp) * HD;
+    float4 kb[ST];
+#pragma unroll
+    for (int s = 0; s < ST; s++) kb[s] = *reinterpret_cast<const float4*>(kbase + s * 16 + c * 4);
     float4 qa[ST];
 #pragma unroll
     for (int s = 0; s < ST; s++) {
@@ -337,51 +350,15 @@ attn_scores_f32(const float* __restrict__ q, const float* __restrict__ kc,
         if (col < n_rep)
             qa[s] = *reinterpret_cast<const float4*>(q + (size_t)(kv * n_rep + col) * HD + s * 16 + c * 4);
     }
-    const float* kbase = kc + (size_t)kv * max_seq * HD;
-    float esum[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int t = 0; t < 4; t++) {
-        const uint32_t pos = p_begin + (wave + 4 * t) * 16 + col;
-        const uint32_t lp = pos < S ? pos : S - 1;
-        float4 kb[ST];
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int s = 0; s < ST; s++)
-            kb[s] = *reinterpret_cast<const float4*>(kbase + (size_t)lp * HD + s * 16 + c * 4);
-        f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < ST; s++) {
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[s].x, kb[s].x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[s].y, kb[s].y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[s].z, kb[s].z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[s].w, kb[s].w, acc, 0, 0, 0);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const uint32_t head = c * 4 + r;
-            if (head < n_rep && pos < S) {
-                const float s = acc[r] * scale;
-                const float e = exp_precise(s);
-                const size_t o = (size_t)(kv * n_rep + head) * max_seq + pos;
-                expv[o] = e;
-                if (scores_dbg) scores_dbg[o] = s;
-                esum[r] += e;
-            }
-        }
+    for (int s = 0; s < ST; s++) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[s].x, kb[s].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[s].y, kb[s].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[s].z, kb[s].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[s].w, kb[s].w, acc, 0, 0, 0);
     }
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-        float v = esum[r];
-        v += __shfl_xor(v, 1, 64);
-        v += __shfl_xor(v, 2, 64);
-        v += __shfl_xor(v, 4, 64);
-        v += __shfl_xor(v, 8, 64);
-        if (col == 0) wsum[wave][c * 4 + r] = v;
-    }
-    __syncthreads();
-    if (threadIdx.x < n_rep) {
-        const float tot = (wsum[0][threadIdx.x] + wsum[1][threadIdx.x]) +
-                          (wsum[2][threadIdx.x] + wsum[3][threadIdx.x]);
-        psum[(size_t)(kv * n_rep + threadIdx.x) * nsplit + split] = tot;
-    }
+    scores_finish<F32>(acc, expv, psum, scores_dbg, wsum, S, pos, kv, n_rep, max_seq, scale, nsplit, split);
 }
 
 extern "C" __global__ void __launch_bounds__(256)
@@ -400,207 +377,139 @@ mc_attn_scores_float(const float* q, const float* kc, float* expv, float* psum, 
 }
 
 // ------------------------------------------------------------------------------------------
-// Decode attention, stage 2: P.V partials.   grid (nsplit, n_kv), 256 threads.
+// Decode attention, stage 2: softmax normalisation + P.V.   grid (hd/16, n_kv), 256 threads.
 //   p = T(e * (1/sum))     softmax output rounded to T     (softmax.metal:84-86)
-//   o = sum_s p[s] V[s]    fp32 MFMA accumulate over the workgroup's PB slots
-// Wave w owns slots [w*64, w*64+64) of the range = two 32-slot MFMA k-steps (bf16) and walks the
-// hd/16 output column blocks.  Partial [n_rep x hd] blocks of the 4 waves are summed through LDS
-// in wave order and written to opart[split]; mc_attn_reduce adds the splits in order and rounds
-// to T once (bmm.metal:80).
+//   o = T(sum_s p[s] V[s]) fp32 MFMA accumulate, rounded once (bmm.metal:80)
+// Workgroup (db, kv) owns output columns [16 db, 16 db + 16) of the n_rep heads of kv head `kv`
+// over ALL cache slots, so the result is final: no cross-workgroup partials, no reduce launch.
+// The four waves interleave the 32-slot MFMA k-steps (wave w takes k-steps w, w+4, ...) and are
+// summed through LDS in wave order.  B = Vt rows (position-contiguous), A = normalised P.
 // ------------------------------------------------------------------------------------------
-template <int HD>
-__device__ __forceinline__ void
-attn_pv_bf(const float* __restrict__ expv, const float* __restrict__ psum,
-           const bf16_t* __restrict__ vt, float* __restrict__ opart, const step_state* st,
-           uint32_t n_rep, uint32_t max_seq, uint32_t nsplit, uint32_t H)
+template <typename T>
+__device__ __forceinline__ float
+softmax_inv(const float* __restrict__ psum, uint32_t head_ok, size_t row, uint32_t nact)
 {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* part = reinterpret_cast<float*>(smem); // [4 waves][16 heads][HD]
-    const uint32_t S = (uint32_t)st->kv_len;
-    const uint32_t split = blockIdx.x, kv = blockIdx.y;
-    const uint32_t p_begin = split * PB;
-    if (p_begin >= S) return;
-    const uint32_t nact = (S + PB - 1) / PB;
+    float inv = 0.0f;
+    if (head_ok) {
+        float tot = 0.0f;
+        for (uint32_t sp = 0; sp < nact; sp++) tot += psum[row + sp];
+        inv = 1.0f / tot; // softmax.metal:66-72: exp_sum = 1 / acc
+    }
+    return inv;
+}
+
+__device__ __forceinline__ void
+pv_finish_store(const f32x4_t& acc, float* part, void* out, int tbytes, uint32_t kv, uint32_t n_rep,
+                uint32_t hd, uint32_t db)
+{
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t col = lane & 15, c = lane >> 4;
-    constexpr int NB = HD / 16;
-
-    // softmax denominator of head `col` (softmax.metal:66-72: exp_sum = 1 / acc)
-    float inv = 0.0f;
-    if (col < n_rep) {
-        float tot = 0.0f;
-        for (uint32_t sp = 0; sp < nact; sp++) tot += psum[(size_t)(kv * n_rep + col) * nsplit + sp];
-        inv = 1.0f / tot;
-    }
-    // A fragments: P[head = col][slot = p0 + 8c + j], two k-steps
-    uint4 pa[2];
 #pragma unroll
-    for (int t = 0; t < 2; t++) {
-        const uint32_t p0 = p_begin + wave * 64 + t * 32 + c * 8;
-        uint32_t w[4] = {0, 0, 0, 0};
-        if (col < n_rep && p0 < S) {
-            const float4 e0 = *reinterpret_cast<const float4*>(expv + (size_t)(kv * n_rep + col) * max_seq + p0);
-            const float4 e1 = *reinterpret_cast<const float4*>(expv + (size_t)(kv * n_rep + col) * max_seq + p0 + 4);
-            const float e[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
-            float p[8];
-#pragma unroll
-            for (int j = 0; j < 8; j++) p[j] = (p0 + j < S) ? e[j] * inv : 0.0f;
-#pragma unroll
-            for (int j = 0; j < 4; j++) w[j] = pack_bf16x2(p[2 * j], p[2 * j + 1]);
-        }
-        pa[t] = make_uint4(w[0], w[1], w[2], w[3]);
-    }
-    // B fragments: Vt[d = nb*16 + col][slot = p0 + 8c + j]
-    const bf16_t* vbase = vt + (size_t)kv * HD * max_seq;
-    uint4 vb[NB][2];
-#pragma unroll
-    for (int nb = 0; nb < NB; nb++)
-#pragma unroll
-        for (int t = 0; t < 2; t++) {
-            uint32_t p0 = p_begin + wave * 64 + t * 32 + c * 8;
-            p0 = p0 + 8 <= max_seq ? p0 : max_seq - 8;
-            vb[nb][t] = *reinterpret_cast<const uint4*>(vbase + (size_t)(nb * 16 + col) * max_seq + p0);
-        }
-#pragma unroll
-    for (int nb = 0; nb < NB; nb++) {
-        f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int t = 0; t < 2; t++)
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, pa[t]),
-                                                          __builtin_bit_cast(bf16x8_t, vb[nb][t]),
-                                                          acc, 0, 0, 0);
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const uint32_t head = c * 4 + r;
-            if (head < n_rep) part[((size_t)wave * 16 + head) * HD + nb * 16 + col] = acc[r];
-        }
-    }
+    for (int r = 0; r < 4; r++) part[(wave * 16 + c * 4 + r) * 16 + col] = acc[r];
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < n_rep * HD; i += blockDim.x) {
-        const uint32_t head = i / HD, d = i % HD;
-        const float v = ((part[(0 * 16 + head) * HD + d] + part[(1 * 16 + head) * HD + d]) +
-                         part[(2 * 16 + head) * HD + d]) + part[(3 * 16 + head) * HD + d];
-        opart[((size_t)split * H + kv * n_rep + head) * HD + d] = v;
+    if (threadIdx.x < n_rep * 16) {
+        const uint32_t head = threadIdx.x / 16, d = threadIdx.x % 16;
+        const float v = ((part[(0 * 16 + head) * 16 + d] + part[(1 * 16 + head) * 16 + d]) +
+                         part[(2 * 16 + head) * 16 + d]) + part[(3 * 16 + head) * 16 + d];
+        const size_t o = (size_t)(kv * n_rep + head) * hd + db * 16 + d;
+        if (tbytes == 2) static_cast<bf16_t*>(out)[o] = f2bf(v);
+        else static_cast<float*>(out)[o] = v;
     }
 }
 
 extern "C" __global__ void __launch_bounds__(256)
-mc_attn_pv_bfloat(const float* expv, const float* psum, const bf16_t* vt, float* opart,
-                  const step_state* st, uint32_t n_rep, uint32_t hd, uint32_t max_seq,
-                  uint32_t nsplit, uint32_t H)
+mc_attn_pv_bfloat(const float* __restrict__ expv, const float* __restrict__ psum,
+                  const bf16_t* __restrict__ vt, bf16_t* __restrict__ out, const step_state* st,
+                  uint32_t n_rep, uint32_t hd, uint32_t max_seq, uint32_t nsplit)
 {
-    if (hd == 128)
-        attn_pv_bf<128>(expv, psum, vt, opart, st, n_rep, max_seq, nsplit, H);
-    else if (hd == 64)
-        attn_pv_bf<64>(expv, psum, vt, opart, st, n_rep, max_seq, nsplit, H);
-    else if (hd == 256)
-        attn_pv_bf<256>(expv, psum, vt, opart, st, n_rep, max_seq, nsplit, H);
-    else if (hd == 32)
-        attn_pv_bf<32>(expv, psum, vt, opart, st, n_rep, max_seq, nsplit, H);
+    __shared__ float part[4 * 16 * 16];
+    const uint32_t S = (uint32_t)st->kv_len;
+    const uint32_t db = blockIdx.x, kv = blockIdx.y;
+    const uint32_t nact = (S + PB - 1) / PB;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t col = lane & 15, c = lane >> 4;
+    const float inv = softmax_inv<BF>(psum, col < n_rep, (size_t)(kv * n_rep + col) * nsplit, nact);
+    const float* erow = expv + (size_t)(kv * n_rep + col) * max_seq;
+    const bf16_t* vrow = vt + ((size_t)kv * hd + db * 16 + col) * max_seq;
+    const uint32_t nk = (S + 31) / 32;
+
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    for (uint32_t t0 = wave; t0 < nk; t0 += 16) {
+        // four k-steps of this wave per iteration: all loads first, then the MFMAs
+        uint4 vb[4];
+        float4 e0[4], e1[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t p0 = (t0 + 4 * u) * 32 + c * 8;
+            const uint32_t pl = p0 + 8 <= max_seq ? p0 : max_seq - 8;
+            vb[u] = *reinterpret_cast<const uint4*>(vrow + pl);
+            e0[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            e1[u] = e0[u];
+            if (col < n_rep && p0 < S) {
+                e0[u] = *reinterpret_cast<const float4*>(erow + p0);
+                e1[u] = *reinterpret_cast<const float4*>(erow + p0 + 4);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t p0 = (t0 + 4 * u) * 32 + c * 8;
+            const float e[8] = {e0[u].x, e0[u].y, e0[u].z, e0[u].w, e1[u].x, e1[u].y, e1[u].z, e1[u].w};
+            uint32_t w[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float pa = (p0 + 2 * j < S) ? e[2 * j] * inv : 0.0f;
+                const float pb = (p0 + 2 * j + 1 < S) ? e[2 * j + 1] * inv : 0.0f;
+                w[j] = pack_bf16x2(pa, pb); // softmax output rounded to bf16
+            }
+            const uint4 pa4 = make_uint4(w[0], w[1], w[2], w[3]);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, pa4),
+                                                          __builtin_bit_cast(bf16x8_t, vb[u]), acc, 0, 0, 0);
+        }
+    }
+    pv_finish_store(acc, part, out, 2, kv, n_rep, hd, db);
 }
 
 // T = float.  k-step = 16 slots: lane (col, c) holds slots p0 + 4c + i; MFMA i contracts slot
-// p0 + 4c + i on both operands.  Wave w owns 64 slots = 4 k-steps.
-template <int HD>
-__device__ __forceinline__ void
-attn_pv_f32(const float* __restrict__ expv, const float* __restrict__ psum,
-            const float* __restrict__ vt, float* __restrict__ opart, const step_state* st,
-            uint32_t n_rep, uint32_t max_seq, uint32_t nsplit, uint32_t H)
+// p0 + 4c + i on both operands.
+extern "C" __global__ void __launch_bounds__(256)
+mc_attn_pv_float(const float* __restrict__ expv, const float* __restrict__ psum,
+                 const float* __restrict__ vt, float* __restrict__ out, const step_state* st,
+                 uint32_t n_rep, uint32_t hd, uint32_t max_seq, uint32_t nsplit)
 {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* part = reinterpret_cast<float*>(smem);
+    __shared__ float part[4 * 16 * 16];
     const uint32_t S = (uint32_t)st->kv_len;
-    const uint32_t split = blockIdx.x, kv = blockIdx.y;
-    const uint32_t p_begin = split * PB;
-    if (p_begin >= S) return;
+    const uint32_t db = blockIdx.x, kv = blockIdx.y;
     const uint32_t nact = (S + PB - 1) / PB;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t col = lane & 15, c = lane >> 4;
-    constexpr int NB = HD / 16;
+    const float inv = softmax_inv<F32>(psum, col < n_rep, (size_t)(kv * n_rep + col) * nsplit, nact);
+    const float* erow = expv + (size_t)(kv * n_rep + col) * max_seq;
+    const float* vrow = vt + ((size_t)kv * hd + db * 16 + col) * max_seq;
+    const uint32_t nk = (S + 15) / 16;
 
-    float inv = 0.0f;
-    if (col < n_rep) {
-        float tot = 0.0f;
-        for (uint32_t sp = 0; sp < nact; sp++) tot += psum[(size_t)(kv * n_rep + col) * nsplit + sp];
-        inv = 1.0f / tot;
-    }
-    float4 pa[4];
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    for (uint32_t t0 = wave; t0 < nk; t0 += 16) {
+        float4 vb[4], pe[4];
 #pragma unroll
-    for (int t = 0; t < 4; t++) {
-        const uint32_t p0 = p_begin + wave * 64 + t * 16 + c * 4;
-        pa[t] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (col < n_rep && p0 < S) {
-            const float4 e = *reinterpret_cast<const float4*>(expv + (size_t)(kv * n_rep + col) * max_seq + p0);
-            pa[t].x = e.x * inv;
-            pa[t].y = p0 + 1 < S ? e.y * inv : 0.0f;
-            pa[t].z = p0 + 2 < S ? e.z * inv : 0.0f;
-            pa[t].w = p0 + 3 < S ? e.w * inv : 0.0f;
-        }
-    }
-    const float* vbase = vt + (size_t)kv * HD * max_seq;
-    for (int nb = 0; nb < NB; nb++) {
-        f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int t = 0; t < 4; t++) {
-            uint32_t p0 = p_begin + wave * 64 + t * 16 + c * 4;
-            p0 = p0 + 4 <= max_seq ? p0 : max_seq - 4;
-            const float4 v = *reinterpret_cast<const float4*>(vbase + (size_t)(nb * 16 + col) * max_seq + p0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[t].x, v.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[t].y, v.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[t].z, v.z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[t].w, v.w, acc, 0, 0, 0);
+        for (int u = 0; u < 4; u++) {
+            const uint32_t p0 = (t0 + 4 * u) * 16 + c * 4;
+            const uint32_t pl = p0 + 4 <= max_seq ? p0 : max_seq - 4;
+            vb[u] = *reinterpret_cast<const float4*>(vrow + pl);
+            pe[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (col < n_rep && p0 < S) pe[u] = *reinterpret_cast<const float4*>(erow + p0);
         }
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const uint32_t head = c * 4 + r;
-            if (head < n_rep) part[((size_t)wave * 16 + head) * HD + nb * 16 + col] = acc[r];
+        for (int u = 0; u < 4; u++) {
+            const uint32_t p0 = (t0 + 4 * u) * 16 + c * 4;
+            const float a0 = p0 < S ? pe[u].x * inv : 0.0f, a1 = p0 + 1 < S ? pe[u].y * inv : 0.0f;
+            const float a2 = p0 + 2 < S ? pe[u].z * inv : 0.0f, a3 = p0 + 3 < S ? pe[u].w * inv : 0.0f;
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, vb[u].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, vb[u].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, vb[u].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, vb[u].w, acc, 0, 0, 0);
         }
     }
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < n_rep * HD; i += blockDim.x) {
-        const uint32_t head = i / HD, d = i % HD;
-        const float v = ((part[(0 * 16 + head) * HD + d] + part[(1 * 16 + head) * HD + d]) +
-                         part[(2 * 16 + head) * HD + d]) + part[(3 * 16 + head) * HD + d];
-        opart[((size_t)split * H + kv * n_rep + head) * HD + d] = v;
-    }
-}
-
-extern "C" __global__ void __launch_bounds__(256)
-mc_attn_pv_float(const float* expv, const float* psum, const float* vt, float* opart,
-                 const step_state* st, uint32_t n_rep, uint32_t hd, uint32_t max_seq,
-                 uint32_t nsplit, uint32_t H)
-{
-    if (hd == 128)
-        attn_pv_f32<128>(expv, psum, vt, opart, st, n_rep, max_seq, nsplit, H);
-    else if (hd == 64)
-        attn_pv_f32<64>(expv, psum, vt, opart, st, n_rep, max_seq, nsplit, H);
-    else if (hd == 256)
-        attn_pv_f32<256>(expv, psum, vt, opart, st, n_rep, max_seq, nsplit, H);
-    else if (hd == 32)
-        attn_pv_f32<32>(expv, psum, vt, opart, st, n_rep, max_seq, nsplit, H);
-}
-
-// out[i] = T(sum over active splits, in split order, of opart[split][i])
-template <typename T>
-__device__ __forceinline__ void
-attn_reduce_body(const float* opart, typename T::S* out, const step_state* st, uint32_t n)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t nact = ((uint32_t)st->kv_len + PB - 1) / PB;
-    float v = 0.0f;
-    for (uint32_t sp = 0; sp < nact; sp++) v += opart[(size_t)sp * n + i];
-    out[i] = T::st(v);
-}
-extern "C" __global__ void
-mc_attn_reduce_bfloat(const float* opart, bf16_t* out, const step_state* st, uint32_t n)
-{
-    attn_reduce_body<BF>(opart, out, st, n);
-}
-extern "C" __global__ void
-mc_attn_reduce_float(const float* opart, float* out, const step_state* st, uint32_t n)
-{
-    attn_reduce_body<F32>(opart, out, st, n);
+    pv_finish_store(acc, part, out, 4, kv, n_rep, hd, db);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -650,12 +559,42 @@ argmax_body(const typename T::S* logits, uint32_t n, step_state* st, int32_t* to
 {
     __shared__ float bv[16];
     __shared__ uint32_t bi[16];
+    constexpr uint32_t EPV = 16 / T::bytes; // elements per 16-byte packet
     float best = -INFINITY;
     uint32_t idx = 0xffffffffu;
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
-        const float v = T::ld(logits[i]);
+    auto take = [&](float v, uint32_t i) {
+        // strictly greater keeps the FIRST maximum inside a thread's increasing index order
         if (v > best || idx == 0xffffffffu) { best = v; idx = i; }
+    };
+    const uint32_t npk = n / EPV;
+    const uint4* pk = reinterpret_cast<const uint4*>(logits);
+    // 16-byte packets, four in flight per thread
+    for (uint32_t p0 = threadIdx.x; p0 < npk; p0 += 4 * blockDim.x) {
+        uint4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t p = p0 + u * blockDim.x;
+            v[u] = pk[p < npk ? p : npk - 1];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t p = p0 + u * blockDim.x;
+            if (p < npk) {
+                const uint32_t w[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if (T::bytes == 2) {
+                        take(__uint_as_float(w[j] << 16), p * EPV + 2 * j);
+                        take(__uint_as_float(w[j] & 0xFFFF0000u), p * EPV + 2 * j + 1);
+                    } else {
+                        take(__uint_as_float(w[j]), p * EPV + j);
+                    }
+                }
+            }
+        }
     }
+    for (uint32_t i = npk * EPV + threadIdx.x; i < n; i += blockDim.x) take(T::ld(logits[i]), i);
+    // a thread's packets are not contiguous, so ties are resolved on the index everywhere below
     for (int off = 32; off >= 1; off >>= 1) {
         const float ov = __shfl_xor(best, off, 64);
         const uint32_t oi = __shfl_xor(idx, off, 64);

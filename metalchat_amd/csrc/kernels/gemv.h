@@ -34,7 +34,22 @@ namespace gemv {
 enum { WF_T = 0, WF_I8 = 1, WF_I4 = 2 };
 enum { Q_EXACT = 0, Q_FAST = 1, Q_DBG_STREAM = 2, Q_DBG_NOLOAD = 3, Q_DBG_TL = 4 }; // 2..4: tuning aids
 enum { PRO_NONE = 0, PRO_RMSNORM = 1 };
-enum { EPI_STORE = 0, EPI_RESID = 1, EPI_SILU_MUL = 2, EPI_GELU_MUL = 3 };
+enum { EPI_STORE = 0, EPI_RESID = 1, EPI_SILU_MUL = 2, EPI_GELU_MUL = 3, EPI_QKV_ROPE = 4 };
+
+// EPI_QKV_ROPE: the fused wq|wk|wv GEMV finishes RoPE and the sink-cache write itself
+// (kernel/rope.metal:49-59 + nn/cache.h:209-213), so q, k and v never make a round trip through
+// HBM as a separate launch.  The q and k rows of the fused matrix are stored with the rotation
+// partners (j, j + hd/2) of a head ADJACENT (packed row head*hd + 2j + e <-> natural row
+// head*hd + j + e*hd/2), so one wavefront tile of four rows holds two complete pairs.
+struct qkv_epilogue {
+    void* q_out;        // T[H*hd]       rotated queries, natural order
+    void* kc;           // T[KV][max_seq][hd]
+    void* vt;           // T[KV][hd][max_seq]
+    const float* fcos;  // [rows][hd/2]
+    const float* fsin;
+    const int32_t* state; // step_state: [3] = write_slot, [6] = rope_row
+    uint32_t H, KV, hd, max_seq;
+};
 
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 
@@ -451,8 +466,15 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
                 if (PRO == PRO_RMSNORM) nr[i] = ng[pc];
             }
         }
+        // MC_GEMV_PRE of the three ring tiles are requested before the row is consumed, the rest
+        // right after the barrier (A/B: tools/gemv_sweep.py with MC_HSACO=..._preN.hsaco)
+#ifndef MC_GEMV_PRE
+#define MC_GEMV_PRE 1
+#endif
         load(t0, ld.rg, ld.c, 0 < ntiles);
         advance(ld);
+        if (MC_GEMV_PRE >= 2) { load(t1, ld.rg, ld.c, 1 < ntiles); advance(ld); }
+        if (MC_GEMV_PRE >= 3) { load(t2, ld.rg, ld.c, 2 < ntiles); advance(ld); }
         if (fits) {
 #pragma unroll
             for (int i = 0; i < MAXP; i++)
@@ -533,10 +555,8 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
     }
     __syncthreads();
     if (QM == Q_DBG_TL) tl1 = __builtin_amdgcn_s_memrealtime();
-    load(t1, ld.rg, ld.c, 1 < ntiles);
-    advance(ld);
-    load(t2, ld.rg, ld.c, 2 < ntiles);
-    advance(ld);
+    if (MC_GEMV_PRE < 2) { load(t1, ld.rg, ld.c, 1 < ntiles); advance(ld); }
+    if (MC_GEMV_PRE < 3) { load(t2, ld.rg, ld.c, 2 < ntiles); advance(ld); }
 
     float acc[R];
 #pragma unroll
@@ -578,6 +598,30 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
                     float v = T::rt(mine);
                     if (EPI == EPI_RESID) v = T::ld(static_cast<const S*>(resp)[row]) + v; // add in T
                     y[row] = T::st(v);
+                }
+            } else if (EPI == EPI_QKV_ROPE) {
+                const qkv_epilogue* q = static_cast<const qkv_epilogue*>(resp);
+                const uint32_t H = q->H, KV = q->KV, hd = q->hd, half = hd / 2, ms = q->max_seq;
+                const uint32_t slot = (uint32_t)q->state[3], rrow = (uint32_t)q->state[6];
+                const uint32_t row0 = crg * R;
+                if (row0 < (H + KV) * hd) {
+                    // two rotation pairs: lane 0 -> rows (0,1), lane 1 -> rows (2,3)
+                    const float x1 = T::rt(lane == 0 ? tot[0] : tot[2]);
+                    const float x2 = T::rt(lane == 0 ? tot[1] : tot[3]);
+                    const uint32_t prow = row0 + 2 * lane;         // packed row of x1
+                    const uint32_t head = prow / hd, j = (prow % hd) / 2;
+                    if (lane < 2) {
+                        const float c = q->fcos[(size_t)rrow * half + j], sn = q->fsin[(size_t)rrow * half + j];
+                        const S o1 = T::st(c * x1 - sn * x2), o2 = T::st(sn * x1 + c * x2);
+                        S* dst = head < H ? static_cast<S*>(q->q_out) + (size_t)head * hd
+                                          : static_cast<S*>(q->kc) + ((size_t)(head - H) * ms + slot) * hd;
+                        dst[j] = o1;
+                        dst[j + half] = o2;
+                    }
+                } else if (lane < (uint32_t)R) {
+                    const float mine = lane == 0 ? tot[0] : (lane == 1 ? tot[1] : (lane == 2 ? tot[2] : tot[3]));
+                    const uint32_t vrow = row0 + lane - (H + KV) * hd; // kv*hd + d
+                    static_cast<S*>(q->vt)[(size_t)vrow * ms + slot] = T::st(mine);
                 }
             } else {
                 // rows (2j, 2j+1) = (w1 row j, w3 row j): out[j] = T(act(T(w1 x)) * T(w3 x));

@@ -1,7 +1,8 @@
 // extern "C" instantiations of the fused GEMV (gemv.h).  Name:
 //   mc_gemv_{i4|i8|w}_{bfloat|float}[_fast]_p{PRO}_e{EPI}
 //   PRO 0 = x as is, 1 = rmsnorm(x) on the way into LDS
-//   EPI 0 = store, 1 = residual add, 2 = silu(w1 x) * (w3 x), 3 = gelu(w1 x) * (w3 x)
+//   EPI 0 = store, 1 = residual add, 2 = silu(w1 x) * (w3 x), 3 = gelu(w1 x) * (w3 x),
+//       4 = wq|wk|wv with RoPE + sink-cache write (`res` carries a qkv_epilogue*)
 #include "gemv.h"
 
 using namespace mc;
@@ -20,7 +21,8 @@ using namespace mc::gemv;
     MC_GEMV(PFX##_p1_e0, WF, T, QM, 1, 0)      \
     MC_GEMV(PFX##_p0_e1, WF, T, QM, 0, 1)      \
     MC_GEMV(PFX##_p1_e2, WF, T, QM, 1, 2)      \
-    MC_GEMV(PFX##_p1_e3, WF, T, QM, 1, 3)
+    MC_GEMV(PFX##_p1_e3, WF, T, QM, 1, 3)      \
+    MC_GEMV(PFX##_p1_e4, WF, T, QM, 1, 4)
 
 MC_GEMV_SET(mc_gemv_i4_bfloat, WF_I4, BF, Q_EXACT)
 MC_GEMV_SET(mc_gemv_i4_bfloat_fast, WF_I4, BF, Q_FAST)

@@ -1,6 +1,8 @@
 // Device-side fill of synthetic weights straight into the packed HBM layouts (see gemv.h).
 // `map` selects how a destination row maps to a (matrix, source row) pair:
-//   0 plain: (m0, r)      1 qkv: rows [0,n0) -> (m0, r), [n0,n0+n1) -> (m0+1, r-n0), rest -> (m0+2, ..)
+//   0 plain: (m0, r)      1 qkv: rows [0,n0) -> (m0, r'), [n0,n0+n1) -> (m0+1, r'), rest -> (m0+2, ..)
+//                              with r' the NATURAL row of packed row r (rotation partners adjacent:
+//                              packed head*hd + 2j + e <-> natural head*hd + j + e*hd/2; hd = map >> 8)
 //   2 interleave: row 2i -> (m0, i), row 2i+1 -> (m0+2, i)            (w1 | w3)
 #include "common.h"
 #include "synth.h"
@@ -10,10 +12,14 @@ using namespace mc;
 __device__ __forceinline__ void
 map_row(uint32_t map, uint32_t m0, uint32_t n0, uint32_t n1, uint32_t r, uint32_t& m, uint32_t& sr)
 {
-    if (map == 1) {
-        if (r < n0) { m = m0; sr = r; }
-        else if (r < n0 + n1) { m = m0 + 1; sr = r - n0; }
-        else { m = m0 + 2; sr = r - n0 - n1; }
+    if ((map & 0xFF) == 1) {
+        const uint32_t hd = map >> 8;
+        if (r < n0 + n1) {
+            const uint32_t lr = r < n0 ? r : r - n0;
+            const uint32_t head = lr / hd, w = lr % hd;
+            m = r < n0 ? m0 : m0 + 1;
+            sr = head * hd + (w >> 1) + (w & 1) * (hd / 2);
+        } else { m = m0 + 2; sr = r - n0 - n1; }
     } else if (map == 2) {
         m = (r & 1) ? m0 + 2 : m0;
         sr = r >> 1;

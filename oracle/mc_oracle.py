@@ -42,6 +42,8 @@ def lib() -> C.CDLL:
         _lib.mco_model_create.restype = C.c_void_p
         _lib.mco_model_step.restype = C.c_int32
         _lib.mco_model_get_kv.restype = C.c_int32
+        # small test shapes: a handful of threads beats one OpenMP team per host core
+        _lib.mco_set_num_threads(C.c_int(min(8, os.cpu_count() or 1)))
     return _lib
 
 

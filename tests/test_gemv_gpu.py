@@ -125,7 +125,14 @@ def test_gemv_fused_qkv_rows_and_rmsnorm_prologue(acc, holder, dt):
     nw = lw["attention_norm"]
     xn = np.zeros((1, dim), dtype=mo.np_dtype(dt))
     mo.rmsnorm(dt, L((1, dim)), xn, L((1, dim)), x.reshape(1, dim), L((dim,)), nw, 1e-5, 0.0)
-    ref = np.concatenate([oracle_linear(dt, lw[k], xn.reshape(-1)) for k in ("wq", "wk", "wv")])
+    # q and k rows are stored with the rotation partners (j, j + hd/2) adjacent (gemv.h)
+    def packed(y, hd):
+        y = y.reshape(-1, 2, hd // 2)          # [head, e, j]
+        return np.ascontiguousarray(y.transpose(0, 2, 1)).reshape(-1)  # [head, j, e]
+    hd = cfg["head_dim"]
+    ref = np.concatenate([packed(oracle_linear(dt, lw["wq"], xn.reshape(-1)), hd),
+                          packed(oracle_linear(dt, lw["wk"], xn.reshape(-1)), hd),
+                          oracle_linear(dt, lw["wv"], xn.reshape(-1))])
     wptr, sptr, rows, inf, ng = dec.weight_ptrs(0, "qkv")
     got = run_gemv(acc, gemv_name(fmt, dt, 1, 0), wptr, sptr, x, rows, rows, inf, 32, dt, norm=nw)
     if dt == F32:
@@ -211,8 +218,11 @@ def test_synthetic_weights_match_host_generator(acc):
                 quad = sb.download(np.uint16, ng * 4, offset=(int(r) // 4) * ng * 4 * 2)
                 sc = quad.reshape(ng, 4)[:, int(r) % 4]
                 if name == "qkv":
-                    if r < H * hd: m, sr = layer * 16 + 0, r
-                    elif r < (H + KV) * hd: m, sr = layer * 16 + 1, r - H * hd
+                    def natural(lr):  # packed row head*hd + 2j + e -> natural head*hd + j + e*hd/2
+                        head, w = lr // hd, lr % hd
+                        return head * hd + (w >> 1) + (w & 1) * (hd // 2)
+                    if r < H * hd: m, sr = layer * 16 + 0, natural(r)
+                    elif r < (H + KV) * hd: m, sr = layer * 16 + 1, natural(r - H * hd)
                     else: m, sr = layer * 16 + 2, r - (H + KV) * hd
                 elif name == "w13":
                     m, sr = layer * 16 + (6 if r & 1 else 4), r >> 1
