@@ -406,7 +406,19 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
                 t.w[r] = make_uint4(lane * 0x01010101u + off, rg, c * 0x11111111u, r);
                 t.s[r] = T::bytes == 2 ? 0x3F803F80u : 0x3F800000u;
             } else {
-                t.w[r] = *reinterpret_cast<const uint4*>(base + (size_t)row * rowb + off);
+                // weights are read exactly once per token: non-temporal loads keep them from
+                // displacing the activation rows / KV lines other kernels re-read from L2
+                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+#ifndef MC_GEMV_NT
+#define MC_GEMV_NT 0 // A/B on MI355X: +2 % on the 60 MB w1|w3 stream, -5..-10 % on the 8-30 MB matrices
+#endif
+                if (MC_GEMV_NT) {
+                    const u32x4 v = __builtin_nontemporal_load(
+                        reinterpret_cast<const u32x4*>(base + (size_t)row * rowb + off));
+                    t.w[r] = make_uint4(v.x, v.y, v.z, v.w);
+                } else {
+                    t.w[r] = *reinterpret_cast<const uint4*>(base + (size_t)row * rowb + off);
+                }
             }
         }
         if (WF != WF_T && QM != Q_DBG_NOLOAD) {
