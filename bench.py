@@ -153,11 +153,17 @@ def main():
         print("bench.py: steps + warmup must not exceed seq-len", file=sys.stderr)
         sys.exit(2)
 
-    # queue on torch's current stream so RCCL hops are ordered against the kernels by torch
-    stream = torch.cuda.current_stream().cuda_stream if world > 1 else None
-    acc = mc.HardwareAccelerator(ordinal=local_rank, stream=stream)
+    # N > 1: the decoder's queue adopts a torch-owned (non-default) stream that is also the current
+    # stream for the RCCL hops, so torch orders send/recv against the kernels
+    tstream = torch.cuda.Stream(device=local_rank) if world > 1 else None
+    if tstream is not None:
+        torch.cuda.set_stream(tstream)
+    acc = mc.HardwareAccelerator(ordinal=local_rank,
+                                 stream=tstream.cuda_stream if tstream is not None else None)
     L = m["n_layers"]
-    lb, le = rank * L // world, (rank + 1) * L // world
+    from metalchat_amd.pipeline import layer_range
+
+    lb, le = layer_range(rank, world, L)
     dec = mc.Decoder(acc, dtype=dtype, family=mc.FAMILY_LLAMA3, max_seq_len=S,
                      attn_scale=float(1.0 / np.sqrt(m["head_dim"])), layer_begin=lb, layer_end=le,
                      weight_format=wfmt, group_size=(args.group if args.wbits != 16 else 0),
@@ -194,29 +200,25 @@ def main():
         h_out = torch.as_tensor(_Raw(dec.hidden_out_ptr(), m["dim"], tt), device=f"cuda:{local_rank}")
         h_in = torch.as_tensor(_Raw(dec.hidden_in_ptr(), m["dim"], tt), device=f"cuda:{local_rank}")
         tok_t = torch.zeros(1, dtype=torch.int32, device=f"cuda:{local_rank}")
+        from metalchat_amd.pipeline import pipelined_decode
+
+        def stage(token, pos):
+            if rank > 0:
+                torch.cuda.current_stream().synchronize()  # inbound row landed
+            nt = dec.step(token, pos, hidden_in=dec.hidden_in_ptr() if rank > 0 else None,
+                          sync=(rank == world - 1))
+            acc.wait()  # outbound row complete before the hop is enqueued
+            return nt if rank == world - 1 else None
 
         def run(start, n, tok):
-            for i in range(n):
-                pos = start + i
-                if rank > 0:
-                    dist.recv(h_in, src=rank - 1)
-                nt = dec.step(tok if rank == 0 else -1, pos,
-                              hidden_in=dec.hidden_in_ptr() if rank > 0 else None,
-                              sync=(rank == world - 1))
-                if rank < world - 1:
-                    dist.send(h_out, dst=rank + 1)
-                # token hop back to the first stage
-                if rank == world - 1:
-                    tok_t.fill_(nt)
-                    dist.send(tok_t, dst=0)
-                elif rank == 0:
-                    dist.recv(tok_t, src=world - 1)
-                    tok = int(tok_t.item())
-            return tok
+            toks = pipelined_decode(dist, rank, world, h_in, h_out, tok_t, stage, tok, start, n)
+            return toks[-1] if toks else tok
 
         tok = 1
-        tok = run(0, fill, tok)
-        tok = run(fill, W, tok)
+        if fill > 0:
+            tok = run(0, fill, tok)
+        if W > 0:
+            tok = run(fill, W, tok)
         sync_all()
         t0 = time.perf_counter()
         tok = run(fill + W, K, tok)

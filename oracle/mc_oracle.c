@@ -630,8 +630,14 @@ sink_cache_update(mco_model* m, void* cache, const float* new_row, int32_t start
     return start_pos + len;
 }
 
+/* Runs layers [layer_begin, layer_end) of one step.  The first stage embeds `token`; other stages
+ * read the hidden row from hidden_in (T[dim]).  The last stage returns the greedy token (and the
+ * logits); other stages write the hidden row to hidden_out and return -1.  This is how a layer
+ * pipeline over several devices splits nn::llama3::operator() (include/metalchat/nn/llama.h:113-134):
+ * the only state that crosses a stage boundary is the hidden row. */
 int32_t
-mco_model_step(mco_model* m, int32_t token, int32_t start_pos, void* logits_out)
+mco_model_step_range(mco_model* m, int32_t token, int32_t start_pos, int32_t layer_begin,
+                     int32_t layer_end, const void* hidden_in, void* hidden_out, void* logits_out)
 {
     const mco_model_options* o = &m->opt;
     const int dt = o->dtype;
@@ -658,14 +664,16 @@ mco_model_step(mco_model* m, int32_t token, int32_t start_pos, void* logits_out)
     float* fsin = (float*)malloc(sizeof(float) * half * 2);
 
     /* embedding (nn/embedding.h:82-86; quantization/lora.h:161-170 dequantises the table once) */
-    if (m->emb_kind == 0) {
+    if (layer_begin > 0) {
+        for (int32_t j = 0; j < dim; j++) x[j] = ld(dt, hidden_in, (size_t)j);
+    } else if (m->emb_kind == 0) {
         for (int32_t j = 0; j < dim; j++) x[j] = ld(dt, m->emb_weight, (size_t)token * dim + j);
     } else {
         const int8_t* qw = (const int8_t*)m->emb_weight + (size_t)token * dim;
         const float s = rt(dt, m->emb_scales[token]);
         for (int32_t j = 0; j < dim; j++) x[j] = rt(dt, (float)qw[j] * s);
     }
-    if (o->family == 1) { /* nn/gemma.h:115 */
+    if (o->family == 1 && layer_begin == 0) { /* nn/gemma.h:115 */
         const float sc = rt(dt, sqrtf((float)dim));
         for (int32_t j = 0; j < dim; j++) x[j] = rt(dt, x[j] * sc);
     }
@@ -681,7 +689,7 @@ mco_model_step(mco_model* m, int32_t token, int32_t start_pos, void* logits_out)
     }
     const float scale_T = rt(dt, o->attn_scale); /* attention.h:148 _M_scale(options.scale) is a T */
 
-    for (int32_t li = 0; li < o->n_layers; li++) {
+    for (int32_t li = layer_begin; li < layer_end; li++) {
         const mco_layer_weights* L = &m->layers[li];
         /* transformer.h:130 */
         rmsnorm_row(dt, x, L->attention_norm, dim, o->norm_eps, mu, hn);
@@ -767,20 +775,31 @@ mco_model_step(mco_model* m, int32_t token, int32_t start_pos, void* logits_out)
         memcpy(m->hidden_taps + (size_t)(li + 1) * dim, x, sizeof(float) * dim);
     }
 
-    /* llama.h:128-133 */
-    rmsnorm_row(dt, x, m->final_norm, dim, o->norm_eps, mu, hn);
-    float* logits = (float*)malloc(sizeof(float) * o->vocab);
-    linear_apply(dt, &m->output, hn, logits);
-    int32_t best = 0;
-    for (int32_t i = 1; i < o->vocab; i++)
-        if (logits[i] > logits[best]) best = i;
-    if (logits_out)
-        for (int32_t i = 0; i < o->vocab; i++) st(dt, logits_out, (size_t)i, logits[i]);
+    int32_t best = -1;
+    if (layer_end == o->n_layers) {
+        /* llama.h:128-133 */
+        rmsnorm_row(dt, x, m->final_norm, dim, o->norm_eps, mu, hn);
+        float* logits = (float*)malloc(sizeof(float) * o->vocab);
+        linear_apply(dt, &m->output, hn, logits);
+        best = 0;
+        for (int32_t i = 1; i < o->vocab; i++)
+            if (logits[i] > logits[best]) best = i;
+        if (logits_out)
+            for (int32_t i = 0; i < o->vocab; i++) st(dt, logits_out, (size_t)i, logits[i]);
+        free(logits);
+    } else if (hidden_out) {
+        for (int32_t j = 0; j < dim; j++) st(dt, hidden_out, (size_t)j, x[j]);
+    }
 
-    free(logits);
     free(x); free(hn); free(q); free(k); free(v); free(qr); free(kr); free(att); free(proj);
     free(h1); free(g1); free(g3); free(ff); free(scores); free(partial); free(fcos); free(fsin);
     return best;
+}
+
+int32_t
+mco_model_step(mco_model* m, int32_t token, int32_t start_pos, void* logits_out)
+{
+    return mco_model_step_range(m, token, start_pos, 0, m->opt.n_layers, NULL, NULL, logits_out);
 }
 
 void

@@ -139,6 +139,12 @@ void mco_model_destroy(mco_model* m);
 /* One reference transform(token, start_pos) with len = 1.  logits_out: T[vocab] (may be NULL).
  * Returns the greedy argmax (first maximum) of the logits. */
 int32_t mco_model_step(mco_model* m, int32_t token, int32_t start_pos, void* logits_out);
+/* One pipeline stage of a step: layers [layer_begin, layer_end).  Stage 0 embeds `token`, later
+ * stages read hidden_in (T[dim]); the last stage returns the greedy token, earlier ones write
+ * hidden_out (T[dim]) and return -1. */
+int32_t mco_model_step_range(mco_model* m, int32_t token, int32_t start_pos, int32_t layer_begin,
+                             int32_t layer_end, const void* hidden_in, void* hidden_out,
+                             void* logits_out);
 /* Debug taps: copy the hidden row after layer `layer` (-1 = embedding output) of the LAST step. */
 void mco_model_get_hidden(const mco_model* m, int32_t layer, void* out_T_dim);
 /* Logical KV view of layer `layer` after the last step: [n_valid, n_kv_heads, head_dim] of T,

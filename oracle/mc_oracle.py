@@ -41,6 +41,7 @@ def lib() -> C.CDLL:
         _lib.mco_f32_to_bf16.argtypes = [C.c_float]
         _lib.mco_model_create.restype = C.c_void_p
         _lib.mco_model_step.restype = C.c_int32
+        _lib.mco_model_step_range.restype = C.c_int32
         _lib.mco_model_get_kv.restype = C.c_int32
         # small test shapes: a handful of threads beats one OpenMP team per host core
         _lib.mco_set_num_threads(C.c_int(min(8, os.cpu_count() or 1)))
@@ -265,6 +266,17 @@ class Model:
         logits = np.empty(self.cfg["vocab"], dtype=np_dtype(dt)) if want_logits else None
         tok = lib().mco_model_step(self._h, C.c_int32(token), C.c_int32(start_pos), _p(logits))
         return tok, logits
+
+    def step_range(self, token: int, start_pos: int, layer_begin: int, layer_end: int,
+                   hidden_in=None):
+        """One pipeline stage; returns (token or -1, hidden_out or None)."""
+        dt = self.cfg["dtype"]
+        last = layer_end == self.cfg["n_layers"]
+        hout = None if last else np.empty(self.cfg["dim"], dtype=np_dtype(dt))
+        tok = lib().mco_model_step_range(self._h, C.c_int32(token), C.c_int32(start_pos),
+                                         C.c_int32(layer_begin), C.c_int32(layer_end),
+                                         _p(hidden_in), _p(hout), None)
+        return tok, hout
 
     def hidden(self, layer: int) -> np.ndarray:
         out = np.empty(self.cfg["dim"], dtype=np_dtype(self.cfg["dtype"]))

@@ -1,0 +1,94 @@
+"""The N > 1 layer-pipeline protocol (metalchat_amd/pipeline.py) over gloo on CPU, world_size 2 and
+3, with the CPU oracle as the stage compute: the pipelined greedy tokens must equal the
+single-process oracle's (bit-exact integer path), and the layer split must cover every layer once."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_layer_range_covers_all_layers():
+    from metalchat_amd.pipeline import layer_range
+
+    for n_layers in (1, 2, 22, 32, 80):
+        for world in (1, 2, 3, 4, 8):
+            if world > n_layers:
+                continue
+            got = [layer_range(r, world, n_layers) for r in range(world)]
+            assert got[0][0] == 0 and got[-1][1] == n_layers
+            for a, b in zip(got, got[1:]):
+                assert a[1] == b[0]
+            sizes = [b - a for a, b in got]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _worker(rank, world, port, n_tokens, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+
+    import modelgen as mg
+    from metalchat_amd.pipeline import layer_range, pipelined_decode
+    from oracle import mc_oracle as mo
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mo.set_num_threads(2)
+    cfg = mg.tiny_cfg(mg.BF16, n_layers=3, max_seq_len=16)
+    weights = mg.make_model(cfg, seed=31, quant="i4", group=32)
+    om = mo.Model(cfg, weights)  # every rank holds the weights; it only runs its own layers
+    lb, le = layer_range(rank, world, cfg["n_layers"])
+    h_in = torch.zeros(cfg["dim"], dtype=torch.int16)
+    h_out = torch.zeros(cfg["dim"], dtype=torch.int16)
+    tok_buf = torch.zeros(1, dtype=torch.int32)
+
+    def step(token, pos):
+        hin = h_in.numpy().view(np.uint16) if rank > 0 else None
+        tok, hout = om.step_range(token, pos, lb, le, hidden_in=hin)
+        if hout is not None:
+            h_out.copy_(torch.from_numpy(hout.view(np.int16)))
+        return tok if le == cfg["n_layers"] else None
+
+    toks = pipelined_decode(dist, rank, world, h_in, h_out, tok_buf, step, 5, 0, n_tokens)
+    if rank == 0:
+        q.put(toks)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_pipelined_tokens_equal_single_process(world):
+    import torch.multiprocessing as mp
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import modelgen as mg
+    from oracle import mc_oracle as mo
+
+    n_tokens = 20  # crosses max_seq_len 16: the sink-cache roll happens on every stage
+    cfg = mg.tiny_cfg(mg.BF16, n_layers=3, max_seq_len=16)
+    weights = mg.make_model(cfg, seed=31, quant="i4", group=32)
+    om = mo.Model(cfg, weights)
+    tok, ref = 5, []
+    for pos in range(n_tokens):
+        tok, _ = om.step(tok, pos, want_logits=False)
+        ref.append(tok)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_tokens, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    toks = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert toks == ref
