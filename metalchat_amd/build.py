@@ -44,7 +44,10 @@ def build_kernels(force: bool = False) -> str:
     os.makedirs(LIB, exist_ok=True)
     if force or _stale(HSACO, KERNEL_SOURCES):
         cmd = [hipcc(), "--offload-arch=gfx950", "--genco", "--no-gpu-bundle-output", "-O3",
-               "-std=c++17", "-fno-slp-vectorize", "-o", HSACO, KERNEL_SOURCES[0]]
+               "-std=c++17", "-fno-slp-vectorize",
+               # a*b+c stays two roundings unless the source says fma: elementwise results then
+               # match the CPU oracle (built with -ffp-contract=off) bit for bit
+               "-ffp-contract=off", "-o", HSACO, KERNEL_SOURCES[0]]
         subprocess.check_call(cmd, cwd=os.path.join(CSRC, "kernels"))
     return HSACO
 
@@ -58,8 +61,25 @@ def build_host(force: bool = False) -> str:
     return SO
 
 
+def build_shim_test(force: bool = False) -> str:
+    """tests/cpp/test_shim: a plain g++ program over include/metalchat_hip.hpp -- host code above
+    the C ABI needs no HIP headers."""
+    root = os.path.dirname(HERE)
+    src = os.path.join(root, "tests", "cpp", "test_shim.cc")
+    out = os.path.join(root, "tests", "cpp", "test_shim")
+    deps = [src, os.path.join(root, "include", "metalchat_hip.hpp"),
+            os.path.join(root, "include", "metalchat_hip.h"), SO]
+    if force or _stale(out, deps):
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-I" + os.path.join(root, "include"), src,
+                               "-o", out, "-L" + LIB, "-lmetalchat_hip",
+                               "-Wl,-rpath," + LIB, "-Wl,-rpath,/opt/rocm/lib", "-pthread"])
+    return out
+
+
 def build_all(force: bool = False):
-    return build_kernels(force), build_host(force)
+    r = build_kernels(force), build_host(force)
+    build_shim_test(force)
+    return r
 
 
 if __name__ == "__main__":

@@ -113,14 +113,16 @@ def test_rmsnorm_and_softmax(acc, dt):
     mo.rmsnorm(dt, mo.layout((rows, dim)), ref, mo.layout((rows, dim)), x, mo.layout((dim,)), w, 1e-5, 0.0)
     parity.check(dt, got, ref.reshape(-1), rel=1e-5 if dt == F32 else 1e-3, max_ulp=1, max_frac=0.01,
                  scale_aware=False, what="rmsnorm")
-    # rmsnorm of ones with w = 3 is exactly 3 (test_kernel_rmsnorm.cc:18-37)
+    # rmsnorm of ones with w = 3: exactly 3 in bf16 (test_kernel_rmsnorm.cc:18-37); in f32 the
+    # eps shows: 3 / sqrt(1 + 1e-5)
     ones, w3 = mo.encode(dt, np.ones((60, 7), np.float32)), mo.encode(dt, np.full(7, 3.0, np.float32))
     out = acc.alloc(60 * 7 * 4)
     mc.KernelTask(k, (7 * 60, 1, 1), (7, 1, 1),
                   [L((60, 7)), out, L((60, 7)), acc.to_device(ones), L((7,)), acc.to_device(w3),
                    np.float32(1e-5), np.float32(0.0), np.uint32(1)])()
     acc.wait()
-    assert np.all(mo.decode(dt, out.download(mo.np_dtype(dt), 420)) == 3.0)
+    got3 = mo.decode(dt, out.download(mo.np_dtype(dt), 420))
+    assert np.all(got3 == (3.0 if dt == BF16 else np.float32(3.0) * (np.float32(1.0) / np.sqrt(np.float32(1.0) + np.float32(1e-5)))))
 
     k = acc.load("softmax", TN[dt])
     rows, dim = 32, 2048
