@@ -71,6 +71,7 @@ mc_device_create(int32_t ordinal, mc_device** out)
         return hip_fail(e, "hipGetDeviceProperties");
     }
     dev->name = dev->prop.name;
+    if (dev->name.empty()) dev->name = std::string("AMD ") + dev->prop.gcnArchName; // no amdgpu.ids on the box
     MC_HIP(hipSetDevice(ordinal));
     *out = dev;
     return MC_OK;
