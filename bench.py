@@ -74,6 +74,31 @@ def algorithmic_bytes(m, wbits, group, seq_len, tbytes):
                 total=w + kv_read + kv_write + dim * tbytes, p_mm=p_mm)
 
 
+def dec_kernel_name(args):
+    """Host name of the dominant kernel for this configuration (gemv_kernels.hip)."""
+    fmt = {4: "i4", 8: "i8", 16: "w"}[args.wbits]
+    t = "bfloat" if args.dtype == "bf16" else "float"
+    fast = "_fast" if (args.qmode == "fast" and args.wbits == 4 and args.dtype == "bf16") else ""
+    return f"mc_gemv_{fmt}_{t}{fast}_p1_e2"
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the newest committed PMC summary
+    (profiles/rNN_pmc_traffic.json, produced by tools/profile_round.sh with separate rocprofv3
+    --pmc FETCH_SIZE / WRITE_SIZE passes and the gfx950 correction).  Counters cannot be read
+    from inside this process, so this is the figure of the last profiled run, or null."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return None
+    try:
+        k = json.load(open(files[-1]))["kernels"].get(kernel)
+        return k["hbm_bytes_per_launch"] if k else None
+    except Exception:
+        return None
+
+
 def cpu_baseline(args, m, tbytes):
     """The oracle (CPU restatement of the reference op sequence) timed on this box's host cores on
     a bounded sample: a 2-layer slice of the same shapes + the full output head, a few tokens,
@@ -127,18 +152,22 @@ def main():
                   f"--nproc-per-node {args.gpus}", file=sys.stderr)
             sys.exit(2)
     import numpy as np
-    import torch
 
     import metalchat_amd as mc
 
-    if not torch.cuda.is_available():
-        print("bench.py: no GPU visible (there is no CPU fallback for the product path)", file=sys.stderr)
-        sys.exit(2)
-    torch.cuda.set_device(local_rank)
+    # N = 1 needs no torch at all: the C ABI owns device memory, stream and events (torch bundles
+    # its own ROCm runtime, which also keeps rocprofv3 --pmc from attaching).  N > 1 uses
+    # torch.distributed over RCCL for the stage hops.
+    torch = None
     dist = None
     if world > 1:
+        import torch
         import torch.distributed as dist_mod
 
+        if not torch.cuda.is_available():
+            print("bench.py: no GPU visible (there is no CPU fallback for the product path)", file=sys.stderr)
+            sys.exit(2)
+        torch.cuda.set_device(local_rank)
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world,
@@ -174,9 +203,10 @@ def main():
     fill = S - K - W  # context decoded (untimed) before warm-up so the timed tokens end at S
 
     def sync_all():
+        # barrier + device synchronize on both sides of the timed region
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
         acc.wait()
 
     if world == 1:
@@ -256,7 +286,8 @@ def main():
         ms_all, by_all, ln_all = dec.time_gemv("all", reps)
         out["roofline"] = {
             "bound": "hbm", "kernel": "mc_gemv (w1|w3 fused, per launch)", "achieved": achieved,
-            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": pmc_traffic(dec_kernel_name(args)),
             "bytes_per_launch": by / ln, "avg_launch_us": per * 1e3,
             "all_gemv": {"achieved": by_all * reps / (ms_all * 1e-3) / 1e9,
                          "frac": by_all * reps / (ms_all * 1e-3) / 1e9 / HBM_PEAK_GBS,

@@ -238,3 +238,33 @@ def test_synthetic_weights_match_host_generator(acc):
                                             for g in range(ng)], np.float32))
                 parity.exact(sc, exps, f"{name} scales row {r}")
     dec.release()
+
+
+@pytest.mark.parametrize("dt", [F32, BF16])
+@pytest.mark.parametrize("quant,group,dim,ffn", [("i4", 32, 96 * 32, 5632), ("i8", 32, 1056, 2080), (None, 0, 224, 352)])
+def test_gemv_ragged_rows_and_row_tails(acc, holder, dt, quant, group, dim, ffn):
+    """Edge cases of the tiling: `in` not a multiple of the 64-lane chunk (Gemma dim 3072 and
+    TinyLlama ffn 5632 with int4: chunk 2048), and an output row count that is not a multiple of
+    the four rows a wavefront owns (vocab-like 250 rows through the head)."""
+    import metalchat_amd as mc
+
+    cfg = mg.tiny_cfg(dt, dim=dim, n_heads=2, n_kv_heads=1, head_dim=32, ffn_dim=ffn, n_layers=1,
+                      vocab=250, max_seq_len=16)
+    w = mg.make_model(cfg, seed=41, quant=quant, group=group or 32)
+    fmt = {None: 0, "i8": 1, "i4": 2}[quant]
+    dec = mc.Decoder(acc, **mg.decoder_kwargs(cfg, weight_format=fmt, group_size=group))
+    dec.load_model(w)
+    rng = np.random.default_rng(9)
+    lw = w["layers"][0]
+    for name, spec in (("w2", lw["w2"]), ("output", w["output"])):
+        out_f, in_f = spec["weight"].shape
+        x = mo.encode(dt, rng.normal(0, 1, in_f).astype(np.float32))
+        wptr, sptr, rows, inf, ng = dec.weight_ptrs(0 if name == "w2" else -1, name)
+        got = run_gemv(acc, gemv_name(fmt, dt, 0, 0), wptr, sptr, x, out_f, out_f, in_f, group, dt, wgs=7)
+        ref = oracle_linear(dt, dict(spec, group_size=group), x)
+        if dt == F32:
+            parity.check(dt, got, ref, rel=1e-5, what=f"{name} ragged f32")
+        else:
+            parity.check(dt, got, ref, rel=1e-3, max_ulp=1, max_frac=0.01, scale_aware=False,
+                         what=f"{name} ragged bf16")
+    dec.release()
