@@ -533,7 +533,12 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
                 float ss = 0.0f;
 #pragma unroll
                 for (int i = 0; i < MAXP; i++) ss += sumsq(xr[i]);
-                const float tot = block_sum(ss, red);
+                // DPP wave reduction, one LDS slot per wave, one barrier
+                const float wsum_ = wave_sum_dpp(ss);
+                if (lane == 0) red[wave] = wsum_;
+                __syncthreads();
+                float tot = 0.0f;
+                for (uint32_t i = 0; i < nwaves; i++) tot += red[i];
                 const float inv = 1.0f / sqrtf(tot / (float)in + eps);
 #pragma unroll
                 for (int i = 0; i < MAXP; i++) {
@@ -649,6 +654,9 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
         }
     };
 
+    // (A per-workgroup LDS work counter with contiguous row ranges was tried instead of the static
+    // round-robin deal: 20.0 vs 19.0 us on the w1|w3 matrix -- the tail of a launch comes from
+    // uneven service by the memory system across CUs, not from the deal inside a workgroup.)
     // One loop, no drain phase: every step consumes the oldest ring slot (if that tile exists) and
     // refills it with the tile three ahead (live or dead), so the loads stay unconditional and the
     // compiler's s_waitcnt vmcnt(N) always leaves the two younger tiles in flight.
@@ -665,7 +673,10 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
         unsigned long long* tl = const_cast<unsigned long long*>(static_cast<const unsigned long long*>(resp));
         const size_t o = ((size_t)blockIdx.x * nwaves + wave) * 4;
         tl[o] = tl0; tl[o + 1] = tl1; tl[o + 2] = __builtin_amdgcn_s_memrealtime();
-        unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); tl[o + 3] = xcc;
+        unsigned xcc, hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        tl[o + 3] = ((unsigned long long)hwid << 32) | xcc;
     }
 }
 

@@ -38,6 +38,17 @@ for which, kname in (("w13", "mc_gemv_i4_bfloat_dbgtl_p1_e2"), ("wo", "mc_gemv_i
         start, pro, end = (st[:, 0] - t0) / 100.0, (st[:, 1] - st[:, 0]) / 100.0, (st[:, 2] - t0) / 100.0
         body = (st[:, 2] - st[:, 1]) / 100.0
         q = lambda a: [round(float(np.percentile(a, p)), 2) for p in (0, 50, 90, 100)]
+        xcc = (st[:, 3] & 0xF)
+        hwid = (st[:, 3] >> 32)
+        # HW_ID (gfx9): wave_id[3:0] simd_id[5:4] pipe[7:6] cu_id[11:8] sh_id[12] se_id[15:13] ...
+        cu = ((hwid >> 8) & 0xF) | (((hwid >> 12) & 0x1) << 4) | (((hwid >> 13) & 0x7) << 5) | (xcc << 8)
+        wg_cu = cu.reshape(wgs, waves)[:, 0]
+        import collections
+        per_cu = collections.Counter(wg_cu.tolist())
+        hist = collections.Counter(per_cu.values())
+        end_by_n = {n: round(float(np.mean([end.reshape(wgs, waves)[i].max() for i in range(wgs) if per_cu[wg_cu[i]] == n])), 2) for n in hist}
+        end_by_xcd = {int(x): round(float(np.percentile(end[xcc == x], 90)), 2) for x in sorted(set(xcc.tolist()))}
         print(json.dumps(dict(which=which, block=block, wgs=wgs, event_us=round(ms * 1e3, 2),
                               start_us=q(start), prologue_us=q(pro), body_us=q(body), end_us=q(end),
-                              xcds=sorted(set(st[:, 3].tolist())))), flush=True)
+                              cus_used=len(per_cu), wgs_per_cu_hist=dict(hist), wg_end_by_wgs_on_cu=end_by_n,
+                              p90_end_by_xcd=end_by_xcd)), flush=True)
