@@ -197,6 +197,14 @@ void mc_decoder_release(mc_decoder* d);
 mc_status mc_decoder_load_linear(mc_decoder* d, int32_t layer, const char* name,
                                  int32_t weight_format, int32_t out_features, int32_t in_features,
                                  int32_t group_size, const void* weight, const float* scales);
+/* quantization::lora_adaptor of one projection (include/metalchat/quantization/lora.h:17-53,
+ * 119-121): result = T(T(x Wd^T) + T(T(B(A x)) * scale)).  name as in mc_decoder_load_linear
+ * ("wq","wk","wv","wo","w1","w3","w2"); a_T = T[rank * in_features], b_T = T[out_features * rank]
+ * (nn::linear weights, row-major [out, in]).  Adaptors of projections that share a fused GEMV
+ * (wq|wk|wv, w1|w3) must share rank and scale; rank is a multiple of 8. */
+mc_status mc_decoder_load_lora(mc_decoder* d, int32_t layer, const char* name, int32_t rank,
+                               int32_t out_features, int32_t in_features, const void* a_T,
+                               const void* b_T, float scale);
 mc_status mc_decoder_load_vector(mc_decoder* d, int32_t layer, const char* name, int32_t n,
                                  const void* data_T);
 /* Synthetic weights generated ON THE DEVICE from a counter-based hash (bench.py at full model

@@ -40,6 +40,16 @@ struct linear_w {
     int ngroups = 1;
     bool allocated = false;
     std::vector<uint8_t> scales_host; // shadow of the quad-interleaved scale buffer (load path only)
+    // quantization::lora_adaptor(s) of the matrices fused here (quantization/lora.h:17-53): the A
+    // matrices stacked [nseg*rank][in] (a T-format GEMV of its own), B in fused row order
+    // [out][nseg*rank] with zeros outside each row's own adaptor columns, a = T(A x) in lora_vec
+    std::unique_ptr<linear_w> lora_a;
+    void* lora_b = nullptr;
+    std::vector<uint8_t> lora_b_host; // load path only
+    void* lora_vec = nullptr;
+    int lora_rank = 0;      // rank of one adaptor
+    int lora_cols = 0;      // nseg * rank
+    float lora_scale = 0.0f;
 };
 
 // mirrors mc::gemv::qkv_epilogue (kernels/gemv.h)
@@ -367,9 +377,16 @@ struct mc_decoder {
         const unsigned kpl = L.fmt == MC_WFMT_I4 ? 32 : (L.fmt == MC_WFMT_I8 ? 16 : (tb == 2 ? 8 : 4));
         const unsigned chunk = 64 * kpl;
         const unsigned lds = (unsigned)((size_t)((L.in + chunk - 1) / chunk) * chunk * tb + 64);
+        if (L.lora_cols) {
+            // a = T(A x): the stacked adaptor inputs through the same kernel family (same prologue,
+            // so a pre-norm GEMV and its adaptor see the identical normalised row)
+            mc_status s = gemv(*L.lora_a, pro, 0, x, L.lora_vec, nullptr, norm_w, mu);
+            if (s != MC_OK) return s;
+        }
         return launch(name, wgs, 1, 1, gemv_block, lds,
                       pack(L.w, L.scales, x, y, res, norm_w, (uint32_t)L.out, (uint32_t)L.in,
-                           (uint32_t)L.group, cfg.norm_eps, mu));
+                           (uint32_t)L.group, cfg.norm_eps, mu, (const void*)L.lora_vec,
+                           (const void*)L.lora_b, (uint32_t)L.lora_cols, L.lora_scale));
     }
 
     mc_status
@@ -690,6 +707,68 @@ mc_decoder_load_linear(mc_decoder* d, int32_t layer, const char* name, int32_t f
     s = d->alloc_linear(*sl.lin, fmt, sl.total, sl.in, group);
     if (s != MC_OK) return s;
     return d->upload_rows(*sl.lin, sl.row0, sl.stride, sl.rows, weight, scales, sl.perm);
+}
+
+mc_status
+mc_decoder_load_lora(mc_decoder* d, int32_t layer, const char* name, int32_t rank,
+                     int32_t out_f, int32_t in_f, const void* a_T, const void* b_T, float scale)
+{
+    if (!d || !name || !a_T || !b_T) return fail(MC_ERR_INVALID_ARGUMENT, "mc_decoder_load_lora: null argument");
+    if (rank <= 0 || rank % 8 != 0 || rank > 256)
+        return fail(MC_ERR_INVALID_ARGUMENT, "decoder: LoRA rank must be a multiple of 8 in [8, 256]");
+    MC_HIP(hipSetDevice(d->dev->ordinal));
+    const mc_decoder_config& c = d->cfg;
+    const std::string n = name;
+    const int H = c.n_heads, KV = c.n_kv_heads, hd = c.head_dim;
+    layer_w* L;
+    mc_status s = find_layer(d, layer, &L);
+    if (s != MC_OK) return s;
+    struct slot { linear_w* lin; int total, row0, stride, rows, in, perm, seg, nseg; };
+    slot sl{};
+    if (n == "wq") sl = {&L->qkv, (H + 2 * KV) * hd, 0, 1, H * hd, c.dim, hd, 0, 3};
+    else if (n == "wk") sl = {&L->qkv, (H + 2 * KV) * hd, H * hd, 1, KV * hd, c.dim, hd, 1, 3};
+    else if (n == "wv") sl = {&L->qkv, (H + 2 * KV) * hd, (H + KV) * hd, 1, KV * hd, c.dim, 0, 2, 3};
+    else if (n == "wo") sl = {&L->wo, c.dim, 0, 1, c.dim, H * hd, 0, 0, 1};
+    else if (n == "w1") sl = {&L->w13, 2 * c.ffn_dim, 0, 2, c.ffn_dim, c.dim, 0, 0, 2};
+    else if (n == "w3") sl = {&L->w13, 2 * c.ffn_dim, 1, 2, c.ffn_dim, c.dim, 0, 1, 2};
+    else if (n == "w2") sl = {&L->w2, c.dim, 0, 1, c.dim, c.ffn_dim, 0, 0, 1};
+    else return fail(MC_ERR_INVALID_ARGUMENT, "decoder: unknown linear '" + n + "'");
+    if (out_f != sl.rows || in_f != sl.in)
+        return fail(MC_ERR_INVALID_ARGUMENT, "decoder: '" + n + "' adaptor shape mismatch");
+    linear_w& W = *sl.lin;
+    const int cols = sl.nseg * rank;
+    const size_t tb = d->tb;
+    if (!W.lora_cols) {
+        W.lora_a.reset(new linear_w());
+        s = d->alloc_linear(*W.lora_a, MC_WFMT_T, cols, sl.in, 0);
+        if (s != MC_OK) return s;
+        MC_HIP(hipMemset(W.lora_a->w, 0, W.lora_a->w_bytes));
+        s = d->alloc(&W.lora_b, (size_t)sl.total * cols * tb, true);
+        if (s != MC_OK) return s;
+        s = d->alloc(&W.lora_vec, (size_t)cols * tb, true);
+        if (s != MC_OK) return s;
+        W.lora_rank = rank;
+        W.lora_cols = cols;
+        W.lora_scale = scale;
+    } else if (W.lora_rank != rank || W.lora_scale != scale) {
+        return fail(MC_ERR_INVALID_ARGUMENT,
+                    "decoder: adaptors of matrices fused into one GEMV must share rank and scale");
+    }
+    // A rows of this adaptor: block `seg` of the stacked matrix
+    s = d->upload_rows(*W.lora_a, sl.seg * rank, 1, rank, a_T, nullptr);
+    if (s != MC_OK) return s;
+    // B[o][:] -> fused row dest(o), columns [seg*rank, (seg+1)*rank)
+    auto dest = [&](int r) -> size_t {
+        if (!sl.perm) return (size_t)sl.row0 + (size_t)r * sl.stride;
+        const int head = r / sl.perm, w = r % sl.perm, half = sl.perm / 2;
+        return (size_t)sl.row0 + (size_t)head * sl.perm + 2 * (w % half) + w / half;
+    };
+    if (W.lora_b_host.size() != (size_t)sl.total * cols * tb) W.lora_b_host.assign((size_t)sl.total * cols * tb, 0);
+    for (int o = 0; o < sl.rows; o++)
+        memcpy(W.lora_b_host.data() + (dest(o) * cols + (size_t)sl.seg * rank) * tb,
+               (const char*)b_T + (size_t)o * rank * tb, (size_t)rank * tb);
+    MC_HIP(hipMemcpy(W.lora_b, W.lora_b_host.data(), W.lora_b_host.size(), hipMemcpyHostToDevice));
+    return MC_OK;
 }
 
 mc_status

@@ -350,7 +350,9 @@ template <int WF, typename T, int QM, int PRO, int EPI, int R>
 __device__ __forceinline__ void
 body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __restrict__ xp,
      void* __restrict__ yp, const void* __restrict__ resp, const void* __restrict__ normp,
-     uint32_t out_rows, uint32_t in, uint32_t group, float eps, float mu)
+     uint32_t out_rows, uint32_t in, uint32_t group, float eps, float mu,
+     const void* __restrict__ lora_ap, const void* __restrict__ lora_bp, uint32_t lora_rank,
+     float lora_scale)
 {
     using F = fmt<WF, T>;
     using S = typename T::S;
@@ -605,6 +607,27 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
             for (int r = 0; r < R; r++) {
                 tot[r] = wave_sum_dpp(acc[r]);
                 acc[r] = 0.0f;
+            }
+            if (lora_rank) {
+                // quantization::lora_linear (quantization/lora.h:119-121):
+                //   result = T(T(x Wd^T) + T(T(B (A x)) * scale)),  A x already rounded to T by the
+                // adaptor launch that ran before this one.  Lane r finishes the adaptation of row r;
+                // B is stored in the fused row order, [out][lora_rank] with zeros outside the
+                // columns of the row's own adaptor (wq|wk|wv and w1/w3 keep separate adaptors).
+                const uint32_t row = crg * R + lane;
+                float ad = 0.0f;
+                if (lane < (uint32_t)R && row < out_rows) {
+                    const S* av = static_cast<const S*>(lora_ap);
+                    const S* bv = static_cast<const S*>(lora_bp) + (size_t)row * lora_rank;
+                    float p = 0.0f;
+                    for (uint32_t i = 0; i < lora_rank; i++) p += T::ld(av[i]) * T::ld(bv[i]);
+                    ad = T::rt(T::rt(p) * T::rt(lora_scale));
+                }
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const float adr = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ad), r));
+                    tot[r] = T::rt(T::rt(tot[r]) + adr);
+                }
             }
             S* y = static_cast<S*>(yp);
             if (EPI == EPI_STORE || EPI == EPI_RESID) {

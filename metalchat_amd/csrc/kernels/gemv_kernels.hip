@@ -3,6 +3,7 @@
 //   PRO 0 = x as is, 1 = rmsnorm(x) on the way into LDS
 //   EPI 0 = store, 1 = residual add, 2 = silu(w1 x) * (w3 x), 3 = gelu(w1 x) * (w3 x),
 //       4 = wq|wk|wv with RoPE + sink-cache write (`res` carries a qkv_epilogue*)
+//   lora_rank != 0: the row results also take the LoRA adaptation T(T(B a) * scale), a = T(A x)
 #include "gemv.h"
 
 using namespace mc;
@@ -11,9 +12,11 @@ using namespace mc::gemv;
 #define MC_GEMV(NAME, WF, T, QM, PRO, EPI)                                                        \
     extern "C" __global__ void __launch_bounds__(512)                                            \
     NAME(const void* w, const void* scales, const void* x, void* y, const void* res,             \
-         const void* norm_w, uint32_t out_rows, uint32_t in, uint32_t group, float eps, float mu) \
+         const void* norm_w, uint32_t out_rows, uint32_t in, uint32_t group, float eps, float mu, \
+         const void* lora_a, const void* lora_b, uint32_t lora_rank, float lora_scale)            \
     {                                                                                             \
-        body<WF, T, QM, PRO, EPI, 4>(w, scales, x, y, res, norm_w, out_rows, in, group, eps, mu); \
+        body<WF, T, QM, PRO, EPI, 4>(w, scales, x, y, res, norm_w, out_rows, in, group, eps, mu,  \
+                                     lora_a, lora_b, lora_rank, lora_scale);                      \
     }
 
 #define MC_GEMV_SET(PFX, WF, T, QM)            \

@@ -102,6 +102,7 @@ def capi() -> C.CDLL:
         "mc_decoder_release": (None, [vp]),
         "mc_decoder_load_linear": (i32, [vp, i32, C.c_char_p, i32, i32, i32, i32, vp, vp]),
         "mc_decoder_load_vector": (i32, [vp, i32, C.c_char_p, i32, vp]),
+        "mc_decoder_load_lora": (i32, [vp, i32, C.c_char_p, i32, i32, i32, vp, vp, C.c_float]),
         "mc_decoder_init_synthetic": (i32, [vp, u64]),
         "mc_decoder_step": (i32, [vp, i32, i32, vp, C.POINTER(i32)]),
         "mc_decoder_generate": (i32, [vp, i32, i32, i32, C.POINTER(i32)]),
@@ -339,6 +340,15 @@ class Decoder:
         data = np.ascontiguousarray(data)
         _check(capi().mc_decoder_load_vector(self._h, layer, name.encode(), data.size, _np_ptr(data)))
 
+    def load_lora(self, layer: int, name: str, a: np.ndarray, b: np.ndarray, scale: float):
+        """a: T[rank, in], b: T[out, rank] (quantization::lora_adaptor, lora.h:17-53)."""
+        a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
+        rank, in_f = a.shape
+        out_f = b.shape[0]
+        assert b.shape[1] == rank
+        _check(capi().mc_decoder_load_lora(self._h, layer, name.encode(), rank, out_f, in_f,
+                                           _np_ptr(a), _np_ptr(b), C.c_float(scale)))
+
     def load_model(self, weights: dict):
         """weights: the dict produced by tests/modelgen.py (reference-native formats)."""
         fmt_of = {0: WFMT_T, 1: None, 2: WFMT_I8}
@@ -352,6 +362,8 @@ class Decoder:
                 else:
                     self.load_linear(li, n, spec["hbm_format"], spec["weight"], spec["scales"],
                                      spec.get("group_size", 0) if spec["kind"] == 1 else 0)
+                if spec.get("lora_a") is not None:
+                    self.load_lora(li, n, spec["lora_a"], spec["lora_b"], spec["lora_scale"])
             for n in ("attention_norm", "ffn_norm", "q_norm", "k_norm", "attention_post_norm",
                       "ffn_post_norm"):
                 if lw.get(n) is not None:

@@ -35,8 +35,18 @@ def make_linear(rng, dt, out_f, in_f, quant, group):
     return dict(kind=1, weight=q, scales=s, group_size=group, hbm_format=fmt)
 
 
+def add_lora(rng, dt, spec, rank, scale=2.0):
+    """Attach a quantization::lora_adaptor (A [rank, in], B [out, rank], lora.h:17-53) to a
+    lora_linear spec; sized so that the adaptation is comparable to the base output."""
+    out_f, in_f = spec["weight"].shape
+    spec["lora_a"] = _enc(dt, rng.uniform(-1.0, 1.0, size=(rank, in_f)) / np.sqrt(in_f))
+    spec["lora_b"] = _enc(dt, rng.uniform(-1.0, 1.0, size=(out_f, rank)) * (0.25 / np.sqrt(rank)))
+    spec["lora_scale"] = float(scale)
+    return spec
+
+
 def make_model(cfg: dict, seed: int = 0, quant=None, group: int = 32, emb_quant: bool = False,
-               head_quant=None):
+               head_quant=None, lora_rank: int = 0, lora_only=None):
     """cfg keys: dtype, family, dim, n_heads, n_kv_heads, head_dim, ffn_dim, n_layers, vocab,
     max_seq_len, rope_theta, norm_eps, attn_scale [, rope_sliding_theta, sliding_stride]."""
     rng = np.random.default_rng(seed)
@@ -56,6 +66,10 @@ def make_model(cfg: dict, seed: int = 0, quant=None, group: int = 32, emb_quant:
             attention_norm=_enc(dt, rng.uniform(0.5, 1.5, dim)),
             ffn_norm=_enc(dt, rng.uniform(0.5, 1.5, dim)),
         )
+        if lora_rank and quant in ("i4", "i8"):
+            for n in ("wq", "wk", "wv", "wo", "w1", "w2", "w3"):
+                if lora_only is None or n in lora_only:
+                    add_lora(rng, dt, lw[n], lora_rank)
         if gemma:
             # gemma norm weights are used as (1 + w): keep w small
             for n, sz in (("attention_norm", dim), ("ffn_norm", dim), ("q_norm", hd), ("k_norm", hd),

@@ -97,6 +97,37 @@ def test_quantised_embedding_and_per_row_head(acc):
     assert agree == 6
 
 
+@pytest.mark.parametrize("dt,only", [(F32, None), (BF16, None), (F32, ("wk", "w3"))])
+def test_qlora_adaptors_match_oracle(acc, dt, only):
+    # quantization::lora_linear with its adaptor: T(T(x Wd^T) + T(T(B(A x)) * scale)), scale 2.0,
+    # on every projection (or only on one member of each fused group: the others must see + 0)
+    cfg = mg.tiny_cfg(dt, max_seq_len=32)
+    weights = mg.make_model(cfg, seed=31, quant="i4", group=32, lora_rank=16, lora_only=only)
+    rel = 1e-4 if dt == F32 else 2e-3
+    agree, _ = run_pair(acc, cfg, weights, 10, dict(weight_format=2, group_size=32),
+                        rel_hidden=rel, rel_logits=rel)
+    assert agree >= (10 if dt == F32 else 9)
+
+
+def test_lora_argument_validation(acc):
+    import metalchat_amd as mc
+
+    cfg = mg.tiny_cfg(F32, n_layers=1)
+    dec = mc.Decoder(acc, **mg.decoder_kwargs(cfg, weight_format=2, group_size=32))
+    a = np.zeros((16, cfg["dim"]), np.float32)
+    b = np.zeros((cfg["dim"], 16), np.float32)
+    dec.load_lora(0, "wo", a, b, 2.0)
+    with pytest.raises(mc.McError, match="shape mismatch"):
+        dec.load_lora(0, "w2", a, b, 2.0)                       # w2 is [dim, ffn]
+    with pytest.raises(mc.McError, match="multiple of 8"):
+        dec.load_lora(0, "wo", a[:12], b[:, :12], 2.0)
+    kq = np.zeros((cfg["n_kv_heads"] * cfg["head_dim"], 16), np.float32)
+    dec.load_lora(0, "wk", a, kq, 2.0)
+    with pytest.raises(mc.McError, match="share rank and scale"):
+        dec.load_lora(0, "wv", a, kq, 1.0)
+    dec.release()
+
+
 @pytest.mark.parametrize("dt", [F32, BF16])
 def test_gemma3_matches_oracle(acc, dt):
     cfg = mg.tiny_cfg(dt, family=1, n_layers=3, rope_sliding_theta=10000.0, sliding_stride=2,

@@ -42,7 +42,7 @@ def gemv_name(fmt, dt, pro, epi, fast=False):
 
 
 def run_gemv(acc, name, wptr, sptr, x_T, out_n, rows, in_f, group, dt, res=None, norm=None,
-             eps=1e-5, mu=0.0, block=256, wgs=64):
+             eps=1e-5, mu=0.0, block=256, wgs=64, lora=None):
     import metalchat_amd as mc
 
     tb = 2 if dt == BF16 else 4
@@ -58,7 +58,10 @@ def run_gemv(acc, name, wptr, sptr, x_T, out_n, rows, in_f, group, dt, res=None,
     lds = (in_f + chunk - 1) // chunk * chunk * tb + 64
     t = mc.KernelTask(k, (wgs * block, 1, 1), (block, 1, 1),
                       [wbuf, sbuf, xb, yb, rb, nb, np.uint32(rows), np.uint32(in_f), np.uint32(group),
-                       np.float32(eps), np.float32(mu)], lds_bytes=lds)
+                       np.float32(eps), np.float32(mu)] +
+                      ([acc.to_device(lora[0]), acc.to_device(lora[1]), np.uint32(lora[0].size),
+                        np.float32(lora[2])] if lora else [None, None, np.uint32(0), np.float32(0)]),
+                      lds_bytes=lds)
     t()
     acc.wait()
     return yb.download(np.uint16 if dt == BF16 else np.float32, out_n)
@@ -179,6 +182,41 @@ def test_gemv_w13_silu_mul_and_residual_epilogues(acc, holder, dt):
         parity.check(dt, got2, ref2, rel=1e-5, what="w2 resid f32")
     else:
         parity.check(dt, got2, ref2, rel=1e-3, max_ulp=1, max_frac=0.01, scale_aware=False, what="w2 resid bf16")
+
+
+@pytest.mark.parametrize("dt", [F32, BF16])
+def test_gemv_lora_adaptation_term(acc, holder, dt):
+    """The row-result hook of lora_linear (quantization/lora.h:119-121) against the reference's op
+    sequence: a = bmm(x, A^T), b = bmm(a, B^T), ad = scalar_mul(b, scale), y = add(x Wd^T, ad)."""
+    L = mo.layout
+    cfg, w, dec, fmt = holder(dt, "i4", 32, seed=27)
+    rng = np.random.default_rng(9)
+    spec = w["layers"][0]["wo"]
+    out_f, in_f = spec["weight"].shape
+    rank, scale = 16, 2.0
+    x = mo.encode(dt, rng.normal(0, 1, in_f).astype(np.float32))
+    A = mo.encode(dt, (rng.uniform(-1, 1, (rank, in_f)) / np.sqrt(in_f)).astype(np.float32))
+    B = mo.encode(dt, (rng.uniform(-1, 1, (out_f, rank)) * 0.1).astype(np.float32))
+    npd = mo.np_dtype(dt)
+    a = np.zeros((1, 1, rank), npd)
+    mo.bmm(dt, L(a.shape), a, L((1, 1, in_f)), x, L((1, in_f, rank), strides=(in_f * rank, 1, in_f)), A)
+    b = np.zeros((1, 1, out_f), npd)
+    mo.bmm(dt, L(b.shape), b, L((1, 1, rank)), a, L((1, rank, out_f), strides=(rank * out_f, 1, rank)), B)
+    ad = np.zeros(out_f, npd)
+    mo.scalar_mul(dt, L((1, out_f)), ad, L((1, out_f)), b.reshape(-1), scale)
+    base = oracle_linear(dt, spec, x)
+    ref = np.zeros(out_f, npd)
+    mo.add(dt, L((1, out_f)), ref, L((1, out_f)), base, L((1, out_f)), ad)
+    wptr, sptr, rows, inf, ng = dec.weight_ptrs(0, "wo")
+    got = run_gemv(acc, gemv_name(fmt, dt, 0, 0), wptr, sptr, x, out_f, out_f, in_f, 32, dt,
+                   lora=(a.reshape(-1), B, scale))
+    if dt == F32:
+        parity.check(dt, got, ref, rel=1e-5, what="lora f32")
+    else:
+        parity.check(dt, got, ref, rel=1e-3, max_ulp=1, max_frac=0.02, what="lora bf16")
+    # rank 0 = no adaptor: the plain result
+    plain = run_gemv(acc, gemv_name(fmt, dt, 0, 0), wptr, sptr, x, out_f, out_f, in_f, 32, dt)
+    assert not np.array_equal(plain, got)
 
 
 def test_gemv_geometry_independent(acc, holder):

@@ -30,7 +30,8 @@ for which, kname in (("w13", "mc_gemv_i4_bfloat_dbgtl_p1_e2"), ("wo", "mc_gemv_i
             lds = (inf + 2047) // 2048 * 2048 * 2 + 64
             t = mc.KernelTask(k, (wgs * block, 1, 1), (block, 1, 1),
                               [acc.wrap(wptr, 1 << 40), acc.wrap(sptr, 1 << 40), x, y, tl, nw,
-                               np.uint32(rows), np.uint32(inf), np.uint32(128), np.float32(1e-5), np.float32(0)],
+                               np.uint32(rows), np.uint32(inf), np.uint32(128), np.float32(1e-5), np.float32(0),
+                               None, None, np.uint32(0), np.float32(0)],
                               lds_bytes=lds)
             acc.timer_begin(); t(); ms = acc.timer_end_ms()
         st = tl.download(np.uint64, wgs * waves * 4).reshape(-1, 4).astype(np.int64)
