@@ -261,6 +261,72 @@ float mc_synth_value(uint64_t seed, uint32_t matrix_id, uint32_t index, int32_t 
  * 8 attention_norm, 9 ffn_norm, 10 q_norm, 11 k_norm, 12 attention_post_norm, 13 ffn_post_norm};
  * 0xFFFF0000 + {0 tok_embeddings, 1 output, 2 norm}. */
 
+/* ================================================================================================
+ * Part 3 -- model files: the data format on the caller side of the decode path.
+ *
+ *   safetensor_document / sharded_safetensor_document
+ *                                   include/metalchat/safetensor.h:534-1030, src/safetensor.cc
+ *   checkpoint adaptors             include/metalchat/huggingface/llama.h:85-171,
+ *                                   include/metalchat/huggingface/gemma.h:56-84,
+ *                                   include/metalchat/reference.h:35-90
+ *   option serializers              src/llama.cc:41-55, src/reference.cc:52-66, src/gemma.cc:20-42
+ *
+ * A document is an ordered list of named tensors over memory-mapped files (host memory; nothing
+ * here touches the GPU until mc_decoder_load_document).  Errors follow the reference: a corrupt or
+ * unreadable file is MC_ERR_RUNTIME ("safetensor_document: header is corrupted, ..."), a missing
+ * name MC_ERR_INVALID_ARGUMENT.
+ * ============================================================================================== */
+typedef struct mc_document mc_document;
+
+typedef struct mc_tensor_info {
+    const char* name;   /* owned by the document */
+    const char* dtype;  /* safetensors spelling: "BF16", "F32", "I8", "I32", ... */
+    int32_t ndim;
+    int64_t shape[8];
+    const void* data;   /* host pointer into the mapped file (or the document's own copy) */
+    size_t nbytes;
+} mc_tensor_info;
+
+enum {
+    MC_CKPT_META_LLAMA3 = 0,       /* reference::llama3_safetensor_serializer (Meta names, wq/wk permuted) */
+    MC_CKPT_HF_LLAMA3 = 1,         /* huggingface::llama3_safetensor_serializer (model.layers.N.self_attn...) */
+    MC_CKPT_META_LLAMA3_QLORA = 2, /* huggingface::llama3_qlora_safetensor_serializer (int8-held int4 + adaptors) */
+    MC_CKPT_HF_GEMMA3 = 3          /* huggingface::gemma3_safetensor_serializer */
+};
+
+mc_status mc_document_create(mc_document** out);                         /* safetensor_document() */
+mc_status mc_document_open(const char* path, mc_document** out);         /* ::open(path) -- src/safetensor.cc:118-136 */
+mc_status mc_document_open_sharded(const char* index_json_path, mc_document** out); /* sharded_...::open */
+void mc_document_release(mc_document* d);
+int32_t mc_document_size(const mc_document* d);                          /* std::distance(begin(), end()) */
+/* Entries in document order (a file's tensors by ascending data offset, src/safetensor.cc:111-115). */
+mc_status mc_document_tensor(const mc_document* d, int32_t index, mc_tensor_info* out);
+mc_status mc_document_find(const mc_document* d, const char* name, mc_tensor_info* out);
+/* insert(name, tensor): the bytes are copied.  src/safetensor.cc:182-200 */
+mc_status mc_document_insert(mc_document* d, const char* name, const char* dtype, int32_t ndim,
+                             const int64_t* shape, const void* data);
+/* insert(name, source): a second name for the same storage.  src/safetensor.cc:203-212 */
+mc_status mc_document_link(mc_document* d, const char* name, const char* source);
+mc_status mc_document_set_metadata(mc_document* d, const char* key, const char* value);
+const char* mc_document_metadata(const mc_document* d, const char* key); /* NULL when absent */
+/* serializer.adapt(document): rename to the reference's parameter paths and link
+ * "output.weight" to "tok_embeddings.weight" (tied head). */
+mc_status mc_document_adapt(mc_document* d, int32_t flavour);
+mc_status mc_document_save(const mc_document* d, const char* path);      /* src/safetensor.cc:264-290 */
+
+/* options_serializer::load: fills family, head geometry, layer count, rope / norm constants,
+ * attn_scale and max_seq_len (1024, as every reference serializer does) from config.json /
+ * params.json text; dim / ffn_dim / vocab when the JSON carries them.  Other fields are left as
+ * the caller set them. */
+mc_status mc_config_from_json(const char* json_text, int32_t flavour, mc_decoder_config* cfg);
+/* Widths the reference takes from the tensors themselves: vocab, dim, ffn_dim, group_size, and
+ * n_layers / layer_end when still 0.  Call on an adapted document. */
+mc_status mc_config_from_document(const mc_document* d, mc_decoder_config* cfg);
+/* serializer.load(document): hands every tensor of the layers this decoder owns to
+ * mc_decoder_load_linear / _vector / _lora (BF16 <-> F32 converted to the decoder's T). */
+mc_status mc_decoder_load_document(mc_decoder* d, const mc_document* doc, int32_t flavour);
+mc_status mc_decoder_get_config(const mc_decoder* d, mc_decoder_config* out);
+
 #ifdef __cplusplus
 }
 #endif

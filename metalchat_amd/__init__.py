@@ -13,4 +13,6 @@ from .runtime import (  # noqa: F401
     BF16, F32, WFMT_T, WFMT_I8, WFMT_I4, QMODE_EXACT, QMODE_FAST, FAMILY_LLAMA3, FAMILY_GEMMA3,
     McError, HardwareAccelerator, Buffer, Kernel, KernelTask, Decoder, DecoderConfig, capi,
     library_path, hsaco_path, layout, make_kernel_grid_2d,
+    Document, TensorInfo, config_from_json, config_from_document,
+    CKPT_META_LLAMA3, CKPT_HF_LLAMA3, CKPT_META_LLAMA3_QLORA, CKPT_HF_GEMMA3,
 )

@@ -21,7 +21,7 @@ SO = os.path.join(LIB, "libmetalchat_hip.so")
 KERNEL_SOURCES = [os.path.join(CSRC, "kernels", f) for f in (
     "metalchat_kernels.hip", "ref_kernels.hip", "gemv_kernels.hip", "decode_kernels.hip",
     "synth_kernels.hip", "common.h", "gemv.h", "synth.h")]
-HOST_SOURCES = [os.path.join(CSRC, f) for f in ("backend.cc", "decoder.cc", "backend_impl.h")] + [
+HOST_SOURCES = [os.path.join(CSRC, f) for f in ("backend.cc", "decoder.cc", "model_io.cc", "json_min.h", "backend_impl.h")] + [
     os.path.join(CSRC, "kernels", "synth.h"),
     os.path.join(os.path.dirname(HERE), "include", "metalchat_hip.h")]
 
@@ -56,7 +56,8 @@ def build_host(force: bool = False) -> str:
     os.makedirs(LIB, exist_ok=True)
     if force or _stale(SO, HOST_SOURCES):
         cmd = [hipcc(), "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function",
-               os.path.join(CSRC, "backend.cc"), os.path.join(CSRC, "decoder.cc"), "-o", SO]
+               os.path.join(CSRC, "backend.cc"), os.path.join(CSRC, "decoder.cc"),
+               os.path.join(CSRC, "model_io.cc"), "-o", SO]
         subprocess.check_call(cmd, cwd=CSRC)
     return SO
 

@@ -647,6 +647,14 @@ find_layer(mc_decoder* d, int32_t layer, layer_w** out)
 }
 
 mc_status
+mc_decoder_get_config(const mc_decoder* d, mc_decoder_config* out)
+{
+    if (!d || !out) return fail(MC_ERR_INVALID_ARGUMENT, "mc_decoder_get_config: null argument");
+    *out = d->cfg;
+    return MC_OK;
+}
+
+mc_status
 mc_decoder_load_linear(mc_decoder* d, int32_t layer, const char* name, int32_t fmt,
                        int32_t out_f, int32_t in_f, int32_t group, const void* weight,
                        const float* scales)

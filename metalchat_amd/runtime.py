@@ -44,6 +44,13 @@ class DecoderConfig(C.Structure):
     ]
 
 
+class TensorInfo(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("dtype", C.c_char_p), ("ndim", C.c_int32),
+                ("shape", C.c_int64 * 8), ("data", C.c_void_p), ("nbytes", C.c_size_t)]
+
+
+CKPT_META_LLAMA3, CKPT_HF_LLAMA3, CKPT_META_LLAMA3_QLORA, CKPT_HF_GEMMA3 = 0, 1, 2, 3
+
 _lib = None
 
 
@@ -117,6 +124,23 @@ def capi() -> C.CDLL:
                                        C.POINTER(i32)]),
         "mc_decoder_weight_ptrs": (i32, [vp, i32, C.c_char_p, pvp, pvp, C.POINTER(i32),
                                          C.POINTER(i32), C.POINTER(i32)]),
+        "mc_decoder_get_config": (i32, [vp, C.POINTER(DecoderConfig)]),
+        "mc_document_create": (i32, [pvp]),
+        "mc_document_open": (i32, [C.c_char_p, pvp]),
+        "mc_document_open_sharded": (i32, [C.c_char_p, pvp]),
+        "mc_document_release": (None, [vp]),
+        "mc_document_size": (i32, [vp]),
+        "mc_document_tensor": (i32, [vp, i32, C.POINTER(TensorInfo)]),
+        "mc_document_find": (i32, [vp, C.c_char_p, C.POINTER(TensorInfo)]),
+        "mc_document_insert": (i32, [vp, C.c_char_p, C.c_char_p, i32, C.POINTER(C.c_int64), vp]),
+        "mc_document_link": (i32, [vp, C.c_char_p, C.c_char_p]),
+        "mc_document_set_metadata": (i32, [vp, C.c_char_p, C.c_char_p]),
+        "mc_document_metadata": (C.c_char_p, [vp, C.c_char_p]),
+        "mc_document_adapt": (i32, [vp, i32]),
+        "mc_document_save": (i32, [vp, C.c_char_p]),
+        "mc_config_from_json": (i32, [C.c_char_p, i32, C.POINTER(DecoderConfig)]),
+        "mc_config_from_document": (i32, [vp, C.POINTER(DecoderConfig)]),
+        "mc_decoder_load_document": (i32, [vp, vp, i32]),
         "mc_synth_weight": (i32, [u64, u32, u32, u32, i32]),
         "mc_synth_scale": (f32, [u64, u32, u32, u32, i32, i32]),
         "mc_synth_value": (f32, [u64, u32, u32, i32, u32]),
@@ -206,6 +230,98 @@ class Kernel:
 
     def max_threads_per_threadgroup(self) -> int:
         return capi().mc_kernel_max_threads_per_group(self._h)
+
+
+_ST_NP = {"F32": np.float32, "BF16": np.uint16, "F16": np.float16, "I8": np.int8, "U8": np.uint8,
+          "I16": np.int16, "U16": np.uint16, "I32": np.int32, "U32": np.uint32, "I64": np.int64,
+          "U64": np.uint64, "F64": np.float64, "BOOL": np.bool_}
+
+
+class Document:
+    """safetensor_document (include/metalchat/safetensor.h:534-975) over the C ABI, host only.
+    bf16 tensors are exposed as uint16 arrays (numpy has no bfloat16)."""
+
+    def __init__(self, path: str | None = None, sharded: bool = False):
+        self._h = C.c_void_p()
+        if path is None:
+            _check(capi().mc_document_create(C.byref(self._h)))
+        elif sharded:
+            _check(capi().mc_document_open_sharded(os.fspath(path).encode(), C.byref(self._h)))
+        else:
+            _check(capi().mc_document_open(os.fspath(path).encode(), C.byref(self._h)))
+
+    def __len__(self):
+        return capi().mc_document_size(self._h)
+
+    @staticmethod
+    def _unpack(ti: TensorInfo):
+        shape = tuple(ti.shape[i] for i in range(ti.ndim))
+        dtype = ti.dtype.decode()
+        npd = _ST_NP.get(dtype)
+        arr = None
+        if npd is not None:
+            n = ti.nbytes // np.dtype(npd).itemsize
+            arr = (np.ctypeslib.as_array(C.cast(ti.data, C.POINTER(C.c_uint8)), (ti.nbytes,)).view(npd)[:n]
+                   .reshape(shape) if ti.nbytes else np.zeros(shape, npd))
+        return dict(name=ti.name.decode(), dtype=dtype, shape=shape, data=arr, address=ti.data, nbytes=ti.nbytes)
+
+    def tensor(self, index: int) -> dict:
+        ti = TensorInfo()
+        _check(capi().mc_document_tensor(self._h, index, C.byref(ti)))
+        return self._unpack(ti)
+
+    def find(self, name: str) -> dict:
+        ti = TensorInfo()
+        _check(capi().mc_document_find(self._h, name.encode(), C.byref(ti)))
+        return self._unpack(ti)
+
+    def names(self):
+        return [self.tensor(i)["name"] for i in range(len(self))]
+
+    def insert(self, name: str, array: np.ndarray, dtype: str | None = None):
+        array = np.ascontiguousarray(array)
+        if dtype is None:
+            dtype = {v: k for k, v in _ST_NP.items() if k != "BF16"}[array.dtype.type]
+        shape = (C.c_int64 * max(array.ndim, 1))(*array.shape)
+        _check(capi().mc_document_insert(self._h, name.encode(), dtype.encode(), array.ndim, shape, _np_ptr(array)))
+
+    def link(self, name: str, source: str):
+        _check(capi().mc_document_link(self._h, name.encode(), source.encode()))
+
+    def set_metadata(self, key: str, value: str):
+        _check(capi().mc_document_set_metadata(self._h, key.encode(), value.encode()))
+
+    def metadata(self, key: str):
+        v = capi().mc_document_metadata(self._h, key.encode())
+        return v.decode() if v is not None else None
+
+    def adapt(self, flavour: int):
+        _check(capi().mc_document_adapt(self._h, flavour))
+
+    def save(self, path: str):
+        _check(capi().mc_document_save(self._h, os.fspath(path).encode()))
+
+    def release(self):
+        if self._h:
+            capi().mc_document_release(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+
+def config_from_json(text: str, flavour: int, cfg: DecoderConfig | None = None) -> DecoderConfig:
+    cfg = cfg or DecoderConfig()
+    _check(capi().mc_config_from_json(text.encode(), flavour, C.byref(cfg)))
+    return cfg
+
+
+def config_from_document(doc: Document, cfg: DecoderConfig) -> DecoderConfig:
+    _check(capi().mc_config_from_document(doc._h, C.byref(cfg)))
+    return cfg
 
 
 class KernelTask:
@@ -326,6 +442,11 @@ class Decoder:
         _check(capi().mc_decoder_create(acc._dev, acc._lib, acc._queue, C.byref(c), C.byref(self._h)))
         self.np_T = np.uint16 if defaults["dtype"] == BF16 else np.float32
 
+    @classmethod
+    def from_config(cls, acc: "HardwareAccelerator", c: DecoderConfig) -> "Decoder":
+        """A decoder from a filled DecoderConfig (mc_config_from_json / mc_config_from_document)."""
+        return cls(acc, **{k: getattr(c, k) for k, _ in DecoderConfig._fields_})
+
     # -- weights ------------------------------------------------------------------------------
     def load_linear(self, layer: int, name: str, fmt: int, weight: np.ndarray, scales=None,
                     group_size: int = 0):
@@ -348,6 +469,9 @@ class Decoder:
         assert b.shape[1] == rank
         _check(capi().mc_decoder_load_lora(self._h, layer, name.encode(), rank, out_f, in_f,
                                            _np_ptr(a), _np_ptr(b), C.c_float(scale)))
+
+    def load_document(self, doc: "Document", flavour: int):
+        _check(capi().mc_decoder_load_document(self._h, doc._h, flavour))
 
     def load_model(self, weights: dict):
         """weights: the dict produced by tests/modelgen.py (reference-native formats)."""
