@@ -224,6 +224,24 @@ mc_status mc_decoder_generate(mc_decoder* d, int32_t first_token, int32_t start_
                               int32_t* tokens_out);
 void* mc_decoder_hidden_out(mc_decoder* d);
 void* mc_decoder_hidden_in(mc_decoder* d);
+/* Sampler of the last stage -- include/metalchat/nn/sampling.h:152-315.
+ *   MC_SAMPLER_GREEDY : argmax, first maximum (the BASELINE configuration).
+ *   MC_SAMPLER_DEFAULT: make_default_sampler() = topk_sampler(top_k) -> nucleus_sampler(temperature,
+ *                       top_p) -> multinomial_sampler(1), run on the device in two launches with no
+ *                       host synchronisation (the reference synchronises three times per token and
+ *                       partial_sorts the vocabulary on the CPU).  Errors as nucleus_sampler's
+ *                       constructor ("temperature must be positive", "probability must be in
+ *                       [0.0, 1.0]").  top_k <= 128.  Equal logits are ordered by index
+ *                       (std::partial_sort leaves them unspecified).
+ * mc_decoder_set_seeds: the (init_state, init_seq) pairs kernel::multinomial draws from its
+ * std::mt19937 per call (include/metalchat/kernel/multinomial.h:46-55); token i of one
+ * mc_decoder_generate call uses pair i % n_pairs (mc_decoder_step: pair 0); no pairs = (0, 0). */
+enum { MC_SAMPLER_GREEDY = 0, MC_SAMPLER_DEFAULT = 1 };
+mc_status mc_decoder_set_sampler(mc_decoder* d, int32_t kind, int32_t top_k, float temperature, float top_p);
+mc_status mc_decoder_set_seeds(mc_decoder* d, const uint64_t* seeds, int32_t n_pairs);
+/* After a step with taps enabled: [7][k] floats -- scaled logits, probabilities, sorted, cumsum,
+ * cumsum - sorted, masked, vocabulary ids -- of the sampler chain. */
+mc_status mc_decoder_get_sampler_taps(mc_decoder* d, float* out_7xk);
 /* Debug / parity taps (synchronise the queue).  mc_decoder_set_taps(1) makes every step also
  * copy the hidden row after the embedding and after each owned layer into a tap buffer. */
 mc_status mc_decoder_set_taps(mc_decoder* d, int32_t enable);

@@ -14,5 +14,5 @@ from .runtime import (  # noqa: F401
     McError, HardwareAccelerator, Buffer, Kernel, KernelTask, Decoder, DecoderConfig, capi,
     library_path, hsaco_path, layout, make_kernel_grid_2d,
     Document, TensorInfo, config_from_json, config_from_document,
-    CKPT_META_LLAMA3, CKPT_HF_LLAMA3, CKPT_META_LLAMA3_QLORA, CKPT_HF_GEMMA3,
+    CKPT_META_LLAMA3, CKPT_HF_LLAMA3, CKPT_META_LLAMA3_QLORA, CKPT_HF_GEMMA3, SAMPLER_GREEDY, SAMPLER_DEFAULT,
 )

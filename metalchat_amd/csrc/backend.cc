@@ -352,7 +352,9 @@ mc_encoder_set_bytes(mc_queue* q, const void* data, size_t size)
         memcpy(&slot, data, size);
         push_arg(q, &slot, 4, 4);
     } else {
-        push_arg(q, data, size, 4);
+        // a uint64 / double scalar (multinomial's init_state, init_seq) sits on an 8-byte
+        // boundary; tensor_layout<N> (12 N bytes) and 4-byte scalars on a 4-byte one
+        push_arg(q, data, size, size == 8 ? 8 : 4);
     }
     return MC_OK;
 }

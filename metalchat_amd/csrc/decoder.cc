@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <algorithm>
 #include <memory>
 
 using namespace mcimpl;
@@ -50,6 +51,12 @@ struct linear_w {
     int lora_rank = 0;      // rank of one adaptor
     int lora_cols = 0;      // nseg * rank
     float lora_scale = 0.0f;
+};
+
+// mirrors sampler_params (kernels/sampler_kernels.hip)
+struct sampler_params_h {
+    uint32_t k, ncand, ncand_pad;
+    float inv_temp, top_p;
 };
 
 // mirrors mc::gemv::qkv_epilogue (kernels/gemv.h)
@@ -165,6 +172,14 @@ struct mc_decoder {
     step_state_h* state = nullptr;
     int32_t* tokens_dev = nullptr;
     int tokens_cap = 0;
+    // sampler (nn/sampling.h:303-313); kind 0 = greedy argmax, 1 = topk -> nucleus -> multinomial
+    int sampler_kind = MC_SAMPLER_GREEDY;
+    int top_k = 50;
+    float inv_temp_T = 0.0f, top_p_T = 0.0f;
+    uint64_t* cand = nullptr;      // [chunks][kpad] candidate keys
+    uint64_t* seeds = nullptr;     // [n_seed_pairs][2]
+    int n_seed_pairs = 0, seed_cap = 0;
+    float* sampler_taps = nullptr; // [7][128]
     float* rope_cos[2] = {nullptr, nullptr};
     float* rope_sin[2] = {nullptr, nullptr};
     int rope_rows = 0;
@@ -508,8 +523,22 @@ struct mc_decoder {
         // final norm + output head (llama.h:128-133) + greedy pick
         mc_status s = gemv(output, 1, 0, hidden, logits, nullptr, final_norm, mu);
         if (s != MC_OK) return s;
-        return launch("mc_argmax_" + tname, 1, 1, 1, 1024, 0,
-                      pack(logits, (uint32_t)cfg.vocab, state, tokens_dev));
+        if (sampler_kind == MC_SAMPLER_GREEDY)
+            return launch("mc_argmax_" + tname, 1, 1, 1, 1024, 0,
+                          pack(logits, (uint32_t)cfg.vocab, state, tokens_dev));
+        // make_default_sampler: per-chunk candidates, then one workgroup finishes the chain
+        const uint32_t chunks = ((uint32_t)cfg.vocab + 2047u) / 2048u;
+        uint32_t kpad = 1;
+        while (kpad < (uint32_t)top_k) kpad *= 2;
+        const uint32_t k = (uint32_t)std::min(top_k, cfg.vocab);
+        s = launch("mc_topk_candidates_" + tname, chunks, 1, 1, 256, 0,
+                   pack(logits, (uint32_t)cfg.vocab, kpad, cand));
+        if (s != MC_OK) return s;
+        sampler_params_h p{k, chunks * kpad, 1, inv_temp_T, top_p_T};
+        while (p.ncand_pad < p.ncand) p.ncand_pad *= 2;
+        return launch("mc_sample_" + tname, 1, 1, 1, 256, p.ncand_pad * 8,
+                      pack(cand, p, seeds, (uint32_t)n_seed_pairs, state, tokens_dev,
+                           want_taps ? sampler_taps : (float*)nullptr));
     }
 
     // everything one token needs after the state has been set
@@ -643,6 +672,74 @@ find_layer(mc_decoder* d, int32_t layer, layer_w** out)
     if (li < 0 || li >= d->n_own)
         return fail(MC_ERR_INVALID_ARGUMENT, "decoder: layer is not owned by this stage");
     *out = &d->layers[li];
+    return MC_OK;
+}
+
+mc_status
+mc_decoder_set_sampler(mc_decoder* d, int32_t kind, int32_t top_k, float temperature, float top_p)
+{
+    if (!d) return fail(MC_ERR_INVALID_ARGUMENT, "mc_decoder_set_sampler: null argument");
+    if (kind != MC_SAMPLER_GREEDY && kind != MC_SAMPLER_DEFAULT)
+        return fail(MC_ERR_INVALID_ARGUMENT, "mc_decoder_set_sampler: unknown sampler");
+    if (kind == MC_SAMPLER_DEFAULT) {
+        // the argument checks of nucleus_sampler (nn/sampling.h:165-174)
+        if (!(temperature > 0.0f)) return fail(MC_ERR_INVALID_ARGUMENT, "nucleus_sampler: temperature must be positive");
+        if (top_p < 0.0f || top_p > 1.0f)
+            return fail(MC_ERR_INVALID_ARGUMENT, "nucleus_sampler: probability must be in [0.0, 1.0]");
+        if (top_k < 1 || top_k > 128)
+            return fail(MC_ERR_INVALID_ARGUMENT, "topk_sampler: the fused sampler keeps 1..128 candidates");
+        if (!d->last_stage) return fail(MC_ERR_INVALID_ARGUMENT, "decoder: only the last stage samples");
+        MC_HIP(hipSetDevice(d->dev->ordinal));
+        if (d->graph_exec) { (void)hipGraphExecDestroy(d->graph_exec); d->graph_exec = nullptr; }
+        if (d->graph) { (void)hipGraphDestroy(d->graph); d->graph = nullptr; }
+        const uint32_t chunks = ((uint32_t)d->cfg.vocab + 2047u) / 2048u;
+        if (!d->cand) {
+            mc_status s = d->alloc((void**)&d->cand, (size_t)chunks * 128 * 8);
+            if (s != MC_OK) return s;
+            s = d->alloc((void**)&d->sampler_taps, 7 * 128 * 4);
+            if (s != MC_OK) return s;
+        }
+        const bool bf = d->tb == 2;
+        auto rt = [&](float v) { return bf ? bf2f_host(f2bf_host(v)) : v; };
+        d->top_k = top_k;
+        d->inv_temp_T = rt(1.0f / rt(temperature)); // T temp = T(1) / _M_temperature  (sampling.h:190)
+        d->top_p_T = rt(top_p);
+    } else if (d->graph_exec) {
+        (void)hipGraphExecDestroy(d->graph_exec);
+        d->graph_exec = nullptr;
+    }
+    d->sampler_kind = kind;
+    return MC_OK;
+}
+
+mc_status
+mc_decoder_set_seeds(mc_decoder* d, const uint64_t* seeds, int32_t n_pairs)
+{
+    if (!d || (n_pairs > 0 && !seeds)) return fail(MC_ERR_INVALID_ARGUMENT, "mc_decoder_set_seeds: null argument");
+    if (n_pairs < 0) return fail(MC_ERR_INVALID_ARGUMENT, "mc_decoder_set_seeds: negative count");
+    MC_HIP(hipSetDevice(d->dev->ordinal));
+    if (n_pairs > d->seed_cap) {
+        if (d->graph_exec) { (void)hipGraphExecDestroy(d->graph_exec); d->graph_exec = nullptr; } // pointer changes
+        mc_status s = d->alloc((void**)&d->seeds, (size_t)n_pairs * 16);
+        if (s != MC_OK) return s;
+        d->seed_cap = n_pairs;
+    }
+    if (n_pairs) MC_HIP(hipMemcpy(d->seeds, seeds, (size_t)n_pairs * 16, hipMemcpyHostToDevice));
+    if (n_pairs != d->n_seed_pairs && d->graph_exec) { (void)hipGraphExecDestroy(d->graph_exec); d->graph_exec = nullptr; }
+    d->n_seed_pairs = n_pairs;
+    return MC_OK;
+}
+
+mc_status
+mc_decoder_get_sampler_taps(mc_decoder* d, float* out_7xk)
+{
+    if (!d || !out_7xk) return fail(MC_ERR_INVALID_ARGUMENT, "mc_decoder_get_sampler_taps: null argument");
+    if (d->sampler_kind != MC_SAMPLER_DEFAULT || !d->sampler_taps)
+        return fail(MC_ERR_INVALID_ARGUMENT, "decoder: the default sampler is not active");
+    MC_HIP(hipSetDevice(d->dev->ordinal));
+    MC_HIP(hipStreamSynchronize(d->stream));
+    const int k = std::min(d->top_k, d->cfg.vocab);
+    MC_HIP(hipMemcpy(out_7xk, d->sampler_taps, (size_t)7 * k * 4, hipMemcpyDeviceToHost));
     return MC_OK;
 }
 

@@ -5,3 +5,4 @@
 #include "gemv_kernels.hip"
 #include "decode_kernels.hip"
 #include "synth_kernels.hip"
+#include "sampler_kernels.hip"

@@ -50,6 +50,7 @@ class TensorInfo(C.Structure):
 
 
 CKPT_META_LLAMA3, CKPT_HF_LLAMA3, CKPT_META_LLAMA3_QLORA, CKPT_HF_GEMMA3 = 0, 1, 2, 3
+SAMPLER_GREEDY, SAMPLER_DEFAULT = 0, 1
 
 _lib = None
 
@@ -125,6 +126,9 @@ def capi() -> C.CDLL:
         "mc_decoder_weight_ptrs": (i32, [vp, i32, C.c_char_p, pvp, pvp, C.POINTER(i32),
                                          C.POINTER(i32), C.POINTER(i32)]),
         "mc_decoder_get_config": (i32, [vp, C.POINTER(DecoderConfig)]),
+        "mc_decoder_set_sampler": (i32, [vp, i32, i32, C.c_float, C.c_float]),
+        "mc_decoder_set_seeds": (i32, [vp, C.POINTER(u64), i32]),
+        "mc_decoder_get_sampler_taps": (i32, [vp, C.POINTER(f32)]),
         "mc_document_create": (i32, [pvp]),
         "mc_document_open": (i32, [C.c_char_p, pvp]),
         "mc_document_open_sharded": (i32, [C.c_char_p, pvp]),
@@ -469,6 +473,21 @@ class Decoder:
         assert b.shape[1] == rank
         _check(capi().mc_decoder_load_lora(self._h, layer, name.encode(), rank, out_f, in_f,
                                            _np_ptr(a), _np_ptr(b), C.c_float(scale)))
+
+    # -- sampler ------------------------------------------------------------------------------
+    def set_sampler(self, kind: int, top_k: int = 50, temperature: float = 0.6, top_p: float = 0.9):
+        """kind: SAMPLER_GREEDY / SAMPLER_DEFAULT (make_default_sampler, nn/sampling.h:303-313)."""
+        _check(capi().mc_decoder_set_sampler(self._h, kind, top_k, temperature, top_p))
+        self._top_k = min(top_k, self.cfg["vocab"])
+
+    def set_seeds(self, pairs):
+        a = np.ascontiguousarray(np.asarray(pairs, dtype=np.uint64).reshape(-1, 2))
+        _check(capi().mc_decoder_set_seeds(self._h, a.ctypes.data_as(C.POINTER(C.c_uint64)), a.shape[0]))
+
+    def sampler_taps(self) -> np.ndarray:
+        out = np.zeros((7, self._top_k), np.float32)
+        _check(capi().mc_decoder_get_sampler_taps(self._h, out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
 
     def load_document(self, doc: "Document", flavour: int):
         _check(capi().mc_decoder_load_document(self._h, doc._h, flavour))

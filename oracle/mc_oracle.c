@@ -419,6 +419,268 @@ mco_gelu(int dt, const uint32_t* ol, void* out, const uint32_t* il, const void* 
 }
 
 /* ==========================================================================================
+ * Sampler chain: the kernels nn::nucleus_sampler / topk_sampler /
+ * multinomial_sampler are made of (include/metalchat/nn/sampling.h:152-315).
+ * ========================================================================================== */
+
+/* sub (kernel/arithmetic.metal:88-121) evaluated in T */
+void
+mco_sub(int dt, const uint32_t* ol, void* out, const uint32_t* al, const void* a,
+        const uint32_t* bl, const void* b)
+{
+    for (uint32_t i = 0; i < al[0]; i++)
+        for (uint32_t k = 0; k < al[1]; k++)
+            st(dt, out, at2(ol, i, k), ld(dt, a, at2(al, i, k)) - ld(dt, b, at2(bl, i, k)));
+}
+
+/* gt / le (kernel/logical.metal:13-68): bool = one byte, compare in T */
+void
+mco_gt(int dt, const uint32_t* ol, uint8_t* out, const uint32_t* il, const void* in, float value)
+{
+    const float v = rt(dt, value);
+    for (uint32_t i = 0; i < il[0]; i++)
+        for (uint32_t k = 0; k < il[1]; k++) out[at2(ol, i, k)] = ld(dt, in, at2(il, i, k)) > v;
+}
+
+void
+mco_le(int dt, const uint32_t* ol, uint8_t* out, const uint32_t* il, const void* in, float value)
+{
+    const float v = rt(dt, value);
+    for (uint32_t i = 0; i < il[0]; i++)
+        for (uint32_t k = 0; k < il[1]; k++) out[at2(ol, i, k)] = ld(dt, in, at2(il, i, k)) <= v;
+}
+
+/* scatter (kernel/copy.metal:45-74): out[mask] = value, in place */
+void
+mco_scatter(int dt, const uint32_t* ol, void* out, const uint32_t* ml, const uint8_t* mask, float value)
+{
+    for (uint32_t i = 0; i < ol[0]; i++)
+        for (uint32_t k = 0; k < ol[1]; k++)
+            if (mask[at2(ml, i, k)]) st(dt, out, at2(ol, i, k), value);
+}
+
+/* gather (kernel/copy.metal:77-113): out[i,k] = in[i, index[i,k]]; dt 2 = int32 */
+void
+mco_gather(int dt, const uint32_t* ol, void* out, const uint32_t* il, const void* in,
+           const uint32_t* xl, const int32_t* index)
+{
+    const size_t esz = dt == MCO_BF16 ? 2 : 4;
+    for (uint32_t i = 0; i < xl[0]; i++)
+        for (uint32_t k = 0; k < xl[1]; k++)
+            memcpy((char*)out + esz * at2(ol, i, k),
+                   (const char*)in + esz * at2(il, i, (uint32_t)index[at2(xl, i, k)]), esz);
+}
+
+/* sort (kernel/sort.metal:33-88, launch include/metalchat/kernel/sort.h:27-62): bitonic network
+ * over ceil_pow2(dim) slots padded with -inf, DESCENDING, values and indices swapped together;
+ * equal values are never swapped.  values / indices are [rows, aligned]; the caller slices
+ * [:, :dim].  Pinned by test/test_kernel_sort.cc:17-50 (is_sorted + index consistency). */
+void
+mco_sort(int dt, const uint32_t* vl, void* values, const uint32_t* xl, int32_t* indices,
+         const uint32_t* il, const void* in)
+{
+    const uint32_t rows = il[0], dim = il[1], aligned = vl[1];
+    for (uint32_t b = 0; b < rows; b++) {
+        for (uint32_t k = 0; k < aligned; k++) {
+            st(dt, values, at2(vl, b, k), k < dim ? ld(dt, in, at2(il, b, k)) : -INFINITY);
+            indices[at2(xl, b, k)] = (int32_t)k;
+        }
+        for (uint32_t k = 2; k <= aligned; k *= 2)
+            for (uint32_t j = k >> 1; j > 0; j >>= 1)
+                for (uint32_t i = 0; i < aligned; i++) {
+                    const uint32_t ij = i ^ j;
+                    if (i >= ij) continue;
+                    const float vi = ld(dt, values, at2(vl, b, i)), vj = ld(dt, values, at2(vl, b, ij));
+                    const int up = (i & k) == 0;
+                    if ((up && vi < vj) || (!up && vi > vj)) {
+                        st(dt, values, at2(vl, b, i), vj);
+                        st(dt, values, at2(vl, b, ij), vi);
+                        const int32_t t = indices[at2(xl, b, i)];
+                        indices[at2(xl, b, i)] = indices[at2(xl, b, ij)];
+                        indices[at2(xl, b, ij)] = t;
+                    }
+                }
+    }
+}
+
+/* cumsum (kernel/cumsum.metal:24-76, launch include/metalchat/kernel/sum.h:28-58): thread t owns
+ * BlockSize = max(2, ceil_pow2(ceil_div(dim, max_threads))) consecutive elements, prefix-sums
+ * them IN T, then adds the totals of the threads before it one at a time (nearest first), each
+ * add rounded to T.  Pinned by test/test_kernel_sum.cc:17-40 (float, margin 1e-4). */
+void
+mco_cumsum(int dt, const uint32_t* ol, void* out, const uint32_t* il, const void* in,
+           uint32_t max_threads)
+{
+    const uint32_t rows = il[0], dim = il[1];
+    uint32_t B = 1;
+    while (B < ceil_div_u32(dim, max_threads)) B *= 2;
+    if (B < 2) B = 2;
+    const uint32_t nthreads = ceil_div_u32(dim, B);
+    float* ls = (float*)malloc(sizeof(float) * (size_t)nthreads * B);
+    float* gs = (float*)malloc(sizeof(float) * nthreads);
+    for (uint32_t i = 0; i < rows; i++) {
+        for (uint32_t t = 0; t < nthreads; t++) {
+            const uint32_t begin = t * B, end = begin + B;
+            const uint32_t bs = end > dim ? dim % B : B;
+            for (uint32_t k = begin, j = 0; k < end && k < dim; k++, j++) {
+                const float x = ld(dt, in, at2(il, i, k));
+                ls[(size_t)t * B + j] = j > 0 ? rt(dt, x + ls[(size_t)t * B + j - 1]) : x;
+            }
+            gs[t] = ls[(size_t)t * B + bs - 1];
+        }
+        for (uint32_t t = 0; t < nthreads; t++) {
+            const uint32_t begin = t * B, end = begin + B;
+            const uint32_t bs = end > dim ? dim % B : B;
+            for (uint32_t a = 1; a < nthreads; a++)
+                if (t >= a)
+                    for (uint32_t j = 0; j < bs; j++)
+                        ls[(size_t)t * B + j] = rt(dt, ls[(size_t)t * B + j] + gs[t - a]);
+            for (uint32_t k = begin; k < end && k < dim; k++)
+                st(dt, out, at2(ol, i, k), ls[(size_t)t * B + (k - begin)]);
+        }
+    }
+    free(ls);
+    free(gs);
+}
+
+/* PCG32 (kernel/multinomial.metal:17-57) */
+typedef struct {
+    uint64_t state, inc;
+} pcg32_t;
+
+static uint32_t
+pcg32_next(pcg32_t* g)
+{
+    const uint64_t pre = g->state;
+    g->state = pre * 6364136223846793005ULL + g->inc;
+    const uint32_t xorshifted = (uint32_t)(((pre >> 18u) ^ pre) >> 27u);
+    const uint32_t rot = (uint32_t)(pre >> 59u);
+    return (xorshifted >> rot) | (xorshifted << ((~rot + 1u) & 31));
+}
+
+float
+mco_pcg32_uniform(uint64_t init_state, uint64_t init_seq)
+{
+    pcg32_t g = {0, (init_seq << 1u) | 1u};
+    pcg32_next(&g);
+    g.state += init_state;
+    pcg32_next(&g);
+    const uint32_t u = (pcg32_next(&g) >> 9) | 0x3f800000u;
+    float f;
+    memcpy(&f, &u, 4);
+    return f - 1.0f;
+}
+
+/* multinomial (kernel/multinomial.metal:60-122): output [rows, sample_size] of positions in a
+ * DESCENDING row.  As in the reference, the lower end of the draw interval is read at column
+ * output.size(1) - 1 of the INPUT (multinomial.metal:112): with sample_size == 1 that is column
+ * 0, so a == b and every draw lands on position 0.  For sample_size > input dim the reference
+ * reads out of bounds; its own test (test/test_kernel_multinomial.cc:17-55) only passes when
+ * that read yields 0, which is what is used here. */
+void
+mco_multinomial(int dt, const uint32_t* ol, int32_t* out, const uint32_t* il, const void* in,
+                uint64_t init_state, uint64_t init_seq)
+{
+    const uint32_t rows = ol[0], ns = ol[1], dim = il[1];
+    for (uint32_t i = 0; i < rows; i++)
+        for (uint32_t k = 0; k < ns; k++) {
+            const float a = ns - 1 < dim ? ld(dt, in, at2(il, i, ns - 1)) : 0.0f;
+            const float b = ld(dt, in, at2(il, i, 0));
+            const float u = mco_pcg32_uniform(init_state + i, init_seq + k);
+            const float random = rt(dt, u * (b - a) + a);
+            int low = 0, high = (int)dim;
+            while (low < high) {
+                const uint32_t mid = (uint32_t)(low + high) / 2;
+                if (ld(dt, in, at2(il, i, mid)) > random) low = (int)mid + 1;
+                else high = (int)mid;
+            }
+            out[at2(ol, i, k)] = (low > 1 ? low : 1) - 1;
+        }
+}
+
+/* topk_sampler (nn/sampling.h:216-258): std::partial_sort of the index row by value, descending.
+ * The standard leaves the order of equal values unspecified; this restatement (and the HIP path)
+ * break ties by the LOWER index first.  values_out / indices_out: [k]. */
+void
+mco_topk(int dt, const void* logits, const int32_t* indices, uint32_t n, uint32_t k,
+         void* values_out, int32_t* indices_out)
+{
+    if (k > n) k = n;
+    uint8_t* taken = (uint8_t*)calloc(n, 1);
+    for (uint32_t r = 0; r < k; r++) {
+        int64_t best = -1;
+        float bv = 0.0f;
+        for (uint32_t i = 0; i < n; i++) {
+            if (taken[i]) continue;
+            const float v = ld(dt, logits, i);
+            if (best < 0 || v > bv) { best = i; bv = v; }
+        }
+        taken[best] = 1;
+        st(dt, values_out, r, bv);
+        indices_out[r] = indices ? indices[best] : (int32_t)best;
+    }
+    free(taken);
+}
+
+/* make_default_sampler (nn/sampling.h:303-313): topk(max(sample_size, 50)) -> nucleus(T(0.6),
+ * T(0.9)) -> multinomial(sample_size), one row of logits; returns the sampled vocabulary id.
+ * Intermediates (all T, length k) can be tapped through `taps` (7*k floats: scaled, probs, sorted,
+ * cumsum, diff, masked, ids-as-float) when non-NULL. */
+int32_t
+mco_sample_default(int dt, const void* logits, uint32_t vocab, uint32_t top_k, float temperature,
+                   float top_p, uint64_t init_state, uint64_t init_seq, float* taps)
+{
+    const uint32_t k = top_k < vocab ? top_k : vocab;
+    uint32_t aligned = 1;
+    while (aligned < k) aligned *= 2;
+    const size_t esz = dt == MCO_BF16 ? 2 : 4;
+    void* v0 = malloc(esz * aligned);
+    void* v1 = malloc(esz * aligned);
+    void* v2 = malloc(esz * aligned);
+    void* v3 = malloc(esz * aligned);
+    void* v4 = malloc(esz * aligned);
+    int32_t* id0 = (int32_t*)malloc(4 * aligned);
+    int32_t* sidx = (int32_t*)malloc(4 * aligned);
+    int32_t* id1 = (int32_t*)malloc(4 * aligned);
+    uint8_t* mask = (uint8_t*)malloc(aligned);
+    const uint32_t lk[6] = {1, k, k, 1, 0, 0}, la[6] = {1, aligned, aligned, 1, 0, 0};
+    mco_topk(dt, logits, NULL, vocab, k, v0, id0);
+    /* nucleus_sampler::sample (nn/sampling.h:187-203) */
+    const float temp_T = rt(dt, temperature);
+    const float inv = rt(dt, 1.0f / temp_T);
+    mco_bf16 mb = mco_f32_to_bf16(inv);
+    mco_scalar_mul(dt, lk, v1, lk, v0, dt == MCO_BF16 ? (const void*)&mb : (const void*)&inv);
+    mco_softmax(dt, lk, v2, lk, v1, 1024);
+    mco_sort(dt, la, v3, la, sidx, lk, v2);
+    mco_cumsum(dt, lk, v4, lk, v3, 1024);
+    if (taps)
+        for (uint32_t i = 0; i < k; i++) {
+            taps[0 * k + i] = ld(dt, v1, i);
+            taps[1 * k + i] = ld(dt, v2, i);
+            taps[2 * k + i] = ld(dt, v3, i);
+            taps[3 * k + i] = ld(dt, v4, i);
+        }
+    mco_sub(dt, lk, v1, lk, v4, lk, v3); /* probs_diff */
+    mco_gt(dt, lk, mask, lk, v1, top_p);
+    if (taps)
+        for (uint32_t i = 0; i < k; i++) taps[4 * k + i] = ld(dt, v1, i);
+    mco_scatter(dt, lk, v3, lk, mask, 0.0f);
+    mco_gather(2, lk, id1, lk, id0, lk, sidx);
+    if (taps)
+        for (uint32_t i = 0; i < k; i++) {
+            taps[5 * k + i] = ld(dt, v3, i);
+            taps[6 * k + i] = (float)id1[i];
+        }
+    /* multinomial_sampler::sample (nn/sampling.h:284-292), sample_size 1 */
+    int32_t pos = 0;
+    const uint32_t l1[6] = {1, 1, 1, 1, 0, 0};
+    mco_multinomial(dt, l1, &pos, lk, v3, init_state, init_seq);
+    const int32_t token = id1[pos];
+    free(v0); free(v1); free(v2); free(v3); free(v4); free(id0); free(sidx); free(id1); free(mask);
+    return token;
+}
+
+/* ==========================================================================================
  * Model-level restatement: one transform(token, start_pos) with len == 1.
  *   nn::llama3::operator()        include/metalchat/nn/llama.h:113-134
  *   nn::gemma3::operator()        include/metalchat/nn/gemma.h:110-137

@@ -85,6 +85,25 @@ void mco_add_broadcast(int dt, const uint32_t* out_l, void* out, const uint32_t*
 void mco_silu(int dt, const uint32_t* out_l, void* out, const uint32_t* in_l, const void* in);
 void mco_gelu(int dt, const uint32_t* out_l, void* out, const uint32_t* in_l, const void* in);
 
+/* ---- sampler chain (include/metalchat/nn/sampling.h:152-315 and the kernels it launches) ---- */
+void mco_sub(int dt, const uint32_t* out_l, void* out, const uint32_t* a_l, const void* a,
+             const uint32_t* b_l, const void* b);
+void mco_gt(int dt, const uint32_t* out_l, uint8_t* out, const uint32_t* in_l, const void* in, float value);
+void mco_le(int dt, const uint32_t* out_l, uint8_t* out, const uint32_t* in_l, const void* in, float value);
+void mco_scatter(int dt, const uint32_t* out_l, void* out, const uint32_t* mask_l, const uint8_t* mask, float value);
+void mco_gather(int dt, const uint32_t* out_l, void* out, const uint32_t* in_l, const void* in,
+                const uint32_t* index_l, const int32_t* index);
+void mco_sort(int dt, const uint32_t* values_l, void* values, const uint32_t* indices_l, int32_t* indices,
+              const uint32_t* in_l, const void* in);
+void mco_cumsum(int dt, const uint32_t* out_l, void* out, const uint32_t* in_l, const void* in, uint32_t max_threads);
+float mco_pcg32_uniform(uint64_t init_state, uint64_t init_seq);
+void mco_multinomial(int dt, const uint32_t* out_l, int32_t* out, const uint32_t* in_l, const void* in,
+                     uint64_t init_state, uint64_t init_seq);
+void mco_topk(int dt, const void* logits, const int32_t* indices, uint32_t n, uint32_t k, void* values_out,
+              int32_t* indices_out);
+int32_t mco_sample_default(int dt, const void* logits, uint32_t vocab, uint32_t top_k, float temperature,
+                           float top_p, uint64_t init_state, uint64_t init_seq, float* taps);
+
 /* ---- model-level restatement (nn::llama3 / nn::gemma3 one-token step) ---- */
 
 /* One linear layer in the reference's own formats. */

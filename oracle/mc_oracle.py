@@ -40,6 +40,9 @@ def lib() -> C.CDLL:
         _lib.mco_f32_to_bf16.restype = C.c_uint16
         _lib.mco_f32_to_bf16.argtypes = [C.c_float]
         _lib.mco_model_create.restype = C.c_void_p
+        _lib.mco_pcg32_uniform.restype = C.c_float
+        _lib.mco_pcg32_uniform.argtypes = [C.c_uint64, C.c_uint64]
+        _lib.mco_sample_default.restype = C.c_int32
         _lib.mco_model_step.restype = C.c_int32
         _lib.mco_model_step_range.restype = C.c_int32
         _lib.mco_model_get_kv.restype = C.c_int32
@@ -166,6 +169,64 @@ def add(dt, out_l, out, a_l, a, b_l, b):
 
 def add_broadcast(dt, out_l, out, a_l, a, b_l, b):
     lib().mco_add_broadcast(dt, _l(out_l), _p(out), _l(a_l), _p(a), _l(b_l), _p(b))
+
+
+# ---- sampler chain (include/metalchat/nn/sampling.h:152-315)
+def sub(dt, out_l, out, a_l, a, b_l, b):
+    lib().mco_sub(dt, _l(out_l), _p(out), _l(a_l), _p(a), _l(b_l), _p(b))
+
+
+def gt(dt, out_l, out, in_l, inp, value):
+    lib().mco_gt(dt, _l(out_l), _p(out), _l(in_l), _p(inp), C.c_float(value))
+
+
+def le(dt, out_l, out, in_l, inp, value):
+    lib().mco_le(dt, _l(out_l), _p(out), _l(in_l), _p(inp), C.c_float(value))
+
+
+def scatter(dt, out_l, out, mask_l, mask, value):
+    lib().mco_scatter(dt, _l(out_l), _p(out), _l(mask_l), _p(mask), C.c_float(value))
+
+
+def gather(dt, out_l, out, in_l, inp, index_l, index):
+    """dt 2 = int32 payload"""
+    lib().mco_gather(dt, _l(out_l), _p(out), _l(in_l), _p(inp), _l(index_l), _p(index))
+
+
+def sort(dt, values_l, values, indices_l, indices, in_l, inp):
+    lib().mco_sort(dt, _l(values_l), _p(values), _l(indices_l), _p(indices), _l(in_l), _p(inp))
+
+
+def cumsum(dt, out_l, out, in_l, inp, max_threads=1024):
+    lib().mco_cumsum(dt, _l(out_l), _p(out), _l(in_l), _p(inp), C.c_uint32(max_threads))
+
+
+def pcg32_uniform(init_state: int, init_seq: int) -> float:
+    return float(lib().mco_pcg32_uniform(C.c_uint64(init_state & (2**64 - 1)), C.c_uint64(init_seq & (2**64 - 1))))
+
+
+def multinomial(dt, out_l, out, in_l, inp, init_state, init_seq):
+    lib().mco_multinomial(dt, _l(out_l), _p(out), _l(in_l), _p(inp), C.c_uint64(init_state), C.c_uint64(init_seq))
+
+
+def topk(dt, logits, k):
+    n = logits.size
+    k = min(k, n)
+    values = np.zeros(k, dtype=logits.dtype)
+    indices = np.zeros(k, dtype=np.int32)
+    lib().mco_topk(dt, _p(logits), None, C.c_uint32(n), C.c_uint32(k), _p(values), _p(indices))
+    return values, indices
+
+
+def sample_default(dt, logits, top_k=50, temperature=0.6, top_p=0.9, init_state=0, init_seq=0, taps=False):
+    """make_default_sampler (nn/sampling.h:303-313) on one row of logits -> vocabulary id
+    (and, with taps, the [7, k] float table of intermediates)."""
+    k = min(top_k, logits.size)
+    t = np.zeros((7, k), np.float32) if taps else None
+    tok = lib().mco_sample_default(dt, _p(logits), C.c_uint32(logits.size), C.c_uint32(top_k),
+                                   C.c_float(temperature), C.c_float(top_p), C.c_uint64(init_state),
+                                   C.c_uint64(init_seq), _p(t))
+    return (tok, t) if taps else tok
 
 
 def silu(dt, out_l, out, in_l, inp):
