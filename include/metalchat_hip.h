@@ -218,6 +218,17 @@ mc_status mc_decoder_init_synthetic(mc_decoder* d, uint64_t seed);
  * row in the buffer returned by mc_decoder_hidden_out(). */
 mc_status mc_decoder_step(mc_decoder* d, int32_t token, int32_t start_pos, const void* hidden_in,
                           int32_t* next_token);
+/* The prompt pass: transformer<Layer>::transform(input[1, len], start_pos) with len > 1 --
+ * nn::llama3 / nn::gemma3 operator() (include/metalchat/nn/llama.h:113-134, nn/gemma.h:110-137).
+ * All len rows go through the layers as GEMMs (weights dequantised once per tile), the K / V rows
+ * are written to cache positions [start_pos, start_pos + len), scores take the reference's mask
+ * (make_causal_mask / make_sliding_causal_mask, nn/attention.h:283-321: only the LAST len columns
+ * form the causal square, columns of an earlier context stay masked -- as the reference builds it),
+ * and the last row goes through the head and the sampler; *next_token receives its pick.
+ * sliding_window: gemma3_options.sliding_window (sliding layers only); 0 for llama3.
+ * len == 1 is mc_decoder_step.  start_pos + len must not exceed max_seq_len. */
+mc_status mc_decoder_prefill(mc_decoder* d, const int32_t* tokens, int32_t len, int32_t start_pos,
+                             int32_t sliding_window, int32_t* next_token);
 /* Enqueue `n` chained greedy steps entirely on the device (token feedback through HBM, one host
  * sync at the end); tokens_out receives the n generated ids.  Single-stage decoders only. */
 mc_status mc_decoder_generate(mc_decoder* d, int32_t first_token, int32_t start_pos, int32_t n,

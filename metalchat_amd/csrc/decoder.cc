@@ -180,6 +180,13 @@ struct mc_decoder {
     uint64_t* seeds = nullptr;     // [n_seed_pairs][2]
     int n_seed_pairs = 0, seed_cap = 0;
     float* sampler_taps = nullptr; // [7][128]
+    // prompt pass (prefill_kernels.hip): row buffers for up to pf_cap rows
+    int pf_cap = 0;
+    size_t pf_probs_elems = 0;
+    void *pf_x = nullptr, *pf_xn = nullptr, *pf_h = nullptr, *pf_proj = nullptr, *pf_qkv = nullptr,
+         *pf_q = nullptr, *pf_att = nullptr, *pf_g2 = nullptr, *pf_g = nullptr, *pf_probs = nullptr;
+    int32_t* pf_tokens = nullptr;
+    bool ring_turned = false;
     float* rope_cos[2] = {nullptr, nullptr};
     float* rope_sin[2] = {nullptr, nullptr};
     int rope_rows = 0;
@@ -539,6 +546,134 @@ struct mc_decoder {
         return launch("mc_sample_" + tname, 1, 1, 1, 256, p.ncand_pad * 8,
                       pack(cand, p, seeds, (uint32_t)n_seed_pairs, state, tokens_dev,
                            want_taps ? sampler_taps : (float*)nullptr));
+    }
+
+    // ---------------------------------------------------------------- prompt pass
+    mc_status
+    ensure_prefill(int M, int S)
+    {
+        const int H = cfg.n_heads, KV = cfg.n_kv_heads, hd = cfg.head_dim;
+        mc_status s;
+        if (M > pf_cap) {
+            const int cap = std::max(M, 64);
+#define A(ptr, bytes)                         \
+    s = alloc((void**)&(ptr), (bytes), true); \
+    if (s != MC_OK) return s;
+            A(pf_x, (size_t)cap * cfg.dim * tb);
+            A(pf_xn, (size_t)cap * cfg.dim * tb);
+            A(pf_h, (size_t)cap * cfg.dim * tb);
+            A(pf_proj, (size_t)cap * cfg.dim * tb);
+            A(pf_qkv, (size_t)cap * (H + 2 * KV) * hd * tb);
+            A(pf_q, (size_t)cap * H * hd * tb);
+            A(pf_att, (size_t)cap * H * hd * tb);
+            A(pf_g2, (size_t)cap * 2 * cfg.ffn_dim * tb);
+            A(pf_g, (size_t)cap * cfg.ffn_dim * tb);
+            A(pf_tokens, (size_t)cap * 4);
+#undef A
+            pf_cap = cap;
+        }
+        const size_t need = (size_t)H * M * S;
+        if (need > pf_probs_elems) {
+            s = alloc(&pf_probs, need * tb, false);
+            if (s != MC_OK) return s;
+            pf_probs_elems = need;
+        }
+        return MC_OK;
+    }
+
+    // Y[M, L.out] = T(X[M, L.in] Wd^T) (+ res): the fused matrices of the decode GEMV, same HBM layout
+    mc_status
+    gemm(const linear_w& L, int epi, const void* X, void* Y, const void* res, int M)
+    {
+        if (L.lora_cols)
+            return fail(MC_ERR_INVALID_ARGUMENT, "decoder: the prompt pass does not take LoRA adaptors yet "
+                                                 "(feed the prompt through mc_decoder_step)");
+        std::string name = "mc_pf_gemm_";
+        name += L.fmt == MC_WFMT_I4 ? "i4_" : (L.fmt == MC_WFMT_I8 ? "i8_" : "w_");
+        name += tname + "_e" + std::to_string(epi);
+        return launch(name, (L.out + 63) / 64, (M + 63) / 64, 1, 256, 0,
+                      pack(L.w, L.scales, X, Y, res, (uint32_t)M, (uint32_t)L.out, (uint32_t)L.in, (uint32_t)L.group));
+    }
+
+    mc_status
+    norm_rows(const void* x, const void* w, const void* res, void* y, int M, float mu)
+    {
+        return launch("mc_pf_rmsnorm_" + tname, M, 1, 1, 256, 0,
+                      pack(x, w, res, y, (uint32_t)cfg.dim, cfg.norm_eps, mu));
+    }
+
+    // nn::llama3 / nn::gemma3 operator() on M > 1 rows (llama.h:113-134, gemma.h:110-137)
+    mc_status
+    run_prefill(int M, int start_pos, int window)
+    {
+        const int dim = cfg.dim, H = cfg.n_heads, KV = cfg.n_kv_heads, hd = cfg.head_dim;
+        const int S = start_pos + M;
+        const bool gemma = cfg.family == MC_FAMILY_GEMMA3;
+        const float mu = gemma ? 1.0f : 0.0f;
+        const float scale_T = tb == 2 ? bf2f_host(f2bf_host(cfg.attn_scale)) : cfg.attn_scale;
+        float sc = std::sqrt((float)dim);
+        if (tb == 2) sc = bf2f_host(f2bf_host(sc));
+        mc_status s;
+        const unsigned gd = (dim + 255) / 256;
+        if (emb_fmt == MC_WFMT_T)
+            s = launch("mc_pf_embed_" + tname, gd, M, 1, 256, 0,
+                       pack(emb_table, pf_tokens, pf_x, (uint32_t)dim, sc, (int32_t)(gemma ? 1 : 0)));
+        else
+            s = launch("mc_pf_embed_q8_" + tname, gd, M, 1, 256, 0,
+                       pack(emb_table, emb_scales, pf_tokens, pf_x, (uint32_t)dim, sc, (int32_t)(gemma ? 1 : 0)));
+        if (s != MC_OK) return s;
+        const size_t last = (size_t)(M - 1) * dim * tb;
+        if (want_taps) MC_HIP(hipMemcpyAsync(taps, (char*)pf_x + last, (size_t)dim * tb, hipMemcpyDeviceToDevice, stream));
+        for (int li = 0; li < n_own; li++) {
+            layer_w& L = layers[li];
+            s = norm_rows(pf_x, L.attention_norm, nullptr, pf_xn, M, mu);
+            if (s != MC_OK) return s;
+            s = gemm(L.qkv, 0, pf_xn, pf_qkv, nullptr, M);
+            if (s != MC_OK) return s;
+            s = launch("mc_pf_rope_cache_" + tname, H + 2 * KV, M, 1, hd / 2, 0,
+                       pack(pf_qkv, pf_q, L.kc, L.vt, rope_cos[L.rope_table], rope_sin[L.rope_table], L.q_norm,
+                            L.k_norm, (uint32_t)H, (uint32_t)KV, (uint32_t)hd, (uint32_t)cfg.max_seq_len,
+                            (uint32_t)start_pos, (uint32_t)(start_pos - rope_start), cfg.norm_eps, mu));
+            if (s != MC_OK) return s;
+            const uint32_t win = (gemma && L.rope_table == 1) ? (uint32_t)window : 0u;
+            s = launch("mc_pf_scores_" + tname, (M + 15) / 16, H, 1, 256, 0,
+                       pack(pf_q, L.kc, pf_probs, (uint32_t)M, (uint32_t)S, (uint32_t)H, (uint32_t)(H / KV),
+                            (uint32_t)hd, (uint32_t)cfg.max_seq_len, scale_T, win));
+            if (s != MC_OK) return s;
+            s = launch("mc_pf_pv_" + tname, (M + 15) / 16, H, 1, 256, 0,
+                       pack(pf_probs, L.vt, pf_att, (uint32_t)M, (uint32_t)S, (uint32_t)H, (uint32_t)(H / KV),
+                            (uint32_t)hd, (uint32_t)cfg.max_seq_len, win));
+            if (s != MC_OK) return s;
+            if (L.attention_post_norm) {
+                s = gemm(L.wo, 0, pf_att, pf_proj, nullptr, M);
+                if (s != MC_OK) return s;
+                s = norm_rows(pf_proj, L.attention_post_norm, pf_x, pf_h, M, mu);
+            } else {
+                s = gemm(L.wo, 1, pf_att, pf_h, pf_x, M);
+            }
+            if (s != MC_OK) return s;
+            s = norm_rows(pf_h, L.ffn_norm, nullptr, pf_xn, M, mu);
+            if (s != MC_OK) return s;
+            s = gemm(L.w13, 0, pf_xn, pf_g2, nullptr, M);
+            if (s != MC_OK) return s;
+            s = launch("mc_pf_act_mul_" + tname, (cfg.ffn_dim + 255) / 256, M, 1, 256, 0,
+                       pack(pf_g2, pf_g, (uint32_t)cfg.ffn_dim, (int32_t)(gemma ? 1 : 0)));
+            if (s != MC_OK) return s;
+            if (L.ffn_post_norm) {
+                s = gemm(L.w2, 0, pf_g, pf_proj, nullptr, M);
+                if (s != MC_OK) return s;
+                s = norm_rows(pf_proj, L.ffn_post_norm, pf_h, pf_x, M, mu);
+            } else {
+                s = gemm(L.w2, 1, pf_g, pf_x, pf_h, M);
+            }
+            if (s != MC_OK) return s;
+            if (want_taps)
+                MC_HIP(hipMemcpyAsync((char*)taps + (size_t)(li + 1) * dim * tb, (char*)pf_x + last, (size_t)dim * tb,
+                                      hipMemcpyDeviceToDevice, stream));
+        }
+        // only the last row goes through the head (llama.h:130-133)
+        MC_HIP(hipMemcpyAsync(hidden, (char*)pf_x + last, (size_t)dim * tb, hipMemcpyDeviceToDevice, stream));
+        return run_head();
     }
 
     // everything one token needs after the state has been set
@@ -1027,10 +1162,60 @@ mc_decoder_step(mc_decoder* d, int32_t token, int32_t start_pos, const void* hid
     s = d->run_token(d->first_stage ? nullptr : hidden_in);
     if (s != MC_OK) return s;
     d->last_pos = start_pos;
+    if (start_pos == 0) d->ring_turned = false;
+    if (start_pos >= d->cfg.max_seq_len) d->ring_turned = true;
     if (next_token && d->last_stage) {
         MC_HIP(hipMemcpyAsync(next_token, &d->state->token, 4, hipMemcpyDeviceToHost, d->stream));
         MC_HIP(hipStreamSynchronize(d->stream));
     }
+    return MC_OK;
+}
+
+mc_status
+mc_decoder_prefill(mc_decoder* d, const int32_t* tokens, int32_t len, int32_t start_pos,
+                   int32_t sliding_window, int32_t* next_token)
+{
+    if (!d || !tokens) return fail(MC_ERR_INVALID_ARGUMENT, "mc_decoder_prefill: null argument");
+    if (len < 1 || start_pos < 0) return fail(MC_ERR_INVALID_ARGUMENT, "mc_decoder_prefill: bad length or position");
+    if (len == 1) return mc_decoder_step(d, tokens[0], start_pos, nullptr, next_token);
+    if (!d->first_stage || !d->last_stage)
+        return fail(MC_ERR_INVALID_ARGUMENT, "mc_decoder_prefill: single-stage decoders only");
+    if (len > d->cfg.max_seq_len)
+        return fail(MC_ERR_INVALID_ARGUMENT, "sink_cache: requested length (" + std::to_string(len) +
+                                                 ") is larger than the cache size (" +
+                                                 std::to_string(d->cfg.max_seq_len) + ")"); // nn/cache.h:178-183
+    if (start_pos + len > d->cfg.max_seq_len || (d->ring_turned && start_pos != 0))
+        return fail(MC_ERR_INVALID_ARGUMENT, "decoder: the prompt pass writes cache rows [start_pos, start_pos + len) "
+                                             "and needs them inside max_seq_len; past it, feed tokens through "
+                                             "mc_decoder_step");
+    for (int i = 0; i < len; i++)
+        if (tokens[i] < 0 || tokens[i] >= d->cfg.vocab)
+            return fail(MC_ERR_INVALID_ARGUMENT, "decoder: token id outside the vocabulary");
+    mc_status s = check_ready(d);
+    if (s != MC_OK) return s;
+    MC_HIP(hipSetDevice(d->dev->ordinal));
+    s = d->ensure_prefill(len, start_pos + len);
+    if (s != MC_OK) return s;
+    // rope rows start_pos .. start_pos + len - 1 must lie inside the table window
+    s = d->ensure_rope(start_pos);
+    if (s != MC_OK) return s;
+    if (start_pos - d->rope_start + len > d->rope_rows) {
+        d->rope_valid = false;
+        s = d->ensure_rope(start_pos);
+        if (s != MC_OK) return s;
+    }
+    MC_HIP(hipMemcpyAsync(d->pf_tokens, tokens, (size_t)len * 4, hipMemcpyHostToDevice, d->stream));
+    // the state a following mc_decoder_step / _generate continues from: last row of the prompt
+    s = d->launch("mc_step_set", 1, 1, 1, 64, 0,
+                  pack(d->state, tokens[len - 1], start_pos + len - 1, (int32_t)d->cfg.max_seq_len,
+                       (int32_t)d->pre_len, (int32_t)d->rope_start, (int32_t)(start_pos == 0 ? 1 : 0)));
+    if (s != MC_OK) return s;
+    if (start_pos == 0) d->ring_turned = false;
+    s = d->run_prefill(len, start_pos, sliding_window);
+    if (s != MC_OK) return s;
+    d->last_pos = start_pos + len - 1;
+    MC_HIP(hipStreamSynchronize(d->stream)); // `tokens` is the caller's buffer
+    if (next_token) MC_HIP(hipMemcpy(next_token, &d->state->token, 4, hipMemcpyDeviceToHost));
     return MC_OK;
 }
 
@@ -1053,6 +1238,8 @@ mc_decoder_generate(mc_decoder* d, int32_t first_token, int32_t start_pos, int32
     if (s != MC_OK) return s;
     // step_index restarts at 0 for every generate call
     MC_HIP(hipMemsetAsync(&d->state->step_index, 0, 4, d->stream));
+    if (start_pos == 0) d->ring_turned = false;
+    if (start_pos + n > d->cfg.max_seq_len) d->ring_turned = true;
     s = d->run_token(nullptr);
     if (s != MC_OK) return s;
     for (int i = 1; i < n; i++) {

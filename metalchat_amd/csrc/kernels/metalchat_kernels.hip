@@ -6,3 +6,4 @@
 #include "decode_kernels.hip"
 #include "synth_kernels.hip"
 #include "sampler_kernels.hip"
+#include "prefill_kernels.hip"

@@ -1,0 +1,536 @@
+// Prompt pass: nn::llama3 / nn::gemma3 operator() on len > 1 tokens
+// (include/metalchat/nn/llama.h:113-134, nn/gemma.h:110-137, nn/attention.h:161-206,283-321).
+//
+// Same arithmetic contract as the decode path -- every tensor the reference materialises is
+// rounded to T at the same place, quantised weights are dequantised as Wd = T(T(q) * T(s)) --
+// but with M = len rows the linears are GEMMs: the weight tile is dequantised ONCE into LDS and
+// reused by all the rows of the tile, and the products run on MFMA (bf16) with fp32 accumulation
+// like kernel/bmm.metal:54-67.
+//
+//   mc_pf_embed_T / _q8_T      embedding rows (+ gemma's T(sqrt(dim)) scale)
+//   mc_pf_rmsnorm_T            rmsnorm of M rows, optional residual add behind it (gemma post-norms)
+//   mc_pf_gemm_{i4,i8,w}_T_e{0,1}   Y[M,N] = T(X[M,K] Wd[N,K]^T)  (e1: T(res + that))
+//   mc_pf_act_mul_T            act(w1 x) * (w3 x) on the interleaved w1|w3 output
+//   mc_pf_rope_cache_T         (q/k-norm,) rope of rows start_pos.., K / V cache write of M rows
+//   mc_pf_scores_T             T(T(T(q.k) * scale) + mask), softmax without max shift -> T probs
+//   mc_pf_pv_T                 probs . V on MFMA
+#include "common.h"
+
+using namespace mc;
+
+typedef __bf16 pf_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float pf_f32x4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------------ rows
+template <typename T>
+__device__ __forceinline__ void
+pf_embed_body(const typename T::S* table, const int32_t* tokens, typename T::S* out, uint32_t dim,
+              float scale, int32_t use_scale)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
+    if (k >= dim) return;
+    const typename T::S v = table[(size_t)tokens[r] * dim + k];
+    out[(size_t)r * dim + k] = use_scale ? T::st(T::ld(v) * scale) : v;
+}
+extern "C" __global__ void
+mc_pf_embed_bfloat(const bf16_t* table, const int32_t* tokens, bf16_t* out, uint32_t dim, float scale, int32_t use_scale)
+{
+    pf_embed_body<BF>(table, tokens, out, dim, scale, use_scale);
+}
+extern "C" __global__ void
+mc_pf_embed_float(const float* table, const int32_t* tokens, float* out, uint32_t dim, float scale, int32_t use_scale)
+{
+    pf_embed_body<F32>(table, tokens, out, dim, scale, use_scale);
+}
+
+template <typename T>
+__device__ __forceinline__ void
+pf_embed_q8_body(const int8_t* table, const float* scales, const int32_t* tokens, typename T::S* out,
+                 uint32_t dim, float scale, int32_t use_scale)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
+    if (k >= dim) return;
+    const int32_t tok = tokens[r];
+    const float s = T::rt(scales[tok]);
+    float v = T::rt((float)table[(size_t)tok * dim + k] * s);
+    if (use_scale) v = T::rt(v * scale);
+    out[(size_t)r * dim + k] = T::st(v);
+}
+extern "C" __global__ void
+mc_pf_embed_q8_bfloat(const int8_t* table, const float* scales, const int32_t* tokens, bf16_t* out, uint32_t dim,
+                      float scale, int32_t use_scale)
+{
+    pf_embed_q8_body<BF>(table, scales, tokens, out, dim, scale, use_scale);
+}
+extern "C" __global__ void
+mc_pf_embed_q8_float(const int8_t* table, const float* scales, const int32_t* tokens, float* out, uint32_t dim,
+                     float scale, int32_t use_scale)
+{
+    pf_embed_q8_body<F32>(table, scales, tokens, out, dim, scale, use_scale);
+}
+
+// y[r] = T((mu + w) * x[r] * rsqrt(mean(x[r]^2) + eps)); with res: y[r] = T(res[r] + that)
+template <typename T>
+__device__ __forceinline__ void
+pf_rmsnorm_body(const typename T::S* x, const typename T::S* w, const typename T::S* res, typename T::S* y,
+                uint32_t dim, float eps, float mu)
+{
+    __shared__ float red[16];
+    const size_t base = (size_t)blockIdx.x * dim;
+    float ss = 0.0f;
+    for (uint32_t j = threadIdx.x; j < dim; j += blockDim.x) {
+        const float v = T::ld(x[base + j]);
+        ss += v * v;
+    }
+    const float tot = block_sum(ss, red);
+    const float inv = 1.0f / sqrtf(tot / (float)dim + eps);
+    for (uint32_t j = threadIdx.x; j < dim; j += blockDim.x) {
+        float v = T::rt((mu + T::ld(w[j])) * T::ld(x[base + j]) * inv);
+        if (res) v = T::ld(res[base + j]) + v;
+        y[base + j] = T::st(v);
+    }
+}
+extern "C" __global__ void
+mc_pf_rmsnorm_bfloat(const bf16_t* x, const bf16_t* w, const bf16_t* res, bf16_t* y, uint32_t dim, float eps, float mu)
+{
+    pf_rmsnorm_body<BF>(x, w, res, y, dim, eps, mu);
+}
+extern "C" __global__ void
+mc_pf_rmsnorm_float(const float* x, const float* w, const float* res, float* y, uint32_t dim, float eps, float mu)
+{
+    pf_rmsnorm_body<F32>(x, w, res, y, dim, eps, mu);
+}
+
+// rows (2j, 2j+1) of the fused matrix = (w1 row j, w3 row j): out[r][j] = T(act(a) * b)
+template <typename T>
+__device__ __forceinline__ float
+pf_silu_T(float x)
+{
+    const float e = T::rt(exp_precise(-x));
+    const float d = T::rt(1.0f + e);
+    return T::rt(x / d);
+}
+__device__ __forceinline__ float
+pf_gelu_f(float x)
+{
+    const float beta = 1.41421356237309504880f * 1.12837916709551257390f * 0.5f;
+    const float kappa = 0.044715f;
+    const float x3 = x * x * x;
+    const float inner = beta * (x + kappa * x3);
+    return 0.5f * x * (1.0f + (float)tanh((double)inner));
+}
+template <typename T>
+__device__ __forceinline__ void
+pf_act_mul_body(const typename T::S* in, typename T::S* out, uint32_t ffn, int32_t gelu)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
+    if (j >= ffn) return;
+    const float a = T::ld(in[(size_t)r * 2 * ffn + 2 * j]), b = T::ld(in[(size_t)r * 2 * ffn + 2 * j + 1]);
+    const float g = gelu ? T::rt(pf_gelu_f(a)) : pf_silu_T<T>(a);
+    out[(size_t)r * ffn + j] = T::st(g * b);
+}
+extern "C" __global__ void
+mc_pf_act_mul_bfloat(const bf16_t* in, bf16_t* out, uint32_t ffn, int32_t gelu)
+{
+    pf_act_mul_body<BF>(in, out, ffn, gelu);
+}
+extern "C" __global__ void
+mc_pf_act_mul_float(const float* in, float* out, uint32_t ffn, int32_t gelu)
+{
+    pf_act_mul_body<F32>(in, out, ffn, gelu);
+}
+
+// ------------------------------------------------------------------------------------------ GEMM
+// Workgroup tile: 64 rows of X (tokens) x 64 rows of W (outputs), K walked in chunks of 64.
+// Weights: the HBM layout of the decode GEMV -- int4 offset-binary nibbles in the
+// {0,2,4,6,1,3,5,7} order, scales in row quads.  A chunk of W is dequantised exactly once into LDS.
+enum { PF_W_T = 0, PF_W_I8 = 1, PF_W_I4 = 2 };
+constexpr uint32_t PF_BM = 64, PF_BN = 64, PF_BK = 64;
+
+template <typename T> struct pf_lds;
+template <> struct pf_lds<BF> { static constexpr uint32_t LD = PF_BK + 8; };  // 144-byte rows: spreads banks
+template <> struct pf_lds<F32> { static constexpr uint32_t LD = PF_BK + 4; };
+
+template <int WF, typename T>
+__device__ __forceinline__ float
+pf_scale(const void* sp, uint32_t row, uint32_t g, uint32_t ngroups)
+{
+    const size_t idx = ((size_t)(row / 4) * ngroups + g) * 4 + row % 4;
+    return T::bytes == 2 ? bf2f(static_cast<const bf16_t*>(sp)[idx]) : static_cast<const float*>(sp)[idx];
+}
+
+template <int WF, typename T, int EPI>
+__device__ __forceinline__ void
+pf_gemm_body(const void* __restrict__ wp, const void* __restrict__ sp, const typename T::S* __restrict__ X,
+             typename T::S* __restrict__ Y, const typename T::S* __restrict__ res, uint32_t M, uint32_t N,
+             uint32_t K, uint32_t group)
+{
+    using S = typename T::S;
+    constexpr uint32_t LD = pf_lds<T>::LD;
+    __shared__ __attribute__((aligned(16))) S Xs[PF_BM * LD];
+    __shared__ __attribute__((aligned(16))) S Ws[PF_BN * LD];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t n0 = blockIdx.x * PF_BN, m0 = blockIdx.y * PF_BM;
+    const uint32_t ngroups = group ? K / group : 1;
+    const uint32_t glog = group ? 31u - __builtin_clz(group) : 31u;
+    const size_t rowb = WF == PF_W_I4 ? K / 2 : (WF == PF_W_I8 ? K : (size_t)K * T::bytes);
+
+    pf_f32x4 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    float facc[4][4] = {};
+
+    for (uint32_t k0 = 0; k0 < K; k0 += PF_BK) {
+        // ---- X tile: 64 rows x 64 k, thread t -> row t/4, 16 consecutive k
+        {
+            const uint32_t r = tid >> 2, kk = (tid & 3) * 16;
+            const uint32_t gr = m0 + r < M ? m0 + r : M - 1;
+            const S* src = X + (size_t)gr * K + k0 + kk;
+            S* dst = Xs + r * LD + kk;
+#pragma unroll
+            for (int i = 0; i < 16; i++) dst[i] = (k0 + kk + i < K) ? src[i] : T::st(0.0f);
+        }
+        // ---- W tile, dequantised exactly: Wd = T(T(q) * T(s))   (kernel/mul.metal:78-82)
+        {
+            const uint32_t r = tid >> 2, kk = (tid & 3) * 16;
+            const uint32_t gr = n0 + r < N ? n0 + r : N - 1;
+            S* dst = Ws + r * LD + kk;
+            const uint32_t kabs = k0 + kk;
+            if (kabs >= K) {
+#pragma unroll
+                for (int i = 0; i < 16; i++) dst[i] = T::st(0.0f);
+            } else if (WF == PF_W_T) {
+                const S* src = static_cast<const S*>(wp) + (size_t)gr * K + kabs;
+#pragma unroll
+                for (int i = 0; i < 16; i++) dst[i] = src[i];
+            } else if (WF == PF_W_I8) {
+                const int8_t* src = static_cast<const int8_t*>(wp) + (size_t)gr * rowb + kabs;
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    const float s = T::rt(pf_scale<WF, T>(sp, gr, group ? (kabs + i) >> glog : 0, ngroups));
+                    dst[i] = T::st((float)src[i] * s);
+                }
+            } else {
+                // 16 weights = two dwords; nibble p of a dword is weight {0,2,4,6,1,3,5,7}[p]
+                const uint32_t* src = reinterpret_cast<const uint32_t*>(static_cast<const char*>(wp) + (size_t)gr * rowb + kabs / 2);
+#pragma unroll
+                for (int d = 0; d < 2; d++) {
+                    const uint32_t v = src[d];
+#pragma unroll
+                    for (int p = 0; p < 8; p++) {
+                        const int wi = (p < 4) ? 2 * p : 2 * (p - 4) + 1;
+                        const int q = (int)((v >> (4 * p)) & 0xF) - 8;
+                        const uint32_t kq = kabs + 8 * d + wi;
+                        const float s = T::rt(pf_scale<WF, T>(sp, gr, group ? kq >> glog : 0, ngroups));
+                        dst[8 * d + wi] = T::st((float)q * s);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (T::bytes == 2) {
+            // wave w: token rows [16w, 16w+16) x 4 column tiles; A/B fragments of 8 consecutive k
+            const uint32_t ar = wave * 16 + (lane & 15), kg = (lane >> 4) * 8;
+#pragma unroll
+            for (uint32_t ks = 0; ks < PF_BK; ks += 32) {
+                const uint4 a = *reinterpret_cast<const uint4*>(Xs + ar * LD + ks + kg);
+#pragma unroll
+                for (int nt = 0; nt < 4; nt++) {
+                    const uint4 b = *reinterpret_cast<const uint4*>(Ws + (nt * 16 + (lane & 15)) * LD + ks + kg);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(pf_bf16x8, a),
+                                                                     __builtin_bit_cast(pf_bf16x8, b), acc[nt], 0, 0, 0);
+                }
+            }
+        } else {
+            // T = float (parity path): thread (ty, tx) owns a 4 x 4 block, plain fp32 multiply-adds
+            const uint32_t ty = tid >> 4, tx = tid & 15;
+            for (uint32_t k = 0; k < PF_BK; k++) {
+                float xa[4], wb[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    xa[i] = T::ld(Xs[(ty * 4 + i) * LD + k]);
+                    wb[i] = T::ld(Ws[(tx * 4 + i) * LD + k]);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+#pragma unroll
+                    for (int j = 0; j < 4; j++) facc[i][j] += xa[i] * wb[j];
+            }
+        }
+        __syncthreads();
+    }
+    if (T::bytes == 2) {
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const uint32_t m = m0 + wave * 16 + (lane >> 4) * 4 + i, n = n0 + nt * 16 + (lane & 15);
+                if (m < M && n < N) {
+                    float v = T::rt(acc[nt][i]);
+                    if (EPI == 1) v = T::ld(res[(size_t)m * N + n]) + v;
+                    Y[(size_t)m * N + n] = T::st(v);
+                }
+            }
+    } else {
+        const uint32_t ty = tid >> 4, tx = tid & 15;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t m = m0 + ty * 4 + i, n = n0 + tx * 4 + j;
+                if (m < M && n < N) {
+                    float v = facc[i][j];
+                    if (EPI == 1) v = T::ld(res[(size_t)m * N + n]) + v;
+                    Y[(size_t)m * N + n] = T::st(v);
+                }
+            }
+    }
+}
+
+#define MC_PF_GEMM(NAME, WF, T, EPI)                                                                     \
+    extern "C" __global__ void __launch_bounds__(256)                                                    \
+    NAME(const void* w, const void* scales, const typename T::S* X, typename T::S* Y,                    \
+         const typename T::S* res, uint32_t M, uint32_t N, uint32_t K, uint32_t group)                   \
+    {                                                                                                    \
+        pf_gemm_body<WF, T, EPI>(w, scales, X, Y, res, M, N, K, group);                                  \
+    }
+MC_PF_GEMM(mc_pf_gemm_i4_bfloat_e0, PF_W_I4, BF, 0)
+MC_PF_GEMM(mc_pf_gemm_i4_bfloat_e1, PF_W_I4, BF, 1)
+MC_PF_GEMM(mc_pf_gemm_i8_bfloat_e0, PF_W_I8, BF, 0)
+MC_PF_GEMM(mc_pf_gemm_i8_bfloat_e1, PF_W_I8, BF, 1)
+MC_PF_GEMM(mc_pf_gemm_w_bfloat_e0, PF_W_T, BF, 0)
+MC_PF_GEMM(mc_pf_gemm_w_bfloat_e1, PF_W_T, BF, 1)
+MC_PF_GEMM(mc_pf_gemm_i4_float_e0, PF_W_I4, F32, 0)
+MC_PF_GEMM(mc_pf_gemm_i4_float_e1, PF_W_I4, F32, 1)
+MC_PF_GEMM(mc_pf_gemm_i8_float_e0, PF_W_I8, F32, 0)
+MC_PF_GEMM(mc_pf_gemm_i8_float_e1, PF_W_I8, F32, 1)
+MC_PF_GEMM(mc_pf_gemm_w_float_e0, PF_W_T, F32, 0)
+MC_PF_GEMM(mc_pf_gemm_w_float_e1, PF_W_T, F32, 1)
+
+// ------------------------------------------------------------------------------------------ rope + cache
+// grid (H + 2 KV, M), hd/2 threads.  Row r of the prompt sits at position start_pos + r, cache slot
+// start_pos + r (the prompt pass is only taken while the ring has not started to turn), rope
+// table row start_pos - rope_start + r.  The fused wq|wk|wv matrix stores the rotation partners
+// of q and k adjacently: packed [2j] = natural [j], [2j+1] = natural [j + hd/2].
+template <typename T>
+__device__ __forceinline__ void
+pf_rope_cache_body(const typename T::S* qkv, typename T::S* q_out, typename T::S* kc, typename T::S* vt,
+                   const float* fcos, const float* fsin, const typename T::S* q_norm, const typename T::S* k_norm,
+                   uint32_t H, uint32_t KV, uint32_t hd, uint32_t max_seq, uint32_t start_pos, uint32_t rope_row0,
+                   float eps, float mu)
+{
+    __shared__ float red[16];
+    const uint32_t b = blockIdx.x, r = blockIdx.y, j = threadIdx.x, half = hd / 2;
+    const uint32_t slot = start_pos + r;
+    const typename T::S* row = qkv + (size_t)r * (H + 2 * KV) * hd;
+    if (b >= H + KV) {
+        const uint32_t kv = b - H - KV;
+        const typename T::S* src = row + (size_t)(H + KV + kv) * hd;
+        typename T::S* dst = vt + (size_t)kv * hd * max_seq;
+        dst[(size_t)j * max_seq + slot] = src[j];
+        dst[(size_t)(j + half) * max_seq + slot] = src[j + half];
+        return;
+    }
+    const bool is_q = b < H;
+    const typename T::S* src = row + (size_t)b * hd;
+    float x1 = T::ld(src[2 * j]), x2 = T::ld(src[2 * j + 1]);
+    const typename T::S* nw = is_q ? q_norm : k_norm;
+    if (nw) {
+        const float tot = block_sum(x1 * x1 + x2 * x2, red);
+        const float inv = 1.0f / sqrtf(tot / (float)hd + eps);
+        x1 = T::rt((mu + T::ld(nw[j])) * x1 * inv);
+        x2 = T::rt((mu + T::ld(nw[j + half])) * x2 * inv);
+    }
+    const size_t tr = (size_t)(rope_row0 + r) * half + j;
+    const float c = fcos[tr], s = fsin[tr];
+    const typename T::S o1 = T::st(c * x1 - s * x2), o2 = T::st(s * x1 + c * x2);
+    typename T::S* dst = is_q ? q_out + ((size_t)r * H + b) * hd : kc + ((size_t)(b - H) * max_seq + slot) * hd;
+    dst[j] = o1;
+    dst[j + half] = o2;
+}
+extern "C" __global__ void
+mc_pf_rope_cache_bfloat(const bf16_t* qkv, bf16_t* q_out, bf16_t* kc, bf16_t* vt, const float* fcos, const float* fsin,
+                        const bf16_t* q_norm, const bf16_t* k_norm, uint32_t H, uint32_t KV, uint32_t hd,
+                        uint32_t max_seq, uint32_t start_pos, uint32_t rope_row0, float eps, float mu)
+{
+    pf_rope_cache_body<BF>(qkv, q_out, kc, vt, fcos, fsin, q_norm, k_norm, H, KV, hd, max_seq, start_pos, rope_row0, eps, mu);
+}
+extern "C" __global__ void
+mc_pf_rope_cache_float(const float* qkv, float* q_out, float* kc, float* vt, const float* fcos, const float* fsin,
+                       const float* q_norm, const float* k_norm, uint32_t H, uint32_t KV, uint32_t hd,
+                       uint32_t max_seq, uint32_t start_pos, uint32_t rope_row0, float eps, float mu)
+{
+    pf_rope_cache_body<F32>(qkv, q_out, kc, vt, fcos, fsin, q_norm, k_norm, H, KV, hd, max_seq, start_pos, rope_row0, eps, mu);
+}
+
+// ------------------------------------------------------------------------------------------ attention
+// Visibility of cache column c (0 <= c < S) from prompt row r, as make_causal_mask /
+// make_sliding_causal_mask build it (nn/attention.h:283-321): only the LAST M columns form the
+// causal square -- columns of an earlier context stay at -inf (reproduced).
+__device__ __forceinline__ bool
+pf_visible(uint32_t r, uint32_t c, uint32_t S, uint32_t M, uint32_t window)
+{
+    if (c + M < S) return false;
+    const uint32_t cc = c - (S - M);
+    if (cc > r) return false;
+    if (window && r >= window + cc) return false;
+    return true;
+}
+
+// grid (ceil(M/16), H), 256 threads.  Workgroup = 16 prompt rows of one head; wave w takes the
+// 16-column key tiles w, w+4, ... of the visible range.  Pass 1 stores the masked scores (T) and
+// accumulates exp row sums; pass 2 rewrites them as probabilities T(exp(s) / sum).
+// probs: [H][M][S] of T.
+template <typename T>
+__device__ __forceinline__ void
+pf_scores_body(const typename T::S* Q, const typename T::S* kc, typename T::S* probs, uint32_t M, uint32_t S,
+               uint32_t H, uint32_t n_rep, uint32_t hd, uint32_t max_seq, float scale, uint32_t window)
+{
+    using St = typename T::S;
+    __shared__ float wsum[4][16];
+    __shared__ float inv_sum[16];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t r0 = blockIdx.x * 16, h = blockIdx.y, kv = h / n_rep;
+    const St* kbase = kc + (size_t)kv * max_seq * hd;
+    St* pbase = probs + (size_t)h * M * S;
+    // visible column range of the whole row block
+    const uint32_t sq = S - M; // first column of the causal square
+    const uint32_t rlast = min(r0 + 15, M - 1);
+    uint32_t clo = sq, chi = sq + rlast; // inclusive
+    if (window && r0 + 1 > window) clo = sq + (r0 + 1 - window);
+    const uint32_t t_lo = clo / 16, t_hi = chi / 16;
+    float rsum[4] = {0, 0, 0, 0};
+    // rows of this lane in the C layout: (lane/16)*4 + i ; column lane%16
+    for (uint32_t t = t_lo + wave; t <= t_hi; t += 4) {
+        pf_f32x4 acc = {0, 0, 0, 0};
+        const uint32_t key = t * 16 + (lane & 15);
+        const uint32_t keyc = key < S ? key : S - 1;
+        const uint32_t qr = min(r0 + (lane & 15), M - 1);
+        if (T::bytes == 2) {
+            const uint32_t kg = (lane >> 4) * 8;
+            for (uint32_t d0 = 0; d0 < hd; d0 += 32) {
+                const uint4 a = *reinterpret_cast<const uint4*>(Q + ((size_t)qr * H + h) * hd + d0 + kg);
+                const uint4 b = *reinterpret_cast<const uint4*>(kbase + (size_t)keyc * hd + d0 + kg);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(pf_bf16x8, a),
+                                                              __builtin_bit_cast(pf_bf16x8, b), acc, 0, 0, 0);
+            }
+        } else {
+            const uint32_t kq = lane >> 4;
+            for (uint32_t d0 = 0; d0 < hd; d0 += 4) {
+                const float a = T::ld(Q[((size_t)qr * H + h) * hd + d0 + kq]);
+                const float b = T::ld(kbase[(size_t)keyc * hd + d0 + kq]);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t r = r0 + (lane >> 4) * 4 + i;
+            if (r < M && key < S) {
+                float s = T::rt(T::rt(acc[i]) * scale);                       // bmm -> T, scalar_mul in T
+                s = pf_visible(r, key, S, M, window) ? T::rt(s + 0.0f) : -INFINITY; // add_broadcast(mask) in T
+                pbase[(size_t)r * S + key] = T::st(s);
+                rsum[i] += s == -INFINITY ? 0.0f : exp_precise(s);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        float e = rsum[i];
+        e += __shfl_xor(e, 1, 64);
+        e += __shfl_xor(e, 2, 64);
+        e += __shfl_xor(e, 4, 64);
+        e += __shfl_xor(e, 8, 64);
+        if ((lane & 15) == 0) wsum[wave][(lane >> 4) * 4 + i] = e;
+    }
+    __syncthreads();
+    if (threadIdx.x < 16)
+        inv_sum[threadIdx.x] = 1.0f / ((wsum[0][threadIdx.x] + wsum[1][threadIdx.x]) + (wsum[2][threadIdx.x] + wsum[3][threadIdx.x]));
+    __syncthreads();
+    // pass 2: probabilities; columns outside the visible tiles are exactly 0 (exp(-inf) = 0)
+    for (uint32_t r = r0 + wave; r < r0 + 16 && r < M; r += 4) {
+        const float inv = inv_sum[r - r0];
+        St* prow = pbase + (size_t)r * S;
+        for (uint32_t c = lane; c < S; c += 64) {
+            float p = 0.0f;
+            if (c >= t_lo * 16 && c < (t_hi + 1) * 16) {
+                const float s = T::ld(prow[c]);
+                p = s == -INFINITY ? 0.0f : T::rt(exp_precise(s) * inv);
+            }
+            prow[c] = T::st(p);
+        }
+    }
+}
+extern "C" __global__ void
+mc_pf_scores_bfloat(const bf16_t* Q, const bf16_t* kc, bf16_t* probs, uint32_t M, uint32_t S, uint32_t H,
+                    uint32_t n_rep, uint32_t hd, uint32_t max_seq, float scale, uint32_t window)
+{
+    pf_scores_body<BF>(Q, kc, probs, M, S, H, n_rep, hd, max_seq, scale, window);
+}
+extern "C" __global__ void
+mc_pf_scores_float(const float* Q, const float* kc, float* probs, uint32_t M, uint32_t S, uint32_t H,
+                   uint32_t n_rep, uint32_t hd, uint32_t max_seq, float scale, uint32_t window)
+{
+    pf_scores_body<F32>(Q, kc, probs, M, S, H, n_rep, hd, max_seq, scale, window);
+}
+
+// grid (ceil(M/16), H), 256 threads: out[r][h*hd + d] = T(sum_c probs[h][r][c] * V[c][d]); wave w
+// owns the 16-wide d tiles w, w+4, ...; V is the transposed cache Vt[kv][d][slot].
+template <typename T>
+__device__ __forceinline__ void
+pf_pv_body(const typename T::S* probs, const typename T::S* vt, typename T::S* out, uint32_t M, uint32_t S,
+           uint32_t H, uint32_t n_rep, uint32_t hd, uint32_t max_seq, uint32_t window)
+{
+    using St = typename T::S;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t r0 = blockIdx.x * 16, h = blockIdx.y, kv = h / n_rep;
+    const St* pbase = probs + (size_t)h * M * S;
+    const St* vbase = vt + (size_t)kv * hd * max_seq;
+    const uint32_t sq = S - M, rlast = min(r0 + 15, M - 1);
+    uint32_t clo = sq, chi = sq + rlast;
+    if (window && r0 + 1 > window) clo = sq + (r0 + 1 - window);
+    const uint32_t pr = min(r0 + (lane & 15), M - 1);
+    for (uint32_t dt0 = wave * 16; dt0 < hd; dt0 += 64) {
+        pf_f32x4 acc = {0, 0, 0, 0};
+        const uint32_t d = dt0 + (lane & 15);
+        if (T::bytes == 2) {
+            const uint32_t kg = (lane >> 4) * 8;
+            for (uint32_t c0 = clo & ~31u; c0 <= chi; c0 += 32) {
+                uint4 a = make_uint4(0, 0, 0, 0), b = make_uint4(0, 0, 0, 0);
+                const uint32_t c = c0 + kg;
+                if (c + 8 <= S && (S % 8 == 0)) {
+                    a = *reinterpret_cast<const uint4*>(pbase + (size_t)pr * S + c);
+                } else {
+                    bf16_t tmp[8];
+                    for (int i = 0; i < 8; i++) tmp[i] = c + i < S ? reinterpret_cast<const bf16_t*>(pbase)[(size_t)pr * S + c + i] : (bf16_t)0;
+                    a = *reinterpret_cast<const uint4*>(tmp);
+                }
+                if (c + 8 <= max_seq) b = *reinterpret_cast<const uint4*>(vbase + (size_t)d * max_seq + c);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(pf_bf16x8, a),
+                                                              __builtin_bit_cast(pf_bf16x8, b), acc, 0, 0, 0);
+            }
+        } else {
+            const uint32_t kq = lane >> 4;
+            for (uint32_t c0 = clo & ~3u; c0 <= chi; c0 += 4) {
+                const uint32_t c = c0 + kq;
+                const float a = c < S ? T::ld(pbase[(size_t)pr * S + c]) : 0.0f;
+                const float b = c < S ? T::ld(vbase[(size_t)d * max_seq + c]) : 0.0f;
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t r = r0 + (lane >> 4) * 4 + i;
+            if (r < M) out[((size_t)r * H + h) * hd + d] = T::st(acc[i]);
+        }
+    }
+}
+extern "C" __global__ void
+mc_pf_pv_bfloat(const bf16_t* probs, const bf16_t* vt, bf16_t* out, uint32_t M, uint32_t S, uint32_t H, uint32_t n_rep,
+                uint32_t hd, uint32_t max_seq, uint32_t window)
+{
+    pf_pv_body<BF>(probs, vt, out, M, S, H, n_rep, hd, max_seq, window);
+}
+extern "C" __global__ void
+mc_pf_pv_float(const float* probs, const float* vt, float* out, uint32_t M, uint32_t S, uint32_t H, uint32_t n_rep,
+               uint32_t hd, uint32_t max_seq, uint32_t window)
+{
+    pf_pv_body<F32>(probs, vt, out, M, S, H, n_rep, hd, max_seq, window);
+}

@@ -114,6 +114,7 @@ def capi() -> C.CDLL:
         "mc_decoder_init_synthetic": (i32, [vp, u64]),
         "mc_decoder_step": (i32, [vp, i32, i32, vp, C.POINTER(i32)]),
         "mc_decoder_generate": (i32, [vp, i32, i32, i32, C.POINTER(i32)]),
+        "mc_decoder_prefill": (i32, [vp, C.POINTER(i32), i32, i32, i32, C.POINTER(i32)]),
         "mc_decoder_hidden_out": (vp, [vp]),
         "mc_decoder_hidden_in": (vp, [vp]),
         "mc_decoder_set_taps": (i32, [vp, i32]),
@@ -535,6 +536,14 @@ class Decoder:
         _check(capi().mc_decoder_step(self._h, token, start_pos,
                                       C.c_void_p(hidden_in) if hidden_in else None,
                                       C.byref(nt) if sync else None))
+        return nt.value
+
+    def prefill(self, tokens, start_pos: int = 0, sliding_window: int = 0) -> int:
+        """The prompt pass on len(tokens) rows; returns the sampler's pick for the last row."""
+        t = np.ascontiguousarray(tokens, dtype=np.int32)
+        nt = C.c_int32(-1)
+        _check(capi().mc_decoder_prefill(self._h, t.ctypes.data_as(C.POINTER(C.c_int32)), t.size, start_pos,
+                                         sliding_window, C.byref(nt)))
         return nt.value
 
     def generate(self, first_token: int, start_pos: int, n: int) -> np.ndarray:

@@ -1058,6 +1058,191 @@ mco_model_step_range(mco_model* m, int32_t token, int32_t start_pos, int32_t lay
     return best;
 }
 
+/* nn::sink_cache::copy (nn/cache.h:167-216) for any len <= cache size: rows [len][row] floats. */
+static int32_t
+sink_cache_update_n(mco_model* m, void* cache, const float* rows, int32_t len, int32_t start_pos)
+{
+    const int dt = m->opt.dtype;
+    const int32_t cache_size = m->opt.max_seq_len;
+    const size_t row = (size_t)m->opt.n_kv_heads * m->opt.head_dim;
+    const size_t rb = row * m->esz;
+    const int32_t pre = m->pre_len, post = cache_size - pre;
+    if (start_pos >= cache_size) {
+        char* src = (char*)cache;
+        char* dst = (char*)m->roll_tmp;
+        memcpy(dst, src, (size_t)pre * rb);
+        for (int32_t p = 0; p < post; p++)
+            memcpy(dst + (size_t)(pre + p) * rb, src + (size_t)(pre + (p + len) % post) * rb, rb);
+        memcpy(src, dst, (size_t)cache_size * rb);
+        start_pos = cache_size - len;
+    }
+    for (int32_t r = 0; r < len; r++)
+        for (size_t j = 0; j < row; j++)
+            st(dt, cache, (size_t)(start_pos + r) * row + j, rows[(size_t)r * row + j]);
+    return start_pos + len;
+}
+
+/* nn::llama3::operator() / nn::gemma3::operator() for an input of `len` tokens
+ * (include/metalchat/nn/llama.h:113-134, nn/gemma.h:110-137): the prompt pass.  Row-wise layers
+ * are the same arithmetic as the one-token step applied to each row; what is new is
+ *   - rope rows start_pos .. start_pos+len-1 (kernel/rope.metal:46-59, pos = row / n_head),
+ *   - the cache write of len rows (nn/cache.h:205-213),
+ *   - the mask: make_causal_mask(len, end_pos) (nn/attention.h:283-299) is -inf everywhere
+ *     except the lower triangle of its LAST len columns, so with start_pos > 0 the earlier cache
+ *     columns stay masked -- reproduced as is; sliding layers (gemma) add the second triangle
+ *     (nn/attention.h:302-321): column c of the square is visible from row r iff r-window < c <= r;
+ *     scores = T(T(T(q.k) * scale) + mask) (attention.h:197-201), softmax without max shift,
+ *   - only the last row goes through the output head (llama.h:130-133).
+ * len == 1 takes no mask at all (make_causal_mask returns nullopt) and equals mco_model_step.
+ * PARITY UNPINNED: the reference asserts nothing about prompt logits.  Returns the greedy token. */
+int32_t
+mco_model_forward(mco_model* m, const int32_t* tokens, int32_t len, int32_t start_pos,
+                  int32_t sliding_window, void* logits_out)
+{
+    const mco_model_options* o = &m->opt;
+    const int dt = o->dtype;
+    const int32_t dim = o->dim, H = o->n_heads, KV = o->n_kv_heads, hd = o->head_dim, ffn = o->ffn_dim;
+    const int32_t n_rep = H / KV, half = hd / 2;
+    const float mu = o->family == 1 ? 1.0f : 0.0f;
+    const size_t row = (size_t)KV * hd;
+#define NEW(n) (float*)malloc(sizeof(float) * (size_t)(n))
+    float *x = NEW((size_t)len * dim), *hn = NEW((size_t)len * dim), *q = NEW((size_t)len * H * hd);
+    float *k = NEW((size_t)len * row), *v = NEW((size_t)len * row), *att = NEW((size_t)len * H * hd);
+    float *proj = NEW((size_t)len * dim), *h1 = NEW((size_t)len * dim);
+    float *g1 = NEW((size_t)len * ffn), *g3 = NEW((size_t)len * ffn), *ff = NEW((size_t)len * dim);
+    float *scores = NEW(o->max_seq_len), *partial = NEW(1024), *fcos = NEW((size_t)2 * len * half),
+          *fsin = NEW((size_t)2 * len * half);
+#undef NEW
+    for (int32_t r = 0; r < len; r++) {
+        float* xr = x + (size_t)r * dim;
+        const int32_t token = tokens[r];
+        if (m->emb_kind == 0) {
+            for (int32_t j = 0; j < dim; j++) xr[j] = ld(dt, m->emb_weight, (size_t)token * dim + j);
+        } else {
+            const int8_t* qw = (const int8_t*)m->emb_weight + (size_t)token * dim;
+            const float s = rt(dt, m->emb_scales[token]);
+            for (int32_t j = 0; j < dim; j++) xr[j] = rt(dt, (float)qw[j] * s);
+        }
+        if (o->family == 1) {
+            const float sc = rt(dt, sqrtf((float)dim));
+            for (int32_t j = 0; j < dim; j++) xr[j] = rt(dt, xr[j] * sc);
+        }
+        for (int t = 0; t < 2; t++) {
+            const float theta = t == 0 ? o->rope_theta : o->rope_sliding_theta;
+            if (theta <= 0.0f) continue;
+            for (int32_t j = 0; j < half; j++)
+                rope_angle((uint32_t)(start_pos + r), (uint32_t)j, (uint32_t)hd, theta,
+                           &fcos[((size_t)t * len + r) * half + j], &fsin[((size_t)t * len + r) * half + j]);
+        }
+    }
+    const float scale_T = rt(dt, o->attn_scale);
+    for (int32_t li = 0; li < o->n_layers; li++) {
+        const mco_layer_weights* L = &m->layers[li];
+#pragma omp parallel for schedule(dynamic)
+        for (int32_t r = 0; r < len; r++) {
+            float* hr = hn + (size_t)r * dim;
+            rmsnorm_row(dt, x + (size_t)r * dim, L->attention_norm, dim, o->norm_eps, mu, hr);
+            float* qq = q + (size_t)r * H * hd;
+            float* kk = k + (size_t)r * row;
+            linear_apply(dt, &L->wq, hr, qq);
+            linear_apply(dt, &L->wk, hr, kk);
+            linear_apply(dt, &L->wv, hr, v + (size_t)r * row);
+            if (L->q_norm) {
+                for (int32_t h = 0; h < H; h++) rmsnorm_row(dt, qq + h * hd, L->q_norm, hd, o->norm_eps, mu, qq + h * hd);
+                for (int32_t h = 0; h < KV; h++) rmsnorm_row(dt, kk + h * hd, L->k_norm, hd, o->norm_eps, mu, kk + h * hd);
+            }
+            const float* c = fcos + ((size_t)L->rope_table * len + r) * half;
+            const float* s = fsin + ((size_t)L->rope_table * len + r) * half;
+            for (int32_t h = 0; h < H + KV; h++) {
+                float* p = h < H ? qq + h * hd : kk + (h - H) * hd;
+                for (int32_t j = 0; j < half; j++) {
+                    const float x1 = p[j], x2 = p[half + j];
+                    p[j] = rt(dt, c[j] * x1 - s[j] * x2);
+                    p[half + j] = rt(dt, s[j] * x1 + c[j] * x2);
+                }
+            }
+        }
+        const int32_t S = sink_cache_update_n(m, m->k_cache[li], k, len, start_pos);
+        sink_cache_update_n(m, m->v_cache[li], v, len, start_pos);
+        m->end_pos[li] = S;
+        const int sliding = L->rope_table == 1 && sliding_window > 0;
+        for (int32_t r = 0; r < len; r++) {
+            for (int32_t h = 0; h < H; h++) {
+                const int32_t kvh = h / n_rep;
+                const float* qq = q + ((size_t)r * H + h) * hd;
+                for (int32_t sp = 0; sp < S; sp++) {
+                    float p = 0.0f;
+                    for (int32_t d = 0; d < hd; d++) p += qq[d] * ld(dt, m->k_cache[li], (size_t)sp * row + kvh * hd + d);
+                    float sc = rt(dt, rt(dt, p) * scale_T);
+                    if (len > 1) {
+                        /* mask [len, S]: column sp belongs to the square iff sp >= S - len */
+                        const int32_t cc = sp - (S - len);
+                        float mk = -INFINITY;
+                        if (cc >= 0 && cc <= r) mk = 0.0f;                                   /* upper: triu(.., 1) */
+                        if (sliding) {
+                            const float lower = (cc >= 0 && r < sliding_window + cc) ? 0.0f : -INFINITY;
+                            mk = rt(dt, mk + lower);                                        /* add(upper, lower) */
+                        }
+                        sc = rt(dt, sc + mk);
+                    }
+                    scores[sp] = sc;
+                }
+                const uint32_t block = ceil_div_u32((uint32_t)S, 1024);
+                const uint32_t nthreads = ceil_div_u32((uint32_t)S, block);
+                for (uint32_t t = 0; t < nthreads; t++) {
+                    float acc = 0.0f;
+                    for (uint32_t j = t * block; j < (t + 1) * block && j < (uint32_t)S; j++) acc += exp_precise(scores[j]);
+                    partial[t] = acc;
+                }
+                const float exp_sum = 1.0f / threadgroup_sum(partial, nthreads);
+                for (int32_t sp = 0; sp < S; sp++) scores[sp] = rt(dt, exp_precise(scores[sp]) * exp_sum);
+                for (int32_t d = 0; d < hd; d++) {
+                    float p = 0.0f;
+                    for (int32_t sp = 0; sp < S; sp++) p += scores[sp] * ld(dt, m->v_cache[li], (size_t)sp * row + kvh * hd + d);
+                    att[((size_t)r * H + h) * hd + d] = rt(dt, p);
+                }
+            }
+        }
+#pragma omp parallel for schedule(dynamic)
+        for (int32_t r = 0; r < len; r++) {
+            float* pr = proj + (size_t)r * dim;
+            float* hr = h1 + (size_t)r * dim;
+            float* xr = x + (size_t)r * dim;
+            linear_apply(dt, &L->wo, att + (size_t)r * H * hd, pr);
+            if (L->attention_post_norm) rmsnorm_row(dt, pr, L->attention_post_norm, dim, o->norm_eps, mu, pr);
+            for (int32_t j = 0; j < dim; j++) hr[j] = rt(dt, xr[j] + pr[j]);
+            float* nr = hn + (size_t)r * dim;
+            rmsnorm_row(dt, hr, L->ffn_norm, dim, o->norm_eps, mu, nr);
+            float* a1 = g1 + (size_t)r * ffn;
+            float* a3 = g3 + (size_t)r * ffn;
+            linear_apply(dt, &L->w1, nr, a1);
+            linear_apply(dt, &L->w3, nr, a3);
+            for (int32_t j = 0; j < ffn; j++) {
+                const float a = o->family == 1 ? rt(dt, gelu_f(a1[j])) : silu_T(dt, a1[j]);
+                a1[j] = rt(dt, a * a3[j]);
+            }
+            float* fr = ff + (size_t)r * dim;
+            linear_apply(dt, &L->w2, a1, fr);
+            if (L->ffn_post_norm) rmsnorm_row(dt, fr, L->ffn_post_norm, dim, o->norm_eps, mu, fr);
+            for (int32_t j = 0; j < dim; j++) xr[j] = rt(dt, hr[j] + fr[j]);
+        }
+        /* tap: the LAST row after this layer (what a following decode step continues from) */
+        memcpy(m->hidden_taps + (size_t)(li + 1) * dim, x + (size_t)(len - 1) * dim, sizeof(float) * dim);
+    }
+    rmsnorm_row(dt, x + (size_t)(len - 1) * dim, m->final_norm, dim, o->norm_eps, mu, hn);
+    float* logits = (float*)malloc(sizeof(float) * o->vocab);
+    linear_apply(dt, &m->output, hn, logits);
+    int32_t best = 0;
+    for (int32_t i = 1; i < o->vocab; i++)
+        if (logits[i] > logits[best]) best = i;
+    if (logits_out)
+        for (int32_t i = 0; i < o->vocab; i++) st(dt, logits_out, (size_t)i, logits[i]);
+    free(logits);
+    free(x); free(hn); free(q); free(k); free(v); free(att); free(proj); free(h1); free(g1); free(g3);
+    free(ff); free(scores); free(partial); free(fcos); free(fsin);
+    return best;
+}
+
 int32_t
 mco_model_step(mco_model* m, int32_t token, int32_t start_pos, void* logits_out)
 {

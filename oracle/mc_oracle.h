@@ -157,6 +157,9 @@ mco_model* mco_model_create(const mco_model_options* opt, const mco_layer_weight
 void mco_model_destroy(mco_model* m);
 /* One reference transform(token, start_pos) with len = 1.  logits_out: T[vocab] (may be NULL).
  * Returns the greedy argmax (first maximum) of the logits. */
+/* The prompt pass: nn::llama3 / nn::gemma3 operator() on `len` tokens (llama.h:113-134). */
+int32_t mco_model_forward(mco_model* m, const int32_t* tokens, int32_t len, int32_t start_pos,
+                          int32_t sliding_window, void* logits_out);
 int32_t mco_model_step(mco_model* m, int32_t token, int32_t start_pos, void* logits_out);
 /* One pipeline stage of a step: layers [layer_begin, layer_end).  Stage 0 embeds `token`, later
  * stages read hidden_in (T[dim]); the last stage returns the greedy token, earlier ones write

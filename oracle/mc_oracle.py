@@ -44,6 +44,7 @@ def lib() -> C.CDLL:
         _lib.mco_pcg32_uniform.argtypes = [C.c_uint64, C.c_uint64]
         _lib.mco_sample_default.restype = C.c_int32
         _lib.mco_model_step.restype = C.c_int32
+        _lib.mco_model_forward.restype = C.c_int32
         _lib.mco_model_step_range.restype = C.c_int32
         _lib.mco_model_get_kv.restype = C.c_int32
         # small test shapes: a handful of threads beats one OpenMP team per host core
@@ -326,6 +327,14 @@ class Model:
         dt = self.cfg["dtype"]
         logits = np.empty(self.cfg["vocab"], dtype=np_dtype(dt)) if want_logits else None
         tok = lib().mco_model_step(self._h, C.c_int32(token), C.c_int32(start_pos), _p(logits))
+        return tok, logits
+
+    def forward(self, tokens, start_pos: int = 0, sliding_window: int = 0):
+        """The prompt pass on len(tokens) tokens; returns (greedy token, logits of the last row)."""
+        t = np.ascontiguousarray(tokens, dtype=np.int32)
+        logits = np.empty(self.cfg["vocab"], dtype=np_dtype(self.cfg["dtype"]))
+        tok = lib().mco_model_forward(self._h, _p(t), C.c_int32(t.size), C.c_int32(start_pos),
+                                      C.c_int32(sliding_window), _p(logits))
         return tok, logits
 
     def step_range(self, token: int, start_pos: int, layer_begin: int, layer_end: int,
