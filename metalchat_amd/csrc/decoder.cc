@@ -187,6 +187,30 @@ struct mc_decoder {
          *pf_q = nullptr, *pf_att = nullptr, *pf_g2 = nullptr, *pf_g = nullptr, *pf_probs = nullptr;
     int32_t* pf_tokens = nullptr;
     bool ring_turned = false;
+    // MC_PF_TIMING=1: per-category GPU time of a prompt pass printed to stderr (tuning aid; it
+    // synchronises after every launch)
+    bool pf_timing = false;
+    hipEvent_t pf_e0 = nullptr, pf_e1 = nullptr;
+    std::map<std::string, double> pf_ms;
+
+    template <typename F> mc_status
+    timed(const char* cat, F&& f)
+    {
+        if (!pf_timing) return f();
+        if (!pf_e0) {
+            MC_HIP(hipEventCreate(&pf_e0));
+            MC_HIP(hipEventCreate(&pf_e1));
+        }
+        MC_HIP(hipEventRecord(pf_e0, stream));
+        mc_status s = f();
+        if (s != MC_OK) return s;
+        MC_HIP(hipEventRecord(pf_e1, stream));
+        MC_HIP(hipEventSynchronize(pf_e1));
+        float ms = 0.0f;
+        MC_HIP(hipEventElapsedTime(&ms, pf_e0, pf_e1));
+        pf_ms[cat] += ms;
+        return MC_OK;
+    }
     float* rope_cos[2] = {nullptr, nullptr};
     float* rope_sin[2] = {nullptr, nullptr};
     int rope_rows = 0;
@@ -588,10 +612,13 @@ struct mc_decoder {
         if (L.lora_cols)
             return fail(MC_ERR_INVALID_ARGUMENT, "decoder: the prompt pass does not take LoRA adaptors yet "
                                                  "(feed the prompt through mc_decoder_step)");
-        std::string name = "mc_pf_gemm_";
+        // bf16 prompts longer than one 64-row tile take the 128 x 128 MFMA tiling
+        const bool big = tb == 2 && M > 64 && !getenv("MC_PF_SMALL_GEMM");
+        std::string name = big ? "mc_pf_gemm128_" : "mc_pf_gemm_";
         name += L.fmt == MC_WFMT_I4 ? "i4_" : (L.fmt == MC_WFMT_I8 ? "i8_" : "w_");
         name += tname + "_e" + std::to_string(epi);
-        return launch(name, (L.out + 63) / 64, (M + 63) / 64, 1, 256, 0,
+        const unsigned tile = big ? 128 : 64;
+        return launch(name, (L.out + tile - 1) / tile, (M + tile - 1) / tile, 1, 256, 0,
                       pack(L.w, L.scales, X, Y, res, (uint32_t)M, (uint32_t)L.out, (uint32_t)L.in, (uint32_t)L.group));
     }
 
@@ -626,45 +653,45 @@ struct mc_decoder {
         if (want_taps) MC_HIP(hipMemcpyAsync(taps, (char*)pf_x + last, (size_t)dim * tb, hipMemcpyDeviceToDevice, stream));
         for (int li = 0; li < n_own; li++) {
             layer_w& L = layers[li];
-            s = norm_rows(pf_x, L.attention_norm, nullptr, pf_xn, M, mu);
+            s = timed("norm", [&] { return norm_rows(pf_x, L.attention_norm, nullptr, pf_xn, M, mu); });
             if (s != MC_OK) return s;
-            s = gemm(L.qkv, 0, pf_xn, pf_qkv, nullptr, M);
+            s = timed("gemm_qkv", [&] { return gemm(L.qkv, 0, pf_xn, pf_qkv, nullptr, M); });
             if (s != MC_OK) return s;
-            s = launch("mc_pf_rope_cache_" + tname, H + 2 * KV, M, 1, hd / 2, 0,
+            s = timed("rope_cache", [&] { return launch("mc_pf_rope_cache_" + tname, H + 2 * KV, M, 1, hd / 2, 0,
                        pack(pf_qkv, pf_q, L.kc, L.vt, rope_cos[L.rope_table], rope_sin[L.rope_table], L.q_norm,
                             L.k_norm, (uint32_t)H, (uint32_t)KV, (uint32_t)hd, (uint32_t)cfg.max_seq_len,
-                            (uint32_t)start_pos, (uint32_t)(start_pos - rope_start), cfg.norm_eps, mu));
+                            (uint32_t)start_pos, (uint32_t)(start_pos - rope_start), cfg.norm_eps, mu)); });
             if (s != MC_OK) return s;
             const uint32_t win = (gemma && L.rope_table == 1) ? (uint32_t)window : 0u;
-            s = launch("mc_pf_scores_" + tname, (M + 15) / 16, H, 1, 256, 0,
+            s = timed("scores", [&] { return launch("mc_pf_scores_" + tname, (M + 15) / 16, H, 1, 256, 0,
                        pack(pf_q, L.kc, pf_probs, (uint32_t)M, (uint32_t)S, (uint32_t)H, (uint32_t)(H / KV),
-                            (uint32_t)hd, (uint32_t)cfg.max_seq_len, scale_T, win));
+                            (uint32_t)hd, (uint32_t)cfg.max_seq_len, scale_T, win)); });
             if (s != MC_OK) return s;
-            s = launch("mc_pf_pv_" + tname, (M + 15) / 16, H, 1, 256, 0,
+            s = timed("pv", [&] { return launch("mc_pf_pv_" + tname, (M + 15) / 16, H, 1, 256, 0,
                        pack(pf_probs, L.vt, pf_att, (uint32_t)M, (uint32_t)S, (uint32_t)H, (uint32_t)(H / KV),
-                            (uint32_t)hd, (uint32_t)cfg.max_seq_len, win));
+                            (uint32_t)hd, (uint32_t)cfg.max_seq_len, win)); });
             if (s != MC_OK) return s;
             if (L.attention_post_norm) {
-                s = gemm(L.wo, 0, pf_att, pf_proj, nullptr, M);
+                s = timed("gemm_wo", [&] { return gemm(L.wo, 0, pf_att, pf_proj, nullptr, M); });
                 if (s != MC_OK) return s;
                 s = norm_rows(pf_proj, L.attention_post_norm, pf_x, pf_h, M, mu);
             } else {
-                s = gemm(L.wo, 1, pf_att, pf_h, pf_x, M);
+                s = timed("gemm_wo", [&] { return gemm(L.wo, 1, pf_att, pf_h, pf_x, M); });
             }
             if (s != MC_OK) return s;
-            s = norm_rows(pf_h, L.ffn_norm, nullptr, pf_xn, M, mu);
+            s = timed("norm", [&] { return norm_rows(pf_h, L.ffn_norm, nullptr, pf_xn, M, mu); });
             if (s != MC_OK) return s;
-            s = gemm(L.w13, 0, pf_xn, pf_g2, nullptr, M);
+            s = timed("gemm_w13", [&] { return gemm(L.w13, 0, pf_xn, pf_g2, nullptr, M); });
             if (s != MC_OK) return s;
-            s = launch("mc_pf_act_mul_" + tname, (cfg.ffn_dim + 255) / 256, M, 1, 256, 0,
-                       pack(pf_g2, pf_g, (uint32_t)cfg.ffn_dim, (int32_t)(gemma ? 1 : 0)));
+            s = timed("act_mul", [&] { return launch("mc_pf_act_mul_" + tname, (cfg.ffn_dim + 255) / 256, M, 1, 256, 0,
+                       pack(pf_g2, pf_g, (uint32_t)cfg.ffn_dim, (int32_t)(gemma ? 1 : 0))); });
             if (s != MC_OK) return s;
             if (L.ffn_post_norm) {
-                s = gemm(L.w2, 0, pf_g, pf_proj, nullptr, M);
+                s = timed("gemm_w2", [&] { return gemm(L.w2, 0, pf_g, pf_proj, nullptr, M); });
                 if (s != MC_OK) return s;
                 s = norm_rows(pf_proj, L.ffn_post_norm, pf_h, pf_x, M, mu);
             } else {
-                s = gemm(L.w2, 1, pf_g, pf_x, pf_h, M);
+                s = timed("gemm_w2", [&] { return gemm(L.w2, 1, pf_g, pf_x, pf_h, M); });
             }
             if (s != MC_OK) return s;
             if (want_taps)
@@ -673,7 +700,16 @@ struct mc_decoder {
         }
         // only the last row goes through the head (llama.h:130-133)
         MC_HIP(hipMemcpyAsync(hidden, (char*)pf_x + last, (size_t)dim * tb, hipMemcpyDeviceToDevice, stream));
-        return run_head();
+        s = timed("head", [&] { return run_head(); });
+        if (pf_timing) {
+            double tot = 0;
+            for (auto& kv : pf_ms) tot += kv.second;
+            fprintf(stderr, "[prefill M=%d] GPU ms:", M);
+            for (auto& kv : pf_ms) fprintf(stderr, " %s %.2f", kv.first.c_str(), kv.second);
+            fprintf(stderr, " | total %.2f\n", tot);
+            pf_ms.clear();
+        }
+        return s;
     }
 
     // everything one token needs after the state has been set
@@ -769,6 +805,7 @@ mc_decoder_create(mc_device* dev, mc_library* lib, mc_queue* q, const mc_decoder
         A(d->rope_cos[1], (size_t)d->rope_rows * (hd / 2) * 4);
         A(d->rope_sin[1], (size_t)d->rope_rows * (hd / 2) * 4);
     }
+    if (const char* e = getenv("MC_PF_TIMING")) d->pf_timing = atoi(e) != 0;
     d->layers.resize(d->n_own);
     for (int i = 0; i < d->n_own; i++) {
         layer_w& L = d->layers[i];

@@ -305,6 +305,146 @@ MC_PF_GEMM(mc_pf_gemm_i8_float_e1, PF_W_I8, F32, 1)
 MC_PF_GEMM(mc_pf_gemm_w_float_e0, PF_W_T, F32, 0)
 MC_PF_GEMM(mc_pf_gemm_w_float_e1, PF_W_T, F32, 1)
 
+// bf16, M > 64: 128 x 128 output tile, K in chunks of 64; 4 waves as 2 x 2, each 64 x 64 = 4 x 4
+// MFMA tiles (64 accumulator VGPRs).  Staging is 16 bytes wide: a thread moves 32 consecutive k
+// of one row per chunk (X: copy; W: exact dequant of one 16-byte int4 packet).
+constexpr uint32_t PFB_M = 128, PFB_N = 128, PFB_K = 64, PFB_LD = PFB_K + 8;
+
+template <int WF, int EPI>
+__device__ __forceinline__ void
+pf_gemm_big_body(const void* __restrict__ wp, const void* __restrict__ sp, const bf16_t* __restrict__ X,
+                 bf16_t* __restrict__ Y, const bf16_t* __restrict__ res, uint32_t M, uint32_t N, uint32_t K,
+                 uint32_t group)
+{
+    __shared__ __attribute__((aligned(16))) bf16_t Xs[PFB_M * PFB_LD];
+    __shared__ __attribute__((aligned(16))) bf16_t Ws[PFB_N * PFB_LD];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t wm = wave >> 1, wn = wave & 1;
+    const uint32_t n0 = blockIdx.x * PFB_N, m0 = blockIdx.y * PFB_M;
+    const uint32_t ngroups = group ? K / group : 1;
+    const uint32_t glog = group ? 31u - __builtin_clz(group) : 31u;
+    const size_t rowb = WF == PF_W_I4 ? K / 2 : (WF == PF_W_I8 ? K : (size_t)K * 2);
+    const uint32_t srow = tid >> 1, skk = (tid & 1) * 32; // staging: row, first k of the 32-run
+    const uint32_t xr = m0 + srow < M ? m0 + srow : M - 1;
+    const uint32_t wr = n0 + srow < N ? n0 + srow : N - 1;
+
+    pf_f32x4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) acc[a][b] = pf_f32x4{0, 0, 0, 0};
+
+    for (uint32_t k0 = 0; k0 < K; k0 += PFB_K) {
+        const uint32_t kabs = k0 + skk;
+        const bool live = kabs < K; // K is a multiple of 32: a 32-run is inside or outside
+        uint4 xv[4], wo[4];
+        if (live) {
+            const uint4* src = reinterpret_cast<const uint4*>(X + (size_t)xr * K + kabs);
+#pragma unroll
+            for (int i = 0; i < 4; i++) xv[i] = src[i];
+            if (WF == PF_W_T) {
+                const uint4* ws = reinterpret_cast<const uint4*>(static_cast<const bf16_t*>(wp) + (size_t)wr * K + kabs);
+#pragma unroll
+                for (int i = 0; i < 4; i++) wo[i] = ws[i];
+            } else {
+                const float s = bf2f(f2bf(pf_scale<WF, BF>(sp, wr, group ? kabs >> glog : 0, ngroups)));
+                if (WF == PF_W_I4) {
+                    const uint4 pk = *reinterpret_cast<const uint4*>(static_cast<const char*>(wp) + (size_t)wr * rowb + kabs / 2);
+                    const uint32_t v[4] = {pk.x, pk.y, pk.z, pk.w};
+                    const float c8 = -8.0f * s;
+                    uint32_t o[16];
+#pragma unroll
+                    for (int d = 0; d < 4; d++)
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            // pair j of a dword = weights (2j, 2j+1) = nibbles (j, j+4); (n - 8) * s is exact in fp32
+                            const float a = __builtin_fmaf((float)((v[d] >> (4 * j)) & 0xFu), s, c8);
+                            const float b = __builtin_fmaf((float)((v[d] >> (4 * j + 16)) & 0xFu), s, c8);
+                            o[4 * d + j] = pack_bf16x2(a, b);
+                        }
+#pragma unroll
+                    for (int i = 0; i < 4; i++) wo[i] = make_uint4(o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]);
+                } else {
+                    const uint4* ws = reinterpret_cast<const uint4*>(static_cast<const int8_t*>(wp) + (size_t)wr * rowb + kabs);
+                    uint32_t o[16];
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {
+                        const uint4 pk = ws[h];
+                        const uint32_t v[4] = {pk.x, pk.y, pk.z, pk.w};
+#pragma unroll
+                        for (int d = 0; d < 4; d++) {
+                            const float q0 = (float)(int8_t)(v[d] & 0xFF), q1 = (float)(int8_t)((v[d] >> 8) & 0xFF);
+                            const float q2 = (float)(int8_t)((v[d] >> 16) & 0xFF), q3 = (float)(int8_t)(v[d] >> 24);
+                            o[8 * h + 2 * d] = pack_bf16x2(q0 * s, q1 * s);
+                            o[8 * h + 2 * d + 1] = pack_bf16x2(q2 * s, q3 * s);
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; i++) wo[i] = make_uint4(o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; i++) xv[i] = wo[i] = make_uint4(0, 0, 0, 0);
+        }
+        __syncthreads(); // previous chunk's MFMA reads are done
+        {
+            uint4* xd = reinterpret_cast<uint4*>(Xs + srow * PFB_LD + skk);
+            uint4* wd = reinterpret_cast<uint4*>(Ws + srow * PFB_LD + skk);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                xd[i] = xv[i];
+                wd[i] = wo[i];
+            }
+        }
+        __syncthreads();
+        const uint32_t kg = (lane >> 4) * 8, l15 = lane & 15;
+#pragma unroll
+        for (uint32_t ks = 0; ks < PFB_K; ks += 32) {
+            uint4 a[4], b[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                a[t] = *reinterpret_cast<const uint4*>(Xs + (wm * 64 + t * 16 + l15) * PFB_LD + ks + kg);
+                b[t] = *reinterpret_cast<const uint4*>(Ws + (wn * 64 + t * 16 + l15) * PFB_LD + ks + kg);
+            }
+#pragma unroll
+            for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+                for (int nt = 0; nt < 4; nt++)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(pf_bf16x8, a[mt]),
+                                                                         __builtin_bit_cast(pf_bf16x8, b[nt]),
+                                                                         acc[mt][nt], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const uint32_t m = m0 + wm * 64 + mt * 16 + (lane >> 4) * 4 + i, n = n0 + wn * 64 + nt * 16 + (lane & 15);
+                if (m < M && n < N) {
+                    float v = BF::rt(acc[mt][nt][i]);
+                    if (EPI == 1) v = BF::ld(res[(size_t)m * N + n]) + v;
+                    Y[(size_t)m * N + n] = BF::st(v);
+                }
+            }
+}
+
+#define MC_PF_GEMM_BIG(NAME, WF, EPI)                                                                   \
+    extern "C" __global__ void __launch_bounds__(256)                                                   \
+    NAME(const void* w, const void* scales, const bf16_t* X, bf16_t* Y, const bf16_t* res, uint32_t M,  \
+         uint32_t N, uint32_t K, uint32_t group)                                                        \
+    {                                                                                                   \
+        pf_gemm_big_body<WF, EPI>(w, scales, X, Y, res, M, N, K, group);                                \
+    }
+MC_PF_GEMM_BIG(mc_pf_gemm128_i4_bfloat_e0, PF_W_I4, 0)
+MC_PF_GEMM_BIG(mc_pf_gemm128_i4_bfloat_e1, PF_W_I4, 1)
+MC_PF_GEMM_BIG(mc_pf_gemm128_i8_bfloat_e0, PF_W_I8, 0)
+MC_PF_GEMM_BIG(mc_pf_gemm128_i8_bfloat_e1, PF_W_I8, 1)
+MC_PF_GEMM_BIG(mc_pf_gemm128_w_bfloat_e0, PF_W_T, 0)
+MC_PF_GEMM_BIG(mc_pf_gemm128_w_bfloat_e1, PF_W_T, 1)
+
 // ------------------------------------------------------------------------------------------ rope + cache
 // grid (H + 2 KV, M), hd/2 threads.  Row r of the prompt sits at position start_pos + r, cache slot
 // start_pos + r (the prompt pass is only taken while the ring has not started to turn), rope

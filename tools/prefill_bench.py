@@ -1,0 +1,27 @@
+"""Time-to-first-token of the prompt pass on the BASELINE model shape (tuning aid).
+usage: python tools/prefill_bench.py [len ...]"""
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, ".")
+import metalchat_amd as mc
+
+lens = [int(a) for a in sys.argv[1:]] or [128, 512, 2048]
+acc = mc.HardwareAccelerator()
+dec = mc.Decoder(acc, dtype=mc.BF16, dim=4096, n_heads=32, n_kv_heads=8, head_dim=128, ffn_dim=14336, n_layers=32,
+                 vocab=128256, max_seq_len=2048, rope_theta=500000.0, norm_eps=1e-5, attn_scale=128 ** -0.5,
+                 weight_format=mc.WFMT_I4, group_size=128)
+dec.init_synthetic(1)
+rng = np.random.default_rng(0)
+for n in lens:
+    toks = rng.integers(0, 128256, n)
+    dec.prefill(toks, 0)          # warm-up (allocations, code load)
+    t0 = time.perf_counter()
+    reps = 3
+    for _ in range(reps):
+        dec.prefill(toks, 0)
+    dt = (time.perf_counter() - t0) / reps
+    flops = 2.0 * 7.505e9 * n
+    print(f"len {n:5d}: {dt * 1e3:8.2f} ms  {n / dt:9.0f} prompt tokens/s  {flops / dt / 1e12:6.1f} TFLOP/s (linear layers)")
