@@ -294,6 +294,25 @@ def main():
                          "bytes_per_token": by_all, "ms_per_token": ms_all / reps,
                          "launches_per_token": ln_all},
         }
+    if rank == 0 and world == 1 and not args.no_roofline:
+        # informational (not `value`): the prompt pass that precedes decoding -- time to first token
+        # for a 512-token prompt through mc_decoder_prefill (dequant-once MFMA GEMMs), measured
+        # after the timed region on the same decoder; the first call allocates and is not timed
+        plen = min(512, S)
+        ptoks = np.random.default_rng(1).integers(0, m["vocab"], plen)
+        dec.prefill(ptoks, 0)
+        acc.wait()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            dec.prefill(ptoks, 0)
+        acc.wait()
+        pms = (time.perf_counter() - t0) / 3 * 1e3
+        lin_params = m["n_layers"] * (m["dim"] * m["n_heads"] * m["head_dim"] * 2
+                                      + 2 * m["dim"] * m["n_kv_heads"] * m["head_dim"]
+                                      + 3 * m["dim"] * m["ffn_dim"])
+        out["prompt_pass"] = {"tokens": plen, "ms": pms, "tokens_per_s": plen / (pms * 1e-3),
+                              "linear_TFLOPs": 2.0 * lin_params * plen / (pms * 1e-3) / 1e12,
+                              "mfma_peak_TFLOPs": 2500.0}
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(args, m, tbytes)
     if rank == 0:
