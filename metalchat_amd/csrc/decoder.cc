@@ -186,6 +186,8 @@ struct mc_decoder {
     void *pf_x = nullptr, *pf_xn = nullptr, *pf_h = nullptr, *pf_proj = nullptr, *pf_qkv = nullptr,
          *pf_q = nullptr, *pf_att = nullptr, *pf_g2 = nullptr, *pf_g = nullptr, *pf_probs = nullptr;
     int32_t* pf_tokens = nullptr;
+    void* pf_lora = nullptr;
+    size_t pf_lora_elems = 0;
     bool ring_turned = false;
     // MC_PF_TIMING=1: per-category GPU time of a prompt pass printed to stderr (tuning aid; it
     // synchronises after every launch)
@@ -609,9 +611,16 @@ struct mc_decoder {
     mc_status
     gemm(const linear_w& L, int epi, const void* X, void* Y, const void* res, int M)
     {
-        if (L.lora_cols)
-            return fail(MC_ERR_INVALID_ARGUMENT, "decoder: the prompt pass does not take LoRA adaptors yet "
-                                                 "(feed the prompt through mc_decoder_step)");
+        if (L.lora_cols) {
+            // la = T(X A^T): the stacked adaptor inputs, [M][nseg * rank]
+            if ((size_t)M * L.lora_cols > pf_lora_elems) {
+                mc_status s = alloc(&pf_lora, (size_t)M * L.lora_cols * tb, false);
+                if (s != MC_OK) return s;
+                pf_lora_elems = (size_t)M * L.lora_cols;
+            }
+            mc_status s = gemm(*L.lora_a, 0, X, pf_lora, nullptr, M);
+            if (s != MC_OK) return s;
+        }
         // bf16 prompts longer than one 64-row tile take the 128 x 128 MFMA tiling
         const bool big = tb == 2 && M > 64 && !getenv("MC_PF_SMALL_GEMM");
         std::string name = big ? "mc_pf_gemm128_" : "mc_pf_gemm_";
@@ -619,7 +628,9 @@ struct mc_decoder {
         name += tname + "_e" + std::to_string(epi);
         const unsigned tile = big ? 128 : 64;
         return launch(name, (L.out + tile - 1) / tile, (M + tile - 1) / tile, 1, 256, 0,
-                      pack(L.w, L.scales, X, Y, res, (uint32_t)M, (uint32_t)L.out, (uint32_t)L.in, (uint32_t)L.group));
+                      pack(L.w, L.scales, X, Y, res, (uint32_t)M, (uint32_t)L.out, (uint32_t)L.in, (uint32_t)L.group,
+                           (const void*)(L.lora_cols ? pf_lora : nullptr), (const void*)L.lora_b,
+                           (uint32_t)L.lora_cols, L.lora_scale));
     }
 
     mc_status

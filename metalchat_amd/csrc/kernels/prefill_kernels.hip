@@ -159,11 +159,27 @@ pf_scale(const void* sp, uint32_t row, uint32_t g, uint32_t ngroups)
     return T::bytes == 2 ? bf2f(static_cast<const bf16_t*>(sp)[idx]) : static_cast<const float*>(sp)[idx];
 }
 
+// quantization::lora_linear row results (quantization/lora.h:119-121):
+//   T(T(x Wd^T) + T(T(B (A x)) * scale)); la = T(X A^T) [M][rank] from the adaptor GEMM that ran
+// before, lb = B in the fused row order [N][rank] (zeros outside the row's own adaptor columns).
+template <typename T>
+__device__ __forceinline__ float
+pf_lora(float base_T, const typename T::S* la, const typename T::S* lb, uint32_t rank, float scale, uint32_t m,
+        uint32_t n)
+{
+    const typename T::S* av = la + (size_t)m * rank;
+    const typename T::S* bv = lb + (size_t)n * rank;
+    float p = 0.0f;
+    for (uint32_t i = 0; i < rank; i++) p += T::ld(av[i]) * T::ld(bv[i]);
+    return T::rt(base_T + T::rt(T::rt(p) * T::rt(scale)));
+}
+
 template <int WF, typename T, int EPI>
 __device__ __forceinline__ void
 pf_gemm_body(const void* __restrict__ wp, const void* __restrict__ sp, const typename T::S* __restrict__ X,
              typename T::S* __restrict__ Y, const typename T::S* __restrict__ res, uint32_t M, uint32_t N,
-             uint32_t K, uint32_t group)
+             uint32_t K, uint32_t group, const typename T::S* __restrict__ la, const typename T::S* __restrict__ lb,
+             uint32_t lora_rank, float lora_scale)
 {
     using S = typename T::S;
     constexpr uint32_t LD = pf_lds<T>::LD;
@@ -265,6 +281,7 @@ pf_gemm_body(const void* __restrict__ wp, const void* __restrict__ sp, const typ
                 const uint32_t m = m0 + wave * 16 + (lane >> 4) * 4 + i, n = n0 + nt * 16 + (lane & 15);
                 if (m < M && n < N) {
                     float v = T::rt(acc[nt][i]);
+                    if (lora_rank) v = pf_lora<T>(v, la, lb, lora_rank, lora_scale, m, n);
                     if (EPI == 1) v = T::ld(res[(size_t)m * N + n]) + v;
                     Y[(size_t)m * N + n] = T::st(v);
                 }
@@ -278,6 +295,7 @@ pf_gemm_body(const void* __restrict__ wp, const void* __restrict__ sp, const typ
                 const uint32_t m = m0 + ty * 4 + i, n = n0 + tx * 4 + j;
                 if (m < M && n < N) {
                     float v = facc[i][j];
+                    if (lora_rank) v = pf_lora<T>(v, la, lb, lora_rank, lora_scale, m, n);
                     if (EPI == 1) v = T::ld(res[(size_t)m * N + n]) + v;
                     Y[(size_t)m * N + n] = T::st(v);
                 }
@@ -288,9 +306,10 @@ pf_gemm_body(const void* __restrict__ wp, const void* __restrict__ sp, const typ
 #define MC_PF_GEMM(NAME, WF, T, EPI)                                                                     \
     extern "C" __global__ void __launch_bounds__(256)                                                    \
     NAME(const void* w, const void* scales, const typename T::S* X, typename T::S* Y,                    \
-         const typename T::S* res, uint32_t M, uint32_t N, uint32_t K, uint32_t group)                   \
+         const typename T::S* res, uint32_t M, uint32_t N, uint32_t K, uint32_t group,                   \
+         const typename T::S* la, const typename T::S* lb, uint32_t lora_rank, float lora_scale)         \
     {                                                                                                    \
-        pf_gemm_body<WF, T, EPI>(w, scales, X, Y, res, M, N, K, group);                                  \
+        pf_gemm_body<WF, T, EPI>(w, scales, X, Y, res, M, N, K, group, la, lb, lora_rank, lora_scale);   \
     }
 MC_PF_GEMM(mc_pf_gemm_i4_bfloat_e0, PF_W_I4, BF, 0)
 MC_PF_GEMM(mc_pf_gemm_i4_bfloat_e1, PF_W_I4, BF, 1)
@@ -314,7 +333,8 @@ template <int WF, int EPI>
 __device__ __forceinline__ void
 pf_gemm_big_body(const void* __restrict__ wp, const void* __restrict__ sp, const bf16_t* __restrict__ X,
                  bf16_t* __restrict__ Y, const bf16_t* __restrict__ res, uint32_t M, uint32_t N, uint32_t K,
-                 uint32_t group)
+                 uint32_t group, const bf16_t* __restrict__ la, const bf16_t* __restrict__ lb, uint32_t lora_rank,
+                 float lora_scale)
 {
     __shared__ __attribute__((aligned(16))) bf16_t Xs[PFB_M * PFB_LD];
     __shared__ __attribute__((aligned(16))) bf16_t Ws[PFB_N * PFB_LD];
@@ -425,6 +445,7 @@ pf_gemm_big_body(const void* __restrict__ wp, const void* __restrict__ sp, const
                 const uint32_t m = m0 + wm * 64 + mt * 16 + (lane >> 4) * 4 + i, n = n0 + wn * 64 + nt * 16 + (lane & 15);
                 if (m < M && n < N) {
                     float v = BF::rt(acc[mt][nt][i]);
+                    if (lora_rank) v = pf_lora<BF>(v, la, lb, lora_rank, lora_scale, m, n);
                     if (EPI == 1) v = BF::ld(res[(size_t)m * N + n]) + v;
                     Y[(size_t)m * N + n] = BF::st(v);
                 }
@@ -434,9 +455,10 @@ pf_gemm_big_body(const void* __restrict__ wp, const void* __restrict__ sp, const
 #define MC_PF_GEMM_BIG(NAME, WF, EPI)                                                                   \
     extern "C" __global__ void __launch_bounds__(256)                                                   \
     NAME(const void* w, const void* scales, const bf16_t* X, bf16_t* Y, const bf16_t* res, uint32_t M,  \
-         uint32_t N, uint32_t K, uint32_t group)                                                        \
+         uint32_t N, uint32_t K, uint32_t group, const bf16_t* la, const bf16_t* lb, uint32_t lora_rank, \
+         float lora_scale)                                                                              \
     {                                                                                                   \
-        pf_gemm_big_body<WF, EPI>(w, scales, X, Y, res, M, N, K, group);                                \
+        pf_gemm_big_body<WF, EPI>(w, scales, X, Y, res, M, N, K, group, la, lb, lora_rank, lora_scale); \
     }
 MC_PF_GEMM_BIG(mc_pf_gemm128_i4_bfloat_e0, PF_W_I4, 0)
 MC_PF_GEMM_BIG(mc_pf_gemm128_i4_bfloat_e1, PF_W_I4, 1)

@@ -127,11 +127,15 @@ def test_prefill_argument_errors_and_len_one(acc):
     ref = mc.Decoder(acc, **mg.decoder_kwargs(cfg))
     ref.load_model(weights)
     assert ref.step(5, 0) == a and np.array_equal(ref.logits(), la)
-    # a QLoRA model refuses the prompt pass loudly instead of dropping the adaptors
-    wl = mg.make_model(cfg, seed=77, quant="i4", group=32, lora_rank=8)
-    dl = mc.Decoder(acc, **mg.decoder_kwargs(cfg, weight_format=2, group_size=32))
-    dl.load_model(wl)
-    with pytest.raises(mc.McError, match="LoRA"):
-        dl.prefill([1, 2, 3], 0)
-    for d in (dec, ref, dl):
+    for d in (dec, ref):
         d.release()
+
+
+@pytest.mark.parametrize("dt,n", [(F32, 21), (BF16, 21), (BF16, 90)])
+def test_qlora_prompt(acc, dt, n):
+    # lora_linear on every projection (quantization/lora.h:94-122) with M > 1 rows; 90 rows takes
+    # the 128 x 128 tiling
+    cfg = mg.tiny_cfg(dt, max_seq_len=96)
+    weights = mg.make_model(cfg, seed=78, quant="i4", group=32, lora_rank=16)
+    tokens = np.random.default_rng(8).integers(0, cfg["vocab"], n).tolist()
+    check_against_oracle(acc, cfg, weights, dict(weight_format=2, group_size=32), tokens, follow=2)
