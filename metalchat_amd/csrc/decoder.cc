@@ -192,6 +192,7 @@ struct mc_decoder {
     // MC_PF_TIMING=1: per-category GPU time of a prompt pass printed to stderr (tuning aid; it
     // synchronises after every launch)
     bool pf_timing = false;
+    bool pf_two_pass = false; // MC_PF_TWO_PASS=1: scores + pv kernels with the probability scratch (always for T = float)
     hipEvent_t pf_e0 = nullptr, pf_e1 = nullptr;
     std::map<std::string, double> pf_ms;
 
@@ -598,7 +599,7 @@ struct mc_decoder {
 #undef A
             pf_cap = cap;
         }
-        const size_t need = (size_t)H * M * S;
+        const size_t need = (tb == 2 && !pf_two_pass) ? 0 : (size_t)H * M * S;
         if (need > pf_probs_elems) {
             s = alloc(&pf_probs, need * tb, false);
             if (s != MC_OK) return s;
@@ -674,14 +675,24 @@ struct mc_decoder {
                             (uint32_t)start_pos, (uint32_t)(start_pos - rope_start), cfg.norm_eps, mu)); });
             if (s != MC_OK) return s;
             const uint32_t win = (gemma && L.rope_table == 1) ? (uint32_t)window : 0u;
-            s = timed("scores", [&] { return launch("mc_pf_scores_" + tname, (M + 15) / 16, H, 1, 256, 0,
-                       pack(pf_q, L.kc, pf_probs, (uint32_t)M, (uint32_t)S, (uint32_t)H, (uint32_t)(H / KV),
-                            (uint32_t)hd, (uint32_t)cfg.max_seq_len, scale_T, win)); });
-            if (s != MC_OK) return s;
-            s = timed("pv", [&] { return launch("mc_pf_pv_" + tname, (M + 15) / 16, H, 1, 256, 0,
-                       pack(pf_probs, L.vt, pf_att, (uint32_t)M, (uint32_t)S, (uint32_t)H, (uint32_t)(H / KV),
-                            (uint32_t)hd, (uint32_t)cfg.max_seq_len, win)); });
-            if (s != MC_OK) return s;
+            if (tb == 2 && !pf_two_pass) {
+                // fused: the probabilities stay on chip
+                s = timed("attention", [&] {
+                    return launch("mc_pf_attn_bfloat_hd" + std::to_string(hd), (M + 15) / 16, H, 1, 256, 0,
+                                  pack(pf_q, L.kc, L.vt, pf_att, (uint32_t)M, (uint32_t)S, (uint32_t)H, (uint32_t)(H / KV),
+                                       (uint32_t)cfg.max_seq_len, scale_T, win));
+                });
+                if (s != MC_OK) return s;
+            } else {
+                s = timed("scores", [&] { return launch("mc_pf_scores_" + tname, (M + 15) / 16, H, 1, 256, 0,
+                           pack(pf_q, L.kc, pf_probs, (uint32_t)M, (uint32_t)S, (uint32_t)H, (uint32_t)(H / KV),
+                                (uint32_t)hd, (uint32_t)cfg.max_seq_len, scale_T, win)); });
+                if (s != MC_OK) return s;
+                s = timed("pv", [&] { return launch("mc_pf_pv_" + tname, (M + 15) / 16, H, 1, 256, 0,
+                           pack(pf_probs, L.vt, pf_att, (uint32_t)M, (uint32_t)S, (uint32_t)H, (uint32_t)(H / KV),
+                                (uint32_t)hd, (uint32_t)cfg.max_seq_len, win)); });
+                if (s != MC_OK) return s;
+            }
             if (L.attention_post_norm) {
                 s = timed("gemm_wo", [&] { return gemm(L.wo, 0, pf_att, pf_proj, nullptr, M); });
                 if (s != MC_OK) return s;
@@ -817,6 +828,7 @@ mc_decoder_create(mc_device* dev, mc_library* lib, mc_queue* q, const mc_decoder
         A(d->rope_sin[1], (size_t)d->rope_rows * (hd / 2) * 4);
     }
     if (const char* e = getenv("MC_PF_TIMING")) d->pf_timing = atoi(e) != 0;
+    if (const char* e = getenv("MC_PF_TWO_PASS")) d->pf_two_pass = atoi(e) != 0;
     d->layers.resize(d->n_own);
     for (int i = 0; i < d->n_own; i++) {
         layer_w& L = d->layers[i];
