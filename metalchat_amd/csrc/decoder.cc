@@ -188,6 +188,8 @@ struct mc_decoder {
     int32_t* pf_tokens = nullptr;
     void* pf_lora = nullptr;
     size_t pf_lora_elems = 0;
+    float* pf_part = nullptr; // split-K partial sums [splits][M][N]
+    size_t pf_part_elems = 0;
     bool ring_turned = false;
     // MC_PF_TIMING=1: per-category GPU time of a prompt pass printed to stderr (tuning aid; it
     // synchronises after every launch)
@@ -624,14 +626,39 @@ struct mc_decoder {
         }
         // bf16 prompts longer than one 64-row tile take the 128 x 128 MFMA tiling
         const bool big = tb == 2 && M > 64 && !getenv("MC_PF_SMALL_GEMM");
-        std::string name = big ? "mc_pf_gemm128_" : "mc_pf_gemm_";
-        name += L.fmt == MC_WFMT_I4 ? "i4_" : (L.fmt == MC_WFMT_I8 ? "i8_" : "w_");
-        name += tname + "_e" + std::to_string(epi);
+        const std::string f = L.fmt == MC_WFMT_I4 ? "i4_" : (L.fmt == MC_WFMT_I8 ? "i8_" : "w_");
+        const void* la = L.lora_cols ? pf_lora : nullptr;
+        if (big) {
+            // A 128 x 128 tile walks K serially (~1.5 us per 64-wide chunk), so a grid that does not
+            // oversubscribe the CUs several times is latency-bound: split K until it does.
+            const unsigned tiles = ((L.out + 127) / 128) * ((M + 127) / 128);
+            const unsigned want = 2u * (unsigned)dev->prop.multiProcessorCount;
+            unsigned splits = 1;
+            while (splits < 16 && tiles * splits < want && (unsigned)L.in / (splits * 2) >= 512) splits *= 2;
+            if (splits > 1 && !getenv("MC_PF_NO_SPLITK")) {
+                const size_t need = (size_t)splits * M * L.out;
+                if (need > pf_part_elems) {
+                    mc_status s = alloc((void**)&pf_part, need * 4, false);
+                    if (s != MC_OK) return s;
+                    pf_part_elems = need;
+                }
+                mc_status s = launch("mc_pf_gemm128_" + f + tname + "_e2", (L.out + 127) / 128, (M + 127) / 128, splits,
+                                     256, 0,
+                                     pack(L.w, L.scales, X, (void*)pf_part, (const void*)nullptr, (uint32_t)M,
+                                          (uint32_t)L.out, (uint32_t)L.in, (uint32_t)L.group, (const void*)nullptr,
+                                          (const void*)nullptr, (uint32_t)0, 0.0f));
+                if (s != MC_OK) return s;
+                return launch("mc_pf_splitk_reduce_" + tname, (L.out + 255) / 256, M, 1, 256, 0,
+                              pack((const void*)pf_part, Y, epi == 1 ? res : (const void*)nullptr, (uint32_t)M,
+                                   (uint32_t)L.out, splits, la, (const void*)L.lora_b, (uint32_t)L.lora_cols,
+                                   L.lora_scale));
+            }
+        }
+        const std::string name = (big ? "mc_pf_gemm128_" : "mc_pf_gemm_") + f + tname + "_e" + std::to_string(epi);
         const unsigned tile = big ? 128 : 64;
         return launch(name, (L.out + tile - 1) / tile, (M + tile - 1) / tile, 1, 256, 0,
                       pack(L.w, L.scales, X, Y, res, (uint32_t)M, (uint32_t)L.out, (uint32_t)L.in, (uint32_t)L.group,
-                           (const void*)(L.lora_cols ? pf_lora : nullptr), (const void*)L.lora_b,
-                           (uint32_t)L.lora_cols, L.lora_scale));
+                           la, (const void*)L.lora_b, (uint32_t)L.lora_cols, L.lora_scale));
     }
 
     mc_status

@@ -344,6 +344,11 @@ pf_gemm_big_body(const void* __restrict__ wp, const void* __restrict__ sp, const
     const uint32_t ngroups = group ? K / group : 1;
     const uint32_t glog = group ? 31u - __builtin_clz(group) : 31u;
     const size_t rowb = WF == PF_W_I4 ? K / 2 : (WF == PF_W_I8 ? K : (size_t)K * 2);
+    // split-K (EPI 2): workgroup z of gridDim.z walks K range [z * kper, (z + 1) * kper) and stores
+    // its fp32 partial sums; mc_pf_splitk_reduce adds the partials in z order and finishes the rows
+    const uint32_t kper = EPI == 2 ? ((K / PFB_K + gridDim.z - 1) / gridDim.z) * PFB_K : K;
+    const uint32_t kbeg = EPI == 2 ? blockIdx.z * kper : 0;
+    const uint32_t kend = EPI == 2 ? min(K, kbeg + kper) : K;
     const uint32_t srow = tid >> 1, skk = (tid & 1) * 32; // staging: row, first k of the 32-run
     const uint32_t xr = m0 + srow < M ? m0 + srow : M - 1;
     const uint32_t wr = n0 + srow < N ? n0 + srow : N - 1;
@@ -354,58 +359,75 @@ pf_gemm_big_body(const void* __restrict__ wp, const void* __restrict__ sp, const
 #pragma unroll
         for (int b = 0; b < 4; b++) acc[a][b] = pf_f32x4{0, 0, 0, 0};
 
-    for (uint32_t k0 = 0; k0 < K; k0 += PFB_K) {
+    // Software pipeline: the global loads of chunk k+1 (X packets and RAW weight packets) are
+    // issued before the MFMAs of chunk k and consumed -- dequantised, written to LDS -- at the top
+    // of the next iteration, so their latency hides behind 32 MFMAs and the other workgroups of
+    // the CU.  (Without it a workgroup spent ~1.5 us per chunk: w2 with K = 14336 took the same
+    // 10.8 ms at M = 128 and M = 2048.)
+    uint4 xv[4], wraw[4];
+    float s_next = 0.0f;
+    auto fetch = [&](uint32_t k0) {
         const uint32_t kabs = k0 + skk;
-        const bool live = kabs < K; // K is a multiple of 32: a 32-run is inside or outside
-        uint4 xv[4], wo[4];
-        if (live) {
+        if (kabs < K) { // K is a multiple of 32: a 32-run is inside or outside
             const uint4* src = reinterpret_cast<const uint4*>(X + (size_t)xr * K + kabs);
 #pragma unroll
             for (int i = 0; i < 4; i++) xv[i] = src[i];
             if (WF == PF_W_T) {
                 const uint4* ws = reinterpret_cast<const uint4*>(static_cast<const bf16_t*>(wp) + (size_t)wr * K + kabs);
 #pragma unroll
-                for (int i = 0; i < 4; i++) wo[i] = ws[i];
+                for (int i = 0; i < 4; i++) wraw[i] = ws[i];
             } else {
-                const float s = bf2f(f2bf(pf_scale<WF, BF>(sp, wr, group ? kabs >> glog : 0, ngroups)));
+                s_next = pf_scale<WF, BF>(sp, wr, group ? kabs >> glog : 0, ngroups);
                 if (WF == PF_W_I4) {
-                    const uint4 pk = *reinterpret_cast<const uint4*>(static_cast<const char*>(wp) + (size_t)wr * rowb + kabs / 2);
-                    const uint32_t v[4] = {pk.x, pk.y, pk.z, pk.w};
-                    const float c8 = -8.0f * s;
-                    uint32_t o[16];
-#pragma unroll
-                    for (int d = 0; d < 4; d++)
-#pragma unroll
-                        for (int j = 0; j < 4; j++) {
-                            // pair j of a dword = weights (2j, 2j+1) = nibbles (j, j+4); (n - 8) * s is exact in fp32
-                            const float a = __builtin_fmaf((float)((v[d] >> (4 * j)) & 0xFu), s, c8);
-                            const float b = __builtin_fmaf((float)((v[d] >> (4 * j + 16)) & 0xFu), s, c8);
-                            o[4 * d + j] = pack_bf16x2(a, b);
-                        }
-#pragma unroll
-                    for (int i = 0; i < 4; i++) wo[i] = make_uint4(o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]);
+                    wraw[0] = *reinterpret_cast<const uint4*>(static_cast<const char*>(wp) + (size_t)wr * rowb + kabs / 2);
                 } else {
                     const uint4* ws = reinterpret_cast<const uint4*>(static_cast<const int8_t*>(wp) + (size_t)wr * rowb + kabs);
-                    uint32_t o[16];
-#pragma unroll
-                    for (int h = 0; h < 2; h++) {
-                        const uint4 pk = ws[h];
-                        const uint32_t v[4] = {pk.x, pk.y, pk.z, pk.w};
-#pragma unroll
-                        for (int d = 0; d < 4; d++) {
-                            const float q0 = (float)(int8_t)(v[d] & 0xFF), q1 = (float)(int8_t)((v[d] >> 8) & 0xFF);
-                            const float q2 = (float)(int8_t)((v[d] >> 16) & 0xFF), q3 = (float)(int8_t)(v[d] >> 24);
-                            o[8 * h + 2 * d] = pack_bf16x2(q0 * s, q1 * s);
-                            o[8 * h + 2 * d + 1] = pack_bf16x2(q2 * s, q3 * s);
-                        }
-                    }
-#pragma unroll
-                    for (int i = 0; i < 4; i++) wo[i] = make_uint4(o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]);
+                    wraw[0] = ws[0];
+                    wraw[1] = ws[1];
                 }
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < 4; i++) xv[i] = wo[i] = make_uint4(0, 0, 0, 0);
+            for (int i = 0; i < 4; i++) xv[i] = wraw[i] = make_uint4(0, 0, 0, 0);
+            s_next = 0.0f;
+        }
+    };
+    fetch(kbeg);
+    for (uint32_t k0 = kbeg; k0 < kend; k0 += PFB_K) {
+        uint4 wo[4];
+        if (WF == PF_W_T) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) wo[i] = wraw[i];
+        } else {
+            const float s = bf2f(f2bf(s_next));
+            uint32_t o[16];
+            if (WF == PF_W_I4) {
+                const uint32_t v[4] = {wraw[0].x, wraw[0].y, wraw[0].z, wraw[0].w};
+                const float c8 = -8.0f * s;
+#pragma unroll
+                for (int d = 0; d < 4; d++)
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        // pair j of a dword = weights (2j, 2j+1) = nibbles (j, j+4); (n - 8) * s is exact in fp32
+                        const float a = __builtin_fmaf((float)((v[d] >> (4 * j)) & 0xFu), s, c8);
+                        const float b = __builtin_fmaf((float)((v[d] >> (4 * j + 16)) & 0xFu), s, c8);
+                        o[4 * d + j] = pack_bf16x2(a, b);
+                    }
+            } else {
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const uint32_t v[4] = {wraw[h].x, wraw[h].y, wraw[h].z, wraw[h].w};
+#pragma unroll
+                    for (int d = 0; d < 4; d++) {
+                        const float q0 = (float)(int8_t)(v[d] & 0xFF), q1 = (float)(int8_t)((v[d] >> 8) & 0xFF);
+                        const float q2 = (float)(int8_t)((v[d] >> 16) & 0xFF), q3 = (float)(int8_t)(v[d] >> 24);
+                        o[8 * h + 2 * d] = pack_bf16x2(q0 * s, q1 * s);
+                        o[8 * h + 2 * d + 1] = pack_bf16x2(q2 * s, q3 * s);
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) wo[i] = make_uint4(o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]);
         }
         __syncthreads(); // previous chunk's MFMA reads are done
         {
@@ -418,6 +440,7 @@ pf_gemm_big_body(const void* __restrict__ wp, const void* __restrict__ sp, const
             }
         }
         __syncthreads();
+        if (k0 + PFB_K < kend) fetch(k0 + PFB_K);
         const uint32_t kg = (lane >> 4) * 8, l15 = lane & 15;
 #pragma unroll
         for (uint32_t ks = 0; ks < PFB_K; ks += 32) {
@@ -444,10 +467,14 @@ pf_gemm_big_body(const void* __restrict__ wp, const void* __restrict__ sp, const
             for (int i = 0; i < 4; i++) {
                 const uint32_t m = m0 + wm * 64 + mt * 16 + (lane >> 4) * 4 + i, n = n0 + wn * 64 + nt * 16 + (lane & 15);
                 if (m < M && n < N) {
-                    float v = BF::rt(acc[mt][nt][i]);
-                    if (lora_rank) v = pf_lora<BF>(v, la, lb, lora_rank, lora_scale, m, n);
-                    if (EPI == 1) v = BF::ld(res[(size_t)m * N + n]) + v;
-                    Y[(size_t)m * N + n] = BF::st(v);
+                    if (EPI == 2) {
+                        reinterpret_cast<float*>(Y)[((size_t)blockIdx.z * M + m) * N + n] = acc[mt][nt][i];
+                    } else {
+                        float v = BF::rt(acc[mt][nt][i]);
+                        if (lora_rank) v = pf_lora<BF>(v, la, lb, lora_rank, lora_scale, m, n);
+                        if (EPI == 1) v = BF::ld(res[(size_t)m * N + n]) + v;
+                        Y[(size_t)m * N + n] = BF::st(v);
+                    }
                 }
             }
 }
@@ -466,6 +493,24 @@ MC_PF_GEMM_BIG(mc_pf_gemm128_i8_bfloat_e0, PF_W_I8, 0)
 MC_PF_GEMM_BIG(mc_pf_gemm128_i8_bfloat_e1, PF_W_I8, 1)
 MC_PF_GEMM_BIG(mc_pf_gemm128_w_bfloat_e0, PF_W_T, 0)
 MC_PF_GEMM_BIG(mc_pf_gemm128_w_bfloat_e1, PF_W_T, 1)
+MC_PF_GEMM_BIG(mc_pf_gemm128_i4_bfloat_e2, PF_W_I4, 2)
+MC_PF_GEMM_BIG(mc_pf_gemm128_i8_bfloat_e2, PF_W_I8, 2)
+MC_PF_GEMM_BIG(mc_pf_gemm128_w_bfloat_e2, PF_W_T, 2)
+
+// y = T(sum_z partial[z]) (+ adaptation) (+ residual): the epilogue of a split-K GEMM
+extern "C" __global__ void
+mc_pf_splitk_reduce_bfloat(const float* part, bf16_t* Y, const bf16_t* res, uint32_t M, uint32_t N, uint32_t splits,
+                           const bf16_t* la, const bf16_t* lb, uint32_t lora_rank, float lora_scale)
+{
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x, m = blockIdx.y;
+    if (n >= N) return;
+    float a = 0.0f;
+    for (uint32_t z = 0; z < splits; z++) a += part[((size_t)z * M + m) * N + n];
+    float v = BF::rt(a);
+    if (lora_rank) v = pf_lora<BF>(v, la, lb, lora_rank, lora_scale, m, n);
+    if (res) v = BF::ld(res[(size_t)m * N + n]) + v;
+    Y[(size_t)m * N + n] = BF::st(v);
+}
 
 // ------------------------------------------------------------------------------------------ rope + cache
 // grid (H + 2 KV, M), hd/2 threads.  Row r of the prompt sits at position start_pos + r, cache slot

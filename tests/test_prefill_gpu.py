@@ -87,6 +87,16 @@ def test_head_dim_128_gqa4_prompt(acc):
     check_against_oracle(acc, cfg, weights, dict(weight_format=2, group_size=128), tokens)
 
 
+def test_wide_model_takes_the_split_k_gemm(acc):
+    # K = 1024 / 2048 with few output tiles: the 128 x 128 GEMM splits K (2 and 4 ways here) and a
+    # reduce kernel finishes the rows -- with adaptors, so the reduce epilogue carries them too
+    cfg = mg.tiny_cfg(BF16, dim=1024, n_heads=8, n_kv_heads=2, head_dim=128, ffn_dim=2048, n_layers=1,
+                      vocab=512, max_seq_len=96)
+    weights = mg.make_model(cfg, seed=79, quant="i4", group=128, lora_rank=8)
+    tokens = np.random.default_rng(9).integers(0, cfg["vocab"], 70).tolist()
+    check_against_oracle(acc, cfg, weights, dict(weight_format=2, group_size=128), tokens, follow=1)
+
+
 @pytest.mark.parametrize("dt", [F32, BF16])
 def test_gemma3_prompt_with_sliding_window(acc, dt):
     cfg = mg.tiny_cfg(dt, family=1, n_layers=3, rope_sliding_theta=10000.0, sliding_stride=2,
