@@ -1474,9 +1474,14 @@ mc_decoder_time_gemv(mc_decoder* d, const char* which, int32_t repeats, float* t
     const bool gemma = d->cfg.family == MC_FAMILY_GEMMA3;
     double bytes = 0;
     int launches = 0;
+    // MC_TIME_GEMV_LAYERS=n (tuning aid): every "layer" of the pass uses the weights of layer
+    // i % n, so with a small n the matrices stay resident in the 256 MiB Infinity Cache
+    const char* lim_env = getenv("MC_TIME_GEMV_LAYERS");
+    const size_t lim = lim_env && atoi(lim_env) > 0 ? (size_t)atoi(lim_env) : d->layers.size();
     auto pass = [&](bool count) -> mc_status {
         mc_status r = MC_OK;
-        for (auto& L : d->layers) {
+        for (size_t li = 0; li < d->layers.size(); li++) {
+            layer_w& L = d->layers[li % lim];
             if (w == "qkv" || w == "all") {
                 r = gemma ? d->gemv(L.qkv, 1, 0, d->hidden, d->qkv, nullptr, L.attention_norm, mu)
                           : d->gemv(L.qkv, 1, 4, d->hidden, d->qkv, L.qkv_epi, L.attention_norm, mu);

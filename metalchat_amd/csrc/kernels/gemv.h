@@ -385,7 +385,11 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
 
     unsigned long long tl0 = 0, tl1 = 0;
     if (QM == Q_DBG_TL) tl0 = __builtin_amdgcn_s_memrealtime();
-    tile<R> t0, t1, t2; // register ring: two tiles in flight while one is dequantised
+#ifndef MC_GEMV_RING
+#define MC_GEMV_RING 3
+#endif
+    constexpr int RING = MC_GEMV_RING;
+    tile<R> ring[RING]; // register ring: RING - 1 tiles in flight while one is dequantised
 
     // Loads are UNCONDITIONAL straight-line code: hipcc only emits counted s_waitcnt vmcnt(N) --
     // leaving the younger tiles in flight -- when no load sits behind a branch; one predicated
@@ -485,10 +489,11 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
 #ifndef MC_GEMV_PRE
 #define MC_GEMV_PRE 1
 #endif
-        load(t0, ld.rg, ld.c, 0 < ntiles);
+        load(ring[0], ld.rg, ld.c, 0 < ntiles);
         advance(ld);
-        if (MC_GEMV_PRE >= 2) { load(t1, ld.rg, ld.c, 1 < ntiles); advance(ld); }
-        if (MC_GEMV_PRE >= 3) { load(t2, ld.rg, ld.c, 2 < ntiles); advance(ld); }
+#pragma unroll
+        for (int sl = 1; sl < RING; sl++)
+            if (MC_GEMV_PRE > sl) { load(ring[sl], ld.rg, ld.c, (uint32_t)sl < ntiles); advance(ld); }
         if (fits) {
 #pragma unroll
             for (int i = 0; i < MAXP; i++)
@@ -574,8 +579,9 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
     }
     __syncthreads();
     if (QM == Q_DBG_TL) tl1 = __builtin_amdgcn_s_memrealtime();
-    if (MC_GEMV_PRE < 2) { load(t1, ld.rg, ld.c, 1 < ntiles); advance(ld); }
-    if (MC_GEMV_PRE < 3) { load(t2, ld.rg, ld.c, 2 < ntiles); advance(ld); }
+#pragma unroll
+    for (int sl = 1; sl < RING; sl++)
+        if (MC_GEMV_PRE <= sl) { load(ring[sl], ld.rg, ld.c, (uint32_t)sl < ntiles); advance(ld); }
 
     float acc[R];
 #pragma unroll
@@ -681,15 +687,17 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
     // round-robin deal: 20.0 vs 19.0 us on the w1|w3 matrix -- the tail of a launch comes from
     // uneven service by the memory system across CUs, not from the deal inside a workgroup.)
     // One loop, no drain phase: every step consumes the oldest ring slot (if that tile exists) and
-    // refills it with the tile three ahead (live or dead), so the loads stay unconditional and the
-    // compiler's s_waitcnt vmcnt(N) always leaves the two younger tiles in flight.
-    for (uint32_t i = 0; i < ntiles; i += 3) {
-        compute(t0, cp.rg, cp.c); advance(cp);
-        load(t0, ld.rg, ld.c, i + 3 < ntiles); advance(ld);
-        if (i + 1 < ntiles) { compute(t1, cp.rg, cp.c); advance(cp); }
-        load(t1, ld.rg, ld.c, i + 4 < ntiles); advance(ld);
-        if (i + 2 < ntiles) { compute(t2, cp.rg, cp.c); advance(cp); }
-        load(t2, ld.rg, ld.c, i + 5 < ntiles); advance(ld);
+    // refills it with the tile RING ahead (live or dead), so the loads stay unconditional and the
+    // compiler's s_waitcnt vmcnt(N) always leaves the younger tiles in flight.
+    // (Ring depth A/B on the w1|w3 matrix, tools/ring_ab.py: 3 slots 19.5 us, 4: 20.9, 5: 21.4,
+    // 6: 22.1 -- 2048 waves x 3 tiles x 4 KB = 24 MB are already queued in the memory system, whose
+    // service time IS the latency; deeper rings only lengthen the queue and the start-up.)
+    for (uint32_t i = 0; i < ntiles; i += RING) {
+#pragma unroll
+        for (int sl = 0; sl < RING; sl++) {
+            if (sl == 0 || i + sl < ntiles) { compute(ring[sl], cp.rg, cp.c); advance(cp); }
+            load(ring[sl], ld.rg, ld.c, i + sl + RING < ntiles); advance(ld);
+        }
     }
     if (QM == Q_DBG_TL && lane == 0) {
         // (epilogues of this variant never read `resp`: it carries the stamp buffer)
