@@ -72,9 +72,9 @@ def test_llama_prompt_matches_oracle(acc, dt, quant, fmt, group):
     assert agree >= (4 if dt == F32 else 3)
 
 
-@pytest.mark.parametrize("n", [2, 16, 17, 64, 100])
+@pytest.mark.parametrize("n", [2, 16, 17, 64, 100, 256, 300])
 def test_prompt_lengths_around_the_tile_edges(acc, n):
-    cfg = mg.tiny_cfg(BF16, max_seq_len=128, n_layers=1)
+    cfg = mg.tiny_cfg(BF16, max_seq_len=320, n_layers=1)
     weights = mg.make_model(cfg, seed=72, quant="i4", group=32)
     tokens = np.random.default_rng(n).integers(0, cfg["vocab"], n).tolist()
     check_against_oracle(acc, cfg, weights, dict(weight_format=2, group_size=32), tokens, follow=1)
@@ -105,6 +105,14 @@ def test_gemma3_prompt_with_sliding_window(acc, dt):
     tokens = np.random.default_rng(6).integers(0, cfg["vocab"], 30).tolist()
     # window 5 < len: the second triangle of make_sliding_causal_mask (nn/attention.h:302-321) bites
     check_against_oracle(acc, cfg, weights, dict(weight_format=2, group_size=32), tokens, window=5)
+
+
+def test_gemma3_long_prompt_sliding_window(acc):
+    cfg = mg.tiny_cfg(BF16, family=1, n_layers=2, rope_sliding_theta=10000.0, sliding_stride=2,
+                      attn_scale=float(1.0 / np.sqrt(48.0)), max_seq_len=320)
+    weights = mg.make_model(cfg, seed=80, quant="i4", group=32)
+    tokens = np.random.default_rng(10).integers(0, cfg["vocab"], 270).tolist()
+    check_against_oracle(acc, cfg, weights, dict(weight_format=2, group_size=32), tokens, window=37, follow=1)
 
 
 def test_second_chunk_sees_only_itself_like_the_reference(acc):
