@@ -58,6 +58,9 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-roofline", action="store_true")
     p.add_argument("--seed", type=int, default=0x5EED)
+    p.add_argument("--force-pipeline", action="store_true",
+                   help="run the N > 1 code path (torch stream, RCCL group, stage loop) with one rank: a "
+                        "smoke check of the multi-GPU plumbing on a 1-GPU box")
     return p.parse_args()
 
 
@@ -160,7 +163,8 @@ def main():
     # torch.distributed over RCCL for the stage hops.
     torch = None
     dist = None
-    if world > 1:
+    piped = world > 1 or args.force_pipeline
+    if piped:
         import torch
         import torch.distributed as dist_mod
 
@@ -184,7 +188,7 @@ def main():
 
     # N > 1: the decoder's queue adopts a torch-owned (non-default) stream that is also the current
     # stream for the RCCL hops, so torch orders send/recv against the kernels
-    tstream = torch.cuda.Stream(device=local_rank) if world > 1 else None
+    tstream = torch.cuda.Stream(device=local_rank) if piped else None
     if tstream is not None:
         torch.cuda.set_stream(tstream)
     acc = mc.HardwareAccelerator(ordinal=local_rank,
@@ -197,7 +201,7 @@ def main():
                      attn_scale=float(1.0 / np.sqrt(m["head_dim"])), layer_begin=lb, layer_end=le,
                      weight_format=wfmt, group_size=(args.group if args.wbits != 16 else 0),
                      qmode=(mc.QMODE_FAST if args.qmode == "fast" else mc.QMODE_EXACT),
-                     use_graph=0 if (args.no_graph or world > 1) else 1, **m)
+                     use_graph=0 if (args.no_graph or piped) else 1, **m)
     dec.init_synthetic(args.seed)
 
     fill = S - K - W  # context decoded (untimed) before warm-up so the timed tokens end at S
@@ -209,7 +213,7 @@ def main():
             torch.cuda.synchronize()
         acc.wait()
 
-    if world == 1:
+    if not piped:
         tok = 1
         if fill > 0:
             tok = int(dec.generate(tok, 0, fill)[-1])
@@ -269,7 +273,7 @@ def main():
         "config": {"workload": f"{args.model} int{args.wbits} (group={args.group}) batch=1 greedy decode, "
                                f"seq_len={S}, {args.dtype} activations/KV, qmode={args.qmode}",
                    "parallelism": "single GPU" if world == 1 else f"layer pipeline pp{world} (RCCL send/recv)",
-                   "hipgraph": bool(world == 1 and not args.no_graph)},
+                   "hipgraph": bool(not piped and not args.no_graph)},
         "whole_token": {"algorithmic_bytes": ab["total"], "achieved_GBs": ab["total"] * tok_s / 1e9,
                         "frac_of_hbm_peak": ab["total"] * tok_s / 1e9 / HBM_PEAK_GBS},
     }
