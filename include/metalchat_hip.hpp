@@ -28,6 +28,7 @@
 #include <string>
 #include <tuple>
 #include <unordered_map>
+#include <vector>
 
 #include "metalchat_hip.h"
 
@@ -322,6 +323,105 @@ public:
 
     const basic_kernel& load(const std::string& name, const std::string& type) { return load(name + "_" + type); }
 };
+
+// ---- model files (part 3 of the ABI) --------------------------------------------------------
+/// One entry of a document -- the read-only face of the reference's `safetensor`
+/// (include/metalchat/safetensor.h:143-236): name(), dtype(), sizes(), data pointer.
+class safetensor {
+    mc_tensor_info _M_info;
+
+public:
+    explicit safetensor(const mc_tensor_info& info) : _M_info(info) {}
+    std::string name() const { return _M_info.name; }
+    std::string dtype() const { return _M_info.dtype; }
+    std::size_t dimensions() const { return (std::size_t)_M_info.ndim; }
+    std::size_t size(std::size_t i) const { return (std::size_t)_M_info.shape[i]; }
+    std::size_t numel() const
+    {
+        std::size_t n = 1;
+        for (int i = 0; i < _M_info.ndim; i++) n *= (std::size_t)_M_info.shape[i];
+        return n;
+    }
+    const void* data_ptr() const { return _M_info.data; }
+    std::size_t nbytes() const { return _M_info.nbytes; }
+};
+
+/// safetensor_document / sharded_safetensor_document (include/metalchat/safetensor.h:534-1030):
+/// open / insert / link / adapt (rename) / save, iteration in file-offset order.
+class safetensor_document {
+    std::shared_ptr<mc_document> _M_doc;
+
+    explicit safetensor_document(mc_document* d) : _M_doc(d, mc_document_release) {}
+
+public:
+    safetensor_document()
+    {
+        mc_document* d = nullptr;
+        check(mc_document_create(&d));
+        _M_doc.reset(d, mc_document_release);
+    }
+
+    static safetensor_document
+    open(const std::string& path)
+    {
+        mc_document* d = nullptr;
+        check(mc_document_open(path.c_str(), &d)); // runtime_error: "safetensor_document: header is corrupted, ..."
+        return safetensor_document(d);
+    }
+
+    static safetensor_document
+    open_sharded(const std::string& index_path)
+    {
+        mc_document* d = nullptr;
+        check(mc_document_open_sharded(index_path.c_str(), &d));
+        return safetensor_document(d);
+    }
+
+    std::size_t size() const { return (std::size_t)mc_document_size(_M_doc.get()); }
+
+    safetensor
+    operator[](std::size_t i) const
+    {
+        mc_tensor_info t;
+        check(mc_document_tensor(_M_doc.get(), (int32_t)i, &t));
+        return safetensor(t);
+    }
+
+    safetensor
+    at(const std::string& name) const
+    {
+        mc_tensor_info t;
+        check(mc_document_find(_M_doc.get(), name.c_str(), &t)); // invalid_argument when absent
+        return safetensor(t);
+    }
+
+    void
+    insert(const std::string& name, const std::string& dtype, const std::vector<int64_t>& shape, const void* data)
+    {
+        check(mc_document_insert(_M_doc.get(), name.c_str(), dtype.c_str(), (int32_t)shape.size(), shape.data(), data));
+    }
+
+    /// insert(name, source): a second name sharing the storage of `source`
+    void insert(const std::string& name, const std::string& source) { check(mc_document_link(_M_doc.get(), name.c_str(), source.c_str())); }
+
+    /// serializer.adapt(document) for one of the MC_CKPT_* flavours
+    void adapt(int32_t flavour) { check(mc_document_adapt(_M_doc.get(), flavour)); }
+
+    void save(const std::string& path) const { check(mc_document_save(_M_doc.get(), path.c_str())); }
+
+    mc_document* get() const { return _M_doc.get(); }
+};
+
+/// options_serializer::load for the three JSON dialects (src/llama.cc:41-55, src/reference.cc:52-66,
+/// src/gemma.cc:20-42); widths that the reference reads off the tensors come from the document.
+inline mc_decoder_config
+load_options(const std::string& json_text, int32_t flavour, const safetensor_document* document = nullptr)
+{
+    mc_decoder_config cfg{};
+    check(mc_config_from_json(json_text.c_str(), flavour, &cfg));
+    if (document) check(mc_config_from_document(document->get(), &cfg));
+    return cfg;
+}
 
 } // namespace hip
 } // namespace metalchat

@@ -77,9 +77,24 @@ def build_shim_test(force: bool = False) -> str:
     return out
 
 
+def build_model_io_test(force: bool = False) -> str:
+    """tests/cpp/test_model_io: host-only C++ test of the document / options part of the ABI."""
+    root = os.path.dirname(HERE)
+    src = os.path.join(root, "tests", "cpp", "test_model_io.cc")
+    out = os.path.join(root, "tests", "cpp", "test_model_io")
+    deps = [src, os.path.join(root, "include", "metalchat_hip.hpp"),
+            os.path.join(root, "include", "metalchat_hip.h"), SO]
+    if force or _stale(out, deps):
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-I" + os.path.join(root, "include"), src,
+                               "-o", out, "-L" + LIB, "-lmetalchat_hip",
+                               "-Wl,-rpath," + LIB, "-Wl,-rpath,/opt/rocm/lib", "-pthread"])
+    return out
+
+
 def build_all(force: bool = False):
     r = build_kernels(force), build_host(force)
     build_shim_test(force)
+    build_model_io_test(force)
     return r
 
 

@@ -27,3 +27,14 @@ def test_cpp_shim_compiles_without_hip_headers():
     build.build_host()
     exe = build.build_shim_test(force=True)
     assert os.path.exists(exe)
+
+
+def test_cpp_model_io_host_only(tmp_path):
+    # documents, links, shards and option serializers through the C++ shim; no GPU involved
+    from metalchat_amd import build
+
+    build.build_host()
+    exe = build.build_model_io_test()
+    r = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "model_io ok" in r.stdout
