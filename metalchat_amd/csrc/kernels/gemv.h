@@ -683,6 +683,12 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
         }
     };
 
+    // (Cutting a workgroup's (row group, chunk) tiles into equal per-wave ranges -- every wave 7
+    // tiles of w1|w3 instead of 3 or 4 whole row groups, shared groups finished from LDS partials
+    // after a barrier -- was built and passed parity, and was SLOWER by ~1 us on every matrix
+    // (w1|w3 20.7 vs 19.5 us): the two waves of a SIMD share its VALU, so a wave that finishes early
+    // hands its issue slots to its neighbour and per-SIMD work was already even; the contiguous
+    // sweep of the old deal is worth more than equal per-wave end times.)
     // (A per-workgroup LDS work counter with contiguous row ranges was tried instead of the static
     // round-robin deal: 20.0 vs 19.0 us on the w1|w3 matrix -- the tail of a launch comes from
     // uneven service by the memory system across CUs, not from the deal inside a workgroup.)
