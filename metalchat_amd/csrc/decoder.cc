@@ -410,6 +410,8 @@ struct mc_decoder {
         std::string name = "mc_gemv_";
         name += L.fmt == MC_WFMT_I4 ? "i4_" : (L.fmt == MC_WFMT_I8 ? "i8_" : "w_");
         name += tname;
+        const unsigned waves = gemv_block / 64;
+        const unsigned cap = (unsigned)(dev->prop.multiProcessorCount * gemv_wgs_per_cu);
         if (L.fmt == MC_WFMT_I4 && tb == 2 && cfg.qmode == MC_QMODE_FAST) name += "_fast";
         if (L.fmt == MC_WFMT_I4 && tb == 2 && dbg_variant && ((pro == 1 && epi == 2) || (pro == 0 && epi == 0)))
             name += dbg_variant == 1 ? "_dbgstream" : "_dbgnoload";
@@ -418,10 +420,8 @@ struct mc_decoder {
         // whole multiple of the CU count: what has to balance is the work per CU -- its SIMDs
         // time-share their waves -- so 3.5 row groups per wave on every CU beats an even 4 per
         // wave on 448 workgroups, measured 19.0 vs 21.4 us on the 60 MB w1|w3 matrix).
-        const unsigned waves = gemv_block / 64;
         const unsigned ng = (L.out + 3) / 4;
         unsigned wgs = (ng + waves - 1) / waves;
-        const unsigned cap = (unsigned)(dev->prop.multiProcessorCount * gemv_wgs_per_cu);
         if (wgs > cap) wgs = cap;
         if (wgs == 0) wgs = 1;
         // LDS: activation row zero-padded to whole chunks (64 lanes x 16 B of packed weights) + scratch

@@ -443,6 +443,76 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
         }
     };
 
+    // ---- epilogue of row group crg from its four row sums (wave-uniform values in tot[])
+    auto finish = [&](uint32_t crg, float (&tot)[R]) {
+        if (lora_rank) {
+            // quantization::lora_linear (quantization/lora.h:119-121):
+            //   result = T(T(x Wd^T) + T(T(B (A x)) * scale)),  A x already rounded to T by the
+            // adaptor launch that ran before this one.  Lane r finishes the adaptation of row r;
+            // B is stored in the fused row order, [out][lora_rank] with zeros outside the
+            // columns of the row's own adaptor (wq|wk|wv and w1/w3 keep separate adaptors).
+            const uint32_t row = crg * R + lane;
+            float ad = 0.0f;
+            if (lane < (uint32_t)R && row < out_rows) {
+                const S* av = static_cast<const S*>(lora_ap);
+                const S* bv = static_cast<const S*>(lora_bp) + (size_t)row * lora_rank;
+                float p = 0.0f;
+                for (uint32_t i = 0; i < lora_rank; i++) p += T::ld(av[i]) * T::ld(bv[i]);
+                ad = T::rt(T::rt(p) * T::rt(lora_scale));
+            }
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const float adr = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ad), r));
+                tot[r] = T::rt(T::rt(tot[r]) + adr);
+            }
+        }
+        S* y = static_cast<S*>(yp);
+        if (EPI == EPI_STORE || EPI == EPI_RESID) {
+            // lane r finishes row r
+            const float mine = lane == 0 ? tot[0] : (lane == 1 ? tot[1] : (lane == 2 ? tot[2] : tot[3]));
+            const uint32_t row = crg * R + lane;
+            if (lane < (uint32_t)R && row < out_rows) {
+                float v = T::rt(mine);
+                if (EPI == EPI_RESID) v = T::ld(static_cast<const S*>(resp)[row]) + v; // add in T
+                y[row] = T::st(v);
+            }
+        } else if (EPI == EPI_QKV_ROPE) {
+            const qkv_epilogue* q = static_cast<const qkv_epilogue*>(resp);
+            const uint32_t H = q->H, KV = q->KV, hd = q->hd, half = hd / 2, ms = q->max_seq;
+            const uint32_t slot = (uint32_t)q->state[3], rrow = (uint32_t)q->state[6];
+            const uint32_t row0 = crg * R;
+            if (row0 < (H + KV) * hd) {
+                // two rotation pairs: lane 0 -> rows (0,1), lane 1 -> rows (2,3)
+                const float x1 = T::rt(lane == 0 ? tot[0] : tot[2]);
+                const float x2 = T::rt(lane == 0 ? tot[1] : tot[3]);
+                const uint32_t prow = row0 + 2 * lane;         // packed row of x1
+                const uint32_t head = prow / hd, j = (prow % hd) / 2;
+                if (lane < 2) {
+                    const float c = q->fcos[(size_t)rrow * half + j], sn = q->fsin[(size_t)rrow * half + j];
+                    const S o1 = T::st(c * x1 - sn * x2), o2 = T::st(sn * x1 + c * x2);
+                    S* dst = head < H ? static_cast<S*>(q->q_out) + (size_t)head * hd
+                                      : static_cast<S*>(q->kc) + ((size_t)(head - H) * ms + slot) * hd;
+                    dst[j] = o1;
+                    dst[j + half] = o2;
+                }
+            } else if (lane < (uint32_t)R) {
+                const float mine = lane == 0 ? tot[0] : (lane == 1 ? tot[1] : (lane == 2 ? tot[2] : tot[3]));
+                const uint32_t vrow = row0 + lane - (H + KV) * hd; // kv*hd + d
+                static_cast<S*>(q->vt)[(size_t)vrow * ms + slot] = T::st(mine);
+            }
+        } else {
+            // rows (2j, 2j+1) = (w1 row j, w3 row j): out[j] = T(act(T(w1 x)) * T(w3 x));
+            // lane 0 finishes pair 0, lane 1 pair 1 (one activation evaluation per wave)
+            const float a = T::rt(lane == 0 ? tot[0] : tot[2]);
+            const float b = T::rt(lane == 0 ? tot[1] : tot[3]);
+            const uint32_t row = crg * R + 2 * lane;
+            if (lane < 2 && row + 1 < out_rows) {
+                const float g = EPI == EPI_SILU_MUL ? silu_T<T>(a) : T::rt(gelu_f32(a));
+                y[row / 2] = T::st(g * b);
+            }
+        }
+    };
+
     // Tile cursor (scalar): the wave walks (row group, chunk) pairs; row groups are dealt
     // round-robin over all waves of the grid.  `ld` runs three tiles ahead of `cp`.
     struct cursor {
@@ -464,7 +534,7 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
     // norm weight) are REQUESTED FIRST, then the first weight tile (HBM latency) and only then is
     // the row consumed: the counted wait for the row does not sit behind the weight stream.
     // PRO_RMSNORM: kernel/rmsnorm.metal:52-95, y = T((mu + w) * x * rsqrt(mean(x^2) + eps)).
-    {
+    auto stage_x = [&](auto&& prefetch) {
         constexpr uint32_t EPV = 16 / T::bytes; // elements per 16-byte packet
         constexpr int MAXP = PRO == PRO_RMSNORM ? 4 : 8;
         const uint32_t npk = in / EPV;
@@ -484,16 +554,7 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
                 if (PRO == PRO_RMSNORM) nr[i] = ng[pc];
             }
         }
-        // MC_GEMV_PRE of the three ring tiles are requested before the row is consumed, the rest
-        // right after the barrier (A/B: tools/gemv_sweep.py with MC_HSACO=..._preN.hsaco)
-#ifndef MC_GEMV_PRE
-#define MC_GEMV_PRE 1
-#endif
-        load(ring[0], ld.rg, ld.c, 0 < ntiles);
-        advance(ld);
-#pragma unroll
-        for (int sl = 1; sl < RING; sl++)
-            if (MC_GEMV_PRE > sl) { load(ring[sl], ld.rg, ld.c, (uint32_t)sl < ntiles); advance(ld); }
+        prefetch(); // the first weight tile(s): requested behind the row, before the row is consumed
         if (fits) {
 #pragma unroll
             for (int i = 0; i < MAXP; i++)
@@ -576,7 +637,29 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
                 for (uint32_t p = tid; p < npk; p += bd) xl[p] = xg[p];
             }
         }
-    }
+    };
+
+    // (Products on the matrix pipe were tried for the exact int4 / bfloat path: 16-row tiles, the
+    // dequantised dword of a lane used directly as the A fragment of v_mfma_f32_16x16x32_bf16, the
+    // activations broadcast as B, K shared between the four waves of a workgroup with a per-tile
+    // barrier.  It removes the 16 v_dot2c per packet -- a quarter of the VALU cycles, and the
+    // counters say the kernel is issue-bound (SQ_ACTIVE_INST_ANY ~ 90 % of SQ_WAVE_CYCLES per
+    // SIMD) -- passed every parity test, and was SLOWER: w1|w3 21.1 vs 18.3 us, Wo 7.2 vs 5.4, w2
+    // 14.0 vs 10.9 (slots of one wave-load: 22.8; K dealt round-robin for DRAM locality: no change).
+    // The 16 x 64-byte access shape, the per-tile barrier and the cross-wave sums cost more than
+    // the dot products save.)
+    // MC_GEMV_PRE of the ring tiles are requested before the row is consumed, the rest right after
+    // the barrier (A/B: tools/gemv_sweep.py with MC_HSACO=..._preN.hsaco)
+#ifndef MC_GEMV_PRE
+#define MC_GEMV_PRE 1
+#endif
+    stage_x([&] {
+        load(ring[0], ld.rg, ld.c, 0 < ntiles);
+        advance(ld);
+#pragma unroll
+        for (int sl = 1; sl < RING; sl++)
+            if (MC_GEMV_PRE > sl) { load(ring[sl], ld.rg, ld.c, (uint32_t)sl < ntiles); advance(ld); }
+    });
     __syncthreads();
     if (QM == Q_DBG_TL) tl1 = __builtin_amdgcn_s_memrealtime();
 #pragma unroll
@@ -607,79 +690,13 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
             }
         }
         if (cc + 1 == nchunks) {
-            // ---- epilogue for row group crg (wave-uniform branch)
             float tot[R];
 #pragma unroll
             for (int r = 0; r < R; r++) {
                 tot[r] = wave_sum_dpp(acc[r]);
                 acc[r] = 0.0f;
             }
-            if (lora_rank) {
-                // quantization::lora_linear (quantization/lora.h:119-121):
-                //   result = T(T(x Wd^T) + T(T(B (A x)) * scale)),  A x already rounded to T by the
-                // adaptor launch that ran before this one.  Lane r finishes the adaptation of row r;
-                // B is stored in the fused row order, [out][lora_rank] with zeros outside the
-                // columns of the row's own adaptor (wq|wk|wv and w1/w3 keep separate adaptors).
-                const uint32_t row = crg * R + lane;
-                float ad = 0.0f;
-                if (lane < (uint32_t)R && row < out_rows) {
-                    const S* av = static_cast<const S*>(lora_ap);
-                    const S* bv = static_cast<const S*>(lora_bp) + (size_t)row * lora_rank;
-                    float p = 0.0f;
-                    for (uint32_t i = 0; i < lora_rank; i++) p += T::ld(av[i]) * T::ld(bv[i]);
-                    ad = T::rt(T::rt(p) * T::rt(lora_scale));
-                }
-#pragma unroll
-                for (int r = 0; r < R; r++) {
-                    const float adr = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ad), r));
-                    tot[r] = T::rt(T::rt(tot[r]) + adr);
-                }
-            }
-            S* y = static_cast<S*>(yp);
-            if (EPI == EPI_STORE || EPI == EPI_RESID) {
-                // lane r finishes row r
-                const float mine = lane == 0 ? tot[0] : (lane == 1 ? tot[1] : (lane == 2 ? tot[2] : tot[3]));
-                const uint32_t row = crg * R + lane;
-                if (lane < (uint32_t)R && row < out_rows) {
-                    float v = T::rt(mine);
-                    if (EPI == EPI_RESID) v = T::ld(static_cast<const S*>(resp)[row]) + v; // add in T
-                    y[row] = T::st(v);
-                }
-            } else if (EPI == EPI_QKV_ROPE) {
-                const qkv_epilogue* q = static_cast<const qkv_epilogue*>(resp);
-                const uint32_t H = q->H, KV = q->KV, hd = q->hd, half = hd / 2, ms = q->max_seq;
-                const uint32_t slot = (uint32_t)q->state[3], rrow = (uint32_t)q->state[6];
-                const uint32_t row0 = crg * R;
-                if (row0 < (H + KV) * hd) {
-                    // two rotation pairs: lane 0 -> rows (0,1), lane 1 -> rows (2,3)
-                    const float x1 = T::rt(lane == 0 ? tot[0] : tot[2]);
-                    const float x2 = T::rt(lane == 0 ? tot[1] : tot[3]);
-                    const uint32_t prow = row0 + 2 * lane;         // packed row of x1
-                    const uint32_t head = prow / hd, j = (prow % hd) / 2;
-                    if (lane < 2) {
-                        const float c = q->fcos[(size_t)rrow * half + j], sn = q->fsin[(size_t)rrow * half + j];
-                        const S o1 = T::st(c * x1 - sn * x2), o2 = T::st(sn * x1 + c * x2);
-                        S* dst = head < H ? static_cast<S*>(q->q_out) + (size_t)head * hd
-                                          : static_cast<S*>(q->kc) + ((size_t)(head - H) * ms + slot) * hd;
-                        dst[j] = o1;
-                        dst[j + half] = o2;
-                    }
-                } else if (lane < (uint32_t)R) {
-                    const float mine = lane == 0 ? tot[0] : (lane == 1 ? tot[1] : (lane == 2 ? tot[2] : tot[3]));
-                    const uint32_t vrow = row0 + lane - (H + KV) * hd; // kv*hd + d
-                    static_cast<S*>(q->vt)[(size_t)vrow * ms + slot] = T::st(mine);
-                }
-            } else {
-                // rows (2j, 2j+1) = (w1 row j, w3 row j): out[j] = T(act(T(w1 x)) * T(w3 x));
-                // lane 0 finishes pair 0, lane 1 pair 1 (one activation evaluation per wave)
-                const float a = T::rt(lane == 0 ? tot[0] : tot[2]);
-                const float b = T::rt(lane == 0 ? tot[1] : tot[3]);
-                const uint32_t row = crg * R + 2 * lane;
-                if (lane < 2 && row + 1 < out_rows) {
-                    const float g = EPI == EPI_SILU_MUL ? silu_T<T>(a) : T::rt(gelu_f32(a));
-                    y[row / 2] = T::st(g * b);
-                }
-            }
+            finish(crg, tot);
         }
     };
 

@@ -3,59 +3,17 @@ adopting a torch-owned non-default stream, torch tensors aliasing decoder-owned 
 (hidden_in / hidden_out rows of a pipeline stage), and a two-stage split on one device giving the
 tokens of a single decoder.  torch is imported FIRST, as in bench.py (its bundled HIP runtime and
 the library's must resolve to one)."""
-import numpy as np
+import os
+import subprocess
+import sys
+
 import pytest
 
-import modelgen as mg
-
 pytestmark = pytest.mark.gpu
-BF16, F32 = 0, 1
-
-
-class _Raw:
-    def __init__(self, ptr, n, typestr):
-        self.__cuda_array_interface__ = dict(shape=(n,), typestr=typestr, data=(ptr, False), version=3)
-
-
-@pytest.mark.parametrize("dt", [BF16, F32])
-def test_two_stages_on_a_torch_stream_match_one_decoder(dt):
-    import torch
-
-    import metalchat_amd as mc
-
-    assert torch.cuda.is_available()
-    torch.cuda.set_device(0)
-    ts = torch.cuda.Stream(device=0)
-    torch.cuda.set_stream(ts)
-    acc = mc.HardwareAccelerator(ordinal=0, stream=ts.cuda_stream)
-    cfg = mg.tiny_cfg(dt, n_layers=4, max_seq_len=32)
-    w = mg.make_model(cfg, seed=91, quant="i4", group=32)
-    kw = dict(weight_format=2, group_size=32)
-    whole = mc.Decoder(acc, **mg.decoder_kwargs(cfg, **kw))
-    whole.load_model(w)
-    s0 = mc.Decoder(acc, **mg.decoder_kwargs(cfg, layer_begin=0, layer_end=2, **kw))
-    s1 = mc.Decoder(acc, **mg.decoder_kwargs(cfg, layer_begin=2, layer_end=4, **kw))
-    s0.load_model(w)
-    s1.load_model(w)
-    s0.set_taps(True)
-    tt = "<u2" if dt == BF16 else "<f4"
-    h_out = torch.as_tensor(_Raw(s0.hidden_out_ptr(), cfg["dim"], tt), device="cuda:0")
-    h_in = torch.as_tensor(_Raw(s1.hidden_in_ptr(), cfg["dim"], tt), device="cuda:0")
-    tok = 3
-    for pos in range(6):
-        s0.step(tok, pos, sync=False)
-        acc.wait()
-        # the "hop": a torch copy on the adopted stream between the two stages' buffers
-        h_in.copy_(h_out)
-        torch.cuda.current_stream().synchronize()
-        got = s1.step(-1, pos, hidden_in=s1.hidden_in_ptr())
-        ref = whole.step(tok, pos)
-        assert got == ref, f"pos {pos}"
-        assert np.array_equal(s1.logits(), whole.logits())
-        # torch sees exactly the bytes the decoder wrote
-        host = h_out.cpu().numpy().view(np.uint16 if dt == BF16 else np.float32)
-        assert np.array_equal(host, s0.hidden(1))
-        tok = ref
-    for d in (whole, s0, s1):
-        d.release()
-    torch.cuda.set_stream(torch.cuda.default_stream(0))
+def test_two_stages_on_a_torch_stream_match_one_decoder():
+    # a fresh interpreter: in this pytest process the library may already have loaded the system HIP
+    # runtime before torch brings its own, which is not the order bench.py uses
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, os.path.join(here, "interop_child.py"), here, os.path.dirname(here)],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "interop ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
