@@ -168,6 +168,8 @@ struct mc_decoder {
     void* logits = nullptr;     // T[vocab]
     float* expv = nullptr;      // [H][max_seq]
     float* psum = nullptr;      // [H][nsplit]
+    float* pv_parts = nullptr;  // [pv_ranges][H*hd] fp32 partial P.V sums (long contexts)
+    int pv_ranges = 1;
     void* taps = nullptr;       // T[(n_own+1)*dim]
     step_state_h* state = nullptr;
     int32_t* tokens_dev = nullptr;
@@ -494,10 +496,15 @@ struct mc_decoder {
                             (uint32_t)hd, (uint32_t)cfg.max_seq_len, scale_T, (uint32_t)nsplit));
             if (s != MC_OK) return s;
             // softmax normalisation + P.V          (attention.h:200-203)
-            s = launch("mc_attn_pv_" + tname, hd / 16, KV, 1, 256, 0,
+            s = launch("mc_attn_pv_" + tname, hd / 16, KV, pv_ranges, 256, 0,
                        pack(expv, psum, L.vt, attn_out, state, (uint32_t)n_rep, (uint32_t)hd,
-                            (uint32_t)cfg.max_seq_len, (uint32_t)nsplit));
+                            (uint32_t)cfg.max_seq_len, (uint32_t)nsplit, pv_parts, (uint32_t)H));
             if (s != MC_OK) return s;
+            if (pv_ranges > 1) {
+                s = launch("mc_attn_pv_reduce_" + tname, (H * hd + 255) / 256, 1, 1, 256, 0,
+                           pack((const void*)pv_parts, attn_out, (uint32_t)(H * hd), (uint32_t)pv_ranges));
+                if (s != MC_OK) return s;
+            }
             // wo (+ post norm) + residual          (attention.h:205, transformer.h:132-133)
             if (!gemma) {
                 s = gemv(L.wo, 0, 1, attn_out, hidden, x, nullptr, mu);
@@ -843,6 +850,11 @@ mc_decoder_create(mc_device* dev, mc_library* lib, mc_queue* q, const mc_decoder
     A(d->logits, (size_t)c.vocab * tb);
     A(d->expv, (size_t)H * c.max_seq_len * 4);
     A(d->psum, (size_t)H * d->nsplit * 4);
+    // contexts of 4096 slots and more: P.V in ranges of 1024 slots + one reduce launch (the 64
+    // whole-context workgroups took 27.9 us per layer at S = 8192); shorter ones keep the single launch
+    d->pv_ranges = c.max_seq_len >= 4096 ? std::min(16, c.max_seq_len / 1024) : 1;
+    if (const char* e = getenv("MC_PV_RANGES")) d->pv_ranges = std::max(1, std::min(64, atoi(e)));
+    A(d->pv_parts, (size_t)d->pv_ranges * H * hd * 4);
     A(d->taps, (size_t)(d->n_own + 1) * dim * tb);
     A(d->state, sizeof(step_state_h));
     d->tokens_cap = 1 << 16;

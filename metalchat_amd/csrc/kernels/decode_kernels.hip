@@ -384,23 +384,33 @@ mc_attn_scores_float(const float* q, const float* kc, float* expv, float* psum, 
 // over ALL cache slots, so the result is final: no cross-workgroup partials, no reduce launch.
 // The four waves interleave the 32-slot MFMA k-steps (wave w takes k-steps w, w+4, ...) and are
 // summed through LDS in wave order.  B = Vt rows (position-contiguous), A = normalised P.
+// Long contexts: gridDim.z > 1 splits the cache slots into gridDim.z ranges of whole k-steps (fixed
+// by max_seq, so a captured graph stays valid as kv_len grows); every range leaves its UNROUNDED
+// fp32 sums in `parts` [gridDim.z][H*hd] and mc_attn_pv_reduce_T adds them in range order and
+// rounds once -- at S = 8192 the 64 whole-context workgroups took 27.9 us per layer.
 // ------------------------------------------------------------------------------------------
-template <typename T>
+// 1 / (sum of the exp partials of one head), softmax.metal:66-72.  The partials of a head (one per
+// 64 cache slots: 125 at S = 8000) are added by a whole wave -- lane-strided, then a shuffle tree --
+// one head per wave at a time; a serial loop per lane cost every workgroup 2-3 us at long contexts.
 __device__ __forceinline__ float
-softmax_inv(const float* __restrict__ psum, uint32_t head_ok, size_t row, uint32_t nact)
+softmax_inv(const float* __restrict__ psum, float* inv_s, uint32_t kv, uint32_t n_rep, uint32_t nsplit, uint32_t nact)
 {
-    float inv = 0.0f;
-    if (head_ok) {
-        float tot = 0.0f;
-        for (uint32_t sp = 0; sp < nact; sp++) tot += psum[row + sp];
-        inv = 1.0f / tot; // softmax.metal:66-72: exp_sum = 1 / acc
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (uint32_t head = wave; head < n_rep; head += nw) {
+        const float* row = psum + (size_t)(kv * n_rep + head) * nsplit;
+        float t = 0.0f;
+        for (uint32_t sp = lane; sp < nact; sp += 64) t += row[sp];
+        t = wave_sum(t);
+        if (lane == 0) inv_s[head] = 1.0f / t;
     }
-    return inv;
+    __syncthreads();
+    const uint32_t col = lane & 15;
+    return col < n_rep ? inv_s[col] : 0.0f;
 }
 
 __device__ __forceinline__ void
 pv_finish_store(const f32x4_t& acc, float* part, void* out, int tbytes, uint32_t kv, uint32_t n_rep,
-                uint32_t hd, uint32_t db)
+                uint32_t hd, uint32_t db, float* parts, uint32_t n_heads)
 {
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t col = lane & 15, c = lane >> 4;
@@ -412,7 +422,8 @@ pv_finish_store(const f32x4_t& acc, float* part, void* out, int tbytes, uint32_t
         const float v = ((part[(0 * 16 + head) * 16 + d] + part[(1 * 16 + head) * 16 + d]) +
                          part[(2 * 16 + head) * 16 + d]) + part[(3 * 16 + head) * 16 + d];
         const size_t o = (size_t)(kv * n_rep + head) * hd + db * 16 + d;
-        if (tbytes == 2) static_cast<bf16_t*>(out)[o] = f2bf(v);
+        if (gridDim.z > 1) parts[(size_t)blockIdx.z * n_heads * hd + o] = v;
+        else if (tbytes == 2) static_cast<bf16_t*>(out)[o] = f2bf(v);
         else static_cast<float*>(out)[o] = v;
     }
 }
@@ -420,7 +431,8 @@ pv_finish_store(const f32x4_t& acc, float* part, void* out, int tbytes, uint32_t
 extern "C" __global__ void __launch_bounds__(256)
 mc_attn_pv_bfloat(const float* __restrict__ expv, const float* __restrict__ psum,
                   const bf16_t* __restrict__ vt, bf16_t* __restrict__ out, const step_state* st,
-                  uint32_t n_rep, uint32_t hd, uint32_t max_seq, uint32_t nsplit)
+                  uint32_t n_rep, uint32_t hd, uint32_t max_seq, uint32_t nsplit, float* __restrict__ parts,
+                  uint32_t n_heads)
 {
     __shared__ float part[4 * 16 * 16];
     const uint32_t S = (uint32_t)st->kv_len;
@@ -428,13 +440,16 @@ mc_attn_pv_bfloat(const float* __restrict__ expv, const float* __restrict__ psum
     const uint32_t nact = (S + PB - 1) / PB;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t col = lane & 15, c = lane >> 4;
-    const float inv = softmax_inv<BF>(psum, col < n_rep, (size_t)(kv * n_rep + col) * nsplit, nact);
+    __shared__ float inv_s[16];
+    const float inv = softmax_inv(psum, inv_s, kv, n_rep, nsplit, nact);
     const float* erow = expv + (size_t)(kv * n_rep + col) * max_seq;
     const bf16_t* vrow = vt + ((size_t)kv * hd + db * 16 + col) * max_seq;
-    const uint32_t nk = (S + 31) / 32;
+    const uint32_t nk_all = (S + 31) / 32;
+    const uint32_t kper = ((max_seq + 31) / 32 + gridDim.z - 1) / gridDim.z; // k-steps per context range
+    const uint32_t kbeg = blockIdx.z * kper, nk = min(nk_all, kbeg + kper);
 
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-    for (uint32_t t0 = wave; t0 < nk; t0 += 16) {
+    for (uint32_t t0 = kbeg + wave; t0 < nk; t0 += 16) {
         // four k-steps of this wave per iteration: all loads first, then the MFMAs
         uint4 vb[4];
         float4 e0[4], e1[4];
@@ -445,7 +460,7 @@ mc_attn_pv_bfloat(const float* __restrict__ expv, const float* __restrict__ psum
             vb[u] = *reinterpret_cast<const uint4*>(vrow + pl);
             e0[u] = make_float4(0.f, 0.f, 0.f, 0.f);
             e1[u] = e0[u];
-            if (col < n_rep && p0 < S) {
+            if (col < n_rep && p0 < S && t0 + 4 * u < nk) {
                 e0[u] = *reinterpret_cast<const float4*>(erow + p0);
                 e1[u] = *reinterpret_cast<const float4*>(erow + p0 + 4);
             }
@@ -466,7 +481,7 @@ mc_attn_pv_bfloat(const float* __restrict__ expv, const float* __restrict__ psum
                                                           __builtin_bit_cast(bf16x8_t, vb[u]), acc, 0, 0, 0);
         }
     }
-    pv_finish_store(acc, part, out, 2, kv, n_rep, hd, db);
+    pv_finish_store(acc, part, out, 2, kv, n_rep, hd, db, parts, n_heads);
 }
 
 // T = float.  k-step = 16 slots: lane (col, c) holds slots p0 + 4c + i; MFMA i contracts slot
@@ -474,7 +489,8 @@ mc_attn_pv_bfloat(const float* __restrict__ expv, const float* __restrict__ psum
 extern "C" __global__ void __launch_bounds__(256)
 mc_attn_pv_float(const float* __restrict__ expv, const float* __restrict__ psum,
                  const float* __restrict__ vt, float* __restrict__ out, const step_state* st,
-                 uint32_t n_rep, uint32_t hd, uint32_t max_seq, uint32_t nsplit)
+                  uint32_t n_rep, uint32_t hd, uint32_t max_seq, uint32_t nsplit, float* __restrict__ parts,
+                  uint32_t n_heads)
 {
     __shared__ float part[4 * 16 * 16];
     const uint32_t S = (uint32_t)st->kv_len;
@@ -482,13 +498,16 @@ mc_attn_pv_float(const float* __restrict__ expv, const float* __restrict__ psum,
     const uint32_t nact = (S + PB - 1) / PB;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t col = lane & 15, c = lane >> 4;
-    const float inv = softmax_inv<F32>(psum, col < n_rep, (size_t)(kv * n_rep + col) * nsplit, nact);
+    __shared__ float inv_s[16];
+    const float inv = softmax_inv(psum, inv_s, kv, n_rep, nsplit, nact);
     const float* erow = expv + (size_t)(kv * n_rep + col) * max_seq;
     const float* vrow = vt + ((size_t)kv * hd + db * 16 + col) * max_seq;
-    const uint32_t nk = (S + 15) / 16;
+    const uint32_t nk_all = (S + 15) / 16;
+    const uint32_t kper = ((max_seq + 15) / 16 + gridDim.z - 1) / gridDim.z;
+    const uint32_t kbeg = blockIdx.z * kper, nk = min(nk_all, kbeg + kper);
 
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-    for (uint32_t t0 = wave; t0 < nk; t0 += 16) {
+    for (uint32_t t0 = kbeg + wave; t0 < nk; t0 += 16) {
         float4 vb[4], pe[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
@@ -496,7 +515,7 @@ mc_attn_pv_float(const float* __restrict__ expv, const float* __restrict__ psum,
             const uint32_t pl = p0 + 4 <= max_seq ? p0 : max_seq - 4;
             vb[u] = *reinterpret_cast<const float4*>(vrow + pl);
             pe[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (col < n_rep && p0 < S) pe[u] = *reinterpret_cast<const float4*>(erow + p0);
+            if (col < n_rep && p0 < S && t0 + 4 * u < nk) pe[u] = *reinterpret_cast<const float4*>(erow + p0);
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
@@ -509,7 +528,27 @@ mc_attn_pv_float(const float* __restrict__ expv, const float* __restrict__ psum,
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, vb[u].w, acc, 0, 0, 0);
         }
     }
-    pv_finish_store(acc, part, out, 4, kv, n_rep, hd, db);
+    pv_finish_store(acc, part, out, 4, kv, n_rep, hd, db, parts, n_heads);
+}
+
+// out[i] = T(sum over context ranges of parts[r][i]), ranges added in order
+extern "C" __global__ void
+mc_attn_pv_reduce_bfloat(const float* __restrict__ parts, bf16_t* __restrict__ out, uint32_t n, uint32_t nr)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float a = 0.0f;
+    for (uint32_t r = 0; r < nr; r++) a += parts[(size_t)r * n + i];
+    out[i] = f2bf(a);
+}
+extern "C" __global__ void
+mc_attn_pv_reduce_float(const float* __restrict__ parts, float* __restrict__ out, uint32_t n, uint32_t nr)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float a = 0.0f;
+    for (uint32_t r = 0; r < nr; r++) a += parts[(size_t)r * n + i];
+    out[i] = a;
 }
 
 // ------------------------------------------------------------------------------------------

@@ -88,6 +88,20 @@ def test_sink_cache_ring_past_max_seq_len(acc, dt):
     assert agree >= 38
 
 
+@pytest.mark.parametrize("dt,ranges", [(F32, 3), (BF16, 3), (BF16, 8)])
+def test_pv_context_ranges(acc, dt, ranges, monkeypatch):
+    # long contexts split P.V over ranges of cache slots (fp32 partials + one reduce launch);
+    # forced here on a short cache: 96 slots = 3 (6 for float) MFMA k-steps over 3 / 8 ranges --
+    # ranges past kv_len contribute zeros -- and run past max_seq_len so the ring turns as well
+    monkeypatch.setenv("MC_PV_RANGES", str(ranges))
+    cfg = mg.tiny_cfg(dt, max_seq_len=96, n_layers=1)
+    weights = mg.make_model(cfg, seed=17, quant="i4", group=32)
+    rel = 1e-4 if dt == F32 else 5e-3
+    agree, _ = run_pair(acc, cfg, weights, 100, dict(weight_format=2, group_size=32),
+                        rel_hidden=rel, rel_logits=rel)
+    assert agree >= 97
+
+
 def test_quantised_embedding_and_per_row_head(acc):
     # quantization::lora_embedding + quantization::linear (per-row scale) for the output head
     cfg = mg.tiny_cfg(F32)

@@ -5,7 +5,9 @@ Run twice: `python tools/mall_probe.py` and `MC_TIME_GEMV_LAYERS=1 python tools/
 import os
 import sys
 
-sys.path.insert(0, ".")
+import os
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import metalchat_amd as mc
 
 acc = mc.HardwareAccelerator()

@@ -5,7 +5,9 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, ".")
+import os
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import metalchat_amd as mc
 
 lens = [int(a) for a in sys.argv[1:]] or [128, 512, 2048]

@@ -3,7 +3,9 @@ import json
 import os
 import sys
 
-sys.path.insert(0, ".")
+import os
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import metalchat_amd as mc
 
 acc = mc.HardwareAccelerator(path=os.environ.get("MC_HSACO"))
