@@ -42,3 +42,4 @@ MC_GEMV(mc_gemv_i4_bfloat_dbgstream_p0_e0, WF_I4, BF, Q_DBG_STREAM, 0, 0)
 MC_GEMV(mc_gemv_i4_bfloat_dbgnoload_p0_e0, WF_I4, BF, Q_DBG_NOLOAD, 0, 0)
 MC_GEMV(mc_gemv_i4_bfloat_dbgtl_p1_e2, WF_I4, BF, Q_DBG_TL, 1, 2)
 MC_GEMV(mc_gemv_i4_bfloat_dbgtl_p0_e0, WF_I4, BF, Q_DBG_TL, 0, 0)
+MC_GEMV(mc_gemv_i4_bfloat_dbgtl_p1_e0, WF_I4, BF, Q_DBG_TL, 1, 0)

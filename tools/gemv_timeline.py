@@ -18,6 +18,7 @@ x = acc.to_device((np.random.default_rng(0).normal(0, 1, 14336).astype(np.float3
 nw = acc.to_device(np.full(14336, 0x3F80, np.uint16))
 y = acc.alloc(2 * 28672)
 for which, kname in (("w13", "mc_gemv_i4_bfloat_dbgtl_p1_e2"), ("wo", "mc_gemv_i4_bfloat_dbgtl_p0_e0"),
+                     ("wo", "mc_gemv_i4_bfloat_dbgtl_p1_e0"),
                      ("w2", "mc_gemv_i4_bfloat_dbgtl_p0_e0")):
     for block, wgs_per_cu in ((256, 2), (256, 4)):
         k = acc.load(kname)
