@@ -105,8 +105,64 @@ def make_rope():
                         theta=500000.0, **out)
 
 
+PROMPT_CASES = {
+    # name: (cfg overrides, make_model kwargs, decoder kwargs, prompt length, sliding window)
+    "prompt_llama_f32_i4g32": (dict(dtype=F32, max_seq_len=48), dict(seed=111, quant="i4", group=32),
+                               dict(weight_format=2, group_size=32), 21, 0),
+    "prompt_gemma3_bf16_i4g32": (dict(dtype=BF16, family=1, n_layers=3, rope_sliding_theta=10000.0, sliding_stride=2,
+                                      attn_scale=float(1.0 / np.sqrt(48.0)), max_seq_len=48),
+                                 dict(seed=112, quant="i4", group=32), dict(weight_format=2, group_size=32), 30, 5),
+}
+
+
+def prompt_case(name):
+    over, mk, dk, n, window = PROMPT_CASES[name]
+    cfg = mg.tiny_cfg(**over)
+    weights = mg.make_model(cfg, **mk)
+    tokens = np.random.default_rng(len(name)).integers(0, cfg["vocab"], n).astype(np.int32)
+    return cfg, weights, dk, tokens, window
+
+
+def make_prompt(name):
+    """mco_model_forward (the prompt pass, nn/llama.h:113-134) + two decode steps behind it."""
+    cfg, weights, dk, tokens, window = prompt_case(name)
+    om = mo.Model(cfg, weights)
+    tok, logits = om.forward(tokens, 0, window)
+    hidden = np.stack([np.array(om.hidden(l), copy=True) for l in range(0, cfg["n_layers"])])
+    k, v = om.kv(cfg["n_layers"] - 1)
+    follow_tok, follow_logits = [], []
+    t, pos = tok, len(tokens)
+    for _ in range(2):
+        t, lg = om.step(t, pos)
+        follow_tok.append(t)
+        follow_logits.append(np.array(lg, copy=True))
+        pos += 1
+    om.close()
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), cfg=json.dumps(cfg), digest=weights_digest(weights),
+                        tokens=tokens, window=window, token=tok, logits=logits, hidden=hidden, k_last=k, v_last=v,
+                        follow_tokens=np.array(follow_tok, np.int32), follow_logits=np.stack(follow_logits))
+
+
+def make_sampler():
+    """make_default_sampler (nn/sampling.h:303-313) on seeded logit rows: the seven intermediates of
+    the chain and the sampled id, for both dtypes, with exact ties in the bf16 row."""
+    rng = np.random.default_rng(21)
+    out = {}
+    for dt, tag in ((F32, "f32"), (BF16, "bf16")):
+        x = rng.normal(0, 2.0, 4096).astype(np.float32)
+        if dt == BF16:
+            x = np.round(x * 2) / 2
+        logits = mo.encode(dt, x)
+        tok, taps = mo.sample_default(dt, logits, top_k=50, temperature=0.6, top_p=0.9, init_state=7, init_seq=9, taps=True)
+        out["logits_" + tag], out["taps_" + tag], out["token_" + tag] = logits, taps, tok
+    np.savez_compressed(os.path.join(HERE, "sampler.npz"), top_k=50, temperature=0.6, top_p=0.9, init_state=7, init_seq=9, **out)
+
+
 if __name__ == "__main__":
     for n in DECODE_CASES:
         make_decode(n)
+    for n in PROMPT_CASES:
+        make_prompt(n)
+    make_sampler()
     make_rope()
     print("wrote", sorted(f for f in os.listdir(HERE) if f.endswith(".npz")))

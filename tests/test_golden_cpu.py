@@ -51,3 +51,32 @@ def test_oracle_reproduces_rope_golden():
         mo.rope(dt, L(y.shape), y, L(x.shape), x, L(fcos.shape), fcos, L(fsin.shape), fsin, 1,
                 int(z["n_head"]), int(z["start_pos"]))
         assert np.array_equal(y, z["y_" + tag])
+
+
+@pytest.mark.parametrize("name", sorted(G.PROMPT_CASES))
+def test_oracle_reproduces_prompt_golden(name):
+    z = np.load(os.path.join(GOLD, name + ".npz"))
+    cfg, weights, _, tokens, window = G.prompt_case(name)
+    assert str(z["digest"]) == G.weights_digest(weights) and np.array_equal(tokens, z["tokens"])
+    om = mo.Model(cfg, weights)
+    tok, logits = om.forward(tokens, 0, window)
+    assert tok == int(z["token"]) and np.array_equal(logits, z["logits"])
+    for i in range(cfg["n_layers"]):
+        assert np.array_equal(np.asarray(om.hidden(i)), z["hidden"][i])
+    k, v = om.kv(cfg["n_layers"] - 1)
+    assert np.array_equal(k, z["k_last"]) and np.array_equal(v, z["v_last"])
+    t, pos = tok, len(tokens)
+    for i in range(2):
+        t, lg = om.step(t, pos)
+        assert t == int(z["follow_tokens"][i]) and np.array_equal(lg, z["follow_logits"][i])
+        pos += 1
+    om.close()
+
+
+def test_oracle_reproduces_sampler_golden():
+    z = np.load(os.path.join(GOLD, "sampler.npz"))
+    for dt, tag in ((1, "f32"), (0, "bf16")):
+        tok, taps = mo.sample_default(dt, z["logits_" + tag], top_k=int(z["top_k"]), temperature=float(z["temperature"]),
+                                      top_p=float(z["top_p"]), init_state=int(z["init_state"]), init_seq=int(z["init_seq"]),
+                                      taps=True)
+        assert tok == int(z["token_" + tag]) and np.array_equal(taps, z["taps_" + tag])

@@ -77,3 +77,44 @@ def test_rope_kernels_match_golden(acc, dt, tag):
     acc.wait()
     parity.check(dt, out.download(x.dtype, x.size), z["y_" + tag].reshape(-1),
                  rel=1e-6 if dt == F32 else 1e-3, max_ulp=1, max_frac=0.01, scale_aware=False, what="golden rope")
+
+
+@pytest.mark.parametrize("name", sorted(G.PROMPT_CASES))
+def test_prompt_pass_matches_golden(acc, name):
+    import metalchat_amd as mc
+
+    z = np.load(os.path.join(GOLD, name + ".npz"))
+    cfg, weights, dk, tokens, window = G.prompt_case(name)
+    assert str(z["digest"]) == G.weights_digest(weights)
+    dt = cfg["dtype"]
+    rel, frac = (1e-4, 1.0) if dt == F32 else (7.8e-3, 0.7)
+    dec = mc.Decoder(acc, **mg.decoder_kwargs(cfg, **dk))
+    dec.load_model(weights)
+    dec.set_taps(True)
+    got = dec.prefill(tokens, 0, window)
+    for i in range(cfg["n_layers"]):
+        parity.check(dt, dec.hidden(i), z["hidden"][i], rel=rel, max_ulp=2, max_frac=frac, what=f"{name} hidden[{i}]")
+    parity.check(dt, dec.logits(), z["logits"], rel=rel, max_ulp=2, max_frac=frac, what=f"{name} logits")
+    gk, gv = dec.export_kv(cfg["n_layers"] - 1)
+    parity.check(dt, gk, z["k_last"], rel=rel, max_ulp=2, max_frac=frac, what=f"{name} K")
+    parity.check(dt, gv, z["v_last"], rel=rel, max_ulp=2, max_frac=frac, what=f"{name} V")
+    agree = int(got == int(z["token"]))
+    t, pos = int(z["token"]), len(tokens)
+    for i in range(2):
+        g = dec.step(t, pos)
+        parity.check(dt, dec.logits(), z["follow_logits"][i], rel=rel, max_ulp=2, max_frac=frac, what=f"{name} follow {i}")
+        agree += int(g == int(z["follow_tokens"][i]))
+        t, pos = int(z["follow_tokens"][i]), pos + 1
+    assert agree >= (3 if dt == F32 else 2)
+    dec.release()
+
+
+@pytest.mark.parametrize("dt,tag", [(F32, "f32"), (BF16, "bf16")])
+def test_fused_sampler_matches_golden(acc, dt, tag):
+    from test_sampler_gpu import fused_sample
+
+    z = np.load(os.path.join(GOLD, "sampler.npz"))
+    tok, taps = fused_sample(acc, dt, z["logits_" + tag], top_k=int(z["top_k"]), temperature=float(z["temperature"]),
+                             top_p=float(z["top_p"]), seed=(int(z["init_state"]), int(z["init_seq"])))
+    assert tok == int(z["token_" + tag])
+    parity.exact(taps, z["taps_" + tag], "sampler chain intermediates")
