@@ -53,6 +53,13 @@ struct linear_w {
     float lora_scale = 0.0f;
 };
 
+// mirrors mc::gemv::postnorm_args (kernels/gemv.h)
+struct postnorm_args_h {
+    const void* post_w;
+    const void* res;
+    void* h_out;
+};
+
 // mirrors sampler_params (kernels/sampler_kernels.hip)
 struct sampler_params_h {
     uint32_t k, ncand, ncand_pad;
@@ -73,6 +80,8 @@ struct qkv_epilogue_h {
 struct layer_w {
     linear_w qkv, wo, w13, w2;
     void* qkv_epi = nullptr; // device copy of qkv_epilogue_h
+    void* pn_attn = nullptr; // device postnorm_args: attention post-norm, residual = layer input, h_out = hidden_b
+    void* pn_ffn = nullptr;  // device postnorm_args: ffn post-norm, residual = hidden_b, h_out = hidden
     void* attention_norm = nullptr;
     void* ffn_norm = nullptr;
     void* q_norm = nullptr;
@@ -160,6 +169,8 @@ struct mc_decoder {
     // arena
     void* hidden = nullptr;     // T[dim]   running hidden row (h)
     void* hidden_in = nullptr;  // T[dim]   inbound row for non-first stages
+    void* hidden_b = nullptr;   // T[dim]   gemma3: the row between the attention and the ffn half of a block
+    const void* pending_pn = nullptr; // gemma3: postnorm_args the next pre-norm GEMV has to apply to `proj`
     void* qkv = nullptr;        // T[(H+2KV)*hd]
     void* q_rot = nullptr;      // T[H*hd]
     void* attn_out = nullptr;   // T[H*hd]
@@ -233,6 +244,8 @@ struct mc_decoder {
     int gemv_block = 256;
     int gemv_wgs_per_cu = 2;
     int dbg_variant = 0; // MC_GEMV_DBG=1 stream-only, 2 compute-only (tuning ablations)
+    bool gemma_fuse = true; // MC_GEMMA_UNFUSED=1: keep the post-norms as launches of their own
+    bool pn_ready = false;
 
     ~mc_decoder()
     {
@@ -433,7 +446,7 @@ struct mc_decoder {
         if (L.lora_cols) {
             // a = T(A x): the stacked adaptor inputs through the same kernel family (same prologue,
             // so a pre-norm GEMV and its adaptor see the identical normalised row)
-            mc_status s = gemv(*L.lora_a, pro, 0, x, L.lora_vec, nullptr, norm_w, mu);
+            mc_status s = gemv(*L.lora_a, pro, 0, x, L.lora_vec, pro == 2 ? res : nullptr, norm_w, mu);
             if (s != MC_OK) return s;
         }
         return launch(name, wgs, 1, 1, gemv_block, lds,
@@ -472,6 +485,17 @@ struct mc_decoder {
         const float scale_T = tb == 2 ? bf2f_host(f2bf_host(cfg.attn_scale)) : cfg.attn_scale;
         mc_status s;
         const void* x = x_in; // current hidden row
+        // gemma3: post-norms folded into the prologue of the GEMV that consumes them (gemv.h PRO 2) --
+        // 7 launches per block instead of 9.  Not with parity taps (they want every block output in
+        // HBM) and only while the row fits the prologue's register path.
+        const bool fuse_pn = gemma && !want_taps && gemma_fuse && (size_t)dim * tb / 16 <= (size_t)4 * gemv_block;
+        pending_pn = nullptr;
+        if (fuse_pn && x != hidden && n_own > 0) {
+            // the residual pointers of the fused prologues are fixed at `hidden`: a later pipeline
+            // stage first parks its inbound row there
+            MC_HIP(hipMemcpyAsync(hidden, x, (size_t)dim * tb, hipMemcpyDeviceToDevice, stream));
+            x = hidden;
+        }
         for (int li = 0; li < n_own; li++) {
             layer_w& L = layers[li];
             if (!gemma) {
@@ -482,7 +506,15 @@ struct mc_decoder {
             } else {
                 // gemma3 normalises q and k per head before the rotation (attention.h:174-175):
                 // that needs whole heads, so rope + cache write stay a launch of their own
-                s = gemv(L.qkv, 1, 0, x, qkv, nullptr, L.attention_norm, mu);
+                // (fused flow: the previous block's ffn post-norm + residual is applied by this
+                // kernel's prologue, PRO 2, and its workgroup 0 leaves the block input in `hidden`)
+                if (pending_pn) {
+                    s = gemv(L.qkv, 2, 0, proj, qkv, pending_pn, L.attention_norm, mu);
+                    pending_pn = nullptr;
+                    x = hidden;
+                } else {
+                    s = gemv(L.qkv, 1, 0, x, qkv, nullptr, L.attention_norm, mu);
+                }
                 if (s != MC_OK) return s;
                 s = launch("mc_rope_kv_" + tname, H + 2 * KV, 1, 1, hd / 2, 0,
                            pack(qkv, q_rot, L.kc, L.vt, rope_cos[L.rope_table], rope_sin[L.rope_table],
@@ -512,12 +544,19 @@ struct mc_decoder {
             } else {
                 s = gemv(L.wo, 0, 0, attn_out, proj, nullptr, nullptr, mu);
                 if (s != MC_OK) return s;
-                s = launch("mc_rmsnorm_row_" + tname, 1, 1, 1, 1024, 0,
-                           pack(proj, L.attention_post_norm, x, hidden, (uint32_t)dim, cfg.norm_eps, mu));
-                if (s != MC_OK) return s;
+                if (!fuse_pn) {
+                    s = launch("mc_rmsnorm_row_" + tname, 1, 1, 1, 1024, 0,
+                               pack(proj, L.attention_post_norm, x, hidden, (uint32_t)dim, cfg.norm_eps, mu));
+                    if (s != MC_OK) return s;
+                }
             }
             // ffn_norm + w1|w3 + act*mul           (transformer.h:135-137, 53-59)
-            s = gemv(L.w13, 1, gemma ? 3 : 2, hidden, gate, nullptr, L.ffn_norm, mu);
+            if (gemma && fuse_pn) {
+                // attention post-norm + residual (-> hidden_b) + ffn_norm in the prologue
+                s = gemv(L.w13, 2, 3, proj, gate, L.pn_attn, L.ffn_norm, mu);
+            } else {
+                s = gemv(L.w13, 1, gemma ? 3 : 2, hidden, gate, nullptr, L.ffn_norm, mu);
+            }
             if (s != MC_OK) return s;
             // w2 (+ post norm) + residual          (transformer.h:59, 138-139)
             if (!gemma) {
@@ -526,9 +565,20 @@ struct mc_decoder {
             } else {
                 s = gemv(L.w2, 0, 0, gate, proj, nullptr, nullptr, mu);
                 if (s != MC_OK) return s;
-                s = launch("mc_rmsnorm_row_" + tname, 1, 1, 1, 1024, 0,
-                           pack(proj, L.ffn_post_norm, hidden, hidden, (uint32_t)dim, cfg.norm_eps, mu));
-                if (s != MC_OK) return s;
+                if (!fuse_pn) {
+                    s = launch("mc_rmsnorm_row_" + tname, 1, 1, 1, 1024, 0,
+                               pack(proj, L.ffn_post_norm, hidden, hidden, (uint32_t)dim, cfg.norm_eps, mu));
+                    if (s != MC_OK) return s;
+                } else if (li + 1 < n_own || last_stage) {
+                    // ffn post-norm + residual (hidden_b) is left to the next pre-norm GEMV: the next
+                    // block's wq|wk|wv, or the output head
+                    pending_pn = L.pn_ffn;
+                } else {
+                    // the row leaves this pipeline stage: materialise it
+                    s = launch("mc_rmsnorm_row_" + tname, 1, 1, 1, 1024, 0,
+                               pack(proj, L.ffn_post_norm, (const void*)hidden_b, hidden, (uint32_t)dim, cfg.norm_eps, mu));
+                    if (s != MC_OK) return s;
+                }
             }
             x = hidden;
             if (want_taps)
@@ -564,7 +614,9 @@ struct mc_decoder {
     {
         const float mu = cfg.family == MC_FAMILY_GEMMA3 ? 1.0f : 0.0f;
         // final norm + output head (llama.h:128-133) + greedy pick
-        mc_status s = gemv(output, 1, 0, hidden, logits, nullptr, final_norm, mu);
+        mc_status s = pending_pn ? gemv(output, 2, 0, proj, logits, pending_pn, final_norm, mu)
+                                 : gemv(output, 1, 0, hidden, logits, nullptr, final_norm, mu);
+        pending_pn = nullptr;
         if (s != MC_OK) return s;
         if (sampler_kind == MC_SAMPLER_GREEDY)
             return launch("mc_argmax_" + tname, 1, 1, 1, 1024, 0,
@@ -831,6 +883,7 @@ mc_decoder_create(mc_device* dev, mc_library* lib, mc_queue* q, const mc_decoder
     if (const char* e = getenv("MC_GEMV_BLOCK")) d->gemv_block = atoi(e);
     if (const char* e = getenv("MC_GEMV_WGS_PER_CU")) d->gemv_wgs_per_cu = atoi(e);
     if (const char* e = getenv("MC_GEMV_DBG")) d->dbg_variant = atoi(e);
+    if (const char* e = getenv("MC_GEMMA_UNFUSED")) d->gemma_fuse = atoi(e) == 0;
     if (d->gemv_block % 64 || d->gemv_block < 64 || d->gemv_block > 512) d->gemv_block = 256;
     if (d->gemv_wgs_per_cu < 1) d->gemv_wgs_per_cu = 2;
 
@@ -842,6 +895,7 @@ mc_decoder_create(mc_device* dev, mc_library* lib, mc_queue* q, const mc_decoder
     if (s != MC_OK) return s;
     A(d->hidden, dim * tb);
     A(d->hidden_in, dim * tb);
+    A(d->hidden_b, dim * tb);
     A(d->qkv, (size_t)(H + 2 * KV) * hd * tb);
     A(d->q_rot, (size_t)H * hd * tb);
     A(d->attn_out, (size_t)H * hd * tb);
@@ -886,6 +940,8 @@ mc_decoder_create(mc_device* dev, mc_library* lib, mc_queue* q, const mc_decoder
         A(L.qkv_epi, sizeof e);
         MC_HIP(hipMemcpyAsync(L.qkv_epi, &e, sizeof e, hipMemcpyHostToDevice, d->stream));
         MC_HIP(hipStreamSynchronize(d->stream)); // `e` is a stack temporary
+        A(L.pn_attn, sizeof(postnorm_args_h));
+        A(L.pn_ffn, sizeof(postnorm_args_h));
     }
 #undef A
     MC_HIP(hipStreamSynchronize(d->stream));
@@ -1238,6 +1294,16 @@ check_ready(mc_decoder* d)
     if (d->first_stage && !d->emb_table) return fail(MC_ERR_RUNTIME, "decoder: tok_embeddings not loaded");
     if (d->last_stage && (!d->output.allocated || !d->final_norm))
         return fail(MC_ERR_RUNTIME, "decoder: output head not loaded");
+    if (d->cfg.family == MC_FAMILY_GEMMA3 && !d->pn_ready) {
+        for (auto& L : d->layers) {
+            if (!L.attention_post_norm || !L.ffn_post_norm) return fail(MC_ERR_RUNTIME, "decoder: post-norm weights are not loaded");
+            const postnorm_args_h a{L.attention_post_norm, d->hidden, d->hidden_b};
+            const postnorm_args_h f{L.ffn_post_norm, d->hidden_b, d->hidden};
+            MC_HIP(hipMemcpy(L.pn_attn, &a, sizeof a, hipMemcpyHostToDevice));
+            MC_HIP(hipMemcpy(L.pn_ffn, &f, sizeof f, hipMemcpyHostToDevice));
+        }
+        d->pn_ready = true;
+    }
     return MC_OK;
 }
 

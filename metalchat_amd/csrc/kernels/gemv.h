@@ -33,7 +33,20 @@ namespace gemv {
 
 enum { WF_T = 0, WF_I8 = 1, WF_I4 = 2 };
 enum { Q_EXACT = 0, Q_FAST = 1, Q_DBG_STREAM = 2, Q_DBG_NOLOAD = 3, Q_DBG_TL = 4 }; // 2..4: tuning aids
-enum { PRO_NONE = 0, PRO_RMSNORM = 1 };
+enum { PRO_NONE = 0, PRO_RMSNORM = 1, PRO_POSTNORM = 2 };
+
+// PRO_POSTNORM (gemma3 blocks, include/metalchat/nn/transformer.h:132-139): the row handed to the
+// kernel is the OUTPUT of the previous linear; the prologue applies its post-norm, adds the residual,
+// leaves that hidden row in HBM for later (workgroup 0 writes it) and then applies this linear's
+// own pre-norm -- two rmsnorm launches of the reference folded into the GEMV that consumes them:
+//   h = T(res + T((mu + post_w) * x * rsqrt(mean(x^2) + eps)))
+//   row in LDS = T((mu + norm_w) * h * rsqrt(mean(h^2) + eps))
+// `res` of the kernel carries a postnorm_args* (the epilogues e0 / e3 do not use it).
+struct postnorm_args {
+    const void* post_w; // T[in]
+    const void* res;    // T[in]
+    void* h_out;        // T[in]
+};
 enum { EPI_STORE = 0, EPI_RESID = 1, EPI_SILU_MUL = 2, EPI_GELU_MUL = 3, EPI_QKV_ROPE = 4 };
 
 // EPI_QKV_ROPE: the fused wq|wk|wv GEMV finishes RoPE and the sink-cache write itself
@@ -536,7 +549,7 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
     // PRO_RMSNORM: kernel/rmsnorm.metal:52-95, y = T((mu + w) * x * rsqrt(mean(x^2) + eps)).
     auto stage_x = [&](auto&& prefetch) {
         constexpr uint32_t EPV = 16 / T::bytes; // elements per 16-byte packet
-        constexpr int MAXP = PRO == PRO_RMSNORM ? 4 : 8;
+        constexpr int MAXP = PRO != PRO_NONE ? 4 : 8;
         const uint32_t npk = in / EPV;
         const uint32_t npk_pad = nchunks * CHUNK / EPV;
         const uint4* xg = static_cast<const uint4*>(xp);
@@ -544,14 +557,19 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
         uint4* xl = reinterpret_cast<uint4*>(xs);
         const uint32_t bd = blockDim.x;
         const bool fits = npk <= (uint32_t)MAXP * bd;
-        uint4 xr[MAXP], nr[MAXP];
+        uint4 xr[MAXP], nr[MAXP], pw[PRO == PRO_POSTNORM ? MAXP : 1], rr[PRO == PRO_POSTNORM ? MAXP : 1];
+        const postnorm_args* pna = static_cast<const postnorm_args*>(resp);
         if (fits) {
 #pragma unroll
             for (int i = 0; i < MAXP; i++) {
                 const uint32_t p = tid + i * bd;
                 const uint32_t pc = p < npk ? p : npk - 1;
                 xr[i] = xg[pc];
-                if (PRO == PRO_RMSNORM) nr[i] = ng[pc];
+                if (PRO != PRO_NONE) nr[i] = ng[pc];
+                if (PRO == PRO_POSTNORM) {
+                    pw[i] = static_cast<const uint4*>(pna->post_w)[pc];
+                    rr[i] = static_cast<const uint4*>(pna->res)[pc];
+                }
             }
         }
         prefetch(); // the first weight tile(s): requested behind the row, before the row is consumed
@@ -596,7 +614,49 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
             return make_uint4(o[0], o[1], o[2], o[3]);
         };
 
-        if (fits) {
+        if (fits && PRO == PRO_POSTNORM) {
+            // elementwise T(a + b) on packets (the residual add of the block, evaluated in T)
+            auto add_T = [&](const uint4& a, const uint4& b) {
+                const uint32_t aa[4] = {a.x, a.y, a.z, a.w}, bb[4] = {b.x, b.y, b.z, b.w};
+                uint32_t o[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    if (T::bytes == 2)
+                        o[i] = pack_bf16x2(asf(aa[i] << 16) + asf(bb[i] << 16), asf(aa[i] & 0xFFFF0000u) + asf(bb[i] & 0xFFFF0000u));
+                    else
+                        o[i] = __float_as_uint(asf(aa[i]) + asf(bb[i]));
+                }
+                return make_uint4(o[0], o[1], o[2], o[3]);
+            };
+            float ss = 0.0f;
+#pragma unroll
+            for (int i = 0; i < MAXP; i++) ss += sumsq(xr[i]);
+            const float w1 = wave_sum_dpp(ss);
+            if (lane == 0) red[wave] = w1;
+            __syncthreads();
+            float tot = 0.0f;
+            for (uint32_t i = 0; i < nwaves; i++) tot += red[i];
+            const float inv1 = 1.0f / sqrtf(tot / (float)in + eps);
+            float ss2 = 0.0f;
+#pragma unroll
+            for (int i = 0; i < MAXP; i++) {
+                const uint32_t p = tid + i * bd;
+                xr[i] = p < npk ? add_T(rr[i], normalise(xr[i], pw[i], inv1)) : make_uint4(0, 0, 0, 0);
+                ss2 += sumsq(xr[i]);
+                if (blockIdx.x == 0 && p < npk) static_cast<uint4*>(pna->h_out)[p] = xr[i];
+            }
+            const float w2 = wave_sum_dpp(ss2);
+            if (lane == 0) red[8 + wave] = w2; // the second half of the scratch: no barrier between the two sums' readers and writers
+            __syncthreads();
+            float tot2 = 0.0f;
+            for (uint32_t i = 0; i < nwaves; i++) tot2 += red[8 + i];
+            const float inv2 = 1.0f / sqrtf(tot2 / (float)in + eps);
+#pragma unroll
+            for (int i = 0; i < MAXP; i++) {
+                const uint32_t p = tid + i * bd;
+                if (p < npk) xl[p] = normalise(xr[i], nr[i], inv2);
+            }
+        } else if (fits) {
             if (PRO == PRO_RMSNORM) {
                 float ss = 0.0f;
 #pragma unroll

@@ -1,6 +1,7 @@
 // extern "C" instantiations of the fused GEMV (gemv.h).  Name:
 //   mc_gemv_{i4|i8|w}_{bfloat|float}[_fast]_p{PRO}_e{EPI}
-//   PRO 0 = x as is, 1 = rmsnorm(x) on the way into LDS
+//   PRO 0 = x as is, 1 = rmsnorm(x) on the way into LDS, 2 = gemma3: post-norm of the previous linear's
+//       output + residual (written back by workgroup 0) + this linear's pre-norm (`res` = postnorm_args*)
 //   EPI 0 = store, 1 = residual add, 2 = silu(w1 x) * (w3 x), 3 = gelu(w1 x) * (w3 x),
 //       4 = wq|wk|wv with RoPE + sink-cache write (`res` carries a qkv_epilogue*)
 //   lora_rank != 0: the row results also take the LoRA adaptation T(T(B a) * scale), a = T(A x)
@@ -25,7 +26,9 @@ using namespace mc::gemv;
     MC_GEMV(PFX##_p0_e1, WF, T, QM, 0, 1)      \
     MC_GEMV(PFX##_p1_e2, WF, T, QM, 1, 2)      \
     MC_GEMV(PFX##_p1_e3, WF, T, QM, 1, 3)      \
-    MC_GEMV(PFX##_p1_e4, WF, T, QM, 1, 4)
+    MC_GEMV(PFX##_p1_e4, WF, T, QM, 1, 4)      \
+    MC_GEMV(PFX##_p2_e0, WF, T, QM, 2, 0)      \
+    MC_GEMV(PFX##_p2_e3, WF, T, QM, 2, 3)
 
 MC_GEMV_SET(mc_gemv_i4_bfloat, WF_I4, BF, Q_EXACT)
 MC_GEMV_SET(mc_gemv_i4_bfloat_fast, WF_I4, BF, Q_FAST)

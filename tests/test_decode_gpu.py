@@ -153,6 +153,64 @@ def test_gemma3_matches_oracle(acc, dt):
     assert agree >= 7
 
 
+@pytest.mark.parametrize("dt", [F32, BF16])
+def test_gemma3_fused_post_norms_without_taps(acc, dt, monkeypatch):
+    # without parity taps the gemma3 block runs 7 launches: both post-norms are applied inside the
+    # prologue of the GEMV that consumes them (gemv.h PRO 2).  Logits and tokens against the
+    # oracle, one decoder and a two-stage split, eager and chained through the captured graph.
+    import metalchat_amd as mc
+
+    cfg = mg.tiny_cfg(dt, family=1, n_layers=4, rope_sliding_theta=10000.0, sliding_stride=2,
+                      attn_scale=float(1.0 / np.sqrt(48.0)))
+    weights = mg.make_model(cfg, seed=18, quant="i4", group=32)
+    # T = float shows the fused arithmetic is the reference's (1e-4).  bf16, four gemma blocks
+    # with four norms each: the vector-wise bound is the one of the chained llama runs (5e-3) and the
+    # share of elements that land on the neighbouring bf16 value is larger than for llama (the bound
+    # on HOW FAR stays 2 scaled steps)
+    rel = 1e-4 if dt == F32 else 5e-3
+    frac = 1.0 if dt == F32 else 0.7
+    om = mo.Model(cfg, weights)
+    kw = dict(weight_format=2, group_size=32)
+    one = mc.Decoder(acc, **mg.decoder_kwargs(cfg, **kw))
+    s0 = mc.Decoder(acc, **mg.decoder_kwargs(cfg, layer_begin=0, layer_end=2, **kw))
+    s1 = mc.Decoder(acc, **mg.decoder_kwargs(cfg, layer_begin=2, layer_end=4, **kw))
+    for d in (one, s0, s1):
+        d.load_model(weights)
+    tok, seq = 3, []
+    for pos in range(8):
+        otok, ologits = om.step(tok, pos)
+        got = one.step(tok, pos)
+        parity.check(dt, one.logits(), ologits, rel=rel, max_ulp=2, max_frac=frac, what=f"fused gemma pos {pos}")
+        s0.step(tok, pos, sync=False)
+        acc.wait()
+        got2 = s1.step(-1, pos, hidden_in=s0.hidden_out_ptr())
+        parity.check(dt, s1.logits(), ologits, rel=rel, max_ulp=2, max_frac=frac, what=f"fused gemma 2-stage pos {pos}")
+        assert got2 == got
+        seq.append(got)
+        tok = otok
+    om.close()
+    # the same tokens when the steps are chained on the device (teacher forcing used the oracle's
+    # tokens above, so replay the decoder's own chain)
+    ref = mc.Decoder(acc, **mg.decoder_kwargs(cfg, **kw))
+    ref.load_model(weights)
+    monkeypatch.setenv("MC_GEMMA_UNFUSED", "1")
+    unf = mc.Decoder(acc, **mg.decoder_kwargs(cfg, use_graph=1, **kw))
+    monkeypatch.delenv("MC_GEMMA_UNFUSED")
+    unf.load_model(weights)
+    g = mc.Decoder(acc, **mg.decoder_kwargs(cfg, use_graph=1, **kw))
+    g.load_model(weights)
+    chain = list(g.generate(3, 0, 8))
+    t, stepped = 3, []
+    for pos in range(8):
+        t = ref.step(t, pos)
+        stepped.append(t)
+    assert chain == stepped
+    if dt == F32:
+        assert list(unf.generate(3, 0, 8)) == chain   # fused and unfused agree on the tokens
+    for d in (one, s0, s1, ref, unf, g):
+        d.release()
+
+
 def test_head_dim_128_gqa4(acc):
     # Llama-3-8B head geometry (hd 128, 4 query heads per kv head) at reduced width
     cfg = mg.tiny_cfg(BF16, dim=512, n_heads=4, n_kv_heads=1, head_dim=128, ffn_dim=1024,
