@@ -244,6 +244,7 @@ struct mc_decoder {
     int gemv_block = 256;
     int gemv_wgs_per_cu = 2;
     int dbg_variant = 0; // MC_GEMV_DBG=1 stream-only, 2 compute-only (tuning ablations)
+    bool gemv_m4 = true;   // MC_GEMV_M4=0: the exact int4 dot products on v_dot2c instead of the 4x4x4 MFMA
     bool gemma_fuse = true; // MC_GEMMA_UNFUSED=1: keep the post-norms as launches of their own
     bool pn_ready = false;
 
@@ -428,6 +429,7 @@ struct mc_decoder {
         const unsigned waves = gemv_block / 64;
         const unsigned cap = (unsigned)(dev->prop.multiProcessorCount * gemv_wgs_per_cu);
         if (L.fmt == MC_WFMT_I4 && tb == 2 && cfg.qmode == MC_QMODE_FAST) name += "_fast";
+        if (L.fmt == MC_WFMT_I4 && tb == 2 && cfg.qmode == MC_QMODE_EXACT && gemv_m4 && !dbg_variant) name += "_m4";
         if (L.fmt == MC_WFMT_I4 && tb == 2 && dbg_variant && ((pro == 1 && epi == 2) || (pro == 0 && epi == 0)))
             name += dbg_variant == 1 ? "_dbgstream" : "_dbgnoload";
         name += "_p" + std::to_string(pro) + "_e" + std::to_string(epi);
@@ -884,6 +886,7 @@ mc_decoder_create(mc_device* dev, mc_library* lib, mc_queue* q, const mc_decoder
     if (const char* e = getenv("MC_GEMV_WGS_PER_CU")) d->gemv_wgs_per_cu = atoi(e);
     if (const char* e = getenv("MC_GEMV_DBG")) d->dbg_variant = atoi(e);
     if (const char* e = getenv("MC_GEMMA_UNFUSED")) d->gemma_fuse = atoi(e) == 0;
+    if (const char* e = getenv("MC_GEMV_M4")) d->gemv_m4 = atoi(e) != 0;
     if (d->gemv_block % 64 || d->gemv_block < 64 || d->gemv_block > 512) d->gemv_block = 256;
     if (d->gemv_wgs_per_cu < 1) d->gemv_wgs_per_cu = 2;
 

@@ -32,6 +32,7 @@ using namespace mc::gemv;
 
 MC_GEMV_SET(mc_gemv_i4_bfloat, WF_I4, BF, Q_EXACT)
 MC_GEMV_SET(mc_gemv_i4_bfloat_fast, WF_I4, BF, Q_FAST)
+MC_GEMV_SET(mc_gemv_i4_bfloat_m4, WF_I4, BF, Q_M4)
 MC_GEMV_SET(mc_gemv_i4_float, WF_I4, F32, Q_EXACT)
 MC_GEMV_SET(mc_gemv_i8_bfloat, WF_I8, BF, Q_EXACT)
 MC_GEMV_SET(mc_gemv_i8_float, WF_I8, F32, Q_EXACT)
