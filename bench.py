@@ -81,8 +81,9 @@ def dec_kernel_name(args):
     """Host name of the dominant kernel for this configuration (gemv_kernels.hip)."""
     fmt = {4: "i4", 8: "i8", 16: "w"}[args.wbits]
     t = "bfloat" if args.dtype == "bf16" else "float"
-    fast = "_fast" if (args.qmode == "fast" and args.wbits == 4 and args.dtype == "bf16") else ""
-    return f"mc_gemv_{fmt}_{t}{fast}_p1_e2"
+    i4bf = args.wbits == 4 and args.dtype == "bf16"
+    variant = ("_fast" if args.qmode == "fast" else "_m4") if i4bf else ""   # decoder.cc gemv(): name selection
+    return f"mc_gemv_{fmt}_{t}{variant}_p1_e2"
 
 
 def pmc_traffic(kernel):
