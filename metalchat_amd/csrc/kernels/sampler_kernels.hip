@@ -8,7 +8,8 @@
 //   gt_T / le_T     kernel/logical.metal:13-68      (bool = one byte)
 //   scatter_T       kernel/copy.metal:45-74
 //   gather_T        kernel/copy.metal:77-113        (T = bfloat, float, int32_t)
-//   sub_T           kernel/arithmetic.metal:88-121
+//   sub_T / div_T   kernel/arithmetic.metal:88-157
+//   sum_T           kernel/sum.metal:22-74          (launch: include/metalchat/kernel/sum.h:88-117)
 //
 // Part B -- mc_topk_candidates_T + mc_sample_T: make_default_sampler (nn/sampling.h:303-313,
 // topk(50) -> nucleus(0.6, 0.9) -> multinomial(1)) fused into two launches on the decode stream,
@@ -43,6 +44,51 @@ extern "C" __global__ void
 sub_float(layout2 ol, float* out, layout2 al, const float* a, layout2 bl, const float* b)
 {
     sub_body<F32>(ol, out, al, a, bl, b);
+}
+
+template <typename T>
+__device__ __forceinline__ void
+div_body(const layout2& ol, typename T::S* out, const layout2& al, const typename T::S* a,
+         const layout2& bl, const typename T::S* b)
+{
+    MC_IJ;
+    if (i < al.sizes[0] && k < al.sizes[1])
+        out[at(ol, i, k)] = T::st(T::ld(a[at(al, i, k)]) / T::ld(b[at(bl, i, k)]));
+}
+extern "C" __global__ void
+div_bfloat(layout2 ol, bf16_t* out, layout2 al, const bf16_t* a, layout2 bl, const bf16_t* b)
+{
+    div_body<BF>(ol, out, al, a, bl, b);
+}
+extern "C" __global__ void
+div_float(layout2 ol, float* out, layout2 al, const float* a, layout2 bl, const float* b)
+{
+    div_body<F32>(ol, out, al, a, bl, b);
+}
+
+// sum of every row in fp32, one workgroup per row, thread t adds its contiguous slice of
+// `block` elements, then the two-level wavefront reduction (kernel/sum.metal:37-70)
+template <typename T>
+__device__ __forceinline__ void
+sum_body(const layout1& ol, typename T::S* out, const layout2& il, const typename T::S* in, uint32_t block)
+{
+    __shared__ float red[16];
+    const uint32_t dim = il.sizes[1], i = blockIdx.x;
+    const uint32_t begin = threadIdx.x * block, end = begin + block;
+    float s = 0.0f;
+    for (uint32_t j = begin; j < end && j < dim; j++) s += T::ld(in[at(il, i, j)]);
+    const float tot = block_sum(s, red);
+    if (threadIdx.x == 0) out[at(ol, i)] = T::st(tot);
+}
+extern "C" __global__ void
+sum_bfloat(layout1 ol, bf16_t* out, layout2 il, const bf16_t* in, uint32_t block)
+{
+    sum_body<BF>(ol, out, il, in, block);
+}
+extern "C" __global__ void
+sum_float(layout1 ol, float* out, layout2 il, const float* in, uint32_t block)
+{
+    sum_body<F32>(ol, out, il, in, block);
 }
 
 #define MC_LOGICAL(NAME, OP)                                                                     \

@@ -433,6 +433,37 @@ mco_sub(int dt, const uint32_t* ol, void* out, const uint32_t* al, const void* a
             st(dt, out, at2(ol, i, k), ld(dt, a, at2(al, i, k)) - ld(dt, b, at2(bl, i, k)));
 }
 
+/* div (kernel/arithmetic.metal:124-157) evaluated in T */
+void
+mco_div(int dt, const uint32_t* ol, void* out, const uint32_t* al, const void* a,
+        const uint32_t* bl, const void* b)
+{
+    for (uint32_t i = 0; i < al[0]; i++)
+        for (uint32_t k = 0; k < al[1]; k++)
+            st(dt, out, at2(ol, i, k), ld(dt, a, at2(al, i, k)) / ld(dt, b, at2(bl, i, k)));
+}
+
+/* sum (kernel/sum.metal:22-74, launch include/metalchat/kernel/sum.h:88-117): per-thread slices of
+ * block = ceil(dim / max_threads) elements, then the two-level 32-lane reduction, fp32, stored as T.
+ * Pinned by test/test_kernel_sum.cc:43-64 (within 0.01 of the sequential sum). */
+void
+mco_sum(int dt, const uint32_t* ol, void* out, const uint32_t* il, const void* in, uint32_t max_threads)
+{
+    const uint32_t rows = il[0], dim = il[1];
+    const uint32_t block = ceil_div_u32(dim, max_threads);
+    const uint32_t nthreads = ceil_div_u32(dim, block);
+    float* partial = (float*)malloc(sizeof(float) * nthreads);
+    for (uint32_t i = 0; i < rows; i++) {
+        for (uint32_t t = 0; t < nthreads; t++) {
+            float s = 0.0f;
+            for (uint32_t j = t * block; j < (t + 1) * block && j < dim; j++) s += ld(dt, in, at2(il, i, j));
+            partial[t] = s;
+        }
+        st(dt, out, at1(ol, i), threadgroup_sum(partial, nthreads));
+    }
+    free(partial);
+}
+
 /* gt / le (kernel/logical.metal:13-68): bool = one byte, compare in T */
 void
 mco_gt(int dt, const uint32_t* ol, uint8_t* out, const uint32_t* il, const void* in, float value)

@@ -88,6 +88,9 @@ void mco_gelu(int dt, const uint32_t* out_l, void* out, const uint32_t* in_l, co
 /* ---- sampler chain (include/metalchat/nn/sampling.h:152-315 and the kernels it launches) ---- */
 void mco_sub(int dt, const uint32_t* out_l, void* out, const uint32_t* a_l, const void* a,
              const uint32_t* b_l, const void* b);
+void mco_div(int dt, const uint32_t* out_l, void* out, const uint32_t* a_l, const void* a,
+             const uint32_t* b_l, const void* b);
+void mco_sum(int dt, const uint32_t* out_l, void* out, const uint32_t* in_l, const void* in, uint32_t max_threads);
 void mco_gt(int dt, const uint32_t* out_l, uint8_t* out, const uint32_t* in_l, const void* in, float value);
 void mco_le(int dt, const uint32_t* out_l, uint8_t* out, const uint32_t* in_l, const void* in, float value);
 void mco_scatter(int dt, const uint32_t* out_l, void* out, const uint32_t* mask_l, const uint8_t* mask, float value);

@@ -177,6 +177,14 @@ def sub(dt, out_l, out, a_l, a, b_l, b):
     lib().mco_sub(dt, _l(out_l), _p(out), _l(a_l), _p(a), _l(b_l), _p(b))
 
 
+def div(dt, out_l, out, a_l, a, b_l, b):
+    lib().mco_div(dt, _l(out_l), _p(out), _l(a_l), _p(a), _l(b_l), _p(b))
+
+
+def row_sum(dt, out_l, out, in_l, inp, max_threads=1024):
+    lib().mco_sum(dt, _l(out_l), _p(out), _l(in_l), _p(inp), C.c_uint32(max_threads))
+
+
 def gt(dt, out_l, out, in_l, inp, value):
     lib().mco_gt(dt, _l(out_l), _p(out), _l(in_l), _p(inp), C.c_float(value))
 

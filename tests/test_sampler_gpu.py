@@ -166,6 +166,47 @@ def test_logical_scatter_gather_sub_exact(acc, dt):
         assert np.array_equal(g, np.take_along_axis(src, index, axis=1))
 
 
+@pytest.mark.parametrize("dt", [F32, BF16])
+def test_div_and_row_sum(acc, dt):
+    # div: kernel/arithmetic.metal:124-157; sum: test/test_kernel_sum.cc:43-64 ([4, 64, 4098] rows,
+    # within 0.01 of the sequential float sum) -- and both bit-exact against the oracle
+    import metalchat_amd as mc
+
+    rng = np.random.default_rng(4)
+    shp = (5, 300)
+    a = mo.encode(dt, rng.uniform(0.5, 2.0, shp).astype(np.float32))
+    b = mo.encode(dt, rng.uniform(0.5, 2.0, shp).astype(np.float32))
+    k = acc.load(f"div_{TN[dt]}")
+    grid, thread = mc.make_kernel_grid_2d(*shp, k.max_threads_per_threadgroup())
+    out = acc.alloc(a.size * a.itemsize)
+    mc.KernelTask(k, grid, thread, [L(shp), out, L(shp), acc.to_device(a), L(shp), acc.to_device(b)])()
+    acc.wait()
+    ref = np.zeros_like(a)
+    mo.div(dt, mo.layout(shp), ref, mo.layout(shp), a, mo.layout(shp), b)
+    parity.exact(out.download(a.dtype, a.size).reshape(shp), ref, "div")
+    rows, dim = 4 * 64, 4098
+    x = mo.encode(dt, rng.uniform(size=(rows, dim)).astype(np.float32))
+    k = acc.load(f"sum_{TN[dt]}")
+    block = -(-dim // k.max_threads_per_threadgroup())
+    threads = -(-dim // block)
+    so = acc.alloc(rows * x.itemsize)
+    mc.KernelTask(k, (threads * rows, 1, 1), (threads, 1, 1), [L((rows,)), so, L(x.shape), acc.to_device(x), np.uint32(block)])()
+    acc.wait()
+    got = so.download(x.dtype, rows)
+    if dt == F32:
+        seq = np.zeros(rows, np.float32)
+        for r in range(rows):
+            acc_ = np.float32(0)
+            for v in x[r]:
+                acc_ = np.float32(acc_ + v)
+            seq[r] = acc_
+        assert np.all(np.abs(got - seq) <= 0.01)
+    ref = np.zeros(rows, x.dtype)
+    mo.row_sum(dt, mo.layout((rows,)), ref, mo.layout(x.shape), x)
+    # fp32 summation order differs (64-lane shuffle tree vs the oracle's 32-lane butterfly)
+    parity.check(dt, got, ref, rel=1e-5 if dt == F32 else 1e-2, max_ulp=1, max_frac=0.1, scale_aware=False, what="sum")
+
+
 # ------------------------------------------------------------------------------------------ fused
 SP = np.dtype([("k", np.uint32), ("ncand", np.uint32), ("ncand_pad", np.uint32), ("inv_temp", np.float32),
                ("top_p", np.float32)])
