@@ -278,7 +278,7 @@ mc_status mc_decoder_weight_ptrs(mc_decoder* d, int32_t layer, const char* name,
                                  int32_t* ngroups);
 
 /* Host-side helpers shared by tests and the synthetic initialiser. */
-/* value in [-8,7] (bits = 4) or [-128,127] (bits = 8) of element (row, col) of matrix `matrix_id` */
+/* value in [-7,7] (bits = 4) or [-127,127] (bits = 8), zero mean, of element (row, col) of matrix `matrix_id` */
 int32_t mc_synth_weight(uint64_t seed, uint32_t matrix_id, uint32_t row, uint32_t col, int32_t bits);
 /* scale of (row, group) : U(0.5,1.5) / (sqrt(in) * 2^(bits-1)) as float */
 float mc_synth_scale(uint64_t seed, uint32_t matrix_id, uint32_t row, uint32_t group,
