@@ -273,3 +273,41 @@ def test_end_to_end_against_the_oracle_at_full_width(acc, name):
         d.release()
     om.close()
     om2.close()
+
+
+def test_int8_long_context_against_the_oracle_at_full_width(acc):
+    # BASELINE configs[2] territory: int8-held weights, a long context.  One Llama-3-8B-wide block,
+    # max_seq_len 4096 (so P.V runs in ranges of cache slots + the reduce launch), a 600-token prompt
+    # through the prompt pass (128 x 128 MFMA GEMMs on int8 weights, split-K) and decode steps behind
+    # it -- all against the oracle on the regenerated weights.
+    import metalchat_amd as mc
+    import modelgen as mg
+
+    cfg = dict(dtype=BF16, n_layers=1, vocab=2048, max_seq_len=4096, norm_eps=1e-5, **FULL_WIDTH["llama3-8b"])
+    weights = synth_model(cfg, SEED, bits=8)
+    om = mo.Model(cfg, weights)
+    dec = mc.Decoder(acc, **mg.decoder_kwargs(cfg, weight_format=mc.WFMT_I8, group_size=128))
+    dec.init_synthetic(SEED)
+    n = 600
+    ptoks = np.random.default_rng(4).integers(0, cfg["vocab"], n)
+    otok, ologits = om.forward(ptoks, 0, 0)
+    gtok = dec.prefill(ptoks, 0)
+    # 600 rows feed each other through attention: measured 0.006 vector-wise and up to 2.5 scaled bf16
+    # steps on single logits (0.005 / 2.05 at 100 rows)
+    parity.check(BF16, dec.logits(), ologits, rel=7.8e-3, max_ulp=3, max_frac=0.9, what="int8 prompt logits")
+    gk, gv = dec.export_kv(0)
+    ok, ov = om.kv(0)
+    assert gk.shape == ok.shape == (n, 8, 128)
+    # K / V rows of the first block depend on their own row only: a handful of last-bit differences
+    parity.check(BF16, gk, ok, rel=1e-3, max_ulp=1, max_frac=0.02, what="int8 prompt K")
+    parity.check(BF16, gv, ov, rel=1e-3, max_ulp=1, max_frac=0.02, what="int8 prompt V")
+    tok, agree = otok, int(gtok == otok)
+    for i in range(4):
+        o2, ol2 = om.step(tok, n + i)
+        g2 = dec.step(tok, n + i)
+        parity.check(BF16, dec.logits(), ol2, rel=7.8e-3, max_ulp=3, max_frac=0.9, what=f"int8 decode at context {n + i}")
+        agree += int(g2 == o2)
+        tok = o2
+    assert agree >= 4
+    dec.release()
+    om.close()
