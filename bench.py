@@ -82,7 +82,7 @@ def dec_kernel_name(args):
     fmt = {4: "i4", 8: "i8", 16: "w"}[args.wbits]
     t = "bfloat" if args.dtype == "bf16" else "float"
     i4bf = args.wbits == 4 and args.dtype == "bf16"
-    variant = ("_fast" if args.qmode == "fast" else "_m4") if i4bf else ""   # decoder.cc gemv(): name selection
+    variant = ("_fast" if args.qmode == "fast" else "_m4d") if i4bf else ""   # decoder.cc gemv(): name selection
     return f"mc_gemv_{fmt}_{t}{variant}_p1_e2"
 
 

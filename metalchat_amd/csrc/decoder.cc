@@ -244,7 +244,7 @@ struct mc_decoder {
     int gemv_block = 256;
     int gemv_wgs_per_cu = 2;
     int dbg_variant = 0; // MC_GEMV_DBG=1 stream-only, 2 compute-only (tuning ablations)
-    bool gemv_m4 = true;   // MC_GEMV_M4=0: the exact int4 dot products on v_dot2c instead of the 4x4x4 MFMA
+    int gemv_m4 = 2;       // MC_GEMV_M4: 0 = exact int4 on the VALU (v_dot2c), 1 = dot products on the 4x4x4 MFMA, 2 = dequantisation too
     bool gemma_fuse = true; // MC_GEMMA_UNFUSED=1: keep the post-norms as launches of their own
     bool pn_ready = false;
 
@@ -429,7 +429,11 @@ struct mc_decoder {
         const unsigned waves = gemv_block / 64;
         const unsigned cap = (unsigned)(dev->prop.multiProcessorCount * gemv_wgs_per_cu);
         if (L.fmt == MC_WFMT_I4 && tb == 2 && cfg.qmode == MC_QMODE_FAST) name += "_fast";
-        if (L.fmt == MC_WFMT_I4 && tb == 2 && cfg.qmode == MC_QMODE_EXACT && gemv_m4 && !dbg_variant) name += "_m4";
+        // exact int4 on bfloat rows: dot products on the 4x4x4 MFMA (_m4); with scale groups that are
+        // whole 128-weight lane blocks the dequantisation goes there too (_m4d, gemv.h Q_M4D)
+        const bool m4 = L.fmt == MC_WFMT_I4 && tb == 2 && cfg.qmode == MC_QMODE_EXACT && gemv_m4 && !dbg_variant;
+        const bool m4d = m4 && gemv_m4 >= 2 && (L.group == 0 || L.group % 128 == 0) && L.in % 128 == 0;
+        if (m4) name += m4d ? "_m4d" : "_m4";
         if (L.fmt == MC_WFMT_I4 && tb == 2 && dbg_variant && ((pro == 1 && epi == 2) || (pro == 0 && epi == 0)))
             name += dbg_variant == 1 ? "_dbgstream" : "_dbgnoload";
         name += "_p" + std::to_string(pro) + "_e" + std::to_string(epi);
@@ -444,7 +448,9 @@ struct mc_decoder {
         // LDS: activation row zero-padded to whole chunks (64 lanes x 16 B of packed weights) + scratch
         const unsigned kpl = L.fmt == MC_WFMT_I4 ? 32 : (L.fmt == MC_WFMT_I8 ? 16 : (tb == 2 ? 8 : 4));
         const unsigned chunk = 64 * kpl;
-        const unsigned lds = (unsigned)((size_t)((L.in + chunk - 1) / chunk) * chunk * tb + 64);
+        unsigned lds = (unsigned)((size_t)((L.in + chunk - 1) / chunk) * chunk * tb);
+        if (m4d) lds = lds / 16 * 17; // 16 bytes of padding per 256 for the transposed reads
+        lds += 64;
         if (L.lora_cols) {
             // a = T(A x): the stacked adaptor inputs through the same kernel family (same prologue,
             // so a pre-norm GEMV and its adaptor see the identical normalised row)
@@ -886,7 +892,7 @@ mc_decoder_create(mc_device* dev, mc_library* lib, mc_queue* q, const mc_decoder
     if (const char* e = getenv("MC_GEMV_WGS_PER_CU")) d->gemv_wgs_per_cu = atoi(e);
     if (const char* e = getenv("MC_GEMV_DBG")) d->dbg_variant = atoi(e);
     if (const char* e = getenv("MC_GEMMA_UNFUSED")) d->gemma_fuse = atoi(e) == 0;
-    if (const char* e = getenv("MC_GEMV_M4")) d->gemv_m4 = atoi(e) != 0;
+    if (const char* e = getenv("MC_GEMV_M4")) d->gemv_m4 = atoi(e);
     if (d->gemv_block % 64 || d->gemv_block < 64 || d->gemv_block > 512) d->gemv_block = 256;
     if (d->gemv_wgs_per_cu < 1) d->gemv_wgs_per_cu = 2;
 

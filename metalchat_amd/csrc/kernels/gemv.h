@@ -33,7 +33,9 @@ namespace gemv {
 
 enum { WF_T = 0, WF_I8 = 1, WF_I4 = 2 };
 enum { Q_EXACT = 0, Q_FAST = 1, Q_DBG_STREAM = 2, Q_DBG_NOLOAD = 3, Q_DBG_TL = 4, // 2..4: tuning aids
-       Q_M4 = 5 }; // exact, the dot products of a lane on v_mfma_f32_4x4x4_16b_bf16 (int4, bfloat)
+       Q_M4 = 5,   // exact, the dot products of a lane on v_mfma_f32_4x4x4_16b_bf16 (int4, bfloat)
+       Q_M4D = 6,  // Q_M4 with the dequantisation itself on the same instruction (group % 128 == 0)
+       Q_DBG_TL4D = 7 }; // Q_M4D with the per-wave time stamps of Q_DBG_TL
 enum { PRO_NONE = 0, PRO_RMSNORM = 1, PRO_POSTNORM = 2 };
 
 // PRO_POSTNORM (gemma3 blocks, include/metalchat/nn/transformer.h:132-139): the row handed to the
@@ -275,6 +277,52 @@ mac4(mf_f4& acc, const uint4& w, float s, const xregs<BF, 32>& x)
     }
 }
 
+// Q_M4D: the DEQUANTISATION on the matrix pipe as well.  (v >> 4p) & 0x000F000F | 0x43004300 is the
+// bf16 pair (128 + n[2p], 128 + n[2p+1]) -- two instructions per two weights instead of the
+// cvt / cvt / fma / fma of the VALU path.  A first 4x4x4 MFMA with those four values as the lane's A
+// row, B = T(s) on the lane's own k (lane j of a block: s at k = j, zero elsewhere) and C = -136 s
+// returns (128 + n) s - 136 s = (n - 8) s: every term and the result fit 17 bits, so the fp32
+// multiply-add is exact whatever the order, and v_cvt_pk_bf16_f32 then applies the reference's one
+// rounding, Wd = T(q * T(s)) (kernel/mul.metal:78-82), bit for bit as the VALU path does.
+// The price is a transposition: element e of lane j's result is weight j of lane 4b + e (the A ROW
+// came from that lane), so lane j ends up with weights (8d + 4m + j) of the four lanes of its
+// block.  Nothing moves back: the four lanes of a block share a scale group (32 weights each, groups
+// of >= 128) and a dot product does not care who sums what -- the lane just needs the matching
+// activations x[128 b + 32 e + 8 d + 4 m + j], e = 0..3, which is exactly the 4 x 16 transposed
+// gather ds_read_b64_tr_b16 performs (cdna_hip_programming.md T10) from the natural row in LDS.
+// Measured (tools/ubench, operands in registers, 4 waves per SIMD): 0.625 x the cycles of mac4.
+struct m4d_scale {
+    uint2 b;  // B operand of the dequant MFMA
+    mf_f4 c;  // C operand: -136 s in all four elements
+};
+__device__ __forceinline__ m4d_scale
+m4d_prepare(uint32_t sbits, uint32_t mask_x, uint32_t mask_y) // sbits: T(s) in both halves
+{
+    m4d_scale r;
+    r.b = make_uint2(sbits & mask_x, sbits & mask_y);
+    const float c = -136.0f * asf(sbits & 0xFFFF0000u);
+    r.c = mf_f4{c, c, c, c};
+    return r;
+}
+__device__ __forceinline__ void
+mac4d(mf_f4& acc, const uint4& w, const m4d_scale& sc, const uint2 (&x)[8])
+{
+    const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
+    const mf_s4 bs = __builtin_bit_cast(mf_s4, sc.b);
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        const uint32_t v = ws[d];
+        const uint32_t t0 = (v & 0x000F000Fu) | 0x43004300u, t1 = ((v >> 4) & 0x000F000Fu) | 0x43004300u;
+        const uint32_t t2 = ((v >> 8) & 0x000F000Fu) | 0x43004300u, t3 = ((v >> 12) & 0x000F000Fu) | 0x43004300u;
+        const mf_f4 d1 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(mf_s4, make_uint2(t0, t1)), bs, sc.c, 0, 0, 0);
+        const mf_f4 d2 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(mf_s4, make_uint2(t2, t3)), bs, sc.c, 0, 0, 0);
+        const uint2 a0 = make_uint2(pack_bf16x2(d1[0], d1[1]), pack_bf16x2(d1[2], d1[3]));
+        const uint2 a1 = make_uint2(pack_bf16x2(d2[0], d2[1]), pack_bf16x2(d2[2], d2[3]));
+        acc = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(mf_s4, a0), __builtin_bit_cast(mf_s4, x[2 * d]), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(mf_s4, a1), __builtin_bit_cast(mf_s4, x[2 * d + 1]), acc, 0, 0, 0);
+    }
+}
+
 // (The same substitution on int8-held and plain bfloat weights changes nothing -- 984 vs 988 and 390
 // vs 392 tokens/s: those kernels wait for memory, not for the VALU -- so only int4 takes it.)
 // I4, T = float: Wd = fl(float(q) * s), the reference's float(q) * float(s)
@@ -406,11 +454,19 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
     constexpr uint32_t CHUNK_BYTES = 64 * 16;    // = 1 KiB of packed weights
     static_assert(R == 4, "tiles are four rows deep (scale quads, paired epilogues)");
 
+    constexpr bool M4 = (QM == Q_M4 || QM == Q_M4D || QM == Q_DBG_TL4D) && WF == WF_I4 && T::bytes == 2;
+    constexpr bool M4D = (QM == Q_M4D || QM == Q_DBG_TL4D) && M4;
+    constexpr bool TL = QM == Q_DBG_TL || QM == Q_DBG_TL4D;
+    // Q_M4D reads the row with ds_read_b64_tr_b16, four lanes of a block 256 bytes apart: 16 bytes of
+    // padding behind every 256 spread them over the banks (packet p sits in slot p + p / 16)
+    constexpr uint32_t CHUNK_LDS = M4D ? CHUNK * T::bytes / 16 * 17 : CHUNK * T::bytes;
+    auto xpk = [](uint32_t p) { return M4D ? p + (p >> 4) : p; };
+
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const uint32_t nchunks = (in + CHUNK - 1) / CHUNK;
     // LDS: the activation row, zero-padded to a whole number of chunks, then 16 floats of scratch
     char* xs = smem;
-    float* red = reinterpret_cast<float*>(smem + (size_t)nchunks * CHUNK * T::bytes);
+    float* red = reinterpret_cast<float*>(smem + (size_t)nchunks * CHUNK_LDS);
 
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     // Everything that is the same for the 64 lanes of a wavefront is kept in SGPRs: the wave index
@@ -428,8 +484,9 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
     const char* wbase = static_cast<const char*>(wp);
     const uint32_t lane16 = lane * 16;
 
-    unsigned long long tl0 = 0, tl1 = 0;
-    if (QM == Q_DBG_TL) tl0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long tl0 = 0, tl1 = 0, tlt[4] = {0, 0, 0, 0}; // start, prologue done, end of tiles 0..3
+    uint32_t tln = 0;
+    if (TL) tl0 = __builtin_amdgcn_s_memrealtime();
 #ifndef MC_GEMV_RING
 #define MC_GEMV_RING 3
 #endif
@@ -611,7 +668,7 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
                 if (tid + i * bd >= npk) xr[i] = make_uint4(0, 0, 0, 0); // absent packets count as zero
         }
         // zero padding behind the row
-        for (uint32_t p = npk + tid; p < npk_pad; p += bd) xl[p] = make_uint4(0, 0, 0, 0);
+        for (uint32_t p = npk + tid; p < npk_pad; p += bd) xl[xpk(p)] = make_uint4(0, 0, 0, 0);
 
         auto sumsq = [&](const uint4& v) {
             const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
@@ -686,7 +743,7 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
 #pragma unroll
             for (int i = 0; i < MAXP; i++) {
                 const uint32_t p = tid + i * bd;
-                if (p < npk) xl[p] = normalise(xr[i], nr[i], inv2);
+                if (p < npk) xl[xpk(p)] = normalise(xr[i], nr[i], inv2);
             }
         } else if (fits) {
             if (PRO == PRO_RMSNORM) {
@@ -703,13 +760,13 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
 #pragma unroll
                 for (int i = 0; i < MAXP; i++) {
                     const uint32_t p = tid + i * bd;
-                    if (p < npk) xl[p] = normalise(xr[i], nr[i], inv);
+                    if (p < npk) xl[xpk(p)] = normalise(xr[i], nr[i], inv);
                 }
             } else {
 #pragma unroll
                 for (int i = 0; i < MAXP; i++) {
                     const uint32_t p = tid + i * bd;
-                    if (p < npk) xl[p] = xr[i];
+                    if (p < npk) xl[xpk(p)] = xr[i];
                 }
             }
         } else {
@@ -719,14 +776,14 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
                 float ss = 0.0f;
                 for (uint32_t p = tid; p < npk; p += bd) {
                     const uint4 v = xg[p];
-                    xl[p] = v;
+                    xl[xpk(p)] = v;
                     ss += sumsq(v);
                 }
                 const float tot = block_sum(ss, red);
                 const float inv = 1.0f / sqrtf(tot / (float)in + eps);
-                for (uint32_t p = tid; p < npk; p += bd) xl[p] = normalise(xl[p], ng[p], inv);
+                for (uint32_t p = tid; p < npk; p += bd) xl[xpk(p)] = normalise(xl[xpk(p)], ng[p], inv);
             } else {
-                for (uint32_t p = tid; p < npk; p += bd) xl[p] = xg[p];
+                for (uint32_t p = tid; p < npk; p += bd) xl[xpk(p)] = xg[p];
             }
         }
     };
@@ -753,7 +810,7 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
             if (MC_GEMV_PRE > sl) { load(ring[sl], ld.rg, ld.c, (uint32_t)sl < ntiles); advance(ld); }
     });
     __syncthreads();
-    if (QM == Q_DBG_TL) tl1 = __builtin_amdgcn_s_memrealtime();
+    if (TL) tl1 = __builtin_amdgcn_s_memrealtime();
 #pragma unroll
     for (int sl = 1; sl < RING; sl++)
         if (MC_GEMV_PRE <= sl) { load(ring[sl], ld.rg, ld.c, (uint32_t)sl < ntiles); advance(ld); }
@@ -766,9 +823,26 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
         accv[r] = mf_f4{0, 0, 0, 0};
     }
     const uint32_t lane_x = lane * KPL * T::bytes; // byte offset of the lane's x slice in a chunk
+    // Q_M4D: lane 16g + 4q + p supplies row q of the transposed gather = 32-weight run q of block
+    // 4g + p; and lane j of a block carries T(s) on k = j of the dequant MFMA's B operand
+    const uint32_t lane_tr = (((lane >> 4) * 4 + (lane & 3)) * 17 + ((lane >> 2) & 3) * 4) * 16;
+    const uint32_t m4d_mx = (lane & 3) == 0 ? 0x0000FFFFu : ((lane & 3) == 1 ? 0xFFFF0000u : 0u);
+    const uint32_t m4d_my = (lane & 3) == 2 ? 0x0000FFFFu : ((lane & 3) == 3 ? 0xFFFF0000u : 0u);
 
     auto compute = [&](const tile<R>& t, uint32_t crg, uint32_t cc) {
-        {
+        if constexpr (M4D) {
+            typedef __attribute__((address_space(3))) mf_s4 lds_s4;
+            lds_s4* xt = (lds_s4*)(xs + cc * CHUNK_LDS + lane_tr);
+            uint2 x[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) x[i] = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16(xt + i));
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const uint32_t raw = t.s[r >> 1];
+                const uint32_t s2 = (r & 1) ? ((raw & 0xFFFF0000u) | (raw >> 16)) : ((raw << 16) | (raw & 0xFFFFu));
+                mac4d(accv[r], t.w[r], m4d_prepare(s2, m4d_mx, m4d_my), x);
+            }
+        } else {
             xregs<T, KPL> x;
             x.load(xs + (size_t)cc * CHUNK * T::bytes + lane_x, 0);
             float xsum = 0.0f;
@@ -782,17 +856,17 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
                 const float sc = WF == WF_T ? 1.0f
                                  : (T::bytes == 2 ? ((r & 1) ? asf(t.s[r >> 1] & 0xFFFF0000u) : asf(t.s[r >> 1] << 16))
                                                   : asf(t.s[r]));
-                if constexpr (QM == Q_M4 && WF == WF_I4 && T::bytes == 2)
+                if constexpr (M4)
                     mac4(accv[r], t.w[r], sc, x);
                 else
-                    mac<QM == Q_M4 ? Q_EXACT : QM>(acc[r], t.w[r], sc, x, xsum, static_cast<F*>(nullptr));
+                    mac<QM == Q_M4 || QM == Q_M4D || QM == Q_DBG_TL4D ? Q_EXACT : QM>(acc[r], t.w[r], sc, x, xsum, static_cast<F*>(nullptr));
             }
         }
         if (cc + 1 == nchunks) {
             float tot[R];
 #pragma unroll
             for (int r = 0; r < R; r++) {
-                if constexpr (QM == Q_M4 && WF == WF_I4 && T::bytes == 2) {
+                if constexpr (M4) {
                     // element lane % 4 of the lane's four results is its own dot product
                     const uint32_t e = lane & 3;
                     const float mine = e == 0 ? accv[r][0] : (e == 1 ? accv[r][1] : (e == 2 ? accv[r][2] : accv[r][3]));
@@ -826,14 +900,22 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
 #pragma unroll
         for (int sl = 0; sl < RING; sl++) {
             if (sl == 0 || i + sl < ntiles) { compute(ring[sl], cp.rg, cp.c); advance(cp); }
+            if (TL) {
+                __builtin_amdgcn_sched_barrier(0);
+                const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+                __builtin_amdgcn_sched_barrier(0);
+                if (tln < 4) tlt[tln] = now; // scalar selects: tln is wave-uniform
+                tln++;
+            }
             load(ring[sl], ld.rg, ld.c, i + sl + RING < ntiles); advance(ld);
         }
     }
-    if (QM == Q_DBG_TL && lane == 0) {
+    if (TL && lane == 0) {
         // (epilogues of this variant never read `resp`: it carries the stamp buffer)
         unsigned long long* tl = const_cast<unsigned long long*>(static_cast<const unsigned long long*>(resp));
-        const size_t o = ((size_t)blockIdx.x * nwaves + wave) * 4;
+        const size_t o = ((size_t)blockIdx.x * nwaves + wave) * 8;
         tl[o] = tl0; tl[o + 1] = tl1; tl[o + 2] = __builtin_amdgcn_s_memrealtime();
+        tl[o + 4] = tlt[0]; tl[o + 5] = tlt[1]; tl[o + 6] = tlt[2]; tl[o + 7] = tlt[3];
         unsigned xcc, hwid;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));

@@ -33,6 +33,7 @@ using namespace mc::gemv;
 MC_GEMV_SET(mc_gemv_i4_bfloat, WF_I4, BF, Q_EXACT)
 MC_GEMV_SET(mc_gemv_i4_bfloat_fast, WF_I4, BF, Q_FAST)
 MC_GEMV_SET(mc_gemv_i4_bfloat_m4, WF_I4, BF, Q_M4)
+MC_GEMV_SET(mc_gemv_i4_bfloat_m4d, WF_I4, BF, Q_M4D)
 MC_GEMV_SET(mc_gemv_i4_float, WF_I4, F32, Q_EXACT)
 MC_GEMV_SET(mc_gemv_i8_bfloat, WF_I8, BF, Q_EXACT)
 MC_GEMV_SET(mc_gemv_i8_float, WF_I8, F32, Q_EXACT)
@@ -47,3 +48,5 @@ MC_GEMV(mc_gemv_i4_bfloat_dbgnoload_p0_e0, WF_I4, BF, Q_DBG_NOLOAD, 0, 0)
 MC_GEMV(mc_gemv_i4_bfloat_dbgtl_p1_e2, WF_I4, BF, Q_DBG_TL, 1, 2)
 MC_GEMV(mc_gemv_i4_bfloat_dbgtl_p0_e0, WF_I4, BF, Q_DBG_TL, 0, 0)
 MC_GEMV(mc_gemv_i4_bfloat_dbgtl_p1_e0, WF_I4, BF, Q_DBG_TL, 1, 0)
+MC_GEMV(mc_gemv_i4_bfloat_dbgtl4d_p1_e2, WF_I4, BF, Q_DBG_TL4D, 1, 2)
+MC_GEMV(mc_gemv_i4_bfloat_dbgtl4d_p0_e0, WF_I4, BF, Q_DBG_TL4D, 0, 0)

@@ -80,7 +80,7 @@ def test_dominant_gemvs_on_sampled_rows_at_full_size(acc):
     mo.hadamard(BF16, L(ref.shape), ref, L(ref.shape), act, L(ref.shape), b.reshape(1, -1))
     wptr, sptr, rows, inf, ng = dec.weight_ptrs(0, "w13")
     assert (rows, inf) == (2 * ffn, dim)
-    got = run_gemv(acc, "mc_gemv_i4_bfloat_m4_p1_e2", wptr, sptr, x, ffn, rows, inf, 128, BF16, norm=nw, wgs=512)
+    got = run_gemv(acc, "mc_gemv_i4_bfloat_m4d_p1_e2", wptr, sptr, x, ffn, rows, inf, 128, BF16, norm=nw, wgs=512)
     parity.check(BF16, got[js], ref.reshape(-1), rel=2e-3, max_ulp=1, max_frac=0.2, scale_aware=False, what="w1|w3 rows")
     # ---- w2 with the residual epilogue (K = 14336: seven chunks per row)
     g = mo.encode(BF16, rng.normal(0, 0.5, ffn).astype(np.float32))
@@ -91,7 +91,7 @@ def test_dominant_gemvs_on_sampled_rows_at_full_size(acc):
     ref2 = np.zeros((1, len(rs)), np.uint16)
     mo.add(BF16, L(ref2.shape), ref2, L(ref2.shape), res[rs].reshape(1, -1), L(ref2.shape), y2.reshape(1, -1))
     wptr, sptr, rows, inf, ng = dec.weight_ptrs(0, "w2")
-    got2 = run_gemv(acc, "mc_gemv_i4_bfloat_m4_p0_e1", wptr, sptr, g, dim, rows, inf, 128, BF16, res=res, wgs=256)
+    got2 = run_gemv(acc, "mc_gemv_i4_bfloat_m4d_p0_e1", wptr, sptr, g, dim, rows, inf, 128, BF16, res=res, wgs=256)
     parity.check(BF16, got2[rs], ref2.reshape(-1), rel=2e-3, max_ulp=1, max_frac=0.3, scale_aware=False, what="w2 rows")
     # ---- output head: 128256 rows, final norm prologue
     fw = norm_weights(0xFFFF0002, dim)
@@ -100,7 +100,7 @@ def test_dominant_gemvs_on_sampled_rows_at_full_size(acc):
     qh, sh = synth_rows(0xFFFF0001, vs, dim)
     refh = oracle_rows(qh, sh, xn.reshape(-1))
     wptr, sptr, rows, inf, ng = dec.weight_ptrs(-1, "output")
-    goth = run_gemv(acc, "mc_gemv_i4_bfloat_m4_p1_e0", wptr, sptr, x, M["vocab"], rows, inf, 128, BF16, norm=fw, wgs=512)
+    goth = run_gemv(acc, "mc_gemv_i4_bfloat_m4d_p1_e0", wptr, sptr, x, M["vocab"], rows, inf, 128, BF16, norm=fw, wgs=512)
     parity.check(BF16, goth[vs], refh, rel=2e-3, max_ulp=1, max_frac=0.2, scale_aware=False, what="head rows")
     dec.release()
 

@@ -36,9 +36,9 @@ def oracle_linear(dt, spec, x_T):
     return y.reshape(-1)
 
 
-def gemv_name(fmt, dt, pro, epi, fast=False):
+def gemv_name(fmt, dt, pro, epi, fast=False, variant=""):
     return "mc_gemv_" + {0: "w", 1: "i8", 2: "i4"}[fmt] + "_" + ("bfloat" if dt == BF16 else "float") + \
-        ("_fast" if fast else "") + f"_p{pro}_e{epi}"
+        ("_fast" if fast else "") + variant + f"_p{pro}_e{epi}"
 
 
 def run_gemv(acc, name, wptr, sptr, x_T, out_n, rows, in_f, group, dt, res=None, norm=None,
@@ -55,7 +55,10 @@ def run_gemv(acc, name, wptr, sptr, x_T, out_n, rows, in_f, group, dt, res=None,
     nb = acc.to_device(norm) if norm is not None else None
     kpl = {0: 8 if dt == BF16 else 4, 1: 16, 2: 32}[{"w": 0, "i8": 1, "i4": 2}[name.split("_")[2]]]
     chunk = 64 * kpl
-    lds = (in_f + chunk - 1) // chunk * chunk * tb + 64
+    lds = (in_f + chunk - 1) // chunk * chunk * tb
+    if "_m4d_" in name:
+        lds = lds // 16 * 17  # the row is padded by 16 bytes per 256 for the transposed reads
+    lds += 64
     t = mc.KernelTask(k, (wgs * block, 1, 1), (block, 1, 1),
                       [wbuf, sbuf, xb, yb, rb, nb, np.uint32(rows), np.uint32(in_f), np.uint32(group),
                        np.float32(eps), np.float32(mu)] +
@@ -217,6 +220,40 @@ def test_gemv_lora_adaptation_term(acc, holder, dt):
     # rank 0 = no adaptor: the plain result
     plain = run_gemv(acc, gemv_name(fmt, dt, 0, 0), wptr, sptr, x, out_f, out_f, in_f, 32, dt)
     assert not np.array_equal(plain, got)
+
+
+@pytest.mark.parametrize("group", [128, 256])
+def test_gemv_matrix_pipe_dequant_is_exact_for_every_weight(acc, holder, group):
+    """Q_M4D dequantises on v_mfma_f32_4x4x4_16b_bf16 and gathers the activations through
+    ds_read_b64_tr_b16.  A one-hot row x = e_k makes y[o] = Wd[o, k], so every position of the
+    128-weight blocks, in whole and in ragged chunks, is compared BIT FOR BIT with the oracle's
+    T(T(q) * T(s)) -- and a wrong gather would pick the wrong column."""
+    cfg, w, dec, fmt = holder(BF16, "i4", group, dim=2304, ffn=4096, seed=33)
+    lw = w["layers"][0]
+    for name, key in (("w2", "w2"), ("wo", "wo")):
+        spec = lw[key]
+        out_f, in_f = spec["weight"].shape
+        wptr, sptr, rows, inf, ng = dec.weight_ptrs(0, name)
+        ks = sorted(set(list(range(0, 128)) + list(range(in_f - 128, in_f)) + list(range(2048 - 64, min(in_f, 2048 + 64))) +
+                        list(range(128 * 5, 128 * 6, 3))))
+        ks = [k for k in ks if 0 <= k < in_f]
+        for k in ks:
+            xf = np.zeros(in_f, np.float32)
+            xf[k] = 1.0
+            x = mo.encode(BF16, xf)
+            got = run_gemv(acc, gemv_name(fmt, BF16, 0, 0, variant="_m4d"), wptr, sptr, x, out_f, out_f, in_f, group, BF16)
+            ref = oracle_linear(BF16, spec, x)
+            assert np.array_equal(got, ref), f"{name} column {k}: {np.flatnonzero(got != ref)[:8]}"
+    # and an ordinary row: same answer as the VALU dequantisation up to the fp32 summation order
+    rng = np.random.default_rng(9)
+    spec = lw["w2"]
+    out_f, in_f = spec["weight"].shape
+    x = mo.encode(BF16, rng.normal(0, 1, in_f).astype(np.float32))
+    wptr, sptr, rows, inf, ng = dec.weight_ptrs(0, "w2")
+    got = run_gemv(acc, gemv_name(fmt, BF16, 0, 0, variant="_m4d"), wptr, sptr, x, out_f, out_f, in_f, group, BF16)
+    r = parity.check(BF16, got, oracle_linear(BF16, spec, x), rel=1e-3, max_ulp=1, max_frac=0.01, scale_aware=False,
+                     what="w2 m4d")
+    assert r["frac"] <= 0.01
 
 
 def test_gemv_geometry_independent(acc, holder):

@@ -14,7 +14,7 @@ acc = mc.HardwareAccelerator(path=out)
 cus = acc.compute_units()
 buf = acc.alloc(4 * 1024 * 1024 * 4)
 iters = 20000
-for name in (() if os.environ.get("STREAM_ONLY") else ("ub_fma", "ub_andor2", "ub_pkfma", "ub_mul")):
+for name in (() if os.environ.get("STREAM_ONLY") else ("ub_fma", "ub_mfma4", "ub_deq_cur", "ub_deq_new")):
     k = acc.load(name)
     for waves_per_simd in (1, 2, 4):
         threads = 256 * waves_per_simd  # 4 SIMDs x waves
@@ -28,6 +28,8 @@ for name in (() if os.environ.get("STREAM_ONLY") else ("ub_fma", "ub_andor2", "u
         winst = iters * 16 * waves_per_simd  # per SIMD
         print(json.dumps(dict(kernel=name, waves_per_simd=waves_per_simd, ms=round(ms, 3),
                               wave_inst_per_us_per_simd=round(winst / (ms * 1e3), 1))), flush=True)
+if os.environ.get("VALU_ONLY"):
+    sys.exit(0)
 # streaming read ceiling
 n = 2 * 1024 ** 3
 big = acc.alloc(n)
