@@ -510,7 +510,10 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
         for (int r = 0; r < R; r++) {
             uint32_t row = rg_l * R + r;
             row = row < out_rows ? row : out_rows - 1;
-            if (QM == Q_DBG_NOLOAD) {
+#ifndef MC_GEMV_FORCE_NOLOAD
+#define MC_GEMV_FORCE_NOLOAD 0 // tuning ablation (tools/variants): every kernel of the family computes on synthesised tiles
+#endif
+            if (QM == Q_DBG_NOLOAD || MC_GEMV_FORCE_NOLOAD) {
                 t.w[r] = make_uint4(lane * 0x01010101u + off, rg, c * 0x11111111u, r);
                 t.s[r] = T::bytes == 2 ? 0x3F803F80u : 0x3F800000u;
             } else {
@@ -529,7 +532,7 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
                 }
             }
         }
-        if (WF != WF_T && QM != Q_DBG_NOLOAD) {
+        if (WF != WF_T && QM != Q_DBG_NOLOAD && !MC_GEMV_FORCE_NOLOAD) {
             // weight index of the lane's packet -> group; scales are stored in row quads
             const uint32_t k = (cbyte + off) * (8 / F::BITS == 0 ? 1 : 8 / F::BITS);
             const uint32_t g = live ? (group ? k >> glog : 0u) : 0u;

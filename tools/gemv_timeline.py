@@ -19,7 +19,7 @@ nw = acc.to_device(np.full(14336, 0x3F80, np.uint16))
 y = acc.alloc(2 * 28672)
 for which, kname in (("w13", "mc_gemv_i4_bfloat_dbgtl_p1_e2"), ("w13", "mc_gemv_i4_bfloat_dbgtl4d_p1_e2"),
                      ("w2", "mc_gemv_i4_bfloat_dbgtl_p0_e0"), ("w2", "mc_gemv_i4_bfloat_dbgtl4d_p0_e0")):
-    for block, wgs_per_cu in ((256, 4),):
+    for block, wgs_per_cu in ((256, 2), (256, 4)):
         k = acc.load(kname)
         waves = block // 64
         for layer in (1, 2):
@@ -58,7 +58,10 @@ for which, kname in (("w13", "mc_gemv_i4_bfloat_dbgtl_p1_e2"), ("w13", "mc_gemv_
         hist = collections.Counter(per_cu.values())
         end_by_n = {n: round(float(np.mean([end.reshape(wgs, waves)[i].max() for i in range(wgs) if per_cu[wg_cu[i]] == n])), 2) for n in hist}
         end_by_xcd = {int(x): round(float(np.percentile(end[xcc == x], 90)), 2) for x in sorted(set(xcc.tolist()))}
-        print(json.dumps(dict(which=which, kernel=kname.split("_")[4], block=block, wgs=wgs, event_us=round(ms * 1e3, 2),
+        by_xcd = {int(x): dict(start=round(float(np.median(start[xcc == x])), 2), pro=round(float(np.median(pro[xcc == x])), 2),
+                               end50=round(float(np.median(end[xcc == x])), 2), end100=round(float(end[xcc == x].max()), 2),
+                               waves=int((xcc == x).sum())) for x in sorted(set(xcc.tolist()))}
+        print(json.dumps(dict(which=which, kernel=kname.split("_")[4], by_xcd=by_xcd, block=block, wgs=wgs, event_us=round(ms * 1e3, 2),
                               tile_end_us=tile_end, tile_gap_us=gaps,
                               start_us=q(start), prologue_us=q(pro), body_us=q(body), end_us=q(end),
                               cus_used=len(per_cu), wgs_per_cu_hist=dict(hist), wg_end_by_wgs_on_cu=end_by_n,
