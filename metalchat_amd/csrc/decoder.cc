@@ -244,7 +244,7 @@ struct mc_decoder {
     int gemv_block = 256;
     int gemv_wgs_per_cu = 2;
     int dbg_variant = 0; // MC_GEMV_DBG=1 stream-only, 2 compute-only (tuning ablations)
-    int gemv_m4 = 2;       // MC_GEMV_M4: 0 = exact int4 on the VALU (v_dot2c), 1 = dot products on the 4x4x4 MFMA, 2 = dequantisation too
+    int gemv_m4 = 2;       // MC_GEMV_M4: 0 = exact int4 on the VALU (v_dot2c), 1 = dot products on the 4x4x4 MFMA, 2 = dequantisation too where a SIMD holds > 1 wave, 3 = always
     bool gemma_fuse = true; // MC_GEMMA_UNFUSED=1: keep the post-norms as launches of their own
     bool pn_ready = false;
 
@@ -429,14 +429,6 @@ struct mc_decoder {
         const unsigned waves = gemv_block / 64;
         const unsigned cap = (unsigned)(dev->prop.multiProcessorCount * gemv_wgs_per_cu);
         if (L.fmt == MC_WFMT_I4 && tb == 2 && cfg.qmode == MC_QMODE_FAST) name += "_fast";
-        // exact int4 on bfloat rows: dot products on the 4x4x4 MFMA (_m4); with scale groups that are
-        // whole 128-weight lane blocks the dequantisation goes there too (_m4d, gemv.h Q_M4D)
-        const bool m4 = L.fmt == MC_WFMT_I4 && tb == 2 && cfg.qmode == MC_QMODE_EXACT && gemv_m4 && !dbg_variant;
-        const bool m4d = m4 && gemv_m4 >= 2 && (L.group == 0 || L.group % 128 == 0) && L.in % 128 == 0;
-        if (m4) name += m4d ? "_m4d" : "_m4";
-        if (L.fmt == MC_WFMT_I4 && tb == 2 && dbg_variant && ((pro == 1 && epi == 2) || (pro == 0 && epi == 0)))
-            name += dbg_variant == 1 ? "_dbgstream" : "_dbgnoload";
-        name += "_p" + std::to_string(pro) + "_e" + std::to_string(epi);
         // Grid: one workgroup per four row groups, capped at gemv_wgs_per_cu workgroups per CU (a
         // whole multiple of the CU count: what has to balance is the work per CU -- its SIMDs
         // time-share their waves -- so 3.5 row groups per wave on every CU beats an even 4 per
@@ -445,6 +437,19 @@ struct mc_decoder {
         unsigned wgs = (ng + waves - 1) / waves;
         if (wgs > cap) wgs = cap;
         if (wgs == 0) wgs = 1;
+        // exact int4 on bfloat rows: dot products on the 4x4x4 MFMA (_m4); with scale groups that are
+        // whole 128-weight lane blocks the dequantisation goes there too (_m4d, gemv.h Q_M4D) -- when
+        // a SIMD holds more than one wave of the launch: the MFMA -> cvt_pk -> MFMA chain of a weight
+        // is longer than the VALU one and a lone wave per SIMD (Wo, w2: 1024 row groups) has nobody
+        // to hide it behind (8.2 vs 8.5 us per launch, profiles/r01_kernel_stats.csv).
+        const bool m4 = L.fmt == MC_WFMT_I4 && tb == 2 && cfg.qmode == MC_QMODE_EXACT && gemv_m4 && !dbg_variant;
+        const bool m4d_ok = m4 && (L.group == 0 || L.group % 128 == 0) && L.in % 128 == 0;
+        const bool shared_simd = wgs * waves > 4u * (unsigned)dev->prop.multiProcessorCount;
+        const bool m4d = m4d_ok && (gemv_m4 >= 3 || (gemv_m4 == 2 && shared_simd));
+        if (m4) name += m4d ? "_m4d" : "_m4";
+        if (L.fmt == MC_WFMT_I4 && tb == 2 && dbg_variant && ((pro == 1 && epi == 2) || (pro == 0 && epi == 0)))
+            name += dbg_variant == 1 ? "_dbgstream" : "_dbgnoload";
+        name += "_p" + std::to_string(pro) + "_e" + std::to_string(epi);
         // LDS: activation row zero-padded to whole chunks (64 lanes x 16 B of packed weights) + scratch
         const unsigned kpl = L.fmt == MC_WFMT_I4 ? 32 : (L.fmt == MC_WFMT_I8 ? 16 : (tb == 2 ? 8 : 4));
         const unsigned chunk = 64 * kpl;
