@@ -356,6 +356,110 @@ mc_status mc_config_from_document(const mc_document* d, mc_decoder_config* cfg);
 mc_status mc_decoder_load_document(mc_decoder* d, const mc_document* doc, int32_t flavour);
 mc_status mc_decoder_get_config(const mc_decoder* d, mc_decoder_config* out);
 
+/* ================================================================================================
+ * Part 4 -- text in, text out: the callers either side of the token loop.
+ *
+ *   text::gpt2_codec                include/metalchat/text/gpt.h, src/gpt.cc:20-100
+ *   text::byte_pair_encoder<char>   include/metalchat/text/bpe.h:82-345 (tiktoken token map)
+ *   text::regexp / regexp_iterator  include/metalchat/text/regexp.h:24-92, src/regexp.cc:34-178 (PCRE2)
+ *   reference::llama3_tokenizer_loader   include/metalchat/reference.h:117-165, src/reference.cc:76-127
+ *   huggingface llama3_tokenizer_loader  src/llama.cc:81-112 (tokenizer.json)
+ *   token scanners, interpreter     include/metalchat/interpreter.h:60-175,296-374, src/interpreter.cc:84-136
+ *
+ * Host code, no GPU work of its own; the interpreter drives mc_decoder_prefill / mc_decoder_step.
+ * The reference's behaviour is kept where it is peculiar, because token ids are the contract:
+ *   - the split pattern is compiled by PCRE2 with NO options (src/regexp.cc:38-41): the subject is
+ *     bytes, \p{L} / \p{N} see Latin-1 code points, \s is the C-locale set;
+ *   - a piece is cut at the PREVIOUS match end with the length of the new match (src/regexp.cc:146-155);
+ *   - a piece that is not a token is merged by visiting segments in rank order and joining a segment
+ *     with its right neighbour whenever the concatenation is a token; the LAST byte of the piece never
+ *     gets a segment of its own and is dropped unless a merge absorbs it (bpe.h:120-168);
+ *   - gpt2_codec::decode keeps the low byte of a code point that is not in its table (src/gpt.cc:92-96).
+ * One deviation: a pattern that matches the empty string makes the reference loop forever; here it
+ * is MC_ERR_RUNTIME "regexp_iterator: empty match".
+ * The regular expressions run on the system's libpcre2-8.so.0 (the engine the reference links),
+ * opened at first use; without it mc_tokenizer_* fail with MC_ERR_RUNTIME.
+ * ============================================================================================== */
+typedef struct mc_tokenizer mc_tokenizer;
+typedef struct mc_interpreter mc_interpreter;
+
+/* text::token kinds -- include/metalchat/text/tokenizer.h:27-38 */
+enum {
+    MC_TOKEN_REGULAR = 1 << 0,
+    MC_TOKEN_BEGIN_TEXT = 1 << 1,
+    MC_TOKEN_END_TEXT = 1 << 2,
+    MC_TOKEN_RESERVED = 1 << 3,
+    MC_TOKEN_FINETUNE_RIGHT_PAD = 1 << 4,
+    MC_TOKEN_BEGIN_HEADER = 1 << 5,
+    MC_TOKEN_END_HEADER = 1 << 6,
+    MC_TOKEN_END_MESSAGE = 1 << 7,
+    MC_TOKEN_END_TURN = 1 << 8,
+    MC_TOKEN_IPYTHON = 1 << 9
+};
+
+/* Output convention of the byte / id producers below: up to `cap` elements are written, *n always
+ * receives the full count (call again with a larger buffer when *n > cap). */
+
+/* gpt2_codec::encode / decode: bytes <-> the printable code points of GPT-2's byte alphabet, UTF-8.
+ * decode of malformed UTF-8 or of a code point above U+FFFF: MC_ERR_RUNTIME (std::range_error in the
+ * reference's std::wstring_convert). */
+mc_status mc_gpt2_encode(const char* bytes, size_t len, char* out, size_t cap, size_t* n);
+mc_status mc_gpt2_decode(const char* utf8, size_t len, char* out, size_t cap, size_t* n);
+
+/* The split pattern on its own (text::regexp::begin .. end): piece i occupies
+ * [offsets[2i], offsets[2i+1]) of the subject, cut the way the reference's iterator cuts it. */
+mc_status mc_regexp_split(const char* pattern, const char* subject, size_t len, size_t* offsets,
+                          size_t cap_pairs, size_t* n_pairs);
+
+/* byte_pair_encoder(token_regex): an empty encoder.  token_regex == NULL: the llama3 pattern
+ * (reference::llama3_tokenizer_loader::default_regex). */
+mc_status mc_tokenizer_create(const char* token_regex, mc_tokenizer** out);
+/* reference::llama3_tokenizer_loader::load(path[, regex]): "base64 rank" lines (tiktoken), then the
+ * eleven llama3 control tokens at the ids that follow (128000 .. 128010 for the published model). */
+mc_status mc_tokenizer_open_tiktoken(const char* path, const char* token_regex, mc_tokenizer** out);
+/* huggingface llama3_tokenizer_loader::load(path): tokenizer.json -- the Split pattern of the
+ * pre_tokenizer Sequence, model.vocab with GPT-2-coded keys, then the same control tokens. */
+mc_status mc_tokenizer_open_hf(const char* tokenizer_json_path, mc_tokenizer** out);
+void mc_tokenizer_release(mc_tokenizer* t);
+mc_status mc_tokenizer_insert(mc_tokenizer* t, const char* bytes, size_t len, int32_t id, int32_t kind);
+mc_status mc_tokenizer_insert_back(mc_tokenizer* t, const char* bytes, size_t len, int32_t kind);
+size_t mc_tokenizer_size(const mc_tokenizer* t);
+/* encode(string): split, look every piece up, merge the ones that are not tokens. */
+mc_status mc_tokenizer_encode(const mc_tokenizer* t, const char* text, size_t len, int32_t* ids,
+                              size_t cap, size_t* n);
+/* encode(tokenkind): MC_ERR_INVALID_ARGUMENT "byte_pair_encoder: unknown control token '<kind>'" */
+mc_status mc_tokenizer_encode_control(const mc_tokenizer* t, int32_t kind, int32_t* id);
+/* decode(id): MC_ERR_RUNTIME "byte_pair_encoder: unable to decode id '<id>'" */
+mc_status mc_tokenizer_decode(const mc_tokenizer* t, const int32_t* ids, size_t n_ids, char* out,
+                              size_t cap, size_t* n);
+
+/* interpreter(transformer, tokenizer): the buffer starts with begin_text, the scanner is
+ * limit_token_scanner(50), start_pos 0.  The decoder must own every layer (single stage); its sampler
+ * is whatever mc_decoder_set_sampler selected.  Neither handle is owned.  d == NULL gives an interpreter
+ * that frames messages (write / pending) but cannot read. */
+mc_status mc_interpreter_create(mc_decoder* d, const mc_tokenizer* t, mc_interpreter** out);
+void mc_interpreter_release(mc_interpreter* it);
+/* set_token_scanner(composite_token_scanner<Op>{limit_token_scanner(limit), match_token_scanner(stop_ids)}):
+ * generation continues while op(limit.scan(tok), match.scan(tok)) holds -- op_and != 0:
+ * std::logical_and (stop at a stop id OR at the limit, the reference's test set-up), 0: std::logical_or.
+ * limit == 0: no limit scanner; n_stop == 0: no match scanner; neither: the empty composite, which
+ * stops at once (interpreter.h:148-152). */
+mc_status mc_interpreter_set_scanner(mc_interpreter* it, size_t limit, const int32_t* stop_ids,
+                                     size_t n_stop, int32_t op_and);
+/* declare_variable: "{{ name }}" in later message contents is replaced by value (the reference
+ * renders contents with mustache; sections, commands and tool dispatch are not provided). */
+mc_status mc_interpreter_declare_variable(mc_interpreter* it, const char* name, const char* value);
+/* write(basic_message(role, content)): header, content, end_turn appended to the token buffer. */
+mc_status mc_interpreter_write(mc_interpreter* it, const char* role, const char* content);
+/* read(): assistant header, flush the buffer through the prompt pass, then one token per step until
+ * the scanner says stop; the decoded text goes to out, the ids (optionally) to ids.  sliding_window
+ * as for mc_decoder_prefill. */
+mc_status mc_interpreter_read(mc_interpreter* it, int32_t sliding_window, char* out, size_t cap, size_t* n,
+                              int32_t* ids, size_t ids_cap, size_t* n_ids);
+size_t mc_interpreter_start_pos(const mc_interpreter* it);
+/* the token buffer that the next read() will flush (for tests) */
+mc_status mc_interpreter_pending(const mc_interpreter* it, int32_t* ids, size_t cap, size_t* n);
+
 #ifdef __cplusplus
 }
 #endif

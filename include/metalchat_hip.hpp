@@ -423,5 +423,155 @@ load_options(const std::string& json_text, int32_t flavour, const safetensor_doc
     return cfg;
 }
 
+// ------------------------------------------------------------------------------------------ text (Part 4)
+namespace text {
+
+/// text::gpt2_codec (include/metalchat/text/gpt.h)
+struct gpt2_codec {
+    std::string
+    encode(const std::string& input) const
+    {
+        std::size_t n = 0;
+        check(mc_gpt2_encode(input.data(), input.size(), nullptr, 0, &n));
+        std::string out(n, '\0');
+        check(mc_gpt2_encode(input.data(), input.size(), out.data(), out.size(), &n));
+        return out;
+    }
+
+    std::string
+    decode(const std::string& input) const
+    {
+        std::size_t n = 0;
+        check(mc_gpt2_decode(input.data(), input.size(), nullptr, 0, &n));
+        std::string out(n, '\0');
+        check(mc_gpt2_decode(input.data(), input.size(), out.data(), out.size(), &n));
+        return out;
+    }
+};
+
+/// text::byte_pair_encoder<char> (include/metalchat/text/bpe.h:82-345) with the two llama3 loaders as
+/// named constructors (reference::llama3_tokenizer_loader, huggingface llama3_tokenizer_loader).
+class byte_pair_encoder {
+    std::shared_ptr<mc_tokenizer> _M_tok;
+
+    explicit byte_pair_encoder(mc_tokenizer* t) : _M_tok(t, mc_tokenizer_release) {}
+
+public:
+    using index_type = int32_t;
+
+    explicit byte_pair_encoder(const std::string& token_regex)
+    {
+        mc_tokenizer* t = nullptr;
+        check(mc_tokenizer_create(token_regex.c_str(), &t)); // invalid_argument: "regexp: invalid regular expression: ..."
+        _M_tok.reset(t, mc_tokenizer_release);
+    }
+
+    static byte_pair_encoder
+    load_tiktoken(const std::string& path, const char* token_regex = nullptr)
+    {
+        mc_tokenizer* t = nullptr;
+        check(mc_tokenizer_open_tiktoken(path.c_str(), token_regex, &t));
+        return byte_pair_encoder(t);
+    }
+
+    static byte_pair_encoder
+    load_huggingface(const std::string& tokenizer_json)
+    {
+        mc_tokenizer* t = nullptr;
+        check(mc_tokenizer_open_hf(tokenizer_json.c_str(), &t));
+        return byte_pair_encoder(t);
+    }
+
+    void insert(const std::string& value, index_type key, int32_t kind = MC_TOKEN_REGULAR) { check(mc_tokenizer_insert(_M_tok.get(), value.data(), value.size(), key, kind)); }
+    void insert_back(const std::string& value, int32_t kind = MC_TOKEN_REGULAR) { check(mc_tokenizer_insert_back(_M_tok.get(), value.data(), value.size(), kind)); }
+    std::size_t size() const { return mc_tokenizer_size(_M_tok.get()); }
+
+    std::vector<index_type>
+    encode(const std::string& s) const
+    {
+        std::size_t n = 0;
+        check(mc_tokenizer_encode(_M_tok.get(), s.data(), s.size(), nullptr, 0, &n));
+        std::vector<index_type> ids(n);
+        check(mc_tokenizer_encode(_M_tok.get(), s.data(), s.size(), ids.data(), ids.size(), &n));
+        return ids;
+    }
+
+    index_type
+    encode(int32_t kind) const
+    {
+        index_type id = 0;
+        check(mc_tokenizer_encode_control(_M_tok.get(), kind, &id)); // invalid_argument: unknown control token
+        return id;
+    }
+
+    std::string
+    decode(const index_type* first, const index_type* last) const
+    {
+        std::size_t n = 0;
+        check(mc_tokenizer_decode(_M_tok.get(), first, (std::size_t)(last - first), nullptr, 0, &n)); // runtime_error: unable to decode id
+        std::string out(n, '\0');
+        check(mc_tokenizer_decode(_M_tok.get(), first, (std::size_t)(last - first), out.data(), out.size(), &n));
+        return out;
+    }
+
+    std::string decode(index_type id) const { return decode(&id, &id + 1); }
+
+    mc_tokenizer* get() const { return _M_tok.get(); }
+};
+
+using bpe = byte_pair_encoder;
+
+} // namespace text
+
+/// basic_message (include/metalchat/interpreter.h:26-58)
+class basic_message {
+    std::string _M_role, _M_content;
+
+public:
+    basic_message(const std::string& role, const std::string& content = "") : _M_role(role), _M_content(content) {}
+    const std::string& role() const { return _M_role; }
+    const std::string& content() const { return _M_content; }
+};
+
+/// metalchat::interpreter (include/metalchat/interpreter.h:180-374) over an mc_decoder and a
+/// byte_pair_encoder: write() frames messages, read() runs the prompt pass and the token loop.
+class interpreter {
+    std::shared_ptr<mc_interpreter> _M_it;
+    text::byte_pair_encoder _M_tok;
+    int32_t _M_window;
+
+public:
+    interpreter(mc_decoder* decoder, const text::byte_pair_encoder& tokenizer, int32_t sliding_window = 0)
+    : _M_tok(tokenizer),
+      _M_window(sliding_window)
+    {
+        mc_interpreter* it = nullptr;
+        check(mc_interpreter_create(decoder, tokenizer.get(), &it));
+        _M_it.reset(it, mc_interpreter_release);
+    }
+
+    /// composite_token_scanner<Op>{limit_token_scanner(limit), match_token_scanner(stop)}
+    void
+    set_token_scanner(std::size_t limit, const std::vector<int32_t>& stop, bool logical_and = true)
+    {
+        check(mc_interpreter_set_scanner(_M_it.get(), limit, stop.data(), stop.size(), logical_and ? 1 : 0));
+    }
+
+    void declare_variable(const std::string& name, const std::string& value) { check(mc_interpreter_declare_variable(_M_it.get(), name.c_str(), value.c_str())); }
+    void write(const basic_message& m) { check(mc_interpreter_write(_M_it.get(), m.role().c_str(), m.content().c_str())); }
+
+    basic_message
+    read()
+    {
+        std::vector<char> buf(1 << 16);
+        std::size_t n = 0, nid = 0;
+        check(mc_interpreter_read(_M_it.get(), _M_window, buf.data(), buf.size(), &n, nullptr, 0, &nid));
+        return basic_message("assistant", std::string(buf.data(), n < buf.size() ? n : buf.size()));
+    }
+
+    std::string read_text() { return read().content(); }
+    std::size_t start_pos() const { return mc_interpreter_start_pos(_M_it.get()); }
+};
+
 } // namespace hip
 } // namespace metalchat

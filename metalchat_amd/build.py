@@ -21,7 +21,7 @@ SO = os.path.join(LIB, "libmetalchat_hip.so")
 KERNEL_SOURCES = [os.path.join(CSRC, "kernels", f) for f in (
     "metalchat_kernels.hip", "ref_kernels.hip", "gemv_kernels.hip", "decode_kernels.hip",
     "synth_kernels.hip", "sampler_kernels.hip", "prefill_kernels.hip", "common.h", "gemv.h", "synth.h")]
-HOST_SOURCES = [os.path.join(CSRC, f) for f in ("backend.cc", "decoder.cc", "model_io.cc", "json_min.h", "backend_impl.h")] + [
+HOST_SOURCES = [os.path.join(CSRC, f) for f in ("backend.cc", "decoder.cc", "model_io.cc", "text.cc", "json_min.h", "backend_impl.h")] + [
     os.path.join(CSRC, "kernels", "synth.h"),
     os.path.join(os.path.dirname(HERE), "include", "metalchat_hip.h")]
 
@@ -57,7 +57,7 @@ def build_host(force: bool = False) -> str:
     if force or _stale(SO, HOST_SOURCES):
         cmd = [hipcc(), "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function",
                os.path.join(CSRC, "backend.cc"), os.path.join(CSRC, "decoder.cc"),
-               os.path.join(CSRC, "model_io.cc"), "-o", SO]
+               os.path.join(CSRC, "model_io.cc"), os.path.join(CSRC, "text.cc"), "-ldl", "-o", SO]
         subprocess.check_call(cmd, cwd=CSRC)
     return SO
 
@@ -91,10 +91,25 @@ def build_model_io_test(force: bool = False) -> str:
     return out
 
 
+def build_text_test(force: bool = False) -> str:
+    """tests/cpp/test_text: host-only C++ test of the text / interpreter-framing classes of the shim."""
+    root = os.path.dirname(HERE)
+    src = os.path.join(root, "tests", "cpp", "test_text.cc")
+    out = os.path.join(root, "tests", "cpp", "test_text")
+    deps = [src, os.path.join(root, "include", "metalchat_hip.hpp"),
+            os.path.join(root, "include", "metalchat_hip.h"), SO]
+    if force or _stale(out, deps):
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-I" + os.path.join(root, "include"), src,
+                               "-o", out, "-L" + LIB, "-lmetalchat_hip",
+                               "-Wl,-rpath," + LIB, "-Wl,-rpath,/opt/rocm/lib", "-pthread"])
+    return out
+
+
 def build_all(force: bool = False):
     r = build_kernels(force), build_host(force)
     build_shim_test(force)
     build_model_io_test(force)
+    build_text_test(force)
     return r
 
 

@@ -146,6 +146,27 @@ def capi() -> C.CDLL:
         "mc_config_from_json": (i32, [C.c_char_p, i32, C.POINTER(DecoderConfig)]),
         "mc_config_from_document": (i32, [vp, C.POINTER(DecoderConfig)]),
         "mc_decoder_load_document": (i32, [vp, vp, i32]),
+        "mc_gpt2_encode": (i32, [C.c_char_p, sz, C.c_char_p, sz, C.POINTER(sz)]),
+        "mc_gpt2_decode": (i32, [C.c_char_p, sz, C.c_char_p, sz, C.POINTER(sz)]),
+        "mc_regexp_split": (i32, [C.c_char_p, C.c_char_p, sz, C.POINTER(sz), sz, C.POINTER(sz)]),
+        "mc_tokenizer_create": (i32, [C.c_char_p, pvp]),
+        "mc_tokenizer_open_tiktoken": (i32, [C.c_char_p, C.c_char_p, pvp]),
+        "mc_tokenizer_open_hf": (i32, [C.c_char_p, pvp]),
+        "mc_tokenizer_release": (None, [vp]),
+        "mc_tokenizer_insert": (i32, [vp, C.c_char_p, sz, i32, i32]),
+        "mc_tokenizer_insert_back": (i32, [vp, C.c_char_p, sz, i32]),
+        "mc_tokenizer_size": (sz, [vp]),
+        "mc_tokenizer_encode": (i32, [vp, C.c_char_p, sz, C.POINTER(i32), sz, C.POINTER(sz)]),
+        "mc_tokenizer_encode_control": (i32, [vp, i32, C.POINTER(i32)]),
+        "mc_tokenizer_decode": (i32, [vp, C.POINTER(i32), sz, C.c_char_p, sz, C.POINTER(sz)]),
+        "mc_interpreter_create": (i32, [vp, vp, pvp]),
+        "mc_interpreter_release": (None, [vp]),
+        "mc_interpreter_set_scanner": (i32, [vp, sz, C.POINTER(i32), sz, i32]),
+        "mc_interpreter_declare_variable": (i32, [vp, C.c_char_p, C.c_char_p]),
+        "mc_interpreter_write": (i32, [vp, C.c_char_p, C.c_char_p]),
+        "mc_interpreter_read": (i32, [vp, i32, C.c_char_p, sz, C.POINTER(sz), C.POINTER(i32), sz, C.POINTER(sz)]),
+        "mc_interpreter_start_pos": (sz, [vp]),
+        "mc_interpreter_pending": (i32, [vp, C.POINTER(i32), sz, C.POINTER(sz)]),
         "mc_synth_weight": (i32, [u64, u32, u32, u32, i32]),
         "mc_synth_scale": (f32, [u64, u32, u32, u32, i32, i32]),
         "mc_synth_value": (f32, [u64, u32, u32, i32, u32]),
@@ -606,3 +627,141 @@ class Decoder:
             self.release()
         except Exception:
             pass
+
+
+# ------------------------------------------------------------------------------------------ Part 4: text
+TOKEN_REGULAR, TOKEN_BEGIN_TEXT, TOKEN_END_TEXT, TOKEN_RESERVED, TOKEN_FINETUNE_RIGHT_PAD = 1, 2, 4, 8, 16
+TOKEN_BEGIN_HEADER, TOKEN_END_HEADER, TOKEN_END_MESSAGE, TOKEN_END_TURN, TOKEN_IPYTHON = 32, 64, 128, 256, 512
+
+
+def _bytes_call(fn, *args) -> bytes:
+    """Calls an ABI function whose last three arguments are (out, cap, n): sizes, then fills."""
+    n = C.c_size_t()
+    _check(fn(*args, None, 0, C.byref(n)))
+    buf = C.create_string_buffer(max(n.value, 1))
+    _check(fn(*args, buf, n.value, C.byref(n)))
+    return buf.raw[:n.value]
+
+
+def gpt2_encode(data: bytes) -> str:
+    """text::gpt2_codec::encode"""
+    return _bytes_call(capi().mc_gpt2_encode, data, len(data)).decode("utf-8")
+
+
+def gpt2_decode(text: str) -> bytes:
+    """text::gpt2_codec::decode"""
+    raw = text.encode("utf-8")
+    return _bytes_call(capi().mc_gpt2_decode, raw, len(raw))
+
+
+def regexp_split(pattern: bytes | None, subject: bytes) -> list[bytes]:
+    """text::regexp::begin .. end over `subject` (None: the llama3 pattern)."""
+    n = C.c_size_t()
+    _check(capi().mc_regexp_split(pattern, subject, len(subject), None, 0, C.byref(n)))
+    off = (C.c_size_t * max(2 * n.value, 1))()
+    _check(capi().mc_regexp_split(pattern, subject, len(subject), off, n.value, C.byref(n)))
+    return [subject[off[2 * i]:off[2 * i + 1]] for i in range(n.value)]
+
+
+class Tokenizer:
+    """text::byte_pair_encoder<char> (+ the llama3 loaders)."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    @classmethod
+    def create(cls, token_regex: bytes | None = None):
+        h = C.c_void_p()
+        _check(capi().mc_tokenizer_create(token_regex, C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def open_tiktoken(cls, path: str, token_regex: bytes | None = None):
+        h = C.c_void_p()
+        _check(capi().mc_tokenizer_open_tiktoken(path.encode(), token_regex, C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def open_hf(cls, path: str):
+        h = C.c_void_p()
+        _check(capi().mc_tokenizer_open_hf(path.encode(), C.byref(h)))
+        return cls(h)
+
+    def release(self):
+        if self._h:
+            capi().mc_tokenizer_release(self._h)
+            self._h = None
+
+    def insert(self, value: bytes, key: int, kind: int = TOKEN_REGULAR):
+        _check(capi().mc_tokenizer_insert(self._h, value, len(value), key, kind))
+
+    def insert_back(self, value: bytes, kind: int = TOKEN_REGULAR):
+        _check(capi().mc_tokenizer_insert_back(self._h, value, len(value), kind))
+
+    def __len__(self):
+        return capi().mc_tokenizer_size(self._h)
+
+    def encode(self, text: bytes | str) -> list[int]:
+        raw = text.encode("utf-8") if isinstance(text, str) else text
+        n = C.c_size_t()
+        _check(capi().mc_tokenizer_encode(self._h, raw, len(raw), None, 0, C.byref(n)))
+        ids = (C.c_int32 * max(n.value, 1))()
+        _check(capi().mc_tokenizer_encode(self._h, raw, len(raw), ids, n.value, C.byref(n)))
+        return list(ids[:n.value])
+
+    def encode_control(self, kind: int) -> int:
+        v = C.c_int32()
+        _check(capi().mc_tokenizer_encode_control(self._h, kind, C.byref(v)))
+        return v.value
+
+    def decode(self, ids) -> bytes:
+        ids = [ids] if isinstance(ids, int) else list(ids)
+        arr = (C.c_int32 * max(len(ids), 1))(*ids)
+        return _bytes_call(capi().mc_tokenizer_decode, self._h, arr, len(ids))
+
+
+class Interpreter:
+    """metalchat::interpreter over a Decoder and a Tokenizer (message framing + the read loop)."""
+
+    def __init__(self, dec: "Decoder | None", tok: Tokenizer):
+        self.dec, self.tok = dec, tok
+        h = C.c_void_p()
+        _check(capi().mc_interpreter_create(dec._h if dec is not None else None, tok._h, C.byref(h)))
+        self._h = h
+
+    def release(self):
+        if self._h:
+            capi().mc_interpreter_release(self._h)
+            self._h = None
+
+    def set_token_scanner(self, limit: int = 0, stop_ids=(), op_and: bool = True):
+        stop = list(stop_ids)
+        arr = (C.c_int32 * max(len(stop), 1))(*stop)
+        _check(capi().mc_interpreter_set_scanner(self._h, limit, arr, len(stop), 1 if op_and else 0))
+
+    def declare_variable(self, name: str, value: str):
+        _check(capi().mc_interpreter_declare_variable(self._h, name.encode(), value.encode()))
+
+    def write(self, role: str, content: str | bytes):
+        raw = content.encode("utf-8") if isinstance(content, str) else content
+        _check(capi().mc_interpreter_write(self._h, role.encode(), raw))
+
+    def read(self, sliding_window: int = 0, max_tokens: int = 4096):
+        """-> (text bytes, ids)"""
+        n, nid = C.c_size_t(), C.c_size_t()
+        buf = C.create_string_buffer(max_tokens * 64)
+        ids = (C.c_int32 * max_tokens)()
+        _check(capi().mc_interpreter_read(self._h, sliding_window, buf, len(buf), C.byref(n), ids, max_tokens,
+                                          C.byref(nid)))
+        return buf.raw[:min(n.value, len(buf))], list(ids[:min(nid.value, max_tokens)])
+
+    @property
+    def start_pos(self) -> int:
+        return capi().mc_interpreter_start_pos(self._h)
+
+    def pending(self) -> list[int]:
+        n = C.c_size_t()
+        _check(capi().mc_interpreter_pending(self._h, None, 0, C.byref(n)))
+        ids = (C.c_int32 * max(n.value, 1))()
+        _check(capi().mc_interpreter_pending(self._h, ids, n.value, C.byref(n)))
+        return list(ids[:n.value])

@@ -38,3 +38,14 @@ def test_cpp_model_io_host_only(tmp_path):
     r = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=60)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "model_io ok" in r.stdout
+
+
+def test_cpp_text_host_only(tmp_path):
+    # GPT-2 codec, byte-pair encoder, llama3 loader and message framing through the C++ shim; no GPU
+    from metalchat_amd import build
+
+    build.build_host()
+    exe = build.build_text_test()
+    r = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "text ok" in r.stdout
