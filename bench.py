@@ -175,6 +175,7 @@ def main():
         torch.cuda.set_device(local_rank)
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")  # torch.distributed.run sets both; --force-pipeline alone does not
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
 

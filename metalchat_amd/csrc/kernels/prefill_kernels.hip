@@ -329,6 +329,34 @@ MC_PF_GEMM(mc_pf_gemm_w_float_e1, PF_W_T, F32, 1)
 // of one row per chunk (X: copy; W: exact dequant of one 16-byte int4 packet).
 constexpr uint32_t PFB_M = 128, PFB_N = 128, PFB_K = 64, PFB_LD = PFB_K + 8;
 
+// Which output tile a workgroup takes.  Workgroups go to the 8 XCDs round-robin in launch order and
+// each XCD has its own 4 MiB L2: with the plain (x = column tile, y = row tile) order every XCD sees
+// every row tile of X, and X (16 MB at M = 2048, K = 4096) is re-read from beyond L2 once per column
+// tile.  Here XCD k owns ny / 8 row tiles (its slice of X stays in its L2) and walks all column tiles,
+// consecutive workgroups of an XCD sharing the W tile; with fewer than 8 row tiles the XCDs that
+// share one split the column tiles.  Any other grid keeps the plain order.
+#ifndef MC_PF_XCD_MAP
+#define MC_PF_XCD_MAP 1
+#endif
+__device__ __forceinline__ void
+pf_tile_of(uint32_t& nt, uint32_t& mt)
+{
+    const uint32_t nx = gridDim.x, ny = gridDim.y;
+    nt = blockIdx.x;
+    mt = blockIdx.y;
+    if (!MC_PF_XCD_MAP || (nx * ny) % 8u) return;
+    const uint32_t p = blockIdx.y * nx + blockIdx.x, k = p & 7u, j = p >> 3;
+    if (ny % 8u == 0) {
+        const uint32_t per = ny / 8u;
+        mt = k * per + j % per;
+        nt = j / per;
+    } else if (8u % ny == 0 && nx % (8u / ny) == 0) {
+        const uint32_t g = 8u / ny;
+        mt = k / g;
+        nt = j * g + k % g;
+    }
+}
+
 template <int WF, int EPI>
 __device__ __forceinline__ void
 pf_gemm_big_body(const void* __restrict__ wp, const void* __restrict__ sp, const bf16_t* __restrict__ X,
@@ -340,7 +368,9 @@ pf_gemm_big_body(const void* __restrict__ wp, const void* __restrict__ sp, const
     __shared__ __attribute__((aligned(16))) bf16_t Ws[PFB_N * PFB_LD];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t wm = wave >> 1, wn = wave & 1;
-    const uint32_t n0 = blockIdx.x * PFB_N, m0 = blockIdx.y * PFB_M;
+    uint32_t tile_n, tile_m;
+    pf_tile_of(tile_n, tile_m);
+    const uint32_t n0 = tile_n * PFB_N, m0 = tile_m * PFB_M;
     const uint32_t ngroups = group ? K / group : 1;
     const uint32_t glog = group ? 31u - __builtin_clz(group) : 31u;
     const size_t rowb = WF == PF_W_I4 ? K / 2 : (WF == PF_W_I8 ? K : (size_t)K * 2);

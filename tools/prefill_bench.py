@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import metalchat_amd as mc
 
 lens = [int(a) for a in sys.argv[1:]] or [128, 512, 2048]
-acc = mc.HardwareAccelerator()
+acc = mc.HardwareAccelerator(path=os.environ.get("MC_HSACO"))
 dec = mc.Decoder(acc, dtype=mc.BF16, dim=4096, n_heads=32, n_kv_heads=8, head_dim=128, ffn_dim=14336, n_layers=32,
                  vocab=128256, max_seq_len=2048, rope_theta=500000.0, norm_eps=1e-5, attn_scale=128 ** -0.5,
                  weight_format=mc.WFMT_I4, group_size=128)
