@@ -485,6 +485,7 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
     const uint32_t lane16 = lane * 16;
 
     unsigned long long tl0 = 0, tl1 = 0, tlt[4] = {0, 0, 0, 0}; // start, prologue done, end of tiles 0..3
+    unsigned long long tlx = 0, tlb = 0;                          // TL variants: row arrived, row sum known
     uint32_t tln = 0;
     if (TL) tl0 = __builtin_amdgcn_s_memrealtime();
 #ifndef MC_GEMV_RING
@@ -755,8 +756,14 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
                 for (int i = 0; i < MAXP; i++) ss += sumsq(xr[i]);
                 // DPP wave reduction, one LDS slot per wave, one barrier
                 const float wsum_ = wave_sum_dpp(ss);
+                if (TL) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    tlx = __builtin_amdgcn_s_memrealtime();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 if (lane == 0) red[wave] = wsum_;
                 __syncthreads();
+                if (TL) tlb = __builtin_amdgcn_s_memrealtime();
                 float tot = 0.0f;
                 for (uint32_t i = 0; i < nwaves; i++) tot += red[i];
                 const float inv = 1.0f / sqrtf(tot / (float)in + eps);
@@ -918,7 +925,8 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
         unsigned long long* tl = const_cast<unsigned long long*>(static_cast<const unsigned long long*>(resp));
         const size_t o = ((size_t)blockIdx.x * nwaves + wave) * 8;
         tl[o] = tl0; tl[o + 1] = tl1; tl[o + 2] = __builtin_amdgcn_s_memrealtime();
-        tl[o + 4] = tlt[0]; tl[o + 5] = tlt[1]; tl[o + 6] = tlt[2]; tl[o + 7] = tlt[3];
+        tl[o + 4] = tlt[0]; tl[o + 5] = tlt[1]; tl[o + 6] = tlt[2];
+        tl[o + 7] = PRO == PRO_RMSNORM ? ((tlx - tl0) << 32) | (tlb - tl0) : tlt[3]; // prologue detail instead of tile 3
         unsigned xcc, hwid;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
