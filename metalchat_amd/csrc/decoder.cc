@@ -700,6 +700,10 @@ struct mc_decoder {
         const bool big = tb == 2 && M > 64 && !getenv("MC_PF_SMALL_GEMM");
         const std::string f = L.fmt == MC_WFMT_I4 ? "i4_" : (L.fmt == MC_WFMT_I8 ? "i8_" : "w_");
         const void* la = L.lora_cols ? pf_lora : nullptr;
+        // two K chunks in flight per workgroup (prefill_kernels.hip: measured best at every length);
+        // MC_PF_DEPTH=1 selects the one-chunk build for A/B runs
+        const char* depth_env = getenv("MC_PF_DEPTH");
+        const std::string deep = depth_env && atoi(depth_env) == 1 ? "" : "_d2";
         if (big) {
             // A 128 x 128 tile walks K serially (~1.5 us per 64-wide chunk), so a grid that does not
             // oversubscribe the CUs several times is latency-bound: split K until it does.
@@ -714,7 +718,7 @@ struct mc_decoder {
                     if (s != MC_OK) return s;
                     pf_part_elems = need;
                 }
-                mc_status s = launch("mc_pf_gemm128_" + f + tname + "_e2", (L.out + 127) / 128, (M + 127) / 128, splits,
+                mc_status s = launch("mc_pf_gemm128_" + f + tname + deep + "_e2", (L.out + 127) / 128, (M + 127) / 128, splits,
                                      256, 0,
                                      pack(L.w, L.scales, X, (void*)pf_part, (const void*)nullptr, (uint32_t)M,
                                           (uint32_t)L.out, (uint32_t)L.in, (uint32_t)L.group, (const void*)nullptr,
@@ -726,7 +730,7 @@ struct mc_decoder {
                                    L.lora_scale));
             }
         }
-        const std::string name = (big ? "mc_pf_gemm128_" : "mc_pf_gemm_") + f + tname + "_e" + std::to_string(epi);
+        const std::string name = (big ? "mc_pf_gemm128_" : "mc_pf_gemm_") + f + tname + (big ? deep : "") + "_e" + std::to_string(epi);
         const unsigned tile = big ? 128 : 64;
         return launch(name, (L.out + tile - 1) / tile, (M + tile - 1) / tile, 1, 256, 0,
                       pack(L.w, L.scales, X, Y, res, (uint32_t)M, (uint32_t)L.out, (uint32_t)L.in, (uint32_t)L.group,

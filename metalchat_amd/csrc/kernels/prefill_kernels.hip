@@ -357,7 +357,7 @@ pf_tile_of(uint32_t& nt, uint32_t& mt)
     }
 }
 
-template <int WF, int EPI>
+template <int WF, int EPI, int DEPTH>
 __device__ __forceinline__ void
 pf_gemm_big_body(const void* __restrict__ wp, const void* __restrict__ sp, const bf16_t* __restrict__ X,
                  bf16_t* __restrict__ Y, const bf16_t* __restrict__ res, uint32_t M, uint32_t N, uint32_t K,
@@ -389,41 +389,50 @@ pf_gemm_big_body(const void* __restrict__ wp, const void* __restrict__ sp, const
 #pragma unroll
         for (int b = 0; b < 4; b++) acc[a][b] = pf_f32x4{0, 0, 0, 0};
 
-    // Software pipeline: the global loads of chunk k+1 (X packets and RAW weight packets) are
-    // issued before the MFMAs of chunk k and consumed -- dequantised, written to LDS -- at the top
-    // of the next iteration, so their latency hides behind 32 MFMAs and the other workgroups of
-    // the CU.  (Without it a workgroup spent ~1.5 us per chunk: w2 with K = 14336 took the same
-    // 10.8 ms at M = 128 and M = 2048.)
-    uint4 xv[4], wraw[4];
-    float s_next = 0.0f;
-    auto fetch = [&](uint32_t k0) {
+    // Software pipeline: the global loads of chunk k + DEPTH (X packets and RAW weight packets) are
+    // issued before the MFMAs of chunk k and consumed -- dequantised, written to LDS -- DEPTH steps
+    // later, so their latency hides behind 32 * DEPTH MFMAs and the other workgroups of the CU.
+    // (Without it a workgroup spent ~1.5 us per chunk: w2 with K = 14336 took the same 10.8 ms at
+    // M = 128 and M = 2048.)  The loads are UNCONDITIONAL straight-line code from clamped addresses
+    // -- a load behind a branch makes hipcc wait vmcnt(0) and drain the younger chunks too -- and a
+    // run past the end of the K range is neutralised when it is consumed (its X packets become
+    // zeros), so the loop can always run whole groups of DEPTH steps.
+    uint4 xvs[DEPTH][4], wraws[DEPTH][4];
+    float s_nexts[DEPTH];
+    auto fetch = [&](int slot, uint32_t k0) {
         const uint32_t kabs = k0 + skk;
-        if (kabs < K) { // K is a multiple of 32: a 32-run is inside or outside
-            const uint4* src = reinterpret_cast<const uint4*>(X + (size_t)xr * K + kabs);
+        const uint32_t kc = kabs < K ? kabs : K - 32; // K is a multiple of 32: a 32-run is inside or outside
+        const uint4* src = reinterpret_cast<const uint4*>(X + (size_t)xr * K + kc);
 #pragma unroll
-            for (int i = 0; i < 4; i++) xv[i] = src[i];
-            if (WF == PF_W_T) {
-                const uint4* ws = reinterpret_cast<const uint4*>(static_cast<const bf16_t*>(wp) + (size_t)wr * K + kabs);
+        for (int i = 0; i < 4; i++) xvs[slot][i] = src[i];
+        if (WF == PF_W_T) {
+            const uint4* ws = reinterpret_cast<const uint4*>(static_cast<const bf16_t*>(wp) + (size_t)wr * K + kc);
 #pragma unroll
-                for (int i = 0; i < 4; i++) wraw[i] = ws[i];
-            } else {
-                s_next = pf_scale<WF, BF>(sp, wr, group ? kabs >> glog : 0, ngroups);
-                if (WF == PF_W_I4) {
-                    wraw[0] = *reinterpret_cast<const uint4*>(static_cast<const char*>(wp) + (size_t)wr * rowb + kabs / 2);
-                } else {
-                    const uint4* ws = reinterpret_cast<const uint4*>(static_cast<const int8_t*>(wp) + (size_t)wr * rowb + kabs);
-                    wraw[0] = ws[0];
-                    wraw[1] = ws[1];
-                }
-            }
+            for (int i = 0; i < 4; i++) wraws[slot][i] = ws[i];
         } else {
-#pragma unroll
-            for (int i = 0; i < 4; i++) xv[i] = wraw[i] = make_uint4(0, 0, 0, 0);
-            s_next = 0.0f;
+            s_nexts[slot] = pf_scale<WF, BF>(sp, wr, group ? kc >> glog : 0, ngroups);
+            if (WF == PF_W_I4) {
+                wraws[slot][0] = *reinterpret_cast<const uint4*>(static_cast<const char*>(wp) + (size_t)wr * rowb + kc / 2);
+            } else {
+                const uint4* ws = reinterpret_cast<const uint4*>(static_cast<const int8_t*>(wp) + (size_t)wr * rowb + kc);
+                wraws[slot][0] = ws[0];
+                wraws[slot][1] = ws[1];
+            }
         }
     };
-    fetch(kbeg);
-    for (uint32_t k0 = kbeg; k0 < kend; k0 += PFB_K) {
+#pragma unroll
+    for (int d = 0; d < DEPTH; d++) fetch(d, kbeg + d * PFB_K);
+    for (uint32_t kg0 = kbeg; kg0 < kend; kg0 += DEPTH * PFB_K) {
+#pragma unroll
+      for (int slot = 0; slot < DEPTH; slot++) {
+        const uint32_t k0 = kg0 + slot * PFB_K;
+        uint4 (&xv)[4] = xvs[slot];
+        uint4 (&wraw)[4] = wraws[slot];
+        const float s_next = s_nexts[slot];
+        if (k0 + skk >= kend) { // wave-uniform per half-wave pair; no loads behind it
+#pragma unroll
+            for (int i = 0; i < 4; i++) xv[i] = make_uint4(0, 0, 0, 0);
+        }
         uint4 wo[4];
         if (WF == PF_W_T) {
 #pragma unroll
@@ -470,7 +479,7 @@ pf_gemm_big_body(const void* __restrict__ wp, const void* __restrict__ sp, const
             }
         }
         __syncthreads();
-        if (k0 + PFB_K < kend) fetch(k0 + PFB_K);
+        fetch(slot, k0 + DEPTH * PFB_K);
         const uint32_t kg = (lane >> 4) * 8, l15 = lane & 15;
 #pragma unroll
         for (uint32_t ks = 0; ks < PFB_K; ks += 32) {
@@ -488,6 +497,7 @@ pf_gemm_big_body(const void* __restrict__ wp, const void* __restrict__ sp, const
                                                                          __builtin_bit_cast(pf_bf16x8, b[nt]),
                                                                          acc[mt][nt], 0, 0, 0);
         }
+      }
     }
 #pragma unroll
     for (int mt = 0; mt < 4; mt++)
@@ -509,13 +519,14 @@ pf_gemm_big_body(const void* __restrict__ wp, const void* __restrict__ sp, const
             }
 }
 
-#define MC_PF_GEMM_BIG(NAME, WF, EPI)                                                                   \
+#define MC_PF_GEMM_BIG(NAME, WF, EPI) MC_PF_GEMM_BIG_D(NAME, WF, EPI, 1)
+#define MC_PF_GEMM_BIG_D(NAME, WF, EPI, DEPTH)                                                          \
     extern "C" __global__ void __launch_bounds__(256)                                                   \
     NAME(const void* w, const void* scales, const bf16_t* X, bf16_t* Y, const bf16_t* res, uint32_t M,  \
          uint32_t N, uint32_t K, uint32_t group, const bf16_t* la, const bf16_t* lb, uint32_t lora_rank, \
          float lora_scale)                                                                              \
     {                                                                                                   \
-        pf_gemm_big_body<WF, EPI>(w, scales, X, Y, res, M, N, K, group, la, lb, lora_rank, lora_scale); \
+        pf_gemm_big_body<WF, EPI, DEPTH>(w, scales, X, Y, res, M, N, K, group, la, lb, lora_rank, lora_scale); \
     }
 MC_PF_GEMM_BIG(mc_pf_gemm128_i4_bfloat_e0, PF_W_I4, 0)
 MC_PF_GEMM_BIG(mc_pf_gemm128_i4_bfloat_e1, PF_W_I4, 1)
@@ -526,6 +537,18 @@ MC_PF_GEMM_BIG(mc_pf_gemm128_w_bfloat_e1, PF_W_T, 1)
 MC_PF_GEMM_BIG(mc_pf_gemm128_i4_bfloat_e2, PF_W_I4, 2)
 MC_PF_GEMM_BIG(mc_pf_gemm128_i8_bfloat_e2, PF_W_I8, 2)
 MC_PF_GEMM_BIG(mc_pf_gemm128_w_bfloat_e2, PF_W_T, 2)
+// two chunks in flight per workgroup (204 VGPRs, two workgroups per CU): the default -- faster than one
+// chunk (144 VGPRs, three per CU) at every prompt length, 6.3 vs 6.9 ms at 128 rows, 14.5 vs 16.2 at
+// 512, 54.0 vs 55.5 at 2048; three chunks (220 VGPRs) lose again: 7.0 / 15.7 / 56.7 ms
+MC_PF_GEMM_BIG_D(mc_pf_gemm128_i4_bfloat_d2_e0, PF_W_I4, 0, 2)
+MC_PF_GEMM_BIG_D(mc_pf_gemm128_i4_bfloat_d2_e1, PF_W_I4, 1, 2)
+MC_PF_GEMM_BIG_D(mc_pf_gemm128_i4_bfloat_d2_e2, PF_W_I4, 2, 2)
+MC_PF_GEMM_BIG_D(mc_pf_gemm128_i8_bfloat_d2_e0, PF_W_I8, 0, 2)
+MC_PF_GEMM_BIG_D(mc_pf_gemm128_i8_bfloat_d2_e1, PF_W_I8, 1, 2)
+MC_PF_GEMM_BIG_D(mc_pf_gemm128_i8_bfloat_d2_e2, PF_W_I8, 2, 2)
+MC_PF_GEMM_BIG_D(mc_pf_gemm128_w_bfloat_d2_e0, PF_W_T, 0, 2)
+MC_PF_GEMM_BIG_D(mc_pf_gemm128_w_bfloat_d2_e1, PF_W_T, 1, 2)
+MC_PF_GEMM_BIG_D(mc_pf_gemm128_w_bfloat_d2_e2, PF_W_T, 2, 2)
 
 // y = T(sum_z partial[z]) (+ adaptation) (+ residual): the epilogue of a split-K GEMM
 extern "C" __global__ void
