@@ -244,6 +244,7 @@ struct mc_decoder {
     int gemv_block = 256;
     int gemv_wgs_per_cu = 2;
     int dbg_variant = 0; // MC_GEMV_DBG=1 stream-only, 2 compute-only (tuning ablations)
+    int pv_block = 1024;   // MC_PV_BLOCK: threads of a P.V workgroup (16 waves: one round of loads per wave at S = 2048)
     int gemv_m4 = 2;       // MC_GEMV_M4: 0 = exact int4 on the VALU (v_dot2c), 1 = dot products on the 4x4x4 MFMA, 2 = dequantisation too where a SIMD holds > 1 wave, 3 = always
     bool gemma_fuse = true; // MC_GEMMA_UNFUSED=1: keep the post-norms as launches of their own
     bool pn_ready = false;
@@ -541,7 +542,7 @@ struct mc_decoder {
                             (uint32_t)hd, (uint32_t)cfg.max_seq_len, scale_T, (uint32_t)nsplit));
             if (s != MC_OK) return s;
             // softmax normalisation + P.V          (attention.h:200-203)
-            s = launch("mc_attn_pv_" + tname, hd / 16, KV, pv_ranges, 256, 0,
+            s = launch("mc_attn_pv_" + tname, hd / 16, KV, pv_ranges, pv_block, 0,
                        pack(expv, psum, L.vt, attn_out, state, (uint32_t)n_rep, (uint32_t)hd,
                             (uint32_t)cfg.max_seq_len, (uint32_t)nsplit, pv_parts, (uint32_t)H));
             if (s != MC_OK) return s;
@@ -902,6 +903,8 @@ mc_decoder_create(mc_device* dev, mc_library* lib, mc_queue* q, const mc_decoder
     if (const char* e = getenv("MC_GEMV_DBG")) d->dbg_variant = atoi(e);
     if (const char* e = getenv("MC_GEMMA_UNFUSED")) d->gemma_fuse = atoi(e) == 0;
     if (const char* e = getenv("MC_GEMV_M4")) d->gemv_m4 = atoi(e);
+    if (const char* e = getenv("MC_PV_BLOCK")) d->pv_block = atoi(e);
+    if (d->pv_block % 64 || d->pv_block < 256 || d->pv_block > 1024) d->pv_block = 1024;
     if (d->gemv_block % 64 || d->gemv_block < 64 || d->gemv_block > 512) d->gemv_block = 256;
     if (d->gemv_wgs_per_cu < 1) d->gemv_wgs_per_cu = 2;
 
@@ -922,9 +925,10 @@ mc_decoder_create(mc_device* dev, mc_library* lib, mc_queue* q, const mc_decoder
     A(d->logits, (size_t)c.vocab * tb);
     A(d->expv, (size_t)H * c.max_seq_len * 4);
     A(d->psum, (size_t)H * d->nsplit * 4);
-    // contexts of 4096 slots and more: P.V in ranges of 1024 slots + one reduce launch (the 64
-    // whole-context workgroups took 27.9 us per layer at S = 8192); shorter ones keep the single launch
-    d->pv_ranges = c.max_seq_len >= 4096 ? std::min(16, c.max_seq_len / 1024) : 1;
+    // P.V: one whole-context launch of 16-wave workgroups while a wave has at most ~16 k-steps of 32
+    // slots (four rounds of loads); from 8192 slots on, ranges of 2048 slots + one reduce launch
+    // (S = 8192, int8 weights: 1 range 369, 2: 391, 4: 402, 8: 383, 16: 347 tokens/s)
+    d->pv_ranges = c.max_seq_len >= 8192 ? std::min(16, c.max_seq_len / 2048) : 1;
     if (const char* e = getenv("MC_PV_RANGES")) d->pv_ranges = std::max(1, std::min(64, atoi(e)));
     A(d->pv_parts, (size_t)d->pv_ranges * H * hd * 4);
     A(d->taps, (size_t)(d->n_own + 1) * dim * tb);

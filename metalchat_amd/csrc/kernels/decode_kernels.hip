@@ -382,8 +382,9 @@ mc_attn_scores_float(const float* q, const float* kc, float* expv, float* psum, 
 //   o = T(sum_s p[s] V[s]) fp32 MFMA accumulate, rounded once (bmm.metal:80)
 // Workgroup (db, kv) owns output columns [16 db, 16 db + 16) of the n_rep heads of kv head `kv`
 // over ALL cache slots, so the result is final: no cross-workgroup partials, no reduce launch.
-// The four waves interleave the 32-slot MFMA k-steps (wave w takes k-steps w, w+4, ...) and are
-// summed through LDS in wave order.  B = Vt rows (position-contiguous), A = normalised P.
+// The waves interleave the 32-slot MFMA k-steps (wave w of nw takes k-steps w, w + nw, ..., four of
+// them per iteration with all loads first) and are summed through LDS in wave order.  16 waves: at
+// S = 2048 every wave then needs ONE round of loads instead of four dependent ones.  B = Vt rows (position-contiguous), A = normalised P.
 // Long contexts: gridDim.z > 1 splits the cache slots into gridDim.z ranges of whole k-steps (fixed
 // by max_seq, so a captured graph stays valid as kv_len grows); every range leaves its UNROUNDED
 // fp32 sums in `parts` [gridDim.z][H*hd] and mc_attn_pv_reduce_T adds them in range order and
@@ -412,15 +413,15 @@ __device__ __forceinline__ void
 pv_finish_store(const f32x4_t& acc, float* part, void* out, int tbytes, uint32_t kv, uint32_t n_rep,
                 uint32_t hd, uint32_t db, float* parts, uint32_t n_heads)
 {
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const uint32_t col = lane & 15, c = lane >> 4;
 #pragma unroll
     for (int r = 0; r < 4; r++) part[(wave * 16 + c * 4 + r) * 16 + col] = acc[r];
     __syncthreads();
     if (threadIdx.x < n_rep * 16) {
         const uint32_t head = threadIdx.x / 16, d = threadIdx.x % 16;
-        const float v = ((part[(0 * 16 + head) * 16 + d] + part[(1 * 16 + head) * 16 + d]) +
-                         part[(2 * 16 + head) * 16 + d]) + part[(3 * 16 + head) * 16 + d];
+        float v = part[(0 * 16 + head) * 16 + d];
+        for (uint32_t w = 1; w < nw; w++) v += part[(w * 16 + head) * 16 + d]; // wave order
         const size_t o = (size_t)(kv * n_rep + head) * hd + db * 16 + d;
         if (gridDim.z > 1) parts[(size_t)blockIdx.z * n_heads * hd + o] = v;
         else if (tbytes == 2) static_cast<bf16_t*>(out)[o] = f2bf(v);
@@ -428,17 +429,17 @@ pv_finish_store(const f32x4_t& acc, float* part, void* out, int tbytes, uint32_t
     }
 }
 
-extern "C" __global__ void __launch_bounds__(256)
+extern "C" __global__ void __launch_bounds__(1024)
 mc_attn_pv_bfloat(const float* __restrict__ expv, const float* __restrict__ psum,
                   const bf16_t* __restrict__ vt, bf16_t* __restrict__ out, const step_state* st,
                   uint32_t n_rep, uint32_t hd, uint32_t max_seq, uint32_t nsplit, float* __restrict__ parts,
                   uint32_t n_heads)
 {
-    __shared__ float part[4 * 16 * 16];
+    __shared__ float part[16 * 16 * 16]; // up to 16 waves
     const uint32_t S = (uint32_t)st->kv_len;
     const uint32_t db = blockIdx.x, kv = blockIdx.y;
     const uint32_t nact = (S + PB - 1) / PB;
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const uint32_t col = lane & 15, c = lane >> 4;
     __shared__ float inv_s[16];
     const float inv = softmax_inv(psum, inv_s, kv, n_rep, nsplit, nact);
@@ -449,25 +450,25 @@ mc_attn_pv_bfloat(const float* __restrict__ expv, const float* __restrict__ psum
     const uint32_t kbeg = blockIdx.z * kper, nk = min(nk_all, kbeg + kper);
 
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-    for (uint32_t t0 = kbeg + wave; t0 < nk; t0 += 16) {
+    for (uint32_t t0 = kbeg + wave; t0 < nk; t0 += 4 * nw) {
         // four k-steps of this wave per iteration: all loads first, then the MFMAs
         uint4 vb[4];
         float4 e0[4], e1[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            const uint32_t p0 = (t0 + 4 * u) * 32 + c * 8;
+            const uint32_t p0 = (t0 + nw * u) * 32 + c * 8;
             const uint32_t pl = p0 + 8 <= max_seq ? p0 : max_seq - 8;
             vb[u] = *reinterpret_cast<const uint4*>(vrow + pl);
             e0[u] = make_float4(0.f, 0.f, 0.f, 0.f);
             e1[u] = e0[u];
-            if (col < n_rep && p0 < S && t0 + 4 * u < nk) {
+            if (col < n_rep && p0 < S && t0 + nw * u < nk) {
                 e0[u] = *reinterpret_cast<const float4*>(erow + p0);
                 e1[u] = *reinterpret_cast<const float4*>(erow + p0 + 4);
             }
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            const uint32_t p0 = (t0 + 4 * u) * 32 + c * 8;
+            const uint32_t p0 = (t0 + nw * u) * 32 + c * 8;
             const float e[8] = {e0[u].x, e0[u].y, e0[u].z, e0[u].w, e1[u].x, e1[u].y, e1[u].z, e1[u].w};
             uint32_t w[4];
 #pragma unroll
@@ -486,17 +487,17 @@ mc_attn_pv_bfloat(const float* __restrict__ expv, const float* __restrict__ psum
 
 // T = float.  k-step = 16 slots: lane (col, c) holds slots p0 + 4c + i; MFMA i contracts slot
 // p0 + 4c + i on both operands.
-extern "C" __global__ void __launch_bounds__(256)
+extern "C" __global__ void __launch_bounds__(1024)
 mc_attn_pv_float(const float* __restrict__ expv, const float* __restrict__ psum,
                  const float* __restrict__ vt, float* __restrict__ out, const step_state* st,
                   uint32_t n_rep, uint32_t hd, uint32_t max_seq, uint32_t nsplit, float* __restrict__ parts,
                   uint32_t n_heads)
 {
-    __shared__ float part[4 * 16 * 16];
+    __shared__ float part[16 * 16 * 16]; // up to 16 waves
     const uint32_t S = (uint32_t)st->kv_len;
     const uint32_t db = blockIdx.x, kv = blockIdx.y;
     const uint32_t nact = (S + PB - 1) / PB;
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const uint32_t col = lane & 15, c = lane >> 4;
     __shared__ float inv_s[16];
     const float inv = softmax_inv(psum, inv_s, kv, n_rep, nsplit, nact);
@@ -507,19 +508,19 @@ mc_attn_pv_float(const float* __restrict__ expv, const float* __restrict__ psum,
     const uint32_t kbeg = blockIdx.z * kper, nk = min(nk_all, kbeg + kper);
 
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-    for (uint32_t t0 = kbeg + wave; t0 < nk; t0 += 16) {
+    for (uint32_t t0 = kbeg + wave; t0 < nk; t0 += 4 * nw) {
         float4 vb[4], pe[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            const uint32_t p0 = (t0 + 4 * u) * 16 + c * 4;
+            const uint32_t p0 = (t0 + nw * u) * 16 + c * 4;
             const uint32_t pl = p0 + 4 <= max_seq ? p0 : max_seq - 4;
             vb[u] = *reinterpret_cast<const float4*>(vrow + pl);
             pe[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (col < n_rep && p0 < S && t0 + 4 * u < nk) pe[u] = *reinterpret_cast<const float4*>(erow + p0);
+            if (col < n_rep && p0 < S && t0 + nw * u < nk) pe[u] = *reinterpret_cast<const float4*>(erow + p0);
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            const uint32_t p0 = (t0 + 4 * u) * 16 + c * 4;
+            const uint32_t p0 = (t0 + nw * u) * 16 + c * 4;
             const float a0 = p0 < S ? pe[u].x * inv : 0.0f, a1 = p0 + 1 < S ? pe[u].y * inv : 0.0f;
             const float a2 = p0 + 2 < S ? pe[u].z * inv : 0.0f, a3 = p0 + 3 < S ? pe[u].w * inv : 0.0f;
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, vb[u].x, acc, 0, 0, 0);

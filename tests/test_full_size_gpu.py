@@ -275,14 +275,16 @@ def test_end_to_end_against_the_oracle_at_full_width(acc, name):
     om2.close()
 
 
-def test_int8_long_context_against_the_oracle_at_full_width(acc):
+def test_int8_long_context_against_the_oracle_at_full_width(acc, monkeypatch):
     # BASELINE configs[2] territory: int8-held weights, a long context.  One Llama-3-8B-wide block,
-    # max_seq_len 4096 (so P.V runs in ranges of cache slots + the reduce launch), a 600-token prompt
+    # max_seq_len 4096 with P.V forced into 4 ranges of cache slots + the reduce launch (the layout a
+    # context of 8192 slots takes by itself), a 600-token prompt
     # through the prompt pass (128 x 128 MFMA GEMMs on int8 weights, split-K) and decode steps behind
     # it -- all against the oracle on the regenerated weights.
     import metalchat_amd as mc
     import modelgen as mg
 
+    monkeypatch.setenv("MC_PV_RANGES", "4")
     cfg = dict(dtype=BF16, n_layers=1, vocab=2048, max_seq_len=4096, norm_eps=1e-5, **FULL_WIDTH["llama3-8b"])
     weights = synth_model(cfg, SEED, bits=8)
     om = mo.Model(cfg, weights)

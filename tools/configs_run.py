@@ -16,7 +16,10 @@ CASES = [
     ("gemma-7b-shaped int4 g128 S=2048 (gemma3 block)", dict(dim=3072, n_heads=16, n_kv_heads=16, head_dim=256, ffn_dim=24576, n_layers=28, vocab=256000, rope_theta=10000.0), mc.WFMT_I4, 128, 2048, 64, 0),
     ("llama3-70b int4 g128 S=2048 on ONE GPU", dict(dim=8192, n_heads=64, n_kv_heads=8, head_dim=128, ffn_dim=28672, n_layers=80, vocab=128256, rope_theta=500000.0), mc.WFMT_I4, 128, 2048, 32, 0),
 ]
+only = os.environ.get("CASE")
 for name, m, fmt, group, S, K, past in CASES:
+    if only and only not in name:
+        continue
     fam = mc.FAMILY_GEMMA3 if "gemma" in name else mc.FAMILY_LLAMA3
     extra = dict(rope_sliding_theta=10000.0, sliding_stride=6) if fam else {}
     dec = mc.Decoder(acc, dtype=mc.BF16, family=fam, max_seq_len=S, norm_eps=1e-5,
