@@ -442,7 +442,6 @@ mc_attn_pv_bfloat(const float* __restrict__ expv, const float* __restrict__ psum
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const uint32_t col = lane & 15, c = lane >> 4;
     __shared__ float inv_s[16];
-    const float inv = softmax_inv(psum, inv_s, kv, n_rep, nsplit, nact);
     const float* erow = expv + (size_t)(kv * n_rep + col) * max_seq;
     const bf16_t* vrow = vt + ((size_t)kv * hd + db * 16 + col) * max_seq;
     const uint32_t nk_all = (S + 31) / 32;
@@ -450,10 +449,12 @@ mc_attn_pv_bfloat(const float* __restrict__ expv, const float* __restrict__ psum
     const uint32_t kbeg = blockIdx.z * kper, nk = min(nk_all, kbeg + kper);
 
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-    for (uint32_t t0 = kbeg + wave; t0 < nk; t0 += 4 * nw) {
-        // four k-steps of this wave per iteration: all loads first, then the MFMAs
-        uint4 vb[4];
-        float4 e0[4], e1[4];
+    // four k-steps of this wave per round: all loads first, then the MFMAs.  The first round is
+    // requested BEFORE the softmax denominators are reduced (they need the psum loads, a wave
+    // reduction and a barrier): V and the numerators do not depend on them.
+    uint4 vb[4];
+    float4 e0[4], e1[4];
+    auto request = [&](uint32_t t0) {
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const uint32_t p0 = (t0 + nw * u) * 32 + c * 8;
@@ -466,6 +467,11 @@ mc_attn_pv_bfloat(const float* __restrict__ expv, const float* __restrict__ psum
                 e1[u] = *reinterpret_cast<const float4*>(erow + p0 + 4);
             }
         }
+    };
+    uint32_t t0 = kbeg + wave;
+    if (t0 < nk) request(t0);
+    const float inv = softmax_inv(psum, inv_s, kv, n_rep, nsplit, nact);
+    while (t0 < nk) {
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const uint32_t p0 = (t0 + nw * u) * 32 + c * 8;
@@ -481,6 +487,8 @@ mc_attn_pv_bfloat(const float* __restrict__ expv, const float* __restrict__ psum
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, pa4),
                                                           __builtin_bit_cast(bf16x8_t, vb[u]), acc, 0, 0, 0);
         }
+        t0 += 4 * nw;
+        if (t0 < nk) request(t0);
     }
     pv_finish_store(acc, part, out, 2, kv, n_rep, hd, db, parts, n_heads);
 }
