@@ -812,18 +812,22 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
 #ifndef MC_GEMV_PRE
 #define MC_GEMV_PRE 1
 #endif
+#ifndef MC_GEMV_PRE_P0
+#define MC_GEMV_PRE_P0 MC_GEMV_PRE // kernels without a norm prologue (Wo, w2)
+#endif
+    constexpr int PRE = PRO == PRO_NONE ? MC_GEMV_PRE_P0 : MC_GEMV_PRE;
     stage_x([&] {
         load(ring[0], ld.rg, ld.c, 0 < ntiles);
         advance(ld);
 #pragma unroll
         for (int sl = 1; sl < RING; sl++)
-            if (MC_GEMV_PRE > sl) { load(ring[sl], ld.rg, ld.c, (uint32_t)sl < ntiles); advance(ld); }
+            if (PRE > sl) { load(ring[sl], ld.rg, ld.c, (uint32_t)sl < ntiles); advance(ld); }
     });
     __syncthreads();
     if (TL) tl1 = __builtin_amdgcn_s_memrealtime();
 #pragma unroll
     for (int sl = 1; sl < RING; sl++)
-        if (MC_GEMV_PRE <= sl) { load(ring[sl], ld.rg, ld.c, (uint32_t)sl < ntiles); advance(ld); }
+        if (PRE <= sl) { load(ring[sl], ld.rg, ld.c, (uint32_t)sl < ntiles); advance(ld); }
 
     float acc[R];
     mf_f4 accv[R];
