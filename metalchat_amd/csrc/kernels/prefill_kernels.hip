@@ -77,6 +77,58 @@ pf_rmsnorm_body(const typename T::S* x, const typename T::S* w, const typename T
 {
     __shared__ float red[16];
     const size_t base = (size_t)blockIdx.x * dim;
+    constexpr uint32_t EPV = 16 / T::bytes; // elements per 16-byte packet
+    const uint32_t npk = dim / EPV, bd = blockDim.x;
+    if (dim % EPV == 0 && npk <= 4 * bd) {
+        // the row, its weight and its residual in ONE round of 16-byte loads, kept in registers
+        // between the sum and the scaling (the scalar two-pass loop below took 14 us per launch at
+        // 128 rows: three dependent rounds of 2-byte loads)
+        uint4 xv[4], wv[4], rv[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t pk = threadIdx.x + i * bd, pc = pk < npk ? pk : npk - 1;
+            xv[i] = reinterpret_cast<const uint4*>(x + base)[pc];
+            wv[i] = reinterpret_cast<const uint4*>(w)[pc];
+            rv[i] = res ? reinterpret_cast<const uint4*>(res + base)[pc] : make_uint4(0, 0, 0, 0);
+        }
+        auto elem = [](const uint4& v, int j) -> float {
+            const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+            if (T::bytes == 2) return __uint_as_float((j & 1) ? (d[j >> 1] & 0xFFFF0000u) : (d[j >> 1] << 16));
+            return __uint_as_float(d[j]);
+        };
+        float ss = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            if (threadIdx.x + i * bd < npk)
+#pragma unroll
+                for (int j = 0; j < (int)EPV; j++) {
+                    const float v = elem(xv[i], j);
+                    ss += v * v;
+                }
+        const float tot = block_sum(ss, red);
+        const float inv = 1.0f / sqrtf(tot / (float)dim + eps);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t pk = threadIdx.x + i * bd;
+            if (pk >= npk) continue;
+            float o[EPV];
+#pragma unroll
+            for (int j = 0; j < (int)EPV; j++) {
+                float v = T::rt((mu + elem(wv[i], j)) * elem(xv[i], j) * inv);
+                if (res) v = elem(rv[i], j) + v;
+                o[j] = v;
+            }
+            uint4 out;
+            if (T::bytes == 2) {
+                out = make_uint4(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4 % EPV], o[5 % EPV]),
+                                 pack_bf16x2(o[6 % EPV], o[7 % EPV]));
+            } else {
+                out = make_uint4(__float_as_uint(o[0]), __float_as_uint(o[1]), __float_as_uint(o[2]), __float_as_uint(o[3]));
+            }
+            reinterpret_cast<uint4*>(y + base)[pk] = out;
+        }
+        return;
+    }
     float ss = 0.0f;
     for (uint32_t j = threadIdx.x; j < dim; j += blockDim.x) {
         const float v = T::ld(x[base + j]);
