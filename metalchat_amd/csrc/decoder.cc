@@ -809,7 +809,8 @@ struct mc_decoder {
             if (s != MC_OK) return s;
             s = timed("gemm_w13", [&] { return gemm(L.w13, 0, pf_xn, pf_g2, nullptr, M); });
             if (s != MC_OK) return s;
-            s = timed("act_mul", [&] { return launch("mc_pf_act_mul_" + tname, (cfg.ffn_dim + 255) / 256, M, 1, 256, 0,
+            const unsigned act_pp = 8u / (unsigned)tb; // pairs per thread (one 16-byte packet)
+            s = timed("act_mul", [&] { return launch("mc_pf_act_mul_" + tname, (cfg.ffn_dim / act_pp + 255) / 256 + 1, M, 1, 256, 0,
                        pack(pf_g2, pf_g, (uint32_t)cfg.ffn_dim, (int32_t)(gemma ? 1 : 0))); });
             if (s != MC_OK) return s;
             if (L.ffn_post_norm) {

@@ -175,11 +175,32 @@ template <typename T>
 __device__ __forceinline__ void
 pf_act_mul_body(const typename T::S* in, typename T::S* out, uint32_t ffn, int32_t gelu)
 {
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
-    if (j >= ffn) return;
-    const float a = T::ld(in[(size_t)r * 2 * ffn + 2 * j]), b = T::ld(in[(size_t)r * 2 * ffn + 2 * j + 1]);
-    const float g = gelu ? T::rt(pf_gelu_f(a)) : pf_silu_T<T>(a);
-    out[(size_t)r * ffn + j] = T::st(g * b);
+    // a thread finishes the pairs of one 16-byte packet of the fused row (4 pairs in bf16, 2 in float)
+    constexpr uint32_t PP = 8 / T::bytes;
+    const uint32_t j0 = (blockIdx.x * blockDim.x + threadIdx.x) * PP, r = blockIdx.y;
+    if (j0 >= ffn) return;
+    auto one = [&](float a, float b) {
+        const float g = gelu ? T::rt(pf_gelu_f(a)) : pf_silu_T<T>(a);
+        return g * b;
+    };
+    if (ffn % PP == 0) {
+        const uint4 v = *reinterpret_cast<const uint4*>(in + (size_t)r * 2 * ffn + 2 * j0);
+        const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+        if (T::bytes == 2) {
+            float o[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) o[k] = one(__uint_as_float(d[k] << 16), __uint_as_float(d[k] & 0xFFFF0000u));
+            *reinterpret_cast<uint2*>(out + (size_t)r * ffn + j0) = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
+        } else {
+            const float o0 = one(__uint_as_float(d[0]), __uint_as_float(d[1])), o1 = one(__uint_as_float(d[2]), __uint_as_float(d[3]));
+            *reinterpret_cast<float2*>(out + (size_t)r * ffn + j0) = make_float2(o0, o1);
+        }
+        return;
+    }
+    for (uint32_t j = j0; j < min(ffn, j0 + PP); j++) {
+        const float a = T::ld(in[(size_t)r * 2 * ffn + 2 * j]), b = T::ld(in[(size_t)r * 2 * ffn + 2 * j + 1]);
+        out[(size_t)r * ffn + j] = T::st(one(a, b));
+    }
 }
 extern "C" __global__ void
 mc_pf_act_mul_bfloat(const bf16_t* in, bf16_t* out, uint32_t ffn, int32_t gelu)
