@@ -782,7 +782,14 @@ struct mc_decoder {
             if (tb == 2 && !pf_two_pass) {
                 // fused: the probabilities stay on chip
                 s = timed("attention", [&] {
-                    return launch("mc_pf_attn_bfloat_hd" + std::to_string(hd), (M + 15) / 16, H, 1, 256, 0,
+                    // two query heads of a kv head per workgroup where the grouping allows it: each K / V
+                    // fragment is loaded once for both (MC_PF_ATTN_HEADS=1: one head per workgroup)
+                    // (measured: 2048 rows 15.8 -> 14.0 ms, 512 rows 2.05 -> 1.56 ms per prompt; with too few
+                    // workgroups to fill the chip -- 128 rows -- it loses, 0.46 -> 0.61 ms)
+                    const char* heads_env = getenv("MC_PF_ATTN_HEADS");
+                    const bool enough = (unsigned)((M + 15) / 16) * (unsigned)(H / 2) >= 2u * (unsigned)dev->prop.multiProcessorCount;
+                    const bool two = (H / KV) % 2 == 0 && hd <= 128 && (heads_env ? atoi(heads_env) == 2 : enough);
+                    return launch(std::string(two ? "mc_pf_attn2_bfloat_hd" : "mc_pf_attn_bfloat_hd") + std::to_string(hd), (M + 15) / 16, two ? H / 2 : H, 1, 256, 0,
                                   pack(pf_q, L.kc, L.vt, pf_att, (uint32_t)M, (uint32_t)S, (uint32_t)H, (uint32_t)(H / KV),
                                        (uint32_t)cfg.max_seq_len, scale_T, win));
                 });

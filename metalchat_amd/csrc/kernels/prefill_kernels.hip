@@ -876,21 +876,24 @@ mc_pf_pv_float(const float* probs, const float* vt, float* out, uint32_t M, uint
 // into an A operand through 1 KiB of wave-private LDS, and multiplies by the transposed V cache.
 // Wave w owns the 32-key blocks w, w+4, ... of the visible range; the four partial outputs are
 // summed through LDS at the end.
-template <uint32_t HD>
+template <uint32_t HD, int NH>
 __device__ __forceinline__ void
 pf_attn_body(const bf16_t* Q, const bf16_t* kc, const bf16_t* vt, bf16_t* out, uint32_t M, uint32_t S, uint32_t H,
              uint32_t n_rep, uint32_t max_seq, float scale, uint32_t window)
 {
+    // NH query heads of ONE kv head per workgroup (grid.y = H / NH; NH divides n_rep): every K and V
+    // fragment a wave loads is multiplied NH times -- the waves of this kernel spend two thirds of
+    // their time waiting for those loads (SQ_WAIT_ANY, tools/pmc_attn.sh).
     using T = BF;
     constexpr uint32_t DT = HD / 16, DK = HD / 32;
-    __shared__ float wsum[4][16];
-    __shared__ float inv_sum[16];
-    __shared__ __attribute__((aligned(16))) bf16_t pl[4][16 * 40]; // 16 rows x 32 keys, rows padded to 80 bytes
+    __shared__ float wsum[NH][4][16];
+    __shared__ float inv_sum[NH][16];
+    __shared__ __attribute__((aligned(16))) bf16_t pl[NH][4][16 * 40]; // 16 rows x 32 keys, rows padded to 80 bytes
     constexpr uint32_t OD = HD < 128 ? HD : 128; // output columns reduced per phase
     __shared__ float osum[4][16][OD + 1];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t l15 = lane & 15, lg = lane >> 4, kg = lg * 8;
-    const uint32_t r0 = blockIdx.x * 16, h = blockIdx.y, kv = h / n_rep;
+    const uint32_t r0 = blockIdx.x * 16, h0 = blockIdx.y * NH, kv = h0 / n_rep;
     const bf16_t* kbase = kc + (size_t)kv * max_seq * HD;
     const bf16_t* vbase = vt + (size_t)kv * HD * max_seq;
     const uint32_t sq = S - M, rlast = min(r0 + 15, M - 1);
@@ -898,76 +901,101 @@ pf_attn_body(const bf16_t* Q, const bf16_t* kc, const bf16_t* vt, bf16_t* out, u
     if (window && r0 + 1 > window) clo = sq + (r0 + 1 - window);
     const uint32_t b_lo = clo / 32, b_hi = chi / 32;
     // Q fragments of this row block (A operand), kept in registers
-    uint4 qa[DK];
+    uint4 qa[NH][DK];
     {
         const uint32_t qr = min(r0 + l15, M - 1);
 #pragma unroll
-        for (uint32_t d = 0; d < DK; d++) qa[d] = *reinterpret_cast<const uint4*>(Q + ((size_t)qr * H + h) * HD + d * 32 + kg);
+        for (int j = 0; j < NH; j++)
+#pragma unroll
+            for (uint32_t d = 0; d < DK; d++)
+                qa[j][d] = *reinterpret_cast<const uint4*>(Q + ((size_t)qr * H + h0 + j) * HD + d * 32 + kg);
     }
-    // masked, scaled score tile of 16 keys starting at key0 -> s[i] for row (lg*4+i), column l15
-    auto score_tile = [&](uint32_t key0, float (&sv)[4]) {
+    // masked, scaled score tiles of 16 keys starting at key0 -> sv[j][i] for head j, row (lg*4+i), column l15
+    auto score_tile = [&](uint32_t key0, float (&sv)[NH][4]) {
         const uint32_t key = key0 + l15, keyc = key < S ? key : S - 1;
-        pf_f32x4 acc = {0, 0, 0, 0};
+        uint4 kb[DK];
 #pragma unroll
-        for (uint32_t d = 0; d < DK; d++) {
-            const uint4 b = *reinterpret_cast<const uint4*>(kbase + (size_t)keyc * HD + d * 32 + kg);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(pf_bf16x8, qa[d]), __builtin_bit_cast(pf_bf16x8, b), acc, 0, 0, 0);
-        }
+        for (uint32_t d = 0; d < DK; d++) kb[d] = *reinterpret_cast<const uint4*>(kbase + (size_t)keyc * HD + d * 32 + kg);
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const uint32_t r = r0 + lg * 4 + i;
-            const float sc = T::rt(T::rt(acc[i]) * scale);
-            sv[i] = (r < M && key < S && pf_visible(r, key, S, M, window)) ? sc : -INFINITY;
+        for (int j = 0; j < NH; j++) {
+            pf_f32x4 acc = {0, 0, 0, 0};
+#pragma unroll
+            for (uint32_t d = 0; d < DK; d++)
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(pf_bf16x8, qa[j][d]), __builtin_bit_cast(pf_bf16x8, kb[d]), acc, 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const uint32_t r = r0 + lg * 4 + i;
+                const float sc = T::rt(T::rt(acc[i]) * scale);
+                sv[j][i] = (r < M && key < S && pf_visible(r, key, S, M, window)) ? sc : -INFINITY;
+            }
         }
     };
     // ---- pass 1: exp row sums
-    float rsum[4] = {0, 0, 0, 0};
+    float rsum[NH][4];
+#pragma unroll
+    for (int j = 0; j < NH; j++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) rsum[j][i] = 0.0f;
     for (uint32_t b = b_lo + wave; b <= b_hi; b += 4) {
 #pragma unroll
         for (uint32_t half = 0; half < 2; half++) {
-            float sv[4];
+            float sv[NH][4];
             score_tile(b * 32 + half * 16, sv);
 #pragma unroll
-            for (int i = 0; i < 4; i++) rsum[i] += sv[i] == -INFINITY ? 0.0f : exp_precise(sv[i]);
+            for (int j = 0; j < NH; j++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) rsum[j][i] += sv[j][i] == -INFINITY ? 0.0f : exp_precise(sv[j][i]);
         }
     }
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        float e = rsum[i];
-        e += __shfl_xor(e, 1, 64);
-        e += __shfl_xor(e, 2, 64);
-        e += __shfl_xor(e, 4, 64);
-        e += __shfl_xor(e, 8, 64);
-        if (l15 == 0) wsum[wave][lg * 4 + i] = e;
+    for (int j = 0; j < NH; j++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            float e = rsum[j][i];
+            e += __shfl_xor(e, 1, 64);
+            e += __shfl_xor(e, 2, 64);
+            e += __shfl_xor(e, 4, 64);
+            e += __shfl_xor(e, 8, 64);
+            if (l15 == 0) wsum[j][wave][lg * 4 + i] = e;
+        }
+    __syncthreads();
+    if (threadIdx.x < 16 * NH) {
+        const uint32_t j = threadIdx.x / 16, r = threadIdx.x % 16;
+        inv_sum[j][r] = 1.0f / ((wsum[j][0][r] + wsum[j][1][r]) + (wsum[j][2][r] + wsum[j][3][r]));
     }
     __syncthreads();
-    if (threadIdx.x < 16)
-        inv_sum[threadIdx.x] = 1.0f / ((wsum[0][threadIdx.x] + wsum[1][threadIdx.x]) + (wsum[2][threadIdx.x] + wsum[3][threadIdx.x]));
-    __syncthreads();
-    float inv[4];
+    float inv[NH][4];
 #pragma unroll
-    for (int i = 0; i < 4; i++) inv[i] = inv_sum[lg * 4 + i];
+    for (int j = 0; j < NH; j++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) inv[j][i] = inv_sum[j][lg * 4 + i];
     // ---- pass 2: probabilities (T) x V
-    pf_f32x4 oacc[DT];
+    pf_f32x4 oacc[NH][DT];
 #pragma unroll
-    for (uint32_t t = 0; t < DT; t++) oacc[t] = pf_f32x4{0, 0, 0, 0};
-    volatile bf16_t* mine = pl[wave];
+    for (int j = 0; j < NH; j++)
+#pragma unroll
+        for (uint32_t t = 0; t < DT; t++) oacc[j][t] = pf_f32x4{0, 0, 0, 0};
     for (uint32_t b = b_lo + wave; b <= b_hi; b += 4) {
 #pragma unroll
         for (uint32_t half = 0; half < 2; half++) {
-            float sv[4];
+            float sv[NH][4];
             score_tile(b * 32 + half * 16, sv);
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const float p = sv[i] == -INFINITY ? 0.0f : T::rt(exp_precise(sv[i]) * inv[i]);
-                mine[(lg * 4 + i) * 40 + half * 16 + l15] = T::st(p);
+            for (int j = 0; j < NH; j++) {
+                volatile bf16_t* mine = pl[j][wave];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const float p = sv[j][i] == -INFINITY ? 0.0f : T::rt(exp_precise(sv[j][i]) * inv[j][i]);
+                    mine[(lg * 4 + i) * 40 + half * 16 + l15] = T::st(p);
+                }
             }
         }
         __builtin_amdgcn_wave_barrier();
-        uint4 pa;
-        {
-            const volatile uint32_t* src = reinterpret_cast<const volatile uint32_t*>(mine + l15 * 40 + kg);
-            pa = make_uint4(src[0], src[1], src[2], src[3]);
+        uint4 pa[NH];
+#pragma unroll
+        for (int j = 0; j < NH; j++) {
+            const volatile uint32_t* src = reinterpret_cast<const volatile uint32_t*>(pl[j][wave] + l15 * 40 + kg);
+            pa[j] = make_uint4(src[0], src[1], src[2], src[3]);
         }
         __builtin_amdgcn_wave_barrier();
         const uint32_t c = b * 32 + kg;
@@ -975,31 +1003,41 @@ pf_attn_body(const bf16_t* Q, const bf16_t* kc, const bf16_t* vt, bf16_t* out, u
         for (uint32_t t = 0; t < DT; t++) {
             uint4 vb = make_uint4(0, 0, 0, 0);
             if (c + 8 <= max_seq) vb = *reinterpret_cast<const uint4*>(vbase + (size_t)(t * 16 + l15) * max_seq + c);
-            oacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(pf_bf16x8, pa), __builtin_bit_cast(pf_bf16x8, vb), oacc[t], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < NH; j++)
+                oacc[j][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(pf_bf16x8, pa[j]), __builtin_bit_cast(pf_bf16x8, vb), oacc[j][t], 0, 0, 0);
         }
     }
 #pragma unroll
-    for (uint32_t ph = 0; ph < HD / OD; ph++) {
-        if (ph) __syncthreads();
+    for (int j = 0; j < NH; j++)
 #pragma unroll
-        for (uint32_t t = 0; t < OD / 16; t++)
+        for (uint32_t ph = 0; ph < HD / OD; ph++) {
+            if (ph || j) __syncthreads();
 #pragma unroll
-            for (int i = 0; i < 4; i++) osum[wave][lg * 4 + i][t * 16 + l15] = oacc[ph * (OD / 16) + t][i];
-        __syncthreads();
-        for (uint32_t e = threadIdx.x; e < 16 * OD; e += blockDim.x) {
-            const uint32_t rr = e / OD, d = e % OD, r = r0 + rr;
-            if (r < M)
-                out[((size_t)r * H + h) * HD + ph * OD + d] =
-                    T::st((osum[0][rr][d] + osum[1][rr][d]) + (osum[2][rr][d] + osum[3][rr][d]));
+            for (uint32_t t = 0; t < OD / 16; t++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) osum[wave][lg * 4 + i][t * 16 + l15] = oacc[j][ph * (OD / 16) + t][i];
+            __syncthreads();
+            for (uint32_t e = threadIdx.x; e < 16 * OD; e += blockDim.x) {
+                const uint32_t rr = e / OD, d = e % OD, r = r0 + rr;
+                if (r < M)
+                    out[((size_t)r * H + h0 + j) * HD + ph * OD + d] =
+                        T::st((osum[0][rr][d] + osum[1][rr][d]) + (osum[2][rr][d] + osum[3][rr][d]));
+            }
         }
-    }
 }
 #define MC_PF_ATTN(HD)                                                                                              \
     extern "C" __global__ void __launch_bounds__(256)                                                               \
     mc_pf_attn_bfloat_hd##HD(const bf16_t* Q, const bf16_t* kc, const bf16_t* vt, bf16_t* out, uint32_t M, uint32_t S, \
                              uint32_t H, uint32_t n_rep, uint32_t max_seq, float scale, uint32_t window)          \
     {                                                                                                               \
-        pf_attn_body<HD>(Q, kc, vt, out, M, S, H, n_rep, max_seq, scale, window);                                   \
+        pf_attn_body<HD, 1>(Q, kc, vt, out, M, S, H, n_rep, max_seq, scale, window);                                \
+    }                                                                                                               \
+    extern "C" __global__ void __launch_bounds__(256)                                                               \
+    mc_pf_attn2_bfloat_hd##HD(const bf16_t* Q, const bf16_t* kc, const bf16_t* vt, bf16_t* out, uint32_t M, uint32_t S, \
+                              uint32_t H, uint32_t n_rep, uint32_t max_seq, float scale, uint32_t window)         \
+    {                                                                                                               \
+        pf_attn_body<HD, 2>(Q, kc, vt, out, M, S, H, n_rep, max_seq, scale, window);                                \
     }
 MC_PF_ATTN(32)
 MC_PF_ATTN(64)
