@@ -114,6 +114,7 @@ public:
     void
     split(const char* subject, size_t size, F&& piece) const
     {
+        if (size == 0) return; // nothing to match (and no NULL subject handed to the engine)
         const pcre2_api& api = pcre2_api::get();
         std::shared_ptr<void> md(api.match_data_create_from_pattern(code_.get(), nullptr), api.match_data_free);
         if (api.get_ovector_count(md.get()) == 0) return;
