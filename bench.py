@@ -232,9 +232,11 @@ def main():
             def __init__(self, ptr, n, typestr):
                 self.__cuda_array_interface__ = dict(shape=(n,), typestr=typestr, data=(ptr, False),
                                                      version=3)
-        tt = "<u2" if tbytes == 2 else "<f4"
-        h_out = torch.as_tensor(_Raw(dec.hidden_out_ptr(), m["dim"], tt), device=f"cuda:{local_rank}")
-        h_in = torch.as_tensor(_Raw(dec.hidden_in_ptr(), m["dim"], tt), device=f"cuda:{local_rank}")
+        # the hidden row travels as raw bytes: uint8 is a type every process-group backend carries
+        # (RCCL has no 16-bit unsigned integer type)
+        nb = m["dim"] * tbytes
+        h_out = torch.as_tensor(_Raw(dec.hidden_out_ptr(), nb, "|u1"), device=f"cuda:{local_rank}")
+        h_in = torch.as_tensor(_Raw(dec.hidden_in_ptr(), nb, "|u1"), device=f"cuda:{local_rank}")
         tok_t = torch.zeros(1, dtype=torch.int32, device=f"cuda:{local_rank}")
         from metalchat_amd.pipeline import pipelined_decode
 

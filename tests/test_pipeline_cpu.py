@@ -92,3 +92,12 @@ def test_pipelined_tokens_equal_single_process(world):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert toks == ref
+
+
+def test_bench_ships_the_hidden_row_as_bytes():
+    # RCCL's process group rejects 16-bit unsigned tensors ("Input tensor data type is not supported for
+    # NCCL process group: UInt16", tools/dtype_probe.py on the MI355X box): the bf16 hidden row of the
+    # N > 1 bench path has to travel as uint8
+    import os
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")).read()
+    assert '"|u1"' in src and '"<u2"' not in src
