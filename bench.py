@@ -58,6 +58,9 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-roofline", action="store_true")
     p.add_argument("--seed", type=int, default=0x5EED)
+    p.add_argument("--share-device", action="store_true",
+                   help="validation aid: every rank uses GPU 0 and the hops go over gloo (RCCL refuses two "
+                        "ranks on one device), so the N > 1 path can be exercised end to end on a 1-GPU box")
     p.add_argument("--force-pipeline", action="store_true",
                    help="run the N > 1 code path (torch stream, RCCL group, stage loop) with one rank: a "
                         "smoke check of the multi-GPU plumbing on a 1-GPU box")
@@ -172,12 +175,17 @@ def main():
         if not torch.cuda.is_available():
             print("bench.py: no GPU visible (there is no CPU fallback for the product path)", file=sys.stderr)
             sys.exit(2)
+        if args.share_device:
+            local_rank = 0
         torch.cuda.set_device(local_rank)
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")  # torch.distributed.run sets both; --force-pipeline alone does not
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if args.share_device:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
 
     m = MODELS[args.model]
     tbytes = 2 if args.dtype == "bf16" else 4
