@@ -284,7 +284,8 @@ def main():
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"{args.model} int{args.wbits} (group={args.group}) batch=1 greedy decode, "
                                f"seq_len={S}, {args.dtype} activations/KV, qmode={args.qmode}",
-                   "parallelism": "single GPU" if world == 1 else f"layer pipeline pp{world} (RCCL send/recv)",
+                   "parallelism": "single GPU" if world == 1 else
+                   f"layer pipeline pp{world} ({'gloo hops, ranks sharing GPU 0' if args.share_device else 'RCCL send/recv'})",
                    "hipgraph": bool(not piped and not args.no_graph)},
         "whole_token": {"algorithmic_bytes": ab["total"], "achieved_GBs": ab["total"] * tok_s / 1e9,
                         "frac_of_hbm_peak": ab["total"] * tok_s / 1e9 / HBM_PEAK_GBS},
