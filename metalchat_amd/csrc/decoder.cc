@@ -697,8 +697,10 @@ struct mc_decoder {
             mc_status s = gemm(*L.lora_a, 0, X, pf_lora, nullptr, M);
             if (s != MC_OK) return s;
         }
-        // bf16 prompts longer than one 64-row tile take the 128 x 128 MFMA tiling
-        const bool big = tb == 2 && M > 64 && !getenv("MC_PF_SMALL_GEMM");
+        // every bf16 prompt takes the pipelined 128 x 128 MFMA tiling: a short prompt is bound by the
+        // weight stream, and the unpipelined 64 x 64 tile (kept for T = float, the parity path) needed
+        // 32-42 ms for 8-64 rows where this one needs 5
+        const bool big = tb == 2 && !getenv("MC_PF_SMALL_GEMM");
         const std::string f = L.fmt == MC_WFMT_I4 ? "i4_" : (L.fmt == MC_WFMT_I8 ? "i8_" : "w_");
         const void* la = L.lora_cols ? pf_lora : nullptr;
         // two K chunks in flight per workgroup (prefill_kernels.hip: measured best at every length);
