@@ -244,6 +244,7 @@ struct mc_decoder {
     int gemv_block = 256;
     int gemv_wgs_per_cu = 2;
     int dbg_variant = 0; // MC_GEMV_DBG=1 stream-only, 2 compute-only (tuning ablations)
+    int sampler_block = 1024; // MC_SAMPLER_BLOCK
     int pv_block = 1024;   // MC_PV_BLOCK: threads of a P.V workgroup (16 waves: one round of loads per wave at S = 2048)
     int gemv_m4 = 2;       // MC_GEMV_M4: 0 = exact int4 on the VALU (v_dot2c), 1 = dot products on the 4x4x4 MFMA, 2 = dequantisation too where a SIMD holds > 1 wave, 3 = always
     bool gemma_fuse = true; // MC_GEMMA_UNFUSED=1: keep the post-norms as launches of their own
@@ -640,12 +641,14 @@ struct mc_decoder {
         uint32_t kpad = 1;
         while (kpad < (uint32_t)top_k) kpad *= 2;
         const uint32_t k = (uint32_t)std::min(top_k, cfg.vocab);
-        s = launch("mc_topk_candidates_" + tname, chunks, 1, 1, 256, 0,
+        // 1024 threads: the bitonic networks (66 stages over a 2048-key chunk, 78 over the <= 4096
+        // candidates) are barrier-paced, so every stage should be one compare-exchange per thread
+        s = launch("mc_topk_candidates_" + tname, chunks, 1, 1, sampler_block, 0,
                    pack(logits, (uint32_t)cfg.vocab, kpad, cand));
         if (s != MC_OK) return s;
         sampler_params_h p{k, chunks * kpad, 1, inv_temp_T, top_p_T};
         while (p.ncand_pad < p.ncand) p.ncand_pad *= 2;
-        return launch("mc_sample_" + tname, 1, 1, 1, 256, p.ncand_pad * 8,
+        return launch("mc_sample_" + tname, 1, 1, 1, sampler_block, p.ncand_pad * 8,
                       pack(cand, p, seeds, (uint32_t)n_seed_pairs, state, tokens_dev,
                            want_taps ? sampler_taps : (float*)nullptr));
     }
@@ -914,6 +917,8 @@ mc_decoder_create(mc_device* dev, mc_library* lib, mc_queue* q, const mc_decoder
     if (const char* e = getenv("MC_GEMMA_UNFUSED")) d->gemma_fuse = atoi(e) == 0;
     if (const char* e = getenv("MC_GEMV_M4")) d->gemv_m4 = atoi(e);
     if (const char* e = getenv("MC_PV_BLOCK")) d->pv_block = atoi(e);
+    if (const char* e = getenv("MC_SAMPLER_BLOCK")) d->sampler_block = atoi(e);
+    if (d->sampler_block % 64 || d->sampler_block < 256 || d->sampler_block > 1024) d->sampler_block = 1024;
     if (d->pv_block % 64 || d->pv_block < 256 || d->pv_block > 1024) d->pv_block = 1024;
     if (d->gemv_block % 64 || d->gemv_block < 64 || d->gemv_block > 512) d->gemv_block = 256;
     if (d->gemv_wgs_per_cu < 1) d->gemv_wgs_per_cu = 2;
