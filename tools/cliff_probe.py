@@ -38,3 +38,22 @@ run("context 64..136 of max 2048", fill=64)
 run("context 512 of max 2048", fill=512)
 run("max_seq 4096 full", S=4096)
 run("T=float, 8 layers scaled to 32", dtype=mc.F32, layers=8)
+
+
+def run_steps(name, use_graph):
+    dec = mc.Decoder(acc, dtype=mc.BF16, family=mc.FAMILY_LLAMA3, max_seq_len=2048, norm_eps=1e-5, attn_scale=128 ** -0.5,
+                     weight_format=mc.WFMT_I4, group_size=128, use_graph=use_graph, **M)
+    dec.init_synthetic(3)
+    tok = int(dec.generate(1, 0, 1900)[-1])
+    for i in range(8):
+        tok = dec.step(tok, 1900 + i)
+    t0 = time.perf_counter()
+    for i in range(64):
+        tok = dec.step(tok, 1908 + i)   # one host round trip per token: what interpreter::read_until does
+    dt = time.perf_counter() - t0
+    print(json.dumps(dict(case=name, tokens_per_s=round(64 / dt, 1), ms_per_token=round(dt / 64 * 1e3, 3))), flush=True)
+    dec.release()
+
+
+run_steps("mc_decoder_step per token, use_graph=1", 1)
+run_steps("mc_decoder_step per token, use_graph=0", 0)
