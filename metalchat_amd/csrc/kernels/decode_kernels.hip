@@ -616,16 +616,17 @@ argmax_body(const typename T::S* logits, uint32_t n, step_state* st, int32_t* to
     };
     const uint32_t npk = n / EPV;
     const uint4* pk = reinterpret_cast<const uint4*>(logits);
-    // 16-byte packets, four in flight per thread
-    for (uint32_t p0 = threadIdx.x; p0 < npk; p0 += 4 * blockDim.x) {
-        uint4 v[4];
+    // 16-byte packets, eight in flight per thread: two rounds of loads for a 128256-entry bf16 row
+    constexpr int INF = 8;
+    for (uint32_t p0 = threadIdx.x; p0 < npk; p0 += INF * blockDim.x) {
+        uint4 v[INF];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < INF; u++) {
             const uint32_t p = p0 + u * blockDim.x;
             v[u] = pk[p < npk ? p : npk - 1];
         }
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < INF; u++) {
             const uint32_t p = p0 + u * blockDim.x;
             if (p < npk) {
                 const uint32_t w[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
