@@ -262,6 +262,14 @@ mc_status mc_decoder_get_hidden(mc_decoder* d, int32_t layer, void* hidden_T_dim
  * [end_pos, n_kv_heads, head_dim] (include/metalchat/nn/cache.h:209-215); *n_valid = end_pos. */
 mc_status mc_decoder_export_kv(mc_decoder* d, int32_t layer, void* keys, void* values,
                                int32_t* n_valid);
+/* Test aid, the inverse of mc_decoder_export_kv: fill `layer`'s cache with n_valid logical rows
+ * [n_valid, n_kv_heads, head_dim] of T as if positions 0 .. n_valid-1 had been decoded (the state
+ * sink_cache::copy's first branch leaves, include/metalchat/nn/cache.h:206-213; n_valid <=
+ * max_seq_len, the ring is reset).  A step at start_pos = n_valid continues from there, so a parity
+ * test can start at the benchmark's context length.  Every owned layer must be imported with the
+ * same n_valid. */
+mc_status mc_decoder_import_kv(mc_decoder* d, int32_t layer, const void* keys, const void* values,
+                               int32_t n_valid);
 /* Bytes of weights + scales this decoder streams per token (the roofline numerator). */
 size_t mc_decoder_weight_bytes(const mc_decoder* d);
 /* Per-kernel timing pass used by bench.py's roofline leg: runs the named fused GEMV of every

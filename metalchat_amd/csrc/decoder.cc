@@ -243,6 +243,9 @@ struct mc_decoder {
     std::vector<void*> allocs;
     int gemv_block = 256;
     int gemv_wgs_per_cu = 2;
+    bool gemv_lin = true;        // MC_GEMV_LIN=0: classic kernels everywhere (A/B)
+    bool gemv_block_env = false; // MC_GEMV_BLOCK / MC_GEMV_WGS_PER_CU given: they apply to every kernel of the family
+    bool gemv_full_grid = false; // MC_GEMV_FULLGRID=1: as many workgroups as CUs allow even when that leaves waves without a row group (kernels built with MC_GEMV_WAVEMAJOR)
     int dbg_variant = 0; // MC_GEMV_DBG=1 stream-only, 2 compute-only (tuning ablations)
     int sampler_block = 1024; // MC_SAMPLER_BLOCK
     int pv_block = 1024;   // MC_PV_BLOCK: threads of a P.V workgroup (16 waves: one round of loads per wave at S = 2048)
@@ -428,15 +431,15 @@ struct mc_decoder {
         std::string name = "mc_gemv_";
         name += L.fmt == MC_WFMT_I4 ? "i4_" : (L.fmt == MC_WFMT_I8 ? "i8_" : "w_");
         name += tname;
-        const unsigned waves = gemv_block / 64;
-        const unsigned cap = (unsigned)(dev->prop.multiProcessorCount * gemv_wgs_per_cu);
+        unsigned block = (unsigned)gemv_block, waves = block / 64;
+        unsigned cap = (unsigned)(dev->prop.multiProcessorCount * gemv_wgs_per_cu);
         if (L.fmt == MC_WFMT_I4 && tb == 2 && cfg.qmode == MC_QMODE_FAST) name += "_fast";
         // Grid: one workgroup per four row groups, capped at gemv_wgs_per_cu workgroups per CU (a
         // whole multiple of the CU count: what has to balance is the work per CU -- its SIMDs
         // time-share their waves -- so 3.5 row groups per wave on every CU beats an even 4 per
         // wave on 448 workgroups, measured 19.0 vs 21.4 us on the 60 MB w1|w3 matrix).
         const unsigned ng = (L.out + 3) / 4;
-        unsigned wgs = (ng + waves - 1) / waves;
+        unsigned wgs = gemv_full_grid ? ng : (ng + waves - 1) / waves;
         if (wgs > cap) wgs = cap;
         if (wgs == 0) wgs = 1;
         // exact int4 on bfloat rows: dot products on the 4x4x4 MFMA (_m4); with scale groups that are
@@ -446,9 +449,30 @@ struct mc_decoder {
         // to hide it behind (8.2 vs 8.5 us per launch, profiles/r01_kernel_stats.csv).
         const bool m4 = L.fmt == MC_WFMT_I4 && tb == 2 && cfg.qmode == MC_QMODE_EXACT && gemv_m4 && !dbg_variant;
         const bool m4d_ok = m4 && (L.group == 0 || L.group % 128 == 0) && L.in % 128 == 0;
-        const bool shared_simd = wgs * waves > 4u * (unsigned)dev->prop.multiProcessorCount;
+        const bool shared_simd = std::min(wgs * waves, ng) > 4u * (unsigned)dev->prop.multiProcessorCount; // waves that own a row group
         const bool m4d = m4d_ok && (gemv_m4 >= 3 || (gemv_m4 == 2 && shared_simd));
-        if (m4) name += m4d ? "_m4d" : "_m4";
+        // linear-order main loop (gemv.h): rows of whole KiB (K a multiple of 2048: 1, 2, 4, 7 or 14 KiB), whole row groups
+        const int nch = L.in % 2048 == 0 ? L.in / 2048 : 0;
+        const bool lin = gemv_lin && m4d_ok && L.out % 4 == 0 && (nch == 1 || nch == 2 || nch == 4 || nch == 7 || nch == 14);
+        if (lin) {
+            name += "_lin" + std::to_string(nch);
+            // ONE workgroup of eight waves per CU: the activation row is staged once per CU and, with the raw barrier
+            // between the row requests and the first weight requests (gemv.h MC_GEMV_XBAR), always ahead of the weight
+            // stream in the CU's in-order memory pipe (w1|w3: 16.2 us against 17.3 with two four-wave workgroups)
+            if (!gemv_block_env) {
+                block = 512;
+                waves = 8;
+                cap = (unsigned)dev->prop.multiProcessorCount;
+            }
+            // a CU takes in ~25 GB/s whatever its waves do, so what matters is equal BYTES PER CU: a whole multiple of
+            // the CU count, at least one row pair per wave (the kernel cuts the pairs into equal contiguous ranges)
+            const unsigned cus = (unsigned)dev->prop.multiProcessorCount;
+            const unsigned np = (unsigned)L.out / 2;
+            wgs = (np + waves - 1) / waves;
+            if (wgs > cap) wgs = cap;
+            if (wgs > cus) wgs = wgs / cus * cus;
+        }
+        else if (m4) name += m4d ? "_m4d" : "_m4";
         if (L.fmt == MC_WFMT_I4 && tb == 2 && dbg_variant && ((pro == 1 && epi == 2) || (pro == 0 && epi == 0)))
             name += dbg_variant == 1 ? "_dbgstream" : "_dbgnoload";
         name += "_p" + std::to_string(pro) + "_e" + std::to_string(epi);
@@ -456,15 +480,16 @@ struct mc_decoder {
         const unsigned kpl = L.fmt == MC_WFMT_I4 ? 32 : (L.fmt == MC_WFMT_I8 ? 16 : (tb == 2 ? 8 : 4));
         const unsigned chunk = 64 * kpl;
         unsigned lds = (unsigned)((size_t)((L.in + chunk - 1) / chunk) * chunk * tb);
-        if (m4d) lds = lds / 16 * 17; // 16 bytes of padding per 256 for the transposed reads
-        lds += 64;
+        if (m4d || lin) lds = lds / 16 * 17; // 16 bytes of padding per 256 for the transposed reads
+        lds += 128;
+        if (lin) lds += waves * 512; // parked row sums: 64 pairs x 8 bytes per wave
         if (L.lora_cols) {
             // a = T(A x): the stacked adaptor inputs through the same kernel family (same prologue,
             // so a pre-norm GEMV and its adaptor see the identical normalised row)
             mc_status s = gemv(*L.lora_a, pro, 0, x, L.lora_vec, pro == 2 ? res : nullptr, norm_w, mu);
             if (s != MC_OK) return s;
         }
-        return launch(name, wgs, 1, 1, gemv_block, lds,
+        return launch(name, wgs, 1, 1, block, lds,
                       pack(L.w, L.scales, x, y, res, norm_w, (uint32_t)L.out, (uint32_t)L.in,
                            (uint32_t)L.group, cfg.norm_eps, mu, (const void*)L.lora_vec,
                            (const void*)L.lora_b, (uint32_t)L.lora_cols, L.lora_scale));
@@ -911,16 +936,18 @@ mc_decoder_create(mc_device* dev, mc_library* lib, mc_queue* q, const mc_decoder
     d->n_own = c.layer_end - c.layer_begin;
     d->first_stage = c.layer_begin == 0;
     d->last_stage = c.layer_end == c.n_layers;
-    if (const char* e = getenv("MC_GEMV_BLOCK")) d->gemv_block = atoi(e);
-    if (const char* e = getenv("MC_GEMV_WGS_PER_CU")) d->gemv_wgs_per_cu = atoi(e);
+    if (const char* e = getenv("MC_GEMV_BLOCK")) { d->gemv_block = atoi(e); d->gemv_block_env = true; }
+    if (const char* e = getenv("MC_GEMV_WGS_PER_CU")) { d->gemv_wgs_per_cu = atoi(e); d->gemv_block_env = true; }
     if (const char* e = getenv("MC_GEMV_DBG")) d->dbg_variant = atoi(e);
+    if (const char* e = getenv("MC_GEMV_FULLGRID")) d->gemv_full_grid = atoi(e) != 0;
+    if (const char* e = getenv("MC_GEMV_LIN")) d->gemv_lin = atoi(e) != 0;
     if (const char* e = getenv("MC_GEMMA_UNFUSED")) d->gemma_fuse = atoi(e) == 0;
     if (const char* e = getenv("MC_GEMV_M4")) d->gemv_m4 = atoi(e);
     if (const char* e = getenv("MC_PV_BLOCK")) d->pv_block = atoi(e);
     if (const char* e = getenv("MC_SAMPLER_BLOCK")) d->sampler_block = atoi(e);
     if (d->sampler_block % 64 || d->sampler_block < 256 || d->sampler_block > 1024) d->sampler_block = 1024;
     if (d->pv_block % 64 || d->pv_block < 256 || d->pv_block > 1024) d->pv_block = 1024;
-    if (d->gemv_block % 64 || d->gemv_block < 64 || d->gemv_block > 512) d->gemv_block = 256;
+    if (d->gemv_block % 64 || d->gemv_block < 64 || d->gemv_block > 1024) d->gemv_block = 256;
     if (d->gemv_wgs_per_cu < 1) d->gemv_wgs_per_cu = 2;
 
     const size_t tb = d->tb;
@@ -1557,6 +1584,43 @@ mc_decoder_export_kv(mc_decoder* d, int32_t layer, void* keys, void* values, int
     (void)hipFree(vtmp);
     if (s != MC_OK) return s;
     if (e != hipSuccess) return hip_fail(e, "mc_decoder_export_kv");
+    return MC_OK;
+}
+
+mc_status
+mc_decoder_import_kv(mc_decoder* d, int32_t layer, const void* keys, const void* values, int32_t n_valid)
+{
+    if (!d || !keys || !values) return fail(MC_ERR_INVALID_ARGUMENT, "mc_decoder_import_kv: null argument");
+    layer_w* L;
+    mc_status s = find_layer(d, layer, &L);
+    if (s != MC_OK) return s;
+    const mc_decoder_config& c = d->cfg;
+    if (n_valid < 1 || n_valid > c.max_seq_len)
+        return fail(MC_ERR_INVALID_ARGUMENT, "mc_decoder_import_kv: n_valid must lie in [1, max_seq_len]");
+    MC_HIP(hipSetDevice(d->dev->ordinal));
+    const size_t nb = (size_t)n_valid * c.n_kv_heads * c.head_dim * d->tb;
+    void *kt = nullptr, *vtmp = nullptr;
+    MC_HIP(hipMalloc(&kt, nb));
+    hipError_t e = hipMalloc(&vtmp, nb);
+    if (e == hipSuccess) e = hipMemcpy(kt, keys, nb, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(vtmp, values, nb, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        s = d->launch("mc_kv_import_" + d->tname, 512, 1, 1, 256, 0,
+                      pack(L->kc, L->vt, (const void*)kt, (const void*)vtmp, (uint32_t)n_valid, (uint32_t)c.n_kv_heads,
+                           (uint32_t)c.head_dim, (uint32_t)c.max_seq_len));
+        // the state of a decoder that has just decoded position n_valid - 1 on an unturned ring
+        if (s == MC_OK)
+            s = d->launch("mc_step_set", 1, 1, 1, 64, 0,
+                          pack(d->state, (int32_t)-1, (int32_t)(n_valid - 1), (int32_t)c.max_seq_len, (int32_t)d->pre_len,
+                               (int32_t)d->rope_start, (int32_t)1));
+        e = hipStreamSynchronize(d->stream);
+    }
+    (void)hipFree(kt);
+    (void)hipFree(vtmp);
+    if (e != hipSuccess) return hip_fail(e, "mc_decoder_import_kv");
+    if (s != MC_OK) return s;
+    d->ring_turned = false;
+    d->last_pos = n_valid - 1;
     return MC_OK;
 }
 

@@ -705,3 +705,32 @@ mc_kv_export_float(const float* kc, const float* vt, float* k_out, float* v_out,
 {
     kv_export_body(kc, vt, k_out, v_out, st, KV, hd, max_seq, pre_len);
 }
+
+// ------------------------------------------------------------------------------------------
+// Logical KV import (test aid, the inverse of mc_kv_export_* on an unturned ring): rows
+// in[p][kv][d], p in [0, n), go to the slots positions 0 .. n-1 occupy before any roll
+// (slot = p; include/metalchat/nn/cache.h:206-213).  The host resets the step state.
+// ------------------------------------------------------------------------------------------
+template <typename S>
+__device__ __forceinline__ void
+kv_import_body(S* kc, S* vt, const S* k_in, const S* v_in, uint32_t n, uint32_t KV, uint32_t hd, uint32_t max_seq)
+{
+    const size_t total = (size_t)n * KV * hd;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t d = i % hd, kv = (i / hd) % KV, p = i / ((size_t)hd * KV);
+        kc[((size_t)kv * max_seq + p) * hd + d] = k_in[i];
+        vt[((size_t)kv * hd + d) * max_seq + p] = v_in[i];
+    }
+}
+extern "C" __global__ void
+mc_kv_import_bfloat(bf16_t* kc, bf16_t* vt, const bf16_t* k_in, const bf16_t* v_in, uint32_t n, uint32_t KV, uint32_t hd,
+                    uint32_t max_seq)
+{
+    kv_import_body(kc, vt, k_in, v_in, n, KV, hd, max_seq);
+}
+extern "C" __global__ void
+mc_kv_import_float(float* kc, float* vt, const float* k_in, const float* v_in, uint32_t n, uint32_t KV, uint32_t hd,
+                   uint32_t max_seq)
+{
+    kv_import_body(kc, vt, k_in, v_in, n, KV, hd, max_seq);
+}

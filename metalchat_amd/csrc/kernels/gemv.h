@@ -28,6 +28,8 @@
 
 #include "common.h"
 
+#include <type_traits>
+
 namespace mc {
 namespace gemv {
 
@@ -323,6 +325,30 @@ mac4d(mf_f4& acc, const uint4& w, const m4d_scale& sc, const uint2 (&x)[8])
     }
 }
 
+// mac4d with the eight accumulating MFMAs of a packet dealt over NA independent accumulators (the caller adds them up
+// when the row is complete): one accumulator is one dependency chain through the matrix pipe.
+template <int NA>
+__device__ __forceinline__ void
+mac4d_n(mf_f4 (&acc)[NA], const uint4& w, const m4d_scale& sc, const uint2 (&x)[8])
+{
+    const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
+    const mf_s4 bs = __builtin_bit_cast(mf_s4, sc.b);
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        const uint32_t v = ws[d];
+        const uint32_t t0 = (v & 0x000F000Fu) | 0x43004300u, t1 = ((v >> 4) & 0x000F000Fu) | 0x43004300u;
+        const uint32_t t2 = ((v >> 8) & 0x000F000Fu) | 0x43004300u, t3 = ((v >> 12) & 0x000F000Fu) | 0x43004300u;
+        const mf_f4 d1 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(mf_s4, make_uint2(t0, t1)), bs, sc.c, 0, 0, 0);
+        const mf_f4 d2 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(mf_s4, make_uint2(t2, t3)), bs, sc.c, 0, 0, 0);
+        const uint2 a0 = make_uint2(pack_bf16x2(d1[0], d1[1]), pack_bf16x2(d1[2], d1[3]));
+        const uint2 a1 = make_uint2(pack_bf16x2(d2[0], d2[1]), pack_bf16x2(d2[2], d2[3]));
+        mf_f4& A0 = acc[(2 * d) % NA];
+        mf_f4& A1 = acc[(2 * d + 1) % NA];
+        A0 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(mf_s4, a0), __builtin_bit_cast(mf_s4, x[2 * d]), A0, 0, 0, 0);
+        A1 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(mf_s4, a1), __builtin_bit_cast(mf_s4, x[2 * d + 1]), A1, 0, 0, 0);
+    }
+}
+
 // (The same substitution on int8-held and plain bfloat weights changes nothing -- 984 vs 988 and 390
 // vs 392 tokens/s: those kernels wait for memory, not for the VALU -- so only int4 takes it.)
 // I4, T = float: Wd = fl(float(q) * s), the reference's float(q) * float(s)
@@ -437,9 +463,10 @@ template <int R> struct tile {
 };
 
 // ------------------------------------------------------------------------------------------
-// The kernel body.  blockDim.x = 64 * waves; dynamic LDS = round16(in * sizeof(T)) + 64.
+// The kernel body.  blockDim.x = 64 * waves; dynamic LDS = round16(in * sizeof(T)) + 128.
 // ------------------------------------------------------------------------------------------
-template <int WF, typename T, int QM, int PRO, int EPI, int R>
+// LNCH / LTP != 0 select the LINEAR-ORDER main loop (int4, bfloat, Q_M4D only; rows of LNCH whole KiB): see below.
+template <int WF, typename T, int QM, int PRO, int EPI, int R, int LNCH = 0, int LTP = 0>
 __device__ __forceinline__ void
 body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __restrict__ xp,
      void* __restrict__ yp, const void* __restrict__ resp, const void* __restrict__ normp,
@@ -464,7 +491,7 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const uint32_t nchunks = (in + CHUNK - 1) / CHUNK;
-    // LDS: the activation row, zero-padded to a whole number of chunks, then 16 floats of scratch
+    // LDS: the activation row, zero-padded to a whole number of chunks, then 32 floats of scratch
     char* xs = smem;
     float* red = reinterpret_cast<float*>(smem + (size_t)nchunks * CHUNK_LDS);
 
@@ -549,74 +576,71 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
         }
     };
 
-    // ---- epilogue of row group crg from its four row sums (wave-uniform values in tot[])
-    auto finish = [&](uint32_t crg, float (&tot)[R]) {
+    // ---- epilogue of ONE row pair (rows 2 pair, 2 pair + 1) from its two fp32 row sums; executed by a single lane.
+    // The pair is the unit every epilogue works on: (w1 row j, w3 row j) of the fused ffn matrix, the two RoPE
+    // partners of a q / k head (stored adjacently), or simply two rows.
+    auto finish_pair = [&](uint32_t pair, float a, float b) {
+        const uint32_t row = 2 * pair;
+        if (row >= out_rows) return;
+        const bool two = row + 1 < out_rows;
         if (lora_rank) {
             // quantization::lora_linear (quantization/lora.h:119-121):
             //   result = T(T(x Wd^T) + T(T(B (A x)) * scale)),  A x already rounded to T by the
-            // adaptor launch that ran before this one.  Lane r finishes the adaptation of row r;
-            // B is stored in the fused row order, [out][lora_rank] with zeros outside the
-            // columns of the row's own adaptor (wq|wk|wv and w1/w3 keep separate adaptors).
-            const uint32_t row = crg * R + lane;
-            float ad = 0.0f;
-            if (lane < (uint32_t)R && row < out_rows) {
-                const S* av = static_cast<const S*>(lora_ap);
-                const S* bv = static_cast<const S*>(lora_bp) + (size_t)row * lora_rank;
-                float p = 0.0f;
-                for (uint32_t i = 0; i < lora_rank; i++) p += T::ld(av[i]) * T::ld(bv[i]);
-                ad = T::rt(T::rt(p) * T::rt(lora_scale));
-            }
-#pragma unroll
-            for (int r = 0; r < R; r++) {
-                const float adr = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ad), r));
-                tot[r] = T::rt(T::rt(tot[r]) + adr);
+            // adaptor launch that ran before this one.  B is stored in the fused row order,
+            // [out][lora_rank] with zeros outside the columns of the row's own adaptor (wq|wk|wv and
+            // w1/w3 keep separate adaptors).
+            const S* av = static_cast<const S*>(lora_ap);
+            const S* bv = static_cast<const S*>(lora_bp) + (size_t)row * lora_rank;
+            float pa = 0.0f, pb = 0.0f;
+            for (uint32_t i = 0; i < lora_rank; i++) pa += T::ld(av[i]) * T::ld(bv[i]);
+            a = T::rt(T::rt(a) + T::rt(T::rt(pa) * T::rt(lora_scale)));
+            if (two) {
+                for (uint32_t i = 0; i < lora_rank; i++) pb += T::ld(av[i]) * T::ld(bv[lora_rank + i]);
+                b = T::rt(T::rt(b) + T::rt(T::rt(pb) * T::rt(lora_scale)));
             }
         }
         S* y = static_cast<S*>(yp);
         if (EPI == EPI_STORE || EPI == EPI_RESID) {
-            // lane r finishes row r
-            const float mine = lane == 0 ? tot[0] : (lane == 1 ? tot[1] : (lane == 2 ? tot[2] : tot[3]));
-            const uint32_t row = crg * R + lane;
-            if (lane < (uint32_t)R && row < out_rows) {
-                float v = T::rt(mine);
-                if (EPI == EPI_RESID) v = T::ld(static_cast<const S*>(resp)[row]) + v; // add in T
-                y[row] = T::st(v);
+            float va = T::rt(a), vb = T::rt(b);
+            if (EPI == EPI_RESID) { // add in T
+                va = T::ld(static_cast<const S*>(resp)[row]) + va;
+                if (two) vb = T::ld(static_cast<const S*>(resp)[row + 1]) + vb;
             }
+            y[row] = T::st(va);
+            if (two) y[row + 1] = T::st(vb);
         } else if (EPI == EPI_QKV_ROPE) {
             const qkv_epilogue* q = static_cast<const qkv_epilogue*>(resp);
             const uint32_t H = q->H, KV = q->KV, hd = q->hd, half = hd / 2, ms = q->max_seq;
             const uint32_t slot = (uint32_t)q->state[3], rrow = (uint32_t)q->state[6];
-            const uint32_t row0 = crg * R;
-            if (row0 < (H + KV) * hd) {
-                // two rotation pairs: lane 0 -> rows (0,1), lane 1 -> rows (2,3)
-                const float x1 = T::rt(lane == 0 ? tot[0] : tot[2]);
-                const float x2 = T::rt(lane == 0 ? tot[1] : tot[3]);
-                const uint32_t prow = row0 + 2 * lane;         // packed row of x1
-                const uint32_t head = prow / hd, j = (prow % hd) / 2;
-                if (lane < 2) {
-                    const float c = q->fcos[(size_t)rrow * half + j], sn = q->fsin[(size_t)rrow * half + j];
-                    const S o1 = T::st(c * x1 - sn * x2), o2 = T::st(sn * x1 + c * x2);
-                    S* dst = head < H ? static_cast<S*>(q->q_out) + (size_t)head * hd
-                                      : static_cast<S*>(q->kc) + ((size_t)(head - H) * ms + slot) * hd;
-                    dst[j] = o1;
-                    dst[j + half] = o2;
-                }
-            } else if (lane < (uint32_t)R) {
-                const float mine = lane == 0 ? tot[0] : (lane == 1 ? tot[1] : (lane == 2 ? tot[2] : tot[3]));
-                const uint32_t vrow = row0 + lane - (H + KV) * hd; // kv*hd + d
-                static_cast<S*>(q->vt)[(size_t)vrow * ms + slot] = T::st(mine);
+            if (row < (H + KV) * hd) {
+                // a rotation pair: packed rows (2j, 2j + 1) of a head = natural (j, j + hd/2)
+                const float x1 = T::rt(a), x2 = T::rt(b);
+                const uint32_t head = row / hd, j = (row % hd) / 2;
+                const float c = q->fcos[(size_t)rrow * half + j], sn = q->fsin[(size_t)rrow * half + j];
+                const S o1 = T::st(c * x1 - sn * x2), o2 = T::st(sn * x1 + c * x2);
+                S* dst = head < H ? static_cast<S*>(q->q_out) + (size_t)head * hd
+                                  : static_cast<S*>(q->kc) + ((size_t)(head - H) * ms + slot) * hd;
+                dst[j] = o1;
+                dst[j + half] = o2;
+            } else {
+                const uint32_t vrow = row - (H + KV) * hd; // kv*hd + d
+                static_cast<S*>(q->vt)[(size_t)vrow * ms + slot] = T::st(a);
+                if (two) static_cast<S*>(q->vt)[(size_t)(vrow + 1) * ms + slot] = T::st(b);
             }
-        } else {
-            // rows (2j, 2j+1) = (w1 row j, w3 row j): out[j] = T(act(T(w1 x)) * T(w3 x));
-            // lane 0 finishes pair 0, lane 1 pair 1 (one activation evaluation per wave)
-            const float a = T::rt(lane == 0 ? tot[0] : tot[2]);
-            const float b = T::rt(lane == 0 ? tot[1] : tot[3]);
-            const uint32_t row = crg * R + 2 * lane;
-            if (lane < 2 && row + 1 < out_rows) {
-                const float g = EPI == EPI_SILU_MUL ? silu_T<T>(a) : T::rt(gelu_f32(a));
-                y[row / 2] = T::st(g * b);
-            }
+        } else if (two) {
+            // (w1 row j, w3 row j): out[j] = T(act(T(w1 x)) * T(w3 x))
+            const float ga = T::rt(a), gb = T::rt(b);
+            const float g = EPI == EPI_SILU_MUL ? silu_T<T>(ga) : T::rt(gelu_f32(ga));
+            y[pair] = T::st(g * gb);
         }
+    };
+    // ---- epilogue of row group crg from its four row sums (wave-uniform values in tot[]): lane 0 finishes rows
+    // (0, 1), lane 1 rows (2, 3).  (The sums are pinned in VGPRs first: left as array elements, hipcc turns a select
+    // chain over them into tot[lane] -- scratch stores and an indexed scratch load per row group.)
+    auto finish = [&](uint32_t crg, float (&tot)[R]) {
+        float p0 = tot[0], p1 = tot[1], p2 = tot[2], p3 = tot[3];
+        asm volatile("" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3));
+        if (lane < 2) finish_pair(2 * crg + lane, lane == 0 ? p0 : p2, lane == 0 ? p1 : p3);
     };
 
     // Tile cursor (scalar): the wave walks (row group, chunk) pairs; row groups are dealt
@@ -630,7 +654,10 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
             k.rg += stride;
         }
     };
-    const uint32_t first_rg = blockIdx.x * nwaves + wave;
+#ifndef MC_GEMV_WAVEMAJOR
+#define MC_GEMV_WAVEMAJOR 0 // 1: row group = wave * gridDim.x + workgroup -- a matrix with fewer row groups than waves still
+#endif                      // puts work on every CU (A/B: tools/ring_ab.py)
+    const uint32_t first_rg = MC_GEMV_WAVEMAJOR ? wave * gridDim.x + blockIdx.x : blockIdx.x * nwaves + wave;
     cursor ld{first_rg, 0};
     cursor cp = ld;
     const uint32_t ntiles = first_rg < NG ? ((NG - first_rg + stride - 1) / stride) * nchunks : 0;
@@ -665,6 +692,10 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
                 }
             }
         }
+#ifndef MC_GEMV_XBAR
+#define MC_GEMV_XBAR 1 // 1: a raw s_barrier (no memory wait) between the row requests and the first weight requests: with one
+#endif                 // workgroup per CU every row packet is then AHEAD of every weight packet in the CU's in-order memory pipe
+        if (MC_GEMV_XBAR) asm volatile("s_barrier" ::: "memory");
         prefetch(); // the first weight tile(s): requested behind the row, before the row is consumed
         if (fits) {
 #pragma unroll
@@ -739,10 +770,10 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
                 if (blockIdx.x == 0 && p < npk) static_cast<uint4*>(pna->h_out)[p] = xr[i];
             }
             const float w2 = wave_sum_dpp(ss2);
-            if (lane == 0) red[8 + wave] = w2; // the second half of the scratch: no barrier between the two sums' readers and writers
+            if (lane == 0) red[16 + wave] = w2; // the second half of the scratch: no barrier between the two sums' readers and writers
             __syncthreads();
             float tot2 = 0.0f;
-            for (uint32_t i = 0; i < nwaves; i++) tot2 += red[8 + i];
+            for (uint32_t i = 0; i < nwaves; i++) tot2 += red[16 + i];
             const float inv2 = 1.0f / sqrtf(tot2 / (float)in + eps);
 #pragma unroll
             for (int i = 0; i < MAXP; i++) {
@@ -815,13 +846,234 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
 #ifndef MC_GEMV_PRE_P0
 #define MC_GEMV_PRE_P0 MC_GEMV_PRE // kernels without a norm prologue (Wo, w2)
 #endif
+    // ======================================================================================
+    // LINEAR-ORDER main loop (LNCH > 0).  Measured on MI355X (tools/lds_stream_lab, tools/lin_timeline.py):
+    //   * ONE launch streams a 67 MB matrix at 6.06 TB/s, launch boundary included, when every wave walks its own
+    //     CONTIGUOUS span with non-temporal 16-byte loads and 4 - 8 KiB in flight per wave; the classic loop below
+    //     (row groups dealt round-robin over all waves of the chip, a row group's K chunks visited one sweep
+    //     apart, default cache policy) streams the same bytes at 4.8 TB/s;
+    //   * a CU takes in at most ~25 GB/s, so what a launch costs is the LONGEST per-CU byte count: 3.5 row
+    //     groups per wave dealt as 3 and 4 made the 4-row-group waves finish 3 us after the others;
+    //   * an epilogue per row group (the fp64 exponential of SiLU evaluated by two lanes while 62 idle) cost
+    //     as much as two of its four tiles.
+    // So here
+    //   * the ROW PAIRS (the unit every epilogue works on) are cut into one contiguous range per wave, equal to
+    //     within one pair, adjacent ranges inside a workgroup;
+    //   * a tile is LTP consecutive KiB of ONE row -- the whole row when LTP == LNCH -- so the loads of a wave
+    //     sweep its range in pure address order; the loop body is one row group, fully unrolled (4 * LNCH / LTP
+    //     tiles) over a static register ring of LR tiles, with the halves of the first / last row group that
+    //     belong to a neighbour skipped (their loads read one broadcast line: loads stay unconditional);
+    //   * the scale quads of a row group ([ngroups][4] bf16, see the header) are requested one row group ahead;
+    //   * the row sums of the wave's pairs are parked in LDS and finished TOGETHER at the end, one lane per
+    //     pair (one activation / rotation evaluation per wave instead of one per row group);
+    //   * the activation row lives in REGISTERS for the whole kernel when it is at most two chunks (K <= 4096:
+    //     32 VGPRs), otherwise each piece gathers its 32 activations from LDS as before.
+    // Arithmetic is mac4d (exact, bit for bit the classic Q_M4D path per weight); only the order in which a
+    // row's fp32 partial sums are added differs (per lane: chunk after chunk of one row).
+    // ======================================================================================
+    if constexpr (LNCH > 0) {
+        static_assert(WF == WF_I4 && T::bytes == 2 && M4D, "linear order: int4 weights, bfloat rows, Q_M4D");
+        static_assert(LNCH % LTP == 0, "a row is a whole number of tiles");
+        constexpr int SUB = LNCH / LTP;       // tiles per row
+        constexpr int TPP = 2 * SUB;          // tiles per row pair
+#ifndef MC_GEMV_LIN_INFLIGHT
+#define MC_GEMV_LIN_INFLIGHT 4 // KiB in flight per wave: the ring holds two pairs when they fit, else one (A/B on MI355X, 8 waves per CU:
+                               // 4 KiB 16.2 us, 8 KiB 17.5 us on the 60 MB w1|w3 matrix -- a CU keeps ~32 KiB in flight whatever is asked)
+#endif
+        constexpr int LR = 2 * TPP * LTP <= MC_GEMV_LIN_INFLIGHT ? 2 * TPP : TPP; // ring slots (tiles)
+        constexpr bool XREG = LNCH <= 2;
+#ifndef MC_GEMV_LIN_NT
+#define MC_GEMV_LIN_NT 1
+#endif
+#ifndef MC_GEMV_LIN_STREAM
+#define MC_GEMV_LIN_STREAM 0 // tuning ablation: loads and epilogues only
+#endif
+#ifndef MC_GEMV_LIN_NOLOAD
+#define MC_GEMV_LIN_NOLOAD 0 // tuning ablation: tiles and scales synthesised in registers, no weight traffic
+#endif
+#ifndef MC_GEMV_LIN_TL
+#define MC_GEMV_LIN_TL 0 // tuning aid: per-wave s_memrealtime stamps (start, row staged, first 12 tiles, end) into `resp` (kernels whose epilogue ignores it)
+#endif
+#ifndef MC_GEMV_LIN_ACCS
+#define MC_GEMV_LIN_ACCS 1 // independent accumulators per row (the MFMAs of a packet dealt round-robin): 1 = one dependency chain
+#endif
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const uint32_t nw_total = gridDim.x * nwaves, gw = blockIdx.x * nwaves + wave;
+        const uint32_t NP = (out_rows + 1) / 2; // row pairs (the host takes this path only for even out_rows)
+        const uint32_t pb = (uint32_t)(((uint64_t)NP * gw) / nw_total);
+        const uint32_t pe = (uint32_t)(((uint64_t)NP * (gw + 1)) / nw_total);
+        const char* sbase = static_cast<const char*>(sp);
+
+        uint4 lring[LR][LTP];
+        uint32_t sa[LNCH], sb[LNCH]; // T(scale) of the pair's two rows per chunk: current pair, next pair
+        // tile t of pair pr: row 2 pr + t / SUB, KiB (t % SUB) * LTP ... of it.  Dead tiles read one broadcast line
+        // of the buffer base.  (live ? offset : 0 is written as a mask: given a select between two address
+        // computations hipcc builds a branch, and a load behind a branch costs every counted s_waitcnt vmcnt(N).)
+        auto ltile = [&](uint4 (&dst)[LTP], uint32_t pr, int t, bool live) {
+            const uint64_t m = 0ull - (uint64_t)live;
+            const uint64_t rbyte = (((uint64_t)pr * 2 + (uint64_t)(t / SUB)) * rowb + (uint64_t)(t % SUB) * LTP * 1024 + lane16) & m;
+            const char* a = wbase + rbyte;
+#pragma unroll
+            for (int p = 0; p < LTP; p++) {
+                if (MC_GEMV_LIN_NOLOAD) {
+                    dst[p] = make_uint4(lane * 0x01010101u + pr, (lane + pr) * 0x9E3779B9u, lane * 0x85EBCA6Bu + (uint32_t)(t * 0x11111111u),
+                                        (p + lane) * 0xC2B2AE35u + pr); // every dword differs per lane: nothing folds onto the scalar unit
+                    continue;
+                }
+                const u32x4* ap = reinterpret_cast<const u32x4*>(a + p * 1024);
+                const u32x4 v = MC_GEMV_LIN_NT ? __builtin_nontemporal_load(ap) : *ap;
+                dst[p] = make_uint4(v.x, v.y, v.z, v.w);
+            }
+        };
+        // scales of pair pr: half a row quad ([ngroups][4] bf16 per four rows) per chunk; the lane's 32 weights of
+        // chunk c sit in group (2048 c + 32 lane) / group
+        auto lscales = [&](uint32_t (&q)[LNCH], uint32_t pr, bool live) {
+            const uint64_t m = 0ull - (uint64_t)live;
+#pragma unroll
+            for (int c = 0; c < LNCH; c++) {
+                if (MC_GEMV_LIN_NOLOAD) {
+                    q[c] = 0x3C003C00u;
+                    continue;
+                }
+                const uint32_t g = group ? ((2048u * c + 32u * lane) >> glog) : 0u;
+                q[c] = *reinterpret_cast<const uint32_t*>(sbase + (((((uint64_t)(pr >> 1) * ngroups + g) * 4 + (pr & 1u) * 2) * 2) & m));
+            }
+        };
+
+        unsigned long long ltl[16];
+        uint32_t ltn = 2;
+        if (MC_GEMV_LIN_TL) ltl[0] = __builtin_amdgcn_s_memrealtime();
+        constexpr int U = LR / TPP; // pairs per unrolled iteration (1 or 2)
+        stage_x([&] {
+            lscales(sa, pb, pb < pe);
+#pragma unroll
+            for (int j = 0; j < LR; j++) ltile(lring[j], pb + j / TPP, j % TPP, pb + j / TPP < pe);
+        });
+        __syncthreads();
+        if (MC_GEMV_LIN_TL) ltl[1] = __builtin_amdgcn_s_memrealtime();
+
+        const uint32_t lane_tr = (((lane >> 4) * 4 + (lane & 3)) * 17 + ((lane >> 2) & 3) * 4) * 16;
+        const uint32_t m4d_mx = (lane & 3) == 0 ? 0x0000FFFFu : ((lane & 3) == 1 ? 0xFFFF0000u : 0u);
+        const uint32_t m4d_my = (lane & 3) == 2 ? 0x0000FFFFu : ((lane & 3) == 3 ? 0xFFFF0000u : 0u);
+        typedef __attribute__((address_space(3))) mf_s4 lds_s4;
+        auto xload = [&](uint2 (&x)[8], int c) {
+            lds_s4* xt = (lds_s4*)(xs + c * CHUNK_LDS + lane_tr);
+#pragma unroll
+            for (int i = 0; i < 8; i++) x[i] = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16(xt + i));
+        };
+        uint2 xr[XREG ? LNCH : 1][8];
+        if constexpr (XREG) {
+#pragma unroll
+            for (int c = 0; c < LNCH; c++) xload(xr[c], c);
+        }
+        // parked row sums: 64 pairs x (a, b) per wave, behind the reduction scratch
+        float2* park = reinterpret_cast<float2*>(red + 32) + wave * 64;
+        uint32_t parked = 0, park_first = pb;
+        auto flush = [&]() {
+            // one lane per parked pair (the LDS operations of a wave complete in order: no barrier needed)
+            if (lane < parked) {
+                const float2 v = park[lane];
+                finish_pair(park_first + lane, v.x, v.y);
+            }
+            park_first += parked;
+            parked = 0;
+        };
+
+        constexpr int NA = MC_GEMV_LIN_ACCS;
+        mf_f4 laccs[NA];
+#pragma unroll
+        for (int a = 0; a < NA; a++) laccs[a] = mf_f4{0, 0, 0, 0};
+        // one pair: TPP tiles out of ring slots [SLOT0, SLOT0 + TPP); every slot is refilled with the same tile of
+        // the pair U ahead as soon as it has been consumed.  Straight-line code: no branch, every load unconditional.
+        auto do_pair = [&](auto slot0, uint32_t pr) {
+            constexpr int SLOT0 = decltype(slot0)::value;
+            lscales(sb, pr + 1, pr + 1 < pe);
+            float ra = 0.f, rb = 0.f;
+#pragma unroll
+            for (int t = 0; t < TPP; t++) {
+                const int r = t / SUB, sidx = t % SUB, slot = SLOT0 + t;
+#pragma unroll
+                for (int p = 0; p < LTP; p++) {
+                    const int c = sidx * LTP + p;
+                    const uint32_t raw = sa[c];
+                    const uint32_t s2 = r ? ((raw & 0xFFFF0000u) | (raw >> 16)) : ((raw << 16) | (raw & 0xFFFFu));
+                    if (MC_GEMV_LIN_STREAM) {
+                        const uint4& w = lring[slot][p];
+                        laccs[0][0] += asf(((w.x ^ w.y ^ w.z ^ w.w) & 0x3FFFFFFFu) | (s2 & 1u));
+                    } else if constexpr (XREG) {
+                        mac4d_n<NA>(laccs, lring[slot][p], m4d_prepare(s2, m4d_mx, m4d_my), xr[c]);
+                    } else {
+                        uint2 x[8];
+                        xload(x, c);
+                        mac4d_n<NA>(laccs, lring[slot][p], m4d_prepare(s2, m4d_mx, m4d_my), x);
+                    }
+                }
+                ltile(lring[slot], pr + U, t, pr + U < pe);
+                if (MC_GEMV_LIN_TL) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int q = 2; q < 14; q++)
+                        if (ltn == (uint32_t)q) ltl[q] = now; // ltn is wave-uniform
+                    ltn++;
+                }
+                if (sidx == SUB - 1) {
+                    // the row is complete: element lane % 4 of the lane's four results is its own dot product
+                    const uint32_t e = lane & 3;
+                    mf_f4 lacc = laccs[0];
+#pragma unroll
+                    for (int a = 1; a < NA; a++) lacc += laccs[a];
+                    const float mine = e == 0 ? lacc[0] : (e == 1 ? lacc[1] : (e == 2 ? lacc[2] : lacc[3]));
+                    const float rs = wave_sum_dpp(MC_GEMV_LIN_STREAM ? lacc[0] : mine);
+                    if (r == 0) ra = rs;
+                    else rb = rs;
+#pragma unroll
+                    for (int a = 0; a < NA; a++) laccs[a] = mf_f4{0, 0, 0, 0};
+                }
+            }
+            if (lane == 0) park[parked] = make_float2(ra, rb);
+            parked++;
+            if (parked == 64) flush();
+#pragma unroll
+            for (int c = 0; c < LNCH; c++) sa[c] = sb[c];
+        };
+        uint32_t pr = pb;
+        for (; pr + U <= pe; pr += U) {
+            do_pair(std::integral_constant<int, 0>{}, pr);
+            if constexpr (U == 2) do_pair(std::integral_constant<int, TPP>{}, pr + 1);
+        }
+        if constexpr (U == 2) {
+            if (pr < pe) do_pair(std::integral_constant<int, 0>{}, pr); // odd count: the last pair sits in the first slots
+        }
+        flush();
+        if (MC_GEMV_LIN_TL && lane == 0) {
+            unsigned long long* tl = const_cast<unsigned long long*>(static_cast<const unsigned long long*>(resp));
+            const size_t o = ((size_t)blockIdx.x * nwaves + wave) * 16;
+            ltl[14] = __builtin_amdgcn_s_memrealtime();
+            unsigned xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            ltl[15] = ((unsigned long long)ltn << 32) | xcc;
+#pragma unroll
+            for (int q = 0; q < 16; q++) tl[o + q] = (q >= 2 && q < 14 && (uint32_t)q >= ltn) ? 0ull : ltl[q];
+        }
+        return;
+    }
+
     constexpr int PRE = PRO == PRO_NONE ? MC_GEMV_PRE_P0 : MC_GEMV_PRE;
+#ifndef MC_GEMV_ILV
+#define MC_GEMV_ILV 0 // 1: a raw s_barrier behind every tile requested ahead: the CU's in-order memory pipe then holds tile t of
+#endif                // every wave before tile t + 1 of any (a wave that queues its whole ring first starves its neighbours)
     stage_x([&] {
         load(ring[0], ld.rg, ld.c, 0 < ntiles);
         advance(ld);
 #pragma unroll
         for (int sl = 1; sl < RING; sl++)
-            if (PRE > sl) { load(ring[sl], ld.rg, ld.c, (uint32_t)sl < ntiles); advance(ld); }
+            if (PRE > sl) {
+                if (MC_GEMV_ILV) asm volatile("s_barrier" ::: "memory");
+                load(ring[sl], ld.rg, ld.c, (uint32_t)sl < ntiles);
+                advance(ld);
+            }
     });
     __syncthreads();
     if (TL) tl1 = __builtin_amdgcn_s_memrealtime();

@@ -10,8 +10,11 @@
 using namespace mc;
 using namespace mc::gemv;
 
+#ifndef MC_GEMV_LB
+#define MC_GEMV_LB 512 // largest workgroup the family is launched with (1024: 16 waves, at most 128 VGPRs)
+#endif
 #define MC_GEMV(NAME, WF, T, QM, PRO, EPI)                                                        \
-    extern "C" __global__ void __launch_bounds__(512)                                            \
+    extern "C" __global__ void __launch_bounds__(MC_GEMV_LB)                                          \
     NAME(const void* w, const void* scales, const void* x, void* y, const void* res,             \
          const void* norm_w, uint32_t out_rows, uint32_t in, uint32_t group, float eps, float mu, \
          const void* lora_a, const void* lora_b, uint32_t lora_rank, float lora_scale)            \
@@ -19,6 +22,27 @@ using namespace mc::gemv;
         body<WF, T, QM, PRO, EPI, 4>(w, scales, x, y, res, norm_w, out_rows, in, group, eps, mu,  \
                                      lora_a, lora_b, lora_rank, lora_scale);                      \
     }
+
+// linear-order variants (gemv.h): mc_gemv_i4_bfloat_lin{K/2048}_p{PRO}_e{EPI}, rows of K/2048 whole KiB
+#define MC_GEMV_LIN(NAME, NCH, TP, PRO, EPI)                                                      \
+    extern "C" __global__ void __launch_bounds__(MC_GEMV_LB)                                     \
+    NAME(const void* w, const void* scales, const void* x, void* y, const void* res,             \
+         const void* norm_w, uint32_t out_rows, uint32_t in, uint32_t group, float eps, float mu, \
+         const void* lora_a, const void* lora_b, uint32_t lora_rank, float lora_scale)            \
+    {                                                                                             \
+        body<WF_I4, BF, Q_M4D, PRO, EPI, 4, NCH, TP>(w, scales, x, y, res, norm_w, out_rows, in,  \
+                                                     group, eps, mu, lora_a, lora_b, lora_rank,   \
+                                                     lora_scale);                                 \
+    }
+#define MC_GEMV_LIN_SET(PFX, NCH, TP)       \
+    MC_GEMV_LIN(PFX##_p0_e0, NCH, TP, 0, 0) \
+    MC_GEMV_LIN(PFX##_p1_e0, NCH, TP, 1, 0) \
+    MC_GEMV_LIN(PFX##_p0_e1, NCH, TP, 0, 1) \
+    MC_GEMV_LIN(PFX##_p1_e2, NCH, TP, 1, 2) \
+    MC_GEMV_LIN(PFX##_p1_e3, NCH, TP, 1, 3) \
+    MC_GEMV_LIN(PFX##_p1_e4, NCH, TP, 1, 4) \
+    MC_GEMV_LIN(PFX##_p2_e0, NCH, TP, 2, 0) \
+    MC_GEMV_LIN(PFX##_p2_e3, NCH, TP, 2, 3)
 
 #define MC_GEMV_SET(PFX, WF, T, QM)            \
     MC_GEMV(PFX##_p0_e0, WF, T, QM, 0, 0)      \
@@ -39,6 +63,12 @@ MC_GEMV_SET(mc_gemv_i8_bfloat, WF_I8, BF, Q_EXACT)
 MC_GEMV_SET(mc_gemv_i8_float, WF_I8, F32, Q_EXACT)
 MC_GEMV_SET(mc_gemv_w_bfloat, WF_T, BF, Q_EXACT)
 MC_GEMV_SET(mc_gemv_w_float, WF_T, F32, Q_EXACT)
+
+MC_GEMV_LIN_SET(mc_gemv_i4_bfloat_lin1, 1, 1)   // K = 2048
+MC_GEMV_LIN_SET(mc_gemv_i4_bfloat_lin2, 2, 2)   // K = 4096
+MC_GEMV_LIN_SET(mc_gemv_i4_bfloat_lin4, 4, 4)   // K = 8192
+MC_GEMV_LIN_SET(mc_gemv_i4_bfloat_lin7, 7, 7)   // K = 14336
+MC_GEMV_LIN_SET(mc_gemv_i4_bfloat_lin14, 14, 7) // K = 28672
 
 // tuning ablations (not used by the product path): stream-only and compute-only variants
 MC_GEMV(mc_gemv_i4_bfloat_dbgstream_p1_e2, WF_I4, BF, Q_DBG_STREAM, 1, 2)

@@ -121,6 +121,7 @@ def capi() -> C.CDLL:
         "mc_decoder_get_logits": (i32, [vp, vp]),
         "mc_decoder_get_hidden": (i32, [vp, i32, vp]),
         "mc_decoder_export_kv": (i32, [vp, i32, vp, vp, C.POINTER(i32)]),
+        "mc_decoder_import_kv": (i32, [vp, i32, vp, vp, i32]),
         "mc_decoder_weight_bytes": (sz, [vp]),
         "mc_decoder_time_gemv": (i32, [vp, C.c_char_p, i32, C.POINTER(f32), C.POINTER(C.c_double),
                                        C.POINTER(i32)]),
@@ -600,6 +601,13 @@ class Decoder:
         n = C.c_int32()
         _check(capi().mc_decoder_export_kv(self._h, layer, _np_ptr(k), _np_ptr(v), C.byref(n)))
         return k[: n.value], v[: n.value]
+
+    def import_kv(self, layer: int, keys: np.ndarray, values: np.ndarray):
+        """Test aid: logical rows [n, n_kv_heads, head_dim] of T become positions 0 .. n-1 of `layer`'s cache."""
+        k = np.ascontiguousarray(keys, dtype=self.np_T)
+        v = np.ascontiguousarray(values, dtype=self.np_T)
+        assert k.shape == v.shape and k.shape[1:] == (self.cfg["n_kv_heads"], self.cfg["head_dim"])
+        _check(capi().mc_decoder_import_kv(self._h, layer, _np_ptr(k), _np_ptr(v), k.shape[0]))
 
     def weight_bytes(self) -> int:
         return capi().mc_decoder_weight_bytes(self._h)

@@ -1287,6 +1287,21 @@ mco_model_get_hidden(const mco_model* m, int32_t layer, void* out)
     for (int32_t j = 0; j < m->opt.dim; j++) st(m->opt.dtype, out, (size_t)j, src[j]);
 }
 
+/* Test aid (no reference counterpart): fill layer `layer`'s cache with n logical rows [n, n_kv, hd] of T,
+ * as if positions 0 .. n-1 had been decoded -- what sink_cache::copy's first branch leaves behind
+ * (nn/cache.h:206-213).  Lets a parity test start at the benchmark's context length without
+ * thousands of oracle steps; the GPU side takes the same rows through mc_decoder_import_kv. */
+int32_t
+mco_model_set_kv(mco_model* m, int32_t layer, const void* keys, const void* values, int32_t n)
+{
+    if (n < 0 || n > m->opt.max_seq_len || layer < 0 || layer >= m->opt.n_layers) return -1;
+    const size_t rb = (size_t)m->opt.n_kv_heads * m->opt.head_dim * m->esz;
+    memcpy(m->k_cache[layer], keys, (size_t)n * rb);
+    memcpy(m->v_cache[layer], values, (size_t)n * rb);
+    m->end_pos[layer] = n;
+    return n;
+}
+
 int32_t
 mco_model_get_kv(const mco_model* m, int32_t layer, void* keys_out, void* values_out)
 {

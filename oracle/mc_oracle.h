@@ -175,6 +175,8 @@ void mco_model_get_hidden(const mco_model* m, int32_t layer, void* out_T_dim);
 /* Logical KV view of layer `layer` after the last step: [n_valid, n_kv_heads, head_dim] of T,
  * returns n_valid (end_pos). */
 int32_t mco_model_get_kv(const mco_model* m, int32_t layer, void* keys_out, void* values_out);
+/* test aid: inject n logical cache rows [n, n_kv, hd] of T (positions 0 .. n-1) */
+int32_t mco_model_set_kv(mco_model* m, int32_t layer, const void* keys, const void* values, int32_t n);
 void mco_set_num_threads(int n);
 
 #ifdef __cplusplus

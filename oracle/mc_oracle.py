@@ -47,6 +47,7 @@ def lib() -> C.CDLL:
         _lib.mco_model_forward.restype = C.c_int32
         _lib.mco_model_step_range.restype = C.c_int32
         _lib.mco_model_get_kv.restype = C.c_int32
+        _lib.mco_model_set_kv.restype = C.c_int32
         # small test shapes: a handful of threads beats one OpenMP team per host core
         _lib.mco_set_num_threads(C.c_int(min(8, os.cpu_count() or 1)))
     return _lib
@@ -368,6 +369,13 @@ class Model:
         v = np.zeros(shape, dtype=np_dtype(c["dtype"]))
         n = lib().mco_model_get_kv(self._h, C.c_int32(layer), _p(k), _p(v))
         return k[:n], v[:n]
+
+    def set_kv(self, layer: int, keys: np.ndarray, values: np.ndarray):
+        """Test aid: logical rows [n, n_kv, hd] of T become positions 0 .. n-1 of `layer`'s cache."""
+        k = np.ascontiguousarray(keys, dtype=np_dtype(self.cfg["dtype"]))
+        v = np.ascontiguousarray(values, dtype=np_dtype(self.cfg["dtype"]))
+        n = lib().mco_model_set_kv(self._h, C.c_int32(layer), _p(k), _p(v), C.c_int32(k.shape[0]))
+        assert n == k.shape[0]
 
     def close(self):
         if self._h:

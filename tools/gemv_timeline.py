@@ -30,7 +30,7 @@ for which, kname in (("w13", "mc_gemv_i4_bfloat_dbgtl4d_p1_e2"), ("w2", "mc_gemv
             lds = (inf + 2047) // 2048 * 2048 * 2
             if "4d" in kname:
                 lds = lds // 16 * 17
-            lds += 64
+            lds += 128
             t = mc.KernelTask(k, (wgs * block, 1, 1), (block, 1, 1),
                               [acc.wrap(wptr, 1 << 40), acc.wrap(sptr, 1 << 40), x, y, tl, nw,
                                np.uint32(rows), np.uint32(inf), np.uint32(128), np.float32(1e-5), np.float32(0),
