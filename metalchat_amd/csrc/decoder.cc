@@ -28,7 +28,7 @@ namespace {
 constexpr int PB = 64; // cache slots per attention-scores workgroup (decode_kernels.hip)
 
 struct step_state_h {
-    int32_t token, pos, kv_len, write_slot, ring_base, step_index, rope_row, rolled;
+    int32_t token, pos, kv_len, write_slot, ring_base, step_index, rope_row, rolled, rope_start, pad[3];
 };
 
 struct linear_w {
@@ -256,8 +256,7 @@ struct mc_decoder {
     ~mc_decoder()
     {
         (void)hipSetDevice(dev->ordinal);
-        if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
-        if (graph) (void)hipGraphDestroy(graph);
+        drop_graph();
         for (void* p : allocs) (void)hipFree(p);
     }
 
@@ -269,8 +268,33 @@ struct mc_decoder {
             return fail(MC_ERR_ALLOC, std::string("hardware_memory_allocator: failed to allocate ") +
                                           std::to_string(bytes) + " bytes: " + hipGetErrorString(e));
         allocs.push_back(*p);
-        if (zero) MC_HIP(hipMemsetAsync(*p, 0, bytes ? bytes : 16, stream));
+        if (zero) {
+            // complete before alloc returns: callers fill some of these buffers with synchronous copies on the null
+            // stream, which is not ordered against this (non-blocking, or adopted) stream
+            MC_HIP(hipMemsetAsync(*p, 0, bytes ? bytes : 16, stream));
+            MC_HIP(hipStreamSynchronize(stream));
+        }
         return MC_OK;
+    }
+
+    // give a buffer of the arena back (the caller has synchronised the stream)
+    void
+    release(void** p)
+    {
+        if (!*p) return;
+        auto it = std::find(allocs.begin(), allocs.end(), *p);
+        if (it != allocs.end()) allocs.erase(it);
+        (void)hipFree(*p);
+        *p = nullptr;
+    }
+
+    void
+    drop_graph()
+    {
+        if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
+        if (graph) (void)hipGraphDestroy(graph);
+        graph_exec = nullptr;
+        graph = nullptr;
     }
 
     mc_status
@@ -512,7 +536,9 @@ struct mc_decoder {
             if (s != MC_OK) return s;
         }
         rope_valid = true;
-        return MC_OK;
+        // the window start lives in the step state: a captured mc_step_advance reads it there, so a graph captured
+        // under another window stays valid
+        return launch("mc_step_rope", 1, 1, 1, 64, 0, pack(state, (int32_t)rope_start));
     }
 
     mc_status
@@ -685,8 +711,12 @@ struct mc_decoder {
         const int H = cfg.n_heads, KV = cfg.n_kv_heads, hd = cfg.head_dim;
         mc_status s;
         if (M > pf_cap) {
-            const int cap = std::max(M, 64);
+            // grow geometrically in whole 128-row tiles and give the superseded buffers back: a chat whose prompts
+            // grow a little every turn must not strand a set of row buffers per turn
+            const int cap = std::min(std::max({M, 2 * pf_cap, 128}), std::max(M, cfg.max_seq_len)) + 127 & ~127;
+            MC_HIP(hipStreamSynchronize(stream));
 #define A(ptr, bytes)                         \
+    release((void**)&(ptr));                  \
     s = alloc((void**)&(ptr), (bytes), true); \
     if (s != MC_OK) return s;
             A(pf_x, (size_t)cap * cfg.dim * tb);
@@ -704,6 +734,8 @@ struct mc_decoder {
         }
         const size_t need = (tb == 2 && !pf_two_pass) ? 0 : (size_t)H * M * S;
         if (need > pf_probs_elems) {
+            MC_HIP(hipStreamSynchronize(stream));
+            release(&pf_probs);
             s = alloc(&pf_probs, need * tb, false);
             if (s != MC_OK) return s;
             pf_probs_elems = need;
@@ -718,6 +750,8 @@ struct mc_decoder {
         if (L.lora_cols) {
             // la = T(X A^T): the stacked adaptor inputs, [M][nseg * rank]
             if ((size_t)M * L.lora_cols > pf_lora_elems) {
+                MC_HIP(hipStreamSynchronize(stream));
+                release(&pf_lora);
                 mc_status s = alloc(&pf_lora, (size_t)M * L.lora_cols * tb, false);
                 if (s != MC_OK) return s;
                 pf_lora_elems = (size_t)M * L.lora_cols;
@@ -745,6 +779,8 @@ struct mc_decoder {
             if (splits > 1 && !getenv("MC_PF_NO_SPLITK")) {
                 const size_t need = (size_t)splits * M * L.out;
                 if (need > pf_part_elems) {
+                    MC_HIP(hipStreamSynchronize(stream));
+                    release((void**)&pf_part);
                     mc_status s = alloc((void**)&pf_part, need * 4, false);
                     if (s != MC_OK) return s;
                     pf_part_elems = need;
@@ -1044,8 +1080,7 @@ mc_decoder_set_sampler(mc_decoder* d, int32_t kind, int32_t top_k, float tempera
             return fail(MC_ERR_INVALID_ARGUMENT, "topk_sampler: the fused sampler keeps 1..128 candidates");
         if (!d->last_stage) return fail(MC_ERR_INVALID_ARGUMENT, "decoder: only the last stage samples");
         MC_HIP(hipSetDevice(d->dev->ordinal));
-        if (d->graph_exec) { (void)hipGraphExecDestroy(d->graph_exec); d->graph_exec = nullptr; }
-        if (d->graph) { (void)hipGraphDestroy(d->graph); d->graph = nullptr; }
+        d->drop_graph();
         const uint32_t chunks = ((uint32_t)d->cfg.vocab + 2047u) / 2048u;
         if (!d->cand) {
             mc_status s = d->alloc((void**)&d->cand, (size_t)chunks * 128 * 8);
@@ -1058,9 +1093,8 @@ mc_decoder_set_sampler(mc_decoder* d, int32_t kind, int32_t top_k, float tempera
         d->top_k = top_k;
         d->inv_temp_T = rt(1.0f / rt(temperature)); // T temp = T(1) / _M_temperature  (sampling.h:190)
         d->top_p_T = rt(top_p);
-    } else if (d->graph_exec) {
-        (void)hipGraphExecDestroy(d->graph_exec);
-        d->graph_exec = nullptr;
+    } else {
+        d->drop_graph();
     }
     d->sampler_kind = kind;
     return MC_OK;
@@ -1073,13 +1107,13 @@ mc_decoder_set_seeds(mc_decoder* d, const uint64_t* seeds, int32_t n_pairs)
     if (n_pairs < 0) return fail(MC_ERR_INVALID_ARGUMENT, "mc_decoder_set_seeds: negative count");
     MC_HIP(hipSetDevice(d->dev->ordinal));
     if (n_pairs > d->seed_cap) {
-        if (d->graph_exec) { (void)hipGraphExecDestroy(d->graph_exec); d->graph_exec = nullptr; } // pointer changes
+        d->drop_graph(); // pointer changes
         mc_status s = d->alloc((void**)&d->seeds, (size_t)n_pairs * 16);
         if (s != MC_OK) return s;
         d->seed_cap = n_pairs;
     }
     if (n_pairs) MC_HIP(hipMemcpy(d->seeds, seeds, (size_t)n_pairs * 16, hipMemcpyHostToDevice));
-    if (n_pairs != d->n_seed_pairs && d->graph_exec) { (void)hipGraphExecDestroy(d->graph_exec); d->graph_exec = nullptr; }
+    if (n_pairs != d->n_seed_pairs) d->drop_graph();
     d->n_seed_pairs = n_pairs;
     return MC_OK;
 }
@@ -1379,6 +1413,9 @@ mc_decoder_step(mc_decoder* d, int32_t token, int32_t start_pos, const void* hid
     mc_status s = check_ready(d);
     if (s != MC_OK) return s;
     if (start_pos < 0) return fail(MC_ERR_INVALID_ARGUMENT, "decoder: negative start position");
+    // token < 0 keeps the token the previous step left in the state (and means nothing to a later stage)
+    if (d->first_stage && token >= d->cfg.vocab)
+        return fail(MC_ERR_INVALID_ARGUMENT, "decoder: token id outside the vocabulary");
     if (!d->first_stage && !hidden_in)
         return fail(MC_ERR_INVALID_ARGUMENT, "decoder: a non-first stage needs the inbound hidden row");
     MC_HIP(hipSetDevice(d->dev->ordinal));
@@ -1456,6 +1493,8 @@ mc_decoder_generate(mc_decoder* d, int32_t first_token, int32_t start_pos, int32
     if (!d->first_stage || !d->last_stage)
         return fail(MC_ERR_INVALID_ARGUMENT, "mc_decoder_generate: single-stage decoders only");
     if (n > d->tokens_cap) return fail(MC_ERR_INVALID_ARGUMENT, "mc_decoder_generate: n too large");
+    if (first_token >= d->cfg.vocab) return fail(MC_ERR_INVALID_ARGUMENT, "decoder: token id outside the vocabulary");
+    if (start_pos < 0) return fail(MC_ERR_INVALID_ARGUMENT, "decoder: negative start position");
     mc_status s = check_ready(d);
     if (s != MC_OK) return s;
     MC_HIP(hipSetDevice(d->dev->ordinal));
@@ -1473,16 +1512,14 @@ mc_decoder_generate(mc_decoder* d, int32_t first_token, int32_t start_pos, int32
     if (s != MC_OK) return s;
     for (int i = 1; i < n; i++) {
         const int pos = start_pos + i;
-        const int old_start = d->rope_start;
-        s = d->ensure_rope(pos);
+        s = d->ensure_rope(pos); // moves the table window when pos leaves it (the step state carries the new start)
         if (s != MC_OK) return s;
-        const bool rope_moved = d->rope_start != old_start;
-        if (d->cfg.use_graph && !rope_moved) {
+        if (d->cfg.use_graph) {
             if (!d->graph_exec) {
+                d->drop_graph();
                 MC_HIP(hipStreamBeginCapture(d->stream, hipStreamCaptureModeGlobal));
                 s = d->launch("mc_step_advance", 1, 1, 1, 64, 0,
-                              pack(d->state, (int32_t)d->cfg.max_seq_len, (int32_t)d->pre_len,
-                                   (int32_t)d->rope_start));
+                              pack(d->state, (int32_t)d->cfg.max_seq_len, (int32_t)d->pre_len));
                 mc_status s2 = s == MC_OK ? d->run_token(nullptr) : s;
                 hipError_t e = hipStreamEndCapture(d->stream, &d->graph);
                 if (s2 != MC_OK) return s2;
@@ -1491,16 +1528,8 @@ mc_decoder_generate(mc_decoder* d, int32_t first_token, int32_t start_pos, int32
             }
             MC_HIP(hipGraphLaunch(d->graph_exec, d->stream));
         } else {
-            if (rope_moved && d->graph_exec) {
-                // the captured advance kernel froze rope_start: drop the graph, it is re-captured
-                (void)hipGraphExecDestroy(d->graph_exec);
-                (void)hipGraphDestroy(d->graph);
-                d->graph_exec = nullptr;
-                d->graph = nullptr;
-            }
             s = d->launch("mc_step_advance", 1, 1, 1, 64, 0,
-                          pack(d->state, (int32_t)d->cfg.max_seq_len, (int32_t)d->pre_len,
-                               (int32_t)d->rope_start));
+                          pack(d->state, (int32_t)d->cfg.max_seq_len, (int32_t)d->pre_len));
             if (s != MC_OK) return s;
             s = d->run_token(nullptr);
             if (s != MC_OK) return s;
@@ -1529,6 +1558,13 @@ mc_decoder_hidden_in(mc_decoder* d)
 mc_status
 mc_decoder_set_taps(mc_decoder* d, int32_t enable)
 {
+    if (!d) return fail(MC_ERR_INVALID_ARGUMENT, "mc_decoder_set_taps: null argument");
+    if (d->want_taps != (enable != 0)) {
+        // taps change the launch sequence (tap copies, unfused gemma post-norms, sampler tap pointer): a captured
+        // token no longer matches
+        MC_HIP(hipSetDevice(d->dev->ordinal));
+        d->drop_graph();
+    }
     d->want_taps = enable != 0;
     return MC_OK;
 }

@@ -30,10 +30,12 @@ struct step_state {
     int32_t step_index; // index into tokens_out for chained generation
     int32_t rope_row;   // pos - rope_table_start
     int32_t rolled;     // number of rolls so far (debug)
+    int32_t rope_start; // first position of the rope table window (nn/embedding.h:190-198); moved by mc_step_rope
+    int32_t pad[3];
 };
 
 __device__ __forceinline__ void
-derive_state(step_state* st, int32_t max_seq, int32_t pre_len, int32_t rope_start)
+derive_state(step_state* st, int32_t max_seq, int32_t pre_len)
 {
     const int32_t post = max_seq - pre_len;
     if (st->pos >= max_seq) {
@@ -48,7 +50,7 @@ derive_state(step_state* st, int32_t max_seq, int32_t pre_len, int32_t rope_star
         st->write_slot = p < pre_len ? p : pre_len + (p - pre_len + st->ring_base) % post;
         st->kv_len = p + 1;
     }
-    st->rope_row = st->pos - rope_start;
+    st->rope_row = st->pos - st->rope_start;
 }
 
 // start a step at an explicit (token, pos).  token < 0 keeps the token left by the argmax.
@@ -64,19 +66,28 @@ mc_step_set(step_state* st, int32_t token, int32_t pos, int32_t max_seq, int32_t
         }
         if (token >= 0) st->token = token;
         st->pos = pos;
-        derive_state(st, max_seq, pre_len, rope_start);
+        st->rope_start = rope_start;
+        derive_state(st, max_seq, pre_len);
     }
 }
 
 // chained generation: pos += 1 (the token was written by mc_argmax)
 extern "C" __global__ void
-mc_step_advance(step_state* st, int32_t max_seq, int32_t pre_len, int32_t rope_start)
+mc_step_advance(step_state* st, int32_t max_seq, int32_t pre_len)
 {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         st->pos += 1;
         st->step_index += 1;
-        derive_state(st, max_seq, pre_len, rope_start);
+        derive_state(st, max_seq, pre_len);
     }
+}
+
+// the rope table window moved (nn::rope::operator(), nn/embedding.h:190-198): the steps that follow -- a replayed
+// graph included -- take their table row relative to the new start
+extern "C" __global__ void
+mc_step_rope(step_state* st, int32_t rope_start)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) st->rope_start = rope_start;
 }
 
 // ------------------------------------------------------------------------------------------

@@ -1,0 +1,235 @@
+"""Parity at the context lengths and widths bench.py actually runs (BASELINE.json configs[1], [2], [0], [4]).
+
+The CPU oracle cannot decode thousands of tokens in a test, so the cache is INJECTED on both sides
+(mc_decoder_import_kv / mco_model_set_kv: n logical rows as if positions 0 .. n-1 had been decoded) and
+the decode steps around and past max_seq_len are compared against the oracle on one full-width block
+with the benchmark's own synthetic weights (tests/synthgen.py regenerates what mc_decoder_init_synthetic
+put in HBM):
+  * Llama-3-8B int4 g128, S = 2048, bf16 and f32: kv_len 2041 .. 2048 and eight steps past the end
+    (multi-round score loops, whole-context P.V workgroups, the sink ring with pre_len 11);
+  * Llama-3-8B int8, S = 8192 with the automatic P.V context ranges: kv_len 8186 .. 8192 and on past the end;
+  * TinyLlama-1.1B shapes (head_dim 64, 8 query heads per kv head, ffn 5632, bf16 weights, vocab 32000);
+  * Llama-3-70B widths (dim 8192, 64 heads, ffn 28672): K = 8192 / 28672 GEMVs;
+  * rows already in the cache do not change by a single bit across a roll (nn/cache.h:187-204).
+"""
+import numpy as np
+import pytest
+
+import modelgen as mg
+import parity
+from oracle import mc_oracle as mo
+from test_full_size_gpu import FULL_WIDTH, SEED, synth_model
+
+pytestmark = pytest.mark.gpu
+BF16, F32 = 0, 1
+
+
+def random_cache(cfg, n, seed):
+    """[n, n_kv, hd] keys / values of T with the magnitudes decoded rows have (scores stay far from overflow:
+    the reference's softmax has no max shift, kernel/softmax.metal:24-88)."""
+    rng = np.random.default_rng(seed)
+    shape = (n, cfg["n_kv_heads"], cfg["head_dim"])
+    k = mo.encode(cfg["dtype"], rng.normal(0, 0.4, shape).astype(np.float32))
+    v = mo.encode(cfg["dtype"], rng.normal(0, 0.5, shape).astype(np.float32))
+    return k, v
+
+
+def run_injected(acc, cfg, weights, n_inject, n_steps, dec_over, rel_logits, max_ulp, max_frac, rel_f32=2e-4, what=""):
+    import metalchat_amd as mc
+
+    dt = cfg["dtype"]
+    om = mo.Model(cfg, weights)
+    dec = mc.Decoder(acc, **mg.decoder_kwargs(cfg, **dec_over))
+    dec.init_synthetic(SEED)
+    dec.set_taps(True)
+    for layer in range(cfg["n_layers"]):
+        k, v = random_cache(cfg, n_inject, 100 + layer)
+        om.set_kv(layer, k, v)
+        dec.import_kv(layer, k, v)
+    gk, gv = dec.export_kv(0)
+    ok, ov = om.kv(0)
+    parity.exact(gk, ok, f"{what} imported K")  # import -> export is the identity (index work)
+    parity.exact(gv, ov, f"{what} imported V")
+    prev = (gk.copy(), gv.copy())
+    tok, agree = 7, 0
+    for i in range(n_steps):
+        pos = n_inject + i
+        otok, ologits = om.step(tok, pos)
+        gtok = dec.step(tok, pos)
+        if dt == BF16:
+            for layer in range(cfg["n_layers"]):
+                parity.check(dt, dec.hidden(layer), om.hidden(layer), rel=3.9e-3 * (1 + layer), max_ulp=max_ulp + layer, max_frac=max_frac,
+                             what=f"{what} pos {pos} hidden[{layer}]")
+            # (a logit is a 4096-term dot product of a hidden row that already carries last-bit differences from a
+            # 2048-term softmax / P.V sum in another order: up to 3 scaled bf16 steps on single logits, as in the
+            # long-context test of test_full_size_gpu.py; the f32 twin below holds 2e-4)
+            parity.check(dt, dec.logits(), ologits, rel=rel_logits, max_ulp=max_ulp + cfg["n_layers"], max_frac=max_frac,
+                         what=f"{what} pos {pos} logits")
+        else:
+            for layer in range(cfg["n_layers"]):
+                parity.check(dt, dec.hidden(layer), om.hidden(layer), rel=rel_f32, what=f"{what} pos {pos} hidden[{layer}]")
+            parity.check(dt, dec.logits(), ologits, rel=rel_f32, what=f"{what} pos {pos} logits")
+        agree += int(gtok == otok)
+        gk, gv = dec.export_kv(0)
+        ok, ov = om.kv(0)
+        assert gk.shape == ok.shape, (what, pos, gk.shape, ok.shape)
+        S, pre = cfg["max_seq_len"], int(cfg["max_seq_len"]).bit_length() - 1
+        # (1) index work is bit-exact: rows already in the cache do not move (before the cache is full) or move exactly
+        # as sink_cache::copy moves them (prefix kept, post region rotated left by one, nn/cache.h:187-204)
+        for new, old, name in ((gk, prev[0], "K"), (gv, prev[1], "V")):
+            if pos < S:
+                parity.exact(new[:-1], old, f"{what} pos {pos} {name}: rows already in the cache")
+            else:
+                parity.exact(new[:pre], old[:pre], f"{what} pos {pos} {name}: sink prefix")
+                parity.exact(new[pre:S - 1], old[pre + 1:S], f"{what} pos {pos} {name}: rotated rows")
+        prev = (gk.copy(), gv.copy())
+        # (2) the injected rows still in the window are the oracle's rows bit for bit; rows either side computed
+        # (rope of a GEMV output) carry the T tolerance
+        rolled = max(0, pos + 1 - S)
+        if rolled == 0:
+            parity.exact(gk[:n_inject], ok[:n_inject], f"{what} pos {pos} injected K rows")
+            parity.exact(gv[:n_inject], ov[:n_inject], f"{what} pos {pos} injected V rows")
+            ck, cok, cv, cov = gk[n_inject:], ok[n_inject:], gv[n_inject:], ov[n_inject:]
+        else:
+            parity.exact(gk[:pre], ok[:pre], f"{what} pos {pos} injected K prefix")
+            parity.exact(gv[:pre], ov[:pre], f"{what} pos {pos} injected V prefix")
+            ncomp = pos + 1 - n_inject  # rows computed by the steps of this test: the tail of the window
+            ck, cok, cv, cov = gk[S - ncomp:], ok[S - ncomp:], gv[S - ncomp:], ov[S - ncomp:]
+            parity.exact(gk[pre:S - ncomp], ok[pre:S - ncomp], f"{what} pos {pos} injected K rows after {rolled} rolls")
+            parity.exact(gv[pre:S - ncomp], ov[pre:S - ncomp], f"{what} pos {pos} injected V rows after {rolled} rolls")
+        if dt == BF16:
+            parity.check(dt, ck, cok, rel=3.9e-3, max_ulp=max_ulp, max_frac=max_frac, what=f"{what} pos {pos} computed K rows")
+            parity.check(dt, cv, cov, rel=3.9e-3, max_ulp=max_ulp, max_frac=max_frac, what=f"{what} pos {pos} computed V rows")
+        else:
+            parity.check(dt, ck, cok, rel=rel_f32, what=f"{what} pos {pos} computed K rows")
+            parity.check(dt, cv, cov, rel=rel_f32, what=f"{what} pos {pos} computed V rows")
+        tok = otok
+    dec.release()
+    om.close()
+    return agree
+
+
+@pytest.mark.parametrize("dtype", [BF16, F32])
+def test_llama3_8b_int4_at_the_benchmark_context(acc, dtype):
+    # BASELINE configs[1]: S = 2048.  Steps at positions 2040 .. 2055: kv_len 2041 .. 2048, then eight rolls.
+    import metalchat_amd as mc
+
+    cfg = dict(dtype=dtype, n_layers=1, vocab=2048, max_seq_len=2048, norm_eps=1e-5, **FULL_WIDTH["llama3-8b"])
+    weights = synth_model(cfg, SEED)
+    agree = run_injected(acc, cfg, weights, 2040, 16, dict(weight_format=mc.WFMT_I4, group_size=128),
+                         rel_logits=5e-3, max_ulp=2, max_frac=0.7, what=f"8B int4 S=2048 dt{dtype}")
+    assert agree >= 14
+
+
+def test_llama3_8b_int8_at_8192_with_automatic_context_ranges(acc, monkeypatch):
+    # BASELINE configs[2]: S = 8192, P.V split over max_seq_len / 2048 context ranges + the reduce launch, no override.
+    import metalchat_amd as mc
+
+    monkeypatch.delenv("MC_PV_RANGES", raising=False)
+    cfg = dict(dtype=BF16, n_layers=1, vocab=2048, max_seq_len=8192, norm_eps=1e-5, **FULL_WIDTH["llama3-8b"])
+    weights = synth_model(cfg, SEED, bits=8)
+    agree = run_injected(acc, cfg, weights, 8185, 15, dict(weight_format=mc.WFMT_I8, group_size=128),
+                         rel_logits=5e-3, max_ulp=2, max_frac=0.7, what="8B int8 S=8192")
+    assert agree >= 13
+
+
+def t_weights_model(cfg, seed):
+    """Plain T weights (nn::linear) exactly as mc_decoder_init_synthetic fills them with weight_format = T."""
+    import synthgen as sg
+
+    dt = cfg["dtype"]
+    dim, H, KV, hd, ffn = cfg["dim"], cfg["n_heads"], cfg["n_kv_heads"], cfg["head_dim"], cfg["ffn_dim"]
+
+    def lin(mid, out_f, in_f):
+        return dict(kind=0, weight=mo.encode(dt, sg.values(seed, mid, out_f * in_f, 2, in_f).reshape(out_f, in_f)))
+
+    def vec(mid, n):
+        return mo.encode(dt, sg.values(seed, mid, n, 0))
+
+    layers = []
+    for i in range(cfg["n_layers"]):
+        b = i * 16
+        layers.append(dict(wq=lin(b + 0, H * hd, dim), wk=lin(b + 1, KV * hd, dim), wv=lin(b + 2, KV * hd, dim),
+                           wo=lin(b + 3, dim, H * hd), w1=lin(b + 4, ffn, dim), w2=lin(b + 5, dim, ffn), w3=lin(b + 6, ffn, dim),
+                           attention_norm=vec(b + 8, dim), ffn_norm=vec(b + 9, dim)))
+    emb = mo.encode(dt, sg.values(seed, 0xFFFF0000, cfg["vocab"] * dim, 1).reshape(cfg["vocab"], dim))
+    return dict(layers=layers, embedding=dict(kind=0, weight=emb), output=lin(0xFFFF0001, cfg["vocab"], dim),
+                final_norm=vec(0xFFFF0002, dim))
+
+
+@pytest.mark.parametrize("dtype", [BF16, F32])
+def test_tinyllama_1b_shapes_end_to_end(acc, dtype):
+    # BASELINE configs[0]: TinyLlama-1.1B -- head_dim 64, 8 query heads per kv head, ffn 5632 (a ragged K for the
+    # 2048-weight chunks of the GEMV), plain T weights, the full 32000-row head.  Two blocks, from position 0 and at
+    # S = 2048.  T = float pins the arithmetic (2e-4); T = bfloat is the benchmark's type.
+    import metalchat_amd as mc
+
+    cfg = dict(dtype=dtype, family=0, n_layers=2, vocab=32000, max_seq_len=2048, norm_eps=1e-5, dim=2048, n_heads=32,
+               n_kv_heads=4, head_dim=64, ffn_dim=5632, rope_theta=10000.0, attn_scale=64 ** -0.5)
+    weights = t_weights_model(cfg, SEED)
+    om = mo.Model(cfg, weights)
+    dec = mc.Decoder(acc, **mg.decoder_kwargs(cfg, weight_format=mc.WFMT_T, group_size=0))
+    dec.init_synthetic(SEED)
+    dec.set_taps(True)
+    tok, agree = 5, 0
+    for pos in range(5):
+        otok, ologits = om.step(tok, pos)
+        gtok = dec.step(tok, pos)
+        for layer in range(-1, cfg["n_layers"]):
+            if dtype == F32:
+                parity.check(F32, dec.hidden(layer), om.hidden(layer), rel=2e-4, what=f"tinyllama f32 pos {pos} hidden[{layer}]")
+                continue
+            # (two blocks: the second block's output has passed two attention + ffn compositions, each of which can
+            # move an element by a bf16 step)
+            parity.check(BF16, dec.hidden(layer), om.hidden(layer), rel=3.9e-3 * (1 + max(layer, 0)), max_ulp=(2 + layer) if layer >= 0 else 0,
+                         max_frac=(0.5 + 0.2 * layer) if layer >= 0 else 0.0, what=f"tinyllama pos {pos} hidden[{layer}]")
+        if dtype == F32:
+            parity.check(F32, dec.logits(), ologits, rel=2e-4, what=f"tinyllama f32 pos {pos} logits")
+        else:
+            # (measured: up to 3.2 scaled bf16 steps on single logits behind two blocks; the f32 twin holds 2e-4)
+            parity.check(BF16, dec.logits(), ologits, rel=7.8e-3, max_ulp=4, max_frac=0.8, what=f"tinyllama pos {pos} logits")
+        agree += int(gtok == otok)
+        tok = otok
+    assert agree >= 4
+    dec.release()
+    om.close()
+    agree = run_injected(acc, cfg, weights, 2044, 8, dict(weight_format=mc.WFMT_T, group_size=0), rel_logits=7.8e-3,
+                         max_ulp=3, max_frac=0.8, what=f"tinyllama S=2048 dt{dtype}")
+    assert agree >= 7
+
+
+def test_llama3_70b_widths_one_block(acc):
+    # BASELINE configs[4] widths: dim 8192, 64 query / 8 kv heads, ffn 28672 -- rows of 4 and 14 KiB of int4 weights
+    import metalchat_amd as mc
+
+    cfg = dict(dtype=BF16, family=0, n_layers=1, vocab=2048, max_seq_len=256, norm_eps=1e-5, dim=8192, n_heads=64,
+               n_kv_heads=8, head_dim=128, ffn_dim=28672, rope_theta=500000.0, attn_scale=128 ** -0.5)
+    weights = synth_model(cfg, SEED)
+    agree = run_injected(acc, cfg, weights, 250, 9, dict(weight_format=mc.WFMT_I4, group_size=128), rel_logits=5e-3,
+                         max_ulp=2, max_frac=0.7, what="70B widths")
+    assert agree >= 8
+
+
+def test_rows_in_the_cache_do_not_move_across_a_roll(acc):
+    # nn/cache.h:187-204: prefix kept, post region rotated left by one, new row last.  Small model, many rolls,
+    # both dtypes; export(t + 1) must be the literal roll of export(t) bit for bit (only the last row is computed).
+    import metalchat_amd as mc
+
+    for dt in (BF16, F32):
+        cfg = mg.tiny_cfg(dt, max_seq_len=24, n_layers=2)
+        weights = mg.make_model(cfg, seed=3, quant="i4", group=32)
+        dec = mc.Decoder(acc, **mg.decoder_kwargs(cfg, weight_format=mc.WFMT_I4, group_size=32))
+        dec.load_model(weights)
+        pre = int(cfg["max_seq_len"]).bit_length() - 1
+        tok, prev = 3, None
+        for pos in range(cfg["max_seq_len"] + 40):
+            tok = dec.step(tok, pos)
+            k, v = dec.export_kv(1)
+            if pos >= cfg["max_seq_len"]:
+                S = cfg["max_seq_len"]
+                assert k.shape[0] == S
+                for new, old in ((k, prev[0]), (v, prev[1])):
+                    parity.exact(new[:pre], old[:pre], f"dt{dt} pos {pos}: sink prefix")
+                    parity.exact(new[pre:S - 1], old[pre + 1:S], f"dt{dt} pos {pos}: rotated rows")
+            prev = (k.copy(), v.copy())
+        dec.release()

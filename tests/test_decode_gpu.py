@@ -254,3 +254,38 @@ def test_fast_qmode_error_is_reported(acc):
     agree, _ = run_pair(acc, cfg, weights, 6, dict(weight_format=2, group_size=32, qmode=1),
                         rel_hidden=1e-2, rel_logits=1e-2, max_frac=0.9, max_ulp=4)
     assert agree >= 5
+
+
+def test_a_captured_token_survives_a_moved_rope_window_and_a_new_conversation(acc):
+    # the rope table holds 2 * max_seq_len rows and is regenerated when the position leaves it
+    # (nn/embedding.h:190-198).  A hipGraph captured under one window start must not replay a stale
+    # start: generate far past the window, then start a new conversation at position 0 on the SAME
+    # decoder -- tokens must equal a fresh decoder's.  Toggling the parity taps in between must not
+    # replay a graph captured with another launch sequence either.
+    import metalchat_amd as mc
+
+    cfg = mg.tiny_cfg(BF16, max_seq_len=16, n_layers=2)
+    weights = mg.make_model(cfg, seed=5, quant="i4", group=32)
+
+    def fresh():
+        d = mc.Decoder(acc, **mg.decoder_kwargs(cfg, weight_format=mc.WFMT_I4, group_size=32, use_graph=1))
+        d.load_model(weights)
+        return d
+
+    ref = fresh()
+    want_long = list(ref.generate(3, 0, 80))      # window starts: 0, 32, 64
+    want_short = list(fresh().generate(9, 0, 12))
+    d = fresh()
+    assert list(d.generate(3, 0, 80)) == want_long
+    assert list(d.generate(9, 0, 12)) == want_short          # graph captured at window 64 replayed at window 0
+    d.set_taps(True)
+    assert list(d.generate(9, 0, 12)) == want_short          # taps on: the captured sequence is dropped
+    d.set_taps(False)
+    assert list(d.generate(3, 0, 80)) == want_long
+    eager = mc.Decoder(acc, **mg.decoder_kwargs(cfg, weight_format=mc.WFMT_I4, group_size=32, use_graph=0))
+    eager.load_model(weights)
+    assert list(eager.generate(3, 0, 80)) == want_long
+    with pytest.raises(mc.McError):
+        d.step(cfg["vocab"], 0)                               # token id outside the vocabulary
+    for x in (ref, d, eager):
+        x.release()
