@@ -654,9 +654,11 @@ struct mc_decoder {
         return MC_OK;
     }
 
+    // advance: the embedding launch also advances the step state (chained generation on a first stage)
     mc_status
-    run_embed()
+    run_embed(bool advance = false)
     {
+        const int32_t adv_seq = advance ? (int32_t)cfg.max_seq_len : 0;
         const bool gemma = cfg.family == MC_FAMILY_GEMMA3;
         float sc = std::sqrt((float)cfg.dim);
         if (tb == 2) sc = bf2f_host(f2bf_host(sc));
@@ -664,11 +666,11 @@ struct mc_decoder {
         mc_status s;
         if (emb_fmt == MC_WFMT_T)
             s = launch("mc_embed_" + tname, g, 1, 1, 256, 0,
-                       pack(emb_table, hidden, state, (uint32_t)cfg.dim, sc, (int32_t)(gemma ? 1 : 0)));
+                       pack(emb_table, hidden, state, (uint32_t)cfg.dim, sc, (int32_t)(gemma ? 1 : 0), adv_seq, (int32_t)pre_len));
         else
             s = launch("mc_embed_q8_" + tname, g, 1, 1, 256, 0,
                        pack(emb_table, emb_scales, hidden, state, (uint32_t)cfg.dim, sc,
-                            (int32_t)(gemma ? 1 : 0)));
+                            (int32_t)(gemma ? 1 : 0), adv_seq, (int32_t)pre_len));
         if (s != MC_OK) return s;
         if (want_taps)
             MC_HIP(hipMemcpyAsync(taps, hidden, (size_t)cfg.dim * tb, hipMemcpyDeviceToDevice, stream));
@@ -914,12 +916,12 @@ struct mc_decoder {
 
     // everything one token needs after the state has been set
     mc_status
-    run_token(const void* hidden_src)
+    run_token(const void* hidden_src, bool advance = false)
     {
         mc_status s;
         const void* x = hidden_src;
         if (first_stage) {
-            s = run_embed();
+            s = run_embed(advance);
             if (s != MC_OK) return s;
             x = hidden;
         }
@@ -1518,9 +1520,8 @@ mc_decoder_generate(mc_decoder* d, int32_t first_token, int32_t start_pos, int32
             if (!d->graph_exec) {
                 d->drop_graph();
                 MC_HIP(hipStreamBeginCapture(d->stream, hipStreamCaptureModeGlobal));
-                s = d->launch("mc_step_advance", 1, 1, 1, 64, 0,
-                              pack(d->state, (int32_t)d->cfg.max_seq_len, (int32_t)d->pre_len));
-                mc_status s2 = s == MC_OK ? d->run_token(nullptr) : s;
+                mc_status s2 = d->run_token(nullptr, true); // the embedding launch advances the step state
+
                 hipError_t e = hipStreamEndCapture(d->stream, &d->graph);
                 if (s2 != MC_OK) return s2;
                 if (e != hipSuccess) return hip_fail(e, "hipStreamEndCapture");
@@ -1528,10 +1529,7 @@ mc_decoder_generate(mc_decoder* d, int32_t first_token, int32_t start_pos, int32
             }
             MC_HIP(hipGraphLaunch(d->graph_exec, d->stream));
         } else {
-            s = d->launch("mc_step_advance", 1, 1, 1, 64, 0,
-                          pack(d->state, (int32_t)d->cfg.max_seq_len, (int32_t)d->pre_len));
-            if (s != MC_OK) return s;
-            s = d->run_token(nullptr);
+            s = d->run_token(nullptr, true);
             if (s != MC_OK) return s;
         }
     }

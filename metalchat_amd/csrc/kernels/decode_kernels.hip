@@ -93,54 +93,69 @@ mc_step_rope(step_state* st, int32_t rope_start)
 // ------------------------------------------------------------------------------------------
 // embedding row:  hidden[k] = T(table[token, k] (* T(scale)))        (gemma: nn/gemma.h:115)
 // ------------------------------------------------------------------------------------------
+// max_seq > 0: the launch also ADVANCES the step state (what mc_step_advance does) -- chained generation then needs
+// no launch of its own for it.  The token was left by the previous step's pick and nothing else in this launch
+// reads the fields the advance writes, so workgroup 0's thread 0 can update them while every workgroup gathers.
 template <typename T>
 __device__ __forceinline__ void
-embed_body(const typename T::S* table, typename T::S* out, const step_state* st, uint32_t dim,
-           float scale, int32_t use_scale)
+embed_body(const typename T::S* table, typename T::S* out, step_state* st, uint32_t dim,
+           float scale, int32_t use_scale, int32_t max_seq, int32_t pre_len)
 {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    const int32_t token = st->token;
+    if (max_seq > 0 && k == 0) {
+        st->pos += 1;
+        st->step_index += 1;
+        derive_state(st, max_seq, pre_len);
+    }
     if (k >= dim) return;
-    const typename T::S v = table[(size_t)st->token * dim + k];
+    const typename T::S v = table[(size_t)token * dim + k];
     out[k] = use_scale ? T::st(T::ld(v) * scale) : v;
 }
 extern "C" __global__ void
-mc_embed_bfloat(const bf16_t* table, bf16_t* out, const step_state* st, uint32_t dim, float scale,
-                int32_t use_scale)
+mc_embed_bfloat(const bf16_t* table, bf16_t* out, step_state* st, uint32_t dim, float scale,
+                int32_t use_scale, int32_t max_seq, int32_t pre_len)
 {
-    embed_body<BF>(table, out, st, dim, scale, use_scale);
+    embed_body<BF>(table, out, st, dim, scale, use_scale, max_seq, pre_len);
 }
 extern "C" __global__ void
-mc_embed_float(const float* table, float* out, const step_state* st, uint32_t dim, float scale,
-               int32_t use_scale)
+mc_embed_float(const float* table, float* out, step_state* st, uint32_t dim, float scale,
+               int32_t use_scale, int32_t max_seq, int32_t pre_len)
 {
-    embed_body<F32>(table, out, st, dim, scale, use_scale);
+    embed_body<F32>(table, out, st, dim, scale, use_scale, max_seq, pre_len);
 }
 
 // quantization::lora_embedding (include/metalchat/quantization/lora.h:161-170): the table is
 // int8 with one f32 scale per row; dequantised value = T(T(q) * T(s)), gathered per token.
 template <typename T>
 __device__ __forceinline__ void
-embed_q8_body(const int8_t* table, const float* scales, typename T::S* out, const step_state* st,
-              uint32_t dim, float scale, int32_t use_scale)
+embed_q8_body(const int8_t* table, const float* scales, typename T::S* out, step_state* st,
+              uint32_t dim, float scale, int32_t use_scale, int32_t max_seq, int32_t pre_len)
 {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    const int32_t token = st->token;
+    if (max_seq > 0 && k == 0) {
+        st->pos += 1;
+        st->step_index += 1;
+        derive_state(st, max_seq, pre_len);
+    }
     if (k >= dim) return;
-    const float s = T::rt(scales[st->token]);
-    float v = T::rt((float)table[(size_t)st->token * dim + k] * s);
+    const float s = T::rt(scales[token]);
+    float v = T::rt((float)table[(size_t)token * dim + k] * s);
     if (use_scale) v = T::rt(v * scale);
     out[k] = T::st(v);
 }
 extern "C" __global__ void
-mc_embed_q8_bfloat(const int8_t* table, const float* scales, bf16_t* out, const step_state* st,
-                   uint32_t dim, float scale, int32_t use_scale)
+mc_embed_q8_bfloat(const int8_t* table, const float* scales, bf16_t* out, step_state* st,
+                   uint32_t dim, float scale, int32_t use_scale, int32_t max_seq, int32_t pre_len)
 {
-    embed_q8_body<BF>(table, scales, out, st, dim, scale, use_scale);
+    embed_q8_body<BF>(table, scales, out, st, dim, scale, use_scale, max_seq, pre_len);
 }
 extern "C" __global__ void
-mc_embed_q8_float(const int8_t* table, const float* scales, float* out, const step_state* st,
-                  uint32_t dim, float scale, int32_t use_scale)
+mc_embed_q8_float(const int8_t* table, const float* scales, float* out, step_state* st,
+                  uint32_t dim, float scale, int32_t use_scale, int32_t max_seq, int32_t pre_len)
 {
-    embed_q8_body<F32>(table, scales, out, st, dim, scale, use_scale);
+    embed_q8_body<F32>(table, scales, out, st, dim, scale, use_scale, max_seq, pre_len);
 }
 
 // ------------------------------------------------------------------------------------------

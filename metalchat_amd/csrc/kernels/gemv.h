@@ -606,8 +606,13 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
                 va = T::ld(static_cast<const S*>(resp)[row]) + va;
                 if (two) vb = T::ld(static_cast<const S*>(resp)[row + 1]) + vb;
             }
-            y[row] = T::st(va);
-            if (two) y[row + 1] = T::st(vb);
+            if (two && T::bytes == 2) {
+                // both rows in ONE 4-byte store (row is even): half the store instructions of the head's 128256 rows
+                reinterpret_cast<uint32_t*>(y)[pair] = pack_bf16x2(va, vb);
+            } else {
+                y[row] = T::st(va);
+                if (two) y[row + 1] = T::st(vb);
+            }
         } else if (EPI == EPI_QKV_ROPE) {
             const qkv_epilogue* q = static_cast<const qkv_epilogue*>(resp);
             const uint32_t H = q->H, KV = q->KV, hd = q->hd, half = hd / 2, ms = q->max_seq;

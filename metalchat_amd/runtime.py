@@ -395,7 +395,7 @@ class HardwareAccelerator:
         self._dev = C.c_void_p()
         _check(lib.mc_device_create(ordinal, C.byref(self._dev)))
         self._lib = C.c_void_p()
-        _check(lib.mc_library_open(self._dev, (path or hsaco_path()).encode(), C.byref(self._lib)))
+        _check(lib.mc_library_open(self._dev, (path or os.environ.get("MC_HSACO") or hsaco_path()).encode(), C.byref(self._lib)))  # MC_HSACO: tuning builds (tools/)
         self._queue = C.c_void_p()
         _check(lib.mc_queue_create(self._dev, C.c_void_p(stream) if stream else None,
                                    C.byref(self._queue)))
