@@ -3,8 +3,8 @@
 MI355X, with the achieved HBM rate of the dominant kernel (the fused int4 GEMV) against the
 8 TB/s roofline and the CPU restatement of the reference timed beside it.
 
-  python bench.py --gpus N --steps K --warmup W          (N = 1 default)
-  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+  python bench.py --gpus N --steps K --warmup W                         (N = 1 default)
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (also accepted)
 
 A "step" is one generated token: embedding -> 32 x (rmsnorm, QKV GEMV, RoPE, sink-cache write,
 QK^T, softmax, PV, Wo, residual, rmsnorm, w1|w3 GEMV, SiLU*mul, w2 GEMV, residual) -> final norm
@@ -15,15 +15,22 @@ seq_len - steps before the timed region, and the timed tokens end at position se
 traffic is at its configured maximum.
 
 N > 1: the layers are pipelined over N GPUs (contiguous layer ranges, one RCCL send/recv of the
-hidden row per stage boundary and one 4-byte token hop back), one process per GPU.  At batch 1
-only one stage is busy at a time, so this buys capacity, not speed: scaling is "strong".
+hidden row per stage boundary and one 4-byte token hop back -- mc_pipeline_* of the C ABI, every
+hop enqueued on the decoder's stream), one process per GPU.  Launched without a launcher,
+`python bench.py --gpus N` starts its N workers itself (fresh child processes, before anything
+touches the GPU) and hands the RCCL id over through a file; under torch.distributed.run it reads
+RANK / LOCAL_RANK / WORLD_SIZE from the environment.  torch is never imported.  At batch 1 only
+one stage is busy at a time, so this buys capacity (70B fits), not speed: the same model is
+split over more GPUs, i.e. scaling is "strong".
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -40,6 +47,8 @@ MODELS = {
                            n_layers=22, vocab=32000, rope_theta=10000.0, norm_eps=1e-5),
     "llama3-70b": dict(dim=8192, n_heads=64, n_kv_heads=8, head_dim=128, ffn_dim=28672,
                        n_layers=80, vocab=128256, rope_theta=500000.0, norm_eps=1e-5),
+    "gemma-7b": dict(dim=3072, n_heads=16, n_kv_heads=16, head_dim=256, ffn_dim=24576, n_layers=28,
+                     vocab=256000, rope_theta=10000.0, norm_eps=1e-5),
 }
 
 
@@ -57,13 +66,12 @@ def parse():
     p.add_argument("--no-graph", action="store_true")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-roofline", action="store_true")
+    p.add_argument("--no-other-configs", action="store_true")
     p.add_argument("--seed", type=int, default=0x5EED)
     p.add_argument("--share-device", action="store_true",
-                   help="validation aid: every rank uses GPU 0 and the hops go over gloo (RCCL refuses two "
-                        "ranks on one device), so the N > 1 path can be exercised end to end on a 1-GPU box")
-    p.add_argument("--force-pipeline", action="store_true",
-                   help="run the N > 1 code path (torch stream, RCCL group, stage loop) with one rank: a "
-                        "smoke check of the multi-GPU plumbing on a 1-GPU box")
+                   help="validation aid for a 1-GPU box: the N stages run in THIS process on GPU 0 "
+                        "(mc_pipeline_create_local: device-to-device hops), the same launches per stage "
+                        "as the RCCL transport")
     return p.parse_args()
 
 
@@ -80,42 +88,94 @@ def algorithmic_bytes(m, wbits, group, seq_len, tbytes):
                 total=w + kv_read + kv_write + dim * tbytes, p_mm=p_mm)
 
 
-def dec_kernel_name(args):
-    """Host name of the dominant kernel for this configuration (gemv_kernels.hip)."""
+def dec_kernel_name(args, m):
+    """Host name of the dominant kernel for this configuration (decoder.cc gemv(): name selection)."""
     fmt = {4: "i4", 8: "i8", 16: "w"}[args.wbits]
     t = "bfloat" if args.dtype == "bf16" else "float"
     i4bf = args.wbits == 4 and args.dtype == "bf16"
-    variant = ("_fast" if args.qmode == "fast" else "_m4d") if i4bf else ""   # decoder.cc gemv(): name selection
-    return f"mc_gemv_{fmt}_{t}{variant}_p1_e2"
+    if not i4bf:
+        return f"mc_gemv_{fmt}_{t}_p1_e2"
+    if args.qmode == "fast":
+        return f"mc_gemv_{fmt}_{t}_fast_p1_e2"
+    nch = m["dim"] // 2048 if m["dim"] % 2048 == 0 else 0
+    lin = args.group % 128 == 0 and nch in (1, 2, 4, 7, 14) and os.environ.get("MC_GEMV_LIN", "1") != "0"
+    return f"mc_gemv_{fmt}_{t}_lin{nch}_p1_e2" if lin else f"mc_gemv_{fmt}_{t}_m4d_p1_e2"
 
 
 def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the newest committed PMC summary
-    (profiles/rNN_pmc_traffic.json, produced by tools/profile_round.sh with separate rocprofv3
-    --pmc FETCH_SIZE / WRITE_SIZE passes and the gfx950 correction).  Counters cannot be read
-    from inside this process, so this is the figure of the last profiled run, or null."""
+    """HBM bytes per launch of `kernel` from the newest committed PMC summary (profiles/rNN_pmc_traffic.json,
+    produced by tools/profile_round.sh with separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes and the gfx950
+    correction).  Counters cannot be read from inside this process, so this is the figure of the last PROFILED
+    build: the entry names its file and the git HEAD it was taken at, and is null when the file has no such kernel."""
     import glob
 
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
     if not files:
         return None
     try:
-        k = json.load(open(files[-1]))["kernels"].get(kernel)
-        return k["hbm_bytes_per_launch"] if k else None
+        doc = json.load(open(files[-1]))
+        k = doc["kernels"].get(kernel)
+        if not k:
+            return None
+        return dict(hbm_bytes_per_launch=k["hbm_bytes_per_launch"], file=os.path.relpath(files[-1], ROOT),
+                    git_head=doc.get("git_head"), kernel=kernel)
     except Exception:
         return None
 
 
+def usable_cores():
+    """Host cores this process may actually use: the affinity mask, capped by the cgroup CPU quota (a container on
+    a 256-core host is often given a fraction of it; an OpenMP team of one thread per HOST core then spends its
+    time being descheduled inside barriers)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = max(1, min(n, q // per))
+        except Exception:
+            pass
+    return n
+
+
+def native_oracle():
+    """The oracle built -O3 -march=native ON THIS HOST for the cpu_baseline leg (the .so that ships with the
+    repository is a portable -O2 build: it must run on whatever CPU the box has).  Falls back to the portable
+    build when there is no compiler."""
+    odir = os.path.join(ROOT, "oracle")
+    so = os.path.join(odir, "_build", "libmc_oracle_native.so")
+    flags = "-O3 -march=native -fPIC -std=c11 -fno-fast-math -ffp-contract=off -fopenmp"
+    try:
+        src = os.path.join(odir, "mc_oracle.c")
+        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+            os.makedirs(os.path.dirname(so), exist_ok=True)
+            subprocess.check_call(["gcc"] + flags.split() + ["-shared", "-o", so, src, "-lm"],
+                                  stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        os.environ["MC_ORACLE_SO"] = so
+        return flags
+    except Exception:
+        return "-O2 (portable build shipped with the repository; no compiler on this host)"
+
+
 def cpu_baseline(args, m, tbytes):
     """The oracle (CPU restatement of the reference op sequence) timed on this box's host cores on
-    a bounded sample: a 2-layer slice of the same shapes + the full output head, a few tokens,
-    scaled to the full depth.  kind = "port" (there is no reference CPU path to run)."""
+    bounded samples.  kind = "port" (there is no reference CPU path to run).
+      * the selected model: a 2-layer slice of the same shapes + the full output head, a few tokens at context
+        <= 4 (no KV traffic to speak of), scaled to the full depth;
+      * BASELINE configs[0] in FULL: TinyLlama-1.1B, 22 layers, bf16 weights, vocabulary 32000,
+        random weights, a few tokens from position 0."""
     import numpy as np
 
+    flags = native_oracle()
     import modelgen as mg
     from oracle import mc_oracle as mo
 
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     mo.set_num_threads(cores)
     sample_layers = 2
     cfg = dict(m)
@@ -134,6 +194,7 @@ def cpu_baseline(args, m, tbytes):
         tok, _ = om.step(tok, pos, want_logits=False)
     per_tok = (time.time() - t0) / n
     om.close()
+    del weights
     # time of the head alone ~ vocab*dim MACs vs layer MACs: split by parameter count
     L = m["n_layers"]
     p_layer = m["dim"] * (m["n_heads"] + 2 * m["n_kv_heads"]) * m["head_dim"] + \
@@ -142,50 +203,155 @@ def cpu_baseline(args, m, tbytes):
     t_layer = per_tok * p_layer / (sample_layers * p_layer + p_head)
     t_head = per_tok * p_head / (sample_layers * p_layer + p_head)
     full = L * t_layer + t_head
-    return dict(value=1.0 / full, unit="tokens/s", cores=cores, kind="port",
-                sample=f"{sample_layers}-layer slice of {args.model} + full output head, {n} tokens at "
-                       f"context <= 4, {per_tok:.2f} s/token measured, scaled to {L} layers "
-                       f"(weights generated in {gen_s:.0f} s, not timed)")
+    out = dict(value=1.0 / full, unit="tokens/s", cores=cores, kind="port", compiler_flags=flags,
+               sample=f"{sample_layers}-layer slice of {args.model} + full output head, {n} tokens at context <= 4 "
+                      f"(KV traffic negligible), {per_tok:.2f} s/token measured, scaled to {L} layers "
+                      f"(weights generated in {gen_s:.0f} s, not timed)")
+    # ---- TinyLlama-1.1B in full
+    try:
+        tm = MODELS["tinyllama-1.1b"]
+        tcfg = dict(tm)
+        tcfg.update(dtype=0, family=0, max_seq_len=64, attn_scale=float(1.0 / np.sqrt(tm["head_dim"])))
+        rng = np.random.default_rng(7)
+
+        def lin(o, i):  # bf16 bits of N(0, 1/sqrt(in)) weights: the truncated upper half of the float
+            w = rng.standard_normal((o, i), dtype=np.float32) * np.float32(1.0 / np.sqrt(i))
+            return dict(kind=0, weight=(w.view(np.uint32) >> 16).astype(np.uint16))
+
+        def vec(k):
+            return mo.encode(0, rng.uniform(0.5, 1.5, k).astype(np.float32))
+
+        t0 = time.time()
+        dim, H, KV, hd, ffn = tm["dim"], tm["n_heads"], tm["n_kv_heads"], tm["head_dim"], tm["ffn_dim"]
+        layers = [dict(wq=lin(H * hd, dim), wk=lin(KV * hd, dim), wv=lin(KV * hd, dim), wo=lin(dim, H * hd),
+                       w1=lin(ffn, dim), w2=lin(dim, ffn), w3=lin(ffn, dim), attention_norm=vec(dim), ffn_norm=vec(dim))
+                  for _ in range(tm["n_layers"])]
+        tw = dict(layers=layers, embedding=lin(tm["vocab"], dim), output=lin(tm["vocab"], dim), final_norm=vec(dim))
+        tgen = time.time() - t0
+        om = mo.Model(tcfg, tw)
+        tok = 1
+        om.step(tok, 0, want_logits=False)
+        nt = 2
+        t0 = time.time()
+        for pos in range(1, 1 + nt):
+            tok, _ = om.step(tok, pos, want_logits=False)
+        tper = (time.time() - t0) / nt
+        om.close()
+        ab = algorithmic_bytes(tm, 16, 0, nt, 2)
+        out["tinyllama_1_1b_full"] = dict(value=1.0 / tper, unit="tokens/s", cores=cores, kind="port",
+                                          effective_GBs=ab["total"] / tper / 1e9,
+                                          sample=f"all 22 layers + head, bf16 weights (random, generated in {tgen:.0f} s, not timed), "
+                                                 f"{nt} tokens at context <= {nt + 1}, {tper:.3f} s/token")
+    except MemoryError:
+        out["tinyllama_1_1b_full"] = None
+    return out
+
+
+def spawn_workers(args):
+    """`python bench.py --gpus N` without a launcher: N fresh child processes, one per GPU, started BEFORE this
+    process touches the GPU; rank 0 prints the JSON line.  The RCCL id travels through a file."""
+    n = args.gpus
+    uid_file = os.path.join(tempfile.mkdtemp(prefix="mc_bench_"), "rccl_uid")
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MC_UID_FILE=uid_file,
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    # a worker that dies (no such device, RCCL error) would leave its peers waiting in the communicator: watch
+    # them and take the rest down
+    rc = 0
+    live = list(procs)
+    while live:
+        time.sleep(0.2)
+        for p in list(live):
+            r = p.poll()
+            if r is None:
+                continue
+            live.remove(p)
+            if r != 0:
+                rc = r
+                for q in live:
+                    q.kill()
+    sys.exit(rc)
+
+
+def exchange_uid(mc, rank, world):
+    """Rank 0 makes the 128-byte RCCL id; the others read it from a file rank 0 wrote atomically."""
+    path = os.environ.get("MC_UID_FILE")
+    if not path:
+        # under torch.distributed.run: one job per MASTER_PORT on this node
+        key = os.environ.get("TORCHELASTIC_RUN_ID", "none") + "_" + os.environ.get("MASTER_PORT", "29500")
+        path = os.path.join(tempfile.gettempdir(), f"mc_bench_uid_{os.getuid()}_{key}")
+        if rank == 0 and os.path.exists(path):
+            os.unlink(path)
+    if rank == 0:
+        uid = mc.pipeline_unique_id()
+        tmp = path + f".{os.getpid()}"
+        with open(tmp, "wb") as f:
+            f.write(uid)
+        os.replace(tmp, path)
+        return uid
+    t0 = time.time()
+    while time.time() - t0 < 120:
+        try:
+            if os.path.getsize(path) == 128 and time.time() - os.path.getmtime(path) < 600:
+                with open(path, "rb") as f:
+                    return f.read()
+        except OSError:
+            pass
+        time.sleep(0.05)
+    print("bench.py: no RCCL id from rank 0 after 120 s", file=sys.stderr)
+    sys.exit(2)
+
+
+def run_other_configs(mc, acc, np):
+    """The other BASELINE.json configurations, briefly, on this one GPU (informational, driver-observed): each
+    builds its own decoder, STARTS at position seq_len - tokens - 8 (the earlier cache rows are zero: the context
+    is not decoded, the KV / weight traffic per token is what the position implies) and times `tokens` chained
+    greedy tokens after 8 warm-up tokens."""
+    cases = [
+        ("TinyLlama-1.1B bf16 weights, S=2048 (configs[0] on the GPU)", "tinyllama-1.1b", 16, 0, 2048, 128, 0, mc.FAMILY_LLAMA3),
+        ("Llama-3-8B int8 g128, S=8192, 64 of the tokens past max_seq_len (configs[2])", "llama3-8b", 8, 128, 8192, 64, 64, mc.FAMILY_LLAMA3),
+        ("Gemma-7B shapes int4 g128, gemma3 block, S=2048 (configs[3])", "gemma-7b", 4, 128, 2048, 64, 0, mc.FAMILY_GEMMA3),
+        ("Llama-3-70B int4 g128 on ONE GPU, S=2048 (configs[4] without the pipeline)", "llama3-70b", 4, 128, 2048, 32, 0, mc.FAMILY_LLAMA3),
+    ]
+    out = []
+    for name, model, wbits, group, S, K, past, fam in cases:
+        try:
+            m = MODELS[model]
+            extra = dict(rope_sliding_theta=10000.0, sliding_stride=6) if fam == mc.FAMILY_GEMMA3 else {}
+            dec = mc.Decoder(acc, dtype=mc.BF16, family=fam, max_seq_len=S, attn_scale=float(1 / np.sqrt(m["head_dim"])),
+                             weight_format={4: mc.WFMT_I4, 8: mc.WFMT_I8, 16: mc.WFMT_T}[wbits], group_size=group,
+                             use_graph=1, **extra, **m)
+            dec.init_synthetic(7)
+            start = S - K - 8
+            tok = int(dec.generate(1, start, 8)[-1])
+            acc.wait()
+            t0 = time.perf_counter()
+            dec.generate(tok, start + 8, K + past)
+            acc.wait()
+            dt = time.perf_counter() - t0
+            ab = algorithmic_bytes(m, wbits, group or 1, S, 2)
+            tps = (K + past) / dt
+            out.append(dict(config=name, tokens_per_s=tps, ms_per_token=dt / (K + past) * 1e3, tokens=K + past,
+                            algorithmic_bytes=ab["total"], frac_of_hbm_peak=ab["total"] * tps / 1e9 / HBM_PEAK_GBS))
+            dec.release()
+        except Exception as e:  # an informational leg must not take the headline down
+            out.append(dict(config=name, error=str(e)[:200]))
+    return out
 
 
 def main():
     args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with "
-                  f"--nproc-per-node {args.gpus}", file=sys.stderr)
-            sys.exit(2)
+    env_world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and env_world != args.gpus and not args.share_device:
+        spawn_workers(args)  # does not return
+    rank = int(os.environ.get("RANK", "0")) if not args.share_device else 0
+    world = args.gpus
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) if not args.share_device else 0
     import numpy as np
 
     import metalchat_amd as mc
-
-    # N = 1 needs no torch at all: the C ABI owns device memory, stream and events (torch bundles
-    # its own ROCm runtime, which also keeps rocprofv3 --pmc from attaching).  N > 1 uses
-    # torch.distributed over RCCL for the stage hops.
-    torch = None
-    dist = None
-    piped = world > 1 or args.force_pipeline
-    if piped:
-        import torch
-        import torch.distributed as dist_mod
-
-        if not torch.cuda.is_available():
-            print("bench.py: no GPU visible (there is no CPU fallback for the product path)", file=sys.stderr)
-            sys.exit(2)
-        if args.share_device:
-            local_rank = 0
-        torch.cuda.set_device(local_rank)
-        dist = dist_mod
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")  # torch.distributed.run sets both; --force-pipeline alone does not
-        if args.share_device:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world,
-                                    device_id=torch.device("cuda", local_rank))
 
     m = MODELS[args.model]
     tbytes = 2 if args.dtype == "bf16" else 4
@@ -196,83 +362,54 @@ def main():
         print("bench.py: steps + warmup must not exceed seq-len", file=sys.stderr)
         sys.exit(2)
 
-    # N > 1: the decoder's queue adopts a torch-owned (non-default) stream that is also the current
-    # stream for the RCCL hops, so torch orders send/recv against the kernels
-    tstream = torch.cuda.Stream(device=local_rank) if piped else None
-    if tstream is not None:
-        torch.cuda.set_stream(tstream)
-    acc = mc.HardwareAccelerator(ordinal=local_rank,
-                                 stream=tstream.cuda_stream if tstream is not None else None)
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+    acc = mc.HardwareAccelerator(ordinal=local_rank)
     L = m["n_layers"]
-    from metalchat_amd.pipeline import layer_range
+    piped = world > 1
 
-    lb, le = layer_range(rank, world, L)
-    dec = mc.Decoder(acc, dtype=dtype, family=mc.FAMILY_LLAMA3, max_seq_len=S,
-                     attn_scale=float(1.0 / np.sqrt(m["head_dim"])), layer_begin=lb, layer_end=le,
-                     weight_format=wfmt, group_size=(args.group if args.wbits != 16 else 0),
-                     qmode=(mc.QMODE_FAST if args.qmode == "fast" else mc.QMODE_EXACT),
-                     use_graph=0 if (args.no_graph or piped) else 1, **m)
-    dec.init_synthetic(args.seed)
+    def stage(r):
+        lb, le = mc.pipeline_layer_range(r, world, L)
+        d = mc.Decoder(acc, dtype=dtype, family=mc.FAMILY_LLAMA3, max_seq_len=S,
+                       attn_scale=float(1.0 / np.sqrt(m["head_dim"])), layer_begin=lb, layer_end=le,
+                       weight_format=wfmt, group_size=(args.group if args.wbits != 16 else 0),
+                       qmode=(mc.QMODE_FAST if args.qmode == "fast" else mc.QMODE_EXACT),
+                       use_graph=0 if (args.no_graph or piped) else 1, **m)
+        d.init_synthetic(args.seed)
+        return d
+
+    pipe = None
+    if not piped:
+        dec = stage(0)
+        gen = dec.generate
+    elif args.share_device:
+        stages = [stage(r) for r in range(world)]
+        dec = stages[0]
+        pipe = mc.Pipeline.local(stages)
+        gen = pipe.generate
+    else:
+        dec = stage(rank)
+        pipe = mc.Pipeline.rccl(dec, rank, world, exchange_uid(mc, rank, world))
+        gen = pipe.generate
+
+    def sync_all(v=0.0):
+        # barrier over the ranks + device synchronize; returns max(v) over the ranks
+        if pipe is not None:
+            return pipe.allreduce_max(v)
+        acc.wait()
+        return v
 
     fill = S - K - W  # context decoded (untimed) before warm-up so the timed tokens end at S
-
-    def sync_all():
-        # barrier + device synchronize on both sides of the timed region
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize()
-        acc.wait()
-
-    if not piped:
-        tok = 1
-        if fill > 0:
-            tok = int(dec.generate(tok, 0, fill)[-1])
-        if W > 0:
-            tok = int(dec.generate(tok, fill, W)[-1])
-        sync_all()
-        t0 = time.perf_counter()
-        toks = dec.generate(tok, fill + W, K)
-        sync_all()
-        dt = time.perf_counter() - t0
-        tmax = dt
-    else:
-        class _Raw:  # expose a decoder-owned device buffer to torch (CUDA array interface)
-            def __init__(self, ptr, n, typestr):
-                self.__cuda_array_interface__ = dict(shape=(n,), typestr=typestr, data=(ptr, False),
-                                                     version=3)
-        # the hidden row travels as raw bytes: uint8 is a type every process-group backend carries
-        # (RCCL has no 16-bit unsigned integer type)
-        nb = m["dim"] * tbytes
-        h_out = torch.as_tensor(_Raw(dec.hidden_out_ptr(), nb, "|u1"), device=f"cuda:{local_rank}")
-        h_in = torch.as_tensor(_Raw(dec.hidden_in_ptr(), nb, "|u1"), device=f"cuda:{local_rank}")
-        tok_t = torch.zeros(1, dtype=torch.int32, device=f"cuda:{local_rank}")
-        from metalchat_amd.pipeline import pipelined_decode
-
-        def stage(token, pos):
-            if rank > 0:
-                torch.cuda.current_stream().synchronize()  # inbound row landed
-            nt = dec.step(token, pos, hidden_in=dec.hidden_in_ptr() if rank > 0 else None,
-                          sync=(rank == world - 1))
-            acc.wait()  # outbound row complete before the hop is enqueued
-            return nt if rank == world - 1 else None
-
-        def run(start, n, tok):
-            toks = pipelined_decode(dist, rank, world, h_in, h_out, tok_t, stage, tok, start, n)
-            return toks[-1] if toks else tok
-
-        tok = 1
-        if fill > 0:
-            tok = run(0, fill, tok)
-        if W > 0:
-            tok = run(fill, W, tok)
-        sync_all()
-        t0 = time.perf_counter()
-        tok = run(fill + W, K, tok)
-        sync_all()
-        dt = time.perf_counter() - t0
-        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        tmax = float(t.item())
+    tok = 1
+    if fill > 0:
+        tok = int(gen(tok, 0, fill)[-1])
+    if W > 0:
+        tok = int(gen(tok, fill, W)[-1])
+    sync_all()
+    t0 = time.perf_counter()
+    gen(tok, fill + W, K)
+    sync_all()
+    dt = time.perf_counter() - t0
+    tmax = sync_all(dt)
 
     ab = algorithmic_bytes(m, args.wbits, args.group, S, tbytes)
     tok_s = K / tmax
@@ -280,12 +417,12 @@ def main():
         "metric": "decode tokens/s (batch=1) + achieved HBM GB/s vs roofline, int4 Llama-3-8B",
         "value": tok_s, "unit": "tokens/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": 1e3 * tmax / K, "higher_is_better": True,
-        "scaling": "strong" if world > 1 else "weak", "vs_baseline": None,
+        "scaling": "strong", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"{args.model} int{args.wbits} (group={args.group}) batch=1 greedy decode, "
                                f"seq_len={S}, {args.dtype} activations/KV, qmode={args.qmode}",
                    "parallelism": "single GPU" if world == 1 else
-                   f"layer pipeline pp{world} ({'gloo hops, ranks sharing GPU 0' if args.share_device else 'RCCL send/recv'})",
+                   f"layer pipeline pp{world} ({'stages sharing GPU 0 in one process, device-to-device hops' if args.share_device else 'one process per GPU, RCCL send/recv on the decoder stream'})",
                    "hipgraph": bool(not piped and not args.no_graph)},
         "whole_token": {"algorithmic_bytes": ab["total"], "achieved_GBs": ab["total"] * tok_s / 1e9,
                         "frac_of_hbm_peak": ab["total"] * tok_s / 1e9 / HBM_PEAK_GBS},
@@ -301,17 +438,24 @@ def main():
         per = ms / (reps * ln)
         achieved = by / ln / (per * 1e-3) / 1e9
         ms_all, by_all, ln_all = dec.time_gemv("all", reps)
+        per_kind = {}
+        for which in ("qkv", "wo", "w2", "head"):
+            msk, byk, lnk = dec.time_gemv(which, reps)
+            pk = msk / (reps * lnk)
+            per_kind[which] = {"avg_launch_us": pk * 1e3, "bytes_per_launch": byk / lnk,
+                               "frac": byk / lnk / (pk * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        kname = dec_kernel_name(args, m)
         out["roofline"] = {
-            "bound": "hbm", "kernel": "mc_gemv (w1|w3 fused, per launch)", "achieved": achieved,
+            "bound": "hbm", "kernel": f"{kname} (w1|w3 fused, per launch)", "achieved": achieved,
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": pmc_traffic(dec_kernel_name(args)),
+            "traffic": pmc_traffic(kname),
             "bytes_per_launch": by / ln, "avg_launch_us": per * 1e3,
+            "other_gemvs": per_kind,
             "all_gemv": {"achieved": by_all * reps / (ms_all * 1e-3) / 1e9,
                          "frac": by_all * reps / (ms_all * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "bytes_per_token": by_all, "ms_per_token": ms_all / reps,
                          "launches_per_token": ln_all},
         }
-    if rank == 0 and world == 1 and not args.no_roofline:
         # informational (not `value`): the prompt pass that precedes decoding -- time to first token
         # for a 512-token prompt through mc_decoder_prefill (dequant-once MFMA GEMMs), measured
         # after the timed region on the same decoder; the first call allocates and is not timed
@@ -330,13 +474,15 @@ def main():
         out["prompt_pass"] = {"tokens": plen, "ms": pms, "tokens_per_s": plen / (pms * 1e-3),
                               "linear_TFLOPs": 2.0 * lin_params * plen / (pms * 1e-3) / 1e12,
                               "mfma_peak_TFLOPs": 2500.0}
+    if rank == 0 and world == 1 and not args.no_other_configs and args.model == "llama3-8b":
+        if pipe is None:
+            dec.release()
+        out["other_configs"] = run_other_configs(mc, acc, np)
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(args, m, tbytes)
     if rank == 0:
-        print(json.dumps(out))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        print(json.dumps(out), flush=True)
+    sync_all()
 
 
 if __name__ == "__main__":

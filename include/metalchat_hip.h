@@ -235,6 +235,27 @@ mc_status mc_decoder_generate(mc_decoder* d, int32_t first_token, int32_t start_
                               int32_t* tokens_out);
 void* mc_decoder_hidden_out(mc_decoder* d);
 void* mc_decoder_hidden_in(mc_decoder* d);
+
+/* Layer pipeline over N stages: stage r owns a contiguous range of L / N layers (the first L % N
+ * stages one more: mc_pipeline_layer_range) of the strict layer
+ * chain include/metalchat/nn/llama.h:123-126 and their caches (nn/attention.h:122-130); per token the hidden row
+ * hops stage to stage and the 4-byte pick returns to stage 0.  Everything, hops included, is enqueued on the
+ * stages' streams: one host synchronisation per mc_pipeline_generate call.
+ *   mc_pipeline_unique_id / _create : one process per GPU; the hop is ONE ncclSend / ncclRecv pair (RCCL over
+ *       xGMI) on the decoder's own stream.  Rank 0 makes the 128-byte id, every rank passes the same bytes.
+ *   mc_pipeline_create_local        : all N stages in this process (on one device or several): the hop is a
+ *       device-to-device copy behind an event -- the same launches per stage, runnable on a one-GPU box.
+ *   mc_pipeline_generate            : called by EVERY rank with the same arguments; tokens_out is filled on
+ *       rank 0 and on the last rank (local: always).  Greedy or the last stage's sampler.
+ *   mc_pipeline_allreduce_max       : barrier + device synchronise, then *value = max over ranks. */
+typedef struct mc_pipeline mc_pipeline;
+void mc_pipeline_layer_range(int32_t rank, int32_t world, int32_t n_layers, int32_t* layer_begin, int32_t* layer_end);
+mc_status mc_pipeline_unique_id(void* id_128_bytes);
+mc_status mc_pipeline_create(mc_decoder* stage, int32_t rank, int32_t world, const void* id_128_bytes, mc_pipeline** out);
+mc_status mc_pipeline_create_local(mc_decoder** stages, int32_t n, mc_pipeline** out);
+mc_status mc_pipeline_generate(mc_pipeline* p, int32_t first_token, int32_t start_pos, int32_t n, int32_t* tokens_out);
+mc_status mc_pipeline_allreduce_max(mc_pipeline* p, double* value);
+void mc_pipeline_release(mc_pipeline* p);
 /* Sampler of the last stage -- include/metalchat/nn/sampling.h:152-315.
  *   MC_SAMPLER_GREEDY : argmax, first maximum (the BASELINE configuration).
  *   MC_SAMPLER_DEFAULT: make_default_sampler() = topk_sampler(top_k) -> nucleus_sampler(temperature,

@@ -1766,6 +1766,291 @@ mc_decoder_weight_ptrs(mc_decoder* d, int32_t layer, const char* name, void** w,
     return MC_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Layer pipeline: stage r of N owns a contiguous range of about L / N layers and their caches; the only
+// state that crosses a stage boundary is the hidden row (include/metalchat/nn/llama.h:123-126 is a strict
+// chain of layers, each with its own cache, nn/attention.h:122-130), plus the 4-byte token on its way back to
+// stage 0.  Everything is ENQUEUED on the stages' streams -- hops included -- with one host synchronisation
+// per generate call:
+//   * RCCL transport (one process per GPU): ncclSend / ncclRecv of the row on the decoder's own stream,
+//     ncclRecv of the token straight into stage 0's step state.  librccl is opened with dlopen on first
+//     use, so single-GPU users never load it.
+//   * local transport (all stages in one process, on one or several devices): a device-to-device copy on
+//     the consuming stage's stream behind an event of the producing stage -- what the one-GPU test box
+//     can run, and bit-for-bit the same launches per stage.
+// ------------------------------------------------------------------------------------------------
+} // extern "C"
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+namespace {
+
+struct rccl_api {
+    void* handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    std::string error;
+};
+
+rccl_api&
+rccl()
+{
+    static rccl_api api;
+    if (api.handle || !api.error.empty()) return api;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        api.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (api.handle) break;
+    }
+    if (!api.handle) {
+        api.error = std::string("pipeline: librccl not found (") + dlerror() + ")";
+        return api;
+    }
+#define SYM(field, sym)                                                        \
+    api.field = reinterpret_cast<decltype(api.field)>(dlsym(api.handle, sym)); \
+    if (!api.field) api.error = std::string("pipeline: librccl has no ") + sym;
+    SYM(GetUniqueId, "ncclGetUniqueId")
+    SYM(CommInitRank, "ncclCommInitRank")
+    SYM(CommDestroy, "ncclCommDestroy")
+    SYM(Send, "ncclSend")
+    SYM(Recv, "ncclRecv")
+    SYM(AllReduce, "ncclAllReduce")
+    SYM(GetErrorString, "ncclGetErrorString")
+#undef SYM
+    return api;
+}
+
+mc_status
+nccl_fail(ncclResult_t r, const char* what)
+{
+    return fail(MC_ERR_RUNTIME, std::string("rccl: ") + what + ": " + (rccl().GetErrorString ? rccl().GetErrorString(r) : "error"));
+}
+#define MC_NCCL(call, what)                               \
+    do {                                                  \
+        ncclResult_t r_ = (call);                         \
+        if (r_ != ncclSuccess) return nccl_fail(r_, what); \
+    } while (0)
+
+} // namespace
+
+struct mc_pipeline {
+    int rank = 0, world = 1;
+    ncclComm_t comm = nullptr;           // RCCL transport
+    std::vector<mc_decoder*> stages;     // this process's stages: one (RCCL) or all of them (local)
+    std::vector<hipEvent_t> done;        // local transport: stage s finished its part of the current token
+    double* red = nullptr;               // device scratch of the max-reduction
+    bool local = false;
+};
+
+extern "C" {
+
+void
+mc_pipeline_layer_range(int32_t rank, int32_t world, int32_t n_layers, int32_t* layer_begin, int32_t* layer_end)
+{
+    const int base = n_layers / world, extra = n_layers % world;
+    const int lb = rank * base + std::min(rank, extra);
+    if (layer_begin) *layer_begin = lb;
+    if (layer_end) *layer_end = lb + base + (rank < extra ? 1 : 0);
+}
+
+mc_status
+mc_pipeline_unique_id(void* id128)
+{
+    if (!id128) return fail(MC_ERR_INVALID_ARGUMENT, "mc_pipeline_unique_id: null argument");
+    rccl_api& api = rccl();
+    if (!api.error.empty()) return fail(MC_ERR_RUNTIME, api.error);
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+    MC_NCCL(api.GetUniqueId(static_cast<ncclUniqueId*>(id128)), "ncclGetUniqueId");
+    return MC_OK;
+}
+
+static mc_status
+check_stage(mc_decoder* d, int rank, int world)
+{
+    if (!d) return fail(MC_ERR_INVALID_ARGUMENT, "pipeline: null decoder");
+    // layer_range of stage `rank`: what metalchat_amd/pipeline.py and the oracle's stage split use
+    const int L = d->cfg.n_layers, base = L / world, extra = L % world; // the first L % world stages get one extra layer
+    const int lb = rank * base + std::min(rank, extra), le = lb + base + (rank < extra ? 1 : 0);
+    if (d->cfg.layer_begin != lb || d->cfg.layer_end != le)
+        return fail(MC_ERR_INVALID_ARGUMENT, "pipeline: stage " + std::to_string(rank) + " of " + std::to_string(world) +
+                                                 " must own layers [" + std::to_string(lb) + ", " + std::to_string(le) + ")");
+    return check_ready(d);
+}
+
+mc_status
+mc_pipeline_create(mc_decoder* stage, int32_t rank, int32_t world, const void* id128, mc_pipeline** out)
+{
+    if (!stage || !id128 || !out || world < 1 || rank < 0 || rank >= world)
+        return fail(MC_ERR_INVALID_ARGUMENT, "mc_pipeline_create: bad argument");
+    mc_status s = check_stage(stage, rank, world);
+    if (s != MC_OK) return s;
+    rccl_api& api = rccl();
+    if (!api.error.empty()) return fail(MC_ERR_RUNTIME, api.error);
+    MC_HIP(hipSetDevice(stage->dev->ordinal));
+    auto p = std::unique_ptr<mc_pipeline>(new mc_pipeline());
+    p->rank = rank;
+    p->world = world;
+    p->stages.push_back(stage);
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof id);
+    MC_NCCL(api.CommInitRank(&p->comm, world, id, rank), "ncclCommInitRank");
+    MC_HIP(hipMalloc((void**)&p->red, 16));
+    *out = p.release();
+    return MC_OK;
+}
+
+mc_status
+mc_pipeline_create_local(mc_decoder** stages, int32_t n, mc_pipeline** out)
+{
+    if (!stages || !out || n < 1) return fail(MC_ERR_INVALID_ARGUMENT, "mc_pipeline_create_local: bad argument");
+    auto p = std::unique_ptr<mc_pipeline>(new mc_pipeline());
+    p->local = true;
+    p->world = n;
+    for (int i = 0; i < n; i++) {
+        mc_status s = check_stage(stages[i], i, n);
+        if (s != MC_OK) return s;
+        p->stages.push_back(stages[i]);
+        MC_HIP(hipSetDevice(stages[i]->dev->ordinal));
+        hipEvent_t e;
+        MC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        p->done.push_back(e);
+    }
+    *out = p.release();
+    return MC_OK;
+}
+
+void
+mc_pipeline_release(mc_pipeline* p)
+{
+    if (!p) return;
+    if (p->comm) (void)rccl().CommDestroy(p->comm);
+    for (hipEvent_t e : p->done) (void)hipEventDestroy(e);
+    if (p->red) (void)hipFree(p->red);
+    delete p;
+}
+
+// the launches of token i on one stage (state, layers, head on the last stage); hops are the caller's
+static mc_status
+stage_token(mc_decoder* d, int i, int32_t first_token, int32_t start_pos)
+{
+    const int pos = start_pos + i;
+    mc_status s = d->ensure_rope(pos);
+    if (s != MC_OK) return s;
+    bool fused_advance = false;
+    if (i == 0) {
+        s = d->launch("mc_step_set", 1, 1, 1, 64, 0,
+                      pack(d->state, d->first_stage ? first_token : (int32_t)-1, start_pos, (int32_t)d->cfg.max_seq_len,
+                           (int32_t)d->pre_len, (int32_t)d->rope_start, (int32_t)(start_pos == 0 ? 1 : 0)));
+        if (s != MC_OK) return s;
+        MC_HIP(hipMemsetAsync(&d->state->step_index, 0, 4, d->stream));
+    } else if (d->first_stage) {
+        fused_advance = true; // the embedding launch advances the state
+    } else {
+        s = d->launch("mc_step_advance", 1, 1, 1, 64, 0, pack(d->state, (int32_t)d->cfg.max_seq_len, (int32_t)d->pre_len));
+        if (s != MC_OK) return s;
+    }
+    return d->run_token(d->first_stage ? nullptr : d->hidden_in, fused_advance);
+}
+
+mc_status
+mc_pipeline_generate(mc_pipeline* p, int32_t first_token, int32_t start_pos, int32_t n, int32_t* tokens_out)
+{
+    if (!p || n <= 0 || start_pos < 0) return fail(MC_ERR_INVALID_ARGUMENT, "mc_pipeline_generate: bad argument");
+    const int W = p->world;
+    for (mc_decoder* d : p->stages) {
+        if (n > d->tokens_cap) return fail(MC_ERR_INVALID_ARGUMENT, "mc_pipeline_generate: n too large");
+        if (d->first_stage && (first_token < 0 || first_token >= d->cfg.vocab))
+            return fail(MC_ERR_INVALID_ARGUMENT, "decoder: token id outside the vocabulary");
+        if (d->sampler_kind != MC_SAMPLER_GREEDY && !d->last_stage)
+            return fail(MC_ERR_INVALID_ARGUMENT, "decoder: only the last stage samples");
+    }
+    mc_status s;
+    if (p->local) {
+        mc_decoder* first = p->stages.front();
+        mc_decoder* last = p->stages.back();
+        const size_t row = (size_t)first->cfg.dim * first->tb;
+        for (int i = 0; i < n; i++) {
+            for (int r = 0; r < W; r++) {
+                mc_decoder* d = p->stages[r];
+                MC_HIP(hipSetDevice(d->dev->ordinal));
+                if (r > 0) {
+                    mc_decoder* prev = p->stages[r - 1];
+                    if (prev->stream != d->stream) MC_HIP(hipStreamWaitEvent(d->stream, p->done[r - 1], 0));
+                    MC_HIP(hipMemcpyAsync(d->hidden_in, prev->hidden, row, hipMemcpyDeviceToDevice, d->stream));
+                } else if (i > 0 && W > 1) {
+                    // the token picked by the last stage, straight into stage 0's step state
+                    if (last->stream != d->stream) MC_HIP(hipStreamWaitEvent(d->stream, p->done[W - 1], 0));
+                    MC_HIP(hipMemcpyAsync(&d->state->token, &last->state->token, 4, hipMemcpyDeviceToDevice, d->stream));
+                }
+                s = stage_token(d, i, first_token, start_pos);
+                if (s != MC_OK) return s;
+                MC_HIP(hipEventRecord(p->done[r], d->stream));
+            }
+        }
+        for (mc_decoder* d : p->stages) {
+            d->last_pos = start_pos + n - 1;
+            if (start_pos == 0) d->ring_turned = false;
+            if (start_pos + n > d->cfg.max_seq_len) d->ring_turned = true;
+        }
+        MC_HIP(hipSetDevice(last->dev->ordinal));
+        if (tokens_out) MC_HIP(hipMemcpyAsync(tokens_out, last->tokens_dev, (size_t)n * 4, hipMemcpyDeviceToHost, last->stream));
+        for (mc_decoder* d : p->stages) {
+            MC_HIP(hipSetDevice(d->dev->ordinal));
+            MC_HIP(hipStreamSynchronize(d->stream));
+        }
+        return MC_OK;
+    }
+    // ---- RCCL: this process is stage `rank`
+    rccl_api& api = rccl();
+    mc_decoder* d = p->stages[0];
+    const int r = p->rank;
+    MC_HIP(hipSetDevice(d->dev->ordinal));
+    const size_t row = (size_t)d->cfg.dim * d->tb; // the row travels as bytes (RCCL has no 16-bit unsigned type)
+    for (int i = 0; i < n; i++) {
+        if (r > 0) MC_NCCL(api.Recv(d->hidden_in, row, ncclUint8, r - 1, p->comm, d->stream), "ncclRecv(hidden row)");
+        else if (i > 0 && W > 1) MC_NCCL(api.Recv(&d->state->token, 1, ncclInt32, W - 1, p->comm, d->stream), "ncclRecv(token)");
+        s = stage_token(d, i, first_token, start_pos);
+        if (s != MC_OK) return s;
+        if (r < W - 1) MC_NCCL(api.Send(d->hidden, row, ncclUint8, r + 1, p->comm, d->stream), "ncclSend(hidden row)");
+        else if (W > 1 && i + 1 < n) MC_NCCL(api.Send(&d->state->token, 1, ncclInt32, 0, p->comm, d->stream), "ncclSend(token)");
+    }
+    d->last_pos = start_pos + n - 1;
+    if (start_pos == 0) d->ring_turned = false;
+    if (start_pos + n > d->cfg.max_seq_len) d->ring_turned = true;
+    // the generated ids: collected by the last stage, handed to stage 0 in one message
+    if (W > 1 && r == W - 1) MC_NCCL(api.Send(d->tokens_dev, (size_t)n, ncclInt32, 0, p->comm, d->stream), "ncclSend(tokens)");
+    if (W > 1 && r == 0) MC_NCCL(api.Recv(d->tokens_dev, (size_t)n, ncclInt32, W - 1, p->comm, d->stream), "ncclRecv(tokens)");
+    if (tokens_out && (r == 0 || r == W - 1))
+        MC_HIP(hipMemcpyAsync(tokens_out, d->tokens_dev, (size_t)n * 4, hipMemcpyDeviceToHost, d->stream));
+    MC_HIP(hipStreamSynchronize(d->stream));
+    return MC_OK;
+}
+
+// barrier over the stages + device synchronise, and the maximum of a host value over the stages (bench.py's timing
+// contract); a local pipeline has nothing to exchange
+mc_status
+mc_pipeline_allreduce_max(mc_pipeline* p, double* value)
+{
+    if (!p || !value) return fail(MC_ERR_INVALID_ARGUMENT, "mc_pipeline_allreduce_max: null argument");
+    for (mc_decoder* d : p->stages) {
+        MC_HIP(hipSetDevice(d->dev->ordinal));
+        MC_HIP(hipStreamSynchronize(d->stream));
+    }
+    if (p->local || p->world == 1) return MC_OK;
+    rccl_api& api = rccl();
+    mc_decoder* d = p->stages[0];
+    MC_HIP(hipMemcpyAsync(p->red, value, 8, hipMemcpyHostToDevice, d->stream));
+    MC_NCCL(api.AllReduce(p->red, p->red, 1, ncclDouble, ncclMax, p->comm, d->stream), "ncclAllReduce");
+    MC_HIP(hipMemcpyAsync(value, p->red, 8, hipMemcpyDeviceToHost, d->stream));
+    MC_HIP(hipStreamSynchronize(d->stream));
+    return MC_OK;
+}
+
 int32_t
 mc_synth_weight(uint64_t seed, uint32_t matrix_id, uint32_t row, uint32_t col, int32_t bits)
 {

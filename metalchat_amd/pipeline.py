@@ -15,7 +15,7 @@ from typing import Callable, List, Optional, Tuple
 
 
 def layer_range(rank: int, world: int, n_layers: int) -> Tuple[int, int]:
-    """Contiguous split; the first n_layers % world stages get one extra layer."""
+    """Contiguous split; the first n_layers % world stages get one extra layer (== mc_pipeline_layer_range)."""
     base, extra = divmod(n_layers, world)
     lb = rank * base + min(rank, extra)
     return lb, lb + base + (1 if rank < extra else 0)

@@ -117,6 +117,13 @@ def capi() -> C.CDLL:
         "mc_decoder_prefill": (i32, [vp, C.POINTER(i32), i32, i32, i32, C.POINTER(i32)]),
         "mc_decoder_hidden_out": (vp, [vp]),
         "mc_decoder_hidden_in": (vp, [vp]),
+        "mc_pipeline_layer_range": (None, [i32, i32, i32, C.POINTER(i32), C.POINTER(i32)]),
+        "mc_pipeline_unique_id": (i32, [vp]),
+        "mc_pipeline_create": (i32, [vp, i32, i32, vp, pvp]),
+        "mc_pipeline_create_local": (i32, [pvp, i32, pvp]),
+        "mc_pipeline_generate": (i32, [vp, i32, i32, i32, C.POINTER(i32)]),
+        "mc_pipeline_allreduce_max": (i32, [vp, C.POINTER(C.c_double)]),
+        "mc_pipeline_release": (None, [vp]),
         "mc_decoder_set_taps": (i32, [vp, i32]),
         "mc_decoder_get_logits": (i32, [vp, vp]),
         "mc_decoder_get_hidden": (i32, [vp, i32, vp]),
@@ -449,6 +456,63 @@ class HardwareAccelerator:
 
     def stream(self) -> int:
         return capi().mc_queue_stream(self._queue)
+
+
+def pipeline_unique_id() -> bytes:
+    """The 128-byte RCCL id rank 0 creates and hands to every rank (file, socket, ...)."""
+    buf = C.create_string_buffer(128)
+    _check(capi().mc_pipeline_unique_id(buf))
+    return buf.raw
+
+
+def pipeline_layer_range(rank: int, world: int, n_layers: int):
+    lb, le = C.c_int32(), C.c_int32()
+    capi().mc_pipeline_layer_range(rank, world, n_layers, C.byref(lb), C.byref(le))
+    return lb.value, le.value
+
+
+class Pipeline:
+    """mc_pipeline_*: the layer pipeline behind the C ABI.  Pipeline.local(stages) keeps all stages in this
+    process (device-to-device hops); Pipeline.rccl(stage, rank, world, uid) is one process per GPU."""
+
+    def __init__(self, handle, keep):
+        self._h, self._keep = handle, keep
+
+    @classmethod
+    def local(cls, stages):
+        arr = (C.c_void_p * len(stages))(*[d._h for d in stages])
+        h = C.c_void_p()
+        _check(capi().mc_pipeline_create_local(arr, len(stages), C.byref(h)))
+        return cls(h, list(stages))
+
+    @classmethod
+    def rccl(cls, stage, rank: int, world: int, uid: bytes):
+        assert len(uid) == 128
+        h = C.c_void_p()
+        _check(capi().mc_pipeline_create(stage._h, rank, world, uid, C.byref(h)))
+        return cls(h, [stage])
+
+    def generate(self, first_token: int, start_pos: int, n: int) -> np.ndarray:
+        out = np.zeros(n, dtype=np.int32)
+        _check(capi().mc_pipeline_generate(self._h, first_token, start_pos, n, out.ctypes.data_as(C.POINTER(C.c_int32))))
+        return out
+
+    def allreduce_max(self, value: float = 0.0) -> float:
+        """Barrier over the stages + device synchronise; returns max(value) over the ranks."""
+        v = C.c_double(value)
+        _check(capi().mc_pipeline_allreduce_max(self._h, C.byref(v)))
+        return v.value
+
+    def release(self):
+        if self._h:
+            capi().mc_pipeline_release(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
 
 
 class Decoder:

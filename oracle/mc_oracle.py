@@ -34,7 +34,8 @@ _lib = None
 def lib() -> C.CDLL:
     global _lib
     if _lib is None:
-        _lib = C.CDLL(build())
+        # MC_ORACLE_SO: bench.py's cpu_baseline leg loads a build made -O3 -march=native on the timing host
+        _lib = C.CDLL(os.environ.get("MC_ORACLE_SO") or build())
         _lib.mco_bf16_to_f32.restype = C.c_float
         _lib.mco_bf16_to_f32.argtypes = [C.c_uint16]
         _lib.mco_f32_to_bf16.restype = C.c_uint16

@@ -1,0 +1,135 @@
+"""The layer pipeline behind the C ABI (mc_pipeline_*) on the GPU.
+
+One box has one GPU, so the N stages run in ONE process here (mc_pipeline_create_local: device-to-device hops
+behind events -- the same launches per stage as the RCCL transport, whose hop is ncclSend / ncclRecv on the same
+stream).  The split must not change a single bit: tokens, logits and every stage's caches equal the single-stage
+decoder's for N = 2, 4, 8, llama3 and gemma3, greedy and the device sampler, past max_seq_len (sink ring), and
+against the oracle's own stage split (mco_model_step_range)."""
+import numpy as np
+import pytest
+
+import modelgen as mg
+import parity
+from oracle import mc_oracle as mo
+
+pytestmark = pytest.mark.gpu
+BF16, F32 = 0, 1
+
+
+def build(acc, cfg, weights, world, fmt, group, **over):
+    import metalchat_amd as mc
+
+    stages = []
+    for r in range(world):
+        lb, le = mc.pipeline_layer_range(r, world, cfg["n_layers"])
+        d = mc.Decoder(acc, **mg.decoder_kwargs(cfg, weight_format=fmt, group_size=group, layer_begin=lb, layer_end=le, **over))
+        d.load_model(weights)
+        stages.append(d)
+    return stages
+
+
+@pytest.mark.parametrize("family,dtype", [(0, BF16), (0, F32), (1, BF16)])
+def test_local_pipeline_equals_the_single_stage_bit_for_bit(acc, family, dtype):
+    import metalchat_amd as mc
+
+    over = dict(family=family, n_layers=8, max_seq_len=24)
+    if family == 1:
+        over.update(rope_sliding_theta=10000.0, sliding_stride=2)
+    cfg = mg.tiny_cfg(dtype, **over)
+    weights = mg.make_model(cfg, seed=11, quant="i4", group=32)
+    single = mc.Decoder(acc, **mg.decoder_kwargs(cfg, weight_format=mc.WFMT_I4, group_size=32))
+    single.load_model(weights)
+    n = 40  # 16 tokens past max_seq_len: every stage's ring turns
+    want = list(single.generate(5, 0, n))
+    want_logits = single.logits().copy()
+    want_kv = {layer: tuple(a.copy() for a in single.export_kv(layer)) for layer in range(cfg["n_layers"])}
+    want_more = list(single.generate(want[-1], n, 6))  # a second call continues from the caches (start_pos > 0)
+    single.release()
+    for world in (2, 4, 8):
+        stages = build(acc, cfg, weights, world, mc.WFMT_I4, 32)
+        pipe = mc.Pipeline.local(stages)
+        got = list(pipe.generate(5, 0, n))
+        assert got == want, f"world {world}: tokens differ"
+        parity.exact(stages[-1].logits(), want_logits, f"world {world}: logits of the last token")
+        for r, d in enumerate(stages):
+            for layer in range(d.cfg["layer_begin"], d.cfg["layer_end"]):
+                gk, gv = d.export_kv(layer)
+                parity.exact(gk, want_kv[layer][0], f"world {world} stage {r} K[{layer}]")
+                parity.exact(gv, want_kv[layer][1], f"world {world} stage {r} V[{layer}]")
+        assert list(pipe.generate(got[-1], n, 6)) == want_more, f"world {world}: continuation differs"
+        pipe.release()
+        for d in stages:
+            d.release()
+
+
+def test_local_pipeline_against_the_oracle_stage_split(acc):
+    import metalchat_amd as mc
+
+    cfg = mg.tiny_cfg(F32, n_layers=4, max_seq_len=32)
+    weights = mg.make_model(cfg, seed=2, quant="i8", group=32)
+    om = mo.Model(cfg, weights)
+    otoks, tok = [], 3
+    for pos in range(12):
+        tok, _ = om.step(tok, pos)
+        otoks.append(tok)
+    stages = build(acc, cfg, weights, 2, mc.WFMT_I8, 32)
+    pipe = mc.Pipeline.local(stages)
+    assert list(pipe.generate(3, 0, 12)) == otoks
+    pipe.release()
+    for d in stages:
+        d.release()
+    om.close()
+
+
+def test_local_pipeline_with_the_device_sampler(acc):
+    import metalchat_amd as mc
+
+    cfg = mg.tiny_cfg(BF16, n_layers=4, max_seq_len=32)
+    weights = mg.make_model(cfg, seed=4, quant="i4", group=32)
+    single = mc.Decoder(acc, **mg.decoder_kwargs(cfg, weight_format=mc.WFMT_I4, group_size=32))
+    single.load_model(weights)
+    single.set_sampler(mc.SAMPLER_DEFAULT, 50, 0.6, 0.9)
+    single.set_seeds([(1, 2), (3, 4)])
+    want = list(single.generate(7, 0, 20))
+    stages = build(acc, cfg, weights, 4, mc.WFMT_I4, 32)
+    stages[-1].set_sampler(mc.SAMPLER_DEFAULT, 50, 0.6, 0.9)
+    stages[-1].set_seeds([(1, 2), (3, 4)])
+    pipe = mc.Pipeline.local(stages)
+    assert list(pipe.generate(7, 0, 20)) == want
+    pipe.release()
+    for d in stages + [single]:
+        d.release()
+
+
+def test_pipeline_rejects_a_wrong_layer_split(acc):
+    import metalchat_amd as mc
+
+    cfg = mg.tiny_cfg(BF16, n_layers=4)
+    weights = mg.make_model(cfg, seed=1, quant="i4", group=32)
+    a = mc.Decoder(acc, **mg.decoder_kwargs(cfg, weight_format=mc.WFMT_I4, group_size=32, layer_begin=0, layer_end=3))
+    b = mc.Decoder(acc, **mg.decoder_kwargs(cfg, weight_format=mc.WFMT_I4, group_size=32, layer_begin=3, layer_end=4))
+    a.load_model(weights)
+    b.load_model(weights)
+    with pytest.raises(mc.McError, match="must own layers"):
+        mc.Pipeline.local([a, b])
+    a.release()
+    b.release()
+
+
+def test_rccl_transport_comes_up_with_one_rank(acc):
+    # the RCCL path needs one GPU per rank; what a one-GPU box can check is that librccl loads, a unique id is made, a
+    # communicator of one rank initialises on the decoder's device and generate() degenerates to the single stage
+    import metalchat_amd as mc
+
+    cfg = mg.tiny_cfg(BF16, n_layers=2)
+    weights = mg.make_model(cfg, seed=1, quant="i4", group=32)
+    d = mc.Decoder(acc, **mg.decoder_kwargs(cfg, weight_format=mc.WFMT_I4, group_size=32))
+    d.load_model(weights)
+    want = list(d.generate(3, 0, 10))
+    uid = mc.pipeline_unique_id()
+    assert len(uid) == 128 and any(uid)
+    pipe = mc.Pipeline.rccl(d, 0, 1, uid)
+    assert list(pipe.generate(3, 0, 10)) == want
+    assert pipe.allreduce_max(1.5) == 1.5
+    pipe.release()
+    d.release()
