@@ -94,10 +94,28 @@ def test_pipelined_tokens_equal_single_process(world):
     assert toks == ref
 
 
-def test_bench_ships_the_hidden_row_as_bytes():
-    # RCCL's process group rejects 16-bit unsigned tensors ("Input tensor data type is not supported for
-    # NCCL process group: UInt16", tools/dtype_probe.py on the MI355X box): the bf16 hidden row of the
-    # N > 1 bench path has to travel as uint8
+def test_the_native_pipeline_ships_the_hidden_row_as_bytes_and_bench_needs_no_torch():
+    # RCCL has no 16-bit unsigned element type (its process group rejects UInt16 tensors, tools/dtype_probe.py on the
+    # MI355X box): the bf16 hidden row travels as bytes through ncclSend / ncclRecv (csrc/decoder.cc, mc_pipeline_generate);
+    # bench.py drives that C ABI and must not import torch at any N
     import os
-    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")).read()
-    assert '"|u1"' in src and '"<u2"' not in src
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    host = open(os.path.join(root, "metalchat_amd", "csrc", "decoder.cc")).read()
+    assert re.search(r"api\.Send\(d->hidden, row, ncclUint8", host) and re.search(r"api\.Recv\(d->hidden_in, row, ncclUint8", host)
+    bench = open(os.path.join(root, "bench.py")).read()
+    assert not re.search(r"^\s*(import|from)\s+torch", bench, re.M)
+
+
+def test_bench_gpus_n_starts_its_own_workers_and_does_not_hang_when_they_die():
+    # `python bench.py --gpus 2` without a launcher spawns two fresh workers; in this container there is no GPU, so both
+    # fail in mc_device_create ("no HIP device") -- the parent must come back with their exit code instead of waiting
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0
+    assert "HIP" in r.stderr or "hip" in r.stderr
