@@ -226,9 +226,18 @@ mc_status mc_decoder_step(mc_decoder* d, int32_t token, int32_t start_pos, const
  * form the causal square, columns of an earlier context stay masked -- as the reference builds it),
  * and the last row goes through the head and the sampler; *next_token receives its pick.
  * sliding_window: gemma3_options.sliding_window (sliding layers only); 0 for llama3.
- * len == 1 is mc_decoder_step.  start_pos + len must not exceed max_seq_len. */
+ * len == 1 is mc_decoder_step.  The cache follows nn::sink_cache::copy (nn/cache.h:167-216): a chunk either fits
+ * behind start_pos (start_pos + len <= max_seq_len), or, once start_pos >= max_seq_len, the post-sink region is
+ * rotated left by len and the chunk takes the last len rows (len <= max_seq_len, "sink_cache: requested length ... is
+ * larger than the cache size" otherwise).  A chunk that starts inside the cache and ends outside is an error, as it
+ * is in the reference (its cache slice runs out of range).
+ * mc_decoder_prefill_stage is the same pass on ONE STAGE of a layer pipeline: the first stage takes `tokens`, a later
+ * stage the [len][dim] hidden rows of the previous one (`rows_in`, device memory); *rows_out (device memory, valid
+ * until the next prompt pass) receives this stage's rows; the last stage runs the head and fills *next_token. */
 mc_status mc_decoder_prefill(mc_decoder* d, const int32_t* tokens, int32_t len, int32_t start_pos,
                              int32_t sliding_window, int32_t* next_token);
+mc_status mc_decoder_prefill_stage(mc_decoder* d, const int32_t* tokens, const void* rows_in, int32_t len,
+                                   int32_t start_pos, int32_t sliding_window, void** rows_out, int32_t* next_token);
 /* Enqueue `n` chained greedy steps entirely on the device (token feedback through HBM, one host
  * sync at the end); tokens_out receives the n generated ids.  Single-stage decoders only. */
 mc_status mc_decoder_generate(mc_decoder* d, int32_t first_token, int32_t start_pos, int32_t n,
@@ -254,6 +263,8 @@ mc_status mc_pipeline_unique_id(void* id_128_bytes);
 mc_status mc_pipeline_create(mc_decoder* stage, int32_t rank, int32_t world, const void* id_128_bytes, mc_pipeline** out);
 mc_status mc_pipeline_create_local(mc_decoder** stages, int32_t n, mc_pipeline** out);
 mc_status mc_pipeline_generate(mc_pipeline* p, int32_t first_token, int32_t start_pos, int32_t n, int32_t* tokens_out);
+mc_status mc_pipeline_prefill(mc_pipeline* p, const int32_t* tokens, int32_t len, int32_t start_pos, int32_t sliding_window,
+                              int32_t* next_token); /* the prompt pass: [len][dim] rows hop stage to stage */
 mc_status mc_pipeline_allreduce_max(mc_pipeline* p, double* value);
 void mc_pipeline_release(mc_pipeline* p);
 /* Sampler of the last stage -- include/metalchat/nn/sampling.h:152-315.

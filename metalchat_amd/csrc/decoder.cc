@@ -204,6 +204,7 @@ struct mc_decoder {
     float* pf_part = nullptr; // split-K partial sums [splits][M][N]
     size_t pf_part_elems = 0;
     bool ring_turned = false;
+    void *rot_k = nullptr, *rot_v = nullptr; // scratch of mc_kv_rotate (one layer's K and Vt)
     // MC_PF_TIMING=1: per-category GPU time of a prompt pass printed to stderr (tuning aid; it
     // synchronises after every launch)
     bool pf_timing = false;
@@ -520,12 +521,13 @@ struct mc_decoder {
     }
 
     mc_status
-    ensure_rope(int pos)
+    ensure_rope(int pos, int len = 1)
     {
-        // nn::rope::operator() (include/metalchat/nn/embedding.h:190-198)
-        if (rope_valid && pos >= rope_start && pos < rope_start + rope_rows) return MC_OK;
-        rope_start = rope_valid ? pos : 0;
-        if (!rope_valid && pos >= rope_rows) rope_start = pos;
+        // nn::rope::operator() (include/metalchat/nn/embedding.h:190-198): the table holds 2 * max_seq_len rows and is
+        // regenerated from the requested position when that leaves the window (a table row depends on the absolute
+        // position only, so where the window starts never shows in a value)
+        if (rope_valid && pos >= rope_start && pos + len <= rope_start + rope_rows) return MC_OK;
+        rope_start = pos + len <= rope_rows && !rope_valid ? 0 : pos;
         const unsigned half = cfg.head_dim / 2;
         for (int t = 0; t < 2; t++) {
             const float theta = t == 0 ? cfg.rope_theta : cfg.rope_sliding_theta;
@@ -814,10 +816,14 @@ struct mc_decoder {
     }
 
     // nn::llama3 / nn::gemma3 operator() on M > 1 rows (llama.h:113-134, gemma.h:110-137)
+    // cache_pos: first cache row (= logical column) the M rows are written to; rope_pos: their sequence position
+    // (they differ for a chunk behind a full cache: rows max_seq_len - M .., positions start_pos ..);
+    // rows_in: hidden rows [M][dim] from the previous pipeline stage (device), null on the first stage
     mc_status
-    run_prefill(int M, int start_pos, int window)
+    run_prefill(int M, int cache_pos, int rope_pos, int window, const void* rows_in)
     {
         const int dim = cfg.dim, H = cfg.n_heads, KV = cfg.n_kv_heads, hd = cfg.head_dim;
+        const int start_pos = cache_pos;
         const int S = start_pos + M;
         const bool gemma = cfg.family == MC_FAMILY_GEMMA3;
         const float mu = gemma ? 1.0f : 0.0f;
@@ -826,7 +832,10 @@ struct mc_decoder {
         if (tb == 2) sc = bf2f_host(f2bf_host(sc));
         mc_status s;
         const unsigned gd = (dim + 255) / 256;
-        if (emb_fmt == MC_WFMT_T)
+        if (!first_stage) {
+            MC_HIP(hipMemcpyAsync(pf_x, rows_in, (size_t)M * dim * tb, hipMemcpyDeviceToDevice, stream));
+            s = MC_OK;
+        } else if (emb_fmt == MC_WFMT_T)
             s = launch("mc_pf_embed_" + tname, gd, M, 1, 256, 0,
                        pack(emb_table, pf_tokens, pf_x, (uint32_t)dim, sc, (int32_t)(gemma ? 1 : 0)));
         else
@@ -844,7 +853,7 @@ struct mc_decoder {
             s = timed("rope_cache", [&] { return launch("mc_pf_rope_cache_" + tname, H + 2 * KV, M, 1, hd / 2, 0,
                        pack(pf_qkv, pf_q, L.kc, L.vt, rope_cos[L.rope_table], rope_sin[L.rope_table], L.q_norm,
                             L.k_norm, (uint32_t)H, (uint32_t)KV, (uint32_t)hd, (uint32_t)cfg.max_seq_len,
-                            (uint32_t)start_pos, (uint32_t)(start_pos - rope_start), cfg.norm_eps, mu)); });
+                            (uint32_t)start_pos, (uint32_t)(rope_pos - rope_start), cfg.norm_eps, mu)); });
             if (s != MC_OK) return s;
             const uint32_t win = (gemma && L.rope_table == 1) ? (uint32_t)window : 0u;
             if (tb == 2 && !pf_two_pass) {
@@ -900,9 +909,9 @@ struct mc_decoder {
                 MC_HIP(hipMemcpyAsync((char*)taps + (size_t)(li + 1) * dim * tb, (char*)pf_x + last, (size_t)dim * tb,
                                       hipMemcpyDeviceToDevice, stream));
         }
-        // only the last row goes through the head (llama.h:130-133)
+        // only the last row goes through the head (llama.h:130-133); other stages hand all rows on (pf_x)
         MC_HIP(hipMemcpyAsync(hidden, (char*)pf_x + last, (size_t)dim * tb, hipMemcpyDeviceToDevice, stream));
-        s = timed("head", [&] { return run_head(); });
+        s = last_stage ? timed("head", [&] { return run_head(); }) : MC_OK;
         if (pf_timing) {
             double tot = 0;
             for (auto& kv : pf_ms) tot += kv.second;
@@ -1440,51 +1449,87 @@ mc_decoder_step(mc_decoder* d, int32_t token, int32_t start_pos, const void* hid
 }
 
 mc_status
+mc_decoder_prefill_stage(mc_decoder* d, const int32_t* tokens, const void* rows_in, int32_t len, int32_t start_pos,
+                         int32_t sliding_window, void** rows_out, int32_t* next_token)
+{
+    if (!d) return fail(MC_ERR_INVALID_ARGUMENT, "mc_decoder_prefill: null argument");
+    if (d->first_stage ? !tokens : !rows_in)
+        return fail(MC_ERR_INVALID_ARGUMENT, "mc_decoder_prefill: the first stage takes token ids, a later stage the inbound hidden rows");
+    if (len < 1 || start_pos < 0) return fail(MC_ERR_INVALID_ARGUMENT, "mc_decoder_prefill: bad length or position");
+    const int S = d->cfg.max_seq_len;
+    if (len > S)
+        return fail(MC_ERR_INVALID_ARGUMENT, "sink_cache: requested length (" + std::to_string(len) +
+                                                 ") is larger than the cache size (" + std::to_string(S) + ")"); // nn/cache.h:178-183
+    // nn::sink_cache::copy (nn/cache.h:187-213): a chunk either fits behind start_pos, or -- once start_pos has
+    // left the cache -- the post-sink region is rotated left by len and the chunk takes the last len rows.  A chunk
+    // that starts inside the cache and ends outside has no branch there (its slice runs past the tensor).
+    const bool behind_full = start_pos >= S;
+    if (!behind_full && start_pos + len > S)
+        return fail(MC_ERR_INVALID_ARGUMENT, "sink_cache: rows [" + std::to_string(start_pos) + ", " + std::to_string(start_pos + len) +
+                                                 ") straddle the end of the cache (" + std::to_string(S) + "): the reference clamps the "
+                                                 "target slice and its clone kernel rejects the element counts "
+                                                 "(kernel/copy.h:38-39); split the chunk at the cache size");
+    if (d->first_stage)
+        for (int i = 0; i < len; i++)
+            if (tokens[i] < 0 || tokens[i] >= d->cfg.vocab)
+                return fail(MC_ERR_INVALID_ARGUMENT, "decoder: token id outside the vocabulary");
+    mc_status s = check_ready(d);
+    if (s != MC_OK) return s;
+    MC_HIP(hipSetDevice(d->dev->ordinal));
+    if (len == 1 && d->first_stage && d->last_stage && !behind_full)
+        return mc_decoder_step(d, tokens[0], start_pos, nullptr, next_token);
+    const int cache_pos = behind_full ? S - len : start_pos;
+    s = d->ensure_prefill(len, cache_pos + len);
+    if (s != MC_OK) return s;
+    // rope rows start_pos .. start_pos + len - 1 must lie inside the table window
+    s = d->ensure_rope(start_pos, len);
+    if (s != MC_OK) return s;
+    if (start_pos == 0) d->ring_turned = false;
+    // a ring that has turned is made linear again (the rotation by len of a chunk behind a full cache included),
+    // so the prompt kernels keep addressing physical slot == logical column
+    const bool rotate = d->n_own > 0 && (behind_full || d->ring_turned);
+    if (rotate) {
+        const mc_decoder_config& c = d->cfg;
+        const size_t cache_bytes = (size_t)c.n_kv_heads * c.max_seq_len * c.head_dim * d->tb;
+        if (!d->rot_k) {
+            s = d->alloc(&d->rot_k, cache_bytes, false);
+            if (s != MC_OK) return s;
+            s = d->alloc(&d->rot_v, cache_bytes, false);
+            if (s != MC_OK) return s;
+        }
+        for (auto& L : d->layers) {
+            s = d->launch("mc_kv_rotate_" + d->tname, 1024, 1, 1, 256, 0,
+                          pack((const void*)L.kc, (const void*)L.vt, d->rot_k, d->rot_v, d->state, (uint32_t)c.n_kv_heads,
+                               (uint32_t)c.head_dim, (uint32_t)c.max_seq_len, (uint32_t)d->pre_len, (uint32_t)(behind_full ? len : 0)));
+            if (s != MC_OK) return s;
+            MC_HIP(hipMemcpyAsync(L.kc, d->rot_k, cache_bytes, hipMemcpyDeviceToDevice, d->stream));
+            MC_HIP(hipMemcpyAsync(L.vt, d->rot_v, cache_bytes, hipMemcpyDeviceToDevice, d->stream));
+        }
+    }
+    if (d->first_stage) MC_HIP(hipMemcpyAsync(d->pf_tokens, tokens, (size_t)len * 4, hipMemcpyHostToDevice, d->stream));
+    // the state a following mc_decoder_step / _generate continues from: last row of the prompt
+    s = d->launch("mc_step_after_prompt", 1, 1, 1, 64, 0,
+                  pack(d->state, d->first_stage ? tokens[len - 1] : (int32_t)-1, (int32_t)(start_pos + len - 1), (int32_t)(cache_pos + len),
+                       (int32_t)d->rope_start, (int32_t)(rotate || d->n_own == 0 ? 1 : 0), (int32_t)(start_pos == 0 ? 1 : 0)));
+    if (s != MC_OK) return s;
+    if (rotate) d->ring_turned = false; // linear again; the next step behind a full cache turns it anew
+    s = d->run_prefill(len, cache_pos, start_pos, sliding_window, rows_in);
+    if (s != MC_OK) return s;
+    d->last_pos = start_pos + len - 1;
+    if (rows_out) *rows_out = d->pf_x;
+    MC_HIP(hipStreamSynchronize(d->stream)); // `tokens` is the caller's buffer
+    if (next_token && d->last_stage) MC_HIP(hipMemcpy(next_token, &d->state->token, 4, hipMemcpyDeviceToHost));
+    return MC_OK;
+}
+
+mc_status
 mc_decoder_prefill(mc_decoder* d, const int32_t* tokens, int32_t len, int32_t start_pos,
                    int32_t sliding_window, int32_t* next_token)
 {
     if (!d || !tokens) return fail(MC_ERR_INVALID_ARGUMENT, "mc_decoder_prefill: null argument");
-    if (len < 1 || start_pos < 0) return fail(MC_ERR_INVALID_ARGUMENT, "mc_decoder_prefill: bad length or position");
-    if (len == 1) return mc_decoder_step(d, tokens[0], start_pos, nullptr, next_token);
     if (!d->first_stage || !d->last_stage)
-        return fail(MC_ERR_INVALID_ARGUMENT, "mc_decoder_prefill: single-stage decoders only");
-    if (len > d->cfg.max_seq_len)
-        return fail(MC_ERR_INVALID_ARGUMENT, "sink_cache: requested length (" + std::to_string(len) +
-                                                 ") is larger than the cache size (" +
-                                                 std::to_string(d->cfg.max_seq_len) + ")"); // nn/cache.h:178-183
-    if (start_pos + len > d->cfg.max_seq_len || (d->ring_turned && start_pos != 0))
-        return fail(MC_ERR_INVALID_ARGUMENT, "decoder: the prompt pass writes cache rows [start_pos, start_pos + len) "
-                                             "and needs them inside max_seq_len; past it, feed tokens through "
-                                             "mc_decoder_step");
-    for (int i = 0; i < len; i++)
-        if (tokens[i] < 0 || tokens[i] >= d->cfg.vocab)
-            return fail(MC_ERR_INVALID_ARGUMENT, "decoder: token id outside the vocabulary");
-    mc_status s = check_ready(d);
-    if (s != MC_OK) return s;
-    MC_HIP(hipSetDevice(d->dev->ordinal));
-    s = d->ensure_prefill(len, start_pos + len);
-    if (s != MC_OK) return s;
-    // rope rows start_pos .. start_pos + len - 1 must lie inside the table window
-    s = d->ensure_rope(start_pos);
-    if (s != MC_OK) return s;
-    if (start_pos - d->rope_start + len > d->rope_rows) {
-        d->rope_valid = false;
-        s = d->ensure_rope(start_pos);
-        if (s != MC_OK) return s;
-    }
-    MC_HIP(hipMemcpyAsync(d->pf_tokens, tokens, (size_t)len * 4, hipMemcpyHostToDevice, d->stream));
-    // the state a following mc_decoder_step / _generate continues from: last row of the prompt
-    s = d->launch("mc_step_set", 1, 1, 1, 64, 0,
-                  pack(d->state, tokens[len - 1], start_pos + len - 1, (int32_t)d->cfg.max_seq_len,
-                       (int32_t)d->pre_len, (int32_t)d->rope_start, (int32_t)(start_pos == 0 ? 1 : 0)));
-    if (s != MC_OK) return s;
-    if (start_pos == 0) d->ring_turned = false;
-    s = d->run_prefill(len, start_pos, sliding_window);
-    if (s != MC_OK) return s;
-    d->last_pos = start_pos + len - 1;
-    MC_HIP(hipStreamSynchronize(d->stream)); // `tokens` is the caller's buffer
-    if (next_token) MC_HIP(hipMemcpy(next_token, &d->state->token, 4, hipMemcpyDeviceToHost));
-    return MC_OK;
+        return fail(MC_ERR_INVALID_ARGUMENT, "mc_decoder_prefill: a stage of a layer pipeline takes mc_decoder_prefill_stage / mc_pipeline_prefill");
+    return mc_decoder_prefill_stage(d, tokens, nullptr, len, start_pos, sliding_window, nullptr, next_token);
 }
 
 mc_status
@@ -1844,6 +1889,8 @@ struct mc_pipeline {
     std::vector<mc_decoder*> stages;     // this process's stages: one (RCCL) or all of them (local)
     std::vector<hipEvent_t> done;        // local transport: stage s finished its part of the current token
     double* red = nullptr;               // device scratch of the max-reduction
+    void* rows_in = nullptr;             // RCCL transport: inbound prompt rows
+    size_t rows_cap = 0;
     bool local = false;
 };
 
@@ -1931,6 +1978,7 @@ mc_pipeline_release(mc_pipeline* p)
     if (p->comm) (void)rccl().CommDestroy(p->comm);
     for (hipEvent_t e : p->done) (void)hipEventDestroy(e);
     if (p->red) (void)hipFree(p->red);
+    if (p->rows_in) (void)hipFree(p->rows_in);
     delete p;
 }
 
@@ -2028,6 +2076,56 @@ mc_pipeline_generate(mc_pipeline* p, int32_t first_token, int32_t start_pos, int
     if (tokens_out && (r == 0 || r == W - 1))
         MC_HIP(hipMemcpyAsync(tokens_out, d->tokens_dev, (size_t)n * 4, hipMemcpyDeviceToHost, d->stream));
     MC_HIP(hipStreamSynchronize(d->stream));
+    return MC_OK;
+}
+
+// The prompt pass through the pipeline: the [len][dim] hidden rows hop stage to stage, the last stage's pick returns
+// to stage 0.  next_token is filled on rank 0 and on the last rank (local: always).
+mc_status
+mc_pipeline_prefill(mc_pipeline* p, const int32_t* tokens, int32_t len, int32_t start_pos, int32_t sliding_window,
+                    int32_t* next_token)
+{
+    if (!p || len < 1) return fail(MC_ERR_INVALID_ARGUMENT, "mc_pipeline_prefill: bad argument");
+    const int W = p->world;
+    mc_status s;
+    if (p->local) {
+        void* rows = nullptr;
+        for (int r = 0; r < W; r++) {
+            void* out = nullptr;
+            s = mc_decoder_prefill_stage(p->stages[r], r == 0 ? tokens : nullptr, rows, len, start_pos, sliding_window, &out,
+                                         r == W - 1 ? next_token : nullptr);
+            if (s != MC_OK) return s;
+            rows = out;
+        }
+        if (W > 1) { // the pick, into stage 0's step state (a following mc_pipeline_generate takes its first token from the caller)
+            mc_decoder *first = p->stages.front(), *last = p->stages.back();
+            MC_HIP(hipSetDevice(first->dev->ordinal));
+            MC_HIP(hipMemcpy(&first->state->token, &last->state->token, 4, hipMemcpyDefault));
+        }
+        return MC_OK;
+    }
+    rccl_api& api = rccl();
+    mc_decoder* d = p->stages[0];
+    const int r = p->rank;
+    MC_HIP(hipSetDevice(d->dev->ordinal));
+    const size_t bytes = (size_t)len * d->cfg.dim * d->tb;
+    if (r > 0) {
+        if (bytes > p->rows_cap) {
+            if (p->rows_in) (void)hipFree(p->rows_in);
+            p->rows_in = nullptr;
+            MC_HIP(hipMalloc(&p->rows_in, bytes));
+            p->rows_cap = bytes;
+        }
+        MC_NCCL(api.Recv(p->rows_in, bytes, ncclUint8, r - 1, p->comm, d->stream), "ncclRecv(prompt rows)");
+    }
+    void* out = nullptr;
+    s = mc_decoder_prefill_stage(d, r == 0 ? tokens : nullptr, p->rows_in, len, start_pos, sliding_window, &out, nullptr);
+    if (s != MC_OK) return s;
+    if (r < W - 1) MC_NCCL(api.Send(out, bytes, ncclUint8, r + 1, p->comm, d->stream), "ncclSend(prompt rows)");
+    if (W > 1 && r == W - 1) MC_NCCL(api.Send(&d->state->token, 1, ncclInt32, 0, p->comm, d->stream), "ncclSend(token)");
+    if (W > 1 && r == 0) MC_NCCL(api.Recv(&d->state->token, 1, ncclInt32, W - 1, p->comm, d->stream), "ncclRecv(token)");
+    MC_HIP(hipStreamSynchronize(d->stream));
+    if (next_token && (r == 0 || r == W - 1)) MC_HIP(hipMemcpy(next_token, &d->state->token, 4, hipMemcpyDeviceToHost));
     return MC_OK;
 }
 

@@ -760,3 +760,68 @@ mc_kv_import_float(float* kc, float* vt, const float* k_in, const float* v_in, u
 {
     kv_import_body(kc, vt, k_in, v_in, n, KV, hd, max_seq);
 }
+
+// ------------------------------------------------------------------------------------------
+// Prompt chunks on a cache whose ring has turned (nn::sink_cache::copy with len > 1, include/metalchat/nn/cache.h:
+// 187-204): the reference allocates a cache, copies the sink prefix and rotates the post region left by len, then
+// writes the len new rows at the end.  The decode path never moves a byte (ring index); a prompt chunk, which is
+// rare and costs milliseconds anyway, makes the ring LINEAR again -- post[j] = old post[(j + ring_base + shift) %
+// post_len], shift = len for a chunk behind a full cache, 0 otherwise -- so the prompt kernels keep addressing
+// physical slot == logical column.  Written into a scratch copy (dst), copied back by the host.
+// ------------------------------------------------------------------------------------------
+template <typename S>
+__device__ __forceinline__ void
+kv_rotate_body(const S* kc, const S* vt, S* kc_dst, S* vt_dst, const step_state* st, uint32_t KV, uint32_t hd,
+               uint32_t max_seq, uint32_t pre_len, uint32_t shift)
+{
+    const uint32_t post = max_seq - pre_len;
+    const uint32_t rot = ((uint32_t)st->ring_base + shift) % post;
+    const size_t total = (size_t)KV * max_seq * hd;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        {   // K: [kv][slot][d]
+            const uint32_t d = i % hd, slot = (i / hd) % max_seq, kv = i / ((size_t)hd * max_seq);
+            const uint32_t src = slot < pre_len ? slot : pre_len + (slot - pre_len + rot) % post;
+            kc_dst[i] = kc[((size_t)kv * max_seq + src) * hd + d];
+        }
+        {   // Vt: [kv][d][slot]
+            const uint32_t slot = i % max_seq;
+            const size_t rowbase = i - slot;
+            const uint32_t src = slot < pre_len ? slot : pre_len + (slot - pre_len + rot) % post;
+            vt_dst[i] = vt[rowbase + src];
+        }
+    }
+}
+extern "C" __global__ void
+mc_kv_rotate_bfloat(const bf16_t* kc, const bf16_t* vt, bf16_t* kc_dst, bf16_t* vt_dst, const step_state* st, uint32_t KV,
+                    uint32_t hd, uint32_t max_seq, uint32_t pre_len, uint32_t shift)
+{
+    kv_rotate_body(kc, vt, kc_dst, vt_dst, st, KV, hd, max_seq, pre_len, shift);
+}
+extern "C" __global__ void
+mc_kv_rotate_float(const float* kc, const float* vt, float* kc_dst, float* vt_dst, const step_state* st, uint32_t KV,
+                   uint32_t hd, uint32_t max_seq, uint32_t pre_len, uint32_t shift)
+{
+    kv_rotate_body(kc, vt, kc_dst, vt_dst, st, KV, hd, max_seq, pre_len, shift);
+}
+
+// the step state behind a prompt pass: the last prompt row's position; the ring is linear again when the caches were
+// rotated (linear != 0)
+extern "C" __global__ void
+mc_step_after_prompt(step_state* st, int32_t token, int32_t pos, int32_t kv_len, int32_t rope_start, int32_t linear,
+                     int32_t reset)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        if (reset) {
+            st->ring_base = 0;
+            st->rolled = 0;
+            st->step_index = 0;
+        }
+        if (linear) st->ring_base = 0;
+        if (token >= 0) st->token = token;
+        st->pos = pos;
+        st->kv_len = kv_len;
+        st->write_slot = kv_len - 1;
+        st->rope_start = rope_start;
+        st->rope_row = pos - rope_start;
+    }
+}

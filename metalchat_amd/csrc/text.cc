@@ -738,6 +738,7 @@ mc_interpreter_read(mc_interpreter* it, int32_t sliding_window, char* out, size_
     if (!it) return fail(MC_ERR_INVALID_ARGUMENT, "mc_interpreter_read: null interpreter");
     return guarded([&] {
         if (!it->dec) raise(MC_ERR_INVALID_ARGUMENT, "mc_interpreter_read: the interpreter was created without a decoder");
+        const size_t pending_before = it->buf.size();
         it->write_header("assistant"); // interpreter.h:318-322
         // read_until (interpreter.h:358-374)
         it->scanner->reset();
@@ -748,7 +749,13 @@ mc_interpreter_read(mc_interpreter* it, int32_t sliding_window, char* out, size_
                           ? mc_decoder_step(it->dec, prompt[0], (int32_t)it->start_pos, nullptr, &token)
                           : mc_decoder_prefill(it->dec, prompt.data(), (int32_t)prompt.size(), (int32_t)it->start_pos,
                                                sliding_window, &token);
-        if (s != MC_OK) return s;
+        if (s != MC_OK) {
+            // nothing was consumed (the decoder validates before it touches its caches): the pending tokens stay
+            // pending -- without the assistant header this call wrote -- and the caller can recover (e.g. split the turn)
+            prompt.resize(pending_before);
+            it->buf.swap(prompt);
+            return s;
+        }
         it->start_pos += prompt.size();
         std::string text;
         std::vector<int32_t> seen;

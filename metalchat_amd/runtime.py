@@ -123,6 +123,8 @@ def capi() -> C.CDLL:
         "mc_pipeline_create_local": (i32, [pvp, i32, pvp]),
         "mc_pipeline_generate": (i32, [vp, i32, i32, i32, C.POINTER(i32)]),
         "mc_pipeline_allreduce_max": (i32, [vp, C.POINTER(C.c_double)]),
+        "mc_pipeline_prefill": (i32, [vp, C.POINTER(i32), i32, i32, i32, C.POINTER(i32)]),
+        "mc_decoder_prefill_stage": (i32, [vp, C.POINTER(i32), vp, i32, i32, i32, pvp, C.POINTER(i32)]),
         "mc_pipeline_release": (None, [vp]),
         "mc_decoder_set_taps": (i32, [vp, i32]),
         "mc_decoder_get_logits": (i32, [vp, vp]),
@@ -496,6 +498,13 @@ class Pipeline:
         out = np.zeros(n, dtype=np.int32)
         _check(capi().mc_pipeline_generate(self._h, first_token, start_pos, n, out.ctypes.data_as(C.POINTER(C.c_int32))))
         return out
+
+    def prefill(self, tokens, start_pos: int, sliding_window: int = 0) -> int:
+        t = np.ascontiguousarray(tokens, dtype=np.int32)
+        nxt = C.c_int32(-1)
+        _check(capi().mc_pipeline_prefill(self._h, t.ctypes.data_as(C.POINTER(C.c_int32)), len(t), start_pos, sliding_window,
+                                          C.byref(nxt)))
+        return nxt.value
 
     def allreduce_max(self, value: float = 0.0) -> float:
         """Barrier over the stages + device synchronise; returns max(value) over the ranks."""

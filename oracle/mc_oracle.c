@@ -1136,6 +1136,10 @@ mco_model_forward(mco_model* m, const int32_t* tokens, int32_t len, int32_t star
     const int32_t n_rep = H / KV, half = hd / 2;
     const float mu = o->family == 1 ? 1.0f : 0.0f;
     const size_t row = (size_t)KV * hd;
+    /* nn/cache.h:205-213 + kernel/copy.h:38-39: a chunk that starts inside the cache and ends outside has a
+     * clamped target slice whose element count differs from the input's -- clone throws invalid_argument; so does
+     * len > cache size (cache.h:178-183).  Nothing is touched. */
+    if (len > o->max_seq_len || (start_pos < o->max_seq_len && start_pos + len > o->max_seq_len)) return -2;
 #define NEW(n) (float*)malloc(sizeof(float) * (size_t)(n))
     float *x = NEW((size_t)len * dim), *hn = NEW((size_t)len * dim), *q = NEW((size_t)len * H * hd);
     float *k = NEW((size_t)len * row), *v = NEW((size_t)len * row), *att = NEW((size_t)len * H * hd);

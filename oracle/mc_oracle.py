@@ -345,6 +345,8 @@ class Model:
         logits = np.empty(self.cfg["vocab"], dtype=np_dtype(self.cfg["dtype"]))
         tok = lib().mco_model_forward(self._h, _p(t), C.c_int32(t.size), C.c_int32(start_pos),
                                       C.c_int32(sliding_window), _p(logits))
+        if tok == -2:  # the reference throws std::invalid_argument here (nn/cache.h:178-183, kernel/copy.h:38-39)
+            raise ValueError("sink_cache: the chunk does not fit the cache")
         return tok, logits
 
     def step_range(self, token: int, start_pos: int, layer_begin: int, layer_end: int,

@@ -153,3 +153,73 @@ def test_default_scanner_and_empty_composite(acc, toks):
     it.release()
     da.release()
     db.release()
+
+
+def test_a_chat_longer_than_the_cache_keeps_going_and_a_straddling_turn_is_recoverable(acc, toks):
+    # nn::sink_cache::copy (nn/cache.h:167-216): turns whose prompt starts behind the end of the cache rotate the post-sink
+    # region by their length and go on; a turn that starts inside the cache and ends outside is an error in the reference
+    # (clone's same_numel check) -- here it must leave the pending tokens pending so that the caller can recover.
+    import metalchat_amd as mc
+
+    t, o = toks
+    cfg = mg.tiny_cfg(F32, vocab=512, max_seq_len=48, n_layers=1)
+    weights = mg.make_model(cfg, seed=5)
+
+    def pair():
+        ds = []
+        for _ in range(2):
+            d = mc.Decoder(acc, **mg.decoder_kwargs(cfg))
+            d.load_model(weights)
+            ds.append(d)
+        return ds
+
+    header = to.header_ids(o, b"assistant")
+    # (1) a turn that straddles the end of the cache
+    da, db = pair()
+    it = mc.Interpreter(da, t)
+    it.set_token_scanner(limit=6)
+    straddled = False
+    for turn in range(20):
+        it.write("user", "Hello the system")
+        pending, start = it.pending(), it.start_pos
+        full = pending + header
+        if start < 48 < start + len(full):
+            with pytest.raises(mc.McError, match="straddle the end of the cache"):
+                it.read()
+            assert it.start_pos == start and it.pending() == pending   # nothing consumed, nothing lost, no stray header
+            straddled = True
+            break
+        _, ids = it.read()
+        want, pos = by_hand(db, full, to.LimitScanner(6), start)
+        assert ids == want and it.start_pos == pos, f"turn {turn} at start_pos {start}"
+    assert straddled
+    it.release(), da.release(), db.release()
+    # (2) a conversation whose turns never straddle: it runs far past the cache size (chunks behind a full cache)
+    da, db = pair()
+    it = mc.Interpreter(da, t)
+    it.set_token_scanner(limit=6)
+    # the first prompt is sized to end 43 .. 48 rows into the cache, so that the 5 tokens the turn emits carry start_pos
+    # to or past the end: every later turn starts behind a full cache
+    text = "Hello the system Hello the system Hello the system Hello"
+    while True:
+        probe = mc.Interpreter(None, t)
+        probe.write("user", text)
+        n1 = len(probe.pending()) + len(header)
+        probe.release()
+        if n1 >= 43:
+            break
+        text += " the"
+    assert n1 <= 48
+    it.write("user", text)
+    done = 0
+    while it.start_pos < 200:
+        pending, start = it.pending(), it.start_pos
+        full = pending + header
+        assert not (start < 48 < start + len(full)), "this conversation was built not to straddle the cache end"
+        _, ids = it.read()
+        want, pos = by_hand(db, full, to.LimitScanner(6), start)
+        assert ids == want and it.start_pos == pos, f"turn at start_pos {start}"
+        it.write("user", "Hello")
+        done += 1
+    assert done >= 3 and it.start_pos > 48 * 3
+    it.release(), da.release(), db.release()

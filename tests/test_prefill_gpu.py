@@ -135,7 +135,7 @@ def test_prefill_argument_errors_and_len_one(acc):
     dec.load_model(weights)
     with pytest.raises(mc.McError, match=r"requested length \(17\) is larger than the cache size \(16\)"):
         dec.prefill(list(range(17)), 0)
-    with pytest.raises(mc.McError, match="inside max_seq_len"):
+    with pytest.raises(mc.McError, match="straddle the end of the cache"):
         dec.prefill(list(range(8)), 10)
     with pytest.raises(mc.McError, match="outside the vocabulary"):
         dec.prefill([1, cfg["vocab"]], 0)
@@ -157,3 +157,128 @@ def test_qlora_prompt(acc, dt, n):
     weights = mg.make_model(cfg, seed=78, quant="i4", group=32, lora_rank=16)
     tokens = np.random.default_rng(8).integers(0, cfg["vocab"], n).tolist()
     check_against_oracle(acc, cfg, weights, dict(weight_format=2, group_size=32), tokens, follow=2)
+
+
+# ------------------------------------------------------------------------------------------------
+# nn::sink_cache::copy with len > 1 behind a full cache (nn/cache.h:187-204): post region rotated left by
+# len, the chunk takes the last len rows -- against the oracle's literal restatement, with a turned ring
+# on the HIP side (decode steps past max_seq_len before the chunk) and decode steps behind it.
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype,family", [(F32, 0), (BF16, 0), (F32, 1)])
+def test_prompt_chunk_behind_a_full_cache(acc, dtype, family):
+    import metalchat_amd as mc
+
+    over = dict(max_seq_len=32, n_layers=2, family=family)
+    if family == 1:
+        over.update(rope_sliding_theta=10000.0, sliding_stride=2)
+    cfg = mg.tiny_cfg(dtype, **over)
+    weights = mg.make_model(cfg, seed=21, quant="i4", group=32)
+    rel, frac = tol(dtype)
+    om = mo.Model(cfg, weights)
+    dec = mc.Decoder(acc, **mg.decoder_kwargs(cfg, weight_format=mc.WFMT_I4, group_size=32))
+    dec.load_model(weights)
+    rng = np.random.default_rng(5)
+    win = 8 if family == 1 else 0
+    # a first prompt, then decode PAST the end of the cache: the HIP ring turns (ring_base = 9)
+    p0 = rng.integers(0, cfg["vocab"], 20)
+    otok, _ = om.forward(p0, 0, win)
+    dec.prefill(p0, 0, win)
+    tok, pos = otok, 20
+    for _ in range(21):                     # positions 20 .. 40
+        o2, ol = om.step(tok, pos)
+        dec.step(tok, pos)
+        tok, pos = o2, pos + 1
+    parity.check(dtype, dec.logits(), ol, rel=rel, max_ulp=2, max_frac=frac, what="decode before the chunk")
+    # the chunk: 10 rows at start_pos 41 >= max_seq_len
+    chunk = rng.integers(0, cfg["vocab"], 10)
+    otok, ologits = om.forward(chunk, pos, win)
+    gtok = dec.prefill(chunk, pos, win)
+    parity.check(dtype, dec.logits(), ologits, rel=rel, max_ulp=2, max_frac=frac, what="chunk behind a full cache: logits")
+    for layer in range(cfg["n_layers"]):
+        gk, gv = dec.export_kv(layer)
+        ok, ov = om.kv(layer)
+        assert gk.shape == ok.shape == (32, cfg["n_kv_heads"], cfg["head_dim"])
+        parity.check(dtype, gk, ok, rel=rel, max_ulp=2, max_frac=frac, what=f"chunk behind a full cache: K[{layer}]")
+        parity.check(dtype, gv, ov, rel=rel, max_ulp=2, max_frac=frac, what=f"chunk behind a full cache: V[{layer}]")
+    pos += 10
+    tok = otok
+    agree = int(gtok == otok)
+    for _ in range(6):                      # and decode on: the ring turns again from its linear state
+        o2, ol = om.step(tok, pos)
+        g2 = dec.step(tok, pos)
+        parity.check(dtype, dec.logits(), ol, rel=rel, max_ulp=2, max_frac=frac, what=f"decode behind the chunk, pos {pos}")
+        agree += int(g2 == o2)
+        tok, pos = o2, pos + 1
+    assert agree >= (7 if dtype == F32 else 5)
+    # a second chunk right away (ring turned by the six steps), as long as the whole cache
+    chunk2 = rng.integers(0, cfg["vocab"], 32)
+    otok, ologits = om.forward(chunk2, pos, win)
+    dec.prefill(chunk2, pos, win)
+    parity.check(dtype, dec.logits(), ologits, rel=rel, max_ulp=2, max_frac=frac, what="cache-sized chunk: logits")
+    gk, _ = dec.export_kv(0)
+    ok, _ = om.kv(0)
+    parity.check(dtype, gk, ok, rel=rel, max_ulp=2, max_frac=frac, what="cache-sized chunk: K[0]")
+    # a new conversation on the same decoder
+    otok, ologits = om.forward(p0, 0, win)
+    dec.prefill(p0, 0, win)
+    parity.check(dtype, dec.logits(), ologits, rel=rel, max_ulp=2, max_frac=frac, what="new conversation: logits")
+    dec.release()
+    om.close()
+
+
+def test_prompt_chunk_errors_are_the_reference_errors(acc):
+    import metalchat_amd as mc
+
+    cfg = mg.tiny_cfg(BF16, max_seq_len=32, n_layers=1)
+    weights = mg.make_model(cfg, seed=2, quant="i4", group=32)
+    dec = mc.Decoder(acc, **mg.decoder_kwargs(cfg, weight_format=mc.WFMT_I4, group_size=32))
+    dec.load_model(weights)
+    om = mo.Model(cfg, weights)
+    toks = np.arange(10) % cfg["vocab"]
+    dec.prefill(toks, 0)
+    om.forward(toks, 0)
+    before = dec.export_kv(0)[0].copy()
+    # rows [28, 38) straddle the end of a 32-row cache: the reference's clamped slice fails clone's same_numel check
+    with pytest.raises(mc.McError, match="straddle the end of the cache"):
+        dec.prefill(toks, 28)
+    with pytest.raises(ValueError):
+        om.forward(toks, 28)
+    # nn/cache.h:178-183
+    with pytest.raises(mc.McError, match=r"sink_cache: requested length \(33\) is larger than the cache size \(32\)"):
+        dec.prefill(np.zeros(33, np.int64), 40)
+    parity.exact(dec.export_kv(0)[0], before, "a rejected chunk leaves the cache alone")
+    dec.release()
+    om.close()
+
+
+def test_prompt_pass_through_a_local_pipeline_equals_the_single_stage(acc):
+    # mc_pipeline_prefill: the [len][dim] hidden rows hop stage to stage; same kernels per layer -> same bits
+    import metalchat_amd as mc
+
+    cfg = mg.tiny_cfg(BF16, max_seq_len=32, n_layers=4)
+    weights = mg.make_model(cfg, seed=8, quant="i4", group=32)
+    single = mc.Decoder(acc, **mg.decoder_kwargs(cfg, weight_format=mc.WFMT_I4, group_size=32))
+    single.load_model(weights)
+    toks = np.random.default_rng(3).integers(0, cfg["vocab"], 18)
+    want_tok = single.prefill(toks, 0)
+    want_logits = single.logits().copy()
+    want_more = list(single.generate(want_tok, 18, 20))     # runs past the end of the cache
+    want_chunk = single.prefill(toks[:9], 38)                # a chunk behind the full cache
+    want_logits2 = single.logits().copy()
+    for world in (2, 4):
+        stages = []
+        for r in range(world):
+            lb, le = mc.pipeline_layer_range(r, world, cfg["n_layers"])
+            d = mc.Decoder(acc, **mg.decoder_kwargs(cfg, weight_format=mc.WFMT_I4, group_size=32, layer_begin=lb, layer_end=le))
+            d.load_model(weights)
+            stages.append(d)
+        pipe = mc.Pipeline.local(stages)
+        assert pipe.prefill(toks, 0) == want_tok
+        parity.exact(stages[-1].logits(), want_logits, f"world {world}: prompt logits")
+        assert list(pipe.generate(want_tok, 18, 20)) == want_more
+        assert pipe.prefill(toks[:9], 38) == want_chunk
+        parity.exact(stages[-1].logits(), want_logits2, f"world {world}: logits of the chunk behind the full cache")
+        pipe.release()
+        for d in stages:
+            d.release()
+    single.release()
