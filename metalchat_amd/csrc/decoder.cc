@@ -245,6 +245,7 @@ struct mc_decoder {
     int gemv_block = 256;
     int gemv_wgs_per_cu = 2;
     bool gemv_lin = true;        // MC_GEMV_LIN=0: classic kernels everywhere (A/B)
+    int lin_waves = 8;           // MC_LIN_WAVES: tuning builds of the linear-order kernels with another workgroup size
     bool gemv_block_env = false; // MC_GEMV_BLOCK / MC_GEMV_WGS_PER_CU given: they apply to every kernel of the family
     bool gemv_full_grid = false; // MC_GEMV_FULLGRID=1: as many workgroups as CUs allow even when that leaves waves without a row group (kernels built with MC_GEMV_WAVEMAJOR)
     int dbg_variant = 0; // MC_GEMV_DBG=1 stream-only, 2 compute-only (tuning ablations)
@@ -484,11 +485,10 @@ struct mc_decoder {
             // ONE workgroup of eight waves per CU: the activation row is staged once per CU and, with the raw barrier
             // between the row requests and the first weight requests (gemv.h MC_GEMV_XBAR), always ahead of the weight
             // stream in the CU's in-order memory pipe (w1|w3: 16.2 us against 17.3 with two four-wave workgroups)
-            if (!gemv_block_env) {
-                block = 512;
-                waves = 8;
-                cap = (unsigned)dev->prop.multiProcessorCount;
-            }
+            // (the kernels are built for exactly this workgroup size, gemv_kernels.hip MC_LIN_WAVES: no blockDim load)
+            block = 64u * (unsigned)lin_waves;
+            waves = (unsigned)lin_waves;
+            cap = (unsigned)dev->prop.multiProcessorCount * (gemv_block_env ? (unsigned)gemv_wgs_per_cu : 1u);
             // a CU takes in ~25 GB/s whatever its waves do, so what matters is equal BYTES PER CU: a whole multiple of
             // the CU count, at least one row pair per wave (the kernel cuts the pairs into equal contiguous ranges)
             const unsigned cus = (unsigned)dev->prop.multiProcessorCount;
@@ -988,6 +988,7 @@ mc_decoder_create(mc_device* dev, mc_library* lib, mc_queue* q, const mc_decoder
     if (const char* e = getenv("MC_GEMV_DBG")) d->dbg_variant = atoi(e);
     if (const char* e = getenv("MC_GEMV_FULLGRID")) d->gemv_full_grid = atoi(e) != 0;
     if (const char* e = getenv("MC_GEMV_LIN")) d->gemv_lin = atoi(e) != 0;
+    if (const char* e = getenv("MC_LIN_WAVES")) d->lin_waves = std::max(1, std::min(16, atoi(e)));
     if (const char* e = getenv("MC_GEMMA_UNFUSED")) d->gemma_fuse = atoi(e) == 0;
     if (const char* e = getenv("MC_GEMV_M4")) d->gemv_m4 = atoi(e);
     if (const char* e = getenv("MC_PV_BLOCK")) d->pv_block = atoi(e);
@@ -1945,6 +1946,10 @@ mc_pipeline_create(mc_decoder* stage, int32_t rank, int32_t world, const void* i
     p->stages.push_back(stage);
     ncclUniqueId id;
     memcpy(&id, id128, sizeof id);
+    // RCCL checks hipGetLastError() between its own calls: an error an EARLIER, unrelated call of this process left behind
+    // (the last-error word is sticky until read) fails the bring-up as "unhandled cuda error".  Read it away first.
+    MC_HIP(hipStreamSynchronize(stage->stream));
+    (void)hipGetLastError();
     MC_NCCL(api.CommInitRank(&p->comm, world, id, rank), "ncclCommInitRank");
     MC_HIP(hipMalloc((void**)&p->red, 16));
     *out = p.release();

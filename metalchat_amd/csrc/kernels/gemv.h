@@ -466,7 +466,9 @@ template <int R> struct tile {
 // The kernel body.  blockDim.x = 64 * waves; dynamic LDS = round16(in * sizeof(T)) + 128.
 // ------------------------------------------------------------------------------------------
 // LNCH / LTP != 0 select the LINEAR-ORDER main loop (int4, bfloat, Q_M4D only; rows of LNCH whole KiB): see below.
-template <int WF, typename T, int QM, int PRO, int EPI, int R, int LNCH = 0, int LTP = 0>
+// LRING: ring slots in tiles (0: the MC_GEMV_LIN_INFLIGHT rule); LWAVES: waves of the workgroup when it is fixed at build time
+// (0: read blockDim -- a dependent load from the hidden kernel arguments before anything else can be addressed).
+template <int WF, typename T, int QM, int PRO, int EPI, int R, int LNCH = 0, int LTP = 0, int LRING = 0, int LWAVES = 0>
 __device__ __forceinline__ void
 body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __restrict__ xp,
      void* __restrict__ yp, const void* __restrict__ resp, const void* __restrict__ normp,
@@ -501,7 +503,7 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
     // work and the per-lane address of a load is ONE v_min (the clamp) -- the first version spent
     // ~240 VALU instructions per tile on 64-bit per-lane addressing, selects and masks.
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t nwaves = blockDim.x >> 6;
+    const uint32_t nwaves = LWAVES ? (uint32_t)LWAVES : blockDim.x >> 6;
     const uint32_t ngroups = group ? in / group : 1;
     const uint32_t glog = group ? 31u - __builtin_clz(group) : 31u; // group is a power of two
     const uint32_t NG = (out_rows + R - 1) / R;
@@ -680,7 +682,7 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
         const uint4* xg = static_cast<const uint4*>(xp);
         const uint4* ng = static_cast<const uint4*>(normp);
         uint4* xl = reinterpret_cast<uint4*>(xs);
-        const uint32_t bd = blockDim.x;
+        const uint32_t bd = LWAVES ? (uint32_t)LWAVES * 64u : blockDim.x;
         const bool fits = npk <= (uint32_t)MAXP * bd;
         uint4 xr[MAXP], nr[MAXP], pw[PRO == PRO_POSTNORM ? MAXP : 1], rr[PRO == PRO_POSTNORM ? MAXP : 1];
         const postnorm_args* pna = static_cast<const postnorm_args*>(resp);
@@ -885,7 +887,12 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
 #define MC_GEMV_LIN_INFLIGHT 4 // KiB in flight per wave: the ring holds two pairs when they fit, else one (A/B on MI355X, 8 waves per CU:
                                // 4 KiB 16.2 us, 8 KiB 17.5 us on the 60 MB w1|w3 matrix -- a CU keeps ~32 KiB in flight whatever is asked)
 #endif
-        constexpr int LR = 2 * TPP * LTP <= MC_GEMV_LIN_INFLIGHT ? 2 * TPP : TPP; // ring slots (tiles)
+        // ring slots (tiles).  A slot is refilled the moment its tile has been consumed, with the tile LR ahead in the
+        // wave's stream: LR < TPP keeps the bytes in flight small while a load is issued after EVERY tile -- with whole
+        // rows as tiles (LR = 2) a wave computed a row with only the other row's load in flight, and half of every
+        // row's compute time was added to the load latency instead of hiding behind it (tools/lin_timeline.py).
+        constexpr int LR = LRING ? LRING : (2 * TPP * LTP <= MC_GEMV_LIN_INFLIGHT ? 2 * TPP : TPP);
+        static_assert(LR % TPP == 0 || TPP % LR == 0, "the ring and a pair's tiles divide one another");
         constexpr bool XREG = LNCH <= 2;
 #ifndef MC_GEMV_LIN_NT
 #define MC_GEMV_LIN_NT 1
@@ -905,8 +912,10 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
         const uint32_t nw_total = gridDim.x * nwaves, gw = blockIdx.x * nwaves + wave;
         const uint32_t NP = (out_rows + 1) / 2; // row pairs (the host takes this path only for even out_rows)
-        const uint32_t pb = (uint32_t)(((uint64_t)NP * gw) / nw_total);
-        const uint32_t pe = (uint32_t)(((uint64_t)NP * (gw + 1)) / nw_total);
+        // equal ranges to within one pair, without a 64-bit division: the first NP % nw_total waves take one pair more
+        const uint32_t pq = NP / nw_total, prem = NP - pq * nw_total;
+        const uint32_t pb = gw * pq + min(gw, prem);
+        const uint32_t pe = pb + pq + (gw < prem ? 1u : 0u);
         const char* sbase = static_cast<const char*>(sp);
 
         uint4 lring[LR][LTP];
@@ -947,8 +956,12 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
 
         unsigned long long ltl[16];
         uint32_t ltn = 2;
-        if (MC_GEMV_LIN_TL) ltl[0] = __builtin_amdgcn_s_memrealtime();
-        constexpr int U = LR / TPP; // pairs per unrolled iteration (1 or 2)
+        unsigned long long lclk0 = 0;
+        if (MC_GEMV_LIN_TL) {
+            ltl[0] = __builtin_amdgcn_s_memrealtime();
+            lclk0 = __builtin_amdgcn_s_memtime(); // shader clock: with the 100 MHz stamps it gives the clock the wave really ran at
+        }
+        constexpr int U = LR >= TPP ? LR / TPP : 1; // pairs per unrolled iteration
         stage_x([&] {
             lscales(sa, pb, pb < pe);
 #pragma unroll
@@ -984,6 +997,8 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
             parked = 0;
         };
 
+        uint32_t lin_never, lin_dummy = 0;
+        asm volatile("s_mov_b32 %0, 0" : "=s"(lin_never));
         constexpr int NA = MC_GEMV_LIN_ACCS;
         mf_f4 laccs[NA];
 #pragma unroll
@@ -996,13 +1011,23 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
             float ra = 0.f, rb = 0.f;
 #pragma unroll
             for (int t = 0; t < TPP; t++) {
-                const int r = t / SUB, sidx = t % SUB, slot = SLOT0 + t;
+                const int r = t / SUB, sidx = t % SUB, slot = LR >= TPP ? SLOT0 + t : t % LR;
 #pragma unroll
                 for (int p = 0; p < LTP; p++) {
                     const int c = sidx * LTP + p;
                     const uint32_t raw = sa[c];
                     const uint32_t s2 = r ? ((raw & 0xFFFF0000u) | (raw >> 16)) : ((raw << 16) | (raw & 0xFFFFu));
-                    if (MC_GEMV_LIN_STREAM) {
+#ifndef MC_GEMV_LIN_DECOUPLE
+#define MC_GEMV_LIN_DECOUPLE 0 // tuning ablation: the arithmetic runs on a synthesised packet BEFORE the loaded one is waited for (and only folded into a dummy)
+#endif
+                    if (MC_GEMV_LIN_DECOUPLE && XREG) {
+                        const uint4 fake = make_uint4(lane * 0x01010101u + pr, (lane + pr) * 0x9E3779B9u, lane * 0x85EBCA6Bu + (uint32_t)(t * 0x11111111u),
+                                                      (p + lane) * 0xC2B2AE35u + pr);
+                        if constexpr (XREG) mac4d_n<NA>(laccs, fake, m4d_prepare(0x3C003C00u, m4d_mx, m4d_my), xr[c]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        const uint4& w = lring[slot][p];
+                        lin_dummy += ((w.x ^ w.y ^ w.z ^ w.w) & 0x3FFFFFFFu) | (s2 & 1u);
+                    } else if (MC_GEMV_LIN_STREAM) {
                         const uint4& w = lring[slot][p];
                         laccs[0][0] += asf(((w.x ^ w.y ^ w.z ^ w.w) & 0x3FFFFFFFu) | (s2 & 1u));
                     } else if constexpr (XREG) {
@@ -1013,7 +1038,18 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
                         mac4d_n<NA>(laccs, lring[slot][p], m4d_prepare(s2, m4d_mx, m4d_my), x);
                     }
                 }
-                ltile(lring[slot], pr + U, t, pr + U < pe);
+                if constexpr (LR >= TPP) ltile(lring[slot], pr + U, t, pr + U < pe);
+                else if (t + LR < TPP) ltile(lring[slot], pr, t + LR, true);
+                else ltile(lring[slot], pr + 1, t + LR - TPP, pr + 1 < pe);
+#ifndef MC_GEMV_LIN_PIN
+#define MC_GEMV_LIN_PIN (LRING ? 2 : 0) // explicit rings pin their refills
+#endif
+                // the refill stays HERE: left alone, the scheduler sinks the loads of several tiles to one place behind
+                // their computations, and a wave then computes with fewer bytes in flight than its ring holds
+                if (MC_GEMV_LIN_PIN == 1) __builtin_amdgcn_sched_barrier(0);
+                // (instruction selection orders a basic block by data dependence alone and puts a load whose value leaves the
+                //  block at its END, so a scheduling barrier does not hold it.  An opaque never-taken branch ends the block.)
+                if (MC_GEMV_LIN_PIN == 2 && lin_never) asm volatile("s_nop 0");
                 if (MC_GEMV_LIN_TL) {
                     __builtin_amdgcn_sched_barrier(0);
                     const unsigned long long now = __builtin_amdgcn_s_memrealtime();
@@ -1052,15 +1088,17 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
             if (pr < pe) do_pair(std::integral_constant<int, 0>{}, pr); // odd count: the last pair sits in the first slots
         }
         flush();
+        if (MC_GEMV_LIN_DECOUPLE && lin_dummy == 0x12345678u) static_cast<uint32_t*>(yp)[0] = 1;
         if (MC_GEMV_LIN_TL && lane == 0) {
             unsigned long long* tl = const_cast<unsigned long long*>(static_cast<const unsigned long long*>(resp));
             const size_t o = ((size_t)blockIdx.x * nwaves + wave) * 16;
             ltl[14] = __builtin_amdgcn_s_memrealtime();
+            ltl[13] = __builtin_amdgcn_s_memtime() - lclk0; // (replaces the stamp of tile 11)
             unsigned xcc;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
             ltl[15] = ((unsigned long long)ltn << 32) | xcc;
 #pragma unroll
-            for (int q = 0; q < 16; q++) tl[o + q] = (q >= 2 && q < 14 && (uint32_t)q >= ltn) ? 0ull : ltl[q];
+            for (int q = 0; q < 16; q++) tl[o + q] = (q >= 2 && q < 13 && (uint32_t)q >= ltn) ? 0ull : ltl[q];
         }
         return;
     }

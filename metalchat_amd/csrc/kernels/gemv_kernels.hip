@@ -23,26 +23,29 @@ using namespace mc::gemv;
                                      lora_a, lora_b, lora_rank, lora_scale);                      \
     }
 
-// linear-order variants (gemv.h): mc_gemv_i4_bfloat_lin{K/2048}_p{PRO}_e{EPI}, rows of K/2048 whole KiB
-#define MC_GEMV_LIN(NAME, NCH, TP, PRO, EPI)                                                      \
-    extern "C" __global__ void __launch_bounds__(MC_GEMV_LB)                                     \
+// linear-order variants (gemv.h): mc_gemv_i4_bfloat_lin{K/2048}_p{PRO}_e{EPI}, rows of K/2048 whole KiB.
+// CFG = KiB per row, KiB per tile, ring slots (tiles; 0: by bytes in flight), waves per workgroup (0: any)
+#ifndef MC_LIN_WAVES
+#define MC_LIN_WAVES 8 // the host launches these kernels with 64 * MC_LIN_WAVES threads (decoder.cc, gemv())
+#endif
+#define MC_GEMV_LIN(NAME, PRO, EPI, ...)                                                          \
+    extern "C" __global__ void __launch_bounds__(MC_LIN_WAVES ? 64 * MC_LIN_WAVES : MC_GEMV_LB)   \
     NAME(const void* w, const void* scales, const void* x, void* y, const void* res,             \
          const void* norm_w, uint32_t out_rows, uint32_t in, uint32_t group, float eps, float mu, \
          const void* lora_a, const void* lora_b, uint32_t lora_rank, float lora_scale)            \
     {                                                                                             \
-        body<WF_I4, BF, Q_M4D, PRO, EPI, 4, NCH, TP>(w, scales, x, y, res, norm_w, out_rows, in,  \
-                                                     group, eps, mu, lora_a, lora_b, lora_rank,   \
-                                                     lora_scale);                                 \
+        body<WF_I4, BF, Q_M4D, PRO, EPI, 4, __VA_ARGS__, MC_LIN_WAVES>(                           \
+            w, scales, x, y, res, norm_w, out_rows, in, group, eps, mu, lora_a, lora_b, lora_rank, lora_scale); \
     }
-#define MC_GEMV_LIN_SET(PFX, NCH, TP)       \
-    MC_GEMV_LIN(PFX##_p0_e0, NCH, TP, 0, 0) \
-    MC_GEMV_LIN(PFX##_p1_e0, NCH, TP, 1, 0) \
-    MC_GEMV_LIN(PFX##_p0_e1, NCH, TP, 0, 1) \
-    MC_GEMV_LIN(PFX##_p1_e2, NCH, TP, 1, 2) \
-    MC_GEMV_LIN(PFX##_p1_e3, NCH, TP, 1, 3) \
-    MC_GEMV_LIN(PFX##_p1_e4, NCH, TP, 1, 4) \
-    MC_GEMV_LIN(PFX##_p2_e0, NCH, TP, 2, 0) \
-    MC_GEMV_LIN(PFX##_p2_e3, NCH, TP, 2, 3)
+#define MC_GEMV_LIN_SET(PFX, ...)               \
+    MC_GEMV_LIN(PFX##_p0_e0, 0, 0, __VA_ARGS__) \
+    MC_GEMV_LIN(PFX##_p1_e0, 1, 0, __VA_ARGS__) \
+    MC_GEMV_LIN(PFX##_p0_e1, 0, 1, __VA_ARGS__) \
+    MC_GEMV_LIN(PFX##_p1_e2, 1, 2, __VA_ARGS__) \
+    MC_GEMV_LIN(PFX##_p1_e3, 1, 3, __VA_ARGS__) \
+    MC_GEMV_LIN(PFX##_p1_e4, 1, 4, __VA_ARGS__) \
+    MC_GEMV_LIN(PFX##_p2_e0, 2, 0, __VA_ARGS__) \
+    MC_GEMV_LIN(PFX##_p2_e3, 2, 3, __VA_ARGS__)
 
 #define MC_GEMV_SET(PFX, WF, T, QM)            \
     MC_GEMV(PFX##_p0_e0, WF, T, QM, 0, 0)      \
@@ -64,11 +67,26 @@ MC_GEMV_SET(mc_gemv_i8_float, WF_I8, F32, Q_EXACT)
 MC_GEMV_SET(mc_gemv_w_bfloat, WF_T, BF, Q_EXACT)
 MC_GEMV_SET(mc_gemv_w_float, WF_T, F32, Q_EXACT)
 
-MC_GEMV_LIN_SET(mc_gemv_i4_bfloat_lin1, 1, 1)   // K = 2048
-MC_GEMV_LIN_SET(mc_gemv_i4_bfloat_lin2, 2, 2)   // K = 4096
-MC_GEMV_LIN_SET(mc_gemv_i4_bfloat_lin4, 4, 4)   // K = 8192
-MC_GEMV_LIN_SET(mc_gemv_i4_bfloat_lin7, 7, 7)   // K = 14336
-MC_GEMV_LIN_SET(mc_gemv_i4_bfloat_lin14, 14, 7) // K = 28672
+#ifndef MC_LIN1_CFG
+#define MC_LIN1_CFG 1, 1, 0
+#endif
+#ifndef MC_LIN2_CFG
+#define MC_LIN2_CFG 2, 2, 0
+#endif
+#ifndef MC_LIN4_CFG
+#define MC_LIN4_CFG 4, 4, 0
+#endif
+#ifndef MC_LIN7_CFG
+#define MC_LIN7_CFG 7, 1, 2 // K = 14336: 28 KB of activations per workgroup come in first; two KiB per wave behind them (w2: 12.0 -> 9.9 us)
+#endif
+#ifndef MC_LIN14_CFG
+#define MC_LIN14_CFG 14, 1, 2
+#endif
+MC_GEMV_LIN_SET(mc_gemv_i4_bfloat_lin1, MC_LIN1_CFG)   // K = 2048
+MC_GEMV_LIN_SET(mc_gemv_i4_bfloat_lin2, MC_LIN2_CFG)   // K = 4096
+MC_GEMV_LIN_SET(mc_gemv_i4_bfloat_lin4, MC_LIN4_CFG)   // K = 8192
+MC_GEMV_LIN_SET(mc_gemv_i4_bfloat_lin7, MC_LIN7_CFG)   // K = 14336
+MC_GEMV_LIN_SET(mc_gemv_i4_bfloat_lin14, MC_LIN14_CFG) // K = 28672
 
 // tuning ablations (not used by the product path): stream-only and compute-only variants
 MC_GEMV(mc_gemv_i4_bfloat_dbgstream_p1_e2, WF_I4, BF, Q_DBG_STREAM, 1, 2)

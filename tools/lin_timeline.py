@@ -23,11 +23,11 @@ for which, kname in (("w13", "mc_gemv_i4_bfloat_lin2_p1_e2"), ("w2", "mc_gemv_i4
     for block, wgs_per_cu in [tuple(int(v) for v in g.split("x")) for g in os.environ.get("GEOMS", "256x2").split(",")]:
         k = acc.load(kname)
         waves = block // 64
-        for layer in (0, 1, 2, 3, 4, 5, 6, 7, 0, 1, 2, 3, 4, 5):  # a chain of launches over distinct weights; the stamps kept are the last one's
+        tl = acc.alloc(cus * 4 * waves * 128)
+        for layer in (0, 1, 2, 3, 4, 5, 6, 7) * int(os.environ.get('CHAIN', '40')) + (0, 1, 2, 3, 4, 5):  # a chain of launches over distinct weights; the stamps kept are the last one's
             wptr, sptr, rows, inf, ng = dec.weight_ptrs(layer, which)
             ngp = (rows + 3) // 4
             wgs = min((ngp + waves - 1) // waves, cus * wgs_per_cu)
-            tl = acc.alloc(wgs * waves * 128)
             lds = (inf + 2047) // 2048 * 2048 * 2 // 16 * 17 + 128 + waves * 512
             t = mc.KernelTask(k, (wgs * block, 1, 1), (block, 1, 1),
                               [acc.wrap(wptr, 1 << 40), acc.wrap(sptr, 1 << 40), x, y, tl, nw,
@@ -41,18 +41,19 @@ for which, kname in (("w13", "mc_gemv_i4_bfloat_lin2_p1_e2"), ("w2", "mc_gemv_i4
         start, staged, end = (st[:, 0] - t0) / 100.0, (st[:, 1] - t0) / 100.0, (st[:, 14] - t0) / 100.0
         ntl = (st[:, 15] >> 32)
         tiles = []
-        for i in range(2, 14):
+        for i in range(2, 13):
             m = st[:, i] > 0
             if m.any():
                 tiles.append(q((st[m, i] - t0) / 100.0))
         gaps = []
         prev = st[:, 1]
-        for i in range(2, 14):
+        for i in range(2, 13):
             m = st[:, i] > 0
             if m.any():
                 gaps.append(q((st[m, i] - prev[m]) / 100.0))
             prev = st[:, i]
+        mhz = st[:, 13] / ((st[:, 14] - st[:, 0]) / 100.0)  # shader cycles per microsecond of the wave's life
         xcc = st[:, 15] & 0xF
         print(json.dumps(dict(which=which, kernel=kname, block=block, wgs=wgs, event_us=round(ms * 1e3, 2), start=q(start),
-                              staged=q(staged), end=q(end), tile_end=tiles, tile_gap=gaps,
+                              staged=q(staged), end=q(end), clock_mhz=q(mhz), tile_end=tiles, tile_gap=gaps,
                               end_by_xcd={int(c): round(float(np.percentile(end[xcc == c], 90)), 2) for c in sorted(set(xcc.tolist()))})), flush=True)

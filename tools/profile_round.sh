@@ -9,7 +9,7 @@ mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
 # hipGraph replay under rocprofv3 segfaults with the ROCm 7.2 runtime on this image (reproduced with
 # --kernel-trace alone), so the profiled runs launch the same kernels eagerly (--no-graph)
-ARGS="--steps 64 --warmup 8 --no-cpu-baseline --no-graph $*"
+ARGS="--steps 64 --warmup 8 --no-cpu-baseline --no-graph --no-other-configs $*"
 # 1. kernel durations
 rm -rf /tmp/p_trace; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_trace -- python3 /root/repo/bench.py $ARGS > $OUT/${R}_bench_under_trace.json 2> /tmp/p_trace.err
 cp $(find /tmp/p_trace -name "*kernel_stats.csv" | head -1) $OUT/${R}_kernel_stats.csv
