@@ -483,6 +483,12 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
     constexpr uint32_t CHUNK_BYTES = 64 * 16;    // = 1 KiB of packed weights
     static_assert(R == 4, "tiles are four rows deep (scale quads, paired epilogues)");
 
+    if (LNCH > 0) {
+        // every kernel argument in ONE round of scalar loads: left to itself hipcc loads them where they are first used --
+        // three dependent kernarg round trips (scalar-cache misses, ~0.1-0.2 us each) before the row is even requested
+        asm volatile("" ::"s"(wp), "s"(sp), "s"(xp), "s"(yp), "s"(resp), "s"(normp), "s"(out_rows), "s"(in), "s"(group), "s"(eps),
+                     "s"(mu), "s"(lora_rank), "s"(gridDim.x));
+    }
     constexpr bool M4 = (QM == Q_M4 || QM == Q_M4D || QM == Q_DBG_TL4D) && WF == WF_I4 && T::bytes == 2;
     constexpr bool M4D = (QM == Q_M4D || QM == Q_DBG_TL4D) && M4;
     constexpr bool TL = QM == Q_DBG_TL || QM == Q_DBG_TL4D;
@@ -504,8 +510,8 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
     // ~240 VALU instructions per tile on 64-bit per-lane addressing, selects and masks.
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t nwaves = LWAVES ? (uint32_t)LWAVES : blockDim.x >> 6;
-    const uint32_t ngroups = group ? in / group : 1;
     const uint32_t glog = group ? 31u - __builtin_clz(group) : 31u; // group is a power of two
+    const uint32_t ngroups = group ? in >> glog : 1;
     const uint32_t NG = (out_rows + R - 1) / R;
     const uint32_t stride = gridDim.x * nwaves;
     const size_t rowb = F::row_bytes(in);
@@ -581,7 +587,14 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
     // ---- epilogue of ONE row pair (rows 2 pair, 2 pair + 1) from its two fp32 row sums; executed by a single lane.
     // The pair is the unit every epilogue works on: (w1 row j, w3 row j) of the fused ffn matrix, the two RoPE
     // partners of a q / k head (stored adjacently), or simply two rows.
-    auto finish_pair = [&](uint32_t pair, float a, float b) {
+    // Operands of the epilogue that do not depend on the row sums, requested EARLY by the linear-order kernels (one lane
+    // per pair of the wave's first 64): the residual pair, the rotation's cos / sin and the step state.  Read at the
+    // end they are one or two dependent memory round trips (~ 1 us each) behind the last multiply of a launch that
+    // lasts 5 - 8 us; read before the main loop they are the wave's OLDEST loads and cost the loop nothing.
+    uint32_t eo_res = 0, eo_slot = 0, eo_rrow = 0;
+    float eo_c = 0.0f, eo_s = 0.0f;
+    qkv_epilogue eo_q = {};
+    auto finish_pair = [&](uint32_t pair, float a, float b, bool early = false) {
         const uint32_t row = 2 * pair;
         if (row >= out_rows) return;
         const bool two = row + 1 < out_rows;
@@ -605,8 +618,13 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
         if (EPI == EPI_STORE || EPI == EPI_RESID) {
             float va = T::rt(a), vb = T::rt(b);
             if (EPI == EPI_RESID) { // add in T
-                va = T::ld(static_cast<const S*>(resp)[row]) + va;
-                if (two) vb = T::ld(static_cast<const S*>(resp)[row + 1]) + vb;
+                if (early && T::bytes == 2) {
+                    va = asf(eo_res << 16) + va;
+                    vb = asf(eo_res & 0xFFFF0000u) + vb;
+                } else {
+                    va = T::ld(static_cast<const S*>(resp)[row]) + va;
+                    if (two) vb = T::ld(static_cast<const S*>(resp)[row + 1]) + vb;
+                }
             }
             if (two && T::bytes == 2) {
                 // both rows in ONE 4-byte store (row is even): half the store instructions of the head's 128256 rows
@@ -616,23 +634,27 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
                 if (two) y[row + 1] = T::st(vb);
             }
         } else if (EPI == EPI_QKV_ROPE) {
-            const qkv_epilogue* q = static_cast<const qkv_epilogue*>(resp);
+            // (linear-order kernels read the descriptor once, at the top, with scalar loads: eo_q)
+            const qkv_epilogue* q = LNCH ? &eo_q : static_cast<const qkv_epilogue*>(resp);
             const uint32_t H = q->H, KV = q->KV, hd = q->hd, half = hd / 2, ms = q->max_seq;
-            const uint32_t slot = (uint32_t)q->state[3], rrow = (uint32_t)q->state[6];
+            const uint32_t slot = LNCH ? eo_slot : (uint32_t)q->state[3], rrow = LNCH ? eo_rrow : (uint32_t)q->state[6];
+            typedef const __attribute__((address_space(1))) float* gfloat_p;
+            typedef __attribute__((address_space(1))) S* gS_p;
             if (row < (H + KV) * hd) {
                 // a rotation pair: packed rows (2j, 2j + 1) of a head = natural (j, j + hd/2)
                 const float x1 = T::rt(a), x2 = T::rt(b);
                 const uint32_t head = row / hd, j = (row % hd) / 2;
-                const float c = q->fcos[(size_t)rrow * half + j], sn = q->fsin[(size_t)rrow * half + j];
+                const float c = early ? eo_c : ((gfloat_p)q->fcos)[(size_t)rrow * half + j];
+                const float sn = early ? eo_s : ((gfloat_p)q->fsin)[(size_t)rrow * half + j];
                 const S o1 = T::st(c * x1 - sn * x2), o2 = T::st(sn * x1 + c * x2);
-                S* dst = head < H ? static_cast<S*>(q->q_out) + (size_t)head * hd
-                                  : static_cast<S*>(q->kc) + ((size_t)(head - H) * ms + slot) * hd;
+                gS_p dst = head < H ? (gS_p)q->q_out + (size_t)head * hd
+                                    : (gS_p)q->kc + ((size_t)(head - H) * ms + slot) * hd;
                 dst[j] = o1;
                 dst[j + half] = o2;
             } else {
                 const uint32_t vrow = row - (H + KV) * hd; // kv*hd + d
-                static_cast<S*>(q->vt)[(size_t)vrow * ms + slot] = T::st(a);
-                if (two) static_cast<S*>(q->vt)[(size_t)(vrow + 1) * ms + slot] = T::st(b);
+                ((gS_p)q->vt)[(size_t)vrow * ms + slot] = T::st(a);
+                if (two) ((gS_p)q->vt)[(size_t)(vrow + 1) * ms + slot] = T::st(b);
             }
         } else if (two) {
             // (w1 row j, w3 row j): out[j] = T(act(T(w1 x)) * T(w3 x))
@@ -702,8 +724,27 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
 #ifndef MC_GEMV_XBAR
 #define MC_GEMV_XBAR 1 // 1: a raw s_barrier (no memory wait) between the row requests and the first weight requests: with one
 #endif                 // workgroup per CU every row packet is then AHEAD of every weight packet in the CU's in-order memory pipe
-        if (MC_GEMV_XBAR) asm volatile("s_barrier" ::: "memory");
-        prefetch(); // the first weight tile(s): requested behind the row, before the row is consumed
+#ifndef MC_GEMV_XFIRST
+#define MC_GEMV_XFIRST 0 // 1 (linear-order kernels): the first weight tiles are requested only once the row has ARRIVED
+#endif
+        constexpr bool XFIRST = MC_GEMV_XFIRST && LNCH > 0;
+        uint32_t xf_never = 0;
+        if (XFIRST) asm volatile("s_mov_b32 %0, 0" : "=s"(xf_never));
+        if (!XFIRST) {
+            if (MC_GEMV_XBAR) asm volatile("s_barrier" ::: "memory");
+            prefetch(); // the first weight tile(s): requested behind the row, before the row is consumed
+        } else if (fits) {
+            // With 2048 waves asking for 4 KiB of weights each the moment they start, the row (and the kernel arguments and
+            // instructions of the waves that start a little later) queue behind 8 MB of weight requests: the row takes
+            // 1.3 - 1.7 us to arrive instead of the 0.56 us of an idle memory system (tools/floor_lab).
+            asm volatile("" ::"v"(xr[0].x), "v"(xr[MAXP - 1].w)); // the row is here
+            if (PRO != PRO_NONE) asm volatile("" ::"v"(nr[MAXP - 1].w));
+            if (xf_never) asm volatile("s_nop 0");
+            prefetch();
+            if (xf_never) asm volatile("s_nop 0");
+        } else {
+            prefetch();
+        }
         if (fits) {
 #pragma unroll
             for (int i = 0; i < MAXP; i++)
@@ -910,6 +951,34 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
 #define MC_GEMV_LIN_ACCS 1 // independent accumulators per row (the MFMAs of a packet dealt round-robin): 1 = one dependency chain
 #endif
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+#ifndef MC_GEMV_LIN_LEANPRO
+#define MC_GEMV_LIN_LEANPRO 1
+#endif
+        // The prologue with everything known at build time (K = 2048 LNCH, 64 LWAVES threads): NXP packets of 16 bytes
+        // per thread, no padding, no fallback path.  A wave issues ~ 0.5 instructions per ns, and the generic
+        // stage_x -- unrolled for the longest row it may meet, every iteration predicated -- put 620 (plain row) to
+        // 1160 (rmsnorm) instructions in front of the first multiply of a launch that lasts 5 - 16 us: its 1.3 - 1.7 us
+        // from wave start to "row staged" were instruction issue, not memory latency (an idle memory system delivers
+        // the row in 0.56 us, tools/floor_lab).  The row is requested FIRST, before the wave even works out its range.
+        constexpr bool LEAN = MC_GEMV_LIN_LEANPRO && LWAVES > 0 && PRO != PRO_POSTNORM;
+        constexpr uint32_t NPK = 256u * LNCH, BD = LWAVES ? 64u * LWAVES : 64u;
+        constexpr int NXP = LEAN ? (int)((NPK + BD - 1) / BD) : 1;
+        constexpr bool RAGGED = NPK % BD != 0; // the last packet of a thread may not exist (lin7: 3.5 per thread, lin1: 0.5)
+        uint4 lxr[NXP], lnr[PRO == PRO_RMSNORM ? NXP : 1];
+        uint32_t lin_never;
+        asm volatile("s_mov_b32 %0, 0" : "=s"(lin_never));
+        if constexpr (LEAN) {
+            const uint4* xg = static_cast<const uint4*>(xp);
+            const uint4* ng = static_cast<const uint4*>(normp);
+#pragma unroll
+            for (int i = 0; i < NXP; i++) {
+                const uint32_t p = tid + i * BD;
+                const uint32_t pc = (RAGGED && i == NXP - 1) ? min(p, NPK - 1) : p;
+                lxr[i] = xg[pc];
+                if (PRO == PRO_RMSNORM) lnr[i] = ng[pc];
+            }
+            if (lin_never) asm volatile("" ::"v"(lxr[0].x)); // ends the basic block: the requests stay in front of what follows
+        }
         const uint32_t nw_total = gridDim.x * nwaves, gw = blockIdx.x * nwaves + wave;
         const uint32_t NP = (out_rows + 1) / 2; // row pairs (the host takes this path only for even out_rows)
         // equal ranges to within one pair, without a 64-bit division: the first NP % nw_total waves take one pair more
@@ -924,9 +993,14 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
         // of the buffer base.  (live ? offset : 0 is written as a mask: given a select between two address
         // computations hipcc builds a branch, and a load behind a branch costs every counted s_waitcnt vmcnt(N).)
         auto ltile = [&](uint4 (&dst)[LTP], uint32_t pr, int t, bool live) {
-            const uint64_t m = 0ull - (uint64_t)live;
-            const uint64_t rbyte = (((uint64_t)pr * 2 + (uint64_t)(t / SUB)) * rowb + (uint64_t)(t % SUB) * LTP * 1024 + lane16) & m;
-            const char* a = wbase + rbyte;
+            // wave-uniform 64-bit base (SALU) + a 32-bit lane offset: the load takes its base from an SGPR pair and the
+            // address costs ONE vector instruction (the per-lane 64-bit form cost ~ 10 per tile)
+            const uint64_t rb = ((uint64_t)pr * 2 + (uint64_t)(t / SUB)) * rowb + (uint64_t)(t % SUB) * LTP * 1024;
+            // (masks, not selects: given a select between two addresses hipcc builds a branch, and a load behind a branch
+            //  costs every counted s_waitcnt vmcnt(N))
+            const uint32_t lm = 0u - (uint32_t)live;
+            const char* a = wbase + (rb & (((uint64_t)lm << 32) | lm));
+            const uint32_t lo = lane16 & lm;
 #pragma unroll
             for (int p = 0; p < LTP; p++) {
                 if (MC_GEMV_LIN_NOLOAD) {
@@ -934,7 +1008,7 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
                                         (p + lane) * 0xC2B2AE35u + pr); // every dword differs per lane: nothing folds onto the scalar unit
                     continue;
                 }
-                const u32x4* ap = reinterpret_cast<const u32x4*>(a + p * 1024);
+                const u32x4* ap = reinterpret_cast<const u32x4*>(a + p * 1024 + lo);
                 const u32x4 v = MC_GEMV_LIN_NT ? __builtin_nontemporal_load(ap) : *ap;
                 dst[p] = make_uint4(v.x, v.y, v.z, v.w);
             }
@@ -942,7 +1016,9 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
         // scales of pair pr: half a row quad ([ngroups][4] bf16 per four rows) per chunk; the lane's 32 weights of
         // chunk c sit in group (2048 c + 32 lane) / group
         auto lscales = [&](uint32_t (&q)[LNCH], uint32_t pr, bool live) {
-            const uint64_t m = 0ull - (uint64_t)live;
+            const uint64_t ub = (((uint64_t)(pr >> 1) * ngroups) * 4 + (pr & 1u) * 2) * 2; // wave-uniform part
+            const uint32_t lm = 0u - (uint32_t)live;
+            const char* a = sbase + (ub & (((uint64_t)lm << 32) | lm));
 #pragma unroll
             for (int c = 0; c < LNCH; c++) {
                 if (MC_GEMV_LIN_NOLOAD) {
@@ -950,7 +1026,7 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
                     continue;
                 }
                 const uint32_t g = group ? ((2048u * c + 32u * lane) >> glog) : 0u;
-                q[c] = *reinterpret_cast<const uint32_t*>(sbase + (((((uint64_t)(pr >> 1) * ngroups + g) * 4 + (pr & 1u) * 2) * 2) & m));
+                q[c] = *reinterpret_cast<const uint32_t*>(a + ((g * 8u) & lm));
             }
         };
 
@@ -962,13 +1038,89 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
             lclk0 = __builtin_amdgcn_s_memtime(); // shader clock: with the 100 MHz stamps it gives the clock the wave really ran at
         }
         constexpr int U = LR >= TPP ? LR / TPP : 1; // pairs per unrolled iteration
-        stage_x([&] {
+        // an opaque zero: `if (lin_never) use(v)` keeps the load of v in front of that point (a value needed on both
+        // sides of a branch cannot be sunk to its later use) without waiting for it on the path that is taken
+        const uint32_t eo_pair = min(pb + lane, NP - 1); // the pair this lane will finish in the wave's first flush
+        if (EPI == EPI_RESID && T::bytes == 2) {
+            eo_res = reinterpret_cast<const uint32_t*>(resp)[eo_pair];
+            if (lin_never) asm volatile("" ::"v"(eo_res));
+        }
+        if (EPI == EPI_QKV_ROPE) {
+            // the whole descriptor with scalar loads, before anything of this kernel can have clobbered memory (behind
+            // a barrier hipcc reads such fields with VECTOR loads and waits for them with vmcnt(0) -- i.e. for every
+            // weight tile in flight); pointers found in memory are generic: without the address-space cast a read through
+            // them is a flat_load, which counts on both wait counters
+            eo_q = *static_cast<const qkv_epilogue*>(resp);
+            const __attribute__((address_space(1))) int32_t* stp = (const __attribute__((address_space(1))) int32_t*)eo_q.state;
+            eo_slot = (uint32_t)stp[3];
+            eo_rrow = (uint32_t)stp[6];
+            if (lin_never) asm volatile("" ::"s"(eo_slot), "s"(eo_rrow), "s"(eo_q.H), "s"(eo_q.KV), "s"(eo_q.hd), "s"(eo_q.max_seq));
+        }
+        auto lin_prefetch = [&] {
             lscales(sa, pb, pb < pe);
 #pragma unroll
             for (int j = 0; j < LR; j++) ltile(lring[j], pb + j / TPP, j % TPP, pb + j / TPP < pe);
-        });
+        };
+        if constexpr (LEAN) {
+            uint4* xl = reinterpret_cast<uint4*>(xs);
+            uint4 (&xr)[NXP] = lxr;
+            uint4 (&nr)[PRO == PRO_RMSNORM ? NXP : 1] = lnr;
+            if (MC_GEMV_XBAR) asm volatile("s_barrier" ::: "memory");
+            lin_prefetch();
+            auto live = [&](int i) { return !(RAGGED && i == NXP - 1) || tid + i * BD < NPK; };
+            if (PRO == PRO_RMSNORM) {
+                float ss = 0.0f;
+#pragma unroll
+                for (int i = 0; i < NXP; i++) {
+                    const uint32_t vv[4] = {xr[i].x, xr[i].y, xr[i].z, xr[i].w};
+                    float s1 = 0.0f;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const float a = asf(vv[e] << 16), b = asf(vv[e] & 0xFFFF0000u);
+                        s1 += a * a;
+                        s1 += b * b;
+                    }
+                    ss += live(i) ? s1 : 0.0f; // same per-packet, per-thread order of additions as stage_x
+                }
+                const float wsum_ = wave_sum_dpp(ss);
+                if (lane == 0) red[wave] = wsum_;
+                __syncthreads();
+                float tot = 0.0f;
+#pragma unroll
+                for (uint32_t i = 0; i < (uint32_t)LWAVES; i++) tot += red[i];
+                const float inv = 1.0f / sqrtf(tot / (float)in + eps);
+#pragma unroll
+                for (int i = 0; i < NXP; i++) {
+                    const uint32_t vv[4] = {xr[i].x, xr[i].y, xr[i].z, xr[i].w};
+                    const uint32_t ww[4] = {nr[i].x, nr[i].y, nr[i].z, nr[i].w};
+                    uint32_t o[4];
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const float a = (mu + asf(ww[e] << 16)) * asf(vv[e] << 16) * inv;
+                        const float b = (mu + asf(ww[e] & 0xFFFF0000u)) * asf(vv[e] & 0xFFFF0000u) * inv;
+                        o[e] = pack_bf16x2(a, b);
+                    }
+                    if (live(i)) xl[xpk(tid + i * BD)] = make_uint4(o[0], o[1], o[2], o[3]);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < NXP; i++)
+                    if (live(i)) xl[xpk(tid + i * BD)] = xr[i];
+            }
+        } else {
+            stage_x(lin_prefetch);
+        }
         __syncthreads();
         if (MC_GEMV_LIN_TL) ltl[1] = __builtin_amdgcn_s_memrealtime();
+        if (EPI == EPI_QKV_ROPE) {
+            // the step state has long arrived: the table row of this lane's pair, behind the first ring tiles
+            typedef const __attribute__((address_space(1))) float* gfloat_p;
+            const uint32_t hd = eo_q.hd, row = 2 * eo_pair;
+            const uint32_t j = row < (eo_q.H + eo_q.KV) * hd ? (row % hd) / 2 : 0u;
+            eo_c = ((gfloat_p)eo_q.fcos)[(size_t)eo_rrow * (hd / 2) + j];
+            eo_s = ((gfloat_p)eo_q.fsin)[(size_t)eo_rrow * (hd / 2) + j];
+            if (lin_never) asm volatile("" ::"v"(eo_c), "v"(eo_s));
+        }
 
         const uint32_t lane_tr = (((lane >> 4) * 4 + (lane & 3)) * 17 + ((lane >> 2) & 3) * 4) * 16;
         const uint32_t m4d_mx = (lane & 3) == 0 ? 0x0000FFFFu : ((lane & 3) == 1 ? 0xFFFF0000u : 0u);
@@ -991,14 +1143,13 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
             // one lane per parked pair (the LDS operations of a wave complete in order: no barrier needed)
             if (lane < parked) {
                 const float2 v = park[lane];
-                finish_pair(park_first + lane, v.x, v.y);
+                finish_pair(park_first + lane, v.x, v.y, park_first == pb);
             }
             park_first += parked;
             parked = 0;
         };
 
-        uint32_t lin_never, lin_dummy = 0;
-        asm volatile("s_mov_b32 %0, 0" : "=s"(lin_never));
+        uint32_t lin_dummy = 0;
         constexpr int NA = MC_GEMV_LIN_ACCS;
         mf_f4 laccs[NA];
 #pragma unroll
