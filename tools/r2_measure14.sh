@@ -1,0 +1,10 @@
+#!/bin/bash
+cd /root/repo
+O=gpurun_out; L=$O/ab14.log; : > $L
+run() { hs=$1; lw=$2; geom=$3; MC_LIN_WAVES=$lw DBGS=0 timeout -k 10 120 python3 tools/gemv_ab.py $hs $geom >> $L 2>> $O/ab14.err || echo "{\"hsaco\": \"$hs\", \"failed\": $?}" >> $L; }
+run metalchat_amd/lib/metalchat.hsaco 8 512x1
+run tools/variants/l7r7.hsaco 8 512x1
+run tools/variants/l7r14.hsaco 8 512x1
+run tools/variants/l2r4.hsaco 8 512x1
+run tools/variants/l2r8.hsaco 8 512x1
+cat $L
