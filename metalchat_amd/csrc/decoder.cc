@@ -245,6 +245,7 @@ struct mc_decoder {
     int gemv_block = 256;
     int gemv_wgs_per_cu = 2;
     bool gemv_lin = true;        // MC_GEMV_LIN=0: classic kernels everywhere (A/B)
+    bool pv_fold_on = true;      // MC_PV_FOLD=0: P.V ranges reduced by their own launch (A/B, parity)
     int lin_waves = 8;           // MC_LIN_WAVES: tuning builds of the linear-order kernels with another workgroup size
     bool gemv_block_env = false; // MC_GEMV_BLOCK / MC_GEMV_WGS_PER_CU given: they apply to every kernel of the family
     bool gemv_full_grid = false; // MC_GEMV_FULLGRID=1: as many workgroups as CUs allow even when that leaves waves without a row group (kernels built with MC_GEMV_WAVEMAJOR)
@@ -450,6 +451,25 @@ struct mc_decoder {
     }
 
     // ---------------------------------------------------------------- launches
+    // does this linear take the linear-order kernels (gemv.h)?  int4 on bfloat rows, exact arithmetic, scale groups of
+    // whole 128-weight lane blocks, rows of 1, 2, 4, 7 or 14 whole KiB, whole row groups
+    bool
+    lin_ok(const linear_w& L) const
+    {
+        const bool m4 = L.fmt == MC_WFMT_I4 && tb == 2 && cfg.qmode == MC_QMODE_EXACT && gemv_m4 && !dbg_variant;
+        const bool m4d_ok = m4 && (L.group == 0 || L.group % 128 == 0) && L.in % 128 == 0;
+        const int nch = L.in % 2048 == 0 ? L.in / 2048 : 0;
+        return gemv_lin && m4d_ok && L.out % 4 == 0 && (nch == 1 || nch == 2 || nch == 4 || nch == 7 || nch == 14);
+    }
+    // P.V over four ranges of cache slots (256 workgroups instead of 64: a CU takes in ~ 25 GB/s, and 64 of them need
+    // ~ 4 us for the V cache of one layer at S = 2048) with the range sums added by the Wo GEMV's prologue (gemv.h
+    // PRO_PARTS) instead of a reduce launch
+    bool
+    pv_fold(const linear_w& wo) const
+    {
+        return pv_fold_on && lin_ok(wo) && !wo.lora_cols && cfg.max_seq_len <= 16384;
+    }
+
     mc_status
     gemv(const linear_w& L, int pro, int epi, const void* x, void* y, const void* res,
          const void* norm_w, float mu)
@@ -479,7 +499,8 @@ struct mc_decoder {
         const bool m4d = m4d_ok && (gemv_m4 >= 3 || (gemv_m4 == 2 && shared_simd));
         // linear-order main loop (gemv.h): rows of whole KiB (K a multiple of 2048: 1, 2, 4, 7 or 14 KiB), whole row groups
         const int nch = L.in % 2048 == 0 ? L.in / 2048 : 0;
-        const bool lin = gemv_lin && m4d_ok && L.out % 4 == 0 && (nch == 1 || nch == 2 || nch == 4 || nch == 7 || nch == 14);
+        const bool lin = lin_ok(L);
+        if (pro == 3 && !lin) return fail(MC_ERR_RUNTIME, "gemv: the partial-sum prologue exists for the linear-order kernels only");
         if (lin) {
             name += "_lin" + std::to_string(nch);
             // ONE workgroup of eight waves per CU: the activation row is staged once per CU and, with the raw barrier
@@ -596,21 +617,27 @@ struct mc_decoder {
                             (uint32_t)hd, (uint32_t)cfg.max_seq_len, scale_T, (uint32_t)nsplit));
             if (s != MC_OK) return s;
             // softmax normalisation + P.V          (attention.h:200-203)
-            s = launch("mc_attn_pv_" + tname, hd / 16, KV, pv_ranges, pv_block, 0,
+            const bool fold = pv_fold(L.wo);
+            const int ranges = fold ? 4 : pv_ranges;
+            // folded: one round of loads per wave (four k-steps of 32 slots each)
+            const int fold_waves = std::max(4, std::min(16, ((cfg.max_seq_len + 31) / 32 / 4 + 3) / 4));
+            s = launch("mc_attn_pv_" + tname, hd / 16, KV, ranges, fold ? 64 * fold_waves : pv_block, 0,
                        pack(expv, psum, L.vt, attn_out, state, (uint32_t)n_rep, (uint32_t)hd,
                             (uint32_t)cfg.max_seq_len, (uint32_t)nsplit, pv_parts, (uint32_t)H));
             if (s != MC_OK) return s;
-            if (pv_ranges > 1) {
+            if (ranges > 1 && !fold) {
                 s = launch("mc_attn_pv_reduce_" + tname, (H * hd + 255) / 256, 1, 1, 256, 0,
-                           pack((const void*)pv_parts, attn_out, (uint32_t)(H * hd), (uint32_t)pv_ranges));
+                           pack((const void*)pv_parts, attn_out, (uint32_t)(H * hd), (uint32_t)ranges));
                 if (s != MC_OK) return s;
             }
             // wo (+ post norm) + residual          (attention.h:205, transformer.h:132-133)
+            const void* wo_x = fold ? (const void*)pv_parts : (const void*)attn_out;
+            const int wo_pro = fold ? 3 : 0;
             if (!gemma) {
-                s = gemv(L.wo, 0, 1, attn_out, hidden, x, nullptr, mu);
+                s = gemv(L.wo, wo_pro, 1, wo_x, hidden, x, nullptr, mu);
                 if (s != MC_OK) return s;
             } else {
-                s = gemv(L.wo, 0, 0, attn_out, proj, nullptr, nullptr, mu);
+                s = gemv(L.wo, wo_pro, 0, wo_x, proj, nullptr, nullptr, mu);
                 if (s != MC_OK) return s;
                 if (!fuse_pn) {
                     s = launch("mc_rmsnorm_row_" + tname, 1, 1, 1, 1024, 0,
@@ -988,6 +1015,7 @@ mc_decoder_create(mc_device* dev, mc_library* lib, mc_queue* q, const mc_decoder
     if (const char* e = getenv("MC_GEMV_DBG")) d->dbg_variant = atoi(e);
     if (const char* e = getenv("MC_GEMV_FULLGRID")) d->gemv_full_grid = atoi(e) != 0;
     if (const char* e = getenv("MC_GEMV_LIN")) d->gemv_lin = atoi(e) != 0;
+    if (const char* e = getenv("MC_PV_FOLD")) d->pv_fold_on = atoi(e) != 0;
     if (const char* e = getenv("MC_LIN_WAVES")) d->lin_waves = std::max(1, std::min(16, atoi(e)));
     if (const char* e = getenv("MC_GEMMA_UNFUSED")) d->gemma_fuse = atoi(e) == 0;
     if (const char* e = getenv("MC_GEMV_M4")) d->gemv_m4 = atoi(e);
@@ -1020,7 +1048,7 @@ mc_decoder_create(mc_device* dev, mc_library* lib, mc_queue* q, const mc_decoder
     // (S = 8192, int8 weights: 1 range 369, 2: 391, 4: 402, 8: 383, 16: 347 tokens/s)
     d->pv_ranges = c.max_seq_len >= 8192 ? std::min(16, c.max_seq_len / 2048) : 1;
     if (const char* e = getenv("MC_PV_RANGES")) d->pv_ranges = std::max(1, std::min(64, atoi(e)));
-    A(d->pv_parts, (size_t)d->pv_ranges * H * hd * 4);
+    A(d->pv_parts, (size_t)std::max(d->pv_ranges, 4) * H * hd * 4);
     A(d->taps, (size_t)(d->n_own + 1) * dim * tb);
     A(d->state, sizeof(step_state_h));
     d->tokens_cap = 1 << 16;
@@ -1748,7 +1776,11 @@ mc_decoder_time_gemv(mc_decoder* d, const char* which, int32_t repeats, float* t
                 if (count) { bytes += linear_bytes(L.qkv); launches++; }
             }
             if (w == "wo" || w == "all") {
-                r = d->gemv(L.wo, 0, 0, d->attn_out, d->proj, nullptr, nullptr, mu);
+                // the variant the token really launches (residual epilogue; the partial-sum prologue when P.V is folded);
+                // the result goes to `proj`, so the hidden row stays what it was
+                const bool fold = d->pv_fold(L.wo);
+                r = d->gemv(L.wo, fold ? 3 : 0, gemma ? 0 : 1, fold ? (const void*)d->pv_parts : (const void*)d->attn_out, d->proj,
+                            gemma ? nullptr : d->hidden, nullptr, mu);
                 if (r != MC_OK) return r;
                 if (count) { bytes += linear_bytes(L.wo); launches++; }
             }
@@ -1758,7 +1790,7 @@ mc_decoder_time_gemv(mc_decoder* d, const char* which, int32_t repeats, float* t
                 if (count) { bytes += linear_bytes(L.w13); launches++; }
             }
             if (w == "w2" || w == "all") {
-                r = d->gemv(L.w2, 0, 0, d->gate, d->proj, nullptr, nullptr, mu);
+                r = d->gemv(L.w2, 0, gemma ? 0 : 1, d->gate, d->proj, gemma ? nullptr : d->hidden, nullptr, mu);
                 if (r != MC_OK) return r;
                 if (count) { bytes += linear_bytes(L.w2); launches++; }
             }

@@ -38,7 +38,12 @@ enum { Q_EXACT = 0, Q_FAST = 1, Q_DBG_STREAM = 2, Q_DBG_NOLOAD = 3, Q_DBG_TL = 4
        Q_M4 = 5,   // exact, the dot products of a lane on v_mfma_f32_4x4x4_16b_bf16 (int4, bfloat)
        Q_M4D = 6,  // Q_M4 with the dequantisation itself on the same instruction (group % 128 == 0)
        Q_DBG_TL4D = 7 }; // Q_M4D with the per-wave time stamps of Q_DBG_TL
-enum { PRO_NONE = 0, PRO_RMSNORM = 1, PRO_POSTNORM = 2 };
+enum { PRO_NONE = 0, PRO_RMSNORM = 1, PRO_POSTNORM = 2, PRO_PARTS = 3 };
+// PRO_PARTS (linear-order kernels only): the row is the decode attention output still in pieces --
+// `x` = fp32 partial P.V sums [PARTS_R][in], one per range of cache slots (mc_attn_pv_T with gridDim.z = PARTS_R);
+// the prologue adds them in range order and rounds ONCE to T, exactly what mc_attn_pv_reduce_T does (bmm.metal:80:
+// one rounding of the fp32 sum), so the reduce launch between P.V and Wo disappears.
+constexpr int PARTS_R = 4;
 
 // PRO_POSTNORM (gemma3 blocks, include/metalchat/nn/transformer.h:132-139): the row handed to the
 // kernel is the OUTPUT of the previous linear; the prologue applies its post-norm, adds the residual,
@@ -961,10 +966,12 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
         // from wave start to "row staged" were instruction issue, not memory latency (an idle memory system delivers
         // the row in 0.56 us, tools/floor_lab).  The row is requested FIRST, before the wave even works out its range.
         constexpr bool LEAN = MC_GEMV_LIN_LEANPRO && LWAVES > 0 && PRO != PRO_POSTNORM;
+        static_assert(PRO != PRO_PARTS || LEAN, "PRO_PARTS needs the build-time prologue");
         constexpr uint32_t NPK = 256u * LNCH, BD = LWAVES ? 64u * LWAVES : 64u;
         constexpr int NXP = LEAN ? (int)((NPK + BD - 1) / BD) : 1;
         constexpr bool RAGGED = NPK % BD != 0; // the last packet of a thread may not exist (lin7: 3.5 per thread, lin1: 0.5)
         uint4 lxr[NXP], lnr[PRO == PRO_RMSNORM ? NXP : 1];
+        float4 lpr[PRO == PRO_PARTS ? NXP : 1][PRO == PRO_PARTS ? 2 * PARTS_R : 1];
         uint32_t lin_never;
         asm volatile("s_mov_b32 %0, 0" : "=s"(lin_never));
         if constexpr (LEAN) {
@@ -974,10 +981,20 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
             for (int i = 0; i < NXP; i++) {
                 const uint32_t p = tid + i * BD;
                 const uint32_t pc = (RAGGED && i == NXP - 1) ? min(p, NPK - 1) : p;
-                lxr[i] = xg[pc];
+                if constexpr (PRO == PRO_PARTS) {
+                    // eight elements of the row = 32 bytes of every range's partial sums
+                    const float4* pg = static_cast<const float4*>(xp);
+#pragma unroll
+                    for (int r = 0; r < PARTS_R; r++) {
+                        lpr[i][2 * r] = pg[(size_t)r * (in / 4) + 2 * pc];
+                        lpr[i][2 * r + 1] = pg[(size_t)r * (in / 4) + 2 * pc + 1];
+                    }
+                } else {
+                    lxr[i] = xg[pc];
+                }
                 if (PRO == PRO_RMSNORM) lnr[i] = ng[pc];
             }
-            if (lin_never) asm volatile("" ::"v"(lxr[0].x)); // ends the basic block: the requests stay in front of what follows
+            if (lin_never) asm volatile("" ::"v"(PRO == PRO_PARTS ? __float_as_uint(lpr[0][0].x) : lxr[0].x)); // ends the basic block: the requests stay in front of what follows
         }
         const uint32_t nw_total = gridDim.x * nwaves, gw = blockIdx.x * nwaves + wave;
         const uint32_t NP = (out_rows + 1) / 2; // row pairs (the host takes this path only for even out_rows)
@@ -1068,6 +1085,19 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
             if (MC_GEMV_XBAR) asm volatile("s_barrier" ::: "memory");
             lin_prefetch();
             auto live = [&](int i) { return !(RAGGED && i == NXP - 1) || tid + i * BD < NPK; };
+            if constexpr (PRO == PRO_PARTS) {
+#pragma unroll
+                for (int i = 0; i < NXP; i++) {
+                    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int r = 0; r < PARTS_R; r++) { // ranges in order, as mc_attn_pv_reduce_T adds them
+                        const float4 lo = lpr[i][2 * r], hi = lpr[i][2 * r + 1];
+                        a[0] += lo.x; a[1] += lo.y; a[2] += lo.z; a[3] += lo.w;
+                        a[4] += hi.x; a[5] += hi.y; a[6] += hi.z; a[7] += hi.w;
+                    }
+                    xr[i] = make_uint4(pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]), pack_bf16x2(a[4], a[5]), pack_bf16x2(a[6], a[7]));
+                }
+            }
             if (PRO == PRO_RMSNORM) {
                 float ss = 0.0f;
 #pragma unroll

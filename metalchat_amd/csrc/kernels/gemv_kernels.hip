@@ -1,6 +1,6 @@
 // extern "C" instantiations of the fused GEMV (gemv.h).  Name:
 //   mc_gemv_{i4|i8|w}_{bfloat|float}[_fast]_p{PRO}_e{EPI}
-//   PRO 0 = x as is, 1 = rmsnorm(x) on the way into LDS, 2 = gemma3: post-norm of the previous linear's
+//   PRO 0 = x as is, 1 = rmsnorm(x) on the way into LDS, 3 = x is the sum of four fp32 partial rows (linear-order kernels), 2 = gemma3: post-norm of the previous linear's
 //       output + residual (written back by workgroup 0) + this linear's pre-norm (`res` = postnorm_args*)
 //   EPI 0 = store, 1 = residual add, 2 = silu(w1 x) * (w3 x), 3 = gelu(w1 x) * (w3 x),
 //       4 = wq|wk|wv with RoPE + sink-cache write (`res` carries a qkv_epilogue*)
@@ -45,7 +45,9 @@ using namespace mc::gemv;
     MC_GEMV_LIN(PFX##_p1_e3, 1, 3, __VA_ARGS__) \
     MC_GEMV_LIN(PFX##_p1_e4, 1, 4, __VA_ARGS__) \
     MC_GEMV_LIN(PFX##_p2_e0, 2, 0, __VA_ARGS__) \
-    MC_GEMV_LIN(PFX##_p2_e3, 2, 3, __VA_ARGS__)
+    MC_GEMV_LIN(PFX##_p2_e3, 2, 3, __VA_ARGS__) \
+    MC_GEMV_LIN(PFX##_p3_e0, 3, 0, __VA_ARGS__) \
+    MC_GEMV_LIN(PFX##_p3_e1, 3, 1, __VA_ARGS__)
 
 #define MC_GEMV_SET(PFX, WF, T, QM)            \
     MC_GEMV(PFX##_p0_e0, WF, T, QM, 0, 0)      \

@@ -233,3 +233,36 @@ def test_rows_in_the_cache_do_not_move_across_a_roll(acc):
                     parity.exact(new[pre:S - 1], old[pre + 1:S], f"dt{dt} pos {pos}: rotated rows")
             prev = (k.copy(), v.copy())
         dec.release()
+
+
+@pytest.mark.parametrize("max_seq", [2048, 8192])
+def test_pv_ranges_folded_into_wo_equal_the_reduce_launch_bit_for_bit(acc, monkeypatch, max_seq):
+    # P.V over four ranges of cache slots whose fp32 sums the Wo GEMV's prologue adds (gemv.h PRO_PARTS) must be the very
+    # numbers of the same four ranges reduced by mc_attn_pv_reduce_T and followed by the plain Wo GEMV: hidden rows,
+    # logits, tokens.  (A whole-context P.V adds the same products in another order: that is parity, not identity.)
+    import metalchat_amd as mc
+
+    monkeypatch.setenv("MC_PV_RANGES", "4")
+    # ... and the same waves per workgroup (they add their k-steps' sums in wave order): one round of loads per wave
+    monkeypatch.setenv("MC_PV_BLOCK", "256" if max_seq == 2048 else "1024")
+
+    cfg = dict(dtype=BF16, n_layers=2, vocab=2048, max_seq_len=max_seq, norm_eps=1e-5, **FULL_WIDTH["llama3-8b"])
+    out = {}
+    for fold in ("1", "0"):
+        monkeypatch.setenv("MC_PV_FOLD", fold)
+        dec = mc.Decoder(acc, **mg.decoder_kwargs(cfg, weight_format=mc.WFMT_I4, group_size=128))
+        dec.init_synthetic(SEED)
+        dec.set_taps(True)
+        for layer in range(cfg["n_layers"]):
+            k, v = random_cache(cfg, max_seq - 5, 300 + layer)
+            dec.import_kv(layer, k, v)
+        tok, rows = 11, []
+        for i in range(9):  # up to the end of the cache and four rolls past it
+            tok = dec.step(tok, max_seq - 5 + i)
+            rows.append((tok, dec.logits().copy(), np.stack([dec.hidden(l) for l in range(-1, cfg["n_layers"])])))
+        out[fold] = rows
+        dec.release()
+    for (ta, la, ha), (tb_, lb, hb) in zip(out["1"], out["0"]):
+        assert ta == tb_
+        parity.exact(la, lb, "logits, folded vs reduce launch")
+        parity.exact(ha, hb, "hidden rows, folded vs reduce launch")
