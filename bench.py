@@ -47,6 +47,10 @@ MODELS = {
                            n_layers=22, vocab=32000, rope_theta=10000.0, norm_eps=1e-5),
     "llama3-70b": dict(dim=8192, n_heads=64, n_kv_heads=8, head_dim=128, ffn_dim=28672,
                        n_layers=80, vocab=128256, rope_theta=500000.0, norm_eps=1e-5),
+    # the reference's default model (src/llama.cc:19-31) and the decode layer MI355X_MICROARCH.md prices
+    # ("launches-baseline": 121.6 MB of bf16 weights per layer in 30.6 us as five captured launches)
+    "llama3.2-1b": dict(dim=2048, n_heads=32, n_kv_heads=8, head_dim=64, ffn_dim=8192, n_layers=16,
+                        vocab=128256, rope_theta=500000.0, norm_eps=1e-5),
     "gemma-7b": dict(dim=3072, n_heads=16, n_kv_heads=16, head_dim=256, ffn_dim=24576, n_layers=28,
                      vocab=256000, rope_theta=10000.0, norm_eps=1e-5),
 }

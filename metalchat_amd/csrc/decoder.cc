@@ -245,6 +245,7 @@ struct mc_decoder {
     int gemv_block = 256;
     int gemv_wgs_per_cu = 2;
     bool gemv_lin = true;        // MC_GEMV_LIN=0: classic kernels everywhere (A/B)
+    bool lin_lds_ring = false;   // MC_LIN_LDS_RING=1 for code objects built with -DMC_GEMV_LIN_LDSRING=1 (they need the rings' LDS)
     bool pv_fold_on = true;      // MC_PV_FOLD=0: P.V ranges reduced by their own launch (A/B, parity)
     int lin_waves = 8;           // MC_LIN_WAVES: tuning builds of the linear-order kernels with another workgroup size
     bool gemv_block_env = false; // MC_GEMV_BLOCK / MC_GEMV_WGS_PER_CU given: they apply to every kernel of the family
@@ -529,6 +530,9 @@ struct mc_decoder {
         if (m4d || lin) lds = lds / 16 * 17; // 16 bytes of padding per 256 for the transposed reads
         lds += 128;
         if (lin) lds += waves * 512; // parked row sums: 64 pairs x 8 bytes per wave
+        // the waves' DMA rings (gemv.h LDSR: rows of two or more KiB, build-time prologue): 7 or 8 KiB per wave
+        // + two slots of scale dwords per wave (256 bytes per 64 scale groups)
+        if (lin && nch >= 2 && lin_lds_ring) lds += waves * (((2 * nch) % 7 == 0 ? 7u : 8u) * 1024u + 2u * ((nch + 3u) / 4u) * 256u); // (also granted to the variants that do not use it)
         if (L.lora_cols) {
             // a = T(A x): the stacked adaptor inputs through the same kernel family (same prologue,
             // so a pre-norm GEMV and its adaptor see the identical normalised row)
@@ -1016,6 +1020,7 @@ mc_decoder_create(mc_device* dev, mc_library* lib, mc_queue* q, const mc_decoder
     if (const char* e = getenv("MC_GEMV_FULLGRID")) d->gemv_full_grid = atoi(e) != 0;
     if (const char* e = getenv("MC_GEMV_LIN")) d->gemv_lin = atoi(e) != 0;
     if (const char* e = getenv("MC_PV_FOLD")) d->pv_fold_on = atoi(e) != 0;
+    if (const char* e = getenv("MC_LIN_LDS_RING")) d->lin_lds_ring = atoi(e) != 0;
     if (const char* e = getenv("MC_LIN_WAVES")) d->lin_waves = std::max(1, std::min(16, atoi(e)));
     if (const char* e = getenv("MC_GEMMA_UNFUSED")) d->gemma_fuse = atoi(e) == 0;
     if (const char* e = getenv("MC_GEMV_M4")) d->gemv_m4 = atoi(e);

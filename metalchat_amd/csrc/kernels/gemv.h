@@ -338,19 +338,48 @@ mac4d_n(mf_f4 (&acc)[NA], const uint4& w, const m4d_scale& sc, const uint2 (&x)[
 {
     const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
     const mf_s4 bs = __builtin_bit_cast(mf_s4, sc.b);
-#pragma unroll
-    for (int d = 0; d < 4; d++) {
+#ifndef MC_GEMV_M4D_SKEW
+#define MC_GEMV_M4D_SKEW 0 // (A/B on MI355X: w1|w3 15.03 -> 14.82 us, w2 10.6 -> 11.1: inside the noise, off) 1: the dequantising MFMAs of dword d + 1 are issued BEFORE the conversions of dword d read theirs
+#endif
+    auto deq = [&](int d, mf_f4& d1, mf_f4& d2) {
         const uint32_t v = ws[d];
         const uint32_t t0 = (v & 0x000F000Fu) | 0x43004300u, t1 = ((v >> 4) & 0x000F000Fu) | 0x43004300u;
         const uint32_t t2 = ((v >> 8) & 0x000F000Fu) | 0x43004300u, t3 = ((v >> 12) & 0x000F000Fu) | 0x43004300u;
-        const mf_f4 d1 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(mf_s4, make_uint2(t0, t1)), bs, sc.c, 0, 0, 0);
-        const mf_f4 d2 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(mf_s4, make_uint2(t2, t3)), bs, sc.c, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(mf_s4, make_uint2(t0, t1)), bs, sc.c, 0, 0, 0);
+        d2 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(mf_s4, make_uint2(t2, t3)), bs, sc.c, 0, 0, 0);
+    };
+    auto fin = [&](int d, const mf_f4& d1, const mf_f4& d2) {
         const uint2 a0 = make_uint2(pack_bf16x2(d1[0], d1[1]), pack_bf16x2(d1[2], d1[3]));
         const uint2 a1 = make_uint2(pack_bf16x2(d2[0], d2[1]), pack_bf16x2(d2[2], d2[3]));
         mf_f4& A0 = acc[(2 * d) % NA];
         mf_f4& A1 = acc[(2 * d + 1) % NA];
         A0 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(mf_s4, a0), __builtin_bit_cast(mf_s4, x[2 * d]), A0, 0, 0, 0);
         A1 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(mf_s4, a1), __builtin_bit_cast(mf_s4, x[2 * d + 1]), A1, 0, 0, 0);
+    };
+    if (MC_GEMV_M4D_SKEW) {
+        // a 4x4x4 MFMA's result can be read ~ 5 issue slots after it was issued: back to back with its conversion the
+        // wave sits in s_nop (hipcc's schedule of the unskewed source: MFMA, s_nop 4, cvt, cvt, MFMA, s_nop 0, MFMA,
+        // s_nop 2, ...) -- a wave alone on its SIMD ran at 61 % of the rate two waves reach together
+        mf_f4 p1, p2, q1, q2;
+        deq(0, p1, p2);
+        deq(1, q1, q2);
+        __builtin_amdgcn_sched_barrier(0);
+        fin(0, p1, p2);
+        deq(2, p1, p2);
+        __builtin_amdgcn_sched_barrier(0);
+        fin(1, q1, q2);
+        deq(3, q1, q2);
+        __builtin_amdgcn_sched_barrier(0);
+        fin(2, p1, p2);
+        __builtin_amdgcn_sched_barrier(0);
+        fin(3, q1, q2);
+    } else {
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            mf_f4 d1, d2;
+            deq(d, d1, d2);
+            fin(d, d1, d2);
+        }
     }
 }
 
@@ -458,6 +487,96 @@ gelu_f32(float x)
     const float inner = beta * (x + kappa * x3);
     return 0.5f * x * (1.0f + (float)tanh((double)inner));
 }
+
+// ------------------------------------------------------------------------------------------
+// LDS accesses hipcc does not see.  A wave that fills its own ring in LDS by DMA (global_load_lds) must read the slots
+// with instructions the compiler's wait insertion knows nothing about: next to an LDS-DMA every compiler-visible LDS
+// access (and every workgroup fence) is preceded by s_waitcnt vmcnt(0) -- the whole ring drained per access.
+// Each read is tied to its wait through the "+v" operand of lds_wait, so no use can be scheduled in front of it.
+// ------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) char lds_char_t;
+typedef uint32_t lds_v4 __attribute__((ext_vector_type(4))); // (asm operands must be native vectors, not HIP's uint4 struct)
+typedef uint32_t lds_v2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)(lds_char_t*)p; }
+template <int OFF> __device__ __forceinline__ lds_v4 lds_rd128(uint32_t a)
+{
+    lds_v4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF) : "memory");
+    return v;
+}
+template <int OFF> __device__ __forceinline__ lds_v2 lds_rd64(uint32_t a)
+{
+    lds_v2 v;
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF) : "memory");
+    return v;
+}
+template <int OFF> __device__ __forceinline__ lds_v2 lds_rd64_tr16(uint32_t a) // ds_read_b64_tr_b16: EXEC must be all ones
+{
+    lds_v2 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF) : "memory");
+    return v;
+}
+__device__ __forceinline__ uint32_t lds_rd32(uint32_t a)
+{
+    uint32_t v;
+    asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(a) : "memory");
+    return v;
+}
+__device__ __forceinline__ void lds_wait(uint32_t& a) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a)::"memory"); }
+__device__ __forceinline__ void lds_wr128(uint32_t a, const uint4& v)
+{
+    const lds_v4 t = {v.x, v.y, v.z, v.w};
+    asm volatile("ds_write_b128 %0, %1" ::"v"(a), "v"(t) : "memory");
+}
+__device__ __forceinline__ void lds_wr64(uint32_t a, uint32_t lo, uint32_t hi)
+{
+    const lds_v2 t = {lo, hi};
+    asm volatile("ds_write_b64 %0, %1" ::"v"(a), "v"(t) : "memory");
+}
+__device__ __forceinline__ void lds_wr32(uint32_t a, uint32_t v) { asm volatile("ds_write_b32 %0, %1" ::"v"(a), "v"(v) : "memory"); }
+__device__ __forceinline__ void lds_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void lds_wait(lds_v4& a) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a)::"memory"); }
+__device__ __forceinline__ void lds_wait(lds_v2& a) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a)::"memory"); }
+__device__ __forceinline__ void lds_wait(lds_v2 (&x)[8])
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7])::"memory");
+}
+// Global loads hipcc does not see either: with an LDS-DMA outstanding its wait insertion treats the vector-memory counter
+// as out of order and waits with vmcnt(0) for ANY load result (the scales of the next row pair, the activation row) --
+// the ring drained again.  So next to the DMA ring every load is issued here and waited for by count (vm_wait<N>: at most N
+// younger vector-memory operations still outstanding; loads, stores and DMAs retire in issue order).
+__device__ __forceinline__ lds_v4 gload128(const void* sbase, uint32_t voff) // wave-uniform base + 32-bit lane offset
+{
+    lds_v4 v;
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(v) : "v"(voff), "s"(sbase) : "memory");
+    return v;
+}
+__device__ __forceinline__ uint32_t gload32(const void* sbase, uint32_t voff)
+{
+    uint32_t v;
+    asm volatile("global_load_dword %0, %1, %2" : "=v"(v) : "v"(voff), "s"(sbase) : "memory");
+    return v;
+}
+__device__ __forceinline__ uint32_t gload32v(const void* p) // per-lane 64-bit address
+{
+    uint32_t v;
+    asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+template <int N> __device__ __forceinline__ void vm_wait(lds_v4& a) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(a) : "n"(N) : "memory"); }
+template <int N> __device__ __forceinline__ void vm_wait(uint32_t& a) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(a) : "n"(N) : "memory"); }
+template <int I, int N, typename F> __device__ __forceinline__ void static_for(F&& f) // f(integral_constant<I>) ... f(integral_constant<N - 1>)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+template <int N> __device__ __forceinline__ void vm_wait() // at most N vector-memory operations still outstanding
+{
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void wg_barrier_raw() { asm volatile("s_barrier" ::: "memory"); }
 
 // A tile as it comes out of memory: the scale stays RAW (bf16 bits or f32 bits) until the tile is
 // consumed -- converting it in the load path would make the compiler wait for that load (and, as
@@ -952,6 +1071,9 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
 #ifndef MC_GEMV_LIN_TL
 #define MC_GEMV_LIN_TL 0 // tuning aid: per-wave s_memrealtime stamps (start, row staged, first 12 tiles, end) into `resp` (kernels whose epilogue ignores it)
 #endif
+#ifndef MC_GEMV_LIN_DECOUPLE
+#define MC_GEMV_LIN_DECOUPLE 0 // tuning ablation: the arithmetic runs on a synthesised packet BEFORE the loaded one is waited for (and only folded into a dummy)
+#endif
 #ifndef MC_GEMV_LIN_ACCS
 #define MC_GEMV_LIN_ACCS 1 // independent accumulators per row (the MFMAs of a packet dealt round-robin): 1 = one dependency chain
 #endif
@@ -974,7 +1096,34 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
         float4 lpr[PRO == PRO_PARTS ? NXP : 1][PRO == PRO_PARTS ? 2 * PARTS_R : 1];
         uint32_t lin_never;
         asm volatile("s_mov_b32 %0, 0" : "=s"(lin_never));
-        if constexpr (LEAN) {
+#ifndef MC_GEMV_LIN_LDSRING
+#define MC_GEMV_LIN_LDSRING 0 // 1: the weights through a DMA ring in LDS (below; launch with MC_LIN_LDS_RING=1).  Correct (tools/lin_check.py,
+#endif                        // the context tests) and, in the real kernels, SLOWER than the register ring: see the numbers at the block
+        // (its loads are all issued through the asm forms)
+#ifndef MC_LDSR_ONLY
+#define MC_LDSR_ONLY 0 // tuning / bisection: the DMA ring for rows of exactly this many KiB only
+#endif
+        constexpr bool LDSR = MC_GEMV_LIN_LDSRING && LEAN && LNCH >= 2 && (MC_LDSR_ONLY == 0 || MC_LDSR_ONLY == LNCH) && !MC_GEMV_LIN_TL && !MC_GEMV_LIN_STREAM && !MC_GEMV_LIN_NOLOAD && !MC_GEMV_LIN_DECOUPLE;
+        constexpr int NXL = PRO == PRO_PARTS ? NXP * 2 * PARTS_R : (PRO == PRO_RMSNORM ? 2 * NXP : NXP); // row loads per thread
+        lds_v4 axr[LDSR ? NXL : 1];
+        if constexpr (LDSR) {
+#pragma unroll
+            for (int i = 0; i < NXP; i++) {
+                const uint32_t p = tid + i * BD;
+                const uint32_t pc = (RAGGED && i == NXP - 1) ? min(p, NPK - 1) : p;
+                if constexpr (PRO == PRO_PARTS) {
+#pragma unroll
+                    for (int r = 0; r < PARTS_R; r++) {
+                        const char* pb_r = static_cast<const char*>(xp) + (size_t)r * in * 4; // wave-uniform
+                        axr[(i * PARTS_R + r) * 2] = gload128(pb_r, pc * 32);
+                        axr[(i * PARTS_R + r) * 2 + 1] = gload128(pb_r, pc * 32 + 16);
+                    }
+                } else {
+                    axr[i] = gload128(xp, pc * 16);
+                    if constexpr (PRO == PRO_RMSNORM) axr[NXP + i] = gload128(normp, pc * 16);
+                }
+            }
+        } else if constexpr (LEAN) {
             const uint4* xg = static_cast<const uint4*>(xp);
             const uint4* ng = static_cast<const uint4*>(normp);
 #pragma unroll
@@ -1069,9 +1218,252 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
             // them is a flat_load, which counts on both wait counters
             eo_q = *static_cast<const qkv_epilogue*>(resp);
             const __attribute__((address_space(1))) int32_t* stp = (const __attribute__((address_space(1))) int32_t*)eo_q.state;
-            eo_slot = (uint32_t)stp[3];
-            eo_rrow = (uint32_t)stp[6];
+            if constexpr (LDSR) {
+                eo_slot = gload32v(reinterpret_cast<const char*>(eo_q.state) + 12);
+                eo_rrow = gload32v(reinterpret_cast<const char*>(eo_q.state) + 24);
+            } else {
+                eo_slot = (uint32_t)stp[3];
+                eo_rrow = (uint32_t)stp[6];
+            }
             if (lin_never) asm volatile("" ::"s"(eo_slot), "s"(eo_rrow), "s"(eo_q.H), "s"(eo_q.KV), "s"(eo_q.hd), "s"(eo_q.max_seq));
+        }
+
+#ifndef MC_GEMV_LDS_INFLIGHT
+#define MC_GEMV_LDS_INFLIGHT 4
+#endif
+        // ==================================================================================
+        // The wave's weights through its OWN ring in LDS, filled by DMA (global_load_lds, 1 KiB per instruction).
+        // With a register ring a slot can be refilled only when its packet has been multiplied, so a wave computes with
+        // less in flight than its ring holds and every load has (period - one packet's arithmetic) to come back; a DMA
+        // needs no register: packet q + D is requested the moment packet q has been READ out of LDS, D stay in flight
+        // whatever the arithmetic does, and NS - D landed packets absorb the jitter.  tools/overlap_lab (58.7 MB, the real
+        // mac4d arithmetic, launch boundary included): register ring of 2 / 4 / 7 KiB 15.1 / 13.5 / 13.1 us, LDS ring of
+        // 7 KiB with 4 in flight 11.3 us (streaming alone: 10.4 and 9.8).
+        // IN THE REAL KERNELS it did not carry over (same box, per launch): QKV 6.9 -> 7.6 us, w1|w3 14.9 -> 15.8, Wo 5.1 -> 5.1,
+        // w2 10.1 -> 9.9; 3 or 4 DMAs in flight the same; refills pinned in front of the arithmetic 16.4.  What the lab kernel
+        // does not have is per pair: the scale reads, two wave reductions, the parked sums -- and a prologue.  Kept, OFF by
+        // default (MC_GEMV_LIN_LDSRING), for the next attempt at the loop's overlap.
+        // ==================================================================================
+        if constexpr (LDSR) {
+            constexpr int PP = 2 * LNCH;                 // packets (KiB) per row pair
+            constexpr int NS = PP % 7 == 0 ? 7 : 8;      // ring slots per wave (decoder.cc sizes the LDS: lin_lds_slots)
+            constexpr int DD = MC_GEMV_LDS_INFLIGHT;     // DMAs in flight per wave
+            static_assert(DD < NS && DD <= PP && (NS % PP == 0 || PP % NS == 0), "ring geometry");
+            constexpr int UL = NS > PP ? NS / PP : 1;    // pairs per unrolled iteration (slots stay static)
+            constexpr bool XREG = LNCH <= 2;
+            const uint32_t xs_a = lds_addr(xs), red_a = lds_addr(red);
+            const uint32_t park_a = red_a + 128 + wave * 512;                       // 64 pairs x (a, b) per wave
+            char* ring = smem + (size_t)nchunks * CHUNK_LDS + 128 + LWAVES * 512 + wave * (NS * 1024);
+            const uint32_t ring_a = lds_addr(ring) + lane16;
+            // stream packet (pair pr, tile t) -> global address; dead packets read one broadcast line at the buffer base
+            auto dma = [&](uint32_t pr, int t, int slot, bool live) {
+                const uint64_t rb = ((uint64_t)pr * 2 + (uint64_t)(t / LNCH)) * rowb + (uint64_t)(t % LNCH) * 1024;
+                const uint32_t lm = 0u - (uint32_t)live;
+                const char* a = wbase + (rb & (((uint64_t)lm << 32) | lm)) + (lane16 & lm);
+                typedef const void __attribute__((address_space(1))) gvoid_t;
+                typedef __attribute__((address_space(3))) void lvoid_t;
+                __builtin_amdgcn_global_load_lds((gvoid_t*)a, (lvoid_t*)(ring + slot * 1024), 16, 0, MC_GEMV_LIN_NT ? 2 : 0);
+            };
+            // The scales travel by DMA as well, 4 bytes per lane: a register that a load is still writing must not live across
+            // the loop's entry or back edge (hipcc copies such values there -- v_mov of a register whose load has not
+            // landed: garbage scales in the first pair of half the waves).  Per pair: the dword (rows a, b) of every scale
+            // group once, group gi = lane + 64 j -> LDS slot[j][lane]; read back at group (2048 c + 32 lane) / group.
+            constexpr int NSC = (LNCH + 3) / 4; // DMAs per pair: at most 16 LNCH groups (groups of >= 128 weights)
+            constexpr int SCB = NSC * 256;      // bytes per slot; two slots per wave: this pair's and the next one's
+            char* scr = smem + (size_t)nchunks * CHUNK_LDS + 128 + LWAVES * 512 + LWAVES * (NS * 1024) + wave * (2 * SCB);
+            const uint32_t scr_a = lds_addr(scr);
+            auto sdma = [&](uint32_t pr, uint32_t slot, bool live) {
+                const uint64_t ub = (((uint64_t)(pr >> 1) * ngroups) * 4 + (pr & 1u) * 2) * 2;
+                const uint32_t lm = 0u - (uint32_t)live;
+                const char* a = sbase + (ub & (((uint64_t)lm << 32) | lm));
+                typedef const void __attribute__((address_space(1))) gvoid_t;
+                typedef __attribute__((address_space(3))) void lvoid_t;
+#pragma unroll
+                for (int j = 0; j < NSC; j++) {
+                    const uint32_t gi = min(lane + 64u * j, ngroups - 1);
+                    __builtin_amdgcn_global_load_lds((gvoid_t*)(a + ((gi * 8u) & lm)), (lvoid_t*)(scr + slot * SCB + j * 256), 4, 0, 0);
+                }
+            };
+            uint32_t goff[LNCH]; // LDS byte offset of the lane's scale group per chunk
+#pragma unroll
+            for (int c = 0; c < LNCH; c++) goff[c] = (group ? ((2048u * c + 32u * lane) >> glog) : 0u) * 4u;
+            if (MC_GEMV_XBAR) wg_barrier_raw();
+            sdma(pb, 0, pb < pe);
+#pragma unroll
+            for (int j = 0; j < DD; j++) dma(pb + j / PP, j % PP, j % NS, pb + j / PP < pe);
+            // ---- the row into LDS (build-time geometry, see LEAN above), every LDS access through the asm forms.
+            // Younger than the row's requests: at least the NSC scale DMAs and the DD weight DMAs (and the early epilogue
+            // operands: waiting for two or three of those as well costs nothing here)
+#pragma unroll
+            for (int i = 0; i < NXL; i++) vm_wait<NSC + DD>(axr[i]);
+            if (EPI == EPI_QKV_ROPE) {
+                vm_wait<NSC + DD>(eo_slot);
+                vm_wait<NSC + DD>(eo_rrow);
+            }
+            auto live = [&](int i) { return !(RAGGED && i == NXP - 1) || tid + i * BD < NPK; };
+            uint4 (&xr)[NXP] = lxr;
+#pragma unroll
+            for (int i = 0; i < NXP; i++) {
+                if constexpr (PRO != PRO_PARTS) xr[i] = make_uint4(axr[i].x, axr[i].y, axr[i].z, axr[i].w);
+                if constexpr (PRO == PRO_RMSNORM) lnr[i] = make_uint4(axr[NXP + i].x, axr[NXP + i].y, axr[NXP + i].z, axr[NXP + i].w);
+            }
+            if constexpr (PRO == PRO_PARTS) {
+#pragma unroll
+                for (int i = 0; i < NXP; i++) {
+                    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int r = 0; r < PARTS_R; r++) { // ranges in order, as mc_attn_pv_reduce_T adds them
+                        const lds_v4 lo = axr[(i * PARTS_R + r) * 2], hi = axr[(i * PARTS_R + r) * 2 + 1];
+                        a[0] += asf(lo.x); a[1] += asf(lo.y); a[2] += asf(lo.z); a[3] += asf(lo.w);
+                        a[4] += asf(hi.x); a[5] += asf(hi.y); a[6] += asf(hi.z); a[7] += asf(hi.w);
+                    }
+                    xr[i] = make_uint4(pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]), pack_bf16x2(a[4], a[5]), pack_bf16x2(a[6], a[7]));
+                }
+            }
+            if constexpr (PRO == PRO_RMSNORM) {
+                float ss = 0.0f;
+#pragma unroll
+                for (int i = 0; i < NXP; i++) {
+                    const uint32_t vv[4] = {xr[i].x, xr[i].y, xr[i].z, xr[i].w};
+                    float s1 = 0.0f;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const float a = asf(vv[e] << 16), b = asf(vv[e] & 0xFFFF0000u);
+                        s1 += a * a;
+                        s1 += b * b;
+                    }
+                    ss += live(i) ? s1 : 0.0f;
+                }
+                const float wsum_ = wave_sum_dpp(ss);
+                if (lane == 0) lds_wr32(red_a + wave * 4, __float_as_uint(wsum_));
+                lds_wait();
+                wg_barrier_raw();
+                lds_v4 r0 = lds_rd128<0>(red_a), r1 = lds_rd128<16>(red_a);
+                lds_wait(r0);
+                lds_wait(r1);
+                const uint32_t rr[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+                static_assert(LWAVES <= 8, "the eight-wave reduction scratch");
+                float tot = 0.0f;
+#pragma unroll
+                for (int i = 0; i < LWAVES; i++) tot += asf(rr[i]);
+                const float inv = 1.0f / sqrtf(tot / (float)in + eps);
+#pragma unroll
+                for (int i = 0; i < NXP; i++) {
+                    const uint32_t vv[4] = {xr[i].x, xr[i].y, xr[i].z, xr[i].w};
+                    const uint32_t ww[4] = {lnr[i].x, lnr[i].y, lnr[i].z, lnr[i].w};
+                    uint32_t o[4];
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const float a = (mu + asf(ww[e] << 16)) * asf(vv[e] << 16) * inv;
+                        const float b = (mu + asf(ww[e] & 0xFFFF0000u)) * asf(vv[e] & 0xFFFF0000u) * inv;
+                        o[e] = pack_bf16x2(a, b);
+                    }
+                    xr[i] = make_uint4(o[0], o[1], o[2], o[3]);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NXP; i++)
+                if (live(i)) lds_wr128(xs_a + xpk(tid + i * BD) * 16, xr[i]);
+            lds_wait();
+            wg_barrier_raw();
+            if (EPI == EPI_QKV_ROPE) {
+                typedef const __attribute__((address_space(1))) float* gfloat_p;
+                const uint32_t hd = eo_q.hd, row = 2 * eo_pair;
+                const uint32_t j = row < (eo_q.H + eo_q.KV) * hd ? (row % hd) / 2 : 0u;
+                eo_c = ((gfloat_p)eo_q.fcos)[(size_t)eo_rrow * (hd / 2) + j];
+                eo_s = ((gfloat_p)eo_q.fsin)[(size_t)eo_rrow * (hd / 2) + j];
+                if (lin_never) asm volatile("" ::"v"(eo_c), "v"(eo_s));
+            }
+            const uint32_t lane_tr = (((lane >> 4) * 4 + (lane & 3)) * 17 + ((lane >> 2) & 3) * 4) * 16;
+            const uint32_t m4d_mx = (lane & 3) == 0 ? 0x0000FFFFu : ((lane & 3) == 1 ? 0xFFFF0000u : 0u);
+            const uint32_t m4d_my = (lane & 3) == 2 ? 0x0000FFFFu : ((lane & 3) == 3 ? 0xFFFF0000u : 0u);
+            const uint32_t xt_a = xs_a + lane_tr;
+            auto xrd = [&](lds_v2 (&x)[8], auto cc) {
+                constexpr int C0 = decltype(cc)::value * (int)CHUNK_LDS;
+                x[0] = lds_rd64_tr16<C0 + 0>(xt_a);  x[1] = lds_rd64_tr16<C0 + 8>(xt_a);
+                x[2] = lds_rd64_tr16<C0 + 16>(xt_a); x[3] = lds_rd64_tr16<C0 + 24>(xt_a);
+                x[4] = lds_rd64_tr16<C0 + 32>(xt_a); x[5] = lds_rd64_tr16<C0 + 40>(xt_a);
+                x[6] = lds_rd64_tr16<C0 + 48>(xt_a); x[7] = lds_rd64_tr16<C0 + 56>(xt_a);
+            };
+            lds_v2 xrg[XREG ? LNCH : 1][8];
+            auto as_x = [](const lds_v2 (&x)[8]) -> const uint2 (&)[8] { return reinterpret_cast<const uint2 (&)[8]>(x); };
+            if constexpr (XREG) {
+                xrd(xrg[0], std::integral_constant<int, 0>{});
+                lds_wait(xrg[0]);
+                if constexpr (LNCH > 1) {
+                    xrd(xrg[LNCH > 1 ? 1 : 0], std::integral_constant<int, (LNCH > 1 ? 1 : 0)>{});
+                    lds_wait(xrg[LNCH > 1 ? 1 : 0]);
+                }
+            }
+            uint32_t parked = 0, park_first = pb;
+            auto flush = [&]() {
+                lds_v2 v = lds_rd64<0>(park_a + lane * 8); // (a wave's LDS operations complete in order: its own stores are in)
+                lds_wait(v);
+                if (lane < parked) finish_pair(park_first + lane, asf(v.x), asf(v.y), park_first == pb);
+                park_first += parked;
+                parked = 0;
+            };
+            constexpr int NA = MC_GEMV_LIN_ACCS;
+            mf_f4 laccs[NA];
+#pragma unroll
+            for (int a = 0; a < NA; a++) laccs[a] = mf_f4{0, 0, 0, 0};
+            auto pair_l = [&](auto slot0, uint32_t pr) {
+                constexpr int SLOT0 = decltype(slot0)::value;
+                float ra = 0.f, rb = 0.f;
+                const uint32_t sc_cur = scr_a + ((pr - pb) & 1u) * SCB;
+                static_for<0, PP>([&](auto tc) {
+                    {
+                        constexpr int t = decltype(tc)::value, r = t / LNCH, c = t % LNCH, slot = (SLOT0 + t) % NS;
+                        // younger than the DMA of this packet: D - 1 weight DMAs, and the scale DMAs of step 0 when it went out before them
+                        vm_wait<DD - 1 + (t >= 1 && t < DD ? NSC : 0)>();
+                        lds_v4 wv = lds_rd128<slot * 1024>(ring_a);
+                        uint32_t raw = lds_rd32(sc_cur + goff[c]); // (this pair's scales went out before its first packet: they are in)
+                        if constexpr (t == 0) sdma(pr + 1, ((pr - pb) & 1u) ^ 1u, pr + 1 < pe);
+                        lds_v2 x[8];
+                        if constexpr (!XREG) xrd(x, std::integral_constant<int, c>{});
+                        lds_wait(wv); // (covers the scale and the activation reads too: one counter)
+                        lds_wait(raw);
+                        if constexpr (!XREG) lds_wait(x);
+                        const uint4 w = make_uint4(wv.x, wv.y, wv.z, wv.w);
+                        dma(pr + (t + DD) / PP, (t + DD) % PP, (SLOT0 + t + DD) % NS, pr + (t + DD) / PP < pe);
+                        // (pinning the refill in front of the arithmetic and the steps apart with scheduling barriers was
+                        //  measured SLOWER: w1|w3 15.6 -> 16.4 us; left to hipcc, the tail of a packet's arithmetic covers
+                        //  the LDS read of the next)
+                        const uint32_t s2 = r ? ((raw & 0xFFFF0000u) | (raw >> 16)) : ((raw << 16) | (raw & 0xFFFFu));
+                        if constexpr (XREG) mac4d_n<NA>(laccs, w, m4d_prepare(s2, m4d_mx, m4d_my), as_x(xrg[c]));
+                        else mac4d_n<NA>(laccs, w, m4d_prepare(s2, m4d_mx, m4d_my), as_x(x));
+                        if constexpr (c == LNCH - 1) {
+                            const uint32_t e = lane & 3;
+                            mf_f4 lacc = laccs[0];
+#pragma unroll
+                            for (int a = 1; a < NA; a++) lacc += laccs[a];
+                            const float mine = e == 0 ? lacc[0] : (e == 1 ? lacc[1] : (e == 2 ? lacc[2] : lacc[3]));
+                            const float rs = wave_sum_dpp(mine);
+                            if (r == 0) ra = rs;
+                            else rb = rs;
+#pragma unroll
+                            for (int a = 0; a < NA; a++) laccs[a] = mf_f4{0, 0, 0, 0};
+                        }
+                    }
+                });
+                if (lane == 0) lds_wr64(park_a + parked * 8, __float_as_uint(ra), __float_as_uint(rb));
+                parked++;
+                if (parked == 64) flush();
+            };
+            uint32_t pr = pb;
+            for (; pr + UL <= pe; pr += UL) {
+                pair_l(std::integral_constant<int, 0>{}, pr);
+                if constexpr (UL == 2) pair_l(std::integral_constant<int, PP % NS>{}, pr + 1);
+            }
+            if constexpr (UL == 2) {
+                if (pr < pe) pair_l(std::integral_constant<int, 0>{}, pr);
+            }
+            // the DMAs of packets past the range (one broadcast line each) before the ring's LDS is given back.
+            // (No asm load's result may be left unread: a value nobody reads is DEAD to hipcc, which then reuses the
+            //  destination register while the load is still in flight -- a late write into an address computation: a fault.)
+            vm_wait<0>();
+            flush();
+            return;
         }
         auto lin_prefetch = [&] {
             lscales(sa, pb, pb < pe);
@@ -1198,9 +1590,6 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
                     const int c = sidx * LTP + p;
                     const uint32_t raw = sa[c];
                     const uint32_t s2 = r ? ((raw & 0xFFFF0000u) | (raw >> 16)) : ((raw << 16) | (raw & 0xFFFFu));
-#ifndef MC_GEMV_LIN_DECOUPLE
-#define MC_GEMV_LIN_DECOUPLE 0 // tuning ablation: the arithmetic runs on a synthesised packet BEFORE the loaded one is waited for (and only folded into a dummy)
-#endif
                     if (MC_GEMV_LIN_DECOUPLE && XREG) {
                         const uint4 fake = make_uint4(lane * 0x01010101u + pr, (lane + pr) * 0x9E3779B9u, lane * 0x85EBCA6Bu + (uint32_t)(t * 0x11111111u),
                                                       (p + lane) * 0xC2B2AE35u + pr);

@@ -73,10 +73,10 @@ MC_GEMV_SET(mc_gemv_w_float, WF_T, F32, Q_EXACT)
 #define MC_LIN1_CFG 1, 1, 0
 #endif
 #ifndef MC_LIN2_CFG
-#define MC_LIN2_CFG 2, 2, 0
+#define MC_LIN2_CFG 2, 1, 0 // (tiles of one KiB: what the DMA ring moves; the register ring of the gemma3 prologue variants holds 4)
 #endif
 #ifndef MC_LIN4_CFG
-#define MC_LIN4_CFG 4, 4, 0
+#define MC_LIN4_CFG 4, 1, 4
 #endif
 #ifndef MC_LIN7_CFG
 #define MC_LIN7_CFG 7, 1, 2 // K = 14336: 28 KB of activations per workgroup come in first; two KiB per wave behind them (w2: 12.0 -> 9.9 us)
