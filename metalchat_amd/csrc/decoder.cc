@@ -529,7 +529,7 @@ struct mc_decoder {
         unsigned lds = (unsigned)((size_t)((L.in + chunk - 1) / chunk) * chunk * tb);
         if (m4d || lin) lds = lds / 16 * 17; // 16 bytes of padding per 256 for the transposed reads
         lds += 128;
-        if (lin) lds += waves * 512; // parked row sums: 64 pairs x 8 bytes per wave
+        if (lin) lds += waves * 512; // parked row sums: 64 pairs x 8 bytes per wave (gemv.h PARKB)
         // the waves' DMA rings (gemv.h LDSR: rows of two or more KiB, build-time prologue): 7 or 8 KiB per wave
         // + two slots of scale dwords per wave (256 bytes per 64 scale groups)
         if (lin && nch >= 2 && lin_lds_ring) lds += waves * (((2 * nch) % 7 == 0 ? 7u : 8u) * 1024u + 2u * ((nch + 3u) / 4u) * 256u); // (also granted to the variants that do not use it)

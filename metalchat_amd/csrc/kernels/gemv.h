@@ -1059,6 +1059,18 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
         constexpr int LR = LRING ? LRING : (2 * TPP * LTP <= MC_GEMV_LIN_INFLIGHT ? 2 * TPP : TPP);
         static_assert(LR % TPP == 0 || TPP % LR == 0, "the ring and a pair's tiles divide one another");
         constexpr bool XREG = LNCH <= 2;
+#ifndef MC_GEMV_LIN_RAWPARK
+#define MC_GEMV_LIN_RAWPARK 0
+#endif
+        // MC_GEMV_LIN_RAWPARK=1 (measured, off): a completed row's 64 per-lane partial sums PARKED as they are (one ds_write_b32
+        // per row, rows 65 dwords apart: lane L reading row 2 L meets no bank conflict) and added up at the end of the wave by
+        // the lane that finishes the pair -- 128 LDS reads and adds by 16 lanes per 16 pairs instead of two DPP chains + four
+        // readlanes per pair in the middle of the weight stream (the reductions cost 1.0 us of a 15 us w1|w3 launch).  The head
+        // (31 pairs per wave) gains 4 us, every layer kernel LOSES 1 us: with 1 - 7 pairs per wave the serial adds sit at the
+        // end of the launch, where nothing hides them (and the sequential sum is a little less accurate than the tree:
+        // the 70B-width parity test then sits at its bound).
+        constexpr int PARKP = 16;                                               // pairs per flush
+        constexpr uint32_t PARKB = MC_GEMV_LIN_RAWPARK ? PARKP * 2 * 65 * 4 : 512; // bytes of parking space per wave (decoder.cc: lin_park_bytes)
 #ifndef MC_GEMV_LIN_NT
 #define MC_GEMV_LIN_NT 1
 #endif
@@ -1246,14 +1258,23 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
         // ==================================================================================
         if constexpr (LDSR) {
             constexpr int PP = 2 * LNCH;                 // packets (KiB) per row pair
-            constexpr int NS = PP % 7 == 0 ? 7 : 8;      // ring slots per wave (decoder.cc sizes the LDS: lin_lds_slots)
+#ifndef MC_LDSR_NS
+#define MC_LDSR_NS 0 // tuning: ring slots per wave (the LDS the host grants is sized for 7 or 8)
+#endif
+#ifndef MC_LDSR_NOSCALE
+#define MC_LDSR_NOSCALE 0 // tuning ablation: constant scale, no scale reads
+#endif
+#ifndef MC_LDSR_NOREDUCE
+#define MC_LDSR_NOREDUCE 0 // tuning ablation: no wave reductions / parked sums (results wrong)
+#endif
+            constexpr int NS = MC_LDSR_NS ? MC_LDSR_NS : (PP % 7 == 0 ? 7 : 8); // ring slots per wave (decoder.cc sizes the LDS)
             constexpr int DD = MC_GEMV_LDS_INFLIGHT;     // DMAs in flight per wave
             static_assert(DD < NS && DD <= PP && (NS % PP == 0 || PP % NS == 0), "ring geometry");
             constexpr int UL = NS > PP ? NS / PP : 1;    // pairs per unrolled iteration (slots stay static)
             constexpr bool XREG = LNCH <= 2;
             const uint32_t xs_a = lds_addr(xs), red_a = lds_addr(red);
-            const uint32_t park_a = red_a + 128 + wave * 512;                       // 64 pairs x (a, b) per wave
-            char* ring = smem + (size_t)nchunks * CHUNK_LDS + 128 + LWAVES * 512 + wave * (NS * 1024);
+            const uint32_t park_a = red_a + 128 + wave * PARKB;                     // 64 pairs x (a, b) per wave
+            char* ring = smem + (size_t)nchunks * CHUNK_LDS + 128 + LWAVES * PARKB + wave * (NS * 1024);
             const uint32_t ring_a = lds_addr(ring) + lane16;
             // stream packet (pair pr, tile t) -> global address; dead packets read one broadcast line at the buffer base
             auto dma = [&](uint32_t pr, int t, int slot, bool live) {
@@ -1270,7 +1291,7 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
             // group once, group gi = lane + 64 j -> LDS slot[j][lane]; read back at group (2048 c + 32 lane) / group.
             constexpr int NSC = (LNCH + 3) / 4; // DMAs per pair: at most 16 LNCH groups (groups of >= 128 weights)
             constexpr int SCB = NSC * 256;      // bytes per slot; two slots per wave: this pair's and the next one's
-            char* scr = smem + (size_t)nchunks * CHUNK_LDS + 128 + LWAVES * 512 + LWAVES * (NS * 1024) + wave * (2 * SCB);
+            char* scr = smem + (size_t)nchunks * CHUNK_LDS + 128 + LWAVES * PARKB + LWAVES * (NS * 1024) + wave * (2 * SCB);
             const uint32_t scr_a = lds_addr(scr);
             auto sdma = [&](uint32_t pr, uint32_t slot, bool live) {
                 const uint64_t ub = (((uint64_t)(pr >> 1) * ngroups) * 4 + (pr & 1u) * 2) * 2;
@@ -1417,12 +1438,12 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
                         // younger than the DMA of this packet: D - 1 weight DMAs, and the scale DMAs of step 0 when it went out before them
                         vm_wait<DD - 1 + (t >= 1 && t < DD ? NSC : 0)>();
                         lds_v4 wv = lds_rd128<slot * 1024>(ring_a);
-                        uint32_t raw = lds_rd32(sc_cur + goff[c]); // (this pair's scales went out before its first packet: they are in)
+                        uint32_t raw = MC_LDSR_NOSCALE ? 0x3C003C00u : lds_rd32(sc_cur + goff[c]); // (this pair's scales went out before its first packet: they are in)
                         if constexpr (t == 0) sdma(pr + 1, ((pr - pb) & 1u) ^ 1u, pr + 1 < pe);
                         lds_v2 x[8];
                         if constexpr (!XREG) xrd(x, std::integral_constant<int, c>{});
                         lds_wait(wv); // (covers the scale and the activation reads too: one counter)
-                        lds_wait(raw);
+                        if (!MC_LDSR_NOSCALE) lds_wait(raw);
                         if constexpr (!XREG) lds_wait(x);
                         const uint4 w = make_uint4(wv.x, wv.y, wv.z, wv.w);
                         dma(pr + (t + DD) / PP, (t + DD) % PP, (SLOT0 + t + DD) % NS, pr + (t + DD) / PP < pe);
@@ -1432,7 +1453,7 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
                         const uint32_t s2 = r ? ((raw & 0xFFFF0000u) | (raw >> 16)) : ((raw << 16) | (raw & 0xFFFFu));
                         if constexpr (XREG) mac4d_n<NA>(laccs, w, m4d_prepare(s2, m4d_mx, m4d_my), as_x(xrg[c]));
                         else mac4d_n<NA>(laccs, w, m4d_prepare(s2, m4d_mx, m4d_my), as_x(x));
-                        if constexpr (c == LNCH - 1) {
+                        if constexpr (c == LNCH - 1 && !MC_LDSR_NOREDUCE) {
                             const uint32_t e = lane & 3;
                             mf_f4 lacc = laccs[0];
 #pragma unroll
@@ -1446,6 +1467,7 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
                         }
                     }
                 });
+                if (MC_LDSR_NOREDUCE) ra = laccs[0][0], rb = laccs[0][1];
                 if (lane == 0) lds_wr64(park_a + parked * 8, __float_as_uint(ra), __float_as_uint(rb));
                 parked++;
                 if (parked == 64) flush();
@@ -1558,14 +1580,27 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
 #pragma unroll
             for (int c = 0; c < LNCH; c++) xload(xr[c], c);
         }
-        // parked row sums: 64 pairs x (a, b) per wave, behind the reduction scratch
-        float2* park = reinterpret_cast<float2*>(red + 32) + wave * 64;
+        // parked row sums, behind the reduction scratch (LWAVES == 0: the kernel may run with any workgroup size -- 512 bytes per wave)
+        constexpr bool RAWPARK = MC_GEMV_LIN_RAWPARK && LWAVES > 0 && !MC_GEMV_LIN_STREAM;
+        float2* park = reinterpret_cast<float2*>(reinterpret_cast<char*>(red + 32) + wave * (LWAVES ? PARKB : 512u));
+        float* praw = reinterpret_cast<float*>(park);
         uint32_t parked = 0, park_first = pb;
         auto flush = [&]() {
             // one lane per parked pair (the LDS operations of a wave complete in order: no barrier needed)
             if (lane < parked) {
-                const float2 v = park[lane];
-                finish_pair(park_first + lane, v.x, v.y, park_first == pb);
+                if constexpr (RAWPARK) {
+                    const float* ra_p = praw + (2 * lane) * 65;
+                    float a = 0.0f, b = 0.0f;
+#pragma unroll 16
+                    for (int l = 0; l < 64; l++) {
+                        a += ra_p[l];
+                        b += ra_p[65 + l];
+                    }
+                    finish_pair(park_first + lane, a, b, park_first == pb);
+                } else {
+                    const float2 v = park[lane];
+                    finish_pair(park_first + lane, v.x, v.y, park_first == pb);
+                }
             }
             park_first += parked;
             parked = 0;
@@ -1636,16 +1671,20 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
 #pragma unroll
                     for (int a = 1; a < NA; a++) lacc += laccs[a];
                     const float mine = e == 0 ? lacc[0] : (e == 1 ? lacc[1] : (e == 2 ? lacc[2] : lacc[3]));
-                    const float rs = wave_sum_dpp(MC_GEMV_LIN_STREAM ? lacc[0] : mine);
-                    if (r == 0) ra = rs;
-                    else rb = rs;
+                    if constexpr (RAWPARK) {
+                        praw[(2 * parked + r) * 65 + lane] = mine;
+                    } else {
+                        const float rs = wave_sum_dpp(MC_GEMV_LIN_STREAM ? lacc[0] : mine);
+                        if (r == 0) ra = rs;
+                        else rb = rs;
+                    }
 #pragma unroll
                     for (int a = 0; a < NA; a++) laccs[a] = mf_f4{0, 0, 0, 0};
                 }
             }
-            if (lane == 0) park[parked] = make_float2(ra, rb);
+            if (!RAWPARK && lane == 0) park[parked] = make_float2(ra, rb);
             parked++;
-            if (parked == 64) flush();
+            if (parked == (RAWPARK ? (uint32_t)PARKP : 64u)) flush();
 #pragma unroll
             for (int c = 0; c < LNCH; c++) sa[c] = sb[c];
         };
