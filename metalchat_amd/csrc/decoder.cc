@@ -245,6 +245,7 @@ struct mc_decoder {
     int gemv_block = 256;
     int gemv_wgs_per_cu = 2;
     bool gemv_lin = true;        // MC_GEMV_LIN=0: classic kernels everywhere (A/B)
+    bool gemv_ling = true;       // MC_GEMV_LING=0: int8 / bfloat weights on the classic kernels (A/B)
     bool lin_lds_ring = false;   // MC_LIN_LDS_RING=1 for code objects built with -DMC_GEMV_LIN_LDSRING=1 (they need the rings' LDS)
     bool pv_fold_on = true;      // MC_PV_FOLD=0: P.V ranges reduced by their own launch (A/B, parity)
     int lin_waves = 8;           // MC_LIN_WAVES: tuning builds of the linear-order kernels with another workgroup size
@@ -462,13 +463,29 @@ struct mc_decoder {
         const int nch = L.in % 2048 == 0 ? L.in / 2048 : 0;
         return gemv_lin && m4d_ok && L.out % 4 == 0 && (nch == 1 || nch == 2 || nch == 4 || nch == 7 || nch == 14);
     }
+    // ... or the linear-order kernels of the VALU-dequantising formats (gemv.h LGEN): int8 / plain bfloat weights on
+    // bfloat rows, rows of 4 (int8) or 4 / 8 / 11 / 16 (bfloat) whole KiB; returns that count, 0 = no
+    int
+    ling_kib(const linear_w& L) const
+    {
+        if (!gemv_lin || !gemv_ling || tb != 2 || dbg_variant || L.out % 4 != 0) return 0;
+        const size_t rb = row_bytes(L.fmt, L.in);
+        if (rb % 1024) return 0;
+        const int n = (int)(rb / 1024);
+        if (L.fmt == MC_WFMT_I8) {
+            const bool g_ok = L.group == 0 || (L.group % 16 == 0 && (L.group & (L.group - 1)) == 0);
+            return g_ok && n == 4 ? n : 0;
+        }
+        if (L.fmt == MC_WFMT_T) return (n == 4 || n == 8 || n == 11 || n == 16) ? n : 0;
+        return 0;
+    }
     // P.V over four ranges of cache slots (256 workgroups instead of 64: a CU takes in ~ 25 GB/s, and 64 of them need
     // ~ 4 us for the V cache of one layer at S = 2048) with the range sums added by the Wo GEMV's prologue (gemv.h
     // PRO_PARTS) instead of a reduce launch
     bool
     pv_fold(const linear_w& wo) const
     {
-        return pv_fold_on && lin_ok(wo) && !wo.lora_cols && cfg.max_seq_len <= 16384;
+        return pv_fold_on && (lin_ok(wo) || ling_kib(wo)) && !wo.lora_cols && cfg.max_seq_len <= 16384;
     }
 
     mc_status
@@ -501,7 +518,19 @@ struct mc_decoder {
         // linear-order main loop (gemv.h): rows of whole KiB (K a multiple of 2048: 1, 2, 4, 7 or 14 KiB), whole row groups
         const int nch = L.in % 2048 == 0 ? L.in / 2048 : 0;
         const bool lin = lin_ok(L);
-        if (pro == 3 && !lin) return fail(MC_ERR_RUNTIME, "gemv: the partial-sum prologue exists for the linear-order kernels only");
+        const int ling = lin || pro == 2 ? 0 : ling_kib(L);
+        if (pro == 3 && !lin && !ling) return fail(MC_ERR_RUNTIME, "gemv: the partial-sum prologue exists for the linear-order kernels only");
+        if (ling) {
+            name += "_ling" + std::to_string(ling);
+            block = 64u * (unsigned)lin_waves;
+            waves = (unsigned)lin_waves;
+            const unsigned cus = (unsigned)dev->prop.multiProcessorCount;
+            cap = cus * (gemv_block_env ? (unsigned)gemv_wgs_per_cu : 1u);
+            const unsigned np = (unsigned)L.out / 2;
+            wgs = (np + waves - 1) / waves;
+            if (wgs > cap) wgs = cap;
+            if (wgs > cus) wgs = wgs / cus * cus;
+        }
         if (lin) {
             name += "_lin" + std::to_string(nch);
             // ONE workgroup of eight waves per CU: the activation row is staged once per CU and, with the raw barrier
@@ -529,7 +558,7 @@ struct mc_decoder {
         unsigned lds = (unsigned)((size_t)((L.in + chunk - 1) / chunk) * chunk * tb);
         if (m4d || lin) lds = lds / 16 * 17; // 16 bytes of padding per 256 for the transposed reads
         lds += 128;
-        if (lin) lds += waves * 512; // parked row sums: 64 pairs x 8 bytes per wave (gemv.h PARKB)
+        if (lin || ling) lds += waves * 512; // parked row sums: 64 pairs x 8 bytes per wave (gemv.h PARKB)
         // the waves' DMA rings (gemv.h LDSR: rows of two or more KiB, build-time prologue): 7 or 8 KiB per wave
         // + two slots of scale dwords per wave (256 bytes per 64 scale groups)
         if (lin && nch >= 2 && lin_lds_ring) lds += waves * (((2 * nch) % 7 == 0 ? 7u : 8u) * 1024u + 2u * ((nch + 3u) / 4u) * 256u); // (also granted to the variants that do not use it)
@@ -1020,6 +1049,7 @@ mc_decoder_create(mc_device* dev, mc_library* lib, mc_queue* q, const mc_decoder
     if (const char* e = getenv("MC_GEMV_FULLGRID")) d->gemv_full_grid = atoi(e) != 0;
     if (const char* e = getenv("MC_GEMV_LIN")) d->gemv_lin = atoi(e) != 0;
     if (const char* e = getenv("MC_PV_FOLD")) d->pv_fold_on = atoi(e) != 0;
+    if (const char* e = getenv("MC_GEMV_LING")) d->gemv_ling = atoi(e) != 0;
     if (const char* e = getenv("MC_LIN_LDS_RING")) d->lin_lds_ring = atoi(e) != 0;
     if (const char* e = getenv("MC_LIN_WAVES")) d->lin_waves = std::max(1, std::min(16, atoi(e)));
     if (const char* e = getenv("MC_GEMMA_UNFUSED")) d->gemma_fuse = atoi(e) == 0;

@@ -592,7 +592,8 @@ template <int R> struct tile {
 // LNCH / LTP != 0 select the LINEAR-ORDER main loop (int4, bfloat, Q_M4D only; rows of LNCH whole KiB): see below.
 // LRING: ring slots in tiles (0: the MC_GEMV_LIN_INFLIGHT rule); LWAVES: waves of the workgroup when it is fixed at build time
 // (0: read blockDim -- a dependent load from the hidden kernel arguments before anything else can be addressed).
-template <int WF, typename T, int QM, int PRO, int EPI, int R, int LNCH = 0, int LTP = 0, int LRING = 0, int LWAVES = 0>
+// LGEN: the linear-order loop for the formats that dequantise on the VALU (int8, plain bfloat weights), rows of LGEN whole KiB.
+template <int WF, typename T, int QM, int PRO, int EPI, int R, int LNCH = 0, int LTP = 0, int LRING = 0, int LWAVES = 0, int LGEN = 0>
 __device__ __forceinline__ void
 body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __restrict__ xp,
      void* __restrict__ yp, const void* __restrict__ resp, const void* __restrict__ normp,
@@ -607,7 +608,7 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
     constexpr uint32_t CHUNK_BYTES = 64 * 16;    // = 1 KiB of packed weights
     static_assert(R == 4, "tiles are four rows deep (scale quads, paired epilogues)");
 
-    if (LNCH > 0) {
+    if (LNCH > 0 || LGEN > 0) {
         // every kernel argument in ONE round of scalar loads: left to itself hipcc loads them where they are first used --
         // three dependent kernarg round trips (scalar-cache misses, ~0.1-0.2 us each) before the row is even requested
         asm volatile("" ::"s"(wp), "s"(sp), "s"(xp), "s"(yp), "s"(resp), "s"(normp), "s"(out_rows), "s"(in), "s"(group), "s"(eps),
@@ -1043,6 +1044,215 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
     // Arithmetic is mac4d (exact, bit for bit the classic Q_M4D path per weight); only the order in which a
     // row's fp32 partial sums are added differs (per lane: chunk after chunk of one row).
     // ======================================================================================
+    // ======================================================================================
+    // LINEAR ORDER for the other weight formats (LGEN > 0: int8 and plain bfloat weights on bfloat rows).  The same
+    // organisation as the int4 kernels below -- one 8-wave workgroup per CU, every wave a contiguous span of row pairs swept
+    // in address order with non-temporal loads, a 4 KiB register ring refilled packet by packet, the row requested by the
+    // first instructions and staged with build-time geometry, row sums parked and finished once per wave -- around the
+    // classic per-packet arithmetic (mac<>: Wd = T(T(q) T(s)) per weight, fp32 accumulate).  These formats are memory-bound
+    // (no matrix-pipe dequantisation to hide), so what the int4 kernels gained from the organisation they gain in full.
+    // ======================================================================================
+    if constexpr (LGEN > 0) {
+        static_assert(T::bytes == 2 && LWAVES > 0 && PRO != PRO_POSTNORM && !M4, "generic linear order: bfloat rows, int8 / bfloat weights");
+        constexpr int PP = 2 * LGEN;                       // packets (KiB) per row pair
+        constexpr int RS = PP % 4 == 0 ? 4 : 2;            // ring slots (packets)
+        constexpr uint32_t NPK = 8u * KPL * LGEN, BD = 64u * LWAVES; // 16-byte packets of the row; threads
+        constexpr int NXP = (int)((NPK + BD - 1) / BD);
+        constexpr bool RAGGED = NPK % BD != 0;
+        constexpr bool XREG = LGEN * (KPL / 2) <= 64;      // the whole row in registers (KPL / 2 VGPRs per packet)
+        constexpr bool SCALED = WF != WF_T;
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        uint32_t never;
+        asm volatile("s_mov_b32 %0, 0" : "=s"(never));
+        // ---- the row first
+        uint4 gxr[NXP], gnr[PRO == PRO_RMSNORM ? NXP : 1];
+        float4 gpr[PRO == PRO_PARTS ? NXP : 1][PRO == PRO_PARTS ? 2 * PARTS_R : 1];
+        {
+            const uint4* xg = static_cast<const uint4*>(xp);
+            const uint4* ng = static_cast<const uint4*>(normp);
+#pragma unroll
+            for (int i = 0; i < NXP; i++) {
+                const uint32_t p = tid + i * BD;
+                const uint32_t pc = (RAGGED && i == NXP - 1) ? min(p, NPK - 1) : p;
+                if constexpr (PRO == PRO_PARTS) {
+                    const float4* pg = static_cast<const float4*>(xp);
+#pragma unroll
+                    for (int r = 0; r < PARTS_R; r++) {
+                        gpr[i][2 * r] = pg[(size_t)r * (in / 4) + 2 * pc];
+                        gpr[i][2 * r + 1] = pg[(size_t)r * (in / 4) + 2 * pc + 1];
+                    }
+                } else {
+                    gxr[i] = xg[pc];
+                }
+                if (PRO == PRO_RMSNORM) gnr[i] = ng[pc];
+            }
+            if (never) asm volatile("" ::"v"(PRO == PRO_PARTS ? __float_as_uint(gpr[0][0].x) : gxr[0].x));
+        }
+        // ---- the wave's range of row pairs
+        const uint32_t nw_total = gridDim.x * nwaves, gw = blockIdx.x * nwaves + wave;
+        const uint32_t NP = (out_rows + 1) / 2;
+        const uint32_t pq = NP / nw_total, prem = NP - pq * nw_total;
+        const uint32_t pb = gw * pq + min(gw, prem);
+        const uint32_t pe = pb + pq + (gw < prem ? 1u : 0u);
+        const char* sbase = static_cast<const char*>(sp);
+        const uint32_t eo_pair = min(pb + lane, NP - 1);
+        if (EPI == EPI_RESID) {
+            eo_res = reinterpret_cast<const uint32_t*>(resp)[eo_pair];
+            if (never) asm volatile("" ::"v"(eo_res));
+        }
+        if (EPI == EPI_QKV_ROPE) {
+            eo_q = *static_cast<const qkv_epilogue*>(resp);
+            const __attribute__((address_space(1))) int32_t* stp = (const __attribute__((address_space(1))) int32_t*)eo_q.state;
+            eo_slot = (uint32_t)stp[3];
+            eo_rrow = (uint32_t)stp[6];
+            if (never) asm volatile("" ::"s"(eo_slot), "s"(eo_rrow), "s"(eo_q.H), "s"(eo_q.KV), "s"(eo_q.hd), "s"(eo_q.max_seq));
+        }
+        // packet t of pair pr: row 2 pr + t / LGEN, KiB t % LGEN of it (dead packets: one broadcast line of the buffer base)
+        auto gload = [&](uint4& dst, uint32_t pr, int t, bool live) {
+            const uint64_t rb = ((uint64_t)pr * 2 + (uint64_t)(t / LGEN)) * rowb + (uint64_t)(t % LGEN) * 1024;
+            const uint32_t lm = 0u - (uint32_t)live;
+            const char* a = wbase + (rb & (((uint64_t)lm << 32) | lm));
+            const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a + (lane16 & lm)));
+            dst = make_uint4(v.x, v.y, v.z, v.w);
+        };
+        // scales of pair pr: per chunk the dword (rows a, b) of the lane's group; chunk c of the row = elements [CHUNK c, CHUNK (c + 1))
+        uint32_t gsa[SCALED ? LGEN : 1], gsb[SCALED ? LGEN : 1];
+        auto gscales = [&](uint32_t (&q)[SCALED ? LGEN : 1], uint32_t pr, bool live) {
+            if constexpr (SCALED) {
+                const uint64_t ub = (((uint64_t)(pr >> 1) * ngroups) * 4 + (pr & 1u) * 2) * 2;
+                const uint32_t lm = 0u - (uint32_t)live;
+                const char* a = sbase + (ub & (((uint64_t)lm << 32) | lm));
+#pragma unroll
+                for (int c = 0; c < LGEN; c++) {
+                    const uint32_t g = group ? ((CHUNK * c + KPL * lane) >> glog) : 0u;
+                    q[c] = *reinterpret_cast<const uint32_t*>(a + ((g * 8u) & lm));
+                }
+            }
+        };
+        uint4 gring[RS];
+        if (MC_GEMV_XBAR) asm volatile("s_barrier" ::: "memory");
+        gscales(gsa, pb, pb < pe);
+#pragma unroll
+        for (int j = 0; j < RS; j++) gload(gring[j], pb + j / PP, j % PP, pb + j / PP < pe);
+        // ---- the row into LDS (natural order: these formats read their 16-byte slices straight)
+        {
+            uint4* xl = reinterpret_cast<uint4*>(xs);
+            auto live = [&](int i) { return !(RAGGED && i == NXP - 1) || tid + i * BD < NPK; };
+            if constexpr (PRO == PRO_PARTS) {
+#pragma unroll
+                for (int i = 0; i < NXP; i++) {
+                    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int r = 0; r < PARTS_R; r++) {
+                        const float4 lo = gpr[i][2 * r], hi = gpr[i][2 * r + 1];
+                        a[0] += lo.x; a[1] += lo.y; a[2] += lo.z; a[3] += lo.w;
+                        a[4] += hi.x; a[5] += hi.y; a[6] += hi.z; a[7] += hi.w;
+                    }
+                    gxr[i] = make_uint4(pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]), pack_bf16x2(a[4], a[5]), pack_bf16x2(a[6], a[7]));
+                }
+            }
+            if constexpr (PRO == PRO_RMSNORM) {
+                float ss = 0.0f;
+#pragma unroll
+                for (int i = 0; i < NXP; i++) {
+                    const uint32_t vv[4] = {gxr[i].x, gxr[i].y, gxr[i].z, gxr[i].w};
+                    float s1 = 0.0f;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const float a = asf(vv[e] << 16), b = asf(vv[e] & 0xFFFF0000u);
+                        s1 += a * a;
+                        s1 += b * b;
+                    }
+                    ss += live(i) ? s1 : 0.0f;
+                }
+                const float wsum_ = wave_sum_dpp(ss);
+                if (lane == 0) red[wave] = wsum_;
+                __syncthreads();
+                float tot = 0.0f;
+#pragma unroll
+                for (uint32_t i = 0; i < (uint32_t)LWAVES; i++) tot += red[i];
+                const float inv = 1.0f / sqrtf(tot / (float)in + eps);
+#pragma unroll
+                for (int i = 0; i < NXP; i++) {
+                    const uint32_t vv[4] = {gxr[i].x, gxr[i].y, gxr[i].z, gxr[i].w};
+                    const uint32_t ww[4] = {gnr[i].x, gnr[i].y, gnr[i].z, gnr[i].w};
+                    uint32_t o[4];
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const float a = (mu + asf(ww[e] << 16)) * asf(vv[e] << 16) * inv;
+                        const float b = (mu + asf(ww[e] & 0xFFFF0000u)) * asf(vv[e] & 0xFFFF0000u) * inv;
+                        o[e] = pack_bf16x2(a, b);
+                    }
+                    gxr[i] = make_uint4(o[0], o[1], o[2], o[3]);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NXP; i++)
+                if (live(i)) xl[tid + i * BD] = gxr[i];
+        }
+        __syncthreads();
+        if (EPI == EPI_QKV_ROPE) {
+            typedef const __attribute__((address_space(1))) float* gfloat_p;
+            const uint32_t hd = eo_q.hd, row = 2 * eo_pair;
+            const uint32_t j = row < (eo_q.H + eo_q.KV) * hd ? (row % hd) / 2 : 0u;
+            eo_c = ((gfloat_p)eo_q.fcos)[(size_t)eo_rrow * (hd / 2) + j];
+            eo_s = ((gfloat_p)eo_q.fsin)[(size_t)eo_rrow * (hd / 2) + j];
+            if (never) asm volatile("" ::"v"(eo_c), "v"(eo_s));
+        }
+        const uint32_t lane_xb = lane * KPL * 2; // byte offset of the lane's slice inside a chunk of the row
+        xregs<T, KPL> gx[XREG ? LGEN : 1];
+        if constexpr (XREG) {
+#pragma unroll
+            for (int c = 0; c < LGEN; c++) gx[c].load(xs + (size_t)c * CHUNK * 2 + lane_xb, 0);
+        }
+        float2* park = reinterpret_cast<float2*>(red + 32) + wave * 64;
+        uint32_t parked = 0, park_first = pb;
+        auto flush = [&]() {
+            if (lane < parked) {
+                const float2 v = park[lane];
+                finish_pair(park_first + lane, v.x, v.y, park_first == pb);
+            }
+            park_first += parked;
+            parked = 0;
+        };
+        auto pair_g = [&](uint32_t pr) {
+            gscales(gsb, pr + 1, pr + 1 < pe);
+            float ra = 0.f, rb = 0.f, accf = 0.f;
+#pragma unroll
+            for (int t = 0; t < PP; t++) {
+                const int r = t / LGEN, c = t % LGEN, slot = t % RS;
+                float sc = 1.0f;
+                if constexpr (SCALED) sc = r ? asf(gsa[c] & 0xFFFF0000u) : asf(gsa[c] << 16);
+                if constexpr (XREG) {
+                    mac<Q_EXACT>(accf, gring[slot], sc, gx[c], 0.0f, static_cast<F*>(nullptr));
+                } else {
+                    xregs<T, KPL> x;
+                    x.load(xs + (size_t)c * CHUNK * 2 + lane_xb, 0);
+                    mac<Q_EXACT>(accf, gring[slot], sc, x, 0.0f, static_cast<F*>(nullptr));
+                }
+                if (t + RS < PP) gload(gring[slot], pr, t + RS, true);
+                else gload(gring[slot], pr + 1, t + RS - PP, pr + 1 < pe);
+                if (never) asm volatile("s_nop 0"); // ends the basic block: the refill stays behind its packet
+                if (c == LGEN - 1) {
+                    const float rs = wave_sum_dpp(accf);
+                    if (r == 0) ra = rs;
+                    else rb = rs;
+                    accf = 0.0f;
+                }
+            }
+            if (lane == 0) park[parked] = make_float2(ra, rb);
+            parked++;
+            if (parked == 64) flush();
+            if constexpr (SCALED) {
+#pragma unroll
+                for (int c = 0; c < LGEN; c++) gsa[c] = gsb[c];
+            }
+        };
+        static_assert(PP % RS == 0, "a pair is a whole number of ring turns");
+        for (uint32_t pr = pb; pr < pe; pr++) pair_g(pr);
+        flush();
+        return;
+    }
     if constexpr (LNCH > 0) {
         static_assert(WF == WF_I4 && T::bytes == 2 && M4D, "linear order: int4 weights, bfloat rows, Q_M4D");
         static_assert(LNCH % LTP == 0, "a row is a whole number of tiles");

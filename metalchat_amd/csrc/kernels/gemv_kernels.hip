@@ -90,6 +90,34 @@ MC_GEMV_LIN_SET(mc_gemv_i4_bfloat_lin4, MC_LIN4_CFG)   // K = 8192
 MC_GEMV_LIN_SET(mc_gemv_i4_bfloat_lin7, MC_LIN7_CFG)   // K = 14336
 MC_GEMV_LIN_SET(mc_gemv_i4_bfloat_lin14, MC_LIN14_CFG) // K = 28672
 
+// linear-order kernels of the VALU-dequantising formats (gemv.h LGEN): mc_gemv_{i8|w}_bfloat_ling{KiB per row}_p{PRO}_e{EPI}
+#define MC_GEMV_LING(NAME, WF, PRO, EPI, NCH)                                                     \
+    extern "C" __global__ void __launch_bounds__(64 * MC_LIN_WAVES)                              \
+    NAME(const void* w, const void* scales, const void* x, void* y, const void* res,             \
+         const void* norm_w, uint32_t out_rows, uint32_t in, uint32_t group, float eps, float mu, \
+         const void* lora_a, const void* lora_b, uint32_t lora_rank, float lora_scale)            \
+    {                                                                                             \
+        body<WF, BF, Q_EXACT, PRO, EPI, 4, 0, 0, 0, MC_LIN_WAVES, NCH>(                           \
+            w, scales, x, y, res, norm_w, out_rows, in, group, eps, mu, lora_a, lora_b, lora_rank, lora_scale); \
+    }
+#define MC_GEMV_LING_SET(PFX, WF, NCH)          \
+    MC_GEMV_LING(PFX##_p0_e0, WF, 0, 0, NCH)    \
+    MC_GEMV_LING(PFX##_p1_e0, WF, 1, 0, NCH)    \
+    MC_GEMV_LING(PFX##_p0_e1, WF, 0, 1, NCH)    \
+    MC_GEMV_LING(PFX##_p1_e2, WF, 1, 2, NCH)    \
+    MC_GEMV_LING(PFX##_p1_e3, WF, 1, 3, NCH)    \
+    MC_GEMV_LING(PFX##_p1_e4, WF, 1, 4, NCH)    \
+    MC_GEMV_LING(PFX##_p3_e0, WF, 3, 0, NCH)    \
+    MC_GEMV_LING(PFX##_p3_e1, WF, 3, 1, NCH)
+#if MC_LIN_WAVES
+MC_GEMV_LING_SET(mc_gemv_i8_bfloat_ling4, WF_I8, 4)   // K = 4096
+// (K = 14336 int8 rows: 14 x 8 VGPRs of activations do not fit in registers and the unrolled pair spills; the classic kernel is faster there: 13.3 vs 15.4 us)
+MC_GEMV_LING_SET(mc_gemv_w_bfloat_ling4, WF_T, 4)     // K = 2048
+MC_GEMV_LING_SET(mc_gemv_w_bfloat_ling8, WF_T, 8)     // K = 4096
+MC_GEMV_LING_SET(mc_gemv_w_bfloat_ling11, WF_T, 11)   // K = 5632
+MC_GEMV_LING_SET(mc_gemv_w_bfloat_ling16, WF_T, 16)   // K = 8192
+#endif
+
 // tuning ablations (not used by the product path): stream-only and compute-only variants
 MC_GEMV(mc_gemv_i4_bfloat_dbgstream_p1_e2, WF_I4, BF, Q_DBG_STREAM, 1, 2)
 MC_GEMV(mc_gemv_i4_bfloat_dbgnoload_p1_e2, WF_I4, BF, Q_DBG_NOLOAD, 1, 2)
