@@ -1,0 +1,59 @@
+"""Every kernel the decoder can ask the code object for exists in it (no GPU needed: the names are read out of the built
+metalchat.hsaco).  The host forms GEMV names from (format, dtype, arithmetic, linear-order row length, prologue, epilogue) in
+decoder.cc::gemv(); a combination it may form but gemv_kernels.hip does not instantiate would only fail on the GPU, for the
+one model shape that reaches it."""
+import itertools
+import os
+import subprocess
+
+import pytest
+
+import metalchat_amd
+from metalchat_amd import build as b
+
+READELF = ["/opt/rocm/lib/llvm/bin/llvm-readelf", "/usr/bin/readelf"]
+
+
+@pytest.fixture(scope="module")
+def symbols():
+    hsaco, _ = b.build_all()
+    tool = next((t for t in READELF if os.path.exists(t)), None)
+    if tool is None:
+        pytest.skip("no readelf available")
+    out = subprocess.check_output([tool, "--symbols", "--wide", hsaco], text=True)
+    return {line.split()[-1] for line in out.splitlines() if " FUNC " in line}
+
+
+# prologue / epilogue pairs run_layers(), run_head() and mc_decoder_time_gemv() launch (gemv_kernels.hip MC_GEMV_SET)
+PE = ["p0_e0", "p1_e0", "p0_e1", "p1_e2", "p1_e3", "p1_e4", "p2_e0", "p2_e3"]
+PE_FOLD = ["p3_e0", "p3_e1"]  # P.V range sums added by the Wo prologue: linear-order kernels only
+
+
+def test_classic_gemv_family_is_complete(symbols):
+    fams = ["i4_bfloat", "i4_bfloat_fast", "i4_bfloat_m4", "i4_bfloat_m4d", "i4_float", "i8_bfloat", "i8_float", "w_bfloat", "w_float"]
+    missing = [f"mc_gemv_{f}_{pe}" for f, pe in itertools.product(fams, PE) if f"mc_gemv_{f}_{pe}" not in symbols]
+    assert not missing, missing
+
+
+def test_linear_order_families_are_complete(symbols):
+    want = []
+    for nch in (1, 2, 4, 7, 14):  # decoder.cc lin_ok(): int4 rows of whole KiB
+        want += [f"mc_gemv_i4_bfloat_lin{nch}_{pe}" for pe in PE + PE_FOLD]
+    for nch in (4,):  # decoder.cc ling_kib(): int8
+        want += [f"mc_gemv_i8_bfloat_ling{nch}_{pe}" for pe in PE + PE_FOLD if not pe.startswith("p2")]
+    for nch in (4, 8, 11, 16):  # ... and plain bfloat weights
+        want += [f"mc_gemv_w_bfloat_ling{nch}_{pe}" for pe in PE + PE_FOLD if not pe.startswith("p2")]
+    missing = [n for n in want if n not in symbols]
+    assert not missing, missing
+
+
+def test_decode_and_reference_kernels_present(symbols):
+    for t in ("bfloat", "float"):
+        for k in ("mc_attn_scores", "mc_attn_pv", "mc_attn_pv_reduce", "mc_embed", "mc_embed_q8", "mc_argmax", "mc_rope_kv",
+                  "mc_rmsnorm_row", "mc_topk_candidates", "mc_sample"):
+            assert f"{k}_{t}" in symbols, f"{k}_{t}"
+    for k in ("mc_step_set", "mc_step_advance", "mc_step_rope", "mc_rope_table"):
+        assert k in symbols, k
+    # the reference's own kernel names (ABI part 1, kernel/kernel.h:30-90)
+    for k in ("rmsnorm_bfloat", "softmax_bfloat", "bmm_8_float", "hadamard_broadcast_bfloat_int8_t_float"):
+        assert k in symbols, k
