@@ -245,6 +245,7 @@ struct mc_decoder {
     int gemv_block = 256;
     int gemv_wgs_per_cu = 2;
     bool gemv_lin = true;        // MC_GEMV_LIN=0: classic kernels everywhere (A/B)
+    bool lin_ksplit = false;     // MC_LIN_KSPLIT=1: w2's K range cut between two waves (sixteen per workgroup): measured SLOWER (10.2 vs 8.8 us)
     bool gemv_ling = true;       // MC_GEMV_LING=0: int8 / bfloat weights on the classic kernels (A/B)
     bool lin_lds_ring = false;   // MC_LIN_LDS_RING=1 for code objects built with -DMC_GEMV_LIN_LDSRING=1 (they need the rings' LDS)
     bool pv_fold_on = true;      // MC_PV_FOLD=0: P.V ranges reduced by their own launch (A/B, parity)
@@ -518,6 +519,7 @@ struct mc_decoder {
         // linear-order main loop (gemv.h): rows of whole KiB (K a multiple of 2048: 1, 2, 4, 7 or 14 KiB), whole row groups
         const int nch = L.in % 2048 == 0 ? L.in / 2048 : 0;
         const bool lin = lin_ok(L);
+        bool ksplit = false;
         const int ling = lin || pro == 2 ? 0 : ling_kib(L);
         if (pro == 3 && !lin && !ling) return fail(MC_ERR_RUNTIME, "gemv: the partial-sum prologue exists for the linear-order kernels only");
         if (ling) {
@@ -547,6 +549,14 @@ struct mc_decoder {
             wgs = (np + waves - 1) / waves;
             if (wgs > cap) wgs = cap;
             if (wgs > cus) wgs = wgs / cus * cus;
+            // long rows with at most a pair per wave (w2: 2048 pairs for 2048 waves): sixteen waves per workgroup, the K range
+            // of a pair cut between two of them (gemv.h LKS) -- half the chain of dependent round trips per wave
+            if (lin_ksplit && (nch == 7 || nch == 14) && pro == 0 && (epi == 0 || epi == 1) && lin_waves == 8 &&
+                np <= 64u * waves * wgs && np <= 2u * waves * cus) {
+                name += "k2";
+                block = 1024;
+                ksplit = true;
+            }
         }
         else if (m4) name += m4d ? "_m4d" : "_m4";
         if (L.fmt == MC_WFMT_I4 && tb == 2 && dbg_variant && ((pro == 1 && epi == 2) || (pro == 0 && epi == 0)))
@@ -559,6 +569,7 @@ struct mc_decoder {
         if (m4d || lin) lds = lds / 16 * 17; // 16 bytes of padding per 256 for the transposed reads
         lds += 128;
         if (lin || ling) lds += waves * 512; // parked row sums: 64 pairs x 8 bytes per wave (gemv.h PARKB)
+        if (ksplit) lds += waves * 512 + 4352; // sixteen waves park; one chunk of zero activations behind the row
         // the waves' DMA rings (gemv.h LDSR: rows of two or more KiB, build-time prologue): 7 or 8 KiB per wave
         // + two slots of scale dwords per wave (256 bytes per 64 scale groups)
         if (lin && nch >= 2 && lin_lds_ring) lds += waves * (((2 * nch) % 7 == 0 ? 7u : 8u) * 1024u + 2u * ((nch + 3u) / 4u) * 256u); // (also granted to the variants that do not use it)
@@ -1050,6 +1061,7 @@ mc_decoder_create(mc_device* dev, mc_library* lib, mc_queue* q, const mc_decoder
     if (const char* e = getenv("MC_GEMV_LIN")) d->gemv_lin = atoi(e) != 0;
     if (const char* e = getenv("MC_PV_FOLD")) d->pv_fold_on = atoi(e) != 0;
     if (const char* e = getenv("MC_GEMV_LING")) d->gemv_ling = atoi(e) != 0;
+    if (const char* e = getenv("MC_LIN_KSPLIT")) d->lin_ksplit = atoi(e) != 0;
     if (const char* e = getenv("MC_LIN_LDS_RING")) d->lin_lds_ring = atoi(e) != 0;
     if (const char* e = getenv("MC_LIN_WAVES")) d->lin_waves = std::max(1, std::min(16, atoi(e)));
     if (const char* e = getenv("MC_GEMMA_UNFUSED")) d->gemma_fuse = atoi(e) == 0;

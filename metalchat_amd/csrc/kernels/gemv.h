@@ -593,7 +593,8 @@ template <int R> struct tile {
 // LRING: ring slots in tiles (0: the MC_GEMV_LIN_INFLIGHT rule); LWAVES: waves of the workgroup when it is fixed at build time
 // (0: read blockDim -- a dependent load from the hidden kernel arguments before anything else can be addressed).
 // LGEN: the linear-order loop for the formats that dequantise on the VALU (int8, plain bfloat weights), rows of LGEN whole KiB.
-template <int WF, typename T, int QM, int PRO, int EPI, int R, int LNCH = 0, int LTP = 0, int LRING = 0, int LWAVES = 0, int LGEN = 0>
+// LKS = 2 (linear-order int4, long rows, plain prologue): the K range of a row pair is cut between TWO waves.
+template <int WF, typename T, int QM, int PRO, int EPI, int R, int LNCH = 0, int LTP = 0, int LRING = 0, int LWAVES = 0, int LGEN = 0, int LKS = 1>
 __device__ __forceinline__ void
 body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __restrict__ xp,
      void* __restrict__ yp, const void* __restrict__ resp, const void* __restrict__ normp,
@@ -1065,7 +1066,8 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
         uint32_t never;
         asm volatile("s_mov_b32 %0, 0" : "=s"(never));
         // ---- the row first
-        uint4 gxr[NXP], gnr[PRO == PRO_RMSNORM ? NXP : 1];
+        typedef uint32_t rowv4 __attribute__((ext_vector_type(4))); // (not HIP's uint4 struct: see the int4 kernels' prologue)
+        rowv4 gxr[NXP], gnr[PRO == PRO_RMSNORM ? NXP : 1];
         float4 gpr[PRO == PRO_PARTS ? NXP : 1][PRO == PRO_PARTS ? 2 * PARTS_R : 1];
         {
             const uint4* xg = static_cast<const uint4*>(xp);
@@ -1082,9 +1084,9 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
                         gpr[i][2 * r + 1] = pg[(size_t)r * (in / 4) + 2 * pc + 1];
                     }
                 } else {
-                    gxr[i] = xg[pc];
+                    gxr[i] = reinterpret_cast<const rowv4*>(xg)[pc];
                 }
-                if (PRO == PRO_RMSNORM) gnr[i] = ng[pc];
+                if (PRO == PRO_RMSNORM) gnr[i] = reinterpret_cast<const rowv4*>(ng)[pc];
             }
             if (never) asm volatile("" ::"v"(PRO == PRO_PARTS ? __float_as_uint(gpr[0][0].x) : gxr[0].x));
         }
@@ -1136,7 +1138,7 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
         for (int j = 0; j < RS; j++) gload(gring[j], pb + j / PP, j % PP, pb + j / PP < pe);
         // ---- the row into LDS (natural order: these formats read their 16-byte slices straight)
         {
-            uint4* xl = reinterpret_cast<uint4*>(xs);
+            rowv4* xl = reinterpret_cast<rowv4*>(xs);
             auto live = [&](int i) { return !(RAGGED && i == NXP - 1) || tid + i * BD < NPK; };
             if constexpr (PRO == PRO_PARTS) {
 #pragma unroll
@@ -1148,7 +1150,7 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
                         a[0] += lo.x; a[1] += lo.y; a[2] += lo.z; a[3] += lo.w;
                         a[4] += hi.x; a[5] += hi.y; a[6] += hi.z; a[7] += hi.w;
                     }
-                    gxr[i] = make_uint4(pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]), pack_bf16x2(a[4], a[5]), pack_bf16x2(a[6], a[7]));
+                    gxr[i] = rowv4{pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]), pack_bf16x2(a[4], a[5]), pack_bf16x2(a[6], a[7])};
                 }
             }
             if constexpr (PRO == PRO_RMSNORM) {
@@ -1183,7 +1185,7 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
                         const float b = (mu + asf(ww[e] & 0xFFFF0000u)) * asf(vv[e] & 0xFFFF0000u) * inv;
                         o[e] = pack_bf16x2(a, b);
                     }
-                    gxr[i] = make_uint4(o[0], o[1], o[2], o[3]);
+                    gxr[i] = rowv4{o[0], o[1], o[2], o[3]};
                 }
             }
 #pragma unroll
@@ -1256,8 +1258,18 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
     if constexpr (LNCH > 0) {
         static_assert(WF == WF_I4 && T::bytes == 2 && M4D, "linear order: int4 weights, bfloat rows, Q_M4D");
         static_assert(LNCH % LTP == 0, "a row is a whole number of tiles");
-        constexpr int SUB = LNCH / LTP;       // tiles per row
-        constexpr int TPP = 2 * SUB;          // tiles per row pair
+        // K split (LKS = 2): a wave of the first half of the workgroup takes chunks [0, SUB) of its pairs' rows, its partner
+        // in the second half chunks [SUB, 2 SUB) -- the last of them past the row when LNCH is odd: a dead tile (one broadcast
+        // line of weights) against a chunk of ZERO activations appended to the row in LDS.  w2 of Llama-3-8B is 2048 row pairs
+        // for 2048 waves: ONE pair of 14 KiB per wave, fetched through a two-KiB ring (a deeper one is slower, see the ring
+        // note) = seven dependent round trips of ~ 0.7 us; with sixteen waves per CU a wave has half of that chain.
+        // MEASURED (parity-green, MC_LIN_KSPLIT=1): w2 10.2 us against 8.8 on the eight-wave kernel -- like every other
+        // sixteen-wave variant of this round, slower.  Off.
+        static_assert(LKS == 1 || (LKS == 2 && LTP == 1 && LWAVES % 2 == 0 && (PRO == PRO_NONE || PRO == PRO_PARTS)), "K split: one-KiB tiles, no norm prologue");
+        constexpr int SUB = LKS == 2 ? (LNCH + 1) / 2 : LNCH / LTP; // tiles per row (of this wave's share)
+        constexpr int TPP = 2 * SUB;                                // tiles per row pair
+        const uint32_t nwp = nwaves / LKS;                          // waves that own row pairs
+        const uint32_t khalf = LKS == 2 ? wave / nwp : 0u, cbase = khalf * SUB;
 #ifndef MC_GEMV_LIN_INFLIGHT
 #define MC_GEMV_LIN_INFLIGHT 4 // KiB in flight per wave: the ring holds two pairs when they fit, else one (A/B on MI355X, 8 waves per CU:
                                // 4 KiB 16.2 us, 8 KiB 17.5 us on the 60 MB w1|w3 matrix -- a CU keeps ~32 KiB in flight whatever is asked)
@@ -1269,6 +1281,7 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
         constexpr int LR = LRING ? LRING : (2 * TPP * LTP <= MC_GEMV_LIN_INFLIGHT ? 2 * TPP : TPP);
         static_assert(LR % TPP == 0 || TPP % LR == 0, "the ring and a pair's tiles divide one another");
         constexpr bool XREG = LNCH <= 2;
+        static_assert(LKS == 1 || !XREG, "K split: the row is read from LDS");
 #ifndef MC_GEMV_LIN_RAWPARK
 #define MC_GEMV_LIN_RAWPARK 0
 #endif
@@ -1314,7 +1327,11 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
         constexpr uint32_t NPK = 256u * LNCH, BD = LWAVES ? 64u * LWAVES : 64u;
         constexpr int NXP = LEAN ? (int)((NPK + BD - 1) / BD) : 1;
         constexpr bool RAGGED = NPK % BD != 0; // the last packet of a thread may not exist (lin7: 3.5 per thread, lin1: 0.5)
-        uint4 lxr[NXP], lnr[PRO == PRO_RMSNORM ? NXP : 1];
+        // (native vectors, not HIP's uint4 struct: a struct that is only copied global -> register -> LDS is recognised as a
+        //  memcpy, and with several packets per thread hipcc routed two of them through a PRIVATE-memory temporary: scratch
+        //  stores behind a vmcnt wait in the first instructions of the w2 kernel)
+        typedef uint32_t rowv4 __attribute__((ext_vector_type(4)));
+        rowv4 lxr[NXP], lnr[PRO == PRO_RMSNORM ? NXP : 1];
         float4 lpr[PRO == PRO_PARTS ? NXP : 1][PRO == PRO_PARTS ? 2 * PARTS_R : 1];
         uint32_t lin_never;
         asm volatile("s_mov_b32 %0, 0" : "=s"(lin_never));
@@ -1361,13 +1378,13 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
                         lpr[i][2 * r + 1] = pg[(size_t)r * (in / 4) + 2 * pc + 1];
                     }
                 } else {
-                    lxr[i] = xg[pc];
+                    lxr[i] = reinterpret_cast<const rowv4*>(xg)[pc];
                 }
-                if (PRO == PRO_RMSNORM) lnr[i] = ng[pc];
+                if (PRO == PRO_RMSNORM) lnr[i] = reinterpret_cast<const rowv4*>(ng)[pc];
             }
             if (lin_never) asm volatile("" ::"v"(PRO == PRO_PARTS ? __float_as_uint(lpr[0][0].x) : lxr[0].x)); // ends the basic block: the requests stay in front of what follows
         }
-        const uint32_t nw_total = gridDim.x * nwaves, gw = blockIdx.x * nwaves + wave;
+        const uint32_t nw_total = gridDim.x * nwp, gw = blockIdx.x * nwp + (LKS == 2 ? wave - khalf * nwp : wave);
         const uint32_t NP = (out_rows + 1) / 2; // row pairs (the host takes this path only for even out_rows)
         // equal ranges to within one pair, without a 64-bit division: the first NP % nw_total waves take one pair more
         const uint32_t pq = NP / nw_total, prem = NP - pq * nw_total;
@@ -1383,7 +1400,9 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
         auto ltile = [&](uint4 (&dst)[LTP], uint32_t pr, int t, bool live) {
             // wave-uniform 64-bit base (SALU) + a 32-bit lane offset: the load takes its base from an SGPR pair and the
             // address costs ONE vector instruction (the per-lane 64-bit form cost ~ 10 per tile)
-            const uint64_t rb = ((uint64_t)pr * 2 + (uint64_t)(t / SUB)) * rowb + (uint64_t)(t % SUB) * LTP * 1024;
+            const uint32_t chunk0 = (LKS == 2 ? cbase : 0u) + (uint32_t)(t % SUB) * LTP;
+            if (LKS == 2) live = live && chunk0 < (uint32_t)LNCH;
+            const uint64_t rb = ((uint64_t)pr * 2 + (uint64_t)(t / SUB)) * rowb + (uint64_t)chunk0 * 1024;
             // (masks, not selects: given a select between two addresses hipcc builds a branch, and a load behind a branch
             //  costs every counted s_waitcnt vmcnt(N))
             const uint32_t lm = 0u - (uint32_t)live;
@@ -1408,13 +1427,15 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
             const uint32_t lm = 0u - (uint32_t)live;
             const char* a = sbase + (ub & (((uint64_t)lm << 32) | lm));
 #pragma unroll
-            for (int c = 0; c < LNCH; c++) {
+            for (int c = 0; c < (LKS == 2 ? SUB : LNCH); c++) {
                 if (MC_GEMV_LIN_NOLOAD) {
                     q[c] = 0x3C003C00u;
                     continue;
                 }
-                const uint32_t g = group ? ((2048u * c + 32u * lane) >> glog) : 0u;
-                q[c] = *reinterpret_cast<const uint32_t*>(a + ((g * 8u) & lm));
+                const uint32_t cc = (LKS == 2 ? cbase : 0u) + (uint32_t)c; // (a chunk past the row: any valid scale, it meets zeros)
+                const uint32_t lmc = LKS == 2 ? (cc < (uint32_t)LNCH ? lm : 0u) : lm;
+                const uint32_t g = group ? ((2048u * cc + 32u * lane) >> glog) : 0u;
+                q[c] = *reinterpret_cast<const uint32_t*>(a + ((g * 8u) & lmc));
             }
         };
 
@@ -1532,11 +1553,11 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
                 vm_wait<NSC + DD>(eo_rrow);
             }
             auto live = [&](int i) { return !(RAGGED && i == NXP - 1) || tid + i * BD < NPK; };
-            uint4 (&xr)[NXP] = lxr;
+            rowv4 (&xr)[NXP] = lxr;
 #pragma unroll
             for (int i = 0; i < NXP; i++) {
-                if constexpr (PRO != PRO_PARTS) xr[i] = make_uint4(axr[i].x, axr[i].y, axr[i].z, axr[i].w);
-                if constexpr (PRO == PRO_RMSNORM) lnr[i] = make_uint4(axr[NXP + i].x, axr[NXP + i].y, axr[NXP + i].z, axr[NXP + i].w);
+                if constexpr (PRO != PRO_PARTS) xr[i] = axr[i];
+                if constexpr (PRO == PRO_RMSNORM) lnr[i] = axr[NXP + i];
             }
             if constexpr (PRO == PRO_PARTS) {
 #pragma unroll
@@ -1594,7 +1615,7 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
             }
 #pragma unroll
             for (int i = 0; i < NXP; i++)
-                if (live(i)) lds_wr128(xs_a + xpk(tid + i * BD) * 16, xr[i]);
+                if (live(i)) lds_wr128(xs_a + xpk(tid + i * BD) * 16, make_uint4(xr[i].x, xr[i].y, xr[i].z, xr[i].w));
             lds_wait();
             wg_barrier_raw();
             if (EPI == EPI_QKV_ROPE) {
@@ -1704,8 +1725,9 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
         };
         if constexpr (LEAN) {
             uint4* xl = reinterpret_cast<uint4*>(xs);
-            uint4 (&xr)[NXP] = lxr;
-            uint4 (&nr)[PRO == PRO_RMSNORM ? NXP : 1] = lnr;
+            rowv4 (&xr)[NXP] = lxr;
+            rowv4 (&nr)[PRO == PRO_RMSNORM ? NXP : 1] = lnr;
+            rowv4* xlv = reinterpret_cast<rowv4*>(xs);
             if (MC_GEMV_XBAR) asm volatile("s_barrier" ::: "memory");
             lin_prefetch();
             auto live = [&](int i) { return !(RAGGED && i == NXP - 1) || tid + i * BD < NPK; };
@@ -1719,7 +1741,7 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
                         a[0] += lo.x; a[1] += lo.y; a[2] += lo.z; a[3] += lo.w;
                         a[4] += hi.x; a[5] += hi.y; a[6] += hi.z; a[7] += hi.w;
                     }
-                    xr[i] = make_uint4(pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]), pack_bf16x2(a[4], a[5]), pack_bf16x2(a[6], a[7]));
+                    xr[i] = rowv4{pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]), pack_bf16x2(a[4], a[5]), pack_bf16x2(a[6], a[7])};
                 }
             }
             if (PRO == PRO_RMSNORM) {
@@ -1754,14 +1776,18 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
                         const float b = (mu + asf(ww[e] & 0xFFFF0000u)) * asf(vv[e] & 0xFFFF0000u) * inv;
                         o[e] = pack_bf16x2(a, b);
                     }
-                    if (live(i)) xl[xpk(tid + i * BD)] = make_uint4(o[0], o[1], o[2], o[3]);
+                    if (live(i)) xlv[xpk(tid + i * BD)] = rowv4{o[0], o[1], o[2], o[3]};
                 }
             } else {
 #pragma unroll
                 for (int i = 0; i < NXP; i++)
-                    if (live(i)) xl[xpk(tid + i * BD)] = xr[i];
+                    if (live(i)) xlv[xpk(tid + i * BD)] = xr[i];
+            }
+            if constexpr (LKS == 2) { // the chunk of zeros behind the row (272 padded packets)
+                if (tid < CHUNK_LDS / 16) xlv[(size_t)nchunks * (CHUNK_LDS / 16) + tid] = rowv4{0, 0, 0, 0};
             }
         } else {
+            static_assert(LKS == 1, "K split needs the build-time prologue");
             stage_x(lin_prefetch);
         }
         __syncthreads();
@@ -1792,7 +1818,10 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
         }
         // parked row sums, behind the reduction scratch (LWAVES == 0: the kernel may run with any workgroup size -- 512 bytes per wave)
         constexpr bool RAWPARK = MC_GEMV_LIN_RAWPARK && LWAVES > 0 && !MC_GEMV_LIN_STREAM;
-        float2* park = reinterpret_cast<float2*>(reinterpret_cast<char*>(red + 32) + wave * (LWAVES ? PARKB : 512u));
+        // (K split: the zero chunk sits where the reduction scratch would be -- there is no norm prologue -- and the parking
+        //  space behind it)
+        char* park0 = reinterpret_cast<char*>(red + 32) + (LKS == 2 ? CHUNK_LDS : 0u);
+        float2* park = reinterpret_cast<float2*>(park0 + wave * (LWAVES ? PARKB : 512u));
         float* praw = reinterpret_cast<float*>(park);
         uint32_t parked = 0, park_first = pb;
         auto flush = [&]() {
@@ -1807,6 +1836,11 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
                         b += ra_p[65 + l];
                     }
                     finish_pair(park_first + lane, a, b, park_first == pb);
+                } else if constexpr (LKS == 2) {
+                    // the partner's sums over the other half of K (a workgroup barrier stands between its stores and this read)
+                    const float2 v = park[lane];
+                    const float2 u = reinterpret_cast<const float2*>(park0 + (wave + nwp) * PARKB)[lane];
+                    finish_pair(park_first + lane, v.x + u.x, v.y + u.y, park_first == pb);
                 } else {
                     const float2 v = park[lane];
                     finish_pair(park_first + lane, v.x, v.y, park_first == pb);
@@ -1849,7 +1883,7 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
                         mac4d_n<NA>(laccs, lring[slot][p], m4d_prepare(s2, m4d_mx, m4d_my), xr[c]);
                     } else {
                         uint2 x[8];
-                        xload(x, c);
+                        xload(x, (LKS == 2 ? (int)cbase : 0) + c);
                         mac4d_n<NA>(laccs, lring[slot][p], m4d_prepare(s2, m4d_mx, m4d_my), x);
                     }
                 }
@@ -1894,7 +1928,7 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
             }
             if (!RAWPARK && lane == 0) park[parked] = make_float2(ra, rb);
             parked++;
-            if (parked == (RAWPARK ? (uint32_t)PARKP : 64u)) flush();
+            if (LKS == 1 && parked == (RAWPARK ? (uint32_t)PARKP : 64u)) flush(); // (K split: the host grants at most 64 pairs per wave)
 #pragma unroll
             for (int c = 0; c < LNCH; c++) sa[c] = sb[c];
         };
@@ -1906,7 +1940,12 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
         if constexpr (U == 2) {
             if (pr < pe) do_pair(std::integral_constant<int, 0>{}, pr); // odd count: the last pair sits in the first slots
         }
-        flush();
+        if constexpr (LKS == 2) {
+            __syncthreads();
+            if (khalf == 0) flush();
+        } else {
+            flush();
+        }
         if (MC_GEMV_LIN_DECOUPLE && lin_dummy == 0x12345678u) static_cast<uint32_t*>(yp)[0] = 1;
         if (MC_GEMV_LIN_TL && lane == 0) {
             unsigned long long* tl = const_cast<unsigned long long*>(static_cast<const unsigned long long*>(resp));
