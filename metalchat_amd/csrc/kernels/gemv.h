@@ -400,6 +400,83 @@ mac4d_n(mf_f4 (&acc)[NA], const uint4& w, const m4d_scale& sc, const uint2 (&x)[
     }
 }
 
+// Q_M4D with the nibbles UNMIXED BY THE MATRIX PIPE (linear-order kernels): the dequantisation above spends seven bit
+// operations per dword (three shifts, four and-or) to put each nibble into the mantissa of a bf16 of its own.  A bf16 whose
+// upper exponent bits are zero is linear in its low EIGHT bits -- subnormals m * 2^-133, and exponent field 1 continues
+// them: (128 + m) * 2^-133 -- and the 4x4x4 MFMA takes subnormal inputs exactly (tools/denorm_lab.hip: 0 of 256 wrong).
+// So a whole byte goes in as ONE operand, (16 hi + lo) * 2^-133, next to (16 hi) * 2^-133 (the same byte masked), and B
+// unmixes them: column 0 = (s, 0, -s, 0) returns lo * s, column 2 = (0, 0, s/16, 0) returns hi * s.  Per dword:
+//   t0 = v & 0x00FF00FF, t1 = v & 0x00F000F0, t2 = bytes 1 and 3 of v moved down (v_perm_b32), t3 = t2 & 0x00F000F0
+// -- four instructions, no shift, and the results leave the MFMA in the same order as before (weights 4m + j), so the
+// activations stay where they are.  Exactness as above: every term is a whole multiple of one unit below 2^17.
+// The 2^-133 cannot ride on T(s) in full (s * 2^133 overflows for s >= 2^-6): B carries s * 2^M4B_P and the dequantised
+// weights, the products and the row sum are the reference's times 2^-M4B_Q (a power of two moves no rounding: weights
+// stay normal for 2^-89 < s < 2^31); the row sum is multiplied by 2^M4B_Q once.
+constexpr int M4B_P = 96, M4B_Q = 133 - M4B_P;
+typedef float m4b_f2 __attribute__((ext_vector_type(2)));
+struct m4b_lane {
+    m4b_f2 ca, cb; // (-8 * 2^-Q) twice over, as two values hipcc cannot tell are equal
+    uint32_t sel; // v_perm_b32 selector: the upper half of a float to the lane's half of a B register (even lane: low)
+    float m0;     // 2^P on the lanes of columns 0 and 1, zero on the others
+    float m1;     // -2^P there, 2^P / 16 on the lanes of columns 2 and 3
+};
+__device__ __forceinline__ m4b_lane
+m4b_lane_consts(uint32_t lane)
+{
+    m4b_lane k;
+    k.sel = (lane & 1) ? 0x07060C0Cu : 0x0C0C0706u;
+    k.m0 = (lane & 2) ? 0.0f : 0x1p96f;
+    k.m1 = (lane & 2) ? 0x1p92f : -0x1p96f;
+    k.ca = m4b_f2{-0x1p-34f, -0x1p-34f};
+    k.cb = k.ca;
+    asm("" : "+s"(k.ca));
+    asm("" : "+s"(k.cb));
+    return k;
+}
+__device__ __forceinline__ m4d_scale
+m4b_prepare(uint32_t fbits, const m4b_lane& k) // fbits: T(s) << 16, i.e. s as a float
+{
+    m4d_scale r;
+    const float f = asf(fbits);
+    const m4b_f2 fm = m4b_f2{f, f} * m4b_f2{k.m0, k.m1}; // one v_pk_mul_f32
+    r.b = make_uint2(__builtin_amdgcn_perm(__float_as_uint(fm[0]), 0u, k.sel), __builtin_amdgcn_perm(__float_as_uint(fm[1]), 0u, k.sel));
+#ifndef MC_GEMV_M4B_PKC
+#define MC_GEMV_M4B_PKC 1
+#endif
+    if (MC_GEMV_M4B_PKC) {
+        // -8 s 2^-Q in all four elements: two v_pk_mul_f32 (both halves read f) instead of a multiply and three moves;
+        // the two constant pairs are opaque copies (m4b_lane_consts), or hipcc folds the second product into moves again
+        const m4b_f2 ff = {f, f};
+        const m4b_f2 c01 = ff * k.ca, c23 = ff * k.cb;
+        r.c = mf_f4{c01[0], c01[1], c23[0], c23[1]};
+    } else {
+        const float c = f * -0x1p-34f; // -8 s 2^-Q
+        r.c = mf_f4{c, c, c, c};
+    }
+    return r;
+}
+template <int NA>
+__device__ __forceinline__ void
+mac4b_n(mf_f4 (&acc)[NA], const uint4& w, const m4d_scale& sc, const uint2 (&x)[8])
+{
+    const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
+    const mf_s4 bs = __builtin_bit_cast(mf_s4, sc.b);
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        const uint32_t v = ws[d];
+        const uint32_t t0 = v & 0x00FF00FFu, t1 = v & 0x00F000F0u;
+        const uint32_t t2 = __builtin_amdgcn_perm(v, 0u, 0x0C070C05u), t3 = t2 & 0x00F000F0u;
+        const mf_f4 d1 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(mf_s4, make_uint2(t0, t1)), bs, sc.c, 0, 0, 0);
+        const mf_f4 d2 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(mf_s4, make_uint2(t2, t3)), bs, sc.c, 0, 0, 0);
+        const uint2 a0 = make_uint2(pack_bf16x2(d1[0], d1[1]), pack_bf16x2(d1[2], d1[3]));
+        const uint2 a1 = make_uint2(pack_bf16x2(d2[0], d2[1]), pack_bf16x2(d2[2], d2[3]));
+        mf_f4& A0 = acc[(2 * d) % NA];
+        mf_f4& A1 = acc[(2 * d + 1) % NA];
+        A0 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(mf_s4, a0), __builtin_bit_cast(mf_s4, x[2 * d]), A0, 0, 0, 0);
+        A1 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(mf_s4, a1), __builtin_bit_cast(mf_s4, x[2 * d + 1]), A1, 0, 0, 0);
+    }
+}
+
 // (The same substitution on int8-held and plain bfloat weights changes nothing -- 984 vs 988 and 390
 // vs 392 tokens/s: those kernels wait for memory, not for the VALU -- so only int4 takes it.)
 // I4, T = float: Wd = fl(float(q) * s), the reference's float(q) * float(s)
@@ -1822,6 +1899,10 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
         const uint32_t lane_tr = (((lane >> 4) * 4 + (lane & 3)) * 17 + ((lane >> 2) & 3) * 4) * 16;
         const uint32_t m4d_mx = (lane & 3) == 0 ? 0x0000FFFFu : ((lane & 3) == 1 ? 0xFFFF0000u : 0u);
         const uint32_t m4d_my = (lane & 3) == 2 ? 0x0000FFFFu : ((lane & 3) == 3 ? 0xFFFF0000u : 0u);
+#ifndef MC_GEMV_M4B
+#define MC_GEMV_M4B 1 // whole bytes into the dequantising MFMA, nibbles unmixed by its B operand (mac4b_n)
+#endif
+        const m4b_lane m4bk = m4b_lane_consts(lane);
         typedef __attribute__((address_space(3))) mf_s4 lds_s4;
         auto xload = [&](uint2 (&x)[8], int c) {
             lds_s4* xt = (lds_s4*)(xs + c * CHUNK_LDS + lane_tr);
@@ -1886,6 +1967,7 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
                     const int c = sidx * LTP + p;
                     const uint32_t raw = sa[c];
                     const uint32_t s2 = r ? ((raw & 0xFFFF0000u) | (raw >> 16)) : ((raw << 16) | (raw & 0xFFFFu));
+                    const uint32_t sf = r ? (raw & 0xFFFF0000u) : (raw << 16); // the row's scale as a float
                     if (MC_GEMV_LIN_DECOUPLE && XREG) {
                         const uint4 fake = make_uint4(lane * 0x01010101u + pr, (lane + pr) * 0x9E3779B9u, lane * 0x85EBCA6Bu + (uint32_t)(t * 0x11111111u),
                                                       (p + lane) * 0xC2B2AE35u + pr);
@@ -1897,11 +1979,13 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
                         const uint4& w = lring[slot][p];
                         laccs[0][0] += asf(((w.x ^ w.y ^ w.z ^ w.w) & 0x3FFFFFFFu) | (s2 & 1u));
                     } else if constexpr (XREG) {
-                        mac4d_n<NA>(laccs, lring[slot][p], m4d_prepare(s2, m4d_mx, m4d_my), xr[c]);
+                        if (MC_GEMV_M4B) mac4b_n<NA>(laccs, lring[slot][p], m4b_prepare(sf, m4bk), xr[c]);
+                        else mac4d_n<NA>(laccs, lring[slot][p], m4d_prepare(s2, m4d_mx, m4d_my), xr[c]);
                     } else {
                         uint2 x[8];
                         xload(x, (LKS == 2 ? (int)cbase : 0) + c);
-                        mac4d_n<NA>(laccs, lring[slot][p], m4d_prepare(s2, m4d_mx, m4d_my), x);
+                        if (MC_GEMV_M4B) mac4b_n<NA>(laccs, lring[slot][p], m4b_prepare(sf, m4bk), x);
+                        else mac4d_n<NA>(laccs, lring[slot][p], m4d_prepare(s2, m4d_mx, m4d_my), x);
                     }
                 }
                 if constexpr (LR >= TPP) ltile(lring[slot], pr + U, t, pr + U < pe);
@@ -1933,9 +2017,11 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
                     for (int a = 1; a < NA; a++) lacc += laccs[a];
                     const float mine = e == 0 ? lacc[0] : (e == 1 ? lacc[1] : (e == 2 ? lacc[2] : lacc[3]));
                     if constexpr (RAWPARK) {
+                        static_assert(!(RAWPARK && MC_GEMV_M4B), "raw parking keeps the unscaled sums of mac4d_n");
                         praw[(2 * parked + r) * 65 + lane] = mine;
                     } else {
-                        const float rs = wave_sum_dpp(MC_GEMV_LIN_STREAM ? lacc[0] : mine);
+                        float rs = wave_sum_dpp(MC_GEMV_LIN_STREAM ? lacc[0] : mine);
+                        if (MC_GEMV_M4B && !MC_GEMV_LIN_STREAM) rs *= 0x1p37f; // 2^M4B_Q: the sum was formed at 2^-Q (mac4b_n)
                         if (r == 0) ra = rs;
                         else rb = rs;
                     }
