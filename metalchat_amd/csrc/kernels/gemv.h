@@ -413,6 +413,10 @@ mac4d_n(mf_f4 (&acc)[NA], const uint4& w, const m4d_scale& sc, const uint2 (&x)[
 // weights, the products and the row sum are the reference's times 2^-M4B_Q (a power of two moves no rounding: weights
 // stay normal for 2^-89 < s < 2^31); the row sum is multiplied by 2^M4B_Q once.
 constexpr int M4B_P = 96, M4B_Q = 133 - M4B_P;
+#ifndef MC_GEMV_M4B_MAC16
+#define MC_GEMV_M4B_MAC16 0
+#endif
+typedef uint32_t mf_u4 __attribute__((ext_vector_type(4)));
 typedef float m4b_f2 __attribute__((ext_vector_type(2)));
 struct m4b_lane {
     m4b_f2 ca, cb; // (-8 * 2^-Q) twice over, as two values hipcc cannot tell are equal
@@ -470,10 +474,21 @@ mac4b_n(mf_f4 (&acc)[NA], const uint4& w, const m4d_scale& sc, const uint2 (&x)[
         const mf_f4 d2 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(mf_s4, make_uint2(t2, t3)), bs, sc.c, 0, 0, 0);
         const uint2 a0 = make_uint2(pack_bf16x2(d1[0], d1[1]), pack_bf16x2(d1[2], d1[3]));
         const uint2 a1 = make_uint2(pack_bf16x2(d2[0], d2[1]), pack_bf16x2(d2[2], d2[3]));
-        mf_f4& A0 = acc[(2 * d) % NA];
-        mf_f4& A1 = acc[(2 * d + 1) % NA];
-        A0 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(mf_s4, a0), __builtin_bit_cast(mf_s4, x[2 * d]), A0, 0, 0, 0);
-        A1 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(mf_s4, a1), __builtin_bit_cast(mf_s4, x[2 * d + 1]), A1, 0, 0, 0);
+        if (MC_GEMV_M4B_MAC16) {
+            // the eight products of the dword in ONE v_mfma_f32_16x16x32_bf16 (16 cycles of the pipe, as the two 4x4x4 it
+            // replaces, one issue slot less): lane l = (row l % 16, k chunk l / 16) of A and (column l % 16, chunk l / 16) of
+            // B, so D[i][i] is the sum of the private dot products of lanes i, i + 16, i + 32, i + 48 -- it sits in element
+            // i % 4 of lane 16 (i / 4) + i (m4b_diag); the other 240 results are cross terms nobody reads
+            typedef __bf16 mf_b8 __attribute__((ext_vector_type(8)));
+            const mf_u4 av = {a0.x, a0.y, a1.x, a1.y}, xv = {x[2 * d].x, x[2 * d].y, x[2 * d + 1].x, x[2 * d + 1].y};
+            mf_f4& A0 = acc[d % NA];
+            A0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mf_b8, av), __builtin_bit_cast(mf_b8, xv), A0, 0, 0, 0);
+        } else {
+            mf_f4& A0 = acc[(2 * d) % NA];
+            mf_f4& A1 = acc[(2 * d + 1) % NA];
+            A0 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(mf_s4, a0), __builtin_bit_cast(mf_s4, x[2 * d]), A0, 0, 0, 0);
+            A1 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(mf_s4, a1), __builtin_bit_cast(mf_s4, x[2 * d + 1]), A1, 0, 0, 0);
+        }
     }
 }
 
@@ -709,6 +724,19 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
         asm volatile("" ::"s"(wp), "s"(sp), "s"(xp), "s"(yp), "s"(resp), "s"(normp), "s"(out_rows), "s"(in), "s"(group), "s"(eps),
                      "s"(mu), "s"(lora_rank), "s"(gridDim.x));
     }
+#ifdef MC_LIN_XCD_DELAY
+    // tuning experiment (tools/lin_timeline.py, profiles/r02_gemv_ablations.log): in the decode chain the XCDs start the
+    // workgroups of a launch one after another over ~1.1 us (XCC 0, 1, 2, 3, 6, 7, 4, 5; each XCD's own 32 workgroups within
+    // 0.2 us) and finish in that order -- every wave needs the same time from "row staged" to its end.  Holding the early
+    // XCDs back (nibble i: units of s_sleep 2, ~0.055 us, for the waves of XCC i) does not bring the late ones forward: the
+    // stagger is the dispatcher's, not the memory system's.  +0.15..0.3 us per launch: off.
+    if (LNCH > 0) {
+        uint32_t xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        const uint32_t nd = ((uint32_t)(MC_LIN_XCD_DELAY) >> (4 * (xcc & 7))) & 15u;
+        for (uint32_t i = 0; i < nd; i++) __builtin_amdgcn_s_sleep(2);
+    }
+#endif
     constexpr bool M4 = (QM == Q_M4 || QM == Q_M4D || QM == Q_DBG_TL4D) && WF == WF_I4 && T::bytes == 2;
     constexpr bool M4D = (QM == Q_M4D || QM == Q_DBG_TL4D) && M4;
     constexpr bool TL = QM == Q_DBG_TL || QM == Q_DBG_TL4D;
@@ -2015,7 +2043,8 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
                     mf_f4 lacc = laccs[0];
 #pragma unroll
                     for (int a = 1; a < NA; a++) lacc += laccs[a];
-                    const float mine = e == 0 ? lacc[0] : (e == 1 ? lacc[1] : (e == 2 ? lacc[2] : lacc[3]));
+                    float mine = e == 0 ? lacc[0] : (e == 1 ? lacc[1] : (e == 2 ? lacc[2] : lacc[3]));
+                    if (MC_GEMV_M4B && MC_GEMV_M4B_MAC16 && (lane >> 4) != ((lane >> 2) & 3)) mine = 0.0f; // only D[i][i] (mac4b_n)
                     if constexpr (RAWPARK) {
                         static_assert(!(RAWPARK && MC_GEMV_M4B), "raw parking keeps the unscaled sums of mac4d_n");
                         praw[(2 * parked + r) * 65 + lane] = mine;

@@ -52,7 +52,7 @@ for kind in ("classic", "lin"):
     outs[kind] = (y.download(np.uint16, OUT).astype(np.uint32) << 16).view(np.float32)
 a, b = outs["classic"], outs["lin"]
 bad = np.nonzero(~np.isclose(a, b, rtol=2e-2, atol=1e-2 * np.abs(a).max()))[0]
-print(f"K={K} out={OUT} pro={pro}: max|classic|={np.abs(a).max():.3g} mismatches={len(bad)} of {OUT}", "first", bad[:16].tolist())
+print(f"K={K} out={OUT} pro={pro}: max|classic|={np.abs(a).max():.3g} mismatches={len(bad)} of {OUT} (not bit-identical: {int((a.view(np.uint32) != b.view(np.uint32)).sum())})", "first", bad[:16].tolist())
 if len(bad):
     rows_per_wave_pairs = OUT // 2 / (min((OUT // 2 + 7) // 8, cus) * 8)
     print("pairs per wave ~", rows_per_wave_pairs, "bad rows mod 32:", np.bincount(bad % 32, minlength=32).tolist())

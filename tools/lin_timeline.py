@@ -19,14 +19,14 @@ x = acc.to_device((np.random.default_rng(0).normal(0, 1, 14336).astype(np.float3
 nw = acc.to_device(np.full(14336, 0x3F80, np.uint16))
 y = acc.alloc(2 * 28672)
 for which, kname in (("w13", "mc_gemv_i4_bfloat_lin2_p1_e2"), ("w2", "mc_gemv_i4_bfloat_lin7_p0_e0"),
-                     ("wo", "mc_gemv_i4_bfloat_lin2_p0_e0")):
+                     ("wo", "mc_gemv_i4_bfloat_lin2_p0_e0"), ("qkv", "mc_gemv_i4_bfloat_lin2_p1_e0")):  # (qkv: the matrix and the norm prologue, a plain epilogue)
     for block, wgs_per_cu in [tuple(int(v) for v in g.split("x")) for g in os.environ.get("GEOMS", "256x2").split(",")]:
         k = acc.load(kname)
         waves = block // 64
         tl = acc.alloc(cus * 4 * waves * 128)
         for layer in (0, 1, 2, 3, 4, 5, 6, 7) * int(os.environ.get('CHAIN', '40')) + (0, 1, 2, 3, 4, 5):  # a chain of launches over distinct weights; the stamps kept are the last one's
             wptr, sptr, rows, inf, ng = dec.weight_ptrs(layer, which)
-            ngp = (rows + 3) // 4
+            ngp = rows // 2  # row pairs, one wave at a time
             wgs = min((ngp + waves - 1) // waves, cus * wgs_per_cu)
             lds = (inf + 2047) // 2048 * 2048 * 2 // 16 * 17 + 128 + waves * 512
             t = mc.KernelTask(k, (wgs * block, 1, 1), (block, 1, 1),
@@ -56,4 +56,6 @@ for which, kname in (("w13", "mc_gemv_i4_bfloat_lin2_p1_e2"), ("w2", "mc_gemv_i4
         xcc = st[:, 15] & 0xF
         print(json.dumps(dict(which=which, kernel=kname, block=block, wgs=wgs, event_us=round(ms * 1e3, 2), start=q(start),
                               staged=q(staged), end=q(end), clock_mhz=q(mhz), tile_end=tiles, tile_gap=gaps,
-                              end_by_xcd={int(c): round(float(np.percentile(end[xcc == c], 90)), 2) for c in sorted(set(xcc.tolist()))})), flush=True)
+                              end_by_xcd={int(c): round(float(np.percentile(end[xcc == c], 90)), 2) for c in sorted(set(xcc.tolist()))},
+                              start_by_xcd={int(c): [round(float(np.percentile(start[xcc == c], p)), 2) for p in (0, 50, 100)] for c in sorted(set(xcc.tolist()))},
+                              span_by_xcd={int(c): round(float(np.median((end - staged)[xcc == c])), 2) for c in sorted(set(xcc.tolist()))})), flush=True)
