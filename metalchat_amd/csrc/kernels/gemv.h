@@ -424,14 +424,15 @@ struct m4b_lane {
     float m0;     // 2^P on the lanes of columns 0 and 1, zero on the others
     float m1;     // -2^P there, 2^P / 16 on the lanes of columns 2 and 3
 };
+template <bool I8 = false>
 __device__ __forceinline__ m4b_lane
 m4b_lane_consts(uint32_t lane)
 {
     m4b_lane k;
     k.sel = (lane & 1) ? 0x07060C0Cu : 0x0C0C0706u;
     k.m0 = (lane & 2) ? 0.0f : 0x1p96f;
-    k.m1 = (lane & 2) ? 0x1p92f : -0x1p96f;
-    k.ca = m4b_f2{-0x1p-34f, -0x1p-34f};
+    k.m1 = I8 ? ((lane & 2) ? 0x1p96f : 0.0f) : ((lane & 2) ? 0x1p92f : -0x1p96f); // int8: B = s I (mac8b_n)
+    k.ca = I8 ? m4b_f2{-0x1p-30f, -0x1p-30f} : m4b_f2{-0x1p-34f, -0x1p-34f};        // -128 s 2^-Q / -8 s 2^-Q
     k.cb = k.ca;
     asm("" : "+s"(k.ca));
     asm("" : "+s"(k.cb));
@@ -454,7 +455,7 @@ m4b_prepare(uint32_t fbits, const m4b_lane& k) // fbits: T(s) << 16, i.e. s as a
         const m4b_f2 c01 = ff * k.ca, c23 = ff * k.cb;
         r.c = mf_f4{c01[0], c01[1], c23[0], c23[1]};
     } else {
-        const float c = f * -0x1p-34f; // -8 s 2^-Q
+        const float c = f * k.ca[0]; // -8 s 2^-Q
         r.c = mf_f4{c, c, c, c};
     }
     return r;
@@ -490,6 +491,40 @@ mac4b_n(mf_f4 (&acc)[NA], const uint4& w, const m4d_scale& sc, const uint2 (&x)[
             A1 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(mf_s4, a1), __builtin_bit_cast(mf_s4, x[2 * d + 1]), A1, 0, 0, 0);
         }
     }
+}
+
+// int8-held weights the same way (linear-order kernels, LGEN): a byte XOR 0x80 is q + 128, offset binary, and goes into the
+// dequantising MFMA whole -- (v ^ 0x80808080) & 0x00FF00FF are bytes 0 and 2, one v_perm_b32 moves bytes 1 and 3 down --
+// against B = s I and C = -128 s: three bit operations, one MFMA and two conversions per FOUR weights where the VALU path
+// spends a sign extension, a conversion and a multiply per weight, two packs and two v_dot2c_f32_bf16 (~10 issue cycles
+// each).  (q + 128) T(s) - 128 T(s) is exact (every term a multiple of one unit below 2^17) and v_cvt_pk_bf16_f32 applies the
+// reference's rounding, Wd = T(float(q) * T(s)).  Lane j of a block receives the weights of slot j -- byte {0, 2, 1, 3}[j]
+// of the dword -- of the four lanes of its block: the row is staged in LDS in exactly that order (x_perm8), so every lane
+// still reads its own 32 bytes.
+template <int NA>
+__device__ __forceinline__ void
+mac8b_n(mf_f4 (&acc)[NA], const uint4& w, const m4d_scale& sc, const xregs<BF, 16>& x)
+{
+    const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
+    const mf_s4 bs = __builtin_bit_cast(mf_s4, sc.b);
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        const uint32_t vx = ws[d] ^ 0x80808080u;
+        const uint32_t t0 = vx & 0x00FF00FFu, t2 = __builtin_amdgcn_perm(vx, 0u, 0x0C070C05u);
+        const mf_f4 d1 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(mf_s4, make_uint2(t0, t2)), bs, sc.c, 0, 0, 0);
+        const uint2 a = make_uint2(pack_bf16x2(d1[0], d1[1]), pack_bf16x2(d1[2], d1[3]));
+        mf_f4& A = acc[d % NA];
+        A = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(mf_s4, a), __builtin_bit_cast(mf_s4, make_uint2(x.v[2 * d], x.v[2 * d + 1])), A, 0, 0, 0);
+    }
+}
+// where element n of the row goes in LDS for mac8b_n: inside its chunk of 1024, n = 64 b + 16 e + 4 d + p (lane 4 b + e,
+// dword d, byte p) sits at 64 b + 16 j + 4 d + e, j = {0, 2, 1, 3}[p] -- lane 4 b + j reads [e = 0..3] of (d, its slot) as
+// the 8 bytes its accumulating MFMA d takes
+__device__ __forceinline__ uint32_t
+x_perm8(uint32_t n)
+{
+    const uint32_t p = n & 3u, e = (n >> 4) & 3u, j = ((p & 1u) << 1) | (p >> 1);
+    return (n & ~0x33u) | (j << 4) | e;
 }
 
 // (The same substitution on int8-held and plain bfloat weights changes nothing -- 984 vs 988 and 390
@@ -1184,6 +1219,12 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
         constexpr bool RAGGED = NPK % BD != 0;
         constexpr bool XREG = LGEN * (KPL / 2) <= 64;      // the whole row in registers (KPL / 2 VGPRs per packet)
         constexpr bool SCALED = WF != WF_T;
+#ifndef MC_GEMV_I8M
+#define MC_GEMV_I8M 0 // 1: int8-held weights dequantised and multiplied on the matrix pipe (mac8b_n).  Parity-green (tools/lin_check.py i8, the
+                      // context tests) and no faster: these kernels wait for memory (w1|w3 of Llama-3-8B int8: 121 MB in 20.8 us = 5.8 TB/s
+                      // either way; 464-466 tokens/s at S = 8192 both) -- off, the row sums keep the classic kernels' order
+#endif
+        constexpr bool I8M = MC_GEMV_I8M && WF == WF_I8;
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
         uint32_t never;
         asm volatile("s_mov_b32 %0, 0" : "=s"(never));
@@ -1311,8 +1352,18 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
                 }
             }
 #pragma unroll
-            for (int i = 0; i < NXP; i++)
-                if (live(i)) xl[tid + i * BD] = gxr[i];
+            for (int i = 0; i < NXP; i++) {
+                if (!live(i)) continue;
+                if constexpr (I8M) {
+                    // the order mac8b_n wants: the packet's eight elements are (lane 4 b + e, dwords d0 and d0 + 1, bytes 0..3)
+                    uint16_t* xh = reinterpret_cast<uint16_t*>(xs);
+                    const uint32_t n0 = 8u * (tid + i * BD), vv[4] = {gxr[i].x, gxr[i].y, gxr[i].z, gxr[i].w};
+#pragma unroll
+                    for (int e2 = 0; e2 < 8; e2++) xh[x_perm8(n0 + e2)] = (uint16_t)(vv[e2 / 2] >> (16 * (e2 & 1)));
+                } else {
+                    xl[tid + i * BD] = gxr[i];
+                }
+            }
         }
         __syncthreads();
         if (EPI == EPI_QKV_ROPE) {
@@ -1339,6 +1390,8 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
             park_first += parked;
             parked = 0;
         };
+        const m4b_lane i8k = m4b_lane_consts<true>(lane);
+        mf_f4 acc4[1] = {mf_f4{0, 0, 0, 0}};
         auto pair_g = [&](uint32_t pr) {
             gscales(gsb, pr + 1, pr + 1 < pe);
             float ra = 0.f, rb = 0.f, accf = 0.f;
@@ -1347,7 +1400,15 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
                 const int r = t / LGEN, c = t % LGEN, slot = t % RS;
                 float sc = 1.0f;
                 if constexpr (SCALED) sc = r ? asf(gsa[c] & 0xFFFF0000u) : asf(gsa[c] << 16);
-                if constexpr (XREG) {
+                if constexpr (I8M) {
+                    if constexpr (XREG) {
+                        mac8b_n<1>(acc4, gring[slot], m4b_prepare(__float_as_uint(sc), i8k), gx[c]);
+                    } else {
+                        xregs<T, KPL> x;
+                        x.load(xs + (size_t)c * CHUNK * 2 + lane_xb, 0);
+                        mac8b_n<1>(acc4, gring[slot], m4b_prepare(__float_as_uint(sc), i8k), x);
+                    }
+                } else if constexpr (XREG) {
                     mac<Q_EXACT>(accf, gring[slot], sc, gx[c], 0.0f, static_cast<F*>(nullptr));
                 } else {
                     xregs<T, KPL> x;
@@ -1358,6 +1419,12 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
                 else gload(gring[slot], pr + 1, t + RS - PP, pr + 1 < pe);
                 if (never) asm volatile("s_nop 0"); // ends the basic block: the refill stays behind its packet
                 if (c == LGEN - 1) {
+                    if constexpr (I8M) {
+                        // element lane % 4 of the lane's four results is its own dot product, formed at 2^-M4B_Q
+                        const uint32_t e = lane & 3;
+                        accf = (e == 0 ? acc4[0][0] : (e == 1 ? acc4[0][1] : (e == 2 ? acc4[0][2] : acc4[0][3]))) * 0x1p37f;
+                        acc4[0] = mf_f4{0, 0, 0, 0};
+                    }
                     const float rs = wave_sum_dpp(accf);
                     if (r == 0) ra = rs;
                     else rb = rs;
