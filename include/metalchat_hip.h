@@ -43,6 +43,9 @@ enum {
 const char* mc_last_error(void);
 /* "metalchat-hip <version> gfx950" */
 const char* mc_version(void);
+/* 1 when every kernel launch is wrapped in a named range "name<grid,group>" (roctxRangePush / Pop; MC_TRACE_RANGES=1 and
+ * libroctx64 found) -- the reference labels every encoder that way for GPU capture, src/kernel_thread.cc:109-115 */
+int32_t mc_trace_ranges_enabled(void);
 
 /* ------------------------------------------------------------------------------------------
  * Part 1 -- backend seam

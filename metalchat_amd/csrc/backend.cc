@@ -7,12 +7,66 @@
 #include "backend_impl.h"
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 
 namespace {
 thread_local std::string g_last_error;
 }
+
+#include <dlfcn.h>
+namespace mcimpl {
+namespace {
+struct roctx_api {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    bool on = false;
+    roctx_api()
+    {
+        const char* e = getenv("MC_TRACE_RANGES");
+        if (!e || !*e || *e == '0') return;
+        // (the rocprofiler-sdk library first: that is the one rocprofv3 --marker-trace listens to; libroctx64 is the roctracer-era one)
+        for (const char* lib : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "/opt/rocm/lib/librocprofiler-sdk-roctx.so",
+                                "libroctx64.so", "libroctx64.so.4", "/opt/rocm/lib/libroctx64.so"}) {
+            void* h = dlopen(lib, RTLD_NOW | RTLD_GLOBAL);
+            if (!h) continue;
+            push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+            pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+            if (push && pop) {
+                on = true;
+                return;
+            }
+        }
+        fprintf(stderr, "metalchat_amd: MC_TRACE_RANGES is set but no roctx library could be loaded: no ranges\n");
+    }
+};
+roctx_api&
+roctx()
+{
+    static roctx_api api;
+    return api;
+}
+} // namespace
+bool
+trace_ranges_enabled()
+{
+    return roctx().on;
+}
+launch_range::launch_range(const char* name, unsigned gx, unsigned gy, unsigned gz, unsigned bx, unsigned by, unsigned bz)
+{
+    roctx_api& r = roctx();
+    if (!r.on) return;
+    char label[256];
+    snprintf(label, sizeof label, "%s<%u,%u,%u,%u,%u,%u>", name, gx, gy, gz, bx, by, bz);
+    r.push(label);
+    on = true;
+}
+launch_range::~launch_range()
+{
+    if (on) roctx().pop();
+}
+} // namespace mcimpl
 
 namespace mcimpl {
 
@@ -45,6 +99,12 @@ const char*
 mc_version(void)
 {
     return "metalchat-hip 0.1.0 gfx950";
+}
+
+int32_t
+mc_trace_ranges_enabled(void)
+{
+    return mcimpl::trace_ranges_enabled() ? 1 : 0;
 }
 
 // ---------------------------------------------------------------- device
@@ -402,6 +462,7 @@ mc_encoder_dispatch_threads_lds(mc_queue* q, const size_t grid[3], const size_t 
     size_t arg_size = q->args.size();
     void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, q->args.data(), HIP_LAUNCH_PARAM_BUFFER_SIZE,
                      &arg_size, HIP_LAUNCH_PARAM_END};
+    mcimpl::launch_range range(q->cur->name.c_str(), b[0], b[1], b[2], (unsigned)group[0], (unsigned)group[1], (unsigned)group[2]);
     hipError_t e = hipModuleLaunchKernel(q->cur->fn, b[0], b[1], b[2], (unsigned)group[0],
                                          (unsigned)group[1], (unsigned)group[2], (unsigned)lds_bytes,
                                          q->stream, nullptr, extra);

@@ -47,6 +47,16 @@ struct mc_queue {
 namespace mcimpl {
 mc_status fail(mc_status code, const std::string& msg);
 mc_status hip_fail(hipError_t e, const char* what);
+// A named range around every kernel launch, as the reference labels every encoder "name<grid,group>" for GPU capture
+// (src/kernel_thread.cc:109-115): roctxRangePush / Pop from libroctx64 (found with dlopen, so nothing links against it),
+// on when MC_TRACE_RANGES=1 -- `rocprofv3 --marker-trace --kernel-trace` then shows the launches under their names.
+// Launches recorded into a hipGraph are labelled once, when they are captured.
+struct launch_range {
+    explicit launch_range(const char* name, unsigned gx, unsigned gy, unsigned gz, unsigned bx, unsigned by, unsigned bz);
+    ~launch_range();
+    bool on = false;
+};
+bool trace_ranges_enabled();
 } // namespace mcimpl
 
 #define MC_HIP(expr)                                              \

@@ -331,6 +331,7 @@ struct mc_decoder {
         size_t n = a.buf.size();
         void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, a.buf.data(), HIP_LAUNCH_PARAM_BUFFER_SIZE,
                          &n, HIP_LAUNCH_PARAM_END};
+        mcimpl::launch_range range(name.c_str(), gx, gy, gz, bx, 1, 1);
         hipError_t e = hipModuleLaunchKernel(f, gx, gy, gz, bx, 1, 1, lds, stream, nullptr, extra);
         if (e != hipSuccess) return hip_fail(e, name.c_str());
         return MC_OK;

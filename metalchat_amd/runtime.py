@@ -70,6 +70,7 @@ def capi() -> C.CDLL:
     P = {
         "mc_last_error": (C.c_char_p, []),
         "mc_version": (C.c_char_p, []),
+        "mc_trace_ranges_enabled": (i32, []),
         "mc_device_create": (i32, [i32, pvp]),
         "mc_device_release": (None, [vp]),
         "mc_device_name": (C.c_char_p, [vp]),
