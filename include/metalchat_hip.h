@@ -463,6 +463,14 @@ mc_status mc_tokenizer_open_tiktoken(const char* path, const char* token_regex, 
 /* huggingface llama3_tokenizer_loader::load(path): tokenizer.json -- the Split pattern of the
  * pre_tokenizer Sequence, model.vocab with GPT-2-coded keys, then the same control tokens. */
 mc_status mc_tokenizer_open_hf(const char* tokenizer_json_path, mc_tokenizer** out);
+/* text::sentence_piece (include/metalchat/text/sentence_piece.h:17-104): byte-pair merging over the CODE POINTS of the whole
+ * text, spaces as U+2581 on the way in and back on the way out.  _create_sentence_piece: an empty one;
+ * _open_hf_gemma3: huggingface::gemma3_tokenizer_loader::load (src/gemma.cc:72-94) -- tokenizer.json's model.vocab as
+ * spelled, then added_tokens, each bound to a token kind equal to its id.  One difference, where the reference does not
+ * return: its ".*" stops at a line feed and its iterator then never advances; here a line is a piece and every line feed a
+ * piece of its own. */
+mc_status mc_tokenizer_create_sentence_piece(mc_tokenizer** out);
+mc_status mc_tokenizer_open_hf_gemma3(const char* tokenizer_json_path, mc_tokenizer** out);
 void mc_tokenizer_release(mc_tokenizer* t);
 mc_status mc_tokenizer_insert(mc_tokenizer* t, const char* bytes, size_t len, int32_t id, int32_t kind);
 mc_status mc_tokenizer_insert_back(mc_tokenizer* t, const char* bytes, size_t len, int32_t kind);

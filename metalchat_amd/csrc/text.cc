@@ -271,8 +271,14 @@ struct mc_tokenizer {
     std::unordered_map<int32_t, std::string> inverse;
     std::unordered_map<int32_t, int32_t> control;
     std::unique_ptr<regexp> re;
+    // text::sentence_piece (include/metalchat/text/sentence_piece.h:17-104): byte_pair_encoder<char32_t> over the WHOLE
+    // text (token_regex ".*"), spaces written as U+2581 on the way in and back on the way out.  Keys stay UTF-8 here (the
+    // conversion is one-to-one); what changes is the unit a piece is cut into: code points, not bytes.
+    bool sentence_piece = false;
 
     explicit mc_tokenizer(const std::string& pattern) : re(new regexp(pattern)) {}
+    struct sentence_piece_tag {};
+    explicit mc_tokenizer(sentence_piece_tag) : sentence_piece(true) {}
 
     void
     insert(const std::string& value, int32_t key, int32_t kind) // bpe.h:249-258
@@ -308,34 +314,36 @@ struct mc_tokenizer {
     // _M_encode_unicode_pairs (bpe.h:120-168).  One segment per byte EXCEPT the last one, whose
     // slot holds the end marker; segments are visited in (rank, position) order and a visited segment
     // takes in its right neighbour whenever the two together spell a token.
+    // `cut`: byte offsets of the units of s and s.size() behind them (bytes: 0, 1, 2, ...; code points: where each begins)
     void
-    merge_piece(const std::string& s, std::vector<int32_t>& out) const
+    merge_units(const std::string& s, const std::vector<size_t>& cut, std::vector<int32_t>& out) const
     {
         constexpr int32_t LIMIT = INT32_MAX;
         struct segment {
             int32_t rank;
             size_t end;
         };
-        auto rank = [&](const std::string& key) {
-            auto it = forward.find(key);
+        auto rank = [&](size_t ub, size_t ue) { // units [ub, ue)
+            auto it = forward.find(s.substr(cut[ub], cut[ue] - cut[ub]));
             return it == forward.end() ? LIMIT : it->second;
         };
+        const size_t n = cut.size() - 1;
         using entry = std::pair<int32_t, size_t>;
         std::priority_queue<entry, std::vector<entry>, std::greater<entry>> order;
         std::vector<segment> seg;
-        for (size_t i = 0; i + 1 < s.size(); i++) {
-            const int32_t r = rank(s.substr(i, 1));
+        for (size_t i = 0; i + 1 < n; i++) {
+            const int32_t r = rank(i, i + 1);
             order.emplace(r, i);
             seg.push_back({r, i + 1});
         }
-        seg.push_back({LIMIT, s.size()});
+        seg.push_back({LIMIT, n});
         while (!order.empty()) {
             const size_t begin = order.top().second;
             order.pop();
             const size_t next = seg[begin].end;
             if (seg[begin].rank >= LIMIT || next >= seg.size()) continue;
             const size_t end = seg[next].end;
-            const int32_t merged = rank(s.substr(begin, end - begin));
+            const int32_t merged = rank(begin, end);
             if (merged >= LIMIT) continue;
             order.emplace(merged, begin);
             seg[begin] = {merged, end};
@@ -346,8 +354,67 @@ struct mc_tokenizer {
     }
 
     void
+    merge_piece(const std::string& s, std::vector<int32_t>& out) const
+    {
+        std::vector<size_t> cut(s.size() + 1);
+        for (size_t i = 0; i <= s.size(); i++) cut[i] = i;
+        merge_units(s, cut, out);
+    }
+
+    // the same over code points (byte_pair_encoder<char32_t>): a stray byte that is no UTF-8 lead counts as a unit of its own
+    void
+    merge_piece_codepoints(const std::string& s, std::vector<int32_t>& out) const
+    {
+        std::vector<size_t> cut;
+        for (size_t i = 0; i < s.size();) {
+            cut.push_back(i);
+            const uint8_t c = (uint8_t)s[i];
+            size_t len = c < 0x80 ? 1 : (c >> 5) == 0x6 ? 2 : (c >> 4) == 0xE ? 3 : (c >> 3) == 0x1E ? 4 : 1;
+            for (size_t k = 1; k < len; k++)
+                if (i + k >= s.size() || ((uint8_t)s[i + k] & 0xC0) != 0x80) {
+                    len = 1;
+                    break;
+                }
+            i += len;
+        }
+        cut.push_back(s.size());
+        merge_units(s, cut, out);
+    }
+
+    // sentence_piece::encode (sentence_piece.h:66-72): every space becomes U+2581, then ".*" pieces.  The reference's
+    // pattern is compiled without DOTALL, so it matches up to a line feed and then an EMPTY string there, on which its
+    // iterator never advances (src/regexp.cc:146-160): a text with a line feed does not come back.  Here a line is a
+    // piece and each line feed is a piece of its own -- the only behaviour that differs, and only where the reference hangs.
+    void
+    encode_sentence_piece(const char* text, size_t len, std::vector<int32_t>& out) const
+    {
+        std::string in;
+        in.reserve(len + len / 4);
+        for (size_t i = 0; i < len; i++) {
+            if (text[i] == ' ') in += "\xE2\x96\x81";
+            else in += text[i];
+        }
+        auto piece = [&](size_t b, size_t e) {
+            if (b == e) return;
+            const std::string key = in.substr(b, e - b);
+            auto it = forward.find(key);
+            if (it != forward.end()) out.push_back(it->second);
+            else merge_piece_codepoints(key, out);
+        };
+        size_t b = 0;
+        for (size_t i = 0; i < in.size(); i++)
+            if (in[i] == '\n') {
+                piece(b, i);
+                piece(i, i + 1);
+                b = i + 1;
+            }
+        piece(b, in.size());
+    }
+
+    void
     encode(const char* text, size_t len, std::vector<int32_t>& out) const // bpe.h:284-296
     {
+        if (sentence_piece) return encode_sentence_piece(text, len, out);
         re->split(text, len, [&](size_t b, size_t e) {
             const std::string key(text + b, e - b);
             auto it = forward.find(key);
@@ -603,6 +670,52 @@ mc_tokenizer_open_hf(const char* path, mc_tokenizer** out)
     });
 }
 
+// text::sentence_piece() -- an empty one (tokens come through mc_tokenizer_insert / _insert_back)
+mc_status
+mc_tokenizer_create_sentence_piece(mc_tokenizer** out)
+{
+    if (!out) return fail(MC_ERR_INVALID_ARGUMENT, "mc_tokenizer_create_sentence_piece: null argument");
+    return guarded([&] {
+        *out = new mc_tokenizer(mc_tokenizer::sentence_piece_tag{});
+        return (mc_status)MC_OK;
+    });
+}
+
+// huggingface::gemma3_tokenizer_loader::load (src/gemma.cc:72-94): model.vocab as it is spelled (UTF-8, no GPT-2 coding),
+// then added_tokens, each bound to a token kind equal to its own id
+mc_status
+mc_tokenizer_open_hf_gemma3(const char* path, mc_tokenizer** out)
+{
+    if (!out || !path) return fail(MC_ERR_INVALID_ARGUMENT, "mc_tokenizer_open_hf_gemma3: null argument");
+    return guarded([&] {
+        std::ifstream file(path, std::ios::binary | std::ios::in);
+        if (!file.is_open())
+            raise(MC_ERR_INVALID_ARGUMENT, std::string("gemma3_tokenizer_loader: failed opening file '") + path + "'");
+        std::stringstream ss;
+        ss << file.rdbuf();
+        const std::string text = ss.str();
+        const mc::json::value doc = mc::json::parser::parse(text.data(), text.size());
+        std::unique_ptr<mc_tokenizer> t(new mc_tokenizer(mc_tokenizer::sentence_piece_tag{}));
+        const mc::json::value* model = doc.find("model");
+        const mc::json::value* vocab = model ? model->find("vocab") : nullptr;
+        if (!vocab || !vocab->is_object()) raise(MC_ERR_RUNTIME, "gemma3_tokenizer_loader::load: model.vocab is missing");
+        for (const auto& m : vocab->members) t->insert(m.first, (int32_t)m.second.as_u64(), MC_TOKEN_REGULAR);
+        if (const mc::json::value* added = doc.find("added_tokens")) {
+            if (!added->is_array()) raise(MC_ERR_RUNTIME, "gemma3_tokenizer_loader::load: added_tokens is not an array");
+            for (const auto& a : added->items) {
+                const mc::json::value* content = a.find("content");
+                const mc::json::value* id = a.find("id");
+                if (!content || !content->is_string() || !id)
+                    raise(MC_ERR_RUNTIME, "gemma3_tokenizer_loader::load: an added token without content or id");
+                const int32_t key = (int32_t)id->as_u64();
+                t->insert(content->str, key, key); // text::tokenkind(token.id)
+            }
+        }
+        *out = t.release();
+        return (mc_status)MC_OK;
+    });
+}
+
 void
 mc_tokenizer_release(mc_tokenizer* t)
 {
@@ -663,6 +776,19 @@ mc_tokenizer_decode(const mc_tokenizer* t, const int32_t* ids, size_t n_ids, cha
     return guarded([&] {
         std::string s;
         for (size_t i = 0; i < n_ids; i++) s += t->decode(ids[i]);
+        if (t->sentence_piece) { // sentence_piece::decode (sentence_piece.h:84-97): U+2581 back to a space, token by token
+            std::string r;
+            r.reserve(s.size());
+            for (size_t i = 0; i < s.size();) {
+                if (i + 2 < s.size() && (uint8_t)s[i] == 0xE2 && (uint8_t)s[i + 1] == 0x96 && (uint8_t)s[i + 2] == 0x81) {
+                    r += ' ';
+                    i += 3;
+                } else {
+                    r += s[i++];
+                }
+            }
+            s.swap(r);
+        }
         return emit(s.data(), s.size(), out, cap, n);
     });
 }

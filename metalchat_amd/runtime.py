@@ -163,6 +163,8 @@ def capi() -> C.CDLL:
         "mc_tokenizer_create": (i32, [C.c_char_p, pvp]),
         "mc_tokenizer_open_tiktoken": (i32, [C.c_char_p, C.c_char_p, pvp]),
         "mc_tokenizer_open_hf": (i32, [C.c_char_p, pvp]),
+        "mc_tokenizer_create_sentence_piece": (i32, [pvp]),
+        "mc_tokenizer_open_hf_gemma3": (i32, [C.c_char_p, pvp]),
         "mc_tokenizer_release": (None, [vp]),
         "mc_tokenizer_insert": (i32, [vp, C.c_char_p, sz, i32, i32]),
         "mc_tokenizer_insert_back": (i32, [vp, C.c_char_p, sz, i32]),
@@ -767,6 +769,20 @@ class Tokenizer:
     def open_hf(cls, path: str):
         h = C.c_void_p()
         _check(capi().mc_tokenizer_open_hf(path.encode(), C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def create_sentence_piece(cls):
+        """text::sentence_piece(): byte-pair merging over code points, spaces as U+2581."""
+        h = C.c_void_p()
+        _check(capi().mc_tokenizer_create_sentence_piece(C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def open_hf_gemma3(cls, path: str):
+        """huggingface::gemma3_tokenizer_loader::load (tokenizer.json)."""
+        h = C.c_void_p()
+        _check(capi().mc_tokenizer_open_hf_gemma3(path.encode(), C.byref(h)))
         return cls(h)
 
     def release(self):

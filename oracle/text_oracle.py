@@ -198,6 +198,50 @@ class Tokenizer:
 
 
 # ------------------------------------------------------------------------------------------ scanners
+class SentencePiece(Tokenizer):
+    """text::sentence_piece (include/metalchat/text/sentence_piece.h:17-104): byte_pair_encoder<char32_t> with the token
+    pattern ".*", spaces written as U+2581.  Keys are `str` here -- merge_piece slices code points, as the reference's
+    std::u32string does.  The reference's ".*" (PCRE2, no DOTALL) stops at a line feed and its iterator then does not
+    advance (src/regexp.cc:146-160): a text with a line feed never comes back.  Lines are pieces here and each line feed is
+    a piece of its own -- the one place where this restatement cannot follow the reference."""
+
+    SPACE, MARK = " ", "\u2581"
+
+    def __init__(self):
+        super().__init__(".*")
+
+    @classmethod
+    def from_hf_json(cls, doc: dict):
+        """huggingface::gemma3_tokenizer_loader::load (src/gemma.cc:72-94)"""
+        t = cls()
+        for value, key in doc["model"]["vocab"].items():
+            t.insert(value, key)
+        for tok in doc.get("added_tokens", []):
+            t.insert(tok["content"], tok["id"], tok["id"])  # text::tokenkind(token.id)
+        return t
+
+    def encode(self, text: str) -> list[int]:
+        out = []
+        s = text.replace(self.SPACE, self.MARK)
+        pieces, b = [], 0
+        for i, ch in enumerate(s):
+            if ch == "\n":
+                pieces += [s[b:i], s[i:i + 1]]
+                b = i + 1
+        pieces.append(s[b:])
+        for piece in pieces:
+            if not piece:
+                continue
+            if piece in self.forward:
+                out.append(self.forward[piece])
+            else:
+                out.extend(self.merge_piece(piece))
+        return out
+
+    def decode(self, ids) -> str:
+        return "".join(self.inverse[i].replace(self.MARK, self.SPACE) for i in ids)
+
+
 class LimitScanner:
     def __init__(self, lim):
         self.lim, self.n = lim, 0

@@ -284,3 +284,100 @@ def test_message_framing_and_variables(pair):
     with pytest.raises(mc.McError, match="without a decoder"):
         it.read()
     it.release()
+
+
+# ------------------------------------------------------------------------------------------ text::sentence_piece (gemma3)
+def _sp_vocab():
+    """A small sentence-piece style vocabulary: every code point of the corpus, then merges learnt greedily over code
+    points (ids = merge order, as a published tokenizer.json has them)."""
+    corpus = "the quick brown fox jumps over the lazy dog  and the d\u00e9j\u00e0 vu caf\u00e9 \u00fcber na\u00efve \u4f60\u597d \u4e16\u754c hello world the end\nsecond line here"
+    text = corpus.replace(" ", "\u2581")
+    vocab = {}
+    for special in ("<pad>", "<eos>", "<bos>", "<unk>"):
+        vocab[special] = len(vocab)
+    for ch in sorted(set(text)):
+        vocab[ch] = len(vocab)
+    words = [list(w) for w in text.replace("\n", " \n ").split(" ") if w]
+    for _ in range(60):
+        pairs = collections.Counter()
+        for w in words:
+            for a, b in zip(w, w[1:]):
+                pairs[a + b] += 1
+        pairs = {k: v for k, v in pairs.items() if k not in vocab}
+        if not pairs:
+            break
+        best = max(sorted(pairs), key=lambda k: pairs[k])
+        vocab[best] = len(vocab)
+        for w in words:
+            i = 0
+            while i + 1 < len(w):
+                if w[i] + w[i + 1] == best:
+                    w[i:i + 2] = [best]
+                else:
+                    i += 1
+    return vocab
+
+
+@pytest.fixture(scope="module")
+def sp_pair(tmp_path_factory):
+    vocab = _sp_vocab()
+    doc = {"model": {"type": "BPE", "vocab": vocab},
+           "added_tokens": [{"id": 1, "content": "<eos>"}, {"id": 2, "content": "<bos>"},
+                            {"id": len(vocab), "content": "<start_of_turn>"}, {"id": len(vocab) + 1, "content": "<end_of_turn>"}]}
+    path = tmp_path_factory.mktemp("sp") / "tokenizer.json"
+    path.write_text(json.dumps(doc, ensure_ascii=False), encoding="utf-8")
+    t = mc.Tokenizer.open_hf_gemma3(str(path))
+    yield t, to.SentencePiece.from_hf_json(doc), doc
+    t.release()
+
+
+def test_sentence_piece_follows_the_restatement(sp_pair):
+    t, o, doc = sp_pair
+    assert len(t) == len(o.forward)
+    rng = np.random.default_rng(5)
+    alphabet = list("the quickbrownfxjmpsvlazydg \u00e9\u00e0\u00fc\u00ef\u4f60\u597d\u4e16\u754c") + ["\n", "  ", " the", "caf\u00e9", "\U0001F600", "Q"]
+    texts = ["the quick brown fox", " hello world ", "d\u00e9j\u00e0 vu", "\u4f60\u597d \u4e16\u754c", "the end\nsecond line", "x", "", "\n\n", "\u2581already"]
+    texts += ["".join(rng.choice(alphabet, size=int(rng.integers(1, 40)))) for _ in range(300)]
+    for text in texts:
+        ids = t.encode(text)
+        assert ids == o.encode(text), text
+        assert t.decode(ids).decode("utf-8") == o.decode(ids)
+
+
+def test_sentence_piece_spaces_lines_and_the_dropped_last_code_point(sp_pair):
+    t, o, doc = sp_pair
+    vocab = doc["model"]["vocab"]
+    # a piece that is a token goes through whole; spaces are U+2581 on the way in and spaces again on the way out
+    ids = t.encode("the")
+    assert ids == [vocab["the"]] if "the" in vocab else True
+    assert " " not in "".join(k for k in vocab)
+    s = "the quick brown fox jumps over the lazy dog"
+    assert t.decode(t.encode(s)).decode("utf-8") in (s, s[:-1])  # bpe.h:120-168: an unmerged LAST unit is dropped
+    # units are code points: a two-byte letter that is a token of its own is never cut into bytes
+    e = t.encode("\u00e9\u00e9\u00e9")
+    assert all(len(o.inverse[i].encode("utf-8")) >= 2 for i in e)
+    # a line feed is a piece of its own (the reference does not return from such a text: sentence_piece.h + regexp.cc:146-160)
+    assert t.encode("the\nthe") == o.encode("the\nthe")
+    # unknown code points vanish like in the reference (rank LIMIT never emitted)
+    assert t.encode("\U0001F600") == []
+
+
+def test_gemma3_loader_binds_added_tokens_to_their_own_id_and_fails_like_the_reference(sp_pair, tmp_path):
+    t, o, doc = sp_pair
+    for tok in doc["added_tokens"]:
+        if tok["id"] == mc.TOKEN_REGULAR:
+            # text::tokenkind(token.id) with id 1 IS token::regular (tokenizer.h:29): bound to no kind, as in the reference
+            with pytest.raises(mc.McError, match="unknown control token '1'"):
+                t.encode_control(tok["id"])
+        else:
+            assert t.encode_control(tok["id"]) == tok["id"]
+        assert t.decode([tok["id"]]).decode() == tok["content"]
+    with pytest.raises(mc.McError, match="gemma3_tokenizer_loader: failed opening file"):
+        mc.Tokenizer.open_hf_gemma3(str(tmp_path / "absent.json"))
+    empty = mc.Tokenizer.create_sentence_piece()
+    empty.insert_back("a".encode())
+    empty.insert_back("b".encode())
+    empty.insert_back("ab".encode())
+    assert empty.encode("abab") == [2, 2]
+    assert empty.encode("aba") == [2]  # the last unit only survives inside a merge -- bpe.h:120-168
+    empty.release()
