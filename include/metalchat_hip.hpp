@@ -482,6 +482,24 @@ public:
         return byte_pair_encoder(t);
     }
 
+    /// text::sentence_piece() (include/metalchat/text/sentence_piece.h:31-33): merging over code points, spaces as U+2581
+    static byte_pair_encoder
+    sentence_piece()
+    {
+        mc_tokenizer* t = nullptr;
+        check(mc_tokenizer_create_sentence_piece(&t));
+        return byte_pair_encoder(t);
+    }
+
+    /// huggingface::gemma3_tokenizer_loader::load (src/gemma.cc:72-94)
+    static byte_pair_encoder
+    load_gemma3(const std::string& tokenizer_json)
+    {
+        mc_tokenizer* t = nullptr;
+        check(mc_tokenizer_open_hf_gemma3(tokenizer_json.c_str(), &t));
+        return byte_pair_encoder(t);
+    }
+
     void insert(const std::string& value, index_type key, int32_t kind = MC_TOKEN_REGULAR) { check(mc_tokenizer_insert(_M_tok.get(), value.data(), value.size(), key, kind)); }
     void insert_back(const std::string& value, int32_t kind = MC_TOKEN_REGULAR) { check(mc_tokenizer_insert_back(_M_tok.get(), value.data(), value.size(), kind)); }
     std::size_t size() const { return mc_tokenizer_size(_M_tok.get()); }
