@@ -184,6 +184,16 @@ struct mc_decoder {
     void* taps = nullptr;       // T[(n_own+1)*dim]
     step_state_h* state = nullptr;
     int32_t* tokens_dev = nullptr;
+    // the greedy pick inside the output head's launch (gemv.h EPI_STORE_PICK): two descriptors {key*, ticket*, state*, tokens_out*}
+    // -- [0, 32) with the atomic key at [64, 72) and the ticket at [72, 76), both zero between launches; [32, 64) with pick_keys
+    // and no ticket
+    char* pick_desc = nullptr;
+    unsigned long long* pick_keys = nullptr; // MC_HEAD_PICK=2: one key per workgroup of the head's launch, folded by mc_argmax_keys
+    static constexpr unsigned pick_slots = 1024;
+    int head_pick_mode = 2;
+    bool head_pick_on = true;    // MC_HEAD_PICK: 0 = mc_argmax_T behind the head (round 1); 1 = the pick wholly inside the head's launch (atomic max
+                                 // + ticket per workgroup: parity-green, 1448 vs 1449 us per token -- the atomics cost what the launch costs);
+                                 // 2 = one key per workgroup + mc_argmax_keys, a one-workgroup launch over 8 KB instead of 256 KB of logits
     int tokens_cap = 0;
     // sampler (nn/sampling.h:303-313); kind 0 = greedy argmax, 1 = topk -> nucleus -> multinomial
     int sampler_kind = MC_SAMPLER_GREEDY;
@@ -756,10 +766,18 @@ struct mc_decoder {
     {
         const float mu = cfg.family == MC_FAMILY_GEMMA3 ? 1.0f : 0.0f;
         // final norm + output head (llama.h:128-133) + greedy pick
+        // greedy on a linear-order head kernel: the pick rides in the head's own launch (gemv.h EPI_STORE_PICK; the post-norm
+        // prologue passes its row through `res`, so that variant keeps the argmax launch)
+        const bool pick = sampler_kind == MC_SAMPLER_GREEDY && head_pick_on && !pending_pn && lin_waves == 8 && !output.lora_cols &&
+                          (lin_ok(output) || ling_kib(output)) && cfg.vocab % 2 == 0;
         mc_status s = pending_pn ? gemv(output, 2, 0, proj, logits, pending_pn, final_norm, mu)
-                                 : gemv(output, 1, 0, hidden, logits, nullptr, final_norm, mu);
+                                 : gemv(output, 1, pick ? 5 : 0, hidden, logits,
+                                        pick ? (const void*)(pick_desc + (head_pick_mode == 2 ? 32 : 0)) : nullptr, final_norm, mu);
         pending_pn = nullptr;
         if (s != MC_OK) return s;
+        if (pick && head_pick_mode == 2)
+            return launch("mc_argmax_keys", 1, 1, 1, 256, 0, pack((const void*)pick_keys, (uint32_t)pick_slots, state, tokens_dev));
+        if (pick) return MC_OK;
         if (sampler_kind == MC_SAMPLER_GREEDY)
             return launch("mc_argmax_" + tname, 1, 1, 1, 1024, 0,
                           pack(logits, (uint32_t)cfg.vocab, state, tokens_dev));
@@ -1101,6 +1119,15 @@ mc_decoder_create(mc_device* dev, mc_library* lib, mc_queue* q, const mc_decoder
     A(d->state, sizeof(step_state_h));
     d->tokens_cap = 1 << 16;
     A(d->tokens_dev, (size_t)d->tokens_cap * 4);
+    A(d->pick_desc, 128);
+    A(d->pick_keys, (size_t)mc_decoder::pick_slots * 8);
+    {
+        const void* desc[8] = {d->pick_desc + 64, d->pick_desc + 72, d->state, d->tokens_dev, // [0, 32): atomic key + ticket
+                               d->pick_keys, nullptr, d->state, d->tokens_dev};                 // [32, 64): one key per workgroup
+        MC_HIP(hipMemcpy(d->pick_desc, desc, sizeof desc, hipMemcpyHostToDevice));
+    }
+    if (const char* e = getenv("MC_HEAD_PICK")) d->head_pick_mode = std::max(0, std::min(2, atoi(e)));
+    d->head_pick_on = d->head_pick_mode != 0;
     d->rope_rows = 2 * c.max_seq_len; // nn/embedding.h:171: _M_seq_len(max_seq_len * 2)
     A(d->rope_cos[0], (size_t)d->rope_rows * (hd / 2) * 4);
     A(d->rope_sin[0], (size_t)d->rope_rows * (hd / 2) * 4);

@@ -686,6 +686,24 @@ argmax_body(const typename T::S* logits, uint32_t n, step_state* st, int32_t* to
         if (tokens_out) tokens_out[st->step_index] = (int32_t)idx;
     }
 }
+// the output head left one (value, lowest index) key per workgroup (gemv.h EPI_STORE_PICK, pick_key): the largest key is the pick
+extern "C" __global__ void __launch_bounds__(256)
+mc_argmax_keys(const unsigned long long* keys, uint32_t n, step_state* st, int32_t* tokens_out)
+{
+    __shared__ unsigned long long wk[4];
+    unsigned long long k = 0ull;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) k = max(k, keys[i]);
+    for (int off = 32; off >= 1; off >>= 1) k = max(k, (unsigned long long)__shfl_xor(k, off, 64));
+    if ((threadIdx.x & 63) == 0) wk[threadIdx.x >> 6] = k;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (uint32_t w = 1; w < (blockDim.x >> 6); w++) k = max(k, wk[w]);
+        const int32_t token = (int32_t)(0xFFFFFFFFu - (uint32_t)k);
+        st->token = token;
+        if (tokens_out) tokens_out[st->step_index] = token;
+    }
+}
+
 extern "C" __global__ void
 mc_argmax_bfloat(const bf16_t* logits, uint32_t n, step_state* st, int32_t* tokens_out)
 {

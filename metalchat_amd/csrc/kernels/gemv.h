@@ -57,7 +57,27 @@ struct postnorm_args {
     const void* res;    // T[in]
     void* h_out;        // T[in]
 };
-enum { EPI_STORE = 0, EPI_RESID = 1, EPI_SILU_MUL = 2, EPI_GELU_MUL = 3, EPI_QKV_ROPE = 4 };
+enum { EPI_STORE = 0, EPI_RESID = 1, EPI_SILU_MUL = 2, EPI_GELU_MUL = 3, EPI_QKV_ROPE = 4, EPI_STORE_PICK = 5 };
+// EPI_STORE_PICK (linear-order kernels): EPI_STORE + the greedy pick of the stored row, so the output head needs no argmax
+// launch behind it.  `res` points at this descriptor.  Every lane that finishes a pair keeps the best (value, lowest index)
+// it has seen as ONE 64-bit key; a wave folds its lanes, the workgroup's waves meet in LDS, the last of them hands the
+// workgroup's key to `key` with an agent-scope atomic max and takes a ticket; the workgroup whose ticket is the last reads the
+// final key back, writes the token where mc_argmax_T writes it and clears key and ticket for the next launch.
+struct pick_epilogue {
+    unsigned long long* key; // 0 between launches
+    uint32_t* ticket;        // 0 between launches; NULL: `key` has one slot per workgroup and a one-workgroup launch folds them
+    int32_t* state;          // step_state: [0] = token, [5] = step_index
+    int32_t* tokens_out;     // may be null
+};
+// larger float <=> larger key; equal floats (-0 = +0) <=> the LOWER index wins: mc_argmax_T's "first index of the maximum"
+__device__ __forceinline__ unsigned long long
+pick_key(float v, uint32_t index)
+{
+    uint32_t u = __float_as_uint(v);
+    if (u == 0x80000000u) u = 0u;
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    return ((unsigned long long)u << 32) | (unsigned long long)(0xFFFFFFFFu - index);
+}
 
 // EPI_QKV_ROPE: the fused wq|wk|wv GEMV finishes RoPE and the sink-cache write itself
 // (kernel/rope.metal:49-59 + nn/cache.h:209-213), so q, k and v never make a round trip through
@@ -785,6 +805,12 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
     // LDS: the activation row, zero-padded to a whole number of chunks, then 32 floats of scratch
     char* xs = smem;
     float* red = reinterpret_cast<float*>(smem + (size_t)nchunks * CHUNK_LDS);
+    static_assert(EPI != EPI_STORE_PICK || ((LNCH > 0 || LGEN > 0) && LWAVES > 0 && LWAVES <= 8 && LKS == 1), "the pick rides on the linear-order kernels");
+    if (EPI == EPI_STORE_PICK && threadIdx.x == 0) { // the workgroup's key and arrival count (pick_finish): the scratch's last floats,
+        red[24] = 0.0f;                              // which no prologue of an eight-wave workgroup touches; a prologue barrier follows
+        red[25] = 0.0f;
+        red[26] = 0.0f;
+    }
 
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     // Everything that is the same for the 64 lanes of a wavefront is kept in SGPRs: the wave index
@@ -877,6 +903,41 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
     uint32_t eo_res = 0, eo_slot = 0, eo_rrow = 0;
     float eo_c = 0.0f, eo_s = 0.0f;
     qkv_epilogue eo_q = {};
+    unsigned long long pick_best = 0ull; // EPI_STORE_PICK: the best key this lane has finished
+    // the tail of EPI_STORE_PICK, run by every wave of the launch exactly once, after its last flush
+    auto pick_finish = [&](float* red_, uint32_t nwaves_) {
+        unsigned long long k = pick_best;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const unsigned long long o = __shfl_xor(k, off, 64);
+            k = max(k, o);
+        }
+        if (lane == 0) {
+            unsigned long long* wg_key = reinterpret_cast<unsigned long long*>(red_ + 24);
+            uint32_t* wg_count = reinterpret_cast<uint32_t*>(red_ + 26);
+            (void)__hip_atomic_fetch_max(wg_key, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const uint32_t arrived = __hip_atomic_fetch_add(wg_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (arrived == nwaves_ - 1) { // a wave's LDS operations complete in order: every wave's key is in
+                const pick_epilogue pe_ = *static_cast<const pick_epilogue*>(resp);
+                const unsigned long long wk = __hip_atomic_load(wg_key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (pe_.ticket == nullptr) { // no ticket: `key` is an array, one slot per workgroup, folded by mc_argmax_keys behind this launch
+                    ((__attribute__((address_space(1))) unsigned long long*)pe_.key)[blockIdx.x] = wk;
+                    return;
+                }
+                const unsigned long long before = __hip_atomic_fetch_max(pe_.key, wk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("" ::"v"(before)); // the ticket is taken only when the maximum has been applied
+                const uint32_t t = __hip_atomic_fetch_add(pe_.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (t == gridDim.x - 1) {
+                    const unsigned long long fin = __hip_atomic_fetch_max(pe_.key, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const int32_t token = (int32_t)(0xFFFFFFFFu - (uint32_t)fin);
+                    pe_.state[0] = token;
+                    if (pe_.tokens_out) pe_.tokens_out[pe_.state[5]] = token;
+                    __hip_atomic_store(pe_.key, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(pe_.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+    };
     auto finish_pair = [&](uint32_t pair, float a, float b, bool early = false) {
         const uint32_t row = 2 * pair;
         if (row >= out_rows) return;
@@ -898,8 +959,12 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
             }
         }
         S* y = static_cast<S*>(yp);
-        if (EPI == EPI_STORE || EPI == EPI_RESID) {
+        if (EPI == EPI_STORE || EPI == EPI_RESID || EPI == EPI_STORE_PICK) {
             float va = T::rt(a), vb = T::rt(b);
+            if (EPI == EPI_STORE_PICK) {
+                const unsigned long long ka = pick_key(va, row), kb = two ? pick_key(vb, row + 1) : 0ull;
+                pick_best = max(pick_best, max(ka, kb));
+            }
             if (EPI == EPI_RESID) { // add in T
                 if (early && T::bytes == 2) {
                     va = asf(eo_res << 16) + va;
@@ -1442,6 +1507,7 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
         static_assert(PP % RS == 0, "a pair is a whole number of ring turns");
         for (uint32_t pr = pb; pr < pe; pr++) pair_g(pr);
         flush();
+        if (EPI == EPI_STORE_PICK) pick_finish(red, nwaves);
         return;
     }
     if constexpr (LNCH > 0) {
@@ -2145,6 +2211,7 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
         } else {
             flush();
         }
+        if (EPI == EPI_STORE_PICK) pick_finish(red, nwaves);
         if (MC_GEMV_LIN_DECOUPLE && lin_dummy == 0x12345678u) static_cast<uint32_t*>(yp)[0] = 1;
         if (MC_GEMV_LIN_TL && lane == 0) {
             unsigned long long* tl = const_cast<unsigned long long*>(static_cast<const unsigned long long*>(resp));

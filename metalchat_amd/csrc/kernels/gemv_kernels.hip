@@ -47,7 +47,9 @@ using namespace mc::gemv;
     MC_GEMV_LIN(PFX##_p2_e0, 2, 0, __VA_ARGS__) \
     MC_GEMV_LIN(PFX##_p2_e3, 2, 3, __VA_ARGS__) \
     MC_GEMV_LIN(PFX##_p3_e0, 3, 0, __VA_ARGS__) \
-    MC_GEMV_LIN(PFX##_p3_e1, 3, 1, __VA_ARGS__)
+    MC_GEMV_LIN(PFX##_p3_e1, 3, 1, __VA_ARGS__) \
+    MC_GEMV_LIN(PFX##_p1_e5, 1, 5, __VA_ARGS__) \
+    MC_GEMV_LIN(PFX##_p2_e5, 2, 5, __VA_ARGS__)
 
 #define MC_GEMV_SET(PFX, WF, T, QM)            \
     MC_GEMV(PFX##_p0_e0, WF, T, QM, 0, 0)      \
@@ -124,7 +126,8 @@ MC_GEMV_LINK2(mc_gemv_i4_bfloat_lin14k2_p0_e1, 1, 14)
     MC_GEMV_LING(PFX##_p1_e3, WF, 1, 3, NCH)    \
     MC_GEMV_LING(PFX##_p1_e4, WF, 1, 4, NCH)    \
     MC_GEMV_LING(PFX##_p3_e0, WF, 3, 0, NCH)    \
-    MC_GEMV_LING(PFX##_p3_e1, WF, 3, 1, NCH)
+    MC_GEMV_LING(PFX##_p3_e1, WF, 3, 1, NCH)    \
+    MC_GEMV_LING(PFX##_p1_e5, WF, 1, 5, NCH)
 #if MC_LIN_WAVES
 MC_GEMV_LING_SET(mc_gemv_i8_bfloat_ling4, WF_I8, 4)   // K = 4096
 // (K = 14336 int8 rows: 14 x 8 VGPRs of activations do not fit in registers and the unrolled pair spills; the classic kernel is faster there: 13.3 vs 15.4 us)

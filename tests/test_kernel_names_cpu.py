@@ -27,6 +27,7 @@ def symbols():
 # prologue / epilogue pairs run_layers(), run_head() and mc_decoder_time_gemv() launch (gemv_kernels.hip MC_GEMV_SET)
 PE = ["p0_e0", "p1_e0", "p0_e1", "p1_e2", "p1_e3", "p1_e4", "p2_e0", "p2_e3"]
 PE_FOLD = ["p3_e0", "p3_e1"]  # P.V range sums added by the Wo prologue: linear-order kernels only
+PE_PICK = ["p1_e5", "p2_e5"]  # the greedy pick inside the output head's launch (gemv.h EPI_STORE_PICK): linear-order kernels only
 
 
 def test_classic_gemv_family_is_complete(symbols):
@@ -38,11 +39,11 @@ def test_classic_gemv_family_is_complete(symbols):
 def test_linear_order_families_are_complete(symbols):
     want = []
     for nch in (1, 2, 4, 7, 14):  # decoder.cc lin_ok(): int4 rows of whole KiB
-        want += [f"mc_gemv_i4_bfloat_lin{nch}_{pe}" for pe in PE + PE_FOLD]
+        want += [f"mc_gemv_i4_bfloat_lin{nch}_{pe}" for pe in PE + PE_FOLD + PE_PICK]
     for nch in (4,):  # decoder.cc ling_kib(): int8
-        want += [f"mc_gemv_i8_bfloat_ling{nch}_{pe}" for pe in PE + PE_FOLD if not pe.startswith("p2")]
+        want += [f"mc_gemv_i8_bfloat_ling{nch}_{pe}" for pe in PE + PE_FOLD + PE_PICK if not pe.startswith("p2")]
     for nch in (4, 8, 11, 16):  # ... and plain bfloat weights
-        want += [f"mc_gemv_w_bfloat_ling{nch}_{pe}" for pe in PE + PE_FOLD if not pe.startswith("p2")]
+        want += [f"mc_gemv_w_bfloat_ling{nch}_{pe}" for pe in PE + PE_FOLD + PE_PICK if not pe.startswith("p2")]
     missing = [n for n in want if n not in symbols]
     assert not missing, missing
 
@@ -52,7 +53,7 @@ def test_decode_and_reference_kernels_present(symbols):
         for k in ("mc_attn_scores", "mc_attn_pv", "mc_attn_pv_reduce", "mc_embed", "mc_embed_q8", "mc_argmax", "mc_rope_kv",
                   "mc_rmsnorm_row", "mc_topk_candidates", "mc_sample"):
             assert f"{k}_{t}" in symbols, f"{k}_{t}"
-    for k in ("mc_step_set", "mc_step_advance", "mc_step_rope", "mc_rope_table"):
+    for k in ("mc_step_set", "mc_step_advance", "mc_step_rope", "mc_rope_table", "mc_argmax_keys"):
         assert k in symbols, k
     # the reference's own kernel names (ABI part 1, kernel/kernel.h:30-90)
     for k in ("rmsnorm_bfloat", "softmax_bfloat", "bmm_8_float", "hadamard_broadcast_bfloat_int8_t_float"):
