@@ -258,6 +258,7 @@ struct mc_decoder {
     bool lin_ksplit = false;     // MC_LIN_KSPLIT=1: w2's K range cut between two waves (sixteen per workgroup): measured SLOWER (10.2 vs 8.8 us)
     bool gemv_ling = true;       // MC_GEMV_LING=0: int8 / bfloat weights on the classic kernels (A/B)
     bool lin_lds_ring = false;   // MC_LIN_LDS_RING=1 for code objects built with -DMC_GEMV_LIN_LDSRING=1 (they need the rings' LDS)
+    bool ling_half = true;       // MC_LING_HALF=0: whole row pairs per wave whatever the matrix (A/B)
     bool pv_fold_on = true;      // MC_PV_FOLD=0: P.V ranges reduced by their own launch (A/B, parity)
     int lin_waves = 8;           // MC_LIN_WAVES: tuning builds of the linear-order kernels with another workgroup size
     bool gemv_block_env = false; // MC_GEMV_BLOCK / MC_GEMV_WGS_PER_CU given: they apply to every kernel of the family
@@ -541,6 +542,10 @@ struct mc_decoder {
             cap = cus * (gemv_block_env ? (unsigned)gemv_wgs_per_cu : 1u);
             const unsigned np = (unsigned)L.out / 2;
             wgs = (np + waves - 1) / waves;
+            // fewer pairs than half the waves a full grid has (the 2048-row matrices of the small models) and an epilogue that
+            // treats the rows of a pair separately: one ROW per wave (gemv.h LGEN, `half`)
+            if (ling_half && (epi == 0 || epi == 1) && !L.lora_cols && 2u * np <= cap * waves && (unsigned)L.out % 2 == 0)
+                wgs = std::max(wgs, std::min(cap, ((unsigned)L.out + waves - 1) / waves));
             if (wgs > cap) wgs = cap;
             if (wgs > cus) wgs = wgs / cus * cus;
         }
@@ -1079,6 +1084,7 @@ mc_decoder_create(mc_device* dev, mc_library* lib, mc_queue* q, const mc_decoder
     if (const char* e = getenv("MC_GEMV_FULLGRID")) d->gemv_full_grid = atoi(e) != 0;
     if (const char* e = getenv("MC_GEMV_LIN")) d->gemv_lin = atoi(e) != 0;
     if (const char* e = getenv("MC_PV_FOLD")) d->pv_fold_on = atoi(e) != 0;
+    if (const char* e = getenv("MC_LING_HALF")) d->ling_half = atoi(e) != 0;
     if (const char* e = getenv("MC_GEMV_LING")) d->gemv_ling = atoi(e) != 0;
     if (const char* e = getenv("MC_LIN_KSPLIT")) d->lin_ksplit = atoi(e) != 0;
     if (const char* e = getenv("MC_LIN_LDS_RING")) d->lin_lds_ring = atoi(e) != 0;

@@ -1290,6 +1290,9 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
                       // either way; 464-466 tokens/s at S = 8192 both) -- off, the row sums keep the classic kernels' order
 #endif
         constexpr bool I8M = MC_GEMV_I8M && WF == WF_I8;
+#ifndef MC_GEMV_LING_HALF
+#define MC_GEMV_LING_HALF 1
+#endif
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
         uint32_t never;
         asm volatile("s_mov_b32 %0, 0" : "=s"(never));
@@ -1321,9 +1324,15 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
         // ---- the wave's range of row pairs
         const uint32_t nw_total = gridDim.x * nwaves, gw = blockIdx.x * nwaves + wave;
         const uint32_t NP = (out_rows + 1) / 2;
+        // ONE ROW PER WAVE when the launch has at least two waves per row pair (small models: 2048 rows of Wo / w2 are 1024
+        // pairs for 2048 waves -- with whole pairs half the waves had nothing to do and the other half streamed a pair
+        // each through four KiB in flight) and the epilogue treats the rows of a pair separately: wave gw takes row gw
+        constexpr bool HALF_OK = MC_GEMV_LING_HALF && (EPI == EPI_STORE || EPI == EPI_RESID);
+        const bool half = HALF_OK && 2u * NP <= nw_total;
         const uint32_t pq = NP / nw_total, prem = NP - pq * nw_total;
-        const uint32_t pb = gw * pq + min(gw, prem);
-        const uint32_t pe = pb + pq + (gw < prem ? 1u : 0u);
+        const uint32_t pb = half ? gw >> 1 : gw * pq + min(gw, prem);
+        const uint32_t pe = half ? pb + (gw < out_rows ? 1u : 0u) : pb + pq + (gw < prem ? 1u : 0u);
+        const uint32_t hrow = gw & 1u, toff = half ? hrow * (uint32_t)LGEN : 0u; // (half) the wave's row of its pair; its first packet
         const char* sbase = static_cast<const char*>(sp);
         const uint32_t eo_pair = min(pb + lane, NP - 1);
         if (EPI == EPI_RESID) {
@@ -1338,8 +1347,8 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
             if (never) asm volatile("" ::"s"(eo_slot), "s"(eo_rrow), "s"(eo_q.H), "s"(eo_q.KV), "s"(eo_q.hd), "s"(eo_q.max_seq));
         }
         // packet t of pair pr: row 2 pr + t / LGEN, KiB t % LGEN of it (dead packets: one broadcast line of the buffer base)
-        auto gload = [&](uint4& dst, uint32_t pr, int t, bool live) {
-            const uint64_t rb = ((uint64_t)pr * 2 + (uint64_t)(t / LGEN)) * rowb + (uint64_t)(t % LGEN) * 1024;
+        auto gload = [&](uint4& dst, uint32_t pr, uint32_t t, bool live) {
+            const uint64_t rb = ((uint64_t)pr * 2 + (uint64_t)(t / (uint32_t)LGEN)) * rowb + (uint64_t)(t % (uint32_t)LGEN) * 1024;
             const uint32_t lm = 0u - (uint32_t)live;
             const char* a = wbase + (rb & (((uint64_t)lm << 32) | lm));
             const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a + (lane16 & lm)));
@@ -1363,7 +1372,10 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
         if (MC_GEMV_XBAR) asm volatile("s_barrier" ::: "memory");
         gscales(gsa, pb, pb < pe);
 #pragma unroll
-        for (int j = 0; j < RS; j++) gload(gring[j], pb + j / PP, j % PP, pb + j / PP < pe);
+        for (int j = 0; j < RS; j++) {
+            if (HALF_OK && half) gload(gring[j], pb, toff + (uint32_t)j, pb < pe && j < LGEN);
+            else gload(gring[j], pb + j / PP, j % PP, pb + j / PP < pe);
+        }
         // ---- the row into LDS (natural order: these formats read their 16-byte slices straight)
         {
             rowv4* xl = reinterpret_cast<rowv4*>(xs);
@@ -1505,6 +1517,48 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
             }
         };
         static_assert(PP % RS == 0, "a pair is a whole number of ring turns");
+        if (HALF_OK && half) {
+            // the wave's one row: packets toff .. toff + LGEN of its pair, the same ring, finished by lane 0 at once
+            if (pb < pe) {
+                float accf = 0.f;
+#pragma unroll
+                for (int c = 0; c < LGEN; c++) {
+                    const int slot = c % RS;
+                    float sc = 1.0f;
+                    if constexpr (SCALED) sc = hrow ? asf(gsa[c] & 0xFFFF0000u) : asf(gsa[c] << 16);
+                    if constexpr (I8M) {
+                        if constexpr (XREG) {
+                            mac8b_n<1>(acc4, gring[slot], m4b_prepare(__float_as_uint(sc), i8k), gx[c]);
+                        } else {
+                            xregs<T, KPL> x;
+                            x.load(xs + (size_t)c * CHUNK * 2 + lane_xb, 0);
+                            mac8b_n<1>(acc4, gring[slot], m4b_prepare(__float_as_uint(sc), i8k), x);
+                        }
+                    } else if constexpr (XREG) {
+                        mac<Q_EXACT>(accf, gring[slot], sc, gx[c], 0.0f, static_cast<F*>(nullptr));
+                    } else {
+                        xregs<T, KPL> x;
+                        x.load(xs + (size_t)c * CHUNK * 2 + lane_xb, 0);
+                        mac<Q_EXACT>(accf, gring[slot], sc, x, 0.0f, static_cast<F*>(nullptr));
+                    }
+                    if (c + RS < LGEN) gload(gring[slot], pb, toff + (uint32_t)(c + RS), true);
+                    if (never) asm volatile("s_nop 0"); // ends the basic block: the refill stays behind its packet
+                }
+                if constexpr (I8M) {
+                    const uint32_t e = lane & 3;
+                    accf = (e == 0 ? acc4[0][0] : (e == 1 ? acc4[0][1] : (e == 2 ? acc4[0][2] : acc4[0][3]))) * 0x1p37f;
+                }
+                const float rs = wave_sum_dpp(accf);
+                const uint32_t row = 2 * pb + hrow;
+                if (lane == 0 && row < out_rows) {
+                    // finish_pair's arithmetic for one row of the pair: T(sum), the residual added in T
+                    float v = T::rt(rs);
+                    if (EPI == EPI_RESID) v = (hrow ? asf(eo_res & 0xFFFF0000u) : asf(eo_res << 16)) + v;
+                    static_cast<S*>(yp)[row] = T::st(v);
+                }
+            }
+            return;
+        }
         for (uint32_t pr = pb; pr < pe; pr++) pair_g(pr);
         flush();
         if (EPI == EPI_STORE_PICK) pick_finish(red, nwaves);
