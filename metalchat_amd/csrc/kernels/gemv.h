@@ -1715,7 +1715,12 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
             // (masks, not selects: given a select between two addresses hipcc builds a branch, and a load behind a branch
             //  costs every counted s_waitcnt vmcnt(N))
             const uint32_t lm = 0u - (uint32_t)live;
-            const char* a = wbase + (rb & (((uint64_t)lm << 32) | lm));
+#ifndef MC_GEMV_LIN_DEADOWN
+#define MC_GEMV_LIN_DEADOWN 0 // 1: dead tiles re-read the wave's OWN first line instead of the buffer's first line, which every wave of the launch
+#endif                        // requests TPP times at its end (one hot line per XCD?).  Measured: no difference (w1|w3 13.2 / 13.3, QKV 6.4 / 6.5 us) -- off
+            const uint64_t lm64 = ((uint64_t)lm << 32) | lm;
+            const uint64_t dead = MC_GEMV_LIN_DEADOWN ? (uint64_t)min(pb, NP - 1) * 2 * rowb : 0ull;
+            const char* a = wbase + ((rb & lm64) | (dead & ~lm64));
             const uint32_t lo = lane16 & lm;
 #pragma unroll
             for (int p = 0; p < LTP; p++) {
