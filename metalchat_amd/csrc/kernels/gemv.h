@@ -1695,10 +1695,31 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
         }
         const uint32_t nw_total = gridDim.x * nwp, gw = blockIdx.x * nwp + (LKS == 2 ? wave - khalf * nwp : wave);
         const uint32_t NP = (out_rows + 1) / 2; // row pairs (the host takes this path only for even out_rows)
+#ifndef MC_GEMV_LIN_ROWS
+#define MC_GEMV_LIN_ROWS 0
+#endif
+        // ROW-GRANULAR SPANS (MC_GEMV_LIN_ROWS=1; the QKV kernel of K = 4096): 3072 row pairs are 1.5 per wave -- with whole pairs
+        // half the waves of a CU stream two and the other half one, and the launch lasts as long as two (tools/lin_timeline.py: a
+        // pair takes a wave 1.5 us whatever its neighbours do).  Here a WORKGROUP owns whole pairs and its rows are dealt evenly
+        // over its waves: a wave's span may begin or end in the middle of a pair.  It is swept as before in steps of two rows
+        // ("pseudo pairs", row offset `roff` against the real ones; the arithmetic of a row that is another wave's is skipped),
+        // the row sums go to a workgroup-wide array in LDS and the pairs are finished behind a barrier, thread t the workgroup's
+        // pair t.  MEASURED (parity-green: the full-size, context, golden and decode tests): QKV 6.5 -> 6.9 us, 689 / 697 / 682 ->
+        // 691 / 694 / 676 tokens/s -- three rows each are no faster than two pairs for half the waves (two scale loads per
+        // chunk where a pair has one dword, a workgroup barrier, twelve epilogues in one wave).  Off.
+        constexpr bool LROW = MC_GEMV_LIN_ROWS && EPI == EPI_QKV_ROPE && LNCH == 2 && LTP == 1 && LKS == 1 && LWAVES > 0 && LRING == 0 && LEAN &&
+                              !MC_GEMV_LIN_TL && !MC_GEMV_LIN_STREAM && !MC_GEMV_LIN_NOLOAD && !MC_GEMV_LIN_DECOUPLE && !MC_GEMV_LIN_LDSRING && !MC_GEMV_LIN_RAWPARK;
         // equal ranges to within one pair, without a 64-bit division: the first NP % nw_total waves take one pair more
         const uint32_t pq = NP / nw_total, prem = NP - pq * nw_total;
-        const uint32_t pb = gw * pq + min(gw, prem);
-        const uint32_t pe = pb + pq + (gw < prem ? 1u : 0u);
+        // (LROW) the workgroup's pairs [wp0, wp1), its rows [2 wp0, 2 wp1) dealt over the waves: this wave's rows [rwb, rwe)
+        const uint32_t wpq = NP / gridDim.x, wprem = NP - wpq * gridDim.x;
+        const uint32_t wp0 = blockIdx.x * wpq + min(blockIdx.x, wprem), wp1 = wp0 + wpq + (blockIdx.x < wprem ? 1u : 0u);
+        const uint32_t wrows = 2u * (wp1 - wp0), rq = wrows / nwp, rrem = wrows - rq * nwp;
+        const uint32_t rwb = min(2u * wp0 + wave * rq + min(wave, rrem), out_rows);
+        const uint32_t rwe = min(rwb + rq + (wave < rrem ? 1u : 0u), out_rows);
+        const uint32_t roff = LROW ? (rwb & 1u) : 0u;
+        const uint32_t pb = LROW ? rwb >> 1 : gw * pq + min(gw, prem);
+        const uint32_t pe = LROW ? pb + (rwe - rwb + 1u) / 2u : pb + pq + (gw < prem ? 1u : 0u);
         const char* sbase = static_cast<const char*>(sp);
 
         uint4 lring[LR][LTP];
@@ -1711,7 +1732,8 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
             // address costs ONE vector instruction (the per-lane 64-bit form cost ~ 10 per tile)
             const uint32_t chunk0 = (LKS == 2 ? cbase : 0u) + (uint32_t)(t % SUB) * LTP;
             if (LKS == 2) live = live && chunk0 < (uint32_t)LNCH;
-            const uint64_t rb = ((uint64_t)pr * 2 + (uint64_t)(t / SUB)) * rowb + (uint64_t)chunk0 * 1024;
+            if (LROW) live = live && pr * 2 + roff + (uint32_t)(t / SUB) < rwe; // (the second row of the span's last step may not be the wave's)
+            const uint64_t rb = ((uint64_t)pr * 2 + roff + (uint64_t)(t / SUB)) * rowb + (uint64_t)chunk0 * 1024;
             // (masks, not selects: given a select between two addresses hipcc builds a branch, and a load behind a branch
             //  costs every counted s_waitcnt vmcnt(N))
             const uint32_t lm = 0u - (uint32_t)live;
@@ -1737,6 +1759,24 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
         // scales of pair pr: half a row quad ([ngroups][4] bf16 per four rows) per chunk; the lane's 32 weights of
         // chunk c sit in group (2048 c + 32 lane) / group
         auto lscales = [&](uint32_t (&q)[LNCH], uint32_t pr, bool live) {
+            if constexpr (LROW) {
+                // rows 2 pr + roff and the one behind it: element (row, g) of the quad layout sits at ((row / 4) ngroups + g) 4 + row % 4;
+                // with roff = 1 the two are not one dword (and may sit in different quads): two 2-byte loads
+                const uint32_t r0 = min(pr * 2 + roff, out_rows - 1), r1 = min(r0 + 1, out_rows - 1);
+                const uint32_t lm = 0u - (uint32_t)live;
+                const uint64_t u0 = ((uint64_t)(r0 >> 2) * ngroups * 4 + (r0 & 3u)) * 2, u1 = ((uint64_t)(r1 >> 2) * ngroups * 4 + (r1 & 3u)) * 2;
+                const uint64_t lm64 = ((uint64_t)lm << 32) | lm;
+                const char* a0 = sbase + (u0 & lm64);
+                const char* a1 = sbase + (u1 & lm64);
+#pragma unroll
+                for (int c = 0; c < LNCH; c++) {
+                    const uint32_t g = group ? ((2048u * (uint32_t)c + 32u * lane) >> glog) : 0u;
+                    const uint32_t lo = *reinterpret_cast<const uint16_t*>(a0 + ((g * 8u) & lm));
+                    const uint32_t hi = *reinterpret_cast<const uint16_t*>(a1 + ((g * 8u) & lm));
+                    q[c] = lo | (hi << 16);
+                }
+                return;
+            }
             const uint64_t ub = (((uint64_t)(pr >> 1) * ngroups) * 4 + (pr & 1u) * 2) * 2; // wave-uniform part
             const uint32_t lm = 0u - (uint32_t)live;
             const char* a = sbase + (ub & (((uint64_t)lm << 32) | lm));
@@ -1763,7 +1803,7 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
         constexpr int U = LR >= TPP ? LR / TPP : 1; // pairs per unrolled iteration
         // an opaque zero: `if (lin_never) use(v)` keeps the load of v in front of that point (a value needed on both
         // sides of a branch cannot be sunk to its later use) without waiting for it on the path that is taken
-        const uint32_t eo_pair = min(pb + lane, NP - 1); // the pair this lane will finish in the wave's first flush
+        const uint32_t eo_pair = LROW ? min(wp0 + tid, NP - 1) : min(pb + lane, NP - 1); // the pair this lane will finish in the wave's first flush
         if (EPI == EPI_RESID && T::bytes == 2) {
             eo_res = reinterpret_cast<const uint32_t*>(resp)[eo_pair];
             if (lin_never) asm volatile("" ::"v"(eo_res));
@@ -2182,6 +2222,8 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
 #pragma unroll
             for (int t = 0; t < TPP; t++) {
                 const int r = t / SUB, sidx = t % SUB, slot = LR >= TPP ? SLOT0 + t : t % LR;
+                // (row-granular spans) the second row of the span's last step is another wave's: nothing to multiply, nothing to refill
+                if (LROW && r == 1 && 2 * pr + roff + 1 >= rwe) continue;
 #pragma unroll
                 for (int p = 0; p < LTP; p++) {
                     const int c = sidx * LTP + p;
@@ -2250,9 +2292,19 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
                     for (int a = 0; a < NA; a++) laccs[a] = mf_f4{0, 0, 0, 0};
                 }
             }
-            if (!RAWPARK && lane == 0) park[parked] = make_float2(ra, rb);
-            parked++;
-            if (LKS == 1 && parked == (RAWPARK ? (uint32_t)PARKP : 64u)) flush(); // (K split: the host grants at most 64 pairs per wave)
+            if constexpr (LROW) {
+                // the workgroup's row sums, one float per row of its pairs (the parking space: 512 bytes per wave = 1024 rows)
+                float* rowsum = reinterpret_cast<float*>(park0);
+                const uint32_t row0 = 2 * pr + roff;
+                if (lane == 0) {
+                    if (row0 < rwe) rowsum[row0 - 2 * wp0] = ra;
+                    if (row0 + 1 < rwe) rowsum[row0 + 1 - 2 * wp0] = rb;
+                }
+            } else {
+                if (!RAWPARK && lane == 0) park[parked] = make_float2(ra, rb);
+                parked++;
+                if (LKS == 1 && parked == (RAWPARK ? (uint32_t)PARKP : 64u)) flush(); // (K split: the host grants at most 64 pairs per wave)
+            }
 #pragma unroll
             for (int c = 0; c < LNCH; c++) sa[c] = sb[c];
         };
@@ -2264,7 +2316,11 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
         if constexpr (U == 2) {
             if (pr < pe) do_pair(std::integral_constant<int, 0>{}, pr); // odd count: the last pair sits in the first slots
         }
-        if constexpr (LKS == 2) {
+        if constexpr (LROW) {
+            __syncthreads();
+            const float* rowsum = reinterpret_cast<const float*>(park0);
+            for (uint32_t t = tid; t < wp1 - wp0; t += BD) finish_pair(wp0 + t, rowsum[2 * t], rowsum[2 * t + 1], t == tid);
+        } else if constexpr (LKS == 2) {
             __syncthreads();
             if (khalf == 0) flush();
         } else {
