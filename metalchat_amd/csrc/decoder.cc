@@ -467,14 +467,14 @@ struct mc_decoder {
 
     // ---------------------------------------------------------------- launches
     // does this linear take the linear-order kernels (gemv.h)?  int4 on bfloat rows, exact arithmetic, scale groups of
-    // whole 128-weight lane blocks, rows of 1, 2, 4, 7 or 14 whole KiB, whole row groups
+    // whole 128-weight lane blocks, rows of 1, 2, 4, 7, 12 or 14 whole KiB, whole row groups
     bool
     lin_ok(const linear_w& L) const
     {
         const bool m4 = L.fmt == MC_WFMT_I4 && tb == 2 && cfg.qmode == MC_QMODE_EXACT && gemv_m4 && !dbg_variant;
         const bool m4d_ok = m4 && (L.group == 0 || L.group % 128 == 0) && L.in % 128 == 0;
         const int nch = L.in % 2048 == 0 ? L.in / 2048 : 0;
-        return gemv_lin && m4d_ok && L.out % 4 == 0 && (nch == 1 || nch == 2 || nch == 4 || nch == 7 || nch == 14);
+        return gemv_lin && m4d_ok && L.out % 4 == 0 && (nch == 1 || nch == 2 || nch == 4 || nch == 7 || nch == 12 || nch == 14);
     }
     // ... or the linear-order kernels of the VALU-dequantising formats (gemv.h LGEN): int8 / plain bfloat weights on
     // bfloat rows, rows of 4 (int8) or 4 / 8 / 11 / 16 (bfloat) whole KiB; returns that count, 0 = no

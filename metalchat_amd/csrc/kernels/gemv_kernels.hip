@@ -83,6 +83,9 @@ MC_GEMV_SET(mc_gemv_w_float, WF_T, F32, Q_EXACT)
 #ifndef MC_LIN7_CFG
 #define MC_LIN7_CFG 7, 1, 2 // K = 14336: 28 KB of activations per workgroup come in first; two KiB per wave behind them (w2: 12.0 -> 9.9 us)
 #endif
+#ifndef MC_LIN12_CFG
+#define MC_LIN12_CFG 12, 1, 2
+#endif
 #ifndef MC_LIN14_CFG
 #define MC_LIN14_CFG 14, 1, 2
 #endif
@@ -90,6 +93,7 @@ MC_GEMV_LIN_SET(mc_gemv_i4_bfloat_lin1, MC_LIN1_CFG)   // K = 2048
 MC_GEMV_LIN_SET(mc_gemv_i4_bfloat_lin2, MC_LIN2_CFG)   // K = 4096
 MC_GEMV_LIN_SET(mc_gemv_i4_bfloat_lin4, MC_LIN4_CFG)   // K = 8192
 MC_GEMV_LIN_SET(mc_gemv_i4_bfloat_lin7, MC_LIN7_CFG)   // K = 14336
+MC_GEMV_LIN_SET(mc_gemv_i4_bfloat_lin12, MC_LIN12_CFG) // K = 24576 (Gemma-7B's w2)
 MC_GEMV_LIN_SET(mc_gemv_i4_bfloat_lin14, MC_LIN14_CFG) // K = 28672
 
 // K split (gemv.h LKS = 2): sixteen waves per workgroup, a row pair's K range cut between two of them -- long rows with ONE

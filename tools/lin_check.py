@@ -14,7 +14,7 @@ WF = dict(i4=mc.WFMT_I4, i8=mc.WFMT_I8, w=mc.WFMT_T)[fmt]
 row_bytes = dict(i4=K // 2, i8=K, w=2 * K)[fmt]
 nch = row_bytes // 1024
 acc = mc.HardwareAccelerator(path=os.environ.get("MC_HSACO"))
-M = dict(dim=K, n_heads=K // 128, n_kv_heads=8, head_dim=128, ffn_dim=OUT // 2, n_layers=1, vocab=1024, rope_theta=500000.0, norm_eps=1e-5)
+M = dict(dim=K, n_heads=K // 128, n_kv_heads=max(8, K // 128 // 4), head_dim=128, ffn_dim=OUT // 2, n_layers=1, vocab=1024, rope_theta=500000.0, norm_eps=1e-5)
 dec = mc.Decoder(acc, dtype=mc.BF16, max_seq_len=64, attn_scale=0.088, weight_format=WF, group_size=(0 if fmt == "w" else 128), **M)
 dec.init_synthetic(3)
 wptr, sptr, rows, inf, ng = dec.weight_ptrs(0, "w13")
