@@ -2377,6 +2377,10 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
     const uint32_t m4d_mx = (lane & 3) == 0 ? 0x0000FFFFu : ((lane & 3) == 1 ? 0xFFFF0000u : 0u);
     const uint32_t m4d_my = (lane & 3) == 2 ? 0x0000FFFFu : ((lane & 3) == 3 ? 0xFFFF0000u : 0u);
 
+#ifndef MC_GEMV_M4B_CLASSIC
+#define MC_GEMV_M4B_CLASSIC 1
+#endif
+    const m4b_lane m4bk_c = m4b_lane_consts(lane);
     auto compute = [&](const tile<R>& t, uint32_t crg, uint32_t cc) {
         if constexpr (M4D) {
             typedef __attribute__((address_space(3))) mf_s4 lds_s4;
@@ -2388,7 +2392,13 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
             for (int r = 0; r < R; r++) {
                 const uint32_t raw = t.s[r >> 1];
                 const uint32_t s2 = (r & 1) ? ((raw & 0xFFFF0000u) | (raw >> 16)) : ((raw << 16) | (raw & 0xFFFFu));
-                mac4d(accv[r], t.w[r], m4d_prepare(s2, m4d_mx, m4d_my), x);
+                if (MC_GEMV_M4B_CLASSIC) { // whole bytes into the dequantising MFMA (mac4b_n): four bit operations per dword instead of seven
+                    mf_f4 one[1] = {accv[r]};
+                    mac4b_n<1>(one, t.w[r], m4b_prepare((r & 1) ? (raw & 0xFFFF0000u) : (raw << 16), m4bk_c), x);
+                    accv[r] = one[0];
+                } else {
+                    mac4d(accv[r], t.w[r], m4d_prepare(s2, m4d_mx, m4d_my), x);
+                }
             }
         } else {
             xregs<T, KPL> x;
@@ -2417,7 +2427,8 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
                 if constexpr (M4) {
                     // element lane % 4 of the lane's four results is its own dot product
                     const uint32_t e = lane & 3;
-                    const float mine = e == 0 ? accv[r][0] : (e == 1 ? accv[r][1] : (e == 2 ? accv[r][2] : accv[r][3]));
+                    float mine = e == 0 ? accv[r][0] : (e == 1 ? accv[r][1] : (e == 2 ? accv[r][2] : accv[r][3]));
+                    if (M4D && MC_GEMV_M4B_CLASSIC) mine *= 0x1p37f; // the sums were formed at 2^-M4B_Q (mac4b_n)
                     tot[r] = wave_sum_dpp(mine);
                     accv[r] = mf_f4{0, 0, 0, 0};
                 } else {
