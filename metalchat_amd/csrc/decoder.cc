@@ -258,6 +258,7 @@ struct mc_decoder {
     bool lin_ksplit = false;     // MC_LIN_KSPLIT=1: w2's K range cut between two waves (sixteen per workgroup): measured SLOWER (10.2 vs 8.8 us)
     bool gemv_ling = true;       // MC_GEMV_LING=0: int8 / bfloat weights on the classic kernels (A/B)
     bool lin_lds_ring = false;   // MC_LIN_LDS_RING=1 for code objects built with -DMC_GEMV_LIN_LDSRING=1 (they need the rings' LDS)
+    bool lin_split = true;       // MC_LIN_SPLIT=0: K = 3072 on the classic kernels (A/B)
     bool ling_half = true;       // MC_LING_HALF=0: whole row pairs per wave whatever the matrix (A/B)
     bool pv_fold_on = true;      // MC_PV_FOLD=0: P.V ranges reduced by their own launch (A/B, parity)
     int lin_waves = 8;           // MC_LIN_WAVES: tuning builds of the linear-order kernels with another workgroup size
@@ -476,6 +477,13 @@ struct mc_decoder {
         const int nch = L.in % 2048 == 0 ? L.in / 2048 : 0;
         return gemv_lin && m4d_ok && L.out % 4 == 0 && (nch == 1 || nch == 2 || nch == 4 || nch == 7 || nch == 12 || nch == 14);
     }
+    // ... rows of 1.5 KiB (K = 3072: Gemma-7B's QKV and w1|w3), two to a 3 KiB super row (gemv.h LSPLIT, `_lin3s_`)
+    bool
+    lin_split_ok(const linear_w& L) const
+    {
+        const bool m4 = L.fmt == MC_WFMT_I4 && tb == 2 && cfg.qmode == MC_QMODE_EXACT && gemv_m4 && !dbg_variant;
+        return gemv_lin && lin_split && m4 && L.group == 128 && L.in == 3072 && L.out % 4 == 0 && lin_waves == 8 && !L.lora_cols;
+    }
     // ... or the linear-order kernels of the VALU-dequantising formats (gemv.h LGEN): int8 / plain bfloat weights on
     // bfloat rows, rows of 4 (int8) or 4 / 8 / 11 / 16 (bfloat) whole KiB; returns that count, 0 = no
     int
@@ -532,7 +540,10 @@ struct mc_decoder {
         const int nch = L.in % 2048 == 0 ? L.in / 2048 : 0;
         const bool lin = lin_ok(L);
         bool ksplit = false;
-        const int ling = lin || pro == 2 ? 0 : ling_kib(L);
+        const int pe_code = pro * 10 + epi;
+        const bool lins = !lin && lin_split_ok(L) &&
+                          (pe_code == 0 || pe_code == 10 || pe_code == 1 || pe_code == 12 || pe_code == 13 || pe_code == 14 || pe_code == 20 || pe_code == 23);
+        const int ling = lin || lins || pro == 2 ? 0 : ling_kib(L);
         if (pro == 3 && !lin && !ling) return fail(MC_ERR_RUNTIME, "gemv: the partial-sum prologue exists for the linear-order kernels only");
         if (ling) {
             name += "_ling" + std::to_string(ling);
@@ -546,6 +557,18 @@ struct mc_decoder {
             // treats the rows of a pair separately: one ROW per wave (gemv.h LGEN, `half`)
             if (ling_half && (epi == 0 || epi == 1) && !L.lora_cols && 2u * np <= cap * waves && (unsigned)L.out % 2 == 0)
                 wgs = std::max(wgs, std::min(cap, ((unsigned)L.out + waves - 1) / waves));
+            if (wgs > cap) wgs = cap;
+            if (wgs > cus) wgs = wgs / cus * cus;
+        }
+        if (lins) {
+            // the loop's unit is a quad of rows (two super rows); one eight-wave workgroup per CU as below
+            name += "_lin3s";
+            block = 64u * (unsigned)lin_waves;
+            waves = (unsigned)lin_waves;
+            const unsigned cus = (unsigned)dev->prop.multiProcessorCount;
+            cap = cus * (gemv_block_env ? (unsigned)gemv_wgs_per_cu : 1u);
+            const unsigned nq = (unsigned)L.out / 4;
+            wgs = (nq + waves - 1) / waves;
             if (wgs > cap) wgs = cap;
             if (wgs > cus) wgs = wgs / cus * cus;
         }
@@ -574,6 +597,7 @@ struct mc_decoder {
                 ksplit = true;
             }
         }
+        else if (lins) {}
         else if (m4) name += m4d ? "_m4d" : "_m4";
         if (L.fmt == MC_WFMT_I4 && tb == 2 && dbg_variant && ((pro == 1 && epi == 2) || (pro == 0 && epi == 0)))
             name += dbg_variant == 1 ? "_dbgstream" : "_dbgnoload";
@@ -582,9 +606,10 @@ struct mc_decoder {
         const unsigned kpl = L.fmt == MC_WFMT_I4 ? 32 : (L.fmt == MC_WFMT_I8 ? 16 : (tb == 2 ? 8 : 4));
         const unsigned chunk = 64 * kpl;
         unsigned lds = (unsigned)((size_t)((L.in + chunk - 1) / chunk) * chunk * tb);
-        if (m4d || lin) lds = lds / 16 * 17; // 16 bytes of padding per 256 for the transposed reads
+        if (lins) lds = 3u * chunk * (unsigned)tb; // the row twice: [x, x] = three chunks of 2048
+        if (m4d || lin || lins) lds = lds / 16 * 17; // 16 bytes of padding per 256 for the transposed reads
         lds += 128;
-        if (lin || ling) lds += waves * 512; // parked row sums: 64 pairs x 8 bytes per wave (gemv.h PARKB)
+        if (lin || ling || lins) lds += waves * 512; // parked row sums: 64 pairs x 8 bytes per wave (gemv.h PARKB)
         if (ksplit) lds += waves * 512 + 4352; // sixteen waves park; one chunk of zero activations behind the row
         // the waves' DMA rings (gemv.h LDSR: rows of two or more KiB, build-time prologue): 7 or 8 KiB per wave
         // + two slots of scale dwords per wave (256 bytes per 64 scale groups)
@@ -1085,6 +1110,7 @@ mc_decoder_create(mc_device* dev, mc_library* lib, mc_queue* q, const mc_decoder
     if (const char* e = getenv("MC_GEMV_LIN")) d->gemv_lin = atoi(e) != 0;
     if (const char* e = getenv("MC_PV_FOLD")) d->pv_fold_on = atoi(e) != 0;
     if (const char* e = getenv("MC_LING_HALF")) d->ling_half = atoi(e) != 0;
+    if (const char* e = getenv("MC_LIN_SPLIT")) d->lin_split = atoi(e) != 0;
     if (const char* e = getenv("MC_GEMV_LING")) d->gemv_ling = atoi(e) != 0;
     if (const char* e = getenv("MC_LIN_KSPLIT")) d->lin_ksplit = atoi(e) != 0;
     if (const char* e = getenv("MC_LIN_LDS_RING")) d->lin_lds_ring = atoi(e) != 0;

@@ -758,7 +758,12 @@ template <int R> struct tile {
 // (0: read blockDim -- a dependent load from the hidden kernel arguments before anything else can be addressed).
 // LGEN: the linear-order loop for the formats that dequantise on the VALU (int8, plain bfloat weights), rows of LGEN whole KiB.
 // LKS = 2 (linear-order int4, long rows, plain prologue): the K range of a row pair is cut between TWO waves.
-template <int WF, typename T, int QM, int PRO, int EPI, int R, int LNCH = 0, int LTP = 0, int LRING = 0, int LWAVES = 0, int LGEN = 0, int LKS = 1>
+// LSPLIT (linear-order int4, LNCH = 3): rows of 1.5 KiB (K = 3072, Gemma-7B's QKV and w1|w3).  TWO rows are swept as one 3 KiB
+// "super row" against the activation row staged TWICE in LDS ([x, x]: chunk 1 is then x[2048..3071] | x[0..1023], exactly what
+// the two halves of the middle packet need with the unchanged lane mapping); one accumulator per packet, the middle one split
+// by a lane mask when the super row is complete.  A super row is a rotation / SiLU pair, so the epilogues see what they always
+// see; the loop's "pair" is two super rows = one quad of rows (and one quad of scales).
+template <int WF, typename T, int QM, int PRO, int EPI, int R, int LNCH = 0, int LTP = 0, int LRING = 0, int LWAVES = 0, int LGEN = 0, int LKS = 1, int LSPLIT = 0>
 __device__ __forceinline__ void
 body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __restrict__ xp,
      void* __restrict__ yp, const void* __restrict__ resp, const void* __restrict__ normp,
@@ -801,7 +806,7 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
     auto xpk = [](uint32_t p) { return M4D ? p + (p >> 4) : p; };
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const uint32_t nchunks = (in + CHUNK - 1) / CHUNK;
+    const uint32_t nchunks = LSPLIT ? (uint32_t)LNCH : (in + CHUNK - 1) / CHUNK; // (LSPLIT: the row twice, 1.5 chunks each)
     // LDS: the activation row, zero-padded to a whole number of chunks, then 32 floats of scratch
     char* xs = smem;
     float* red = reinterpret_cast<float*>(smem + (size_t)nchunks * CHUNK_LDS);
@@ -1631,7 +1636,7 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
         // 1160 (rmsnorm) instructions in front of the first multiply of a launch that lasts 5 - 16 us: its 1.3 - 1.7 us
         // from wave start to "row staged" were instruction issue, not memory latency (an idle memory system delivers
         // the row in 0.56 us, tools/floor_lab).  The row is requested FIRST, before the wave even works out its range.
-        constexpr bool LEAN = MC_GEMV_LIN_LEANPRO && LWAVES > 0 && PRO != PRO_POSTNORM;
+        constexpr bool LEAN = MC_GEMV_LIN_LEANPRO && LWAVES > 0 && PRO != PRO_POSTNORM && !LSPLIT; // (split rows: the generic staging, then the copy)
         static_assert(PRO != PRO_PARTS || LEAN, "PRO_PARTS needs the build-time prologue");
         constexpr uint32_t NPK = 256u * LNCH, BD = LWAVES ? 64u * LWAVES : 64u;
         constexpr int NXP = LEAN ? (int)((NPK + BD - 1) / BD) : 1;
@@ -1694,7 +1699,11 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
             if (lin_never) asm volatile("" ::"v"(PRO == PRO_PARTS ? __float_as_uint(lpr[0][0].x) : lxr[0].x)); // ends the basic block: the requests stay in front of what follows
         }
         const uint32_t nw_total = gridDim.x * nwp, gw = blockIdx.x * nwp + (LKS == 2 ? wave - khalf * nwp : wave);
-        const uint32_t NP = (out_rows + 1) / 2; // row pairs (the host takes this path only for even out_rows)
+        static_assert(!LSPLIT || (LNCH == 3 && LTP == 1 && LKS == 1 && LWAVES > 0), "split rows: 1.5 KiB each, two to a 3 KiB super row");
+        // (LSPLIT: the loop's pairs are pairs of SUPER rows = quads of rows; NPR counts the real pairs the epilogues finish)
+        const uint32_t NPR = (out_rows + 1) / 2;
+        const uint32_t NP = LSPLIT ? out_rows / 4 : NPR; // row pairs (the host takes this path only for even out_rows; LSPLIT: whole quads)
+        const size_t rowb_l = LSPLIT ? 2 * rowb : rowb;
 #ifndef MC_GEMV_LIN_ROWS
 #define MC_GEMV_LIN_ROWS 0
 #endif
@@ -1724,6 +1733,25 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
 
         uint4 lring[LR][LTP];
         uint32_t sa[LNCH], sb[LNCH]; // T(scale) of the pair's two rows per chunk: current pair, next pair
+        uint32_t sa2[LSPLIT ? LNCH : 1], sb2[LSPLIT ? LNCH : 1]; // (LSPLIT) ... of the second super row: rows 2 and 3 of the quad
+        // (LSPLIT) the lane's 32 weights of packet c belong to the super row's SECOND row when they lie past 3072
+        auto second_half = [&](int c) { return (2048u * (uint32_t)c + 32u * lane) >= 3072u; };
+        // (LSPLIT) the whole quad of scales of the lane's group: rows 0, 1 -> q, rows 2, 3 -> q2
+        auto lscales_quad = [&](uint32_t (&q)[LNCH], uint32_t (&q2)[LSPLIT ? LNCH : 1], uint32_t pr, bool live) {
+            if constexpr (LSPLIT != 0) {
+                const uint64_t ub = ((uint64_t)pr * ngroups) * 4 * 2; // quad pr: [ngroups][4] bf16
+                const uint32_t lm = 0u - (uint32_t)live;
+                const char* a = sbase + (ub & (((uint64_t)lm << 32) | lm));
+#pragma unroll
+                for (int c = 0; c < LNCH; c++) {
+                    const uint32_t ks = 2048u * (uint32_t)c + 32u * lane, k = ks >= 3072u ? ks - 3072u : ks;
+                    const uint32_t g = group ? (k >> glog) : 0u;
+                    const uint2 v = *reinterpret_cast<const uint2*>(a + ((g * 8u) & lm));
+                    q[c] = v.x;
+                    q2[c] = v.y;
+                }
+            }
+        };
         // tile t of pair pr: row 2 pr + t / SUB, KiB (t % SUB) * LTP ... of it.  Dead tiles read one broadcast line
         // of the buffer base.  (live ? offset : 0 is written as a mask: given a select between two address
         // computations hipcc builds a branch, and a load behind a branch costs every counted s_waitcnt vmcnt(N).)
@@ -1733,7 +1761,7 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
             const uint32_t chunk0 = (LKS == 2 ? cbase : 0u) + (uint32_t)(t % SUB) * LTP;
             if (LKS == 2) live = live && chunk0 < (uint32_t)LNCH;
             if (LROW) live = live && pr * 2 + roff + (uint32_t)(t / SUB) < rwe; // (the second row of the span's last step may not be the wave's)
-            const uint64_t rb = ((uint64_t)pr * 2 + roff + (uint64_t)(t / SUB)) * rowb + (uint64_t)chunk0 * 1024;
+            const uint64_t rb = ((uint64_t)pr * 2 + roff + (uint64_t)(t / SUB)) * rowb_l + (uint64_t)chunk0 * 1024;
             // (masks, not selects: given a select between two addresses hipcc builds a branch, and a load behind a branch
             //  costs every counted s_waitcnt vmcnt(N))
             const uint32_t lm = 0u - (uint32_t)live;
@@ -1741,7 +1769,7 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
 #define MC_GEMV_LIN_DEADOWN 0 // 1: dead tiles re-read the wave's OWN first line instead of the buffer's first line, which every wave of the launch
 #endif                        // requests TPP times at its end (one hot line per XCD?).  Measured: no difference (w1|w3 13.2 / 13.3, QKV 6.4 / 6.5 us) -- off
             const uint64_t lm64 = ((uint64_t)lm << 32) | lm;
-            const uint64_t dead = MC_GEMV_LIN_DEADOWN ? (uint64_t)min(pb, NP - 1) * 2 * rowb : 0ull;
+            const uint64_t dead = MC_GEMV_LIN_DEADOWN ? (uint64_t)min(pb, NP - 1) * 2 * rowb_l : 0ull;
             const char* a = wbase + ((rb & lm64) | (dead & ~lm64));
             const uint32_t lo = lane16 & lm;
 #pragma unroll
@@ -1803,7 +1831,7 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
         constexpr int U = LR >= TPP ? LR / TPP : 1; // pairs per unrolled iteration
         // an opaque zero: `if (lin_never) use(v)` keeps the load of v in front of that point (a value needed on both
         // sides of a branch cannot be sunk to its later use) without waiting for it on the path that is taken
-        const uint32_t eo_pair = LROW ? min(wp0 + tid, NP - 1) : min(pb + lane, NP - 1); // the pair this lane will finish in the wave's first flush
+        const uint32_t eo_pair = LSPLIT ? min(2 * pb + lane, NPR - 1) : (LROW ? min(wp0 + tid, NP - 1) : min(pb + lane, NP - 1)); // the pair this lane will finish in the wave's first flush
         if (EPI == EPI_RESID && T::bytes == 2) {
             eo_res = reinterpret_cast<const uint32_t*>(resp)[eo_pair];
             if (lin_never) asm volatile("" ::"v"(eo_res));
@@ -2073,7 +2101,8 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
             return;
         }
         auto lin_prefetch = [&] {
-            lscales(sa, pb, pb < pe);
+            if constexpr (LSPLIT != 0) lscales_quad(sa, sa2, pb, pb < pe);
+            else lscales(sa, pb, pb < pe);
 #pragma unroll
             for (int j = 0; j < LR; j++) ltile(lring[j], pb + j / TPP, j % TPP, pb + j / TPP < pe);
         };
@@ -2145,6 +2174,16 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
             stage_x(lin_prefetch);
         }
         __syncthreads();
+        if constexpr (LSPLIT != 0) {
+            // the row a second time, behind itself: [x, x] (16-byte packets; packet p sits in slot p + p / 16)
+            rowv4* xl2 = reinterpret_cast<rowv4*>(xs);
+            const uint32_t npk = in / 8;
+            for (uint32_t p = tid; p < npk; p += 64u * LWAVES) {
+                const rowv4 v = xl2[xpk(p)];
+                xl2[xpk(npk + p)] = v;
+            }
+            __syncthreads();
+        }
         if (MC_GEMV_LIN_TL) ltl[1] = __builtin_amdgcn_s_memrealtime();
         if (EPI == EPI_QKV_ROPE) {
             // the step state has long arrived: the table row of this lane's pair, behind the first ring tiles
@@ -2181,7 +2220,7 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
         char* park0 = reinterpret_cast<char*>(red + 32) + (LKS == 2 ? CHUNK_LDS : 0u);
         float2* park = reinterpret_cast<float2*>(park0 + wave * (LWAVES ? PARKB : 512u));
         float* praw = reinterpret_cast<float*>(park);
-        uint32_t parked = 0, park_first = pb;
+        uint32_t parked = 0, park_first = LSPLIT ? 2 * pb : pb;
         auto flush = [&]() {
             // one lane per parked pair (the LDS operations of a wave complete in order: no barrier needed)
             if (lane < parked) {
@@ -2201,7 +2240,7 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
                     finish_pair(park_first + lane, v.x + u.x, v.y + u.y, park_first == pb);
                 } else {
                     const float2 v = park[lane];
-                    finish_pair(park_first + lane, v.x, v.y, park_first == pb);
+                    finish_pair(park_first + lane, v.x, v.y, park_first == (LSPLIT ? 2 * pb : pb));
                 }
             }
             park_first += parked;
@@ -2210,6 +2249,7 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
 
         uint32_t lin_dummy = 0;
         constexpr int NA = MC_GEMV_LIN_ACCS;
+        mf_f4 laccs3[3] = {mf_f4{0, 0, 0, 0}, mf_f4{0, 0, 0, 0}, mf_f4{0, 0, 0, 0}}; // (LSPLIT) one per packet of the super row
         mf_f4 laccs[NA];
 #pragma unroll
         for (int a = 0; a < NA; a++) laccs[a] = mf_f4{0, 0, 0, 0};
@@ -2217,8 +2257,10 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
         // the pair U ahead as soon as it has been consumed.  Straight-line code: no branch, every load unconditional.
         auto do_pair = [&](auto slot0, uint32_t pr) {
             constexpr int SLOT0 = decltype(slot0)::value;
-            lscales(sb, pr + 1, pr + 1 < pe);
+            if constexpr (LSPLIT != 0) lscales_quad(sb, sb2, pr + 1, pr + 1 < pe);
+            else lscales(sb, pr + 1, pr + 1 < pe);
             float ra = 0.f, rb = 0.f;
+            float ra2 = 0.f, rb2 = 0.f; // (LSPLIT) the second super row's two sums
 #pragma unroll
             for (int t = 0; t < TPP; t++) {
                 const int r = t / SUB, sidx = t % SUB, slot = LR >= TPP ? SLOT0 + t : t % LR;
@@ -2243,6 +2285,16 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
                     } else if constexpr (XREG) {
                         if (MC_GEMV_M4B) mac4b_n<NA>(laccs, lring[slot][p], m4b_prepare(sf, m4bk), xr[c]);
                         else mac4d_n<NA>(laccs, lring[slot][p], m4d_prepare(s2, m4d_mx, m4d_my), xr[c]);
+                    } else if constexpr (LSPLIT != 0) {
+                        // packet c of the super row: its own accumulator (the middle packet is two rows' worth, split below);
+                        // the scale of the lane's row of the quad: super row r -> rows 2 r, 2 r + 1
+                        uint2 x[8];
+                        xload(x, c);
+                        const uint32_t dw = r ? sa2[c] : sa[c];
+                        const uint32_t sfl = second_half(c) ? (dw & 0xFFFF0000u) : (dw << 16);
+                        mf_f4 one[1] = {laccs3[c]};
+                        mac4b_n<1>(one, lring[slot][p], m4b_prepare(sfl, m4bk), x);
+                        laccs3[c] = one[0];
                     } else {
                         uint2 x[8];
                         xload(x, (LKS == 2 ? (int)cbase : 0) + c);
@@ -2271,7 +2323,19 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
                         if (ltn == (uint32_t)q) ltl[q] = now; // ltn is wave-uniform
                     ltn++;
                 }
-                if (sidx == SUB - 1) {
+                if (LSPLIT != 0 && sidx == SUB - 1) {
+                    // the super row is complete: packets 0 and 2 are whole rows' worth, the middle one is the first row's in
+                    // lanes 0..31 and the second row's in lanes 32..63
+                    const uint32_t e = lane & 3;
+                    auto diag = [&](const mf_f4& v) { return e == 0 ? v[0] : (e == 1 ? v[1] : (e == 2 ? v[2] : v[3])); };
+                    const float m0 = diag(laccs3[0]), m1 = diag(laccs3[1]), m2 = diag(laccs3[2]);
+                    const float fa = wave_sum_dpp((m0 + (lane < 32 ? m1 : 0.0f)) * 0x1p37f);
+                    const float fb = wave_sum_dpp((m2 + (lane < 32 ? 0.0f : m1)) * 0x1p37f);
+                    if (r == 0) { ra = fa; rb = fb; }
+                    else { ra2 = fa; rb2 = fb; }
+#pragma unroll
+                    for (int a = 0; a < 3; a++) laccs3[a] = mf_f4{0, 0, 0, 0};
+                } else if (sidx == SUB - 1) {
                     // the row is complete: element lane % 4 of the lane's four results is its own dot product
                     const uint32_t e = lane & 3;
                     mf_f4 lacc = laccs[0];
@@ -2300,6 +2364,13 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
                     if (row0 < rwe) rowsum[row0 - 2 * wp0] = ra;
                     if (row0 + 1 < rwe) rowsum[row0 + 1 - 2 * wp0] = rb;
                 }
+            } else if constexpr (LSPLIT != 0) {
+                if (lane == 0) {
+                    park[parked] = make_float2(ra, rb);       // real pair 2 pr     (rows 0, 1 of the quad)
+                    park[parked + 1] = make_float2(ra2, rb2); // real pair 2 pr + 1 (rows 2, 3)
+                }
+                parked += 2;
+                if (parked == 64u) flush();
             } else {
                 if (!RAWPARK && lane == 0) park[parked] = make_float2(ra, rb);
                 parked++;
@@ -2307,6 +2378,10 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
             }
 #pragma unroll
             for (int c = 0; c < LNCH; c++) sa[c] = sb[c];
+            if constexpr (LSPLIT != 0) {
+#pragma unroll
+                for (int c = 0; c < LNCH; c++) sa2[c] = sb2[c];
+            }
         };
         uint32_t pr = pb;
         for (; pr + U <= pe; pr += U) {

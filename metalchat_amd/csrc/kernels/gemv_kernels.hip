@@ -94,6 +94,26 @@ MC_GEMV_LIN_SET(mc_gemv_i4_bfloat_lin2, MC_LIN2_CFG)   // K = 4096
 MC_GEMV_LIN_SET(mc_gemv_i4_bfloat_lin4, MC_LIN4_CFG)   // K = 8192
 MC_GEMV_LIN_SET(mc_gemv_i4_bfloat_lin7, MC_LIN7_CFG)   // K = 14336
 MC_GEMV_LIN_SET(mc_gemv_i4_bfloat_lin12, MC_LIN12_CFG) // K = 24576 (Gemma-7B's w2)
+// K = 3072 (Gemma-7B's QKV and w1|w3): rows of 1.5 KiB, two to a 3 KiB super row (gemv.h LSPLIT)
+#define MC_GEMV_LINS(NAME, PRO, EPI)                                                              \
+    extern "C" __global__ void __launch_bounds__(64 * MC_LIN_WAVES)                               \
+    NAME(const void* w, const void* scales, const void* x, void* y, const void* res,             \
+         const void* norm_w, uint32_t out_rows, uint32_t in, uint32_t group, float eps, float mu, \
+         const void* lora_a, const void* lora_b, uint32_t lora_rank, float lora_scale)            \
+    {                                                                                             \
+        body<WF_I4, BF, Q_M4D, PRO, EPI, 4, 3, 1, 2, MC_LIN_WAVES, 0, 1, 1>(                       \
+            w, scales, x, y, res, norm_w, out_rows, in, group, eps, mu, lora_a, lora_b, lora_rank, lora_scale); \
+    }
+#if MC_LIN_WAVES
+MC_GEMV_LINS(mc_gemv_i4_bfloat_lin3s_p0_e0, 0, 0)
+MC_GEMV_LINS(mc_gemv_i4_bfloat_lin3s_p1_e0, 1, 0)
+MC_GEMV_LINS(mc_gemv_i4_bfloat_lin3s_p0_e1, 0, 1)
+MC_GEMV_LINS(mc_gemv_i4_bfloat_lin3s_p1_e2, 1, 2)
+MC_GEMV_LINS(mc_gemv_i4_bfloat_lin3s_p1_e3, 1, 3)
+MC_GEMV_LINS(mc_gemv_i4_bfloat_lin3s_p1_e4, 1, 4)
+MC_GEMV_LINS(mc_gemv_i4_bfloat_lin3s_p2_e0, 2, 0)
+MC_GEMV_LINS(mc_gemv_i4_bfloat_lin3s_p2_e3, 2, 3)
+#endif
 MC_GEMV_LIN_SET(mc_gemv_i4_bfloat_lin14, MC_LIN14_CFG) // K = 28672
 
 // K split (gemv.h LKS = 2): sixteen waves per workgroup, a row pair's K range cut between two of them -- long rows with ONE

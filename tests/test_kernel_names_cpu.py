@@ -44,6 +44,8 @@ def test_linear_order_families_are_complete(symbols):
         want += [f"mc_gemv_i8_bfloat_ling{nch}_{pe}" for pe in PE + PE_FOLD + PE_PICK if not pe.startswith("p2")]
     for nch in (4, 8, 11, 16):  # ... and plain bfloat weights
         want += [f"mc_gemv_w_bfloat_ling{nch}_{pe}" for pe in PE + PE_FOLD + PE_PICK if not pe.startswith("p2")]
+    # rows of 1.5 KiB, two to a super row (gemv.h LSPLIT; decoder.cc lin_split_ok: K = 3072)
+    want += [f"mc_gemv_i4_bfloat_lin3s_{pe}" for pe in PE]
     missing = [n for n in want if n not in symbols]
     assert not missing, missing
 

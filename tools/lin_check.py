@@ -33,6 +33,10 @@ for kind in ("classic", "lin"):
         name, block, waves = (f"mc_gemv_i4_bfloat_m4d_p{pro}_e0" if fmt == "i4" else f"mc_gemv_{fmt}_bfloat_p{pro}_e0"), 256, 4
         wgs = min((OUT // 4 + waves - 1) // waves, cus * 2)
         lds = (xbytes // 16 * 17 if fmt == "i4" else xbytes) + 128
+    elif fmt == "i4" and K == 3072:  # rows of 1.5 KiB: two to a super row, the activation row twice in LDS (gemv.h LSPLIT)
+        name, block, waves = f"mc_gemv_i4_bfloat_lin3s_p{pro}_e0", 512, 8
+        wgs = min((OUT // 4 + waves - 1) // waves, cus)
+        lds = 3 * 2048 * 2 // 16 * 17 + 128 + waves * 512
     elif fmt == "i4":
         name, block, waves = f"mc_gemv_i4_bfloat_lin{nch}_p{pro}_e0", 512, 8
         wgs = min((OUT // 2 + waves - 1) // waves, cus)
