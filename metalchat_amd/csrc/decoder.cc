@@ -258,6 +258,7 @@ struct mc_decoder {
     bool lin_ksplit = false;     // MC_LIN_KSPLIT=1: w2's K range cut between two waves (sixteen per workgroup): measured SLOWER (10.2 vs 8.8 us)
     bool gemv_ling = true;       // MC_GEMV_LING=0: int8 / bfloat weights on the classic kernels (A/B)
     bool lin_lds_ring = false;   // MC_LIN_LDS_RING=1 for code objects built with -DMC_GEMV_LIN_LDSRING=1 (they need the rings' LDS)
+    bool i8_ling14 = true;       // MC_I8_LING14=0: int8 rows of 14 KiB (w2 of Llama-3-8B) on the classic kernel (A/B)
     bool lin_split = true;       // MC_LIN_SPLIT=0: K = 3072 on the classic kernels (A/B)
     bool ling_half = true;       // MC_LING_HALF=0: whole row pairs per wave whatever the matrix (A/B)
     bool pv_fold_on = true;      // MC_PV_FOLD=0: P.V ranges reduced by their own launch (A/B, parity)
@@ -485,7 +486,7 @@ struct mc_decoder {
         return gemv_lin && lin_split && m4 && L.group == 128 && L.in == 3072 && L.out % 4 == 0 && lin_waves == 8 && !L.lora_cols;
     }
     // ... or the linear-order kernels of the VALU-dequantising formats (gemv.h LGEN): int8 / plain bfloat weights on
-    // bfloat rows, rows of 4 (int8) or 4 / 8 / 11 / 16 (bfloat) whole KiB; returns that count, 0 = no
+    // bfloat rows, rows of 4 / 14 (int8) or 4 / 8 / 11 / 16 (bfloat) whole KiB; returns that count, 0 = no
     int
     ling_kib(const linear_w& L) const
     {
@@ -495,7 +496,7 @@ struct mc_decoder {
         const int n = (int)(rb / 1024);
         if (L.fmt == MC_WFMT_I8) {
             const bool g_ok = L.group == 0 || (L.group % 16 == 0 && (L.group & (L.group - 1)) == 0);
-            return g_ok && n == 4 ? n : 0;
+            return g_ok && (n == 4 || (n == 14 && i8_ling14)) ? n : 0;
         }
         if (L.fmt == MC_WFMT_T) return (n == 4 || n == 8 || n == 11 || n == 16) ? n : 0;
         return 0;
@@ -1111,6 +1112,7 @@ mc_decoder_create(mc_device* dev, mc_library* lib, mc_queue* q, const mc_decoder
     if (const char* e = getenv("MC_PV_FOLD")) d->pv_fold_on = atoi(e) != 0;
     if (const char* e = getenv("MC_LING_HALF")) d->ling_half = atoi(e) != 0;
     if (const char* e = getenv("MC_LIN_SPLIT")) d->lin_split = atoi(e) != 0;
+    if (const char* e = getenv("MC_I8_LING14")) d->i8_ling14 = atoi(e) != 0;
     if (const char* e = getenv("MC_GEMV_LING")) d->gemv_ling = atoi(e) != 0;
     if (const char* e = getenv("MC_LIN_KSPLIT")) d->lin_ksplit = atoi(e) != 0;
     if (const char* e = getenv("MC_LIN_LDS_RING")) d->lin_lds_ring = atoi(e) != 0;

@@ -1290,9 +1290,9 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
         constexpr bool XREG = LGEN * (KPL / 2) <= 64;      // the whole row in registers (KPL / 2 VGPRs per packet)
         constexpr bool SCALED = WF != WF_T;
 #ifndef MC_GEMV_I8M
-#define MC_GEMV_I8M 0 // 1: int8-held weights dequantised and multiplied on the matrix pipe (mac8b_n).  Parity-green (tools/lin_check.py i8, the
-                      // context tests) and no faster: these kernels wait for memory (w1|w3 of Llama-3-8B int8: 121 MB in 20.8 us = 5.8 TB/s
-                      // either way; 464-466 tokens/s at S = 8192 both) -- off, the row sums keep the classic kernels' order
+#define MC_GEMV_I8M 1 // int8-held weights dequantised and multiplied on the matrix pipe (mac8b_n).  On 4 KiB rows no faster than the VALU path
+                      // (those kernels wait for memory: w1|w3 of Llama-3-8B int8 121 MB in 20.8 us = 5.8 TB/s either way), but it needs
+                      // half the registers, which is what lets 14 KiB rows (w2) onto the linear order at all: 13.1 -> 11.6 us
 #endif
         constexpr bool I8M = MC_GEMV_I8M && WF == WF_I8;
 #ifndef MC_GEMV_LING_HALF

@@ -154,7 +154,10 @@ MC_GEMV_LINK2(mc_gemv_i4_bfloat_lin14k2_p0_e1, 1, 14)
     MC_GEMV_LING(PFX##_p1_e5, WF, 1, 5, NCH)
 #if MC_LIN_WAVES
 MC_GEMV_LING_SET(mc_gemv_i8_bfloat_ling4, WF_I8, 4)   // K = 4096
-// (K = 14336 int8 rows: 14 x 8 VGPRs of activations do not fit in registers and the unrolled pair spills; the classic kernel is faster there: 13.3 vs 15.4 us)
+// (K = 14336 int8 rows on the VALU path: 14 x 8 VGPRs of activations do not fit in registers, the unrolled pair takes 241 VGPRs and the
+//  classic kernel is faster, 13.3 vs 15.4 us; dequantised and multiplied on the matrix pipe -- gemv.h MC_GEMV_I8M, mac8b_n -- it takes 104:
+//  w2 of Llama-3-8B int8 13.1 -> 11.6 us, 461 -> 466 tokens/s at S = 8192)
+MC_GEMV_LING_SET(mc_gemv_i8_bfloat_ling14, WF_I8, 14)  // K = 14336
 MC_GEMV_LING_SET(mc_gemv_w_bfloat_ling4, WF_T, 4)     // K = 2048
 MC_GEMV_LING_SET(mc_gemv_w_bfloat_ling8, WF_T, 8)     // K = 4096
 MC_GEMV_LING_SET(mc_gemv_w_bfloat_ling11, WF_T, 11)   // K = 5632

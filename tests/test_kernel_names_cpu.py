@@ -40,7 +40,7 @@ def test_linear_order_families_are_complete(symbols):
     want = []
     for nch in (1, 2, 4, 7, 12, 14):  # decoder.cc lin_ok(): int4 rows of whole KiB
         want += [f"mc_gemv_i4_bfloat_lin{nch}_{pe}" for pe in PE + PE_FOLD + PE_PICK]
-    for nch in (4,):  # decoder.cc ling_kib(): int8
+    for nch in (4, 14):  # decoder.cc ling_kib(): int8
         want += [f"mc_gemv_i8_bfloat_ling{nch}_{pe}" for pe in PE + PE_FOLD + PE_PICK if not pe.startswith("p2")]
     for nch in (4, 8, 11, 16):  # ... and plain bfloat weights
         want += [f"mc_gemv_w_bfloat_ling{nch}_{pe}" for pe in PE + PE_FOLD + PE_PICK if not pe.startswith("p2")]
