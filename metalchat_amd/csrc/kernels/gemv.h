@@ -547,8 +547,9 @@ x_perm8(uint32_t n)
     return (n & ~0x33u) | (j << 4) | e;
 }
 
-// (The same substitution on int8-held and plain bfloat weights changes nothing -- 984 vs 988 and 390
-// vs 392 tokens/s: those kernels wait for memory, not for the VALU -- so only int4 takes it.)
+// (mac4 -- the dot products alone on the MFMA -- on int8-held and plain bfloat weights changed nothing in the classic kernels,
+// 984 vs 988 and 390 vs 392 tokens/s: those wait for memory, not for the VALU.  int8 went to the matrix pipe whole in the
+// linear-order kernels later, for its register count: mac8b_n above.)
 // I4, T = float: Wd = fl(float(q) * s), the reference's float(q) * float(s)
 // (kernel/mul.metal:80-81 with Output = float).
 template <int QM>
