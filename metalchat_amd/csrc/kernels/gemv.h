@@ -1595,7 +1595,10 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
         // row's compute time was added to the load latency instead of hiding behind it (tools/lin_timeline.py).
         constexpr int LR = LRING ? LRING : (2 * TPP * LTP <= MC_GEMV_LIN_INFLIGHT ? 2 * TPP : TPP);
         static_assert(LR % TPP == 0 || TPP % LR == 0, "the ring and a pair's tiles divide one another");
-        constexpr bool XREG = LNCH <= 2;
+#ifndef MC_GEMV_LSPLIT_XREG
+#define MC_GEMV_LSPLIT_XREG 0 // 1: the doubled 3072-long row in 48 VGPRs instead of eight LDS reads per packet -- measured the same (588-593 tokens/s)
+#endif
+        constexpr bool XREG = LNCH <= 2 || (LSPLIT && MC_GEMV_LSPLIT_XREG);
         static_assert(LKS == 1 || !XREG, "K split: the row is read from LDS");
 #ifndef MC_GEMV_LIN_RAWPARK
 #define MC_GEMV_LIN_RAWPARK 0
@@ -2283,19 +2286,23 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
                     } else if (MC_GEMV_LIN_STREAM) {
                         const uint4& w = lring[slot][p];
                         laccs[0][0] += asf(((w.x ^ w.y ^ w.z ^ w.w) & 0x3FFFFFFFu) | (s2 & 1u));
-                    } else if constexpr (XREG) {
-                        if (MC_GEMV_M4B) mac4b_n<NA>(laccs, lring[slot][p], m4b_prepare(sf, m4bk), xr[c]);
-                        else mac4d_n<NA>(laccs, lring[slot][p], m4d_prepare(s2, m4d_mx, m4d_my), xr[c]);
                     } else if constexpr (LSPLIT != 0) {
                         // packet c of the super row: its own accumulator (the middle packet is two rows' worth, split below);
                         // the scale of the lane's row of the quad: super row r -> rows 2 r, 2 r + 1
-                        uint2 x[8];
-                        xload(x, c);
                         const uint32_t dw = r ? sa2[c] : sa[c];
                         const uint32_t sfl = second_half(c) ? (dw & 0xFFFF0000u) : (dw << 16);
                         mf_f4 one[1] = {laccs3[c]};
-                        mac4b_n<1>(one, lring[slot][p], m4b_prepare(sfl, m4bk), x);
+                        if constexpr (XREG) {
+                            mac4b_n<1>(one, lring[slot][p], m4b_prepare(sfl, m4bk), xr[c]);
+                        } else {
+                            uint2 x[8];
+                            xload(x, c);
+                            mac4b_n<1>(one, lring[slot][p], m4b_prepare(sfl, m4bk), x);
+                        }
                         laccs3[c] = one[0];
+                    } else if constexpr (XREG) {
+                        if (MC_GEMV_M4B) mac4b_n<NA>(laccs, lring[slot][p], m4b_prepare(sf, m4bk), xr[c]);
+                        else mac4d_n<NA>(laccs, lring[slot][p], m4d_prepare(s2, m4d_mx, m4d_my), xr[c]);
                     } else {
                         uint2 x[8];
                         xload(x, (LKS == 2 ? (int)cbase : 0) + c);
