@@ -92,20 +92,6 @@ def algorithmic_bytes(m, wbits, group, seq_len, tbytes):
                 total=w + kv_read + kv_write + dim * tbytes, p_mm=p_mm)
 
 
-def dec_kernel_name(args, m):
-    """Host name of the dominant kernel for this configuration (decoder.cc gemv(): name selection)."""
-    fmt = {4: "i4", 8: "i8", 16: "w"}[args.wbits]
-    t = "bfloat" if args.dtype == "bf16" else "float"
-    i4bf = args.wbits == 4 and args.dtype == "bf16"
-    if not i4bf:
-        return f"mc_gemv_{fmt}_{t}_p1_e2"
-    if args.qmode == "fast":
-        return f"mc_gemv_{fmt}_{t}_fast_p1_e2"
-    nch = m["dim"] // 2048 if m["dim"] % 2048 == 0 else 0
-    lin = args.group % 128 == 0 and nch in (1, 2, 4, 7, 14) and os.environ.get("MC_GEMV_LIN", "1") != "0"
-    return f"mc_gemv_{fmt}_{t}_lin{nch}_p1_e2" if lin else f"mc_gemv_{fmt}_{t}_m4d_p1_e2"
-
-
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the newest committed PMC summary (profiles/rNN_pmc_traffic.json,
     produced by tools/profile_round.sh with separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes and the gfx950
@@ -254,8 +240,11 @@ def cpu_baseline(args, m, tbytes):
 def spawn_workers(args):
     """`python bench.py --gpus N` without a launcher: N fresh child processes, one per GPU, started BEFORE this
     process touches the GPU; rank 0 prints the JSON line.  The RCCL id travels through a file."""
+    import shutil
+
     n = args.gpus
-    uid_file = os.path.join(tempfile.mkdtemp(prefix="mc_bench_"), "rccl_uid")
+    uid_dir = tempfile.mkdtemp(prefix="mc_bench_")
+    uid_file = os.path.join(uid_dir, "rccl_uid")
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MC_UID_FILE=uid_file,
@@ -276,18 +265,25 @@ def spawn_workers(args):
                 rc = r
                 for q in live:
                     q.kill()
+    shutil.rmtree(uid_dir, ignore_errors=True)
     sys.exit(rc)
 
 
-def exchange_uid(mc, rank, world):
-    """Rank 0 makes the 128-byte RCCL id; the others read it from a file rank 0 wrote atomically."""
+_T_START = time.time()
+
+
+def exchange_uid(mc, rank, world, tag=""):
+    """Rank 0 makes the 128-byte RCCL id; the others read it from a file rank 0 wrote atomically.  `tag` names a
+    second communicator of the same job (the 70B stages)."""
     path = os.environ.get("MC_UID_FILE")
+    launcher = False
     if not path:
-        # under torch.distributed.run: one job per MASTER_PORT on this node
-        key = os.environ.get("TORCHELASTIC_RUN_ID", "none") + "_" + os.environ.get("MASTER_PORT", "29500")
+        # under torch.distributed.run: one job per (run id, MASTER_PORT, launcher process) on this node -- the workers of
+        # one launch share their parent, a back-to-back run has another
+        launcher = True
+        key = "_".join((os.environ.get("TORCHELASTIC_RUN_ID", "none"), os.environ.get("MASTER_PORT", "29500"), str(os.getppid())))
         path = os.path.join(tempfile.gettempdir(), f"mc_bench_uid_{os.getuid()}_{key}")
-        if rank == 0 and os.path.exists(path):
-            os.unlink(path)
+    path += tag
     if rank == 0:
         uid = mc.pipeline_unique_id()
         tmp = path + f".{os.getpid()}"
@@ -298,7 +294,8 @@ def exchange_uid(mc, rank, world):
     t0 = time.time()
     while time.time() - t0 < 120:
         try:
-            if os.path.getsize(path) == 128 and time.time() - os.path.getmtime(path) < 600:
+            # (a file older than this process is a previous run's id: rank 0 of THIS run writes after it has started)
+            if os.path.getsize(path) == 128 and (not launcher or os.path.getmtime(path) >= _T_START - 2.0):
                 with open(path, "rb") as f:
                     return f.read()
         except OSError:
@@ -343,6 +340,48 @@ def run_other_configs(mc, acc, np):
         except Exception as e:  # an informational leg must not take the headline down
             out.append(dict(config=name, error=str(e)[:200]))
     return out
+
+
+def run_pipelined_70b(mc, acc, np, args, rank, world):
+    """BASELINE configs[4]: Llama-3-70B int4 g128, layers pipelined over the `world` stages of this job (80 / world
+    layers and their caches per stage, include/metalchat/nn/llama.h:123-126 cut into stages), S = 2048, batch 1 greedy.
+    Runs after the headline timing with a communicator of its own; the value is absolute tokens/s and the fraction of the
+    219 tokens/s a single 8 TB/s stream of the model's 36.5 GB allows -- at batch 1 one stage is busy at a time, so the
+    aggregate bandwidth of the N GPUs is not the ceiling."""
+    m = MODELS["llama3-70b"]
+    S, K = 2048, 32
+    lb, le = mc.pipeline_layer_range(rank, world, m["n_layers"])
+
+    def stage(r):
+        b, e = mc.pipeline_layer_range(r, world, m["n_layers"])
+        d = mc.Decoder(acc, dtype=mc.BF16, family=mc.FAMILY_LLAMA3, max_seq_len=S, attn_scale=float(1.0 / np.sqrt(m["head_dim"])),
+                       layer_begin=b, layer_end=e, weight_format=mc.WFMT_I4, group_size=128, use_graph=0, **m)
+        d.init_synthetic(7)
+        return d
+
+    if args.share_device:
+        stages = [stage(r) for r in range(world)]
+        pipe = mc.Pipeline.local(stages)
+    else:
+        stages = [stage(rank)]
+        pipe = mc.Pipeline.rccl(stages[0], rank, world, exchange_uid(mc, rank, world, tag="_70b"))
+    start = S - K - 8
+    tok = int(pipe.generate(1, start, 8)[-1])
+    pipe.allreduce_max(0.0)
+    t0 = time.perf_counter()
+    pipe.generate(tok, start + 8, K)
+    pipe.allreduce_max(0.0)
+    dt = pipe.allreduce_max(time.perf_counter() - t0)
+    pipe.release()
+    for d in stages:
+        d.release()
+    ab = algorithmic_bytes(m, 4, 128, S, 2)
+    tps = K / dt
+    return dict(config=f"Llama-3-70B int4 g128 layer-pipelined pp{world}, S=2048 (configs[4]), "
+                       f"{'stages sharing GPU 0, device-to-device hops' if args.share_device else 'one process per GPU, RCCL send/recv per hop'}",
+                tokens_per_s=tps, ms_per_token=dt / K * 1e3, tokens=K, layers_per_stage=le - lb, algorithmic_bytes=ab["total"],
+                single_stream_ceiling_tokens_per_s=HBM_PEAK_GBS * 1e9 / ab["total"],
+                frac_of_hbm_peak=ab["total"] * tps / 1e9 / HBM_PEAK_GBS, hipgraph=False)
 
 
 def main():
@@ -427,7 +466,9 @@ def main():
                                f"seq_len={S}, {args.dtype} activations/KV, qmode={args.qmode}",
                    "parallelism": "single GPU" if world == 1 else
                    f"layer pipeline pp{world} ({'stages sharing GPU 0 in one process, device-to-device hops' if args.share_device else 'one process per GPU, RCCL send/recv on the decoder stream'})",
-                   "hipgraph": bool(not piped and not args.no_graph)},
+                   "hipgraph": bool(not piped and not args.no_graph),
+                   # (the pipeline path launches eagerly: its hops sit between the launches of a token)
+                   "hop_transport": None if not piped else ("device-to-device copy behind an event" if args.share_device else "ncclSend / ncclRecv (RCCL) on the decoder stream")},
         "whole_token": {"algorithmic_bytes": ab["total"], "achieved_GBs": ab["total"] * tok_s / 1e9,
                         "frac_of_hbm_peak": ab["total"] * tok_s / 1e9 / HBM_PEAK_GBS},
     }
@@ -446,9 +487,9 @@ def main():
         for which in ("qkv", "wo", "w2", "head"):
             msk, byk, lnk = dec.time_gemv(which, reps)
             pk = msk / (reps * lnk)
-            per_kind[which] = {"avg_launch_us": pk * 1e3, "bytes_per_launch": byk / lnk,
+            per_kind[which] = {"kernel": dec.gemv_kernel_name(which), "avg_launch_us": pk * 1e3, "bytes_per_launch": byk / lnk,
                                "frac": byk / lnk / (pk * 1e-3) / 1e9 / HBM_PEAK_GBS}
-        kname = dec_kernel_name(args, m)
+        kname = dec.gemv_kernel_name("w13")  # the name decoder.cc gemv() selects, asked of the decoder itself
         out["roofline"] = {
             "bound": "hbm", "kernel": f"{kname} (w1|w3 fused, per launch)", "achieved": achieved,
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -482,6 +523,17 @@ def main():
         if pipe is None:
             dec.release()
         out["other_configs"] = run_other_configs(mc, acc, np)
+    if piped and not args.no_other_configs and args.model == "llama3-8b":
+        # every rank takes part; rank 0 reports
+        pipe.release()
+        for d in (stages if args.share_device else [dec]):
+            d.release()
+        pipe = None
+        try:
+            r70 = run_pipelined_70b(mc, acc, np, args, rank, world)
+        except Exception as e:  # an informational leg must not take the headline down
+            r70 = dict(config=f"Llama-3-70B int4 g128 layer-pipelined pp{world}", error=str(e)[:300])
+        out["other_configs"] = [r70]
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(args, m, tbytes)
     if rank == 0:

@@ -60,6 +60,9 @@ typedef struct mc_queue mc_queue;
  * device (LOCAL_RANK-aware callers pass their own ordinal). */
 mc_status mc_device_create(int32_t ordinal, mc_device** out);
 void mc_device_release(mc_device* dev);
+/* HIP devices visible to this process (the reference has exactly one: MTL::CreateSystemDefaultDevice, src/metal.cc:51-55);
+ * the layer pipeline puts one stage on each. */
+int32_t mc_device_count(void);
 /* device->name() -- src/accelerator.cc:108-113 */
 const char* mc_device_name(const mc_device* dev);
 /* device->maxBufferLength() -- src/accelerator.cc:73-77 */
@@ -312,6 +315,15 @@ size_t mc_decoder_weight_bytes(const mc_decoder* d);
  * milliseconds and the algorithmic bytes moved.  which: "qkv","wo","w13","w2","head","all". */
 mc_status mc_decoder_time_gemv(mc_decoder* d, const char* which, int32_t repeats, float* total_ms,
                                double* bytes_per_pass, int32_t* launches_per_pass);
+/* Host name of the kernel mc_decoder_time_gemv(which) launches -- the variant a token really runs (linear-order
+ * kernels, prologue / epilogue codes, the greedy pick inside the head).  Launches nothing. */
+mc_status mc_decoder_gemv_kernel_name(mc_decoder* d, const char* which, char* buf, size_t cap);
+/* Test aid: record the host names of every kernel the decoder launches from now on (enable = 1 clears the log and
+ * drops a captured token graph, whose replay would launch without passing here; 0 stops recording).
+ * mc_decoder_launch_log_read copies the newline-separated names and returns the bytes needed (terminator included).
+ * The reference labels every encoder with its kernel name for the same purpose (src/kernel_thread.cc:109-115). */
+mc_status mc_decoder_launch_log(mc_decoder* d, int32_t enable);
+size_t mc_decoder_launch_log_read(mc_decoder* d, char* buf, size_t cap);
 
 /* Device addresses of a fused weight matrix as it lies in HBM: per layer "qkv" (wq|wk|wv rows),
  * "wo", "w13" (w1/w3 rows interleaved), "w2"; layer -1: "output".  For kernel-level tests that

@@ -15,7 +15,7 @@ from .runtime import (  # noqa: F401
     library_path, hsaco_path, layout, make_kernel_grid_2d,
     Document, TensorInfo, config_from_json, config_from_document,
     CKPT_META_LLAMA3, CKPT_HF_LLAMA3, CKPT_META_LLAMA3_QLORA, CKPT_HF_GEMMA3, SAMPLER_GREEDY, SAMPLER_DEFAULT,
-    Tokenizer, Interpreter, gpt2_encode, gpt2_decode, regexp_split, Pipeline, pipeline_unique_id, pipeline_layer_range,
+    Tokenizer, Interpreter, gpt2_encode, gpt2_decode, regexp_split, Pipeline, pipeline_unique_id, pipeline_layer_range, device_count,
     TOKEN_REGULAR, TOKEN_BEGIN_TEXT, TOKEN_END_TEXT, TOKEN_RESERVED, TOKEN_FINETUNE_RIGHT_PAD,
     TOKEN_BEGIN_HEADER, TOKEN_END_HEADER, TOKEN_END_MESSAGE, TOKEN_END_TURN, TOKEN_IPYTHON,
 )

@@ -143,6 +143,13 @@ mc_device_release(mc_device* dev)
     delete dev;
 }
 
+int32_t
+mc_device_count(void)
+{
+    int count = 0;
+    return hipGetDeviceCount(&count) == hipSuccess ? count : 0;
+}
+
 const char*
 mc_device_name(const mc_device* dev)
 {

@@ -271,6 +271,11 @@ struct mc_decoder {
     int gemv_m4 = 2;       // MC_GEMV_M4: 0 = exact int4 on the VALU (v_dot2c), 1 = dot products on the 4x4x4 MFMA, 2 = dequantisation too where a SIMD holds > 1 wave, 3 = always
     bool gemma_fuse = true; // MC_GEMMA_UNFUSED=1: keep the post-norms as launches of their own
     bool pn_ready = false;
+    // test / measurement aids: the names of the kernels launched eagerly since the log was switched on (a replayed graph
+    // launches what was logged when it was captured), and "tell me the kernel gemv() would launch" (no launch)
+    bool log_on = false;
+    std::vector<std::string> launch_log;
+    std::string* capture_name = nullptr;
 
     ~mc_decoder()
     {
@@ -345,6 +350,7 @@ struct mc_decoder {
         void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, a.buf.data(), HIP_LAUNCH_PARAM_BUFFER_SIZE,
                          &n, HIP_LAUNCH_PARAM_END};
         mcimpl::launch_range range(name.c_str(), gx, gy, gz, bx, 1, 1);
+        if (log_on) launch_log.push_back(name);
         hipError_t e = hipModuleLaunchKernel(f, gx, gy, gz, bx, 1, 1, lds, stream, nullptr, extra);
         if (e != hipSuccess) return hip_fail(e, name.c_str());
         return MC_OK;
@@ -615,6 +621,12 @@ struct mc_decoder {
         // the waves' DMA rings (gemv.h LDSR: rows of two or more KiB, build-time prologue): 7 or 8 KiB per wave
         // + two slots of scale dwords per wave (256 bytes per 64 scale groups)
         if (lin && nch >= 2 && lin_lds_ring) lds += waves * (((2 * nch) % 7 == 0 ? 7u : 8u) * 1024u + 2u * ((nch + 3u) / 4u) * 256u); // (also granted to the variants that do not use it)
+        // EPI_STORE_PICK leaves one key per workgroup in pick_keys (pick_slots of them, folded by mc_argmax_keys)
+        if (epi == 5 && wgs > pick_slots) wgs = pick_slots;
+        if (capture_name) {
+            *capture_name = name;
+            return MC_OK;
+        }
         if (L.lora_cols) {
             // a = T(A x): the stacked adaptor inputs through the same kernel family (same prologue,
             // so a pre-norm GEMV and its adaptor see the identical normalised row)
@@ -792,6 +804,14 @@ struct mc_decoder {
         return MC_OK;
     }
 
+    // does the greedy pick ride in the head's own launch (gemv.h EPI_STORE_PICK)?
+    bool
+    head_pick() const
+    {
+        return sampler_kind == MC_SAMPLER_GREEDY && head_pick_on && !pending_pn && lin_waves == 8 && !output.lora_cols &&
+               (lin_ok(output) || ling_kib(output)) && cfg.vocab % 2 == 0;
+    }
+
     mc_status
     run_head()
     {
@@ -799,8 +819,7 @@ struct mc_decoder {
         // final norm + output head (llama.h:128-133) + greedy pick
         // greedy on a linear-order head kernel: the pick rides in the head's own launch (gemv.h EPI_STORE_PICK; the post-norm
         // prologue passes its row through `res`, so that variant keeps the argmax launch)
-        const bool pick = sampler_kind == MC_SAMPLER_GREEDY && head_pick_on && !pending_pn && lin_waves == 8 && !output.lora_cols &&
-                          (lin_ok(output) || ling_kib(output)) && cfg.vocab % 2 == 0;
+        const bool pick = head_pick();
         mc_status s = pending_pn ? gemv(output, 2, 0, proj, logits, pending_pn, final_norm, mu)
                                  : gemv(output, 1, pick ? 5 : 0, hidden, logits,
                                         pick ? (const void*)(pick_desc + (head_pick_mode == 2 ? 32 : 0)) : nullptr, final_norm, mu);
@@ -1857,6 +1876,54 @@ mc_decoder_weight_bytes(const mc_decoder* d)
 }
 
 mc_status
+mc_decoder_launch_log(mc_decoder* d, int32_t enable)
+{
+    if (!d) return fail(MC_ERR_INVALID_ARGUMENT, "mc_decoder_launch_log: null argument");
+    d->launch_log.clear();
+    d->log_on = enable != 0;
+    if (d->log_on) {
+        // a replayed graph would launch without passing through the log: the next chained token is captured anew
+        MC_HIP(hipSetDevice(d->dev->ordinal));
+        d->drop_graph();
+    }
+    return MC_OK;
+}
+
+size_t
+mc_decoder_launch_log_read(mc_decoder* d, char* buf, size_t cap)
+{
+    if (!d) return 0;
+    std::string all;
+    for (const std::string& n : d->launch_log) {
+        all += n;
+        all += '\n';
+    }
+    if (buf && cap) {
+        const size_t n = std::min(cap - 1, all.size());
+        memcpy(buf, all.data(), n);
+        buf[n] = 0;
+    }
+    return all.size() + 1;
+}
+
+mc_status
+mc_decoder_gemv_kernel_name(mc_decoder* d, const char* which, char* buf, size_t cap)
+{
+    if (!d || !which || !buf || !cap) return fail(MC_ERR_INVALID_ARGUMENT, "mc_decoder_gemv_kernel_name: bad argument");
+    std::string name;
+    d->capture_name = &name;
+    float ms = 0.0f;
+    mc_status s = mc_decoder_time_gemv(d, which, 1, &ms, nullptr, nullptr);
+    d->capture_name = nullptr;
+    if (s != MC_OK) return s;
+    if (name.empty()) return fail(MC_ERR_INVALID_ARGUMENT, std::string("mc_decoder_gemv_kernel_name: no such GEMV '") + which + "'");
+    const size_t n = std::min(cap - 1, name.size());
+    memcpy(buf, name.data(), n);
+    buf[n] = 0;
+    return MC_OK;
+}
+
+mc_status
 mc_decoder_time_gemv(mc_decoder* d, const char* which, int32_t repeats, float* total_ms,
                      double* bytes_per_pass, int32_t* launches_per_pass)
 {
@@ -1905,7 +1972,10 @@ mc_decoder_time_gemv(mc_decoder* d, const char* which, int32_t repeats, float* t
             }
         }
         if ((w == "head" || w == "all") && d->last_stage) {
-            r = d->gemv(d->output, 1, 0, d->hidden, d->logits, nullptr, d->final_norm, mu);
+            // the variant the token really launches: with the greedy pick inside (one key per workgroup into pick_keys;
+            // the step state is not touched) when run_head() would take it
+            const bool pick = d->head_pick();
+            r = d->gemv(d->output, 1, pick ? 5 : 0, d->hidden, d->logits, pick ? (const void*)(d->pick_desc + 32) : nullptr, d->final_norm, mu);
             if (r != MC_OK) return r;
             if (count) { bytes += linear_bytes(d->output); launches++; }
         }
@@ -1913,6 +1983,7 @@ mc_decoder_time_gemv(mc_decoder* d, const char* which, int32_t repeats, float* t
     };
     s = pass(true); // warm-up + byte count
     if (s != MC_OK) return s;
+    if (d->capture_name) return MC_OK; // mc_decoder_gemv_kernel_name: the pass above launched nothing
     MC_HIP(hipEventRecord(d->q->t0, d->stream));
     for (int i = 0; i < repeats; i++) {
         s = pass(false);
@@ -2158,7 +2229,9 @@ mc_pipeline_generate(mc_pipeline* p, int32_t first_token, int32_t start_pos, int
     const int W = p->world;
     for (mc_decoder* d : p->stages) {
         if (n > d->tokens_cap) return fail(MC_ERR_INVALID_ARGUMENT, "mc_pipeline_generate: n too large");
-        if (d->first_stage && (first_token < 0 || first_token >= d->cfg.vocab))
+        // checked on EVERY stage, not only the one that consumes the token: a rank that returned early would leave its
+        // peers waiting in ncclRecv
+        if (first_token < 0 || first_token >= d->cfg.vocab)
             return fail(MC_ERR_INVALID_ARGUMENT, "decoder: token id outside the vocabulary");
         if (d->sampler_kind != MC_SAMPLER_GREEDY && !d->last_stage)
             return fail(MC_ERR_INVALID_ARGUMENT, "decoder: only the last stage samples");

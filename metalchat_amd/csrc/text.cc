@@ -439,6 +439,27 @@ struct mc_tokenizer {
         if (it == inverse.end()) raise(MC_ERR_RUNTIME, "byte_pair_encoder: unable to decode id '" + std::to_string(id) + "'");
         return it->second;
     }
+
+    // what tokenizer_traits::decode hands out for ONE id: byte_pair_encoder::decode, or sentence_piece::decode
+    // (sentence_piece.h:84-97: U+2581 back to a space, token by token).  mc_tokenizer_decode and the interpreter's
+    // read loop (interpreter.h:365) both go through here.
+    std::string
+    decode_text(int32_t id) const
+    {
+        const std::string& s = decode(id);
+        if (!sentence_piece) return s;
+        std::string r;
+        r.reserve(s.size());
+        for (size_t i = 0; i < s.size();) {
+            if (i + 2 < s.size() && (uint8_t)s[i] == 0xE2 && (uint8_t)s[i + 1] == 0x96 && (uint8_t)s[i + 2] == 0x81) {
+                r += ' ';
+                i += 3;
+            } else {
+                r += s[i++];
+            }
+        }
+        return r;
+    }
 };
 
 // ------------------------------------------------------------------------------------------ scanners (interpreter.h:60-175)
@@ -775,20 +796,7 @@ mc_tokenizer_decode(const mc_tokenizer* t, const int32_t* ids, size_t n_ids, cha
     if (!t) return fail(MC_ERR_INVALID_ARGUMENT, "mc_tokenizer_decode: null tokenizer");
     return guarded([&] {
         std::string s;
-        for (size_t i = 0; i < n_ids; i++) s += t->decode(ids[i]);
-        if (t->sentence_piece) { // sentence_piece::decode (sentence_piece.h:84-97): U+2581 back to a space, token by token
-            std::string r;
-            r.reserve(s.size());
-            for (size_t i = 0; i < s.size();) {
-                if (i + 2 < s.size() && (uint8_t)s[i] == 0xE2 && (uint8_t)s[i + 1] == 0x96 && (uint8_t)s[i + 2] == 0x81) {
-                    r += ' ';
-                    i += 3;
-                } else {
-                    r += s[i++];
-                }
-            }
-            s.swap(r);
-        }
+        for (size_t i = 0; i < n_ids; i++) s += t->decode_text(ids[i]);
         return emit(s.data(), s.size(), out, cap, n);
     });
 }
@@ -876,8 +884,10 @@ mc_interpreter_read(mc_interpreter* it, int32_t sliding_window, char* out, size_
                           : mc_decoder_prefill(it->dec, prompt.data(), (int32_t)prompt.size(), (int32_t)it->start_pos,
                                                sliding_window, &token);
         if (s != MC_OK) {
-            // nothing was consumed (the decoder validates before it touches its caches): the pending tokens stay
-            // pending -- without the assistant header this call wrote -- and the caller can recover (e.g. split the turn)
+            // a rejected ARGUMENT consumed nothing (the decoder validates before it touches its caches): the pending tokens
+            // stay pending -- without the assistant header this call wrote -- and the caller can recover (e.g. split the
+            // turn).  A failure behind the validation (an allocation, a launch) may have written cache rows; the positions
+            // are re-written by the retry, so the pending tokens are restored all the same.
             prompt.resize(pending_before);
             it->buf.swap(prompt);
             return s;
@@ -886,7 +896,7 @@ mc_interpreter_read(mc_interpreter* it, int32_t sliding_window, char* out, size_
         std::string text;
         std::vector<int32_t> seen;
         while (it->scanner->scan(token)) {
-            text += it->tok->decode(token);
+            text += it->tok->decode_text(token);
             seen.push_back(token);
             int32_t next = 0;
             s = mc_decoder_step(it->dec, token, (int32_t)it->start_pos++, nullptr, &next);

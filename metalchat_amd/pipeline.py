@@ -5,9 +5,13 @@ boundary is the hidden row [1,1,dim] (include/metalchat/nn/llama.h:123-126), so 
 ranges shard naturally with ONE point-to-point hop per stage boundary and one 4-byte hop that
 brings the greedy token back to the first stage.  No all-reduce, no all-gather.
 
-Backend-agnostic on purpose: bench.py drives it with the HIP decoder over RCCL ("nccl" backend on
-ROCm), tests/test_pipeline_cpu.py drives the same schedule over gloo with the CPU oracle as the
-stage, so the N > 1 protocol is covered without a GPU.
+This module is the SCHEDULE only, kept for the CPU test: tests/test_pipeline_cpu.py drives it over gloo
+(world 2 and 3) with the CPU oracle as the stage, so the hop protocol -- who sends what to whom, in which
+order, past max_seq_len -- is covered without a GPU.  The product path does not use it: bench.py and the
+C++ shim go through mc_pipeline_* (metalchat_amd/csrc/decoder.cc: ncclSend / ncclRecv on the decoder's
+stream, or device-to-device copies behind events), which implement the same schedule and are checked on the
+GPU by tests/test_pipeline_gpu.py (local transport == single stage bit for bit; RCCL with 2 and 4 ranks
+where that many devices are visible).
 """
 from __future__ import annotations
 

@@ -73,6 +73,7 @@ def capi() -> C.CDLL:
         "mc_trace_ranges_enabled": (i32, []),
         "mc_device_create": (i32, [i32, pvp]),
         "mc_device_release": (None, [vp]),
+        "mc_device_count": (i32, []),
         "mc_device_name": (C.c_char_p, [vp]),
         "mc_device_max_buffer_size": (sz, [vp]),
         "mc_device_ordinal": (i32, [vp]),
@@ -135,6 +136,9 @@ def capi() -> C.CDLL:
         "mc_decoder_weight_bytes": (sz, [vp]),
         "mc_decoder_time_gemv": (i32, [vp, C.c_char_p, i32, C.POINTER(f32), C.POINTER(C.c_double),
                                        C.POINTER(i32)]),
+        "mc_decoder_gemv_kernel_name": (i32, [vp, C.c_char_p, C.c_char_p, sz]),
+        "mc_decoder_launch_log": (i32, [vp, i32]),
+        "mc_decoder_launch_log_read": (sz, [vp, C.c_char_p, sz]),
         "mc_decoder_weight_ptrs": (i32, [vp, i32, C.c_char_p, pvp, pvp, C.POINTER(i32),
                                          C.POINTER(i32), C.POINTER(i32)]),
         "mc_decoder_get_config": (i32, [vp, C.POINTER(DecoderConfig)]),
@@ -463,6 +467,10 @@ class HardwareAccelerator:
         return capi().mc_queue_stream(self._queue)
 
 
+def device_count() -> int:
+    return capi().mc_device_count()
+
+
 def pipeline_unique_id() -> bytes:
     """The 128-byte RCCL id rank 0 creates and hands to every rank (file, socket, ...)."""
     buf = C.create_string_buffer(128)
@@ -693,6 +701,22 @@ class Decoder:
         _check(capi().mc_decoder_time_gemv(self._h, which.encode(), repeats, C.byref(ms),
                                            C.byref(by), C.byref(ln)))
         return ms.value, by.value, ln.value
+
+    def gemv_kernel_name(self, which: str) -> str:
+        """host name of the kernel time_gemv(which) -- i.e. a token -- launches for that matrix"""
+        buf = C.create_string_buffer(256)
+        _check(capi().mc_decoder_gemv_kernel_name(self._h, which.encode(), buf, 256))
+        return buf.value.decode()
+
+    def launch_log(self, enable: bool = True):
+        """start (and clear) / stop recording the names of the kernels this decoder launches"""
+        _check(capi().mc_decoder_launch_log(self._h, 1 if enable else 0))
+
+    def launched(self) -> list[str]:
+        n = capi().mc_decoder_launch_log_read(self._h, None, 0)
+        buf = C.create_string_buffer(n)
+        capi().mc_decoder_launch_log_read(self._h, buf, n)
+        return [x for x in buf.value.decode().split("\n") if x]
 
     def weight_ptrs(self, layer: int, name: str):
         w, s = C.c_void_p(), C.c_void_p()

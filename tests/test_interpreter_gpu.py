@@ -223,3 +223,32 @@ def test_a_chat_longer_than_the_cache_keeps_going_and_a_straddling_turn_is_recov
         done += 1
     assert done >= 3 and it.start_pos > 48 * 3
     it.release(), da.release(), db.release()
+
+
+def test_sentence_piece_interpreter_reads_spaces_not_u2581(acc):
+    """interpreter::read_until decodes every emitted token through tokenizer_traits::decode, which for text::sentence_piece
+    writes U+2581 back as a space (interpreter.h:365, sentence_piece.h:84-97): the text a gemma3 chat returns has spaces."""
+    import metalchat_amd as mc
+
+    cfg, (da,) = make_decoders(acc, n=1)
+    t = mc.Tokenizer.create_sentence_piece()
+    # every regular id of the model's vocabulary spells "<U+2581>w<i>": whatever the decoder emits carries a space
+    n_regular = 512 - 11
+    for i in range(n_regular):
+        t.insert_back(("▁w%d" % i).encode())
+    for kind in (mc.TOKEN_BEGIN_TEXT, mc.TOKEN_END_TEXT, mc.TOKEN_RESERVED, mc.TOKEN_FINETUNE_RIGHT_PAD, mc.TOKEN_BEGIN_HEADER,
+                 mc.TOKEN_END_HEADER, mc.TOKEN_END_MESSAGE, mc.TOKEN_END_TURN, mc.TOKEN_IPYTHON):
+        t.insert_back(("<|c%d|>" % kind).encode(), kind)
+    it = mc.Interpreter(da, t)
+    it.set_token_scanner(limit=9)
+    it.write("user", " w1 w2")
+    text, ids = it.read()
+    assert len(ids) == 8
+    regular = [i for i in ids if i < n_regular]
+    assert regular, ids
+    assert "▁" not in text
+    assert text == t.decode(ids).decode("utf-8")
+    assert text.count(" w") == len(regular)
+    it.release()
+    t.release()
+    da.release()

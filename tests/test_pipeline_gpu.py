@@ -128,3 +128,36 @@ def test_rccl_transport_comes_up_with_one_rank():
     r = subprocess.run([sys.executable, os.path.join(here, "rccl_child.py"), here, os.path.dirname(here)],
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "rccl child ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_rccl_two_ranks_equal_single_stage(world):
+    # The RCCL hop for real: `world` torch-free child processes, one GPU each, started BEFORE any of them touches the
+    # GPU (tests/rccl_rank_child.py); tokens past max_seq_len, the prompt pass and its continuation must equal the
+    # single-stage decoder's.  Skipped where fewer devices are visible (the one-GPU test box).
+    import os
+    import subprocess
+    import sys
+    import tempfile
+
+    import metalchat_amd as mc
+
+    if mc.device_count() < world:
+        pytest.skip(f"{world} GPUs needed, {mc.device_count()} visible")
+    here = os.path.dirname(os.path.abspath(__file__))
+    with tempfile.TemporaryDirectory(prefix="mc_rccl_") as tmp:
+        uid_file = os.path.join(tmp, "uid")
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs = [subprocess.Popen([sys.executable, os.path.join(here, "rccl_rank_child.py"), here, os.path.dirname(here), str(r), str(world),
+                                   uid_file], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env) for r in range(world)]
+        outs = []
+        try:
+            for p in procs:
+                outs.append(p.communicate(timeout=600))
+        finally:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+    for r, (p, (o, e)) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {r}: rc {p.returncode}\n{o[-2000:]}\n{e[-4000:]}"
+    assert f"rccl {world} ranks ok" in outs[0][0]
