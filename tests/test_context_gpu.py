@@ -34,14 +34,20 @@ def random_cache(cfg, n, seed):
     return k, v
 
 
-def run_injected(acc, cfg, weights, n_inject, n_steps, dec_over, rel_logits, max_ulp, max_frac, rel_f32=2e-4, what=""):
+def run_injected(acc, cfg, weights, n_inject, n_steps, dec_over, rel_logits, max_ulp, max_frac, rel_f32=2e-4, what="", taps=True,
+                 launched=None):
+    """`launched` (a set) collects the host names of the kernels the decoder launched for these steps, so that a test can
+    require the kernels it is about (a silent fallback to another kernel family must not pass);
+    taps = False: the production launch sequence (gemma3: post-norms folded into the next GEMV's prologue) -- logits,
+    tokens and caches only."""
     import metalchat_amd as mc
 
     dt = cfg["dtype"]
     om = mo.Model(cfg, weights)
     dec = mc.Decoder(acc, **mg.decoder_kwargs(cfg, **dec_over))
     dec.init_synthetic(SEED)
-    dec.set_taps(True)
+    dec.set_taps(taps)
+    dec.launch_log(True)
     for layer in range(cfg["n_layers"]):
         k, v = random_cache(cfg, n_inject, 100 + layer)
         om.set_kv(layer, k, v)
@@ -57,7 +63,7 @@ def run_injected(acc, cfg, weights, n_inject, n_steps, dec_over, rel_logits, max
         otok, ologits = om.step(tok, pos)
         gtok = dec.step(tok, pos)
         if dt == BF16:
-            for layer in range(cfg["n_layers"]):
+            for layer in range(cfg["n_layers"] if taps else 0):
                 parity.check(dt, dec.hidden(layer), om.hidden(layer), rel=3.9e-3 * (1 + layer), max_ulp=max_ulp + layer, max_frac=max_frac,
                              what=f"{what} pos {pos} hidden[{layer}]")
             # (a logit is a 4096-term dot product of a hidden row that already carries last-bit differences from a
@@ -104,6 +110,8 @@ def run_injected(acc, cfg, weights, n_inject, n_steps, dec_over, rel_logits, max
             parity.check(dt, ck, cok, rel=rel_f32, what=f"{what} pos {pos} computed K rows")
             parity.check(dt, cv, cov, rel=rel_f32, what=f"{what} pos {pos} computed V rows")
         tok = otok
+    if launched is not None:
+        launched.update(dec.launched())
     dec.release()
     om.close()
     return agree
@@ -116,9 +124,16 @@ def test_llama3_8b_int4_at_the_benchmark_context(acc, dtype):
 
     cfg = dict(dtype=dtype, n_layers=1, vocab=2048, max_seq_len=2048, norm_eps=1e-5, **FULL_WIDTH["llama3-8b"])
     weights = synth_model(cfg, SEED)
+    names = set()
     agree = run_injected(acc, cfg, weights, 2040, 16, dict(weight_format=mc.WFMT_I4, group_size=128),
-                         rel_logits=5e-3, max_ulp=2, max_frac=0.7, what=f"8B int4 S=2048 dt{dtype}")
+                         rel_logits=5e-3, max_ulp=2, max_frac=0.7, what=f"8B int4 S=2048 dt{dtype}", launched=names)
     assert agree >= 14
+    if dtype == BF16:  # the kernels bench.py's headline runs (and its roofline names): not a fallback family
+        assert {"mc_gemv_i4_bfloat_lin2_p1_e4", "mc_gemv_i4_bfloat_lin2_p3_e1", "mc_gemv_i4_bfloat_lin2_p1_e2", "mc_gemv_i4_bfloat_lin7_p0_e1",
+                "mc_gemv_i4_bfloat_lin2_p1_e5", "mc_argmax_keys"} <= names, sorted(names)
+        assert not [n for n in names if n.startswith("mc_gemv") and "_lin" not in n], sorted(names)
+    else:
+        assert "mc_gemv_i4_float_p1_e2" in names, sorted(names)
 
 
 def test_llama3_8b_int8_at_8192_with_automatic_context_ranges(acc, monkeypatch):
@@ -128,9 +143,12 @@ def test_llama3_8b_int8_at_8192_with_automatic_context_ranges(acc, monkeypatch):
     monkeypatch.delenv("MC_PV_RANGES", raising=False)
     cfg = dict(dtype=BF16, n_layers=1, vocab=2048, max_seq_len=8192, norm_eps=1e-5, **FULL_WIDTH["llama3-8b"])
     weights = synth_model(cfg, SEED, bits=8)
+    names = set()
     agree = run_injected(acc, cfg, weights, 8185, 15, dict(weight_format=mc.WFMT_I8, group_size=128),
-                         rel_logits=5e-3, max_ulp=2, max_frac=0.7, what="8B int8 S=8192")
+                         rel_logits=5e-3, max_ulp=2, max_frac=0.7, what="8B int8 S=8192", launched=names)
     assert agree >= 13
+    assert {"mc_gemv_i8_bfloat_ling4_p1_e4", "mc_gemv_i8_bfloat_ling4_p3_e1", "mc_gemv_i8_bfloat_ling4_p1_e2", "mc_gemv_i8_bfloat_ling14_p0_e1",
+            "mc_gemv_i8_bfloat_ling4_p1_e5"} <= names, sorted(names)
 
 
 def t_weights_model(cfg, seed):
@@ -193,21 +211,49 @@ def test_tinyllama_1b_shapes_end_to_end(acc, dtype):
     assert agree >= 4
     dec.release()
     om.close()
+    names = set()
     agree = run_injected(acc, cfg, weights, 2044, 8, dict(weight_format=mc.WFMT_T, group_size=0), rel_logits=7.8e-3,
-                         max_ulp=3, max_frac=0.8, what=f"tinyllama S=2048 dt{dtype}")
+                         max_ulp=3, max_frac=0.8, what=f"tinyllama S=2048 dt{dtype}", launched=names)
     assert agree >= 7
+    if dtype == BF16:
+        assert {"mc_gemv_w_bfloat_ling4_p1_e4", "mc_gemv_w_bfloat_ling4_p3_e1", "mc_gemv_w_bfloat_ling4_p1_e2", "mc_gemv_w_bfloat_ling11_p0_e1",
+                "mc_gemv_w_bfloat_ling4_p1_e5"} <= names, sorted(names)
 
 
 def test_llama3_70b_widths_one_block(acc):
     # BASELINE configs[4] widths: dim 8192, 64 query / 8 kv heads, ffn 28672 -- rows of 4 and 14 KiB of int4 weights
     import metalchat_amd as mc
 
-    cfg = dict(dtype=BF16, family=0, n_layers=1, vocab=2048, max_seq_len=256, norm_eps=1e-5, dim=8192, n_heads=64,
+    # ... at the context bench.py runs them at (S = 2048: kv_len 2043 .. 2048 and four rolls)
+    cfg = dict(dtype=BF16, family=0, n_layers=1, vocab=2048, max_seq_len=2048, norm_eps=1e-5, dim=8192, n_heads=64,
                n_kv_heads=8, head_dim=128, ffn_dim=28672, rope_theta=500000.0, attn_scale=128 ** -0.5)
     weights = synth_model(cfg, SEED)
-    agree = run_injected(acc, cfg, weights, 250, 9, dict(weight_format=mc.WFMT_I4, group_size=128), rel_logits=5e-3,
-                         max_ulp=2, max_frac=0.7, what="70B widths")
-    assert agree >= 8
+    names = set()
+    agree = run_injected(acc, cfg, weights, 2042, 10, dict(weight_format=mc.WFMT_I4, group_size=128), rel_logits=5e-3,
+                         max_ulp=2, max_frac=0.7, what="70B widths S=2048", launched=names)
+    assert agree >= 9
+    assert {"mc_gemv_i4_bfloat_lin4_p1_e4", "mc_gemv_i4_bfloat_lin4_p3_e1", "mc_gemv_i4_bfloat_lin4_p1_e2", "mc_gemv_i4_bfloat_lin14_p0_e1",
+            "mc_gemv_i4_bfloat_lin4_p1_e5"} <= names, sorted(names)
+
+
+@pytest.mark.parametrize("taps", [True, False])
+def test_gemma_7b_widths_at_the_benchmark_context(acc, taps):
+    # BASELINE configs[3] shapes on the gemma3 block: MHA (one query head per kv head: ONE live row of the 16-row MFMA
+    # tile in QK^T and P.V), head_dim 256, K = 3072 (`_lin3s_`) and 24576 (`_lin12_`), S = 2048 with rolls.  taps = False is
+    # the production launch sequence: both post-norms folded into the prologue of the GEMV that follows (`_p2_`).
+    import metalchat_amd as mc
+
+    cfg = dict(dtype=BF16, n_layers=1, vocab=2048, max_seq_len=2048, norm_eps=1e-5, dim=3072, n_heads=16, n_kv_heads=16, head_dim=256,
+               ffn_dim=24576, family=1, rope_theta=10000.0, rope_sliding_theta=10000.0, sliding_stride=2, attn_scale=256 ** -0.5)
+    weights = synth_model(cfg, SEED)
+    names = set()
+    # (four norms per block and a 24576-long w2 reduction: the bounds of the full-width gemma test)
+    agree = run_injected(acc, cfg, weights, 2042, 10, dict(weight_format=mc.WFMT_I4, group_size=128), rel_logits=5e-3, max_ulp=2,
+                         max_frac=0.7, what=f"gemma-7b widths S=2048 taps={taps}", taps=taps, launched=names)
+    assert agree >= 9
+    want = {"mc_gemv_i4_bfloat_lin2_p3_e0", "mc_gemv_i4_bfloat_lin12_p0_e0", "mc_rope_kv_bfloat"}
+    want |= {"mc_gemv_i4_bfloat_lin3s_p1_e0", "mc_gemv_i4_bfloat_lin3s_p1_e3"} if taps else {"mc_gemv_i4_bfloat_lin3s_p2_e3", "mc_gemv_i4_bfloat_lin3s_p2_e0"}
+    assert want <= names, sorted(names)
 
 
 def test_rows_in_the_cache_do_not_move_across_a_roll(acc):
