@@ -28,7 +28,9 @@ namespace {
 constexpr int PB = 64; // cache slots per attention-scores workgroup (decode_kernels.hip)
 
 struct step_state_h {
-    int32_t token, pos, kv_len, write_slot, ring_base, step_index, rope_row, rolled, rope_start, pad[3];
+    int32_t token, pos, kv_len, write_slot, ring_base, step_index, rope_row, rolled, rope_start;
+    uint32_t epoch, err; // steps since creation (the tag of in-launch hand-offs); a hand-off that gave up (mc_attn_fused_T)
+    int32_t pad[1];
 };
 
 struct linear_w {
@@ -181,6 +183,10 @@ struct mc_decoder {
     float* psum = nullptr;      // [H][nsplit]
     float* pv_parts = nullptr;  // [pv_ranges][H*hd] fp32 partial P.V sums (long contexts)
     int pv_ranges = 1;
+    // decode attention in one launch (mc_attn_fused_bfloat): {value, tag} granules of its two in-launch hand-offs
+    unsigned long long* attn_psum_g = nullptr; // [H][nsplit]            partial softmax denominators
+    unsigned long long* attn_slab_g = nullptr; // [KV][nsplit][n_rep][hd] fp32 partial P.V sums
+    bool attn_fused_on = true;   // MC_ATTN_FUSED=0: scores and P.V as two launches (A/B, parity)
     void* taps = nullptr;       // T[(n_own+1)*dim]
     step_state_h* state = nullptr;
     int32_t* tokens_dev = nullptr;
@@ -516,6 +522,28 @@ struct mc_decoder {
         return pv_fold_on && (lin_ok(wo) || ling_kib(wo)) && !wo.lora_cols && cfg.max_seq_len <= 16384;
     }
 
+    // scores + softmax + P.V in one launch: bfloat rows, a grid that is certainly co-resident (its workgroups wait for
+    // one another: at most four 256-thread workgroups per CU), layer tags of one byte
+    bool
+    attn_fused() const
+    {
+        return attn_fused_on && attn_psum_g && tb == 2 && n_own <= 254 &&
+               (unsigned)(nsplit * cfg.n_kv_heads) <= 4u * (unsigned)dev->prop.multiProcessorCount;
+    }
+
+    // a hand-off inside a launch that gave up (bounded waits, decode_kernels.hip): reported once, then cleared
+    mc_status
+    check_handoffs(const step_state_h& st)
+    {
+        if (!st.err) return MC_OK;
+        (void)hipMemsetAsync(&state->err, 0, 4, stream);
+        (void)hipStreamSynchronize(stream);
+        char buf[160];
+        snprintf(buf, sizeof buf, "decoder: an in-launch hand-off of the decode attention timed out (code 0x%08x): the workgroups of "
+                                  "the launch were not resident together; set MC_ATTN_FUSED=0", st.err);
+        return fail(MC_ERR_RUNTIME, buf);
+    }
+
     mc_status
     gemv(const linear_w& L, int pro, int epi, const void* x, void* y, const void* res,
          const void* norm_w, float mu)
@@ -709,6 +737,20 @@ struct mc_decoder {
                                 (uint32_t)cfg.max_seq_len, cfg.norm_eps, mu));
                 if (s != MC_OK) return s;
             }
+            if (attn_fused()) {
+                // scores, softmax, P.V                 (attention.h:191-203) in ONE launch, then Wo from the finished row
+                s = launch("mc_attn_fused_" + tname, (unsigned)(nsplit * KV), 1, 1, 256, 0,
+                           pack(q_rot, L.kc, L.vt, attn_out, attn_psum_g, attn_slab_g, state, (uint32_t)n_rep, (uint32_t)KV, (uint32_t)hd,
+                                (uint32_t)cfg.max_seq_len, scale_T, (uint32_t)nsplit, (uint32_t)(li + 1)));
+                if (s != MC_OK) return s;
+                s = gemma ? gemv(L.wo, 0, 0, attn_out, proj, nullptr, nullptr, mu) : gemv(L.wo, 0, 1, attn_out, hidden, x, nullptr, mu);
+                if (s != MC_OK) return s;
+                if (gemma && !fuse_pn) {
+                    s = launch("mc_rmsnorm_row_" + tname, 1, 1, 1, 1024, 0,
+                               pack(proj, L.attention_post_norm, x, hidden, (uint32_t)dim, cfg.norm_eps, mu));
+                    if (s != MC_OK) return s;
+                }
+            } else {
             // scores, softmax denominators         (attention.h:195-200)
             s = launch("mc_attn_scores_" + tname, nsplit, KV, 1, 256, 0,
                        pack(q_rot, L.kc, expv, psum, (void*)nullptr, state, (uint32_t)n_rep,
@@ -742,6 +784,7 @@ struct mc_decoder {
                                pack(proj, L.attention_post_norm, x, hidden, (uint32_t)dim, cfg.norm_eps, mu));
                     if (s != MC_OK) return s;
                 }
+            }
             }
             // ffn_norm + w1|w3 + act*mul           (transformer.h:135-137, 53-59)
             if (gemma && fuse_pn) {
@@ -1129,6 +1172,7 @@ mc_decoder_create(mc_device* dev, mc_library* lib, mc_queue* q, const mc_decoder
     if (const char* e = getenv("MC_GEMV_FULLGRID")) d->gemv_full_grid = atoi(e) != 0;
     if (const char* e = getenv("MC_GEMV_LIN")) d->gemv_lin = atoi(e) != 0;
     if (const char* e = getenv("MC_PV_FOLD")) d->pv_fold_on = atoi(e) != 0;
+    if (const char* e = getenv("MC_ATTN_FUSED")) d->attn_fused_on = atoi(e) != 0;
     if (const char* e = getenv("MC_LING_HALF")) d->ling_half = atoi(e) != 0;
     if (const char* e = getenv("MC_LIN_SPLIT")) d->lin_split = atoi(e) != 0;
     if (const char* e = getenv("MC_I8_LING14")) d->i8_ling14 = atoi(e) != 0;
@@ -1168,6 +1212,10 @@ mc_decoder_create(mc_device* dev, mc_library* lib, mc_queue* q, const mc_decoder
     d->pv_ranges = c.max_seq_len >= 8192 ? std::min(16, c.max_seq_len / 2048) : 1;
     if (const char* e = getenv("MC_PV_RANGES")) d->pv_ranges = std::max(1, std::min(64, atoi(e)));
     A(d->pv_parts, (size_t)std::max(d->pv_ranges, 4) * H * hd * 4);
+    if (d->tb == 2) {
+        A(d->attn_psum_g, (size_t)H * d->nsplit * 8);
+        A(d->attn_slab_g, (size_t)H * hd * d->nsplit * 8);
+    }
     A(d->taps, (size_t)(d->n_own + 1) * dim * tb);
     A(d->state, sizeof(step_state_h));
     d->tokens_cap = 1 << 16;
@@ -1599,8 +1647,11 @@ mc_decoder_step(mc_decoder* d, int32_t token, int32_t start_pos, const void* hid
     if (start_pos == 0) d->ring_turned = false;
     if (start_pos >= d->cfg.max_seq_len) d->ring_turned = true;
     if (next_token && d->last_stage) {
-        MC_HIP(hipMemcpyAsync(next_token, &d->state->token, 4, hipMemcpyDeviceToHost, d->stream));
+        step_state_h st;
+        MC_HIP(hipMemcpyAsync(&st, d->state, sizeof st, hipMemcpyDeviceToHost, d->stream));
         MC_HIP(hipStreamSynchronize(d->stream));
+        *next_token = st.token;
+        return d->check_handoffs(st);
     }
     return MC_OK;
 }
@@ -1739,8 +1790,10 @@ mc_decoder_generate(mc_decoder* d, int32_t first_token, int32_t start_pos, int32
     if (tokens_out) {
         MC_HIP(hipMemcpyAsync(tokens_out, d->tokens_dev, (size_t)n * 4, hipMemcpyDeviceToHost, d->stream));
     }
+    step_state_h st;
+    MC_HIP(hipMemcpyAsync(&st, d->state, sizeof st, hipMemcpyDeviceToHost, d->stream));
     MC_HIP(hipStreamSynchronize(d->stream));
-    return MC_OK;
+    return d->check_handoffs(st);
 }
 
 void*
@@ -2268,7 +2321,11 @@ mc_pipeline_generate(mc_pipeline* p, int32_t first_token, int32_t start_pos, int
         if (tokens_out) MC_HIP(hipMemcpyAsync(tokens_out, last->tokens_dev, (size_t)n * 4, hipMemcpyDeviceToHost, last->stream));
         for (mc_decoder* d : p->stages) {
             MC_HIP(hipSetDevice(d->dev->ordinal));
+            step_state_h st;
+            MC_HIP(hipMemcpyAsync(&st, d->state, sizeof st, hipMemcpyDeviceToHost, d->stream));
             MC_HIP(hipStreamSynchronize(d->stream));
+            s = d->check_handoffs(st);
+            if (s != MC_OK) return s;
         }
         return MC_OK;
     }
@@ -2294,8 +2351,10 @@ mc_pipeline_generate(mc_pipeline* p, int32_t first_token, int32_t start_pos, int
     if (W > 1 && r == 0) MC_NCCL(api.Recv(d->tokens_dev, (size_t)n, ncclInt32, W - 1, p->comm, d->stream), "ncclRecv(tokens)");
     if (tokens_out && (r == 0 || r == W - 1))
         MC_HIP(hipMemcpyAsync(tokens_out, d->tokens_dev, (size_t)n * 4, hipMemcpyDeviceToHost, d->stream));
+    step_state_h st;
+    MC_HIP(hipMemcpyAsync(&st, d->state, sizeof st, hipMemcpyDeviceToHost, d->stream));
     MC_HIP(hipStreamSynchronize(d->stream));
-    return MC_OK;
+    return d->check_handoffs(st);
 }
 
 // The prompt pass through the pipeline: the [len][dim] hidden rows hop stage to stage, the last stage's pick returns

@@ -31,7 +31,9 @@ struct step_state {
     int32_t rope_row;   // pos - rope_table_start
     int32_t rolled;     // number of rolls so far (debug)
     int32_t rope_start; // first position of the rope table window (nn/embedding.h:190-198); moved by mc_step_rope
-    int32_t pad[3];
+    uint32_t epoch;     // counts the steps since the decoder was created (never reset): the tag of in-launch hand-offs
+    uint32_t err;       // set by a kernel whose in-launch hand-off gave up (mc_attn_fused_T); 0 = none
+    int32_t pad[1];
 };
 
 __device__ __forceinline__ void
@@ -51,6 +53,7 @@ derive_state(step_state* st, int32_t max_seq, int32_t pre_len)
         st->kv_len = p + 1;
     }
     st->rope_row = st->pos - st->rope_start;
+    st->epoch += 1;
 }
 
 // start a step at an explicit (token, pos).  token < 0 keeps the token left by the argmax.
@@ -584,6 +587,250 @@ mc_attn_pv_reduce_float(const float* __restrict__ parts, float* __restrict__ out
     float a = 0.0f;
     for (uint32_t r = 0; r < nr; r++) a += parts[(size_t)r * n + i];
     out[i] = a;
+}
+
+// ------------------------------------------------------------------------------------------
+// Decode attention in ONE launch (T = bfloat): scores, softmax and P.V of include/metalchat/nn/attention.h:191-203 with the
+// rounding points of the two-launch form above (T(q.k), T(. scale), exp, p = T(e / sum), one rounding of the fp32 P.V sum).
+//
+// Why: the two launches cost 4.9 + 4.9 us per layer at S = 2048 for 2 x 4.2 MB of cache -- a launch boundary, a wave
+// start and a dependent prologue each (~ 3.3 us) before a byte moves, the numerators making a round trip through HBM as
+// fp32 (P.V fetched 1.54 x its algorithmic bytes: every 16-column workgroup re-read them).  Here workgroup (split, kv)
+// owns 64 cache slots of kv head `kv` for BOTH products:
+//   1. requests its K tile [64 slots][hd] AND its V tile [hd][64 slots] at once (neither depends on anything),
+//   2. scores + exp as mc_attn_scores_T; the numerators stay in LDS;
+//   3. publishes its partial denominators and gathers those of the other ranges of its kv head (hand-off A),
+//   4. P.V over its own 64 slots for all hd columns from the numerators in LDS,
+//   5. publishes the fp32 partial sums [n_rep][hd] and gathers, for the 16 outputs it is to finish, the partials of every
+//      range (hand-off B): added in RANGE ORDER, rounded once to T -- what mc_attn_pv_reduce_T does -- and stored as the
+//      final attention row (the Wo GEMV then reads 8 KB, not 64 KB of partial rows).
+// Hand-offs inside a launch follow MI355X_MICROARCH.md / cdna_hip_programming.md Guideline 16, form R2: every shared word
+// is ONE naturally aligned 8-byte {value, tag} granule written by one agent-scope (sc1) store and read by agent-scope
+// loads until its tag is this launch's -- the data is the flag, no fence, nothing depends on dispatch order or on which
+// XCD a workgroup lands (workgroups with equal blockIdx.x % 8 share an XCD in practice: the ranges of one kv head sit
+// together, so most hand-offs stay inside one L2 -- for speed only).  tag = step epoch * 256 + layer + 1: unique per
+// launch (the epoch counts steps since the decoder was created and is never reset), so a granule of an earlier launch is
+// never mistaken for this one's and nothing has to be cleared between launches.  Every wait is bounded (2 s of
+// s_memrealtime): on expiry the launch sets state.err and carries on with what it has; later waits see the flag and do not
+// wait at all, and the host reports it (mc_decoder_generate / _step return MC_ERR_RUNTIME).  The grid must be co-resident:
+// the host takes this path only while nsplit * n_kv <= 4 workgroups per CU.
+// ------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(1))) unsigned long long gu64_t;
+typedef __attribute__((address_space(1))) uint32_t gu32_t;
+
+__device__ __forceinline__ void
+granule_store(unsigned long long* g, uint32_t tag, uint32_t value)
+{
+    __hip_atomic_store((gu64_t*)g, ((unsigned long long)tag << 32) | value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long
+granule_load(const unsigned long long* g)
+{
+    return __hip_atomic_load((gu64_t*)g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// one round of a bounded wait: false = keep waiting.  `ok` is wave-uniform.
+struct handoff_wait {
+    unsigned long long t0;
+    uint32_t spins;
+    __device__ __forceinline__ handoff_wait() : t0(__builtin_amdgcn_s_memrealtime()), spins(0) {}
+    // true: give up (this launch or an earlier one of the token ran out of time)
+    __device__ __forceinline__ bool
+    expired(step_state* st, uint32_t code)
+    {
+        __builtin_amdgcn_s_sleep(4);
+        if ((++spins & 63u) != 0) return false;
+        if (__hip_atomic_load((gu32_t*)&st->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return true;
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { // 2 s at 100 MHz
+            __hip_atomic_store((gu32_t*)&st->err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return true;
+        }
+        return false;
+    }
+};
+
+template <int HD>
+__device__ __forceinline__ void
+attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const bf16_t* __restrict__ vt, bf16_t* __restrict__ out,
+              unsigned long long* psum_g, unsigned long long* slab_g, step_state* st, uint32_t n_rep, uint32_t KV, uint32_t max_seq,
+              float scale, uint32_t nsplit, uint32_t layer_tag)
+{
+    constexpr int KS = HD / 32;                 // MFMA k-steps of q.k
+    constexpr int NDB = HD / 16;                // 16-column blocks of the output
+    constexpr int NB = NDB >= 4 ? NDB / 4 : 1;  // ... per wave
+    constexpr int ES = PB + 4;                  // numerator row stride in LDS (floats): 16 rows read 32 bytes apart in the banks
+    __shared__ float wsum[4][16];
+    __shared__ float inv_s[16];
+    __shared__ __attribute__((aligned(16))) float ebuf[16 * ES];
+
+    const uint32_t S = (uint32_t)st->kv_len;
+    const uint32_t tag = st->epoch * 256u + layer_tag;
+    const uint32_t kv = blockIdx.x % KV, split = blockIdx.x / KV;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t col = lane & 15, c = lane >> 4;
+    const uint32_t p_begin = split * PB;
+    const uint32_t nact = (S + PB - 1) / PB;
+    const bool active = p_begin < S;
+
+    f32x4_t oacc[NB];
+#pragma unroll
+    for (int b = 0; b < NB; b++) oacc[b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    if (active) {
+        // ---- 1. K and V tiles: every load of the launch that touches the caches, issued before anything is waited for
+        const uint32_t pos = p_begin + wave * 16 + col;
+        const uint32_t lp = pos < S ? pos : S - 1;
+        const bf16_t* kbase = kc + ((size_t)kv * max_seq + lp) * HD;
+        uint4 kb[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) kb[ks] = *reinterpret_cast<const uint4*>(kbase + ks * 32 + c * 8);
+        uint4 vb[NB][2];
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+            const uint32_t db = wave + 4 * b;
+            const bf16_t* vrow = vt + ((size_t)kv * HD + (db < (uint32_t)NDB ? db : 0u) * 16 + col) * max_seq;
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const uint32_t p0 = p_begin + u * 32 + c * 8;
+                vb[b][u] = *reinterpret_cast<const uint4*>(vrow + (p0 + 8 <= max_seq ? p0 : max_seq - 8));
+            }
+        }
+        uint4 qa[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) {
+            qa[ks] = make_uint4(0, 0, 0, 0);
+            if (col < n_rep) qa[ks] = *reinterpret_cast<const uint4*>(q + (size_t)(kv * n_rep + col) * HD + ks * 32 + c * 8);
+        }
+        // ---- 2. scores (mc_attn_scores_bfloat: the same tile, the same roundings, the same partial sums)
+        f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++)
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, qa[ks]), __builtin_bit_cast(bf16x8_t, kb[ks]), acc, 0, 0, 0);
+        const uint32_t nm = (n_rep + 3) / 4;
+        for (uint32_t m = 0; m < nm; m++) {
+            const int src = (int)(m * 16 + col);
+            const float v0 = __shfl(acc[0], src, 64), v1 = __shfl(acc[1], src, 64);
+            const float v2 = __shfl(acc[2], src, 64), v3 = __shfl(acc[3], src, 64);
+            const float mine = c == 0 ? v0 : (c == 1 ? v1 : (c == 2 ? v2 : v3));
+            const uint32_t head = 4 * m + c;
+            float e = 0.0f;
+            if (head < n_rep && pos < S) {
+                float sc = BF::rt(mine);
+                sc = BF::rt(sc * scale);
+                e = exp_precise(sc);
+            }
+            if (head < 16) ebuf[head * ES + wave * 16 + col] = e;
+            e += __shfl_xor(e, 1, 64);
+            e += __shfl_xor(e, 2, 64);
+            e += __shfl_xor(e, 4, 64);
+            e += __shfl_xor(e, 8, 64);
+            if (col == 0 && head < 16) wsum[wave][head] = e;
+        }
+        __syncthreads();
+        // ---- 3. hand-off A: this range's partial denominators out, the kv head's denominators in
+        if (threadIdx.x < n_rep) {
+            const float tot = (wsum[0][threadIdx.x] + wsum[1][threadIdx.x]) + (wsum[2][threadIdx.x] + wsum[3][threadIdx.x]);
+            granule_store(psum_g + (size_t)(kv * n_rep + threadIdx.x) * nsplit + split, tag, __float_as_uint(tot));
+        }
+        for (uint32_t head = wave; head < n_rep; head += 4) {
+            // (softmax_inv's order: lane-strided partial sums, then the shuffle tree)
+            const unsigned long long* row = psum_g + (size_t)(kv * n_rep + head) * nsplit;
+            float t = 0.0f;
+            handoff_wait w;
+            for (;;) {
+                bool ok = true;
+                t = 0.0f;
+                for (uint32_t sp = lane; sp < nact; sp += 64) {
+                    const unsigned long long g = granule_load(row + sp);
+                    ok = ok && (uint32_t)(g >> 32) == tag;
+                    t += __uint_as_float((uint32_t)g);
+                }
+                if (__all(ok) || w.expired(st, 0xA0000000u | layer_tag)) break;
+            }
+            t = wave_sum(t);
+            if (lane == 0) inv_s[head] = 1.0f / t;
+        }
+        __syncthreads();
+        const float inv = col < n_rep ? inv_s[col] : 0.0f;
+        // ---- 4. P.V over the range's 64 slots: A = T(e * inv) from LDS (softmax.metal:84-86), B = the V tile
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+            if (wave + 4 * b >= (uint32_t)NDB) continue;
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const uint32_t p0 = p_begin + u * 32 + c * 8;
+                const float4 e0 = *reinterpret_cast<const float4*>(ebuf + col * ES + u * 32 + c * 8);
+                const float4 e1 = *reinterpret_cast<const float4*>(ebuf + col * ES + u * 32 + c * 8 + 4);
+                const float e[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
+                uint32_t wv[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    // (rows past n_rep of the numerator buffer were never written: they must not reach the MFMA as NaNs)
+                    const float pa = (col < n_rep && p0 + 2 * j < S) ? e[2 * j] * inv : 0.0f;
+                    const float pb = (col < n_rep && p0 + 2 * j + 1 < S) ? e[2 * j + 1] * inv : 0.0f;
+                    wv[j] = pack_bf16x2(pa, pb);
+                }
+                const uint4 pa4 = make_uint4(wv[0], wv[1], wv[2], wv[3]);
+                oacc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, pa4), __builtin_bit_cast(bf16x8_t, vb[b][u]), oacc[b], 0, 0, 0);
+            }
+        }
+        // ---- 5. the range's fp32 partial sums out: element r of lane (col, c) is head 4 c + r, column 16 db + col
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+            const uint32_t db = wave + 4 * b;
+            if (db >= (uint32_t)NDB) continue;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const uint32_t head = 4 * c + r;
+                if (head < n_rep)
+                    granule_store(slab_g + ((size_t)(kv * nsplit + split) * n_rep + head) * HD + db * 16 + col, tag, __float_as_uint(oacc[b][r]));
+            }
+        }
+    }
+    // ---- 6. hand-off B: chunk q = (head, 16-column block) of this kv head is finished by workgroup q % nsplit (every
+    // workgroup of the launch takes part, ranges past kv_len included): lane (col, jj) gathers column col of ranges jj,
+    // jj + 4, ..., adds them in that order, the four lane groups are added in order too, one rounding to T
+    const uint32_t nq = n_rep * (uint32_t)NDB;
+    for (uint32_t qi = split + wave * nsplit; qi < nq; qi += 4 * nsplit) {
+        const uint32_t head = qi / (uint32_t)NDB, db = qi % (uint32_t)NDB;
+        const unsigned long long* base = slab_g + ((size_t)kv * nsplit * n_rep + head) * HD + db * 16 + col;
+        const size_t jstride = (size_t)n_rep * HD;
+        float v = 0.0f;
+        handoff_wait w;
+        for (;;) {
+            bool ok = true;
+            v = 0.0f;
+            for (uint32_t j0 = 0; j0 < nact; j0 += 32) { // eight loads in flight per lane
+                unsigned long long g[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const uint32_t j = j0 + 4 * k + c;
+                    g[k] = granule_load(base + (size_t)(j < nact ? j : nact - 1) * jstride);
+                }
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const uint32_t j = j0 + 4 * k + c;
+                    if (j < nact) {
+                        ok = ok && (uint32_t)(g[k] >> 32) == tag;
+                        v += __uint_as_float((uint32_t)g[k]);
+                    }
+                }
+            }
+            if (__all(ok) || w.expired(st, 0xB0000000u | layer_tag)) break;
+        }
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        if (lane < 16) out[(size_t)(kv * n_rep + head) * HD + db * 16 + col] = f2bf(v);
+    }
+}
+
+extern "C" __global__ void __launch_bounds__(256)
+mc_attn_fused_bfloat(const bf16_t* q, const bf16_t* kc, const bf16_t* vt, bf16_t* out, unsigned long long* psum_g,
+                     unsigned long long* slab_g, step_state* st, uint32_t n_rep, uint32_t n_kv, uint32_t hd, uint32_t max_seq, float scale,
+                     uint32_t nsplit, uint32_t layer_tag)
+{
+    if (hd == 128) attn_fused_bf<128>(q, kc, vt, out, psum_g, slab_g, st, n_rep, n_kv, max_seq, scale, nsplit, layer_tag);
+    else if (hd == 64) attn_fused_bf<64>(q, kc, vt, out, psum_g, slab_g, st, n_rep, n_kv, max_seq, scale, nsplit, layer_tag);
+    else if (hd == 256) attn_fused_bf<256>(q, kc, vt, out, psum_g, slab_g, st, n_rep, n_kv, max_seq, scale, nsplit, layer_tag);
+    else if (hd == 32) attn_fused_bf<32>(q, kc, vt, out, psum_g, slab_g, st, n_rep, n_kv, max_seq, scale, nsplit, layer_tag);
 }
 
 // ------------------------------------------------------------------------------------------

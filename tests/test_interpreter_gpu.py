@@ -246,6 +246,7 @@ def test_sentence_piece_interpreter_reads_spaces_not_u2581(acc):
     assert len(ids) == 8
     regular = [i for i in ids if i < n_regular]
     assert regular, ids
+    text = text.decode("utf-8") if isinstance(text, bytes) else text
     assert "▁" not in text
     assert text == t.decode(ids).decode("utf-8")
     assert text.count(" w") == len(regular)

@@ -315,14 +315,14 @@ def test_greedy_pick_epilogue(acc, models, family):
     keys.upload(np.zeros(wgs, np.uint64))
     state = acc.to_device(np.zeros(12, np.int32))
     toks = acc.to_device(np.full(4, -1, np.int32))
-    desc = acc.to_device(np.frombuffer(struct.pack("<QQQQ", keys.device_ptr(), 0, state.device_ptr(), toks.device_ptr()), np.uint8))
+    desc = acc.to_device(np.frombuffer(struct.pack("<QQQQ", keys.device_ptr, 0, state.device_ptr, toks.device_ptr), np.uint8))
     got = launch(acc, kname(family, 1, 5), wptr, sptr, x, rows, rows, K, grp(family), res=desc, norm=nw, wgs=wgs, lds=lds)
     parity.exact(got, plain, f"{family} e5 logits")
     k = int(keys.download(np.uint64, wgs).max())
     assert 0xFFFFFFFF - (k & 0xFFFFFFFF) == want, (family, want)
     # mode 1: atomic key + ticket, the last workgroup writes the token and clears both
     kt = acc.to_device(np.zeros(2, np.uint64))
-    desc1 = acc.to_device(np.frombuffer(struct.pack("<QQQQ", kt.device_ptr(), kt.device_ptr() + 8, state.device_ptr(), toks.device_ptr()), np.uint8))
+    desc1 = acc.to_device(np.frombuffer(struct.pack("<QQQQ", kt.device_ptr, kt.device_ptr + 8, state.device_ptr, toks.device_ptr), np.uint8))
     got = launch(acc, kname(family, 1, 5), wptr, sptr, x, rows, rows, K, grp(family), res=desc1, norm=nw, wgs=wgs, lds=lds)
     parity.exact(got, plain, f"{family} e5 logits (ticket)")
     assert int(state.download(np.int32, 12)[0]) == want and int(toks.download(np.int32, 4)[0]) == want
@@ -361,8 +361,8 @@ def test_rope_and_cache_write_epilogue(acc, models, family):
         st[3], st[6] = slot, rrow
         state = acc.to_device(st)
         cb, sb = acc.to_device(fcos.reshape(-1)), acc.to_device(fsin.reshape(-1))
-        desc = acc.to_device(np.frombuffer(struct.pack("<QQQQQQIIII", q_out.device_ptr(), kc.device_ptr(), vt.device_ptr(), cb.device_ptr(),
-                                                       sb.device_ptr(), state.device_ptr(), H, KV, hd, ms), np.uint8))
+        desc = acc.to_device(np.frombuffer(struct.pack("<QQQQQQIIII", q_out.device_ptr, kc.device_ptr, vt.device_ptr, cb.device_ptr,
+                                                       sb.device_ptr, state.device_ptr, H, KV, hd, ms), np.uint8))
         launch(acc, kname(family, 1, 4), wptr, sptr, x, rows, rows, K, grp(family), res=desc, norm=nw, wgs=wgs, lds=lds)
         yf = mo.from_bf16(y)
         heads = yf[: (H + KV) * hd].reshape(H + KV, half, 2)      # packed: (2j, 2j + 1) = natural (j, j + hd/2)
@@ -402,7 +402,7 @@ def test_gemma_post_norm_prologue(acc, models, family):
     wptr, sptr, rows, inf, ng = dec.weight_ptrs(0, "w13")
     pwb, rsb = acc.to_device(post_w), acc.to_device(res)
     hb = acc.alloc(K * 2)
-    desc = acc.to_device(np.frombuffer(struct.pack("<QQQ", pwb.device_ptr(), rsb.device_ptr(), hb.device_ptr()), np.uint8))
+    desc = acc.to_device(np.frombuffer(struct.pack("<QQQ", pwb.device_ptr, rsb.device_ptr, hb.device_ptr), np.uint8))
     got = launch(acc, kname(family, 2, 0), wptr, sptr, x, rows, rows, K, grp(family), res=desc, norm=nw, wgs=5, lds=lds_bytes(family, K), mu=mu)
     parity.exact(hb.download(np.uint16, K), h.reshape(-1), f"{family} p2 hidden row")  # (the first norm is exact: dyadic row)
     ref_rows = np.stack([g1.reshape(-1), g3.reshape(-1)], 1).reshape(-1)
