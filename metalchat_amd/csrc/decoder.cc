@@ -261,9 +261,7 @@ struct mc_decoder {
     int gemv_block = 256;
     int gemv_wgs_per_cu = 2;
     bool gemv_lin = true;        // MC_GEMV_LIN=0: classic kernels everywhere (A/B)
-    bool lin_ksplit = false;     // MC_LIN_KSPLIT=1: w2's K range cut between two waves (sixteen per workgroup): measured SLOWER (10.2 vs 8.8 us)
     bool gemv_ling = true;       // MC_GEMV_LING=0: int8 / bfloat weights on the classic kernels (A/B)
-    bool lin_lds_ring = false;   // MC_LIN_LDS_RING=1 for code objects built with -DMC_GEMV_LIN_LDSRING=1 (they need the rings' LDS)
     bool i8_ling14 = true;       // MC_I8_LING14=0: int8 rows of 14 KiB (w2 of Llama-3-8B) on the classic kernel (A/B)
     bool lin_split = true;       // MC_LIN_SPLIT=0: K = 3072 on the classic kernels (A/B)
     bool ling_half = true;       // MC_LING_HALF=0: whole row pairs per wave whatever the matrix (A/B)
@@ -574,7 +572,6 @@ struct mc_decoder {
         // linear-order main loop (gemv.h): rows of whole KiB (K a multiple of 2048: 1, 2, 4, 7 or 14 KiB), whole row groups
         const int nch = L.in % 2048 == 0 ? L.in / 2048 : 0;
         const bool lin = lin_ok(L);
-        bool ksplit = false;
         const int pe_code = pro * 10 + epi;
         const bool lins = !lin && lin_split_ok(L) &&
                           (pe_code == 0 || pe_code == 10 || pe_code == 1 || pe_code == 12 || pe_code == 13 || pe_code == 14 || pe_code == 20 || pe_code == 23);
@@ -623,14 +620,6 @@ struct mc_decoder {
             wgs = (np + waves - 1) / waves;
             if (wgs > cap) wgs = cap;
             if (wgs > cus) wgs = wgs / cus * cus;
-            // long rows with at most a pair per wave (w2: 2048 pairs for 2048 waves): sixteen waves per workgroup, the K range
-            // of a pair cut between two of them (gemv.h LKS) -- half the chain of dependent round trips per wave
-            if (lin_ksplit && (nch == 7 || nch == 14) && pro == 0 && (epi == 0 || epi == 1) && lin_waves == 8 &&
-                np <= 64u * waves * wgs && np <= 2u * waves * cus) {
-                name += "k2";
-                block = 1024;
-                ksplit = true;
-            }
         }
         else if (lins) {}
         else if (m4) name += m4d ? "_m4d" : "_m4";
@@ -645,10 +634,6 @@ struct mc_decoder {
         if (m4d || lin || lins) lds = lds / 16 * 17; // 16 bytes of padding per 256 for the transposed reads
         lds += 128;
         if (lin || ling || lins) lds += waves * 512; // parked row sums: 64 pairs x 8 bytes per wave (gemv.h PARKB)
-        if (ksplit) lds += waves * 512 + 4352; // sixteen waves park; one chunk of zero activations behind the row
-        // the waves' DMA rings (gemv.h LDSR: rows of two or more KiB, build-time prologue): 7 or 8 KiB per wave
-        // + two slots of scale dwords per wave (256 bytes per 64 scale groups)
-        if (lin && nch >= 2 && lin_lds_ring) lds += waves * (((2 * nch) % 7 == 0 ? 7u : 8u) * 1024u + 2u * ((nch + 3u) / 4u) * 256u); // (also granted to the variants that do not use it)
         // EPI_STORE_PICK leaves one key per workgroup in pick_keys (pick_slots of them, folded by mc_argmax_keys)
         if (epi == 5 && wgs > pick_slots) wgs = pick_slots;
         if (capture_name) {
@@ -741,7 +726,7 @@ struct mc_decoder {
                 // scores, softmax, P.V                 (attention.h:191-203) in ONE launch, then Wo from the finished row
                 s = launch("mc_attn_fused_" + tname, (unsigned)(nsplit * KV), 1, 1, 256, 0,
                            pack(q_rot, L.kc, L.vt, attn_out, attn_psum_g, attn_slab_g, state, (uint32_t)n_rep, (uint32_t)KV, (uint32_t)hd,
-                                (uint32_t)cfg.max_seq_len, scale_T, (uint32_t)nsplit, (uint32_t)(li + 1)));
+                                (uint32_t)cfg.max_seq_len, scale_T, (uint32_t)nsplit, (uint32_t)(li + 1), (void*)nullptr));
                 if (s != MC_OK) return s;
                 s = gemma ? gemv(L.wo, 0, 0, attn_out, proj, nullptr, nullptr, mu) : gemv(L.wo, 0, 1, attn_out, hidden, x, nullptr, mu);
                 if (s != MC_OK) return s;
@@ -1177,8 +1162,6 @@ mc_decoder_create(mc_device* dev, mc_library* lib, mc_queue* q, const mc_decoder
     if (const char* e = getenv("MC_LIN_SPLIT")) d->lin_split = atoi(e) != 0;
     if (const char* e = getenv("MC_I8_LING14")) d->i8_ling14 = atoi(e) != 0;
     if (const char* e = getenv("MC_GEMV_LING")) d->gemv_ling = atoi(e) != 0;
-    if (const char* e = getenv("MC_LIN_KSPLIT")) d->lin_ksplit = atoi(e) != 0;
-    if (const char* e = getenv("MC_LIN_LDS_RING")) d->lin_lds_ring = atoi(e) != 0;
     if (const char* e = getenv("MC_LIN_WAVES")) d->lin_waves = std::max(1, std::min(16, atoi(e)));
     if (const char* e = getenv("MC_GEMMA_UNFUSED")) d->gemma_fuse = atoi(e) == 0;
     if (const char* e = getenv("MC_GEMV_M4")) d->gemv_m4 = atoi(e);

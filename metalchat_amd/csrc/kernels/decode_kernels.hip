@@ -652,8 +652,13 @@ template <int HD>
 __device__ __forceinline__ void
 attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const bf16_t* __restrict__ vt, bf16_t* __restrict__ out,
               unsigned long long* psum_g, unsigned long long* slab_g, step_state* st, uint32_t n_rep, uint32_t KV, uint32_t max_seq,
-              float scale, uint32_t nsplit, uint32_t layer_tag)
+              float scale, uint32_t nsplit, uint32_t layer_tag, unsigned long long* tl)
 {
+    // tl != null (tools/attn_timeline.py only): thread 0 of every workgroup leaves s_memrealtime stamps of its phases
+    auto stamp = [&](int i) {
+        if (tl && threadIdx.x == 0) tl[(size_t)blockIdx.x * 8 + i] = __builtin_amdgcn_s_memrealtime();
+    };
+    stamp(0);
     constexpr int KS = HD / 32;                 // MFMA k-steps of q.k
     constexpr int NDB = HD / 16;                // 16-column blocks of the output
     constexpr int NB = NDB >= 4 ? NDB / 4 : 1;  // ... per wave
@@ -725,6 +730,7 @@ attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const
             if (col == 0 && head < 16) wsum[wave][head] = e;
         }
         __syncthreads();
+        stamp(1);
         // ---- 3. hand-off A: this range's partial denominators out, the kv head's denominators in
         if (threadIdx.x < n_rep) {
             const float tot = (wsum[0][threadIdx.x] + wsum[1][threadIdx.x]) + (wsum[2][threadIdx.x] + wsum[3][threadIdx.x]);
@@ -749,6 +755,7 @@ attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const
             if (lane == 0) inv_s[head] = 1.0f / t;
         }
         __syncthreads();
+        stamp(2);
         const float inv = col < n_rep ? inv_s[col] : 0.0f;
         // ---- 4. P.V over the range's 64 slots: A = T(e * inv) from LDS (softmax.metal:84-86), B = the V tile
 #pragma unroll
@@ -772,6 +779,7 @@ attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const
                 oacc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, pa4), __builtin_bit_cast(bf16x8_t, vb[b][u]), oacc[b], 0, 0, 0);
             }
         }
+        stamp(3);
         // ---- 5. the range's fp32 partial sums out: element r of lane (col, c) is head 4 c + r, column 16 db + col
 #pragma unroll
         for (int b = 0; b < NB; b++) {
@@ -788,6 +796,7 @@ attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const
     // ---- 6. hand-off B: chunk q = (head, 16-column block) of this kv head is finished by workgroup q % nsplit (every
     // workgroup of the launch takes part, ranges past kv_len included): lane (col, jj) gathers column col of ranges jj,
     // jj + 4, ..., adds them in that order, the four lane groups are added in order too, one rounding to T
+    stamp(4);
     const uint32_t nq = n_rep * (uint32_t)NDB;
     for (uint32_t qi = split + wave * nsplit; qi < nq; qi += 4 * nsplit) {
         const uint32_t head = qi / (uint32_t)NDB, db = qi % (uint32_t)NDB;
@@ -820,17 +829,18 @@ attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const
         v += __shfl_xor(v, 32, 64);
         if (lane < 16) out[(size_t)(kv * n_rep + head) * HD + db * 16 + col] = f2bf(v);
     }
+    stamp(5);
 }
 
 extern "C" __global__ void __launch_bounds__(256)
 mc_attn_fused_bfloat(const bf16_t* q, const bf16_t* kc, const bf16_t* vt, bf16_t* out, unsigned long long* psum_g,
                      unsigned long long* slab_g, step_state* st, uint32_t n_rep, uint32_t n_kv, uint32_t hd, uint32_t max_seq, float scale,
-                     uint32_t nsplit, uint32_t layer_tag)
+                     uint32_t nsplit, uint32_t layer_tag, unsigned long long* tl)
 {
-    if (hd == 128) attn_fused_bf<128>(q, kc, vt, out, psum_g, slab_g, st, n_rep, n_kv, max_seq, scale, nsplit, layer_tag);
-    else if (hd == 64) attn_fused_bf<64>(q, kc, vt, out, psum_g, slab_g, st, n_rep, n_kv, max_seq, scale, nsplit, layer_tag);
-    else if (hd == 256) attn_fused_bf<256>(q, kc, vt, out, psum_g, slab_g, st, n_rep, n_kv, max_seq, scale, nsplit, layer_tag);
-    else if (hd == 32) attn_fused_bf<32>(q, kc, vt, out, psum_g, slab_g, st, n_rep, n_kv, max_seq, scale, nsplit, layer_tag);
+    if (hd == 128) attn_fused_bf<128>(q, kc, vt, out, psum_g, slab_g, st, n_rep, n_kv, max_seq, scale, nsplit, layer_tag, tl);
+    else if (hd == 64) attn_fused_bf<64>(q, kc, vt, out, psum_g, slab_g, st, n_rep, n_kv, max_seq, scale, nsplit, layer_tag, tl);
+    else if (hd == 256) attn_fused_bf<256>(q, kc, vt, out, psum_g, slab_g, st, n_rep, n_kv, max_seq, scale, nsplit, layer_tag, tl);
+    else if (hd == 32) attn_fused_bf<32>(q, kc, vt, out, psum_g, slab_g, st, n_rep, n_kv, max_seq, scale, nsplit, layer_tag, tl);
 }
 
 // ------------------------------------------------------------------------------------------

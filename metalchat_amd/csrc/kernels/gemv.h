@@ -34,10 +34,9 @@ namespace mc {
 namespace gemv {
 
 enum { WF_T = 0, WF_I8 = 1, WF_I4 = 2 };
-enum { Q_EXACT = 0, Q_FAST = 1, Q_DBG_STREAM = 2, Q_DBG_NOLOAD = 3, Q_DBG_TL = 4, // 2..4: tuning aids
+enum { Q_EXACT = 0, Q_FAST = 1, Q_DBG_STREAM = 2, Q_DBG_NOLOAD = 3, // 2, 3: tuning ablations (stream only / compute only)
        Q_M4 = 5,   // exact, the dot products of a lane on v_mfma_f32_4x4x4_16b_bf16 (int4, bfloat)
-       Q_M4D = 6,  // Q_M4 with the dequantisation itself on the same instruction (group % 128 == 0)
-       Q_DBG_TL4D = 7 }; // Q_M4D with the per-wave time stamps of Q_DBG_TL
+       Q_M4D = 6 }; // Q_M4 with the dequantisation itself on the same instruction (group % 128 == 0)
 enum { PRO_NONE = 0, PRO_RMSNORM = 1, PRO_POSTNORM = 2, PRO_PARTS = 3 };
 // PRO_PARTS (linear-order kernels only): the row is the decode attention output still in pieces --
 // `x` = fp32 partial P.V sums [PARTS_R][in], one per range of cache slots (mc_attn_pv_T with gridDim.z = PARTS_R);
@@ -232,7 +231,7 @@ mac(float& acc, const uint4& w, float s, const xregs<BF, 32>& x, float xsum,
         acc += asf((w.x ^ w.y ^ w.z ^ w.w) & 0x3FFFFFFFu) * s;
         return;
     }
-    if (QM == Q_EXACT || QM == Q_DBG_NOLOAD || QM == Q_DBG_TL) {
+    if (QM == Q_EXACT || QM == Q_DBG_NOLOAD) {
         // n = q + 8 in [0,15] converted with the full-rate v_cvt_f32_ubyteN; fma(n, s, -8 s) =
         // q*s EXACTLY (n*s has <= 12 significant bits, -8 s is a power-of-two multiple of s).
         const float c8 = -8.0f * s;
@@ -322,106 +321,9 @@ struct m4d_scale {
     uint2 b;  // B operand of the dequant MFMA
     mf_f4 c;  // C operand: -136 s in all four elements
 };
-__device__ __forceinline__ m4d_scale
-m4d_prepare(uint32_t sbits, uint32_t mask_x, uint32_t mask_y) // sbits: T(s) in both halves
-{
-    m4d_scale r;
-    r.b = make_uint2(sbits & mask_x, sbits & mask_y);
-    const float c = -136.0f * asf(sbits & 0xFFFF0000u);
-    r.c = mf_f4{c, c, c, c};
-    return r;
-}
-__device__ __forceinline__ void
-mac4d(mf_f4& acc, const uint4& w, const m4d_scale& sc, const uint2 (&x)[8])
-{
-    const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
-    const mf_s4 bs = __builtin_bit_cast(mf_s4, sc.b);
-    uint32_t nmask, ncst; // opaque operands: hipcc then selects v_and_or_b32 (see nib2_bf16)
-    asm("s_mov_b32 %0, 0x000F000F" : "=s"(nmask));
-    asm("v_mov_b32 %0, 0x43004300" : "=v"(ncst));
-#pragma unroll
-    for (int d = 0; d < 4; d++) {
-        const uint32_t v = ws[d];
-        const uint32_t t0 = (v & nmask) | ncst, t1 = ((v >> 4) & nmask) | ncst;
-        const uint32_t t2 = ((v >> 8) & nmask) | ncst, t3 = ((v >> 12) & nmask) | ncst;
-        const mf_f4 d1 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(mf_s4, make_uint2(t0, t1)), bs, sc.c, 0, 0, 0);
-        const mf_f4 d2 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(mf_s4, make_uint2(t2, t3)), bs, sc.c, 0, 0, 0);
-        const uint2 a0 = make_uint2(pack_bf16x2(d1[0], d1[1]), pack_bf16x2(d1[2], d1[3]));
-        const uint2 a1 = make_uint2(pack_bf16x2(d2[0], d2[1]), pack_bf16x2(d2[2], d2[3]));
-        acc = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(mf_s4, a0), __builtin_bit_cast(mf_s4, x[2 * d]), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(mf_s4, a1), __builtin_bit_cast(mf_s4, x[2 * d + 1]), acc, 0, 0, 0);
-    }
-}
-
-// (v & 0x000F000F) | 0x43004300 in ONE instruction.  hipcc emits v_and_b32 + v_or_b32 (a literal each): v_and_or_b32 is a
-// VOP3, which on gfx9 takes no literal and one constant-bus operand -- so the mask rides in an SGPR and the constant in a
-// VGPR.  Four instructions less per dword of eight weights (11 -> 7 bit operations).
-// (Plain C on OPAQUE operands, not an asm v_and_or_b32: hipcc pads no hazard for an instruction inside an asm string, and a
-// VGPR written there and read by the next MFMA as an operand needs two wait states -- NaNs on some waves.)
-__device__ __forceinline__ uint32_t
-nib2_bf16(uint32_t v, uint32_t mask_s, uint32_t cst_v)
-{
-    return (v & mask_s) | cst_v;
-}
-
-// mac4d with the eight accumulating MFMAs of a packet dealt over NA independent accumulators (the caller adds them up
-// when the row is complete): one accumulator is one dependency chain through the matrix pipe.
-template <int NA>
-__device__ __forceinline__ void
-mac4d_n(mf_f4 (&acc)[NA], const uint4& w, const m4d_scale& sc, const uint2 (&x)[8])
-{
-    const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
-    const mf_s4 bs = __builtin_bit_cast(mf_s4, sc.b);
-#ifndef MC_GEMV_M4D_SKEW
-#define MC_GEMV_M4D_SKEW 0 // (A/B on MI355X: w1|w3 15.03 -> 14.82 us, w2 10.6 -> 11.1: inside the noise, off) 1: the dequantising MFMAs of dword d + 1 are issued BEFORE the conversions of dword d read theirs
-#endif
-    uint32_t nmask, ncst; // opaque to hipcc (it would fold them back into literals): s_mov / v_mov once per packet
-    asm("s_mov_b32 %0, 0x000F000F" : "=s"(nmask));
-    asm("v_mov_b32 %0, 0x43004300" : "=v"(ncst));
-    auto deq = [&](int d, mf_f4& d1, mf_f4& d2) {
-        const uint32_t v = ws[d];
-        const uint32_t t0 = nib2_bf16(v, nmask, ncst), t1 = nib2_bf16(v >> 4, nmask, ncst);
-        const uint32_t t2 = nib2_bf16(v >> 8, nmask, ncst), t3 = nib2_bf16(v >> 12, nmask, ncst);
-        d1 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(mf_s4, make_uint2(t0, t1)), bs, sc.c, 0, 0, 0);
-        d2 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(mf_s4, make_uint2(t2, t3)), bs, sc.c, 0, 0, 0);
-    };
-    auto fin = [&](int d, const mf_f4& d1, const mf_f4& d2) {
-        const uint2 a0 = make_uint2(pack_bf16x2(d1[0], d1[1]), pack_bf16x2(d1[2], d1[3]));
-        const uint2 a1 = make_uint2(pack_bf16x2(d2[0], d2[1]), pack_bf16x2(d2[2], d2[3]));
-        mf_f4& A0 = acc[(2 * d) % NA];
-        mf_f4& A1 = acc[(2 * d + 1) % NA];
-        A0 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(mf_s4, a0), __builtin_bit_cast(mf_s4, x[2 * d]), A0, 0, 0, 0);
-        A1 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(mf_s4, a1), __builtin_bit_cast(mf_s4, x[2 * d + 1]), A1, 0, 0, 0);
-    };
-    if (MC_GEMV_M4D_SKEW) {
-        // a 4x4x4 MFMA's result can be read ~ 5 issue slots after it was issued: back to back with its conversion the
-        // wave sits in s_nop (hipcc's schedule of the unskewed source: MFMA, s_nop 4, cvt, cvt, MFMA, s_nop 0, MFMA,
-        // s_nop 2, ...) -- a wave alone on its SIMD ran at 61 % of the rate two waves reach together
-        mf_f4 p1, p2, q1, q2;
-        deq(0, p1, p2);
-        deq(1, q1, q2);
-        __builtin_amdgcn_sched_barrier(0);
-        fin(0, p1, p2);
-        deq(2, p1, p2);
-        __builtin_amdgcn_sched_barrier(0);
-        fin(1, q1, q2);
-        deq(3, q1, q2);
-        __builtin_amdgcn_sched_barrier(0);
-        fin(2, p1, p2);
-        __builtin_amdgcn_sched_barrier(0);
-        fin(3, q1, q2);
-    } else {
-#pragma unroll
-        for (int d = 0; d < 4; d++) {
-            mf_f4 d1, d2;
-            deq(d, d1, d2);
-            fin(d, d1, d2);
-        }
-    }
-}
-
-// Q_M4D with the nibbles UNMIXED BY THE MATRIX PIPE (linear-order kernels): the dequantisation above spends seven bit
-// operations per dword (three shifts, four and-or) to put each nibble into the mantissa of a bf16 of its own.  A bf16 whose
+// The nibbles UNMIXED BY THE MATRIX PIPE: the form above spends seven bit operations per dword (three shifts, four
+// and-or) to put each nibble into the mantissa of a bf16 of its own (round 2 measured it: 367 issue slots per row pair
+// against 245 for what follows; tools/experiments/README.md has the superseded code).  A bf16 whose
 // upper exponent bits are zero is linear in its low EIGHT bits -- subnormals m * 2^-133, and exponent field 1 continues
 // them: (128 + m) * 2^-133 -- and the 4x4x4 MFMA takes subnormal inputs exactly (tools/denorm_lab.hip: 0 of 256 wrong).
 // So a whole byte goes in as ONE operand, (16 hi + lo) * 2^-133, next to (16 hi) * 2^-133 (the same byte masked), and B
@@ -433,9 +335,6 @@ mac4d_n(mf_f4 (&acc)[NA], const uint4& w, const m4d_scale& sc, const uint2 (&x)[
 // weights, the products and the row sum are the reference's times 2^-M4B_Q (a power of two moves no rounding: weights
 // stay normal for 2^-89 < s < 2^31); the row sum is multiplied by 2^M4B_Q once.
 constexpr int M4B_P = 96, M4B_Q = 133 - M4B_P;
-#ifndef MC_GEMV_M4B_MAC16
-#define MC_GEMV_M4B_MAC16 0
-#endif
 typedef uint32_t mf_u4 __attribute__((ext_vector_type(4)));
 typedef float m4b_f2 __attribute__((ext_vector_type(2)));
 struct m4b_lane {
@@ -465,19 +364,11 @@ m4b_prepare(uint32_t fbits, const m4b_lane& k) // fbits: T(s) << 16, i.e. s as a
     const float f = asf(fbits);
     const m4b_f2 fm = m4b_f2{f, f} * m4b_f2{k.m0, k.m1}; // one v_pk_mul_f32
     r.b = make_uint2(__builtin_amdgcn_perm(__float_as_uint(fm[0]), 0u, k.sel), __builtin_amdgcn_perm(__float_as_uint(fm[1]), 0u, k.sel));
-#ifndef MC_GEMV_M4B_PKC
-#define MC_GEMV_M4B_PKC 1
-#endif
-    if (MC_GEMV_M4B_PKC) {
-        // -8 s 2^-Q in all four elements: two v_pk_mul_f32 (both halves read f) instead of a multiply and three moves;
-        // the two constant pairs are opaque copies (m4b_lane_consts), or hipcc folds the second product into moves again
-        const m4b_f2 ff = {f, f};
-        const m4b_f2 c01 = ff * k.ca, c23 = ff * k.cb;
-        r.c = mf_f4{c01[0], c01[1], c23[0], c23[1]};
-    } else {
-        const float c = f * k.ca[0]; // -8 s 2^-Q
-        r.c = mf_f4{c, c, c, c};
-    }
+    // -8 s 2^-Q in all four elements: two v_pk_mul_f32 (both halves read f) instead of a multiply and three moves;
+    // the two constant pairs are opaque copies (m4b_lane_consts), or hipcc folds the second product into moves again
+    const m4b_f2 ff = {f, f};
+    const m4b_f2 c01 = ff * k.ca, c23 = ff * k.cb;
+    r.c = mf_f4{c01[0], c01[1], c23[0], c23[1]};
     return r;
 }
 template <int NA>
@@ -495,21 +386,10 @@ mac4b_n(mf_f4 (&acc)[NA], const uint4& w, const m4d_scale& sc, const uint2 (&x)[
         const mf_f4 d2 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(mf_s4, make_uint2(t2, t3)), bs, sc.c, 0, 0, 0);
         const uint2 a0 = make_uint2(pack_bf16x2(d1[0], d1[1]), pack_bf16x2(d1[2], d1[3]));
         const uint2 a1 = make_uint2(pack_bf16x2(d2[0], d2[1]), pack_bf16x2(d2[2], d2[3]));
-        if (MC_GEMV_M4B_MAC16) {
-            // the eight products of the dword in ONE v_mfma_f32_16x16x32_bf16 (16 cycles of the pipe, as the two 4x4x4 it
-            // replaces, one issue slot less): lane l = (row l % 16, k chunk l / 16) of A and (column l % 16, chunk l / 16) of
-            // B, so D[i][i] is the sum of the private dot products of lanes i, i + 16, i + 32, i + 48 -- it sits in element
-            // i % 4 of lane 16 (i / 4) + i (m4b_diag); the other 240 results are cross terms nobody reads
-            typedef __bf16 mf_b8 __attribute__((ext_vector_type(8)));
-            const mf_u4 av = {a0.x, a0.y, a1.x, a1.y}, xv = {x[2 * d].x, x[2 * d].y, x[2 * d + 1].x, x[2 * d + 1].y};
-            mf_f4& A0 = acc[d % NA];
-            A0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mf_b8, av), __builtin_bit_cast(mf_b8, xv), A0, 0, 0, 0);
-        } else {
-            mf_f4& A0 = acc[(2 * d) % NA];
-            mf_f4& A1 = acc[(2 * d + 1) % NA];
-            A0 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(mf_s4, a0), __builtin_bit_cast(mf_s4, x[2 * d]), A0, 0, 0, 0);
-            A1 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(mf_s4, a1), __builtin_bit_cast(mf_s4, x[2 * d + 1]), A1, 0, 0, 0);
-        }
+        mf_f4& A0 = acc[(2 * d) % NA];
+        mf_f4& A1 = acc[(2 * d + 1) % NA];
+        A0 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(mf_s4, a0), __builtin_bit_cast(mf_s4, x[2 * d]), A0, 0, 0, 0);
+        A1 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(mf_s4, a1), __builtin_bit_cast(mf_s4, x[2 * d + 1]), A1, 0, 0, 0);
     }
 }
 
@@ -653,96 +533,6 @@ gelu_f32(float x)
     return 0.5f * x * (1.0f + (float)tanh((double)inner));
 }
 
-// ------------------------------------------------------------------------------------------
-// LDS accesses hipcc does not see.  A wave that fills its own ring in LDS by DMA (global_load_lds) must read the slots
-// with instructions the compiler's wait insertion knows nothing about: next to an LDS-DMA every compiler-visible LDS
-// access (and every workgroup fence) is preceded by s_waitcnt vmcnt(0) -- the whole ring drained per access.
-// Each read is tied to its wait through the "+v" operand of lds_wait, so no use can be scheduled in front of it.
-// ------------------------------------------------------------------------------------------
-typedef __attribute__((address_space(3))) char lds_char_t;
-typedef uint32_t lds_v4 __attribute__((ext_vector_type(4))); // (asm operands must be native vectors, not HIP's uint4 struct)
-typedef uint32_t lds_v2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)(lds_char_t*)p; }
-template <int OFF> __device__ __forceinline__ lds_v4 lds_rd128(uint32_t a)
-{
-    lds_v4 v;
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF) : "memory");
-    return v;
-}
-template <int OFF> __device__ __forceinline__ lds_v2 lds_rd64(uint32_t a)
-{
-    lds_v2 v;
-    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF) : "memory");
-    return v;
-}
-template <int OFF> __device__ __forceinline__ lds_v2 lds_rd64_tr16(uint32_t a) // ds_read_b64_tr_b16: EXEC must be all ones
-{
-    lds_v2 v;
-    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF) : "memory");
-    return v;
-}
-__device__ __forceinline__ uint32_t lds_rd32(uint32_t a)
-{
-    uint32_t v;
-    asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(a) : "memory");
-    return v;
-}
-__device__ __forceinline__ void lds_wait(uint32_t& a) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a)::"memory"); }
-__device__ __forceinline__ void lds_wr128(uint32_t a, const uint4& v)
-{
-    const lds_v4 t = {v.x, v.y, v.z, v.w};
-    asm volatile("ds_write_b128 %0, %1" ::"v"(a), "v"(t) : "memory");
-}
-__device__ __forceinline__ void lds_wr64(uint32_t a, uint32_t lo, uint32_t hi)
-{
-    const lds_v2 t = {lo, hi};
-    asm volatile("ds_write_b64 %0, %1" ::"v"(a), "v"(t) : "memory");
-}
-__device__ __forceinline__ void lds_wr32(uint32_t a, uint32_t v) { asm volatile("ds_write_b32 %0, %1" ::"v"(a), "v"(v) : "memory"); }
-__device__ __forceinline__ void lds_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-__device__ __forceinline__ void lds_wait(lds_v4& a) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a)::"memory"); }
-__device__ __forceinline__ void lds_wait(lds_v2& a) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a)::"memory"); }
-__device__ __forceinline__ void lds_wait(lds_v2 (&x)[8])
-{
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7])::"memory");
-}
-// Global loads hipcc does not see either: with an LDS-DMA outstanding its wait insertion treats the vector-memory counter
-// as out of order and waits with vmcnt(0) for ANY load result (the scales of the next row pair, the activation row) --
-// the ring drained again.  So next to the DMA ring every load is issued here and waited for by count (vm_wait<N>: at most N
-// younger vector-memory operations still outstanding; loads, stores and DMAs retire in issue order).
-__device__ __forceinline__ lds_v4 gload128(const void* sbase, uint32_t voff) // wave-uniform base + 32-bit lane offset
-{
-    lds_v4 v;
-    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(v) : "v"(voff), "s"(sbase) : "memory");
-    return v;
-}
-__device__ __forceinline__ uint32_t gload32(const void* sbase, uint32_t voff)
-{
-    uint32_t v;
-    asm volatile("global_load_dword %0, %1, %2" : "=v"(v) : "v"(voff), "s"(sbase) : "memory");
-    return v;
-}
-__device__ __forceinline__ uint32_t gload32v(const void* p) // per-lane 64-bit address
-{
-    uint32_t v;
-    asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(p) : "memory");
-    return v;
-}
-template <int N> __device__ __forceinline__ void vm_wait(lds_v4& a) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(a) : "n"(N) : "memory"); }
-template <int N> __device__ __forceinline__ void vm_wait(uint32_t& a) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(a) : "n"(N) : "memory"); }
-template <int I, int N, typename F> __device__ __forceinline__ void static_for(F&& f) // f(integral_constant<I>) ... f(integral_constant<N - 1>)
-{
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<I + 1, N>(f);
-    }
-}
-template <int N> __device__ __forceinline__ void vm_wait() // at most N vector-memory operations still outstanding
-{
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-__device__ __forceinline__ void wg_barrier_raw() { asm volatile("s_barrier" ::: "memory"); }
-
 // A tile as it comes out of memory: the scale stays RAW (bf16 bits or f32 bits) until the tile is
 // consumed -- converting it in the load path would make the compiler wait for that load (and, as
 // vector memory returns in order, for every older one) right after issuing it.
@@ -757,14 +547,13 @@ template <int R> struct tile {
 // LNCH / LTP != 0 select the LINEAR-ORDER main loop (int4, bfloat, Q_M4D only; rows of LNCH whole KiB): see below.
 // LRING: ring slots in tiles (0: the MC_GEMV_LIN_INFLIGHT rule); LWAVES: waves of the workgroup when it is fixed at build time
 // (0: read blockDim -- a dependent load from the hidden kernel arguments before anything else can be addressed).
-// LGEN: the linear-order loop for the formats that dequantise on the VALU (int8, plain bfloat weights), rows of LGEN whole KiB.
-// LKS = 2 (linear-order int4, long rows, plain prologue): the K range of a row pair is cut between TWO waves.
+// LGEN: the linear-order loop for int8 and plain bfloat weights, rows of LGEN whole KiB.
 // LSPLIT (linear-order int4, LNCH = 3): rows of 1.5 KiB (K = 3072, Gemma-7B's QKV and w1|w3).  TWO rows are swept as one 3 KiB
 // "super row" against the activation row staged TWICE in LDS ([x, x]: chunk 1 is then x[2048..3071] | x[0..1023], exactly what
 // the two halves of the middle packet need with the unchanged lane mapping); one accumulator per packet, the middle one split
 // by a lane mask when the super row is complete.  A super row is a rotation / SiLU pair, so the epilogues see what they always
 // see; the loop's "pair" is two super rows = one quad of rows (and one quad of scales).
-template <int WF, typename T, int QM, int PRO, int EPI, int R, int LNCH = 0, int LTP = 0, int LRING = 0, int LWAVES = 0, int LGEN = 0, int LKS = 1, int LSPLIT = 0>
+template <int WF, typename T, int QM, int PRO, int EPI, int R, int LNCH = 0, int LTP = 0, int LRING = 0, int LWAVES = 0, int LGEN = 0, int LSPLIT = 0>
 __device__ __forceinline__ void
 body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __restrict__ xp,
      void* __restrict__ yp, const void* __restrict__ resp, const void* __restrict__ normp,
@@ -785,22 +574,8 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
         asm volatile("" ::"s"(wp), "s"(sp), "s"(xp), "s"(yp), "s"(resp), "s"(normp), "s"(out_rows), "s"(in), "s"(group), "s"(eps),
                      "s"(mu), "s"(lora_rank), "s"(gridDim.x));
     }
-#ifdef MC_LIN_XCD_DELAY
-    // tuning experiment (tools/lin_timeline.py, profiles/r02_gemv_ablations.log): in the decode chain the XCDs start the
-    // workgroups of a launch one after another over ~1.1 us (XCC 0, 1, 2, 3, 6, 7, 4, 5; each XCD's own 32 workgroups within
-    // 0.2 us) and finish in that order -- every wave needs the same time from "row staged" to its end.  Holding the early
-    // XCDs back (nibble i: units of s_sleep 2, ~0.055 us, for the waves of XCC i) does not bring the late ones forward: the
-    // stagger is the dispatcher's, not the memory system's.  +0.15..0.3 us per launch: off.
-    if (LNCH > 0) {
-        uint32_t xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        const uint32_t nd = ((uint32_t)(MC_LIN_XCD_DELAY) >> (4 * (xcc & 7))) & 15u;
-        for (uint32_t i = 0; i < nd; i++) __builtin_amdgcn_s_sleep(2);
-    }
-#endif
-    constexpr bool M4 = (QM == Q_M4 || QM == Q_M4D || QM == Q_DBG_TL4D) && WF == WF_I4 && T::bytes == 2;
-    constexpr bool M4D = (QM == Q_M4D || QM == Q_DBG_TL4D) && M4;
-    constexpr bool TL = QM == Q_DBG_TL || QM == Q_DBG_TL4D;
+    constexpr bool M4 = (QM == Q_M4 || QM == Q_M4D) && WF == WF_I4 && T::bytes == 2;
+    constexpr bool M4D = QM == Q_M4D && M4;
     // Q_M4D reads the row with ds_read_b64_tr_b16, four lanes of a block 256 bytes apart: 16 bytes of
     // padding behind every 256 spread them over the banks (packet p sits in slot p + p / 16)
     constexpr uint32_t CHUNK_LDS = M4D ? CHUNK * T::bytes / 16 * 17 : CHUNK * T::bytes;
@@ -811,7 +586,7 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
     // LDS: the activation row, zero-padded to a whole number of chunks, then 32 floats of scratch
     char* xs = smem;
     float* red = reinterpret_cast<float*>(smem + (size_t)nchunks * CHUNK_LDS);
-    static_assert(EPI != EPI_STORE_PICK || ((LNCH > 0 || LGEN > 0) && LWAVES > 0 && LWAVES <= 8 && LKS == 1), "the pick rides on the linear-order kernels");
+    static_assert(EPI != EPI_STORE_PICK || ((LNCH > 0 || LGEN > 0) && LWAVES > 0 && LWAVES <= 8), "the pick rides on the linear-order kernels");
     if (EPI == EPI_STORE_PICK && threadIdx.x == 0) { // the workgroup's key and arrival count (pick_finish): the scratch's last floats,
         red[24] = 0.0f;                              // which no prologue of an eight-wave workgroup touches; a prologue barrier follows
         red[25] = 0.0f;
@@ -834,14 +609,8 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
     const char* wbase = static_cast<const char*>(wp);
     const uint32_t lane16 = lane * 16;
 
-    unsigned long long tl0 = 0, tl1 = 0, tlt[4] = {0, 0, 0, 0}; // start, prologue done, end of tiles 0..3
-    unsigned long long tlx = 0, tlb = 0;                          // TL variants: row arrived, row sum known
-    uint32_t tln = 0;
-    if (TL) tl0 = __builtin_amdgcn_s_memrealtime();
-#ifndef MC_GEMV_RING
-#define MC_GEMV_RING 3
-#endif
-    constexpr int RING = MC_GEMV_RING;
+    // (ring depth A/B on the w1|w3 matrix: 3 slots 19.5 us, 4: 20.9, 5: 21.4, 6: 22.1 -- see the note at the main loop)
+    constexpr int RING = 3;
     tile<R> ring[RING]; // register ring: RING - 1 tiles in flight while one is dequantised
 
     // Loads are UNCONDITIONAL straight-line code: hipcc only emits counted s_waitcnt vmcnt(N) --
@@ -861,29 +630,16 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
         for (int r = 0; r < R; r++) {
             uint32_t row = rg_l * R + r;
             row = row < out_rows ? row : out_rows - 1;
-#ifndef MC_GEMV_FORCE_NOLOAD
-#define MC_GEMV_FORCE_NOLOAD 0 // tuning ablation (tools/variants): every kernel of the family computes on synthesised tiles
-#endif
-            if (QM == Q_DBG_NOLOAD || MC_GEMV_FORCE_NOLOAD) {
+            if (QM == Q_DBG_NOLOAD) {
                 t.w[r] = make_uint4(lane * 0x01010101u + off, rg, c * 0x11111111u, r);
                 t.s[r] = T::bytes == 2 ? 0x3F803F80u : 0x3F800000u;
             } else {
-                // weights are read exactly once per token: non-temporal loads keep them from
-                // displacing the activation rows / KV lines other kernels re-read from L2
-                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-#ifndef MC_GEMV_NT
-#define MC_GEMV_NT 0 // A/B on MI355X: +2 % on the 60 MB w1|w3 stream, -5..-10 % on the 8-30 MB matrices
-#endif
-                if (MC_GEMV_NT) {
-                    const u32x4 v = __builtin_nontemporal_load(
-                        reinterpret_cast<const u32x4*>(base + (size_t)row * rowb + off));
-                    t.w[r] = make_uint4(v.x, v.y, v.z, v.w);
-                } else {
-                    t.w[r] = *reinterpret_cast<const uint4*>(base + (size_t)row * rowb + off);
-                }
+                // (default cache policy here: non-temporal loads were +2 % on the 60 MB w1|w3 stream and -5..-10 % on
+                //  the 8-30 MB matrices in this loop; the linear-order loops below stream non-temporally)
+                t.w[r] = *reinterpret_cast<const uint4*>(base + (size_t)row * rowb + off);
             }
         }
-        if (WF != WF_T && QM != Q_DBG_NOLOAD && !MC_GEMV_FORCE_NOLOAD) {
+        if (WF != WF_T && QM != Q_DBG_NOLOAD) {
             // weight index of the lane's packet -> group; scales are stored in row quads
             const uint32_t k = (cbyte + off) * (8 / F::BITS == 0 ? 1 : 8 / F::BITS);
             const uint32_t g = live ? (group ? k >> glog : 0u) : 0u;
@@ -1037,10 +793,7 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
             k.rg += stride;
         }
     };
-#ifndef MC_GEMV_WAVEMAJOR
-#define MC_GEMV_WAVEMAJOR 0 // 1: row group = wave * gridDim.x + workgroup -- a matrix with fewer row groups than waves still
-#endif                      // puts work on every CU (A/B: tools/ring_ab.py)
-    const uint32_t first_rg = MC_GEMV_WAVEMAJOR ? wave * gridDim.x + blockIdx.x : blockIdx.x * nwaves + wave;
+    const uint32_t first_rg = blockIdx.x * nwaves + wave;
     cursor ld{first_rg, 0};
     cursor cp = ld;
     const uint32_t ntiles = first_rg < NG ? ((NG - first_rg + stride - 1) / stride) * nchunks : 0;
@@ -1075,30 +828,10 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
                 }
             }
         }
-#ifndef MC_GEMV_XBAR
-#define MC_GEMV_XBAR 1 // 1: a raw s_barrier (no memory wait) between the row requests and the first weight requests: with one
-#endif                 // workgroup per CU every row packet is then AHEAD of every weight packet in the CU's in-order memory pipe
-#ifndef MC_GEMV_XFIRST
-#define MC_GEMV_XFIRST 0 // 1 (linear-order kernels): the first weight tiles are requested only once the row has ARRIVED
-#endif
-        constexpr bool XFIRST = MC_GEMV_XFIRST && LNCH > 0;
-        uint32_t xf_never = 0;
-        if (XFIRST) asm volatile("s_mov_b32 %0, 0" : "=s"(xf_never));
-        if (!XFIRST) {
-            if (MC_GEMV_XBAR) asm volatile("s_barrier" ::: "memory");
-            prefetch(); // the first weight tile(s): requested behind the row, before the row is consumed
-        } else if (fits) {
-            // With 2048 waves asking for 4 KiB of weights each the moment they start, the row (and the kernel arguments and
-            // instructions of the waves that start a little later) queue behind 8 MB of weight requests: the row takes
-            // 1.3 - 1.7 us to arrive instead of the 0.56 us of an idle memory system (tools/floor_lab).
-            asm volatile("" ::"v"(xr[0].x), "v"(xr[MAXP - 1].w)); // the row is here
-            if (PRO != PRO_NONE) asm volatile("" ::"v"(nr[MAXP - 1].w));
-            if (xf_never) asm volatile("s_nop 0");
-            prefetch();
-            if (xf_never) asm volatile("s_nop 0");
-        } else {
-            prefetch();
-        }
+        // a raw s_barrier (no memory wait) between the row requests and the first weight requests: with one workgroup per
+        // CU every row packet is then AHEAD of every weight packet in the CU's in-order memory pipe
+        asm volatile("s_barrier" ::: "memory");
+        prefetch(); // the first weight tile(s): requested behind the row, before the row is consumed
         if (fits) {
 #pragma unroll
             for (int i = 0; i < MAXP; i++)
@@ -1189,14 +922,8 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
                 for (int i = 0; i < MAXP; i++) ss += sumsq(xr[i]);
                 // DPP wave reduction, one LDS slot per wave, one barrier
                 const float wsum_ = wave_sum_dpp(ss);
-                if (TL) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    tlx = __builtin_amdgcn_s_memrealtime();
-                    __builtin_amdgcn_sched_barrier(0);
-                }
                 if (lane == 0) red[wave] = wsum_;
                 __syncthreads();
-                if (TL) tlb = __builtin_amdgcn_s_memrealtime();
                 float tot = 0.0f;
                 for (uint32_t i = 0; i < nwaves; i++) tot += red[i];
                 const float inv = 1.0f / sqrtf(tot / (float)in + eps);
@@ -1240,14 +967,8 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
     // 14.0 vs 10.9 (slots of one wave-load: 22.8; K dealt round-robin for DRAM locality: no change).
     // The 16 x 64-byte access shape, the per-tile barrier and the cross-wave sums cost more than
     // the dot products save.)
-    // MC_GEMV_PRE of the ring tiles are requested before the row is consumed, the rest right after
-    // the barrier (A/B: tools/gemv_sweep.py with MC_HSACO=..._preN.hsaco)
-#ifndef MC_GEMV_PRE
-#define MC_GEMV_PRE 1
-#endif
-#ifndef MC_GEMV_PRE_P0
-#define MC_GEMV_PRE_P0 MC_GEMV_PRE // kernels without a norm prologue (Wo, w2)
-#endif
+    // ONE ring tile is requested before the row is consumed, the rest right after the barrier (1 / 2 / 3 ahead: 17.3 / 18.3 /
+    // 19.3 us on the w1|w3 matrix)
     // ======================================================================================
     // LINEAR-ORDER main loop (LNCH > 0).  Measured on MI355X (tools/lds_stream_lab, tools/lin_timeline.py):
     //   * ONE launch streams a 67 MB matrix at 6.06 TB/s, launch boundary included, when every wave walks its own
@@ -1290,15 +1011,10 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
         constexpr bool RAGGED = NPK % BD != 0;
         constexpr bool XREG = LGEN * (KPL / 2) <= 64;      // the whole row in registers (KPL / 2 VGPRs per packet)
         constexpr bool SCALED = WF != WF_T;
-#ifndef MC_GEMV_I8M
-#define MC_GEMV_I8M 1 // int8-held weights dequantised and multiplied on the matrix pipe (mac8b_n).  On 4 KiB rows no faster than the VALU path
-                      // (those kernels wait for memory: w1|w3 of Llama-3-8B int8 121 MB in 20.8 us = 5.8 TB/s either way), but it needs
-                      // half the registers, which is what lets 14 KiB rows (w2) onto the linear order at all: 13.1 -> 11.6 us
-#endif
-        constexpr bool I8M = MC_GEMV_I8M && WF == WF_I8;
-#ifndef MC_GEMV_LING_HALF
-#define MC_GEMV_LING_HALF 1
-#endif
+        // int8-held weights are dequantised and multiplied on the matrix pipe (mac8b_n).  On 4 KiB rows no faster than the VALU
+        // path (those kernels wait for memory: w1|w3 of Llama-3-8B int8 121 MB in 20.8 us = 5.8 TB/s either way), but it needs
+        // half the registers, which is what lets 14 KiB rows (w2) onto the linear order at all: 13.1 -> 11.6 us
+        constexpr bool I8M = WF == WF_I8;
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
         uint32_t never;
         asm volatile("s_mov_b32 %0, 0" : "=s"(never));
@@ -1333,7 +1049,7 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
         // ONE ROW PER WAVE when the launch has at least two waves per row pair (small models: 2048 rows of Wo / w2 are 1024
         // pairs for 2048 waves -- with whole pairs half the waves had nothing to do and the other half streamed a pair
         // each through four KiB in flight) and the epilogue treats the rows of a pair separately: wave gw takes row gw
-        constexpr bool HALF_OK = MC_GEMV_LING_HALF && (EPI == EPI_STORE || EPI == EPI_RESID);
+        constexpr bool HALF_OK = EPI == EPI_STORE || EPI == EPI_RESID;
         const bool half = HALF_OK && 2u * NP <= nw_total;
         const uint32_t pq = NP / nw_total, prem = NP - pq * nw_total;
         const uint32_t pb = half ? gw >> 1 : gw * pq + min(gw, prem);
@@ -1375,7 +1091,7 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
             }
         };
         uint4 gring[RS];
-        if (MC_GEMV_XBAR) asm volatile("s_barrier" ::: "memory");
+        asm volatile("s_barrier" ::: "memory"); // (the row's requests stay ahead of the weight requests: stage_x)
         gscales(gsa, pb, pb < pe);
 #pragma unroll
         for (int j = 0; j < RS; j++) {
@@ -1573,74 +1289,33 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
     if constexpr (LNCH > 0) {
         static_assert(WF == WF_I4 && T::bytes == 2 && M4D, "linear order: int4 weights, bfloat rows, Q_M4D");
         static_assert(LNCH % LTP == 0, "a row is a whole number of tiles");
-        // K split (LKS = 2): a wave of the first half of the workgroup takes chunks [0, SUB) of its pairs' rows, its partner
-        // in the second half chunks [SUB, 2 SUB) -- the last of them past the row when LNCH is odd: a dead tile (one broadcast
-        // line of weights) against a chunk of ZERO activations appended to the row in LDS.  w2 of Llama-3-8B is 2048 row pairs
-        // for 2048 waves: ONE pair of 14 KiB per wave, fetched through a two-KiB ring (a deeper one is slower, see the ring
-        // note) = seven dependent round trips of ~ 0.7 us; with sixteen waves per CU a wave has half of that chain.
-        // MEASURED (parity-green, MC_LIN_KSPLIT=1): w2 10.2 us against 8.8 on the eight-wave kernel -- like every other
-        // sixteen-wave variant of this round, slower.  Off.
-        static_assert(LKS == 1 || (LKS == 2 && LTP == 1 && LWAVES % 2 == 0 && (PRO == PRO_NONE || PRO == PRO_PARTS)), "K split: one-KiB tiles, no norm prologue");
-        constexpr int SUB = LKS == 2 ? (LNCH + 1) / 2 : LNCH / LTP; // tiles per row (of this wave's share)
-        constexpr int TPP = 2 * SUB;                                // tiles per row pair
-        const uint32_t nwp = nwaves / LKS;                          // waves that own row pairs
-        const uint32_t khalf = LKS == 2 ? wave / nwp : 0u, cbase = khalf * SUB;
-#ifndef MC_GEMV_LIN_INFLIGHT
-#define MC_GEMV_LIN_INFLIGHT 4 // KiB in flight per wave: the ring holds two pairs when they fit, else one (A/B on MI355X, 8 waves per CU:
-                               // 4 KiB 16.2 us, 8 KiB 17.5 us on the 60 MB w1|w3 matrix -- a CU keeps ~32 KiB in flight whatever is asked)
-#endif
+        constexpr int SUB = LNCH / LTP; // tiles per row
+        constexpr int TPP = 2 * SUB;    // tiles per row pair
+        // KiB in flight per wave: the ring holds two pairs when they fit in 4 KiB, else one (A/B on MI355X, 8 waves per CU: 4 KiB
+        // 16.2 us, 8 KiB 17.5 us on the 60 MB w1|w3 matrix -- a CU keeps ~32 KiB in flight whatever is asked)
         // ring slots (tiles).  A slot is refilled the moment its tile has been consumed, with the tile LR ahead in the
         // wave's stream: LR < TPP keeps the bytes in flight small while a load is issued after EVERY tile -- with whole
         // rows as tiles (LR = 2) a wave computed a row with only the other row's load in flight, and half of every
         // row's compute time was added to the load latency instead of hiding behind it (tools/lin_timeline.py).
-        constexpr int LR = LRING ? LRING : (2 * TPP * LTP <= MC_GEMV_LIN_INFLIGHT ? 2 * TPP : TPP);
+        constexpr int LR = LRING ? LRING : (2 * TPP * LTP <= 4 ? 2 * TPP : TPP);
         static_assert(LR % TPP == 0 || TPP % LR == 0, "the ring and a pair's tiles divide one another");
-#ifndef MC_GEMV_LSPLIT_XREG
-#define MC_GEMV_LSPLIT_XREG 0 // 1: the doubled 3072-long row in 48 VGPRs instead of eight LDS reads per packet -- measured the same (588-593 tokens/s)
-#endif
-        constexpr bool XREG = LNCH <= 2 || (LSPLIT && MC_GEMV_LSPLIT_XREG);
-        static_assert(LKS == 1 || !XREG, "K split: the row is read from LDS");
-#ifndef MC_GEMV_LIN_RAWPARK
-#define MC_GEMV_LIN_RAWPARK 0
-#endif
-        // MC_GEMV_LIN_RAWPARK=1 (measured, off): a completed row's 64 per-lane partial sums PARKED as they are (one ds_write_b32
-        // per row, rows 65 dwords apart: lane L reading row 2 L meets no bank conflict) and added up at the end of the wave by
-        // the lane that finishes the pair -- 128 LDS reads and adds by 16 lanes per 16 pairs instead of two DPP chains + four
-        // readlanes per pair in the middle of the weight stream (the reductions cost 1.0 us of a 15 us w1|w3 launch).  The head
-        // (31 pairs per wave) gains 4 us, every layer kernel LOSES 1 us: with 1 - 7 pairs per wave the serial adds sit at the
-        // end of the launch, where nothing hides them (and the sequential sum is a little less accurate than the tree:
-        // the 70B-width parity test then sits at its bound).
-        constexpr int PARKP = 16;                                               // pairs per flush
-        constexpr uint32_t PARKB = MC_GEMV_LIN_RAWPARK ? PARKP * 2 * 65 * 4 : 512; // bytes of parking space per wave (decoder.cc: lin_park_bytes)
-#ifndef MC_GEMV_LIN_NT
-#define MC_GEMV_LIN_NT 1
-#endif
+        // (split rows: the doubled 3072-long row in 48 VGPRs instead of eight LDS reads per packet measured the same)
+        constexpr bool XREG = LNCH <= 2;
+        constexpr uint32_t PARKB = 512; // bytes of parking space per wave: 64 pairs x (a, b) (decoder.cc sizes the LDS)
 #ifndef MC_GEMV_LIN_STREAM
-#define MC_GEMV_LIN_STREAM 0 // tuning ablation: loads and epilogues only
+#define MC_GEMV_LIN_STREAM 0 // tuning ablation: loads and epilogues only (profiles/r02_gemv_ablations.log)
 #endif
 #ifndef MC_GEMV_LIN_NOLOAD
 #define MC_GEMV_LIN_NOLOAD 0 // tuning ablation: tiles and scales synthesised in registers, no weight traffic
 #endif
-#ifndef MC_GEMV_LIN_TL
-#define MC_GEMV_LIN_TL 0 // tuning aid: per-wave s_memrealtime stamps (start, row staged, first 12 tiles, end) into `resp` (kernels whose epilogue ignores it)
-#endif
-#ifndef MC_GEMV_LIN_DECOUPLE
-#define MC_GEMV_LIN_DECOUPLE 0 // tuning ablation: the arithmetic runs on a synthesised packet BEFORE the loaded one is waited for (and only folded into a dummy)
-#endif
-#ifndef MC_GEMV_LIN_ACCS
-#define MC_GEMV_LIN_ACCS 1 // independent accumulators per row (the MFMAs of a packet dealt round-robin): 1 = one dependency chain
-#endif
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-#ifndef MC_GEMV_LIN_LEANPRO
-#define MC_GEMV_LIN_LEANPRO 1
-#endif
         // The prologue with everything known at build time (K = 2048 LNCH, 64 LWAVES threads): NXP packets of 16 bytes
         // per thread, no padding, no fallback path.  A wave issues ~ 0.5 instructions per ns, and the generic
         // stage_x -- unrolled for the longest row it may meet, every iteration predicated -- put 620 (plain row) to
         // 1160 (rmsnorm) instructions in front of the first multiply of a launch that lasts 5 - 16 us: its 1.3 - 1.7 us
         // from wave start to "row staged" were instruction issue, not memory latency (an idle memory system delivers
         // the row in 0.56 us, tools/floor_lab).  The row is requested FIRST, before the wave even works out its range.
-        constexpr bool LEAN = MC_GEMV_LIN_LEANPRO && LWAVES > 0 && PRO != PRO_POSTNORM && !LSPLIT; // (split rows: the generic staging, then the copy)
+        constexpr bool LEAN = LWAVES > 0 && PRO != PRO_POSTNORM && !LSPLIT; // (split rows: the generic staging, then the copy)
         static_assert(PRO != PRO_PARTS || LEAN, "PRO_PARTS needs the build-time prologue");
         constexpr uint32_t NPK = 256u * LNCH, BD = LWAVES ? 64u * LWAVES : 64u;
         constexpr int NXP = LEAN ? (int)((NPK + BD - 1) / BD) : 1;
@@ -1653,34 +1328,7 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
         float4 lpr[PRO == PRO_PARTS ? NXP : 1][PRO == PRO_PARTS ? 2 * PARTS_R : 1];
         uint32_t lin_never;
         asm volatile("s_mov_b32 %0, 0" : "=s"(lin_never));
-#ifndef MC_GEMV_LIN_LDSRING
-#define MC_GEMV_LIN_LDSRING 0 // 1: the weights through a DMA ring in LDS (below; launch with MC_LIN_LDS_RING=1).  Correct (tools/lin_check.py,
-#endif                        // the context tests) and, in the real kernels, SLOWER than the register ring: see the numbers at the block
-        // (its loads are all issued through the asm forms)
-#ifndef MC_LDSR_ONLY
-#define MC_LDSR_ONLY 0 // tuning / bisection: the DMA ring for rows of exactly this many KiB only
-#endif
-        constexpr bool LDSR = MC_GEMV_LIN_LDSRING && LEAN && LNCH >= 2 && (MC_LDSR_ONLY == 0 || MC_LDSR_ONLY == LNCH) && !MC_GEMV_LIN_TL && !MC_GEMV_LIN_STREAM && !MC_GEMV_LIN_NOLOAD && !MC_GEMV_LIN_DECOUPLE;
-        constexpr int NXL = PRO == PRO_PARTS ? NXP * 2 * PARTS_R : (PRO == PRO_RMSNORM ? 2 * NXP : NXP); // row loads per thread
-        lds_v4 axr[LDSR ? NXL : 1];
-        if constexpr (LDSR) {
-#pragma unroll
-            for (int i = 0; i < NXP; i++) {
-                const uint32_t p = tid + i * BD;
-                const uint32_t pc = (RAGGED && i == NXP - 1) ? min(p, NPK - 1) : p;
-                if constexpr (PRO == PRO_PARTS) {
-#pragma unroll
-                    for (int r = 0; r < PARTS_R; r++) {
-                        const char* pb_r = static_cast<const char*>(xp) + (size_t)r * in * 4; // wave-uniform
-                        axr[(i * PARTS_R + r) * 2] = gload128(pb_r, pc * 32);
-                        axr[(i * PARTS_R + r) * 2 + 1] = gload128(pb_r, pc * 32 + 16);
-                    }
-                } else {
-                    axr[i] = gload128(xp, pc * 16);
-                    if constexpr (PRO == PRO_RMSNORM) axr[NXP + i] = gload128(normp, pc * 16);
-                }
-            }
-        } else if constexpr (LEAN) {
+        if constexpr (LEAN) {
             const uint4* xg = static_cast<const uint4*>(xp);
             const uint4* ng = static_cast<const uint4*>(normp);
 #pragma unroll
@@ -1702,37 +1350,16 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
             }
             if (lin_never) asm volatile("" ::"v"(PRO == PRO_PARTS ? __float_as_uint(lpr[0][0].x) : lxr[0].x)); // ends the basic block: the requests stay in front of what follows
         }
-        const uint32_t nw_total = gridDim.x * nwp, gw = blockIdx.x * nwp + (LKS == 2 ? wave - khalf * nwp : wave);
-        static_assert(!LSPLIT || (LNCH == 3 && LTP == 1 && LKS == 1 && LWAVES > 0), "split rows: 1.5 KiB each, two to a 3 KiB super row");
+        const uint32_t nw_total = gridDim.x * nwaves, gw = blockIdx.x * nwaves + wave;
+        static_assert(!LSPLIT || (LNCH == 3 && LTP == 1 && LWAVES > 0), "split rows: 1.5 KiB each, two to a 3 KiB super row");
         // (LSPLIT: the loop's pairs are pairs of SUPER rows = quads of rows; NPR counts the real pairs the epilogues finish)
         const uint32_t NPR = (out_rows + 1) / 2;
         const uint32_t NP = LSPLIT ? out_rows / 4 : NPR; // row pairs (the host takes this path only for even out_rows; LSPLIT: whole quads)
         const size_t rowb_l = LSPLIT ? 2 * rowb : rowb;
-#ifndef MC_GEMV_LIN_ROWS
-#define MC_GEMV_LIN_ROWS 0
-#endif
-        // ROW-GRANULAR SPANS (MC_GEMV_LIN_ROWS=1; the QKV kernel of K = 4096): 3072 row pairs are 1.5 per wave -- with whole pairs
-        // half the waves of a CU stream two and the other half one, and the launch lasts as long as two (tools/lin_timeline.py: a
-        // pair takes a wave 1.5 us whatever its neighbours do).  Here a WORKGROUP owns whole pairs and its rows are dealt evenly
-        // over its waves: a wave's span may begin or end in the middle of a pair.  It is swept as before in steps of two rows
-        // ("pseudo pairs", row offset `roff` against the real ones; the arithmetic of a row that is another wave's is skipped),
-        // the row sums go to a workgroup-wide array in LDS and the pairs are finished behind a barrier, thread t the workgroup's
-        // pair t.  MEASURED (parity-green: the full-size, context, golden and decode tests): QKV 6.5 -> 6.9 us, 689 / 697 / 682 ->
-        // 691 / 694 / 676 tokens/s -- three rows each are no faster than two pairs for half the waves (two scale loads per
-        // chunk where a pair has one dword, a workgroup barrier, twelve epilogues in one wave).  Off.
-        constexpr bool LROW = MC_GEMV_LIN_ROWS && EPI == EPI_QKV_ROPE && LNCH == 2 && LTP == 1 && LKS == 1 && LWAVES > 0 && LRING == 0 && LEAN &&
-                              !MC_GEMV_LIN_TL && !MC_GEMV_LIN_STREAM && !MC_GEMV_LIN_NOLOAD && !MC_GEMV_LIN_DECOUPLE && !MC_GEMV_LIN_LDSRING && !MC_GEMV_LIN_RAWPARK;
         // equal ranges to within one pair, without a 64-bit division: the first NP % nw_total waves take one pair more
         const uint32_t pq = NP / nw_total, prem = NP - pq * nw_total;
-        // (LROW) the workgroup's pairs [wp0, wp1), its rows [2 wp0, 2 wp1) dealt over the waves: this wave's rows [rwb, rwe)
-        const uint32_t wpq = NP / gridDim.x, wprem = NP - wpq * gridDim.x;
-        const uint32_t wp0 = blockIdx.x * wpq + min(blockIdx.x, wprem), wp1 = wp0 + wpq + (blockIdx.x < wprem ? 1u : 0u);
-        const uint32_t wrows = 2u * (wp1 - wp0), rq = wrows / nwp, rrem = wrows - rq * nwp;
-        const uint32_t rwb = min(2u * wp0 + wave * rq + min(wave, rrem), out_rows);
-        const uint32_t rwe = min(rwb + rq + (wave < rrem ? 1u : 0u), out_rows);
-        const uint32_t roff = LROW ? (rwb & 1u) : 0u;
-        const uint32_t pb = LROW ? rwb >> 1 : gw * pq + min(gw, prem);
-        const uint32_t pe = LROW ? pb + (rwe - rwb + 1u) / 2u : pb + pq + (gw < prem ? 1u : 0u);
+        const uint32_t pb = gw * pq + min(gw, prem);
+        const uint32_t pe = pb + pq + (gw < prem ? 1u : 0u);
         const char* sbase = static_cast<const char*>(sp);
 
         uint4 lring[LR][LTP];
@@ -1762,19 +1389,14 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
         auto ltile = [&](uint4 (&dst)[LTP], uint32_t pr, int t, bool live) {
             // wave-uniform 64-bit base (SALU) + a 32-bit lane offset: the load takes its base from an SGPR pair and the
             // address costs ONE vector instruction (the per-lane 64-bit form cost ~ 10 per tile)
-            const uint32_t chunk0 = (LKS == 2 ? cbase : 0u) + (uint32_t)(t % SUB) * LTP;
-            if (LKS == 2) live = live && chunk0 < (uint32_t)LNCH;
-            if (LROW) live = live && pr * 2 + roff + (uint32_t)(t / SUB) < rwe; // (the second row of the span's last step may not be the wave's)
-            const uint64_t rb = ((uint64_t)pr * 2 + roff + (uint64_t)(t / SUB)) * rowb_l + (uint64_t)chunk0 * 1024;
+            const uint32_t chunk0 = (uint32_t)(t % SUB) * LTP;
+            const uint64_t rb = ((uint64_t)pr * 2 + (uint64_t)(t / SUB)) * rowb_l + (uint64_t)chunk0 * 1024;
             // (masks, not selects: given a select between two addresses hipcc builds a branch, and a load behind a branch
-            //  costs every counted s_waitcnt vmcnt(N))
+            //  costs every counted s_waitcnt vmcnt(N).  Dead tiles re-reading the wave's OWN first line instead of the buffer's
+            //  first line measured the same.)
             const uint32_t lm = 0u - (uint32_t)live;
-#ifndef MC_GEMV_LIN_DEADOWN
-#define MC_GEMV_LIN_DEADOWN 0 // 1: dead tiles re-read the wave's OWN first line instead of the buffer's first line, which every wave of the launch
-#endif                        // requests TPP times at its end (one hot line per XCD?).  Measured: no difference (w1|w3 13.2 / 13.3, QKV 6.4 / 6.5 us) -- off
             const uint64_t lm64 = ((uint64_t)lm << 32) | lm;
-            const uint64_t dead = MC_GEMV_LIN_DEADOWN ? (uint64_t)min(pb, NP - 1) * 2 * rowb_l : 0ull;
-            const char* a = wbase + ((rb & lm64) | (dead & ~lm64));
+            const char* a = wbase + (rb & lm64);
             const uint32_t lo = lane16 & lm;
 #pragma unroll
             for (int p = 0; p < LTP; p++) {
@@ -1784,58 +1406,31 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
                     continue;
                 }
                 const u32x4* ap = reinterpret_cast<const u32x4*>(a + p * 1024 + lo);
-                const u32x4 v = MC_GEMV_LIN_NT ? __builtin_nontemporal_load(ap) : *ap;
+                const u32x4 v = __builtin_nontemporal_load(ap); // (weights are read once per token)
                 dst[p] = make_uint4(v.x, v.y, v.z, v.w);
             }
         };
         // scales of pair pr: half a row quad ([ngroups][4] bf16 per four rows) per chunk; the lane's 32 weights of
         // chunk c sit in group (2048 c + 32 lane) / group
         auto lscales = [&](uint32_t (&q)[LNCH], uint32_t pr, bool live) {
-            if constexpr (LROW) {
-                // rows 2 pr + roff and the one behind it: element (row, g) of the quad layout sits at ((row / 4) ngroups + g) 4 + row % 4;
-                // with roff = 1 the two are not one dword (and may sit in different quads): two 2-byte loads
-                const uint32_t r0 = min(pr * 2 + roff, out_rows - 1), r1 = min(r0 + 1, out_rows - 1);
-                const uint32_t lm = 0u - (uint32_t)live;
-                const uint64_t u0 = ((uint64_t)(r0 >> 2) * ngroups * 4 + (r0 & 3u)) * 2, u1 = ((uint64_t)(r1 >> 2) * ngroups * 4 + (r1 & 3u)) * 2;
-                const uint64_t lm64 = ((uint64_t)lm << 32) | lm;
-                const char* a0 = sbase + (u0 & lm64);
-                const char* a1 = sbase + (u1 & lm64);
-#pragma unroll
-                for (int c = 0; c < LNCH; c++) {
-                    const uint32_t g = group ? ((2048u * (uint32_t)c + 32u * lane) >> glog) : 0u;
-                    const uint32_t lo = *reinterpret_cast<const uint16_t*>(a0 + ((g * 8u) & lm));
-                    const uint32_t hi = *reinterpret_cast<const uint16_t*>(a1 + ((g * 8u) & lm));
-                    q[c] = lo | (hi << 16);
-                }
-                return;
-            }
             const uint64_t ub = (((uint64_t)(pr >> 1) * ngroups) * 4 + (pr & 1u) * 2) * 2; // wave-uniform part
             const uint32_t lm = 0u - (uint32_t)live;
             const char* a = sbase + (ub & (((uint64_t)lm << 32) | lm));
 #pragma unroll
-            for (int c = 0; c < (LKS == 2 ? SUB : LNCH); c++) {
+            for (int c = 0; c < LNCH; c++) {
                 if (MC_GEMV_LIN_NOLOAD) {
                     q[c] = 0x3C003C00u;
                     continue;
                 }
-                const uint32_t cc = (LKS == 2 ? cbase : 0u) + (uint32_t)c; // (a chunk past the row: any valid scale, it meets zeros)
-                const uint32_t lmc = LKS == 2 ? (cc < (uint32_t)LNCH ? lm : 0u) : lm;
-                const uint32_t g = group ? ((2048u * cc + 32u * lane) >> glog) : 0u;
-                q[c] = *reinterpret_cast<const uint32_t*>(a + ((g * 8u) & lmc));
+                const uint32_t g = group ? ((2048u * (uint32_t)c + 32u * lane) >> glog) : 0u;
+                q[c] = *reinterpret_cast<const uint32_t*>(a + ((g * 8u) & lm));
             }
         };
 
-        unsigned long long ltl[16];
-        uint32_t ltn = 2;
-        unsigned long long lclk0 = 0;
-        if (MC_GEMV_LIN_TL) {
-            ltl[0] = __builtin_amdgcn_s_memrealtime();
-            lclk0 = __builtin_amdgcn_s_memtime(); // shader clock: with the 100 MHz stamps it gives the clock the wave really ran at
-        }
         constexpr int U = LR >= TPP ? LR / TPP : 1; // pairs per unrolled iteration
         // an opaque zero: `if (lin_never) use(v)` keeps the load of v in front of that point (a value needed on both
         // sides of a branch cannot be sunk to its later use) without waiting for it on the path that is taken
-        const uint32_t eo_pair = LSPLIT ? min(2 * pb + lane, NPR - 1) : (LROW ? min(wp0 + tid, NP - 1) : min(pb + lane, NP - 1)); // the pair this lane will finish in the wave's first flush
+        const uint32_t eo_pair = LSPLIT ? min(2 * pb + lane, NPR - 1) : min(pb + lane, NP - 1); // the pair this lane will finish in the wave's first flush
         if (EPI == EPI_RESID && T::bytes == 2) {
             eo_res = reinterpret_cast<const uint32_t*>(resp)[eo_pair];
             if (lin_never) asm volatile("" ::"v"(eo_res));
@@ -1847,263 +1442,11 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
             // them is a flat_load, which counts on both wait counters
             eo_q = *static_cast<const qkv_epilogue*>(resp);
             const __attribute__((address_space(1))) int32_t* stp = (const __attribute__((address_space(1))) int32_t*)eo_q.state;
-            if constexpr (LDSR) {
-                eo_slot = gload32v(reinterpret_cast<const char*>(eo_q.state) + 12);
-                eo_rrow = gload32v(reinterpret_cast<const char*>(eo_q.state) + 24);
-            } else {
-                eo_slot = (uint32_t)stp[3];
-                eo_rrow = (uint32_t)stp[6];
-            }
+            eo_slot = (uint32_t)stp[3];
+            eo_rrow = (uint32_t)stp[6];
             if (lin_never) asm volatile("" ::"s"(eo_slot), "s"(eo_rrow), "s"(eo_q.H), "s"(eo_q.KV), "s"(eo_q.hd), "s"(eo_q.max_seq));
         }
 
-#ifndef MC_GEMV_LDS_INFLIGHT
-#define MC_GEMV_LDS_INFLIGHT 4
-#endif
-        // ==================================================================================
-        // The wave's weights through its OWN ring in LDS, filled by DMA (global_load_lds, 1 KiB per instruction).
-        // With a register ring a slot can be refilled only when its packet has been multiplied, so a wave computes with
-        // less in flight than its ring holds and every load has (period - one packet's arithmetic) to come back; a DMA
-        // needs no register: packet q + D is requested the moment packet q has been READ out of LDS, D stay in flight
-        // whatever the arithmetic does, and NS - D landed packets absorb the jitter.  tools/overlap_lab (58.7 MB, the real
-        // mac4d arithmetic, launch boundary included): register ring of 2 / 4 / 7 KiB 15.1 / 13.5 / 13.1 us, LDS ring of
-        // 7 KiB with 4 in flight 11.3 us (streaming alone: 10.4 and 9.8).
-        // IN THE REAL KERNELS it did not carry over (same box, per launch): QKV 6.9 -> 7.6 us, w1|w3 14.9 -> 15.8, Wo 5.1 -> 5.1,
-        // w2 10.1 -> 9.9; 3 or 4 DMAs in flight the same; refills pinned in front of the arithmetic 16.4.  What the lab kernel
-        // does not have is per pair: the scale reads, two wave reductions, the parked sums -- and a prologue.  Kept, OFF by
-        // default (MC_GEMV_LIN_LDSRING), for the next attempt at the loop's overlap.
-        // ==================================================================================
-        if constexpr (LDSR) {
-            constexpr int PP = 2 * LNCH;                 // packets (KiB) per row pair
-#ifndef MC_LDSR_NS
-#define MC_LDSR_NS 0 // tuning: ring slots per wave (the LDS the host grants is sized for 7 or 8)
-#endif
-#ifndef MC_LDSR_NOSCALE
-#define MC_LDSR_NOSCALE 0 // tuning ablation: constant scale, no scale reads
-#endif
-#ifndef MC_LDSR_NOREDUCE
-#define MC_LDSR_NOREDUCE 0 // tuning ablation: no wave reductions / parked sums (results wrong)
-#endif
-            constexpr int NS = MC_LDSR_NS ? MC_LDSR_NS : (PP % 7 == 0 ? 7 : 8); // ring slots per wave (decoder.cc sizes the LDS)
-            constexpr int DD = MC_GEMV_LDS_INFLIGHT;     // DMAs in flight per wave
-            static_assert(DD < NS && DD <= PP && (NS % PP == 0 || PP % NS == 0), "ring geometry");
-            constexpr int UL = NS > PP ? NS / PP : 1;    // pairs per unrolled iteration (slots stay static)
-            constexpr bool XREG = LNCH <= 2;
-            const uint32_t xs_a = lds_addr(xs), red_a = lds_addr(red);
-            const uint32_t park_a = red_a + 128 + wave * PARKB;                     // 64 pairs x (a, b) per wave
-            char* ring = smem + (size_t)nchunks * CHUNK_LDS + 128 + LWAVES * PARKB + wave * (NS * 1024);
-            const uint32_t ring_a = lds_addr(ring) + lane16;
-            // stream packet (pair pr, tile t) -> global address; dead packets read one broadcast line at the buffer base
-            auto dma = [&](uint32_t pr, int t, int slot, bool live) {
-                const uint64_t rb = ((uint64_t)pr * 2 + (uint64_t)(t / LNCH)) * rowb + (uint64_t)(t % LNCH) * 1024;
-                const uint32_t lm = 0u - (uint32_t)live;
-                const char* a = wbase + (rb & (((uint64_t)lm << 32) | lm)) + (lane16 & lm);
-                typedef const void __attribute__((address_space(1))) gvoid_t;
-                typedef __attribute__((address_space(3))) void lvoid_t;
-                __builtin_amdgcn_global_load_lds((gvoid_t*)a, (lvoid_t*)(ring + slot * 1024), 16, 0, MC_GEMV_LIN_NT ? 2 : 0);
-            };
-            // The scales travel by DMA as well, 4 bytes per lane: a register that a load is still writing must not live across
-            // the loop's entry or back edge (hipcc copies such values there -- v_mov of a register whose load has not
-            // landed: garbage scales in the first pair of half the waves).  Per pair: the dword (rows a, b) of every scale
-            // group once, group gi = lane + 64 j -> LDS slot[j][lane]; read back at group (2048 c + 32 lane) / group.
-            constexpr int NSC = (LNCH + 3) / 4; // DMAs per pair: at most 16 LNCH groups (groups of >= 128 weights)
-            constexpr int SCB = NSC * 256;      // bytes per slot; two slots per wave: this pair's and the next one's
-            char* scr = smem + (size_t)nchunks * CHUNK_LDS + 128 + LWAVES * PARKB + LWAVES * (NS * 1024) + wave * (2 * SCB);
-            const uint32_t scr_a = lds_addr(scr);
-            auto sdma = [&](uint32_t pr, uint32_t slot, bool live) {
-                const uint64_t ub = (((uint64_t)(pr >> 1) * ngroups) * 4 + (pr & 1u) * 2) * 2;
-                const uint32_t lm = 0u - (uint32_t)live;
-                const char* a = sbase + (ub & (((uint64_t)lm << 32) | lm));
-                typedef const void __attribute__((address_space(1))) gvoid_t;
-                typedef __attribute__((address_space(3))) void lvoid_t;
-#pragma unroll
-                for (int j = 0; j < NSC; j++) {
-                    const uint32_t gi = min(lane + 64u * j, ngroups - 1);
-                    __builtin_amdgcn_global_load_lds((gvoid_t*)(a + ((gi * 8u) & lm)), (lvoid_t*)(scr + slot * SCB + j * 256), 4, 0, 0);
-                }
-            };
-            uint32_t goff[LNCH]; // LDS byte offset of the lane's scale group per chunk
-#pragma unroll
-            for (int c = 0; c < LNCH; c++) goff[c] = (group ? ((2048u * c + 32u * lane) >> glog) : 0u) * 4u;
-            if (MC_GEMV_XBAR) wg_barrier_raw();
-            sdma(pb, 0, pb < pe);
-#pragma unroll
-            for (int j = 0; j < DD; j++) dma(pb + j / PP, j % PP, j % NS, pb + j / PP < pe);
-            // ---- the row into LDS (build-time geometry, see LEAN above), every LDS access through the asm forms.
-            // Younger than the row's requests: at least the NSC scale DMAs and the DD weight DMAs (and the early epilogue
-            // operands: waiting for two or three of those as well costs nothing here)
-#pragma unroll
-            for (int i = 0; i < NXL; i++) vm_wait<NSC + DD>(axr[i]);
-            if (EPI == EPI_QKV_ROPE) {
-                vm_wait<NSC + DD>(eo_slot);
-                vm_wait<NSC + DD>(eo_rrow);
-            }
-            auto live = [&](int i) { return !(RAGGED && i == NXP - 1) || tid + i * BD < NPK; };
-            rowv4 (&xr)[NXP] = lxr;
-#pragma unroll
-            for (int i = 0; i < NXP; i++) {
-                if constexpr (PRO != PRO_PARTS) xr[i] = axr[i];
-                if constexpr (PRO == PRO_RMSNORM) lnr[i] = axr[NXP + i];
-            }
-            if constexpr (PRO == PRO_PARTS) {
-#pragma unroll
-                for (int i = 0; i < NXP; i++) {
-                    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int r = 0; r < PARTS_R; r++) { // ranges in order, as mc_attn_pv_reduce_T adds them
-                        const lds_v4 lo = axr[(i * PARTS_R + r) * 2], hi = axr[(i * PARTS_R + r) * 2 + 1];
-                        a[0] += asf(lo.x); a[1] += asf(lo.y); a[2] += asf(lo.z); a[3] += asf(lo.w);
-                        a[4] += asf(hi.x); a[5] += asf(hi.y); a[6] += asf(hi.z); a[7] += asf(hi.w);
-                    }
-                    xr[i] = make_uint4(pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]), pack_bf16x2(a[4], a[5]), pack_bf16x2(a[6], a[7]));
-                }
-            }
-            if constexpr (PRO == PRO_RMSNORM) {
-                float ss = 0.0f;
-#pragma unroll
-                for (int i = 0; i < NXP; i++) {
-                    const uint32_t vv[4] = {xr[i].x, xr[i].y, xr[i].z, xr[i].w};
-                    float s1 = 0.0f;
-#pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        const float a = asf(vv[e] << 16), b = asf(vv[e] & 0xFFFF0000u);
-                        s1 += a * a;
-                        s1 += b * b;
-                    }
-                    ss += live(i) ? s1 : 0.0f;
-                }
-                const float wsum_ = wave_sum_dpp(ss);
-                if (lane == 0) lds_wr32(red_a + wave * 4, __float_as_uint(wsum_));
-                lds_wait();
-                wg_barrier_raw();
-                lds_v4 r0 = lds_rd128<0>(red_a), r1 = lds_rd128<16>(red_a);
-                lds_wait(r0);
-                lds_wait(r1);
-                const uint32_t rr[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
-                static_assert(LWAVES <= 8, "the eight-wave reduction scratch");
-                float tot = 0.0f;
-#pragma unroll
-                for (int i = 0; i < LWAVES; i++) tot += asf(rr[i]);
-                const float inv = 1.0f / sqrtf(tot / (float)in + eps);
-#pragma unroll
-                for (int i = 0; i < NXP; i++) {
-                    const uint32_t vv[4] = {xr[i].x, xr[i].y, xr[i].z, xr[i].w};
-                    const uint32_t ww[4] = {lnr[i].x, lnr[i].y, lnr[i].z, lnr[i].w};
-                    uint32_t o[4];
-#pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        const float a = (mu + asf(ww[e] << 16)) * asf(vv[e] << 16) * inv;
-                        const float b = (mu + asf(ww[e] & 0xFFFF0000u)) * asf(vv[e] & 0xFFFF0000u) * inv;
-                        o[e] = pack_bf16x2(a, b);
-                    }
-                    xr[i] = make_uint4(o[0], o[1], o[2], o[3]);
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < NXP; i++)
-                if (live(i)) lds_wr128(xs_a + xpk(tid + i * BD) * 16, make_uint4(xr[i].x, xr[i].y, xr[i].z, xr[i].w));
-            lds_wait();
-            wg_barrier_raw();
-            if (EPI == EPI_QKV_ROPE) {
-                typedef const __attribute__((address_space(1))) float* gfloat_p;
-                const uint32_t hd = eo_q.hd, row = 2 * eo_pair;
-                const uint32_t j = row < (eo_q.H + eo_q.KV) * hd ? (row % hd) / 2 : 0u;
-                eo_c = ((gfloat_p)eo_q.fcos)[(size_t)eo_rrow * (hd / 2) + j];
-                eo_s = ((gfloat_p)eo_q.fsin)[(size_t)eo_rrow * (hd / 2) + j];
-                if (lin_never) asm volatile("" ::"v"(eo_c), "v"(eo_s));
-            }
-            const uint32_t lane_tr = (((lane >> 4) * 4 + (lane & 3)) * 17 + ((lane >> 2) & 3) * 4) * 16;
-            const uint32_t m4d_mx = (lane & 3) == 0 ? 0x0000FFFFu : ((lane & 3) == 1 ? 0xFFFF0000u : 0u);
-            const uint32_t m4d_my = (lane & 3) == 2 ? 0x0000FFFFu : ((lane & 3) == 3 ? 0xFFFF0000u : 0u);
-            const uint32_t xt_a = xs_a + lane_tr;
-            auto xrd = [&](lds_v2 (&x)[8], auto cc) {
-                constexpr int C0 = decltype(cc)::value * (int)CHUNK_LDS;
-                x[0] = lds_rd64_tr16<C0 + 0>(xt_a);  x[1] = lds_rd64_tr16<C0 + 8>(xt_a);
-                x[2] = lds_rd64_tr16<C0 + 16>(xt_a); x[3] = lds_rd64_tr16<C0 + 24>(xt_a);
-                x[4] = lds_rd64_tr16<C0 + 32>(xt_a); x[5] = lds_rd64_tr16<C0 + 40>(xt_a);
-                x[6] = lds_rd64_tr16<C0 + 48>(xt_a); x[7] = lds_rd64_tr16<C0 + 56>(xt_a);
-            };
-            lds_v2 xrg[XREG ? LNCH : 1][8];
-            auto as_x = [](const lds_v2 (&x)[8]) -> const uint2 (&)[8] { return reinterpret_cast<const uint2 (&)[8]>(x); };
-            if constexpr (XREG) {
-                xrd(xrg[0], std::integral_constant<int, 0>{});
-                lds_wait(xrg[0]);
-                if constexpr (LNCH > 1) {
-                    xrd(xrg[LNCH > 1 ? 1 : 0], std::integral_constant<int, (LNCH > 1 ? 1 : 0)>{});
-                    lds_wait(xrg[LNCH > 1 ? 1 : 0]);
-                }
-            }
-            uint32_t parked = 0, park_first = pb;
-            auto flush = [&]() {
-                lds_v2 v = lds_rd64<0>(park_a + lane * 8); // (a wave's LDS operations complete in order: its own stores are in)
-                lds_wait(v);
-                if (lane < parked) finish_pair(park_first + lane, asf(v.x), asf(v.y), park_first == pb);
-                park_first += parked;
-                parked = 0;
-            };
-            constexpr int NA = MC_GEMV_LIN_ACCS;
-            mf_f4 laccs[NA];
-#pragma unroll
-            for (int a = 0; a < NA; a++) laccs[a] = mf_f4{0, 0, 0, 0};
-            auto pair_l = [&](auto slot0, uint32_t pr) {
-                constexpr int SLOT0 = decltype(slot0)::value;
-                float ra = 0.f, rb = 0.f;
-                const uint32_t sc_cur = scr_a + ((pr - pb) & 1u) * SCB;
-                static_for<0, PP>([&](auto tc) {
-                    {
-                        constexpr int t = decltype(tc)::value, r = t / LNCH, c = t % LNCH, slot = (SLOT0 + t) % NS;
-                        // younger than the DMA of this packet: D - 1 weight DMAs, and the scale DMAs of step 0 when it went out before them
-                        vm_wait<DD - 1 + (t >= 1 && t < DD ? NSC : 0)>();
-                        lds_v4 wv = lds_rd128<slot * 1024>(ring_a);
-                        uint32_t raw = MC_LDSR_NOSCALE ? 0x3C003C00u : lds_rd32(sc_cur + goff[c]); // (this pair's scales went out before its first packet: they are in)
-                        if constexpr (t == 0) sdma(pr + 1, ((pr - pb) & 1u) ^ 1u, pr + 1 < pe);
-                        lds_v2 x[8];
-                        if constexpr (!XREG) xrd(x, std::integral_constant<int, c>{});
-                        lds_wait(wv); // (covers the scale and the activation reads too: one counter)
-                        if (!MC_LDSR_NOSCALE) lds_wait(raw);
-                        if constexpr (!XREG) lds_wait(x);
-                        const uint4 w = make_uint4(wv.x, wv.y, wv.z, wv.w);
-                        dma(pr + (t + DD) / PP, (t + DD) % PP, (SLOT0 + t + DD) % NS, pr + (t + DD) / PP < pe);
-                        // (pinning the refill in front of the arithmetic and the steps apart with scheduling barriers was
-                        //  measured SLOWER: w1|w3 15.6 -> 16.4 us; left to hipcc, the tail of a packet's arithmetic covers
-                        //  the LDS read of the next)
-                        const uint32_t s2 = r ? ((raw & 0xFFFF0000u) | (raw >> 16)) : ((raw << 16) | (raw & 0xFFFFu));
-                        if constexpr (XREG) mac4d_n<NA>(laccs, w, m4d_prepare(s2, m4d_mx, m4d_my), as_x(xrg[c]));
-                        else mac4d_n<NA>(laccs, w, m4d_prepare(s2, m4d_mx, m4d_my), as_x(x));
-                        if constexpr (c == LNCH - 1 && !MC_LDSR_NOREDUCE) {
-                            const uint32_t e = lane & 3;
-                            mf_f4 lacc = laccs[0];
-#pragma unroll
-                            for (int a = 1; a < NA; a++) lacc += laccs[a];
-                            const float mine = e == 0 ? lacc[0] : (e == 1 ? lacc[1] : (e == 2 ? lacc[2] : lacc[3]));
-                            const float rs = wave_sum_dpp(mine);
-                            if (r == 0) ra = rs;
-                            else rb = rs;
-#pragma unroll
-                            for (int a = 0; a < NA; a++) laccs[a] = mf_f4{0, 0, 0, 0};
-                        }
-                    }
-                });
-                if (MC_LDSR_NOREDUCE) ra = laccs[0][0], rb = laccs[0][1];
-                if (lane == 0) lds_wr64(park_a + parked * 8, __float_as_uint(ra), __float_as_uint(rb));
-                parked++;
-                if (parked == 64) flush();
-            };
-            uint32_t pr = pb;
-            for (; pr + UL <= pe; pr += UL) {
-                pair_l(std::integral_constant<int, 0>{}, pr);
-                if constexpr (UL == 2) pair_l(std::integral_constant<int, PP % NS>{}, pr + 1);
-            }
-            if constexpr (UL == 2) {
-                if (pr < pe) pair_l(std::integral_constant<int, 0>{}, pr);
-            }
-            // the DMAs of packets past the range (one broadcast line each) before the ring's LDS is given back.
-            // (No asm load's result may be left unread: a value nobody reads is DEAD to hipcc, which then reuses the
-            //  destination register while the load is still in flight -- a late write into an address computation: a fault.)
-            vm_wait<0>();
-            flush();
-            return;
-        }
         auto lin_prefetch = [&] {
             if constexpr (LSPLIT != 0) lscales_quad(sa, sa2, pb, pb < pe);
             else lscales(sa, pb, pb < pe);
@@ -2115,7 +1458,7 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
             rowv4 (&xr)[NXP] = lxr;
             rowv4 (&nr)[PRO == PRO_RMSNORM ? NXP : 1] = lnr;
             rowv4* xlv = reinterpret_cast<rowv4*>(xs);
-            if (MC_GEMV_XBAR) asm volatile("s_barrier" ::: "memory");
+            asm volatile("s_barrier" ::: "memory"); // (the row's requests stay ahead of the weight requests: stage_x)
             lin_prefetch();
             auto live = [&](int i) { return !(RAGGED && i == NXP - 1) || tid + i * BD < NPK; };
             if constexpr (PRO == PRO_PARTS) {
@@ -2170,11 +1513,7 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
                 for (int i = 0; i < NXP; i++)
                     if (live(i)) xlv[xpk(tid + i * BD)] = xr[i];
             }
-            if constexpr (LKS == 2) { // the chunk of zeros behind the row (272 padded packets)
-                if (tid < CHUNK_LDS / 16) xlv[(size_t)nchunks * (CHUNK_LDS / 16) + tid] = rowv4{0, 0, 0, 0};
-            }
         } else {
-            static_assert(LKS == 1, "K split needs the build-time prologue");
             stage_x(lin_prefetch);
         }
         __syncthreads();
@@ -2188,7 +1527,6 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
             }
             __syncthreads();
         }
-        if (MC_GEMV_LIN_TL) ltl[1] = __builtin_amdgcn_s_memrealtime();
         if (EPI == EPI_QKV_ROPE) {
             // the step state has long arrived: the table row of this lane's pair, behind the first ring tiles
             typedef const __attribute__((address_space(1))) float* gfloat_p;
@@ -2200,11 +1538,6 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
         }
 
         const uint32_t lane_tr = (((lane >> 4) * 4 + (lane & 3)) * 17 + ((lane >> 2) & 3) * 4) * 16;
-        const uint32_t m4d_mx = (lane & 3) == 0 ? 0x0000FFFFu : ((lane & 3) == 1 ? 0xFFFF0000u : 0u);
-        const uint32_t m4d_my = (lane & 3) == 2 ? 0x0000FFFFu : ((lane & 3) == 3 ? 0xFFFF0000u : 0u);
-#ifndef MC_GEMV_M4B
-#define MC_GEMV_M4B 1 // whole bytes into the dequantising MFMA, nibbles unmixed by its B operand (mac4b_n)
-#endif
         const m4b_lane m4bk = m4b_lane_consts(lane);
         typedef __attribute__((address_space(3))) mf_s4 lds_s4;
         auto xload = [&](uint2 (&x)[8], int c) {
@@ -2218,45 +1551,20 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
             for (int c = 0; c < LNCH; c++) xload(xr[c], c);
         }
         // parked row sums, behind the reduction scratch (LWAVES == 0: the kernel may run with any workgroup size -- 512 bytes per wave)
-        constexpr bool RAWPARK = MC_GEMV_LIN_RAWPARK && LWAVES > 0 && !MC_GEMV_LIN_STREAM;
-        // (K split: the zero chunk sits where the reduction scratch would be -- there is no norm prologue -- and the parking
-        //  space behind it)
-        char* park0 = reinterpret_cast<char*>(red + 32) + (LKS == 2 ? CHUNK_LDS : 0u);
-        float2* park = reinterpret_cast<float2*>(park0 + wave * (LWAVES ? PARKB : 512u));
-        float* praw = reinterpret_cast<float*>(park);
+        float2* park = reinterpret_cast<float2*>(reinterpret_cast<char*>(red + 32) + wave * PARKB);
         uint32_t parked = 0, park_first = LSPLIT ? 2 * pb : pb;
         auto flush = [&]() {
             // one lane per parked pair (the LDS operations of a wave complete in order: no barrier needed)
             if (lane < parked) {
-                if constexpr (RAWPARK) {
-                    const float* ra_p = praw + (2 * lane) * 65;
-                    float a = 0.0f, b = 0.0f;
-#pragma unroll 16
-                    for (int l = 0; l < 64; l++) {
-                        a += ra_p[l];
-                        b += ra_p[65 + l];
-                    }
-                    finish_pair(park_first + lane, a, b, park_first == pb);
-                } else if constexpr (LKS == 2) {
-                    // the partner's sums over the other half of K (a workgroup barrier stands between its stores and this read)
-                    const float2 v = park[lane];
-                    const float2 u = reinterpret_cast<const float2*>(park0 + (wave + nwp) * PARKB)[lane];
-                    finish_pair(park_first + lane, v.x + u.x, v.y + u.y, park_first == pb);
-                } else {
-                    const float2 v = park[lane];
-                    finish_pair(park_first + lane, v.x, v.y, park_first == (LSPLIT ? 2 * pb : pb));
-                }
+                const float2 v = park[lane];
+                finish_pair(park_first + lane, v.x, v.y, park_first == (LSPLIT ? 2 * pb : pb));
             }
             park_first += parked;
             parked = 0;
         };
 
-        uint32_t lin_dummy = 0;
-        constexpr int NA = MC_GEMV_LIN_ACCS;
         mf_f4 laccs3[3] = {mf_f4{0, 0, 0, 0}, mf_f4{0, 0, 0, 0}, mf_f4{0, 0, 0, 0}}; // (LSPLIT) one per packet of the super row
-        mf_f4 laccs[NA];
-#pragma unroll
-        for (int a = 0; a < NA; a++) laccs[a] = mf_f4{0, 0, 0, 0};
+        mf_f4 laccs[1] = {mf_f4{0, 0, 0, 0}}; // one dependency chain per row (independent accumulators per row measured the same)
         // one pair: TPP tiles out of ring slots [SLOT0, SLOT0 + TPP); every slot is refilled with the same tile of
         // the pair U ahead as soon as it has been consumed.  Straight-line code: no branch, every load unconditional.
         auto do_pair = [&](auto slot0, uint32_t pr) {
@@ -2268,24 +1576,14 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
 #pragma unroll
             for (int t = 0; t < TPP; t++) {
                 const int r = t / SUB, sidx = t % SUB, slot = LR >= TPP ? SLOT0 + t : t % LR;
-                // (row-granular spans) the second row of the span's last step is another wave's: nothing to multiply, nothing to refill
-                if (LROW && r == 1 && 2 * pr + roff + 1 >= rwe) continue;
 #pragma unroll
                 for (int p = 0; p < LTP; p++) {
                     const int c = sidx * LTP + p;
                     const uint32_t raw = sa[c];
-                    const uint32_t s2 = r ? ((raw & 0xFFFF0000u) | (raw >> 16)) : ((raw << 16) | (raw & 0xFFFFu));
                     const uint32_t sf = r ? (raw & 0xFFFF0000u) : (raw << 16); // the row's scale as a float
-                    if (MC_GEMV_LIN_DECOUPLE && XREG) {
-                        const uint4 fake = make_uint4(lane * 0x01010101u + pr, (lane + pr) * 0x9E3779B9u, lane * 0x85EBCA6Bu + (uint32_t)(t * 0x11111111u),
-                                                      (p + lane) * 0xC2B2AE35u + pr);
-                        if constexpr (XREG) mac4d_n<NA>(laccs, fake, m4d_prepare(0x3C003C00u, m4d_mx, m4d_my), xr[c]);
-                        __builtin_amdgcn_sched_barrier(0);
+                    if (MC_GEMV_LIN_STREAM) {
                         const uint4& w = lring[slot][p];
-                        lin_dummy += ((w.x ^ w.y ^ w.z ^ w.w) & 0x3FFFFFFFu) | (s2 & 1u);
-                    } else if (MC_GEMV_LIN_STREAM) {
-                        const uint4& w = lring[slot][p];
-                        laccs[0][0] += asf(((w.x ^ w.y ^ w.z ^ w.w) & 0x3FFFFFFFu) | (s2 & 1u));
+                        laccs[0][0] += asf(((w.x ^ w.y ^ w.z ^ w.w) & 0x3FFFFFFFu) | (sf & 0x10000u));
                     } else if constexpr (LSPLIT != 0) {
                         // packet c of the super row: its own accumulator (the middle packet is two rows' worth, split below);
                         // the scale of the lane's row of the quad: super row r -> rows 2 r, 2 r + 1
@@ -2301,36 +1599,22 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
                         }
                         laccs3[c] = one[0];
                     } else if constexpr (XREG) {
-                        if (MC_GEMV_M4B) mac4b_n<NA>(laccs, lring[slot][p], m4b_prepare(sf, m4bk), xr[c]);
-                        else mac4d_n<NA>(laccs, lring[slot][p], m4d_prepare(s2, m4d_mx, m4d_my), xr[c]);
+                        mac4b_n<1>(laccs, lring[slot][p], m4b_prepare(sf, m4bk), xr[c]);
                     } else {
                         uint2 x[8];
-                        xload(x, (LKS == 2 ? (int)cbase : 0) + c);
-                        if (MC_GEMV_M4B) mac4b_n<NA>(laccs, lring[slot][p], m4b_prepare(sf, m4bk), x);
-                        else mac4d_n<NA>(laccs, lring[slot][p], m4d_prepare(s2, m4d_mx, m4d_my), x);
+                        xload(x, c);
+                        mac4b_n<1>(laccs, lring[slot][p], m4b_prepare(sf, m4bk), x);
                     }
                 }
                 if constexpr (LR >= TPP) ltile(lring[slot], pr + U, t, pr + U < pe);
                 else if (t + LR < TPP) ltile(lring[slot], pr, t + LR, true);
                 else ltile(lring[slot], pr + 1, t + LR - TPP, pr + 1 < pe);
-#ifndef MC_GEMV_LIN_PIN
-#define MC_GEMV_LIN_PIN (LRING ? 2 : 0) // explicit rings pin their refills
-#endif
                 // the refill stays HERE: left alone, the scheduler sinks the loads of several tiles to one place behind
-                // their computations, and a wave then computes with fewer bytes in flight than its ring holds
-                if (MC_GEMV_LIN_PIN == 1) __builtin_amdgcn_sched_barrier(0);
-                // (instruction selection orders a basic block by data dependence alone and puts a load whose value leaves the
-                //  block at its END, so a scheduling barrier does not hold it.  An opaque never-taken branch ends the block.)
-                if (MC_GEMV_LIN_PIN == 2 && lin_never) asm volatile("s_nop 0");
-                if (MC_GEMV_LIN_TL) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    const unsigned long long now = __builtin_amdgcn_s_memrealtime();
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int q = 2; q < 14; q++)
-                        if (ltn == (uint32_t)q) ltl[q] = now; // ltn is wave-uniform
-                    ltn++;
-                }
+                // their computations, and a wave then computes with fewer bytes in flight than its ring holds.  Explicit rings
+                // (LRING) pin theirs: instruction selection orders a basic block by data dependence alone and puts a load whose
+                // value leaves the block at its END, so a scheduling barrier does not hold it -- an opaque never-taken branch
+                // ends the block.
+                if (LRING != 0 && lin_never) asm volatile("s_nop 0");
                 if (LSPLIT != 0 && sidx == SUB - 1) {
                     // the super row is complete: packets 0 and 2 are whole rows' worth, the middle one is the first row's in
                     // lanes 0..31 and the second row's in lanes 32..63
@@ -2346,33 +1630,16 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
                 } else if (sidx == SUB - 1) {
                     // the row is complete: element lane % 4 of the lane's four results is its own dot product
                     const uint32_t e = lane & 3;
-                    mf_f4 lacc = laccs[0];
-#pragma unroll
-                    for (int a = 1; a < NA; a++) lacc += laccs[a];
-                    float mine = e == 0 ? lacc[0] : (e == 1 ? lacc[1] : (e == 2 ? lacc[2] : lacc[3]));
-                    if (MC_GEMV_M4B && MC_GEMV_M4B_MAC16 && (lane >> 4) != ((lane >> 2) & 3)) mine = 0.0f; // only D[i][i] (mac4b_n)
-                    if constexpr (RAWPARK) {
-                        static_assert(!(RAWPARK && MC_GEMV_M4B), "raw parking keeps the unscaled sums of mac4d_n");
-                        praw[(2 * parked + r) * 65 + lane] = mine;
-                    } else {
-                        float rs = wave_sum_dpp(MC_GEMV_LIN_STREAM ? lacc[0] : mine);
-                        if (MC_GEMV_M4B && !MC_GEMV_LIN_STREAM) rs *= 0x1p37f; // 2^M4B_Q: the sum was formed at 2^-Q (mac4b_n)
-                        if (r == 0) ra = rs;
-                        else rb = rs;
-                    }
-#pragma unroll
-                    for (int a = 0; a < NA; a++) laccs[a] = mf_f4{0, 0, 0, 0};
+                    const mf_f4 lacc = laccs[0];
+                    const float mine = e == 0 ? lacc[0] : (e == 1 ? lacc[1] : (e == 2 ? lacc[2] : lacc[3]));
+                    float rs = wave_sum_dpp(MC_GEMV_LIN_STREAM ? lacc[0] : mine);
+                    if (!MC_GEMV_LIN_STREAM) rs *= 0x1p37f; // 2^M4B_Q: the sum was formed at 2^-Q (mac4b_n)
+                    if (r == 0) ra = rs;
+                    else rb = rs;
+                    laccs[0] = mf_f4{0, 0, 0, 0};
                 }
             }
-            if constexpr (LROW) {
-                // the workgroup's row sums, one float per row of its pairs (the parking space: 512 bytes per wave = 1024 rows)
-                float* rowsum = reinterpret_cast<float*>(park0);
-                const uint32_t row0 = 2 * pr + roff;
-                if (lane == 0) {
-                    if (row0 < rwe) rowsum[row0 - 2 * wp0] = ra;
-                    if (row0 + 1 < rwe) rowsum[row0 + 1 - 2 * wp0] = rb;
-                }
-            } else if constexpr (LSPLIT != 0) {
+            if constexpr (LSPLIT != 0) {
                 if (lane == 0) {
                     park[parked] = make_float2(ra, rb);       // real pair 2 pr     (rows 0, 1 of the quad)
                     park[parked + 1] = make_float2(ra2, rb2); // real pair 2 pr + 1 (rows 2, 3)
@@ -2380,9 +1647,9 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
                 parked += 2;
                 if (parked == 64u) flush();
             } else {
-                if (!RAWPARK && lane == 0) park[parked] = make_float2(ra, rb);
+                if (lane == 0) park[parked] = make_float2(ra, rb);
                 parked++;
-                if (LKS == 1 && parked == (RAWPARK ? (uint32_t)PARKP : 64u)) flush(); // (K split: the host grants at most 64 pairs per wave)
+                if (parked == 64u) flush();
             }
 #pragma unroll
             for (int c = 0; c < LNCH; c++) sa[c] = sb[c];
@@ -2399,52 +1666,18 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
         if constexpr (U == 2) {
             if (pr < pe) do_pair(std::integral_constant<int, 0>{}, pr); // odd count: the last pair sits in the first slots
         }
-        if constexpr (LROW) {
-            __syncthreads();
-            const float* rowsum = reinterpret_cast<const float*>(park0);
-            for (uint32_t t = tid; t < wp1 - wp0; t += BD) finish_pair(wp0 + t, rowsum[2 * t], rowsum[2 * t + 1], t == tid);
-        } else if constexpr (LKS == 2) {
-            __syncthreads();
-            if (khalf == 0) flush();
-        } else {
-            flush();
-        }
+        flush();
         if (EPI == EPI_STORE_PICK) pick_finish(red, nwaves);
-        if (MC_GEMV_LIN_DECOUPLE && lin_dummy == 0x12345678u) static_cast<uint32_t*>(yp)[0] = 1;
-        if (MC_GEMV_LIN_TL && lane == 0) {
-            unsigned long long* tl = const_cast<unsigned long long*>(static_cast<const unsigned long long*>(resp));
-            const size_t o = ((size_t)blockIdx.x * nwaves + wave) * 16;
-            ltl[14] = __builtin_amdgcn_s_memrealtime();
-            ltl[13] = __builtin_amdgcn_s_memtime() - lclk0; // (replaces the stamp of tile 11)
-            unsigned xcc;
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-            ltl[15] = ((unsigned long long)ltn << 32) | xcc;
-#pragma unroll
-            for (int q = 0; q < 16; q++) tl[o + q] = (q >= 2 && q < 13 && (uint32_t)q >= ltn) ? 0ull : ltl[q];
-        }
         return;
     }
 
-    constexpr int PRE = PRO == PRO_NONE ? MC_GEMV_PRE_P0 : MC_GEMV_PRE;
-#ifndef MC_GEMV_ILV
-#define MC_GEMV_ILV 0 // 1: a raw s_barrier behind every tile requested ahead: the CU's in-order memory pipe then holds tile t of
-#endif                // every wave before tile t + 1 of any (a wave that queues its whole ring first starves its neighbours)
     stage_x([&] {
         load(ring[0], ld.rg, ld.c, 0 < ntiles);
         advance(ld);
-#pragma unroll
-        for (int sl = 1; sl < RING; sl++)
-            if (PRE > sl) {
-                if (MC_GEMV_ILV) asm volatile("s_barrier" ::: "memory");
-                load(ring[sl], ld.rg, ld.c, (uint32_t)sl < ntiles);
-                advance(ld);
-            }
     });
     __syncthreads();
-    if (TL) tl1 = __builtin_amdgcn_s_memrealtime();
 #pragma unroll
-    for (int sl = 1; sl < RING; sl++)
-        if (PRE <= sl) { load(ring[sl], ld.rg, ld.c, (uint32_t)sl < ntiles); advance(ld); }
+    for (int sl = 1; sl < RING; sl++) { load(ring[sl], ld.rg, ld.c, (uint32_t)sl < ntiles); advance(ld); }
 
     float acc[R];
     mf_f4 accv[R];
@@ -2457,12 +1690,6 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
     // Q_M4D: lane 16g + 4q + p supplies row q of the transposed gather = 32-weight run q of block
     // 4g + p; and lane j of a block carries T(s) on k = j of the dequant MFMA's B operand
     const uint32_t lane_tr = (((lane >> 4) * 4 + (lane & 3)) * 17 + ((lane >> 2) & 3) * 4) * 16;
-    const uint32_t m4d_mx = (lane & 3) == 0 ? 0x0000FFFFu : ((lane & 3) == 1 ? 0xFFFF0000u : 0u);
-    const uint32_t m4d_my = (lane & 3) == 2 ? 0x0000FFFFu : ((lane & 3) == 3 ? 0xFFFF0000u : 0u);
-
-#ifndef MC_GEMV_M4B_CLASSIC
-#define MC_GEMV_M4B_CLASSIC 1
-#endif
     const m4b_lane m4bk_c = m4b_lane_consts(lane);
     auto compute = [&](const tile<R>& t, uint32_t crg, uint32_t cc) {
         if constexpr (M4D) {
@@ -2474,14 +1701,10 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
 #pragma unroll
             for (int r = 0; r < R; r++) {
                 const uint32_t raw = t.s[r >> 1];
-                const uint32_t s2 = (r & 1) ? ((raw & 0xFFFF0000u) | (raw >> 16)) : ((raw << 16) | (raw & 0xFFFFu));
-                if (MC_GEMV_M4B_CLASSIC) { // whole bytes into the dequantising MFMA (mac4b_n): four bit operations per dword instead of seven
-                    mf_f4 one[1] = {accv[r]};
-                    mac4b_n<1>(one, t.w[r], m4b_prepare((r & 1) ? (raw & 0xFFFF0000u) : (raw << 16), m4bk_c), x);
-                    accv[r] = one[0];
-                } else {
-                    mac4d(accv[r], t.w[r], m4d_prepare(s2, m4d_mx, m4d_my), x);
-                }
+                // whole bytes into the dequantising MFMA (mac4b_n): four bit operations per dword instead of seven
+                mf_f4 one[1] = {accv[r]};
+                mac4b_n<1>(one, t.w[r], m4b_prepare((r & 1) ? (raw & 0xFFFF0000u) : (raw << 16), m4bk_c), x);
+                accv[r] = one[0];
             }
         } else {
             xregs<T, KPL> x;
@@ -2500,7 +1723,7 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
                 if constexpr (M4)
                     mac4(accv[r], t.w[r], sc, x);
                 else
-                    mac<QM == Q_M4 || QM == Q_M4D || QM == Q_DBG_TL4D ? Q_EXACT : QM>(acc[r], t.w[r], sc, x, xsum, static_cast<F*>(nullptr));
+                    mac<QM == Q_M4 || QM == Q_M4D ? Q_EXACT : QM>(acc[r], t.w[r], sc, x, xsum, static_cast<F*>(nullptr));
             }
         }
         if (cc + 1 == nchunks) {
@@ -2511,7 +1734,7 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
                     // element lane % 4 of the lane's four results is its own dot product
                     const uint32_t e = lane & 3;
                     float mine = e == 0 ? accv[r][0] : (e == 1 ? accv[r][1] : (e == 2 ? accv[r][2] : accv[r][3]));
-                    if (M4D && MC_GEMV_M4B_CLASSIC) mine *= 0x1p37f; // the sums were formed at 2^-M4B_Q (mac4b_n)
+                    if (M4D) mine *= 0x1p37f; // the sums were formed at 2^-M4B_Q (mac4b_n)
                     tot[r] = wave_sum_dpp(mine);
                     accv[r] = mf_f4{0, 0, 0, 0};
                 } else {
@@ -2542,27 +1765,8 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
 #pragma unroll
         for (int sl = 0; sl < RING; sl++) {
             if (sl == 0 || i + sl < ntiles) { compute(ring[sl], cp.rg, cp.c); advance(cp); }
-            if (TL) {
-                __builtin_amdgcn_sched_barrier(0);
-                const unsigned long long now = __builtin_amdgcn_s_memrealtime();
-                __builtin_amdgcn_sched_barrier(0);
-                if (tln < 4) tlt[tln] = now; // scalar selects: tln is wave-uniform
-                tln++;
-            }
             load(ring[sl], ld.rg, ld.c, i + sl + RING < ntiles); advance(ld);
         }
-    }
-    if (TL && lane == 0) {
-        // (epilogues of this variant never read `resp`: it carries the stamp buffer)
-        unsigned long long* tl = const_cast<unsigned long long*>(static_cast<const unsigned long long*>(resp));
-        const size_t o = ((size_t)blockIdx.x * nwaves + wave) * 8;
-        tl[o] = tl0; tl[o + 1] = tl1; tl[o + 2] = __builtin_amdgcn_s_memrealtime();
-        tl[o + 4] = tlt[0]; tl[o + 5] = tlt[1]; tl[o + 6] = tlt[2];
-        tl[o + 7] = PRO == PRO_RMSNORM ? ((tlx - tl0) << 32) | (tlb - tl0) : tlt[3]; // prologue detail instead of tile 3
-        unsigned xcc, hwid;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-        tl[o + 3] = ((unsigned long long)hwid << 32) | xcc;
     }
 }
 

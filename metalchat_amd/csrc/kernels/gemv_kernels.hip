@@ -101,7 +101,7 @@ MC_GEMV_LIN_SET(mc_gemv_i4_bfloat_lin12, MC_LIN12_CFG) // K = 24576 (Gemma-7B's 
          const void* norm_w, uint32_t out_rows, uint32_t in, uint32_t group, float eps, float mu, \
          const void* lora_a, const void* lora_b, uint32_t lora_rank, float lora_scale)            \
     {                                                                                             \
-        body<WF_I4, BF, Q_M4D, PRO, EPI, 4, 3, 1, 2, MC_LIN_WAVES, 0, 1, 1>(                       \
+        body<WF_I4, BF, Q_M4D, PRO, EPI, 4, 3, 1, 2, MC_LIN_WAVES, 0, 1>(                       \
             w, scales, x, y, res, norm_w, out_rows, in, group, eps, mu, lora_a, lora_b, lora_rank, lora_scale); \
     }
 #if MC_LIN_WAVES
@@ -116,23 +116,7 @@ MC_GEMV_LINS(mc_gemv_i4_bfloat_lin3s_p2_e3, 2, 3)
 #endif
 MC_GEMV_LIN_SET(mc_gemv_i4_bfloat_lin14, MC_LIN14_CFG) // K = 28672
 
-// K split (gemv.h LKS = 2): sixteen waves per workgroup, a row pair's K range cut between two of them -- long rows with ONE
-// pair per wave (w2).  mc_gemv_i4_bfloat_lin{7|14}k2_p0_e{0|1}
-#define MC_GEMV_LINK2(NAME, EPI, NCH)                                                             \
-    extern "C" __global__ void __launch_bounds__(1024)                                            \
-    NAME(const void* w, const void* scales, const void* x, void* y, const void* res,             \
-         const void* norm_w, uint32_t out_rows, uint32_t in, uint32_t group, float eps, float mu, \
-         const void* lora_a, const void* lora_b, uint32_t lora_rank, float lora_scale)            \
-    {                                                                                             \
-        body<WF_I4, BF, Q_M4D, 0, EPI, 4, NCH, 1, 2, 16, 0, 2>(                                   \
-            w, scales, x, y, res, norm_w, out_rows, in, group, eps, mu, lora_a, lora_b, lora_rank, lora_scale); \
-    }
-MC_GEMV_LINK2(mc_gemv_i4_bfloat_lin7k2_p0_e0, 0, 7)
-MC_GEMV_LINK2(mc_gemv_i4_bfloat_lin7k2_p0_e1, 1, 7)
-MC_GEMV_LINK2(mc_gemv_i4_bfloat_lin14k2_p0_e0, 0, 14)
-MC_GEMV_LINK2(mc_gemv_i4_bfloat_lin14k2_p0_e1, 1, 14)
-
-// linear-order kernels of the VALU-dequantising formats (gemv.h LGEN): mc_gemv_{i8|w}_bfloat_ling{KiB per row}_p{PRO}_e{EPI}
+// linear-order kernels of int8 / plain bfloat weights (gemv.h LGEN): mc_gemv_{i8|w}_bfloat_ling{KiB per row}_p{PRO}_e{EPI}
 #define MC_GEMV_LING(NAME, WF, PRO, EPI, NCH)                                                     \
     extern "C" __global__ void __launch_bounds__(64 * MC_LIN_WAVES)                              \
     NAME(const void* w, const void* scales, const void* x, void* y, const void* res,             \
@@ -169,8 +153,3 @@ MC_GEMV(mc_gemv_i4_bfloat_dbgstream_p1_e2, WF_I4, BF, Q_DBG_STREAM, 1, 2)
 MC_GEMV(mc_gemv_i4_bfloat_dbgnoload_p1_e2, WF_I4, BF, Q_DBG_NOLOAD, 1, 2)
 MC_GEMV(mc_gemv_i4_bfloat_dbgstream_p0_e0, WF_I4, BF, Q_DBG_STREAM, 0, 0)
 MC_GEMV(mc_gemv_i4_bfloat_dbgnoload_p0_e0, WF_I4, BF, Q_DBG_NOLOAD, 0, 0)
-MC_GEMV(mc_gemv_i4_bfloat_dbgtl_p1_e2, WF_I4, BF, Q_DBG_TL, 1, 2)
-MC_GEMV(mc_gemv_i4_bfloat_dbgtl_p0_e0, WF_I4, BF, Q_DBG_TL, 0, 0)
-MC_GEMV(mc_gemv_i4_bfloat_dbgtl_p1_e0, WF_I4, BF, Q_DBG_TL, 1, 0)
-MC_GEMV(mc_gemv_i4_bfloat_dbgtl4d_p1_e2, WF_I4, BF, Q_DBG_TL4D, 1, 2)
-MC_GEMV(mc_gemv_i4_bfloat_dbgtl4d_p0_e0, WF_I4, BF, Q_DBG_TL4D, 0, 0)

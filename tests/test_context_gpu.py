@@ -364,6 +364,8 @@ def test_one_launch_attention_against_the_two_launch_form(acc, monkeypatch, shap
     same = 0
     for i, ((ta, la, ha), (tb_, lb, hb)) in enumerate(zip(out["1"], out["0"])):
         same += int(ta == tb_)
-        parity.check(BF16, ha, hb, rel=3.9e-3, max_ulp=2, max_frac=0.3, what=f"{shape} step {i} hidden rows, one launch vs two")
+        for layer in range(ha.shape[0]):  # row 0: the embedding (identical); the forms differ from the first attention on
+            parity.check(BF16, ha[layer], hb[layer], rel=3.9e-3 * max(layer, 1), max_ulp=2 * layer, max_frac=0.3 if layer else 0.0,
+                         what=f"{shape} step {i} hidden[{layer - 1}], one launch vs two")
         parity.check(BF16, la, lb, rel=5e-3, max_ulp=3, max_frac=0.7, what=f"{shape} step {i} logits, one launch vs two")
     assert same >= len(out["1"]) - 2, (shape, same)
