@@ -187,7 +187,6 @@ struct mc_decoder {
     unsigned long long* attn_psum_g = nullptr; // [H][nsplit]            partial softmax denominators
     unsigned long long* attn_slab_g = nullptr; // [KV][nsplit][n_rep][hd] fp32 partial P.V sums
     bool attn_fused_on = true;   // MC_ATTN_FUSED=0: scores and P.V as two launches (A/B, parity)
-    bool next_prefetch_on = true; // MC_NEXT_PREFETCH=0: no launch touches the next launch's first weight tiles (A/B)
     void* taps = nullptr;       // T[(n_own+1)*dim]
     step_state_h* state = nullptr;
     int32_t* tokens_dev = nullptr;
@@ -543,11 +542,9 @@ struct mc_decoder {
         return fail(MC_ERR_RUNTIME, buf);
     }
 
-    // next / next_epi: the linear the FOLLOWING launch of the chain streams (and its epilogue code) -- a linear-order
-    // kernel touches that launch's first tiles so that they are on chip when it starts (gemv.h, next-launch prefetch)
     mc_status
     gemv(const linear_w& L, int pro, int epi, const void* x, void* y, const void* res,
-         const void* norm_w, float mu, const linear_w* next = nullptr, int next_epi = 0)
+         const void* norm_w, float mu)
     {
         std::string name = "mc_gemv_";
         name += L.fmt == MC_WFMT_I4 ? "i4_" : (L.fmt == MC_WFMT_I8 ? "i8_" : "w_");
@@ -643,23 +640,6 @@ struct mc_decoder {
             *capture_name = name;
             return MC_OK;
         }
-        // next-launch prefetch: only between launches of the same geometry (wave gw of this launch and wave gw of the next own
-        // the gw-th of equal spans of row pairs: one eight-wave workgroup per CU, whole pairs per wave)
-        const void* next_w = nullptr;
-        uint32_t next_np = 0, next_rowb = 0;
-        if (next && next_prefetch_on && (lin || ling || lins) && lin_waves == 8 && next->allocated && next->out % 2 == 0 && !gemv_block_env) {
-            const bool nlin = lin_ok(*next);
-            const int nling = nlin ? 0 : ling_kib(*next);
-            const unsigned cus = (unsigned)dev->prop.multiProcessorCount, np = (unsigned)next->out / 2;
-            unsigned nwg = (np + 7) / 8;
-            if (nwg > cus) nwg = cus;
-            const bool half = nling && ling_half && (next_epi == 0 || next_epi == 1) && !next->lora_cols && 2u * np <= cus * 8u;
-            if ((nlin || nling) && !half && nwg == wgs && block == 512) {
-                next_w = next->w;
-                next_np = np;
-                next_rowb = (uint32_t)next->row_bytes;
-            }
-        }
         if (L.lora_cols) {
             // a = T(A x): the stacked adaptor inputs through the same kernel family (same prologue,
             // so a pre-norm GEMV and its adaptor see the identical normalised row)
@@ -669,7 +649,7 @@ struct mc_decoder {
         return launch(name, wgs, 1, 1, block, lds,
                       pack(L.w, L.scales, x, y, res, norm_w, (uint32_t)L.out, (uint32_t)L.in,
                            (uint32_t)L.group, cfg.norm_eps, mu, (const void*)L.lora_vec,
-                           (const void*)L.lora_b, (uint32_t)L.lora_cols, L.lora_scale, next_w, next_np, next_rowb));
+                           (const void*)L.lora_b, (uint32_t)L.lora_cols, L.lora_scale));
     }
 
     mc_status
@@ -721,7 +701,7 @@ struct mc_decoder {
             if (!gemma) {
                 // attention_norm + wq|wk|wv + rope + cache write in ONE launch
                 // (transformer.h:130, attention.h:170-177)
-                s = gemv(L.qkv, 1, 4, x, qkv, L.qkv_epi, L.attention_norm, mu, &L.wo, 1);
+                s = gemv(L.qkv, 1, 4, x, qkv, L.qkv_epi, L.attention_norm, mu);
                 if (s != MC_OK) return s;
             } else {
                 // gemma3 normalises q and k per head before the rotation (attention.h:174-175):
@@ -729,11 +709,11 @@ struct mc_decoder {
                 // (fused flow: the previous block's ffn post-norm + residual is applied by this
                 // kernel's prologue, PRO 2, and its workgroup 0 leaves the block input in `hidden`)
                 if (pending_pn) {
-                    s = gemv(L.qkv, 2, 0, proj, qkv, pending_pn, L.attention_norm, mu, &L.wo, 0);
+                    s = gemv(L.qkv, 2, 0, proj, qkv, pending_pn, L.attention_norm, mu);
                     pending_pn = nullptr;
                     x = hidden;
                 } else {
-                    s = gemv(L.qkv, 1, 0, x, qkv, nullptr, L.attention_norm, mu, &L.wo, 0);
+                    s = gemv(L.qkv, 1, 0, x, qkv, nullptr, L.attention_norm, mu);
                 }
                 if (s != MC_OK) return s;
                 s = launch("mc_rope_kv_" + tname, H + 2 * KV, 1, 1, hd / 2, 0,
@@ -748,7 +728,7 @@ struct mc_decoder {
                            pack(q_rot, L.kc, L.vt, attn_out, attn_psum_g, attn_slab_g, state, (uint32_t)n_rep, (uint32_t)KV, (uint32_t)hd,
                                 (uint32_t)cfg.max_seq_len, scale_T, (uint32_t)nsplit, (uint32_t)(li + 1), (void*)nullptr));
                 if (s != MC_OK) return s;
-                s = gemma ? gemv(L.wo, 0, 0, attn_out, proj, nullptr, nullptr, mu, &L.w13, 3) : gemv(L.wo, 0, 1, attn_out, hidden, x, nullptr, mu, &L.w13, 2);
+                s = gemma ? gemv(L.wo, 0, 0, attn_out, proj, nullptr, nullptr, mu) : gemv(L.wo, 0, 1, attn_out, hidden, x, nullptr, mu);
                 if (s != MC_OK) return s;
                 if (gemma && !fuse_pn) {
                     s = launch("mc_rmsnorm_row_" + tname, 1, 1, 1, 1024, 0,
@@ -779,10 +759,10 @@ struct mc_decoder {
             const void* wo_x = fold ? (const void*)pv_parts : (const void*)attn_out;
             const int wo_pro = fold ? 3 : 0;
             if (!gemma) {
-                s = gemv(L.wo, wo_pro, 1, wo_x, hidden, x, nullptr, mu, &L.w13, 2);
+                s = gemv(L.wo, wo_pro, 1, wo_x, hidden, x, nullptr, mu);
                 if (s != MC_OK) return s;
             } else {
-                s = gemv(L.wo, wo_pro, 0, wo_x, proj, nullptr, nullptr, mu, &L.w13, 3);
+                s = gemv(L.wo, wo_pro, 0, wo_x, proj, nullptr, nullptr, mu);
                 if (s != MC_OK) return s;
                 if (!fuse_pn) {
                     s = launch("mc_rmsnorm_row_" + tname, 1, 1, 1, 1024, 0,
@@ -794,19 +774,17 @@ struct mc_decoder {
             // ffn_norm + w1|w3 + act*mul           (transformer.h:135-137, 53-59)
             if (gemma && fuse_pn) {
                 // attention post-norm + residual (-> hidden_b) + ffn_norm in the prologue
-                s = gemv(L.w13, 2, 3, proj, gate, L.pn_attn, L.ffn_norm, mu, &L.w2, 0);
+                s = gemv(L.w13, 2, 3, proj, gate, L.pn_attn, L.ffn_norm, mu);
             } else {
-                s = gemv(L.w13, 1, gemma ? 3 : 2, hidden, gate, nullptr, L.ffn_norm, mu, &L.w2, gemma ? 0 : 1);
+                s = gemv(L.w13, 1, gemma ? 3 : 2, hidden, gate, nullptr, L.ffn_norm, mu);
             }
             if (s != MC_OK) return s;
             // w2 (+ post norm) + residual          (transformer.h:59, 138-139)
-            const linear_w* after = li + 1 < n_own ? &layers[li + 1].qkv : (last_stage ? &output : nullptr);
-            const int after_epi = li + 1 < n_own ? (gemma ? 0 : 4) : 5;
             if (!gemma) {
-                s = gemv(L.w2, 0, 1, gate, hidden, hidden, nullptr, mu, after, after_epi);
+                s = gemv(L.w2, 0, 1, gate, hidden, hidden, nullptr, mu);
                 if (s != MC_OK) return s;
             } else {
-                s = gemv(L.w2, 0, 0, gate, proj, nullptr, nullptr, mu, after, after_epi);
+                s = gemv(L.w2, 0, 0, gate, proj, nullptr, nullptr, mu);
                 if (s != MC_OK) return s;
                 if (!fuse_pn) {
                     s = launch("mc_rmsnorm_row_" + tname, 1, 1, 1, 1024, 0,
@@ -1180,7 +1158,6 @@ mc_decoder_create(mc_device* dev, mc_library* lib, mc_queue* q, const mc_decoder
     if (const char* e = getenv("MC_GEMV_LIN")) d->gemv_lin = atoi(e) != 0;
     if (const char* e = getenv("MC_PV_FOLD")) d->pv_fold_on = atoi(e) != 0;
     if (const char* e = getenv("MC_ATTN_FUSED")) d->attn_fused_on = atoi(e) != 0;
-    if (const char* e = getenv("MC_NEXT_PREFETCH")) d->next_prefetch_on = atoi(e) != 0;
     if (const char* e = getenv("MC_LING_HALF")) d->ling_half = atoi(e) != 0;
     if (const char* e = getenv("MC_LIN_SPLIT")) d->lin_split = atoi(e) != 0;
     if (const char* e = getenv("MC_I8_LING14")) d->i8_ling14 = atoi(e) != 0;
@@ -2004,38 +1981,28 @@ mc_decoder_time_gemv(mc_decoder* d, const char* which, int32_t repeats, float* t
         mc_status r = MC_OK;
         for (size_t li = 0; li < d->layers.size(); li++) {
             layer_w& L = d->layers[li % lim];
-            // (every launch touches the first tiles of the launch that follows it in this pass, as in a token: the same
-            //  kind of matrix of the next layer, or the next matrix of the layer for "all")
-            const bool all = w == "all";
-            layer_w& N = d->layers[(li + 1) % lim];
-            const bool more = li + 1 < d->layers.size();
-            if (w == "qkv" || all) {
-                const linear_w* nx = all ? &L.wo : (more ? &N.qkv : nullptr);
-                r = gemma ? d->gemv(L.qkv, 1, 0, d->hidden, d->qkv, nullptr, L.attention_norm, mu, nx, all ? 0 : 0)
-                          : d->gemv(L.qkv, 1, 4, d->hidden, d->qkv, L.qkv_epi, L.attention_norm, mu, nx, all ? 1 : 4);
+            if (w == "qkv" || w == "all") {
+                r = gemma ? d->gemv(L.qkv, 1, 0, d->hidden, d->qkv, nullptr, L.attention_norm, mu)
+                          : d->gemv(L.qkv, 1, 4, d->hidden, d->qkv, L.qkv_epi, L.attention_norm, mu);
                 if (r != MC_OK) return r;
                 if (count) { bytes += linear_bytes(L.qkv); launches++; }
             }
-            if (w == "wo" || all) {
-                // the variant the token really launches (residual epilogue; the finished attention row, or the partial-sum
-                // prologue when P.V is folded); the result goes to `proj`, so the hidden row stays what it was
-                const bool fold = !d->attn_fused() && d->pv_fold(L.wo);
-                const linear_w* nx = all ? &L.w13 : (more ? &N.wo : nullptr);
+            if (w == "wo" || w == "all") {
+                // the variant the token really launches (residual epilogue; the partial-sum prologue when P.V is folded);
+                // the result goes to `proj`, so the hidden row stays what it was
+                const bool fold = d->pv_fold(L.wo);
                 r = d->gemv(L.wo, fold ? 3 : 0, gemma ? 0 : 1, fold ? (const void*)d->pv_parts : (const void*)d->attn_out, d->proj,
-                            gemma ? nullptr : d->hidden, nullptr, mu, nx, all ? (gemma ? 3 : 2) : (gemma ? 0 : 1));
+                            gemma ? nullptr : d->hidden, nullptr, mu);
                 if (r != MC_OK) return r;
                 if (count) { bytes += linear_bytes(L.wo); launches++; }
             }
-            if (w == "w13" || all) {
-                const linear_w* nx = all ? &L.w2 : (more ? &N.w13 : nullptr);
-                r = d->gemv(L.w13, 1, gemma ? 3 : 2, d->hidden, d->gate, nullptr, L.ffn_norm, mu, nx, all ? (gemma ? 0 : 1) : (gemma ? 3 : 2));
+            if (w == "w13" || w == "all") {
+                r = d->gemv(L.w13, 1, gemma ? 3 : 2, d->hidden, d->gate, nullptr, L.ffn_norm, mu);
                 if (r != MC_OK) return r;
                 if (count) { bytes += linear_bytes(L.w13); launches++; }
             }
-            if (w == "w2" || all) {
-                const linear_w* nx = all ? (more ? &N.qkv : (d->last_stage ? &d->output : nullptr)) : (more ? &N.w2 : nullptr);
-                r = d->gemv(L.w2, 0, gemma ? 0 : 1, d->gate, d->proj, gemma ? nullptr : d->hidden, nullptr, mu, nx,
-                            all ? (more ? (gemma ? 0 : 4) : 5) : (gemma ? 0 : 1));
+            if (w == "w2" || w == "all") {
+                r = d->gemv(L.w2, 0, gemma ? 0 : 1, d->gate, d->proj, gemma ? nullptr : d->hidden, nullptr, mu);
                 if (r != MC_OK) return r;
                 if (count) { bytes += linear_bytes(L.w2); launches++; }
             }

@@ -704,16 +704,6 @@ attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const
             qa[ks] = make_uint4(0, 0, 0, 0);
             if (col < n_rep) qa[ks] = *reinterpret_cast<const uint4*>(q + (size_t)(kv * n_rep + col) * HD + ks * 32 + c * 8);
         }
-        {
-            // the V requests stay HERE: a load whose value is first used behind the hand-off is otherwise sunk to that use (measured:
-            // P.V then waited 0.96 us for its tile).  A value needed on both sides of a never-taken branch cannot be sunk.
-            uint32_t never;
-            asm volatile("s_mov_b32 %0, 0" : "=s"(never));
-            if (never) {
-#pragma unroll
-                for (int b = 0; b < NB; b++) asm volatile("" ::"v"(vb[b][0].x), "v"(vb[b][1].w));
-            }
-        }
         // ---- 2. scores (mc_attn_scores_bfloat: the same tile, the same roundings, the same partial sums)
         f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll

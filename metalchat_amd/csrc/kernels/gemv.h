@@ -559,7 +559,7 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
      void* __restrict__ yp, const void* __restrict__ resp, const void* __restrict__ normp,
      uint32_t out_rows, uint32_t in, uint32_t group, float eps, float mu,
      const void* __restrict__ lora_ap, const void* __restrict__ lora_bp, uint32_t lora_rank,
-     float lora_scale, const void* __restrict__ nextp = nullptr, uint32_t next_np = 0, uint32_t next_rowb = 0)
+     float lora_scale)
 {
     using F = fmt<WF, T>;
     using S = typename T::S;
@@ -572,7 +572,7 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
         // every kernel argument in ONE round of scalar loads: left to itself hipcc loads them where they are first used --
         // three dependent kernarg round trips (scalar-cache misses, ~0.1-0.2 us each) before the row is even requested
         asm volatile("" ::"s"(wp), "s"(sp), "s"(xp), "s"(yp), "s"(resp), "s"(normp), "s"(out_rows), "s"(in), "s"(group), "s"(eps),
-                     "s"(mu), "s"(lora_rank), "s"(gridDim.x), "s"(nextp), "s"(next_np), "s"(next_rowb));
+                     "s"(mu), "s"(lora_rank), "s"(gridDim.x));
     }
     constexpr bool M4 = (QM == Q_M4 || QM == Q_M4D) && WF == WF_I4 && T::bytes == 2;
     constexpr bool M4D = QM == Q_M4D && M4;
@@ -1002,24 +1002,6 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
     // classic per-packet arithmetic (mac<>: Wd = T(T(q) T(s)) per weight, fp32 accumulate).  These formats are memory-bound
     // (no matrix-pipe dequantisation to hide), so what the int4 kernels gained from the organisation they gain in full.
     // ======================================================================================
-    // NEXT-LAUNCH PREFETCH (linear-order kernels).  A launch of this chain spends its first ~2-3 us waiting for its first weight
-    // tiles: every wave of the chip asks HBM at once, behind the launch boundary, and nothing can be multiplied before they are
-    // in.  The launches of a token are known in advance and have the same geometry (one eight-wave workgroup per CU, wave gw
-    // sweeps the gw-th of equal spans of row pairs), so wave gw of THIS launch touches the first 4 KiB of the span wave gw of the
-    // NEXT launch will start with -- one dword per lane, 64 bytes apart: 32 lines of 128 bytes into the XCD's L2 (workgroup b
-    // of consecutive launches lands on XCD b % 8 in practice; otherwise the lines are in the Infinity Cache, still closer than
-    // HBM).  Issued behind this launch's own first tiles, consumed by nobody: no extra HBM bytes in total (the next launch finds
-    // them on chip), one VGPR.  The load is unconditional (a load behind a branch costs every counted vmcnt wait): without a
-    // next matrix (next_np = 0) it re-reads a line of this launch's own weights.
-    auto touch_next = [&](uint32_t gw, uint32_t nw_total) -> uint32_t {
-        const uint32_t nq = next_np / nw_total, nr = next_np - nq * nw_total;
-        const uint64_t total = (uint64_t)next_np * 2 * next_rowb;
-        uint64_t off = ((uint64_t)gw * nq + min(gw, nr)) * 2 * next_rowb;
-        off = off + 4096 <= total ? off : (total >= 4096 ? total - 4096 : 0);
-        const uint64_t m = total >= 4096 ? ~0ull : 0ull; // (no next matrix, or one smaller than the touch: this launch's own first line)
-        const char* a = reinterpret_cast<const char*>(((uint64_t)(uintptr_t)nextp & m) | ((uint64_t)(uintptr_t)wbase & ~m)) + (off & m);
-        return *reinterpret_cast<const uint32_t*>(a + lane * 64u);
-    };
     if constexpr (LGEN > 0) {
         static_assert(T::bytes == 2 && LWAVES > 0 && PRO != PRO_POSTNORM && !M4, "generic linear order: bfloat rows, int8 / bfloat weights");
         constexpr int PP = 2 * LGEN;                       // packets (KiB) per row pair
@@ -1116,7 +1098,6 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
             if (HALF_OK && half) gload(gring[j], pb, toff + (uint32_t)j, pb < pe && j < LGEN);
             else gload(gring[j], pb + j / PP, j % PP, pb + j / PP < pe);
         }
-        const uint32_t next_touch = touch_next(gw, nw_total);
         // ---- the row into LDS (natural order: these formats read their 16-byte slices straight)
         {
             rowv4* xl = reinterpret_cast<rowv4*>(xs);
@@ -1298,13 +1279,11 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
                     static_cast<S*>(yp)[row] = T::st(v);
                 }
             }
-            asm volatile("" ::"v"(next_touch));
             return;
         }
         for (uint32_t pr = pb; pr < pe; pr++) pair_g(pr);
         flush();
         if (EPI == EPI_STORE_PICK) pick_finish(red, nwaves);
-        asm volatile("" ::"v"(next_touch));
         return;
     }
     if constexpr (LNCH > 0) {
@@ -1468,13 +1447,11 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
             if (lin_never) asm volatile("" ::"s"(eo_slot), "s"(eo_rrow), "s"(eo_q.H), "s"(eo_q.KV), "s"(eo_q.hd), "s"(eo_q.max_seq));
         }
 
-        uint32_t next_touch = 0;
         auto lin_prefetch = [&] {
             if constexpr (LSPLIT != 0) lscales_quad(sa, sa2, pb, pb < pe);
             else lscales(sa, pb, pb < pe);
 #pragma unroll
             for (int j = 0; j < LR; j++) ltile(lring[j], pb + j / TPP, j % TPP, pb + j / TPP < pe);
-            next_touch = touch_next(gw, nw_total);
         };
         if constexpr (LEAN) {
             uint4* xl = reinterpret_cast<uint4*>(xs);
@@ -1691,7 +1668,6 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
         }
         flush();
         if (EPI == EPI_STORE_PICK) pick_finish(red, nwaves);
-        asm volatile("" ::"v"(next_touch));
         return;
     }
 

@@ -17,11 +17,10 @@ using namespace mc::gemv;
     extern "C" __global__ void __launch_bounds__(MC_GEMV_LB)                                          \
     NAME(const void* w, const void* scales, const void* x, void* y, const void* res,             \
          const void* norm_w, uint32_t out_rows, uint32_t in, uint32_t group, float eps, float mu, \
-         const void* lora_a, const void* lora_b, uint32_t lora_rank, float lora_scale,            \
-         const void* next_w, uint32_t next_np, uint32_t next_rowb)                                \
+         const void* lora_a, const void* lora_b, uint32_t lora_rank, float lora_scale)            \
     {                                                                                             \
         body<WF, T, QM, PRO, EPI, 4>(w, scales, x, y, res, norm_w, out_rows, in, group, eps, mu,  \
-                                     lora_a, lora_b, lora_rank, lora_scale, next_w, next_np, next_rowb);                      \
+                                     lora_a, lora_b, lora_rank, lora_scale);                      \
     }
 
 // linear-order variants (gemv.h): mc_gemv_i4_bfloat_lin{K/2048}_p{PRO}_e{EPI}, rows of K/2048 whole KiB.
@@ -33,11 +32,10 @@ using namespace mc::gemv;
     extern "C" __global__ void __launch_bounds__(MC_LIN_WAVES ? 64 * MC_LIN_WAVES : MC_GEMV_LB)   \
     NAME(const void* w, const void* scales, const void* x, void* y, const void* res,             \
          const void* norm_w, uint32_t out_rows, uint32_t in, uint32_t group, float eps, float mu, \
-         const void* lora_a, const void* lora_b, uint32_t lora_rank, float lora_scale,            \
-         const void* next_w, uint32_t next_np, uint32_t next_rowb)                                \
+         const void* lora_a, const void* lora_b, uint32_t lora_rank, float lora_scale)            \
     {                                                                                             \
         body<WF_I4, BF, Q_M4D, PRO, EPI, 4, __VA_ARGS__, MC_LIN_WAVES>(                           \
-            w, scales, x, y, res, norm_w, out_rows, in, group, eps, mu, lora_a, lora_b, lora_rank, lora_scale, next_w, next_np, next_rowb); \
+            w, scales, x, y, res, norm_w, out_rows, in, group, eps, mu, lora_a, lora_b, lora_rank, lora_scale); \
     }
 #define MC_GEMV_LIN_SET(PFX, ...)               \
     MC_GEMV_LIN(PFX##_p0_e0, 0, 0, __VA_ARGS__) \
@@ -101,11 +99,10 @@ MC_GEMV_LIN_SET(mc_gemv_i4_bfloat_lin12, MC_LIN12_CFG) // K = 24576 (Gemma-7B's 
     extern "C" __global__ void __launch_bounds__(64 * MC_LIN_WAVES)                               \
     NAME(const void* w, const void* scales, const void* x, void* y, const void* res,             \
          const void* norm_w, uint32_t out_rows, uint32_t in, uint32_t group, float eps, float mu, \
-         const void* lora_a, const void* lora_b, uint32_t lora_rank, float lora_scale,            \
-         const void* next_w, uint32_t next_np, uint32_t next_rowb)                                \
+         const void* lora_a, const void* lora_b, uint32_t lora_rank, float lora_scale)            \
     {                                                                                             \
         body<WF_I4, BF, Q_M4D, PRO, EPI, 4, 3, 1, 2, MC_LIN_WAVES, 0, 1>(                       \
-            w, scales, x, y, res, norm_w, out_rows, in, group, eps, mu, lora_a, lora_b, lora_rank, lora_scale, next_w, next_np, next_rowb); \
+            w, scales, x, y, res, norm_w, out_rows, in, group, eps, mu, lora_a, lora_b, lora_rank, lora_scale); \
     }
 #if MC_LIN_WAVES
 MC_GEMV_LINS(mc_gemv_i4_bfloat_lin3s_p0_e0, 0, 0)
@@ -124,11 +121,10 @@ MC_GEMV_LIN_SET(mc_gemv_i4_bfloat_lin14, MC_LIN14_CFG) // K = 28672
     extern "C" __global__ void __launch_bounds__(64 * MC_LIN_WAVES)                              \
     NAME(const void* w, const void* scales, const void* x, void* y, const void* res,             \
          const void* norm_w, uint32_t out_rows, uint32_t in, uint32_t group, float eps, float mu, \
-         const void* lora_a, const void* lora_b, uint32_t lora_rank, float lora_scale,            \
-         const void* next_w, uint32_t next_np, uint32_t next_rowb)                                \
+         const void* lora_a, const void* lora_b, uint32_t lora_rank, float lora_scale)            \
     {                                                                                             \
         body<WF, BF, Q_EXACT, PRO, EPI, 4, 0, 0, 0, MC_LIN_WAVES, NCH>(                           \
-            w, scales, x, y, res, norm_w, out_rows, in, group, eps, mu, lora_a, lora_b, lora_rank, lora_scale, next_w, next_np, next_rowb); \
+            w, scales, x, y, res, norm_w, out_rows, in, group, eps, mu, lora_a, lora_b, lora_rank, lora_scale); \
     }
 #define MC_GEMV_LING_SET(PFX, WF, NCH)          \
     MC_GEMV_LING(PFX##_p0_e0, WF, 0, 0, NCH)    \

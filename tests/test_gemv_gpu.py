@@ -63,8 +63,7 @@ def run_gemv(acc, name, wptr, sptr, x_T, out_n, rows, in_f, group, dt, res=None,
                       [wbuf, sbuf, xb, yb, rb, nb, np.uint32(rows), np.uint32(in_f), np.uint32(group),
                        np.float32(eps), np.float32(mu)] +
                       ([acc.to_device(lora[0]), acc.to_device(lora[1]), np.uint32(lora[0].size),
-                        np.float32(lora[2])] if lora else [None, None, np.uint32(0), np.float32(0)]) +
-                      [None, np.uint32(0), np.uint32(0)],  # no next-launch prefetch (gemv.h)
+                        np.float32(lora[2])] if lora else [None, None, np.uint32(0), np.float32(0)]),
                       lds_bytes=lds)
     t()
     acc.wait()

@@ -62,8 +62,7 @@ def lds_bytes(family, K, classic=False):
 
 
 def launch(acc, name, wptr, sptr, x, y_elems, rows, K, group, res=None, norm=None, wgs=1, block=64 * WAVES, lds=0, mu=0.0,
-           y_dtype=np.uint16, nxt=(None, np.uint32(0), np.uint32(0))):
-    """nxt = (buffer, row pairs, bytes per row) of the matrix the FOLLOWING launch would stream (gemv.h, next-launch prefetch)"""
+           y_dtype=np.uint16):
     import metalchat_amd as mc
 
     k = acc.load(name)
@@ -74,7 +73,7 @@ def launch(acc, name, wptr, sptr, x, y_elems, rows, K, group, res=None, norm=Non
     nb = norm if (norm is None or hasattr(norm, "device_ptr")) else acc.to_device(norm)
     t = mc.KernelTask(k, (wgs * block, 1, 1), (block, 1, 1),
                       [acc.wrap(wptr, 1 << 40), (acc.wrap(sptr, 1 << 40) if sptr else None), xb, yb, rb, nb, np.uint32(rows),
-                       np.uint32(K), np.uint32(group), np.float32(1e-5), np.float32(mu), None, None, np.uint32(0), np.float32(0)] + list(nxt),
+                       np.uint32(K), np.uint32(group), np.float32(1e-5), np.float32(mu), None, None, np.uint32(0), np.float32(0)],
                       lds_bytes=lds)
     t()
     acc.wait()
@@ -415,23 +414,3 @@ def test_gemma_post_norm_prologue(acc, models, family):
     mo.hadamard(BF16, L(g1.shape), ref, L(g1.shape), a, L(g1.shape), g3)
     got = launch(acc, kname(family, 2, 3), wptr, sptr, x, rows // 2, rows, K, grp(family), res=desc, norm=nw, wgs=5, lds=lds_bytes(family, K), mu=mu)
     parity.check(BF16, got, ref.reshape(-1), rel=3e-3, max_ulp=2, max_frac=0.3, what=f"{family} p2_e3")
-
-
-@pytest.mark.parametrize("family", ["i4_lin2", "i4_lin7", "i4_lin3s", "i8_ling4", "w_ling11"])
-def test_next_launch_prefetch_changes_nothing(acc, models, family):
-    """A linear-order kernel touches the first 4 KiB of the span each of its waves will sweep in the NEXT launch (gemv.h):
-    loads nobody consumes -- the results are bit for bit those without a next matrix, whatever that matrix is (a large one, one
-    whose spans end at the buffer's last byte, one smaller than the touch)."""
-    cfg, w, dec = models.get(family, "w2")
-    K = FAMILIES[family][2]
-    rng = np.random.default_rng(31)
-    x = mo.encode(BF16, rng.normal(0, 1, K).astype(np.float32))
-    wptr, sptr, rows, inf, ng = dec.weight_ptrs(0, "w2")
-    lds = lds_bytes(family, K)
-    for wgs in (1, 16, 40):
-        base = launch(acc, kname(family, 0, 0), wptr, sptr, x, rows, rows, K, grp(family), wgs=wgs, lds=lds)
-        for nbytes, np_pairs, rowb in ((1 << 20, 512, 1024), (4096 * 3, 6, 1024), (2048, 1, 1024), (14336 * 64, 32, 14336)):
-            nxt = acc.to_device(rng.integers(0, 255, nbytes, dtype=np.uint8))
-            got = launch(acc, kname(family, 0, 0), wptr, sptr, x, rows, rows, K, grp(family), wgs=wgs, lds=lds,
-                         nxt=(nxt, np.uint32(np_pairs), np.uint32(rowb)))
-            parity.exact(got, base, f"{family} wgs {wgs} next matrix of {nbytes} bytes")
