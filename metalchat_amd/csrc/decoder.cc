@@ -1990,7 +1990,7 @@ mc_decoder_time_gemv(mc_decoder* d, const char* which, int32_t repeats, float* t
             if (w == "wo" || w == "all") {
                 // the variant the token really launches (residual epilogue; the partial-sum prologue when P.V is folded);
                 // the result goes to `proj`, so the hidden row stays what it was
-                const bool fold = d->pv_fold(L.wo);
+                const bool fold = !d->attn_fused() && d->pv_fold(L.wo);
                 r = d->gemv(L.wo, fold ? 3 : 0, gemma ? 0 : 1, fold ? (const void*)d->pv_parts : (const void*)d->attn_out, d->proj,
                             gemma ? nullptr : d->hidden, nullptr, mu);
                 if (r != MC_OK) return r;

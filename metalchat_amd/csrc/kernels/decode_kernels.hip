@@ -667,12 +667,39 @@ attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const
     __shared__ float inv_s[16];
     __shared__ __attribute__((aligned(16))) float ebuf[16 * ES];
 
-    const uint32_t S = (uint32_t)st->kv_len;
-    const uint32_t tag = st->epoch * 256u + layer_tag;
     const uint32_t kv = blockIdx.x % KV, split = blockIdx.x / KV;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t col = lane & 15, c = lane >> 4;
     const uint32_t p_begin = split * PB;
+    // ---- 1. K and V tiles and the queries: every load of the launch that touches the caches, issued before anything is waited
+    // for -- the step state included (a range past kv_len reads slots nobody uses: their products are masked below)
+    const uint32_t pos = p_begin + wave * 16 + col;
+    const uint32_t lp = pos < max_seq ? pos : max_seq - 1;
+    const bf16_t* kbase = kc + ((size_t)kv * max_seq + lp) * HD;
+    uint4 kb[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++) kb[ks] = *reinterpret_cast<const uint4*>(kbase + ks * 32 + c * 8);
+    uint4 vb[NB][2];
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+        const uint32_t db = wave + 4 * b;
+        const bf16_t* vrow = vt + ((size_t)kv * HD + (db < (uint32_t)NDB ? db : 0u) * 16 + col) * max_seq;
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const uint32_t p0 = p_begin + u * 32 + c * 8;
+            vb[b][u] = *reinterpret_cast<const uint4*>(vrow + (p0 + 8 <= max_seq ? p0 : max_seq - 8));
+        }
+    }
+    uint4 qa[KS];
+    {
+        // (rows past n_rep of the A operand: the row of the last query head again -- their results are never read; an
+        //  unconditional load keeps the compiler's counted waits, a load behind a branch costs every one of them)
+        const uint32_t qh = col < n_rep ? col : n_rep - 1;
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) qa[ks] = *reinterpret_cast<const uint4*>(q + (size_t)(kv * n_rep + qh) * HD + ks * 32 + c * 8);
+    }
+    const uint32_t S = (uint32_t)st->kv_len;
+    const uint32_t tag = st->epoch * 256u + layer_tag;
     const uint32_t nact = (S + PB - 1) / PB;
     const bool active = p_begin < S;
 
@@ -680,30 +707,6 @@ attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const
 #pragma unroll
     for (int b = 0; b < NB; b++) oacc[b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     if (active) {
-        // ---- 1. K and V tiles: every load of the launch that touches the caches, issued before anything is waited for
-        const uint32_t pos = p_begin + wave * 16 + col;
-        const uint32_t lp = pos < S ? pos : S - 1;
-        const bf16_t* kbase = kc + ((size_t)kv * max_seq + lp) * HD;
-        uint4 kb[KS];
-#pragma unroll
-        for (int ks = 0; ks < KS; ks++) kb[ks] = *reinterpret_cast<const uint4*>(kbase + ks * 32 + c * 8);
-        uint4 vb[NB][2];
-#pragma unroll
-        for (int b = 0; b < NB; b++) {
-            const uint32_t db = wave + 4 * b;
-            const bf16_t* vrow = vt + ((size_t)kv * HD + (db < (uint32_t)NDB ? db : 0u) * 16 + col) * max_seq;
-#pragma unroll
-            for (int u = 0; u < 2; u++) {
-                const uint32_t p0 = p_begin + u * 32 + c * 8;
-                vb[b][u] = *reinterpret_cast<const uint4*>(vrow + (p0 + 8 <= max_seq ? p0 : max_seq - 8));
-            }
-        }
-        uint4 qa[KS];
-#pragma unroll
-        for (int ks = 0; ks < KS; ks++) {
-            qa[ks] = make_uint4(0, 0, 0, 0);
-            if (col < n_rep) qa[ks] = *reinterpret_cast<const uint4*>(q + (size_t)(kv * n_rep + col) * HD + ks * 32 + c * 8);
-        }
         // ---- 2. scores (mc_attn_scores_bfloat: the same tile, the same roundings, the same partial sums)
         f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll

@@ -24,10 +24,12 @@ for name, m, fmt, group, S, K, past in CASES:
     extra = dict(rope_sliding_theta=10000.0, sliding_stride=6) if fam else {}
     dec = mc.Decoder(acc, dtype=mc.BF16, family=fam, max_seq_len=S, norm_eps=1e-5,
                      attn_scale=float(1 / np.sqrt(m["head_dim"])), weight_format=fmt, group_size=group,
-                     use_graph=1, **extra, **m)
+                     use_graph=0 if os.environ.get('MC_NO_GRAPH') else 1, **extra, **m)
     dec.init_synthetic(7)
     fill = S - K - 8
-    tok = int(dec.generate(1, 0, fill)[-1])
+    # (MC_SKIP_FILL: profiling runs start at the position instead of decoding up to it -- the cache rows before it are zeros,
+    #  the traffic per token is the same)
+    tok = 1 if os.environ.get('MC_SKIP_FILL') else int(dec.generate(1, 0, fill)[-1])
     tok = int(dec.generate(tok, fill, 8)[-1])
     acc.wait()
     t0 = time.perf_counter()
