@@ -187,6 +187,10 @@ struct mc_decoder {
     unsigned long long* attn_psum_g = nullptr; // [H][nsplit]            partial softmax denominators
     unsigned long long* attn_slab_g = nullptr; // [KV][nsplit][n_rep][hd] fp32 partial P.V sums
     bool attn_fused_on = true;   // MC_ATTN_FUSED=0: scores and P.V as two launches (A/B, parity)
+    // ... while the launch is at most this many 256-thread workgroups per CU (MC_ATTN_FUSED_WGS).  Measured: at S = 8192 (128
+    // ranges x 8 kv heads = 4 per CU, every hand-off gathering from 128 producers) the one launch took 27.8 us against 6.1 + 7.2 for
+    // the two -- long contexts keep the two-launch form
+    unsigned attn_fused_max_wgs_per_cu = 2;
     void* taps = nullptr;       // T[(n_own+1)*dim]
     step_state_h* state = nullptr;
     int32_t* tokens_dev = nullptr;
@@ -526,7 +530,7 @@ struct mc_decoder {
     attn_fused() const
     {
         return attn_fused_on && attn_psum_g && tb == 2 && n_own <= 254 &&
-               (unsigned)(nsplit * cfg.n_kv_heads) <= 4u * (unsigned)dev->prop.multiProcessorCount;
+               (unsigned)(nsplit * cfg.n_kv_heads) <= attn_fused_max_wgs_per_cu * (unsigned)dev->prop.multiProcessorCount;
     }
 
     // a hand-off inside a launch that gave up (bounded waits, decode_kernels.hip): reported once, then cleared
@@ -1158,6 +1162,7 @@ mc_decoder_create(mc_device* dev, mc_library* lib, mc_queue* q, const mc_decoder
     if (const char* e = getenv("MC_GEMV_LIN")) d->gemv_lin = atoi(e) != 0;
     if (const char* e = getenv("MC_PV_FOLD")) d->pv_fold_on = atoi(e) != 0;
     if (const char* e = getenv("MC_ATTN_FUSED")) d->attn_fused_on = atoi(e) != 0;
+    if (const char* e = getenv("MC_ATTN_FUSED_WGS")) d->attn_fused_max_wgs_per_cu = (unsigned)std::max(1, std::min(4, atoi(e)));
     if (const char* e = getenv("MC_LING_HALF")) d->ling_half = atoi(e) != 0;
     if (const char* e = getenv("MC_LIN_SPLIT")) d->lin_split = atoi(e) != 0;
     if (const char* e = getenv("MC_I8_LING14")) d->i8_ling14 = atoi(e) != 0;

@@ -707,6 +707,13 @@ attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const
 #pragma unroll
     for (int b = 0; b < NB; b++) oacc[b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     if (active) {
+        // The V tile is DEFINED here: hipcc otherwise sinks its loads to their first use behind the hand-off (measured: P.V then
+        // waited 0.96 us for them).  Vector memory returns in order and the queries were requested behind the tile, so the
+        // wait this costs is the one the first MFMA below needs anyway.
+#pragma unroll
+        for (int b = 0; b < NB; b++)
+#pragma unroll
+            for (int u = 0; u < 2; u++) asm volatile("" : "+v"(vb[b][u].x), "+v"(vb[b][u].y), "+v"(vb[b][u].z), "+v"(vb[b][u].w));
         // ---- 2. scores (mc_attn_scores_bfloat: the same tile, the same roundings, the same partial sums)
         f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -739,6 +746,7 @@ attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const
             const float tot = (wsum[0][threadIdx.x] + wsum[1][threadIdx.x]) + (wsum[2][threadIdx.x] + wsum[3][threadIdx.x]);
             granule_store(psum_g + (size_t)(kv * n_rep + threadIdx.x) * nsplit + split, tag, __float_as_uint(tot));
         }
+        stamp(6);
         for (uint32_t head = wave; head < n_rep; head += 4) {
             // (softmax_inv's order: lane-strided partial sums, then the shuffle tree)
             const unsigned long long* row = psum_g + (size_t)(kv * n_rep + head) * nsplit;

@@ -147,7 +147,7 @@ def test_llama3_8b_int8_at_8192_with_automatic_context_ranges(acc, monkeypatch):
     agree = run_injected(acc, cfg, weights, 8185, 15, dict(weight_format=mc.WFMT_I8, group_size=128),
                          rel_logits=5e-3, max_ulp=2, max_frac=0.7, what="8B int8 S=8192", launched=names)
     assert agree >= 13
-    assert {"mc_gemv_i8_bfloat_ling4_p1_e4", "mc_attn_fused_bfloat", "mc_gemv_i8_bfloat_ling4_p0_e1", "mc_gemv_i8_bfloat_ling4_p1_e2", "mc_gemv_i8_bfloat_ling14_p0_e1",
+    assert {"mc_gemv_i8_bfloat_ling4_p1_e4", "mc_attn_pv_bfloat", "mc_gemv_i8_bfloat_ling4_p3_e1", "mc_gemv_i8_bfloat_ling4_p1_e2", "mc_gemv_i8_bfloat_ling14_p0_e1",
             "mc_gemv_i8_bfloat_ling4_p1_e5"} <= names, sorted(names)
 
 
@@ -341,6 +341,7 @@ def test_one_launch_attention_against_the_two_launch_form(acc, monkeypatch, shap
         fmt = dict(weight_format=mc.WFMT_I4, group_size=128)
     S = cfg["max_seq_len"]
     out = {}
+    monkeypatch.setenv("MC_ATTN_FUSED_WGS", "4")  # (S = 8192 is 4 workgroups per CU: by default the two-launch form)
     for fused in ("1", "0"):
         monkeypatch.setenv("MC_ATTN_FUSED", fused)
         dec = mc.Decoder(acc, **mg.decoder_kwargs(cfg, **fmt))
@@ -365,7 +366,9 @@ def test_one_launch_attention_against_the_two_launch_form(acc, monkeypatch, shap
     for i, ((ta, la, ha), (tb_, lb, hb)) in enumerate(zip(out["1"], out["0"])):
         same += int(ta == tb_)
         for layer in range(ha.shape[0]):  # row 0: the embedding (identical); the forms differ from the first attention on
-            parity.check(BF16, ha[layer], hb[layer], rel=3.9e-3 * max(layer, 1), max_ulp=2 * layer, max_frac=0.3 if layer else 0.0,
+            # (a last-bit difference in a few elements of the attention row reaches every output of the Wo GEMV: about 40 % of
+            #  the block output lands on the neighbouring bf16 value -- how FAR stays bounded)
+            parity.check(BF16, ha[layer], hb[layer], rel=3.9e-3 * max(layer, 1), max_ulp=2 * layer, max_frac=0.6 if layer else 0.0,
                          what=f"{shape} step {i} hidden[{layer - 1}], one launch vs two")
         parity.check(BF16, la, lb, rel=5e-3, max_ulp=3, max_frac=0.7, what=f"{shape} step {i} logits, one launch vs two")
     assert same >= len(out["1"]) - 2, (shape, same)
