@@ -707,13 +707,10 @@ attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const
 #pragma unroll
     for (int b = 0; b < NB; b++) oacc[b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     if (active) {
-        // The V tile is DEFINED here: hipcc otherwise sinks its loads to their first use behind the hand-off (measured: P.V then
-        // waited 0.96 us for them).  Vector memory returns in order and the queries were requested behind the tile, so the
-        // wait this costs is the one the first MFMA below needs anyway.
-#pragma unroll
-        for (int b = 0; b < NB; b++)
-#pragma unroll
-            for (int u = 0; u < 2; u++) asm volatile("" : "+v"(vb[b][u].x), "+v"(vb[b][u].y), "+v"(vb[b][u].z), "+v"(vb[b][u].w));
+        // (The V tile's requests are written up front but hipcc sinks them to their first use, behind hand-off A.  Pinning them in
+        //  front of the scores -- an asm "+v" on the tile -- measured SLOWER in the token: scores done 2.3 us after the start instead
+        //  of 1.8, 689 vs 710 tokens/s against 687 / 690 for the two-launch form on the same boxes: the first MFMA then waits for
+        //  16 KB more per workgroup.  Left to the compiler.)
         // ---- 2. scores (mc_attn_scores_bfloat: the same tile, the same roundings, the same partial sums)
         f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll

@@ -362,13 +362,18 @@ def test_one_launch_attention_against_the_two_launch_form(acc, monkeypatch, shap
         assert ("mc_attn_pv_bfloat" in names) == (fused == "0"), sorted(names)
         out[fused] = rows
         dec.release()
+    # Each form is held to the oracle element by element in the tests above; between the two forms (a last-bit difference in a
+    # few elements of the attention row reaches every output of the Wo GEMV, so about half of a block's output lands on the
+    # neighbouring bf16 value) the bound is vector-wise: one bf16 step per block, and the same greedy tokens.
+    def nrm(a, b):
+        a, b = mo.from_bf16(a).astype(np.float64), mo.from_bf16(b).astype(np.float64)
+        return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
+
     same = 0
     for i, ((ta, la, ha), (tb_, lb, hb)) in enumerate(zip(out["1"], out["0"])):
         same += int(ta == tb_)
-        for layer in range(ha.shape[0]):  # row 0: the embedding (identical); the forms differ from the first attention on
-            # (a last-bit difference in a few elements of the attention row reaches every output of the Wo GEMV: about 40 % of
-            #  the block output lands on the neighbouring bf16 value -- how FAR stays bounded)
-            parity.check(BF16, ha[layer], hb[layer], rel=3.9e-3 * max(layer, 1), max_ulp=2 * layer, max_frac=0.6 if layer else 0.0,
-                         what=f"{shape} step {i} hidden[{layer - 1}], one launch vs two")
-        parity.check(BF16, la, lb, rel=5e-3, max_ulp=3, max_frac=0.7, what=f"{shape} step {i} logits, one launch vs two")
+        parity.exact(ha[0], hb[0], f"{shape} step {i}: the embedding row")
+        for layer in range(1, ha.shape[0]):
+            assert nrm(ha[layer], hb[layer]) <= 3.9e-3 * layer, f"{shape} step {i} hidden[{layer - 1}], one launch vs two: {nrm(ha[layer], hb[layer]):.3g}"
+        assert nrm(la, lb) <= 3.9e-3 * (ha.shape[0] + 1), f"{shape} step {i} logits, one launch vs two: {nrm(la, lb):.3g}"
     assert same >= len(out["1"]) - 2, (shape, same)
