@@ -648,7 +648,11 @@ struct handoff_wait {
     }
 };
 
-template <int HD>
+// T = 64-slot score tiles per wave: a workgroup owns 64 T cache slots.  T = 1 for contexts up to 4096 slots; longer contexts take
+// wider ranges so that the launch stays within two workgroups per CU (every hand-off gathers from ONE producer per range: at
+// S = 8192 with 64-slot ranges -- 1024 workgroups, 128 producers per gather -- the launch measured 27.8 us against 6.3 + 8.5 for
+// the two-launch form).
+template <int HD, int T>
 __device__ __forceinline__ void
 attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const bf16_t* __restrict__ vt, bf16_t* __restrict__ out,
               unsigned long long* psum_g, unsigned long long* slab_g, step_state* st, uint32_t n_rep, uint32_t KV, uint32_t max_seq,
@@ -662,7 +666,8 @@ attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const
     constexpr int KS = HD / 32;                 // MFMA k-steps of q.k
     constexpr int NDB = HD / 16;                // 16-column blocks of the output
     constexpr int NB = NDB >= 4 ? NDB / 4 : 1;  // ... per wave
-    constexpr int ES = PB + 4;                  // numerator row stride in LDS (floats): 16 rows read 32 bytes apart in the banks
+    constexpr uint32_t PBW = PB * T;            // cache slots per workgroup
+    constexpr int ES = PBW + 4;                 // numerator row stride in LDS (floats): 16 rows read 32 bytes apart in the banks
     __shared__ float wsum[4][16];
     __shared__ float inv_s[16];
     __shared__ __attribute__((aligned(16))) float ebuf[16 * ES];
@@ -670,26 +675,33 @@ attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const
     const uint32_t kv = blockIdx.x % KV, split = blockIdx.x / KV;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t col = lane & 15, c = lane >> 4;
-    const uint32_t p_begin = split * PB;
-    // ---- 1. K and V tiles and the queries: every load of the launch that touches the caches, issued before anything is waited
-    // for -- the step state included (a range past kv_len reads slots nobody uses: their products are masked below)
-    const uint32_t pos = p_begin + wave * 16 + col;
-    const uint32_t lp = pos < max_seq ? pos : max_seq - 1;
-    const bf16_t* kbase = kc + ((size_t)kv * max_seq + lp) * HD;
-    uint4 kb[KS];
+    const uint32_t p_begin = split * PBW;
+    // ---- 1. the K tiles and the queries: requested before anything is waited for -- the step state included (a range past
+    // kv_len reads slots nobody uses: their products are masked below)
+    uint4 kb[T][KS];
 #pragma unroll
-    for (int ks = 0; ks < KS; ks++) kb[ks] = *reinterpret_cast<const uint4*>(kbase + ks * 32 + c * 8);
-    uint4 vb[NB][2];
+    for (int t = 0; t < T; t++) {
+        const uint32_t pos = p_begin + t * PB + wave * 16 + col;
+        const bf16_t* kbase = kc + ((size_t)kv * max_seq + (pos < max_seq ? pos : max_seq - 1)) * HD;
 #pragma unroll
-    for (int b = 0; b < NB; b++) {
-        const uint32_t db = wave + 4 * b;
-        const bf16_t* vrow = vt + ((size_t)kv * HD + (db < (uint32_t)NDB ? db : 0u) * 16 + col) * max_seq;
-#pragma unroll
-        for (int u = 0; u < 2; u++) {
-            const uint32_t p0 = p_begin + u * 32 + c * 8;
-            vb[b][u] = *reinterpret_cast<const uint4*>(vrow + (p0 + 8 <= max_seq ? p0 : max_seq - 8));
-        }
+        for (int ks = 0; ks < KS; ks++) kb[t][ks] = *reinterpret_cast<const uint4*>(kbase + ks * 32 + c * 8);
     }
+    // (the V tile's requests are written here too; hipcc sinks them to their first use behind hand-off A.  Pinning them in front
+    //  of the scores measured SLOWER in the token -- scores done 2.3 us after the start instead of 1.8, 689 vs 710 tokens/s against
+    //  687 / 690 for the two-launch form on the same boxes: the first MFMA then waits for 16 KB more.  Left to the compiler.)
+    uint4 vb[T][NB][2];
+#pragma unroll
+    for (int t = 0; t < T; t++)
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+            const uint32_t db = wave + 4 * b;
+            const bf16_t* vrow = vt + ((size_t)kv * HD + (db < (uint32_t)NDB ? db : 0u) * 16 + col) * max_seq;
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const uint32_t p0 = p_begin + t * PB + u * 32 + c * 8;
+                vb[t][b][u] = *reinterpret_cast<const uint4*>(vrow + (p0 + 8 <= max_seq ? p0 : max_seq - 8));
+            }
+        }
     uint4 qa[KS];
     {
         // (rows past n_rep of the A operand: the row of the last query head again -- their results are never read; an
@@ -700,42 +712,49 @@ attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const
     }
     const uint32_t S = (uint32_t)st->kv_len;
     const uint32_t tag = st->epoch * 256u + layer_tag;
-    const uint32_t nact = (S + PB - 1) / PB;
+    const uint32_t nact = (S + PBW - 1) / PBW;
     const bool active = p_begin < S;
 
     f32x4_t oacc[NB];
 #pragma unroll
     for (int b = 0; b < NB; b++) oacc[b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     if (active) {
-        // (The V tile's requests are written up front but hipcc sinks them to their first use, behind hand-off A.  Pinning them in
-        //  front of the scores -- an asm "+v" on the tile -- measured SLOWER in the token: scores done 2.3 us after the start instead
-        //  of 1.8, 689 vs 710 tokens/s against 687 / 690 for the two-launch form on the same boxes: the first MFMA then waits for
-        //  16 KB more per workgroup.  Left to the compiler.)
-        // ---- 2. scores (mc_attn_scores_bfloat: the same tile, the same roundings, the same partial sums)
-        f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < KS; ks++)
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, qa[ks]), __builtin_bit_cast(bf16x8_t, kb[ks]), acc, 0, 0, 0);
+        // ---- 2. scores (mc_attn_scores_bfloat: the same tiles, the same roundings; the tile sums of a wave are added in tile
+        // order, the four waves' sums as that kernel adds them)
         const uint32_t nm = (n_rep + 3) / 4;
-        for (uint32_t m = 0; m < nm; m++) {
-            const int src = (int)(m * 16 + col);
-            const float v0 = __shfl(acc[0], src, 64), v1 = __shfl(acc[1], src, 64);
-            const float v2 = __shfl(acc[2], src, 64), v3 = __shfl(acc[3], src, 64);
-            const float mine = c == 0 ? v0 : (c == 1 ? v1 : (c == 2 ? v2 : v3));
-            const uint32_t head = 4 * m + c;
-            float e = 0.0f;
-            if (head < n_rep && pos < S) {
-                float sc = BF::rt(mine);
-                sc = BF::rt(sc * scale);
-                e = exp_precise(sc);
+        float esum[4] = {0.f, 0.f, 0.f, 0.f}; // per m: this lane group's running sum over the wave's tiles
+#pragma unroll
+        for (int t = 0; t < T; t++) {
+            const uint32_t pos = p_begin + t * PB + wave * 16 + col;
+            f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ks++)
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, qa[ks]), __builtin_bit_cast(bf16x8_t, kb[t][ks]), acc, 0, 0, 0);
+#pragma unroll
+            for (uint32_t m = 0; m < 4; m++) {
+                if (m >= nm) break;
+                const int src = (int)(m * 16 + col);
+                const float v0 = __shfl(acc[0], src, 64), v1 = __shfl(acc[1], src, 64);
+                const float v2 = __shfl(acc[2], src, 64), v3 = __shfl(acc[3], src, 64);
+                const float mine = c == 0 ? v0 : (c == 1 ? v1 : (c == 2 ? v2 : v3));
+                const uint32_t head = 4 * m + c;
+                float e = 0.0f;
+                if (head < n_rep && pos < S) {
+                    float sc = BF::rt(mine);
+                    sc = BF::rt(sc * scale);
+                    e = exp_precise(sc);
+                }
+                ebuf[head * ES + t * PB + wave * 16 + col] = e;
+                e += __shfl_xor(e, 1, 64);
+                e += __shfl_xor(e, 2, 64);
+                e += __shfl_xor(e, 4, 64);
+                e += __shfl_xor(e, 8, 64);
+                esum[m] += e;
             }
-            if (head < 16) ebuf[head * ES + wave * 16 + col] = e;
-            e += __shfl_xor(e, 1, 64);
-            e += __shfl_xor(e, 2, 64);
-            e += __shfl_xor(e, 4, 64);
-            e += __shfl_xor(e, 8, 64);
-            if (col == 0 && head < 16) wsum[wave][head] = e;
         }
+#pragma unroll
+        for (uint32_t m = 0; m < 4; m++)
+            if (m < nm && col == 0) wsum[wave][4 * m + c] = esum[m];
         __syncthreads();
         stamp(1);
         // ---- 3. hand-off A: this range's partial denominators out, the kv head's denominators in
@@ -743,50 +762,51 @@ attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const
             const float tot = (wsum[0][threadIdx.x] + wsum[1][threadIdx.x]) + (wsum[2][threadIdx.x] + wsum[3][threadIdx.x]);
             granule_store(psum_g + (size_t)(kv * n_rep + threadIdx.x) * nsplit + split, tag, __float_as_uint(tot));
         }
-        stamp(6);
         for (uint32_t head = wave; head < n_rep; head += 4) {
             // (softmax_inv's order: lane-strided partial sums, then the shuffle tree)
             const unsigned long long* row = psum_g + (size_t)(kv * n_rep + head) * nsplit;
-            float t = 0.0f;
+            float tsum = 0.0f;
             handoff_wait w;
             for (;;) {
                 bool ok = true;
-                t = 0.0f;
+                tsum = 0.0f;
                 for (uint32_t sp = lane; sp < nact; sp += 64) {
                     const unsigned long long g = granule_load(row + sp);
                     ok = ok && (uint32_t)(g >> 32) == tag;
-                    t += __uint_as_float((uint32_t)g);
+                    tsum += __uint_as_float((uint32_t)g);
                 }
                 if (__all(ok) || w.expired(st, 0xA0000000u | layer_tag)) break;
             }
-            t = wave_sum(t);
-            if (lane == 0) inv_s[head] = 1.0f / t;
+            tsum = wave_sum(tsum);
+            if (lane == 0) inv_s[head] = 1.0f / tsum;
         }
         __syncthreads();
         stamp(2);
         const float inv = col < n_rep ? inv_s[col] : 0.0f;
-        // ---- 4. P.V over the range's 64 slots: A = T(e * inv) from LDS (softmax.metal:84-86), B = the V tile
+        // ---- 4. P.V over the range's slots: A = T(e * inv) from LDS (softmax.metal:84-86), B = the V tiles
 #pragma unroll
-        for (int b = 0; b < NB; b++) {
-            if (wave + 4 * b >= (uint32_t)NDB) continue;
+        for (int t = 0; t < T; t++)
 #pragma unroll
-            for (int u = 0; u < 2; u++) {
-                const uint32_t p0 = p_begin + u * 32 + c * 8;
-                const float4 e0 = *reinterpret_cast<const float4*>(ebuf + col * ES + u * 32 + c * 8);
-                const float4 e1 = *reinterpret_cast<const float4*>(ebuf + col * ES + u * 32 + c * 8 + 4);
-                const float e[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
-                uint32_t wv[4];
+            for (int b = 0; b < NB; b++) {
+                if (wave + 4 * b >= (uint32_t)NDB) continue;
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    // (rows past n_rep of the numerator buffer were never written: they must not reach the MFMA as NaNs)
-                    const float pa = (col < n_rep && p0 + 2 * j < S) ? e[2 * j] * inv : 0.0f;
-                    const float pb = (col < n_rep && p0 + 2 * j + 1 < S) ? e[2 * j + 1] * inv : 0.0f;
-                    wv[j] = pack_bf16x2(pa, pb);
+                for (int u = 0; u < 2; u++) {
+                    const uint32_t p0 = p_begin + t * PB + u * 32 + c * 8;
+                    const float4 e0 = *reinterpret_cast<const float4*>(ebuf + col * ES + t * PB + u * 32 + c * 8);
+                    const float4 e1 = *reinterpret_cast<const float4*>(ebuf + col * ES + t * PB + u * 32 + c * 8 + 4);
+                    const float e[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
+                    uint32_t wv[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        // (rows past n_rep of the numerator buffer were never written: they must not reach the MFMA as NaNs)
+                        const float pa = (col < n_rep && p0 + 2 * j < S) ? e[2 * j] * inv : 0.0f;
+                        const float pb = (col < n_rep && p0 + 2 * j + 1 < S) ? e[2 * j + 1] * inv : 0.0f;
+                        wv[j] = pack_bf16x2(pa, pb);
+                    }
+                    const uint4 pa4 = make_uint4(wv[0], wv[1], wv[2], wv[3]);
+                    oacc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, pa4), __builtin_bit_cast(bf16x8_t, vb[t][b][u]), oacc[b], 0, 0, 0);
                 }
-                const uint4 pa4 = make_uint4(wv[0], wv[1], wv[2], wv[3]);
-                oacc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, pa4), __builtin_bit_cast(bf16x8_t, vb[b][u]), oacc[b], 0, 0, 0);
             }
-        }
         stamp(3);
         // ---- 5. the range's fp32 partial sums out: element r of lane (col, c) is head 4 c + r, column 16 db + col
 #pragma unroll
@@ -840,16 +860,20 @@ attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const
     stamp(5);
 }
 
-extern "C" __global__ void __launch_bounds__(256)
-mc_attn_fused_bfloat(const bf16_t* q, const bf16_t* kc, const bf16_t* vt, bf16_t* out, unsigned long long* psum_g,
-                     unsigned long long* slab_g, step_state* st, uint32_t n_rep, uint32_t n_kv, uint32_t hd, uint32_t max_seq, float scale,
-                     uint32_t nsplit, uint32_t layer_tag, unsigned long long* tl)
-{
-    if (hd == 128) attn_fused_bf<128>(q, kc, vt, out, psum_g, slab_g, st, n_rep, n_kv, max_seq, scale, nsplit, layer_tag, tl);
-    else if (hd == 64) attn_fused_bf<64>(q, kc, vt, out, psum_g, slab_g, st, n_rep, n_kv, max_seq, scale, nsplit, layer_tag, tl);
-    else if (hd == 256) attn_fused_bf<256>(q, kc, vt, out, psum_g, slab_g, st, n_rep, n_kv, max_seq, scale, nsplit, layer_tag, tl);
-    else if (hd == 32) attn_fused_bf<32>(q, kc, vt, out, psum_g, slab_g, st, n_rep, n_kv, max_seq, scale, nsplit, layer_tag, tl);
-}
+#define MC_ATTN_FUSED(NAME, T)                                                                                                           \
+    extern "C" __global__ void __launch_bounds__(256)                                                                                    \
+    NAME(const bf16_t* q, const bf16_t* kc, const bf16_t* vt, bf16_t* out, unsigned long long* psum_g, unsigned long long* slab_g,      \
+         step_state* st, uint32_t n_rep, uint32_t n_kv, uint32_t hd, uint32_t max_seq, float scale, uint32_t nsplit, uint32_t layer_tag, \
+         unsigned long long* tl)                                                                                                         \
+    {                                                                                                                                    \
+        if (hd == 128) attn_fused_bf<128, T>(q, kc, vt, out, psum_g, slab_g, st, n_rep, n_kv, max_seq, scale, nsplit, layer_tag, tl);    \
+        else if (hd == 64) attn_fused_bf<64, T>(q, kc, vt, out, psum_g, slab_g, st, n_rep, n_kv, max_seq, scale, nsplit, layer_tag, tl); \
+        else if (T == 1 && hd == 256) attn_fused_bf<256, 1>(q, kc, vt, out, psum_g, slab_g, st, n_rep, n_kv, max_seq, scale, nsplit, layer_tag, tl); \
+        else if (T == 1 && hd == 32) attn_fused_bf<32, 1>(q, kc, vt, out, psum_g, slab_g, st, n_rep, n_kv, max_seq, scale, nsplit, layer_tag, tl);   \
+    }
+MC_ATTN_FUSED(mc_attn_fused_bfloat, 1)   // 64-slot ranges
+MC_ATTN_FUSED(mc_attn_fused2_bfloat, 2)  // 128-slot ranges (head_dim 64 / 128)
+MC_ATTN_FUSED(mc_attn_fused4_bfloat, 4)  // 256-slot ranges (head_dim 64 / 128)
 
 // ------------------------------------------------------------------------------------------
 // rmsnorm of one row with optional residual:  out = T(res + rmsnorm(x))  or  rmsnorm(x)

@@ -1,0 +1,134 @@
+"""Kernel-level parity of the DECODE ATTENTION kernels -- the one-launch form `mc_attn_fused_bfloat` (scores, softmax, P.V with
+two in-launch hand-offs) and the two-launch form `mc_attn_scores_bfloat` + `mc_attn_pv_bfloat` -- launched BY NAME through the
+Part-1 seam on a given query row and cache, against the oracle's kernels composed as nn::attention::operator() composes them
+(include/metalchat/nn/attention.h:181-203): repeat_kv, bmm -> T, scalar_mul in T, softmax WITHOUT max shift -> T
+(kernel/softmax.metal:44-47), bmm -> T.  Only the order of the fp32 sums differs (the softmax denominator and the P.V
+contraction are added range by range), so the bound is the single-kernel one: every output within one bf16 step of the oracle.
+
+Cases: Llama-3-8B (4 query heads per kv head, head_dim 128), TinyLlama (8 per kv head, head_dim 64), Gemma-7B shapes (MHA,
+head_dim 256), head_dim 32; caches that are full, nearly empty (most ranges of the launch have nothing to publish), and that end
+in the middle of a 64-slot range / 16-slot tile."""
+import numpy as np
+import pytest
+
+import parity
+from oracle import mc_oracle as mo
+
+pytestmark = pytest.mark.gpu
+BF16 = 0
+PB = 64
+
+
+def oracle_attention(q, k, v, n_rep, scale):
+    """q [H, hd], k / v [n, KV, hd] (bf16 bits) -> [H, hd] bf16 bits"""
+    L = mo.layout
+    H, hd = q.shape
+    n = k.shape[0]
+    krep = np.ascontiguousarray(np.repeat(k.transpose(1, 0, 2), n_rep, axis=0))   # [H, n, hd]  (functional/transform.h:20-90)
+    vrep = np.ascontiguousarray(np.repeat(v.transpose(1, 0, 2), n_rep, axis=0))
+    s = np.zeros((H, 1, n), np.uint16)
+    mo.bmm(BF16, L(s.shape), s, L((H, 1, hd)), q.reshape(H, 1, hd), L((H, hd, n), strides=(n * hd, 1, hd)), krep)
+    s2 = np.zeros_like(s)
+    mo.scalar_mul(BF16, L((H, n)), s2, L((H, n)), s.reshape(H, n), scale)
+    p = np.zeros((H, n), np.uint16)
+    mo.softmax(BF16, L((H, n)), p, L((H, n)), s2.reshape(H, n))
+    o = np.zeros((H, 1, hd), np.uint16)
+    mo.bmm(BF16, L(o.shape), o, L((H, 1, n)), p.reshape(H, 1, n), L((H, n, hd)), vrep)
+    return o.reshape(H, hd)
+
+
+def device_caches(acc, k, v, max_seq):
+    n, KV, hd = k.shape
+    kc = np.zeros((KV, max_seq, hd), np.uint16)
+    vt = np.zeros((KV, hd, max_seq), np.uint16)
+    kc[:, :n] = k.transpose(1, 0, 2)
+    vt[:, :, :n] = v.transpose(1, 2, 0)
+    # slots past kv_len hold garbage of an earlier conversation: they must not matter
+    rng = np.random.default_rng(9)
+    kc[:, n:] = mo.encode(BF16, rng.normal(0, 30, (KV, max_seq - n, hd)).astype(np.float32))
+    vt[:, :, n:] = mo.encode(BF16, rng.normal(0, 30, (KV, hd, max_seq - n)).astype(np.float32))
+    return acc.to_device(kc.reshape(-1)), acc.to_device(vt.reshape(-1))
+
+
+def state_buffer(acc, kv_len, epoch):
+    st = np.zeros(12, np.int32)
+    st[2], st[9] = kv_len, epoch
+    return acc.to_device(st)
+
+
+CASES = [
+    # H, KV, hd, max_seq, kv_len
+    (32, 8, 128, 2048, 2048), (32, 8, 128, 2048, 2047), (32, 8, 128, 2048, 1), (32, 8, 128, 2048, 65), (32, 8, 128, 2048, 1000),
+    (32, 4, 64, 2048, 2048), (32, 4, 64, 2048, 77),
+    (16, 16, 256, 2048, 2048), (16, 16, 256, 2048, 130),
+    (8, 2, 32, 512, 500), (16, 1, 128, 1024, 1024),
+]
+# ... and the wider ranges long contexts take (tiles = 64-slot score tiles per wave): H, KV, hd, max_seq, kv_len, tiles
+WIDE = [(32, 8, 128, 8192, 8192, 4), (32, 8, 128, 8192, 8000, 4), (32, 8, 128, 8192, 300, 4), (32, 8, 128, 4096, 4095, 2),
+        (32, 4, 64, 8192, 8192, 4), (32, 4, 64, 4104, 4100, 2), (16, 2, 128, 1024, 1000, 4)]
+
+
+@pytest.mark.parametrize("H,KV,hd,max_seq,n,tiles", [c + (1,) for c in CASES] + WIDE)
+def test_one_launch_attention_matches_the_oracle(acc, H, KV, hd, max_seq, n, tiles):
+    import metalchat_amd as mc
+
+    rng = np.random.default_rng(H * 7 + hd + n)
+    n_rep, nsplit = H // KV, (max_seq + PB * tiles - 1) // (PB * tiles)
+    q = mo.encode(BF16, rng.normal(0, 1, (H, hd)).astype(np.float32))
+    k = mo.encode(BF16, rng.normal(0, 0.4, (n, KV, hd)).astype(np.float32))
+    v = mo.encode(BF16, rng.normal(0, 0.5, (n, KV, hd)).astype(np.float32))
+    scale = float(mo.from_bf16(mo.to_bf16(np.array([hd ** -0.5], np.float32)))[0])
+    ref = oracle_attention(q, k, v, n_rep, scale)
+    kc, vt = device_caches(acc, k, v, max_seq)
+    qb = acc.to_device(q.reshape(-1))
+    out = acc.alloc(H * hd * 2)
+    psum = acc.to_device(np.zeros(H * nsplit, np.uint64))
+    slab = acc.to_device(np.zeros(H * hd * nsplit, np.uint64))
+    kern = acc.load("mc_attn_fused_bfloat" if tiles == 1 else f"mc_attn_fused{tiles}_bfloat")
+    # several launches over the same granule buffers with the tags consecutive launches of a token (and consecutive tokens)
+    # carry: a granule of an earlier launch must never be taken for this one's
+    for epoch, layer_tag in ((1, 1), (1, 2), (2, 1), (7, 255)):
+        out.upload(np.zeros(H * hd, np.uint16))
+        state = state_buffer(acc, n, epoch)
+        mc.KernelTask(kern, (nsplit * KV * 256, 1, 1), (256, 1, 1),
+                      [qb, kc, vt, out, psum, slab, state, np.uint32(n_rep), np.uint32(KV), np.uint32(hd), np.uint32(max_seq),
+                       np.float32(scale), np.uint32(nsplit), np.uint32(layer_tag), None])()
+        acc.wait()
+        assert int(state.download(np.int32, 12)[10]) == 0, "a hand-off of the launch gave up"
+        got = out.download(np.uint16, H * hd)
+        parity.check(BF16, got, ref, rel=2e-3, max_ulp=1, max_frac=0.02, scale_aware=False,
+                     what=f"one-launch attention H{H} KV{KV} hd{hd} n{n} tiles {tiles} tag ({epoch}, {layer_tag})")
+
+
+@pytest.mark.parametrize("H,KV,hd,max_seq,n", CASES)
+def test_two_launch_attention_matches_the_oracle(acc, H, KV, hd, max_seq, n):
+    import metalchat_amd as mc
+
+    rng = np.random.default_rng(H * 7 + hd + n)
+    n_rep, nsplit = H // KV, (max_seq + PB - 1) // PB
+    q = mo.encode(BF16, rng.normal(0, 1, (H, hd)).astype(np.float32))
+    k = mo.encode(BF16, rng.normal(0, 0.4, (n, KV, hd)).astype(np.float32))
+    v = mo.encode(BF16, rng.normal(0, 0.5, (n, KV, hd)).astype(np.float32))
+    scale = float(mo.from_bf16(mo.to_bf16(np.array([hd ** -0.5], np.float32)))[0])
+    ref = oracle_attention(q, k, v, n_rep, scale)
+    kc, vt = device_caches(acc, k, v, max_seq)
+    qb = acc.to_device(q.reshape(-1))
+    state = state_buffer(acc, n, 1)
+    expv = acc.alloc(H * max_seq * 4)
+    psum = acc.alloc(H * nsplit * 4)
+    for ranges, block in ((1, 1024), (4, 256)):
+        out = acc.to_device(np.zeros(H * hd, np.uint16))
+        parts = acc.alloc(ranges * H * hd * 4)
+        mc.KernelTask(acc.load("mc_attn_scores_bfloat"), (nsplit * 256, KV, 1), (256, 1, 1),
+                      [qb, kc, expv, psum, None, state, np.uint32(n_rep), np.uint32(hd), np.uint32(max_seq), np.float32(scale),
+                       np.uint32(nsplit)])()
+        mc.KernelTask(acc.load("mc_attn_pv_bfloat"), (hd // 16 * block, KV, ranges), (block, 1, 1),
+                      [expv, psum, vt, out, state, np.uint32(n_rep), np.uint32(hd), np.uint32(max_seq), np.uint32(nsplit), parts,
+                       np.uint32(H)])()
+        if ranges > 1:
+            mc.KernelTask(acc.load("mc_attn_pv_reduce_bfloat"), ((H * hd + 255) // 256 * 256, 1, 1), (256, 1, 1),
+                          [parts, out, np.uint32(H * hd), np.uint32(ranges)])()
+        acc.wait()
+        got = out.download(np.uint16, H * hd)
+        parity.check(BF16, got, ref, rel=2e-3, max_ulp=1, max_frac=0.02, scale_aware=False,
+                     what=f"two-launch attention H{H} KV{KV} hd{hd} n{n} ranges {ranges}")

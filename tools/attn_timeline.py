@@ -2,7 +2,7 @@
 """Where a launch of mc_attn_fused_bfloat spends its time (tuning aid): the kernel launched by name with Llama-3-8B shapes at a
 full cache of S slots, `n` launches back to back with consecutive layer tags (as the layers of a token), per-phase
 s_memrealtime stamps of every workgroup (100 MHz), and the launch-to-launch time from the queue's events.
-usage: attn_timeline.py [S=2048] [launches=32]"""
+usage: attn_timeline.py [S=2048] [launches=32] [tiles=1]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -11,8 +11,9 @@ import metalchat_amd as mc
 
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+TILES = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 H, KV, hd = 32, 8, 128
-n_rep, nsplit = H // KV, (S + 63) // 64
+n_rep, nsplit = H // KV, (S + 64 * TILES - 1) // (64 * TILES)
 acc = mc.HardwareAccelerator()
 rng = np.random.default_rng(0)
 bf = lambda a: (np.asarray(a, np.float32).view(np.uint32) >> 16).astype(np.uint16)
@@ -24,7 +25,7 @@ slab = acc.alloc(H * hd * nsplit * 8)
 psum.upload(np.zeros(H * nsplit, np.uint64))
 slab.upload(np.zeros(H * hd * nsplit, np.uint64))
 tl = acc.alloc(N * nsplit * KV * 8 * 8)
-k = acc.load("mc_attn_fused_bfloat")
+k = acc.load("mc_attn_fused_bfloat" if TILES == 1 else f"mc_attn_fused{TILES}_bfloat")
 names = ["start->scores+exp", "hand-off A (denominators)", "P.V", "publish partials", "hand-off B + reduce"]
 for epoch in (1, 2, 3):
     st = np.zeros(12, np.int32)
