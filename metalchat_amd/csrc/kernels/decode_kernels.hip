@@ -755,7 +755,24 @@ attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const
 #pragma unroll
         for (uint32_t m = 0; m < 4; m++)
             if (m < nm && col == 0) wsum[wave][4 * m + c] = esum[m];
-        __syncthreads();
+        if constexpr (T > 1) {
+            // wide ranges: the V tiles (32 KB and more per workgroup) are REQUESTED here, behind the scores and in front of hand-off
+            // A, whose wait then covers their latency (sunk behind it, as hipcc leaves them, P.V waited 3.2 us at S = 8192).  A value
+            // used on a never-taken path cannot be sunk past the branch, and is not waited for on the path that is taken.
+            uint32_t never;
+            asm volatile("s_mov_b32 %0, 0" : "=s"(never));
+            if (never) {
+#pragma unroll
+                for (int t = 0; t < T; t++)
+#pragma unroll
+                    for (int b = 0; b < NB; b++) asm volatile("" ::"v"(vb[t][b][0].x), "v"(vb[t][b][1].w));
+            }
+            // (what crosses this barrier is in LDS: wait for the LDS counter only -- __syncthreads() would also drain the vector-
+            //  memory counter, i.e. wait for the tiles just requested)
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        } else {
+            __syncthreads();
+        }
         stamp(1);
         // ---- 3. hand-off A: this range's partial denominators out, the kv head's denominators in
         if (threadIdx.x < n_rep) {
@@ -780,7 +797,8 @@ attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const
             tsum = wave_sum(tsum);
             if (lane == 0) inv_s[head] = 1.0f / tsum;
         }
-        __syncthreads();
+        if constexpr (T > 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else __syncthreads();
         stamp(2);
         const float inv = col < n_rep ? inv_s[col] : 0.0f;
         // ---- 4. P.V over the range's slots: A = T(e * inv) from LDS (softmax.metal:84-86), B = the V tiles

@@ -3,7 +3,8 @@ two in-launch hand-offs) and the two-launch form `mc_attn_scores_bfloat` + `mc_a
 Part-1 seam on a given query row and cache, against the oracle's kernels composed as nn::attention::operator() composes them
 (include/metalchat/nn/attention.h:181-203): repeat_kv, bmm -> T, scalar_mul in T, softmax WITHOUT max shift -> T
 (kernel/softmax.metal:44-47), bmm -> T.  Only the order of the fp32 sums differs (the softmax denominator and the P.V
-contraction are added range by range), so the bound is the single-kernel one: every output within one bf16 step of the oracle.
+contraction are added range by range), so the bound is the single-kernel one: every output within one bf16 step of the oracle
+-- one step at the row's scale for outputs that are small through cancellation (a 1000-term sum of products of either sign).
 
 Cases: Llama-3-8B (4 query heads per kv head, head_dim 128), TinyLlama (8 per kv head, head_dim 64), Gemma-7B shapes (MHA,
 head_dim 256), head_dim 32; caches that are full, nearly empty (most ranges of the launch have nothing to publish), and that end
@@ -96,7 +97,7 @@ def test_one_launch_attention_matches_the_oracle(acc, H, KV, hd, max_seq, n, til
         acc.wait()
         assert int(state.download(np.int32, 12)[10]) == 0, "a hand-off of the launch gave up"
         got = out.download(np.uint16, H * hd)
-        parity.check(BF16, got, ref, rel=2e-3, max_ulp=1, max_frac=0.02, scale_aware=False,
+        parity.check(BF16, got, ref, rel=2e-3, max_ulp=1, max_frac=0.03, scale_aware=True,
                      what=f"one-launch attention H{H} KV{KV} hd{hd} n{n} tiles {tiles} tag ({epoch}, {layer_tag})")
 
 
@@ -130,5 +131,5 @@ def test_two_launch_attention_matches_the_oracle(acc, H, KV, hd, max_seq, n):
                           [parts, out, np.uint32(H * hd), np.uint32(ranges)])()
         acc.wait()
         got = out.download(np.uint16, H * hd)
-        parity.check(BF16, got, ref, rel=2e-3, max_ulp=1, max_frac=0.02, scale_aware=False,
+        parity.check(BF16, got, ref, rel=2e-3, max_ulp=1, max_frac=0.03, scale_aware=True,
                      what=f"two-launch attention H{H} KV{KV} hd{hd} n{n} ranges {ranges}")
