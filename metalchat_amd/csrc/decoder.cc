@@ -189,7 +189,7 @@ struct mc_decoder {
     bool attn_fused_on = true;   // MC_ATTN_FUSED=0: scores and P.V as two launches (A/B, parity)
     // ... while the launch is at most this many 256-thread workgroups per CU (MC_ATTN_FUSED_WGS).  Measured: at S = 8192 with
     // 64-slot ranges (128 ranges x 8 kv heads = 4 per CU, every hand-off gathering from 128 producers) the one launch took 27.8 us
-    // against 6.3 + 8.5 for the two -- long contexts take 128- or 256-slot ranges (attn_fused_tiles)
+    // against 6.3 + 8.5 for the two -- long contexts keep the two-launch form (wider ranges were built and measured no better)
     unsigned attn_fused_max_wgs_per_cu = 2;
     void* taps = nullptr;       // T[(n_own+1)*dim]
     step_state_h* state = nullptr;
@@ -526,21 +526,13 @@ struct mc_decoder {
 
     // scores + softmax + P.V in one launch: bfloat rows, layer tags of one byte, and a grid that is certainly co-resident (its
     // workgroups wait for one another) and gathers from few producers: at most attn_fused_max_wgs_per_cu 256-thread workgroups
-    // per CU.  A workgroup owns 64 * tiles cache slots: the smallest of 1, 2, 4 tiles per wave that keeps the launch that small
-    // (head_dim 256 / 32: one tile only); 0 = the two-launch form.
-    int
-    attn_fused_tiles() const
+    // of 64 cache slots per CU
+    bool
+    attn_fused() const
     {
-        if (!attn_fused_on || !attn_psum_g || tb != 2 || n_own > 254) return 0;
-        const unsigned cap = attn_fused_max_wgs_per_cu * (unsigned)dev->prop.multiProcessorCount;
-        for (int t : {1, 2, 4}) {
-            if (t > 1 && cfg.head_dim != 64 && cfg.head_dim != 128) break;
-            const unsigned ns = (unsigned)(cfg.max_seq_len + PB * t - 1) / (unsigned)(PB * t);
-            if (ns * (unsigned)cfg.n_kv_heads <= cap) return t;
-        }
-        return 0;
+        return attn_fused_on && attn_psum_g && tb == 2 && n_own <= 254 &&
+               (unsigned)(nsplit * cfg.n_kv_heads) <= attn_fused_max_wgs_per_cu * (unsigned)dev->prop.multiProcessorCount;
     }
-    bool attn_fused() const { return attn_fused_tiles() != 0; }
 
     // a hand-off inside a launch that gave up (bounded waits, decode_kernels.hip): reported once, then cleared
     mc_status
@@ -737,11 +729,9 @@ struct mc_decoder {
             }
             if (attn_fused()) {
                 // scores, softmax, P.V                 (attention.h:191-203) in ONE launch, then Wo from the finished row
-                const int tiles = attn_fused_tiles();
-                const unsigned fsplit = (unsigned)(cfg.max_seq_len + PB * tiles - 1) / (unsigned)(PB * tiles);
-                s = launch(std::string("mc_attn_fused") + (tiles == 1 ? "" : std::to_string(tiles)) + "_" + tname, fsplit * (unsigned)KV, 1, 1, 256, 0,
+                s = launch("mc_attn_fused_" + tname, (unsigned)(nsplit * KV), 1, 1, 256, 0,
                            pack(q_rot, L.kc, L.vt, attn_out, attn_psum_g, attn_slab_g, state, (uint32_t)n_rep, (uint32_t)KV, (uint32_t)hd,
-                                (uint32_t)cfg.max_seq_len, scale_T, (uint32_t)fsplit, (uint32_t)(li + 1), (void*)nullptr));
+                                (uint32_t)cfg.max_seq_len, scale_T, (uint32_t)nsplit, (uint32_t)(li + 1), (void*)nullptr));
                 if (s != MC_OK) return s;
                 s = gemma ? gemv(L.wo, 0, 0, attn_out, proj, nullptr, nullptr, mu) : gemv(L.wo, 0, 1, attn_out, hidden, x, nullptr, mu);
                 if (s != MC_OK) return s;

@@ -648,10 +648,9 @@ struct handoff_wait {
     }
 };
 
-// T = 64-slot score tiles per wave: a workgroup owns 64 T cache slots.  T = 1 for contexts up to 4096 slots; longer contexts take
-// wider ranges so that the launch stays within two workgroups per CU (every hand-off gathers from ONE producer per range: at
-// S = 8192 with 64-slot ranges -- 1024 workgroups, 128 producers per gather -- the launch measured 27.8 us against 6.3 + 8.5 for
-// the two-launch form).
+// T = 64-slot score tiles per wave: a workgroup owns 64 T cache slots.  The product instantiates T = 1 only (see the note at the
+// instantiation); the host takes this path while the launch is at most two workgroups per CU (with 64-slot ranges at S = 8192
+// -- 1024 workgroups, 128 producers per gather -- the launch measured 27.8 us against 6.3 + 8.5 for the two-launch form).
 template <int HD, int T>
 __device__ __forceinline__ void
 attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const bf16_t* __restrict__ vt, bf16_t* __restrict__ out,
@@ -890,8 +889,10 @@ attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const
         else if (T == 1 && hd == 32) attn_fused_bf<32, 1>(q, kc, vt, out, psum_g, slab_g, st, n_rep, n_kv, max_seq, scale, nsplit, layer_tag, tl);   \
     }
 MC_ATTN_FUSED(mc_attn_fused_bfloat, 1)   // 64-slot ranges
-MC_ATTN_FUSED(mc_attn_fused2_bfloat, 2)  // 128-slot ranges (head_dim 64 / 128)
-MC_ATTN_FUSED(mc_attn_fused4_bfloat, 4)  // 256-slot ranges (head_dim 64 / 128)
+// (128- and 256-slot ranges -- T = 2, 4: MC_ATTN_FUSED(mc_attn_fused2_bfloat, 2) ... -- were built for S = 8192, passed the kernel-level
+//  oracle test and measured no better than the two-launch form there: 14.8 us per launch with 256-slot ranges (K tile + scores
+//  5.9, hand-off A 2.2, P.V 3.2, hand-off B 1.6), 19.6 with 128-slot ranges at two workgroups per CU, against 6.3 + 8.5 us;
+//  int8 Llama-3-8B at S = 8192: 450-473 tokens/s with either against 451-469.  Not instantiated: long contexts keep two launches.)
 
 // ------------------------------------------------------------------------------------------
 // rmsnorm of one row with optional residual:  out = T(res + rmsnorm(x))  or  rmsnorm(x)

@@ -147,7 +147,7 @@ def test_llama3_8b_int8_at_8192_with_automatic_context_ranges(acc, monkeypatch):
     agree = run_injected(acc, cfg, weights, 8185, 15, dict(weight_format=mc.WFMT_I8, group_size=128),
                          rel_logits=5e-3, max_ulp=2, max_frac=0.7, what="8B int8 S=8192", launched=names)
     assert agree >= 13
-    assert {"mc_gemv_i8_bfloat_ling4_p1_e4", "mc_attn_fused2_bfloat", "mc_gemv_i8_bfloat_ling4_p0_e1", "mc_gemv_i8_bfloat_ling4_p1_e2", "mc_gemv_i8_bfloat_ling14_p0_e1",
+    assert {"mc_gemv_i8_bfloat_ling4_p1_e4", "mc_attn_pv_bfloat", "mc_gemv_i8_bfloat_ling4_p3_e1", "mc_gemv_i8_bfloat_ling4_p1_e2", "mc_gemv_i8_bfloat_ling14_p0_e1",
             "mc_gemv_i8_bfloat_ling4_p1_e5"} <= names, sorted(names)
 
 
@@ -341,6 +341,7 @@ def test_one_launch_attention_against_the_two_launch_form(acc, monkeypatch, shap
         fmt = dict(weight_format=mc.WFMT_I4, group_size=128)
     S = cfg["max_seq_len"]
     out = {}
+    monkeypatch.setenv("MC_ATTN_FUSED_WGS", "4")  # (S = 8192 is four workgroups per CU: by default the two-launch form)
     for fused in ("1", "0"):
         monkeypatch.setenv("MC_ATTN_FUSED", fused)
         dec = mc.Decoder(acc, **mg.decoder_kwargs(cfg, **fmt))
@@ -357,8 +358,7 @@ def test_one_launch_attention_against_the_two_launch_form(acc, monkeypatch, shap
                 tok = dec.step(tok, n_inject + i)
                 rows.append((tok, dec.logits().copy(), np.stack([dec.hidden(l) for l in range(-1, cfg["n_layers"])])))
         names = set(dec.launched())
-        fused_name = "mc_attn_fused2_bfloat" if S == 8192 else "mc_attn_fused_bfloat"  # (8192 slots: 128-slot ranges, two workgroups per CU)
-        assert (fused_name in names) == (fused == "1"), sorted(names)
+        assert ("mc_attn_fused_bfloat" in names) == (fused == "1"), sorted(names)
         assert ("mc_attn_pv_bfloat" in names) == (fused == "0"), sorted(names)
         out[fused] = rows
         dec.release()

@@ -56,8 +56,7 @@ def test_decode_and_reference_kernels_present(symbols):
                   "mc_rmsnorm_row", "mc_topk_candidates", "mc_sample"):
             assert f"{k}_{t}" in symbols, f"{k}_{t}"
     for k in ("mc_step_set", "mc_step_advance", "mc_step_rope", "mc_rope_table", "mc_argmax_keys",
-              # decode attention in one launch: 64-, 128-, 256-slot ranges (decoder.cc attn_fused_tiles)
-              "mc_attn_fused_bfloat", "mc_attn_fused2_bfloat", "mc_attn_fused4_bfloat"):
+              "mc_attn_fused_bfloat"):  # decode attention in one launch
         assert k in symbols, k
     # the reference's own kernel names (ABI part 1, kernel/kernel.h:30-90)
     for k in ("rmsnorm_bfloat", "softmax_bfloat", "bmm_8_float", "hadamard_broadcast_bfloat_int8_t_float"):

@@ -25,7 +25,7 @@ slab = acc.alloc(H * hd * nsplit * 8)
 psum.upload(np.zeros(H * nsplit, np.uint64))
 slab.upload(np.zeros(H * hd * nsplit, np.uint64))
 tl = acc.alloc(N * nsplit * KV * 8 * 8)
-k = acc.load("mc_attn_fused_bfloat" if TILES == 1 else f"mc_attn_fused{TILES}_bfloat")
+k = acc.load("mc_attn_fused_bfloat" if TILES == 1 else f"mc_attn_fused{TILES}_bfloat")  # (T > 1: tuning builds only)
 names = ["start->scores+exp", "hand-off A (denominators)", "P.V", "publish partials", "hand-off B + reduce"]
 for epoch in (1, 2, 3):
     st = np.zeros(12, np.int32)
