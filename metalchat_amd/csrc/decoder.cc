@@ -186,6 +186,8 @@ struct mc_decoder {
     // decode attention in one launch (mc_attn_fused_bfloat): {value, tag} granules of its two in-launch hand-offs
     unsigned long long* attn_psum_g = nullptr; // [H][nsplit]            partial softmax denominators
     unsigned long long* attn_slab_g = nullptr; // [KV][nsplit][n_rep][hd] fp32 partial P.V sums
+    unsigned long long* attn_row_g = nullptr;  // [H * hd / 2]          the finished attention row, two bf16 per granule (mc_attn_wo_*)
+    bool attn_wo_on = true;      // MC_ATTN_WO=0: the Wo GEMV as a launch of its own behind the one-launch attention (A/B, parity)
     bool attn_fused_on = true;   // MC_ATTN_FUSED=0: scores and P.V as two launches (A/B, parity)
     // ... while the launch is at most this many 256-thread workgroups per CU (MC_ATTN_FUSED_WGS).  Measured: at S = 8192 with
     // 64-slot ranges (128 ranges x 8 kv heads = 4 per CU, every hand-off gathering from 128 producers) the one launch took 27.8 us
@@ -534,6 +536,20 @@ struct mc_decoder {
                (unsigned)(nsplit * cfg.n_kv_heads) <= attn_fused_max_wgs_per_cu * (unsigned)dev->prop.multiProcessorCount;
     }
 
+    // ... with the Wo GEMV and its residual in the same launch (attn_block_kernels.hip): int4 weights on bfloat rows with scale
+    // groups of whole lane blocks, K = H * hd of 1, 2 or 4 KiB per row in one of the built (head_dim, K) pairs, no adaptor, at
+    // most two row pairs per wave of the launch
+    bool
+    attn_wo_fused(const linear_w& wo) const
+    {
+        if (!attn_wo_on || !attn_fused() || !lin_ok(wo) || wo.lora_cols || wo.out % 2 != 0) return false;
+        const int hd = cfg.head_dim, k = wo.in / 2048;
+        const bool built = (hd == 128 && (k == 2 || k == 4)) || (hd == 64 && k == 1) || (hd == 256 && k == 2);
+        // (one 512-thread workgroup per CU: the kernels hold up to 132 VGPRs, two such workgroups would not be resident together)
+        return built && wo.in == cfg.n_heads * hd && (unsigned)wo.out / 2 <= 2u * 8u * (unsigned)(nsplit * cfg.n_kv_heads) &&
+               (unsigned)(nsplit * cfg.n_kv_heads) <= (unsigned)dev->prop.multiProcessorCount;
+    }
+
     // a hand-off inside a launch that gave up (bounded waits, decode_kernels.hip): reported once, then cleared
     mc_status
     check_handoffs(const step_state_h& st)
@@ -727,7 +743,21 @@ struct mc_decoder {
                                 (uint32_t)cfg.max_seq_len, cfg.norm_eps, mu));
                 if (s != MC_OK) return s;
             }
-            if (attn_fused()) {
+            if (attn_wo_fused(L.wo)) {
+                // scores, softmax, P.V, wo + residual  (attention.h:191-205, transformer.h:132-133) in ONE launch
+                s = launch("mc_attn_wo_i4_" + tname + "_hd" + std::to_string(hd) + "_k" + std::to_string(L.wo.in / 2048),
+                           (unsigned)(nsplit * KV), 1, 1, 512, 0,
+                           pack(q_rot, L.kc, L.vt, attn_out, attn_psum_g, attn_slab_g, attn_row_g, state, (uint32_t)n_rep, (uint32_t)KV,
+                                (uint32_t)cfg.max_seq_len, scale_T, (uint32_t)nsplit, (uint32_t)(li + 1), (const void*)L.wo.w,
+                                (const void*)L.wo.scales, gemma ? (const void*)nullptr : x, gemma ? proj : hidden, (uint32_t)L.wo.out,
+                                (uint32_t)L.wo.group, (uint32_t)(gemma ? 0 : 1)));
+                if (s != MC_OK) return s;
+                if (gemma && !fuse_pn) {
+                    s = launch("mc_rmsnorm_row_" + tname, 1, 1, 1, 1024, 0,
+                               pack(proj, L.attention_post_norm, x, hidden, (uint32_t)dim, cfg.norm_eps, mu));
+                    if (s != MC_OK) return s;
+                }
+            } else if (attn_fused()) {
                 // scores, softmax, P.V                 (attention.h:191-203) in ONE launch, then Wo from the finished row
                 s = launch("mc_attn_fused_" + tname, (unsigned)(nsplit * KV), 1, 1, 256, 0,
                            pack(q_rot, L.kc, L.vt, attn_out, attn_psum_g, attn_slab_g, state, (uint32_t)n_rep, (uint32_t)KV, (uint32_t)hd,
@@ -1163,6 +1193,7 @@ mc_decoder_create(mc_device* dev, mc_library* lib, mc_queue* q, const mc_decoder
     if (const char* e = getenv("MC_GEMV_LIN")) d->gemv_lin = atoi(e) != 0;
     if (const char* e = getenv("MC_PV_FOLD")) d->pv_fold_on = atoi(e) != 0;
     if (const char* e = getenv("MC_ATTN_FUSED")) d->attn_fused_on = atoi(e) != 0;
+    if (const char* e = getenv("MC_ATTN_WO")) d->attn_wo_on = atoi(e) != 0;
     if (const char* e = getenv("MC_ATTN_FUSED_WGS")) d->attn_fused_max_wgs_per_cu = (unsigned)std::max(1, std::min(4, atoi(e)));
     if (const char* e = getenv("MC_LING_HALF")) d->ling_half = atoi(e) != 0;
     if (const char* e = getenv("MC_LIN_SPLIT")) d->lin_split = atoi(e) != 0;
@@ -1204,6 +1235,7 @@ mc_decoder_create(mc_device* dev, mc_library* lib, mc_queue* q, const mc_decoder
     if (d->tb == 2) {
         A(d->attn_psum_g, (size_t)H * d->nsplit * 8);
         A(d->attn_slab_g, (size_t)H * hd * d->nsplit * 8);
+        A(d->attn_row_g, (size_t)H * hd / 2 * 8);
     }
     A(d->taps, (size_t)(d->n_own + 1) * dim * tb);
     A(d->state, sizeof(step_state_h));

@@ -651,11 +651,15 @@ struct handoff_wait {
 // T = 64-slot score tiles per wave: a workgroup owns 64 T cache slots.  The product instantiates T = 1 only (see the note at the
 // instantiation); the host takes this path while the launch is at most two workgroups per CU (with 64-slot ranges at S = 8192
 // -- 1024 workgroups, 128 producers per gather -- the launch measured 27.8 us against 6.3 + 8.5 for the two-launch form).
-template <int HD, int T>
+// NW = waves of the workgroup (4: mc_attn_fused_bfloat; 8: the attention inside mc_attn_wo_*, attn_block_kernels.hip -- the scores
+// stay on waves 0-3, one 16-slot tile each; the column blocks of P.V and the chunks of the reduce are dealt over all NW waves,
+// which changes who adds, not what is added).  on_chunk(head, db, col, v): called by the 16 lanes that hold the finished sums of
+// chunk (head, 16-column block db), v = the fp32 sum of column 16 db + col over all ranges, in range order.
+template <int HD, int T, int NW, typename OnChunk>
 __device__ __forceinline__ void
-attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const bf16_t* __restrict__ vt, bf16_t* __restrict__ out,
+attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const bf16_t* __restrict__ vt,
               unsigned long long* psum_g, unsigned long long* slab_g, step_state* st, uint32_t n_rep, uint32_t KV, uint32_t max_seq,
-              float scale, uint32_t nsplit, uint32_t layer_tag, unsigned long long* tl)
+              float scale, uint32_t nsplit, uint32_t layer_tag, unsigned long long* tl, OnChunk&& on_chunk)
 {
     // tl != null (tools/attn_timeline.py only): thread 0 of every workgroup leaves s_memrealtime stamps of its phases
     auto stamp = [&](int i) {
@@ -664,7 +668,7 @@ attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const
     stamp(0);
     constexpr int KS = HD / 32;                 // MFMA k-steps of q.k
     constexpr int NDB = HD / 16;                // 16-column blocks of the output
-    constexpr int NB = NDB >= 4 ? NDB / 4 : 1;  // ... per wave
+    constexpr int NB = NDB >= NW ? NDB / NW : 1; // ... per wave
     constexpr uint32_t PBW = PB * T;            // cache slots per workgroup
     constexpr int ES = PBW + 4;                 // numerator row stride in LDS (floats): 16 rows read 32 bytes apart in the banks
     __shared__ float wsum[4][16];
@@ -678,12 +682,15 @@ attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const
     // ---- 1. the K tiles and the queries: requested before anything is waited for -- the step state included (a range past
     // kv_len reads slots nobody uses: their products are masked below)
     uint4 kb[T][KS];
+    const bool scorer = NW == 4 || wave < 4; // (waves 4 .. NW - 1 compute no scores: no K tile, no queries)
+    if (scorer) {
 #pragma unroll
-    for (int t = 0; t < T; t++) {
-        const uint32_t pos = p_begin + t * PB + wave * 16 + col;
-        const bf16_t* kbase = kc + ((size_t)kv * max_seq + (pos < max_seq ? pos : max_seq - 1)) * HD;
+        for (int t = 0; t < T; t++) {
+            const uint32_t pos = p_begin + t * PB + wave * 16 + col;
+            const bf16_t* kbase = kc + ((size_t)kv * max_seq + (pos < max_seq ? pos : max_seq - 1)) * HD;
 #pragma unroll
-        for (int ks = 0; ks < KS; ks++) kb[t][ks] = *reinterpret_cast<const uint4*>(kbase + ks * 32 + c * 8);
+            for (int ks = 0; ks < KS; ks++) kb[t][ks] = *reinterpret_cast<const uint4*>(kbase + ks * 32 + c * 8);
+        }
     }
     // (the V tile's requests are written here too; hipcc sinks them to their first use behind hand-off A.  Pinning them in front
     //  of the scores measured SLOWER in the token -- scores done 2.3 us after the start instead of 1.8, 689 vs 710 tokens/s against
@@ -693,7 +700,7 @@ attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const
     for (int t = 0; t < T; t++)
 #pragma unroll
         for (int b = 0; b < NB; b++) {
-            const uint32_t db = wave + 4 * b;
+            const uint32_t db = wave + NW * b;
             const bf16_t* vrow = vt + ((size_t)kv * HD + (db < (uint32_t)NDB ? db : 0u) * 16 + col) * max_seq;
 #pragma unroll
             for (int u = 0; u < 2; u++) {
@@ -702,9 +709,9 @@ attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const
             }
         }
     uint4 qa[KS];
-    {
+    if (scorer) {
         // (rows past n_rep of the A operand: the row of the last query head again -- their results are never read; an
-        //  unconditional load keeps the compiler's counted waits, a load behind a branch costs every one of them)
+        //  unconditional load keeps the compiler's counted waits, a load behind a lane-dependent branch costs every one of them)
         const uint32_t qh = col < n_rep ? col : n_rep - 1;
 #pragma unroll
         for (int ks = 0; ks < KS; ks++) qa[ks] = *reinterpret_cast<const uint4*>(q + (size_t)(kv * n_rep + qh) * HD + ks * 32 + c * 8);
@@ -722,6 +729,7 @@ attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const
         // order, the four waves' sums as that kernel adds them)
         const uint32_t nm = (n_rep + 3) / 4;
         float esum[4] = {0.f, 0.f, 0.f, 0.f}; // per m: this lane group's running sum over the wave's tiles
+        if (scorer) {
 #pragma unroll
         for (int t = 0; t < T; t++) {
             const uint32_t pos = p_begin + t * PB + wave * 16 + col;
@@ -754,6 +762,7 @@ attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const
 #pragma unroll
         for (uint32_t m = 0; m < 4; m++)
             if (m < nm && col == 0) wsum[wave][4 * m + c] = esum[m];
+        }
         if constexpr (T > 1) {
             // wide ranges: the V tiles (32 KB and more per workgroup) are REQUESTED here, behind the scores and in front of hand-off
             // A, whose wait then covers their latency (sunk behind it, as hipcc leaves them, P.V waited 3.2 us at S = 8192).  A value
@@ -778,7 +787,7 @@ attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const
             const float tot = (wsum[0][threadIdx.x] + wsum[1][threadIdx.x]) + (wsum[2][threadIdx.x] + wsum[3][threadIdx.x]);
             granule_store(psum_g + (size_t)(kv * n_rep + threadIdx.x) * nsplit + split, tag, __float_as_uint(tot));
         }
-        for (uint32_t head = wave; head < n_rep; head += 4) {
+        for (uint32_t head = wave; head < n_rep; head += NW) {
             // (softmax_inv's order: lane-strided partial sums, then the shuffle tree)
             const unsigned long long* row = psum_g + (size_t)(kv * n_rep + head) * nsplit;
             float tsum = 0.0f;
@@ -805,7 +814,7 @@ attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const
         for (int t = 0; t < T; t++)
 #pragma unroll
             for (int b = 0; b < NB; b++) {
-                if (wave + 4 * b >= (uint32_t)NDB) continue;
+                if (wave + NW * b >= (uint32_t)NDB) continue;
 #pragma unroll
                 for (int u = 0; u < 2; u++) {
                     const uint32_t p0 = p_begin + t * PB + u * 32 + c * 8;
@@ -828,7 +837,7 @@ attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const
         // ---- 5. the range's fp32 partial sums out: element r of lane (col, c) is head 4 c + r, column 16 db + col
 #pragma unroll
         for (int b = 0; b < NB; b++) {
-            const uint32_t db = wave + 4 * b;
+            const uint32_t db = wave + NW * b;
             if (db >= (uint32_t)NDB) continue;
 #pragma unroll
             for (int r = 0; r < 4; r++) {
@@ -843,7 +852,7 @@ attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const
     // jj + 4, ..., adds them in that order, the four lane groups are added in order too, one rounding to T
     stamp(4);
     const uint32_t nq = n_rep * (uint32_t)NDB;
-    for (uint32_t qi = split + wave * nsplit; qi < nq; qi += 4 * nsplit) {
+    for (uint32_t qi = split + wave * nsplit; qi < nq; qi += NW * nsplit) {
         const uint32_t head = qi / (uint32_t)NDB, db = qi % (uint32_t)NDB;
         const unsigned long long* base = slab_g + ((size_t)kv * nsplit * n_rep + head) * HD + db * 16 + col;
         const size_t jstride = (size_t)n_rep * HD;
@@ -872,7 +881,7 @@ attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const
         }
         v += __shfl_xor(v, 16, 64);
         v += __shfl_xor(v, 32, 64);
-        if (lane < 16) out[(size_t)(kv * n_rep + head) * HD + db * 16 + col] = f2bf(v);
+        on_chunk(kv * n_rep + head, db, col, v); // (every lane holds the sum of its column; lanes 16 .. 63 repeat lanes 0 .. 15)
     }
     stamp(5);
 }
@@ -883,10 +892,14 @@ attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const
          step_state* st, uint32_t n_rep, uint32_t n_kv, uint32_t hd, uint32_t max_seq, float scale, uint32_t nsplit, uint32_t layer_tag, \
          unsigned long long* tl)                                                                                                         \
     {                                                                                                                                    \
-        if (hd == 128) attn_fused_bf<128, T>(q, kc, vt, out, psum_g, slab_g, st, n_rep, n_kv, max_seq, scale, nsplit, layer_tag, tl);    \
-        else if (hd == 64) attn_fused_bf<64, T>(q, kc, vt, out, psum_g, slab_g, st, n_rep, n_kv, max_seq, scale, nsplit, layer_tag, tl); \
-        else if (T == 1 && hd == 256) attn_fused_bf<256, 1>(q, kc, vt, out, psum_g, slab_g, st, n_rep, n_kv, max_seq, scale, nsplit, layer_tag, tl); \
-        else if (T == 1 && hd == 32) attn_fused_bf<32, 1>(q, kc, vt, out, psum_g, slab_g, st, n_rep, n_kv, max_seq, scale, nsplit, layer_tag, tl);   \
+        /* one rounding of the fp32 sum (bmm.metal:80): the attention row the Wo GEMV reads */                                           \
+        auto store = [&](uint32_t head, uint32_t db, uint32_t col, float v) {                                                            \
+            if ((threadIdx.x & 63) < 16) out[(size_t)head * hd + db * 16 + col] = f2bf(v);                                               \
+        };                                                                                                                               \
+        if (hd == 128) attn_fused_bf<128, T, 4>(q, kc, vt, psum_g, slab_g, st, n_rep, n_kv, max_seq, scale, nsplit, layer_tag, tl, store);    \
+        else if (hd == 64) attn_fused_bf<64, T, 4>(q, kc, vt, psum_g, slab_g, st, n_rep, n_kv, max_seq, scale, nsplit, layer_tag, tl, store); \
+        else if (T == 1 && hd == 256) attn_fused_bf<256, 1, 4>(q, kc, vt, psum_g, slab_g, st, n_rep, n_kv, max_seq, scale, nsplit, layer_tag, tl, store); \
+        else if (T == 1 && hd == 32) attn_fused_bf<32, 1, 4>(q, kc, vt, psum_g, slab_g, st, n_rep, n_kv, max_seq, scale, nsplit, layer_tag, tl, store);   \
     }
 MC_ATTN_FUSED(mc_attn_fused_bfloat, 1)   // 64-slot ranges
 // (128- and 256-slot ranges -- T = 2, 4: MC_ATTN_FUSED(mc_attn_fused2_bfloat, 2) ... -- were built for S = 8192, passed the kernel-level

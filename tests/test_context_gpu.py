@@ -129,9 +129,10 @@ def test_llama3_8b_int4_at_the_benchmark_context(acc, dtype):
                          rel_logits=5e-3, max_ulp=2, max_frac=0.7, what=f"8B int4 S=2048 dt{dtype}", launched=names)
     assert agree >= 14
     if dtype == BF16:  # the kernels bench.py's headline runs (and its roofline names): not a fallback family
-        assert {"mc_gemv_i4_bfloat_lin2_p1_e4", "mc_attn_fused_bfloat", "mc_gemv_i4_bfloat_lin2_p0_e1", "mc_gemv_i4_bfloat_lin2_p1_e2",
+        assert {"mc_gemv_i4_bfloat_lin2_p1_e4", "mc_attn_wo_i4_bfloat_hd128_k2", "mc_gemv_i4_bfloat_lin2_p1_e2",
                 "mc_gemv_i4_bfloat_lin7_p0_e1", "mc_gemv_i4_bfloat_lin2_p1_e5", "mc_argmax_keys"} <= names, sorted(names)
         assert not [n for n in names if n.startswith("mc_gemv") and "_lin" not in n], sorted(names)
+        assert "mc_attn_fused_bfloat" not in names and "mc_attn_pv_bfloat" not in names
     else:
         assert "mc_gemv_i4_float_p1_e2" in names, sorted(names)
 
@@ -232,7 +233,7 @@ def test_llama3_70b_widths_one_block(acc):
     agree = run_injected(acc, cfg, weights, 2042, 10, dict(weight_format=mc.WFMT_I4, group_size=128), rel_logits=5e-3,
                          max_ulp=2, max_frac=0.7, what="70B widths S=2048", launched=names)
     assert agree >= 9
-    assert {"mc_gemv_i4_bfloat_lin4_p1_e4", "mc_attn_fused_bfloat", "mc_gemv_i4_bfloat_lin4_p0_e1", "mc_gemv_i4_bfloat_lin4_p1_e2", "mc_gemv_i4_bfloat_lin14_p0_e1",
+    assert {"mc_gemv_i4_bfloat_lin4_p1_e4", "mc_attn_wo_i4_bfloat_hd128_k4", "mc_gemv_i4_bfloat_lin4_p1_e2", "mc_gemv_i4_bfloat_lin14_p0_e1",
             "mc_gemv_i4_bfloat_lin4_p1_e5"} <= names, sorted(names)
 
 
@@ -342,6 +343,7 @@ def test_one_launch_attention_against_the_two_launch_form(acc, monkeypatch, shap
     S = cfg["max_seq_len"]
     out = {}
     monkeypatch.setenv("MC_ATTN_FUSED_WGS", "4")  # (S = 8192 is four workgroups per CU: by default the two-launch form)
+    monkeypatch.setenv("MC_ATTN_WO", "0")          # (the attention forms by themselves: the Wo GEMV as a launch of its own)
     for fused in ("1", "0"):
         monkeypatch.setenv("MC_ATTN_FUSED", fused)
         dec = mc.Decoder(acc, **mg.decoder_kwargs(cfg, **fmt))
@@ -378,3 +380,57 @@ def test_one_launch_attention_against_the_two_launch_form(acc, monkeypatch, shap
             assert nrm(ha[layer], hb[layer]) <= 6e-3 * layer, f"{shape} step {i} hidden[{layer - 1}], one launch vs two: {nrm(ha[layer], hb[layer]):.3g}"
         assert nrm(la, lb) <= 6e-3 * (ha.shape[0] + 1), f"{shape} step {i} logits, one launch vs two: {nrm(la, lb):.3g}"
     assert same >= len(out["1"]) - 2, (shape, same)
+
+
+@pytest.mark.parametrize("shape", ["llama3-8b", "llama3-70b", "hd64", "gemma-hd256"])
+def test_attention_and_wo_in_one_launch_equal_the_two_launches_bit_for_bit(acc, monkeypatch, shape):
+    # mc_attn_wo_i4_bfloat_* = mc_attn_fused_bfloat + the Wo GEMV (attn_block_kernels.hip): the same attention phases, the same row,
+    # the same per-row arithmetic -- hidden rows, logits, caches and tokens must be IDENTICAL to the two launches, near an empty
+    # cache and across the end of a full one; the launch log shows which form ran.
+    import metalchat_amd as mc
+
+    base = dict(dtype=BF16, n_layers=2, vocab=2048, norm_eps=1e-5)
+    if shape == "llama3-8b":
+        cfg = dict(base, max_seq_len=2048, **FULL_WIDTH["llama3-8b"])
+        kernel = "mc_attn_wo_i4_bfloat_hd128_k2"
+    elif shape == "llama3-70b":
+        cfg = dict(base, max_seq_len=2048, family=0, dim=8192, n_heads=64, n_kv_heads=8, head_dim=128, ffn_dim=4096, rope_theta=500000.0,
+                   attn_scale=128 ** -0.5)   # (a narrow ffn: the test is about the attention block)
+        kernel = "mc_attn_wo_i4_bfloat_hd128_k4"
+    elif shape == "hd64":
+        cfg = dict(base, max_seq_len=2048, family=0, dim=2048, n_heads=32, n_kv_heads=8, head_dim=64, ffn_dim=4096, rope_theta=10000.0,
+                   attn_scale=64 ** -0.5)
+        kernel = "mc_attn_wo_i4_bfloat_hd64_k1"
+    else:  # gemma3 block, head_dim 256, Wo stored without a residual (its post-norm adds it); 1024 slots: one workgroup per CU
+        cfg = dict(base, max_seq_len=1024, dim=3072, n_heads=16, n_kv_heads=16, head_dim=256, ffn_dim=4096, family=1, rope_theta=10000.0,
+                   rope_sliding_theta=10000.0, sliding_stride=2, attn_scale=256 ** -0.5)
+        kernel = "mc_attn_wo_i4_bfloat_hd256_k2"
+    S = cfg["max_seq_len"]
+    out = {}
+    for one in ("1", "0"):
+        monkeypatch.setenv("MC_ATTN_WO", one)
+        dec = mc.Decoder(acc, **mg.decoder_kwargs(cfg, weight_format=mc.WFMT_I4, group_size=128))
+        dec.init_synthetic(SEED)
+        dec.set_taps(True)
+        dec.launch_log(True)
+        rows = []
+        for n_inject in (2, S - 4):
+            for layer in range(cfg["n_layers"]):
+                k, v = random_cache(cfg, n_inject, 700 + layer)
+                dec.import_kv(layer, k, v)
+            tok = 5
+            for i in range(8):
+                tok = dec.step(tok, n_inject + i)
+                rows.append((tok, dec.logits().copy(), np.stack([dec.hidden(l) for l in range(-1, cfg["n_layers"])])))
+        kk, vv = dec.export_kv(cfg["n_layers"] - 1)
+        names = set(dec.launched())
+        assert (kernel in names) == (one == "1"), sorted(names)
+        assert ("mc_attn_fused_bfloat" in names) == (one == "0"), sorted(names)
+        out[one] = (rows, kk, vv)
+        dec.release()
+    for i, ((ta, la, ha), (tb_, lb, hb)) in enumerate(zip(out["1"][0], out["0"][0])):
+        assert ta == tb_, (shape, i)
+        parity.exact(ha, hb, f"{shape} step {i}: hidden rows, one launch vs attention + Wo")
+        parity.exact(la, lb, f"{shape} step {i}: logits")
+    parity.exact(out["1"][1], out["0"][1], f"{shape}: K cache")
+    parity.exact(out["1"][2], out["0"][2], f"{shape}: V cache")
