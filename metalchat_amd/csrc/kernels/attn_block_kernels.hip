@@ -3,8 +3,8 @@
 //   residual (transformer.h:132-133), for int4 weights on bfloat rows (the arithmetic of mc_gemv_i4_bfloat_lin{1,2,4}_p0_e{0,1}).
 //
 // Why: the Wo GEMV streams 34 KB per CU (1.4 us) and lasts 5.0 us -- its launch ramp, its prologue and its first tiles' latency
-// are all it consists of.  Here its weights are requested when the launch STARTS (one row pair per wave: they sit in registers
-// long before they are needed), the attention row reaches every workgroup through one more in-launch hand-off (C: the 16-value
+// are all it consists of.  Here its weights are requested behind the scores (one row pair per wave: they sit in registers
+// before they are needed: the two hand-offs of the attention cover them), the attention row reaches every workgroup through one more in-launch hand-off (C: the 16-value
 // chunks the reduce of hand-off B finishes are published as {2 x bf16, tag} granules and swept by all eight waves into LDS), and
 // what is left of the GEMV is its arithmetic and its epilogue.
 //
@@ -36,8 +36,10 @@ attn_wo_body(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const 
     __shared__ __attribute__((aligned(16))) char xs[LNCH * CHUNK_LDS];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    // ---- the Wo row pairs of this wave and their weights, requested before anything else: equal contiguous spans of pairs per
-    // wave over the whole launch, at most PMAX each (the host takes this kernel only then)
+    // ---- the Wo row pairs of this wave: equal contiguous spans of pairs per wave over the whole launch, at most PMAX each (the
+    // host takes this kernel only then).  Their weights are requested BEHIND the scores (attn_fused_bf's hook): at the start of the
+    // launch they queue in front of the K tile in the CU's memory pipe (measured: 720 tokens/s against 732 with the Wo GEMV as a
+    // launch of its own); behind the scores the hand-offs of the attention cover them.
     constexpr int PMAX = 2;
     const uint32_t NP = out_rows / 2, nw_total = gridDim.x * 8u, gw = blockIdx.x * 8u + wave;
     const uint32_t pq = NP / nw_total, prem = NP - pq * nw_total;
@@ -46,27 +48,29 @@ attn_wo_body(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const 
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     uint4 ww[PMAX][2][LNCH];
     uint32_t ws[PMAX][LNCH], wres[PMAX];
+    auto request_wo = [&] {
 #pragma unroll
-    for (int i = 0; i < PMAX; i++) {
-        if (pb + i >= pe) break; // (wave-uniform)
-        const uint32_t pr = pb + i;
-        const char* wrow = static_cast<const char*>(wo_w) + (size_t)pr * 2 * ROWB + lane * 16;
+        for (int i = 0; i < PMAX; i++) {
+            if (pb + i >= pe) break; // (wave-uniform)
+            const uint32_t pr = pb + i;
+            const char* wrow = static_cast<const char*>(wo_w) + (size_t)pr * 2 * ROWB + lane * 16;
 #pragma unroll
-        for (int r = 0; r < 2; r++)
+            for (int r = 0; r < 2; r++)
+#pragma unroll
+                for (int c = 0; c < LNCH; c++) {
+                    const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow + (size_t)r * ROWB + c * 1024));
+                    ww[i][r][c] = make_uint4(v.x, v.y, v.z, v.w);
+                }
+            // scales: row quads [ceil(out / 4)][ngroups][4] bf16 (gemv.h); the dword (rows 2 pr, 2 pr + 1) of the lane's group
+            const char* srow = static_cast<const char*>(wo_s) + (((size_t)(pr >> 1) * ngroups) * 4 + (pr & 1u) * 2) * 2;
 #pragma unroll
             for (int c = 0; c < LNCH; c++) {
-                const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow + (size_t)r * ROWB + c * 1024));
-                ww[i][r][c] = make_uint4(v.x, v.y, v.z, v.w);
+                const uint32_t g = group ? ((2048u * c + 32u * lane) >> glog) : 0u;
+                ws[i][c] = *reinterpret_cast<const uint32_t*>(srow + g * 8u);
             }
-        // scales: row quads [ceil(out / 4)][ngroups][4] bf16 (gemv.h); the dword (rows 2 pr, 2 pr + 1) of the lane's group
-        const char* srow = static_cast<const char*>(wo_s) + (((size_t)(pr >> 1) * ngroups) * 4 + (pr & 1u) * 2) * 2;
-#pragma unroll
-        for (int c = 0; c < LNCH; c++) {
-            const uint32_t g = group ? ((2048u * c + 32u * lane) >> glog) : 0u;
-            ws[i][c] = *reinterpret_cast<const uint32_t*>(srow + g * 8u);
+            wres[i] = has_res ? reinterpret_cast<const uint32_t*>(res)[pr] : 0u;
         }
-        wres[i] = has_res ? reinterpret_cast<const uint32_t*>(res)[pr] : 0u;
-    }
+    };
 
     // ---- attention (decode_kernels.hip); every finished 16-value chunk goes out as eight {2 x bf16, tag} granules
     const uint32_t epoch_tag = st->epoch * 256u + layer_tag;
@@ -77,7 +81,7 @@ attn_wo_body(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const 
             if ((col & 1u) == 0) granule_store(row_g + ((size_t)head * HD + db * 16 + col) / 2, epoch_tag, pack_bf16x2(v, vn));
         }
     };
-    attn_fused_bf<HD, 1, 8>(q, kc, vt, psum_g, slab_g, st, n_rep, KV, max_seq, scale, nsplit, layer_tag, nullptr, publish);
+    attn_fused_bf<HD, 1, 8>(q, kc, vt, psum_g, slab_g, st, n_rep, KV, max_seq, scale, nsplit, layer_tag, nullptr, publish, request_wo);
 
     // ---- hand-off C: the whole attention row (K bf16 = K / 2 granules) into LDS, padded as the transposed reads want it
     {

@@ -655,11 +655,13 @@ struct handoff_wait {
 // stay on waves 0-3, one 16-slot tile each; the column blocks of P.V and the chunks of the reduce are dealt over all NW waves,
 // which changes who adds, not what is added).  on_chunk(head, db, col, v): called by the 16 lanes that hold the finished sums of
 // chunk (head, 16-column block db), v = the fp32 sum of column 16 db + col over all ranges, in range order.
-template <int HD, int T, int NW, typename OnChunk>
+// behind_scores(): called once by every wave when its partial denominators are out, in front of the wait of hand-off A -- where a
+// caller puts requests that must not compete with the K tile (mc_attn_wo_*: the Wo weights).
+template <int HD, int T, int NW, typename OnChunk, typename BehindScores>
 __device__ __forceinline__ void
 attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const bf16_t* __restrict__ vt,
               unsigned long long* psum_g, unsigned long long* slab_g, step_state* st, uint32_t n_rep, uint32_t KV, uint32_t max_seq,
-              float scale, uint32_t nsplit, uint32_t layer_tag, unsigned long long* tl, OnChunk&& on_chunk)
+              float scale, uint32_t nsplit, uint32_t layer_tag, unsigned long long* tl, OnChunk&& on_chunk, BehindScores&& behind_scores)
 {
     // tl != null (tools/attn_timeline.py only): thread 0 of every workgroup leaves s_memrealtime stamps of its phases
     auto stamp = [&](int i) {
@@ -787,6 +789,7 @@ attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const
             const float tot = (wsum[0][threadIdx.x] + wsum[1][threadIdx.x]) + (wsum[2][threadIdx.x] + wsum[3][threadIdx.x]);
             granule_store(psum_g + (size_t)(kv * n_rep + threadIdx.x) * nsplit + split, tag, __float_as_uint(tot));
         }
+        behind_scores();
         for (uint32_t head = wave; head < n_rep; head += NW) {
             // (softmax_inv's order: lane-strided partial sums, then the shuffle tree)
             const unsigned long long* row = psum_g + (size_t)(kv * n_rep + head) * nsplit;
@@ -847,6 +850,7 @@ attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const
             }
         }
     }
+    if (!active) behind_scores();
     // ---- 6. hand-off B: chunk q = (head, 16-column block) of this kv head is finished by workgroup q % nsplit (every
     // workgroup of the launch takes part, ranges past kv_len included): lane (col, jj) gathers column col of ranges jj,
     // jj + 4, ..., adds them in that order, the four lane groups are added in order too, one rounding to T
@@ -896,10 +900,10 @@ attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const
         auto store = [&](uint32_t head, uint32_t db, uint32_t col, float v) {                                                            \
             if ((threadIdx.x & 63) < 16) out[(size_t)head * hd + db * 16 + col] = f2bf(v);                                               \
         };                                                                                                                               \
-        if (hd == 128) attn_fused_bf<128, T, 4>(q, kc, vt, psum_g, slab_g, st, n_rep, n_kv, max_seq, scale, nsplit, layer_tag, tl, store);    \
-        else if (hd == 64) attn_fused_bf<64, T, 4>(q, kc, vt, psum_g, slab_g, st, n_rep, n_kv, max_seq, scale, nsplit, layer_tag, tl, store); \
-        else if (T == 1 && hd == 256) attn_fused_bf<256, 1, 4>(q, kc, vt, psum_g, slab_g, st, n_rep, n_kv, max_seq, scale, nsplit, layer_tag, tl, store); \
-        else if (T == 1 && hd == 32) attn_fused_bf<32, 1, 4>(q, kc, vt, psum_g, slab_g, st, n_rep, n_kv, max_seq, scale, nsplit, layer_tag, tl, store);   \
+        if (hd == 128) attn_fused_bf<128, T, 4>(q, kc, vt, psum_g, slab_g, st, n_rep, n_kv, max_seq, scale, nsplit, layer_tag, tl, store, [] {});    \
+        else if (hd == 64) attn_fused_bf<64, T, 4>(q, kc, vt, psum_g, slab_g, st, n_rep, n_kv, max_seq, scale, nsplit, layer_tag, tl, store, [] {}); \
+        else if (T == 1 && hd == 256) attn_fused_bf<256, 1, 4>(q, kc, vt, psum_g, slab_g, st, n_rep, n_kv, max_seq, scale, nsplit, layer_tag, tl, store, [] {}); \
+        else if (T == 1 && hd == 32) attn_fused_bf<32, 1, 4>(q, kc, vt, psum_g, slab_g, st, n_rep, n_kv, max_seq, scale, nsplit, layer_tag, tl, store, [] {});   \
     }
 MC_ATTN_FUSED(mc_attn_fused_bfloat, 1)   // 64-slot ranges
 // (128- and 256-slot ranges -- T = 2, 4: MC_ATTN_FUSED(mc_attn_fused2_bfloat, 2) ... -- were built for S = 8192, passed the kernel-level
