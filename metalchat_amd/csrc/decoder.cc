@@ -550,6 +550,13 @@ struct mc_decoder {
                (unsigned)(nsplit * cfg.n_kv_heads) <= (unsigned)dev->prop.multiProcessorCount;
     }
 
+    // dynamic LDS of a linear-order int4 GEMV (gemv(): the padded row, the scratch, the parked sums of eight waves)
+    static unsigned
+    lin_lds_bytes(const linear_w& L)
+    {
+        return (unsigned)((size_t)(L.in + 2047) / 2048 * 2048 * 2 / 16 * 17) + 128u + 8u * 512u;
+    }
+
     // a hand-off inside a launch that gave up (bounded waits, decode_kernels.hip): reported once, then cleared
     mc_status
     check_handoffs(const step_state_h& st)

@@ -22,7 +22,7 @@ namespace {
 using namespace mc;
 using namespace mc::gemv;
 
-// LNCH = KiB of packed weights per Wo row (K = H * hd = 2048 LNCH); RES: residual epilogue (llama) or plain store (gemma3)
+// LNCH = KiB of packed weights per Wo row (K = H * hd = 2048 LNCH)
 template <int HD, int LNCH>
 __device__ __forceinline__ void
 attn_wo_body(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const bf16_t* __restrict__ vt, bf16_t* __restrict__ attn_out,

@@ -18,23 +18,10 @@
 // prefix, roll, write" (cache.h:187-204) moves zero bytes.  Attention sums over physical slots;
 // RoPE is applied before caching, so slot order does not matter.
 #include "common.h"
+#include "handoff.h"
 
 using namespace mc;
 
-struct step_state {
-    int32_t token;      // input token of the current step
-    int32_t pos;        // start_pos of the current step
-    int32_t kv_len;     // valid cache slots after this step's write  = min(pos + 1, max_seq)
-    int32_t write_slot; // physical slot of this step's K/V row
-    int32_t ring_base;  // rotation of the post-sink ring
-    int32_t step_index; // index into tokens_out for chained generation
-    int32_t rope_row;   // pos - rope_table_start
-    int32_t rolled;     // number of rolls so far (debug)
-    int32_t rope_start; // first position of the rope table window (nn/embedding.h:190-198); moved by mc_step_rope
-    uint32_t epoch;     // counts the steps since the decoder was created (never reset): the tag of in-launch hand-offs
-    uint32_t err;       // set by a kernel whose in-launch hand-off gave up (mc_attn_fused_T); 0 = none
-    int32_t pad[1];
-};
 
 __device__ __forceinline__ void
 derive_state(step_state* st, int32_t max_seq, int32_t pre_len)
@@ -615,39 +602,6 @@ mc_attn_pv_reduce_float(const float* __restrict__ parts, float* __restrict__ out
 // wait at all, and the host reports it (mc_decoder_generate / _step return MC_ERR_RUNTIME).  The grid must be co-resident:
 // the host takes this path only while nsplit * n_kv <= 4 workgroups per CU.
 // ------------------------------------------------------------------------------------------
-typedef __attribute__((address_space(1))) unsigned long long gu64_t;
-typedef __attribute__((address_space(1))) uint32_t gu32_t;
-
-__device__ __forceinline__ void
-granule_store(unsigned long long* g, uint32_t tag, uint32_t value)
-{
-    __hip_atomic_store((gu64_t*)g, ((unsigned long long)tag << 32) | value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ unsigned long long
-granule_load(const unsigned long long* g)
-{
-    return __hip_atomic_load((gu64_t*)g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// one round of a bounded wait: false = keep waiting.  `ok` is wave-uniform.
-struct handoff_wait {
-    unsigned long long t0;
-    uint32_t spins;
-    __device__ __forceinline__ handoff_wait() : t0(__builtin_amdgcn_s_memrealtime()), spins(0) {}
-    // true: give up (this launch or an earlier one of the token ran out of time)
-    __device__ __forceinline__ bool
-    expired(step_state* st, uint32_t code)
-    {
-        __builtin_amdgcn_s_sleep(4);
-        if ((++spins & 63u) != 0) return false;
-        if (__hip_atomic_load((gu32_t*)&st->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return true;
-        if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { // 2 s at 100 MHz
-            __hip_atomic_store((gu32_t*)&st->err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return true;
-        }
-        return false;
-    }
-};
-
 // T = 64-slot score tiles per wave: a workgroup owns 64 T cache slots.  The product instantiates T = 1 only (see the note at the
 // instantiation); the host takes this path while the launch is at most two workgroups per CU (with 64-slot ranges at S = 8192
 // -- 1024 workgroups, 128 producers per gather -- the launch measured 27.8 us against 6.3 + 8.5 for the two-launch form).

@@ -27,6 +27,7 @@
 #pragma once
 
 #include "common.h"
+#include "handoff.h"
 
 #include <type_traits>
 
@@ -57,6 +58,16 @@ struct postnorm_args {
     void* h_out;        // T[in]
 };
 enum { EPI_STORE = 0, EPI_RESID = 1, EPI_SILU_MUL = 2, EPI_GELU_MUL = 3, EPI_QKV_ROPE = 4, EPI_STORE_PICK = 5 };
+// CHAINED launches (chain_kernels.hip): a linear-order GEMV that is the first phase of a longer launch hands its output row to the
+// phase behind it through {2 x bf16, tag} granules (handoff.h): granule g = elements 2 g, 2 g + 1 of the row = the dword a row
+// pair's epilogue stores.  (The other direction -- a GEMV phase taking its ROW from granules, built for attention + Wo + w1|w3 in
+// one launch -- was bit-identical and 1 us per layer slower than the two launches: tools/experiments/README.md.)
+enum { CH_NONE = 0,
+       CH_ROW_OUT = 2 }; // EPI_STORE / EPI_RESID: every stored pair is also published in chain_args::yg
+struct chain_args {
+    unsigned long long* yg; // [out_rows / 2] granules of the row this phase produces
+    uint32_t tag;           // epoch * 256 + the hand-off's number inside the token
+};
 // EPI_STORE_PICK (linear-order kernels): EPI_STORE + the greedy pick of the stored row, so the output head needs no argmax
 // launch behind it.  `res` points at this descriptor.  Every lane that finishes a pair keeps the best (value, lowest index)
 // it has seen as ONE 64-bit key; a wave folds its lanes, the workgroup's waves meet in LDS, the last of them hands the
@@ -553,14 +564,16 @@ template <int R> struct tile {
 // the two halves of the middle packet need with the unchanged lane mapping); one accumulator per packet, the middle one split
 // by a lane mask when the super row is complete.  A super row is a rotation / SiLU pair, so the epilogues see what they always
 // see; the loop's "pair" is two super rows = one quad of rows (and one quad of scales).
-template <int WF, typename T, int QM, int PRO, int EPI, int R, int LNCH = 0, int LTP = 0, int LRING = 0, int LWAVES = 0, int LGEN = 0, int LSPLIT = 0>
+template <int WF, typename T, int QM, int PRO, int EPI, int R, int LNCH = 0, int LTP = 0, int LRING = 0, int LWAVES = 0, int LGEN = 0, int LSPLIT = 0, int CH = CH_NONE>
 __device__ __forceinline__ void
 body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __restrict__ xp,
      void* __restrict__ yp, const void* __restrict__ resp, const void* __restrict__ normp,
      uint32_t out_rows, uint32_t in, uint32_t group, float eps, float mu,
      const void* __restrict__ lora_ap, const void* __restrict__ lora_bp, uint32_t lora_rank,
-     float lora_scale)
+     float lora_scale, chain_args ch = chain_args{})
 {
+    static_assert(CH == CH_NONE || (LNCH > 0 && LWAVES > 0 && !LSPLIT && T::bytes == 2 && (EPI == EPI_STORE || EPI == EPI_RESID)),
+                  "chained phases: the linear-order int4 kernels, an epilogue that stores the row");
     using F = fmt<WF, T>;
     using S = typename T::S;
     constexpr int KPL = F::KPL;
@@ -739,6 +752,7 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
             if (two && T::bytes == 2) {
                 // both rows in ONE 4-byte store (row is even): half the store instructions of the head's 128256 rows
                 reinterpret_cast<uint32_t*>(y)[pair] = pack_bf16x2(va, vb);
+                if constexpr ((CH & CH_ROW_OUT) != 0) ::granule_store(ch.yg + pair, ch.tag, pack_bf16x2(va, vb));
             } else {
                 y[row] = T::st(va);
                 if (two) y[row + 1] = T::st(vb);

@@ -384,8 +384,7 @@ def test_one_launch_attention_against_the_two_launch_form(acc, monkeypatch, shap
 
 @pytest.mark.parametrize("shape", ["llama3-8b", "llama3-70b", "hd64", "gemma-hd256"])
 def test_attention_and_wo_in_one_launch_equal_the_two_launches_bit_for_bit(acc, monkeypatch, shape):
-    # mc_attn_wo_i4_bfloat_* = mc_attn_fused_bfloat + the Wo GEMV (attn_block_kernels.hip): the same attention phases, the same row,
-    # the same per-row arithmetic -- hidden rows, logits, caches and tokens must be IDENTICAL to the two launches, near an empty
+    # mc_attn_wo_i4_bfloat_* = mc_attn_fused_bfloat + the Wo GEMV (attn_block_kernels.hip): the same attention phases, the same row, the same per-row arithmetic -- hidden rows, logits, caches and tokens must be IDENTICAL to the two launches, near an empty
     # cache and across the end of a full one; the launch log shows which form ran.
     import metalchat_amd as mc
 
@@ -406,9 +405,13 @@ def test_attention_and_wo_in_one_launch_equal_the_two_launches_bit_for_bit(acc, 
                    rope_sliding_theta=10000.0, sliding_stride=2, attn_scale=256 ** -0.5)
         kernel = "mc_attn_wo_i4_bfloat_hd256_k2"
     S = cfg["max_seq_len"]
+    # "wo": the default, attention + Wo in one launch;  "sep": mc_attn_fused_bfloat, then the Wo GEMV
     out = {}
-    for one in ("1", "0"):
-        monkeypatch.setenv("MC_ATTN_WO", one)
+    for form, env in (("wo", {}), ("sep", {"MC_ATTN_WO": "0"})):
+        for k_ in ("MC_ATTN_WO",):
+            monkeypatch.delenv(k_, raising=False)
+        for k_, v_ in env.items():
+            monkeypatch.setenv(k_, v_)
         dec = mc.Decoder(acc, **mg.decoder_kwargs(cfg, weight_format=mc.WFMT_I4, group_size=128))
         dec.init_synthetic(SEED)
         dec.set_taps(True)
@@ -424,13 +427,14 @@ def test_attention_and_wo_in_one_launch_equal_the_two_launches_bit_for_bit(acc, 
                 rows.append((tok, dec.logits().copy(), np.stack([dec.hidden(l) for l in range(-1, cfg["n_layers"])])))
         kk, vv = dec.export_kv(cfg["n_layers"] - 1)
         names = set(dec.launched())
-        assert (kernel in names) == (one == "1"), sorted(names)
-        assert ("mc_attn_fused_bfloat" in names) == (one == "0"), sorted(names)
-        out[one] = (rows, kk, vv)
+        assert (kernel in names) == (form != "sep"), sorted(names)
+        assert ("mc_attn_fused_bfloat" in names) == (form == "sep"), sorted(names)
+        out[form] = (rows, kk, vv)
         dec.release()
-    for i, ((ta, la, ha), (tb_, lb, hb)) in enumerate(zip(out["1"][0], out["0"][0])):
-        assert ta == tb_, (shape, i)
-        parity.exact(ha, hb, f"{shape} step {i}: hidden rows, one launch vs attention + Wo")
-        parity.exact(la, lb, f"{shape} step {i}: logits")
-    parity.exact(out["1"][1], out["0"][1], f"{shape}: K cache")
-    parity.exact(out["1"][2], out["0"][2], f"{shape}: V cache")
+    for form in ("wo",):
+        for i, ((ta, la, ha), (tb_, lb, hb)) in enumerate(zip(out[form][0], out["sep"][0])):
+            assert ta == tb_, (shape, form, i)
+            parity.exact(ha, hb, f"{shape} step {i}: hidden rows, {form} vs separate launches")
+            parity.exact(la, lb, f"{shape} step {i}: logits, {form}")
+        parity.exact(out[form][1], out["sep"][1], f"{shape}: K cache, {form}")
+        parity.exact(out[form][2], out["sep"][2], f"{shape}: V cache, {form}")
