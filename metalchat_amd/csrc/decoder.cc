@@ -849,7 +849,7 @@ struct mc_decoder {
                            pack((const void*)L.w2.w, (const void*)L.w2.scales, (const void*)gate, hidden, (const void*)hidden,
                                 (uint32_t)L.w2.out, (uint32_t)L.w2.in, (uint32_t)L.w2.group, chain_hid_g, state, (uint32_t)(li + 1), off,
                                 (const void*)N.qkv.w, (const void*)N.qkv.scales, (const void*)N.attention_norm, (const void*)N.qkv_epi,
-                                (uint32_t)N.qkv.out, (uint32_t)N.qkv.group, cfg.norm_eps, mu));
+                                (uint32_t)N.qkv.out, (uint32_t)N.qkv.group, cfg.norm_eps, mu, (void*)nullptr));
                 if (s != MC_OK) return s;
                 qkv_done = true;
             } else if (!gemma) {

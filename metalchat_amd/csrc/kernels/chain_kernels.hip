@@ -39,40 +39,17 @@ struct qkv_phase {
     uint32_t slot, rrow, pb, pe, eo_pair;
     float eo_c, eo_s;
 
-    // everything this phase reads that does not depend on the hidden row: requested from the tail of the phase in front
+    // at the START of the launch (scalar loads of the descriptor and the step state, nothing of this kernel has stored yet -- behind
+    // stores hipcc reads such fields with vector loads and waits for them with vmcnt(0), i.e. for every weight in flight): the wave's
+    // range of row pairs, the write slot, the rotation of the pair each lane will finish
     __device__ __forceinline__ void
-    request(const void* __restrict__ qkv_w, const void* __restrict__ qkv_s, const void* __restrict__ norm_w, const qkv_epilogue* qep,
-            uint32_t out_rows, uint32_t group)
+    early(const qkv_epilogue* qep, uint32_t out_rows)
     {
         const uint32_t tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
         const uint32_t NP = out_rows / 2, nw_total = gridDim.x * 8u, gw = blockIdx.x * 8u + wave;
         const uint32_t pq = NP / nw_total, prem = NP - pq * nw_total;
         pb = gw * pq + min(gw, prem);
         pe = pb + pq + (gw < prem ? 1u : 0u);
-        const uint32_t glog = group ? 31u - __builtin_clz(group) : 31u, ngroups = group ? K >> glog : 1u;
-#pragma unroll
-        for (int i = 0; i < PMAX; i++) {
-            if (pb + i >= pe) break; // (wave-uniform)
-            const uint32_t pr = pb + i;
-            const char* wrow = static_cast<const char*>(qkv_w) + (size_t)pr * 2 * ROWB + lane * 16;
-#pragma unroll
-            for (int r = 0; r < 2; r++)
-#pragma unroll
-                for (int c = 0; c < LQ; c++) {
-                    const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow + (size_t)r * ROWB + c * 1024));
-                    ww[i][r][c] = make_uint4(v.x, v.y, v.z, v.w);
-                }
-            // scales: row quads [ceil(out / 4)][ngroups][4] bf16 (gemv.h); the dword (rows 2 pr, 2 pr + 1) of the lane's group
-            const char* srow = static_cast<const char*>(qkv_s) + (((size_t)(pr >> 1) * ngroups) * 4 + (pr & 1u) * 2) * 2;
-#pragma unroll
-            for (int c = 0; c < LQ; c++) {
-                const uint32_t g = group ? ((2048u * c + 32u * lane) >> glog) : 0u;
-                ws[i][c] = *reinterpret_cast<const uint32_t*>(srow + g * 8u);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < NXP; i++) nr[i] = reinterpret_cast<const rowv4*>(norm_w)[min(tid + i * BD, NPK - 1)];
-        // the descriptor and the step state with scalar loads; the rotation of the pair this lane will finish
         qe = *qep;
         const __attribute__((address_space(1))) int32_t* stp = (const __attribute__((address_space(1))) int32_t*)qe.state;
         slot = (uint32_t)stp[3];
@@ -83,11 +60,47 @@ struct qkv_phase {
         const uint32_t j = row < (qe.H + qe.KV) * hd ? (row % hd) / 2 : 0u;
         eo_c = ((gfloat_p)qe.fcos)[(size_t)rrow * (hd / 2) + j];
         eo_s = ((gfloat_p)qe.fsin)[(size_t)rrow * (hd / 2) + j];
+        uint32_t never;
+        asm volatile("s_mov_b32 %0, 0" : "=s"(never));
+        if (never) asm volatile("" ::"v"(eo_c), "v"(eo_s), "s"(slot), "s"(qe.H), "s"(qe.KV), "s"(qe.hd), "s"(qe.max_seq)); // (issued HERE)
     }
 
-    // xs: this phase's LDS (LQ * CHUNK_LDS bytes for the row + 32 floats)
+    // the weights, scales and norm weights: requested from the tail of the phase in front.  Straight-line code, every load
+    // unconditional (a pair the wave does not own reads one broadcast line): hipcc then counts its waits, and the epilogue of the
+    // phase in front does not wait for these loads.
     __device__ __forceinline__ void
-    run(char* xs, const unsigned long long* hid_g, uint32_t tag, step_state* st, uint32_t out_rows, float eps, float mu)
+    request(const void* __restrict__ qkv_w, const void* __restrict__ qkv_s, const void* __restrict__ norm_w, uint32_t group)
+    {
+        const uint32_t tid = threadIdx.x, lane = tid & 63;
+        const uint32_t glog = group ? 31u - __builtin_clz(group) : 31u, ngroups = group ? K >> glog : 1u;
+#pragma unroll
+        for (int i = 0; i < PMAX; i++) {
+            const uint32_t pr = pb + i, lm = 0u - (uint32_t)(pr < pe);
+            const uint64_t lm64 = ((uint64_t)lm << 32) | lm;
+            const char* wrow = static_cast<const char*>(qkv_w) + (((uint64_t)pr * 2 * ROWB) & lm64) + ((lane * 16) & lm);
+#pragma unroll
+            for (int r = 0; r < 2; r++)
+#pragma unroll
+                for (int c = 0; c < LQ; c++) {
+                    const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow + (((uint32_t)r * ROWB + c * 1024) & lm)));
+                    ww[i][r][c] = make_uint4(v.x, v.y, v.z, v.w);
+                }
+            // scales: row quads [ceil(out / 4)][ngroups][4] bf16 (gemv.h); the dword (rows 2 pr, 2 pr + 1) of the lane's group
+            const char* srow = static_cast<const char*>(qkv_s) + (((((uint64_t)(pr >> 1) * ngroups) * 4 + (pr & 1u) * 2) * 2) & lm64);
+#pragma unroll
+            for (int c = 0; c < LQ; c++) {
+                const uint32_t g = group ? ((2048u * c + 32u * lane) >> glog) : 0u;
+                ws[i][c] = *reinterpret_cast<const uint32_t*>(srow + ((g * 8u) & lm));
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NXP; i++) nr[i] = reinterpret_cast<const rowv4*>(norm_w)[min(tid + i * BD, NPK - 1)];
+    }
+
+    // xs: this phase's LDS (LQ * CHUNK_LDS bytes for the row + 32 floats); stamp(k): time stamps of tools/chain_timeline.py
+    template <typename Stamp>
+    __device__ __forceinline__ void
+    run(char* xs, const unsigned long long* hid_g, uint32_t tag, step_state* st, uint32_t out_rows, float eps, float mu, Stamp&& stamp)
     {
         const uint32_t tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
         float* red = reinterpret_cast<float*>(xs + LQ * CHUNK_LDS);
@@ -95,7 +108,17 @@ struct qkv_phase {
         // ---- the hidden row: packet p = granules 4 p .. 4 p + 3, in the thread that holds packet p in the stand-alone kernel
         rowv4 xr[NXP];
         {
+            // Waves that finished their part of the phase in front early wait here while others still stream: a wave first watches
+            // ONE granule (its last), sleeping ~ 0.4 us between looks, and sweeps its packets only when that one has arrived --
+            // with every thread re-reading four granules every 0.1 us the waiting waves asked the fabric for 4 MB per round and
+            // the weight requests of this phase took up to 5 us to issue (tools/chain_timeline.py)
             handoff_wait w;
+            const uint32_t last = 4u * min(tid + (NXP - 1) * BD, NPK - 1) + 3u;
+            for (;;) {
+                const bool seen = (uint32_t)(granule_load(hid_g + last) >> 32) == tag;
+                if (__all(seen) || w.expired(st, 0xD0000000u | (tag & 0xFFu))) break;
+                __builtin_amdgcn_s_sleep(16);
+            }
             for (;;) {
                 bool ok = true;
 #pragma unroll
@@ -113,6 +136,7 @@ struct qkv_phase {
                 if (__all(ok) || w.expired(st, 0xD0000000u | (tag & 0xFFu))) break;
             }
         }
+        stamp(3);
         // ---- attention_norm (kernel/rmsnorm.metal:52-95), the additions in the order of gemv.h's build-time prologue
         {
             float ss = 0.0f;
@@ -152,6 +176,7 @@ struct qkv_phase {
             }
         }
         __syncthreads();
+        stamp(4);
         // ---- the wave's row pairs from registers (the arithmetic of the linear-order kernels: mac4b_n chunk after chunk)
         const uint32_t lane_tr = (((lane >> 4) * 4 + (lane & 3)) * 17 + ((lane >> 2) & 3) * 4) * 16;
         const m4b_lane m4bk = m4b_lane_consts(lane);
@@ -191,6 +216,7 @@ struct qkv_phase {
             const uint32_t row = 2 * (pb + lane);
             qkv_rope_finish<BF>(qe, slot, row, row + 1 < out_rows, a, b, eo_c, eo_s);
         }
+        stamp(5);
     }
 };
 
@@ -201,16 +227,27 @@ struct qkv_phase {
     extern "C" __global__ void __launch_bounds__(512)                                                                                    \
     NAME(const void* w2_w, const void* w2_s, const void* gate, void* hidden, const void* res, uint32_t dim, uint32_t ffn,               \
          uint32_t w2_group, unsigned long long* hid_g, step_state* st, uint32_t layer_tag, uint32_t lds_off, const void* qkv_w,          \
-         const void* qkv_s, const void* norm_w, const qkv_epilogue* qe, uint32_t qkv_rows, uint32_t qkv_group, float eps, float mu)      \
+         const void* qkv_s, const void* norm_w, const qkv_epilogue* qe, uint32_t qkv_rows, uint32_t qkv_group, float eps, float mu,      \
+         unsigned long long* tl)                                                                                                         \
     {                                                                                                                                    \
         extern __shared__ __attribute__((aligned(16))) char smem[];                                                                      \
         const uint32_t tag = st->epoch * 256u + layer_tag;                                                                               \
+        /* tl != null (tools/chain_timeline.py only): eight time stamps per wave */                                                      \
+        auto stamp = [&](int k) {                                                                                                        \
+            if (tl && (threadIdx.x & 63) == 0) tl[(size_t)(blockIdx.x * 8u + (threadIdx.x >> 6)) * 8 + k] = __builtin_amdgcn_s_memrealtime(); \
+        };                                                                                                                               \
+        stamp(0);                                                                                                                        \
         qkv_phase<LQ, PMAX> next;                                                                                                        \
-        auto hook = [&] { next.request(qkv_w, qkv_s, norm_w, qe, qkv_rows, qkv_group); };                                                \
+        next.early(qe, qkv_rows);                                                                                                        \
+        auto hook = [&] {                                                                                                                \
+            stamp(1);                                                                                                                    \
+            next.request(qkv_w, qkv_s, norm_w, qkv_group);                                                                               \
+        };                                                                                                                               \
         body<WF_I4, BF, Q_M4D, PRO_NONE, EPI_RESID, 4, __VA_ARGS__, 8, 0, 0, CH_ROW_OUT>(                                                \
             w2_w, w2_s, gate, hidden, res, nullptr, dim, ffn, w2_group, eps, mu, nullptr, nullptr, 0u, 0.0f, chain_args{hid_g, tag},     \
             hook);                                                                                                                       \
-        next.run(smem + lds_off, hid_g, tag, st, qkv_rows, eps, mu);                                                                     \
+        stamp(2);                                                                                                                        \
+        next.run(smem + lds_off, hid_g, tag, st, qkv_rows, eps, mu, stamp);                                                              \
     }
 MC_W2_QKV(mc_w2_qkv_i4_bfloat_w7_q2, 2, 2, MC_LIN7_CFG)   // Llama-3-8B: ffn 14336, dim 4096, 6144 rows of wq|wk|wv
 MC_W2_QKV(mc_w2_qkv_i4_bfloat_w14_q4, 4, 3, MC_LIN14_CFG) // Llama-3-70B: ffn 28672, dim 8192, 10240 rows

@@ -1697,8 +1697,11 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
         if constexpr (U == 2) {
             if (pr < pe) do_pair(std::integral_constant<int, 0>{}, pr); // odd count: the last pair sits in the first slots
         }
-        tail_hook(); // (chained launches: the wave's last tile has been requested -- the next phase's requests go here)
         flush();
+        // chained launches: the next phase's requests go HERE, behind the stores of this one -- issued in front of them they sit in
+        // front of them in the CU's in-order memory pipe, and with the chip's memory system busy the publication of the wave's
+        // pair was delayed by up to 8 us (tools/chain_timeline.py)
+        tail_hook();
         if (EPI == EPI_STORE_PICK) pick_finish(red, nwaves);
         return;
     }
