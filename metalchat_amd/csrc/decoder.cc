@@ -187,8 +187,6 @@ struct mc_decoder {
     unsigned long long* attn_psum_g = nullptr; // [H][nsplit]            partial softmax denominators
     unsigned long long* attn_slab_g = nullptr; // [KV][nsplit][n_rep][hd] fp32 partial P.V sums
     unsigned long long* attn_row_g = nullptr;  // [H * hd / 2]          the finished attention row, two bf16 per granule (mc_attn_wo_*)
-    unsigned long long* chain_hid_g = nullptr; // [dim / 2]             the hidden row behind w2, for the wq|wk|wv phase of mc_w2_qkv_*
-    bool chain_qkv_on = true;    // MC_CHAIN_QKV=0: the next block's wq|wk|wv as a launch of its own behind w2 (A/B, parity)
     bool attn_wo_on = true;      // MC_ATTN_WO=0: the Wo GEMV as a launch of its own behind the one-launch attention (A/B, parity)
     bool attn_fused_on = true;   // MC_ATTN_FUSED=0: scores and P.V as two launches (A/B, parity)
     // ... while the launch is at most this many 256-thread workgroups per CU (MC_ATTN_FUSED_WGS).  Measured: at S = 8192 with
@@ -552,20 +550,6 @@ struct mc_decoder {
                (unsigned)(nsplit * cfg.n_kv_heads) <= (unsigned)dev->prop.multiProcessorCount;
     }
 
-    // block l's w2 + residual and block l + 1's attention_norm + wq|wk|wv + RoPE + cache write in ONE launch (chain_kernels.hip):
-    // llama blocks, both matrices on the linear-order int4 kernels without adaptors, one of the built (w2 KiB, dim KiB) pairs, one
-    // workgroup per CU (what both stand-alone launches use) and no more row pairs per wave than the kernel holds in registers
-    bool
-    w2_qkv_chained(const layer_w& L, const layer_w& N) const
-    {
-        if (!chain_qkv_on || !chain_hid_g || cfg.family == MC_FAMILY_GEMMA3 || tb != 2 || n_own > 254 || lin_waves != 8) return false;
-        if (!lin_ok(L.w2) || !lin_ok(N.qkv) || L.w2.lora_cols || N.qkv.lora_cols) return false;
-        const int kw = L.w2.in / 2048, kq = N.qkv.in / 2048;
-        const unsigned cus = (unsigned)dev->prop.multiProcessorCount, pmax = kq == 2 ? 2u : 3u;
-        const bool built = (kw == 7 && kq == 2) || (kw == 14 && kq == 4);
-        return built && L.w2.out == cfg.dim && N.qkv.in == cfg.dim && N.qkv.out % 2 == 0 && (unsigned)cfg.dim / 2 >= 8u * cus &&
-               ((unsigned)N.qkv.out / 2 + 8u * cus - 1) / (8u * cus) <= pmax;
-    }
     // dynamic LDS of a linear-order int4 GEMV (gemv(): the padded row, the scratch, the parked sums of eight waves)
     static unsigned
     lin_lds_bytes(const linear_w& L)
@@ -740,12 +724,9 @@ struct mc_decoder {
             MC_HIP(hipMemcpyAsync(hidden, x, (size_t)dim * tb, hipMemcpyDeviceToDevice, stream));
             x = hidden;
         }
-        bool qkv_done = false; // block li's wq|wk|wv ran behind block li - 1's w2 (mc_w2_qkv_*)
         for (int li = 0; li < n_own; li++) {
             layer_w& L = layers[li];
-            if (qkv_done) {
-                qkv_done = false;
-            } else if (!gemma) {
+            if (!gemma) {
                 // attention_norm + wq|wk|wv + rope + cache write in ONE launch
                 // (transformer.h:130, attention.h:170-177)
                 s = gemv(L.qkv, 1, 4, x, qkv, L.qkv_epi, L.attention_norm, mu);
@@ -841,18 +822,7 @@ struct mc_decoder {
             }
             if (s != MC_OK) return s;
             // w2 (+ post norm) + residual          (transformer.h:59, 138-139)
-            if (li + 1 < n_own && w2_qkv_chained(L, layers[li + 1])) {
-                const layer_w& N = layers[li + 1];
-                const unsigned off = lin_lds_bytes(L.w2);
-                s = launch("mc_w2_qkv_i4_" + tname + "_w" + std::to_string(L.w2.in / 2048) + "_q" + std::to_string(N.qkv.in / 2048),
-                           (unsigned)dev->prop.multiProcessorCount, 1, 1, 512, off + (unsigned)(N.qkv.in / 2048) * 4352u + 128u,
-                           pack((const void*)L.w2.w, (const void*)L.w2.scales, (const void*)gate, hidden, (const void*)hidden,
-                                (uint32_t)L.w2.out, (uint32_t)L.w2.in, (uint32_t)L.w2.group, chain_hid_g, state, (uint32_t)(li + 1), off,
-                                (const void*)N.qkv.w, (const void*)N.qkv.scales, (const void*)N.attention_norm, (const void*)N.qkv_epi,
-                                (uint32_t)N.qkv.out, (uint32_t)N.qkv.group, cfg.norm_eps, mu, (void*)nullptr));
-                if (s != MC_OK) return s;
-                qkv_done = true;
-            } else if (!gemma) {
+            if (!gemma) {
                 s = gemv(L.w2, 0, 1, gate, hidden, hidden, nullptr, mu);
                 if (s != MC_OK) return s;
             } else {
@@ -1231,7 +1201,6 @@ mc_decoder_create(mc_device* dev, mc_library* lib, mc_queue* q, const mc_decoder
     if (const char* e = getenv("MC_PV_FOLD")) d->pv_fold_on = atoi(e) != 0;
     if (const char* e = getenv("MC_ATTN_FUSED")) d->attn_fused_on = atoi(e) != 0;
     if (const char* e = getenv("MC_ATTN_WO")) d->attn_wo_on = atoi(e) != 0;
-    if (const char* e = getenv("MC_CHAIN_QKV")) d->chain_qkv_on = atoi(e) != 0;
     if (const char* e = getenv("MC_ATTN_FUSED_WGS")) d->attn_fused_max_wgs_per_cu = (unsigned)std::max(1, std::min(4, atoi(e)));
     if (const char* e = getenv("MC_LING_HALF")) d->ling_half = atoi(e) != 0;
     if (const char* e = getenv("MC_LIN_SPLIT")) d->lin_split = atoi(e) != 0;
@@ -1274,7 +1243,6 @@ mc_decoder_create(mc_device* dev, mc_library* lib, mc_queue* q, const mc_decoder
         A(d->attn_psum_g, (size_t)H * d->nsplit * 8);
         A(d->attn_slab_g, (size_t)H * hd * d->nsplit * 8);
         A(d->attn_row_g, (size_t)H * hd / 2 * 8);
-        A(d->chain_hid_g, (size_t)dim / 2 * 8);
     }
     A(d->taps, (size_t)(d->n_own + 1) * dim * tb);
     A(d->state, sizeof(step_state_h));

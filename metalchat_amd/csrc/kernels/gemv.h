@@ -27,7 +27,6 @@
 #pragma once
 
 #include "common.h"
-#include "handoff.h"
 
 #include <type_traits>
 
@@ -58,19 +57,6 @@ struct postnorm_args {
     void* h_out;        // T[in]
 };
 enum { EPI_STORE = 0, EPI_RESID = 1, EPI_SILU_MUL = 2, EPI_GELU_MUL = 3, EPI_QKV_ROPE = 4, EPI_STORE_PICK = 5 };
-// CHAINED launches (chain_kernels.hip): a linear-order GEMV that is the first phase of a longer launch hands its output row to the
-// phase behind it through {2 x bf16, tag} granules (handoff.h): granule g = elements 2 g, 2 g + 1 of the row = the dword a row
-// pair's epilogue stores.  (The other direction -- a GEMV phase taking its ROW from granules, built for attention + Wo + w1|w3 in
-// one launch -- was bit-identical and 1 us per layer slower than the two launches: tools/experiments/README.md.)
-enum { CH_NONE = 0,
-       CH_ROW_OUT = 2 }; // EPI_STORE / EPI_RESID: every stored pair is also published in chain_args::yg
-struct chain_args {
-    unsigned long long* yg; // [out_rows / 2] granules of the row this phase produces
-    uint32_t tag;           // epoch * 256 + the hand-off's number inside the token
-};
-struct no_hook {
-    __device__ __forceinline__ void operator()() const {}
-};
 // EPI_STORE_PICK (linear-order kernels): EPI_STORE + the greedy pick of the stored row, so the output head needs no argmax
 // launch behind it.  `res` points at this descriptor.  Every lane that finishes a pair keeps the best (value, lowest index)
 // it has seen as ONE 64-bit key; a wave folds its lanes, the workgroup's waves meet in LDS, the last of them hands the
@@ -106,30 +92,6 @@ struct qkv_epilogue {
     const int32_t* state; // step_state: [3] = write_slot, [6] = rope_row
     uint32_t H, KV, hd, max_seq;
 };
-
-// one row pair of the fused wq|wk|wv matrix, finished: rows (2 pair, 2 pair + 1) from their fp32 sums a, b; (c, sn) = the rotation
-// of the pair at this step's position (used by the q / k rows only).  Shared by the GEMV epilogue and chain_kernels.hip.
-template <typename T>
-__device__ __forceinline__ void
-qkv_rope_finish(const qkv_epilogue& q, uint32_t slot, uint32_t row, bool two, float a, float b, float c, float sn)
-{
-    using S = typename T::S;
-    typedef __attribute__((address_space(1))) S* gS_p;
-    const uint32_t H = q.H, KV = q.KV, hd = q.hd, half = hd / 2, ms = q.max_seq;
-    if (row < (H + KV) * hd) {
-        // a rotation pair: packed rows (2j, 2j + 1) of a head = natural (j, j + hd/2)
-        const float x1 = T::rt(a), x2 = T::rt(b);
-        const uint32_t head = row / hd, j = (row % hd) / 2;
-        const S o1 = T::st(c * x1 - sn * x2), o2 = T::st(sn * x1 + c * x2);
-        gS_p dst = head < H ? (gS_p)q.q_out + (size_t)head * hd : (gS_p)q.kc + ((size_t)(head - H) * ms + slot) * hd;
-        dst[j] = o1;
-        dst[j + half] = o2;
-    } else {
-        const uint32_t vrow = row - (H + KV) * hd; // kv*hd + d
-        ((gS_p)q.vt)[(size_t)vrow * ms + slot] = T::st(a);
-        if (two) ((gS_p)q.vt)[(size_t)(vrow + 1) * ms + slot] = T::st(b);
-    }
-}
 
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 
@@ -591,16 +553,14 @@ template <int R> struct tile {
 // the two halves of the middle packet need with the unchanged lane mapping); one accumulator per packet, the middle one split
 // by a lane mask when the super row is complete.  A super row is a rotation / SiLU pair, so the epilogues see what they always
 // see; the loop's "pair" is two super rows = one quad of rows (and one quad of scales).
-template <int WF, typename T, int QM, int PRO, int EPI, int R, int LNCH = 0, int LTP = 0, int LRING = 0, int LWAVES = 0, int LGEN = 0, int LSPLIT = 0, int CH = CH_NONE, typename TailHook = no_hook>
+template <int WF, typename T, int QM, int PRO, int EPI, int R, int LNCH = 0, int LTP = 0, int LRING = 0, int LWAVES = 0, int LGEN = 0, int LSPLIT = 0>
 __device__ __forceinline__ void
 body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __restrict__ xp,
      void* __restrict__ yp, const void* __restrict__ resp, const void* __restrict__ normp,
      uint32_t out_rows, uint32_t in, uint32_t group, float eps, float mu,
      const void* __restrict__ lora_ap, const void* __restrict__ lora_bp, uint32_t lora_rank,
-     float lora_scale, chain_args ch = chain_args{}, TailHook&& tail_hook = TailHook{})
+     float lora_scale)
 {
-    static_assert(CH == CH_NONE || (LNCH > 0 && LWAVES > 0 && !LSPLIT && T::bytes == 2 && (EPI == EPI_STORE || EPI == EPI_RESID)),
-                  "chained phases: the linear-order int4 kernels, an epilogue that stores the row");
     using F = fmt<WF, T>;
     using S = typename T::S;
     constexpr int KPL = F::KPL;
@@ -779,7 +739,6 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
             if (two && T::bytes == 2) {
                 // both rows in ONE 4-byte store (row is even): half the store instructions of the head's 128256 rows
                 reinterpret_cast<uint32_t*>(y)[pair] = pack_bf16x2(va, vb);
-                if constexpr ((CH & CH_ROW_OUT) != 0) ::granule_store(ch.yg + pair, ch.tag, pack_bf16x2(va, vb));
             } else {
                 y[row] = T::st(va);
                 if (two) y[row + 1] = T::st(vb);
@@ -787,16 +746,26 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
         } else if (EPI == EPI_QKV_ROPE) {
             // (linear-order kernels read the descriptor once, at the top, with scalar loads: eo_q)
             const qkv_epilogue* q = LNCH ? &eo_q : static_cast<const qkv_epilogue*>(resp);
-            const uint32_t hd = q->hd, half = hd / 2;
+            const uint32_t H = q->H, KV = q->KV, hd = q->hd, half = hd / 2, ms = q->max_seq;
             const uint32_t slot = LNCH ? eo_slot : (uint32_t)q->state[3], rrow = LNCH ? eo_rrow : (uint32_t)q->state[6];
             typedef const __attribute__((address_space(1))) float* gfloat_p;
-            float c = eo_c, sn = eo_s;
-            if (!early && row < (q->H + q->KV) * hd) {
-                const uint32_t j = (row % hd) / 2;
-                c = ((gfloat_p)q->fcos)[(size_t)rrow * half + j];
-                sn = ((gfloat_p)q->fsin)[(size_t)rrow * half + j];
+            typedef __attribute__((address_space(1))) S* gS_p;
+            if (row < (H + KV) * hd) {
+                // a rotation pair: packed rows (2j, 2j + 1) of a head = natural (j, j + hd/2)
+                const float x1 = T::rt(a), x2 = T::rt(b);
+                const uint32_t head = row / hd, j = (row % hd) / 2;
+                const float c = early ? eo_c : ((gfloat_p)q->fcos)[(size_t)rrow * half + j];
+                const float sn = early ? eo_s : ((gfloat_p)q->fsin)[(size_t)rrow * half + j];
+                const S o1 = T::st(c * x1 - sn * x2), o2 = T::st(sn * x1 + c * x2);
+                gS_p dst = head < H ? (gS_p)q->q_out + (size_t)head * hd
+                                    : (gS_p)q->kc + ((size_t)(head - H) * ms + slot) * hd;
+                dst[j] = o1;
+                dst[j + half] = o2;
+            } else {
+                const uint32_t vrow = row - (H + KV) * hd; // kv*hd + d
+                ((gS_p)q->vt)[(size_t)vrow * ms + slot] = T::st(a);
+                if (two) ((gS_p)q->vt)[(size_t)(vrow + 1) * ms + slot] = T::st(b);
             }
-            qkv_rope_finish<T>(*q, slot, row, two, a, b, c, sn);
         } else if (two) {
             // (w1 row j, w3 row j): out[j] = T(act(T(w1 x)) * T(w3 x))
             const float ga = T::rt(a), gb = T::rt(b);
@@ -1698,10 +1667,6 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
             if (pr < pe) do_pair(std::integral_constant<int, 0>{}, pr); // odd count: the last pair sits in the first slots
         }
         flush();
-        // chained launches: the next phase's requests go HERE, behind the stores of this one -- issued in front of them they sit in
-        // front of them in the CU's in-order memory pipe, and with the chip's memory system busy the publication of the wave's
-        // pair was delayed by up to 8 us (tools/chain_timeline.py)
-        tail_hook();
         if (EPI == EPI_STORE_PICK) pick_finish(red, nwaves);
         return;
     }

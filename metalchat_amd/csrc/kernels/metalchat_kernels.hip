@@ -5,7 +5,6 @@
 #include "gemv_kernels.hip"
 #include "decode_kernels.hip"
 #include "attn_block_kernels.hip"
-#include "chain_kernels.hip"
 #include "synth_kernels.hip"
 #include "sampler_kernels.hip"
 #include "prefill_kernels.hip"
