@@ -489,6 +489,9 @@ def main():
             pk = msk / (reps * lnk)
             per_kind[which] = {"kernel": dec.gemv_kernel_name(which), "avg_launch_us": pk * 1e3, "bytes_per_launch": byk / lnk,
                                "frac": byk / lnk / (pk * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        attn_kernel = dec.gemv_kernel_name("attn")
+        if attn_kernel.startswith("mc_attn_wo_"):
+            per_kind["wo"]["note"] = f"stand-alone launch, timed for reference: in the token this GEMV runs inside {attn_kernel}"
         kname = dec.gemv_kernel_name("w13")  # the name decoder.cc gemv() selects, asked of the decoder itself
         out["roofline"] = {
             "bound": "hbm", "kernel": f"{kname} (w1|w3 fused, per launch)", "achieved": achieved,
@@ -496,6 +499,7 @@ def main():
             "traffic": pmc_traffic(kname),
             "bytes_per_launch": by / ln, "avg_launch_us": per * 1e3,
             "other_gemvs": per_kind,
+            "attention_kernel": attn_kernel,
             "all_gemv": {"achieved": by_all * reps / (ms_all * 1e-3) / 1e9,
                          "frac": by_all * reps / (ms_all * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "bytes_per_token": by_all, "ms_per_token": ms_all / reps,

@@ -316,7 +316,9 @@ size_t mc_decoder_weight_bytes(const mc_decoder* d);
 mc_status mc_decoder_time_gemv(mc_decoder* d, const char* which, int32_t repeats, float* total_ms,
                                double* bytes_per_pass, int32_t* launches_per_pass);
 /* Host name of the kernel mc_decoder_time_gemv(which) launches -- the variant a token really runs (linear-order
- * kernels, prologue / epilogue codes, the greedy pick inside the head).  Launches nothing. */
+ * kernels, prologue / epilogue codes, the greedy pick inside the head).  which = "attn": the decode attention kernel(s) of
+ * the first owned block ("mc_attn_wo_i4_*" carries the Wo GEMV: the token then launches no Wo GEMV of its own and
+ * time_gemv("wo") measures a stand-alone launch).  Launches nothing. */
 mc_status mc_decoder_gemv_kernel_name(mc_decoder* d, const char* which, char* buf, size_t cap);
 /* Test aid: record the host names of every kernel the decoder launches from now on (enable = 1 clears the log and
  * drops a captured token graph, whose replay would launch without passing here; 0 stops recording).

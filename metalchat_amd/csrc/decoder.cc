@@ -1992,6 +1992,20 @@ mc_decoder_gemv_kernel_name(mc_decoder* d, const char* which, char* buf, size_t 
 {
     if (!d || !which || !buf || !cap) return fail(MC_ERR_INVALID_ARGUMENT, "mc_decoder_gemv_kernel_name: bad argument");
     std::string name;
+    if (std::string(which) == "attn") {
+        // the decode attention of the first owned block: one launch with Wo, one launch, or scores + P.V (run_layers)
+        mc_status s0 = check_ready(d);
+        if (s0 != MC_OK) return s0;
+        if (d->layers.empty()) return fail(MC_ERR_INVALID_ARGUMENT, "mc_decoder_gemv_kernel_name: this stage owns no block");
+        const linear_w& wo = d->layers[0].wo;
+        name = d->attn_wo_fused(wo) ? "mc_attn_wo_i4_" + d->tname + "_hd" + std::to_string(d->cfg.head_dim) + "_k" + std::to_string(wo.in / 2048)
+               : d->attn_fused()    ? "mc_attn_fused_" + d->tname
+                                    : "mc_attn_scores_" + d->tname + " + mc_attn_pv_" + d->tname;
+        const size_t n0 = std::min(cap - 1, name.size());
+        memcpy(buf, name.data(), n0);
+        buf[n0] = 0;
+        return MC_OK;
+    }
     d->capture_name = &name;
     float ms = 0.0f;
     mc_status s = mc_decoder_time_gemv(d, which, 1, &ms, nullptr, nullptr);

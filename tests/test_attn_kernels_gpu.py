@@ -128,3 +128,49 @@ def test_two_launch_attention_matches_the_oracle(acc, H, KV, hd, max_seq, n):
         got = out.download(np.uint16, H * hd)
         parity.check(BF16, got, ref, rel=2e-3, max_ulp=1, max_frac=0.03, scale_aware=True,
                      what=f"two-launch attention H{H} KV{KV} hd{hd} n{n} ranges {ranges}")
+
+
+def test_a_hand_off_whose_producers_never_run_gives_up_and_reports(acc):
+    """The waits inside a launch are bounded (handoff.h: 2 s of s_memrealtime, then state.err is set and every later wait of the
+    token returns at once).  Here half of the workgroups of mc_attn_fused_bfloat are simply not launched: the others wait for
+    partial denominators nobody will publish, must come back within the bound with the error word set (what
+    mc_decoder_step / _generate turn into MC_ERR_RUNTIME, decoder.cc check_handoffs) -- and the same buffers serve a complete
+    launch of the next step correctly."""
+    import time
+
+    import metalchat_amd as mc
+
+    H, KV, hd, max_seq, n = 32, 8, 128, 2048, 2048
+    rng = np.random.default_rng(5)
+    n_rep, nsplit = H // KV, max_seq // PB
+    q = mo.encode(BF16, rng.normal(0, 1, (H, hd)).astype(np.float32))
+    k = mo.encode(BF16, rng.normal(0, 0.4, (n, KV, hd)).astype(np.float32))
+    v = mo.encode(BF16, rng.normal(0, 0.5, (n, KV, hd)).astype(np.float32))
+    scale = float(mo.from_bf16(mo.to_bf16(np.array([hd ** -0.5], np.float32)))[0])
+    kc, vt = device_caches(acc, k, v, max_seq)
+    qb = acc.to_device(q.reshape(-1))
+    out = acc.alloc(H * hd * 2)
+    psum = acc.to_device(np.zeros(H * nsplit, np.uint64))
+    slab = acc.to_device(np.zeros(H * hd * nsplit, np.uint64))
+    kern = acc.load("mc_attn_fused_bfloat")
+
+    def launch(state, wgs):
+        mc.KernelTask(kern, (wgs * 256, 1, 1), (256, 1, 1),
+                      [qb, kc, vt, out, psum, slab, state, np.uint32(n_rep), np.uint32(KV), np.uint32(hd), np.uint32(max_seq),
+                       np.float32(scale), np.uint32(nsplit), np.uint32(1), None])()
+        acc.wait()
+
+    state = state_buffer(acc, n, 1)
+    t0 = time.perf_counter()
+    launch(state, nsplit * KV // 2)          # the ranges 16..31 of every kv head are missing
+    took = time.perf_counter() - t0
+    err = int(state.download(np.int32, 12)[10]) & 0xFFFFFFFF
+    assert err != 0, "the launch must report the hand-off it gave up on"
+    assert 1.0 < took < 8.0, f"bounded wait: {took:.2f} s"
+    # the next step (a new epoch): complete grid, same granule buffers, a clean state
+    state = state_buffer(acc, n, 2)
+    launch(state, nsplit * KV)
+    assert int(state.download(np.int32, 12)[10]) == 0
+    got = out.download(np.uint16, H * hd)
+    parity.check(BF16, got, oracle_attention(q, k, v, n_rep, scale), rel=2e-3, max_ulp=1, max_frac=0.03, scale_aware=True,
+                 what="one-launch attention after a launch that gave up")
