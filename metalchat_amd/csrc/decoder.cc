@@ -537,14 +537,15 @@ struct mc_decoder {
     }
 
     // ... with the Wo GEMV and its residual in the same launch (attn_block_kernels.hip): int4 weights on bfloat rows with scale
-    // groups of whole lane blocks, K = H * hd of 1, 2 or 4 KiB per row in one of the built (head_dim, K) pairs, no adaptor, at
+    // groups of whole lane blocks, K = H * hd of 1 or 2 KiB per row in one of the built (head_dim, K) pairs, no adaptor, at
     // most two row pairs per wave of the launch
     bool
     attn_wo_fused(const linear_w& wo) const
     {
         if (!attn_wo_on || !attn_fused() || !lin_ok(wo) || wo.lora_cols || wo.out % 2 != 0) return false;
         const int hd = cfg.head_dim, k = wo.in / 2048;
-        const bool built = (hd == 128 && (k == 2 || k == 4)) || (hd == 64 && k == 1) || (hd == 256 && k == 2);
+        // (K = 8192, Llama-3-70B: measured slower than the two launches -- attn_block_kernels.hip)
+        const bool built = (hd == 128 && k == 2) || (hd == 64 && k == 1) || (hd == 256 && k == 2);
         // (one 512-thread workgroup per CU: the kernels hold up to 132 VGPRs, two such workgroups would not be resident together)
         return built && wo.in == cfg.n_heads * hd && (unsigned)wo.out / 2 <= 2u * 8u * (unsigned)(nsplit * cfg.n_kv_heads) &&
                (unsigned)(nsplit * cfg.n_kv_heads) <= (unsigned)dev->prop.multiProcessorCount;

@@ -233,8 +233,9 @@ def test_llama3_70b_widths_one_block(acc):
     agree = run_injected(acc, cfg, weights, 2042, 10, dict(weight_format=mc.WFMT_I4, group_size=128), rel_logits=5e-3,
                          max_ulp=2, max_frac=0.7, what="70B widths S=2048", launched=names)
     assert agree >= 9
-    assert {"mc_gemv_i4_bfloat_lin4_p1_e4", "mc_attn_wo_i4_bfloat_hd128_k4", "mc_gemv_i4_bfloat_lin4_p1_e2", "mc_gemv_i4_bfloat_lin14_p0_e1",
-            "mc_gemv_i4_bfloat_lin4_p1_e5"} <= names, sorted(names)
+    # (K = 8192: the Wo GEMV stays a launch of its own behind the one-launch attention -- attn_block_kernels.hip)
+    assert {"mc_gemv_i4_bfloat_lin4_p1_e4", "mc_attn_fused_bfloat", "mc_gemv_i4_bfloat_lin4_p0_e1", "mc_gemv_i4_bfloat_lin4_p1_e2",
+            "mc_gemv_i4_bfloat_lin14_p0_e1", "mc_gemv_i4_bfloat_lin4_p1_e5"} <= names, sorted(names)
 
 
 @pytest.mark.parametrize("taps", [True, False])
@@ -382,7 +383,7 @@ def test_one_launch_attention_against_the_two_launch_form(acc, monkeypatch, shap
     assert same >= len(out["1"]) - 2, (shape, same)
 
 
-@pytest.mark.parametrize("shape", ["llama3-8b", "llama3-70b", "hd64", "gemma-hd256"])
+@pytest.mark.parametrize("shape", ["llama3-8b", "hd64", "gemma-hd256"])
 def test_attention_and_wo_in_one_launch_equal_the_two_launches_bit_for_bit(acc, monkeypatch, shape):
     # mc_attn_wo_i4_bfloat_* = mc_attn_fused_bfloat + the Wo GEMV (attn_block_kernels.hip): the same attention phases, the same row, the same per-row arithmetic -- hidden rows, logits, caches and tokens must be IDENTICAL to the two launches, near an empty
     # cache and across the end of a full one; the launch log shows which form ran.
@@ -392,10 +393,6 @@ def test_attention_and_wo_in_one_launch_equal_the_two_launches_bit_for_bit(acc, 
     if shape == "llama3-8b":
         cfg = dict(base, max_seq_len=2048, **FULL_WIDTH["llama3-8b"])
         kernel = "mc_attn_wo_i4_bfloat_hd128_k2"
-    elif shape == "llama3-70b":
-        cfg = dict(base, max_seq_len=2048, family=0, dim=8192, n_heads=64, n_kv_heads=8, head_dim=128, ffn_dim=4096, rope_theta=500000.0,
-                   attn_scale=128 ** -0.5)   # (a narrow ffn: the test is about the attention block)
-        kernel = "mc_attn_wo_i4_bfloat_hd128_k4"
     elif shape == "hd64":
         cfg = dict(base, max_seq_len=2048, family=0, dim=2048, n_heads=32, n_kv_heads=8, head_dim=64, ffn_dim=4096, rope_theta=10000.0,
                    attn_scale=64 ** -0.5)

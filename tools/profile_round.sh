@@ -26,15 +26,16 @@ if [ $WHAT = all ] || [ $WHAT = traffic ]; then
     done
     python3 /root/repo/tools/pmc_traffic.py /tmp/p_FETCH_SIZE /tmp/p_WRITE_SIZE > $OUT/${R}_pmc_${P}.json
   done
-  grep -A4 "mc_attn_fused\|lin2_p1_e2" $OUT/${R}_pmc_*.json | head -30
+  grep -A4 "mc_attn_wo\|mc_attn_fused\|lin2_p1_e2" $OUT/${R}_pmc_*.json | head -40
 fi
 if [ $WHAT = all ] || [ $WHAT = mfma ]; then
   : > $OUT/${R}_pmc_attn_mfma.log
-  for F in 1 0; do
+  # the three forms of the decode attention: one launch with Wo (default), one launch (MC_ATTN_WO=0), scores + P.V (MC_ATTN_FUSED=0)
+  for F in "MC_ATTN_WO=1" "MC_ATTN_WO=0" "MC_ATTN_FUSED=0"; do
     for G in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_MFMA" "SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY" "GRBM_GUI_ACTIVE"; do
-      rm -rf /tmp/pq; MC_ATTN_FUSED=$F rocprofv3 --pmc $G --output-format csv -d /tmp/pq -- python3 /root/repo/tools/pmc_attn_decode.py > /dev/null 2> /tmp/pq.err
-      echo "== MC_ATTN_FUSED=$F  $G" >> $OUT/${R}_pmc_attn_mfma.log
-      for K in mc_attn_fused_bfloat mc_attn_scores_bfloat mc_attn_pv_bfloat; do python3 /root/repo/tools/pmc_summary.py /tmp/pq $K 2>/dev/null | tail -6 >> $OUT/${R}_pmc_attn_mfma.log; done
+      rm -rf /tmp/pq; export $F; rocprofv3 --pmc $G --output-format csv -d /tmp/pq -- python3 /root/repo/tools/pmc_attn_decode.py > /dev/null 2> /tmp/pq.err; unset MC_ATTN_WO MC_ATTN_FUSED
+      echo "== $F  $G" >> $OUT/${R}_pmc_attn_mfma.log
+      for K in mc_attn_wo_i4_bfloat mc_attn_fused_bfloat mc_attn_scores_bfloat mc_attn_pv_bfloat; do python3 /root/repo/tools/pmc_summary.py /tmp/pq $K 2>/dev/null | tail -6 >> $OUT/${R}_pmc_attn_mfma.log; done
     done
   done
   cat $OUT/${R}_pmc_attn_mfma.log
