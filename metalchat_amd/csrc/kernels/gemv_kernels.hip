@@ -37,6 +37,17 @@ using namespace mc::gemv;
         body<WF_I4, BF, Q_M4D, PRO, EPI, 4, __VA_ARGS__, MC_LIN_WAVES>(                           \
             w, scales, x, y, res, norm_w, out_rows, in, group, eps, mu, lora_a, lora_b, lora_rank, lora_scale); \
     }
+// (the pick epilogue keeps one key per workgroup in eight waves' scratch: tuning builds with larger workgroups go without it,
+//  and the host then leaves the pick to mc_argmax_T -- decoder.cc head_pick())
+#if MC_LIN_WAVES <= 8
+#define MC_GEMV_LIN_PICK(PFX, ...)              \
+    MC_GEMV_LIN(PFX##_p1_e5, 1, 5, __VA_ARGS__) \
+    MC_GEMV_LIN(PFX##_p2_e5, 2, 5, __VA_ARGS__)
+#define MC_GEMV_LING_PICK(PFX, WF, NCH) MC_GEMV_LING(PFX##_p1_e5, WF, 1, 5, NCH)
+#else
+#define MC_GEMV_LIN_PICK(PFX, ...)
+#define MC_GEMV_LING_PICK(PFX, WF, NCH)
+#endif
 #define MC_GEMV_LIN_SET(PFX, ...)               \
     MC_GEMV_LIN(PFX##_p0_e0, 0, 0, __VA_ARGS__) \
     MC_GEMV_LIN(PFX##_p1_e0, 1, 0, __VA_ARGS__) \
@@ -48,8 +59,7 @@ using namespace mc::gemv;
     MC_GEMV_LIN(PFX##_p2_e3, 2, 3, __VA_ARGS__) \
     MC_GEMV_LIN(PFX##_p3_e0, 3, 0, __VA_ARGS__) \
     MC_GEMV_LIN(PFX##_p3_e1, 3, 1, __VA_ARGS__) \
-    MC_GEMV_LIN(PFX##_p1_e5, 1, 5, __VA_ARGS__) \
-    MC_GEMV_LIN(PFX##_p2_e5, 2, 5, __VA_ARGS__)
+    MC_GEMV_LIN_PICK(PFX, __VA_ARGS__)
 
 #define MC_GEMV_SET(PFX, WF, T, QM)            \
     MC_GEMV(PFX##_p0_e0, WF, T, QM, 0, 0)      \
@@ -135,7 +145,7 @@ MC_GEMV_LIN_SET(mc_gemv_i4_bfloat_lin14, MC_LIN14_CFG) // K = 28672
     MC_GEMV_LING(PFX##_p1_e4, WF, 1, 4, NCH)    \
     MC_GEMV_LING(PFX##_p3_e0, WF, 3, 0, NCH)    \
     MC_GEMV_LING(PFX##_p3_e1, WF, 3, 1, NCH)    \
-    MC_GEMV_LING(PFX##_p1_e5, WF, 1, 5, NCH)
+    MC_GEMV_LING_PICK(PFX, WF, NCH)
 #if MC_LIN_WAVES
 MC_GEMV_LING_SET(mc_gemv_i8_bfloat_ling4, WF_I8, 4)   // K = 4096
 // (K = 14336 int8 rows on the VALU path: 14 x 8 VGPRs of activations do not fit in registers, the unrolled pair takes 241 VGPRs and the
