@@ -2145,6 +2145,7 @@ struct rccl_api {
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr; // optional
     ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
@@ -2176,6 +2177,7 @@ rccl()
     SYM(AllReduce, "ncclAllReduce")
     SYM(GetErrorString, "ncclGetErrorString")
 #undef SYM
+    api.CommAbort = reinterpret_cast<decltype(api.CommAbort)>(dlsym(api.handle, "ncclCommAbort"));
     return api;
 }
 
@@ -2202,6 +2204,29 @@ struct mc_pipeline {
     size_t rows_cap = 0;
     bool local = false;
 };
+
+namespace {
+// RCCL transport: a stage that fails BETWEEN its hops (an allocation, a launch, a hand-off that gave up) must not leave its peers
+// waiting in ncclRecv for a row that will never come: the communicator is aborted -- their pending operations then fail instead
+// of blocking -- and this pipeline object refuses further work.  (Argument errors never get here: every rank validates the same
+// arguments before the first hop.)
+mc_status
+rccl_give_up(mc_pipeline* p, mc_status s)
+{
+    if (p->comm && rccl().CommAbort) {
+        (void)rccl().CommAbort(p->comm);
+        p->comm = nullptr;
+    }
+    return s;
+}
+mc_status
+rccl_usable(const mc_pipeline* p)
+{
+    if (!p->local && p->world > 1 && !p->comm)
+        return fail(MC_ERR_RUNTIME, "pipeline: the communicator was aborted after a stage failed; create a new pipeline");
+    return MC_OK;
+}
+} // namespace
 
 extern "C" {
 
@@ -2373,6 +2398,8 @@ mc_pipeline_generate(mc_pipeline* p, int32_t first_token, int32_t start_pos, int
         return MC_OK;
     }
     // ---- RCCL: this process is stage `rank`
+    s = rccl_usable(p);
+    if (s != MC_OK) return s;
     rccl_api& api = rccl();
     mc_decoder* d = p->stages[0];
     const int r = p->rank;
@@ -2382,7 +2409,7 @@ mc_pipeline_generate(mc_pipeline* p, int32_t first_token, int32_t start_pos, int
         if (r > 0) MC_NCCL(api.Recv(d->hidden_in, row, ncclUint8, r - 1, p->comm, d->stream), "ncclRecv(hidden row)");
         else if (i > 0 && W > 1) MC_NCCL(api.Recv(&d->state->token, 1, ncclInt32, W - 1, p->comm, d->stream), "ncclRecv(token)");
         s = stage_token(d, i, first_token, start_pos);
-        if (s != MC_OK) return s;
+        if (s != MC_OK) return rccl_give_up(p, s);
         if (r < W - 1) MC_NCCL(api.Send(d->hidden, row, ncclUint8, r + 1, p->comm, d->stream), "ncclSend(hidden row)");
         else if (W > 1 && i + 1 < n) MC_NCCL(api.Send(&d->state->token, 1, ncclInt32, 0, p->comm, d->stream), "ncclSend(token)");
     }
@@ -2425,6 +2452,8 @@ mc_pipeline_prefill(mc_pipeline* p, const int32_t* tokens, int32_t len, int32_t 
         }
         return MC_OK;
     }
+    s = rccl_usable(p);
+    if (s != MC_OK) return s;
     rccl_api& api = rccl();
     mc_decoder* d = p->stages[0];
     const int r = p->rank;
@@ -2441,7 +2470,7 @@ mc_pipeline_prefill(mc_pipeline* p, const int32_t* tokens, int32_t len, int32_t 
     }
     void* out = nullptr;
     s = mc_decoder_prefill_stage(d, r == 0 ? tokens : nullptr, p->rows_in, len, start_pos, sliding_window, &out, nullptr);
-    if (s != MC_OK) return s;
+    if (s != MC_OK) return rccl_give_up(p, s);
     if (r < W - 1) MC_NCCL(api.Send(out, bytes, ncclUint8, r + 1, p->comm, d->stream), "ncclSend(prompt rows)");
     if (W > 1 && r == W - 1) MC_NCCL(api.Send(&d->state->token, 1, ncclInt32, 0, p->comm, d->stream), "ncclSend(token)");
     if (W > 1 && r == 0) MC_NCCL(api.Recv(&d->state->token, 1, ncclInt32, W - 1, p->comm, d->stream), "ncclRecv(token)");
@@ -2461,6 +2490,8 @@ mc_pipeline_allreduce_max(mc_pipeline* p, double* value)
         MC_HIP(hipStreamSynchronize(d->stream));
     }
     if (p->local || p->world == 1) return MC_OK;
+    mc_status su = rccl_usable(p);
+    if (su != MC_OK) return su;
     rccl_api& api = rccl();
     mc_decoder* d = p->stages[0];
     MC_HIP(hipMemcpyAsync(p->red, value, 8, hipMemcpyHostToDevice, d->stream));
