@@ -383,7 +383,7 @@ def test_one_launch_attention_against_the_two_launch_form(acc, monkeypatch, shap
     assert same >= len(out["1"]) - 2, (shape, same)
 
 
-@pytest.mark.parametrize("shape", ["llama3-8b", "hd64", "gemma-hd256"])
+@pytest.mark.parametrize("shape", ["llama3-8b", "llama3-8b-1024", "llama3-8b-768", "hd64", "gemma-hd256"])
 def test_attention_and_wo_in_one_launch_equal_the_two_launches_bit_for_bit(acc, monkeypatch, shape):
     # mc_attn_wo_i4_bfloat_* = mc_attn_fused_bfloat + the Wo GEMV (attn_block_kernels.hip): the same attention phases, the same row, the same per-row arithmetic -- hidden rows, logits, caches and tokens must be IDENTICAL to the two launches, near an empty
     # cache and across the end of a full one; the launch log shows which form ran.
@@ -393,6 +393,12 @@ def test_attention_and_wo_in_one_launch_equal_the_two_launches_bit_for_bit(acc, 
     if shape == "llama3-8b":
         cfg = dict(base, max_seq_len=2048, **FULL_WIDTH["llama3-8b"])
         kernel = "mc_attn_wo_i4_bfloat_hd128_k2"
+    elif shape == "llama3-8b-1024":  # 128 workgroups: every wave owns TWO row pairs of Wo (the most the kernel holds)
+        cfg = dict(base, max_seq_len=1024, **FULL_WIDTH["llama3-8b"])
+        kernel = "mc_attn_wo_i4_bfloat_hd128_k2"
+    elif shape == "llama3-8b-768":   # 96 workgroups: 768 waves for 2048 pairs -- two or three pairs per wave: the host must not take it
+        cfg = dict(base, max_seq_len=768, **FULL_WIDTH["llama3-8b"])
+        kernel = None
     elif shape == "hd64":
         cfg = dict(base, max_seq_len=2048, family=0, dim=2048, n_heads=32, n_kv_heads=8, head_dim=64, ffn_dim=4096, rope_theta=10000.0,
                    attn_scale=64 ** -0.5)
@@ -424,8 +430,11 @@ def test_attention_and_wo_in_one_launch_equal_the_two_launches_bit_for_bit(acc, 
                 rows.append((tok, dec.logits().copy(), np.stack([dec.hidden(l) for l in range(-1, cfg["n_layers"])])))
         kk, vv = dec.export_kv(cfg["n_layers"] - 1)
         names = set(dec.launched())
-        assert (kernel in names) == (form != "sep"), sorted(names)
-        assert ("mc_attn_fused_bfloat" in names) == (form == "sep"), sorted(names)
+        if kernel is None:   # a shape the one-launch form with Wo does not cover: both forms are attention + a Wo launch
+            assert not any(n.startswith("mc_attn_wo_") for n in names) and "mc_attn_fused_bfloat" in names, sorted(names)
+        else:
+            assert (kernel in names) == (form != "sep"), sorted(names)
+            assert ("mc_attn_fused_bfloat" in names) == (form == "sep"), sorted(names)
         out[form] = (rows, kk, vv)
         dec.release()
     for form in ("wo",):
