@@ -91,7 +91,10 @@ attn_wo_body(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const 
         for (;;) { // (one watched granule and ~ 0.4 us between looks while the row is not there: chain_kernels.hip)
             const bool seen = (uint32_t)(granule_load(row_g + tid + 512u * (NG - 1)) >> 32) == epoch_tag;
             if (__all(seen) || w.expired(st, 0xC0000000u | layer_tag)) break;
-            __builtin_amdgcn_s_sleep(16);
+#ifndef MC_HANDOFF_C_SLEEP
+#define MC_HANDOFF_C_SLEEP 16
+#endif
+            __builtin_amdgcn_s_sleep(MC_HANDOFF_C_SLEEP);
         }
         for (;;) {
             bool ok = true;

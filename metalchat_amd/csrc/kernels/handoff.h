@@ -48,7 +48,10 @@ struct handoff_wait {
     __device__ __forceinline__ bool
     expired(step_state* st, uint32_t code)
     {
-        __builtin_amdgcn_s_sleep(4);
+#ifndef MC_HANDOFF_SLEEP
+#define MC_HANDOFF_SLEEP 4 // x 64 cycles between two looks of a waiting wave (tuning builds: tools/experiments/README.md)
+#endif
+        __builtin_amdgcn_s_sleep(MC_HANDOFF_SLEEP);
         if ((++spins & 63u) != 0) return false;
         if (__hip_atomic_load((gu32_t*)&st->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return true;
         if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { // 2 s at 100 MHz
