@@ -7,8 +7,8 @@
 //   nn::attention::operator()     include/metalchat/nn/attention.h:161-206
 //   nn::sink_cache / nn::rope     include/metalchat/nn/cache.h:96-232, nn/embedding.h:107-200
 //   transformer<Layer>::transform include/metalchat/transformer.h:357-364
-// Instead of ~1000 one-op launches and as many allocations per token it issues 6 launches per
-// layer (llama3) on one in-order stream over a pre-allocated arena, keeps the token / position state in
+// Instead of ~1000 one-op launches and as many allocations per token it issues 4 to 6 launches per
+// layer (llama3: wq|wk|wv, attention + Wo, w1|w3, w2 for the headline shapes -- run_layers) on one in-order stream over a pre-allocated arena, keeps the token / position state in
 // HBM so successive steps chain without a host round trip, and (optionally) replays one captured
 // hipGraph per token.
 #include "backend_impl.h"
