@@ -12,8 +12,10 @@ in the middle of a 64-slot range / 16-slot tile."""
 import numpy as np
 import pytest
 
+import modelgen as mg
 import parity
 from oracle import mc_oracle as mo
+from test_gemv_gpu import oracle_linear
 
 pytestmark = pytest.mark.gpu
 BF16 = 0
@@ -174,3 +176,61 @@ def test_a_hand_off_whose_producers_never_run_gives_up_and_reports(acc):
     got = out.download(np.uint16, H * hd)
     parity.check(BF16, got, oracle_attention(q, k, v, n_rep, scale), rel=2e-3, max_ulp=1, max_frac=0.03, scale_aware=True,
                  what="one-launch attention after a launch that gave up")
+
+
+@pytest.mark.parametrize("shape,n", [("llama3-8b", 2048), ("llama3-8b", 1000), ("llama3-8b", 3), ("hd64", 2047), ("llama3-8b-1024", 1024)])
+def test_attention_and_wo_in_one_launch_matches_the_oracle(acc, shape, n):
+    """`mc_attn_wo_i4_bfloat_*` (attn_block_kernels.hip: the decode attention AND the Wo GEMV + residual of one block,
+    nn/attention.h:191-205 + nn/transformer.h:132-133) launched BY NAME on a query row, a cache and a hidden row of its own, against
+    the oracle's kernels composed as the reference composes them: the attention above, hadamard_broadcast + bmm for Wo
+    (quantization/lora.h:94-122), add in T (kernel/arithmetic.metal:13-46).  The attention row may differ from the oracle's in the
+    last place of a few elements (the order of the fp32 sums): the composition bound of the suite, two steps at the row's scale.
+    The attention row the launch leaves in HBM is held to the single-kernel bound."""
+    import metalchat_amd as mc
+
+    if shape == "hd64":
+        H, KV, hd, dim, max_seq = 32, 8, 64, 2048, 2048
+    elif shape == "llama3-8b-1024":   # 128 workgroups: two row pairs of Wo per wave
+        H, KV, hd, dim, max_seq = 32, 8, 128, 4096, 1024
+    else:
+        H, KV, hd, dim, max_seq = 32, 8, 128, 4096, 2048
+    cfg = mg.tiny_cfg(BF16, dim=dim, n_heads=H, n_kv_heads=KV, head_dim=hd, ffn_dim=256, n_layers=1, vocab=64, max_seq_len=max_seq)
+    w = mg.make_model(cfg, seed=77 + hd, quant="i4", group=128)
+    dec = mc.Decoder(acc, **mg.decoder_kwargs(cfg, weight_format=mc.WFMT_I4, group_size=128))
+    dec.load_model(w)
+    wptr, sptr, rows, inf, ng = dec.weight_ptrs(0, "wo")
+    assert (rows, inf) == (dim, H * hd)
+    rng = np.random.default_rng(H + hd + n)
+    n_rep, nsplit = H // KV, (max_seq + PB - 1) // PB
+    q = mo.encode(BF16, rng.normal(0, 1, (H, hd)).astype(np.float32))
+    k = mo.encode(BF16, rng.normal(0, 0.4, (n, KV, hd)).astype(np.float32))
+    v = mo.encode(BF16, rng.normal(0, 0.5, (n, KV, hd)).astype(np.float32))
+    hidden = mo.encode(BF16, rng.normal(0, 1, dim).astype(np.float32))
+    scale = float(mo.from_bf16(mo.to_bf16(np.array([hd ** -0.5], np.float32)))[0])
+    att = oracle_attention(q, k, v, n_rep, scale)
+    proj = oracle_linear(BF16, w["layers"][0]["wo"], att.reshape(1, 1, -1))
+    L = mo.layout
+    ref = np.zeros((1, dim), np.uint16)
+    mo.add(BF16, L((1, dim)), ref, L((1, dim)), hidden.reshape(1, -1), L((1, dim)), proj.reshape(1, -1))
+    kc, vt = device_caches(acc, k, v, max_seq)
+    qb = acc.to_device(q.reshape(-1))
+    psum = acc.to_device(np.zeros(H * nsplit, np.uint64))
+    slab = acc.to_device(np.zeros(H * hd * nsplit, np.uint64))
+    row_g = acc.to_device(np.zeros(H * hd // 2, np.uint64))
+    attn_out = acc.alloc(H * hd * 2)
+    kern = acc.load(f"mc_attn_wo_i4_bfloat_hd{hd}_k{H * hd // 2048}")
+    W = lambda p_: acc.wrap(p_, 1 << 40)
+    for epoch, layer_tag in ((1, 1), (1, 2), (9, 200)):   # consecutive launches of a token, a later token: the same granule buffers
+        hb = acc.to_device(hidden)                        # read as the residual and overwritten IN PLACE, as the decoder launches it
+        attn_out.upload(np.zeros(H * hd, np.uint16))
+        state = state_buffer(acc, n, epoch)
+        mc.KernelTask(kern, (nsplit * KV * 512, 1, 1), (512, 1, 1),
+                      [qb, kc, vt, attn_out, psum, slab, row_g, state, np.uint32(n_rep), np.uint32(KV), np.uint32(max_seq), np.float32(scale),
+                       np.uint32(nsplit), np.uint32(layer_tag), W(wptr), W(sptr), hb, hb, np.uint32(dim), np.uint32(128), np.uint32(1)])()
+        acc.wait()
+        assert int(state.download(np.int32, 12)[10]) == 0, "a hand-off of the launch gave up"
+        parity.check(BF16, attn_out.download(np.uint16, H * hd), att, rel=2e-3, max_ulp=1, max_frac=0.03, scale_aware=True,
+                     what=f"attention row of the one launch, {shape} n{n} tag ({epoch}, {layer_tag})")
+        parity.check(BF16, hb.download(np.uint16, dim), ref.reshape(-1), rel=4e-3, max_ulp=2, max_frac=0.3, scale_aware=True,
+                     what=f"attention + Wo + residual in one launch, {shape} n{n} tag ({epoch}, {layer_tag})")
+    dec.release()
