@@ -136,6 +136,28 @@ def test_whole_decoder_properties_at_full_size(acc):
         d.release()
 
 
+def test_graph_replay_equals_eager_at_the_benchmark_context(acc):
+    # bench.py's own configuration -- 32 blocks, 2048 slots, hipGraph replay, the four-launch layer with the attention, its two
+    # in-launch hand-offs, the third one and the Wo GEMV in ONE launch (mc_attn_wo_i4_bfloat_hd128_k2) -- from an empty cache to 64
+    # tokens past its end (the sink ring turns): 67 584 launches with hand-offs per path, every one of which must find this
+    # step's tags; the replayed graph must produce the eager launches' tokens, and the caches must be identical.
+    n = 2048 + 64
+    eager = make(acc, 32, max_seq_len=2048, use_graph=0)
+    eager.launch_log(True)
+    chain = list(eager.generate(7, 0, n))
+    names = set(eager.launched())
+    assert "mc_attn_wo_i4_bfloat_hd128_k2" in names and "mc_gemv_i4_bfloat_lin2_p1_e2" in names, sorted(names)
+    assert not [x for x in names if x.startswith("mc_attn_scores") or x == "mc_attn_fused_bfloat"], sorted(names)
+    ke, ve = eager.export_kv(17)
+    eager.release()
+    graph = make(acc, 32, max_seq_len=2048, use_graph=1)
+    assert list(graph.generate(7, 0, n)) == chain
+    kg, vg = graph.export_kv(17)
+    assert np.array_equal(ke, kg) and np.array_equal(ve, vg)
+    assert len(set(chain)) > 4                                           # not a degenerate constant stream
+    graph.release()
+
+
 def test_prompt_pass_equals_token_by_token_at_full_size(acc):
     # 96 prompt rows through the 128 x 128 MFMA GEMMs (split-K on Wo / w2 / QKV at this length) and
     # the fused attention, against the same tokens fed one at a time through the decode path of a
