@@ -36,14 +36,15 @@ attn_wo_body(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const 
     __shared__ __attribute__((aligned(16))) char xs[LNCH * CHUNK_LDS];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    // ---- the Wo row pairs of this wave: equal contiguous spans of pairs per wave over the whole launch, at most PMAX each (the
+    // ---- the Wo row pairs of this wave: contiguous spans dealt as the linear-order kernels deal theirs, at most PMAX each (the
     // host takes this kernel only then).  Their weights are requested BEHIND the scores (attn_fused_bf's hook): at the start of the
     // launch they queue in front of the K tile in the CU's memory pipe (measured: 720 tokens/s against 732 with the Wo GEMV as a
     // launch of its own); behind the scores the hand-offs of the attention cover them.
     constexpr int PMAX = 2;
-    const uint32_t NP = out_rows / 2, nw_total = gridDim.x * 8u, gw = blockIdx.x * 8u + wave;
-    const uint32_t pq = NP / nw_total, prem = NP - pq * nw_total;
-    const uint32_t pb = gw * pq + min(gw, prem), pe = pb + pq + (gw < prem ? 1u : 0u);
+    const uint32_t NP = out_rows / 2;
+    uint32_t pb, pe;
+    static_assert(MC_LIN_FAVOUR < 63, "with at most 16 pairs per workgroup (the host's condition) no wave may get a third");
+    lin_deal<8>(NP, wave, 8u, pb, pe); // (gemv.h: the same pairs per workgroup, a remainder to waves 0-3 first)
     const uint32_t glog = group ? 31u - __builtin_clz(group) : 31u, ngroups = group ? K >> glog : 1u;
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     uint4 ww[PMAX][2][LNCH];

@@ -542,6 +542,44 @@ template <int R> struct tile {
 };
 
 // ------------------------------------------------------------------------------------------
+// The deal of the row pairs of a linear-order launch: wave `wave` of this workgroup sweeps pairs [pb, pe).
+// Measured with per-wave time stamps (tools/gemv_phase_timeline.py, every launch of every matrix): with two waves per SIMD the one
+// that arrived first (waves 0-3 of the workgroup) is served first by the SIMD's arbiter -- on w1|w3 it finished its 7 pairs in
+// 8.1 us, the other (waves 4-7) in 10.4, the last 2.2 us alone on its SIMD with nothing to overlap its dequantisation chain with.
+// So (1) every WORKGROUP gets the same number of pairs to within one (round 2 gave the remainder to the first waves of the
+// LAUNCH: wq|wk|wv's 3072 pairs were two per wave on CUs 0-127 and one per wave on CUs 128-255), (2) a workgroup's remainder
+// goes to waves 0-3 first, and (3) waves 0-3 take MC_LIN_FAVOUR percent of the pairs a SIMD's two waves share, so that both
+// finish together: 60 % = (8, 6) of w1|w3's 14.  Same box, tokens/s of Llama-3-8B int4: round-2 deal 759 / 748, 50 % 770,
+// 60 % 777 / 779, 65 % 754, 70 % 750; w1|w3 12.65 -> 12.22 us, wq|wk|wv 6.41 -> 5.8-6.1, head 47.9 -> 44.1.
+// Spans stay contiguous and in address order; which wave multiplies a pair does not change a bit of it.
+#ifndef MC_LIN_FAVOUR
+#define MC_LIN_FAVOUR 60 // -1: the round-2 deal
+#endif
+template <int LWAVES>
+__device__ __forceinline__ void
+lin_deal(uint32_t NP, uint32_t wave, uint32_t nwaves, uint32_t& pb, uint32_t& pe)
+{
+    if constexpr (LWAVES == 8 && MC_LIN_FAVOUR >= 0) {
+        const uint32_t G = gridDim.x, wq = NP / G, wrem = NP - wq * G;
+        const uint32_t nb = wq + (blockIdx.x < wrem ? 1u : 0u), sb0 = blockIdx.x * wq + min(blockIdx.x, wrem);
+        const uint32_t e = nb >> 3, r = nb & 7u, ra = min(r, 4u), rb = r - ra;
+        const uint32_t shift = (e * (2u * (uint32_t)MC_LIN_FAVOUR - 100u) + 50u) / 100u; // pairs moved from a late wave to its SIMD's early one
+        const uint32_t ca = e + shift, cb = e - shift;
+        const uint32_t w4 = wave & 3u;
+        const uint32_t mine = wave < 4 ? ca + (w4 < ra ? 1u : 0u) : cb + (w4 < rb ? 1u : 0u);
+        const uint32_t before = wave < 4 ? w4 * ca + min(w4, ra) : 4u * ca + ra + w4 * cb + min(w4, rb);
+        pb = sb0 + before;
+        pe = pb + mine;
+    } else {
+        // equal ranges to within one pair, without a 64-bit division: the first NP % (waves of the launch) waves take one pair more
+        const uint32_t nw_total = gridDim.x * nwaves, gw = blockIdx.x * nwaves + wave;
+        const uint32_t pq = NP / nw_total, prem = NP - pq * nw_total;
+        pb = gw * pq + min(gw, prem);
+        pe = pb + pq + (gw < prem ? 1u : 0u);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // The kernel body.  blockDim.x = 64 * waves; dynamic LDS = round16(in * sizeof(T)) + 128.
 // ------------------------------------------------------------------------------------------
 // LNCH / LTP != 0 select the LINEAR-ORDER main loop (int4, bfloat, Q_M4D only; rows of LNCH whole KiB): see below.
@@ -1051,9 +1089,12 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
         // each through four KiB in flight) and the epilogue treats the rows of a pair separately: wave gw takes row gw
         constexpr bool HALF_OK = EPI == EPI_STORE || EPI == EPI_RESID;
         const bool half = HALF_OK && 2u * NP <= nw_total;
-        const uint32_t pq = NP / nw_total, prem = NP - pq * nw_total;
-        const uint32_t pb = half ? gw >> 1 : gw * pq + min(gw, prem);
-        const uint32_t pe = half ? pb + (gw < out_rows ? 1u : 0u) : pb + pq + (gw < prem ? 1u : 0u);
+        uint32_t pb, pe;
+        lin_deal<LWAVES>(NP, wave, nwaves, pb, pe);
+        if (half) {
+            pb = gw >> 1;
+            pe = pb + (gw < out_rows ? 1u : 0u);
+        }
         const uint32_t hrow = gw & 1u, toff = half ? hrow * (uint32_t)LGEN : 0u; // (half) the wave's row of its pair; its first packet
         const char* sbase = static_cast<const char*>(sp);
         const uint32_t eo_pair = min(pb + lane, NP - 1);
@@ -1350,16 +1391,13 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
             }
             if (lin_never) asm volatile("" ::"v"(PRO == PRO_PARTS ? __float_as_uint(lpr[0][0].x) : lxr[0].x)); // ends the basic block: the requests stay in front of what follows
         }
-        const uint32_t nw_total = gridDim.x * nwaves, gw = blockIdx.x * nwaves + wave;
         static_assert(!LSPLIT || (LNCH == 3 && LTP == 1 && LWAVES > 0), "split rows: 1.5 KiB each, two to a 3 KiB super row");
         // (LSPLIT: the loop's pairs are pairs of SUPER rows = quads of rows; NPR counts the real pairs the epilogues finish)
         const uint32_t NPR = (out_rows + 1) / 2;
         const uint32_t NP = LSPLIT ? out_rows / 4 : NPR; // row pairs (the host takes this path only for even out_rows; LSPLIT: whole quads)
         const size_t rowb_l = LSPLIT ? 2 * rowb : rowb;
-        // equal ranges to within one pair, without a 64-bit division: the first NP % nw_total waves take one pair more
-        const uint32_t pq = NP / nw_total, prem = NP - pq * nw_total;
-        const uint32_t pb = gw * pq + min(gw, prem);
-        const uint32_t pe = pb + pq + (gw < prem ? 1u : 0u);
+        uint32_t pb, pe;
+        lin_deal<LWAVES>(NP, wave, nwaves, pb, pe);
         const char* sbase = static_cast<const char*>(sp);
 
         uint4 lring[LR][LTP];
