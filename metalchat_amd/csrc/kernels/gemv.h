@@ -548,12 +548,14 @@ template <int R> struct tile {
 // 8.1 us, the other (waves 4-7) in 10.4, the last 2.2 us alone on its SIMD with nothing to overlap its dequantisation chain with.
 // So (1) every WORKGROUP gets the same number of pairs to within one (round 2 gave the remainder to the first waves of the
 // LAUNCH: wq|wk|wv's 3072 pairs were two per wave on CUs 0-127 and one per wave on CUs 128-255), (2) a workgroup's remainder
-// goes to waves 0-3 first, and (3) waves 0-3 take MC_LIN_FAVOUR percent of the pairs a SIMD's two waves share, so that both
-// finish together: 60 % = (8, 6) of w1|w3's 14.  Same box, tokens/s of Llama-3-8B int4: round-2 deal 759 / 748, 50 % 770,
-// 60 % 777 / 779, 65 % 754, 70 % 750; w1|w3 12.65 -> 12.22 us, wq|wk|wv 6.41 -> 5.8-6.1, head 47.9 -> 44.1.
+// goes to waves 0-3 first, and (3) the early wave of a SIMD takes MC_LIN_FAVOUR percent of the pairs its two waves share, so
+// that both finish together: 57 % = (8, 6) of w1|w3's 14 -- then 9.1 and 9.8 us.  Same box, tokens/s of Llama-3-8B int4:
+// round-2 deal 759 / 748; (7, 7) with the per-workgroup remainder 770; (8, 6) 777 / 779; (9, 5) 754; (10, 4) 750; on another
+// box (8, 6) 761 / 755, two SIMDs (9, 5) and two (8, 6) 737 / 744, three (9, 5) 747 / 753.  w1|w3 12.65 -> 12.22 us,
+// wq|wk|wv 6.41 -> 5.8-6.1, head 47.9 -> 44.1 (profiles/r03_gemv_phase_timeline_*.log: the stamps before and after).
 // Spans stay contiguous and in address order; which wave multiplies a pair does not change a bit of it.
 #ifndef MC_LIN_FAVOUR
-#define MC_LIN_FAVOUR 60 // -1: the round-2 deal
+#define MC_LIN_FAVOUR 57 // -1: the round-2 deal
 #endif
 template <int LWAVES>
 __device__ __forceinline__ void
@@ -563,11 +565,17 @@ lin_deal(uint32_t NP, uint32_t wave, uint32_t nwaves, uint32_t& pb, uint32_t& pe
         const uint32_t G = gridDim.x, wq = NP / G, wrem = NP - wq * G;
         const uint32_t nb = wq + (blockIdx.x < wrem ? 1u : 0u), sb0 = blockIdx.x * wq + min(blockIdx.x, wrem);
         const uint32_t e = nb >> 3, r = nb & 7u, ra = min(r, 4u), rb = r - ra;
-        const uint32_t shift = (e * (2u * (uint32_t)MC_LIN_FAVOUR - 100u) + 50u) / 100u; // pairs moved from a late wave to its SIMD's early one
-        const uint32_t ca = e + shift, cb = e - shift;
+        // pairs moved from a late wave to the early wave of ITS SIMD (waves i and i + 4 share SIMD i: a SIMD's total stays e + e):
+        // S4 of them over the four SIMDs, the first S4 % 4 SIMDs one more; never more than a third of what the late wave had
+        const uint32_t S4 = min((4u * e * (2u * (uint32_t)MC_LIN_FAVOUR - 100u) + 50u) / 100u, 4u * (e / 3u));
+        const uint32_t sq = S4 >> 2, sr = S4 & 3u;
         const uint32_t w4 = wave & 3u;
-        const uint32_t mine = wave < 4 ? ca + (w4 < ra ? 1u : 0u) : cb + (w4 < rb ? 1u : 0u);
-        const uint32_t before = wave < 4 ? w4 * ca + min(w4, ra) : 4u * ca + ra + w4 * cb + min(w4, rb);
+        auto cnt_a = [&](uint32_t i) { return e + sq + (i < sr ? 1u : 0u) + (i < ra ? 1u : 0u); };
+        auto cnt_b = [&](uint32_t i) { return e - sq - (i < sr ? 1u : 0u) + (i < rb ? 1u : 0u); };
+        // pairs in front of wave w4 of its class: w4 * (e +- sq) +- min(w4, sr) + min(w4, ra | rb)
+        const uint32_t a_all = 4u * (e + sq) + sr + ra;
+        const uint32_t mine = wave < 4 ? cnt_a(w4) : cnt_b(w4);
+        const uint32_t before = wave < 4 ? w4 * (e + sq) + min(w4, sr) + min(w4, ra) : a_all + w4 * (e - sq) - min(w4, sr) + min(w4, rb);
         pb = sb0 + before;
         pe = pb + mine;
     } else {
