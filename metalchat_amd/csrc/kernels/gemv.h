@@ -1406,6 +1406,14 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
         const size_t rowb_l = LSPLIT ? 2 * rowb : rowb;
         uint32_t pb, pe;
         lin_deal<LWAVES>(NP, wave, nwaves, pb, pe);
+        // Where the deal cannot even the two waves of a SIMD out -- one or two pairs per wave: w2 (K = 14336: waves 0-3 done after
+        // 4.2 us, waves 4-7 after 5.0) -- the late wave asks for the arbiter's preference on every other tile instead (s_setprio;
+        // held for the whole launch it simply mirrors the imbalance: 8.2 / 10.6 us on w1|w3): 4.7 / 4.9 us, w2 8.2 -> 7.9-8.0 us.
+        // On the matrices with many pairs per wave it costs what it gains or more (w1|w3 +0.3 us): the deal does the job there.
+#ifndef MC_LIN_PRIO
+#define MC_LIN_PRIO -1 // -1: tiles 0, 2, 4, ... of a pair for rows of 7 KiB and more; 0: never; >= 2: this bit mask over t % 8, all kernels
+#endif
+        constexpr int PRIO_MASK = MC_LIN_PRIO >= 2 ? MC_LIN_PRIO : (MC_LIN_PRIO < 0 && LNCH >= 7 && LWAVES == 8 ? 0x55 : 0);
         const char* sbase = static_cast<const char*>(sp);
 
         uint4 lring[LR][LTP];
@@ -1622,6 +1630,12 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
 #pragma unroll
             for (int t = 0; t < TPP; t++) {
                 const int r = t / SUB, sidx = t % SUB, slot = LR >= TPP ? SLOT0 + t : t % LR;
+                if (PRIO_MASK != 0 && wave >= 4) { // (t is a constant once the loop is unrolled)
+                    const bool now = ((PRIO_MASK >> (t % 8)) & 1) != 0;
+                    const bool was = t == 0 ? !now : ((PRIO_MASK >> ((t - 1) % 8)) & 1) != 0;
+                    if (now && !was) __builtin_amdgcn_s_setprio(1);
+                    if (!now && was) __builtin_amdgcn_s_setprio(0);
+                }
 #pragma unroll
                 for (int p = 0; p < LTP; p++) {
                     const int c = sidx * LTP + p;
@@ -1712,6 +1726,7 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
         if constexpr (U == 2) {
             if (pr < pe) do_pair(std::integral_constant<int, 0>{}, pr); // odd count: the last pair sits in the first slots
         }
+        if (PRIO_MASK != 0) __builtin_amdgcn_s_setprio(0);
         flush();
         if (EPI == EPI_STORE_PICK) pick_finish(red, nwaves);
         return;
