@@ -1026,8 +1026,9 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
     //   * an epilogue per row group (the fp64 exponential of SiLU evaluated by two lanes while 62 idle) cost
     //     as much as two of its four tiles.
     // So here
-    //   * the ROW PAIRS (the unit every epilogue works on) are cut into one contiguous range per wave, equal to
-    //     within one pair, adjacent ranges inside a workgroup;
+    //   * the ROW PAIRS (the unit every epilogue works on) are cut into one contiguous range per wave, adjacent ranges
+    //     inside a workgroup -- the same number per workgroup to within one, (8, 6) of 14 for the two waves of a SIMD
+    //     (lin_deal above: the early wave of a SIMD is served first);
     //   * a tile is LTP consecutive KiB of ONE row -- the whole row when LTP == LNCH -- so the loads of a wave
     //     sweep its range in pure address order; the loop body is one row group, fully unrolled (4 * LNCH / LTP
     //     tiles) over a static register ring of LR tiles, with the halves of the first / last row group that
