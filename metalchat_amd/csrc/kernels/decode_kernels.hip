@@ -650,7 +650,10 @@ attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const
     }
     // (the V tile's requests are written here too; hipcc sinks them to their first use behind hand-off A.  Pinning them in front
     //  of the scores measured SLOWER in the token -- scores done 2.3 us after the start instead of 1.8, 689 vs 710 tokens/s against
-    //  687 / 690 for the two-launch form on the same boxes: the first MFMA then waits for 16 KB more.  Left to the compiler.)
+    //  687 / 690 for the two-launch form on the same boxes: the first MFMA then waits for 16 KB more.  Requested behind the scores
+    //  and in front of hand-off A -- what the wide-range builds below do -- the 64-slot launch gained nothing either: with Wo inside
+    //  11.34 / 11.55 us against 11.28 in the trace, 735 / 735 / 745 tokens/s against 745 / 746 / 758 alternating on one box
+    //  (tools/attn_wo_timeline.py: the scores are done 0.3 us sooner, publish and hand-off C take it back).  Left to the compiler.)
     uint4 vb[T][NB][2];
 #pragma unroll
     for (int t = 0; t < T; t++)
