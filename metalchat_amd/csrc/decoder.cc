@@ -187,6 +187,7 @@ struct mc_decoder {
     unsigned long long* attn_psum_g = nullptr; // [H][nsplit]            partial softmax denominators
     unsigned long long* attn_slab_g = nullptr; // [KV][nsplit][n_rep][hd] fp32 partial P.V sums
     unsigned long long* attn_row_g = nullptr;  // [H * hd / 2]          the finished attention row, two bf16 per granule (mc_attn_wo_*)
+    bool handoff_fast = true;    // MC_HANDOFF_FAST=0: hand-offs A and B through the fabric only (A/B; handoff.h "the XCD-local fast path")
     bool attn_wo_on = true;      // MC_ATTN_WO=0: the Wo GEMV as a launch of its own behind the one-launch attention (A/B, parity)
     bool attn_fused_on = true;   // MC_ATTN_FUSED=0: scores and P.V as two launches (A/B, parity)
     // ... while the launch is at most this many 256-thread workgroups per CU (MC_ATTN_FUSED_WGS).  Measured: at S = 8192 with
@@ -758,7 +759,7 @@ struct mc_decoder {
                            pack(q_rot, L.kc, L.vt, attn_out, attn_psum_g, attn_slab_g, attn_row_g, state, (uint32_t)n_rep, (uint32_t)KV,
                                 (uint32_t)cfg.max_seq_len, scale_T, (uint32_t)nsplit, (uint32_t)(li + 1), (const void*)L.wo.w,
                                 (const void*)L.wo.scales, gemma ? (const void*)nullptr : x, gemma ? proj : hidden, (uint32_t)L.wo.out,
-                                (uint32_t)L.wo.group, (uint32_t)(gemma ? 0 : 1)));
+                                (uint32_t)L.wo.group, (uint32_t)(gemma ? 0 : 1), (uint32_t)(handoff_fast ? 1 : 0), (void*)nullptr));
                 if (s != MC_OK) return s;
                 if (gemma && !fuse_pn) {
                     s = launch("mc_rmsnorm_row_" + tname, 1, 1, 1, 1024, 0,
@@ -769,7 +770,8 @@ struct mc_decoder {
                 // scores, softmax, P.V                 (attention.h:191-203) in ONE launch, then Wo from the finished row
                 s = launch("mc_attn_fused_" + tname, (unsigned)(nsplit * KV), 1, 1, 256, 0,
                            pack(q_rot, L.kc, L.vt, attn_out, attn_psum_g, attn_slab_g, state, (uint32_t)n_rep, (uint32_t)KV, (uint32_t)hd,
-                                (uint32_t)cfg.max_seq_len, scale_T, (uint32_t)nsplit, (uint32_t)(li + 1), (void*)nullptr));
+                                (uint32_t)cfg.max_seq_len, scale_T, (uint32_t)nsplit, (uint32_t)(li + 1), (void*)nullptr,
+                                (uint32_t)(handoff_fast ? 1 : 0)));
                 if (s != MC_OK) return s;
                 s = gemma ? gemv(L.wo, 0, 0, attn_out, proj, nullptr, nullptr, mu) : gemv(L.wo, 0, 1, attn_out, hidden, x, nullptr, mu);
                 if (s != MC_OK) return s;
@@ -1202,6 +1204,7 @@ mc_decoder_create(mc_device* dev, mc_library* lib, mc_queue* q, const mc_decoder
     if (const char* e = getenv("MC_PV_FOLD")) d->pv_fold_on = atoi(e) != 0;
     if (const char* e = getenv("MC_ATTN_FUSED")) d->attn_fused_on = atoi(e) != 0;
     if (const char* e = getenv("MC_ATTN_WO")) d->attn_wo_on = atoi(e) != 0;
+    if (const char* e = getenv("MC_HANDOFF_FAST")) d->handoff_fast = atoi(e) != 0;
     if (const char* e = getenv("MC_ATTN_FUSED_WGS")) d->attn_fused_max_wgs_per_cu = (unsigned)std::max(1, std::min(4, atoi(e)));
     if (const char* e = getenv("MC_LING_HALF")) d->ling_half = atoi(e) != 0;
     if (const char* e = getenv("MC_LIN_SPLIT")) d->lin_split = atoi(e) != 0;
@@ -1241,8 +1244,9 @@ mc_decoder_create(mc_device* dev, mc_library* lib, mc_queue* q, const mc_decoder
     if (const char* e = getenv("MC_PV_RANGES")) d->pv_ranges = std::max(1, std::min(64, atoi(e)));
     A(d->pv_parts, (size_t)std::max(d->pv_ranges, 4) * H * hd * 4);
     if (d->tb == 2) {
-        A(d->attn_psum_g, (size_t)H * d->nsplit * 8);
-        A(d->attn_slab_g, (size_t)H * hd * d->nsplit * 8);
+        // (twice: the XCD-local `fast` copy of every granule sits behind the `slow` one, handoff.h)
+        A(d->attn_psum_g, (size_t)H * d->nsplit * 8 * 2);
+        A(d->attn_slab_g, (size_t)H * hd * d->nsplit * 8 * 2);
         A(d->attn_row_g, (size_t)H * hd / 2 * 8);
     }
     A(d->taps, (size_t)(d->n_own + 1) * dim * tb);

@@ -28,7 +28,8 @@ __device__ __forceinline__ void
 attn_wo_body(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const bf16_t* __restrict__ vt, bf16_t* __restrict__ attn_out,
              unsigned long long* psum_g, unsigned long long* slab_g, unsigned long long* row_g, step_state* st, uint32_t n_rep,
              uint32_t KV, uint32_t max_seq, float scale, uint32_t nsplit, uint32_t layer_tag, const void* __restrict__ wo_w,
-             const void* __restrict__ wo_s, const bf16_t* res, bf16_t* y, uint32_t out_rows, uint32_t group, uint32_t has_res)
+             const void* __restrict__ wo_s, const bf16_t* res, bf16_t* y, uint32_t out_rows, uint32_t group, uint32_t has_res,
+             uint32_t fastpath, unsigned long long* tl)
 {
     constexpr uint32_t K = 2048u * LNCH;
     constexpr uint32_t CHUNK_LDS = 2048 * 2 / 16 * 17;  // a chunk of the row in LDS: 16 bytes of padding per 256 (gemv.h Q_M4D)
@@ -49,7 +50,16 @@ attn_wo_body(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const 
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     uint4 ww[PMAX][2][LNCH];
     uint32_t ws[PMAX][LNCH], wres[PMAX];
-    auto request_wo = [&] {
+    // Who asks when (round 4): a wave's vector-memory results return in issue order, so a wave that polls a hand-off behind its own
+    // 8 KB of weight requests sees its first granule only when those have arrived.  Waves 0-3 gather the denominators of hand-off
+    // A (one query head each): they request their pairs BEHIND that wait (point 1); waves 4-7 wait for nothing there and request
+    // behind the scores (point 0), as every wave did in round 3.
+#ifndef MC_WO_REQ_SPLIT
+#define MC_WO_REQ_SPLIT 1
+#endif
+    auto request_wo = [&](int point) {
+        const bool poller = wave < n_rep; // (attn_fused_bf: head = wave, wave + NW, ... gathers the denominators of hand-off A)
+        if (MC_WO_REQ_SPLIT ? (point == 0) == poller : point != 0) return;
 #pragma unroll
         for (int i = 0; i < PMAX; i++) {
             if (pb + i >= pe) break; // (wave-uniform)
@@ -82,7 +92,11 @@ attn_wo_body(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const 
             if ((col & 1u) == 0) granule_store(row_g + ((size_t)head * HD + db * 16 + col) / 2, epoch_tag, pack_bf16x2(v, vn));
         }
     };
-    attn_fused_bf<HD, 1, 8>(q, kc, vt, psum_g, slab_g, st, n_rep, KV, max_seq, scale, nsplit, layer_tag, nullptr, publish, request_wo);
+    attn_fused_bf<HD, 1, 8>(q, kc, vt, psum_g, slab_g, st, n_rep, KV, max_seq, scale, nsplit, layer_tag, tl, publish, request_wo, fastpath);
+    // tl != null (tools/attn_wo_timeline.py only): thread 0 of every workgroup leaves s_memrealtime stamps of its phases
+    auto stamp = [&](int i) {
+        if (tl && threadIdx.x == 0) tl[(size_t)blockIdx.x * 8 + i] = __builtin_amdgcn_s_memrealtime();
+    };
 
     // ---- hand-off C: the whole attention row (K bf16 = K / 2 granules) into LDS, padded as the transposed reads want it
     {
@@ -114,6 +128,7 @@ attn_wo_body(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const 
         }
     }
     __syncthreads();
+    stamp(6);
 
     // ---- Wo: mc_gemv_i4_bfloat_lin{LNCH}_p0_e{0,1} for the wave's pairs
     const uint32_t lane_tr = (((lane >> 4) * 4 + (lane & 3)) * 17 + ((lane >> 2) & 3) * 4) * 16;
@@ -148,6 +163,7 @@ attn_wo_body(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const 
             reinterpret_cast<uint32_t*>(y)[pb + i] = pack_bf16x2(va, vb);
         }
     }
+    stamp(7);
 }
 
 } // namespace
@@ -157,10 +173,10 @@ attn_wo_body(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const 
     NAME(const bf16_t* q, const bf16_t* kc, const bf16_t* vt, bf16_t* attn_out, unsigned long long* psum_g, unsigned long long* slab_g, \
          unsigned long long* row_g, step_state* st, uint32_t n_rep, uint32_t n_kv, uint32_t max_seq, float scale, uint32_t nsplit,      \
          uint32_t layer_tag, const void* wo_w, const void* wo_s, const bf16_t* res, bf16_t* y, uint32_t out_rows, uint32_t group,       \
-         uint32_t has_res)                                                                                                               \
+         uint32_t has_res, uint32_t fastpath, unsigned long long* tl)                                                                    \
     {                                                                                                                                    \
         attn_wo_body<HD, LNCH>(q, kc, vt, attn_out, psum_g, slab_g, row_g, st, n_rep, n_kv, max_seq, scale, nsplit, layer_tag, wo_w,     \
-                               wo_s, res, y, out_rows, group, has_res);                                                                  \
+                               wo_s, res, y, out_rows, group, has_res, fastpath, tl);                                                    \
     }
 // mc_attn_wo_i4_bfloat_hd{head_dim}_k{KiB per Wo row}
 MC_ATTN_WO(mc_attn_wo_i4_bfloat_hd128_k2, 128, 2)  // Llama-3-8B: 32 heads x 128

@@ -615,8 +615,12 @@ template <int HD, int T, int NW, typename OnChunk, typename BehindScores>
 __device__ __forceinline__ void
 attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const bf16_t* __restrict__ vt,
               unsigned long long* psum_g, unsigned long long* slab_g, step_state* st, uint32_t n_rep, uint32_t KV, uint32_t max_seq,
-              float scale, uint32_t nsplit, uint32_t layer_tag, unsigned long long* tl, OnChunk&& on_chunk, BehindScores&& behind_scores)
+              float scale, uint32_t nsplit, uint32_t layer_tag, unsigned long long* tl, OnChunk&& on_chunk, BehindScores&& behind_scores,
+              uint32_t fastpath)
 {
+    // fastpath != 0: hand-offs A and B publish every granule twice and look at the XCD-local copy first (handoff.h, round 4); the
+    // buffers are then twice as long, the `fast` words behind the `slow` ones
+    const size_t psum_fast = (size_t)KV * n_rep * nsplit, slab_fast = (size_t)KV * nsplit * n_rep * HD;
     // tl != null (tools/attn_timeline.py only): thread 0 of every workgroup leaves s_memrealtime stamps of its phases
     auto stamp = [&](int i) {
         if (tl && threadIdx.x == 0) tl[(size_t)blockIdx.x * 8 + i] = __builtin_amdgcn_s_memrealtime();
@@ -744,19 +748,21 @@ attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const
         // ---- 3. hand-off A: this range's partial denominators out, the kv head's denominators in
         if (threadIdx.x < n_rep) {
             const float tot = (wsum[0][threadIdx.x] + wsum[1][threadIdx.x]) + (wsum[2][threadIdx.x] + wsum[3][threadIdx.x]);
-            granule_store(psum_g + (size_t)(kv * n_rep + threadIdx.x) * nsplit + split, tag, __float_as_uint(tot));
+            unsigned long long* gp = psum_g + (size_t)(kv * n_rep + threadIdx.x) * nsplit + split;
+            if (fastpath) granule_store_dual(gp, psum_fast, tag, __float_as_uint(tot));
+            else granule_store(gp, tag, __float_as_uint(tot));
         }
-        behind_scores();
+        behind_scores(0);
         for (uint32_t head = wave; head < n_rep; head += NW) {
             // (softmax_inv's order: lane-strided partial sums, then the shuffle tree)
             const unsigned long long* row = psum_g + (size_t)(kv * n_rep + head) * nsplit;
             float tsum = 0.0f;
             handoff_wait w;
-            for (;;) {
+            for (uint32_t look = 0;; look++) {
                 bool ok = true;
                 tsum = 0.0f;
                 for (uint32_t sp = lane; sp < nact; sp += 64) {
-                    const unsigned long long g = granule_load(row + sp);
+                    const unsigned long long g = fastpath ? granule_look_dual(row + sp, psum_fast, look) : granule_load(row + sp);
                     ok = ok && (uint32_t)(g >> 32) == tag;
                     tsum += __uint_as_float((uint32_t)g);
                 }
@@ -765,6 +771,7 @@ attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const
             tsum = wave_sum(tsum);
             if (lane == 0) inv_s[head] = 1.0f / tsum;
         }
+        behind_scores(1);
         if constexpr (T > 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         else __syncthreads();
         stamp(2);
@@ -802,12 +809,18 @@ attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const uint32_t head = 4 * c + r;
-                if (head < n_rep)
-                    granule_store(slab_g + ((size_t)(kv * nsplit + split) * n_rep + head) * HD + db * 16 + col, tag, __float_as_uint(oacc[b][r]));
+                if (head < n_rep) {
+                    unsigned long long* gp = slab_g + ((size_t)(kv * nsplit + split) * n_rep + head) * HD + db * 16 + col;
+                    if (fastpath) granule_store_dual(gp, slab_fast, tag, __float_as_uint(oacc[b][r]));
+                    else granule_store(gp, tag, __float_as_uint(oacc[b][r]));
+                }
             }
         }
     }
-    if (!active) behind_scores();
+    if (!active) {
+        behind_scores(0);
+        behind_scores(1);
+    }
     // ---- 6. hand-off B: chunk q = (head, 16-column block) of this kv head is finished by workgroup q % nsplit (every
     // workgroup of the launch takes part, ranges past kv_len included): lane (col, jj) gathers column col of ranges jj,
     // jj + 4, ..., adds them in that order, the four lane groups are added in order too, one rounding to T
@@ -819,15 +832,16 @@ attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const
         const size_t jstride = (size_t)n_rep * HD;
         float v = 0.0f;
         handoff_wait w;
-        for (;;) {
+        for (uint32_t look = 0;; look++) {
             bool ok = true;
             v = 0.0f;
+            const unsigned long long* src = base + (fastpath && (look & 3u) != 3u ? slab_fast : (size_t)0);
             for (uint32_t j0 = 0; j0 < nact; j0 += 32) { // eight loads in flight per lane
                 unsigned long long g[8];
 #pragma unroll
                 for (int k = 0; k < 8; k++) {
                     const uint32_t j = j0 + 4 * k + c;
-                    g[k] = granule_load(base + (size_t)(j < nact ? j : nact - 1) * jstride);
+                    g[k] = granule_load(src + (size_t)(j < nact ? j : nact - 1) * jstride);
                 }
 #pragma unroll
                 for (int k = 0; k < 8; k++) {
@@ -851,16 +865,16 @@ attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const
     extern "C" __global__ void __launch_bounds__(256)                                                                                    \
     NAME(const bf16_t* q, const bf16_t* kc, const bf16_t* vt, bf16_t* out, unsigned long long* psum_g, unsigned long long* slab_g,      \
          step_state* st, uint32_t n_rep, uint32_t n_kv, uint32_t hd, uint32_t max_seq, float scale, uint32_t nsplit, uint32_t layer_tag, \
-         unsigned long long* tl)                                                                                                         \
+         unsigned long long* tl, uint32_t fastpath)                                                                                      \
     {                                                                                                                                    \
         /* one rounding of the fp32 sum (bmm.metal:80): the attention row the Wo GEMV reads */                                           \
         auto store = [&](uint32_t head, uint32_t db, uint32_t col, float v) {                                                            \
             if ((threadIdx.x & 63) < 16) out[(size_t)head * hd + db * 16 + col] = f2bf(v);                                               \
         };                                                                                                                               \
-        if (hd == 128) attn_fused_bf<128, T, 4>(q, kc, vt, psum_g, slab_g, st, n_rep, n_kv, max_seq, scale, nsplit, layer_tag, tl, store, [] {});    \
-        else if (hd == 64) attn_fused_bf<64, T, 4>(q, kc, vt, psum_g, slab_g, st, n_rep, n_kv, max_seq, scale, nsplit, layer_tag, tl, store, [] {}); \
-        else if (T == 1 && hd == 256) attn_fused_bf<256, 1, 4>(q, kc, vt, psum_g, slab_g, st, n_rep, n_kv, max_seq, scale, nsplit, layer_tag, tl, store, [] {}); \
-        else if (T == 1 && hd == 32) attn_fused_bf<32, 1, 4>(q, kc, vt, psum_g, slab_g, st, n_rep, n_kv, max_seq, scale, nsplit, layer_tag, tl, store, [] {});   \
+        if (hd == 128) attn_fused_bf<128, T, 4>(q, kc, vt, psum_g, slab_g, st, n_rep, n_kv, max_seq, scale, nsplit, layer_tag, tl, store, [](int) {}, fastpath);    \
+        else if (hd == 64) attn_fused_bf<64, T, 4>(q, kc, vt, psum_g, slab_g, st, n_rep, n_kv, max_seq, scale, nsplit, layer_tag, tl, store, [](int) {}, fastpath); \
+        else if (T == 1 && hd == 256) attn_fused_bf<256, 1, 4>(q, kc, vt, psum_g, slab_g, st, n_rep, n_kv, max_seq, scale, nsplit, layer_tag, tl, store, [](int) {}, fastpath); \
+        else if (T == 1 && hd == 32) attn_fused_bf<32, 1, 4>(q, kc, vt, psum_g, slab_g, st, n_rep, n_kv, max_seq, scale, nsplit, layer_tag, tl, store, [](int) {}, fastpath);   \
     }
 MC_ATTN_FUSED(mc_attn_fused_bfloat, 1)   // 64-slot ranges
 // (128- and 256-slot ranges -- T = 2, 4: MC_ATTN_FUSED(mc_attn_fused2_bfloat, 2) ... -- were built for S = 8192, passed the kernel-level

@@ -39,6 +39,34 @@ granule_load(const unsigned long long* g)
 {
     return __hip_atomic_load((gu64_t*)g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// ---- the XCD-local fast path of a hand-off (round 4; tools/handoff_lab.hip: 0.72 us per all-to-all round of 32 workgroups on one
+// XCD against 1.24 through the fabric on an idle chip, 1.8 against 3.8 beside streaming waves).  A granule published TWICE: a
+// PLAIN 8-byte store to its `fast` word -- it stays in the producer XCD's L2, where an agent-scope (sc1: L1-bypassing, L2-served)
+// load of a consumer ON THE SAME XCD finds it one L2 round trip later -- and the guide's agent-scope store to its `slow` word,
+// which every XCD sees.  A consumer looks at `fast` and, every fourth look, at `slow` for the granules still missing: whichever
+// carries this launch's tag first is the value (one aligned 8-byte store each: untorn, and a tag is unique per launch, so a stale
+// or foreign line can only read as "not yet").  Placement decides the SPEED only -- workgroups with equal blockIdx.x % 8 share an
+// XCD in practice, and the hand-offs A and B of the decode attention stay inside one kv head = one such class -- never the result:
+// a consumer on another XCD is served by `slow` exactly as before.  `fast` sits `fast_off` granules behind `slow`.
+__device__ __forceinline__ void
+granule_store_plain(unsigned long long* g, uint32_t tag, uint32_t value)
+{
+    const unsigned long long v = ((unsigned long long)tag << 32) | value;
+    asm volatile("global_store_dwordx2 %0, %1, off" ::"v"((gu64_t*)g), "v"(v) : "memory");
+}
+__device__ __forceinline__ void
+granule_store_dual(unsigned long long* slow, size_t fast_off, uint32_t tag, uint32_t value)
+{
+    granule_store_plain(slow + fast_off, tag, value);
+    granule_store(slow, tag, value);
+}
+// one look at a granule: `look` counts this wait's looks (wave-uniform); have = a value with this launch's tag is already in `g`
+__device__ __forceinline__ unsigned long long
+granule_look_dual(const unsigned long long* slow, size_t fast_off, uint32_t look)
+{
+    return granule_load((look & 3u) == 3u ? slow : slow + fast_off);
+}
+
 // one round of a bounded wait: false = keep waiting.  `ok` is wave-uniform.
 struct handoff_wait {
     unsigned long long t0;

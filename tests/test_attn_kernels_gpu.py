@@ -66,8 +66,9 @@ CASES = [
     (16, 16, 256, 2048, 2048), (16, 16, 256, 2048, 130),
     (8, 2, 32, 512, 500), (16, 1, 128, 1024, 1024),
 ]
+@pytest.mark.parametrize("fast", [1, 0])   # hand-offs with / without the XCD-local fast path (handoff.h)
 @pytest.mark.parametrize("H,KV,hd,max_seq,n", CASES + [(32, 8, 128, 8192, 8000)])
-def test_one_launch_attention_matches_the_oracle(acc, H, KV, hd, max_seq, n):
+def test_one_launch_attention_matches_the_oracle(acc, H, KV, hd, max_seq, n, fast):
     import metalchat_amd as mc
 
     rng = np.random.default_rng(H * 7 + hd + n)
@@ -80,8 +81,8 @@ def test_one_launch_attention_matches_the_oracle(acc, H, KV, hd, max_seq, n):
     kc, vt = device_caches(acc, k, v, max_seq)
     qb = acc.to_device(q.reshape(-1))
     out = acc.alloc(H * hd * 2)
-    psum = acc.to_device(np.zeros(H * nsplit, np.uint64))
-    slab = acc.to_device(np.zeros(H * hd * nsplit, np.uint64))
+    psum = acc.to_device(np.zeros(2 * H * nsplit, np.uint64))   # (slow words, then the XCD-local fast words: handoff.h)
+    slab = acc.to_device(np.zeros(2 * H * hd * nsplit, np.uint64))
     kern = acc.load("mc_attn_fused_bfloat")
     # several launches over the same granule buffers with the tags consecutive launches of a token (and consecutive tokens)
     # carry: a granule of an earlier launch must never be taken for this one's
@@ -90,7 +91,7 @@ def test_one_launch_attention_matches_the_oracle(acc, H, KV, hd, max_seq, n):
         state = state_buffer(acc, n, epoch)
         mc.KernelTask(kern, (nsplit * KV * 256, 1, 1), (256, 1, 1),
                       [qb, kc, vt, out, psum, slab, state, np.uint32(n_rep), np.uint32(KV), np.uint32(hd), np.uint32(max_seq),
-                       np.float32(scale), np.uint32(nsplit), np.uint32(layer_tag), None])()
+                       np.float32(scale), np.uint32(nsplit), np.uint32(layer_tag), None, np.uint32(fast)])()
         acc.wait()
         assert int(state.download(np.int32, 12)[10]) == 0, "a hand-off of the launch gave up"
         got = out.download(np.uint16, H * hd)
@@ -152,14 +153,14 @@ def test_a_hand_off_whose_producers_never_run_gives_up_and_reports(acc):
     kc, vt = device_caches(acc, k, v, max_seq)
     qb = acc.to_device(q.reshape(-1))
     out = acc.alloc(H * hd * 2)
-    psum = acc.to_device(np.zeros(H * nsplit, np.uint64))
-    slab = acc.to_device(np.zeros(H * hd * nsplit, np.uint64))
+    psum = acc.to_device(np.zeros(2 * H * nsplit, np.uint64))   # (slow words, then the XCD-local fast words: handoff.h)
+    slab = acc.to_device(np.zeros(2 * H * hd * nsplit, np.uint64))
     kern = acc.load("mc_attn_fused_bfloat")
 
     def launch(state, wgs):
         mc.KernelTask(kern, (wgs * 256, 1, 1), (256, 1, 1),
                       [qb, kc, vt, out, psum, slab, state, np.uint32(n_rep), np.uint32(KV), np.uint32(hd), np.uint32(max_seq),
-                       np.float32(scale), np.uint32(nsplit), np.uint32(1), None])()
+                       np.float32(scale), np.uint32(nsplit), np.uint32(1), None, np.uint32(1)])()
         acc.wait()
 
     state = state_buffer(acc, n, 1)
@@ -178,8 +179,9 @@ def test_a_hand_off_whose_producers_never_run_gives_up_and_reports(acc):
                  what="one-launch attention after a launch that gave up")
 
 
+@pytest.mark.parametrize("fast", [1, 0])
 @pytest.mark.parametrize("shape,n", [("llama3-8b", 2048), ("llama3-8b", 1000), ("llama3-8b", 3), ("hd64", 2047), ("llama3-8b-1024", 1024)])
-def test_attention_and_wo_in_one_launch_matches_the_oracle(acc, shape, n):
+def test_attention_and_wo_in_one_launch_matches_the_oracle(acc, shape, n, fast):
     """`mc_attn_wo_i4_bfloat_*` (attn_block_kernels.hip: the decode attention AND the Wo GEMV + residual of one block,
     nn/attention.h:191-205 + nn/transformer.h:132-133) launched BY NAME on a query row, a cache and a hidden row of its own, against
     the oracle's kernels composed as the reference composes them: the attention above, hadamard_broadcast + bmm for Wo
@@ -214,8 +216,8 @@ def test_attention_and_wo_in_one_launch_matches_the_oracle(acc, shape, n):
     mo.add(BF16, L((1, dim)), ref, L((1, dim)), hidden.reshape(1, -1), L((1, dim)), proj.reshape(1, -1))
     kc, vt = device_caches(acc, k, v, max_seq)
     qb = acc.to_device(q.reshape(-1))
-    psum = acc.to_device(np.zeros(H * nsplit, np.uint64))
-    slab = acc.to_device(np.zeros(H * hd * nsplit, np.uint64))
+    psum = acc.to_device(np.zeros(2 * H * nsplit, np.uint64))   # (slow words, then the XCD-local fast words: handoff.h)
+    slab = acc.to_device(np.zeros(2 * H * hd * nsplit, np.uint64))
     row_g = acc.to_device(np.zeros(H * hd // 2, np.uint64))
     attn_out = acc.alloc(H * hd * 2)
     kern = acc.load(f"mc_attn_wo_i4_bfloat_hd{hd}_k{H * hd // 2048}")
@@ -226,7 +228,8 @@ def test_attention_and_wo_in_one_launch_matches_the_oracle(acc, shape, n):
         state = state_buffer(acc, n, epoch)
         mc.KernelTask(kern, (nsplit * KV * 512, 1, 1), (512, 1, 1),
                       [qb, kc, vt, attn_out, psum, slab, row_g, state, np.uint32(n_rep), np.uint32(KV), np.uint32(max_seq), np.float32(scale),
-                       np.uint32(nsplit), np.uint32(layer_tag), W(wptr), W(sptr), hb, hb, np.uint32(dim), np.uint32(128), np.uint32(1)])()
+                       np.uint32(nsplit), np.uint32(layer_tag), W(wptr), W(sptr), hb, hb, np.uint32(dim), np.uint32(128), np.uint32(1),
+                       np.uint32(fast), None])()
         acc.wait()
         assert int(state.download(np.int32, 12)[10]) == 0, "a hand-off of the launch gave up"
         parity.check(BF16, attn_out.download(np.uint16, H * hd), att, rel=2e-3, max_ulp=1, max_frac=0.03, scale_aware=True,

@@ -20,10 +20,10 @@ bf = lambda a: (np.asarray(a, np.float32).view(np.uint32) >> 16).astype(np.uint1
 q = acc.to_device(bf(rng.normal(0, 1, H * hd)))
 caches = [(acc.to_device(bf(rng.normal(0, 0.4, KV * S * hd))), acc.to_device(bf(rng.normal(0, 0.5, KV * hd * S)))) for _ in range(N)]
 out = acc.alloc(H * hd * 2)
-psum = acc.alloc(H * nsplit * 8)
-slab = acc.alloc(H * hd * nsplit * 8)
-psum.upload(np.zeros(H * nsplit, np.uint64))
-slab.upload(np.zeros(H * hd * nsplit, np.uint64))
+psum = acc.alloc(2 * H * nsplit * 8)
+slab = acc.alloc(2 * H * hd * nsplit * 8)
+psum.upload(np.zeros(2 * H * nsplit, np.uint64))
+slab.upload(np.zeros(2 * H * hd * nsplit, np.uint64))
 tl = acc.alloc(N * nsplit * KV * 8 * 8)
 k = acc.load("mc_attn_fused_bfloat" if TILES == 1 else f"mc_attn_fused{TILES}_bfloat")  # (T > 1: tuning builds only)
 names = ["start->scores+exp", "hand-off A (denominators)", "P.V", "publish partials", "hand-off B + reduce"]
@@ -38,7 +38,8 @@ for epoch in (1, 2, 3):
         kc, vt = caches[i]
         mc.KernelTask(k, (nsplit * KV * 256, 1, 1), (256, 1, 1),
                       [q, kc, vt, out, psum, slab, state, np.uint32(n_rep), np.uint32(KV), np.uint32(hd), np.uint32(S), np.float32(hd ** -0.5),
-                       np.uint32(nsplit), np.uint32(i + 1), acc.wrap(tl.device_ptr + i * nsplit * KV * 64, nsplit * KV * 64)])()
+                       np.uint32(nsplit), np.uint32(i + 1), acc.wrap(tl.device_ptr + i * nsplit * KV * 64, nsplit * KV * 64),
+                       np.uint32(int(os.environ.get("MC_HANDOFF_FAST", "1")))])()
     ms = acc.timer_end_ms()
     acc.wait()
     t = tl.download(np.uint64, N * nsplit * KV * 8).reshape(N, nsplit * KV, 8).astype(np.int64)

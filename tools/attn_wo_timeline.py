@@ -1,11 +1,10 @@
 #!/usr/bin/env python3
-"""Where a launch of mc_attn_wo_i4_bfloat_hd128_k2 spends its time (tuning aid; needs the tuning build of
-tools/experiments/r03_attn_wo_stamps.patch, whose kernel takes a stamp buffer as a last argument): Llama-3-8B shapes, a full
+"""Where a launch of mc_attn_wo_i4_bfloat_hd128_k2 spends its time (tuning aid; the kernel takes a stamp buffer as its last argument, null in the product): Llama-3-8B shapes, a full
 cache of 2048 slots, the Wo matrix of a synthetic decoder, `n` launches back to back with consecutive layer tags, s_memrealtime
 stamps of every workgroup (thread 0; 100 MHz):
   0 start  1 scores + exp done  2 hand-off A done  3 P.V done  4 partial rows published  5 hand-off B + reduce done
   6 hand-off C done, attention row staged  7 Wo pairs stored
-usage: MC_HSACO=<tuning build> attn_wo_timeline.py [launches=32]"""
+usage: [MC_HANDOFF_FAST=0] attn_wo_timeline.py [launches=32]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -15,6 +14,7 @@ import metalchat_amd as mc
 import modelgen as mg
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+FAST = int(os.environ.get("MC_HANDOFF_FAST", "1"))
 H, KV, hd, S, dim = 32, 8, 128, 2048, 4096
 n_rep, nsplit = H // KV, S // 64
 acc = mc.HardwareAccelerator()
@@ -29,8 +29,8 @@ q = acc.to_device(bf(rng.normal(0, 1, H * hd)))
 caches = [(acc.to_device(bf(rng.normal(0, 0.4, KV * S * hd))), acc.to_device(bf(rng.normal(0, 0.5, KV * hd * S)))) for _ in range(N)]
 attn_out = acc.alloc(H * hd * 2)
 hidden = acc.to_device(bf(rng.normal(0, 1, dim)))
-psum = acc.to_device(np.zeros(H * nsplit, np.uint64))
-slab = acc.to_device(np.zeros(H * hd * nsplit, np.uint64))
+psum = acc.to_device(np.zeros(2 * H * nsplit, np.uint64))
+slab = acc.to_device(np.zeros(2 * H * hd * nsplit, np.uint64))
 row_g = acc.to_device(np.zeros(H * hd // 2, np.uint64))
 WGS = nsplit * KV
 tl = acc.alloc(N * WGS * 8 * 8)
@@ -48,7 +48,7 @@ for epoch in (1, 2, 3):
         mc.KernelTask(k, (WGS * 512, 1, 1), (512, 1, 1),
                       [q, kc, vt, attn_out, psum, slab, row_g, state, np.uint32(n_rep), np.uint32(KV), np.uint32(S), np.float32(hd ** -0.5),
                        np.uint32(nsplit), np.uint32(i + 1), W(ptrs[i & 1][0]), W(ptrs[i & 1][1]), hidden, hidden, np.uint32(dim), np.uint32(128),
-                       np.uint32(1), acc.wrap(tl.device_ptr + i * WGS * 64, WGS * 64)])()
+                       np.uint32(1), np.uint32(FAST), acc.wrap(tl.device_ptr + i * WGS * 64, WGS * 64)])()
     ms = acc.timer_end_ms()
     acc.wait()
     t = tl.download(np.uint64, N * WGS * 8).reshape(N, WGS, 8).astype(np.int64)
