@@ -187,6 +187,8 @@ struct mc_decoder {
     unsigned long long* attn_psum_g = nullptr; // [H][nsplit]            partial softmax denominators
     unsigned long long* attn_slab_g = nullptr; // [KV][nsplit][n_rep][hd] fp32 partial P.V sums
     unsigned long long* attn_row_g = nullptr;  // [H * hd / 2]          the finished attention row, two bf16 per granule (mc_attn_wo_*)
+    unsigned long long* attn_qkv_g = nullptr;  // [KV][(n_rep + 2) hd / 2] the step's rotated queries and K / V row, two bf16 per granule (mc_attn_qkv_wo_*)
+    bool attn_qkv_on = true;     // MC_ATTN_QKV=0: wq|wk|wv as a launch of its own in front of mc_attn_wo_* (A/B, parity)
     bool handoff_fast = true;    // MC_HANDOFF_FAST=0: hand-offs A and B through the fabric only (A/B; handoff.h "the XCD-local fast path")
     bool attn_wo_on = true;      // MC_ATTN_WO=0: the Wo GEMV as a launch of its own behind the one-launch attention (A/B, parity)
     bool attn_fused_on = true;   // MC_ATTN_FUSED=0: scores and P.V as two launches (A/B, parity)
@@ -552,6 +554,18 @@ struct mc_decoder {
                (unsigned)(nsplit * cfg.n_kv_heads) <= (unsigned)dev->prop.multiProcessorCount;
     }
 
+    // ... with wq|wk|wv in the same launch too (attn_block_kernels.hip qkv_in_launch): the built shape, the kv head's
+    // (n_rep + 2) hd / 2 row pairs dealt evenly over its nsplit workgroups, at most two per wave
+    bool
+    attn_qkv_wo_fused(const layer_w& L) const
+    {
+        if (!attn_qkv_on || !attn_qkv_g || !attn_wo_fused(L.wo) || !lin_ok(L.qkv) || L.qkv.lora_cols || cfg.family == MC_FAMILY_GEMMA3) return false;
+        const int hd = cfg.head_dim, n_rep = cfg.n_heads / cfg.n_kv_heads, pg = (n_rep + 2) * hd / 2;
+        const bool built = hd == 128 && L.wo.in == 4096 && L.qkv.in == 4096;
+        return built && L.qkv.group == L.wo.group && pg % nsplit == 0 && pg / nsplit <= 16 && n_rep <= 16 &&
+               L.qkv.out == (cfg.n_heads + 2 * cfg.n_kv_heads) * hd && pg >= 64 && pg <= 512;
+    }
+
     // dynamic LDS of a linear-order int4 GEMV (gemv(): the padded row, the scratch, the parked sums of eight waves)
     static unsigned
     lin_lds_bytes(const linear_w& L)
@@ -728,7 +742,21 @@ struct mc_decoder {
         }
         for (int li = 0; li < n_own; li++) {
             layer_w& L = layers[li];
-            if (!gemma) {
+            const bool qkv_in = attn_qkv_wo_fused(L);
+            if (qkv_in) {
+                // attention_norm, wq|wk|wv, rope, cache write, scores, softmax, P.V, wo + residual (transformer.h:130-133,
+                // attention.h:170-205) in ONE launch: every hand-off but the last stays inside one kv head
+                s = launch("mc_attn_qkv_wo_i4_" + tname + "_hd" + std::to_string(hd) + "_k" + std::to_string(L.wo.in / 2048) + "_q" +
+                               std::to_string(L.qkv.in / 2048),
+                           (unsigned)(nsplit * KV), 1, 1, 512, 0,
+                           pack((const void*)L.kc, (const void*)L.vt, attn_out, attn_psum_g, attn_slab_g, attn_row_g, attn_qkv_g, state,
+                                (uint32_t)n_rep, (uint32_t)KV, (uint32_t)cfg.max_seq_len, scale_T, (uint32_t)nsplit, (uint32_t)(li + 1),
+                                (const void*)L.wo.w, (const void*)L.wo.scales, x, hidden, (uint32_t)L.wo.out, (uint32_t)L.wo.group,
+                                (const void*)L.attention_norm, (const void*)L.qkv.w, (const void*)L.qkv.scales,
+                                (const float*)rope_cos[L.rope_table], (const float*)rope_sin[L.rope_table], cfg.norm_eps, mu,
+                                (uint32_t)(handoff_fast ? 1 : 0), (void*)nullptr));
+                if (s != MC_OK) return s;
+            } else if (!gemma) {
                 // attention_norm + wq|wk|wv + rope + cache write in ONE launch
                 // (transformer.h:130, attention.h:170-177)
                 s = gemv(L.qkv, 1, 4, x, qkv, L.qkv_epi, L.attention_norm, mu);
@@ -752,7 +780,8 @@ struct mc_decoder {
                                 (uint32_t)cfg.max_seq_len, cfg.norm_eps, mu));
                 if (s != MC_OK) return s;
             }
-            if (attn_wo_fused(L.wo)) {
+            if (qkv_in) {
+            } else if (attn_wo_fused(L.wo)) {
                 // scores, softmax, P.V, wo + residual  (attention.h:191-205, transformer.h:132-133) in ONE launch
                 s = launch("mc_attn_wo_i4_" + tname + "_hd" + std::to_string(hd) + "_k" + std::to_string(L.wo.in / 2048),
                            (unsigned)(nsplit * KV), 1, 1, 512, 0,
@@ -1205,6 +1234,7 @@ mc_decoder_create(mc_device* dev, mc_library* lib, mc_queue* q, const mc_decoder
     if (const char* e = getenv("MC_ATTN_FUSED")) d->attn_fused_on = atoi(e) != 0;
     if (const char* e = getenv("MC_ATTN_WO")) d->attn_wo_on = atoi(e) != 0;
     if (const char* e = getenv("MC_HANDOFF_FAST")) d->handoff_fast = atoi(e) != 0;
+    if (const char* e = getenv("MC_ATTN_QKV")) d->attn_qkv_on = atoi(e) != 0;
     if (const char* e = getenv("MC_ATTN_FUSED_WGS")) d->attn_fused_max_wgs_per_cu = (unsigned)std::max(1, std::min(4, atoi(e)));
     if (const char* e = getenv("MC_LING_HALF")) d->ling_half = atoi(e) != 0;
     if (const char* e = getenv("MC_LIN_SPLIT")) d->lin_split = atoi(e) != 0;
@@ -1248,6 +1278,7 @@ mc_decoder_create(mc_device* dev, mc_library* lib, mc_queue* q, const mc_decoder
         A(d->attn_psum_g, (size_t)H * d->nsplit * 8 * 2);
         A(d->attn_slab_g, (size_t)H * hd * d->nsplit * 8 * 2);
         A(d->attn_row_g, (size_t)H * hd / 2 * 8);
+        A(d->attn_qkv_g, (size_t)(H + 2 * KV) * hd / 2 * 8 * 2);
     }
     A(d->taps, (size_t)(d->n_own + 1) * dim * tb);
     A(d->state, sizeof(step_state_h));

@@ -22,19 +22,248 @@ namespace {
 using namespace mc;
 using namespace mc::gemv;
 
-// LNCH = KiB of packed weights per Wo row (K = H * hd = 2048 LNCH)
-template <int HD, int LNCH>
+
+// ------------------------------------------------------------------------------------------
+// wq|wk|wv INSIDE the attention launch (round 4, mc_attn_qkv_wo_*): the query-source policy of attn_fused_bf (decode_kernels.hip)
+// that computes the step's queries and its K / V row in the launch that consumes them.
+//
+// Why: as a launch of its own the wq|wk|wv GEMV lasts 6.2 us for 2.1 us of stream -- a launch boundary, the wave start, a
+// dependent prologue and an epilogue whose results make a round trip through HBM, then the attention launch pays the same again
+// before its first score.  Attention needs nothing of wq|wk|wv but the rows of ITS kv head: the 32 workgroups of kv head g (in
+// practice one XCD: blockIdx.x % KV) compute exactly those -- the n_rep query heads, the K row and the V row of head g, 384 row
+// pairs of the packed matrix, 12 per workgroup, 1 or 2 per wave, all of a wave's weights requested up front (<= 32 registers) --
+// and hand them to one another as {2 x bf16, tag} granules through the XCD's L2 (hand-off Q: handoff.h "the XCD-local fast
+// path"; a member on another XCD is served by the fabric copy).  Nothing crosses kv heads, so the chip-wide exchange of the
+// two-launch form (the rotated queries through HBM behind a kernel boundary) becomes 8 local ones.
+//
+// Numerics: bit for bit mc_gemv_i4_bfloat_lin{QN}_p1_e4 -- the rmsnorm prologue in the stand-alone order (per-thread packet sums,
+// wave_sum_dpp, the eight wave sums in wave order), mac4b_n chunk by chunk into one accumulator per row, one wave sum, the
+// epilogue of gemv.h finish_pair (EPI_QKV_ROPE: T(row sum), rotation in fp32 with two roundings, cache write).  Which workgroup
+// multiplies a pair does not change a bit of it.  The packed matrix is read where it lies: pair j of group g is packed pair
+// pp(j) (q heads of the group, then its k head, then its v head), 4 KiB of contiguous rows whichever wave takes it.
+// ------------------------------------------------------------------------------------------
+template <int HD, int QN>
+struct qkv_in_launch {
+    static_assert(QN == 2, "one 16-byte packet of the hidden row per thread (K = 4096, 512 threads)");
+    static constexpr bool LDS = true;
+    static constexpr int TL_STRIDE = 16, TL_BASE = 3; // stamps: 0 start, 1 row staged, 2 pairs published, 3.. attn_fused_bf's 0..
+    static constexpr uint32_t KQ = 2048u * QN, ROWBQ = KQ / 2, CHUNK_LDS = 2048 * 2 / 16 * 17, HALF = HD / 2;
+    static constexpr int PMAXQ = 2;
+    typedef const __attribute__((address_space(3))) bf16_t* lds_row;
+    typedef __attribute__((address_space(3))) bf16_t* lds_row_w;
+    typedef uint32_t rowv4 __attribute__((ext_vector_type(4)));
+    lds_row q_s, k_s, v_s;
+    // ---- what the launch was given
+    const void *xp, *normp, *qw, *qs;
+    const float *fcos, *fsin;
+    bf16_t *kc, *vt;
+    unsigned long long* qkv_g; // [KV][(n_rep + 2) HD / 2] granules, the XCD-local copies behind them
+    step_state* st;
+    char* xs;     // the row in LDS (padded for the transposed reads: gemv.h Q_M4D)
+    float* red;   // 16 floats of scratch
+    uint32_t n_rep, KV, max_seq, nsplit, group, layer_tag, fastpath;
+    float eps, mu;
+    unsigned long long* tl;
+    // ---- what at_start() leaves for before_scores()
+    rowv4 xr, nr;
+    uint4 ww[PMAXQ][2][QN];
+    uint32_t wsc[PMAXQ][QN];
+    float eo_c, eo_s;
+    uint32_t j0, cnt, slot, tag;
+
+    __device__ __forceinline__ void stamp(int i) const
+    {
+        if (tl && threadIdx.x == 0) tl[(size_t)blockIdx.x * TL_STRIDE + i] = __builtin_amdgcn_s_memrealtime();
+    }
+    // packed pair (gemv.h EPI_QKV_ROPE: q heads, k heads, v heads; rotation partners adjacent) of pair j of kv head `kv`
+    __device__ __forceinline__ uint32_t pp_of(uint32_t kv, uint32_t j) const
+    {
+        const uint32_t hq = n_rep * HALF, H = n_rep * KV;
+        return j < hq ? kv * hq + j : (j < hq + HALF ? H * HALF + kv * HALF + (j - hq) : (H + KV) * HALF + kv * HALF + (j - hq - HALF));
+    }
+    __device__ __forceinline__ void at_start()
+    {
+        stamp(0);
+        const uint32_t tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        // the row first (gemv.h, the build-time prologue of the linear-order kernels), the step state with scalar loads
+        xr = reinterpret_cast<const rowv4*>(xp)[tid];
+        nr = reinterpret_cast<const rowv4*>(normp)[tid];
+        const __attribute__((address_space(1))) int32_t* stp = (const __attribute__((address_space(1))) int32_t*)st;
+        slot = (uint32_t)stp[3];
+        const uint32_t rrow = (uint32_t)stp[6];
+        tag = (uint32_t)stp[9] * 256u + layer_tag;
+        asm volatile("s_barrier" ::: "memory"); // (the row's requests stay ahead of the weight requests in the CU's memory pipe)
+        const uint32_t kv = blockIdx.x % KV, split = blockIdx.x / KV;
+        const uint32_t PG = (n_rep + 2u) * HALF, PW = PG / nsplit, e = PW >> 3, r = PW & 7u;
+        cnt = e + (wave < r ? 1u : 0u);
+        j0 = split * PW + wave * e + min(wave, r);
+        const uint32_t glog = group ? 31u - __builtin_clz(group) : 31u, ngroups = group ? KQ >> glog : 1u;
+#pragma unroll
+        for (int i = 0; i < PMAXQ; i++) {
+            if ((uint32_t)i >= cnt) break; // (wave-uniform)
+            const uint32_t pp = pp_of(kv, j0 + i);
+            const char* wrow = static_cast<const char*>(qw) + (size_t)pp * 2 * ROWBQ + lane * 16;
+#pragma unroll
+            for (int rr = 0; rr < 2; rr++)
+#pragma unroll
+                for (int c = 0; c < QN; c++) {
+                    const rowv4 v = __builtin_nontemporal_load(reinterpret_cast<const rowv4*>(wrow + (size_t)rr * ROWBQ + c * 1024));
+                    ww[i][rr][c] = make_uint4(v.x, v.y, v.z, v.w);
+                }
+            const char* srow = static_cast<const char*>(qs) + (((size_t)(pp >> 1) * ngroups) * 4 + (pp & 1u) * 2) * 2;
+#pragma unroll
+            for (int c = 0; c < QN; c++) {
+                const uint32_t g = group ? ((2048u * c + 32u * lane) >> glog) : 0u;
+                wsc[i][c] = *reinterpret_cast<const uint32_t*>(srow + g * 8u);
+            }
+        }
+        // the rotation of the pair this lane will finish (lane i < cnt: pair j0 + i), behind the weights: needed behind them
+        typedef const __attribute__((address_space(1))) float* gfloat_p;
+        const uint32_t jm = j0 + min(lane, cnt ? cnt - 1u : 0u), jj = jm < (n_rep + 1u) * HALF ? jm % HALF : 0u;
+        eo_c = ((gfloat_p)fcos)[(size_t)rrow * HALF + jj];
+        eo_s = ((gfloat_p)fsin)[(size_t)rrow * HALF + jj];
+    }
+    __device__ __forceinline__ void before_scores()
+    {
+        const uint32_t tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const uint32_t kv = blockIdx.x % KV;
+        const uint32_t PG = (n_rep + 2u) * HALF;
+        // ---- rmsnorm on the way into LDS (kernel/rmsnorm.metal:52-95; the additions in the stand-alone kernel's order)
+        {
+            const uint32_t vv[4] = {xr.x, xr.y, xr.z, xr.w}, wv[4] = {nr.x, nr.y, nr.z, nr.w};
+            float ss = 0.0f;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const float a = asf(vv[e] << 16), b = asf(vv[e] & 0xFFFF0000u);
+                ss += a * a;
+                ss += b * b;
+            }
+            const float wsum_ = wave_sum_dpp(ss);
+            if (lane == 0) red[wave] = wsum_;
+            __syncthreads();
+            float tot = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 8; i++) tot += red[i];
+            const float inv = 1.0f / sqrtf(tot / (float)KQ + eps);
+            uint32_t o[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const float a = (mu + asf(wv[e] << 16)) * asf(vv[e] << 16) * inv;
+                const float b = (mu + asf(wv[e] & 0xFFFF0000u)) * asf(vv[e] & 0xFFFF0000u) * inv;
+                o[e] = pack_bf16x2(a, b);
+            }
+            reinterpret_cast<rowv4*>(xs)[tid + (tid >> 4)] = rowv4{o[0], o[1], o[2], o[3]}; // (packet p sits in slot p + p / 16)
+        }
+        __syncthreads();
+        stamp(1);
+        // ---- the wave's pairs from registers (mc_gemv_i4_bfloat_lin{QN}_p1_e4's arithmetic)
+        const uint32_t lane_tr = (((lane >> 4) * 4 + (lane & 3)) * 17 + ((lane >> 2) & 3) * 4) * 16;
+        const m4b_lane m4bk = m4b_lane_consts(lane);
+        typedef __attribute__((address_space(3))) mf_s4 lds_s4;
+        uint2 x[QN][8];
+#pragma unroll
+        for (int c = 0; c < QN; c++) {
+            lds_s4* xt = (lds_s4*)(xs + c * CHUNK_LDS + lane_tr);
+#pragma unroll
+            for (int e = 0; e < 8; e++) x[c][e] = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16(xt + e));
+        }
+        float my_a = 0.0f, my_b = 0.0f;
+#pragma unroll
+        for (int i = 0; i < PMAXQ; i++) {
+            if ((uint32_t)i >= cnt) break;
+            float rsum[2];
+#pragma unroll
+            for (int rr = 0; rr < 2; rr++) {
+                mf_f4 acc[1] = {mf_f4{0, 0, 0, 0}};
+#pragma unroll
+                for (int c = 0; c < QN; c++) {
+                    const uint32_t raw = wsc[i][c];
+                    mac4b_n<1>(acc, ww[i][rr][c], m4b_prepare(rr ? (raw & 0xFFFF0000u) : (raw << 16), m4bk), x[c]);
+                }
+                const uint32_t e = lane & 3;
+                const float mine = e == 0 ? acc[0][0] : (e == 1 ? acc[0][1] : (e == 2 ? acc[0][2] : acc[0][3]));
+                rsum[rr] = wave_sum_dpp(mine) * 0x1p37f; // 2^M4B_Q: the sum was formed at 2^-Q (mac4b_n)
+            }
+            if (lane == (uint32_t)i) {
+                my_a = rsum[0];
+                my_b = rsum[1];
+            }
+        }
+        // ---- the epilogue of gemv.h finish_pair (EPI_QKV_ROPE), one lane per pair; the pair goes to the cache (k, v: for the
+        // steps to come) and, as ONE granule {first | second << 16}, to the workgroups of this kv head (hand-off Q)
+        if (lane < cnt) {
+            typedef __attribute__((address_space(1))) bf16_t* gS_p;
+            const uint32_t j = j0 + lane, hq = n_rep * HALF;
+            uint32_t g;
+            if (j < hq + HALF) {
+                const float x1 = BF::rt(my_a), x2 = BF::rt(my_b);
+                const bf16_t o1 = BF::st(eo_c * x1 - eo_s * x2), o2 = BF::st(eo_s * x1 + eo_c * x2);
+                if (j >= hq) {
+                    gS_p dst = (gS_p)kc + ((size_t)kv * max_seq + slot) * HD;
+                    dst[j - hq] = o1;
+                    dst[j - hq + HALF] = o2;
+                }
+                g = (uint32_t)o1 | ((uint32_t)o2 << 16);
+            } else {
+                const uint32_t d = 2u * (j - hq - HALF);
+                const bf16_t va = BF::st(my_a), vb = BF::st(my_b);
+                ((gS_p)vt)[((size_t)kv * HD + d) * max_seq + slot] = va;
+                ((gS_p)vt)[((size_t)kv * HD + d + 1) * max_seq + slot] = vb;
+                g = (uint32_t)va | ((uint32_t)vb << 16);
+            }
+            unsigned long long* gp = qkv_g + (size_t)kv * PG + j;
+            if (fastpath) granule_store_dual(gp, (size_t)KV * PG, tag, g);
+            else granule_store(gp, tag, g);
+        }
+        stamp(2);
+        // ---- hand-off Q: the PG pairs of this kv head into LDS (thread t: pair t), natural order
+        if (wave * 64u < PG) {
+            const unsigned long long* gp = qkv_g + (size_t)kv * PG + min(tid, PG - 1u);
+            unsigned long long g = 0ull;
+            handoff_wait w;
+            for (uint32_t look = 0;; look++) {
+                g = fastpath ? granule_look_dual(gp, (size_t)KV * PG, look) : granule_load(gp);
+                const bool ok = (uint32_t)(g >> 32) == tag;
+                if (__all(ok) || w.expired(st, 0xD0000000u | layer_tag)) break;
+            }
+            if (tid < PG) {
+                const uint32_t hq = n_rep * HALF;
+                const bf16_t lo = (bf16_t)(g & 0xFFFFu), hi = (bf16_t)((g >> 16) & 0xFFFFu);
+                lds_row_w qw_ = (lds_row_w)q_s;
+                if (tid < hq + HALF) { // q heads of the group, then its k head: [head][HD], element jj and jj + HD / 2
+                    const uint32_t hl = tid / HALF, jj = tid % HALF;
+                    qw_[hl * HD + jj] = lo;
+                    qw_[hl * HD + jj + HALF] = hi;
+                } else { // v: elements 2 jj, 2 jj + 1
+                    const uint32_t jj = tid - hq - HALF;
+                    *(__attribute__((address_space(3))) uint32_t*)(qw_ + (n_rep + 1u) * HD + 2u * jj) = (uint32_t)g;
+                }
+            }
+        }
+        __syncthreads();
+    }
+};
+
+// LNCH = KiB of packed weights per Wo row (K = H * hd = 2048 LNCH); QN != 0: wq|wk|wv (rows of QN KiB) in this launch too -- qx
+template <int HD, int LNCH, int QN = 0>
 __device__ __forceinline__ void
 attn_wo_body(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const bf16_t* __restrict__ vt, bf16_t* __restrict__ attn_out,
              unsigned long long* psum_g, unsigned long long* slab_g, unsigned long long* row_g, step_state* st, uint32_t n_rep,
              uint32_t KV, uint32_t max_seq, float scale, uint32_t nsplit, uint32_t layer_tag, const void* __restrict__ wo_w,
              const void* __restrict__ wo_s, const bf16_t* res, bf16_t* y, uint32_t out_rows, uint32_t group, uint32_t has_res,
-             uint32_t fastpath, unsigned long long* tl)
+             uint32_t fastpath, unsigned long long* tl,
+             // QN != 0: the hidden row is `res`; its norm weight, the packed wq|wk|wv matrix and its scales, the rope tables, the
+             // granules of hand-off Q
+             const void* __restrict__ qnorm_w = nullptr, const void* __restrict__ qkv_w = nullptr, const void* __restrict__ qkv_s = nullptr,
+             const float* fcos = nullptr, const float* fsin = nullptr, unsigned long long* qkv_g = nullptr, float eps = 0.0f, float mu = 0.0f)
 {
     constexpr uint32_t K = 2048u * LNCH;
     constexpr uint32_t CHUNK_LDS = 2048 * 2 / 16 * 17;  // a chunk of the row in LDS: 16 bytes of padding per 256 (gemv.h Q_M4D)
     constexpr uint32_t ROWB = K / 2;                     // bytes of packed weights per row
-    __shared__ __attribute__((aligned(16))) char xs[LNCH * CHUNK_LDS];
+    // (QN != 0: the hidden row of the wq|wk|wv phase first, the attention row of the Wo phase later: hand-off C lies between them)
+    __shared__ __attribute__((aligned(16))) char xs[(LNCH > QN ? LNCH : QN) * CHUNK_LDS];
+    __shared__ float qred[QN ? 16 : 1];
+    __shared__ __attribute__((aligned(16))) bf16_t qkv_rows[QN ? 18 * HD : 8]; // queries of up to 16 heads, the K row, the V row
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
     // ---- the Wo row pairs of this wave: contiguous spans dealt as the linear-order kernels deal theirs, at most PMAX each (the
@@ -92,10 +321,24 @@ attn_wo_body(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const 
             if ((col & 1u) == 0) granule_store(row_g + ((size_t)head * HD + db * 16 + col) / 2, epoch_tag, pack_bf16x2(v, vn));
         }
     };
-    attn_fused_bf<HD, 1, 8>(q, kc, vt, psum_g, slab_g, st, n_rep, KV, max_seq, scale, nsplit, layer_tag, tl, publish, request_wo, fastpath);
+    constexpr int TL_STRIDE = QN ? 16 : 8, TL_BASE = QN ? 3 : 0;
+    if constexpr (QN != 0) {
+        qkv_in_launch<HD, QN> qx;
+        typedef typename qkv_in_launch<HD, QN>::lds_row lds_row;
+        qx.q_s = (lds_row)qkv_rows;
+        qx.k_s = (lds_row)qkv_rows + n_rep * HD;
+        qx.v_s = (lds_row)qkv_rows + (n_rep + 1u) * HD;
+        qx.xp = res; qx.normp = qnorm_w; qx.qw = qkv_w; qx.qs = qkv_s; qx.fcos = fcos; qx.fsin = fsin;
+        qx.kc = const_cast<bf16_t*>(kc); qx.vt = const_cast<bf16_t*>(vt); qx.qkv_g = qkv_g; qx.st = st; qx.xs = xs; qx.red = qred;
+        qx.n_rep = n_rep; qx.KV = KV; qx.max_seq = max_seq; qx.nsplit = nsplit; qx.group = group; qx.layer_tag = layer_tag;
+        qx.fastpath = fastpath; qx.eps = eps; qx.mu = mu; qx.tl = tl;
+        attn_fused_bf<HD, 1, 8>(q, kc, vt, psum_g, slab_g, st, n_rep, KV, max_seq, scale, nsplit, layer_tag, tl, publish, request_wo, fastpath, qx);
+    } else {
+        attn_fused_bf<HD, 1, 8>(q, kc, vt, psum_g, slab_g, st, n_rep, KV, max_seq, scale, nsplit, layer_tag, tl, publish, request_wo, fastpath);
+    }
     // tl != null (tools/attn_wo_timeline.py only): thread 0 of every workgroup leaves s_memrealtime stamps of its phases
     auto stamp = [&](int i) {
-        if (tl && threadIdx.x == 0) tl[(size_t)blockIdx.x * 8 + i] = __builtin_amdgcn_s_memrealtime();
+        if (tl && threadIdx.x == 0) tl[(size_t)blockIdx.x * TL_STRIDE + TL_BASE + i] = __builtin_amdgcn_s_memrealtime();
     };
 
     // ---- hand-off C: the whole attention row (K bf16 = K / 2 granules) into LDS, padded as the transposed reads want it
@@ -178,6 +421,22 @@ attn_wo_body(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const 
         attn_wo_body<HD, LNCH>(q, kc, vt, attn_out, psum_g, slab_g, row_g, st, n_rep, n_kv, max_seq, scale, nsplit, layer_tag, wo_w,     \
                                wo_s, res, y, out_rows, group, has_res, fastpath, tl);                                                    \
     }
+// ... with wq|wk|wv in the launch too (qkv_in_launch above): one launch from the hidden row to the hidden row
+#define MC_ATTN_QKV_WO(NAME, HD, LNCH, QN)                                                                                                \
+    extern "C" __global__ void __launch_bounds__(512)                                                                                    \
+    NAME(const bf16_t* kc, const bf16_t* vt, bf16_t* attn_out, unsigned long long* psum_g, unsigned long long* slab_g,                  \
+         unsigned long long* row_g, unsigned long long* qkv_g, step_state* st, uint32_t n_rep, uint32_t n_kv, uint32_t max_seq,         \
+         float scale, uint32_t nsplit, uint32_t layer_tag, const void* wo_w, const void* wo_s, const bf16_t* x, bf16_t* y,              \
+         uint32_t out_rows, uint32_t group, const void* qnorm_w, const void* qkv_w, const void* qkv_s, const float* fcos, const float* fsin, float eps,    \
+         float mu, uint32_t fastpath, unsigned long long* tl)                                                                            \
+    {                                                                                                                                    \
+        attn_wo_body<HD, LNCH, QN>(nullptr, kc, vt, attn_out, psum_g, slab_g, row_g, st, n_rep, n_kv, max_seq, scale, nsplit, layer_tag, \
+                                   wo_w, wo_s, x, y, out_rows, group, 1u, fastpath, tl, qnorm_w, qkv_w, qkv_s, fcos, fsin,               \
+                                   qkv_g, eps, mu);                                                                                      \
+    }
+// mc_attn_qkv_wo_i4_bfloat_hd{head_dim}_k{KiB per Wo row}_q{KiB per wq|wk|wv row}
+MC_ATTN_QKV_WO(mc_attn_qkv_wo_i4_bfloat_hd128_k2_q2, 128, 2, 2)  // Llama-3-8B: dim 4096, 32 heads x 128
+
 // mc_attn_wo_i4_bfloat_hd{head_dim}_k{KiB per Wo row}
 MC_ATTN_WO(mc_attn_wo_i4_bfloat_hd128_k2, 128, 2)  // Llama-3-8B: 32 heads x 128
 // (hd128_k4 -- Llama-3-70B's 64 heads, 131 KB of Wo per CU -- was built and bit-identical too, and SLOWER than the two launches:

@@ -611,21 +611,37 @@ mc_attn_pv_reduce_float(const float* __restrict__ parts, float* __restrict__ out
 // chunk (head, 16-column block db), v = the fp32 sum of column 16 db + col over all ranges, in range order.
 // behind_scores(): called once by every wave when its partial denominators are out, in front of the wait of hand-off A -- where a
 // caller puts requests that must not compete with the K tile (mc_attn_wo_*: the Wo weights).
-template <int HD, int T, int NW, typename OnChunk, typename BehindScores>
+// Where the step's own query rows come from.  q_from_hbm: the rotated queries a launch of their own left in HBM (the wq|wk|wv
+// GEMV's epilogue, gemv.h EPI_QKV_ROPE), the step's K / V row already in the cache.  A policy with LDS = true (attn_block_kernels.hip,
+// mc_attn_qkv_wo_*) computes them INSIDE this launch: at_start() is called by every wave before the K and V tiles are requested
+// (its own requests go first in the CU's memory pipe), before_scores() once the tiles are requested -- it returns behind a
+// workgroup barrier with the queries of this kv head in q_s [n_rep][HD] and the step's K / V row of this kv head in k_s / v_s [HD]
+// (LDS); the tile registers of the step's slot are then patched from there (the cache row itself is written by the workgroup
+// that computed it, for the steps to come: whatever a tile load found in that slot is never used).
+struct q_from_hbm {
+    static constexpr bool LDS = false;
+    static constexpr int TL_STRIDE = 8, TL_BASE = 0;
+    typedef const __attribute__((address_space(3))) bf16_t* lds_row; // (LDS address space: a generic pointer would make these flat loads)
+    lds_row q_s = nullptr, k_s = nullptr, v_s = nullptr;
+    __device__ __forceinline__ void at_start() {}
+    __device__ __forceinline__ void before_scores() {}
+};
+template <int HD, int T, int NW, typename OnChunk, typename BehindScores, typename QSrc = q_from_hbm>
 __device__ __forceinline__ void
 attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const bf16_t* __restrict__ vt,
               unsigned long long* psum_g, unsigned long long* slab_g, step_state* st, uint32_t n_rep, uint32_t KV, uint32_t max_seq,
               float scale, uint32_t nsplit, uint32_t layer_tag, unsigned long long* tl, OnChunk&& on_chunk, BehindScores&& behind_scores,
-              uint32_t fastpath)
+              uint32_t fastpath, QSrc qsrc = QSrc())
 {
     // fastpath != 0: hand-offs A and B publish every granule twice and look at the XCD-local copy first (handoff.h, round 4); the
     // buffers are then twice as long, the `fast` words behind the `slow` ones
     const size_t psum_fast = (size_t)KV * n_rep * nsplit, slab_fast = (size_t)KV * nsplit * n_rep * HD;
     // tl != null (tools/attn_timeline.py only): thread 0 of every workgroup leaves s_memrealtime stamps of its phases
     auto stamp = [&](int i) {
-        if (tl && threadIdx.x == 0) tl[(size_t)blockIdx.x * 8 + i] = __builtin_amdgcn_s_memrealtime();
+        if (tl && threadIdx.x == 0) tl[(size_t)blockIdx.x * QSrc::TL_STRIDE + QSrc::TL_BASE + i] = __builtin_amdgcn_s_memrealtime();
     };
     stamp(0);
+    qsrc.at_start();
     constexpr int KS = HD / 32;                 // MFMA k-steps of q.k
     constexpr int NDB = HD / 16;                // 16-column blocks of the output
     constexpr int NB = NDB >= NW ? NDB / NW : 1; // ... per wave
@@ -671,13 +687,54 @@ attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const
                 vb[t][b][u] = *reinterpret_cast<const uint4*>(vrow + (p0 + 8 <= max_seq ? p0 : max_seq - 8));
             }
         }
+    if constexpr (QSrc::LDS) {
+        static_assert(T == 1, "queries computed in the launch: 64-slot ranges");
+        // the tile requests stay HERE, in front of the phase that computes the queries (a value used on a never-taken path cannot
+        // be sunk past the branch, and is not waited for on the path that is taken)
+        uint32_t never;
+        asm volatile("s_mov_b32 %0, 0" : "=s"(never));
+        if (never) {
+#pragma unroll
+            for (int b = 0; b < NB; b++) asm volatile("" ::"v"(vb[0][b][0].x), "v"(vb[0][b][1].w));
+#pragma unroll
+            for (int ks = 0; ks < KS; ks++) asm volatile("" ::"v"(kb[0][ks].x));
+        }
+        qsrc.before_scores();
+    }
     uint4 qa[KS];
     if (scorer) {
         // (rows past n_rep of the A operand: the row of the last query head again -- their results are never read; an
         //  unconditional load keeps the compiler's counted waits, a load behind a lane-dependent branch costs every one of them)
         const uint32_t qh = col < n_rep ? col : n_rep - 1;
 #pragma unroll
-        for (int ks = 0; ks < KS; ks++) qa[ks] = *reinterpret_cast<const uint4*>(q + (size_t)(kv * n_rep + qh) * HD + ks * 32 + c * 8);
+        for (int ks = 0; ks < KS; ks++) {
+            if constexpr (QSrc::LDS) qa[ks] = *(const __attribute__((address_space(3))) uint4*)(qsrc.q_s + qh * HD + ks * 32 + c * 8);
+            else qa[ks] = *reinterpret_cast<const uint4*>(q + (size_t)(kv * n_rep + qh) * HD + ks * 32 + c * 8);
+        }
+    }
+    if constexpr (QSrc::LDS) {
+        // the step's own row: its slot of the K tile and its column of the V tile come from LDS (q_from_hbm's note)
+        const uint32_t ws = (uint32_t)st->write_slot;
+        if (scorer && p_begin + wave * 16 + col == ws) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ks++) kb[0][ks] = *(const __attribute__((address_space(3))) uint4*)(qsrc.k_s + ks * 32 + c * 8);
+        }
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+            const uint32_t db = wave + NW * b;
+            const uint32_t vnew = (uint32_t)qsrc.v_s[(db < (uint32_t)NDB ? db : 0u) * 16 + col];
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const uint32_t e = ws - (p_begin + u * 32 + c * 8); // element of the lane's eight slots, if < 8
+                uint32_t w4[4] = {vb[0][b][u].x, vb[0][b][u].y, vb[0][b][u].z, vb[0][b][u].w};
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const uint32_t lo = (w4[i] & 0xFFFF0000u) | vnew, hi = (w4[i] & 0x0000FFFFu) | (vnew << 16);
+                    w4[i] = e == 2u * i ? lo : (e == 2u * i + 1u ? hi : w4[i]);
+                }
+                vb[0][b][u] = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+            }
+        }
     }
     const uint32_t S = (uint32_t)st->kv_len;
     const uint32_t tag = st->epoch * 256u + layer_tag;

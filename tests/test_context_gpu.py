@@ -408,10 +408,12 @@ def test_attention_and_wo_in_one_launch_equal_the_two_launches_bit_for_bit(acc, 
                    rope_sliding_theta=10000.0, sliding_stride=2, attn_scale=256 ** -0.5)
         kernel = "mc_attn_wo_i4_bfloat_hd256_k2"
     S = cfg["max_seq_len"]
-    # "wo": the default, attention + Wo in one launch;  "sep": mc_attn_fused_bfloat, then the Wo GEMV
+    # "qkv": the default where it is built (round 4: wq|wk|wv, attention and Wo in ONE launch, mc_attn_qkv_wo_*);  "wo": the wq|wk|wv GEMV,
+    # then attention + Wo in one launch;  "sep": the GEMV, mc_attn_fused_bfloat, then the Wo GEMV
+    qkv_kernel = "mc_attn_qkv_wo_i4_bfloat_hd128_k2_q2" if shape == "llama3-8b" else None
     out = {}
-    for form, env in (("wo", {}), ("sep", {"MC_ATTN_WO": "0"})):
-        for k_ in ("MC_ATTN_WO",):
+    for form, env in (("qkv", {}), ("wo", {"MC_ATTN_QKV": "0"}), ("sep", {"MC_ATTN_WO": "0"})):
+        for k_ in ("MC_ATTN_WO", "MC_ATTN_QKV"):
             monkeypatch.delenv(k_, raising=False)
         for k_, v_ in env.items():
             monkeypatch.setenv(k_, v_)
@@ -433,11 +435,14 @@ def test_attention_and_wo_in_one_launch_equal_the_two_launches_bit_for_bit(acc, 
         if kernel is None:   # a shape the one-launch form with Wo does not cover: both forms are attention + a Wo launch
             assert not any(n.startswith("mc_attn_wo_") for n in names) and "mc_attn_fused_bfloat" in names, sorted(names)
         else:
-            assert (kernel in names) == (form != "sep"), sorted(names)
+            took_qkv = form == "qkv" and qkv_kernel is not None
+            assert (qkv_kernel in names) == took_qkv, sorted(names)
+            assert (kernel in names) == (form != "sep" and not took_qkv), sorted(names)
             assert ("mc_attn_fused_bfloat" in names) == (form == "sep"), sorted(names)
+            assert any(n.endswith("_p1_e4") or n.endswith("_p2_e0") or n.endswith("_p1_e0") for n in names) == (not took_qkv), sorted(names)
         out[form] = (rows, kk, vv)
         dec.release()
-    for form in ("wo",):
+    for form in ("qkv", "wo"):
         for i, ((ta, la, ha), (tb_, lb, hb)) in enumerate(zip(out[form][0], out["sep"][0])):
             assert ta == tb_, (shape, form, i)
             parity.exact(ha, hb, f"{shape} step {i}: hidden rows, {form} vs separate launches")
