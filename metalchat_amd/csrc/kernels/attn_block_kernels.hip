@@ -42,6 +42,9 @@ using namespace mc::gemv;
 // multiplies a pair does not change a bit of it.  The packed matrix is read where it lies: pair j of group g is packed pair
 // pp(j) (q heads of the group, then its k head, then its v head), 4 KiB of contiguous rows whichever wave takes it.
 // ------------------------------------------------------------------------------------------
+#ifndef MC_QKV_ROW_DEAL
+#define MC_QKV_ROW_DEAL 0 // 1: the remainder pairs dealt in rows (below).  Same box, three alternating runs: 784 tokens/s with, 798 without
+#endif
 template <int HD, int QN>
 struct qkv_in_launch {
     static_assert(QN == 2, "one 16-byte packet of the hidden row per thread (K = 4096, 512 threads)");
@@ -69,7 +72,7 @@ struct qkv_in_launch {
     uint4 ww[PMAXQ][2][QN];
     uint32_t wsc[PMAXQ][QN];
     float eo_c, eo_s;
-    uint32_t j0, cnt, slot, tag;
+    uint32_t j0, cnt, slot, tag, rrow_; // cnt: pairs this wave finishes (lane i < cnt: one each)
 
     __device__ __forceinline__ void stamp(int i) const
     {
@@ -81,53 +84,99 @@ struct qkv_in_launch {
         const uint32_t hq = n_rep * HALF, H = n_rep * KV;
         return j < hq ? kv * hq + j : (j < hq + HALF ? H * HALF + kv * HALF + (j - hq) : (H + KV) * HALF + kv * HALF + (j - hq - HALF));
     }
-    __device__ __forceinline__ void at_start()
+    // The deal of the workgroup's PW pairs over its eight waves.  Waves w and w + 4 share SIMD w, and a wave alone on its SIMD
+    // multiplies at ~ 60 % of the rate two reach together (MFMA and VALU issue overlap only ACROSS waves), so
+    // whole pairs -- (2, 1) per SIMD for Llama-3-8B's 12 -- leave the second pair of wave w without a partner.  Where the
+    // remainder is four pairs (PW % 8 == 4) they are dealt in ROWS: wave w < 4 takes e whole pairs and row 0 of a shared pair,
+    // wave w + 4 takes e whole pairs and row 1 of that pair -- three rows each for the 12 -- hands its row sum over through LDS,
+    // and wave w finishes the shared pair.  Who multiplies a row does not change a bit of it.
+    // full: whole pairs of the wave, [j0, j0 + full); js: the shared pair (shared: the wave has a row of it), row sh_row.
+    uint32_t full, js, shared, sh_row;
+    // whole pair i of the wave: its 2 x QN KiB of weights and its scales (every load unconditional -- a load behind a branch costs
+    // every counted s_waitcnt vmcnt(N) of the launch.  A pair the wave does not have reads one broadcast line of the matrix:
+    // masks, not selects -- gemv.h ltile)
+    __device__ __forceinline__ void request_pair(int i)
     {
-        stamp(0);
-        const uint32_t tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-        // the row first (gemv.h, the build-time prologue of the linear-order kernels), the step state with scalar loads
-        xr = reinterpret_cast<const rowv4*>(xp)[tid];
-        nr = reinterpret_cast<const rowv4*>(normp)[tid];
-        const __attribute__((address_space(1))) int32_t* stp = (const __attribute__((address_space(1))) int32_t*)st;
-        slot = (uint32_t)stp[3];
-        const uint32_t rrow = (uint32_t)stp[6];
-        tag = (uint32_t)stp[9] * 256u + layer_tag;
-        asm volatile("s_barrier" ::: "memory"); // (the row's requests stay ahead of the weight requests in the CU's memory pipe)
-        const uint32_t kv = blockIdx.x % KV, split = blockIdx.x / KV;
-        const uint32_t PG = (n_rep + 2u) * HALF, PW = PG / nsplit, e = PW >> 3, r = PW & 7u;
-        cnt = e + (wave < r ? 1u : 0u);
-        j0 = split * PW + wave * e + min(wave, r);
+        const uint32_t lane = threadIdx.x & 63, kv = blockIdx.x % KV;
         const uint32_t glog = group ? 31u - __builtin_clz(group) : 31u, ngroups = group ? KQ >> glog : 1u;
+        const uint32_t lm = 0u - (uint32_t)((uint32_t)i < full ? 1u : 0u);
+        const uint64_t lm64 = ((uint64_t)lm << 32) | lm;
+        const uint32_t pp = pp_of(kv, j0 + i) & lm;
+        const char* wrow = static_cast<const char*>(qw) + (((uint64_t)pp * 2 * ROWBQ) & lm64) + ((lane * 16) & lm);
 #pragma unroll
-        for (int i = 0; i < PMAXQ; i++) {
-            if ((uint32_t)i >= cnt) break; // (wave-uniform)
-            const uint32_t pp = pp_of(kv, j0 + i);
-            const char* wrow = static_cast<const char*>(qw) + (size_t)pp * 2 * ROWBQ + lane * 16;
-#pragma unroll
-            for (int rr = 0; rr < 2; rr++)
-#pragma unroll
-                for (int c = 0; c < QN; c++) {
-                    const rowv4 v = __builtin_nontemporal_load(reinterpret_cast<const rowv4*>(wrow + (size_t)rr * ROWBQ + c * 1024));
-                    ww[i][rr][c] = make_uint4(v.x, v.y, v.z, v.w);
-                }
-            const char* srow = static_cast<const char*>(qs) + (((size_t)(pp >> 1) * ngroups) * 4 + (pp & 1u) * 2) * 2;
+        for (int rr = 0; rr < 2; rr++)
 #pragma unroll
             for (int c = 0; c < QN; c++) {
-                const uint32_t g = group ? ((2048u * c + 32u * lane) >> glog) : 0u;
-                wsc[i][c] = *reinterpret_cast<const uint32_t*>(srow + g * 8u);
+                const rowv4 v = __builtin_nontemporal_load(reinterpret_cast<const rowv4*>(wrow + (((size_t)rr * ROWBQ + c * 1024) & lm64)));
+                ww[i][rr][c] = make_uint4(v.x, v.y, v.z, v.w);
             }
+        const char* srow = static_cast<const char*>(qs) + (((size_t)(pp >> 1) * ngroups) * 4 + (pp & 1u) * 2) * 2;
+#pragma unroll
+        for (int c = 0; c < QN; c++) {
+            const uint32_t g = group ? ((2048u * c + 32u * lane) >> glog) : 0u;
+            wsc[i][c] = *reinterpret_cast<const uint32_t*>(srow + ((g * 8u) & lm));
         }
-        // the rotation of the pair this lane will finish (lane i < cnt: pair j0 + i), behind the weights: needed behind them
-        typedef const __attribute__((address_space(1))) float* gfloat_p;
-        const uint32_t jm = j0 + min(lane, cnt ? cnt - 1u : 0u), jj = jm < (n_rep + 1u) * HALF ? jm % HALF : 0u;
-        eo_c = ((gfloat_p)fcos)[(size_t)rrow * HALF + jj];
-        eo_s = ((gfloat_p)fsin)[(size_t)rrow * HALF + jj];
     }
-    __device__ __forceinline__ void before_scores()
+    // the wave's row of the shared pair, into slot [PMAXQ - 1][0] (the wave has at most PMAXQ - 1 whole pairs then)
+    __device__ __forceinline__ void request_shared_row()
+    {
+        const uint32_t lane = threadIdx.x & 63, kv = blockIdx.x % KV;
+        const uint32_t glog = group ? 31u - __builtin_clz(group) : 31u, ngroups = group ? KQ >> glog : 1u;
+        const uint32_t lm = 0u - shared;
+        const uint64_t lm64 = ((uint64_t)lm << 32) | lm;
+        const uint32_t pp = pp_of(kv, js) & lm;
+        const char* wrow = static_cast<const char*>(qw) + ((((uint64_t)pp * 2 + sh_row) * ROWBQ) & lm64) + ((lane * 16) & lm);
+#pragma unroll
+        for (int c = 0; c < QN; c++) {
+            const rowv4 v = __builtin_nontemporal_load(reinterpret_cast<const rowv4*>(wrow + (((size_t)c * 1024) & lm64)));
+            ww[PMAXQ - 1][0][c] = make_uint4(v.x, v.y, v.z, v.w);
+        }
+        const char* srow = static_cast<const char*>(qs) + (((size_t)(pp >> 1) * ngroups) * 4 + (pp & 1u) * 2) * 2;
+#pragma unroll
+        for (int c = 0; c < QN; c++) {
+            const uint32_t g = group ? ((2048u * c + 32u * lane) >> glog) : 0u;
+            wsc[PMAXQ - 1][c] = *reinterpret_cast<const uint32_t*>(srow + ((g * 8u) & lm));
+        }
+    }
+    // What is asked for when: a CU takes in ~ 25 GB/s and its waves stall at ISSUE once ~ 32 KB are outstanding (the first build
+    // requested all 81 KB of weights and tiles up front: 3.2 - 3.8 us from the start to "row staged", the row's own round trip
+    // being 0.6).  So: the row and every wave's FIRST pair (32 KB per CU) by the first instructions; the row staged while those
+    // arrive; then the rest of the wave's rows and the K / V tiles, which arrive while the first pairs are multiplied.
+    __device__ __forceinline__ void at_start()
+    {
+        const uint32_t tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        // the row first (gemv.h, the build-time prologue of the linear-order kernels), the step state behind it
+        xr = reinterpret_cast<const rowv4*>(xp)[tid];
+        nr = reinterpret_cast<const rowv4*>(normp)[tid];
+        stamp(0);
+        const __attribute__((address_space(1))) int32_t* stp = (const __attribute__((address_space(1))) int32_t*)st;
+        slot = (uint32_t)stp[3];
+        rrow_ = (uint32_t)stp[6];
+        tag = (uint32_t)stp[9] * 256u + layer_tag;
+        asm volatile("s_barrier" ::: "memory"); // (the row's requests stay ahead of the weight requests in the CU's memory pipe)
+        const uint32_t split = blockIdx.x / KV;
+        const uint32_t PG = (n_rep + 2u) * HALF, PW = PG / nsplit, e = PW >> 3, r = PW & 7u;
+        if (MC_QKV_ROW_DEAL && r == 4u && e + 1u <= (uint32_t)PMAXQ) {
+            const uint32_t w4 = wave & 3u;
+            full = e;
+            j0 = split * PW + (wave < 4u ? w4 * (e + 1u) : 4u * (e + 1u) + w4 * e);
+            js = split * PW + w4 * (e + 1u) + e;
+            shared = 1u;
+            sh_row = wave >> 2;
+        } else {
+            full = e + (wave < r ? 1u : 0u);
+            j0 = split * PW + wave * e + min(wave, r);
+            js = 0u;
+            shared = 0u;
+            sh_row = 0u;
+        }
+        // (the pairs this wave FINISHES: its whole pairs, and the shared pair on the wave that holds its row 0)
+        cnt = full + (shared && sh_row == 0u ? 1u : 0u);
+        request_pair(0);
+    }
+    __device__ __forceinline__ void before_tiles()
     {
         const uint32_t tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-        const uint32_t kv = blockIdx.x % KV;
-        const uint32_t PG = (n_rep + 2u) * HALF;
         // ---- rmsnorm on the way into LDS (kernel/rmsnorm.metal:52-95; the additions in the stand-alone kernel's order)
         {
             const uint32_t vv[4] = {xr.x, xr.y, xr.z, xr.w}, wv[4] = {nr.x, nr.y, nr.z, nr.w};
@@ -140,7 +189,7 @@ struct qkv_in_launch {
             }
             const float wsum_ = wave_sum_dpp(ss);
             if (lane == 0) red[wave] = wsum_;
-            __syncthreads();
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // (LDS only: the first pairs stay in flight)
             float tot = 0.0f;
 #pragma unroll
             for (int i = 0; i < 8; i++) tot += red[i];
@@ -154,9 +203,25 @@ struct qkv_in_launch {
             }
             reinterpret_cast<rowv4*>(xs)[tid + (tid >> 4)] = rowv4{o[0], o[1], o[2], o[3]}; // (packet p sits in slot p + p / 16)
         }
-        __syncthreads();
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         stamp(1);
-        // ---- the wave's pairs from registers (mc_gemv_i4_bfloat_lin{QN}_p1_e4's arithmetic)
+        // ---- the rest of the wave's rows and the rotation of the pair this lane will finish (lane i < cnt: whole pair j0 + i,
+        // then the shared pair; its address waits for the step state: asked for in at_start() that wait sat in the middle of
+        // the weight requests)
+        if (shared) request_shared_row();   // (wave-uniform, and the same for every wave of the launch: no wave's loads
+        else request_pair(PMAXQ - 1);       //  are "behind a branch" that another path of ITS OWN code does not take)
+        typedef const __attribute__((address_space(1))) float* gfloat_p;
+        const uint32_t li = min(lane, cnt ? cnt - 1u : 0u), jm = li < full ? j0 + li : js;
+        const uint32_t jj = jm < (n_rep + 1u) * HALF ? jm % HALF : 0u;
+        eo_c = ((gfloat_p)fcos)[(size_t)rrow_ * HALF + jj];
+        eo_s = ((gfloat_p)fsin)[(size_t)rrow_ * HALF + jj];
+    }
+    __device__ __forceinline__ void before_scores()
+    {
+        const uint32_t tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const uint32_t kv = blockIdx.x % KV;
+        const uint32_t PG = (n_rep + 2u) * HALF;
+        // ---- the wave's rows from registers (mc_gemv_i4_bfloat_lin{QN}_p1_e4's arithmetic)
         const uint32_t lane_tr = (((lane >> 4) * 4 + (lane & 3)) * 17 + ((lane >> 2) & 3) * 4) * 16;
         const m4b_lane m4bk = m4b_lane_consts(lane);
         typedef __attribute__((address_space(3))) mf_s4 lds_s4;
@@ -167,33 +232,39 @@ struct qkv_in_launch {
 #pragma unroll
             for (int e = 0; e < 8; e++) x[c][e] = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16(xt + e));
         }
+        // one row: QN packets into one accumulator, the lane's own element, one wave sum (the stand-alone kernel's order)
+        auto row_sum = [&](const uint4 (&w)[QN], const uint32_t (&sc)[QN], uint32_t hi) {
+            mf_f4 acc[1] = {mf_f4{0, 0, 0, 0}};
+#pragma unroll
+            for (int c = 0; c < QN; c++) mac4b_n<1>(acc, w[c], m4b_prepare(hi ? (sc[c] & 0xFFFF0000u) : (sc[c] << 16), m4bk), x[c]);
+            const uint32_t e = lane & 3;
+            const float mine = e == 0 ? acc[0][0] : (e == 1 ? acc[0][1] : (e == 2 ? acc[0][2] : acc[0][3]));
+            return wave_sum_dpp(mine) * 0x1p37f; // 2^M4B_Q: the sum was formed at 2^-Q (mac4b_n)
+        };
         float my_a = 0.0f, my_b = 0.0f;
 #pragma unroll
         for (int i = 0; i < PMAXQ; i++) {
-            if ((uint32_t)i >= cnt) break;
-            float rsum[2];
-#pragma unroll
-            for (int rr = 0; rr < 2; rr++) {
-                mf_f4 acc[1] = {mf_f4{0, 0, 0, 0}};
-#pragma unroll
-                for (int c = 0; c < QN; c++) {
-                    const uint32_t raw = wsc[i][c];
-                    mac4b_n<1>(acc, ww[i][rr][c], m4b_prepare(rr ? (raw & 0xFFFF0000u) : (raw << 16), m4bk), x[c]);
-                }
-                const uint32_t e = lane & 3;
-                const float mine = e == 0 ? acc[0][0] : (e == 1 ? acc[0][1] : (e == 2 ? acc[0][2] : acc[0][3]));
-                rsum[rr] = wave_sum_dpp(mine) * 0x1p37f; // 2^M4B_Q: the sum was formed at 2^-Q (mac4b_n)
-            }
+            if ((uint32_t)i >= full) break;
+            const float ra = row_sum(ww[i][0], wsc[i], 0u), rb = row_sum(ww[i][1], wsc[i], 1u);
             if (lane == (uint32_t)i) {
-                my_a = rsum[0];
-                my_b = rsum[1];
+                my_a = ra;
+                my_b = rb;
+            }
+        }
+        if (shared) { // (wave-uniform, and uniform over the workgroup: the barrier below is reached by every wave or by none)
+            const float rs = row_sum(ww[PMAXQ - 1][0], wsc[PMAXQ - 1], sh_row);
+            if (sh_row != 0u && lane == 0) red[8 + (wave & 3u)] = rs; // (red[0..7]: the rmsnorm's wave sums, long read)
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (sh_row == 0u && lane == full) {
+                my_a = rs;
+                my_b = red[8 + (wave & 3u)];
             }
         }
         // ---- the epilogue of gemv.h finish_pair (EPI_QKV_ROPE), one lane per pair; the pair goes to the cache (k, v: for the
         // steps to come) and, as ONE granule {first | second << 16}, to the workgroups of this kv head (hand-off Q)
         if (lane < cnt) {
             typedef __attribute__((address_space(1))) bf16_t* gS_p;
-            const uint32_t j = j0 + lane, hq = n_rep * HALF;
+            const uint32_t j = lane < full ? j0 + lane : js, hq = n_rep * HALF;
             uint32_t g;
             if (j < hq + HALF) {
                 const float x1 = BF::rt(my_a), x2 = BF::rt(my_b);
@@ -241,6 +312,7 @@ struct qkv_in_launch {
             }
         }
         __syncthreads();
+        stamp(11);
     }
 };
 
@@ -265,6 +337,20 @@ attn_wo_body(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const 
     __shared__ float qred[QN ? 16 : 1];
     __shared__ __attribute__((aligned(16))) bf16_t qkv_rows[QN ? 18 * HD : 8]; // queries of up to 16 heads, the K row, the V row
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // (QN != 0) the hidden row and the wave's wq|wk|wv pairs are requested by the first instructions of the launch
+    typedef qkv_in_launch<HD, QN ? QN : 2> qx_t;
+    qx_t qx;
+    if constexpr (QN != 0) {
+        typedef typename qx_t::lds_row lds_row;
+        qx.q_s = (lds_row)qkv_rows;
+        qx.k_s = (lds_row)qkv_rows + n_rep * HD;
+        qx.v_s = (lds_row)qkv_rows + (n_rep + 1u) * HD;
+        qx.xp = res; qx.normp = qnorm_w; qx.qw = qkv_w; qx.qs = qkv_s; qx.fcos = fcos; qx.fsin = fsin;
+        qx.kc = const_cast<bf16_t*>(kc); qx.vt = const_cast<bf16_t*>(vt); qx.qkv_g = qkv_g; qx.st = st; qx.xs = xs; qx.red = qred;
+        qx.n_rep = n_rep; qx.KV = KV; qx.max_seq = max_seq; qx.nsplit = nsplit; qx.group = group; qx.layer_tag = layer_tag;
+        qx.fastpath = fastpath; qx.eps = eps; qx.mu = mu; qx.tl = tl;
+        qx.at_start();
+    }
 
     // ---- the Wo row pairs of this wave: contiguous spans dealt as the linear-order kernels deal theirs, at most PMAX each (the
     // host takes this kernel only then).  Their weights are requested BEHIND the scores (attn_fused_bf's hook): at the start of the
@@ -286,19 +372,31 @@ attn_wo_body(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const 
 #ifndef MC_WO_REQ_SPLIT
 #define MC_WO_REQ_SPLIT 1
 #endif
+    // With wq|wk|wv in the launch (QN != 0) the K and V tiles are in long before the scores: every wave requests its pairs in front
+    // of the scores (point -1), whose arithmetic (~ 1 us) the 34 KB per CU then have to themselves, and hand-off A is not queued
+    // behind anybody's weights.
+#ifndef MC_QKV_WO_REQ_EARLY
+#define MC_QKV_WO_REQ_EARLY 0
+#endif
     auto request_wo = [&](int point) {
         const bool poller = wave < n_rep; // (attn_fused_bf: head = wave, wave + NW, ... gathers the denominators of hand-off A)
-        if (MC_WO_REQ_SPLIT ? (point == 0) == poller : point != 0) return;
+        if (QN != 0 && MC_QKV_WO_REQ_EARLY) {
+            if (point != -1) return;
+        } else if (point == -1 || (MC_WO_REQ_SPLIT ? (point == 0) == poller : point != 0)) return;
+        // (every load unconditional: one load behind a branch and hipcc waits vmcnt(0) wherever it waits afterwards -- the scores
+        //  would wait for these weights.  A pair the wave does not have reads one broadcast line: masks, not selects)
+        const bf16_t* rp = has_res ? res : y; // (a pointer that can be read either way; the value is masked below)
 #pragma unroll
         for (int i = 0; i < PMAX; i++) {
-            if (pb + i >= pe) break; // (wave-uniform)
-            const uint32_t pr = pb + i;
-            const char* wrow = static_cast<const char*>(wo_w) + (size_t)pr * 2 * ROWB + lane * 16;
+            const uint32_t lm = 0u - (uint32_t)(pb + i < pe ? 1u : 0u);
+            const uint64_t lm64 = ((uint64_t)lm << 32) | lm;
+            const uint32_t pr = (pb + i) & lm;
+            const char* wrow = static_cast<const char*>(wo_w) + (((uint64_t)pr * 2 * ROWB) & lm64) + ((lane * 16) & lm);
 #pragma unroll
             for (int r = 0; r < 2; r++)
 #pragma unroll
                 for (int c = 0; c < LNCH; c++) {
-                    const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow + (size_t)r * ROWB + c * 1024));
+                    const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow + (((size_t)r * ROWB + c * 1024) & lm64)));
                     ww[i][r][c] = make_uint4(v.x, v.y, v.z, v.w);
                 }
             // scales: row quads [ceil(out / 4)][ngroups][4] bf16 (gemv.h); the dword (rows 2 pr, 2 pr + 1) of the lane's group
@@ -306,9 +404,9 @@ attn_wo_body(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const 
 #pragma unroll
             for (int c = 0; c < LNCH; c++) {
                 const uint32_t g = group ? ((2048u * c + 32u * lane) >> glog) : 0u;
-                ws[i][c] = *reinterpret_cast<const uint32_t*>(srow + g * 8u);
+                ws[i][c] = *reinterpret_cast<const uint32_t*>(srow + ((g * 8u) & lm));
             }
-            wres[i] = has_res ? reinterpret_cast<const uint32_t*>(res)[pr] : 0u;
+            wres[i] = reinterpret_cast<const uint32_t*>(rp)[pr] & (has_res ? 0xFFFFFFFFu : 0u);
         }
     };
 
@@ -323,15 +421,6 @@ attn_wo_body(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const 
     };
     constexpr int TL_STRIDE = QN ? 16 : 8, TL_BASE = QN ? 3 : 0;
     if constexpr (QN != 0) {
-        qkv_in_launch<HD, QN> qx;
-        typedef typename qkv_in_launch<HD, QN>::lds_row lds_row;
-        qx.q_s = (lds_row)qkv_rows;
-        qx.k_s = (lds_row)qkv_rows + n_rep * HD;
-        qx.v_s = (lds_row)qkv_rows + (n_rep + 1u) * HD;
-        qx.xp = res; qx.normp = qnorm_w; qx.qw = qkv_w; qx.qs = qkv_s; qx.fcos = fcos; qx.fsin = fsin;
-        qx.kc = const_cast<bf16_t*>(kc); qx.vt = const_cast<bf16_t*>(vt); qx.qkv_g = qkv_g; qx.st = st; qx.xs = xs; qx.red = qred;
-        qx.n_rep = n_rep; qx.KV = KV; qx.max_seq = max_seq; qx.nsplit = nsplit; qx.group = group; qx.layer_tag = layer_tag;
-        qx.fastpath = fastpath; qx.eps = eps; qx.mu = mu; qx.tl = tl;
         attn_fused_bf<HD, 1, 8>(q, kc, vt, psum_g, slab_g, st, n_rep, KV, max_seq, scale, nsplit, layer_tag, tl, publish, request_wo, fastpath, qx);
     } else {
         attn_fused_bf<HD, 1, 8>(q, kc, vt, psum_g, slab_g, st, n_rep, KV, max_seq, scale, nsplit, layer_tag, tl, publish, request_wo, fastpath);

@@ -613,8 +613,10 @@ mc_attn_pv_reduce_float(const float* __restrict__ parts, float* __restrict__ out
 // caller puts requests that must not compete with the K tile (mc_attn_wo_*: the Wo weights).
 // Where the step's own query rows come from.  q_from_hbm: the rotated queries a launch of their own left in HBM (the wq|wk|wv
 // GEMV's epilogue, gemv.h EPI_QKV_ROPE), the step's K / V row already in the cache.  A policy with LDS = true (attn_block_kernels.hip,
-// mc_attn_qkv_wo_*) computes them INSIDE this launch: at_start() is called by every wave before the K and V tiles are requested
-// (its own requests go first in the CU's memory pipe), before_scores() once the tiles are requested -- it returns behind a
+// mc_attn_qkv_wo_*) computes them INSIDE this launch: the CALLER runs its at_start() as the first thing of the kernel (its
+// requests go first in the CU's memory pipe), before_tiles() is called here in front of the K and V tile requests (a CU takes in
+// ~ 25 GB/s and its waves stall at ISSUE once ~ 32 KB are outstanding: what the first phase needs goes first, the tiles behind
+// it), before_scores() once the tiles are requested -- it returns behind a
 // workgroup barrier with the queries of this kv head in q_s [n_rep][HD] and the step's K / V row of this kv head in k_s / v_s [HD]
 // (LDS); the tile registers of the step's slot are then patched from there (the cache row itself is written by the workgroup
 // that computed it, for the steps to come: whatever a tile load found in that slot is never used).
@@ -624,6 +626,7 @@ struct q_from_hbm {
     typedef const __attribute__((address_space(3))) bf16_t* lds_row; // (LDS address space: a generic pointer would make these flat loads)
     lds_row q_s = nullptr, k_s = nullptr, v_s = nullptr;
     __device__ __forceinline__ void at_start() {}
+    __device__ __forceinline__ void before_tiles() {}
     __device__ __forceinline__ void before_scores() {}
 };
 template <int HD, int T, int NW, typename OnChunk, typename BehindScores, typename QSrc = q_from_hbm>
@@ -641,7 +644,6 @@ attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const
         if (tl && threadIdx.x == 0) tl[(size_t)blockIdx.x * QSrc::TL_STRIDE + QSrc::TL_BASE + i] = __builtin_amdgcn_s_memrealtime();
     };
     stamp(0);
-    qsrc.at_start();
     constexpr int KS = HD / 32;                 // MFMA k-steps of q.k
     constexpr int NDB = HD / 16;                // 16-column blocks of the output
     constexpr int NB = NDB >= NW ? NDB / NW : 1; // ... per wave
@@ -657,9 +659,22 @@ attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const
     const uint32_t p_begin = split * PBW;
     // ---- 1. the K tiles and the queries: requested before anything is waited for -- the step state included (a range past
     // kv_len reads slots nobody uses: their products are masked below)
+    qsrc.before_tiles();
     uint4 kb[T][KS];
     const bool scorer = NW == 4 || wave < 4; // (waves 4 .. NW - 1 compute no scores: no K tile, no queries)
-    if (scorer) {
+    if constexpr (QSrc::LDS) {
+        // (every load of the launch unconditional: with one load behind a branch hipcc waits vmcnt(0) wherever it waits -- the
+        //  rmsnorm of the wq|wk|wv phase would sit behind every tile of the launch.  Waves that compute no scores read one
+        //  broadcast line of the cache: masks, not selects -- gemv.h ltile)
+        const size_t live = (size_t)0 - (size_t)(scorer ? 1 : 0);
+#pragma unroll
+        for (int t = 0; t < T; t++) {
+            const uint32_t pos = p_begin + t * PB + wave * 16 + col;
+            const bf16_t* kbase = kc + ((((size_t)kv * max_seq + (pos < max_seq ? pos : max_seq - 1)) * HD + c * 8) & live);
+#pragma unroll
+            for (int ks = 0; ks < KS; ks++) kb[t][ks] = *reinterpret_cast<const uint4*>(kbase + ks * 32);
+        }
+    } else if (scorer) {
 #pragma unroll
         for (int t = 0; t < T; t++) {
             const uint32_t pos = p_begin + t * PB + wave * 16 + col;
@@ -738,6 +753,14 @@ attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const
     }
     const uint32_t S = (uint32_t)st->kv_len;
     const uint32_t tag = st->epoch * 256u + layer_tag;
+    if constexpr (QSrc::LDS) {
+        // (the tiles are long in: what is requested here has the scores' arithmetic to itself -- behind the step state, which the
+        //  scores wait for)
+        uint32_t never;
+        asm volatile("s_mov_b32 %0, 0" : "=s"(never));
+        if (never) asm volatile("" ::"v"(S), "v"(tag));
+        behind_scores(-1);
+    }
     const uint32_t nact = (S + PBW - 1) / PBW;
     const bool active = p_begin < S;
 
@@ -892,7 +915,7 @@ attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const
         for (uint32_t look = 0;; look++) {
             bool ok = true;
             v = 0.0f;
-            const unsigned long long* src = base + (fastpath && (look & 3u) != 3u ? slab_fast : (size_t)0);
+            const unsigned long long* src = base + (fastpath && !handoff_slow_look(look) ? slab_fast : (size_t)0);
             for (uint32_t j0 = 0; j0 < nact; j0 += 32) { // eight loads in flight per lane
                 unsigned long long g[8];
 #pragma unroll

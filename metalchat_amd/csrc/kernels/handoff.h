@@ -48,6 +48,14 @@ granule_load(const unsigned long long* g)
 // or foreign line can only read as "not yet").  Placement decides the SPEED only -- workgroups with equal blockIdx.x % 8 share an
 // XCD in practice, and the hand-offs A and B of the decode attention stay inside one kv head = one such class -- never the result:
 // a consumer on another XCD is served by `slow` exactly as before.  `fast` sits `fast_off` granules behind `slow`.
+#ifndef MC_HANDOFF_SLOW_EVERY
+#define MC_HANDOFF_SLOW_EVERY 16 // a power of two: every so many looks go to the fabric copy
+#endif
+__device__ __forceinline__ bool
+handoff_slow_look(uint32_t look)
+{
+    return (look & (MC_HANDOFF_SLOW_EVERY - 1u)) == MC_HANDOFF_SLOW_EVERY - 1u;
+}
 __device__ __forceinline__ void
 granule_store_plain(unsigned long long* g, uint32_t tag, uint32_t value)
 {
@@ -64,7 +72,7 @@ granule_store_dual(unsigned long long* slow, size_t fast_off, uint32_t tag, uint
 __device__ __forceinline__ unsigned long long
 granule_look_dual(const unsigned long long* slow, size_t fast_off, uint32_t look)
 {
-    return granule_load((look & 3u) == 3u ? slow : slow + fast_off);
+    return granule_load(handoff_slow_look(look) ? slow : slow + fast_off);
 }
 
 // one round of a bounded wait: false = keep waiting.  `ok` is wave-uniform.

@@ -129,7 +129,8 @@ def test_llama3_8b_int4_at_the_benchmark_context(acc, dtype):
                          rel_logits=5e-3, max_ulp=2, max_frac=0.7, what=f"8B int4 S=2048 dt{dtype}", launched=names)
     assert agree >= 14
     if dtype == BF16:  # the kernels bench.py's headline runs (and its roofline names): not a fallback family
-        assert {"mc_gemv_i4_bfloat_lin2_p1_e4", "mc_attn_wo_i4_bfloat_hd128_k2", "mc_gemv_i4_bfloat_lin2_p1_e2",
+        # (round 4: wq|wk|wv, attention and Wo are ONE launch, mc_attn_qkv_wo_*; the layer is three launches)
+        assert {"mc_attn_qkv_wo_i4_bfloat_hd128_k2_q2", "mc_gemv_i4_bfloat_lin2_p1_e2",
                 "mc_gemv_i4_bfloat_lin7_p0_e1", "mc_gemv_i4_bfloat_lin2_p1_e5", "mc_argmax_keys"} <= names, sorted(names)
         assert not [n for n in names if n.startswith("mc_gemv") and "_lin" not in n], sorted(names)
         assert "mc_attn_fused_bfloat" not in names and "mc_attn_pv_bfloat" not in names

@@ -137,8 +137,8 @@ def test_whole_decoder_properties_at_full_size(acc):
 
 
 def test_graph_replay_equals_eager_at_the_benchmark_context(acc):
-    # bench.py's own configuration -- 32 blocks, 2048 slots, hipGraph replay, the four-launch layer with the attention, its two
-    # in-launch hand-offs, the third one and the Wo GEMV in ONE launch (mc_attn_wo_i4_bfloat_hd128_k2) -- from an empty cache to 64
+    # bench.py's own configuration -- 32 blocks, 2048 slots, hipGraph replay, the three-launch layer with wq|wk|wv, the attention,
+    # their four in-launch hand-offs and the Wo GEMV in ONE launch (mc_attn_qkv_wo_i4_bfloat_hd128_k2_q2) -- from an empty cache to 64
     # tokens past its end (the sink ring turns): 67 584 launches with hand-offs per path, every one of which must find this
     # step's tags; the replayed graph must produce the eager launches' tokens, and the caches must be identical.
     n = 2048 + 64
@@ -146,7 +146,8 @@ def test_graph_replay_equals_eager_at_the_benchmark_context(acc):
     eager.launch_log(True)
     chain = list(eager.generate(7, 0, n))
     names = set(eager.launched())
-    assert "mc_attn_wo_i4_bfloat_hd128_k2" in names and "mc_gemv_i4_bfloat_lin2_p1_e2" in names, sorted(names)
+    assert "mc_attn_qkv_wo_i4_bfloat_hd128_k2_q2" in names and "mc_gemv_i4_bfloat_lin2_p1_e2" in names, sorted(names)
+    assert "mc_gemv_i4_bfloat_lin2_p1_e4" not in names, sorted(names)
     assert not [x for x in names if x.startswith("mc_attn_scores") or x == "mc_attn_fused_bfloat"], sorted(names)
     ke, ve = eager.export_kv(17)
     eager.release()
