@@ -320,6 +320,13 @@ mc_status mc_decoder_time_gemv(mc_decoder* d, const char* which, int32_t repeats
  * the first owned block ("mc_attn_wo_i4_*" carries the Wo GEMV: the token then launches no Wo GEMV of its own and
  * time_gemv("wo") measures a stand-alone launch).  Launches nothing. */
 mc_status mc_decoder_gemv_kernel_name(mc_decoder* d, const char* which, char* buf, size_t cap);
+/* How often an in-launch hand-off of the decode attention gave up (its workgroups were not resident together: another stream or
+ * process held part of the chip) and the decoder fell back, for good, to the launches that need no co-residency.  A step
+ * (mc_decoder_step with a token read back) and a chain that stays inside the cache (mc_decoder_generate, start_pos + n <=
+ * max_seq_len) are repeated on those launches and succeed; anywhere else the call that finds the flag fails with
+ * MC_ERR_RUNTIME ("... repeat the call") -- the reference delivers a GPU execution error the same way, through the future that
+ * is waited for (src/kernel_thread.cc:134-144). */
+int32_t mc_decoder_handoff_fallbacks(const mc_decoder* d);
 /* Test aid: record the host names of every kernel the decoder launches from now on (enable = 1 clears the log and
  * drops a captured token graph, whose replay would launch without passing here; 0 stops recording).
  * mc_decoder_launch_log_read copies the newline-separated names and returns the bytes needed (terminator included).

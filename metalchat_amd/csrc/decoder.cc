@@ -189,6 +189,17 @@ struct mc_decoder {
     unsigned long long* attn_row_g = nullptr;  // [H * hd / 2]          the finished attention row, two bf16 per granule (mc_attn_wo_*)
     unsigned long long* attn_qkv_g = nullptr;  // [KV][(n_rep + 2) hd / 2] the step's rotated queries and K / V row, two bf16 per granule (mc_attn_qkv_wo_*)
     bool attn_qkv_on = true;     // MC_ATTN_QKV=0: wq|wk|wv as a launch of its own in front of mc_attn_wo_* (A/B, parity)
+    // ---- what happens when an in-launch hand-off gives up (its workgroups were not resident together: another stream or process
+    // holds part of the chip).  The launch sets state.err and completes; the host then LATCHES the decoder onto the launches
+    // that need no co-residency (attn_fused_on = false: scores, P.V and the GEMVs as launches of their own), drops the captured
+    // graph and -- where the step can be repeated exactly -- runs it again (mc_decoder_step; mc_decoder_generate while the
+    // ring has not turned inside the call).  handoff_fallbacks counts those events (mc_decoder_handoff_fallbacks).
+    step_state_h* state_bak = nullptr; // the step state in front of the call that may have to be repeated
+    uint32_t* err_host = nullptr;      // pinned: state.err of a step nobody waited for (a non-last stage, next_token == NULL)
+    hipEvent_t err_evt = nullptr;
+    bool err_pending = false;
+    int handoff_fallbacks = 0;
+    int occ_fused = -1, occ_wo = -1;   // co-resident workgroups per CU of the hand-off launches (the occupancy API's answer; -1: not asked yet)
     bool handoff_fast = true;    // MC_HANDOFF_FAST=0: hand-offs A and B through the fabric only (A/B; handoff.h "the XCD-local fast path")
     bool attn_wo_on = true;      // MC_ATTN_WO=0: the Wo GEMV as a launch of its own behind the one-launch attention (A/B, parity)
     bool attn_fused_on = true;   // MC_ATTN_FUSED=0: scores and P.V as two launches (A/B, parity)
@@ -295,6 +306,8 @@ struct mc_decoder {
         (void)hipSetDevice(dev->ordinal);
         drop_graph();
         for (void* p : allocs) (void)hipFree(p);
+        if (err_evt) (void)hipEventDestroy(err_evt);
+        if (err_host) (void)hipHostFree(err_host);
     }
 
     mc_status
@@ -535,8 +548,39 @@ struct mc_decoder {
     bool
     attn_fused() const
     {
+        // co-residency from what a CU can HOLD of the real kernel (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor, asked once:
+        // query_occupancy), capped by what was measured to pay (attn_fused_max_wgs_per_cu).  The API is advisory (ROCm 7.2 reads
+        // one block per CU high for SGPR-heavy 256-thread kernels, MI355X_MICROARCH.md), and another stream can take CUs away
+        // at any time: a launch that is not resident after all gives up and the host falls back (handoff_failed).
+        const unsigned per_cu = std::min(attn_fused_max_wgs_per_cu, occ_fused < 0 ? attn_fused_max_wgs_per_cu : (unsigned)occ_fused);
         return attn_fused_on && attn_psum_g && tb == 2 && n_own <= 254 &&
-               (unsigned)(nsplit * cfg.n_kv_heads) <= attn_fused_max_wgs_per_cu * (unsigned)dev->prop.multiProcessorCount;
+               (unsigned)(nsplit * cfg.n_kv_heads) <= per_cu * (unsigned)dev->prop.multiProcessorCount;
+    }
+    void
+    query_occupancy()
+    {
+        if (tb != 2 || occ_fused >= 0) return;
+        auto ask = [&](const std::string& name, int block) {
+            hipFunction_t f;
+            if (fn(name, &f) != MC_OK) return 0;
+            int n = 0;
+            if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&n, f, block, 0) != hipSuccess) return 0;
+            return n;
+        };
+        occ_fused = ask("mc_attn_fused_bfloat", 256);
+        const int hd = cfg.head_dim, k = cfg.n_heads * hd / 2048;
+        occ_wo = ask("mc_attn_wo_i4_bfloat_hd" + std::to_string(hd) + "_k" + std::to_string(k), 512);
+        (void)hipGetLastError();
+    }
+    // a hand-off gave up: report nothing yet, make the NEXT launches independent of co-residency
+    void
+    handoff_failed()
+    {
+        (void)hipMemsetAsync(&state->err, 0, 4, stream);
+        (void)hipStreamSynchronize(stream);
+        attn_fused_on = false; // (attn_wo_fused and attn_qkv_wo_fused need attn_fused)
+        drop_graph();
+        handoff_fallbacks++;
     }
 
     // ... with the Wo GEMV and its residual in the same launch (attn_block_kernels.hip): int4 weights on bfloat rows with scale
@@ -545,7 +589,7 @@ struct mc_decoder {
     bool
     attn_wo_fused(const linear_w& wo) const
     {
-        if (!attn_wo_on || !attn_fused() || !lin_ok(wo) || wo.lora_cols || wo.out % 2 != 0) return false;
+        if (!attn_wo_on || !attn_fused() || occ_wo == 0 || !lin_ok(wo) || wo.lora_cols || wo.out % 2 != 0) return false;
         const int hd = cfg.head_dim, k = wo.in / 2048;
         // (K = 8192, Llama-3-70B: measured slower than the two launches -- attn_block_kernels.hip)
         const bool built = (hd == 128 && k == 2) || (hd == 64 && k == 1) || (hd == 256 && k == 2);
@@ -578,12 +622,46 @@ struct mc_decoder {
     check_handoffs(const step_state_h& st)
     {
         if (!st.err) return MC_OK;
-        (void)hipMemsetAsync(&state->err, 0, 4, stream);
-        (void)hipStreamSynchronize(stream);
-        char buf[160];
-        snprintf(buf, sizeof buf, "decoder: an in-launch hand-off of the decode attention timed out (code 0x%08x): the workgroups of "
-                                  "the launch were not resident together; set MC_ATTN_FUSED=0", st.err);
+        return report_handoff(st.err);
+    }
+    mc_status
+    report_handoff(uint32_t code)
+    {
+        handoff_failed();
+        char buf[256];
+        snprintf(buf, sizeof buf, "decoder: an in-launch hand-off of the decode attention timed out (code 0x%08x): the workgroups of the "
+                                  "launch were not resident together.  What was computed since is invalid; the decoder now uses the "
+                                  "launches that need no co-residency -- repeat the call", code);
         return fail(MC_ERR_RUNTIME, buf);
+    }
+    // state.err at a point where the stream has just been synchronised (logits / hidden rows / caches read back, a prompt pass):
+    // a step nobody waited for must not leave a set flag behind -- every later hand-off would return at once, on rows that
+    // have not arrived, without an error
+    mc_status
+    check_err_synced()
+    {
+        if (!attn_psum_g) return MC_OK;
+        uint32_t e = 0;
+        MC_HIP(hipMemcpy(&e, &state->err, 4, hipMemcpyDeviceToHost));
+        err_pending = false;
+        return e ? report_handoff(e) : MC_OK;
+    }
+    // ... and at the start of every call: the flag of an earlier step that was copied out behind it (note_err_async), if that
+    // copy has completed -- never a wait
+    mc_status
+    poll_pending_err()
+    {
+        if (!err_pending || hipEventQuery(err_evt) != hipSuccess) return MC_OK;
+        err_pending = false;
+        const uint32_t e = *err_host;
+        return e ? report_handoff(e) : MC_OK;
+    }
+    void
+    note_err_async()
+    {
+        if (!attn_psum_g || !err_host) return;
+        if (hipMemcpyAsync(err_host, &state->err, 4, hipMemcpyDeviceToHost, stream) != hipSuccess) return;
+        if (hipEventRecord(err_evt, stream) == hipSuccess) err_pending = true;
     }
 
     mc_status
@@ -1282,6 +1360,15 @@ mc_decoder_create(mc_device* dev, mc_library* lib, mc_queue* q, const mc_decoder
     }
     A(d->taps, (size_t)(d->n_own + 1) * dim * tb);
     A(d->state, sizeof(step_state_h));
+    A(d->state_bak, sizeof(step_state_h));
+    if (hipHostMalloc((void**)&d->err_host, 64, hipHostMallocDefault) == hipSuccess) {
+        *d->err_host = 0;
+        if (hipEventCreateWithFlags(&d->err_evt, hipEventDisableTiming) != hipSuccess) {
+            (void)hipHostFree(d->err_host);
+            d->err_host = nullptr;
+        }
+    }
+    (void)hipGetLastError();
     d->tokens_cap = 1 << 16;
     A(d->tokens_dev, (size_t)d->tokens_cap * 4);
     A(d->pick_desc, 128);
@@ -1699,25 +1786,40 @@ mc_decoder_step(mc_decoder* d, int32_t token, int32_t start_pos, const void* hid
     if (!d->first_stage && !hidden_in)
         return fail(MC_ERR_INVALID_ARGUMENT, "decoder: a non-first stage needs the inbound hidden row");
     MC_HIP(hipSetDevice(d->dev->ordinal));
-    s = d->ensure_rope(start_pos);
+    s = d->poll_pending_err();
     if (s != MC_OK) return s;
-    s = d->launch("mc_step_set", 1, 1, 1, 64, 0,
-                  pack(d->state, token, start_pos, (int32_t)d->cfg.max_seq_len, (int32_t)d->pre_len,
-                       (int32_t)d->rope_start, (int32_t)(start_pos == 0 ? 1 : 0)));
-    if (s != MC_OK) return s;
-    s = d->run_token(d->first_stage ? nullptr : hidden_in);
-    if (s != MC_OK) return s;
-    d->last_pos = start_pos;
-    if (start_pos == 0) d->ring_turned = false;
-    if (start_pos >= d->cfg.max_seq_len) d->ring_turned = true;
-    if (next_token && d->last_stage) {
+    d->query_occupancy();
+    for (int attempt = 0;; attempt++) {
+        const bool handoffs = d->attn_fused();
+        // (a step whose hand-offs give up is repeated on the launches that need no co-residency: the state in front of it)
+        if (handoffs) MC_HIP(hipMemcpyAsync(d->state_bak, d->state, sizeof(step_state_h), hipMemcpyDeviceToDevice, d->stream));
+        s = d->ensure_rope(start_pos);
+        if (s != MC_OK) return s;
+        s = d->launch("mc_step_set", 1, 1, 1, 64, 0,
+                      pack(d->state, token, start_pos, (int32_t)d->cfg.max_seq_len, (int32_t)d->pre_len,
+                           (int32_t)d->rope_start, (int32_t)(start_pos == 0 ? 1 : 0)));
+        if (s != MC_OK) return s;
+        s = d->run_token(d->first_stage ? nullptr : hidden_in);
+        if (s != MC_OK) return s;
+        d->last_pos = start_pos;
+        if (start_pos == 0) d->ring_turned = false;
+        if (start_pos >= d->cfg.max_seq_len) d->ring_turned = true;
+        if (!(next_token && d->last_stage)) {
+            // nobody waits for this step: its flag is copied out behind it and looked at by the calls that follow (poll_pending_err)
+            // and by every call that synchronises (check_err_synced); a set flag makes THAT call fail and latches the decoder
+            if (handoffs) d->note_err_async();
+            return MC_OK;
+        }
         step_state_h st;
         MC_HIP(hipMemcpyAsync(&st, d->state, sizeof st, hipMemcpyDeviceToHost, d->stream));
         MC_HIP(hipStreamSynchronize(d->stream));
         *next_token = st.token;
-        return d->check_handoffs(st);
+        if (!st.err) return MC_OK;
+        if (attempt > 0 || !handoffs) return d->check_handoffs(st);
+        // the step again, from the state in front of it: its cache row goes to the same slot, every other row is untouched
+        d->handoff_failed();
+        MC_HIP(hipMemcpyAsync(d->state, d->state_bak, sizeof(step_state_h), hipMemcpyDeviceToDevice, d->stream));
     }
-    return MC_OK;
 }
 
 mc_status
@@ -1791,7 +1893,7 @@ mc_decoder_prefill_stage(mc_decoder* d, const int32_t* tokens, const void* rows_
     if (rows_out) *rows_out = d->pf_x;
     MC_HIP(hipStreamSynchronize(d->stream)); // `tokens` is the caller's buffer
     if (next_token && d->last_stage) MC_HIP(hipMemcpy(next_token, &d->state->token, 4, hipMemcpyDeviceToHost));
-    return MC_OK;
+    return d->check_err_synced(); // (the prompt pass has no hand-offs of its own: a step in front of it that nobody waited for)
 }
 
 mc_status
@@ -1817,6 +1919,11 @@ mc_decoder_generate(mc_decoder* d, int32_t first_token, int32_t start_pos, int32
     mc_status s = check_ready(d);
     if (s != MC_OK) return s;
     MC_HIP(hipSetDevice(d->dev->ordinal));
+    s = d->poll_pending_err();
+    if (s != MC_OK) return s;
+    d->query_occupancy();
+    const bool handoffs = d->attn_fused();
+    if (handoffs) MC_HIP(hipMemcpyAsync(d->state_bak, d->state, sizeof(step_state_h), hipMemcpyDeviceToDevice, d->stream));
     s = d->ensure_rope(start_pos);
     if (s != MC_OK) return s;
     s = d->launch("mc_step_set", 1, 1, 1, 64, 0,
@@ -1857,7 +1964,22 @@ mc_decoder_generate(mc_decoder* d, int32_t first_token, int32_t start_pos, int32
     step_state_h st;
     MC_HIP(hipMemcpyAsync(&st, d->state, sizeof st, hipMemcpyDeviceToHost, d->stream));
     MC_HIP(hipStreamSynchronize(d->stream));
+    if (!st.err) return MC_OK;
+    // A hand-off gave up somewhere in the chain.  While the ring has not turned inside this call every row the chain wrote sits
+    // behind kv_len of the state in front of it: the call is repeated from there, exactly, on the launches that need no
+    // co-residency.  Past max_seq_len the failed chain has overwritten rows its own first steps attend to: reported instead.
+    if (handoffs && start_pos + n <= d->cfg.max_seq_len) {
+        d->handoff_failed();
+        MC_HIP(hipMemcpyAsync(d->state, d->state_bak, sizeof(step_state_h), hipMemcpyDeviceToDevice, d->stream));
+        return mc_decoder_generate(d, first_token, start_pos, n, tokens_out);
+    }
     return d->check_handoffs(st);
+}
+
+int32_t
+mc_decoder_handoff_fallbacks(const mc_decoder* d)
+{
+    return d ? d->handoff_fallbacks : 0;
 }
 
 void*
@@ -1892,7 +2014,7 @@ mc_decoder_get_logits(mc_decoder* d, void* out)
     MC_HIP(hipSetDevice(d->dev->ordinal));
     MC_HIP(hipStreamSynchronize(d->stream));
     MC_HIP(hipMemcpy(out, d->logits, (size_t)d->cfg.vocab * d->tb, hipMemcpyDeviceToHost));
-    return MC_OK;
+    return d->check_err_synced(); // (a step nobody waited for: its hand-offs are looked at where its results are read)
 }
 
 mc_status
@@ -1906,7 +2028,7 @@ mc_decoder_get_hidden(mc_decoder* d, int32_t layer, void* out)
     MC_HIP(hipStreamSynchronize(d->stream));
     MC_HIP(hipMemcpy(out, (char*)d->taps + (size_t)li * d->cfg.dim * d->tb, (size_t)d->cfg.dim * d->tb,
                      hipMemcpyDeviceToHost));
-    return MC_OK;
+    return d->check_err_synced();
 }
 
 mc_status
@@ -1937,7 +2059,7 @@ mc_decoder_export_kv(mc_decoder* d, int32_t layer, void* keys, void* values, int
     (void)hipFree(vtmp);
     if (s != MC_OK) return s;
     if (e != hipSuccess) return hip_fail(e, "mc_decoder_export_kv");
-    return MC_OK;
+    return st.err ? d->report_handoff(st.err) : MC_OK;
 }
 
 mc_status

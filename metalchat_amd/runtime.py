@@ -137,6 +137,7 @@ def capi() -> C.CDLL:
         "mc_decoder_time_gemv": (i32, [vp, C.c_char_p, i32, C.POINTER(f32), C.POINTER(C.c_double),
                                        C.POINTER(i32)]),
         "mc_decoder_gemv_kernel_name": (i32, [vp, C.c_char_p, C.c_char_p, sz]),
+        "mc_decoder_handoff_fallbacks": (i32, [vp]),
         "mc_decoder_launch_log": (i32, [vp, i32]),
         "mc_decoder_launch_log_read": (sz, [vp, C.c_char_p, sz]),
         "mc_decoder_weight_ptrs": (i32, [vp, i32, C.c_char_p, pvp, pvp, C.POINTER(i32),
@@ -707,6 +708,10 @@ class Decoder:
         buf = C.create_string_buffer(256)
         _check(capi().mc_decoder_gemv_kernel_name(self._h, which.encode(), buf, 256))
         return buf.value.decode()
+
+    def handoff_fallbacks(self) -> int:
+        """how often an in-launch hand-off gave up and the decoder fell back to launches that need no co-residency"""
+        return int(capi().mc_decoder_handoff_fallbacks(self._h))
 
     def launch_log(self, enable: bool = True):
         """start (and clear) / stop recording the names of the kernels this decoder launches"""

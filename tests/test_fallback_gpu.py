@@ -1,0 +1,118 @@
+"""A hand-off launch whose workgroups are NOT resident together (another stream holds most of the chip): the launch gives up within its
+bound, and the decoder repeats the step on the launches that need no co-residency and stays on them ("the
+default product path must not need an environment variable to survive a busy GPU"; the reference delivers a failed command buffer
+through the future that is waited for, src/kernel_thread.cc:134-144 -- here the step is repeated instead of failing)."""
+import time
+
+import numpy as np
+import pytest
+
+import parity
+from test_context_gpu import FULL_WIDTH, SEED, random_cache
+import modelgen as mg
+
+pytestmark = pytest.mark.gpu
+BF16 = 0
+
+
+@pytest.fixture(scope="module")
+def acc():
+    import metalchat_amd as mc
+
+    return mc.HardwareAccelerator(ordinal=0)
+
+
+def hold_most_of_the_chip(acc2, seconds):
+    # 7 of 8 compute units for `seconds`: what is left holds two, at most three of the 512-thread hand-off workgroups each -- not
+    # the 256 of the launch (half the chip is not enough: the 256 fit two to a CU on the other half).  The holders end by the
+    # clock: any blocking HIP call of this process (a synchronous copy) would wait for them, so nothing here polls or releases
+    import metalchat_amd as mc
+
+    nhold = acc2.compute_units() // 8 * 7
+    release = acc2.to_device(np.zeros(1, np.uint32))
+    started = acc2.to_device(np.zeros(2, np.uint32))
+    mc.KernelTask(acc2.load("mc_test_hold_cu"), (nhold * 64, 1, 1), (64, 1, 1), [release, started, np.uint64(int(seconds * 1e8))])()
+    time.sleep(0.2)
+    return release, started, nhold
+
+
+def test_a_step_whose_handoffs_give_up_is_repeated_without_them(monkeypatch):
+    import metalchat_amd as mc
+
+    acc = mc.HardwareAccelerator(ordinal=0)
+    acc2 = mc.HardwareAccelerator(ordinal=0)   # a second queue: the "other user" of the GPU
+    cfg = dict(dtype=BF16, n_layers=2, vocab=2048, norm_eps=1e-5, max_seq_len=2048, **FULL_WIDTH["llama3-8b"])
+    kw = mg.decoder_kwargs(cfg, weight_format=mc.WFMT_I4, group_size=128)
+    n = 100
+
+    def fresh():
+        d = mc.Decoder(acc, **kw)
+        d.init_synthetic(SEED)
+        for layer in range(cfg["n_layers"]):
+            k, v = random_cache(cfg, n, 900 + layer)
+            d.import_kv(layer, k, v)
+        return d
+
+    # what the launches without hand-offs compute (the form the decoder falls back to)
+    monkeypatch.setenv("MC_ATTN_FUSED", "0")
+    ref = fresh()
+    want = [(ref.step(5, n), ref.logits().copy())]
+    want.append((ref.step(want[0][0], n + 1), ref.logits().copy()))
+    ref.release()
+    monkeypatch.delenv("MC_ATTN_FUSED")
+
+    dec = fresh()
+    dec.launch_log(True)
+ 
+    release, started, nhold = hold_most_of_the_chip(acc2, 6.0)
+    try:
+        t0 = time.perf_counter()
+        tok = dec.step(5, n)                      # most of the hand-off launch's workgroups cannot start: it gives up, the step is repeated
+        took = time.perf_counter() - t0
+        print(f"step under a held chip: {took:.2f} s, fall-backs {dec.handoff_fallbacks()}, launched {sorted(set(dec.launched()))}")
+        assert dec.handoff_fallbacks() == 1
+        assert 1.0 < took < 5.5, f"bounded wait + one repetition, the chip still held: {took:.2f} s"
+        names = dec.launched()
+        assert any(x.startswith("mc_attn_qkv_wo_") or x.startswith("mc_attn_wo_") for x in names), sorted(set(names))
+        assert "mc_attn_scores_bfloat" in names and "mc_attn_pv_bfloat" in names, sorted(set(names))
+        assert tok == want[0][0]
+        parity.exact(dec.logits(), want[0][1], "the repeated step == the two-launch form")
+        # ... and the decoder stays there: the next step has no hand-off launch at all
+        dec.launch_log(True)
+        tok2 = dec.step(tok, n + 1)
+        assert not [x for x in dec.launched() if x.startswith("mc_attn_wo_") or x.startswith("mc_attn_qkv_wo_") or x == "mc_attn_fused_bfloat"]
+        assert dec.handoff_fallbacks() == 1
+        assert tok2 == want[1][0]
+        parity.exact(dec.logits(), want[1][1], "the step after the fall-back")
+    finally:
+        acc2.wait()
+    assert int(started.download(np.uint32, 1)[0]) == nhold
+    dec.release()
+
+
+def test_a_chain_whose_handoffs_give_up_is_repeated_without_them(monkeypatch):
+    import metalchat_amd as mc
+
+    acc = mc.HardwareAccelerator(ordinal=0)
+    acc2 = mc.HardwareAccelerator(ordinal=0)
+    cfg = dict(dtype=BF16, n_layers=2, vocab=2048, norm_eps=1e-5, max_seq_len=2048, **FULL_WIDTH["llama3-8b"])
+    kw = mg.decoder_kwargs(cfg, weight_format=mc.WFMT_I4, group_size=128)
+    monkeypatch.setenv("MC_ATTN_FUSED", "0")
+    ref = mc.Decoder(acc, **kw)
+    ref.init_synthetic(SEED)
+    want = list(ref.generate(3, 0, 12))
+    ref.release()
+    monkeypatch.delenv("MC_ATTN_FUSED")
+    dec = mc.Decoder(acc, **kw)
+    dec.init_synthetic(SEED)
+    release, started, nhold = hold_most_of_the_chip(acc2, 5.0)
+    try:
+        got = list(dec.generate(3, 0, 12))   # stays inside the cache: repeated from the state in front of the call
+        assert dec.handoff_fallbacks() == 1
+        assert got == want
+    finally:
+        acc2.wait()
+    assert int(started.download(np.uint32, 1)[0]) == nhold
+    # a later call: no hand-off launches, no further fall-back
+    assert list(dec.generate(want[-1], 12, 4)) is not None and dec.handoff_fallbacks() == 1
+    dec.release()
