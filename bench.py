@@ -254,8 +254,16 @@ def spawn_workers(args):
     # them and take the rest down
     rc = 0
     live = list(procs)
+    t0 = time.time()
     while live:
         time.sleep(0.2)
+        if time.time() - t0 > float(os.environ.get("MC_BENCH_DEADLINE_S", "3000")):
+            # (a rank that waits in a collective for a peer that will never come: end the job instead of hanging)
+            print("bench.py: the ranks did not finish inside the deadline", file=sys.stderr)
+            rc = 4
+            for q in live:
+                q.kill()
+            break
         for p in list(live):
             r = p.poll()
             if r is None:
@@ -269,19 +277,19 @@ def spawn_workers(args):
     sys.exit(rc)
 
 
-_T_START = time.time()
+_UID_FILES = []
 
 
 def exchange_uid(mc, rank, world, tag=""):
     """Rank 0 makes the 128-byte RCCL id; the others read it from a file rank 0 wrote atomically.  `tag` names a
-    second communicator of the same job (the 70B stages)."""
+    second communicator of the same job (the 70B stages).  The file's NAME is unique per launch -- spawn_workers makes a
+    directory of its own; under torch.distributed.run the run id, the restart count, MASTER_PORT and the launcher's pid -- so a
+    file that exists IS this launch's (no age heuristic: a rank that starts late must not reject a valid id); rank 0 removes
+    it at the end of the job (cleanup_uid_files)."""
     path = os.environ.get("MC_UID_FILE")
-    launcher = False
     if not path:
-        # under torch.distributed.run: one job per (run id, MASTER_PORT, launcher process) on this node -- the workers of
-        # one launch share their parent, a back-to-back run has another
-        launcher = True
-        key = "_".join((os.environ.get("TORCHELASTIC_RUN_ID", "none"), os.environ.get("MASTER_PORT", "29500"), str(os.getppid())))
+        key = "_".join((os.environ.get("TORCHELASTIC_RUN_ID", "none"), os.environ.get("TORCHELASTIC_RESTART_COUNT", "0"),
+                        os.environ.get("MASTER_PORT", "29500"), str(os.getppid())))
         path = os.path.join(tempfile.gettempdir(), f"mc_bench_uid_{os.getuid()}_{key}")
     path += tag
     if rank == 0:
@@ -290,12 +298,12 @@ def exchange_uid(mc, rank, world, tag=""):
         with open(tmp, "wb") as f:
             f.write(uid)
         os.replace(tmp, path)
+        _UID_FILES.append(path)
         return uid
     t0 = time.time()
     while time.time() - t0 < 120:
         try:
-            # (a file older than this process is a previous run's id: rank 0 of THIS run writes after it has started)
-            if os.path.getsize(path) == 128 and (not launcher or os.path.getmtime(path) >= _T_START - 2.0):
+            if os.path.getsize(path) == 128:
                 with open(path, "rb") as f:
                     return f.read()
         except OSError:
@@ -303,6 +311,14 @@ def exchange_uid(mc, rank, world, tag=""):
         time.sleep(0.05)
     print("bench.py: no RCCL id from rank 0 after 120 s", file=sys.stderr)
     sys.exit(2)
+
+
+def cleanup_uid_files():
+    for p in _UID_FILES:
+        try:
+            os.unlink(p)
+        except OSError:
+            pass
 
 
 def run_other_configs(mc, acc, np):
@@ -342,7 +358,21 @@ def run_other_configs(mc, acc, np):
     return out
 
 
-def run_pipelined_70b(mc, acc, np, args, rank, world):
+def build_70b_stage(mc, acc, np, args, rank, world):
+    """This rank's stage(s) of BASELINE configs[4] (everything that can fail locally before the first collective)."""
+    m = MODELS["llama3-70b"]
+
+    def stage(r):
+        b, e = mc.pipeline_layer_range(r, world, m["n_layers"])
+        d = mc.Decoder(acc, dtype=mc.BF16, family=mc.FAMILY_LLAMA3, max_seq_len=2048, attn_scale=float(1.0 / np.sqrt(m["head_dim"])),
+                       layer_begin=b, layer_end=e, weight_format=mc.WFMT_I4, group_size=128, use_graph=0, **m)
+        d.init_synthetic(7)
+        return d
+
+    return [stage(r) for r in range(world)] if args.share_device else [stage(rank)]
+
+
+def run_pipelined_70b(mc, acc, np, args, rank, world, stages):
     """BASELINE configs[4]: Llama-3-70B int4 g128, layers pipelined over the `world` stages of this job (80 / world
     layers and their caches per stage, include/metalchat/nn/llama.h:123-126 cut into stages), S = 2048, batch 1 greedy.
     Runs after the headline timing with a communicator of its own; the value is absolute tokens/s and the fraction of the
@@ -351,20 +381,11 @@ def run_pipelined_70b(mc, acc, np, args, rank, world):
     m = MODELS["llama3-70b"]
     S, K = 2048, 32
     lb, le = mc.pipeline_layer_range(rank, world, m["n_layers"])
-
-    def stage(r):
-        b, e = mc.pipeline_layer_range(r, world, m["n_layers"])
-        d = mc.Decoder(acc, dtype=mc.BF16, family=mc.FAMILY_LLAMA3, max_seq_len=S, attn_scale=float(1.0 / np.sqrt(m["head_dim"])),
-                       layer_begin=b, layer_end=e, weight_format=mc.WFMT_I4, group_size=128, use_graph=0, **m)
-        d.init_synthetic(7)
-        return d
-
     if args.share_device:
-        stages = [stage(r) for r in range(world)]
         pipe = mc.Pipeline.local(stages)
     else:
-        stages = [stage(rank)]
         pipe = mc.Pipeline.rccl(stages[0], rank, world, exchange_uid(mc, rank, world, tag="_70b"))
+    ranks_seen = pipe.comm_info()
     start = S - K - 8
     tok = int(pipe.generate(1, start, 8)[-1])
     pipe.allreduce_max(0.0)
@@ -381,7 +402,8 @@ def run_pipelined_70b(mc, acc, np, args, rank, world):
                        f"{'stages sharing GPU 0, device-to-device hops' if args.share_device else 'one process per GPU, RCCL send/recv per hop'}",
                 tokens_per_s=tps, ms_per_token=dt / K * 1e3, tokens=K, layers_per_stage=le - lb, algorithmic_bytes=ab["total"],
                 single_stream_ceiling_tokens_per_s=HBM_PEAK_GBS * 1e9 / ab["total"],
-                frac_of_hbm_peak=ab["total"] * tps / 1e9 / HBM_PEAK_GBS, hipgraph=False)
+                frac_of_hbm_peak=ab["total"] * tps / 1e9 / HBM_PEAK_GBS, hipgraph=False,
+                rccl={"ranks": ranks_seen[0], "rank": ranks_seen[1]})
 
 
 def main():
@@ -472,6 +494,11 @@ def main():
         "whole_token": {"algorithmic_bytes": ab["total"], "achieved_GBs": ab["total"] * tok_s / 1e9,
                         "frac_of_hbm_peak": ab["total"] * tok_s / 1e9 / HBM_PEAK_GBS},
     }
+    if piped:
+        # what the transport itself says (ncclCommCount / ncclCommUserRank; (-1, -1): stages sharing one process): the driver
+        # can check that RCCL saw N ranks
+        n_seen, r_seen = pipe.comm_info()
+        out["rccl"] = {"ranks": n_seen, "rank": r_seen}
 
     if rank == 0 and world == 1 and not args.no_roofline:
         # dominant kernel: the fused rmsnorm + w1|w3 int4 GEMV + SiLU*mul (81 % of the layer bytes
@@ -528,21 +555,50 @@ def main():
             dec.release()
         out["other_configs"] = run_other_configs(mc, acc, np)
     if piped and not args.no_other_configs and args.model == "llama3-8b":
-        # every rank takes part; rank 0 reports
+        # every rank takes part; rank 0 reports.  A rank that fails ALONE would leave its peers waiting in the new communicator
+        # for ever (the launcher only ends a job whose worker exits non-zero), so: (1) what can fail locally before the first
+        # collective -- building the 70B stage: allocations -- is agreed on over the headline communicator, which is still
+        # alive: one failure and every rank skips the leg; (2) a failure behind that point (RCCL bring-up, a hop) ends the JOB
+        # with a non-zero exit -- rank 0 prints the headline line first, also when it is the launcher that takes it down (SIGTERM).
+        import signal
+
+        label = f"Llama-3-70B int4 g128 layer-pipelined pp{world}"
+        build_err = None
+        stage70 = None
+        try:
+            stage70 = build_70b_stage(mc, acc, np, args, rank, world)
+        except Exception as e:
+            build_err = str(e)[:300]
+        failed = pipe.allreduce_max(1.0 if build_err else 0.0)
         pipe.release()
         for d in (stages if args.share_device else [dec]):
             d.release()
         pipe = None
-        try:
-            r70 = run_pipelined_70b(mc, acc, np, args, rank, world)
-        except Exception as e:  # an informational leg must not take the headline down
-            r70 = dict(config=f"Llama-3-70B int4 g128 layer-pipelined pp{world}", error=str(e)[:300])
-        out["other_configs"] = [r70]
+        if failed:
+            out["other_configs"] = [dict(config=label, error=build_err or "another rank could not build its stages")]
+        else:
+            def headline_then_die(*_):
+                out["other_configs"] = [dict(config=label, error="the leg failed on another rank; the job was ended")]
+                if rank == 0:
+                    print(json.dumps(out), flush=True)
+                os._exit(3)
+
+            signal.signal(signal.SIGTERM, headline_then_die)
+            try:
+                out["other_configs"] = [run_pipelined_70b(mc, acc, np, args, rank, world, stage70)]
+            except Exception as e:
+                out["other_configs"] = [dict(config=label, error=str(e)[:300])]
+                if rank == 0:
+                    print(json.dumps(out), flush=True)
+                sys.stdout.flush()
+                os._exit(3)  # (non-zero: spawn_workers / torchrun end the peers that wait for this rank)
+            signal.signal(signal.SIGTERM, signal.SIG_DFL)
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(args, m, tbytes)
     if rank == 0:
         print(json.dumps(out), flush=True)
     sync_all()
+    cleanup_uid_files()
 
 
 if __name__ == "__main__":

@@ -272,6 +272,9 @@ mc_status mc_pipeline_generate(mc_pipeline* p, int32_t first_token, int32_t star
 mc_status mc_pipeline_prefill(mc_pipeline* p, const int32_t* tokens, int32_t len, int32_t start_pos, int32_t sliding_window,
                               int32_t* next_token); /* the prompt pass: [len][dim] rows hop stage to stage */
 mc_status mc_pipeline_allreduce_max(mc_pipeline* p, double* value);
+/* What the transport itself reports: the communicator's size and this process's rank in it (ncclCommCount /
+ * ncclCommUserRank), so a caller can verify that RCCL saw N ranks; (-1, -1) for a local pipeline. */
+mc_status mc_pipeline_comm_info(mc_pipeline* p, int32_t* ranks, int32_t* rank);
 void mc_pipeline_release(mc_pipeline* p);
 /* Sampler of the last stage -- include/metalchat/nn/sampling.h:152-315.
  *   MC_SAMPLER_GREEDY : argmax, first maximum (the BASELINE configuration).

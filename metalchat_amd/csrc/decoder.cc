@@ -2303,6 +2303,8 @@ struct rccl_api {
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*CommAbort)(ncclComm_t) = nullptr; // optional
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;    // optional
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr; // optional
     ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
@@ -2335,6 +2337,8 @@ rccl()
     SYM(GetErrorString, "ncclGetErrorString")
 #undef SYM
     api.CommAbort = reinterpret_cast<decltype(api.CommAbort)>(dlsym(api.handle, "ncclCommAbort"));
+    api.CommCount = reinterpret_cast<decltype(api.CommCount)>(dlsym(api.handle, "ncclCommCount"));
+    api.CommUserRank = reinterpret_cast<decltype(api.CommUserRank)>(dlsym(api.handle, "ncclCommUserRank"));
     return api;
 }
 
@@ -2655,6 +2659,27 @@ mc_pipeline_allreduce_max(mc_pipeline* p, double* value)
     MC_NCCL(api.AllReduce(p->red, p->red, 1, ncclDouble, ncclMax, p->comm, d->stream), "ncclAllReduce");
     MC_HIP(hipMemcpyAsync(value, p->red, 8, hipMemcpyDeviceToHost, d->stream));
     MC_HIP(hipStreamSynchronize(d->stream));
+    return MC_OK;
+}
+
+// what the TRANSPORT says about this pipeline: ranks of the communicator and this process's rank in it, read back from RCCL
+// (ncclCommCount / ncclCommUserRank) -- not what the caller passed to mc_pipeline_create.  A local pipeline: (-1, -1).
+mc_status
+mc_pipeline_comm_info(mc_pipeline* p, int32_t* ranks, int32_t* rank)
+{
+    if (!p || !ranks || !rank) return fail(MC_ERR_INVALID_ARGUMENT, "mc_pipeline_comm_info: null argument");
+    *ranks = -1;
+    *rank = -1;
+    if (p->local) return MC_OK;
+    mc_status su = rccl_usable(p);
+    if (su != MC_OK) return su;
+    rccl_api& api = rccl();
+    if (!api.CommCount || !api.CommUserRank) return fail(MC_ERR_RUNTIME, "pipeline: librccl has no ncclCommCount / ncclCommUserRank");
+    int n = -1, r = -1;
+    MC_NCCL(api.CommCount(p->comm, &n), "ncclCommCount");
+    MC_NCCL(api.CommUserRank(p->comm, &r), "ncclCommUserRank");
+    *ranks = n;
+    *rank = r;
     return MC_OK;
 }
 

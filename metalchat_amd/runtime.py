@@ -128,6 +128,7 @@ def capi() -> C.CDLL:
         "mc_pipeline_prefill": (i32, [vp, C.POINTER(i32), i32, i32, i32, C.POINTER(i32)]),
         "mc_decoder_prefill_stage": (i32, [vp, C.POINTER(i32), vp, i32, i32, i32, pvp, C.POINTER(i32)]),
         "mc_pipeline_release": (None, [vp]),
+        "mc_pipeline_comm_info": (i32, [vp, C.POINTER(i32), C.POINTER(i32)]),
         "mc_decoder_set_taps": (i32, [vp, i32]),
         "mc_decoder_get_logits": (i32, [vp, vp]),
         "mc_decoder_get_hidden": (i32, [vp, i32, vp]),
@@ -523,6 +524,12 @@ class Pipeline:
         v = C.c_double(value)
         _check(capi().mc_pipeline_allreduce_max(self._h, C.byref(v)))
         return v.value
+
+    def comm_info(self):
+        """(ranks, rank) as the transport reports them (ncclCommCount / ncclCommUserRank); (-1, -1) for a local pipeline"""
+        n, r = C.c_int32(), C.c_int32()
+        _check(capi().mc_pipeline_comm_info(self._h, C.byref(n), C.byref(r)))
+        return n.value, r.value
 
     def release(self):
         if self._h:

@@ -5,7 +5,7 @@ boundary is the hidden row [1,1,dim] (include/metalchat/nn/llama.h:123-126), so 
 ranges shard naturally with ONE point-to-point hop per stage boundary and one 4-byte hop that
 brings the greedy token back to the first stage.  No all-reduce, no all-gather.
 
-This module is the SCHEDULE only, kept for the CPU test: tests/test_pipeline_cpu.py drives it over gloo
+This module is TEST INFRASTRUCTURE -- the schedule only (round 4: moved out of the product package): tests/test_pipeline_cpu.py drives it over gloo
 (world 2 and 3) with the CPU oracle as the stage, so the hop protocol -- who sends what to whom, in which
 order, past max_seq_len -- is covered without a GPU.  The product path does not use it: bench.py and the
 C++ shim go through mc_pipeline_* (metalchat_amd/csrc/decoder.cc: ncclSend / ncclRecv on the decoder's

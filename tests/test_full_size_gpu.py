@@ -66,7 +66,13 @@ def test_dominant_gemvs_on_sampled_rows_at_full_size(acc):
     L = mo.layout
     dim, ffn = M["dim"], M["ffn_dim"]
     x = mo.encode(BF16, rng.normal(0, 1, dim).astype(np.float32))
-    # ---- w1|w3: rmsnorm prologue + GEMV + SiLU*mul epilogue, the kernel bench.py's roofline is about
+    # The LINEAR-ORDER kernels a token really launches (mc_gemv_i4_bfloat_lin{2,7}_*: bench.py's roofline is about _lin2_p1_e2) at the
+    # decoder's own geometry -- one 512-thread workgroup per compute unit, the (8, 6) deal of 56 row pairs per workgroup, s_setprio
+    # on the 7 KiB rows, the decoder's LDS size -- under the single-kernel bound, and the classic kernels of the same arithmetic
+    # beside them
+    from test_lin_kernels_gpu import launch as lin_launch, lds_bytes as lin_lds
+    cus = acc.compute_units()
+    # ---- w1|w3: rmsnorm prologue + GEMV + SiLU*mul epilogue
     nw = norm_weights(9, dim)                                     # layer 0 ffn_norm
     xn = np.zeros((1, dim), np.uint16)
     mo.rmsnorm(BF16, L((1, dim)), xn, L((1, dim)), x.reshape(1, -1), L((dim,)), nw, M["norm_eps"], 0.0)
@@ -82,6 +88,10 @@ def test_dominant_gemvs_on_sampled_rows_at_full_size(acc):
     assert (rows, inf) == (2 * ffn, dim)
     got = run_gemv(acc, "mc_gemv_i4_bfloat_m4d_p1_e2", wptr, sptr, x, ffn, rows, inf, 128, BF16, norm=nw, wgs=512)
     parity.check(BF16, got[js], ref.reshape(-1), rel=2e-3, max_ulp=1, max_frac=0.2, scale_aware=False, what="w1|w3 rows")
+    assert dec.gemv_kernel_name("w13") == "mc_gemv_i4_bfloat_lin2_p1_e2"
+    gotl = lin_launch(acc, "mc_gemv_i4_bfloat_lin2_p1_e2", wptr, sptr, x, ffn, rows, inf, 128, norm=nw, wgs=cus, lds=lin_lds("i4_lin2", inf))
+    parity.check(BF16, gotl[js], ref.reshape(-1), rel=2e-3, max_ulp=1, max_frac=0.2, scale_aware=False, what="w1|w3 rows, linear order, the token's grid")
+    parity.exact(gotl, got, "w1|w3: every one of the 14336 outputs, linear order == classic")
     # ---- w2 with the residual epilogue (K = 14336: seven chunks per row)
     g = mo.encode(BF16, rng.normal(0, 0.5, ffn).astype(np.float32))
     res = mo.encode(BF16, rng.normal(0, 1, dim).astype(np.float32))
@@ -93,6 +103,10 @@ def test_dominant_gemvs_on_sampled_rows_at_full_size(acc):
     wptr, sptr, rows, inf, ng = dec.weight_ptrs(0, "w2")
     got2 = run_gemv(acc, "mc_gemv_i4_bfloat_m4d_p0_e1", wptr, sptr, g, dim, rows, inf, 128, BF16, res=res, wgs=256)
     parity.check(BF16, got2[rs], ref2.reshape(-1), rel=2e-3, max_ulp=1, max_frac=0.3, scale_aware=False, what="w2 rows")
+    assert dec.gemv_kernel_name("w2") == "mc_gemv_i4_bfloat_lin7_p0_e1"
+    got2l = lin_launch(acc, "mc_gemv_i4_bfloat_lin7_p0_e1", wptr, sptr, g, dim, rows, inf, 128, res=res, wgs=cus, lds=lin_lds("i4_lin7", inf))
+    parity.check(BF16, got2l[rs], ref2.reshape(-1), rel=2e-3, max_ulp=1, max_frac=0.2, scale_aware=False, what="w2 rows, linear order, the token's grid")
+    parity.exact(got2l, got2, "w2: every one of the 4096 outputs, linear order == classic")
     # ---- output head: 128256 rows, final norm prologue
     fw = norm_weights(0xFFFF0002, dim)
     mo.rmsnorm(BF16, L((1, dim)), xn, L((1, dim)), x.reshape(1, -1), L((dim,)), fw, M["norm_eps"], 0.0)
@@ -102,6 +116,17 @@ def test_dominant_gemvs_on_sampled_rows_at_full_size(acc):
     wptr, sptr, rows, inf, ng = dec.weight_ptrs(-1, "output")
     goth = run_gemv(acc, "mc_gemv_i4_bfloat_m4d_p1_e0", wptr, sptr, x, M["vocab"], rows, inf, 128, BF16, norm=fw, wgs=512)
     parity.check(BF16, goth[vs], refh, rel=2e-3, max_ulp=1, max_frac=0.2, scale_aware=False, what="head rows")
+    # the head as the token launches it: the greedy pick rides in the launch (gemv.h EPI_STORE_PICK, one key per workgroup)
+    assert dec.gemv_kernel_name("head") == "mc_gemv_i4_bfloat_lin2_p1_e5"
+    keys = acc.to_device(np.zeros(1024, np.uint64))
+    desc = acc.to_device(np.array([keys.device_ptr, 0, 0, 0], np.uint64))   # pick_epilogue {key, ticket = NULL, state, tokens_out}
+    gothl = lin_launch(acc, "mc_gemv_i4_bfloat_lin2_p1_e5", wptr, sptr, x, M["vocab"], rows, inf, 128, res=desc, norm=fw, wgs=cus,
+                       lds=lin_lds("i4_lin2", inf))
+    parity.check(BF16, gothl[vs], refh, rel=2e-3, max_ulp=1, max_frac=0.2, scale_aware=False, what="head rows, linear order + pick, the token's grid")
+    parity.exact(gothl, goth, "head: every one of the 128256 logits, linear order == classic")
+    best = int(keys.download(np.uint64, 1024).max())
+    logits = mo.decode(BF16, gothl) if hasattr(mo, "decode") else (gothl.astype(np.uint32) << 16).view(np.float32)
+    assert 0xFFFFFFFF - (best & 0xFFFFFFFF) == int(np.argmax(logits)), "the pick of the launch == the first maximum of its logits"
     dec.release()
 
 

@@ -58,7 +58,9 @@ def test_decode_and_reference_kernels_present(symbols):
     for k in ("mc_step_set", "mc_step_advance", "mc_step_rope", "mc_rope_table", "mc_argmax_keys",
               "mc_attn_fused_bfloat",  # decode attention in one launch
               # ... with the Wo GEMV behind it (decoder.cc attn_wo_fused: head_dim x KiB per Wo row)
-              "mc_attn_wo_i4_bfloat_hd128_k2", "mc_attn_wo_i4_bfloat_hd64_k1", "mc_attn_wo_i4_bfloat_hd256_k2"):
+              "mc_attn_wo_i4_bfloat_hd128_k2", "mc_attn_wo_i4_bfloat_hd64_k1", "mc_attn_wo_i4_bfloat_hd256_k2",
+              "mc_attn_qkv_wo_i4_bfloat_hd128_k2_q2",  # wq|wk|wv, attention and Wo in one launch (round 4)
+              "mc_test_hold_cu"):
         assert k in symbols, k
     # the reference's own kernel names (ABI part 1, kernel/kernel.h:30-90)
     for k in ("rmsnorm_bfloat", "softmax_bfloat", "bmm_8_float", "hadamard_broadcast_bfloat_int8_t_float"):

@@ -1,4 +1,4 @@
-"""The N > 1 layer-pipeline protocol (metalchat_amd/pipeline.py) over gloo on CPU, world_size 2 and
+"""The N > 1 layer-pipeline protocol (tests/pipeline_schedule.py) over gloo on CPU, world_size 2 and
 3, with the CPU oracle as the stage compute: the pipelined greedy tokens must equal the
 single-process oracle's (bit-exact integer path), and the layer split must cover every layer once."""
 import os
@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_layer_range_covers_all_layers():
-    from metalchat_amd.pipeline import layer_range
+    from pipeline_schedule import layer_range
 
     for n_layers in (1, 2, 22, 32, 80):
         for world in (1, 2, 3, 4, 8):
@@ -33,7 +33,7 @@ def _worker(rank, world, port, n_tokens, q):
     import torch.distributed as dist
 
     import modelgen as mg
-    from metalchat_amd.pipeline import layer_range, pipelined_decode
+    from pipeline_schedule import layer_range, pipelined_decode
     from oracle import mc_oracle as mo
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
