@@ -188,6 +188,7 @@ struct mc_decoder {
     unsigned long long* attn_slab_g = nullptr; // [KV][nsplit][n_rep][hd] fp32 partial P.V sums
     unsigned long long* attn_row_g = nullptr;  // [H * hd / 2]          the finished attention row, two bf16 per granule (mc_attn_wo_*)
     unsigned long long* attn_qkv_g = nullptr;  // [KV][(n_rep + 2) hd / 2] the step's rotated queries and K / V row, two bf16 per granule (mc_attn_qkv_wo_*)
+    bool attn_qkn_on = true;     // MC_ATTN_QKN=0: gemma3's q/k-norm + rope + cache write as a launch of their own (mc_rope_kv_T) in front of the attention (A/B, parity)
     bool attn_qkv_on = true;     // MC_ATTN_QKV=0: wq|wk|wv as a launch of its own in front of mc_attn_wo_* (A/B, parity)
     // ---- what happens when an in-launch hand-off gives up (its workgroups were not resident together: another stream or process
     // holds part of the chip).  The launch sets state.err and completes; the host then LATCHES the decoder onto the launches
@@ -821,6 +822,7 @@ struct mc_decoder {
         for (int li = 0; li < n_own; li++) {
             layer_w& L = layers[li];
             const bool qkv_in = attn_qkv_wo_fused(L);
+            bool qkn_in = false;
             if (qkv_in) {
                 // attention_norm, wq|wk|wv, rope, cache write, scores, softmax, P.V, wo + residual (transformer.h:130-133,
                 // attention.h:170-205) in ONE launch: every hand-off but the last stays inside one kv head
@@ -852,11 +854,16 @@ struct mc_decoder {
                     s = gemv(L.qkv, 1, 0, x, qkv, nullptr, L.attention_norm, mu);
                 }
                 if (s != MC_OK) return s;
-                s = launch("mc_rope_kv_" + tname, H + 2 * KV, 1, 1, hd / 2, 0,
-                           pack(qkv, q_rot, L.kc, L.vt, rope_cos[L.rope_table], rope_sin[L.rope_table],
-                                L.q_norm, L.k_norm, state, (uint32_t)H, (uint32_t)KV, (uint32_t)hd,
-                                (uint32_t)cfg.max_seq_len, cfg.norm_eps, mu));
-                if (s != MC_OK) return s;
+                // q_norm / k_norm + rope + cache write: inside the one-launch attention where that is what follows
+                // (mc_attn_fused_qkn_bfloat, decode_kernels.hip q_from_qkv_rows), a launch of their own otherwise
+                qkn_in = attn_qkn_on && tb == 2 && (hd == 128 || hd == 256) && attn_fused() && !attn_wo_fused(L.wo);
+                if (!qkn_in) {
+                    s = launch("mc_rope_kv_" + tname, H + 2 * KV, 1, 1, hd / 2, 0,
+                               pack(qkv, q_rot, L.kc, L.vt, rope_cos[L.rope_table], rope_sin[L.rope_table],
+                                    L.q_norm, L.k_norm, state, (uint32_t)H, (uint32_t)KV, (uint32_t)hd,
+                                    (uint32_t)cfg.max_seq_len, cfg.norm_eps, mu));
+                    if (s != MC_OK) return s;
+                }
             }
             if (qkv_in) {
             } else if (attn_wo_fused(L.wo)) {
@@ -875,6 +882,13 @@ struct mc_decoder {
                 }
             } else if (attn_fused()) {
                 // scores, softmax, P.V                 (attention.h:191-203) in ONE launch, then Wo from the finished row
+                if (qkn_in)
+                    s = launch("mc_attn_fused_qkn_" + tname, (unsigned)(nsplit * KV), 1, 1, 256, 0,
+                               pack((const void*)qkv, L.kc, L.vt, attn_out, attn_psum_g, attn_slab_g, state, (uint32_t)n_rep, (uint32_t)KV,
+                                    (uint32_t)hd, (uint32_t)cfg.max_seq_len, scale_T, (uint32_t)nsplit, (uint32_t)(li + 1),
+                                    (uint32_t)(handoff_fast ? 1 : 0), (const void*)L.q_norm, (const void*)L.k_norm,
+                                    (const float*)rope_cos[L.rope_table], (const float*)rope_sin[L.rope_table], cfg.norm_eps, mu));
+                else
                 s = launch("mc_attn_fused_" + tname, (unsigned)(nsplit * KV), 1, 1, 256, 0,
                            pack(q_rot, L.kc, L.vt, attn_out, attn_psum_g, attn_slab_g, state, (uint32_t)n_rep, (uint32_t)KV, (uint32_t)hd,
                                 (uint32_t)cfg.max_seq_len, scale_T, (uint32_t)nsplit, (uint32_t)(li + 1), (void*)nullptr,
@@ -1313,6 +1327,7 @@ mc_decoder_create(mc_device* dev, mc_library* lib, mc_queue* q, const mc_decoder
     if (const char* e = getenv("MC_ATTN_WO")) d->attn_wo_on = atoi(e) != 0;
     if (const char* e = getenv("MC_HANDOFF_FAST")) d->handoff_fast = atoi(e) != 0;
     if (const char* e = getenv("MC_ATTN_QKV")) d->attn_qkv_on = atoi(e) != 0;
+    if (const char* e = getenv("MC_ATTN_QKN")) d->attn_qkn_on = atoi(e) != 0;
     if (const char* e = getenv("MC_ATTN_FUSED_WGS")) d->attn_fused_max_wgs_per_cu = (unsigned)std::max(1, std::min(4, atoi(e)));
     if (const char* e = getenv("MC_LING_HALF")) d->ling_half = atoi(e) != 0;
     if (const char* e = getenv("MC_LIN_SPLIT")) d->lin_split = atoi(e) != 0;

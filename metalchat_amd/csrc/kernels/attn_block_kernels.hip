@@ -48,7 +48,7 @@ using namespace mc::gemv;
 template <int HD, int QN>
 struct qkv_in_launch {
     static_assert(QN == 2, "one 16-byte packet of the hidden row per thread (K = 4096, 512 threads)");
-    static constexpr bool LDS = true;
+    static constexpr bool LDS = true, PIN_V = true;
     static constexpr int TL_STRIDE = 16, TL_BASE = 3; // stamps: 0 start, 1 row staged, 2 pairs published, 3.. attn_fused_bf's 0..
     static constexpr uint32_t KQ = 2048u * QN, ROWBQ = KQ / 2, CHUNK_LDS = 2048 * 2 / 16 * 17, HALF = HD / 2;
     static constexpr int PMAXQ = 2;

@@ -643,13 +643,131 @@ mc_attn_pv_reduce_float(const float* __restrict__ parts, float* __restrict__ out
 // (LDS); the tile registers of the step's slot are then patched from there (the cache row itself is written by the workgroup
 // that computed it, for the steps to come: whatever a tile load found in that slot is never used).
 struct q_from_hbm {
-    static constexpr bool LDS = false;
+    static constexpr bool LDS = false, PIN_V = false;
     static constexpr int TL_STRIDE = 8, TL_BASE = 0;
     typedef const __attribute__((address_space(3))) bf16_t* lds_row; // (LDS address space: a generic pointer would make these flat loads)
     lds_row q_s = nullptr, k_s = nullptr, v_s = nullptr;
     __device__ __forceinline__ void at_start() {}
     __device__ __forceinline__ void before_tiles() {}
     __device__ __forceinline__ void before_scores() {}
+};
+
+// gemma3 (include/metalchat/nn/attention.h:170-177): q_norm / k_norm over whole heads, then the rotation, then the cache write --
+// mc_rope_kv_T above, a launch of hd / 2 threads per head that moves nothing (4.9 us per block at Gemma-7B's widths).  This
+// policy does that work in the attention launch: every workgroup of kv head g reads the RAW rows of g from the wq|wk|wv GEMV's
+// output (its n_rep query heads, its K row, its V row: 1.5 KB), normalises and rotates them itself -- bit for bit
+// rope_kv_body: the same thread <-> pair mapping, the same wave_sum tree, the wave sums added in wave order -- and the
+// workgroup whose range holds the step's slot writes the K row and the V column to the cache for the steps to come.
+template <int HD>
+struct q_from_qkv_rows {
+    static_assert(HD == 128 || HD == 256, "hd / 2 threads per head are whole waves");
+    static constexpr bool LDS = true, PIN_V = false;
+    static constexpr int TL_STRIDE = 8, TL_BASE = 0;
+    static constexpr uint32_t HALF = HD / 2, HPP = 256 / HALF, WPH = HALF / 64; // heads per pass of the 256 threads, waves per head
+    typedef const __attribute__((address_space(3))) bf16_t* lds_row;
+    typedef __attribute__((address_space(3))) bf16_t* lds_row_w;
+    lds_row q_s, k_s, v_s;
+    float* red; // 4 floats
+    const bf16_t *qkv, *q_norm, *k_norm;
+    const float *fcos, *fsin;
+    bf16_t *kc, *vt;
+    const step_state* st;
+    uint32_t n_rep, KV, max_seq, split_slots; // split_slots: cache slots per workgroup
+    float eps, mu;
+    // What is asked for when: the raw rows, the norm weights and the step state by the FIRST instructions of the launch
+    // (at_start, called by the kernel before anything else) -- in front of the K and V tiles, 64 KB per workgroup at head_dim 256: asked for behind them (the first
+    // build) these 1.5 KB of L2 hits sat behind 128 KB per CU in the memory pipe and the launch lasted 3.8 us longer.
+    static constexpr int NPRE = 3; // passes whose rows are requested up front (gemma3's shapes: at most 5 heads per kv head)
+    bf16_t px1[NPRE], px2[NPRE]; // RAW: a value converted where it is loaded is waited for there, in front of the tile requests
+    float pc = 0.0f, ps = 0.0f;
+    bf16_t nq0, nq1, nk0, nk1;
+    uint32_t ws_, rrow_;
+    // (what crosses these barriers is in LDS: wait for the LDS counter only.  __syncthreads() behind a global store -- the cache
+    //  write below -- drains the vector-memory counter too, i.e. waits for the V tile in front of the scores: the launch then
+    //  lasted 20.9 us against 11.9 + 4.9 for the two launches it replaces)
+    static __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+    __device__ __forceinline__ const bf16_t* head_row(uint32_t kv, uint32_t hc) const
+    {
+        return qkv + (size_t)(hc < n_rep ? kv * n_rep + hc : n_rep * KV + kv) * HD;
+    }
+    __device__ __forceinline__ void at_start()
+    {
+        const uint32_t tid = threadIdx.x, kv = blockIdx.x % KV, j = tid % HALF;
+        ws_ = (uint32_t)st->write_slot;
+        rrow_ = (uint32_t)st->rope_row;
+#pragma unroll
+        for (int p = 0; p < NPRE; p++) {
+            const uint32_t hl = (uint32_t)p * HPP + tid / HALF, hc = hl < n_rep + 1u ? hl : n_rep;
+            const bf16_t* src = head_row(kv, hc);
+            px1[p] = src[2 * j]; // packed [2j] = natural [j], [2j + 1] = natural [j + hd / 2]
+            px2[p] = src[2 * j + 1];
+        }
+        nq0 = q_norm[j]; nq1 = q_norm[j + HALF];
+        nk0 = k_norm[j]; nk1 = k_norm[j + HALF];
+    }
+    __device__ __forceinline__ void before_tiles() {}
+    __device__ __forceinline__ void before_scores()
+    {
+        const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+        const uint32_t kv = blockIdx.x % KV, split = blockIdx.x / KV, H = n_rep * KV;
+        const uint32_t ws = ws_;
+        // (the table row's address waits for the step state -- the launch's OLDEST load, long in by now; asked for in front of the
+        //  tiles that wait held their requests back (519 tokens/s against 537 with mc_rope_kv as a launch), here the answer arrives
+        //  right behind the tiles the scores wait for anyway)
+        pc = fcos[(size_t)rrow_ * HALF + tid % HALF];
+        ps = fsin[(size_t)rrow_ * HALF + tid % HALF];
+        const bool writer = ws / split_slots == split; // this workgroup's range holds the step's slot
+        lds_row_w qw = (lds_row_w)q_s;
+        // heads n_rep .. : the K row (one more normalised head); passes of HPP heads.  The first pass is straight-line code in front of
+        // the loop: hipcc waits vmcnt(0) at the head of a loop whose body uses loaded values, i.e. for the K tile -- the norms of
+        // the first pass (Gemma-7B: the only one) then run while the tile is still in flight, on the launch's oldest loads
+        auto one_pass = [&](uint32_t h0, uint32_t p) {
+            const uint32_t hl = h0 + tid / HALF, j = tid % HALF;
+            const bool live = hl < n_rep + 1u, is_q = hl < n_rep;
+            const uint32_t hc = live ? hl : n_rep;
+            float x1, x2;
+            if (p < (uint32_t)NPRE) { // (wave-uniform)
+                x1 = bf2f(p == 0 ? px1[0] : (p == 1 ? px1[1] : px1[2]));
+                x2 = bf2f(p == 0 ? px2[0] : (p == 1 ? px2[1] : px2[2]));
+            } else {
+                const bf16_t* src = head_row(kv, hc);
+                x1 = bf2f(src[2 * j]);
+                x2 = bf2f(src[2 * j + 1]);
+            }
+            {
+                const float v = wave_sum(x1 * x1 + x2 * x2);
+                lds_barrier();
+                if (lane == 0) red[wave] = v;
+                lds_barrier();
+                float tot = 0.0f;
+#pragma unroll
+                for (uint32_t i = 0; i < WPH; i++) tot += red[(tid / HALF) * WPH + i];
+                const float inv = 1.0f / sqrtf(tot / (float)HD + eps);
+                x1 = BF::rt((mu + bf2f(is_q ? nq0 : nk0)) * x1 * inv);
+                x2 = BF::rt((mu + bf2f(is_q ? nq1 : nk1)) * x2 * inv);
+            }
+            const float c = pc, sn = ps;
+            const bf16_t o1 = BF::st(c * x1 - sn * x2), o2 = BF::st(sn * x1 + c * x2);
+            if (live) {
+                qw[hc * HD + j] = o1; // (the K row sits behind the n_rep query heads: k_s = q_s + n_rep * HD)
+                qw[hc * HD + j + HALF] = o2;
+                if (!is_q && writer) {
+                    bf16_t* dst = kc + ((size_t)kv * max_seq + ws) * HD;
+                    dst[j] = o1;
+                    dst[j + HALF] = o2;
+                }
+            }
+        };
+        one_pass(0u, 0u);
+        for (uint32_t h0 = HPP, p = 1; h0 < n_rep + 1u; h0 += HPP, p++) one_pass(h0, p);
+        // the V row: as the GEMV left it
+        for (uint32_t d = tid; d < (uint32_t)HD; d += 256) {
+            const bf16_t v = qkv[(size_t)(H + KV + kv) * HD + d];
+            ((lds_row_w)v_s)[d] = v;
+            if (writer) vt[((size_t)kv * HD + d) * max_seq + ws] = v;
+        }
+        lds_barrier();
+    }
 };
 template <int HD, int T, int NW, typename OnChunk, typename BehindScores, typename QSrc = q_from_hbm>
 __device__ __forceinline__ void
@@ -712,18 +830,25 @@ attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const
     //  11.34 / 11.55 us against 11.28 in the trace, 735 / 735 / 745 tokens/s against 745 / 746 / 758 alternating on one box
     //  (tools/attn_wo_timeline.py: the scores are done 0.3 us sooner, publish and hand-off C take it back).  Left to the compiler.)
     uint4 vb[T][NB][2];
+    auto request_v = [&] {
 #pragma unroll
-    for (int t = 0; t < T; t++)
+        for (int t = 0; t < T; t++)
 #pragma unroll
-        for (int b = 0; b < NB; b++) {
-            const uint32_t db = wave + NW * b;
-            const bf16_t* vrow = vt + ((size_t)kv * HD + (db < (uint32_t)NDB ? db : 0u) * 16 + col) * max_seq;
+            for (int b = 0; b < NB; b++) {
+                const uint32_t db = wave + NW * b;
+                const bf16_t* vrow = vt + ((size_t)kv * HD + (db < (uint32_t)NDB ? db : 0u) * 16 + col) * max_seq;
 #pragma unroll
-            for (int u = 0; u < 2; u++) {
-                const uint32_t p0 = p_begin + t * PB + u * 32 + c * 8;
-                vb[t][b][u] = *reinterpret_cast<const uint4*>(vrow + (p0 + 8 <= max_seq ? p0 : max_seq - 8));
+                for (int u = 0; u < 2; u++) {
+                    const uint32_t p0 = p_begin + t * PB + u * 32 + c * 8;
+                    vb[t][b][u] = *reinterpret_cast<const uint4*>(vrow + (p0 + 8 <= max_seq ? p0 : max_seq - 8));
+                }
             }
-        }
+    };
+    // (a policy whose before_scores() has nothing to cover the V tile with -- q_from_qkv_rows: the norms of 1.5 KB -- gets the
+    //  tile requested BEHIND it: its barriers are opaque to the compiler, so requests written in front of them stay there, and
+    //  its first wait -- for the table row, the launch's youngest load -- then waits for the V tile as well)
+    constexpr bool V_LATE = QSrc::LDS && !QSrc::PIN_V;
+    if constexpr (!V_LATE) request_v();
     if constexpr (QSrc::LDS) {
         static_assert(T == 1, "queries computed in the launch: 64-slot ranges");
         // the tile requests stay HERE, in front of the phase that computes the queries (a value used on a never-taken path cannot
@@ -731,8 +856,13 @@ attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const
         uint32_t never;
         asm volatile("s_mov_b32 %0, 0" : "=s"(never));
         if (never) {
+            // (the V tile only where the policy has work of its own in front of the scores that covers it -- QSrc::PIN_V; in front
+            //  of scores that follow at once it makes them wait for twice the bytes: mc_attn_fused_qkn at head_dim 256 21.1 us
+            //  against 12.1 + 5.0 for the two launches it replaces)
+            if constexpr (QSrc::PIN_V) {
 #pragma unroll
-            for (int b = 0; b < NB; b++) asm volatile("" ::"v"(vb[0][b][0].x), "v"(vb[0][b][1].w));
+                for (int b = 0; b < NB; b++) asm volatile("" ::"v"(vb[0][b][0].x), "v"(vb[0][b][1].w));
+            }
 #pragma unroll
             for (int ks = 0; ks < KS; ks++) asm volatile("" ::"v"(kb[0][ks].x));
         }
@@ -750,27 +880,11 @@ attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const
         }
     }
     if constexpr (QSrc::LDS) {
-        // the step's own row: its slot of the K tile and its column of the V tile come from LDS (q_from_hbm's note)
+        // the step's own row: its slot of the K tile comes from LDS (q_from_hbm's note); its column of the V tile in front of P.V
         const uint32_t ws = (uint32_t)st->write_slot;
         if (scorer && p_begin + wave * 16 + col == ws) {
 #pragma unroll
             for (int ks = 0; ks < KS; ks++) kb[0][ks] = *(const __attribute__((address_space(3))) uint4*)(qsrc.k_s + ks * 32 + c * 8);
-        }
-#pragma unroll
-        for (int b = 0; b < NB; b++) {
-            const uint32_t db = wave + NW * b;
-            const uint32_t vnew = (uint32_t)qsrc.v_s[(db < (uint32_t)NDB ? db : 0u) * 16 + col];
-#pragma unroll
-            for (int u = 0; u < 2; u++) {
-                const uint32_t e = ws - (p_begin + u * 32 + c * 8); // element of the lane's eight slots, if < 8
-                uint32_t w4[4] = {vb[0][b][u].x, vb[0][b][u].y, vb[0][b][u].z, vb[0][b][u].w};
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const uint32_t lo = (w4[i] & 0xFFFF0000u) | vnew, hi = (w4[i] & 0x0000FFFFu) | (vnew << 16);
-                    w4[i] = e == 2u * i ? lo : (e == 2u * i + 1u ? hi : w4[i]);
-                }
-                vb[0][b][u] = make_uint4(w4[0], w4[1], w4[2], w4[3]);
-            }
         }
     }
     const uint32_t S = (uint32_t)st->kv_len;
@@ -782,6 +896,9 @@ attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const
         asm volatile("s_mov_b32 %0, 0" : "=s"(never));
         if (never) asm volatile("" ::"v"(S), "v"(tag));
         behind_scores(-1);
+        // (... behind the step state the scores wait for: a wave's loads return in order.  Measured at head_dim 256, the launch:
+        //  in front of before_scores() 20.9 us, right behind it -- in front of the state -- 17.4, behind hand-off A 18.4)
+        if constexpr (V_LATE) request_v();
     }
     const uint32_t nact = (S + PBW - 1) / PBW;
     const bool active = p_begin < S;
@@ -843,6 +960,10 @@ attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const
             // (what crosses this barrier is in LDS: wait for the LDS counter only -- __syncthreads() would also drain the vector-
             //  memory counter, i.e. wait for the tiles just requested)
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        } else if constexpr (QSrc::LDS) {
+            // (as above: behind the policy's global stores -- the cache write, the granules -- __syncthreads() would drain the
+            //  vector-memory counter, i.e. wait for the V tile in front of hand-off A)
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         } else {
             __syncthreads();
         }
@@ -874,10 +995,32 @@ attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const
             if (lane == 0) inv_s[head] = 1.0f / tsum;
         }
         behind_scores(1);
-        if constexpr (T > 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if constexpr (T > 1 || QSrc::LDS) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         else __syncthreads();
         stamp(2);
         const float inv = col < n_rep ? inv_s[col] : 0.0f;
+        if constexpr (QSrc::LDS) {
+            // the step's own column of the V tile from LDS (q_from_hbm's note) -- HERE, in front of the product that reads the tile:
+            // patched in front of the scores it made them wait for the V tile too (mc_attn_fused_qkn at head_dim 256: 21.0 us
+            // against 11.9 + 4.9 for the two launches it replaces)
+            const uint32_t ws = (uint32_t)st->write_slot;
+#pragma unroll
+            for (int b = 0; b < NB; b++) {
+                const uint32_t db = wave + NW * b;
+                const uint32_t vnew = (uint32_t)qsrc.v_s[(db < (uint32_t)NDB ? db : 0u) * 16 + col];
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    const uint32_t e = ws - (p_begin + u * 32 + c * 8); // element of the lane's eight slots, if < 8
+                    uint32_t w4[4] = {vb[0][b][u].x, vb[0][b][u].y, vb[0][b][u].z, vb[0][b][u].w};
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const uint32_t lo = (w4[i] & 0xFFFF0000u) | vnew, hi = (w4[i] & 0x0000FFFFu) | (vnew << 16);
+                        w4[i] = e == 2u * i ? lo : (e == 2u * i + 1u ? hi : w4[i]);
+                    }
+                    vb[0][b][u] = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+                }
+            }
+        }
         // ---- 4. P.V over the range's slots: A = T(e * inv) from LDS (softmax.metal:84-86), B = the V tiles
 #pragma unroll
         for (int t = 0; t < T; t++)
@@ -979,6 +1122,38 @@ attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const
         else if (T == 1 && hd == 32) attn_fused_bf<32, 1, 4>(q, kc, vt, psum_g, slab_g, st, n_rep, n_kv, max_seq, scale, nsplit, layer_tag, tl, store, [](int) {}, fastpath);   \
     }
 MC_ATTN_FUSED(mc_attn_fused_bfloat, 1)   // 64-slot ranges
+// mc_attn_fused_qkn_bfloat: the one-launch attention with gemma3's q_norm / k_norm, rotation and cache write inside (q_from_qkv_rows
+// above) -- mc_rope_kv_bfloat + mc_attn_fused_bfloat in one launch, bit for bit
+template <int HD>
+__device__ __forceinline__ void
+attn_fused_qkn(const bf16_t* qkv, bf16_t* kc, bf16_t* vt, bf16_t* out, unsigned long long* psum_g, unsigned long long* slab_g, step_state* st,
+               uint32_t n_rep, uint32_t n_kv, uint32_t max_seq, float scale, uint32_t nsplit, uint32_t layer_tag, uint32_t fastpath,
+               const bf16_t* q_norm, const bf16_t* k_norm, const float* fcos, const float* fsin, float eps, float mu)
+{
+    __shared__ __attribute__((aligned(16))) bf16_t rows[18 * HD];
+    __shared__ float qred[4];
+    typedef q_from_qkv_rows<HD> qx_t;
+    qx_t qx;
+    qx.q_s = (typename qx_t::lds_row)rows;
+    qx.k_s = (typename qx_t::lds_row)rows + n_rep * HD;
+    qx.v_s = (typename qx_t::lds_row)rows + (n_rep + 1u) * HD;
+    qx.red = qred; qx.qkv = qkv; qx.q_norm = q_norm; qx.k_norm = k_norm; qx.fcos = fcos; qx.fsin = fsin; qx.kc = kc; qx.vt = vt;
+    qx.st = st; qx.n_rep = n_rep; qx.KV = n_kv; qx.max_seq = max_seq; qx.split_slots = PB; qx.eps = eps; qx.mu = mu;
+    qx.at_start();
+    auto store = [&](uint32_t head, uint32_t db, uint32_t col, float v) {
+        if ((threadIdx.x & 63) < 16) out[(size_t)head * HD + db * 16 + col] = f2bf(v);
+    };
+    attn_fused_bf<HD, 1, 4>(nullptr, kc, vt, psum_g, slab_g, st, n_rep, n_kv, max_seq, scale, nsplit, layer_tag, nullptr, store, [](int) {}, fastpath, qx);
+}
+extern "C" __global__ void __launch_bounds__(256)
+mc_attn_fused_qkn_bfloat(const bf16_t* qkv, bf16_t* kc, bf16_t* vt, bf16_t* out, unsigned long long* psum_g, unsigned long long* slab_g,
+                         step_state* st, uint32_t n_rep, uint32_t n_kv, uint32_t hd, uint32_t max_seq, float scale, uint32_t nsplit,
+                         uint32_t layer_tag, uint32_t fastpath, const bf16_t* q_norm, const bf16_t* k_norm, const float* fcos,
+                         const float* fsin, float eps, float mu)
+{
+    if (hd == 256) attn_fused_qkn<256>(qkv, kc, vt, out, psum_g, slab_g, st, n_rep, n_kv, max_seq, scale, nsplit, layer_tag, fastpath, q_norm, k_norm, fcos, fsin, eps, mu);
+    else if (hd == 128) attn_fused_qkn<128>(qkv, kc, vt, out, psum_g, slab_g, st, n_rep, n_kv, max_seq, scale, nsplit, layer_tag, fastpath, q_norm, k_norm, fcos, fsin, eps, mu);
+}
 // (128- and 256-slot ranges -- T = 2, 4: MC_ATTN_FUSED(mc_attn_fused2_bfloat, 2) ... -- were built for S = 8192, passed the kernel-level
 //  oracle test and measured no better than the two-launch form there: 14.8 us per launch with 256-slot ranges (K tile + scores
 //  5.9, hand-off A 2.2, P.V 3.2, hand-off B 1.6), 19.6 with 128-slot ranges at two workgroups per CU, against 6.3 + 8.5 us;

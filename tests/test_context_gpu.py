@@ -255,9 +255,11 @@ def test_gemma_7b_widths_at_the_benchmark_context(acc, taps):
     agree = run_injected(acc, cfg, weights, 2042, 10, dict(weight_format=mc.WFMT_I4, group_size=128), rel_logits=5e-3, max_ulp=3,
                          max_frac=0.7, what=f"gemma-7b widths S=2048 taps={taps}", taps=taps, launched=names)
     assert agree >= 9
-    want = {"mc_gemv_i4_bfloat_lin2_p0_e0", "mc_attn_fused_bfloat", "mc_gemv_i4_bfloat_lin12_p0_e0", "mc_rope_kv_bfloat"}
+    # (round 4: q_norm / k_norm, rope and the cache write ride in the attention launch, mc_attn_fused_qkn_bfloat: no mc_rope_kv launch)
+    want = {"mc_gemv_i4_bfloat_lin2_p0_e0", "mc_attn_fused_qkn_bfloat", "mc_gemv_i4_bfloat_lin12_p0_e0"}
     want |= {"mc_gemv_i4_bfloat_lin3s_p1_e0", "mc_gemv_i4_bfloat_lin3s_p1_e3"} if taps else {"mc_gemv_i4_bfloat_lin3s_p2_e3", "mc_gemv_i4_bfloat_lin3s_p2_e0"}
     assert want <= names, sorted(names)
+    assert "mc_rope_kv_bfloat" not in names and "mc_attn_fused_bfloat" not in names, sorted(names)
 
 
 def test_rows_in_the_cache_do_not_move_across_a_roll(acc):
@@ -362,7 +364,8 @@ def test_one_launch_attention_against_the_two_launch_form(acc, monkeypatch, shap
                 tok = dec.step(tok, n_inject + i)
                 rows.append((tok, dec.logits().copy(), np.stack([dec.hidden(l) for l in range(-1, cfg["n_layers"])])))
         names = set(dec.launched())
-        assert ("mc_attn_fused_bfloat" in names) == (fused == "1"), sorted(names)
+        # (gemma3: the one-launch form carries q_norm / k_norm + rope too, mc_attn_fused_qkn_bfloat)
+        assert ("mc_attn_fused_bfloat" in names or "mc_attn_fused_qkn_bfloat" in names) == (fused == "1"), sorted(names)
         assert ("mc_attn_pv_bfloat" in names) == (fused == "0"), sorted(names)
         out[fused] = rows
         dec.release()
@@ -382,6 +385,51 @@ def test_one_launch_attention_against_the_two_launch_form(acc, monkeypatch, shap
             assert nrm(ha[layer], hb[layer]) <= 6e-3 * layer, f"{shape} step {i} hidden[{layer - 1}], one launch vs two: {nrm(ha[layer], hb[layer]):.3g}"
         assert nrm(la, lb) <= 6e-3 * (ha.shape[0] + 1), f"{shape} step {i} logits, one launch vs two: {nrm(la, lb):.3g}"
     assert same >= len(out["1"]) - 2, (shape, same)
+
+
+@pytest.mark.parametrize("shape", ["gemma-7b", "gemma-hd128-gqa"])
+def test_gemma_norm_and_rope_inside_the_attention_launch_equal_the_two_launches_bit_for_bit(acc, monkeypatch, shape):
+    # mc_attn_fused_qkn_bfloat = mc_rope_kv_bfloat (q_norm / k_norm over whole heads, rotation, cache write: nn/attention.h:170-177) +
+    # mc_attn_fused_bfloat: hidden rows, logits, caches and tokens must be IDENTICAL to the two launches, near an empty cache and
+    # across the end of a full one (the ring turns); sliding and global layers (two rope tables)
+    import metalchat_amd as mc
+
+    base = dict(dtype=BF16, n_layers=2, vocab=2048, norm_eps=1e-5, family=1, rope_theta=10000.0, rope_sliding_theta=10000.0, sliding_stride=2)
+    if shape == "gemma-7b":
+        cfg = dict(base, max_seq_len=2048, dim=3072, n_heads=16, n_kv_heads=16, head_dim=256, ffn_dim=4096, attn_scale=256 ** -0.5)
+    else:  # four query heads per kv head, head_dim 128
+        cfg = dict(base, max_seq_len=2048, dim=2048, n_heads=16, n_kv_heads=4, head_dim=128, ffn_dim=4096, attn_scale=128 ** -0.5)
+    S = cfg["max_seq_len"]
+    out = {}
+    for form, env in (("qkn", {}), ("sep", {"MC_ATTN_QKN": "0"})):
+        monkeypatch.delenv("MC_ATTN_QKN", raising=False)
+        for k_, v_ in env.items():
+            monkeypatch.setenv(k_, v_)
+        dec = mc.Decoder(acc, **mg.decoder_kwargs(cfg, weight_format=mc.WFMT_I4, group_size=128))
+        dec.init_synthetic(SEED)
+        dec.set_taps(True)
+        dec.launch_log(True)
+        rows = []
+        for n_inject in (2, S - 4):
+            for layer in range(cfg["n_layers"]):
+                k, v = random_cache(cfg, n_inject, 700 + layer)
+                dec.import_kv(layer, k, v)
+            tok = 5
+            for i in range(8):
+                tok = dec.step(tok, n_inject + i)
+                rows.append((tok, dec.logits().copy(), np.stack([dec.hidden(l) for l in range(-1, cfg["n_layers"])])))
+        kk, vv = dec.export_kv(cfg["n_layers"] - 1)
+        names = set(dec.launched())
+        assert ("mc_attn_fused_qkn_bfloat" in names) == (form == "qkn"), sorted(names)
+        assert ("mc_rope_kv_bfloat" in names) == (form == "sep"), sorted(names)
+        out[form] = (rows, kk, vv)
+        dec.release()
+    for i, ((ta, la, ha), (tb_, lb, hb)) in enumerate(zip(out["qkn"][0], out["sep"][0])):
+        assert ta == tb_, (shape, i)
+        parity.exact(ha, hb, f"{shape} step {i}: hidden rows, one launch vs rope_kv + attention")
+        parity.exact(la, lb, f"{shape} step {i}: logits")
+    parity.exact(out["qkn"][1], out["sep"][1], f"{shape}: K cache")
+    parity.exact(out["qkn"][2], out["sep"][2], f"{shape}: V cache")
 
 
 @pytest.mark.parametrize("shape", ["llama3-8b", "llama3-8b-1024", "llama3-8b-768", "hd64", "gemma-hd256"])
@@ -439,7 +487,7 @@ def test_attention_and_wo_in_one_launch_equal_the_two_launches_bit_for_bit(acc, 
             took_qkv = form == "qkv" and qkv_kernel is not None
             assert (qkv_kernel in names) == took_qkv, sorted(names)
             assert (kernel in names) == (form != "sep" and not took_qkv), sorted(names)
-            assert ("mc_attn_fused_bfloat" in names) == (form == "sep"), sorted(names)
+            assert ("mc_attn_fused_bfloat" in names or "mc_attn_fused_qkn_bfloat" in names) == (form == "sep"), sorted(names)
             assert any(n.endswith("_p1_e4") or n.endswith("_p2_e0") or n.endswith("_p1_e0") for n in names) == (not took_qkv), sorted(names)
         out[form] = (rows, kk, vv)
         dec.release()

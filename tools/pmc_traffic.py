@@ -26,5 +26,11 @@ for k in sorted(fetch):
     w = (sum(write[k]) / len(write[k]) * 1024.0) if k in write else 0.0
     out[k] = dict(launches=len(fetch[k]), fetch_bytes_per_launch=round(f), write_bytes_per_launch=round(w),
                   hbm_bytes_per_launch=round(f + w))
-print(json.dumps(dict(note="FETCH_SIZE KiB x 1024 x 2 (gfx950 half-count correction) + WRITE_SIZE KiB x 1024",
+import os
+head = None
+try:
+    head = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), ".build_head")).read().strip()
+except OSError:
+    pass
+print(json.dumps(dict(git_head=head, note="FETCH_SIZE KiB x 1024 x 2 (gfx950 half-count correction) + WRITE_SIZE KiB x 1024",
                       kernels=out), indent=1))

@@ -5,6 +5,7 @@
 #      tools/pmc_traffic.py) of the GEMVs (tools/pmc_gemv.py) and of the decode attention (tools/pmc_attn_decode.py)
 #   3. matrix-pipe counters of the decode attention kernels (north_star: MFMA utilisation for the QK^T / PV bmm)
 #   4. kernel durations of the other BASELINE configs (tools/configs_run.py, eager)
+# usage (from the build container): tools/gpu_profile.sh r04 [what]   -- writes .build_head, then runs this through gpurun
 # usage: tools/profile_round.sh r03 [what: all|stats|traffic|mfma|configs]
 set -u
 R=${1:-r03}; WHAT=${2:-all}
@@ -20,22 +21,24 @@ if [ $WHAT = all ] || [ $WHAT = stats ]; then
   stats /tmp/p_trace $OUT/${R}_kernel_stats.csv
 fi
 if [ $WHAT = all ] || [ $WHAT = traffic ]; then
-  for P in gemv attn_decode; do
+  # (the names bench.py's pmc_traffic() and profiles/README expect: rNN_pmc_traffic.json = the GEMVs, rNN_pmc_attn.json = the
+  #  decode attention; pmc_traffic.py stamps the git head it finds in .build_head -- .git does not travel to the GPU box)
+  for P in gemv:traffic attn_decode:attn; do
     for C in FETCH_SIZE WRITE_SIZE; do
-      rm -rf /tmp/p_$C; rocprofv3 --pmc $C --output-format csv -d /tmp/p_$C -- python3 /root/repo/tools/pmc_$P.py > /dev/null 2> /tmp/p_$C.err
+      rm -rf /tmp/p_$C; rocprofv3 --pmc $C --output-format csv -d /tmp/p_$C -- python3 /root/repo/tools/pmc_${P%%:*}.py > /dev/null 2> /tmp/p_$C.err
     done
-    python3 /root/repo/tools/pmc_traffic.py /tmp/p_FETCH_SIZE /tmp/p_WRITE_SIZE > $OUT/${R}_pmc_${P}.json
+    python3 /root/repo/tools/pmc_traffic.py /tmp/p_FETCH_SIZE /tmp/p_WRITE_SIZE > $OUT/${R}_pmc_${P##*:}.json
   done
-  grep -A4 "mc_attn_wo\|mc_attn_fused\|lin2_p1_e2" $OUT/${R}_pmc_*.json | head -40
+  grep -A4 "mc_attn_qkv_wo\|mc_attn_wo\|mc_attn_fused\|lin2_p1_e2" $OUT/${R}_pmc_*.json | head -40
 fi
 if [ $WHAT = all ] || [ $WHAT = mfma ]; then
   : > $OUT/${R}_pmc_attn_mfma.log
   # the three forms of the decode attention: one launch with Wo (default), one launch (MC_ATTN_WO=0), scores + P.V (MC_ATTN_FUSED=0)
-  for F in "MC_ATTN_WO=1" "MC_ATTN_WO=0" "MC_ATTN_FUSED=0"; do
+  for F in "MC_ATTN_QKV=1" "MC_ATTN_QKV=0" "MC_ATTN_WO=0" "MC_ATTN_FUSED=0"; do
     for G in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_MFMA" "SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY" "GRBM_GUI_ACTIVE"; do
-      rm -rf /tmp/pq; export $F; rocprofv3 --pmc $G --output-format csv -d /tmp/pq -- python3 /root/repo/tools/pmc_attn_decode.py > /dev/null 2> /tmp/pq.err; unset MC_ATTN_WO MC_ATTN_FUSED
+      rm -rf /tmp/pq; export $F; rocprofv3 --pmc $G --output-format csv -d /tmp/pq -- python3 /root/repo/tools/pmc_attn_decode.py > /dev/null 2> /tmp/pq.err; unset MC_ATTN_WO MC_ATTN_FUSED MC_ATTN_QKV
       echo "== $F  $G" >> $OUT/${R}_pmc_attn_mfma.log
-      for K in mc_attn_wo_i4_bfloat mc_attn_fused_bfloat mc_attn_scores_bfloat mc_attn_pv_bfloat; do python3 /root/repo/tools/pmc_summary.py /tmp/pq $K 2>/dev/null | tail -6 >> $OUT/${R}_pmc_attn_mfma.log; done
+      for K in mc_attn_qkv_wo_i4_bfloat mc_attn_wo_i4_bfloat mc_attn_fused_bfloat mc_attn_scores_bfloat mc_attn_pv_bfloat; do python3 /root/repo/tools/pmc_summary.py /tmp/pq $K 2>/dev/null | tail -6 >> $OUT/${R}_pmc_attn_mfma.log; done
     done
   done
   cat $OUT/${R}_pmc_attn_mfma.log
