@@ -1365,17 +1365,30 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
         // 1160 (rmsnorm) instructions in front of the first multiply of a launch that lasts 5 - 16 us: its 1.3 - 1.7 us
         // from wave start to "row staged" were instruction issue, not memory latency (an idle memory system delivers
         // the row in 0.56 us, tools/floor_lab).  The row is requested FIRST, before the wave even works out its range.
-        constexpr bool LEAN = LWAVES > 0 && PRO != PRO_POSTNORM && !LSPLIT; // (split rows: the generic staging, then the copy)
+        // (round 4: the post-norm prologue -- gemma3's `_p2_` -- and the split rows too; on the generic staging Gemma-7B's
+        //  wq|wk|wv GEMV lasted 12.7 us for 3.1 us of stream)
+        constexpr bool LEAN = LWAVES > 0;
         static_assert(PRO != PRO_PARTS || LEAN, "PRO_PARTS needs the build-time prologue");
-        constexpr uint32_t NPK = 256u * LNCH, BD = LWAVES ? 64u * LWAVES : 64u;
+        // 16-byte packets of the activation row (split rows: K = 3072, the row is staged twice); threads
+        constexpr uint32_t NPK = LSPLIT ? 384u : 256u * LNCH, BD = LWAVES ? 64u * LWAVES : 64u;
         constexpr int NXP = LEAN ? (int)((NPK + BD - 1) / BD) : 1;
         constexpr bool RAGGED = NPK % BD != 0; // the last packet of a thread may not exist (lin7: 3.5 per thread, lin1: 0.5)
         // (native vectors, not HIP's uint4 struct: a struct that is only copied global -> register -> LDS is recognised as a
         //  memcpy, and with several packets per thread hipcc routed two of them through a PRIVATE-memory temporary: scratch
         //  stores behind a vmcnt wait in the first instructions of the w2 kernel)
         typedef uint32_t rowv4 __attribute__((ext_vector_type(4)));
-        rowv4 lxr[NXP], lnr[PRO == PRO_RMSNORM ? NXP : 1];
+        rowv4 lxr[NXP], lnr[(PRO == PRO_RMSNORM || PRO == PRO_POSTNORM) ? NXP : 1];
+        rowv4 lpw[PRO == PRO_POSTNORM ? NXP : 1], lrr[PRO == PRO_POSTNORM ? NXP : 1]; // post-norm weight, residual
         float4 lpr[PRO == PRO_PARTS ? NXP : 1][PRO == PRO_PARTS ? 2 * PARTS_R : 1];
+        // PRO_POSTNORM: the descriptor behind `res` (post-norm weight, residual row, h_out) with SCALAR loads, once, in front of
+        // everything (one dependent scalar round trip; pointers found in memory are generic: cast to the global address space, or a
+        // read through them is a flat_load, which counts on both wait counters).  No select between two sources of a pointer: a
+        // load whose address comes out of a branch costs every counted s_waitcnt vmcnt(N) of the kernel (measured: the build
+        // that took the pointers from the adaptor's argument slots OR the descriptor waited vmcnt(0) after every request --
+        // lin3s_p2_e3 24.4 us against 20.7)
+        postnorm_args lpn = {};
+        if constexpr (PRO == PRO_POSTNORM) lpn = *static_cast<const postnorm_args*>(resp);
+        typedef const __attribute__((address_space(1))) rowv4* g_rowv4;
         uint32_t lin_never;
         asm volatile("s_mov_b32 %0, 0" : "=s"(lin_never));
         if constexpr (LEAN) {
@@ -1396,7 +1409,11 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
                 } else {
                     lxr[i] = reinterpret_cast<const rowv4*>(xg)[pc];
                 }
-                if (PRO == PRO_RMSNORM) lnr[i] = reinterpret_cast<const rowv4*>(ng)[pc];
+                if (PRO == PRO_RMSNORM || PRO == PRO_POSTNORM) lnr[i] = reinterpret_cast<const rowv4*>(ng)[pc];
+                if constexpr (PRO == PRO_POSTNORM) {
+                    lpw[i] = ((g_rowv4)lpn.post_w)[pc];
+                    lrr[i] = ((g_rowv4)lpn.res)[pc];
+                }
             }
             if (lin_never) asm volatile("" ::"v"(PRO == PRO_PARTS ? __float_as_uint(lpr[0][0].x) : lxr[0].x)); // ends the basic block: the requests stay in front of what follows
         }
@@ -1511,7 +1528,7 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
         if constexpr (LEAN) {
             uint4* xl = reinterpret_cast<uint4*>(xs);
             rowv4 (&xr)[NXP] = lxr;
-            rowv4 (&nr)[PRO == PRO_RMSNORM ? NXP : 1] = lnr;
+            rowv4 (&nr)[(PRO == PRO_RMSNORM || PRO == PRO_POSTNORM) ? NXP : 1] = lnr;
             rowv4* xlv = reinterpret_cast<rowv4*>(xs);
             asm volatile("s_barrier" ::: "memory"); // (the row's requests stay ahead of the weight requests: stage_x)
             lin_prefetch();
@@ -1529,11 +1546,12 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
                     xr[i] = rowv4{pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]), pack_bf16x2(a[4], a[5]), pack_bf16x2(a[6], a[7])};
                 }
             }
-            if (PRO == PRO_RMSNORM) {
+            // sum of squares of the thread's packets / the normalised packet: stage_x's arithmetic, addition for addition
+            auto sumsq_l = [&](const rowv4 (&v)[NXP]) {
                 float ss = 0.0f;
 #pragma unroll
                 for (int i = 0; i < NXP; i++) {
-                    const uint32_t vv[4] = {xr[i].x, xr[i].y, xr[i].z, xr[i].w};
+                    const uint32_t vv[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
                     float s1 = 0.0f;
 #pragma unroll
                     for (int e = 0; e < 4; e++) {
@@ -1543,7 +1561,58 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
                     }
                     ss += live(i) ? s1 : 0.0f; // same per-packet, per-thread order of additions as stage_x
                 }
-                const float wsum_ = wave_sum_dpp(ss);
+                return ss;
+            };
+            auto normalise_l = [&](const rowv4& v, const rowv4& w, float inv) {
+                const uint32_t vv[4] = {v.x, v.y, v.z, v.w}, ww[4] = {w.x, w.y, w.z, w.w};
+                uint32_t o[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const float a = (mu + asf(ww[e] << 16)) * asf(vv[e] << 16) * inv;
+                    const float b = (mu + asf(ww[e] & 0xFFFF0000u)) * asf(vv[e] & 0xFFFF0000u) * inv;
+                    o[e] = pack_bf16x2(a, b);
+                }
+                return rowv4{o[0], o[1], o[2], o[3]};
+            };
+            // the staged row; split rows keep it twice, [x, x] (LSPLIT above), written here instead of copied behind a barrier
+            auto put = [&](int i, const rowv4& v) {
+                if (!live(i)) return;
+                xlv[xpk(tid + i * BD)] = v;
+                if constexpr (LSPLIT != 0) xlv[xpk(NPK + tid + i * BD)] = v;
+            };
+            if constexpr (PRO == PRO_POSTNORM) {
+                // h = T(res + T((mu + post_w) x rsqrt(mean(x^2) + eps))), left in HBM by workgroup 0; the row = this linear's own
+                // pre-norm of h (stage_x's PRO_POSTNORM branch: the same two sums, the same roundings)
+                const float w1 = wave_sum_dpp(sumsq_l(xr));
+                if (lane == 0) red[wave] = w1;
+                __syncthreads();
+                float tot = 0.0f;
+#pragma unroll
+                for (uint32_t i = 0; i < (uint32_t)LWAVES; i++) tot += red[i];
+                const float inv1 = 1.0f / sqrtf(tot / (float)in + eps);
+                rowv4 h[NXP];
+#pragma unroll
+                for (int i = 0; i < NXP; i++) {
+                    const rowv4 y = normalise_l(xr[i], lpw[i], inv1);
+                    const uint32_t aa[4] = {lrr[i].x, lrr[i].y, lrr[i].z, lrr[i].w}, bb[4] = {y.x, y.y, y.z, y.w};
+                    uint32_t o[4];
+#pragma unroll
+                    for (int e = 0; e < 4; e++)
+                        o[e] = pack_bf16x2(asf(aa[e] << 16) + asf(bb[e] << 16), asf(aa[e] & 0xFFFF0000u) + asf(bb[e] & 0xFFFF0000u));
+                    h[i] = live(i) ? rowv4{o[0], o[1], o[2], o[3]} : rowv4{0, 0, 0, 0};
+                    if (blockIdx.x == 0 && live(i)) ((__attribute__((address_space(1))) rowv4*)lpn.h_out)[tid + i * BD] = h[i];
+                }
+                const float w2 = wave_sum_dpp(sumsq_l(h));
+                if (lane == 0) red[16 + wave] = w2; // the second half of the scratch: no barrier between the two sums' readers and writers
+                __syncthreads();
+                float tot2 = 0.0f;
+#pragma unroll
+                for (uint32_t i = 0; i < (uint32_t)LWAVES; i++) tot2 += red[16 + i];
+                const float inv2 = 1.0f / sqrtf(tot2 / (float)in + eps);
+#pragma unroll
+                for (int i = 0; i < NXP; i++) put(i, normalise_l(h[i], nr[i], inv2));
+            } else if (PRO == PRO_RMSNORM) {
+                const float wsum_ = wave_sum_dpp(sumsq_l(xr));
                 if (lane == 0) red[wave] = wsum_;
                 __syncthreads();
                 float tot = 0.0f;
@@ -1551,28 +1620,16 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
                 for (uint32_t i = 0; i < (uint32_t)LWAVES; i++) tot += red[i];
                 const float inv = 1.0f / sqrtf(tot / (float)in + eps);
 #pragma unroll
-                for (int i = 0; i < NXP; i++) {
-                    const uint32_t vv[4] = {xr[i].x, xr[i].y, xr[i].z, xr[i].w};
-                    const uint32_t ww[4] = {nr[i].x, nr[i].y, nr[i].z, nr[i].w};
-                    uint32_t o[4];
-#pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        const float a = (mu + asf(ww[e] << 16)) * asf(vv[e] << 16) * inv;
-                        const float b = (mu + asf(ww[e] & 0xFFFF0000u)) * asf(vv[e] & 0xFFFF0000u) * inv;
-                        o[e] = pack_bf16x2(a, b);
-                    }
-                    if (live(i)) xlv[xpk(tid + i * BD)] = rowv4{o[0], o[1], o[2], o[3]};
-                }
+                for (int i = 0; i < NXP; i++) put(i, normalise_l(xr[i], nr[i], inv));
             } else {
 #pragma unroll
-                for (int i = 0; i < NXP; i++)
-                    if (live(i)) xlv[xpk(tid + i * BD)] = xr[i];
+                for (int i = 0; i < NXP; i++) put(i, xr[i]);
             }
         } else {
             stage_x(lin_prefetch);
         }
         __syncthreads();
-        if constexpr (LSPLIT != 0) {
+        if constexpr (LSPLIT != 0 && !LEAN) {
             // the row a second time, behind itself: [x, x] (16-byte packets; packet p sits in slot p + p / 16)
             rowv4* xl2 = reinterpret_cast<rowv4*>(xs);
             const uint32_t npk = in / 8;
