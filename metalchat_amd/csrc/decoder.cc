@@ -1082,6 +1082,23 @@ struct mc_decoder {
     }
 
     // Y[M, L.out] = T(X[M, L.in] Wd^T) (+ res): the fused matrices of the decode GEMV, same HBM layout
+    // K splits the big prompt GEMM takes for this matrix at M rows (gemm() below), and the row tile
+    unsigned
+    gemm_row_tile(int M) const
+    {
+        const char* depth_env = getenv("MC_PF_DEPTH");
+        return tb == 2 && M >= 256 && !(depth_env && atoi(depth_env) == 1) && !getenv("MC_PF_BM128") ? 256u : 128u;
+    }
+    unsigned
+    gemm_splits(const linear_w& L, int M) const
+    {
+        const unsigned bm = gemm_row_tile(M);
+        const unsigned tiles = ((L.out + 127) / 128) * ((M + bm - 1) / bm);
+        const unsigned want = (bm == 256 ? 1u : 2u) * (unsigned)dev->prop.multiProcessorCount; // (256 rows: one 8-wave workgroup per CU)
+        unsigned splits = 1;
+        while (splits < 16 && tiles * splits < want && (unsigned)L.in / (splits * 2) >= 512) splits *= 2;
+        return getenv("MC_PF_NO_SPLITK") ? 1u : splits;
+    }
     mc_status
     gemm(const linear_w& L, int epi, const void* X, void* Y, const void* res, int M)
     {
@@ -1107,14 +1124,15 @@ struct mc_decoder {
         // MC_PF_DEPTH=1 selects the one-chunk build for A/B runs
         const char* depth_env = getenv("MC_PF_DEPTH");
         const std::string deep = depth_env && atoi(depth_env) == 1 ? "" : "_d2";
+        // 256 rows of X per workgroup from 256 rows on (prefill_kernels.hip pf_gemm_big_body, BM): the W tile is dequantised once
+        // per workgroup, and at 128 rows that vector work is ~ 0.8 of the matrix pipe's time
+        const unsigned bm = big ? gemm_row_tile(M) : 128u;
+        const std::string gname = bm == 256 ? "mc_pf_gemm256_" : "mc_pf_gemm128_";
         if (big) {
             // A 128 x 128 tile walks K serially (~1.5 us per 64-wide chunk), so a grid that does not
             // oversubscribe the CUs several times is latency-bound: split K until it does.
-            const unsigned tiles = ((L.out + 127) / 128) * ((M + 127) / 128);
-            const unsigned want = 2u * (unsigned)dev->prop.multiProcessorCount;
-            unsigned splits = 1;
-            while (splits < 16 && tiles * splits < want && (unsigned)L.in / (splits * 2) >= 512) splits *= 2;
-            if (splits > 1 && !getenv("MC_PF_NO_SPLITK")) {
+            const unsigned splits = gemm_splits(L, M);
+            if (splits > 1) {
                 const size_t need = (size_t)splits * M * L.out;
                 if (need > pf_part_elems) {
                     MC_HIP(hipStreamSynchronize(stream));
@@ -1123,8 +1141,8 @@ struct mc_decoder {
                     if (s != MC_OK) return s;
                     pf_part_elems = need;
                 }
-                mc_status s = launch("mc_pf_gemm128_" + f + tname + deep + "_e2", (L.out + 127) / 128, (M + 127) / 128, splits,
-                                     256, 0,
+                mc_status s = launch(gname + f + tname + deep + "_e2", (L.out + 127) / 128, (M + bm - 1) / bm, splits,
+                                     2 * bm, 0,
                                      pack(L.w, L.scales, X, (void*)pf_part, (const void*)nullptr, (uint32_t)M,
                                           (uint32_t)L.out, (uint32_t)L.in, (uint32_t)L.group, (const void*)nullptr,
                                           (const void*)nullptr, (uint32_t)0, 0.0f));
@@ -1135,9 +1153,9 @@ struct mc_decoder {
                                    L.lora_scale));
             }
         }
-        const std::string name = (big ? "mc_pf_gemm128_" : "mc_pf_gemm_") + f + tname + (big ? deep : "") + "_e" + std::to_string(epi);
-        const unsigned tile = big ? 128 : 64;
-        return launch(name, (L.out + tile - 1) / tile, (M + tile - 1) / tile, 1, 256, 0,
+        const std::string name = (big ? gname : "mc_pf_gemm_") + f + tname + (big ? deep : "") + "_e" + std::to_string(epi);
+        const unsigned tile = big ? 128 : 64, tile_m = big ? bm : 64;
+        return launch(name, (L.out + tile - 1) / tile, (M + tile_m - 1) / tile_m, 1, big ? 2 * bm : 256, 0,
                       pack(L.w, L.scales, X, Y, res, (uint32_t)M, (uint32_t)L.out, (uint32_t)L.in, (uint32_t)L.group,
                            la, (const void*)L.lora_b, (uint32_t)L.lora_cols, L.lora_scale));
     }
@@ -1225,6 +1243,9 @@ struct mc_decoder {
             if (s != MC_OK) return s;
             s = timed("norm", [&] { return norm_rows(pf_h, L.ffn_norm, nullptr, pf_xn, M, mu); });
             if (s != MC_OK) return s;
+            // (act(w1 x) * (w3 x) in the GEMM's epilogue was built -- the even lane of a column pair finishing it -- and measured
+            //  SLOWER: 13.60 against 13.26 ms per 512-row prompt, 52.0 against 50.6 at 2048 rows: half the lanes idle through the
+            //  fp64 exponential, in the kernel that holds the matrix pipe)
             s = timed("gemm_w13", [&] { return gemm(L.w13, 0, pf_xn, pf_g2, nullptr, M); });
             if (s != MC_OK) return s;
             const unsigned act_pp = 8u / (unsigned)tb; // pairs per thread (one 16-byte packet)

@@ -16,6 +16,8 @@
 //   mc_pf_pv_T                 probs . V on MFMA
 #include "common.h"
 
+#include <type_traits>
+
 using namespace mc;
 
 typedef __bf16 pf_bf16x8 __attribute__((ext_vector_type(8)));
@@ -430,20 +432,44 @@ pf_tile_of(uint32_t& nt, uint32_t& mt)
     }
 }
 
-template <int WF, int EPI, int DEPTH>
+// byte k of a dword -> float in one full-rate instruction (gemv.h ubyte_f32: hipcc builds v_bfe_u32 + v_cvt_f32_u32 otherwise)
+template <int K_>
+__device__ __forceinline__ float
+pf_ubyte_f32(uint32_t v)
+{
+    float d;
+    if (K_ == 0) asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(d) : "v"(v));
+    if (K_ == 1) asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(d) : "v"(v));
+    if (K_ == 2) asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(d) : "v"(v));
+    if (K_ == 3) asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(d) : "v"(v));
+    return d;
+}
+
+// BM = rows of X per workgroup: 128 (4 waves) or 256 (8 waves, round 4).  A W tile is dequantised ONCE per workgroup, so what
+// the exact dequantisation costs per MFMA falls with BM: ~2.75 vector instructions per weight (conversion, fma, half a pack)
+// against BM / 512 of a 16-cycle MFMA -- at 128 rows the vector work is ~ 0.8 of the matrix pipe's time and the two share
+// the issue port; at 256 rows 0.4.  With 256 rows every thread stages a 16-run of a W row instead of a 32-run.
+template <int WF, int EPI, int DEPTH, int BM = 128>
 __device__ __forceinline__ void
 pf_gemm_big_body(const void* __restrict__ wp, const void* __restrict__ sp, const bf16_t* __restrict__ X,
                  bf16_t* __restrict__ Y, const bf16_t* __restrict__ res, uint32_t M, uint32_t N, uint32_t K,
                  uint32_t group, const bf16_t* __restrict__ la, const bf16_t* __restrict__ lb, uint32_t lora_rank,
                  float lora_scale)
 {
-    __shared__ __attribute__((aligned(16))) bf16_t Xs[PFB_M * PFB_LD];
-    __shared__ __attribute__((aligned(16))) bf16_t Ws[PFB_N * PFB_LD];
+    static_assert(BM == 128 || BM == 256, "2 BM threads: 4 or 8 waves of 64 x 64 outputs");
+    constexpr uint32_t WRUN = BM == 128 ? 32 : 16, WQ = WRUN / 8; // weights a thread stages per chunk; 16-byte packets of bf16 that makes
+    // Two LDS images per operand where two chunks are in flight (DEPTH == 2: the unrolled step `slot` owns image `slot`): the
+    // chunk that is being staged and the chunk the MFMAs read are different images, so ONE barrier per chunk is enough -- a wave
+    // that writes image p for chunk k + 2 has passed the barrier of chunk k + 1, which every wave reaches only behind its reads
+    // of image p for chunk k (round 4; with one image the loop was write - barrier - read - barrier: 742 TFLOP/s on w1|w3)
+    constexpr int NIMG = DEPTH == 2 ? 2 : 1;
+    __shared__ __attribute__((aligned(16))) bf16_t Xs_[NIMG][BM * PFB_LD];
+    __shared__ __attribute__((aligned(16))) bf16_t Ws_[NIMG][PFB_N * PFB_LD];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t wm = wave >> 1, wn = wave & 1;
     uint32_t tile_n, tile_m;
     pf_tile_of(tile_n, tile_m);
-    const uint32_t n0 = tile_n * PFB_N, m0 = tile_m * PFB_M;
+    const uint32_t n0 = tile_n * PFB_N, m0 = tile_m * BM;
     const uint32_t ngroups = group ? K / group : 1;
     const uint32_t glog = group ? 31u - __builtin_clz(group) : 31u;
     const size_t rowb = WF == PF_W_I4 ? K / 2 : (WF == PF_W_I8 ? K : (size_t)K * 2);
@@ -452,9 +478,10 @@ pf_gemm_big_body(const void* __restrict__ wp, const void* __restrict__ sp, const
     const uint32_t kper = EPI == 2 ? ((K / PFB_K + gridDim.z - 1) / gridDim.z) * PFB_K : K;
     const uint32_t kbeg = EPI == 2 ? blockIdx.z * kper : 0;
     const uint32_t kend = EPI == 2 ? min(K, kbeg + kper) : K;
-    const uint32_t srow = tid >> 1, skk = (tid & 1) * 32; // staging: row, first k of the 32-run
+    const uint32_t srow = tid >> 1, skk = (tid & 1) * 32; // staging of X: row, first k of the 32-run
+    const uint32_t wsrow = BM == 128 ? tid >> 1 : tid >> 2, wkk = BM == 128 ? (tid & 1) * 32 : (tid & 3) * 16; // ... of W
     const uint32_t xr = m0 + srow < M ? m0 + srow : M - 1;
-    const uint32_t wr = n0 + srow < N ? n0 + srow : N - 1;
+    const uint32_t wr = n0 + wsrow < N ? n0 + wsrow : N - 1;
 
     pf_f32x4 acc[4][4];
 #pragma unroll
@@ -478,27 +505,33 @@ pf_gemm_big_body(const void* __restrict__ wp, const void* __restrict__ sp, const
         const uint4* src = reinterpret_cast<const uint4*>(X + (size_t)xr * K + kc);
 #pragma unroll
         for (int i = 0; i < 4; i++) xvs[slot][i] = src[i];
+        const uint32_t wabs = k0 + wkk;
+        const uint32_t wc = wabs < K ? wabs : K - 32 + (wkk & 16u); // (a run past the end: any valid run -- its X packets are zeroed)
         if (WF == PF_W_T) {
-            const uint4* ws = reinterpret_cast<const uint4*>(static_cast<const bf16_t*>(wp) + (size_t)wr * K + kc);
+            const uint4* ws = reinterpret_cast<const uint4*>(static_cast<const bf16_t*>(wp) + (size_t)wr * K + wc);
 #pragma unroll
-            for (int i = 0; i < 4; i++) wraws[slot][i] = ws[i];
+            for (uint32_t i = 0; i < WQ; i++) wraws[slot][i] = ws[i];
         } else {
-            s_nexts[slot] = pf_scale<WF, BF>(sp, wr, group ? kc >> glog : 0, ngroups);
+            s_nexts[slot] = pf_scale<WF, BF>(sp, wr, group ? wc >> glog : 0, ngroups);
             if (WF == PF_W_I4) {
-                wraws[slot][0] = *reinterpret_cast<const uint4*>(static_cast<const char*>(wp) + (size_t)wr * rowb + kc / 2);
+                if (WRUN == 32) {
+                    wraws[slot][0] = *reinterpret_cast<const uint4*>(static_cast<const char*>(wp) + (size_t)wr * rowb + wc / 2);
+                } else {
+                    const uint2 v = *reinterpret_cast<const uint2*>(static_cast<const char*>(wp) + (size_t)wr * rowb + wc / 2);
+                    wraws[slot][0] = make_uint4(v.x, v.y, 0u, 0u);
+                }
             } else {
-                const uint4* ws = reinterpret_cast<const uint4*>(static_cast<const int8_t*>(wp) + (size_t)wr * rowb + kc);
+                const uint4* ws = reinterpret_cast<const uint4*>(static_cast<const int8_t*>(wp) + (size_t)wr * rowb + wc);
                 wraws[slot][0] = ws[0];
-                wraws[slot][1] = ws[1];
+                if (WRUN == 32) wraws[slot][1] = ws[1];
             }
         }
     };
 #pragma unroll
     for (int d = 0; d < DEPTH; d++) fetch(d, kbeg + d * PFB_K);
-    for (uint32_t kg0 = kbeg; kg0 < kend; kg0 += DEPTH * PFB_K) {
-#pragma unroll
-      for (int slot = 0; slot < DEPTH; slot++) {
-        const uint32_t k0 = kg0 + slot * PFB_K;
+    // one chunk out of the registers of `slot` into the LDS image of `slot`: dequantise, store
+    auto stage = [&](auto slot_c, uint32_t k0) {
+        constexpr int slot = decltype(slot_c)::value;
         uint4 (&xv)[4] = xvs[slot];
         uint4 (&wraw)[4] = wraws[slot];
         const float s_next = s_nexts[slot];
@@ -509,7 +542,7 @@ pf_gemm_big_body(const void* __restrict__ wp, const void* __restrict__ sp, const
         uint4 wo[4];
         if (WF == PF_W_T) {
 #pragma unroll
-            for (int i = 0; i < 4; i++) wo[i] = wraw[i];
+            for (uint32_t i = 0; i < WQ; i++) wo[i] = wraw[i];
         } else {
             const float s = bf2f(f2bf(s_next));
             uint32_t o[16];
@@ -517,17 +550,18 @@ pf_gemm_big_body(const void* __restrict__ wp, const void* __restrict__ sp, const
                 const uint32_t v[4] = {wraw[0].x, wraw[0].y, wraw[0].z, wraw[0].w};
                 const float c8 = -8.0f * s;
 #pragma unroll
-                for (int d = 0; d < 4; d++)
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        // pair j of a dword = weights (2j, 2j+1) = nibbles (j, j+4); (n - 8) * s is exact in fp32
-                        const float a = __builtin_fmaf((float)((v[d] >> (4 * j)) & 0xFu), s, c8);
-                        const float b = __builtin_fmaf((float)((v[d] >> (4 * j + 16)) & 0xFu), s, c8);
-                        o[4 * d + j] = pack_bf16x2(a, b);
-                    }
+                for (uint32_t d = 0; d < WRUN / 8; d++) {
+                    // pair j of a dword = weights (2j, 2j + 1) = nibbles (j, j + 4); byte b of lo / hi = nibble 2b / 2b + 1;
+                    // (n - 8) * s is exact in fp32 (gemv.h mac4: one conversion, one fma per weight)
+                    const uint32_t lo = v[d] & 0x0F0F0F0Fu, hi = (v[d] >> 4) & 0x0F0F0F0Fu;
+                    o[4 * d + 0] = pack_bf16x2(__builtin_fmaf(pf_ubyte_f32<0>(lo), s, c8), __builtin_fmaf(pf_ubyte_f32<2>(lo), s, c8));
+                    o[4 * d + 1] = pack_bf16x2(__builtin_fmaf(pf_ubyte_f32<0>(hi), s, c8), __builtin_fmaf(pf_ubyte_f32<2>(hi), s, c8));
+                    o[4 * d + 2] = pack_bf16x2(__builtin_fmaf(pf_ubyte_f32<1>(lo), s, c8), __builtin_fmaf(pf_ubyte_f32<3>(lo), s, c8));
+                    o[4 * d + 3] = pack_bf16x2(__builtin_fmaf(pf_ubyte_f32<1>(hi), s, c8), __builtin_fmaf(pf_ubyte_f32<3>(hi), s, c8));
+                }
             } else {
 #pragma unroll
-                for (int h = 0; h < 2; h++) {
+                for (uint32_t h = 0; h < WRUN / 16; h++) {
                     const uint32_t v[4] = {wraw[h].x, wraw[h].y, wraw[h].z, wraw[h].w};
 #pragma unroll
                     for (int d = 0; d < 4; d++) {
@@ -539,20 +573,24 @@ pf_gemm_big_body(const void* __restrict__ wp, const void* __restrict__ sp, const
                 }
             }
 #pragma unroll
-            for (int i = 0; i < 4; i++) wo[i] = make_uint4(o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]);
+            for (uint32_t i = 0; i < WQ; i++) wo[i] = make_uint4(o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]);
         }
-        __syncthreads(); // previous chunk's MFMA reads are done
+        bf16_t* Xs = Xs_[NIMG == 2 ? slot : 0];
+        bf16_t* Ws = Ws_[NIMG == 2 ? slot : 0];
         {
             uint4* xd = reinterpret_cast<uint4*>(Xs + srow * PFB_LD + skk);
-            uint4* wd = reinterpret_cast<uint4*>(Ws + srow * PFB_LD + skk);
+            uint4* wd = reinterpret_cast<uint4*>(Ws + wsrow * PFB_LD + wkk);
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                xd[i] = xv[i];
-                wd[i] = wo[i];
-            }
+            for (int i = 0; i < 4; i++) xd[i] = xv[i];
+#pragma unroll
+            for (uint32_t i = 0; i < WQ; i++) wd[i] = wo[i];
         }
-        __syncthreads();
-        fetch(slot, k0 + DEPTH * PFB_K);
+    };
+    // the 32 MFMAs of a wave on the image of `slot`
+    auto multiply = [&](auto slot_c) {
+        constexpr int slot = decltype(slot_c)::value;
+        const bf16_t* Xs = Xs_[NIMG == 2 ? slot : 0];
+        const bf16_t* Ws = Ws_[NIMG == 2 ? slot : 0];
         const uint32_t kg = (lane >> 4) * 8, l15 = lane & 15;
 #pragma unroll
         for (uint32_t ks = 0; ks < PFB_K; ks += 32) {
@@ -570,7 +608,29 @@ pf_gemm_big_body(const void* __restrict__ wp, const void* __restrict__ sp, const
                                                                          __builtin_bit_cast(pf_bf16x8, b[nt]),
                                                                          acc[mt][nt], 0, 0, 0);
         }
-      }
+    };
+    if constexpr (NIMG == 2) {
+        // (the software-pipelined order -- multiply chunk k out of image p while chunk k + 1 is dequantised into image p ^ 1, one
+        //  barrier per chunk -- was built too: 13.24 ms against 13.25 per 512-row prompt at 256 rows per workgroup, 14.1 against
+        //  13.3 at 128: hipcc runs the two streams one behind the other either way; the plain order is kept)
+        for (uint32_t k0 = kbeg; k0 < kend; k0 += 2 * PFB_K) {
+            stage(std::integral_constant<int, 0>{}, k0);
+            __syncthreads();
+            fetch(0, k0 + 2 * PFB_K);
+            multiply(std::integral_constant<int, 0>{});
+            stage(std::integral_constant<int, 1>{}, k0 + PFB_K);
+            __syncthreads();
+            fetch(1, k0 + 3 * PFB_K);
+            multiply(std::integral_constant<int, 1>{});
+        }
+    } else {
+        for (uint32_t k0 = kbeg; k0 < kend; k0 += PFB_K) {
+            __syncthreads(); // previous chunk's MFMA reads are done
+            stage(std::integral_constant<int, 0>{}, k0);
+            __syncthreads();
+            fetch(0, k0 + PFB_K);
+            multiply(std::integral_constant<int, 0>{});
+        }
     }
 #pragma unroll
     for (int mt = 0; mt < 4; mt++)
@@ -613,6 +673,24 @@ MC_PF_GEMM_BIG(mc_pf_gemm128_w_bfloat_e2, PF_W_T, 2)
 // two chunks in flight per workgroup (204 VGPRs, two workgroups per CU): the default -- faster than one
 // chunk (144 VGPRs, three per CU) at every prompt length, 6.3 vs 6.9 ms at 128 rows, 14.5 vs 16.2 at
 // 512, 54.0 vs 55.5 at 2048; three chunks (220 VGPRs) lose again: 7.0 / 15.7 / 56.7 ms
+// 256 rows of X per workgroup (eight waves): mc_pf_gemm256_* -- prompts of 256 rows and more (decoder.cc gemm())
+#define MC_PF_GEMM_256(NAME, WF, EPI)                                                                   \
+    extern "C" __global__ void __launch_bounds__(512)                                                   \
+    NAME(const void* w, const void* scales, const bf16_t* X, bf16_t* Y, const bf16_t* res, uint32_t M,  \
+         uint32_t N, uint32_t K, uint32_t group, const bf16_t* la, const bf16_t* lb, uint32_t lora_rank, \
+         float lora_scale)                                                                              \
+    {                                                                                                   \
+        pf_gemm_big_body<WF, EPI, 2, 256>(w, scales, X, Y, res, M, N, K, group, la, lb, lora_rank, lora_scale); \
+    }
+MC_PF_GEMM_256(mc_pf_gemm256_i4_bfloat_d2_e0, PF_W_I4, 0)
+MC_PF_GEMM_256(mc_pf_gemm256_i4_bfloat_d2_e1, PF_W_I4, 1)
+MC_PF_GEMM_256(mc_pf_gemm256_i4_bfloat_d2_e2, PF_W_I4, 2)
+MC_PF_GEMM_256(mc_pf_gemm256_i8_bfloat_d2_e0, PF_W_I8, 0)
+MC_PF_GEMM_256(mc_pf_gemm256_i8_bfloat_d2_e1, PF_W_I8, 1)
+MC_PF_GEMM_256(mc_pf_gemm256_i8_bfloat_d2_e2, PF_W_I8, 2)
+MC_PF_GEMM_256(mc_pf_gemm256_w_bfloat_d2_e0, PF_W_T, 0)
+MC_PF_GEMM_256(mc_pf_gemm256_w_bfloat_d2_e1, PF_W_T, 1)
+MC_PF_GEMM_256(mc_pf_gemm256_w_bfloat_d2_e2, PF_W_T, 2)
 MC_PF_GEMM_BIG_D(mc_pf_gemm128_i4_bfloat_d2_e0, PF_W_I4, 0, 2)
 MC_PF_GEMM_BIG_D(mc_pf_gemm128_i4_bfloat_d2_e1, PF_W_I4, 1, 2)
 MC_PF_GEMM_BIG_D(mc_pf_gemm128_i4_bfloat_d2_e2, PF_W_I4, 2, 2)

@@ -348,8 +348,11 @@ def test_int8_long_context_against_the_oracle_at_full_width(acc, monkeypatch):
     gk, gv = dec.export_kv(0)
     ok, ov = om.kv(0)
     assert gk.shape == ok.shape == (n, 8, 128)
-    # K / V rows of the first block depend on their own row only: a handful of last-bit differences
-    parity.check(BF16, gk, ok, rel=1e-3, max_ulp=1, max_frac=0.02, what="int8 prompt K")
+    # K / V rows of the first block depend on their own row only: a handful of last-bit differences.  K is a composition -- the
+    # GEMM's T(row sum), then the rotation c x1 - s x2 in fp32 -- so one step in x1 can reach the output as two where the two
+    # products cancel (seen once, 1.12 of one step at the rms, with the 256-row tile's two K splits in place of four): the
+    # suite's composition bound, two steps; V is the GEMM's output as it stands: one
+    parity.check(BF16, gk, ok, rel=1e-3, max_ulp=2, max_frac=0.02, what="int8 prompt K")
     parity.check(BF16, gv, ov, rel=1e-3, max_ulp=1, max_frac=0.02, what="int8 prompt V")
     tok, agree = otok, int(gtok == otok)
     for i in range(4):
