@@ -380,8 +380,11 @@ attn_wo_body(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const 
 #endif
     auto request_wo = [&](int point) {
         const bool poller = wave < n_rep; // (attn_fused_bf: head = wave, wave + NW, ... gathers the denominators of hand-off A)
-        if (QN != 0 && MC_QKV_WO_REQ_EARLY) {
+        if (QN != 0 && MC_QKV_WO_REQ_EARLY == 1) {
             if (point != -1) return;
+        } else if (QN != 0 && MC_QKV_WO_REQ_EARLY == 2) {
+            // the waves that compute no scores ask in front of them (they are idle there), the others behind hand-off A
+            if (point != (poller ? 1 : -1)) return;
         } else if (point == -1 || (MC_WO_REQ_SPLIT ? (point == 0) == poller : point != 0)) return;
         // (every load unconditional: one load behind a branch and hipcc waits vmcnt(0) wherever it waits afterwards -- the scores
         //  would wait for these weights.  A pair the wave does not have reads one broadcast line: masks, not selects)

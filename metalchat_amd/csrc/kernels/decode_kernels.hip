@@ -879,9 +879,11 @@ attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const
             else qa[ks] = *reinterpret_cast<const uint4*>(q + (size_t)(kv * n_rep + qh) * HD + ks * 32 + c * 8);
         }
     }
+    uint32_t ws = 0; // (QSrc::LDS) the step's slot: read ONCE, here -- a second read in front of P.V is a vector load behind whatever
+                     //  was requested in between (mc_attn_qkv_wo_*: the Wo weights -- P.V 1.2 us instead of 0.5)
     if constexpr (QSrc::LDS) {
         // the step's own row: its slot of the K tile comes from LDS (q_from_hbm's note); its column of the V tile in front of P.V
-        const uint32_t ws = (uint32_t)st->write_slot;
+        ws = (uint32_t)st->write_slot;
         if (scorer && p_begin + wave * 16 + col == ws) {
 #pragma unroll
             for (int ks = 0; ks < KS; ks++) kb[0][ks] = *(const __attribute__((address_space(3))) uint4*)(qsrc.k_s + ks * 32 + c * 8);
@@ -1003,7 +1005,6 @@ attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const
             // the step's own column of the V tile from LDS (q_from_hbm's note) -- HERE, in front of the product that reads the tile:
             // patched in front of the scores it made them wait for the V tile too (mc_attn_fused_qkn at head_dim 256: 21.0 us
             // against 11.9 + 4.9 for the two launches it replaces)
-            const uint32_t ws = (uint32_t)st->write_slot;
 #pragma unroll
             for (int b = 0; b < NB; b++) {
                 const uint32_t db = wave + NW * b;
