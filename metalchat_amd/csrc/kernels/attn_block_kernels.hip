@@ -433,6 +433,23 @@ attn_wo_body(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const 
         if (tl && threadIdx.x == 0) tl[(size_t)blockIdx.x * TL_STRIDE + TL_BASE + i] = __builtin_amdgcn_s_memrealtime();
     };
 
+    // ---- while the attention row is on its way: everything of the wave's FIRST Wo pair that does not need it -- the dequantisation
+    // (gemv.h m4b_dequant: ~ 60 % of the pair's instructions).  The weights were requested two hand-offs ago; the wait of hand-off C
+    // (~ 2.5 us) covers this.  64 registers; a second pair (contexts of 1024 slots) is dequantised behind the hand-off as before.
+#ifndef MC_WO_PREDEQUANT
+#define MC_WO_PREDEQUANT 1
+#endif
+    const m4b_lane m4bk = m4b_lane_consts(lane);
+    uint2 dq[2][LNCH][8];
+    if (MC_WO_PREDEQUANT && pb < pe) { // (wave-uniform)
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+#pragma unroll
+            for (int c = 0; c < LNCH; c++) {
+                const uint32_t raw = ws[0][c];
+                m4b_dequant(dq[r][c], ww[0][r][c], m4b_prepare(r ? (raw & 0xFFFF0000u) : (raw << 16), m4bk));
+            }
+    }
     // ---- hand-off C: the whole attention row (K bf16 = K / 2 granules) into LDS, padded as the transposed reads want it
     {
         constexpr int NG = (int)(K / 2 / 512); // granules per thread
@@ -467,7 +484,6 @@ attn_wo_body(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const 
 
     // ---- Wo: mc_gemv_i4_bfloat_lin{LNCH}_p0_e{0,1} for the wave's pairs
     const uint32_t lane_tr = (((lane >> 4) * 4 + (lane & 3)) * 17 + ((lane >> 2) & 3) * 4) * 16;
-    const m4b_lane m4bk = m4b_lane_consts(lane);
     typedef __attribute__((address_space(3))) mf_s4 lds_s4;
 #pragma unroll
     for (int i = 0; i < PMAX; i++) {
@@ -483,7 +499,8 @@ attn_wo_body(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const 
 #pragma unroll
                 for (int e = 0; e < 8; e++) x[e] = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16(xt + e));
                 const uint32_t raw = ws[i][c];
-                mac4b_n<1>(acc, ww[i][r][c], m4b_prepare(r ? (raw & 0xFFFF0000u) : (raw << 16), m4bk), x);
+                if (MC_WO_PREDEQUANT && i == 0) m4b_dot(acc[0], dq[r][c], x);
+                else mac4b_n<1>(acc, ww[i][r][c], m4b_prepare(r ? (raw & 0xFFFF0000u) : (raw << 16), m4bk), x);
             }
             const uint32_t e = lane & 3;
             const float mine = e == 0 ? acc[0][0] : (e == 1 ? acc[0][1] : (e == 2 ? acc[0][2] : acc[0][3]));

@@ -393,6 +393,34 @@ mac4b_n(mf_f4 (&acc)[NA], const uint4& w, const m4d_scale& sc, const uint2 (&x)[
     }
 }
 
+// mac4b_n<1> in two halves, for a caller that has the weights long before it has the activations (mc_attn_wo_*: the Wo pair waits
+// through hand-off C): m4b_dequant is everything that does not need x -- the bit operations, the dequantising MFMAs, the
+// reference's rounding -- m4b_dot the accumulating MFMAs, in mac4b_n<1>'s order (dword by dword, its two halves one after the
+// other into ONE accumulator): together bit for bit mac4b_n<1>.
+__device__ __forceinline__ void
+m4b_dequant(uint2 (&a)[8], const uint4& w, const m4d_scale& sc)
+{
+    const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
+    const mf_s4 bs = __builtin_bit_cast(mf_s4, sc.b);
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        const uint32_t v = ws[d];
+        const uint32_t t0 = v & 0x00FF00FFu, t1 = v & 0x00F000F0u;
+        const uint32_t t2 = __builtin_amdgcn_perm(v, 0u, 0x0C070C05u), t3 = t2 & 0x00F000F0u;
+        const mf_f4 d1 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(mf_s4, make_uint2(t0, t1)), bs, sc.c, 0, 0, 0);
+        const mf_f4 d2 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(mf_s4, make_uint2(t2, t3)), bs, sc.c, 0, 0, 0);
+        a[2 * d] = make_uint2(pack_bf16x2(d1[0], d1[1]), pack_bf16x2(d1[2], d1[3]));
+        a[2 * d + 1] = make_uint2(pack_bf16x2(d2[0], d2[1]), pack_bf16x2(d2[2], d2[3]));
+    }
+}
+__device__ __forceinline__ void
+m4b_dot(mf_f4& acc, const uint2 (&a)[8], const uint2 (&x)[8])
+{
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+        acc = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(mf_s4, a[i]), __builtin_bit_cast(mf_s4, x[i]), acc, 0, 0, 0);
+}
+
 // int8-held weights the same way (linear-order kernels, LGEN): a byte XOR 0x80 is q + 128, offset binary, and goes into the
 // dequantising MFMA whole -- (v ^ 0x80808080) & 0x00FF00FF are bytes 0 and 2, one v_perm_b32 moves bytes 1 and 3 down --
 // against B = s I and C = -128 s: three bit operations, one MFMA and two conversions per FOUR weights where the VALU path
