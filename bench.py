@@ -517,8 +517,9 @@ def main():
             per_kind[which] = {"kernel": dec.gemv_kernel_name(which), "avg_launch_us": pk * 1e3, "bytes_per_launch": byk / lnk,
                                "frac": byk / lnk / (pk * 1e-3) / 1e9 / HBM_PEAK_GBS}
         attn_kernel = dec.gemv_kernel_name("attn")
-        if attn_kernel.startswith("mc_attn_wo_"):
-            per_kind["wo"]["note"] = f"stand-alone launch, timed for reference: in the token this GEMV runs inside {attn_kernel}"
+        inside = ("qkv", "wo") if attn_kernel.startswith("mc_attn_qkv_wo_") else ("wo",) if attn_kernel.startswith("mc_attn_wo_") else ()
+        for which in inside:
+            per_kind[which]["note"] = f"stand-alone launch, timed for reference: in the token this GEMV runs inside {attn_kernel}"
         kname = dec.gemv_kernel_name("w13")  # the name decoder.cc gemv() selects, asked of the decoder itself
         out["roofline"] = {
             "bound": "hbm", "kernel": f"{kname} (w1|w3 fused, per launch)", "achieved": achieved,

@@ -599,6 +599,16 @@ struct mc_decoder {
                (unsigned)(nsplit * cfg.n_kv_heads) <= (unsigned)dev->prop.multiProcessorCount;
     }
 
+    // The XCD-local fast path of hand-offs A / B / Q (handoff.h) pays where the workgroups of one kv head CAN share an XCD: they
+    // are the blocks b with equal b % n_kv, blocks with equal b % 8 share an XCD, so n_kv must be a multiple of 8.  With
+    // TinyLlama's 4 kv heads half of every head's ranges sit on another XCD and are found only by the occasional look at the
+    // fabric copy: mc_attn_fused_bfloat 24.1 us against 7.0 without the fast path (profiles/r04_kernel_stats_tinyllama_fastpath_regression.csv)
+    bool
+    handoff_fast_here() const
+    {
+        return handoff_fast && cfg.n_kv_heads % 8 == 0;
+    }
+
     // ... with wq|wk|wv in the same launch too (attn_block_kernels.hip qkv_in_launch): the built shape, the kv head's
     // (n_rep + 2) hd / 2 row pairs dealt evenly over its nsplit workgroups, at most two per wave
     bool
@@ -629,7 +639,7 @@ struct mc_decoder {
     report_handoff(uint32_t code)
     {
         handoff_failed();
-        char buf[256];
+        char buf[384];
         snprintf(buf, sizeof buf, "decoder: an in-launch hand-off of the decode attention timed out (code 0x%08x): the workgroups of the "
                                   "launch were not resident together.  What was computed since is invalid; the decoder now uses the "
                                   "launches that need no co-residency -- repeat the call", code);
@@ -834,7 +844,7 @@ struct mc_decoder {
                                 (const void*)L.wo.w, (const void*)L.wo.scales, x, hidden, (uint32_t)L.wo.out, (uint32_t)L.wo.group,
                                 (const void*)L.attention_norm, (const void*)L.qkv.w, (const void*)L.qkv.scales,
                                 (const float*)rope_cos[L.rope_table], (const float*)rope_sin[L.rope_table], cfg.norm_eps, mu,
-                                (uint32_t)(handoff_fast ? 1 : 0), (void*)nullptr));
+                                (uint32_t)(handoff_fast_here() ? 1 : 0), (void*)nullptr));
                 if (s != MC_OK) return s;
             } else if (!gemma) {
                 // attention_norm + wq|wk|wv + rope + cache write in ONE launch
@@ -873,7 +883,7 @@ struct mc_decoder {
                            pack(q_rot, L.kc, L.vt, attn_out, attn_psum_g, attn_slab_g, attn_row_g, state, (uint32_t)n_rep, (uint32_t)KV,
                                 (uint32_t)cfg.max_seq_len, scale_T, (uint32_t)nsplit, (uint32_t)(li + 1), (const void*)L.wo.w,
                                 (const void*)L.wo.scales, gemma ? (const void*)nullptr : x, gemma ? proj : hidden, (uint32_t)L.wo.out,
-                                (uint32_t)L.wo.group, (uint32_t)(gemma ? 0 : 1), (uint32_t)(handoff_fast ? 1 : 0), (void*)nullptr));
+                                (uint32_t)L.wo.group, (uint32_t)(gemma ? 0 : 1), (uint32_t)(handoff_fast_here() ? 1 : 0), (void*)nullptr));
                 if (s != MC_OK) return s;
                 if (gemma && !fuse_pn) {
                     s = launch("mc_rmsnorm_row_" + tname, 1, 1, 1, 1024, 0,
@@ -886,13 +896,13 @@ struct mc_decoder {
                     s = launch("mc_attn_fused_qkn_" + tname, (unsigned)(nsplit * KV), 1, 1, 256, 0,
                                pack((const void*)qkv, L.kc, L.vt, attn_out, attn_psum_g, attn_slab_g, state, (uint32_t)n_rep, (uint32_t)KV,
                                     (uint32_t)hd, (uint32_t)cfg.max_seq_len, scale_T, (uint32_t)nsplit, (uint32_t)(li + 1),
-                                    (uint32_t)(handoff_fast ? 1 : 0), (const void*)L.q_norm, (const void*)L.k_norm,
+                                    (uint32_t)(handoff_fast_here() ? 1 : 0), (const void*)L.q_norm, (const void*)L.k_norm,
                                     (const float*)rope_cos[L.rope_table], (const float*)rope_sin[L.rope_table], cfg.norm_eps, mu));
                 else
                 s = launch("mc_attn_fused_" + tname, (unsigned)(nsplit * KV), 1, 1, 256, 0,
                            pack(q_rot, L.kc, L.vt, attn_out, attn_psum_g, attn_slab_g, state, (uint32_t)n_rep, (uint32_t)KV, (uint32_t)hd,
                                 (uint32_t)cfg.max_seq_len, scale_T, (uint32_t)nsplit, (uint32_t)(li + 1), (void*)nullptr,
-                                (uint32_t)(handoff_fast ? 1 : 0)));
+                                (uint32_t)(handoff_fast_here() ? 1 : 0)));
                 if (s != MC_OK) return s;
                 s = gemma ? gemv(L.wo, 0, 0, attn_out, proj, nullptr, nullptr, mu) : gemv(L.wo, 0, 1, attn_out, hidden, x, nullptr, mu);
                 if (s != MC_OK) return s;
@@ -2192,7 +2202,10 @@ mc_decoder_gemv_kernel_name(mc_decoder* d, const char* which, char* buf, size_t 
         if (s0 != MC_OK) return s0;
         if (d->layers.empty()) return fail(MC_ERR_INVALID_ARGUMENT, "mc_decoder_gemv_kernel_name: this stage owns no block");
         const linear_w& wo = d->layers[0].wo;
-        name = d->attn_wo_fused(wo) ? "mc_attn_wo_i4_" + d->tname + "_hd" + std::to_string(d->cfg.head_dim) + "_k" + std::to_string(wo.in / 2048)
+        d->query_occupancy();
+        name = d->attn_qkv_wo_fused(d->layers[0]) ? "mc_attn_qkv_wo_i4_" + d->tname + "_hd" + std::to_string(d->cfg.head_dim) + "_k" + std::to_string(wo.in / 2048) +
+                                                         "_q" + std::to_string(d->layers[0].qkv.in / 2048)
+               : d->attn_wo_fused(wo) ? "mc_attn_wo_i4_" + d->tname + "_hd" + std::to_string(d->cfg.head_dim) + "_k" + std::to_string(wo.in / 2048)
                : d->attn_fused()    ? "mc_attn_fused_" + d->tname
                                     : "mc_attn_scores_" + d->tname + " + mc_attn_pv_" + d->tname;
         const size_t n0 = std::min(cap - 1, name.size());
