@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <unordered_map>
 #include <algorithm>
 #include <memory>
 
@@ -173,6 +174,7 @@ struct mc_decoder {
     void* hidden_in = nullptr;  // T[dim]   inbound row for non-first stages
     void* hidden_b = nullptr;   // T[dim]   gemma3: the row between the attention and the ffn half of a block
     const void* pending_pn = nullptr; // gemma3: postnorm_args the next pre-norm GEMV has to apply to `proj`
+    std::unordered_map<const void*, postnorm_args_h> pn_host; // the same descriptors on the host (the linear-order kernels take the three pointers as arguments)
     void* qkv = nullptr;        // T[(H+2KV)*hd]
     void* q_rot = nullptr;      // T[H*hd]
     void* attn_out = nullptr;   // T[H*hd]
@@ -704,7 +706,9 @@ struct mc_decoder {
         const bool m4d = m4d_ok && (gemv_m4 >= 3 || (gemv_m4 == 2 && shared_simd));
         // linear-order main loop (gemv.h): rows of whole KiB (K a multiple of 2048: 1, 2, 4, 7 or 14 KiB), whole row groups
         const int nch = L.in % 2048 == 0 ? L.in / 2048 : 0;
-        const bool lin = lin_ok(L);
+        // (an adapted linear behind a post-norm: the linear-order `_p2_` kernels take the post-norm's pointers in the adaptor's
+        //  argument slots, gemv.h -- the classic kernels serve that combination)
+        const bool lin = lin_ok(L) && !(pro == 2 && L.lora_cols);
         const int pe_code = pro * 10 + epi;
         const bool lins = !lin && lin_split_ok(L) &&
                           (pe_code == 0 || pe_code == 10 || pe_code == 1 || pe_code == 12 || pe_code == 13 || pe_code == 14 || pe_code == 20 || pe_code == 23);
@@ -778,6 +782,14 @@ struct mc_decoder {
             // so a pre-norm GEMV and its adaptor see the identical normalised row)
             mc_status s = gemv(*L.lora_a, pro, 0, x, L.lora_vec, pro == 2 ? res : nullptr, norm_w, mu);
             if (s != MC_OK) return s;
+        }
+        if (pro == 2 && (lin || lins)) {
+            const auto it = pn_host.find(res);
+            if (it == pn_host.end()) return fail(MC_ERR_RUNTIME, "gemv: unknown post-norm descriptor");
+            const postnorm_args_h& h = it->second;
+            return launch(name, wgs, 1, 1, block, lds,
+                          pack(L.w, L.scales, x, y, (const void*)h.res, norm_w, (uint32_t)L.out, (uint32_t)L.in, (uint32_t)L.group,
+                               cfg.norm_eps, mu, (const void*)h.post_w, (const void*)h.h_out, (uint32_t)0, 0.0f));
         }
         return launch(name, wgs, 1, 1, block, lds,
                       pack(L.w, L.scales, x, y, res, norm_w, (uint32_t)L.out, (uint32_t)L.in,
@@ -1812,6 +1824,8 @@ check_ready(mc_decoder* d)
             const postnorm_args_h f{L.ffn_post_norm, d->hidden_b, d->hidden};
             MC_HIP(hipMemcpy(L.pn_attn, &a, sizeof a, hipMemcpyHostToDevice));
             MC_HIP(hipMemcpy(L.pn_ffn, &f, sizeof f, hipMemcpyHostToDevice));
+            d->pn_host[L.pn_attn] = a;
+            d->pn_host[L.pn_ffn] = f;
         }
         d->pn_ready = true;
     }

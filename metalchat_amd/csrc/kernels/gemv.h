@@ -51,6 +51,8 @@ constexpr int PARTS_R = 4;
 //   h = T(res + T((mu + post_w) * x * rsqrt(mean(x^2) + eps)))
 //   row in LDS = T((mu + norm_w) * h * rsqrt(mean(h^2) + eps))
 // `res` of the kernel carries a postnorm_args* (the epilogues e0 / e3 do not use it).
+// a barrier for hand-overs through LDS alone: no wait for the vector memory counter (see the post-norm prologue below)
+static __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 struct postnorm_args {
     const void* post_w; // T[in]
     const void* res;    // T[in]
@@ -1414,8 +1416,15 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
         // load whose address comes out of a branch costs every counted s_waitcnt vmcnt(N) of the kernel (measured: the build
         // that took the pointers from the adaptor's argument slots OR the descriptor waited vmcnt(0) after every request --
         // lin3s_p2_e3 24.4 us against 20.7)
+        // The build-time prologue (LEAN) does not even read a descriptor: the three pointers arrive as kernel arguments of
+        // their own -- `res` = the residual row, the adaptor slots = post-norm weight and h_out (the host gives an adapted
+        // linear behind a post-norm the classic kernels) -- one dependent round trip to HBM less in front of the row
+        // (lin3s_p2_e0 10.5 us against lin3s_p1_e0's 7.4 in the same token, r04_kernel_stats_gemma.csv).
         postnorm_args lpn = {};
-        if constexpr (PRO == PRO_POSTNORM) lpn = *static_cast<const postnorm_args*>(resp);
+        if constexpr (PRO == PRO_POSTNORM) {
+            if constexpr (LWAVES > 0) lpn = postnorm_args{lora_ap, resp, const_cast<void*>(lora_bp)};
+            else lpn = *static_cast<const postnorm_args*>(resp);
+        }
         typedef const __attribute__((address_space(1))) rowv4* g_rowv4;
         uint32_t lin_never;
         asm volatile("s_mov_b32 %0, 0" : "=s"(lin_never));
@@ -1632,7 +1641,9 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
                 }
                 const float w2 = wave_sum_dpp(sumsq_l(h));
                 if (lane == 0) red[16 + wave] = w2; // the second half of the scratch: no barrier between the two sums' readers and writers
-                __syncthreads();
+                // (an LDS-only barrier: __syncthreads() behind workgroup 0's store of h waits vmcnt(0) -- for the store and, the
+                //  counter being in order, for every ring tile requested in front of it; nobody in this launch reads h_out)
+                lds_barrier();
                 float tot2 = 0.0f;
 #pragma unroll
                 for (uint32_t i = 0; i < (uint32_t)LWAVES; i++) tot2 += red[16 + i];
@@ -1656,7 +1667,8 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
         } else {
             stage_x(lin_prefetch);
         }
-        __syncthreads();
+        if constexpr (LEAN && PRO == PRO_POSTNORM) lds_barrier(); // (as above: not behind workgroup 0's store)
+        else __syncthreads();
         if constexpr (LSPLIT != 0 && !LEAN) {
             // the row a second time, behind itself: [x, x] (16-byte packets; packet p sits in slot p + p / 16)
             rowv4* xl2 = reinterpret_cast<rowv4*>(xs);

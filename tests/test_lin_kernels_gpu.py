@@ -62,7 +62,7 @@ def lds_bytes(family, K, classic=False):
 
 
 def launch(acc, name, wptr, sptr, x, y_elems, rows, K, group, res=None, norm=None, wgs=1, block=64 * WAVES, lds=0, mu=0.0,
-           y_dtype=np.uint16):
+           y_dtype=np.uint16, slot_a=None, slot_b=None):
     import metalchat_amd as mc
 
     k = acc.load(name)
@@ -73,7 +73,7 @@ def launch(acc, name, wptr, sptr, x, y_elems, rows, K, group, res=None, norm=Non
     nb = norm if (norm is None or hasattr(norm, "device_ptr")) else acc.to_device(norm)
     t = mc.KernelTask(k, (wgs * block, 1, 1), (block, 1, 1),
                       [acc.wrap(wptr, 1 << 40), (acc.wrap(sptr, 1 << 40) if sptr else None), xb, yb, rb, nb, np.uint32(rows),
-                       np.uint32(K), np.uint32(group), np.float32(1e-5), np.float32(mu), None, None, np.uint32(0), np.float32(0)],
+                       np.uint32(K), np.uint32(group), np.float32(1e-5), np.float32(mu), slot_a, slot_b, np.uint32(0), np.float32(0)],
                       lds_bytes=lds)
     t()
     acc.wait()
@@ -402,8 +402,10 @@ def test_gemma_post_norm_prologue(acc, models, family):
     wptr, sptr, rows, inf, ng = dec.weight_ptrs(0, "w13")
     pwb, rsb = acc.to_device(post_w), acc.to_device(res)
     hb = acc.alloc(K * 2)
-    desc = acc.to_device(np.frombuffer(struct.pack("<QQQ", pwb.device_ptr, rsb.device_ptr, hb.device_ptr), np.uint8))
-    got = launch(acc, kname(family, 2, 0), wptr, sptr, x, rows, rows, K, grp(family), res=desc, norm=nw, wgs=5, lds=lds_bytes(family, K), mu=mu)
+    # (the linear-order `_p2_` kernels take the three pointers as arguments: `res` = the residual row, the adaptor slots = the
+    #  post-norm weight and h_out -- gemv.h; decoder.cc gemv() passes them the same way)
+    pn = dict(res=rsb, slot_a=pwb, slot_b=hb)
+    got = launch(acc, kname(family, 2, 0), wptr, sptr, x, rows, rows, K, grp(family), norm=nw, wgs=5, lds=lds_bytes(family, K), mu=mu, **pn)
     parity.exact(hb.download(np.uint16, K), h.reshape(-1), f"{family} p2 hidden row")  # (the first norm is exact: dyadic row)
     ref_rows = np.stack([g1.reshape(-1), g3.reshape(-1)], 1).reshape(-1)
     # the second sum of squares is an ordinary one (another order than the oracle's): composition bound
@@ -412,5 +414,7 @@ def test_gemma_post_norm_prologue(acc, models, family):
     mo.gelu(BF16, L(g1.shape), a, L(g1.shape), g1)
     ref = np.zeros_like(g1)
     mo.hadamard(BF16, L(g1.shape), ref, L(g1.shape), a, L(g1.shape), g3)
-    got = launch(acc, kname(family, 2, 3), wptr, sptr, x, rows // 2, rows, K, grp(family), res=desc, norm=nw, wgs=5, lds=lds_bytes(family, K), mu=mu)
+    hb.upload(np.zeros(K, np.uint16))
+    got = launch(acc, kname(family, 2, 3), wptr, sptr, x, rows // 2, rows, K, grp(family), norm=nw, wgs=5, lds=lds_bytes(family, K), mu=mu, **pn)
+    parity.exact(hb.download(np.uint16, K), h.reshape(-1), f"{family} p2_e3 hidden row")
     parity.check(BF16, got, ref.reshape(-1), rel=3e-3, max_ulp=2, max_frac=0.3, what=f"{family} p2_e3")
