@@ -65,8 +65,9 @@ struct postnorm_args_h {
 
 // mirrors sampler_params (kernels/sampler_kernels.hip)
 struct sampler_params_h {
-    uint32_t k, ncand, ncand_pad;
+    uint32_t k, ncand, cap;
     float inv_temp, top_p;
+    uint32_t nlists, kpad;
 };
 
 // mirrors mc::gemv::qkv_epilogue (kernels/gemv.h)
@@ -293,7 +294,6 @@ struct mc_decoder {
     bool gemv_block_env = false; // MC_GEMV_BLOCK / MC_GEMV_WGS_PER_CU given: they apply to every kernel of the family
     bool gemv_full_grid = false; // MC_GEMV_FULLGRID=1: as many workgroups as CUs allow even when that leaves waves without a row group (kernels built with MC_GEMV_WAVEMAJOR)
     int dbg_variant = 0; // MC_GEMV_DBG=1 stream-only, 2 compute-only (tuning ablations)
-    int sampler_block = 1024; // MC_SAMPLER_BLOCK
     int pv_block = 1024;   // MC_PV_BLOCK: threads of a P.V workgroup (16 waves: one round of loads per wave at S = 2048)
     int gemv_m4 = 2;       // MC_GEMV_M4: 0 = exact int4 on the VALU (v_dot2c), 1 = dot products on the 4x4x4 MFMA, 2 = dequantisation too where a SIMD holds > 1 wave, 3 = always
     bool gemma_fuse = true; // MC_GEMMA_UNFUSED=1: keep the post-norms as launches of their own
@@ -1048,20 +1048,26 @@ struct mc_decoder {
             return launch("mc_argmax_" + tname, 1, 1, 1, 1024, 0,
                           pack(logits, (uint32_t)cfg.vocab, state, tokens_dev));
         // make_default_sampler: per-chunk candidates, then one workgroup finishes the chain
-        const uint32_t chunks = ((uint32_t)cfg.vocab + 2047u) / 2048u;
         uint32_t kpad = 1;
         while (kpad < (uint32_t)top_k) kpad *= 2;
         const uint32_t k = (uint32_t)std::min(top_k, cfg.vocab);
-        // 1024 threads: the bitonic networks (66 stages over a 2048-key chunk, 78 over the <= 4096
-        // candidates) are barrier-paced, so every stage should be one compare-exchange per thread
-        s = launch("mc_topk_candidates_" + tname, chunks, 1, 1, sampler_block, 0,
-                   pack(logits, (uint32_t)cfg.vocab, kpad, cand));
+        // chunks of 512 logits (1024 / 2048 where that would be more than 1024 lists), each sorted by ONE wave in registers; the
+        // second launch finds the k best of the sorted lists without sorting them all (sampler_kernels.hip)
+        const uint32_t chunk = sampler_chunk((uint32_t)cfg.vocab, kpad), lists = ((uint32_t)cfg.vocab + chunk - 1) / chunk;
+        if (lists > 1024u) return fail(MC_ERR_RUNTIME, "sampler: the fused sampler handles rows of up to 2048 * 1024 logits");
+        s = launch("mc_topk_candidates_" + tname, lists, 1, 1, 64, 0, pack(logits, (uint32_t)cfg.vocab, kpad, cand, chunk));
         if (s != MC_OK) return s;
-        sampler_params_h p{k, chunks * kpad, 1, inv_temp_T, top_p_T};
-        while (p.ncand_pad < p.ncand) p.ncand_pad *= 2;
-        return launch("mc_sample_" + tname, 1, 1, 1, sampler_block, p.ncand_pad * 8,
+        const sampler_params_h p{k, lists * kpad, 4096u, inv_temp_T, top_p_T, lists, kpad};
+        return launch("mc_sample_" + tname, 1, 1, 1, 128, p.cap * 8,
                       pack(cand, p, seeds, (uint32_t)n_seed_pairs, state, tokens_dev,
                            want_taps ? sampler_taps : (float*)nullptr));
+    }
+    static uint32_t
+    sampler_chunk(uint32_t vocab, uint32_t kpad)
+    {
+        uint32_t chunk = std::max(512u, kpad);
+        while (chunk < 2048u && (vocab + chunk - 1) / chunk > 1024u) chunk *= 2;
+        return chunk;
     }
 
     // ---------------------------------------------------------------- prompt pass
@@ -1380,8 +1386,6 @@ mc_decoder_create(mc_device* dev, mc_library* lib, mc_queue* q, const mc_decoder
     if (const char* e = getenv("MC_GEMMA_UNFUSED")) d->gemma_fuse = atoi(e) == 0;
     if (const char* e = getenv("MC_GEMV_M4")) d->gemv_m4 = atoi(e);
     if (const char* e = getenv("MC_PV_BLOCK")) d->pv_block = atoi(e);
-    if (const char* e = getenv("MC_SAMPLER_BLOCK")) d->sampler_block = atoi(e);
-    if (d->sampler_block % 64 || d->sampler_block < 256 || d->sampler_block > 1024) d->sampler_block = 1024;
     if (d->pv_block % 64 || d->pv_block < 256 || d->pv_block > 1024) d->pv_block = 1024;
     if (d->gemv_block % 64 || d->gemv_block < 64 || d->gemv_block > 1024) d->gemv_block = 256;
     if (d->gemv_wgs_per_cu < 1) d->gemv_wgs_per_cu = 2;
@@ -1506,7 +1510,7 @@ mc_decoder_set_sampler(mc_decoder* d, int32_t kind, int32_t top_k, float tempera
         if (!d->last_stage) return fail(MC_ERR_INVALID_ARGUMENT, "decoder: only the last stage samples");
         MC_HIP(hipSetDevice(d->dev->ordinal));
         d->drop_graph();
-        const uint32_t chunks = ((uint32_t)d->cfg.vocab + 2047u) / 2048u;
+        const uint32_t chunks = ((uint32_t)d->cfg.vocab + 511u) / 512u; // (the most lists any top_k makes: sampler_chunk)
         if (!d->cand) {
             mc_status s = d->alloc((void**)&d->cand, (size_t)chunks * 128 * 8);
             if (s != MC_OK) return s;

@@ -355,38 +355,128 @@ lds_sort_desc(uint64_t* keys, uint32_t n)
     __syncthreads();
 }
 
-constexpr uint32_t MC_TOPK_CHUNK = 2048;
+// The same network on ONE wave with the slots in registers (round 4): slot e = lane * KPL + r.  A stage whose partner distance j
+// is below KPL exchanges two registers of a lane; the others exchange with lane ^ (j / KPL) through the cross-lane unit -- no LDS
+// round trip and no barrier per stage.  n (a power of two, 2 .. 64 KPL) is the size of the network: lanes past n / KPL sort
+// padding among themselves.  exch(x, o, first): what a slot holds after its compare-exchange with `o`, `first` = the slot is
+// the one that receives what sorts FIRST in this stage's direction (lds_sort_desc / kernel/sort.metal: slot i < ij with `up`,
+// or slot ij without).
+template <typename E>
+__device__ __forceinline__ E
+wave_xor(const E& v, uint32_t lx)
+{
+    if constexpr (sizeof(E) == 4) {
+        return __builtin_bit_cast(E, __shfl_xor(__builtin_bit_cast(int, v), (int)lx, 64));
+    } else {
+        static_assert(sizeof(E) == 8, "one or two dwords");
+        const uint2 u = __builtin_bit_cast(uint2, v);
+        return __builtin_bit_cast(E, make_uint2((uint32_t)__shfl_xor((int)u.x, (int)lx, 64), (uint32_t)__shfl_xor((int)u.y, (int)lx, 64)));
+    }
+}
+template <int KPL, typename E, typename Exch>
+__device__ __forceinline__ void
+wave_bitonic(E (&x)[KPL], uint32_t lane, uint32_t n, Exch exch)
+{
+    for (uint32_t k = 2; k <= n; k *= 2)
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            if (j < (uint32_t)KPL) {
+#pragma unroll
+                for (int jj = KPL / 2; jj >= 1; jj >>= 1) {
+                    if (j != (uint32_t)jj) continue;
+#pragma unroll
+                    for (int r = 0; r < KPL; r++) {
+                        if (r & jj) continue;
+                        const bool up = ((lane * KPL + r) & k) == 0;
+                        const E a = x[r], b = x[r | jj];
+                        x[r] = exch(a, b, up);
+                        x[r | jj] = exch(b, a, !up);
+                    }
+                }
+            } else {
+                const uint32_t lx = j / KPL;
+                const bool lower = (lane & lx) == 0;
+                E o[KPL]; // (every exchange of the stage in flight before the first is looked at)
+#pragma unroll
+                for (int r = 0; r < KPL; r++) o[r] = wave_xor(x[r], lx);
+#pragma unroll
+                for (int r = 0; r < KPL; r++) {
+                    const bool up = ((lane * KPL + r) & k) == 0;
+                    x[r] = exch(x[r], o[r], lower == up);
+                }
+            }
+        }
+}
+// descending, keys distinct (or zero padding): the first slot keeps the larger
+struct key_exch {
+    __device__ __forceinline__ uint64_t operator()(uint64_t x, uint64_t o, bool first) const { return first == (x > o) ? x : o; }
+    __device__ __forceinline__ uint32_t operator()(uint32_t x, uint32_t o, bool first) const { return first ? max(x, o) : min(x, o); }
+};
 
-// launch 1: workgroup w sorts logits [w*2048, (w+1)*2048) and keeps its best kpad keys
-template <typename T>
+// launch 1: workgroup w -- ONE wave -- sorts logits [w * chunk, (w + 1) * chunk) in registers and keeps its best kpad keys, best
+// first.  chunk = 64 KPL: 512 (~ 250 workgroups for a 128k-entry row), 1024 or 2048.  (Round 3: 2048-key chunks through LDS,
+// 66 barrier stages of sixteen waves, on 63 workgroups.)
+template <typename T, int KPL>
 __device__ __forceinline__ void
 topk_candidates_body(const typename T::S* logits, uint32_t n, uint32_t kpad, uint64_t* cand)
 {
-    __shared__ uint64_t keys[MC_TOPK_CHUNK];
-    const uint32_t base = blockIdx.x * MC_TOPK_CHUNK;
-    for (uint32_t i = threadIdx.x; i < MC_TOPK_CHUNK; i += blockDim.x)
-        keys[i] = base + i < n ? make_key(T::ld(logits[base + i]), base + i) : 0ull; // 0 sorts last
-    lds_sort_desc(keys, MC_TOPK_CHUNK);
-    for (uint32_t i = threadIdx.x; i < kpad; i += blockDim.x) cand[(size_t)blockIdx.x * kpad + i] = keys[i];
+    const uint32_t lane = threadIdx.x, base = blockIdx.x * 64u * KPL + lane * KPL;
+    typename T::S raw[KPL]; // (unconditional loads from clamped addresses: a load behind a branch is waited for on the spot)
+#pragma unroll
+    for (int r = 0; r < KPL; r++) raw[r] = logits[base + r < n ? base + r : n - 1];
+    if constexpr (sizeof(typename T::S) == 2) {
+        // bfloat logits: the upper half of make_key's value word orders them completely (its lower half repeats the sign), and a
+        // position inside the chunk needs 11 bits -- a 32-bit key (value << 16 | 0xFFFF - position) sorts exactly as the 64-bit
+        // one does: half the cross-lane traffic, v_max / v_min instead of 64-bit compares.  Zero stays the padding (no real key
+        // is zero: its lower half is at least 0xF800).
+        uint32_t key[KPL];
+#pragma unroll
+        for (int r = 0; r < KPL; r++) {
+            const uint32_t hi = (uint32_t)(make_key(T::ld(raw[r]), 0u) >> 48);
+            key[r] = base + r < n ? (hi << 16) | (0xFFFFu - (lane * KPL + r)) : 0u;
+        }
+        wave_bitonic<KPL>(key, lane, 64u * KPL, key_exch{});
+#pragma unroll
+        for (int r = 0; r < KPL; r++) {
+            if (lane * KPL + r >= kpad) continue;
+            // back to the row's 64-bit key: the bfloat behind the ordered upper half, the index behind the position
+            const uint32_t hi = key[r] >> 16, bits = hi ^ ((hi & 0x8000u) ? 0x8000u : 0xFFFFu);
+            const uint64_t k64 = make_key(__uint_as_float(bits << 16), blockIdx.x * 64u * KPL + (0xFFFFu - (key[r] & 0xFFFFu)));
+            cand[(size_t)blockIdx.x * kpad + lane * KPL + r] = key[r] ? k64 : 0ull;
+        }
+    } else {
+        uint64_t key[KPL];
+#pragma unroll
+        for (int r = 0; r < KPL; r++) {
+            const uint64_t kk = make_key(T::ld(raw[r]), base + r);
+            key[r] = base + r < n ? kk : 0ull; // 0 sorts last
+        }
+        wave_bitonic<KPL>(key, lane, 64u * KPL, key_exch{});
+#pragma unroll
+        for (int r = 0; r < KPL; r++)
+            if (lane * KPL + r < kpad) cand[(size_t)blockIdx.x * kpad + lane * KPL + r] = key[r];
+    }
 }
-extern "C" __global__ void
-mc_topk_candidates_bfloat(const bf16_t* logits, uint32_t n, uint32_t kpad, uint64_t* cand)
-{
-    topk_candidates_body<BF>(logits, n, kpad, cand);
-}
-extern "C" __global__ void
-mc_topk_candidates_float(const float* logits, uint32_t n, uint32_t kpad, uint64_t* cand)
-{
-    topk_candidates_body<F32>(logits, n, kpad, cand);
-}
+#define MC_TOPK_CANDIDATES(NAME, T)                                                                          \
+    extern "C" __global__ void __launch_bounds__(64)                                                         \
+    NAME(const typename T::S* logits, uint32_t n, uint32_t kpad, uint64_t* cand, uint32_t chunk)             \
+    {                                                                                                        \
+        if (chunk == 512) topk_candidates_body<T, 8>(logits, n, kpad, cand);                                 \
+        else if (chunk == 1024) topk_candidates_body<T, 16>(logits, n, kpad, cand);                          \
+        else if (chunk == 2048) topk_candidates_body<T, 32>(logits, n, kpad, cand);                          \
+    }
+MC_TOPK_CANDIDATES(mc_topk_candidates_bfloat, BF)
+MC_TOPK_CANDIDATES(mc_topk_candidates_float, F32)
 
 struct sampler_params {
     uint32_t k;          // top-k (<= 128)
-    uint32_t ncand;      // candidate keys written by launch 1
-    uint32_t ncand_pad;  // next power of two
+    uint32_t ncand;      // candidate keys written by launch 1 = nlists * kpad
+    uint32_t cap;        // keys the dynamic LDS holds (a power of two >= 2 * kpad)
     float inv_temp;      // T(1 / T(temperature))
     float top_p;         // T(p)
+    uint32_t nlists;     // sorted candidate lists (workgroups of launch 1), <= MC_SAMPLE_LISTS_MAX
+    uint32_t kpad;       // keys per list
 };
+constexpr uint32_t MC_SAMPLE_LISTS_MAX = 1024;
 
 struct step_state_s { // prefix of step_state (decode_kernels.hip)
     int32_t token, pos, kv_len, write_slot, ring_base, step_index, rope_row, rolled;
@@ -405,8 +495,110 @@ sample_body(const uint64_t* cand, sampler_params p, const uint64_t* seeds, uint3
     __shared__ int32_t ids[128], sidx[128];
     __shared__ float exp_sum;
     const uint32_t tid = threadIdx.x, k = p.k;
-    for (uint32_t i = tid; i < p.ncand_pad; i += blockDim.x) keys[i] = i < p.ncand ? cand[i] : 0ull;
-    lds_sort_desc(keys, p.ncand_pad);
+    // the draw's seed pair: requested NOW (two dependent round trips that thread 0 used to start at the very end); unconditional
+    // loads from valid addresses, masked
+    const uint32_t seed_pair = n_seed_pairs ? (uint32_t)st->step_index % n_seed_pairs : 0u;
+    const uint64_t* seed_p = n_seed_pairs ? seeds + 2 * seed_pair : cand;
+    const uint64_t seed0 = seed_p[0], seed1 = seed_p[1];
+    // ---- the k best of the candidate lists WITHOUT sorting them all (round 4; it was one bitonic network over all <= 4096
+    // candidates: 78 barrier stages of 1024 threads).  Every list is sorted, so the k-th largest list HEAD is a lower bound L
+    // of the k-th largest key (k keys are >= it): only keys >= L can be among the k best -- typically k .. 4 k of them.  Keys
+    // are distinct (the index is part of the key), so the k best of that subset are the k best of the row: the result is the
+    // full sort's, key for key.
+    __shared__ uint64_t heads[MC_SAMPLE_LISTS_MAX];
+    __shared__ uint32_t cnt;
+    uint32_t nl_pad = 2;
+    while (nl_pad < p.nlists) nl_pad *= 2;
+    if (tid == 0) cnt = 0;
+    if (tid < 64) {
+        // the list heads, sorted by wave 0 in registers
+        auto sort_heads = [&](auto kpl_c) {
+            constexpr int KPL = decltype(kpl_c)::value;
+            uint64_t h[KPL];
+#pragma unroll
+            for (int r = 0; r < KPL; r++) {
+                const uint32_t e = tid * KPL + r;
+                h[r] = cand[(size_t)(e < p.nlists ? e : p.nlists - 1) * p.kpad];
+            }
+#pragma unroll
+            for (int r = 0; r < KPL; r++) h[r] = tid * KPL + r < p.nlists ? h[r] : 0ull;
+            wave_bitonic<KPL>(h, tid, nl_pad, key_exch{});
+#pragma unroll
+            for (int r = 0; r < KPL; r++)
+                if (tid * KPL + r < nl_pad) heads[tid * KPL + r] = h[r];
+        };
+        if (nl_pad <= 64) sort_heads(std::integral_constant<int, 1>{});
+        else if (nl_pad <= 256) sort_heads(std::integral_constant<int, 4>{});
+        else sort_heads(std::integral_constant<int, 16>{});
+    }
+    __syncthreads();
+    // (fewer lists than k: every candidate may be needed)
+    uint64_t L = p.nlists >= k ? heads[k - 1] : 0ull;
+    // keys >= t over all lists (each list is descending: stop at the first smaller one); with `collect` they go to keys[] while
+    // there is room.  The first four keys of a list come in ONE round of loads (a list rarely contributes more).
+    auto scan = [&](uint64_t t, bool collect) {
+        uint32_t c = 0;
+        for (uint32_t w = tid; w < p.nlists; w += blockDim.x) {
+            const uint64_t* lp = cand + (size_t)w * p.kpad;
+            uint64_t q[4];
+#pragma unroll
+            for (uint32_t i = 0; i < 4; i++) q[i] = lp[i < p.kpad ? i : p.kpad - 1];
+            uint32_t i = 0;
+            for (; i < p.kpad; i++) {
+                const uint64_t key = i < 4 ? (i == 0 ? q[0] : (i == 1 ? q[1] : (i == 2 ? q[2] : q[3]))) : lp[i];
+                if (key < t) break;
+                c++;
+                if (collect) {
+                    const uint32_t at = atomicAdd(&cnt, 1u);
+                    if (at < p.cap) keys[at] = key;
+                }
+            }
+        }
+        return c;
+    };
+    scan(L, true);
+    __syncthreads();
+    if (cnt > p.cap) {
+        // more keys >= L than the LDS holds (long runs of equal logits with a wide top-k): the exact k-th largest key by
+        // bisection over the 64 key bits -- count(keys >= t) is monotone in t, keys are distinct, so the largest t with a
+        // count >= k IS the k-th largest key and exactly k keys are >= it.  64 counting rounds: the slow path, never the usual one.
+        uint64_t lo = 0;
+        for (int bit = 63; bit >= 0; bit--) {
+            const uint64_t t = lo | (1ull << bit);
+            __syncthreads();
+            if (tid == 0) cnt = 0;
+            __syncthreads();
+            const uint32_t c = scan(t, false);
+            if (c) atomicAdd(&cnt, c);
+            __syncthreads();
+            if (cnt >= k) lo = t;
+        }
+        __syncthreads();
+        if (tid == 0) cnt = 0;
+        __syncthreads();
+        scan(lo, true);
+    }
+    __syncthreads();
+    const uint32_t have = cnt < p.cap ? cnt : p.cap;
+    uint32_t npad = 2;
+    while (npad < have || npad < k) npad *= 2;
+    for (uint32_t i = have + tid; i < npad; i += blockDim.x) keys[i] = 0ull;
+    __syncthreads();
+    if (npad <= 512) {
+        // the usual case: one wave, eight keys per lane
+        if (tid < 64) {
+            uint64_t x[8];
+#pragma unroll
+            for (int r = 0; r < 8; r++) x[r] = tid * 8 + r < npad ? keys[tid * 8 + r] : 0ull;
+            wave_bitonic<8>(x, tid, npad, key_exch{});
+#pragma unroll
+            for (int r = 0; r < 8; r++)
+                if (tid * 8 + r < npad) keys[tid * 8 + r] = x[r];
+        }
+        __syncthreads();
+    } else {
+        lds_sort_desc(keys, npad);
+    }
     // topk_sampler: values + vocabulary ids of the k best, best first
     if (tid < k) {
         const float scaled = T::rt(key_value(keys[tid]) * p.inv_temp);   // mul(logits, T(1)/temperature)
@@ -419,22 +611,18 @@ sample_body(const uint64_t* cand, sampler_params p, const uint64_t* seeds, uint3
     // two-level 32-lane reduction -- summed here in the order the oracle fixes for it
     if (tid < 128) srt[tid] = tid < k ? exp_precise(val[tid]) : 0.0f; // srt = exp(x) scratch
     __syncthreads();
-    if (tid < 4) {
-        float lanes[32];
-        for (int l = 0; l < 32; l++) lanes[l] = srt[tid * 32 + l];
-        for (int off = 16; off >= 1; off >>= 1)
-            for (int i = 0; i < off; i++) lanes[i] = lanes[i] + lanes[i + off];
-        grp[tid] = lanes[0];
-    } else if (tid < 32) {
-        grp[tid] = 0.0f;
+    // (lanes[i] += lanes[i + off] for off = 16 .. 1 over 32 lanes IS the shuffle-down tree: lane 0 of a group of 32 ends with
+    //  exactly that sum -- the two levels without their serial loops over LDS)
+    if (tid < 128) {
+        float v = srt[tid];
+        for (int off = 16; off >= 1; off >>= 1) v = v + __shfl_down(v, off, 32);
+        if ((tid & 31u) == 0) grp[tid >> 5] = v;
     }
     __syncthreads();
-    if (tid == 0) {
-        float g[32];
-        for (int l = 0; l < 32; l++) g[l] = grp[l];
-        for (int off = 16; off >= 1; off >>= 1)
-            for (int i = 0; i < off; i++) g[i] = g[i] + g[i + off];
-        exp_sum = 1.0f / g[0];
+    if (tid < 32) {
+        float g = tid < 4 ? grp[tid] : 0.0f;
+        for (int off = 16; off >= 1; off >>= 1) g = g + __shfl_down(g, off, 32);
+        if (tid == 0) exp_sum = 1.0f / g;
     }
     __syncthreads();
     uint32_t aligned = 1;
@@ -446,20 +634,22 @@ sample_body(const uint64_t* cand, sampler_params p, const uint64_t* seeds, uint3
         srt[tid] = pr;
         sidx[tid] = (int32_t)tid;
     }
-    // sort (kernel/sort.metal): the reference's bitonic network over `aligned` slots, -inf padded
-    for (uint32_t kk = 2; kk <= aligned; kk *= 2)
-        for (uint32_t j = kk >> 1; j > 0; j >>= 1) {
-            __syncthreads();
-            const uint32_t i = tid, ij = i ^ j;
-            if (i < aligned && i < ij) {
-                const float vi = srt[i], vj = srt[ij];
-                const bool up = (i & kk) == 0;
-                if ((up && vi < vj) || (!up && vi > vj)) {
-                    srt[i] = vj; srt[ij] = vi;
-                    const int32_t t = sidx[i]; sidx[i] = sidx[ij]; sidx[ij] = t;
-                }
-            }
+    // sort (kernel/sort.metal): the reference's bitonic network over `aligned` slots, -inf padded -- the same compare-exchanges
+    // in the same order, by wave 0 in registers (two slots per lane; the probability carries its position as payload)
+    __syncthreads();
+    if (tid < 64 && aligned >= 2) {
+        struct pv { float v; int32_t i; };
+        pv x[2];
+#pragma unroll
+        for (int r = 0; r < 2; r++) x[r] = pv{srt[2 * tid + r], sidx[2 * tid + r]};
+        // (kernel/sort.metal's strict compares: equal values stay where they are)
+        wave_bitonic<2>(x, tid, aligned, [](const pv& a, const pv& o, bool first) { return (first ? a.v < o.v : a.v > o.v) ? o : a; });
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            srt[2 * tid + r] = x[r].v;
+            sidx[2 * tid + r] = x[r].i;
         }
+    }
     __syncthreads();
     // cumsum (kernel/cumsum.metal, BlockSize 2 for k <= 2048): thread t owns elements 2t, 2t+1
     const uint32_t nth = (k + 1) / 2;
@@ -497,8 +687,7 @@ sample_body(const uint64_t* cand, sampler_params p, const uint64_t* seeds, uint3
     __syncthreads();
     // multinomial(sample_size 1) + gather: see multinomial_body for the interval quirk
     if (tid == 0) {
-        const uint32_t pair = n_seed_pairs ? (uint32_t)st->step_index % n_seed_pairs : 0u;
-        const uint64_t s0 = n_seed_pairs ? seeds[2 * pair] : 0ull, s1 = n_seed_pairs ? seeds[2 * pair + 1] : 0ull;
+        const uint64_t s0 = n_seed_pairs ? seed0 : 0ull, s1 = n_seed_pairs ? seed1 : 0ull;
         const float a = val[0], b = val[0]; // column output.size(1) - 1 == 0
         pcg32 g(s0, s1);
         const float random = T::rt(g.uniform() * (b - a) + a);

@@ -208,37 +208,45 @@ def test_div_and_row_sum(acc, dt):
 
 
 # ------------------------------------------------------------------------------------------ fused
-SP = np.dtype([("k", np.uint32), ("ncand", np.uint32), ("ncand_pad", np.uint32), ("inv_temp", np.float32),
-               ("top_p", np.float32)])
+SP = np.dtype([("k", np.uint32), ("ncand", np.uint32), ("cap", np.uint32), ("inv_temp", np.float32),
+               ("top_p", np.float32), ("nlists", np.uint32), ("kpad", np.uint32)])
 
 
-def fused_sample(acc, dt, logits, top_k=50, temperature=0.6, top_p=0.9, seed=(0, 0)):
+def fused_sample(acc, dt, logits, top_k=50, temperature=0.6, top_p=0.9, seed=(0, 0), cap=4096):
+    """The two launches of decoder.cc run_head() with its geometry (sampler_chunk): 512-logit chunks, one wave and one sorted list of
+    kpad keys per chunk, then one workgroup of two waves."""
     import metalchat_amd as mc
 
     n = logits.size
     k = min(top_k, n)
     kpad = ceil_pow2(top_k)
-    chunks = -(-n // 2048)
-    cand = acc.alloc(chunks * kpad * 8)
+    chunk = max(512, kpad)
+    while chunk < 2048 and -(-n // chunk) > 1024:
+        chunk *= 2
+    lists = -(-n // chunk)
+    cand = acc.alloc(lists * kpad * 8)
     lb = acc.to_device(logits)
-    mc.KernelTask(acc.load("mc_topk_candidates", TN[dt]), (chunks * 256, 1, 1), (256, 1, 1),
-                  [lb, np.uint32(n), np.uint32(kpad), cand])()
+    mc.KernelTask(acc.load("mc_topk_candidates", TN[dt]), (lists * 64, 1, 1), (64, 1, 1),
+                  [lb, np.uint32(n), np.uint32(kpad), cand, np.uint32(chunk)])()
     rt = (lambda v: float(mo.decode(dt, mo.encode(dt, np.array([v], np.float32)))[0]))
     p = np.zeros(1, SP)
-    p["k"], p["ncand"], p["ncand_pad"] = k, chunks * kpad, ceil_pow2(chunks * kpad)
+    p["k"], p["ncand"], p["cap"], p["nlists"], p["kpad"] = k, lists * kpad, cap, lists, kpad
     p["inv_temp"], p["top_p"] = rt(1.0 / rt(temperature)), rt(top_p)
     state = acc.to_device(np.zeros(8, np.int32))
     toks = acc.to_device(np.full(4, -1, np.int32))
     taps = acc.alloc(7 * k * 4)
     seeds = acc.to_device(np.array(seed, np.uint64))
-    mc.KernelTask(acc.load("mc_sample", TN[dt]), (256, 1, 1), (256, 1, 1),
-                  [cand, p, seeds, np.uint32(1), state, toks, taps], lds_bytes=int(p["ncand_pad"][0]) * 8)()
+    mc.KernelTask(acc.load("mc_sample", TN[dt]), (128, 1, 1), (128, 1, 1),
+                  [cand, p, seeds, np.uint32(1), state, toks, taps], lds_bytes=cap * 8)()
     acc.wait()
     return int(toks.download(np.int32, 4)[0]), taps.download(np.float32, 7 * k).reshape(7, k)
 
 
+# ("flat": one value everywhere -- with top_k 128 more keys tie at the bound than the second launch holds: its bisection path;
+#  "coarse" at top_k 128 on the big row: long runs of equal logits)
 CASES = [(F32, 128256, 50, "normal"), (BF16, 128256, 50, "normal"), (BF16, 128256, 50, "coarse"),
-         (F32, 40, 50, "normal"), (BF16, 5000, 128, "coarse"), (F32, 256000, 64, "peaked"), (BF16, 2048, 1, "normal")]
+         (F32, 40, 50, "normal"), (BF16, 5000, 128, "coarse"), (F32, 256000, 64, "peaked"), (BF16, 2048, 1, "normal"),
+         (BF16, 128256, 128, "flat"), (F32, 128256, 128, "coarse"), (BF16, 700000, 50, "normal")]
 
 
 @pytest.mark.parametrize("dt,vocab,top_k,kind", CASES)
@@ -249,6 +257,8 @@ def test_fused_default_sampler_matches_oracle_chain(acc, dt, vocab, top_k, kind)
         x = np.round(x * 2) / 2            # many exactly equal logits: exercises the tie rule
     if kind == "peaked":
         x[rng.integers(0, vocab, 3)] += 12.0
+    if kind == "flat":
+        x[:] = 0.5
     logits = mo.encode(dt, x)
     for seed in ((0, 0), (123456789, 987654321)):
         tok, taps = fused_sample(acc, dt, logits, top_k=top_k, seed=seed)
@@ -260,6 +270,22 @@ def test_fused_default_sampler_matches_oracle_chain(acc, dt, vocab, top_k, kind)
         # nn/sampling.h + kernel/multinomial.metal:112 with sample_size 1: the draw interval is
         # empty, so the chain returns the head of the sorted nucleus
         assert tok == int(otaps[6][0])
+
+
+@pytest.mark.parametrize("dt,vocab,top_k,kind", [(BF16, 128256, 50, "coarse"), (F32, 128256, 50, "normal")])
+def test_fused_default_sampler_bisection_path(acc, dt, vocab, top_k, kind):
+    """The second launch with room for only 2 * kpad keys: more keys lie above the bound than it holds, so the k-th largest key
+    is found by bisection over the key bits -- the same tokens and taps as the usual path."""
+    rng = np.random.default_rng(vocab + top_k)
+    x = rng.normal(0, 2.0, vocab).astype(np.float32)
+    if kind == "coarse":
+        x = np.round(x * 2) / 2
+    logits = mo.encode(dt, x)
+    tok, taps = fused_sample(acc, dt, logits, top_k=top_k, seed=(5, 6), cap=128)
+    otok, otaps = mo.sample_default(dt, logits, top_k=top_k, init_state=5, init_seq=6, taps=True)
+    for r in range(7):
+        parity.exact(taps[r], otaps[r], f"sampler tap {r} (bisection path)")
+    assert tok == otok
 
 
 def test_sampler_argument_errors(acc):

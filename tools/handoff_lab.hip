@@ -9,6 +9,8 @@
 //   mode 1: plain store, sc1 loads                     (L2-local only: wrong placement = the bounded wait gives up)
 //   mode 2: plain store to FAST + sc1 store to SLOW; the consumer polls FAST and looks at SLOW every 8th look
 //           (placement-independent: a member on another XCD is found through SLOW)
+//   mode 3: as mode 2, but FAST is polled with SCALAR loads (s_load_dwordx16 glc: the scalar cache bypassed, served by the XCD's L2) --
+//           they do not queue in the CU's vector-memory pipe behind the tiles other waves stream
 //   load != 0: waves 1-3 of every workgroup stream a private buffer with non-temporal loads meanwhile (a busy CU)
 //   hipcc --offload-arch=gfx950 -O3 tools/handoff_lab.hip -o tools/handoff_lab && tools/handoff_lab
 #include <hip/hip_runtime.h>
@@ -35,6 +37,18 @@ __device__ __forceinline__ unsigned long long
 load_sc1(const unsigned long long* p)
 {
     return __hip_atomic_load((gu64_t*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+// 32 granules = 256 bytes at `p` (wave-uniform) into 64 SGPRs
+__device__ __forceinline__ void
+sload_row(const unsigned long long* p, u32x16& a, u32x16& b, u32x16& c, u32x16& d)
+{
+    asm volatile("s_load_dwordx16 %0, %4, 0x0 glc\n\ts_load_dwordx16 %1, %4, 0x40 glc\n\ts_load_dwordx16 %2, %4, 0x80 glc\n\t"
+                 "s_load_dwordx16 %3, %4, 0xc0 glc\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(a), "=&s"(b), "=&s"(c), "=&s"(d)
+                 : "s"(p)
+                 : "memory");
 }
 
 // fast / slow: [4 buffers][8 groups][32 members] granules; out: [256] final values; xcc: [256]; stamps: [256][rounds + 1]
@@ -77,14 +91,43 @@ k_rounds(unsigned long long* fast, unsigned long long* slow, uint32_t* out, uint
         if (lane == 0) {
             if (mode == 0) store_sc1(fast + slot + member, g);
             if (mode == 1) store_plain(fast + slot + member, g);
-            if (mode == 2) {
+            if (mode >= 2) {
                 store_plain(fast + slot + member, g);
                 store_sc1(slow + slot + member, g);
             }
         }
         uint32_t sum = 0;
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-        for (uint32_t look = 0;; look++) {
+        for (uint32_t look = 0; mode == 3; look++) {
+            u32x16 q[4];
+            sload_row(fast + slot, q[0], q[1], q[2], q[3]);
+            uint32_t bad = 0, tot = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    bad |= q[i][2 * j + 1] ^ tag;
+                    tot += q[i][2 * j];
+                }
+            if (bad == 0) {
+                sum = lane == 0 ? tot : 0u;
+                break;
+            }
+            if ((look & 7u) == 7u) { // the fabric copy, with vector loads as mode 2
+                const unsigned long long v = lane < 32 ? load_sc1(slow + slot + lane) : ((unsigned long long)tag << 32);
+                if (__all((uint32_t)(v >> 32) == tag)) {
+                    sum = lane < 32 ? (uint32_t)v : 0u;
+                    break;
+                }
+            }
+            if (__builtin_amdgcn_s_memrealtime() - t0 > 5000000ull) {
+                if (lane == 0) atomicAdd(gaveup, 1u);
+                sum = 0;
+                break;
+            }
+            if (sleep) __builtin_amdgcn_s_sleep(4);
+        }
+        for (uint32_t look = 0; mode != 3; look++) {
             unsigned long long v = lane < 32 ? load_sc1(fast + slot + lane) : ((unsigned long long)tag << 32);
             bool ok = (uint32_t)(v >> 32) == tag;
             if (mode == 2 && (look & 7u) == 7u && !__all(ok)) {
@@ -136,7 +179,7 @@ main()
     std::vector<uint32_t> ref_out;
     for (uint32_t load = 0; load < 2; load++)
         for (uint32_t sleep = 0; sleep < 2; sleep++)
-            for (uint32_t mode = 0; mode < 3; mode++) {
+            for (uint32_t mode = 0; mode < 4; mode++) {
                 std::vector<double> per_round;
                 uint32_t gave = 0;
                 std::vector<uint32_t> h_out(256), h_xcc(256);
