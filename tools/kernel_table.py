@@ -4,6 +4,7 @@ usage: kernel_table.py profiles/r03_kernel_stats.csv"""
 import csv, sys
 ALG = {  # kernel -> (what, algorithmic MB per launch: Llama-3-8B int4 g128, S = 2048)
     "mc_gemv_i4_bfloat_lin2_p1_e2": ("rmsnorm + w1|w3 + SiLU*mul", 60.555264),
+    "mc_attn_qkv_wo_i4_bfloat_hd128_k2_q2": ("rmsnorm + wq|wk|wv + RoPE + cache write + scores + softmax + P.V + Wo + residual, one launch (wq|wk|wv 12.98 MB, K and V 8.39, Wo 8.65)", 12.976128 + 8.388608 + 8.650752),
     "mc_attn_wo_i4_bfloat_hd128_k2": ("scores + softmax + P.V + Wo + residual, one launch (K and V 8.39 MB, Wo 8.65 MB)", 8.388608 + 8.650752),
     "mc_attn_fused_bfloat": ("scores + softmax + P.V, one launch (K and V)", 8.388608),
     "mc_gemv_i4_bfloat_lin7_p0_e1": ("w2 + residual", 30.277632),
