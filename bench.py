@@ -365,7 +365,7 @@ def build_70b_stage(mc, acc, np, args, rank, world):
     def stage(r):
         b, e = mc.pipeline_layer_range(r, world, m["n_layers"])
         d = mc.Decoder(acc, dtype=mc.BF16, family=mc.FAMILY_LLAMA3, max_seq_len=2048, attn_scale=float(1.0 / np.sqrt(m["head_dim"])),
-                       layer_begin=b, layer_end=e, weight_format=mc.WFMT_I4, group_size=128, use_graph=0, **m)
+                       layer_begin=b, layer_end=e, weight_format=mc.WFMT_I4, group_size=128, use_graph=0 if args.no_graph else 1, **m)
         d.init_synthetic(7)
         return d
 
@@ -438,7 +438,7 @@ def main():
                        attn_scale=float(1.0 / np.sqrt(m["head_dim"])), layer_begin=lb, layer_end=le,
                        weight_format=wfmt, group_size=(args.group if args.wbits != 16 else 0),
                        qmode=(mc.QMODE_FAST if args.qmode == "fast" else mc.QMODE_EXACT),
-                       use_graph=0 if (args.no_graph or piped) else 1, **m)
+                       use_graph=0 if args.no_graph else 1, **m)
         d.init_synthetic(args.seed)
         return d
 
@@ -488,8 +488,9 @@ def main():
                                f"seq_len={S}, {args.dtype} activations/KV, qmode={args.qmode}",
                    "parallelism": "single GPU" if world == 1 else
                    f"layer pipeline pp{world} ({'stages sharing GPU 0 in one process, device-to-device hops' if args.share_device else 'one process per GPU, RCCL send/recv on the decoder stream'})",
-                   "hipgraph": bool(not piped and not args.no_graph),
-                   # (the pipeline path launches eagerly: its hops sit between the launches of a token)
+                   "hipgraph": bool(not args.no_graph),
+                   # (N > 1: one graph per stage -- the launches of a token between two hops; the hops themselves are enqueued
+                   #  on the stream in front of and behind the replay)
                    "hop_transport": None if not piped else ("device-to-device copy behind an event" if args.share_device else "ncclSend / ncclRecv (RCCL) on the decoder stream")},
         "whole_token": {"algorithmic_bytes": ab["total"], "achieved_GBs": ab["total"] * tok_s / 1e9,
                         "frac_of_hbm_peak": ab["total"] * tok_s / 1e9 / HBM_PEAK_GBS},

@@ -2564,11 +2564,29 @@ stage_token(mc_decoder* d, int i, int32_t first_token, int32_t start_pos)
         MC_HIP(hipMemsetAsync(&d->state->step_index, 0, 4, d->stream));
     } else if (d->first_stage) {
         fused_advance = true; // the embedding launch advances the state
-    } else {
-        s = d->launch("mc_step_advance", 1, 1, 1, 64, 0, pack(d->state, (int32_t)d->cfg.max_seq_len, (int32_t)d->pre_len));
-        if (s != MC_OK) return s;
     }
-    return d->run_token(d->first_stage ? nullptr : d->hidden_in, fused_advance);
+    // the launches of a token behind the first: the same sequence every time (the hops sit OUTSIDE it, on the stream in front of
+    // and behind it) -- captured once per stage and replayed, as mc_decoder_generate replays a token (round 4: the pipeline path
+    // launched eagerly, 3-4 % at N = 2 / 4 on one device)
+    auto launches = [&]() -> mc_status {
+        if (i > 0 && !d->first_stage) {
+            mc_status s1 = d->launch("mc_step_advance", 1, 1, 1, 64, 0, pack(d->state, (int32_t)d->cfg.max_seq_len, (int32_t)d->pre_len));
+            if (s1 != MC_OK) return s1;
+        }
+        return d->run_token(d->first_stage ? nullptr : d->hidden_in, fused_advance);
+    };
+    if (i == 0 || !d->cfg.use_graph) return launches();
+    if (!d->graph_exec) {
+        d->drop_graph();
+        MC_HIP(hipStreamBeginCapture(d->stream, hipStreamCaptureModeGlobal));
+        const mc_status s2 = launches();
+        const hipError_t e = hipStreamEndCapture(d->stream, &d->graph);
+        if (s2 != MC_OK) return s2;
+        if (e != hipSuccess) return hip_fail(e, "hipStreamEndCapture");
+        MC_HIP(hipGraphInstantiate(&d->graph_exec, d->graph, nullptr, nullptr, 0));
+    }
+    MC_HIP(hipGraphLaunch(d->graph_exec, d->stream));
+    return MC_OK;
 }
 
 mc_status

@@ -237,3 +237,89 @@ def test_attention_and_wo_in_one_launch_matches_the_oracle(acc, shape, n, fast):
         parity.check(BF16, hb.download(np.uint16, dim), ref.reshape(-1), rel=4e-3, max_ulp=2, max_frac=0.3, scale_aware=True,
                      what=f"attention + Wo + residual in one launch, {shape} n{n} tag ({epoch}, {layer_tag})")
     dec.release()
+
+
+@pytest.mark.parametrize("fast", [1, 0])
+@pytest.mark.parametrize("n", [2048, 1000, 1, 65])
+def test_norm_qkv_rope_attention_and_wo_in_one_launch_matches_the_oracle(acc, n, fast):
+    """`mc_attn_qkv_wo_i4_bfloat_hd128_k2_q2` (attn_block_kernels.hip qkv_in_launch: attention_norm, wq|wk|wv, RoPE, the cache
+    write, the decode attention, Wo and the residual of one block -- nn/transformer.h:130-133, nn/attention.h:170-205 -- the kernel
+    the benchmark's token launches 32 times) launched BY NAME on a hidden row and a cache of its own, against the oracle's kernels
+    composed as the reference composes them: rmsnorm, three linears (hadamard_broadcast + bmm), rope at the step's table row, the
+    rows appended to the cache (nn/cache.h:209-213), the attention of test_one_launch_attention_matches_the_oracle, Wo, add in T.
+    The hidden row is dyadic, so the normalised row is the oracle's bit for bit (test_lin_kernels_gpu.py) and the cache rows the
+    launch writes are held to the GEMV's single-kernel bound; the block's output to the composition bound of the suite."""
+    import metalchat_amd as mc
+    from test_lin_kernels_gpu import dyadic_row, oracle_rmsnorm
+
+    H, KV, hd, dim, max_seq = 32, 8, 128, 4096, 2048
+    half = hd // 2
+    cfg = mg.tiny_cfg(BF16, dim=dim, n_heads=H, n_kv_heads=KV, head_dim=hd, ffn_dim=256, n_layers=1, vocab=64, max_seq_len=max_seq)
+    w = mg.make_model(cfg, seed=303, quant="i4", group=128)
+    dec = mc.Decoder(acc, **mg.decoder_kwargs(cfg, weight_format=mc.WFMT_I4, group_size=128))
+    dec.load_model(w)
+    lw = w["layers"][0]
+    wo_p, wo_s, rows, inf, _ = dec.weight_ptrs(0, "wo")
+    qk_p, qk_s, qrows, qinf, _ = dec.weight_ptrs(0, "qkv")
+    assert (rows, inf, qrows, qinf) == (dim, H * hd, (H + 2 * KV) * hd, dim)
+    rng = np.random.default_rng(1000 + n)
+    n_rep, nsplit = H // KV, max_seq // PB
+    slot, rrow, nrows = n - 1, 5, 8            # the step writes slot n - 1 and reads n slots
+    x = dyadic_row(rng, dim)
+    k = mo.encode(BF16, rng.normal(0, 0.4, (n, KV, hd)).astype(np.float32))
+    v = mo.encode(BF16, rng.normal(0, 0.5, (n, KV, hd)).astype(np.float32))
+    fcos = np.zeros((nrows, half), np.float32)
+    fsin = np.zeros((nrows, half), np.float32)
+    L = mo.layout
+    mo.rope_freqs(L(fcos.shape), fcos, L(fsin.shape), fsin, hd, 0, 500000.0)
+    scale = float(mo.from_bf16(mo.to_bf16(np.array([hd ** -0.5], np.float32)))[0])
+    # ---- the oracle's block
+    xn = oracle_rmsnorm(x, lw["attention_norm"])
+    q0 = oracle_linear(BF16, lw["wq"], xn.reshape(1, 1, -1)).reshape(H, hd)
+    k0 = oracle_linear(BF16, lw["wk"], xn.reshape(1, 1, -1)).reshape(KV, hd)
+    v0 = oracle_linear(BF16, lw["wv"], xn.reshape(1, 1, -1)).reshape(KV, hd)
+    q1, k1 = np.zeros_like(q0), np.zeros_like(k0)
+    mo.rope(BF16, L(q0.shape), q1, L(q0.shape), q0, L(fcos.shape), fcos, L(fsin.shape), fsin, 1, H, rrow)
+    mo.rope(BF16, L(k0.shape), k1, L(k0.shape), k0, L(fcos.shape), fcos, L(fsin.shape), fsin, 1, KV, rrow)
+    k[slot], v[slot] = k1, v0
+    att = oracle_attention(q1, k, v, n_rep, scale)
+    proj = oracle_linear(BF16, lw["wo"], att.reshape(1, 1, -1))
+    ref = np.zeros((1, dim), np.uint16)
+    mo.add(BF16, L((1, dim)), ref, L((1, dim)), x.reshape(1, -1), L((1, dim)), proj.reshape(1, -1))
+    # ---- the launch: the cache holds the n - 1 earlier rows, garbage in the step's slot and behind it
+    kpast, vpast = k.copy(), v.copy()
+    kpast[slot] = mo.encode(BF16, rng.normal(0, 30, (KV, hd)).astype(np.float32))
+    vpast[slot] = mo.encode(BF16, rng.normal(0, 30, (KV, hd)).astype(np.float32))
+    kc, vt = device_caches(acc, kpast, vpast, max_seq)
+    psum = acc.to_device(np.zeros(2 * H * nsplit, np.uint64))
+    slab = acc.to_device(np.zeros(2 * H * hd * nsplit, np.uint64))
+    row_g = acc.to_device(np.zeros(H * hd // 2, np.uint64))
+    qkv_g = acc.to_device(np.zeros(2 * (H + 2 * KV) * hd // 2, np.uint64))
+    attn_out = acc.alloc(H * hd * 2)
+    nw = acc.to_device(lw["attention_norm"])
+    cb, sb = acc.to_device(fcos.reshape(-1)), acc.to_device(fsin.reshape(-1))
+    kern = acc.load("mc_attn_qkv_wo_i4_bfloat_hd128_k2_q2")
+    W = lambda p_: acc.wrap(p_, 1 << 40)
+    for epoch, layer_tag in ((1, 1), (1, 2), (9, 200)):
+        hb = acc.to_device(x)                  # read as the block input and the residual, overwritten IN PLACE, as the decoder launches it
+        attn_out.upload(np.zeros(H * hd, np.uint16))
+        st = np.zeros(12, np.int32)
+        st[2], st[3], st[6], st[9] = n, slot, rrow, epoch
+        state = acc.to_device(st)
+        mc.KernelTask(kern, (nsplit * KV * 512, 1, 1), (512, 1, 1),
+                      [kc, vt, attn_out, psum, slab, row_g, qkv_g, state, np.uint32(n_rep), np.uint32(KV), np.uint32(max_seq),
+                       np.float32(scale), np.uint32(nsplit), np.uint32(layer_tag), W(wo_p), W(wo_s), hb, hb, np.uint32(dim),
+                       np.uint32(128), nw, W(qk_p), W(qk_s), cb, sb, np.float32(1e-5), np.float32(0.0), np.uint32(fast), None])()
+        acc.wait()
+        assert int(state.download(np.int32, 12)[10]) == 0, "a hand-off of the launch gave up"
+        kgot = kc.download(np.uint16, KV * max_seq * hd).reshape(KV, max_seq, hd)
+        vgot = vt.download(np.uint16, KV * hd * max_seq).reshape(KV, hd, max_seq)
+        parity.check(BF16, kgot[:, slot].reshape(-1), k1.reshape(-1), rel=3e-3, max_ulp=2, max_frac=0.2, what=f"K row the launch wrote (GEMV + rotation), n{n}")
+        parity.check(BF16, vgot[:, :, slot].reshape(-1), v0.reshape(-1), rel=2e-3, max_ulp=1, max_frac=0.05, what=f"V row the launch wrote, n{n}")
+        if n > 1:
+            parity.exact(kgot[:, : slot], kpast[: slot].transpose(1, 0, 2), "the earlier K rows are untouched")
+        parity.check(BF16, attn_out.download(np.uint16, H * hd), att.reshape(-1), rel=4e-3, max_ulp=2, max_frac=0.3, scale_aware=True,
+                     what=f"attention row of the one launch, n{n} tag ({epoch}, {layer_tag})")
+        parity.check(BF16, hb.download(np.uint16, dim), ref.reshape(-1), rel=4e-3, max_ulp=2, max_frac=0.3, scale_aware=True,
+                     what=f"norm + wq|wk|wv + rope + attention + Wo + residual in one launch, n{n} tag ({epoch}, {layer_tag})")
+    dec.release()

@@ -45,11 +45,12 @@ def test_local_pipeline_equals_the_single_stage_bit_for_bit(acc, family, dtype):
     want_kv = {layer: tuple(a.copy() for a in single.export_kv(layer)) for layer in range(cfg["n_layers"])}
     want_more = list(single.generate(want[-1], n, 6))  # a second call continues from the caches (start_pos > 0)
     single.release()
-    for world in (2, 4, 8):
-        stages = build(acc, cfg, weights, world, mc.WFMT_I4, 32)
+    # (eager launches, and one hipGraph per stage -- the launches of a token between two hops, captured at the second token)
+    for world, graph in ((2, 0), (4, 0), (8, 0), (2, 1), (4, 1), (8, 1)):
+        stages = build(acc, cfg, weights, world, mc.WFMT_I4, 32, use_graph=graph)
         pipe = mc.Pipeline.local(stages)
         got = list(pipe.generate(5, 0, n))
-        assert got == want, f"world {world}: tokens differ"
+        assert got == want, f"world {world} graph {graph}: tokens differ"
         parity.exact(stages[-1].logits(), want_logits, f"world {world}: logits of the last token")
         for r, d in enumerate(stages):
             for layer in range(d.cfg["layer_begin"], d.cfg["layer_end"]):
