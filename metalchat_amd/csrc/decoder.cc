@@ -175,6 +175,9 @@ struct mc_decoder {
     void* hidden_in = nullptr;  // T[dim]   inbound row for non-first stages
     void* hidden_b = nullptr;   // T[dim]   gemma3: the row between the attention and the ffn half of a block
     const void* pending_pn = nullptr; // gemma3: postnorm_args the next pre-norm GEMV has to apply to `proj`
+    bool lazy_pick = false;    // inside mc_decoder_generate: the pick of a token is folded by the NEXT token's embedding launch
+    bool lazy_pick_on = true;  // MC_LAZY_PICK
+    bool graph_lazy = false;   // the captured token was recorded with lazy_pick
     std::unordered_map<const void*, postnorm_args_h> pn_host; // the same descriptors on the host (the linear-order kernels take the three pointers as arguments)
     void* qkv = nullptr;        // T[(H+2KV)*hd]
     void* q_rot = nullptr;      // T[H*hd]
@@ -610,6 +613,20 @@ struct mc_decoder {
     {
         return handoff_fast && cfg.n_kv_heads % 8 == 0;
     }
+    // ... and for the launches that are the attention ALONE (mc_attn_fused_T: no GEMV phase that needs every workgroup of the
+    // grid) any other head count is dealt with a stride of the next multiple of 8 -- bit 1 of the kernel's `fastpath` argument; the
+    // grid is nsplit x that stride and the workgroups without a head leave at once -- when the heads that then share an XCD
+    // still fit its CUs
+    uint32_t
+    handoff_mode_alone() const
+    {
+        if (!handoff_fast) return 0u;
+        const unsigned KV = (unsigned)cfg.n_kv_heads;
+        if (KV % 8u == 0u) return 1u;
+        const unsigned per_cu = std::min(attn_fused_max_wgs_per_cu, occ_fused < 0 ? attn_fused_max_wgs_per_cu : (unsigned)occ_fused);
+        const bool fits = (unsigned)nsplit * ((KV + 7u) / 8u) <= per_cu * (unsigned)dev->prop.multiProcessorCount / 8u;
+        return fits ? 3u : 0u;
+    }
 
     // ... with wq|wk|wv in the same launch too (attn_block_kernels.hip qkv_in_launch): the built shape, the kv head's
     // (n_rep + 2) hd / 2 row pairs dealt evenly over its nsplit workgroups, at most two per wave
@@ -910,11 +927,13 @@ struct mc_decoder {
                                     (uint32_t)hd, (uint32_t)cfg.max_seq_len, scale_T, (uint32_t)nsplit, (uint32_t)(li + 1),
                                     (uint32_t)(handoff_fast_here() ? 1 : 0), (const void*)L.q_norm, (const void*)L.k_norm,
                                     (const float*)rope_cos[L.rope_table], (const float*)rope_sin[L.rope_table], cfg.norm_eps, mu));
-                else
-                s = launch("mc_attn_fused_" + tname, (unsigned)(nsplit * KV), 1, 1, 256, 0,
-                           pack(q_rot, L.kc, L.vt, attn_out, attn_psum_g, attn_slab_g, state, (uint32_t)n_rep, (uint32_t)KV, (uint32_t)hd,
-                                (uint32_t)cfg.max_seq_len, scale_T, (uint32_t)nsplit, (uint32_t)(li + 1), (void*)nullptr,
-                                (uint32_t)(handoff_fast_here() ? 1 : 0)));
+                else {
+                    const uint32_t mode = handoff_mode_alone();
+                    const unsigned stride = (mode & 2u) ? ((unsigned)KV + 7u) & ~7u : (unsigned)KV;
+                    s = launch("mc_attn_fused_" + tname, (unsigned)nsplit * stride, 1, 1, 256, 0,
+                               pack(q_rot, L.kc, L.vt, attn_out, attn_psum_g, attn_slab_g, state, (uint32_t)n_rep, (uint32_t)KV, (uint32_t)hd,
+                                    (uint32_t)cfg.max_seq_len, scale_T, (uint32_t)nsplit, (uint32_t)(li + 1), (void*)nullptr, mode));
+                }
                 if (s != MC_OK) return s;
                 s = gemma ? gemv(L.wo, 0, 0, attn_out, proj, nullptr, nullptr, mu) : gemv(L.wo, 0, 1, attn_out, hidden, x, nullptr, mu);
                 if (s != MC_OK) return s;
@@ -1007,9 +1026,14 @@ struct mc_decoder {
         if (tb == 2) sc = bf2f_host(f2bf_host(sc));
         const unsigned g = (cfg.dim + 255) / 256;
         mc_status s;
-        if (emb_fmt == MC_WFMT_T)
+        if (emb_fmt == MC_WFMT_T) {
+            // (lazy_pick: the previous token's pick is folded HERE, by every workgroup of this launch, instead of by a
+            //  mc_argmax_keys launch behind its head -- mc_decoder_generate)
+            const bool fold = lazy_pick && advance;
             s = launch("mc_embed_" + tname, g, 1, 1, 256, 0,
-                       pack(emb_table, hidden, state, (uint32_t)cfg.dim, sc, (int32_t)(gemma ? 1 : 0), adv_seq, (int32_t)pre_len));
+                       pack(emb_table, hidden, state, (uint32_t)cfg.dim, sc, (int32_t)(gemma ? 1 : 0), adv_seq, (int32_t)pre_len,
+                            fold ? (const void*)pick_keys : (const void*)nullptr, (uint32_t)pick_slots, fold ? tokens_dev : (int32_t*)nullptr));
+        }
         else
             s = launch("mc_embed_q8_" + tname, g, 1, 1, 256, 0,
                        pack(emb_table, emb_scales, hidden, state, (uint32_t)cfg.dim, sc,
@@ -1020,6 +1044,18 @@ struct mc_decoder {
         return MC_OK;
     }
 
+    // the one-workgroup fold of the head's per-workgroup keys: the token into the step state and the token list
+    mc_status
+    fold_pick()
+    {
+        return launch("mc_argmax_keys", 1, 1, 1, 256, 0, pack((const void*)pick_keys, (uint32_t)pick_slots, state, tokens_dev));
+    }
+    // chained greedy generation on one stage: can the fold wait for the next token's embedding launch?
+    bool
+    lazy_pick_ok() const
+    {
+        return lazy_pick_on && first_stage && last_stage && head_pick() && head_pick_mode == 2 && emb_fmt == MC_WFMT_T && !want_taps;
+    }
     // does the greedy pick ride in the head's own launch (gemv.h EPI_STORE_PICK)?
     bool
     head_pick() const
@@ -1042,7 +1078,7 @@ struct mc_decoder {
         pending_pn = nullptr;
         if (s != MC_OK) return s;
         if (pick && head_pick_mode == 2)
-            return launch("mc_argmax_keys", 1, 1, 1, 256, 0, pack((const void*)pick_keys, (uint32_t)pick_slots, state, tokens_dev));
+            return lazy_pick ? MC_OK : fold_pick();
         if (pick) return MC_OK;
         if (sampler_kind == MC_SAMPLER_GREEDY)
             return launch("mc_argmax_" + tname, 1, 1, 1, 1024, 0,
@@ -1377,6 +1413,7 @@ mc_decoder_create(mc_device* dev, mc_library* lib, mc_queue* q, const mc_decoder
     if (const char* e = getenv("MC_HANDOFF_FAST")) d->handoff_fast = atoi(e) != 0;
     if (const char* e = getenv("MC_ATTN_QKV")) d->attn_qkv_on = atoi(e) != 0;
     if (const char* e = getenv("MC_ATTN_QKN")) d->attn_qkn_on = atoi(e) != 0;
+    if (const char* e = getenv("MC_LAZY_PICK")) d->lazy_pick_on = atoi(e) != 0;
     if (const char* e = getenv("MC_ATTN_FUSED_WGS")) d->attn_fused_max_wgs_per_cu = (unsigned)std::max(1, std::min(4, atoi(e)));
     if (const char* e = getenv("MC_LING_HALF")) d->ling_half = atoi(e) != 0;
     if (const char* e = getenv("MC_LIN_SPLIT")) d->lin_split = atoi(e) != 0;
@@ -1998,6 +2035,14 @@ mc_decoder_generate(mc_decoder* d, int32_t first_token, int32_t start_pos, int32
     MC_HIP(hipMemsetAsync(&d->state->step_index, 0, 4, d->stream));
     if (start_pos == 0) d->ring_turned = false;
     if (start_pos + n > d->cfg.max_seq_len) d->ring_turned = true;
+    // the head leaves one key per workgroup; the fold into a token is done by the NEXT token's embedding launch (every
+    // workgroup of it folds the 2 KB itself) and by one mc_argmax_keys launch behind the LAST token of the call: a launch
+    // less per token (4.7 us of 1240)
+    struct lazy_scope {
+        mc_decoder* d;
+        ~lazy_scope() { d->lazy_pick = false; }
+    } lazy_guard{d};
+    d->lazy_pick = d->lazy_pick_ok();
     s = d->run_token(nullptr);
     if (s != MC_OK) return s;
     for (int i = 1; i < n; i++) {
@@ -2005,8 +2050,10 @@ mc_decoder_generate(mc_decoder* d, int32_t first_token, int32_t start_pos, int32
         s = d->ensure_rope(pos); // moves the table window when pos leaves it (the step state carries the new start)
         if (s != MC_OK) return s;
         if (d->cfg.use_graph) {
+            if (d->graph_exec && d->graph_lazy != d->lazy_pick) d->drop_graph();
             if (!d->graph_exec) {
                 d->drop_graph();
+                d->graph_lazy = d->lazy_pick;
                 MC_HIP(hipStreamBeginCapture(d->stream, hipStreamCaptureModeGlobal));
                 mc_status s2 = d->run_token(nullptr, true); // the embedding launch advances the step state
 
@@ -2020,6 +2067,11 @@ mc_decoder_generate(mc_decoder* d, int32_t first_token, int32_t start_pos, int32
             s = d->run_token(nullptr, true);
             if (s != MC_OK) return s;
         }
+    }
+    if (d->lazy_pick) {
+        s = d->fold_pick(); // the last token's pick
+        if (s != MC_OK) return s;
+        d->lazy_pick = false;
     }
     d->last_pos = start_pos + n - 1;
     if (tokens_out) {
@@ -2576,8 +2628,10 @@ stage_token(mc_decoder* d, int i, int32_t first_token, int32_t start_pos)
         return d->run_token(d->first_stage ? nullptr : d->hidden_in, fused_advance);
     };
     if (i == 0 || !d->cfg.use_graph) return launches();
+    if (d->graph_exec && d->graph_lazy) d->drop_graph(); // (a token captured by mc_decoder_generate with the deferred pick)
     if (!d->graph_exec) {
         d->drop_graph();
+        d->graph_lazy = false;
         MC_HIP(hipStreamBeginCapture(d->stream, hipStreamCaptureModeGlobal));
         const mc_status s2 = launches();
         const hipError_t e = hipStreamEndCapture(d->stream, &d->graph);

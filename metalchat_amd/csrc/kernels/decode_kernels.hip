@@ -108,13 +108,34 @@ mc_step_rope(step_state* st, int32_t rope_start)
 // max_seq > 0: the launch also ADVANCES the step state (what mc_step_advance does) -- chained generation then needs
 // no launch of its own for it.  The token was left by the previous step's pick and nothing else in this launch
 // reads the fields the advance writes, so workgroup 0's thread 0 can update them while every workgroup gathers.
+// keys != null (chained greedy generation, round 4): the previous step's pick has NOT been folded yet -- the head left one
+// (value, lowest index) key per workgroup (gemv.h EPI_STORE_PICK) -- and every workgroup of this launch folds the `nkeys` keys
+// itself (2 KB) instead of a one-workgroup mc_argmax_keys launch in front of it; thread 0 of the grid records the token where
+// mc_argmax_keys would have, BEFORE it advances the step.
 template <typename T>
 __device__ __forceinline__ void
 embed_body(const typename T::S* table, typename T::S* out, step_state* st, uint32_t dim,
-           float scale, int32_t use_scale, int32_t max_seq, int32_t pre_len)
+           float scale, int32_t use_scale, int32_t max_seq, int32_t pre_len, const unsigned long long* keys = nullptr,
+           uint32_t nkeys = 0, int32_t* tokens_out = nullptr)
 {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    const int32_t token = st->token;
+    int32_t token;
+    if (keys) { // (uniform)
+        __shared__ unsigned long long wk[16];
+        unsigned long long best = 0ull;
+        for (uint32_t i = threadIdx.x; i < nkeys; i += blockDim.x) best = max(best, keys[i]);
+        for (int off = 32; off >= 1; off >>= 1) best = max(best, (unsigned long long)__shfl_xor(best, off, 64));
+        if ((threadIdx.x & 63) == 0) wk[threadIdx.x >> 6] = best;
+        __syncthreads();
+        for (uint32_t w = 0; w < ((blockDim.x + 63) >> 6); w++) best = max(best, wk[w]);
+        token = (int32_t)(0xFFFFFFFFu - (uint32_t)best);
+        if (k == 0) {
+            st->token = token;
+            if (tokens_out) tokens_out[st->step_index] = token;
+        }
+    } else {
+        token = st->token;
+    }
     if (max_seq > 0 && k == 0) {
         st->pos += 1;
         st->step_index += 1;
@@ -126,15 +147,15 @@ embed_body(const typename T::S* table, typename T::S* out, step_state* st, uint3
 }
 extern "C" __global__ void
 mc_embed_bfloat(const bf16_t* table, bf16_t* out, step_state* st, uint32_t dim, float scale,
-                int32_t use_scale, int32_t max_seq, int32_t pre_len)
+                int32_t use_scale, int32_t max_seq, int32_t pre_len, const unsigned long long* keys, uint32_t nkeys, int32_t* tokens_out)
 {
-    embed_body<BF>(table, out, st, dim, scale, use_scale, max_seq, pre_len);
+    embed_body<BF>(table, out, st, dim, scale, use_scale, max_seq, pre_len, keys, nkeys, tokens_out);
 }
 extern "C" __global__ void
 mc_embed_float(const float* table, float* out, step_state* st, uint32_t dim, float scale,
-               int32_t use_scale, int32_t max_seq, int32_t pre_len)
+               int32_t use_scale, int32_t max_seq, int32_t pre_len, const unsigned long long* keys, uint32_t nkeys, int32_t* tokens_out)
 {
-    embed_body<F32>(table, out, st, dim, scale, use_scale, max_seq, pre_len);
+    embed_body<F32>(table, out, st, dim, scale, use_scale, max_seq, pre_len, keys, nkeys, tokens_out);
 }
 
 // quantization::lora_embedding (include/metalchat/quantization/lora.h:161-170): the table is
@@ -793,7 +814,13 @@ attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const
     __shared__ float inv_s[16];
     __shared__ __attribute__((aligned(16))) float ebuf[16 * ES];
 
-    const uint32_t kv = blockIdx.x % KV, split = blockIdx.x / KV;
+    // fastpath & 2 (the stand-alone attention launches only; host: handoff_mode()): the kv heads are dealt with a stride that is
+    // a multiple of 8 -- grid = nsplit x stride, workgroups whose slot has no head leave at once -- so that the workgroups of one
+    // head have equal blockIdx.x % 8 (one XCD in practice) whatever n_kv is: TinyLlama's 4 heads otherwise sit on two XCDs each
+    // and the XCD-local words are no use to half of every head's ranges
+    const uint32_t kv_stride = (fastpath & 2u) ? ((KV + 7u) & ~7u) : KV;
+    const uint32_t kv = blockIdx.x % kv_stride, split = blockIdx.x / kv_stride;
+    if (kv >= KV) return;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t col = lane & 15, c = lane >> 4;
     const uint32_t p_begin = split * PBW;

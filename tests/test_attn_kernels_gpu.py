@@ -66,7 +66,9 @@ CASES = [
     (16, 16, 256, 2048, 2048), (16, 16, 256, 2048, 130),
     (8, 2, 32, 512, 500), (16, 1, 128, 1024, 1024),
 ]
-@pytest.mark.parametrize("fast", [1, 0])   # hand-offs with / without the XCD-local fast path (handoff.h)
+# hand-offs with / without the XCD-local fast path (handoff.h); 3: with it AND the kv heads dealt with a stride of the next multiple
+# of 8 (grid = nsplit x stride, the workgroups without a head leave at once: decoder.cc handoff_mode_alone)
+@pytest.mark.parametrize("fast", [1, 0, 3])
 @pytest.mark.parametrize("H,KV,hd,max_seq,n", CASES + [(32, 8, 128, 8192, 8000)])
 def test_one_launch_attention_matches_the_oracle(acc, H, KV, hd, max_seq, n, fast):
     import metalchat_amd as mc
@@ -89,14 +91,15 @@ def test_one_launch_attention_matches_the_oracle(acc, H, KV, hd, max_seq, n, fas
     for epoch, layer_tag in ((1, 1), (1, 2), (2, 1), (7, 255)):
         out.upload(np.zeros(H * hd, np.uint16))
         state = state_buffer(acc, n, epoch)
-        mc.KernelTask(kern, (nsplit * KV * 256, 1, 1), (256, 1, 1),
+        stride = (KV + 7) // 8 * 8 if fast & 2 else KV
+        mc.KernelTask(kern, (nsplit * stride * 256, 1, 1), (256, 1, 1),
                       [qb, kc, vt, out, psum, slab, state, np.uint32(n_rep), np.uint32(KV), np.uint32(hd), np.uint32(max_seq),
                        np.float32(scale), np.uint32(nsplit), np.uint32(layer_tag), None, np.uint32(fast)])()
         acc.wait()
         assert int(state.download(np.int32, 12)[10]) == 0, "a hand-off of the launch gave up"
         got = out.download(np.uint16, H * hd)
         parity.check(BF16, got, ref, rel=2e-3, max_ulp=1, max_frac=0.03, scale_aware=True,
-                     what=f"one-launch attention H{H} KV{KV} hd{hd} n{n} tag ({epoch}, {layer_tag})")
+                     what=f"one-launch attention H{H} KV{KV} hd{hd} n{n} tag ({epoch}, {layer_tag}) mode {fast}")
 
 
 @pytest.mark.parametrize("H,KV,hd,max_seq,n", CASES)
