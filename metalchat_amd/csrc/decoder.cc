@@ -44,6 +44,8 @@ struct linear_w {
     int ngroups = 1;
     bool allocated = false;
     std::vector<uint8_t> scales_host; // shadow of the quad-interleaved scale buffer (load path only)
+    void* wq2 = nullptr;      // int4: the quad-interleaved copy short prompts multiply from (prefill_kernels.hip mc_pf2_*), built on demand
+    uint64_t wq2_gen = 0;     // ... from the weights of this generation (mc_decoder::weights_gen)
     // quantization::lora_adaptor(s) of the matrices fused here (quantization/lora.h:17-53): the A
     // matrices stacked [nseg*rank][in] (a T-format GEMV of its own), B in fused row order
     // [out][nseg*rank] with zeros outside each row's own adaptor columns, a = T(A x) in lora_vec
@@ -175,6 +177,8 @@ struct mc_decoder {
     void* hidden_in = nullptr;  // T[dim]   inbound row for non-first stages
     void* hidden_b = nullptr;   // T[dim]   gemma3: the row between the attention and the ffn half of a block
     const void* pending_pn = nullptr; // gemma3: postnorm_args the next pre-norm GEMV has to apply to `proj`
+    uint64_t weights_gen = 1;  // bumped whenever weight rows change: the derived copies (linear_w::wq2) are rebuilt
+    bool pf2_on = true;        // MC_PF2: short prompts from the quad-interleaved copy
     bool lazy_pick = false;    // inside mc_decoder_generate: the pick of a token is folded by the NEXT token's embedding launch
     bool lazy_pick_on = true;  // MC_LAZY_PICK
     bool graph_lazy = false;   // the captured token was recorded with lazy_pick
@@ -444,6 +448,7 @@ struct mc_decoder {
             const int head = r / perm_hd, w = r % perm_hd, half = perm_hd / 2;
             return (size_t)dst_row0 + (size_t)head * perm_hd + 2 * (w % half) + w / half;
         };
+        weights_gen++; // (derived copies of the weights -- linear_w::wq2 -- are rebuilt when next needed)
         const int in = L.in;
         const size_t sb = tb == 2 ? 2 : 4;
         const bool contiguous = dst_stride == 1; // destination rows form one block (maybe permuted)
@@ -1163,6 +1168,61 @@ struct mc_decoder {
         while (splits < 16 && tiles * splits < want && (unsigned)L.in / (splits * 2) >= 512) splits *= 2;
         return getenv("MC_PF_NO_SPLITK") ? 1u : splits;
     }
+    // Short prompts (<= 64 rows) on int4 weights: the weight-streaming GEMM over the quad-interleaved copy (prefill_kernels.hip
+    // mc_pf2_gemm_i4_bfloat: matrix-pipe dequantisation straight into MFMA operands, no LDS image of W)
+    bool
+    pf2_ok(const linear_w& L, int M) const
+    {
+        return pf2_on && tb == 2 && L.fmt == MC_WFMT_I4 && cfg.qmode == MC_QMODE_EXACT && M <= 64 && L.group == 128 && L.in % 128 == 0 &&
+               L.in >= 256;
+    }
+    mc_status
+    ensure_pf2(const linear_w& Lc)
+    {
+        linear_w& L = const_cast<linear_w&>(Lc);
+        if (L.wq2 && L.wq2_gen == weights_gen) return MC_OK;
+        const size_t bytes = (size_t)((L.out + 15) / 16) * (size_t)(L.in / 128) * 1024;
+        if (!L.wq2) {
+            mc_status s = alloc(&L.wq2, bytes, false);
+            if (s != MC_OK) return s;
+        }
+        mc_status s = launch("mc_pf2_repack_i4", 2048, 1, 1, 256, 0, pack((const void*)L.w, L.wq2, (uint32_t)L.out, (uint32_t)L.in));
+        if (s != MC_OK) return s;
+        L.wq2_gen = weights_gen;
+        return MC_OK;
+    }
+    // K ranges of the weight-streaming GEMM: enough workgroups for the chip, at least two steps of 128 each
+    void
+    pf2_split(const linear_w& L, unsigned& splits, unsigned& ktper) const
+    {
+        const unsigned nwg = ((unsigned)L.out + 127u) / 128u, KT = (unsigned)L.in / 128u;
+        const unsigned cus = (unsigned)dev->prop.multiProcessorCount;
+        splits = std::max(1u, std::min(16u, (cus + nwg - 1) / nwg));
+        ktper = std::max(2u, (KT + splits - 1) / splits);
+        splits = (KT + ktper - 1) / ktper;
+    }
+    mc_status
+    gemm_pf2(const linear_w& L, int epi, const void* X, void* Y, const void* res, int M, const void* la)
+    {
+        mc_status s = ensure_pf2(L);
+        if (s != MC_OK) return s;
+        unsigned splits, ktper;
+        pf2_split(L, splits, ktper);
+        const size_t need = (size_t)splits * M * L.out;
+        if (need > pf_part_elems) {
+            MC_HIP(hipStreamSynchronize(stream));
+            release((void**)&pf_part);
+            s = alloc((void**)&pf_part, need * 4, false);
+            if (s != MC_OK) return s;
+            pf_part_elems = need;
+        }
+        s = launch("mc_pf2_gemm_i4_" + tname, ((unsigned)L.out + 127u) / 128u, 1, splits, 512, 0,
+                   pack((const void*)L.wq2, (const void*)L.scales, X, (void*)pf_part, (uint32_t)M, (uint32_t)L.out, (uint32_t)L.in, ktper));
+        if (s != MC_OK) return s;
+        return launch("mc_pf_splitk_reduce_" + tname, (L.out + 255) / 256, M, 1, 256, 0,
+                      pack((const void*)pf_part, Y, epi == 1 ? res : (const void*)nullptr, (uint32_t)M, (uint32_t)L.out, splits, la,
+                           (const void*)L.lora_b, (uint32_t)L.lora_cols, L.lora_scale));
+    }
     mc_status
     gemm(const linear_w& L, int epi, const void* X, void* Y, const void* res, int M)
     {
@@ -1184,6 +1244,7 @@ struct mc_decoder {
         const bool big = tb == 2 && !getenv("MC_PF_SMALL_GEMM");
         const std::string f = L.fmt == MC_WFMT_I4 ? "i4_" : (L.fmt == MC_WFMT_I8 ? "i8_" : "w_");
         const void* la = L.lora_cols ? pf_lora : nullptr;
+        if (pf2_ok(L, M) && epi != 2) return gemm_pf2(L, epi, X, Y, res, M, la);
         // two K chunks in flight per workgroup (prefill_kernels.hip: measured best at every length);
         // MC_PF_DEPTH=1 selects the one-chunk build for A/B runs
         const char* depth_env = getenv("MC_PF_DEPTH");
@@ -1414,6 +1475,7 @@ mc_decoder_create(mc_device* dev, mc_library* lib, mc_queue* q, const mc_decoder
     if (const char* e = getenv("MC_ATTN_QKV")) d->attn_qkv_on = atoi(e) != 0;
     if (const char* e = getenv("MC_ATTN_QKN")) d->attn_qkn_on = atoi(e) != 0;
     if (const char* e = getenv("MC_LAZY_PICK")) d->lazy_pick_on = atoi(e) != 0;
+    if (const char* e = getenv("MC_PF2")) d->pf2_on = atoi(e) != 0;
     if (const char* e = getenv("MC_ATTN_FUSED_WGS")) d->attn_fused_max_wgs_per_cu = (unsigned)std::max(1, std::min(4, atoi(e)));
     if (const char* e = getenv("MC_LING_HALF")) d->ling_half = atoi(e) != 0;
     if (const char* e = getenv("MC_LIN_SPLIT")) d->lin_split = atoi(e) != 0;
@@ -1770,6 +1832,7 @@ mc_decoder_init_synthetic(mc_decoder* d, uint64_t seed)
 {
     if (!d) return fail(MC_ERR_INVALID_ARGUMENT, "mc_decoder_init_synthetic: null argument");
     MC_HIP(hipSetDevice(d->dev->ordinal));
+    d->weights_gen++;
     const mc_decoder_config& c = d->cfg;
     const int H = c.n_heads, KV = c.n_kv_heads, hd = c.head_dim;
     const int fmt = c.weight_format;

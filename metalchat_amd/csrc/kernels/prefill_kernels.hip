@@ -1126,3 +1126,156 @@ MC_PF_ATTN(256)
 // was built and measured: 2.6 vs 2.1 ms at M = 512 and 66 vs 61 ms whole-prompt at M = 2048.  The
 // L2 re-reads it saves are not what bounds this kernel; the two barriers per key block and the
 // causal imbalance between the waves of a block cost more.)
+
+// ==========================================================================================
+// Round 4: short prompts (M <= 64 rows) from a SECOND, quad-interleaved copy of the int4 weights.
+//
+// Why a second layout.  The decode GEMV dequantises on the matrix pipe (gemv.h m4b_dequant: a whole byte enters a 4x4x4 MFMA as a
+// subnormal bfloat16, B unmixes the nibbles and applies the scale, v_cvt_pk rounds -- Wd = T(T(q) T(s)) bit for bit, ~ 2.4 x
+// fewer issue slots than the vector path of pf_gemm_big_body above).  That MFMA transposes inside every quad of lanes: lane j
+// receives nibble kind j of the dwords of all four lanes i of its quad.  A dot product does not care; a 16x16x32 operand does --
+// its lane must end up with EIGHT CONSECUTIVE k of ONE weight row.  So the weights are stored a second time such that the
+// transposition produces exactly that: the 1 KiB of a (16 rows x 128 k) tile is [lane l = 16 g + c][dword d], and dword d of lane
+// (g, c = 4 q + i) holds the 4 x 2 mini tile  rows 16 nt + 4 q + j (j = nibble kind), k = 128 kt + 32 d + 8 g + i  and  + 4.
+// One 16-byte load per lane and m4b_dequant then leave, in lane (g, c), four B operands: row c, k = 32 d + 8 g .. + 7, d = 0..3 --
+// no LDS image of W, no barrier for it, and every weight is dequantised by exactly one wave.  288 GB of HBM pay for the copy
+// (4 GB for Llama-3-8B), built on the device from the canonical rows when the first short prompt arrives (mc_pf2_repack_i4).
+//
+// The kernel: workgroup = 8 waves = 128 weight rows (wave w: rows 16 (8 bx + w) ..), all M <= 64 prompt rows, one K range of the
+// split (grid.z); per 128-k step a wave loads its 1 KiB of weights straight into registers (four steps in flight), the
+// workgroup stages the X tile (16 MT x 128, two LDS images: one barrier per step) and every wave multiplies MT x 4 MFMAs.  Partial
+// sums (fp32, [z][M][N]) go to mc_pf_splitk_reduce_T, which rounds, adapts and adds the residual as for the big GEMM.
+// Numerics: Wd is the exact dequantisation at 2^-M4B_Q (gemv.h); the fp32 sums are multiplied by 2^M4B_Q once -- a power of two.
+// (Tried: the reduce inside the GEMM -- the last workgroup of a column block adds the partials behind an agent-scope
+//  release / acquire pair: parity-green and 99.6 us per launch instead of 14.6: an agent-scope fence writes back / invalidates
+//  an XCD's L2 and costs ~ 5 us per wave that executes it -- more than the reduce launch it replaces.)
+// ==========================================================================================
+extern "C" __global__ void
+mc_pf2_repack_i4(const uint32_t* __restrict__ w, uint32_t* __restrict__ out, uint32_t N, uint32_t K)
+{
+    const uint32_t KT = K / 128, NT = (N + 15) / 16;
+    const size_t total = (size_t)NT * KT * 256;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t d = idx & 3, lane = (idx >> 2) & 63;
+        const size_t tile = idx >> 8;
+        const uint32_t kt = (uint32_t)(tile % KT), nt = (uint32_t)(tile / KT);
+        const uint32_t g = lane >> 4, c = lane & 15, i = c & 3, q = c >> 2;
+        uint32_t v = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < 4; j++) {
+            const uint32_t row = 16 * nt + 4 * q + j;
+#pragma unroll
+            for (uint32_t h = 0; h < 2; h++) {
+                const uint32_t k = 128 * kt + 32 * d + 8 * g + i + 4 * h;
+                // canonical rows: dword k / 8 of a row, weight 2 p -> nibble p, weight 2 p + 1 -> nibble p + 4 (pf_gemm_big_body)
+                const uint32_t src = row < N ? w[(size_t)row * (K / 8) + k / 8] : 0x88888888u; // (rows past N: q = 0)
+                const uint32_t wq = k & 7, nib = (wq & 1) ? (wq >> 1) + 4 : (wq >> 1);
+                const uint32_t val = (src >> (4 * nib)) & 15u;
+                // nibble kinds of the dequantising MFMAs (gemv.h): first (n0, n4, n1, n5) -> j = 0..3, second (n2, n6, n3, n7)
+                const uint32_t pos = h == 0 ? (j == 0 ? 0u : j == 1 ? 4u : j == 2 ? 1u : 5u) : (j == 0 ? 2u : j == 1 ? 6u : j == 2 ? 3u : 7u);
+                v |= val << (4 * pos);
+            }
+        }
+        out[idx] = v;
+    }
+}
+
+constexpr uint32_t PF2_K = 128, PF2_LD = PF2_K + 8;
+constexpr int PF2_DEPTH = 4; // K steps of weights in flight per wave (1 KiB each: a lone step in flight left the CU waiting on HBM latency)
+// MT: 16-row tiles of X (M <= 16 MT)
+template <int MT>
+__device__ __forceinline__ void
+pf2_gemm_body(const uint4* __restrict__ wq, const void* __restrict__ sp, const bf16_t* __restrict__ X, float* __restrict__ part,
+              uint32_t M, uint32_t N, uint32_t K, uint32_t ktper)
+{
+    using namespace mc::gemv;
+    constexpr uint32_t ROWS = 16u * MT;
+    __shared__ __attribute__((aligned(16))) bf16_t Xs[2][ROWS * PF2_LD];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t KT = K / PF2_K, NT = (N + 15) / 16, ngroups = KT; // (scale groups of 128 = one K step)
+    const uint32_t nt_raw = blockIdx.x * 8 + wave, nt = nt_raw < NT ? nt_raw : NT - 1;
+    const uint32_t kt0 = blockIdx.z * ktper, kt1 = min(KT, kt0 + ktper);
+    const uint32_t g = lane >> 4, c = lane & 15;
+    const uint32_t wrow = min(16 * nt + c, N - 1); // the weight row this lane's operands belong to (its scale)
+    // staging of X: a 16-byte packet = 8 k of a row; ROWS x 16 packets per step over 512 threads
+    constexpr int XP = (int)((ROWS * 16 + 511) / 512); // packets per thread: 1 (MT <= 2) or 2
+    const m4b_lane m4bk = m4b_lane_consts(lane);
+    const uint4* wsrc = wq + ((size_t)nt * KT) * 64 + lane;
+
+    pf_f32x4 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) acc[mt] = pf_f32x4{0, 0, 0, 0};
+    uint4 xn[XP], wn[PF2_DEPTH];
+    float sn[PF2_DEPTH];
+    auto fetch_w = [&](int slot, uint32_t kt) { // (unconditional, clamped: a step past the range is never consumed)
+        const uint32_t kc = kt < KT ? kt : KT - 1;
+        wn[slot] = wsrc[(size_t)kc * 64];
+        sn[slot] = pf_scale<PF_W_I4, BF>(sp, wrow, kc, ngroups);
+    };
+    auto fetch_x = [&](uint32_t kt) {
+        const uint32_t kc = kt < KT ? kt : KT - 1;
+#pragma unroll
+        for (int i = 0; i < XP; i++) {
+            const uint32_t p = tid + 512u * i, row = min(p >> 4, ROWS - 1), k8 = (p & 15) * 8;
+            xn[i] = *reinterpret_cast<const uint4*>(X + (size_t)(row < M ? row : M - 1) * K + (size_t)kc * PF2_K + k8);
+        }
+    };
+#pragma unroll
+    for (int dpt = 0; dpt < PF2_DEPTH; dpt++) fetch_w(dpt, kt0 + dpt);
+    fetch_x(kt0);
+    uint32_t buf = 0;
+    auto step = [&](auto slot_c, uint32_t kt) {
+        constexpr int slot = decltype(slot_c)::value;
+#pragma unroll
+        for (int i = 0; i < XP; i++) {
+            const uint32_t p = tid + 512u * i, row = p >> 4, k8 = (p & 15) * 8;
+            if (row < ROWS) {
+                const uint32_t live = row < M ? 0xFFFFFFFFu : 0u; // rows past M: zeros
+                *reinterpret_cast<uint4*>(&Xs[buf][row * PF2_LD + k8]) = make_uint4(xn[i].x & live, xn[i].y & live, xn[i].z & live, xn[i].w & live);
+            }
+        }
+        const uint4 wc = wn[slot];
+        const float sc = kt < kt1 ? sn[slot] : 0.0f; // (a step past the range: a zero scale dequantises to zeros)
+        __syncthreads(); // image `buf` is complete; the reads of image `buf ^ 1` (the previous step) are all behind it
+        fetch_x(kt + 1);
+        fetch_w(slot, kt + PF2_DEPTH);
+        uint2 dq[8];
+        m4b_dequant(dq, wc, m4b_prepare(__float_as_uint(sc), m4bk));
+        const bf16_t* xs = &Xs[buf][c * PF2_LD + 8 * g];
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            const uint4 b = make_uint4(dq[2 * d].x, dq[2 * d].y, dq[2 * d + 1].x, dq[2 * d + 1].y);
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) {
+                const uint4 a = *reinterpret_cast<const uint4*>(xs + mt * 16 * PF2_LD + 32 * d);
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(pf_bf16x8, a), __builtin_bit_cast(pf_bf16x8, b),
+                                                                 acc[mt], 0, 0, 0);
+            }
+        }
+        buf ^= 1;
+    };
+    // (the ring slot of a step is a compile-time constant: whole groups of PF2_DEPTH steps, straight-line -- a load behind a
+    //  branch costs every counted wait; a step past the range adds zeros)
+    for (uint32_t kt = kt0; kt < kt1; kt += PF2_DEPTH) {
+        step(std::integral_constant<int, 0>{}, kt);
+        step(std::integral_constant<int, 1>{}, kt + 1);
+        step(std::integral_constant<int, 2>{}, kt + 2);
+        step(std::integral_constant<int, 3>{}, kt + 3);
+    }
+    if (nt_raw >= NT) return;
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t m = mt * 16 + g * 4 + i, n = 16 * nt + c;
+            if (m < M && n < N) part[((size_t)blockIdx.z * M + m) * N + n] = acc[mt][i] * 0x1p37f; // 2^M4B_Q
+        }
+}
+extern "C" __global__ void __launch_bounds__(512)
+mc_pf2_gemm_i4_bfloat(const uint4* __restrict__ wq, const void* __restrict__ sp, const bf16_t* __restrict__ X, float* __restrict__ part,
+                      uint32_t M, uint32_t N, uint32_t K, uint32_t ktper)
+{
+    if (M <= 16) pf2_gemm_body<1>(wq, sp, X, part, M, N, K, ktper);
+    else if (M <= 32) pf2_gemm_body<2>(wq, sp, X, part, M, N, K, ktper);
+    else pf2_gemm_body<4>(wq, sp, X, part, M, N, K, ktper);
+}

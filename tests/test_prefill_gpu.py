@@ -282,3 +282,55 @@ def test_prompt_pass_through_a_local_pipeline_equals_the_single_stage(acc):
         for d in stages:
             d.release()
     single.release()
+
+
+@pytest.mark.parametrize("n", [2, 8, 33, 64])
+def test_short_prompt_takes_the_weight_streaming_gemm(acc, n, monkeypatch):
+    """Prompts of up to 64 rows on int4 weights with scale groups of 128 multiply from the quad-interleaved copy of the weights
+    (prefill_kernels.hip mc_pf2_gemm_i4_bfloat: matrix-pipe dequantisation straight into MFMA operands; the copy is built by
+    mc_pf2_repack_i4 when the first such prompt arrives): against the oracle like every prompt pass, with adaptors (the reduce
+    epilogue carries them), K = 1024 / 2048 (8 and 16 steps of 128, split over the grid) -- and the launch log must name the
+    kernels.  A 65-row prompt takes the tiled GEMM again; weights uploaded afterwards rebuild the copy."""
+    import metalchat_amd as mc
+
+    cfg = mg.tiny_cfg(BF16, dim=1024, n_heads=8, n_kv_heads=2, head_dim=128, ffn_dim=2048, n_layers=2, vocab=512, max_seq_len=96)
+    weights = mg.make_model(cfg, seed=81, quant="i4", group=128, lora_rank=8)
+    tokens = np.random.default_rng(n).integers(0, cfg["vocab"], n).tolist()
+    check_against_oracle(acc, cfg, weights, dict(weight_format=2, group_size=128), tokens, follow=1)
+    dec = mc.Decoder(acc, **mg.decoder_kwargs(cfg, weight_format=2, group_size=128))
+    dec.load_model(weights)
+    dec.launch_log(True)
+    t_new = dec.prefill(tokens, 0)
+    names = set(dec.launched())
+    assert "mc_pf2_gemm_i4_bfloat" in names and "mc_pf2_repack_i4" in names, sorted(names)
+    logits_new = dec.logits().copy()
+    dec.launch_log(True)
+    dec.prefill(tokens, 0)
+    assert "mc_pf2_repack_i4" not in set(dec.launched()), "the copy is built once"
+    dec.launch_log(True)
+    dec.prefill(np.random.default_rng(1).integers(0, cfg["vocab"], 65).tolist(), 0)
+    assert "mc_pf2_gemm_i4_bfloat" not in set(dec.launched())
+    # new weights: the copy follows
+    w2 = mg.make_model(cfg, seed=82, quant="i4", group=128, lora_rank=8)
+    dec.load_model(w2)
+    dec.launch_log(True)
+    dec.prefill(tokens, 0)
+    assert "mc_pf2_repack_i4" in set(dec.launched())
+    got2 = dec.logits().copy()
+    dec.release()
+    # ... and equals a decoder that never saw the first weights, bit for bit; the tiled GEMM (MC_PF2=0) within the suite's bound
+    fresh = mc.Decoder(acc, **mg.decoder_kwargs(cfg, weight_format=2, group_size=128))
+    fresh.load_model(w2)
+    fresh.prefill(tokens, 0)
+    parity.exact(got2, fresh.logits(), "logits after a weight reload")
+    fresh.release()
+    monkeypatch.setenv("MC_PF2", "0")
+    old = mc.Decoder(acc, **mg.decoder_kwargs(cfg, weight_format=2, group_size=128))
+    old.load_model(weights)
+    old.launch_log(True)
+    t_old = old.prefill(tokens, 0)
+    assert "mc_pf2_gemm_i4_bfloat" not in set(old.launched())
+    rel, frac = tol(BF16)
+    parity.check(BF16, logits_new, old.logits(), rel=rel, max_ulp=2, max_frac=frac, what="weight-streaming GEMM vs tiled GEMM")
+    old.release()
+    assert t_new is not None and t_old is not None
