@@ -179,6 +179,8 @@ struct mc_decoder {
     const void* pending_pn = nullptr; // gemma3: postnorm_args the next pre-norm GEMV has to apply to `proj`
     uint64_t weights_gen = 1;  // bumped whenever weight rows change: the derived copies (linear_w::wq2) are rebuilt
     bool pf2_on = true;        // MC_PF2: short prompts from the quad-interleaved copy
+    bool pf3_on = true;        // MC_PF3: prompts of more than 64 rows on the quad-interleaved copy as well
+    bool pf_fold_on = true;    // MC_PF_FOLD: the split-K reduce of a prompt GEMM inside the kernel that consumes its rows
     bool lazy_pick = false;    // inside mc_decoder_generate: the pick of a token is folded by the NEXT token's embedding launch
     bool lazy_pick_on = true;  // MC_LAZY_PICK
     bool graph_lazy = false;   // the captured token was recorded with lazy_pick
@@ -1161,7 +1163,7 @@ struct mc_decoder {
     unsigned
     gemm_splits(const linear_w& L, int M) const
     {
-        const unsigned bm = gemm_row_tile(M);
+        const unsigned bm = pf3_ok(L, M) ? 128u : gemm_row_tile(M);
         const unsigned tiles = ((L.out + 127) / 128) * ((M + bm - 1) / bm);
         const unsigned want = (bm == 256 ? 1u : 2u) * (unsigned)dev->prop.multiProcessorCount; // (256 rows: one 8-wave workgroup per CU)
         unsigned splits = 1;
@@ -1175,6 +1177,13 @@ struct mc_decoder {
     {
         return pf2_on && tb == 2 && L.fmt == MC_WFMT_I4 && cfg.qmode == MC_QMODE_EXACT && M <= 64 && L.group == 128 && L.in % 128 == 0 &&
                L.in >= 256;
+    }
+    // ... and longer prompts: the tiled GEMM whose W operands are dequantised on the matrix pipe from the same copy (mc_pf3_gemm_*)
+    bool
+    pf3_ok(const linear_w& L, int M) const
+    {
+        return pf3_on && tb == 2 && L.fmt == MC_WFMT_I4 && cfg.qmode == MC_QMODE_EXACT && M > 64 && L.group == 128 && L.in % 128 == 0 &&
+               L.in >= 256 && !getenv("MC_PF_SMALL_GEMM");
     }
     mc_status
     ensure_pf2(const linear_w& Lc)
@@ -1197,7 +1206,9 @@ struct mc_decoder {
     {
         const unsigned nwg = ((unsigned)L.out + 127u) / 128u, KT = (unsigned)L.in / 128u;
         const unsigned cus = (unsigned)dev->prop.multiProcessorCount;
-        splits = std::max(1u, std::min(16u, (cus + nwg - 1) / nwg));
+        const char* te = getenv("MC_PF2_WGS_PER_CU");
+        const unsigned target = cus * (te ? (unsigned)std::max(1, atoi(te)) : 1u);
+        splits = std::max(1u, std::min(16u, (target + nwg - 1) / nwg));
         ktper = std::max(2u, (KT + splits - 1) / splits);
         splits = (KT + ktper - 1) / ktper;
     }
@@ -1223,6 +1234,57 @@ struct mc_decoder {
                       pack((const void*)pf_part, Y, epi == 1 ? res : (const void*)nullptr, (uint32_t)M, (uint32_t)L.out, splits, la,
                            (const void*)L.lora_b, (uint32_t)L.lora_cols, L.lora_scale));
     }
+    // A prompt GEMM that splits K, stopped at its fp32 partial sums (pf_part, [splits][M][out]): the kernel that consumes the rows
+    // adds them itself (prefill_kernels.hip mc_pf_*_parts_bfloat) and the reduce launch is saved.  false: this matrix at this M
+    // does not split (or carries an adaptor, or T = float): the caller takes gemm().
+    bool
+    gemm_to_parts(const linear_w& L, const void* X, int M, unsigned* splits_out, mc_status* st)
+    {
+        *st = MC_OK;
+        if (!pf_fold_on || tb != 2 || L.lora_cols || getenv("MC_PF_SMALL_GEMM")) return false;
+        const bool small = pf2_ok(L, M);
+        unsigned splits = 1, ktper = 0;
+        if (small) pf2_split(L, splits, ktper);
+        else splits = gemm_splits(L, M);
+        if (splits < 2) return false;
+        const size_t need = (size_t)splits * M * L.out;
+        if (need > pf_part_elems) {
+            const hipError_t e = hipStreamSynchronize(stream);
+            if (e != hipSuccess) {
+                *st = hip_fail(e, "hipStreamSynchronize");
+                return true;
+            }
+            release((void**)&pf_part);
+            *st = alloc((void**)&pf_part, need * 4, false);
+            if (*st != MC_OK) return true;
+            pf_part_elems = need;
+        }
+        *splits_out = splits;
+        if (small) {
+            *st = ensure_pf2(L);
+            if (*st != MC_OK) return true;
+            *st = launch("mc_pf2_gemm_i4_" + tname, ((unsigned)L.out + 127u) / 128u, 1, splits, 512, 0,
+                         pack((const void*)L.wq2, (const void*)L.scales, X, (void*)pf_part, (uint32_t)M, (uint32_t)L.out, (uint32_t)L.in, ktper));
+            return true;
+        }
+        if (pf3_ok(L, M)) {
+            *st = ensure_pf2(L);
+            if (*st != MC_OK) return true;
+            *st = launch("mc_pf3_gemm_i4_" + tname + "_e2", (L.out + 127) / 128, (M + 127) / 128, splits, 256, 0,
+                         pack((const void*)L.wq2, L.scales, X, (void*)pf_part, (const void*)nullptr, (uint32_t)M, (uint32_t)L.out, (uint32_t)L.in,
+                              (uint32_t)L.group, (const void*)nullptr, (const void*)nullptr, (uint32_t)0, 0.0f));
+            return true;
+        }
+        const std::string f = L.fmt == MC_WFMT_I4 ? "i4_" : (L.fmt == MC_WFMT_I8 ? "i8_" : "w_");
+        const char* depth_env = getenv("MC_PF_DEPTH");
+        const std::string deep = depth_env && atoi(depth_env) == 1 ? "" : "_d2";
+        const unsigned bm = gemm_row_tile(M);
+        *st = launch(std::string(bm == 256 ? "mc_pf_gemm256_" : "mc_pf_gemm128_") + f + tname + deep + "_e2", (L.out + 127) / 128, (M + bm - 1) / bm,
+                     splits, 2 * bm, 0,
+                     pack(L.w, L.scales, X, (void*)pf_part, (const void*)nullptr, (uint32_t)M, (uint32_t)L.out, (uint32_t)L.in,
+                          (uint32_t)L.group, (const void*)nullptr, (const void*)nullptr, (uint32_t)0, 0.0f));
+        return true;
+    }
     mc_status
     gemm(const linear_w& L, int epi, const void* X, void* Y, const void* res, int M)
     {
@@ -1245,6 +1307,31 @@ struct mc_decoder {
         const std::string f = L.fmt == MC_WFMT_I4 ? "i4_" : (L.fmt == MC_WFMT_I8 ? "i8_" : "w_");
         const void* la = L.lora_cols ? pf_lora : nullptr;
         if (pf2_ok(L, M) && epi != 2) return gemm_pf2(L, epi, X, Y, res, M, la);
+        if (pf3_ok(L, M) && epi != 2) {
+            mc_status s = ensure_pf2(L);
+            if (s != MC_OK) return s;
+            const unsigned splits = gemm_splits(L, M);
+            if (splits > 1) {
+                const size_t need = (size_t)splits * M * L.out;
+                if (need > pf_part_elems) {
+                    MC_HIP(hipStreamSynchronize(stream));
+                    release((void**)&pf_part);
+                    s = alloc((void**)&pf_part, need * 4, false);
+                    if (s != MC_OK) return s;
+                    pf_part_elems = need;
+                }
+                s = launch("mc_pf3_gemm_i4_" + tname + "_e2", (L.out + 127) / 128, (M + 127) / 128, splits, 256, 0,
+                           pack((const void*)L.wq2, L.scales, X, (void*)pf_part, (const void*)nullptr, (uint32_t)M, (uint32_t)L.out,
+                                (uint32_t)L.in, (uint32_t)L.group, (const void*)nullptr, (const void*)nullptr, (uint32_t)0, 0.0f));
+                if (s != MC_OK) return s;
+                return launch("mc_pf_splitk_reduce_" + tname, (L.out + 255) / 256, M, 1, 256, 0,
+                              pack((const void*)pf_part, Y, epi == 1 ? res : (const void*)nullptr, (uint32_t)M, (uint32_t)L.out, splits, la,
+                                   (const void*)L.lora_b, (uint32_t)L.lora_cols, L.lora_scale));
+            }
+            return launch("mc_pf3_gemm_i4_" + tname + "_e" + std::to_string(epi), (L.out + 127) / 128, (M + 127) / 128, 1, 256, 0,
+                          pack((const void*)L.wq2, L.scales, X, Y, res, (uint32_t)M, (uint32_t)L.out, (uint32_t)L.in, (uint32_t)L.group, la,
+                               (const void*)L.lora_b, (uint32_t)L.lora_cols, L.lora_scale));
+        }
         // two K chunks in flight per workgroup (prefill_kernels.hip: measured best at every length);
         // MC_PF_DEPTH=1 selects the one-chunk build for A/B runs
         const char* depth_env = getenv("MC_PF_DEPTH");
@@ -1321,16 +1408,33 @@ struct mc_decoder {
         if (s != MC_OK) return s;
         const size_t last = (size_t)(M - 1) * dim * tb;
         if (want_taps) MC_HIP(hipMemcpyAsync(taps, (char*)pf_x + last, (size_t)dim * tb, hipMemcpyDeviceToDevice, stream));
+        // (round 4) a GEMM that splits K hands its fp32 partial sums straight to the kernel that consumes its rows -- rope + cache
+        // write, the next rmsnorm (with the residual), act * mul -- instead of to a reduce launch: gemm_to_parts
+        const bool fold_norm = dim % 8 == 0 && dim / 8 <= 4 * 256;
+        bool xn_ready = false; // pf_xn already holds this block's normalised input (the previous block's w2 consumer wrote it)
+        unsigned sp = 1;
+        mc_status gs;
         for (int li = 0; li < n_own; li++) {
             layer_w& L = layers[li];
-            s = timed("norm", [&] { return norm_rows(pf_x, L.attention_norm, nullptr, pf_xn, M, mu); });
-            if (s != MC_OK) return s;
-            s = timed("gemm_qkv", [&] { return gemm(L.qkv, 0, pf_xn, pf_qkv, nullptr, M); });
-            if (s != MC_OK) return s;
-            s = timed("rope_cache", [&] { return launch("mc_pf_rope_cache_" + tname, H + 2 * KV, M, 1, hd / 2, 0,
-                       pack(pf_qkv, pf_q, L.kc, L.vt, rope_cos[L.rope_table], rope_sin[L.rope_table], L.q_norm,
-                            L.k_norm, (uint32_t)H, (uint32_t)KV, (uint32_t)hd, (uint32_t)cfg.max_seq_len,
-                            (uint32_t)start_pos, (uint32_t)(rope_pos - rope_start), cfg.norm_eps, mu)); });
+            if (!xn_ready) {
+                s = timed("norm", [&] { return norm_rows(pf_x, L.attention_norm, nullptr, pf_xn, M, mu); });
+                if (s != MC_OK) return s;
+            }
+            xn_ready = false;
+            if (gemm_to_parts(L.qkv, pf_xn, M, &sp, &gs)) {
+                if (gs != MC_OK) return gs;
+                s = timed("rope_cache", [&] { return launch("mc_pf_rope_cache_parts_" + tname, H + 2 * KV, M, 1, hd / 2, 0,
+                           pack((const void*)pf_part, sp, (uint32_t)M, pf_q, L.kc, L.vt, rope_cos[L.rope_table], rope_sin[L.rope_table], L.q_norm,
+                                L.k_norm, (uint32_t)H, (uint32_t)KV, (uint32_t)hd, (uint32_t)cfg.max_seq_len,
+                                (uint32_t)start_pos, (uint32_t)(rope_pos - rope_start), cfg.norm_eps, mu)); });
+            } else {
+                s = timed("gemm_qkv", [&] { return gemm(L.qkv, 0, pf_xn, pf_qkv, nullptr, M); });
+                if (s != MC_OK) return s;
+                s = timed("rope_cache", [&] { return launch("mc_pf_rope_cache_" + tname, H + 2 * KV, M, 1, hd / 2, 0,
+                           pack(pf_qkv, pf_q, L.kc, L.vt, rope_cos[L.rope_table], rope_sin[L.rope_table], L.q_norm,
+                                L.k_norm, (uint32_t)H, (uint32_t)KV, (uint32_t)hd, (uint32_t)cfg.max_seq_len,
+                                (uint32_t)start_pos, (uint32_t)(rope_pos - rope_start), cfg.norm_eps, mu)); });
+            }
             if (s != MC_OK) return s;
             const uint32_t win = (gemma && L.rope_table == 1) ? (uint32_t)window : 0u;
             if (tb == 2 && !pf_two_pass) {
@@ -1362,25 +1466,46 @@ struct mc_decoder {
                 s = timed("gemm_wo", [&] { return gemm(L.wo, 0, pf_att, pf_proj, nullptr, M); });
                 if (s != MC_OK) return s;
                 s = norm_rows(pf_proj, L.attention_post_norm, pf_x, pf_h, M, mu);
+                if (s != MC_OK) return s;
+                s = timed("norm", [&] { return norm_rows(pf_h, L.ffn_norm, nullptr, pf_xn, M, mu); });
+            } else if (fold_norm && gemm_to_parts(L.wo, pf_att, M, &sp, &gs)) {
+                if (gs != MC_OK) return gs;
+                // h = T(x + T(sum of the partials)) -> pf_h, rmsnorm(h) -> pf_xn: the reduce, the residual and the ffn norm in one launch
+                s = timed("norm", [&] { return launch("mc_pf_rmsnorm_parts_" + tname, M, 1, 1, 256, 0,
+                           pack((const void*)pf_part, sp, (uint32_t)M, (const void*)pf_x, pf_h, (const void*)L.ffn_norm, pf_xn, (uint32_t)dim,
+                                cfg.norm_eps, mu)); });
             } else {
                 s = timed("gemm_wo", [&] { return gemm(L.wo, 1, pf_att, pf_h, pf_x, M); });
+                if (s != MC_OK) return s;
+                s = timed("norm", [&] { return norm_rows(pf_h, L.ffn_norm, nullptr, pf_xn, M, mu); });
             }
-            if (s != MC_OK) return s;
-            s = timed("norm", [&] { return norm_rows(pf_h, L.ffn_norm, nullptr, pf_xn, M, mu); });
             if (s != MC_OK) return s;
             // (act(w1 x) * (w3 x) in the GEMM's epilogue was built -- the even lane of a column pair finishing it -- and measured
             //  SLOWER: 13.60 against 13.26 ms per 512-row prompt, 52.0 against 50.6 at 2048 rows: half the lanes idle through the
             //  fp64 exponential, in the kernel that holds the matrix pipe)
-            s = timed("gemm_w13", [&] { return gemm(L.w13, 0, pf_xn, pf_g2, nullptr, M); });
-            if (s != MC_OK) return s;
             const unsigned act_pp = 8u / (unsigned)tb; // pairs per thread (one 16-byte packet)
-            s = timed("act_mul", [&] { return launch("mc_pf_act_mul_" + tname, (cfg.ffn_dim / act_pp + 255) / 256 + 1, M, 1, 256, 0,
-                       pack(pf_g2, pf_g, (uint32_t)cfg.ffn_dim, (int32_t)(gemma ? 1 : 0))); });
+            if (cfg.ffn_dim % 4 == 0 && gemm_to_parts(L.w13, pf_xn, M, &sp, &gs)) {
+                if (gs != MC_OK) return gs;
+                s = timed("act_mul", [&] { return launch("mc_pf_act_mul_parts_" + tname, (cfg.ffn_dim / 4 + 255) / 256 + 1, M, 1, 256, 0,
+                           pack((const void*)pf_part, sp, (uint32_t)M, pf_g, (uint32_t)cfg.ffn_dim, (int32_t)(gemma ? 1 : 0))); });
+            } else {
+                s = timed("gemm_w13", [&] { return gemm(L.w13, 0, pf_xn, pf_g2, nullptr, M); });
+                if (s != MC_OK) return s;
+                s = timed("act_mul", [&] { return launch("mc_pf_act_mul_" + tname, (cfg.ffn_dim / act_pp + 255) / 256 + 1, M, 1, 256, 0,
+                           pack(pf_g2, pf_g, (uint32_t)cfg.ffn_dim, (int32_t)(gemma ? 1 : 0))); });
+            }
             if (s != MC_OK) return s;
             if (L.ffn_post_norm) {
                 s = timed("gemm_w2", [&] { return gemm(L.w2, 0, pf_g, pf_proj, nullptr, M); });
                 if (s != MC_OK) return s;
                 s = norm_rows(pf_proj, L.ffn_post_norm, pf_h, pf_x, M, mu);
+            } else if (fold_norm && li + 1 < n_own && gemm_to_parts(L.w2, pf_g, M, &sp, &gs)) {
+                if (gs != MC_OK) return gs;
+                // x = T(h + T(sum)) -> pf_x (the block's output), and the NEXT block's attention norm of it -> pf_xn
+                s = timed("norm", [&] { return launch("mc_pf_rmsnorm_parts_" + tname, M, 1, 1, 256, 0,
+                           pack((const void*)pf_part, sp, (uint32_t)M, (const void*)pf_h, pf_x, (const void*)layers[li + 1].attention_norm, pf_xn,
+                                (uint32_t)dim, cfg.norm_eps, mu)); });
+                xn_ready = true;
             } else {
                 s = timed("gemm_w2", [&] { return gemm(L.w2, 1, pf_g, pf_x, pf_h, M); });
             }
@@ -1476,6 +1601,8 @@ mc_decoder_create(mc_device* dev, mc_library* lib, mc_queue* q, const mc_decoder
     if (const char* e = getenv("MC_ATTN_QKN")) d->attn_qkn_on = atoi(e) != 0;
     if (const char* e = getenv("MC_LAZY_PICK")) d->lazy_pick_on = atoi(e) != 0;
     if (const char* e = getenv("MC_PF2")) d->pf2_on = atoi(e) != 0;
+    if (const char* e = getenv("MC_PF_FOLD")) d->pf_fold_on = atoi(e) != 0;
+    if (const char* e = getenv("MC_PF3")) d->pf3_on = atoi(e) != 0;
     if (const char* e = getenv("MC_ATTN_FUSED_WGS")) d->attn_fused_max_wgs_per_cu = (unsigned)std::max(1, std::min(4, atoi(e)));
     if (const char* e = getenv("MC_LING_HALF")) d->ling_half = atoi(e) != 0;
     if (const char* e = getenv("MC_LIN_SPLIT")) d->lin_split = atoi(e) != 0;

@@ -1279,3 +1279,248 @@ mc_pf2_gemm_i4_bfloat(const uint4* __restrict__ wq, const void* __restrict__ sp,
     else if (M <= 32) pf2_gemm_body<2>(wq, sp, X, part, M, N, K, ktper);
     else pf2_gemm_body<4>(wq, sp, X, part, M, N, K, ktper);
 }
+
+// ==========================================================================================
+// Round 4: the split-K reduce FOLDED INTO THE CONSUMER of a prompt GEMM.  A GEMM that splits K leaves fp32 partial sums
+// [z][M][N]; mc_pf_splitk_reduce_T turned them into rows for a kernel that read them once -- four launches of ~ 5-11 us per
+// block.  These are the consumers with the reduce as their first step: T(sum over z, in z order) -- exactly the value the reduce
+// stored -- so every row downstream is bit for bit what it was.  (bfloat rows, no adaptor: decoder.cc gemm_to_parts.)
+// ==========================================================================================
+__device__ __forceinline__ float
+pf_part_sum(const float* part, uint32_t splits, size_t zstride, size_t idx)
+{
+    float a = 0.0f;
+    for (uint32_t z = 0; z < splits; z++) a += part[(size_t)z * zstride + idx];
+    return bf2f(f2bf(a));
+}
+// wq|wk|wv partials -> q/k norm, rope, cache write (mc_pf_rope_cache_bfloat with the reduce in front)
+extern "C" __global__ void
+mc_pf_rope_cache_parts_bfloat(const float* part, uint32_t splits, uint32_t M, bf16_t* q_out, bf16_t* kc, bf16_t* vt, const float* fcos,
+                              const float* fsin, const bf16_t* q_norm, const bf16_t* k_norm, uint32_t H, uint32_t KV, uint32_t hd,
+                              uint32_t max_seq, uint32_t start_pos, uint32_t rope_row0, float eps, float mu)
+{
+    __shared__ float red[16];
+    const uint32_t b = blockIdx.x, r = blockIdx.y, j = threadIdx.x, half = hd / 2;
+    const uint32_t slot = start_pos + r, NQ = (H + 2 * KV) * hd;
+    const size_t zs = (size_t)M * NQ, row = (size_t)r * NQ;
+    if (b >= H + KV) {
+        const uint32_t kv = b - H - KV;
+        const size_t src = row + (size_t)(H + KV + kv) * hd;
+        bf16_t* dst = vt + (size_t)kv * hd * max_seq;
+        dst[(size_t)j * max_seq + slot] = f2bf(pf_part_sum(part, splits, zs, src + j));
+        dst[(size_t)(j + half) * max_seq + slot] = f2bf(pf_part_sum(part, splits, zs, src + j + half));
+        return;
+    }
+    const bool is_q = b < H;
+    const size_t src = row + (size_t)b * hd;
+    float x1 = pf_part_sum(part, splits, zs, src + 2 * j), x2 = pf_part_sum(part, splits, zs, src + 2 * j + 1);
+    const bf16_t* nw = is_q ? q_norm : k_norm;
+    if (nw) {
+        const float tot = block_sum(x1 * x1 + x2 * x2, red);
+        const float inv = 1.0f / sqrtf(tot / (float)hd + eps);
+        x1 = BF::rt((mu + BF::ld(nw[j])) * x1 * inv);
+        x2 = BF::rt((mu + BF::ld(nw[j + half])) * x2 * inv);
+    }
+    const size_t tr = (size_t)(rope_row0 + r) * half + j;
+    const float c = fcos[tr], s = fsin[tr];
+    const bf16_t o1 = BF::st(c * x1 - s * x2), o2 = BF::st(s * x1 + c * x2);
+    bf16_t* dst = is_q ? q_out + ((size_t)r * H + b) * hd : kc + ((size_t)(b - H) * max_seq + slot) * hd;
+    dst[j] = o1;
+    dst[j + half] = o2;
+}
+// w1|w3 partials -> act(a) * b (mc_pf_act_mul_bfloat with the reduce in front); ffn a multiple of 4
+extern "C" __global__ void
+mc_pf_act_mul_parts_bfloat(const float* part, uint32_t splits, uint32_t M, bf16_t* out, uint32_t ffn, int32_t gelu)
+{
+    const uint32_t j0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4, r = blockIdx.y;
+    if (j0 >= ffn) return;
+    const size_t zs = (size_t)M * 2 * ffn, base = (size_t)r * 2 * ffn + 2 * j0;
+    float4 lo = {0, 0, 0, 0}, hi = {0, 0, 0, 0}; // eight consecutive values = four (a, b) pairs
+    for (uint32_t z = 0; z < splits; z++) {
+        const float4 p0 = *reinterpret_cast<const float4*>(part + (size_t)z * zs + base);
+        const float4 p1 = *reinterpret_cast<const float4*>(part + (size_t)z * zs + base + 4);
+        lo.x += p0.x; lo.y += p0.y; lo.z += p0.z; lo.w += p0.w;
+        hi.x += p1.x; hi.y += p1.y; hi.z += p1.z; hi.w += p1.w;
+    }
+    auto one = [&](float a, float b) {
+        a = bf2f(f2bf(a));
+        b = bf2f(f2bf(b));
+        const float g = gelu ? BF::rt(pf_gelu_f(a)) : pf_silu_T<BF>(a);
+        return g * b;
+    };
+    const float o0 = one(lo.x, lo.y), o1 = one(lo.z, lo.w), o2 = one(hi.x, hi.y), o3 = one(hi.z, hi.w);
+    *reinterpret_cast<uint2*>(out + (size_t)r * ffn + j0) = make_uint2(pack_bf16x2(o0, o1), pack_bf16x2(o2, o3));
+}
+// Wo / w2 partials -> h = T(res + T(sum)) (written: the next residual) -> rmsnorm(h) (mc_pf_splitk_reduce_bfloat with a residual +
+// mc_pf_rmsnorm_bfloat in one launch); one workgroup per row, dim a multiple of 8 and at most 32 blockDim
+extern "C" __global__ void
+mc_pf_rmsnorm_parts_bfloat(const float* part, uint32_t splits, uint32_t M, const bf16_t* res, bf16_t* h_out, const bf16_t* w, bf16_t* y,
+                           uint32_t dim, float eps, float mu)
+{
+    __shared__ float red[16];
+    const size_t base = (size_t)blockIdx.x * dim, zs = (size_t)M * dim;
+    const uint32_t npk = dim / 8, bd = blockDim.x;
+    float hv[4][8];
+    uint4 wv[4];
+    float ss = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint32_t pk = threadIdx.x + i * bd, pc = pk < npk ? pk : npk - 1;
+        float4 lo = {0, 0, 0, 0}, hi = {0, 0, 0, 0};
+        for (uint32_t z = 0; z < splits; z++) {
+            const float4 p0 = *reinterpret_cast<const float4*>(part + (size_t)z * zs + base + 8 * pc);
+            const float4 p1 = *reinterpret_cast<const float4*>(part + (size_t)z * zs + base + 8 * pc + 4);
+            lo.x += p0.x; lo.y += p0.y; lo.z += p0.z; lo.w += p0.w;
+            hi.x += p1.x; hi.y += p1.y; hi.z += p1.z; hi.w += p1.w;
+        }
+        const uint4 rv = reinterpret_cast<const uint4*>(res + base)[pc];
+        wv[i] = reinterpret_cast<const uint4*>(w)[pc];
+        const float a[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        const uint32_t rd[4] = {rv.x, rv.y, rv.z, rv.w};
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const float rj = __uint_as_float((j & 1) ? (rd[j >> 1] & 0xFFFF0000u) : (rd[j >> 1] << 16));
+            hv[i][j] = bf2f(f2bf(rj + bf2f(f2bf(a[j])))); // mc_pf_splitk_reduce_bfloat: T(res + T(sum))
+        }
+        if (pk < npk) {
+            reinterpret_cast<uint4*>(h_out + base)[pk] = make_uint4(pack_bf16x2(hv[i][0], hv[i][1]), pack_bf16x2(hv[i][2], hv[i][3]),
+                                                                     pack_bf16x2(hv[i][4], hv[i][5]), pack_bf16x2(hv[i][6], hv[i][7]));
+#pragma unroll
+            for (int j = 0; j < 8; j++) ss += hv[i][j] * hv[i][j]; // (mc_pf_rmsnorm_bfloat's order: packet by packet, element by element)
+        }
+    }
+    const float tot = block_sum(ss, red);
+    const float inv = 1.0f / sqrtf(tot / (float)dim + eps);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint32_t pk = threadIdx.x + i * bd;
+        if (pk >= npk) continue;
+        const uint32_t wd[4] = {wv[i].x, wv[i].y, wv[i].z, wv[i].w};
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const float wj = __uint_as_float((j & 1) ? (wd[j >> 1] & 0xFFFF0000u) : (wd[j >> 1] << 16));
+            o[j] = BF::rt((mu + wj) * hv[i][j] * inv);
+        }
+        reinterpret_cast<uint4*>(y + base)[pk] = make_uint4(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7]));
+    }
+}
+
+// ==========================================================================================
+// Round 4: the BIG prompt GEMM on the quad-interleaved weights (mc_pf3_gemm_i4_bfloat_e*).  128 x 128 outputs per workgroup as
+// pf_gemm_big_body, but a wave owns ALL 128 rows of X and 32 columns (its two 16-row tiles of W): per 128-k step it loads ONE
+// 16-byte packet per lane and tile, m4b_dequant turns it into four B operands (k blocks of 32) IN REGISTERS -- W never touches
+// LDS, no second barrier, every weight dequantised by exactly one wave -- and only the X operands are read from LDS: 32
+// ds_read_b128 per 64 MFMAs where the 64 x 64 wave tile with both operands in LDS reads 64.
+// (First version of this round, same tiling as pf_gemm_big_body with the dequantised operands written to LDS operand-major: the
+//  same 12.8 ms per 512-row prompt as the vector-dequantising GEMM -- the dequantisation was not what bound it; LDS reads were.)
+// X: two LDS images of 128 k (35 KB each), one barrier per step; two workgroups per CU.
+// ==========================================================================================
+constexpr uint32_t PF3_LD = 128 + 8;
+template <int EPI>
+__device__ __forceinline__ void
+pf3_gemm_body(const uint4* __restrict__ wq, const void* __restrict__ sp, const bf16_t* __restrict__ X, bf16_t* __restrict__ Y,
+              const bf16_t* __restrict__ res, uint32_t M, uint32_t N, uint32_t K, const bf16_t* __restrict__ la,
+              const bf16_t* __restrict__ lb, uint32_t lora_rank, float lora_scale)
+{
+    using namespace mc::gemv;
+    __shared__ __attribute__((aligned(16))) bf16_t Xs_[2][PFB_M * PF3_LD];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t tile_n, tile_m;
+    pf_tile_of(tile_n, tile_m);
+    const uint32_t n0 = tile_n * PFB_N, m0 = tile_m * PFB_M;
+    const uint32_t KT = K / 128, NT = (N + 15) / 16;
+    const uint32_t ktper = EPI == 2 ? (KT + gridDim.z - 1) / gridDim.z : KT;
+    const uint32_t kt0 = EPI == 2 ? blockIdx.z * ktper : 0, kt1 = min(KT, kt0 + ktper);
+    const uint32_t srow = tid >> 1, skk = (tid & 1) * 64; // staging of X: row, first k of the thread's 64-run of a step
+    const uint32_t xr = m0 + srow < M ? m0 + srow : M - 1;
+    const m4b_lane m4bk = m4b_lane_consts(lane);
+    // this wave's two 16-row tiles of W
+    uint32_t gnt[2], wrow[2];
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        const uint32_t nt = tile_n * 8 + wave * 2 + t;
+        gnt[t] = nt < NT ? nt : NT - 1;
+        wrow[t] = min(16 * gnt[t] + (lane & 15), N - 1);
+    }
+
+    pf_f32x4 acc[8][2];
+#pragma unroll
+    for (int a = 0; a < 8; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++) acc[a][b] = pf_f32x4{0, 0, 0, 0};
+
+    // (native vectors: a HIP uint4 that is only copied global -> register -> LDS is taken for a memcpy and routed through scratch)
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 xv[8];
+    uint4 wr[2];
+    float sr[2];
+    auto fetch = [&](uint32_t kt) { // (unconditional, clamped: a step past the range is never consumed)
+        const uint32_t kc = kt < KT ? kt : KT - 1;
+        const u32x4* src = reinterpret_cast<const u32x4*>(X + (size_t)xr * K + (size_t)kc * 128 + skk);
+#pragma unroll
+        for (int i = 0; i < 8; i++) xv[i] = src[i];
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            wr[t] = wq[((size_t)gnt[t] * KT + kc) * 64 + lane];
+            sr[t] = pf_scale<PF_W_I4, BF>(sp, wrow[t], kc, KT);
+        }
+    };
+    fetch(kt0);
+    const uint32_t kg = (lane >> 4) * 8, l15 = lane & 15;
+    uint32_t buf = 0;
+    for (uint32_t kt = kt0; kt < kt1; kt++, buf ^= 1) {
+        u32x4* xd = reinterpret_cast<u32x4*>(&Xs_[buf][srow * PF3_LD + skk]);
+#pragma unroll
+        for (int i = 0; i < 8; i++) xd[i] = xv[i];
+        uint2 dq[2][8];
+#pragma unroll
+        for (int t = 0; t < 2; t++) m4b_dequant(dq[t], wr[t], m4b_prepare(__float_as_uint(sr[t]), m4bk));
+        __syncthreads(); // image `buf` is complete; the reads of image `buf ^ 1` (the previous step) are all behind it
+        fetch(kt + 1);
+        const bf16_t* xs = &Xs_[buf][l15 * PF3_LD + kg];
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            uint4 b[2];
+#pragma unroll
+            for (int t = 0; t < 2; t++) b[t] = make_uint4(dq[t][2 * d].x, dq[t][2 * d].y, dq[t][2 * d + 1].x, dq[t][2 * d + 1].y);
+#pragma unroll
+            for (int mt = 0; mt < 8; mt++) {
+                const uint4 a = *reinterpret_cast<const uint4*>(xs + mt * 16 * PF3_LD + 32 * d);
+#pragma unroll
+                for (int t = 0; t < 2; t++)
+                    acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(pf_bf16x8, a), __builtin_bit_cast(pf_bf16x8, b[t]),
+                                                                        acc[mt][t], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int mt = 0; mt < 8; mt++)
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const uint32_t m = m0 + mt * 16 + (lane >> 4) * 4 + i, n = n0 + wave * 32 + t * 16 + (lane & 15);
+                if (m < M && n < N) {
+                    const float sum = acc[mt][t][i] * 0x1p37f; // 2^M4B_Q: the weights were formed at 2^-Q (gemv.h)
+                    if (EPI == 2) {
+                        reinterpret_cast<float*>(Y)[((size_t)blockIdx.z * M + m) * N + n] = sum;
+                    } else {
+                        float v = BF::rt(sum);
+                        if (lora_rank) v = pf_lora<BF>(v, la, lb, lora_rank, lora_scale, m, n);
+                        if (EPI == 1) v = BF::ld(res[(size_t)m * N + n]) + v;
+                        Y[(size_t)m * N + n] = BF::st(v);
+                    }
+                }
+            }
+}
+#define MC_PF3_GEMM(NAME, EPI)                                                                                   \
+    extern "C" __global__ void __launch_bounds__(256)                                                            \
+    NAME(const uint4* wq, const void* scales, const bf16_t* X, bf16_t* Y, const bf16_t* res, uint32_t M, uint32_t N, \
+         uint32_t K, uint32_t group, const bf16_t* la, const bf16_t* lb, uint32_t lora_rank, float lora_scale)    \
+    {                                                                                                            \
+        pf3_gemm_body<EPI>(wq, scales, X, Y, res, M, N, K, la, lb, lora_rank, lora_scale);                       \
+    }
+MC_PF3_GEMM(mc_pf3_gemm_i4_bfloat_e0, 0)
+MC_PF3_GEMM(mc_pf3_gemm_i4_bfloat_e1, 1)
+MC_PF3_GEMM(mc_pf3_gemm_i4_bfloat_e2, 2)
