@@ -179,7 +179,6 @@ struct mc_decoder {
     const void* pending_pn = nullptr; // gemma3: postnorm_args the next pre-norm GEMV has to apply to `proj`
     uint64_t weights_gen = 1;  // bumped whenever weight rows change: the derived copies (linear_w::wq2) are rebuilt
     bool pf2_on = true;        // MC_PF2: short prompts from the quad-interleaved copy
-    bool pf3_on = true;        // MC_PF3: prompts of more than 64 rows on the quad-interleaved copy as well
     bool pf_fold_on = true;    // MC_PF_FOLD: the split-K reduce of a prompt GEMM inside the kernel that consumes its rows
     bool lazy_pick = false;    // inside mc_decoder_generate: the pick of a token is folded by the NEXT token's embedding launch
     bool lazy_pick_on = true;  // MC_LAZY_PICK
@@ -1163,7 +1162,7 @@ struct mc_decoder {
     unsigned
     gemm_splits(const linear_w& L, int M) const
     {
-        const unsigned bm = pf3_ok(L, M) ? 128u : gemm_row_tile(M);
+        const unsigned bm = gemm_row_tile(M);
         const unsigned tiles = ((L.out + 127) / 128) * ((M + bm - 1) / bm);
         const unsigned want = (bm == 256 ? 1u : 2u) * (unsigned)dev->prop.multiProcessorCount; // (256 rows: one 8-wave workgroup per CU)
         unsigned splits = 1;
@@ -1177,13 +1176,6 @@ struct mc_decoder {
     {
         return pf2_on && tb == 2 && L.fmt == MC_WFMT_I4 && cfg.qmode == MC_QMODE_EXACT && M <= 64 && L.group == 128 && L.in % 128 == 0 &&
                L.in >= 256;
-    }
-    // ... and longer prompts: the tiled GEMM whose W operands are dequantised on the matrix pipe from the same copy (mc_pf3_gemm_*)
-    bool
-    pf3_ok(const linear_w& L, int M) const
-    {
-        return pf3_on && tb == 2 && L.fmt == MC_WFMT_I4 && cfg.qmode == MC_QMODE_EXACT && M > 64 && L.group == 128 && L.in % 128 == 0 &&
-               L.in >= 256 && !getenv("MC_PF_SMALL_GEMM");
     }
     mc_status
     ensure_pf2(const linear_w& Lc)
@@ -1267,14 +1259,6 @@ struct mc_decoder {
                          pack((const void*)L.wq2, (const void*)L.scales, X, (void*)pf_part, (uint32_t)M, (uint32_t)L.out, (uint32_t)L.in, ktper));
             return true;
         }
-        if (pf3_ok(L, M)) {
-            *st = ensure_pf2(L);
-            if (*st != MC_OK) return true;
-            *st = launch("mc_pf3_gemm_i4_" + tname + "_e2", (L.out + 127) / 128, (M + 127) / 128, splits, 256, 0,
-                         pack((const void*)L.wq2, L.scales, X, (void*)pf_part, (const void*)nullptr, (uint32_t)M, (uint32_t)L.out, (uint32_t)L.in,
-                              (uint32_t)L.group, (const void*)nullptr, (const void*)nullptr, (uint32_t)0, 0.0f));
-            return true;
-        }
         const std::string f = L.fmt == MC_WFMT_I4 ? "i4_" : (L.fmt == MC_WFMT_I8 ? "i8_" : "w_");
         const char* depth_env = getenv("MC_PF_DEPTH");
         const std::string deep = depth_env && atoi(depth_env) == 1 ? "" : "_d2";
@@ -1307,31 +1291,6 @@ struct mc_decoder {
         const std::string f = L.fmt == MC_WFMT_I4 ? "i4_" : (L.fmt == MC_WFMT_I8 ? "i8_" : "w_");
         const void* la = L.lora_cols ? pf_lora : nullptr;
         if (pf2_ok(L, M) && epi != 2) return gemm_pf2(L, epi, X, Y, res, M, la);
-        if (pf3_ok(L, M) && epi != 2) {
-            mc_status s = ensure_pf2(L);
-            if (s != MC_OK) return s;
-            const unsigned splits = gemm_splits(L, M);
-            if (splits > 1) {
-                const size_t need = (size_t)splits * M * L.out;
-                if (need > pf_part_elems) {
-                    MC_HIP(hipStreamSynchronize(stream));
-                    release((void**)&pf_part);
-                    s = alloc((void**)&pf_part, need * 4, false);
-                    if (s != MC_OK) return s;
-                    pf_part_elems = need;
-                }
-                s = launch("mc_pf3_gemm_i4_" + tname + "_e2", (L.out + 127) / 128, (M + 127) / 128, splits, 256, 0,
-                           pack((const void*)L.wq2, L.scales, X, (void*)pf_part, (const void*)nullptr, (uint32_t)M, (uint32_t)L.out,
-                                (uint32_t)L.in, (uint32_t)L.group, (const void*)nullptr, (const void*)nullptr, (uint32_t)0, 0.0f));
-                if (s != MC_OK) return s;
-                return launch("mc_pf_splitk_reduce_" + tname, (L.out + 255) / 256, M, 1, 256, 0,
-                              pack((const void*)pf_part, Y, epi == 1 ? res : (const void*)nullptr, (uint32_t)M, (uint32_t)L.out, splits, la,
-                                   (const void*)L.lora_b, (uint32_t)L.lora_cols, L.lora_scale));
-            }
-            return launch("mc_pf3_gemm_i4_" + tname + "_e" + std::to_string(epi), (L.out + 127) / 128, (M + 127) / 128, 1, 256, 0,
-                          pack((const void*)L.wq2, L.scales, X, Y, res, (uint32_t)M, (uint32_t)L.out, (uint32_t)L.in, (uint32_t)L.group, la,
-                               (const void*)L.lora_b, (uint32_t)L.lora_cols, L.lora_scale));
-        }
         // two K chunks in flight per workgroup (prefill_kernels.hip: measured best at every length);
         // MC_PF_DEPTH=1 selects the one-chunk build for A/B runs
         const char* depth_env = getenv("MC_PF_DEPTH");
@@ -1602,7 +1561,6 @@ mc_decoder_create(mc_device* dev, mc_library* lib, mc_queue* q, const mc_decoder
     if (const char* e = getenv("MC_LAZY_PICK")) d->lazy_pick_on = atoi(e) != 0;
     if (const char* e = getenv("MC_PF2")) d->pf2_on = atoi(e) != 0;
     if (const char* e = getenv("MC_PF_FOLD")) d->pf_fold_on = atoi(e) != 0;
-    if (const char* e = getenv("MC_PF3")) d->pf3_on = atoi(e) != 0;
     if (const char* e = getenv("MC_ATTN_FUSED_WGS")) d->attn_fused_max_wgs_per_cu = (unsigned)std::max(1, std::min(4, atoi(e)));
     if (const char* e = getenv("MC_LING_HALF")) d->ling_half = atoi(e) != 0;
     if (const char* e = getenv("MC_LIN_SPLIT")) d->lin_split = atoi(e) != 0;

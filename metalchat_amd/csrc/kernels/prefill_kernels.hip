@@ -1405,122 +1405,3 @@ mc_pf_rmsnorm_parts_bfloat(const float* part, uint32_t splits, uint32_t M, const
         reinterpret_cast<uint4*>(y + base)[pk] = make_uint4(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7]));
     }
 }
-
-// ==========================================================================================
-// Round 4: the BIG prompt GEMM on the quad-interleaved weights (mc_pf3_gemm_i4_bfloat_e*).  128 x 128 outputs per workgroup as
-// pf_gemm_big_body, but a wave owns ALL 128 rows of X and 32 columns (its two 16-row tiles of W): per 128-k step it loads ONE
-// 16-byte packet per lane and tile, m4b_dequant turns it into four B operands (k blocks of 32) IN REGISTERS -- W never touches
-// LDS, no second barrier, every weight dequantised by exactly one wave -- and only the X operands are read from LDS: 32
-// ds_read_b128 per 64 MFMAs where the 64 x 64 wave tile with both operands in LDS reads 64.
-// (First version of this round, same tiling as pf_gemm_big_body with the dequantised operands written to LDS operand-major: the
-//  same 12.8 ms per 512-row prompt as the vector-dequantising GEMM -- the dequantisation was not what bound it; LDS reads were.)
-// X: two LDS images of 128 k (35 KB each), one barrier per step; two workgroups per CU.
-// ==========================================================================================
-constexpr uint32_t PF3_LD = 128 + 8;
-template <int EPI>
-__device__ __forceinline__ void
-pf3_gemm_body(const uint4* __restrict__ wq, const void* __restrict__ sp, const bf16_t* __restrict__ X, bf16_t* __restrict__ Y,
-              const bf16_t* __restrict__ res, uint32_t M, uint32_t N, uint32_t K, const bf16_t* __restrict__ la,
-              const bf16_t* __restrict__ lb, uint32_t lora_rank, float lora_scale)
-{
-    using namespace mc::gemv;
-    __shared__ __attribute__((aligned(16))) bf16_t Xs_[2][PFB_M * PF3_LD];
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    uint32_t tile_n, tile_m;
-    pf_tile_of(tile_n, tile_m);
-    const uint32_t n0 = tile_n * PFB_N, m0 = tile_m * PFB_M;
-    const uint32_t KT = K / 128, NT = (N + 15) / 16;
-    const uint32_t ktper = EPI == 2 ? (KT + gridDim.z - 1) / gridDim.z : KT;
-    const uint32_t kt0 = EPI == 2 ? blockIdx.z * ktper : 0, kt1 = min(KT, kt0 + ktper);
-    const uint32_t srow = tid >> 1, skk = (tid & 1) * 64; // staging of X: row, first k of the thread's 64-run of a step
-    const uint32_t xr = m0 + srow < M ? m0 + srow : M - 1;
-    const m4b_lane m4bk = m4b_lane_consts(lane);
-    // this wave's two 16-row tiles of W
-    uint32_t gnt[2], wrow[2];
-#pragma unroll
-    for (int t = 0; t < 2; t++) {
-        const uint32_t nt = tile_n * 8 + wave * 2 + t;
-        gnt[t] = nt < NT ? nt : NT - 1;
-        wrow[t] = min(16 * gnt[t] + (lane & 15), N - 1);
-    }
-
-    pf_f32x4 acc[8][2];
-#pragma unroll
-    for (int a = 0; a < 8; a++)
-#pragma unroll
-        for (int b = 0; b < 2; b++) acc[a][b] = pf_f32x4{0, 0, 0, 0};
-
-    // (native vectors: a HIP uint4 that is only copied global -> register -> LDS is taken for a memcpy and routed through scratch)
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    u32x4 xv[8];
-    uint4 wr[2];
-    float sr[2];
-    auto fetch = [&](uint32_t kt) { // (unconditional, clamped: a step past the range is never consumed)
-        const uint32_t kc = kt < KT ? kt : KT - 1;
-        const u32x4* src = reinterpret_cast<const u32x4*>(X + (size_t)xr * K + (size_t)kc * 128 + skk);
-#pragma unroll
-        for (int i = 0; i < 8; i++) xv[i] = src[i];
-#pragma unroll
-        for (int t = 0; t < 2; t++) {
-            wr[t] = wq[((size_t)gnt[t] * KT + kc) * 64 + lane];
-            sr[t] = pf_scale<PF_W_I4, BF>(sp, wrow[t], kc, KT);
-        }
-    };
-    fetch(kt0);
-    const uint32_t kg = (lane >> 4) * 8, l15 = lane & 15;
-    uint32_t buf = 0;
-    for (uint32_t kt = kt0; kt < kt1; kt++, buf ^= 1) {
-        u32x4* xd = reinterpret_cast<u32x4*>(&Xs_[buf][srow * PF3_LD + skk]);
-#pragma unroll
-        for (int i = 0; i < 8; i++) xd[i] = xv[i];
-        uint2 dq[2][8];
-#pragma unroll
-        for (int t = 0; t < 2; t++) m4b_dequant(dq[t], wr[t], m4b_prepare(__float_as_uint(sr[t]), m4bk));
-        __syncthreads(); // image `buf` is complete; the reads of image `buf ^ 1` (the previous step) are all behind it
-        fetch(kt + 1);
-        const bf16_t* xs = &Xs_[buf][l15 * PF3_LD + kg];
-#pragma unroll
-        for (int d = 0; d < 4; d++) {
-            uint4 b[2];
-#pragma unroll
-            for (int t = 0; t < 2; t++) b[t] = make_uint4(dq[t][2 * d].x, dq[t][2 * d].y, dq[t][2 * d + 1].x, dq[t][2 * d + 1].y);
-#pragma unroll
-            for (int mt = 0; mt < 8; mt++) {
-                const uint4 a = *reinterpret_cast<const uint4*>(xs + mt * 16 * PF3_LD + 32 * d);
-#pragma unroll
-                for (int t = 0; t < 2; t++)
-                    acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(pf_bf16x8, a), __builtin_bit_cast(pf_bf16x8, b[t]),
-                                                                        acc[mt][t], 0, 0, 0);
-            }
-        }
-    }
-#pragma unroll
-    for (int mt = 0; mt < 8; mt++)
-#pragma unroll
-        for (int t = 0; t < 2; t++)
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const uint32_t m = m0 + mt * 16 + (lane >> 4) * 4 + i, n = n0 + wave * 32 + t * 16 + (lane & 15);
-                if (m < M && n < N) {
-                    const float sum = acc[mt][t][i] * 0x1p37f; // 2^M4B_Q: the weights were formed at 2^-Q (gemv.h)
-                    if (EPI == 2) {
-                        reinterpret_cast<float*>(Y)[((size_t)blockIdx.z * M + m) * N + n] = sum;
-                    } else {
-                        float v = BF::rt(sum);
-                        if (lora_rank) v = pf_lora<BF>(v, la, lb, lora_rank, lora_scale, m, n);
-                        if (EPI == 1) v = BF::ld(res[(size_t)m * N + n]) + v;
-                        Y[(size_t)m * N + n] = BF::st(v);
-                    }
-                }
-            }
-}
-#define MC_PF3_GEMM(NAME, EPI)                                                                                   \
-    extern "C" __global__ void __launch_bounds__(256)                                                            \
-    NAME(const uint4* wq, const void* scales, const bf16_t* X, bf16_t* Y, const bf16_t* res, uint32_t M, uint32_t N, \
-         uint32_t K, uint32_t group, const bf16_t* la, const bf16_t* lb, uint32_t lora_rank, float lora_scale)    \
-    {                                                                                                            \
-        pf3_gemm_body<EPI>(wq, scales, X, Y, res, M, N, K, la, lb, lora_rank, lora_scale);                       \
-    }
-MC_PF3_GEMM(mc_pf3_gemm_i4_bfloat_e0, 0)
-MC_PF3_GEMM(mc_pf3_gemm_i4_bfloat_e1, 1)
-MC_PF3_GEMM(mc_pf3_gemm_i4_bfloat_e2, 2)

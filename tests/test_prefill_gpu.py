@@ -368,33 +368,3 @@ def test_split_k_reduce_folded_into_the_consumers_is_bit_identical(acc, n, monke
         parity.exact(out["1"][2][layer], out["0"][2][layer], f"hidden[{layer}]")
         parity.exact(out["1"][3][layer][0], out["0"][3][layer][0], f"K[{layer}]")
         parity.exact(out["1"][3][layer][1], out["0"][3][layer][1], f"V[{layer}]")
-
-
-@pytest.mark.parametrize("n", [65, 130, 300])
-def test_long_prompt_takes_the_matrix_pipe_dequantising_gemm(acc, n, monkeypatch):
-    """Prompts of more than 64 rows on int4 weights with scale groups of 128: the tiled GEMM whose W operands are dequantised on
-    the matrix pipe from the quad-interleaved copy (prefill_kernels.hip mc_pf3_gemm_i4_bfloat_e*) -- against the oracle, with
-    adaptors (direct epilogue and split-K + reduce), ragged row tiles, and next to the vector-dequantising GEMM (MC_PF3=0)."""
-    import metalchat_amd as mc
-
-    # (one block, as test_wide_model_takes_the_split_k_gemm: at this width a second block takes the 2-step bound of the suite to
-    #  1.0-1.2 with EITHER GEMM -- tools/pf3_tol_probe.py prints the same worst ratios for both)
-    cfg = mg.tiny_cfg(BF16, dim=1024, n_heads=8, n_kv_heads=2, head_dim=128, ffn_dim=2048, n_layers=1, vocab=512, max_seq_len=320)
-    weights = mg.make_model(cfg, seed=85, quant="i4", group=128, lora_rank=8)
-    tokens = np.random.default_rng(n).integers(0, cfg["vocab"], n).tolist()
-    check_against_oracle(acc, cfg, weights, dict(weight_format=2, group_size=128), tokens, follow=1)
-    plain = mg.make_model(cfg, seed=86, quant="i4", group=128)
-    check_against_oracle(acc, cfg, plain, dict(weight_format=2, group_size=128), tokens, follow=1)
-    got = {}
-    for pf3 in ("1", "0"):
-        monkeypatch.setenv("MC_PF3", pf3)
-        dec = mc.Decoder(acc, **mg.decoder_kwargs(cfg, weight_format=2, group_size=128))
-        dec.load_model(plain)
-        dec.launch_log(True)
-        dec.prefill(tokens, 0)
-        names = set(dec.launched())
-        assert any(x.startswith("mc_pf3_gemm_i4_bfloat") for x in names) == (pf3 == "1"), sorted(names)
-        got[pf3] = dec.logits().copy()
-        dec.release()
-    rel, frac = tol(BF16)
-    parity.check(BF16, got["1"], got["0"], rel=rel, max_ulp=2, max_frac=frac, what="matrix-pipe vs vector dequantisation in the prompt GEMM")
