@@ -1286,12 +1286,43 @@ mc_pf2_gemm_i4_bfloat(const uint4* __restrict__ wq, const void* __restrict__ sp,
 // block.  These are the consumers with the reduce as their first step: T(sum over z, in z order) -- exactly the value the reduce
 // stored -- so every row downstream is bit for bit what it was.  (bfloat rows, no adaptor: decoder.cc gemm_to_parts.)
 // ==========================================================================================
+// (four splits' loads in flight at a time: a loop of dependent iterations is a round trip to L2 per split -- 9.5 us for the norm of
+//  8 rows; a load past the last split reads split 0 again and adds +0.0, which changes nothing: the sum starts at +0.0 and can
+//  never be -0.0)
 __device__ __forceinline__ float
 pf_part_sum(const float* part, uint32_t splits, size_t zstride, size_t idx)
 {
     float a = 0.0f;
-    for (uint32_t z = 0; z < splits; z++) a += part[(size_t)z * zstride + idx];
+    for (uint32_t z0 = 0; z0 < splits; z0 += 4) {
+        float v[4];
+#pragma unroll
+        for (uint32_t u = 0; u < 4; u++) v[u] = part[(size_t)(z0 + u < splits ? z0 + u : 0u) * zstride + idx];
+#pragma unroll
+        for (uint32_t u = 0; u < 4; u++) a += z0 + u < splits ? v[u] : 0.0f;
+    }
     return bf2f(f2bf(a));
+}
+// eight consecutive values at once (two float4 per split)
+__device__ __forceinline__ void
+pf_part_sum8(const float* part, uint32_t splits, size_t zstride, size_t idx, float (&a)[8])
+{
+#pragma unroll
+    for (int j = 0; j < 8; j++) a[j] = 0.0f;
+    for (uint32_t z0 = 0; z0 < splits; z0 += 4) {
+        float4 p0[4], p1[4];
+#pragma unroll
+        for (uint32_t u = 0; u < 4; u++) {
+            const float* src = part + (size_t)(z0 + u < splits ? z0 + u : 0u) * zstride + idx;
+            p0[u] = *reinterpret_cast<const float4*>(src);
+            p1[u] = *reinterpret_cast<const float4*>(src + 4);
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < 4; u++) {
+            const bool on = z0 + u < splits;
+            a[0] += on ? p0[u].x : 0.0f; a[1] += on ? p0[u].y : 0.0f; a[2] += on ? p0[u].z : 0.0f; a[3] += on ? p0[u].w : 0.0f;
+            a[4] += on ? p1[u].x : 0.0f; a[5] += on ? p1[u].y : 0.0f; a[6] += on ? p1[u].z : 0.0f; a[7] += on ? p1[u].w : 0.0f;
+        }
+    }
 }
 // wq|wk|wv partials -> q/k norm, rope, cache write (mc_pf_rope_cache_bfloat with the reduce in front)
 extern "C" __global__ void
@@ -1335,13 +1366,9 @@ mc_pf_act_mul_parts_bfloat(const float* part, uint32_t splits, uint32_t M, bf16_
     const uint32_t j0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4, r = blockIdx.y;
     if (j0 >= ffn) return;
     const size_t zs = (size_t)M * 2 * ffn, base = (size_t)r * 2 * ffn + 2 * j0;
-    float4 lo = {0, 0, 0, 0}, hi = {0, 0, 0, 0}; // eight consecutive values = four (a, b) pairs
-    for (uint32_t z = 0; z < splits; z++) {
-        const float4 p0 = *reinterpret_cast<const float4*>(part + (size_t)z * zs + base);
-        const float4 p1 = *reinterpret_cast<const float4*>(part + (size_t)z * zs + base + 4);
-        lo.x += p0.x; lo.y += p0.y; lo.z += p0.z; lo.w += p0.w;
-        hi.x += p1.x; hi.y += p1.y; hi.z += p1.z; hi.w += p1.w;
-    }
+    float sum8[8]; // eight consecutive values = four (a, b) pairs
+    pf_part_sum8(part, splits, zs, base, sum8);
+    const float4 lo = {sum8[0], sum8[1], sum8[2], sum8[3]}, hi = {sum8[4], sum8[5], sum8[6], sum8[7]};
     auto one = [&](float a, float b) {
         a = bf2f(f2bf(a));
         b = bf2f(f2bf(b));
@@ -1366,16 +1393,10 @@ mc_pf_rmsnorm_parts_bfloat(const float* part, uint32_t splits, uint32_t M, const
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const uint32_t pk = threadIdx.x + i * bd, pc = pk < npk ? pk : npk - 1;
-        float4 lo = {0, 0, 0, 0}, hi = {0, 0, 0, 0};
-        for (uint32_t z = 0; z < splits; z++) {
-            const float4 p0 = *reinterpret_cast<const float4*>(part + (size_t)z * zs + base + 8 * pc);
-            const float4 p1 = *reinterpret_cast<const float4*>(part + (size_t)z * zs + base + 8 * pc + 4);
-            lo.x += p0.x; lo.y += p0.y; lo.z += p0.z; lo.w += p0.w;
-            hi.x += p1.x; hi.y += p1.y; hi.z += p1.z; hi.w += p1.w;
-        }
         const uint4 rv = reinterpret_cast<const uint4*>(res + base)[pc];
         wv[i] = reinterpret_cast<const uint4*>(w)[pc];
-        const float a[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        float a[8];
+        pf_part_sum8(part, splits, zs, base + 8 * pc, a);
         const uint32_t rd[4] = {rv.x, rv.y, rv.z, rv.w};
 #pragma unroll
         for (int j = 0; j < 8; j++) {
