@@ -211,7 +211,7 @@ struct mc_decoder {
     hipEvent_t err_evt = nullptr;
     bool err_pending = false;
     int handoff_fallbacks = 0;
-    int occ_fused = -1, occ_wo = -1;   // co-resident workgroups per CU of the hand-off launches (the occupancy API's answer; -1: not asked yet)
+    int occ_fused = -1, occ_wo = -1, occ_wo_w = -1;   // co-resident workgroups per CU of the hand-off launches (the occupancy API's answer; -1: not asked yet)
     bool handoff_fast = true;    // MC_HANDOFF_FAST=0: hand-offs A and B through the fabric only (A/B; handoff.h "the XCD-local fast path")
     bool attn_wo_on = true;      // MC_ATTN_WO=0: the Wo GEMV as a launch of its own behind the one-launch attention (A/B, parity)
     bool attn_fused_on = true;   // MC_ATTN_FUSED=0: scores and P.V as two launches (A/B, parity)
@@ -582,6 +582,7 @@ struct mc_decoder {
         occ_fused = ask("mc_attn_fused_bfloat", 256);
         const int hd = cfg.head_dim, k = cfg.n_heads * hd / 2048;
         occ_wo = ask("mc_attn_wo_i4_bfloat_hd" + std::to_string(hd) + "_k" + std::to_string(k), 512);
+        occ_wo_w = hd == 64 ? ask("mc_attn_qkv_wo_w_bfloat_hd64_k4_q4", 512) : 0;
         (void)hipGetLastError();
     }
     // a hand-off gave up: report nothing yet, make the NEXT launches independent of co-residency
@@ -644,6 +645,20 @@ struct mc_decoder {
         const bool built = hd == 128 && L.wo.in == 4096 && L.qkv.in == 4096;
         return built && L.qkv.group == L.wo.group && pg % nsplit == 0 && pg / nsplit <= 16 && n_rep <= 16 &&
                L.qkv.out == (cfg.n_heads + 2 * cfg.n_kv_heads) * hd && pg >= 64 && pg <= 512;
+    }
+
+    // ... the same launch for PLAIN bfloat weights (mc_attn_qkv_wo_w_bfloat_hd64_k4_q4: Llama-3.2-1B, the reference's default model):
+    // rows of 4 KiB (K = 2048), at most ONE row pair per wave in either GEMV phase
+    bool
+    attn_qkv_wo_w_fused(const layer_w& L) const
+    {
+        if (!attn_qkv_on || !attn_wo_on || !attn_qkv_g || !attn_fused() || tb != 2 || cfg.family == MC_FAMILY_GEMMA3) return false;
+        if (L.qkv.fmt != MC_WFMT_T || L.wo.fmt != MC_WFMT_T || L.qkv.lora_cols || L.wo.lora_cols || occ_wo_w == 0) return false;
+        const int hd = cfg.head_dim, n_rep = cfg.n_heads / cfg.n_kv_heads, pg = (n_rep + 2) * hd / 2;
+        const unsigned grid = (unsigned)(nsplit * cfg.n_kv_heads);
+        return hd == 64 && L.wo.in == 2048 && L.qkv.in == 2048 && L.wo.in == cfg.n_heads * hd && L.wo.out % 2 == 0 &&
+               L.qkv.out == (cfg.n_heads + 2 * cfg.n_kv_heads) * hd && grid <= (unsigned)dev->prop.multiProcessorCount &&
+               pg % nsplit == 0 && pg / nsplit <= 8 && n_rep <= 16 && pg >= 64 && pg <= 512 && (unsigned)L.wo.out / 2 <= 8u * grid;
     }
 
     // dynamic LDS of a linear-order int4 GEMV (gemv(): the padded row, the scratch, the parked sums of eight waves)
@@ -866,13 +881,15 @@ struct mc_decoder {
         }
         for (int li = 0; li < n_own; li++) {
             layer_w& L = layers[li];
-            const bool qkv_in = attn_qkv_wo_fused(L);
+            const bool qkv_w_in = attn_qkv_wo_w_fused(L);
+            const bool qkv_in = qkv_w_in || attn_qkv_wo_fused(L);
             bool qkn_in = false;
             if (qkv_in) {
                 // attention_norm, wq|wk|wv, rope, cache write, scores, softmax, P.V, wo + residual (transformer.h:130-133,
                 // attention.h:170-205) in ONE launch: every hand-off but the last stays inside one kv head
-                s = launch("mc_attn_qkv_wo_i4_" + tname + "_hd" + std::to_string(hd) + "_k" + std::to_string(L.wo.in / 2048) + "_q" +
-                               std::to_string(L.qkv.in / 2048),
+                s = launch(qkv_w_in ? std::string("mc_attn_qkv_wo_w_bfloat_hd64_k4_q4")
+                                    : "mc_attn_qkv_wo_i4_" + tname + "_hd" + std::to_string(hd) + "_k" + std::to_string(L.wo.in / 2048) + "_q" +
+                                          std::to_string(L.qkv.in / 2048),
                            (unsigned)(nsplit * KV), 1, 1, 512, 0,
                            pack((const void*)L.kc, (const void*)L.vt, attn_out, attn_psum_g, attn_slab_g, attn_row_g, attn_qkv_g, state,
                                 (uint32_t)n_rep, (uint32_t)KV, (uint32_t)cfg.max_seq_len, scale_T, (uint32_t)nsplit, (uint32_t)(li + 1),
@@ -2421,7 +2438,8 @@ mc_decoder_gemv_kernel_name(mc_decoder* d, const char* which, char* buf, size_t 
         if (d->layers.empty()) return fail(MC_ERR_INVALID_ARGUMENT, "mc_decoder_gemv_kernel_name: this stage owns no block");
         const linear_w& wo = d->layers[0].wo;
         d->query_occupancy();
-        name = d->attn_qkv_wo_fused(d->layers[0]) ? "mc_attn_qkv_wo_i4_" + d->tname + "_hd" + std::to_string(d->cfg.head_dim) + "_k" + std::to_string(wo.in / 2048) +
+        name = d->attn_qkv_wo_w_fused(d->layers[0]) ? std::string("mc_attn_qkv_wo_w_bfloat_hd64_k4_q4")
+               : d->attn_qkv_wo_fused(d->layers[0]) ? "mc_attn_qkv_wo_i4_" + d->tname + "_hd" + std::to_string(d->cfg.head_dim) + "_k" + std::to_string(wo.in / 2048) +
                                                          "_q" + std::to_string(d->layers[0].qkv.in / 2048)
                : d->attn_wo_fused(wo) ? "mc_attn_wo_i4_" + d->tname + "_hd" + std::to_string(d->cfg.head_dim) + "_k" + std::to_string(wo.in / 2048)
                : d->attn_fused()    ? "mc_attn_fused_" + d->tname

@@ -45,13 +45,18 @@ using namespace mc::gemv;
 #ifndef MC_QKV_ROW_DEAL
 #define MC_QKV_ROW_DEAL 0 // 1: the remainder pairs dealt in rows (below).  Same box, three alternating runs: 784 tokens/s with, 798 without
 #endif
-template <int HD, int QN>
+// WB = 1 (round 4, mc_attn_qkv_wo_w_bfloat_*): PLAIN bfloat weights (nn::linear; Llama-3.2-1B, the reference's default model) --
+// rows of QN KiB hold 512 QN weights, no scales, the row in LDS in natural order, a row multiplied packet by packet with
+// v_dot2_f32_bf16 as gemv.h mac<WF_T> does, one pair per wave at most.  Every difference is a compile-time branch: the int4
+// instantiation is the code it was.
+template <int HD, int QN, int WB = 0>
 struct qkv_in_launch {
-    static_assert(QN == 2, "one 16-byte packet of the hidden row per thread (K = 4096, 512 threads)");
+    static_assert(WB ? QN == 4 : QN == 2, "at most one 16-byte packet of the hidden row per thread (K = 4096 int4 / 2048 bfloat, 512 threads)");
     static constexpr bool LDS = true, PIN_V = true;
     static constexpr int TL_STRIDE = 16, TL_BASE = 3; // stamps: 0 start, 1 row staged, 2 pairs published, 3.. attn_fused_bf's 0..
-    static constexpr uint32_t KQ = 2048u * QN, ROWBQ = KQ / 2, CHUNK_LDS = 2048 * 2 / 16 * 17, HALF = HD / 2;
-    static constexpr int PMAXQ = 2;
+    static constexpr uint32_t KQ = WB ? 512u * QN : 2048u * QN, ROWBQ = 1024u * QN, CHUNK_LDS = 2048 * 2 / 16 * 17, HALF = HD / 2;
+    static constexpr uint32_t NPK = KQ / 8; // 16-byte packets of the hidden row
+    static constexpr int PMAXQ = WB ? 1 : 2;
     typedef const __attribute__((address_space(3))) bf16_t* lds_row;
     typedef __attribute__((address_space(3))) bf16_t* lds_row_w;
     typedef uint32_t rowv4 __attribute__((ext_vector_type(4)));
@@ -110,11 +115,13 @@ struct qkv_in_launch {
                 const rowv4 v = __builtin_nontemporal_load(reinterpret_cast<const rowv4*>(wrow + (((size_t)rr * ROWBQ + c * 1024) & lm64)));
                 ww[i][rr][c] = make_uint4(v.x, v.y, v.z, v.w);
             }
-        const char* srow = static_cast<const char*>(qs) + (((size_t)(pp >> 1) * ngroups) * 4 + (pp & 1u) * 2) * 2;
+        if constexpr (WB == 0) {
+            const char* srow = static_cast<const char*>(qs) + (((size_t)(pp >> 1) * ngroups) * 4 + (pp & 1u) * 2) * 2;
 #pragma unroll
-        for (int c = 0; c < QN; c++) {
-            const uint32_t g = group ? ((2048u * c + 32u * lane) >> glog) : 0u;
-            wsc[i][c] = *reinterpret_cast<const uint32_t*>(srow + ((g * 8u) & lm));
+            for (int c = 0; c < QN; c++) {
+                const uint32_t g = group ? ((2048u * c + 32u * lane) >> glog) : 0u;
+                wsc[i][c] = *reinterpret_cast<const uint32_t*>(srow + ((g * 8u) & lm));
+            }
         }
     }
     // the wave's row of the shared pair, into slot [PMAXQ - 1][0] (the wave has at most PMAXQ - 1 whole pairs then)
@@ -146,8 +153,8 @@ struct qkv_in_launch {
     {
         const uint32_t tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
         // the row first (gemv.h, the build-time prologue of the linear-order kernels), the step state behind it
-        xr = reinterpret_cast<const rowv4*>(xp)[tid];
-        nr = reinterpret_cast<const rowv4*>(normp)[tid];
+        xr = reinterpret_cast<const rowv4*>(xp)[tid & (NPK - 1u)]; // (bfloat weights: 256 packets, threads 256.. read them again and add nothing)
+        nr = reinterpret_cast<const rowv4*>(normp)[tid & (NPK - 1u)];
         stamp(0);
         const __attribute__((address_space(1))) int32_t* stp = (const __attribute__((address_space(1))) int32_t*)st;
         slot = (uint32_t)stp[3];
@@ -156,7 +163,7 @@ struct qkv_in_launch {
         asm volatile("s_barrier" ::: "memory"); // (the row's requests stay ahead of the weight requests in the CU's memory pipe)
         const uint32_t split = blockIdx.x / KV;
         const uint32_t PG = (n_rep + 2u) * HALF, PW = PG / nsplit, e = PW >> 3, r = PW & 7u;
-        if (MC_QKV_ROW_DEAL && r == 4u && e + 1u <= (uint32_t)PMAXQ) {
+        if (MC_QKV_ROW_DEAL && WB == 0 && r == 4u && e + 1u <= (uint32_t)PMAXQ) {
             const uint32_t w4 = wave & 3u;
             full = e;
             j0 = split * PW + (wave < 4u ? w4 * (e + 1u) : 4u * (e + 1u) + w4 * e);
@@ -187,7 +194,7 @@ struct qkv_in_launch {
                 ss += a * a;
                 ss += b * b;
             }
-            const float wsum_ = wave_sum_dpp(ss);
+            const float wsum_ = wave_sum_dpp(tid < NPK ? ss : 0.0f);
             if (lane == 0) red[wave] = wsum_;
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // (LDS only: the first pairs stay in flight)
             float tot = 0.0f;
@@ -201,15 +208,18 @@ struct qkv_in_launch {
                 const float b = (mu + asf(wv[e] & 0xFFFF0000u)) * asf(vv[e] & 0xFFFF0000u) * inv;
                 o[e] = pack_bf16x2(a, b);
             }
-            reinterpret_cast<rowv4*>(xs)[tid + (tid >> 4)] = rowv4{o[0], o[1], o[2], o[3]}; // (packet p sits in slot p + p / 16)
+            if constexpr (WB == 0) reinterpret_cast<rowv4*>(xs)[tid + (tid >> 4)] = rowv4{o[0], o[1], o[2], o[3]}; // (packet p sits in slot p + p / 16)
+            else if (tid < NPK) reinterpret_cast<rowv4*>(xs)[tid] = rowv4{o[0], o[1], o[2], o[3]};                  // (natural order)
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         stamp(1);
         // ---- the rest of the wave's rows and the rotation of the pair this lane will finish (lane i < cnt: whole pair j0 + i,
         // then the shared pair; its address waits for the step state: asked for in at_start() that wait sat in the middle of
         // the weight requests)
-        if (shared) request_shared_row();   // (wave-uniform, and the same for every wave of the launch: no wave's loads
-        else request_pair(PMAXQ - 1);       //  are "behind a branch" that another path of ITS OWN code does not take)
+        if constexpr (PMAXQ > 1) {
+            if (shared) request_shared_row();   // (wave-uniform, and the same for every wave of the launch: no wave's loads
+            else request_pair(PMAXQ - 1);       //  are "behind a branch" that another path of ITS OWN code does not take)
+        }
         typedef const __attribute__((address_space(1))) float* gfloat_p;
         const uint32_t li = min(lane, cnt ? cnt - 1u : 0u), jm = li < full ? j0 + li : js;
         const uint32_t jj = jm < (n_rep + 1u) * HALF ? jm % HALF : 0u;
@@ -226,20 +236,42 @@ struct qkv_in_launch {
         const m4b_lane m4bk = m4b_lane_consts(lane);
         typedef __attribute__((address_space(3))) mf_s4 lds_s4;
         uint2 x[QN][8];
+        if constexpr (WB == 0) {
 #pragma unroll
-        for (int c = 0; c < QN; c++) {
-            lds_s4* xt = (lds_s4*)(xs + c * CHUNK_LDS + lane_tr);
+            for (int c = 0; c < QN; c++) {
+                lds_s4* xt = (lds_s4*)(xs + c * CHUNK_LDS + lane_tr);
 #pragma unroll
-            for (int e = 0; e < 8; e++) x[c][e] = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16(xt + e));
+                for (int e = 0; e < 8; e++) x[c][e] = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16(xt + e));
+            }
+        } else {
+            // (bfloat weights: the lane's packet c of a row is weights 8 (64 c + lane) .. + 7: the same packet of the row in LDS)
+#pragma unroll
+            for (int c = 0; c < QN; c++) {
+                const uint4 v = *reinterpret_cast<const uint4*>(xs + (size_t)(c * 64 + lane) * 16);
+                x[c][0] = make_uint2(v.x, v.y);
+                x[c][1] = make_uint2(v.z, v.w);
+            }
         }
         // one row: QN packets into one accumulator, the lane's own element, one wave sum (the stand-alone kernel's order)
         auto row_sum = [&](const uint4 (&w)[QN], const uint32_t (&sc)[QN], uint32_t hi) {
+            if constexpr (WB != 0) {
+                float a = 0.0f; // gemv.h mac<WF_T>: four v_dot2_f32_bf16 per packet, packets in order, one wave sum
+#pragma unroll
+                for (int c = 0; c < QN; c++) {
+                    a = dot2(w[c].x, x[c][0].x, a);
+                    a = dot2(w[c].y, x[c][0].y, a);
+                    a = dot2(w[c].z, x[c][1].x, a);
+                    a = dot2(w[c].w, x[c][1].y, a);
+                }
+                return wave_sum_dpp(a);
+            } else {
             mf_f4 acc[1] = {mf_f4{0, 0, 0, 0}};
 #pragma unroll
             for (int c = 0; c < QN; c++) mac4b_n<1>(acc, w[c], m4b_prepare(hi ? (sc[c] & 0xFFFF0000u) : (sc[c] << 16), m4bk), x[c]);
             const uint32_t e = lane & 3;
             const float mine = e == 0 ? acc[0][0] : (e == 1 ? acc[0][1] : (e == 2 ? acc[0][2] : acc[0][3]));
             return wave_sum_dpp(mine) * 0x1p37f; // 2^M4B_Q: the sum was formed at 2^-Q (mac4b_n)
+            }
         };
         float my_a = 0.0f, my_b = 0.0f;
 #pragma unroll
@@ -317,7 +349,8 @@ struct qkv_in_launch {
 };
 
 // LNCH = KiB of packed weights per Wo row (K = H * hd = 2048 LNCH); QN != 0: wq|wk|wv (rows of QN KiB) in this launch too -- qx
-template <int HD, int LNCH, int QN = 0>
+// WB = 1: plain bfloat weights for Wo and wq|wk|wv (rows of LNCH / QN KiB = 512 LNCH / 512 QN weights; qkv_in_launch above)
+template <int HD, int LNCH, int QN = 0, int WB = 0>
 __device__ __forceinline__ void
 attn_wo_body(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const bf16_t* __restrict__ vt, bf16_t* __restrict__ attn_out,
              unsigned long long* psum_g, unsigned long long* slab_g, unsigned long long* row_g, step_state* st, uint32_t n_rep,
@@ -329,16 +362,16 @@ attn_wo_body(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const 
              const void* __restrict__ qnorm_w = nullptr, const void* __restrict__ qkv_w = nullptr, const void* __restrict__ qkv_s = nullptr,
              const float* fcos = nullptr, const float* fsin = nullptr, unsigned long long* qkv_g = nullptr, float eps = 0.0f, float mu = 0.0f)
 {
-    constexpr uint32_t K = 2048u * LNCH;
+    constexpr uint32_t K = WB ? 512u * LNCH : 2048u * LNCH;
     constexpr uint32_t CHUNK_LDS = 2048 * 2 / 16 * 17;  // a chunk of the row in LDS: 16 bytes of padding per 256 (gemv.h Q_M4D)
-    constexpr uint32_t ROWB = K / 2;                     // bytes of packed weights per row
+    constexpr uint32_t ROWB = 1024u * LNCH;              // bytes of weights per row
     // (QN != 0: the hidden row of the wq|wk|wv phase first, the attention row of the Wo phase later: hand-off C lies between them)
-    __shared__ __attribute__((aligned(16))) char xs[(LNCH > QN ? LNCH : QN) * CHUNK_LDS];
+    __shared__ __attribute__((aligned(16))) char xs[(LNCH > QN ? LNCH : QN) * (WB ? 1024u : CHUNK_LDS)];
     __shared__ float qred[QN ? 16 : 1];
     __shared__ __attribute__((aligned(16))) bf16_t qkv_rows[QN ? 18 * HD : 8]; // queries of up to 16 heads, the K row, the V row
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // (QN != 0) the hidden row and the wave's wq|wk|wv pairs are requested by the first instructions of the launch
-    typedef qkv_in_launch<HD, QN ? QN : 2> qx_t;
+    typedef qkv_in_launch<HD, QN ? QN : (WB ? 4 : 2), WB> qx_t;
     qx_t qx;
     if constexpr (QN != 0) {
         typedef typename qx_t::lds_row lds_row;
@@ -356,7 +389,7 @@ attn_wo_body(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const 
     // host takes this kernel only then).  Their weights are requested BEHIND the scores (attn_fused_bf's hook): at the start of the
     // launch they queue in front of the K tile in the CU's memory pipe (measured: 720 tokens/s against 732 with the Wo GEMV as a
     // launch of its own); behind the scores the hand-offs of the attention cover them.
-    constexpr int PMAX = 2;
+    constexpr int PMAX = WB ? 1 : 2; // (bfloat weights: a pair is 2 LNCH KiB = 32 registers at LNCH = 4)
     const uint32_t NP = out_rows / 2;
     uint32_t pb, pe;
     static_assert(MC_LIN_FAVOUR < 63, "with at most 16 pairs per workgroup (the host's condition) no wave may get a third");
@@ -402,12 +435,14 @@ attn_wo_body(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const 
                     const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow + (((size_t)r * ROWB + c * 1024) & lm64)));
                     ww[i][r][c] = make_uint4(v.x, v.y, v.z, v.w);
                 }
-            // scales: row quads [ceil(out / 4)][ngroups][4] bf16 (gemv.h); the dword (rows 2 pr, 2 pr + 1) of the lane's group
-            const char* srow = static_cast<const char*>(wo_s) + (((size_t)(pr >> 1) * ngroups) * 4 + (pr & 1u) * 2) * 2;
+            if constexpr (WB == 0) {
+                // scales: row quads [ceil(out / 4)][ngroups][4] bf16 (gemv.h); the dword (rows 2 pr, 2 pr + 1) of the lane's group
+                const char* srow = static_cast<const char*>(wo_s) + (((size_t)(pr >> 1) * ngroups) * 4 + (pr & 1u) * 2) * 2;
 #pragma unroll
-            for (int c = 0; c < LNCH; c++) {
-                const uint32_t g = group ? ((2048u * c + 32u * lane) >> glog) : 0u;
-                ws[i][c] = *reinterpret_cast<const uint32_t*>(srow + ((g * 8u) & lm));
+                for (int c = 0; c < LNCH; c++) {
+                    const uint32_t g = group ? ((2048u * c + 32u * lane) >> glog) : 0u;
+                    ws[i][c] = *reinterpret_cast<const uint32_t*>(srow + ((g * 8u) & lm));
+                }
             }
             wres[i] = reinterpret_cast<const uint32_t*>(rp)[pr] & (has_res ? 0xFFFFFFFFu : 0u);
         }
@@ -440,14 +475,16 @@ attn_wo_body(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const 
 #define MC_WO_PREDEQUANT 1
 #endif
     const m4b_lane m4bk = m4b_lane_consts(lane);
-    uint2 dq[2][LNCH][8];
-    if (MC_WO_PREDEQUANT && pb < pe) { // (wave-uniform)
+    uint2 dq[2][WB ? 1 : LNCH][8];
+    if (WB == 0 && MC_WO_PREDEQUANT && pb < pe) { // (wave-uniform)
 #pragma unroll
         for (int r = 0; r < 2; r++)
 #pragma unroll
             for (int c = 0; c < LNCH; c++) {
-                const uint32_t raw = ws[0][c];
-                m4b_dequant(dq[r][c], ww[0][r][c], m4b_prepare(r ? (raw & 0xFFFF0000u) : (raw << 16), m4bk));
+                if constexpr (WB == 0) {
+                    const uint32_t raw = ws[0][c];
+                    m4b_dequant(dq[r][c], ww[0][r][c], m4b_prepare(r ? (raw & 0xFFFF0000u) : (raw << 16), m4bk));
+                }
             }
     }
     // ---- hand-off C: the whole attention row (K bf16 = K / 2 granules) into LDS, padded as the transposed reads want it
@@ -476,7 +513,8 @@ attn_wo_body(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const 
 #pragma unroll
         for (int i = 0; i < NG; i++) {
             const uint32_t g = tid + 512u * i, p = g >> 2; // granule g = elements 2 g, 2 g + 1 = dword g % 4 of packet g / 4
-            *reinterpret_cast<uint32_t*>(xs + (p + (p >> 4)) * 16 + (g & 3u) * 4) = val[i];
+            if constexpr (WB == 0) *reinterpret_cast<uint32_t*>(xs + (p + (p >> 4)) * 16 + (g & 3u) * 4) = val[i];
+            else *reinterpret_cast<uint32_t*>(xs + g * 4) = val[i]; // (natural order)
         }
     }
     __syncthreads();
@@ -491,6 +529,19 @@ attn_wo_body(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const 
         float rsum[2];
 #pragma unroll
         for (int r = 0; r < 2; r++) {
+            if constexpr (WB != 0) {
+                float a = 0.0f; // gemv.h mac<WF_T>: four v_dot2_f32_bf16 per packet, packets in order, one wave sum
+#pragma unroll
+                for (int c = 0; c < LNCH; c++) {
+                    const uint4 xv = *reinterpret_cast<const uint4*>(xs + (size_t)(c * 64 + lane) * 16);
+                    const uint4 wv = ww[i][r][c];
+                    a = dot2(wv.x, xv.x, a);
+                    a = dot2(wv.y, xv.y, a);
+                    a = dot2(wv.z, xv.z, a);
+                    a = dot2(wv.w, xv.w, a);
+                }
+                rsum[r] = wave_sum_dpp(a);
+            } else {
             mf_f4 acc[1] = {mf_f4{0, 0, 0, 0}};
 #pragma unroll
             for (int c = 0; c < LNCH; c++) {
@@ -505,6 +556,7 @@ attn_wo_body(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const 
             const uint32_t e = lane & 3;
             const float mine = e == 0 ? acc[0][0] : (e == 1 ? acc[0][1] : (e == 2 ? acc[0][2] : acc[0][3]));
             rsum[r] = wave_sum_dpp(mine) * 0x1p37f; // 2^M4B_Q: the sum was formed at 2^-Q (mac4b_n)
+            }
         }
         if (lane == 0) {
             float va = BF::rt(rsum[0]), vb = BF::rt(rsum[1]);
@@ -545,6 +597,20 @@ attn_wo_body(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const 
     }
 // mc_attn_qkv_wo_i4_bfloat_hd{head_dim}_k{KiB per Wo row}_q{KiB per wq|wk|wv row}
 MC_ATTN_QKV_WO(mc_attn_qkv_wo_i4_bfloat_hd128_k2_q2, 128, 2, 2)  // Llama-3-8B: dim 4096, 32 heads x 128
+// ... with plain bfloat weights (nn::linear): mc_attn_qkv_wo_w_bfloat_hd{head_dim}_k{KiB per Wo row}_q{KiB per wq|wk|wv row}
+#define MC_ATTN_QKV_WO_W(NAME, HD, LNCH, QN)                                                                                              \
+    extern "C" __global__ void __launch_bounds__(512)                                                                                    \
+    NAME(const bf16_t* kc, const bf16_t* vt, bf16_t* attn_out, unsigned long long* psum_g, unsigned long long* slab_g,                  \
+         unsigned long long* row_g, unsigned long long* qkv_g, step_state* st, uint32_t n_rep, uint32_t n_kv, uint32_t max_seq,         \
+         float scale, uint32_t nsplit, uint32_t layer_tag, const void* wo_w, const void* wo_s, const bf16_t* x, bf16_t* y,              \
+         uint32_t out_rows, uint32_t group, const void* qnorm_w, const void* qkv_w, const void* qkv_s, const float* fcos, const float* fsin, float eps,    \
+         float mu, uint32_t fastpath, unsigned long long* tl)                                                                            \
+    {                                                                                                                                    \
+        attn_wo_body<HD, LNCH, QN, 1>(nullptr, kc, vt, attn_out, psum_g, slab_g, row_g, st, n_rep, n_kv, max_seq, scale, nsplit, layer_tag, \
+                                      wo_w, wo_s, x, y, out_rows, group, 1u, fastpath, tl, qnorm_w, qkv_w, qkv_s, fcos, fsin,            \
+                                      qkv_g, eps, mu);                                                                                   \
+    }
+MC_ATTN_QKV_WO_W(mc_attn_qkv_wo_w_bfloat_hd64_k4_q4, 64, 4, 4)  // Llama-3.2-1B: dim 2048, 32 heads x 64, bf16 weights
 
 // mc_attn_wo_i4_bfloat_hd{head_dim}_k{KiB per Wo row}
 MC_ATTN_WO(mc_attn_wo_i4_bfloat_hd128_k2, 128, 2)  // Llama-3-8B: 32 heads x 128

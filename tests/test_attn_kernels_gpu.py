@@ -244,7 +244,8 @@ def test_attention_and_wo_in_one_launch_matches_the_oracle(acc, shape, n, fast):
 
 @pytest.mark.parametrize("fast", [1, 0])
 @pytest.mark.parametrize("n", [2048, 1000, 1, 65])
-def test_norm_qkv_rope_attention_and_wo_in_one_launch_matches_the_oracle(acc, n, fast):
+@pytest.mark.parametrize("shape", ["llama3-8b-int4", "llama3.2-1b-bf16"])
+def test_norm_qkv_rope_attention_and_wo_in_one_launch_matches_the_oracle(acc, n, fast, shape):
     """`mc_attn_qkv_wo_i4_bfloat_hd128_k2_q2` (attn_block_kernels.hip qkv_in_launch: attention_norm, wq|wk|wv, RoPE, the cache
     write, the decode attention, Wo and the residual of one block -- nn/transformer.h:130-133, nn/attention.h:170-205 -- the kernel
     the benchmark's token launches 32 times) launched BY NAME on a hidden row and a cache of its own, against the oracle's kernels
@@ -255,11 +256,14 @@ def test_norm_qkv_rope_attention_and_wo_in_one_launch_matches_the_oracle(acc, n,
     import metalchat_amd as mc
     from test_lin_kernels_gpu import dyadic_row, oracle_rmsnorm
 
-    H, KV, hd, dim, max_seq = 32, 8, 128, 4096, 2048
+    # (the second shape: `mc_attn_qkv_wo_w_bfloat_hd64_k4_q4`, the same launch for PLAIN bfloat weights -- nn::linear, Llama-3.2-1B,
+    #  the reference's default model, src/llama.cc:19-31)
+    int4 = shape == "llama3-8b-int4"
+    H, KV, hd, dim, max_seq = (32, 8, 128, 4096, 2048) if int4 else (32, 8, 64, 2048, 2048)
     half = hd // 2
     cfg = mg.tiny_cfg(BF16, dim=dim, n_heads=H, n_kv_heads=KV, head_dim=hd, ffn_dim=256, n_layers=1, vocab=64, max_seq_len=max_seq)
-    w = mg.make_model(cfg, seed=303, quant="i4", group=128)
-    dec = mc.Decoder(acc, **mg.decoder_kwargs(cfg, weight_format=mc.WFMT_I4, group_size=128))
+    w = mg.make_model(cfg, seed=303, quant="i4" if int4 else None, group=128)
+    dec = mc.Decoder(acc, **(mg.decoder_kwargs(cfg, weight_format=mc.WFMT_I4, group_size=128) if int4 else mg.decoder_kwargs(cfg)))
     dec.load_model(w)
     lw = w["layers"][0]
     wo_p, wo_s, rows, inf, _ = dec.weight_ptrs(0, "wo")
@@ -301,8 +305,8 @@ def test_norm_qkv_rope_attention_and_wo_in_one_launch_matches_the_oracle(acc, n,
     attn_out = acc.alloc(H * hd * 2)
     nw = acc.to_device(lw["attention_norm"])
     cb, sb = acc.to_device(fcos.reshape(-1)), acc.to_device(fsin.reshape(-1))
-    kern = acc.load("mc_attn_qkv_wo_i4_bfloat_hd128_k2_q2")
-    W = lambda p_: acc.wrap(p_, 1 << 40)
+    kern = acc.load("mc_attn_qkv_wo_i4_bfloat_hd128_k2_q2" if int4 else "mc_attn_qkv_wo_w_bfloat_hd64_k4_q4")
+    W = lambda p_: acc.wrap(p_, 1 << 40) if p_ else None
     for epoch, layer_tag in ((1, 1), (1, 2), (9, 200)):
         hb = acc.to_device(x)                  # read as the block input and the residual, overwritten IN PLACE, as the decoder launches it
         attn_out.upload(np.zeros(H * hd, np.uint16))
@@ -312,7 +316,7 @@ def test_norm_qkv_rope_attention_and_wo_in_one_launch_matches_the_oracle(acc, n,
         mc.KernelTask(kern, (nsplit * KV * 512, 1, 1), (512, 1, 1),
                       [kc, vt, attn_out, psum, slab, row_g, qkv_g, state, np.uint32(n_rep), np.uint32(KV), np.uint32(max_seq),
                        np.float32(scale), np.uint32(nsplit), np.uint32(layer_tag), W(wo_p), W(wo_s), hb, hb, np.uint32(dim),
-                       np.uint32(128), nw, W(qk_p), W(qk_s), cb, sb, np.float32(1e-5), np.float32(0.0), np.uint32(fast), None])()
+                       np.uint32(128 if int4 else 0), nw, W(qk_p), W(qk_s), cb, sb, np.float32(1e-5), np.float32(0.0), np.uint32(fast), None])()
         acc.wait()
         assert int(state.download(np.int32, 12)[10]) == 0, "a hand-off of the launch gave up"
         kgot = kc.download(np.uint16, KV * max_seq * hd).reshape(KV, max_seq, hd)

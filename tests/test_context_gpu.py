@@ -222,6 +222,41 @@ def test_tinyllama_1b_shapes_end_to_end(acc, dtype):
                 "mc_gemv_w_bfloat_ling4_p1_e5"} <= names, sorted(names)
 
 
+def test_llama32_1b_shapes_take_the_one_launch_block_with_plain_weights(acc, monkeypatch):
+    # The reference's default model (src/llama.cc:19-31: Llama-3.2-1B -- dim 2048, 32 query / 8 kv heads of 64, ffn 8192, plain
+    # bfloat weights): attention_norm + wq|wk|wv + rope + cache write + attention + wo + residual in ONE launch
+    # (mc_attn_qkv_wo_w_bfloat_hd64_k4_q4, round 4), against the oracle at S = 2048 and at position 40 with injected caches --
+    # and next to the five-launch form (MC_ATTN_QKV=0): the same tokens, logits within the suite's bound.
+    import metalchat_amd as mc
+
+    cfg = dict(dtype=BF16, family=0, n_layers=2, vocab=32000, max_seq_len=2048, norm_eps=1e-5, dim=2048, n_heads=32,
+               n_kv_heads=8, head_dim=64, ffn_dim=8192, rope_theta=500000.0, attn_scale=64 ** -0.5)
+    weights = t_weights_model(cfg, SEED)
+    names = set()
+    agree = run_injected(acc, cfg, weights, 2044, 8, dict(weight_format=mc.WFMT_T, group_size=0), rel_logits=7.8e-3,
+                         max_ulp=3, max_frac=0.8, what="llama3.2-1b S=2048", launched=names)
+    assert agree >= 7
+    assert "mc_attn_qkv_wo_w_bfloat_hd64_k4_q4" in names and "mc_gemv_w_bfloat_ling4_p1_e4" not in names, sorted(names)
+    agree = run_injected(acc, cfg, weights, 40, 8, dict(weight_format=mc.WFMT_T, group_size=0), rel_logits=7.8e-3,
+                         max_ulp=3, max_frac=0.8, what="llama3.2-1b at position 40 (all but one range of the launch empty)")
+    assert agree >= 7
+    out = {}
+    for form in ("1", "0"):
+        monkeypatch.setenv("MC_ATTN_QKV", form)
+        dec = mc.Decoder(acc, **mg.decoder_kwargs(cfg, weight_format=mc.WFMT_T, group_size=0))
+        dec.init_synthetic(SEED)
+        for layer in range(cfg["n_layers"]):
+            k, v = random_cache(cfg, 1500, 300 + layer)
+            dec.import_kv(layer, k, v)
+        dec.launch_log(True)
+        toks = list(dec.generate(9, 1500, 12))
+        assert ("mc_attn_qkv_wo_w_bfloat_hd64_k4_q4" in set(dec.launched())) == (form == "1")
+        out[form] = (toks, dec.logits().copy())
+        dec.release()
+    assert out["1"][0] == out["0"][0]
+    parity.check(BF16, out["1"][1], out["0"][1], rel=7.8e-3, max_ulp=2, max_frac=0.6, what="one-launch block vs five launches, logits")
+
+
 def test_llama3_70b_widths_one_block(acc):
     # BASELINE configs[4] widths: dim 8192, 64 query / 8 kv heads, ffn 28672 -- rows of 4 and 14 KiB of int4 weights
     import metalchat_amd as mc
