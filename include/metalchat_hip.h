@@ -320,8 +320,8 @@ mc_status mc_decoder_time_gemv(mc_decoder* d, const char* which, int32_t repeats
                                double* bytes_per_pass, int32_t* launches_per_pass);
 /* Host name of the kernel mc_decoder_time_gemv(which) launches -- the variant a token really runs (linear-order
  * kernels, prologue / epilogue codes, the greedy pick inside the head).  which = "attn": the decode attention kernel(s) of
- * the first owned block ("mc_attn_wo_i4_*" carries the Wo GEMV, "mc_attn_qkv_wo_i4_*" the rmsnorm + wq|wk|wv GEMV + RoPE +
- * cache write in front of it as well: the token then launches no Wo (no QKV) GEMV of its own and time_gemv("wo") /
+ * the first owned block ("mc_attn_wo_i4_*" carries the Wo GEMV, "mc_attn_qkv_wo_i4_*" / "mc_attn_qkv_wo_w_*" (plain bfloat weights) the rmsnorm +
+ * wq|wk|wv GEMV + RoPE + cache write in front of it as well: the token then launches no Wo (no QKV) GEMV of its own and time_gemv("wo") /
  * time_gemv("qkv") measure stand-alone launches).  Launches nothing. */
 mc_status mc_decoder_gemv_kernel_name(mc_decoder* d, const char* which, char* buf, size_t cap);
 /* How often an in-launch hand-off of the decode attention gave up (its workgroups were not resident together: another stream or

@@ -153,8 +153,9 @@ struct qkv_in_launch {
     {
         const uint32_t tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
         // the row first (gemv.h, the build-time prologue of the linear-order kernels), the step state behind it
-        xr = reinterpret_cast<const rowv4*>(xp)[tid & (NPK - 1u)]; // (bfloat weights: 256 packets, threads 256.. read them again and add nothing)
-        nr = reinterpret_cast<const rowv4*>(normp)[tid & (NPK - 1u)];
+        const uint32_t pk = WB ? tid & (NPK - 1u) : tid; // (bfloat weights: 256 packets, threads 256.. read them again and add nothing)
+        xr = reinterpret_cast<const rowv4*>(xp)[pk];
+        nr = reinterpret_cast<const rowv4*>(normp)[pk];
         stamp(0);
         const __attribute__((address_space(1))) int32_t* stp = (const __attribute__((address_space(1))) int32_t*)st;
         slot = (uint32_t)stp[3];
@@ -194,7 +195,7 @@ struct qkv_in_launch {
                 ss += a * a;
                 ss += b * b;
             }
-            const float wsum_ = wave_sum_dpp(tid < NPK ? ss : 0.0f);
+            const float wsum_ = wave_sum_dpp(WB && tid >= NPK ? 0.0f : ss);
             if (lane == 0) red[wave] = wsum_;
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // (LDS only: the first pairs stay in flight)
             float tot = 0.0f;
