@@ -790,7 +790,10 @@ struct q_from_qkv_rows {
         lds_barrier();
     }
 };
-template <int HD, int T, int NW, typename OnChunk, typename BehindScores, typename QSrc = q_from_hbm>
+// PADKV: the kv heads may be dealt with a stride of the next multiple of 8 (`fastpath` bit 1, below) -- only the launches that
+// are the attention alone are built with it: in a launch with GEMV phases behind the attention the early exit it needs would
+// put every load of those phases "behind a branch" (hipcc then waits vmcnt(0) wherever it waits)
+template <int HD, int T, int NW, bool PADKV = false, typename OnChunk, typename BehindScores, typename QSrc = q_from_hbm>
 __device__ __forceinline__ void
 attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const bf16_t* __restrict__ vt,
               unsigned long long* psum_g, unsigned long long* slab_g, step_state* st, uint32_t n_rep, uint32_t KV, uint32_t max_seq,
@@ -818,9 +821,11 @@ attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const
     // a multiple of 8 -- grid = nsplit x stride, workgroups whose slot has no head leave at once -- so that the workgroups of one
     // head have equal blockIdx.x % 8 (one XCD in practice) whatever n_kv is: TinyLlama's 4 heads otherwise sit on two XCDs each
     // and the XCD-local words are no use to half of every head's ranges
-    const uint32_t kv_stride = (fastpath & 2u) ? ((KV + 7u) & ~7u) : KV;
+    const uint32_t kv_stride = (PADKV && (fastpath & 2u)) ? ((KV + 7u) & ~7u) : KV;
     const uint32_t kv = blockIdx.x % kv_stride, split = blockIdx.x / kv_stride;
-    if (kv >= KV) return;
+    if constexpr (PADKV) {
+        if (kv >= KV) return;
+    }
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t col = lane & 15, c = lane >> 4;
     const uint32_t p_begin = split * PBW;
@@ -1144,10 +1149,10 @@ attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const
         auto store = [&](uint32_t head, uint32_t db, uint32_t col, float v) {                                                            \
             if ((threadIdx.x & 63) < 16) out[(size_t)head * hd + db * 16 + col] = f2bf(v);                                               \
         };                                                                                                                               \
-        if (hd == 128) attn_fused_bf<128, T, 4>(q, kc, vt, psum_g, slab_g, st, n_rep, n_kv, max_seq, scale, nsplit, layer_tag, tl, store, [](int) {}, fastpath);    \
-        else if (hd == 64) attn_fused_bf<64, T, 4>(q, kc, vt, psum_g, slab_g, st, n_rep, n_kv, max_seq, scale, nsplit, layer_tag, tl, store, [](int) {}, fastpath); \
-        else if (T == 1 && hd == 256) attn_fused_bf<256, 1, 4>(q, kc, vt, psum_g, slab_g, st, n_rep, n_kv, max_seq, scale, nsplit, layer_tag, tl, store, [](int) {}, fastpath); \
-        else if (T == 1 && hd == 32) attn_fused_bf<32, 1, 4>(q, kc, vt, psum_g, slab_g, st, n_rep, n_kv, max_seq, scale, nsplit, layer_tag, tl, store, [](int) {}, fastpath);   \
+        if (hd == 128) attn_fused_bf<128, T, 4, true>(q, kc, vt, psum_g, slab_g, st, n_rep, n_kv, max_seq, scale, nsplit, layer_tag, tl, store, [](int) {}, fastpath);    \
+        else if (hd == 64) attn_fused_bf<64, T, 4, true>(q, kc, vt, psum_g, slab_g, st, n_rep, n_kv, max_seq, scale, nsplit, layer_tag, tl, store, [](int) {}, fastpath); \
+        else if (T == 1 && hd == 256) attn_fused_bf<256, 1, 4, true>(q, kc, vt, psum_g, slab_g, st, n_rep, n_kv, max_seq, scale, nsplit, layer_tag, tl, store, [](int) {}, fastpath); \
+        else if (T == 1 && hd == 32) attn_fused_bf<32, 1, 4, true>(q, kc, vt, psum_g, slab_g, st, n_rep, n_kv, max_seq, scale, nsplit, layer_tag, tl, store, [](int) {}, fastpath);   \
     }
 MC_ATTN_FUSED(mc_attn_fused_bfloat, 1)   // 64-slot ranges
 // mc_attn_fused_qkn_bfloat: the one-launch attention with gemma3's q_norm / k_norm, rotation and cache write inside (q_from_qkv_rows
