@@ -1,4 +1,4 @@
-# Runs ON THE GPU BOX: the whole GPU suite, smoke(), then the driver's default bench line
+# Runs ON THE GPU BOX (gpurun -- bash tools/gpu_final_check.sh): the whole GPU suite, smoke(), then the default bench line -> gpurun_out/
 cd /root/repo
 python3 -m pytest tests -m gpu -x -q > gpurun_out/t_all.log 2>&1 || { tail -40 gpurun_out/t_all.log; exit 1; }
 tail -2 gpurun_out/t_all.log
