@@ -1009,7 +1009,11 @@ attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const
             if (fastpath) granule_store_dual(gp, psum_fast, tag, __float_as_uint(tot));
             else granule_store(gp, tag, __float_as_uint(tot));
         }
-        behind_scores(0);
+    }
+    // (the hooks OUTSIDE the `active` blocks -- straight-line for every workgroup: called inside one arm and again in an else arm
+    //  for the ranges past kv_len, whatever they request was "loaded behind a branch" for everything that waits later)
+    behind_scores(0);
+    if (active) {
         for (uint32_t head = wave; head < n_rep; head += NW) {
             // (softmax_inv's order: lane-strided partial sums, then the shuffle tree)
             const unsigned long long* row = psum_g + (size_t)(kv * n_rep + head) * nsplit;
@@ -1028,7 +1032,9 @@ attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const
             tsum = wave_sum(tsum);
             if (lane == 0) inv_s[head] = 1.0f / tsum;
         }
-        behind_scores(1);
+    }
+    behind_scores(1);
+    if (active) {
         if constexpr (T > 1 || QSrc::LDS) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         else __syncthreads();
         stamp(2);
@@ -1094,10 +1100,6 @@ attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const
                 }
             }
         }
-    }
-    if (!active) {
-        behind_scores(0);
-        behind_scores(1);
     }
     // ---- 6. hand-off B: chunk q = (head, 16-column block) of this kv head is finished by workgroup q % nsplit (every
     // workgroup of the launch takes part, ranges past kv_len included): lane (col, jj) gathers column col of ranges jj,
