@@ -219,6 +219,7 @@ struct mc_decoder {
     // 64-slot ranges (128 ranges x 8 kv heads = 4 per CU, every hand-off gathering from 128 producers) the one launch took 27.8 us
     // against 6.3 + 8.5 for the two -- long contexts keep the two-launch form (wider ranges were built and measured no better)
     unsigned attn_fused_max_wgs_per_cu = 2;
+    bool attn_t2_on = true; // MC_ATTN_T2
     void* taps = nullptr;       // T[(n_own+1)*dim]
     step_state_h* state = nullptr;
     int32_t* tokens_dev = nullptr;
@@ -567,6 +568,17 @@ struct mc_decoder {
         const unsigned per_cu = std::min(attn_fused_max_wgs_per_cu, occ_fused < 0 ? attn_fused_max_wgs_per_cu : (unsigned)occ_fused);
         return attn_fused_on && attn_psum_g && tb == 2 && n_own <= 254 &&
                (unsigned)(nsplit * cfg.n_kv_heads) <= per_cu * (unsigned)dev->prop.multiProcessorCount;
+    }
+    // ... with 128-slot ranges (mc_attn_fused_t2_bfloat: two score tiles per wave) where the 64-slot ranges are too many workgroups to
+    // be resident together -- Llama-3-8B at S = 8192: 1024 -> 512.  Round 3 measured that form at 14.8 us against 6.3 + 8.5 for
+    // the two launches; with the XCD-local hand-offs of round 4 it is re-measured (MC_ATTN_T2)
+    bool
+    attn_fused_t2() const
+    {
+        const unsigned per_cu = std::min(attn_fused_max_wgs_per_cu, occ_fused < 0 ? attn_fused_max_wgs_per_cu : (unsigned)occ_fused);
+        return attn_t2_on && attn_fused_on && attn_psum_g && tb == 2 && n_own <= 254 && !attn_fused() && nsplit % 2 == 0 &&
+               (cfg.head_dim == 128 || cfg.head_dim == 64) && cfg.n_kv_heads % 8 == 0 &&
+               (unsigned)(nsplit / 2 * cfg.n_kv_heads) <= per_cu * (unsigned)dev->prop.multiProcessorCount;
     }
     void
     query_occupancy()
@@ -965,6 +977,15 @@ struct mc_decoder {
                                pack(proj, L.attention_post_norm, x, hidden, (uint32_t)dim, cfg.norm_eps, mu));
                     if (s != MC_OK) return s;
                 }
+            } else if (attn_fused_t2()) {
+                // ... in ONE launch of 128-slot ranges, then Wo from the finished row
+                s = launch("mc_attn_fused_t2_" + tname, (unsigned)(nsplit / 2 * KV), 1, 1, 256, 0,
+                           pack(q_rot, L.kc, L.vt, attn_out, attn_psum_g, attn_slab_g, state, (uint32_t)n_rep, (uint32_t)KV, (uint32_t)hd,
+                                (uint32_t)cfg.max_seq_len, scale_T, (uint32_t)(nsplit / 2), (uint32_t)(li + 1), (void*)nullptr,
+                                (uint32_t)(handoff_fast ? 1 : 0)));
+                if (s != MC_OK) return s;
+                s = gemv(L.wo, 0, 1, attn_out, hidden, x, nullptr, mu);
+                if (s != MC_OK) return s;
             } else {
             // scores, softmax denominators         (attention.h:195-200)
             s = launch("mc_attn_scores_" + tname, nsplit, KV, 1, 256, 0,
@@ -1578,6 +1599,7 @@ mc_decoder_create(mc_device* dev, mc_library* lib, mc_queue* q, const mc_decoder
     if (const char* e = getenv("MC_LAZY_PICK")) d->lazy_pick_on = atoi(e) != 0;
     if (const char* e = getenv("MC_PF2")) d->pf2_on = atoi(e) != 0;
     if (const char* e = getenv("MC_PF_FOLD")) d->pf_fold_on = atoi(e) != 0;
+    if (const char* e = getenv("MC_ATTN_T2")) d->attn_t2_on = atoi(e) != 0;
     if (const char* e = getenv("MC_ATTN_FUSED_WGS")) d->attn_fused_max_wgs_per_cu = (unsigned)std::max(1, std::min(4, atoi(e)));
     if (const char* e = getenv("MC_LING_HALF")) d->ling_half = atoi(e) != 0;
     if (const char* e = getenv("MC_LIN_SPLIT")) d->lin_split = atoi(e) != 0;
@@ -2056,7 +2078,7 @@ mc_decoder_step(mc_decoder* d, int32_t token, int32_t start_pos, const void* hid
     if (s != MC_OK) return s;
     d->query_occupancy();
     for (int attempt = 0;; attempt++) {
-        const bool handoffs = d->attn_fused();
+        const bool handoffs = d->attn_fused() || d->attn_fused_t2();
         // (a step whose hand-offs give up is repeated on the launches that need no co-residency: the state in front of it)
         if (handoffs) MC_HIP(hipMemcpyAsync(d->state_bak, d->state, sizeof(step_state_h), hipMemcpyDeviceToDevice, d->stream));
         s = d->ensure_rope(start_pos);
@@ -2188,7 +2210,7 @@ mc_decoder_generate(mc_decoder* d, int32_t first_token, int32_t start_pos, int32
     s = d->poll_pending_err();
     if (s != MC_OK) return s;
     d->query_occupancy();
-    const bool handoffs = d->attn_fused();
+    const bool handoffs = d->attn_fused() || d->attn_fused_t2();
     if (handoffs) MC_HIP(hipMemcpyAsync(d->state_bak, d->state, sizeof(step_state_h), hipMemcpyDeviceToDevice, d->stream));
     s = d->ensure_rope(start_pos);
     if (s != MC_OK) return s;
@@ -2443,6 +2465,7 @@ mc_decoder_gemv_kernel_name(mc_decoder* d, const char* which, char* buf, size_t 
                                                          "_q" + std::to_string(d->layers[0].qkv.in / 2048)
                : d->attn_wo_fused(wo) ? "mc_attn_wo_i4_" + d->tname + "_hd" + std::to_string(d->cfg.head_dim) + "_k" + std::to_string(wo.in / 2048)
                : d->attn_fused()    ? "mc_attn_fused_" + d->tname
+               : d->attn_fused_t2() ? "mc_attn_fused_t2_" + d->tname
                                     : "mc_attn_scores_" + d->tname + " + mc_attn_pv_" + d->tname;
         const size_t n0 = std::min(cap - 1, name.size());
         memcpy(buf, name.data(), n0);
@@ -2492,7 +2515,7 @@ mc_decoder_time_gemv(mc_decoder* d, const char* which, int32_t repeats, float* t
             if (w == "wo" || w == "all") {
                 // the variant the token really launches (residual epilogue; the partial-sum prologue when P.V is folded);
                 // the result goes to `proj`, so the hidden row stays what it was
-                const bool fold = !d->attn_fused() && d->pv_fold(L.wo);
+                const bool fold = !d->attn_fused() && !d->attn_fused_t2() && d->pv_fold(L.wo);
                 r = d->gemv(L.wo, fold ? 3 : 0, gemma ? 0 : 1, fold ? (const void*)d->pv_parts : (const void*)d->attn_out, d->proj,
                             gemma ? nullptr : d->hidden, nullptr, mu);
                 if (r != MC_OK) return r;

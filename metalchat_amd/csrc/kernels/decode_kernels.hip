@@ -1157,6 +1157,7 @@ attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const
         else if (T == 1 && hd == 32) attn_fused_bf<32, 1, 4, true>(q, kc, vt, psum_g, slab_g, st, n_rep, n_kv, max_seq, scale, nsplit, layer_tag, tl, store, [](int) {}, fastpath);   \
     }
 MC_ATTN_FUSED(mc_attn_fused_bfloat, 1)   // 64-slot ranges
+MC_ATTN_FUSED(mc_attn_fused_t2_bfloat, 2) // 128-slot ranges: contexts whose 64-slot ranges are more workgroups than can be resident together (S = 8192)
 // mc_attn_fused_qkn_bfloat: the one-launch attention with gemma3's q_norm / k_norm, rotation and cache write inside (q_from_qkv_rows
 // above) -- mc_rope_kv_bfloat + mc_attn_fused_bfloat in one launch, bit for bit
 template <int HD>

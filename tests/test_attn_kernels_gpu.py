@@ -69,12 +69,15 @@ CASES = [
 # hand-offs with / without the XCD-local fast path (handoff.h); 3: with it AND the kv heads dealt with a stride of the next multiple
 # of 8 (grid = nsplit x stride, the workgroups without a head leave at once: decoder.cc handoff_mode_alone)
 @pytest.mark.parametrize("fast", [1, 0, 3])
+@pytest.mark.parametrize("tiles", [1, 2])   # 64-slot ranges (mc_attn_fused_bfloat) / 128-slot ranges (mc_attn_fused_t2_bfloat: S = 8192 in the decoder)
 @pytest.mark.parametrize("H,KV,hd,max_seq,n", CASES + [(32, 8, 128, 8192, 8000)])
-def test_one_launch_attention_matches_the_oracle(acc, H, KV, hd, max_seq, n, fast):
+def test_one_launch_attention_matches_the_oracle(acc, H, KV, hd, max_seq, n, fast, tiles):
     import metalchat_amd as mc
 
+    if tiles == 2 and (hd not in (64, 128) or max_seq % (2 * PB)):
+        pytest.skip("128-slot ranges are built for head_dim 64 and 128")
     rng = np.random.default_rng(H * 7 + hd + n)
-    n_rep, nsplit = H // KV, (max_seq + PB - 1) // PB
+    n_rep, nsplit = H // KV, (max_seq + PB * tiles - 1) // (PB * tiles)
     q = mo.encode(BF16, rng.normal(0, 1, (H, hd)).astype(np.float32))
     k = mo.encode(BF16, rng.normal(0, 0.4, (n, KV, hd)).astype(np.float32))
     v = mo.encode(BF16, rng.normal(0, 0.5, (n, KV, hd)).astype(np.float32))
@@ -85,7 +88,7 @@ def test_one_launch_attention_matches_the_oracle(acc, H, KV, hd, max_seq, n, fas
     out = acc.alloc(H * hd * 2)
     psum = acc.to_device(np.zeros(2 * H * nsplit, np.uint64))   # (slow words, then the XCD-local fast words: handoff.h)
     slab = acc.to_device(np.zeros(2 * H * hd * nsplit, np.uint64))
-    kern = acc.load("mc_attn_fused_bfloat")
+    kern = acc.load("mc_attn_fused_bfloat" if tiles == 1 else "mc_attn_fused_t2_bfloat")
     # several launches over the same granule buffers with the tags consecutive launches of a token (and consecutive tokens)
     # carry: a granule of an earlier launch must never be taken for this one's
     for epoch, layer_tag in ((1, 1), (1, 2), (2, 1), (7, 255)):

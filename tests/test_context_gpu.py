@@ -145,12 +145,16 @@ def test_llama3_8b_int8_at_8192_with_automatic_context_ranges(acc, monkeypatch):
     monkeypatch.delenv("MC_PV_RANGES", raising=False)
     cfg = dict(dtype=BF16, n_layers=1, vocab=2048, max_seq_len=8192, norm_eps=1e-5, **FULL_WIDTH["llama3-8b"])
     weights = synth_model(cfg, SEED, bits=8)
-    names = set()
-    agree = run_injected(acc, cfg, weights, 8185, 15, dict(weight_format=mc.WFMT_I8, group_size=128),
-                         rel_logits=5e-3, max_ulp=2, max_frac=0.7, what="8B int8 S=8192", launched=names)
-    assert agree >= 13
-    assert {"mc_gemv_i8_bfloat_ling4_p1_e4", "mc_attn_pv_bfloat", "mc_gemv_i8_bfloat_ling4_p3_e1", "mc_gemv_i8_bfloat_ling4_p1_e2", "mc_gemv_i8_bfloat_ling14_p0_e1",
-            "mc_gemv_i8_bfloat_ling4_p1_e5"} <= names, sorted(names)
+    # (round 4: the attention in ONE launch of 128-slot ranges -- mc_attn_fused_t2_bfloat, 512 workgroups -- where the 64-slot
+    #  ranges would be 1024; MC_ATTN_T2=0: scores + P.V over context ranges folded into Wo's prologue, as before)
+    for t2, attn in (("1", {"mc_attn_fused_t2_bfloat", "mc_gemv_i8_bfloat_ling4_p0_e1"}),
+                     ("0", {"mc_attn_scores_bfloat", "mc_attn_pv_bfloat", "mc_gemv_i8_bfloat_ling4_p3_e1"})):
+        monkeypatch.setenv("MC_ATTN_T2", t2)
+        names = set()
+        agree = run_injected(acc, cfg, weights, 8185, 15, dict(weight_format=mc.WFMT_I8, group_size=128),
+                             rel_logits=5e-3, max_ulp=2, max_frac=0.7, what=f"8B int8 S=8192 (MC_ATTN_T2={t2})", launched=names)
+        assert agree >= 13
+        assert ({"mc_gemv_i8_bfloat_ling4_p1_e4", "mc_gemv_i8_bfloat_ling4_p1_e2", "mc_gemv_i8_bfloat_ling14_p0_e1", "mc_gemv_i8_bfloat_ling4_p1_e5"} | attn) <= names, sorted(names)
 
 
 def t_weights_model(cfg, seed):
