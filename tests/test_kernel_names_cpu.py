@@ -60,6 +60,12 @@ def test_decode_and_reference_kernels_present(symbols):
               # ... with the Wo GEMV behind it (decoder.cc attn_wo_fused: head_dim x KiB per Wo row)
               "mc_attn_wo_i4_bfloat_hd128_k2", "mc_attn_wo_i4_bfloat_hd64_k1", "mc_attn_wo_i4_bfloat_hd256_k2",
               "mc_attn_qkv_wo_i4_bfloat_hd128_k2_q2",  # wq|wk|wv, attention and Wo in one launch (round 4)
+              "mc_attn_qkv_wo_w_bfloat_hd64_k4_q4",    # ... for plain bfloat weights (decoder.cc attn_qkv_wo_w_fused)
+              "mc_attn_fused_qkn_bfloat",              # gemma3: q/k-norm + rope + cache write inside the one-launch attention
+              "mc_attn_fused_t2_bfloat",               # 128-slot ranges (decoder.cc attn_fused_t2: S = 8192)
+              # the prompt pass on the quad-interleaved weight copy and its consumers with the split-K reduce inside (round 4)
+              "mc_pf2_repack_i4", "mc_pf2_gemm_i4_bfloat", "mc_pf_rope_cache_parts_bfloat", "mc_pf_act_mul_parts_bfloat",
+              "mc_pf_rmsnorm_parts_bfloat", "mc_pf_splitk_reduce_bfloat",
               "mc_test_hold_cu"):
         assert k in symbols, k
     # the reference's own kernel names (ABI part 1, kernel/kernel.h:30-90)
