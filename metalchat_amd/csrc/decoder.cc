@@ -617,7 +617,7 @@ struct mc_decoder {
         if (!attn_wo_on || !attn_fused() || occ_wo == 0 || !lin_ok(wo) || wo.lora_cols || wo.out % 2 != 0) return false;
         const int hd = cfg.head_dim, k = wo.in / 2048;
         // (K = 8192, Llama-3-70B: measured slower than the two launches -- attn_block_kernels.hip)
-        const bool built = (hd == 128 && k == 2) || (hd == 64 && k == 1) || (hd == 256 && k == 2);
+        const bool built = (hd == 128 && k == 2) || (hd == 64 && k == 1) || (hd == 256 && k == 2) || (hd == 128 && k == 4 && getenv("MC_ATTN_WO_K4"));
         // (one 512-thread workgroup per CU: the kernels hold up to 132 VGPRs, two such workgroups would not be resident together)
         return built && wo.in == cfg.n_heads * hd && (unsigned)wo.out / 2 <= 2u * 8u * (unsigned)(nsplit * cfg.n_kv_heads) &&
                (unsigned)(nsplit * cfg.n_kv_heads) <= (unsigned)dev->prop.multiProcessorCount;

@@ -618,5 +618,8 @@ MC_ATTN_WO(mc_attn_wo_i4_bfloat_hd128_k2, 128, 2)  // Llama-3-8B: 32 heads x 128
 // (hd128_k4 -- Llama-3-70B's 64 heads, 131 KB of Wo per CU -- was built and bit-identical too, and SLOWER than the two launches:
 //  20.1 us against 9.3 + 9.7, profiles/r03_kernel_stats_70b*.csv: what this kernel gains is the Wo weights waiting in registers
 //  when the row arrives, and two row pairs of 4 KiB rows per wave are 64 registers requested behind the scores, not 16)
+#ifdef MC_ATTN_WO_K4
+MC_ATTN_WO(mc_attn_wo_i4_bfloat_hd128_k4, 128, 4)  // tuning builds (-DMC_ATTN_WO_K4 + env MC_ATTN_WO_K4): Llama-3-70B.  Round 4, with the XCD-local hand-offs: 20.17 us against 9.15 + 9.80, 124.4 / 125.2 against 126.8 / 124.7 tokens/s
+#endif
 MC_ATTN_WO(mc_attn_wo_i4_bfloat_hd64_k1, 64, 1)    // 32 heads x 64
 MC_ATTN_WO(mc_attn_wo_i4_bfloat_hd256_k2, 256, 2)  // Gemma-7B shapes: 16 heads x 256

@@ -9,7 +9,7 @@ import time
 import numpy as np
 import metalchat_amd as mc
 
-acc = mc.HardwareAccelerator()
+acc = mc.HardwareAccelerator(path=os.environ.get("MC_HSACO"))
 CASES = [
     ("tinyllama-1.1b bf16 weights S=2048", dict(dim=2048, n_heads=32, n_kv_heads=4, head_dim=64, ffn_dim=5632, n_layers=22, vocab=32000, rope_theta=10000.0), mc.WFMT_T, 0, 2048, 64, 0),
     ("llama3-8b int8 g128 S=8192 (+64 past the end)", dict(dim=4096, n_heads=32, n_kv_heads=8, head_dim=128, ffn_dim=14336, n_layers=32, vocab=128256, rope_theta=500000.0), mc.WFMT_I8, 128, 8192, 64, 64),
