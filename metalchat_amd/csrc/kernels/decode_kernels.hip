@@ -679,12 +679,13 @@ struct q_from_hbm {
 // output (its n_rep query heads, its K row, its V row: 1.5 KB), normalises and rotates them itself -- bit for bit
 // rope_kv_body: the same thread <-> pair mapping, the same wave_sum tree, the wave sums added in wave order -- and the
 // workgroup whose range holds the step's slot writes the K row and the V column to the cache for the steps to come.
-template <int HD>
+// NT: threads of the workgroup (256: mc_attn_fused_qkn_T; 512: with the Wo GEMV in the launch, mc_attn_wo_qkn_*); `red` holds NT / 64 floats
+template <int HD, int NT = 256>
 struct q_from_qkv_rows {
     static_assert(HD == 128 || HD == 256, "hd / 2 threads per head are whole waves");
     static constexpr bool LDS = true, PIN_V = false;
     static constexpr int TL_STRIDE = 8, TL_BASE = 0;
-    static constexpr uint32_t HALF = HD / 2, HPP = 256 / HALF, WPH = HALF / 64; // heads per pass of the 256 threads, waves per head
+    static constexpr uint32_t HALF = HD / 2, HPP = NT / HALF, WPH = HALF / 64; // heads per pass of the NT threads, waves per head
     typedef const __attribute__((address_space(3))) bf16_t* lds_row;
     typedef __attribute__((address_space(3))) bf16_t* lds_row_w;
     lds_row q_s, k_s, v_s;
@@ -699,9 +700,10 @@ struct q_from_qkv_rows {
     // (at_start, called by the kernel before anything else) -- in front of the K and V tiles, 64 KB per workgroup at head_dim 256: asked for behind them (the first
     // build) these 1.5 KB of L2 hits sat behind 128 KB per CU in the memory pipe and the launch lasted 3.8 us longer.
     static constexpr int NPRE = 3; // passes whose rows are requested up front (gemma3's shapes: at most 5 heads per kv head)
-    bf16_t px1[NPRE], px2[NPRE]; // RAW: a value converted where it is loaded is waited for there, in front of the tile requests
+    uint32_t pxr[NPRE]; // RAW pairs (one 4-byte load each): a value converted where it is loaded is waited for there, in front of the tile requests
+                        // (32-bit members: 2-byte members of a policy passed by value went through scratch -- 160 bytes per thread)
     float pc = 0.0f, ps = 0.0f;
-    bf16_t nq0, nq1, nk0, nk1;
+    uint32_t nq0, nq1, nk0, nk1; // (the norm weights' bits, zero-extended)
     uint32_t ws_, rrow_;
     // (what crosses these barriers is in LDS: wait for the LDS counter only.  __syncthreads() behind a global store -- the cache
     //  write below -- drains the vector-memory counter too, i.e. waits for the V tile in front of the scores: the launch then
@@ -720,8 +722,7 @@ struct q_from_qkv_rows {
         for (int p = 0; p < NPRE; p++) {
             const uint32_t hl = (uint32_t)p * HPP + tid / HALF, hc = hl < n_rep + 1u ? hl : n_rep;
             const bf16_t* src = head_row(kv, hc);
-            px1[p] = src[2 * j]; // packed [2j] = natural [j], [2j + 1] = natural [j + hd / 2]
-            px2[p] = src[2 * j + 1];
+            pxr[p] = *reinterpret_cast<const uint32_t*>(src + 2 * j); // packed [2j] = natural [j], [2j + 1] = natural [j + hd / 2]
         }
         nq0 = q_norm[j]; nq1 = q_norm[j + HALF];
         nk0 = k_norm[j]; nk1 = k_norm[j + HALF];
@@ -742,14 +743,18 @@ struct q_from_qkv_rows {
         // heads n_rep .. : the K row (one more normalised head); passes of HPP heads.  The first pass is straight-line code in front of
         // the loop: hipcc waits vmcnt(0) at the head of a loop whose body uses loaded values, i.e. for the K tile -- the norms of
         // the first pass (Gemma-7B: the only one) then run while the tile is still in flight, on the launch's oldest loads
-        auto one_pass = [&](uint32_t h0, uint32_t p) {
+        // (p is a compile-time constant: with a run-time p hipcc turned the choice among pxr[0..2] into an indexed read of the
+        //  policy object in SCRATCH -- 168 bytes per thread, the whole object stored there by the first instructions of the launch)
+        auto one_pass = [&](uint32_t h0, auto p_c) {
+            constexpr int p = decltype(p_c)::value;
             const uint32_t hl = h0 + tid / HALF, j = tid % HALF;
             const bool live = hl < n_rep + 1u, is_q = hl < n_rep;
             const uint32_t hc = live ? hl : n_rep;
             float x1, x2;
-            if (p < (uint32_t)NPRE) { // (wave-uniform)
-                x1 = bf2f(p == 0 ? px1[0] : (p == 1 ? px1[1] : px1[2]));
-                x2 = bf2f(p == 0 ? px2[0] : (p == 1 ? px2[1] : px2[2]));
+            if constexpr (p < NPRE) {
+                const uint32_t raw = pxr[p];
+                x1 = __uint_as_float(raw << 16);
+                x2 = __uint_as_float(raw & 0xFFFF0000u);
             } else {
                 const bf16_t* src = head_row(kv, hc);
                 x1 = bf2f(src[2 * j]);
@@ -779,10 +784,12 @@ struct q_from_qkv_rows {
                 }
             }
         };
-        one_pass(0u, 0u);
-        for (uint32_t h0 = HPP, p = 1; h0 < n_rep + 1u; h0 += HPP, p++) one_pass(h0, p);
+        one_pass(0u, std::integral_constant<int, 0>{});
+        if (HPP < n_rep + 1u) one_pass(HPP, std::integral_constant<int, 1>{});         // (wave-uniform)
+        if (2u * HPP < n_rep + 1u) one_pass(2u * HPP, std::integral_constant<int, 2>{});
+        for (uint32_t h0 = 3u * HPP; h0 < n_rep + 1u; h0 += HPP) one_pass(h0, std::integral_constant<int, NPRE>{});
         // the V row: as the GEMV left it
-        for (uint32_t d = tid; d < (uint32_t)HD; d += 256) {
+        for (uint32_t d = tid; d < (uint32_t)HD; d += NT) {
             const bf16_t v = qkv[(size_t)(H + KV + kv) * HD + d];
             ((lds_row_w)v_s)[d] = v;
             if (writer) vt[((size_t)kv * HD + d) * max_seq + ws] = v;
