@@ -497,31 +497,36 @@ pf_gemm_big_body(const void* __restrict__ wp, const void* __restrict__ sp, const
     // -- a load behind a branch makes hipcc wait vmcnt(0) and drain the younger chunks too -- and a
     // run past the end of the K range is neutralised when it is consumed (its X packets become
     // zeros), so the loop can always run whole groups of DEPTH steps.
-    uint4 xvs[DEPTH][4], wraws[DEPTH][4];
+    // (native vectors: a HIP uint4 that is only copied global -> register -> LDS -- X always, W for plain bfloat weights -- is taken
+    //  for a memcpy and routed through SCRATCH: the `_w_` instantiations held 80 - 144 bytes of it per thread)
+    //  -- for the quantised formats, whose W packets are consumed by arithmetic, the struct type is kept: their code is what it was)
+    typedef uint32_t pf_u4n __attribute__((ext_vector_type(4)));
+    typedef typename std::conditional<WF == PF_W_T, pf_u4n, uint4>::type pf_u4;
+    pf_u4 xvs[DEPTH][4], wraws[DEPTH][4];
     float s_nexts[DEPTH];
     auto fetch = [&](int slot, uint32_t k0) {
         const uint32_t kabs = k0 + skk;
         const uint32_t kc = kabs < K ? kabs : K - 32; // K is a multiple of 32: a 32-run is inside or outside
-        const uint4* src = reinterpret_cast<const uint4*>(X + (size_t)xr * K + kc);
+        const pf_u4* src = reinterpret_cast<const pf_u4*>(X + (size_t)xr * K + kc);
 #pragma unroll
         for (int i = 0; i < 4; i++) xvs[slot][i] = src[i];
         const uint32_t wabs = k0 + wkk;
         const uint32_t wc = wabs < K ? wabs : K - 32 + (wkk & 16u); // (a run past the end: any valid run -- its X packets are zeroed)
         if (WF == PF_W_T) {
-            const uint4* ws = reinterpret_cast<const uint4*>(static_cast<const bf16_t*>(wp) + (size_t)wr * K + wc);
+            const pf_u4* ws = reinterpret_cast<const pf_u4*>(static_cast<const bf16_t*>(wp) + (size_t)wr * K + wc);
 #pragma unroll
             for (uint32_t i = 0; i < WQ; i++) wraws[slot][i] = ws[i];
         } else {
             s_nexts[slot] = pf_scale<WF, BF>(sp, wr, group ? wc >> glog : 0, ngroups);
             if (WF == PF_W_I4) {
                 if (WRUN == 32) {
-                    wraws[slot][0] = *reinterpret_cast<const uint4*>(static_cast<const char*>(wp) + (size_t)wr * rowb + wc / 2);
+                    wraws[slot][0] = *reinterpret_cast<const pf_u4*>(static_cast<const char*>(wp) + (size_t)wr * rowb + wc / 2);
                 } else {
                     const uint2 v = *reinterpret_cast<const uint2*>(static_cast<const char*>(wp) + (size_t)wr * rowb + wc / 2);
-                    wraws[slot][0] = make_uint4(v.x, v.y, 0u, 0u);
+                    wraws[slot][0] = pf_u4{v.x, v.y, 0u, 0u};
                 }
             } else {
-                const uint4* ws = reinterpret_cast<const uint4*>(static_cast<const int8_t*>(wp) + (size_t)wr * rowb + wc);
+                const pf_u4* ws = reinterpret_cast<const pf_u4*>(static_cast<const int8_t*>(wp) + (size_t)wr * rowb + wc);
                 wraws[slot][0] = ws[0];
                 if (WRUN == 32) wraws[slot][1] = ws[1];
             }
@@ -532,14 +537,14 @@ pf_gemm_big_body(const void* __restrict__ wp, const void* __restrict__ sp, const
     // one chunk out of the registers of `slot` into the LDS image of `slot`: dequantise, store
     auto stage = [&](auto slot_c, uint32_t k0) {
         constexpr int slot = decltype(slot_c)::value;
-        uint4 (&xv)[4] = xvs[slot];
-        uint4 (&wraw)[4] = wraws[slot];
+        pf_u4 (&xv)[4] = xvs[slot];
+        pf_u4 (&wraw)[4] = wraws[slot];
         const float s_next = s_nexts[slot];
         if (k0 + skk >= kend) { // wave-uniform per half-wave pair; no loads behind it
 #pragma unroll
-            for (int i = 0; i < 4; i++) xv[i] = make_uint4(0, 0, 0, 0);
+            for (int i = 0; i < 4; i++) xv[i] = pf_u4{0, 0, 0, 0};
         }
-        uint4 wo[4];
+        pf_u4 wo[4];
         if (WF == PF_W_T) {
 #pragma unroll
             for (uint32_t i = 0; i < WQ; i++) wo[i] = wraw[i];
@@ -573,13 +578,13 @@ pf_gemm_big_body(const void* __restrict__ wp, const void* __restrict__ sp, const
                 }
             }
 #pragma unroll
-            for (uint32_t i = 0; i < WQ; i++) wo[i] = make_uint4(o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]);
+            for (uint32_t i = 0; i < WQ; i++) wo[i] = pf_u4{o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]};
         }
         bf16_t* Xs = Xs_[NIMG == 2 ? slot : 0];
         bf16_t* Ws = Ws_[NIMG == 2 ? slot : 0];
         {
-            uint4* xd = reinterpret_cast<uint4*>(Xs + srow * PFB_LD + skk);
-            uint4* wd = reinterpret_cast<uint4*>(Ws + wsrow * PFB_LD + wkk);
+            pf_u4* xd = reinterpret_cast<pf_u4*>(Xs + srow * PFB_LD + skk);
+            pf_u4* wd = reinterpret_cast<pf_u4*>(Ws + wsrow * PFB_LD + wkk);
 #pragma unroll
             for (int i = 0; i < 4; i++) xd[i] = xv[i];
 #pragma unroll
