@@ -994,11 +994,16 @@ pf_attn_body(const bf16_t* Q, const bf16_t* kc, const bf16_t* vt, bf16_t* out, u
                 qa[j][d] = *reinterpret_cast<const uint4*>(Q + ((size_t)qr * H + h0 + j) * HD + d * 32 + kg);
     }
     // masked, scaled score tiles of 16 keys starting at key0 -> sv[j][i] for head j, row (lg*4+i), column l15
-    auto score_tile = [&](uint32_t key0, float (&sv)[NH][4]) {
+    // (round 4: the K fragment of the NEXT tile is requested before the current one is multiplied -- every load of this kernel
+    //  used to be waited for where it was issued (37 of its 47 s_waitcnt were vmcnt(0)) -- and the V fragments of a block are
+    //  unconditional loads from clamped addresses: a load behind a branch is waited for on the spot)
+    auto load_k = [&](uint32_t key0, uint4 (&kb)[DK]) {
         const uint32_t key = key0 + l15, keyc = key < S ? key : S - 1;
-        uint4 kb[DK];
 #pragma unroll
         for (uint32_t d = 0; d < DK; d++) kb[d] = *reinterpret_cast<const uint4*>(kbase + (size_t)keyc * HD + d * 32 + kg);
+    };
+    auto score_tile = [&](uint32_t key0, const uint4 (&kb)[DK], float (&sv)[NH][4]) {
+        const uint32_t key = key0 + l15;
 #pragma unroll
         for (int j = 0; j < NH; j++) {
             pf_f32x4 acc = {0, 0, 0, 0};
@@ -1009,7 +1014,7 @@ pf_attn_body(const bf16_t* Q, const bf16_t* kc, const bf16_t* vt, bf16_t* out, u
             for (int i = 0; i < 4; i++) {
                 const uint32_t r = r0 + lg * 4 + i;
                 const float sc = T::rt(T::rt(acc[i]) * scale);
-                sv[j][i] = (r < M && key < S && pf_visible(r, key, S, M, window)) ? sc : -INFINITY;
+                sv[j][i] = (int(r < M) & int(key < S) & int(pf_visible(r, key, S, M, window))) ? sc : -INFINITY;
             }
         }
     };
@@ -1019,11 +1024,19 @@ pf_attn_body(const bf16_t* Q, const bf16_t* kc, const bf16_t* vt, bf16_t* out, u
     for (int j = 0; j < NH; j++)
 #pragma unroll
         for (int i = 0; i < 4; i++) rsum[j][i] = 0.0f;
-    for (uint32_t b = b_lo + wave; b <= b_hi; b += 4) {
-#pragma unroll
-        for (uint32_t half = 0; half < 2; half++) {
+    {
+        uint4 k0[DK], k1[DK];
+        load_k((b_lo + wave) * 32, k0);
+        for (uint32_t b = b_lo + wave; b <= b_hi; b += 4) {
             float sv[NH][4];
-            score_tile(b * 32 + half * 16, sv);
+            load_k(b * 32 + 16, k1);
+            score_tile(b * 32, k0, sv);
+#pragma unroll
+            for (int j = 0; j < NH; j++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) rsum[j][i] += sv[j][i] == -INFINITY ? 0.0f : exp_precise(sv[j][i]);
+            load_k((b + 4) * 32, k0); // (past the range: clamped to the last key, never used)
+            score_tile(b * 32 + 16, k1, sv);
 #pragma unroll
             for (int j = 0; j < NH; j++)
 #pragma unroll
@@ -1058,34 +1071,47 @@ pf_attn_body(const bf16_t* Q, const bf16_t* kc, const bf16_t* vt, bf16_t* out, u
     for (int j = 0; j < NH; j++)
 #pragma unroll
         for (uint32_t t = 0; t < DT; t++) oacc[j][t] = pf_f32x4{0, 0, 0, 0};
+    uint4 k0[DK], k1[DK];
+    load_k((b_lo + wave) * 32, k0);
     for (uint32_t b = b_lo + wave; b <= b_hi; b += 4) {
 #pragma unroll
         for (uint32_t half = 0; half < 2; half++) {
             float sv[NH][4];
-            score_tile(b * 32 + half * 16, sv);
+            if (half == 0) {
+                load_k(b * 32 + 16, k1);
+                score_tile(b * 32, k0, sv);
+            } else {
+                load_k((b + 4) * 32, k0); // (past the range: clamped to the last key, never used)
+                score_tile(b * 32 + 16, k1, sv);
+            }
 #pragma unroll
             for (int j = 0; j < NH; j++) {
-                volatile bf16_t* mine = pl[j][wave];
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
                     const float p = sv[j][i] == -INFINITY ? 0.0f : T::rt(exp_precise(sv[j][i]) * inv[j][i]);
-                    mine[(lg * 4 + i) * 40 + half * 16 + l15] = T::st(p);
+                    pl[j][wave][(lg * 4 + i) * 40 + half * 16 + l15] = T::st(p);
                 }
             }
         }
+        // (the tile is private to this wave and LDS executes a wave's accesses in order: wavefront-scope fences keep the compiler
+        //  from moving the accesses and cost no wait.  Round 4: these were `volatile` accesses, which hipcc lowers to FLAT
+        //  loads/stores each followed by s_waitcnt vmcnt(0) -- 24 serial round trips per 32 keys, and every load in flight
+        //  waited for with them)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         uint4 pa[NH];
 #pragma unroll
-        for (int j = 0; j < NH; j++) {
-            const volatile uint32_t* src = reinterpret_cast<const volatile uint32_t*>(pl[j][wave] + l15 * 40 + kg);
-            pa[j] = make_uint4(src[0], src[1], src[2], src[3]);
-        }
+        for (int j = 0; j < NH; j++) pa[j] = *reinterpret_cast<const uint4*>(&pl[j][wave][l15 * 40 + kg]);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const uint32_t c = b * 32 + kg;
 #pragma unroll
         for (uint32_t t = 0; t < DT; t++) {
-            uint4 vb = make_uint4(0, 0, 0, 0);
-            if (c + 8 <= max_seq) vb = *reinterpret_cast<const uint4*>(vbase + (size_t)(t * 16 + l15) * max_seq + c);
+            const uint32_t vm = c + 8 <= max_seq ? 0xFFFFFFFFu : 0u;
+            uint4 vb = *reinterpret_cast<const uint4*>(vbase + (size_t)(t * 16 + l15) * max_seq + (c + 8 <= max_seq ? c : max_seq - 8));
+            vb = make_uint4(vb.x & vm, vb.y & vm, vb.z & vm, vb.w & vm);
 #pragma unroll
             for (int j = 0; j < NH; j++)
                 oacc[j][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(pf_bf16x8, pa[j]), __builtin_bit_cast(pf_bf16x8, vb), oacc[j][t], 0, 0, 0);
