@@ -248,6 +248,7 @@ struct mc_decoder {
     void *pf_x = nullptr, *pf_xn = nullptr, *pf_h = nullptr, *pf_proj = nullptr, *pf_qkv = nullptr,
          *pf_q = nullptr, *pf_att = nullptr, *pf_g2 = nullptr, *pf_g = nullptr, *pf_probs = nullptr;
     int32_t* pf_tokens = nullptr;
+    float* pf_etab = nullptr; // exp_precise of every bfloat16 value (prefill_kernels.hip mc_exp_table_bfloat), 256 KiB
     void* pf_lora = nullptr;
     size_t pf_lora_elems = 0;
     float* pf_part = nullptr; // split-K partial sums [splits][M][N]
@@ -1178,6 +1179,12 @@ struct mc_decoder {
 #undef A
             pf_cap = cap;
         }
+        if (tb == 2 && !pf_etab) {
+            s = alloc((void**)&pf_etab, 65536 * sizeof(float), false);
+            if (s != MC_OK) return s;
+            s = launch("mc_exp_table_bfloat", 256, 1, 1, 256, 0, pack(pf_etab));
+            if (s != MC_OK) return s;
+        }
         const size_t need = (tb == 2 && !pf_two_pass) ? 0 : (size_t)H * M * S;
         if (need > pf_probs_elems) {
             MC_HIP(hipStreamSynchronize(stream));
@@ -1205,6 +1212,15 @@ struct mc_decoder {
         const unsigned want = (bm == 256 ? 1u : 2u) * (unsigned)dev->prop.multiProcessorCount; // (256 rows: one 8-wave workgroup per CU)
         unsigned splits = 1;
         while (splits < 16 && tiles * splits < want && (unsigned)L.in / (splits * 2) >= 512) splits *= 2;
+        // (round 4) ... but not past the point where the extra workgroups only start another round: 96 tiles on 256 CUs take one
+        // round of K/2 at 2 splits and two rounds of K/4 at 4 -- the same time, with twice the partials written and read back
+        // (MC_PF_SPLITS_OLD=1: the plain doubling rule)
+        const bool old_rule = getenv("MC_PF_SPLITS_OLD") != nullptr;
+        if (!old_rule && splits > 1) {
+            auto rounds = [&](unsigned sp) { return (tiles * sp + want - 1) / want; };
+            const unsigned half = splits / 2;
+            if (rounds(splits) * half >= rounds(half) * splits) splits = half; // rounds(s)/s >= rounds(s/2)/(s/2)
+        }
         return getenv("MC_PF_NO_SPLITK") ? 1u : splits;
     }
     // Short prompts (<= 64 rows) on int4 weights: the weight-streaming GEMM over the quad-interleaved copy (prefill_kernels.hip
@@ -1446,7 +1462,7 @@ struct mc_decoder {
                     const bool two = (H / KV) % 2 == 0 && hd <= 128 && (heads_env ? atoi(heads_env) == 2 : enough);
                     return launch(std::string(two ? "mc_pf_attn2_bfloat_hd" : "mc_pf_attn_bfloat_hd") + std::to_string(hd), (M + 15) / 16, two ? H / 2 : H, 1, 256, 0,
                                   pack(pf_q, L.kc, L.vt, pf_att, (uint32_t)M, (uint32_t)S, (uint32_t)H, (uint32_t)(H / KV),
-                                       (uint32_t)cfg.max_seq_len, scale_T, win));
+                                       (uint32_t)cfg.max_seq_len, scale_T, win, (const void*)pf_etab));
                 });
                 if (s != MC_OK) return s;
             } else {
@@ -1481,15 +1497,23 @@ struct mc_decoder {
             //  SLOWER: 13.60 against 13.26 ms per 512-row prompt, 52.0 against 50.6 at 2048 rows: half the lanes idle through the
             //  fp64 exponential, in the kernel that holds the matrix pipe)
             const unsigned act_pp = 8u / (unsigned)tb; // pairs per thread (one 16-byte packet)
-            if (cfg.ffn_dim % 4 == 0 && gemm_to_parts(L.w13, pf_xn, M, &sp, &gs)) {
+            // silu(w1 x) * (w3 x) in the epilogue of an unsplit 256-row GEMM (prefill_kernels.hip pf_gemm_big_body EPI 3; the
+            // table of exponentials rides in `res`).  MC_PF_ACT_EPI=0: the separate launch
+            const bool act_epi_on = !(getenv("MC_PF_ACT_EPI") && atoi(getenv("MC_PF_ACT_EPI")) == 0);
+            const bool act_epi = act_epi_on && tb == 2 && !gemma && !L.w13.lora_cols && !getenv("MC_PF_SMALL_GEMM") && !pf2_ok(L.w13, M) &&
+                                 gemm_row_tile(M) == 256 && gemm_splits(L.w13, M) == 1 && !(getenv("MC_PF_DEPTH") && atoi(getenv("MC_PF_DEPTH")) == 1);
+            if (act_epi) {
+                s = timed("gemm_w13_act", [&] { return gemm(L.w13, 3, pf_xn, pf_g, pf_etab, M); });
+            } else if (cfg.ffn_dim % 4 == 0 && gemm_to_parts(L.w13, pf_xn, M, &sp, &gs)) {
                 if (gs != MC_OK) return gs;
                 s = timed("act_mul", [&] { return launch("mc_pf_act_mul_parts_" + tname, (cfg.ffn_dim / 4 + 255) / 256 + 1, M, 1, 256, 0,
-                           pack((const void*)pf_part, sp, (uint32_t)M, pf_g, (uint32_t)cfg.ffn_dim, (int32_t)(gemma ? 1 : 0))); });
+                           pack((const void*)pf_part, sp, (uint32_t)M, pf_g, (uint32_t)cfg.ffn_dim, (int32_t)(gemma ? 1 : 0), (const void*)pf_etab)); });
             } else {
                 s = timed("gemm_w13", [&] { return gemm(L.w13, 0, pf_xn, pf_g2, nullptr, M); });
                 if (s != MC_OK) return s;
                 s = timed("act_mul", [&] { return launch("mc_pf_act_mul_" + tname, (cfg.ffn_dim / act_pp + 255) / 256 + 1, M, 1, 256, 0,
-                           pack(pf_g2, pf_g, (uint32_t)cfg.ffn_dim, (int32_t)(gemma ? 1 : 0))); });
+                           tb == 2 ? pack(pf_g2, pf_g, (uint32_t)cfg.ffn_dim, (int32_t)(gemma ? 1 : 0), (const void*)pf_etab)
+                                   : pack(pf_g2, pf_g, (uint32_t)cfg.ffn_dim, (int32_t)(gemma ? 1 : 0))); });
             }
             if (s != MC_OK) return s;
             if (L.ffn_post_norm) {

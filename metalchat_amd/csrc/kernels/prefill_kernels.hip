@@ -155,12 +155,62 @@ mc_pf_rmsnorm_float(const float* x, const float* w, const float* res, float* y, 
     pf_rmsnorm_body<F32>(x, w, res, y, dim, eps, mu);
 }
 
+// ------------------------------------------------------------------------------------------ exp of a bfloat16, by table
+// The exponentials of the prompt pass take bfloat16 arguments (a score is T(T(q.k) * scale), the silu argument is a GEMM output),
+// and exp_precise is ~50 fp64 instructions: at 512 rows the attention kernel spent more issue slots on it than on everything else
+// together (8.4 M per layer, twice; 7.3 M more in the activation).  There are 65536 bfloat16 values: mc_exp_table_bfloat evaluates
+// exp_precise once for each of them (256 KiB, built when the decoder is), tab[bits] IS exp_precise(value) -- the same function, the
+// same device, the same bits.  mc_pf_act_mul* gather from the table in global memory; the attention keeps the part of it that is
+// not constant in LDS (pf_exp_window below).
+extern "C" __global__ void
+mc_exp_table_bfloat(float* tab)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 65536u) tab[i] = exp_precise(__uint_as_float(i << 16));
+}
+__device__ __forceinline__ float
+pf_exp_tab(const float* tab, float x) // x a bfloat16 value
+{
+    return tab[__float_as_uint(x) >> 16];
+}
+// The window: |x| in [2^-25, 2^7) -- 32 binades x 128 mantissas x 2 signs = 8192 floats, 32 KiB.  Below it exp(x) rounds to 1.0f
+// (like exp(+-2^-25), the first entries), above it exp(x) is inf or 0 (like the last entries; -inf, the masked score, included):
+// clamping the magnitude bits into the window gives the table's value for every bfloat16 that is not a NaN, and a NaN is passed
+// through.  mc_pf_exp_window_bfloat runs the lookup over all 65536 values for tests/test_prefill_gpu.py to compare with the table.
+struct pf_exp_window {
+    static constexpr uint32_t LO = 102u << 7, HI = 134u << 7, N = HI - LO; // magnitude bits of 2^-25 and of 2^7
+    float* w;                                                                // 2 N floats of LDS
+    __device__ __forceinline__ void
+    fill(const float* tab) const // every thread of the workgroup; a barrier before the first lookup
+    {
+        for (uint32_t i = threadIdx.x * 4; i < 2 * N; i += blockDim.x * 4)
+            *reinterpret_cast<float4*>(w + i) = *reinterpret_cast<const float4*>(tab + ((i / N) << 15) + LO + i % N);
+    }
+    __device__ __forceinline__ float
+    operator()(float x) const
+    {
+        const uint32_t b = __float_as_uint(x) >> 16, a = b & 0x7FFFu;
+        const float e = w[min(max(a, LO), HI - 1) - LO + (b >> 15) * N];
+        return a > 0x7F80u ? x : e;
+    }
+};
+extern "C" __global__ void __launch_bounds__(256)
+mc_pf_exp_window_bfloat(const float* tab, float* out)
+{
+    __shared__ __attribute__((aligned(16))) float win[2 * pf_exp_window::N];
+    const pf_exp_window ew{win};
+    ew.fill(tab);
+    __syncthreads();
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < 65536u; i += gridDim.x * blockDim.x) out[i] = ew(__uint_as_float(i << 16));
+}
+
 // rows (2j, 2j+1) of the fused matrix = (w1 row j, w3 row j): out[r][j] = T(act(a) * b)
 template <typename T>
 __device__ __forceinline__ float
-pf_silu_T(float x)
+pf_silu_T(float x, const float* etab = nullptr)
 {
-    const float e = T::rt(exp_precise(-x));
+    // (bfloat16: x is a bfloat16 value and so is -x -- the table's entry is exp_precise(-x))
+    const float e = T::rt(T::bytes == 2 ? pf_exp_tab(etab, -x) : exp_precise(-x));
     const float d = T::rt(1.0f + e);
     return T::rt(x / d);
 }
@@ -175,14 +225,14 @@ pf_gelu_f(float x)
 }
 template <typename T>
 __device__ __forceinline__ void
-pf_act_mul_body(const typename T::S* in, typename T::S* out, uint32_t ffn, int32_t gelu)
+pf_act_mul_body(const typename T::S* in, typename T::S* out, uint32_t ffn, int32_t gelu, const float* etab = nullptr)
 {
     // a thread finishes the pairs of one 16-byte packet of the fused row (4 pairs in bf16, 2 in float)
     constexpr uint32_t PP = 8 / T::bytes;
     const uint32_t j0 = (blockIdx.x * blockDim.x + threadIdx.x) * PP, r = blockIdx.y;
     if (j0 >= ffn) return;
     auto one = [&](float a, float b) {
-        const float g = gelu ? T::rt(pf_gelu_f(a)) : pf_silu_T<T>(a);
+        const float g = gelu ? T::rt(pf_gelu_f(a)) : pf_silu_T<T>(a, etab);
         return g * b;
     };
     if (ffn % PP == 0) {
@@ -205,9 +255,9 @@ pf_act_mul_body(const typename T::S* in, typename T::S* out, uint32_t ffn, int32
     }
 }
 extern "C" __global__ void
-mc_pf_act_mul_bfloat(const bf16_t* in, bf16_t* out, uint32_t ffn, int32_t gelu)
+mc_pf_act_mul_bfloat(const bf16_t* in, bf16_t* out, uint32_t ffn, int32_t gelu, const float* etab)
 {
-    pf_act_mul_body<BF>(in, out, ffn, gelu);
+    pf_act_mul_body<BF>(in, out, ffn, gelu, etab);
 }
 extern "C" __global__ void
 mc_pf_act_mul_float(const float* in, float* out, uint32_t ffn, int32_t gelu)
@@ -637,6 +687,33 @@ pf_gemm_big_body(const void* __restrict__ wp, const void* __restrict__ sp, const
             multiply(std::integral_constant<int, 0>{});
         }
     }
+    if constexpr (EPI == 3) {
+        // silu(w1 x) * (w3 x) here (round 4): columns (2j, 2j + 1) of the fused w1|w3 output are the pair (a, b) of mc_pf_act_mul and
+        // sit in neighbouring lanes; the even lane finishes rows 0-1 of its four, the odd lane rows 2-3, and Y is [M][N / 2].  The
+        // exponential is the table's (`res` carries it), so no lane sits through an fp64 one -- which is what made the first build
+        // of this epilogue slower than the separate launch -- and the [M][N] intermediate (29 MB per layer at 512 rows) is neither
+        // written nor read back.  Same arithmetic as mc_pf_act_mul_bfloat: a = T(acc), b = T(acc), T(silu_T(a) * b).
+        const float* etab = reinterpret_cast<const float*>(res);
+        const uint32_t odd = lane & 1, N2 = N / 2;
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+            for (int nt = 0; nt < 4; nt++) {
+                float v[4], pr[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) v[i] = BF::rt(acc[mt][nt][i]);
+#pragma unroll
+                for (int i = 0; i < 4; i++) // the neighbour's value: quad_perm [1, 0, 3, 2]
+                    pr[i] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[i]), 0xB1, 0xf, 0xf, true));
+                const uint32_t mb = m0 + wm * 64 + mt * 16 + (lane >> 4) * 4 + odd * 2, n = n0 + wn * 64 + nt * 16 + (lane & 15);
+#pragma unroll
+                for (int i = 0; i < 2; i++) {
+                    const float a = odd ? pr[2 + i] : v[i], b = odd ? v[2 + i] : pr[i];
+                    if (mb + i < M && n < N) Y[(size_t)(mb + i) * N2 + (n >> 1)] = BF::st(pf_silu_T<BF>(a, etab) * b);
+                }
+            }
+        return;
+    }
 #pragma unroll
     for (int mt = 0; mt < 4; mt++)
 #pragma unroll
@@ -696,6 +773,9 @@ MC_PF_GEMM_256(mc_pf_gemm256_i8_bfloat_d2_e2, PF_W_I8, 2)
 MC_PF_GEMM_256(mc_pf_gemm256_w_bfloat_d2_e0, PF_W_T, 0)
 MC_PF_GEMM_256(mc_pf_gemm256_w_bfloat_d2_e1, PF_W_T, 1)
 MC_PF_GEMM_256(mc_pf_gemm256_w_bfloat_d2_e2, PF_W_T, 2)
+MC_PF_GEMM_256(mc_pf_gemm256_i4_bfloat_d2_e3, PF_W_I4, 3)
+MC_PF_GEMM_256(mc_pf_gemm256_i8_bfloat_d2_e3, PF_W_I8, 3)
+MC_PF_GEMM_256(mc_pf_gemm256_w_bfloat_d2_e3, PF_W_T, 3)
 MC_PF_GEMM_BIG_D(mc_pf_gemm128_i4_bfloat_d2_e0, PF_W_I4, 0, 2)
 MC_PF_GEMM_BIG_D(mc_pf_gemm128_i4_bfloat_d2_e1, PF_W_I4, 1, 2)
 MC_PF_GEMM_BIG_D(mc_pf_gemm128_i4_bfloat_d2_e2, PF_W_I4, 2, 2)
@@ -962,7 +1042,7 @@ mc_pf_pv_float(const float* probs, const float* vt, float* out, uint32_t M, uint
 template <uint32_t HD, int NH>
 __device__ __forceinline__ void
 pf_attn_body(const bf16_t* Q, const bf16_t* kc, const bf16_t* vt, bf16_t* out, uint32_t M, uint32_t S, uint32_t H,
-             uint32_t n_rep, uint32_t max_seq, float scale, uint32_t window)
+             uint32_t n_rep, uint32_t max_seq, float scale, uint32_t window, const float* etab)
 {
     // NH query heads of ONE kv head per workgroup (grid.y = H / NH; NH divides n_rep): every K and V
     // fragment a wave loads is multiplied NH times -- the waves of this kernel spend two thirds of
@@ -971,6 +1051,15 @@ pf_attn_body(const bf16_t* Q, const bf16_t* kc, const bf16_t* vt, bf16_t* out, u
     constexpr uint32_t DT = HD / 16, DK = HD / 32;
     __shared__ float wsum[NH][4][16];
     __shared__ float inv_sum[NH][16];
+    // exp of a score (a bfloat16 value; -inf where masked -> 0) from the LDS window of the table: filled here, first used behind
+    // the barrier in front of pass 1
+    // (one head per workgroup -- the kernel of short prompts and of head_dim 256 -- gathers from the table in global memory instead:
+    //  filling the window costs 1.4 us per launch, more than the few exponentials of an 8-row prompt ever did)
+    constexpr bool WIN = NH > 1;
+    __shared__ __attribute__((aligned(16))) float ewin[WIN ? 2 * pf_exp_window::N : 4];
+    const pf_exp_window ewl{ewin};
+    if (WIN) ewl.fill(etab);
+    auto ew = [&](float x) { return WIN ? ewl(x) : pf_exp_tab(etab, x); };
     __shared__ __attribute__((aligned(16))) bf16_t pl[NH][4][16 * 40]; // 16 rows x 32 keys, rows padded to 80 bytes
     constexpr uint32_t OD = HD < 128 ? HD : 128; // output columns reduced per phase
     __shared__ float osum[4][16][OD + 1];
@@ -1027,6 +1116,7 @@ pf_attn_body(const bf16_t* Q, const bf16_t* kc, const bf16_t* vt, bf16_t* out, u
     {
         uint4 k0[DK], k1[DK];
         load_k((b_lo + wave) * 32, k0);
+        if (WIN) __syncthreads(); // the exp window is filled
         for (uint32_t b = b_lo + wave; b <= b_hi; b += 4) {
             float sv[NH][4];
             load_k(b * 32 + 16, k1);
@@ -1034,13 +1124,13 @@ pf_attn_body(const bf16_t* Q, const bf16_t* kc, const bf16_t* vt, bf16_t* out, u
 #pragma unroll
             for (int j = 0; j < NH; j++)
 #pragma unroll
-                for (int i = 0; i < 4; i++) rsum[j][i] += sv[j][i] == -INFINITY ? 0.0f : exp_precise(sv[j][i]);
+                for (int i = 0; i < 4; i++) rsum[j][i] += ew(sv[j][i]);
             load_k((b + 4) * 32, k0); // (past the range: clamped to the last key, never used)
             score_tile(b * 32 + 16, k1, sv);
 #pragma unroll
             for (int j = 0; j < NH; j++)
 #pragma unroll
-                for (int i = 0; i < 4; i++) rsum[j][i] += sv[j][i] == -INFINITY ? 0.0f : exp_precise(sv[j][i]);
+                for (int i = 0; i < 4; i++) rsum[j][i] += ew(sv[j][i]);
         }
     }
 #pragma unroll
@@ -1088,7 +1178,7 @@ pf_attn_body(const bf16_t* Q, const bf16_t* kc, const bf16_t* vt, bf16_t* out, u
             for (int j = 0; j < NH; j++) {
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
-                    const float p = sv[j][i] == -INFINITY ? 0.0f : T::rt(exp_precise(sv[j][i]) * inv[j][i]);
+                    const float p = T::rt(ew(sv[j][i]) * inv[j][i]); // (masked: exp(-inf) = 0 from the table, T(0 * inv) = 0)
                     pl[j][wave][(lg * 4 + i) * 40 + half * 16 + l15] = T::st(p);
                 }
             }
@@ -1138,15 +1228,17 @@ pf_attn_body(const bf16_t* Q, const bf16_t* kc, const bf16_t* vt, bf16_t* out, u
 #define MC_PF_ATTN(HD)                                                                                              \
     extern "C" __global__ void __launch_bounds__(256)                                                               \
     mc_pf_attn_bfloat_hd##HD(const bf16_t* Q, const bf16_t* kc, const bf16_t* vt, bf16_t* out, uint32_t M, uint32_t S, \
-                             uint32_t H, uint32_t n_rep, uint32_t max_seq, float scale, uint32_t window)          \
+                             uint32_t H, uint32_t n_rep, uint32_t max_seq, float scale, uint32_t window,          \
+                             const float* etab)                                                                     \
     {                                                                                                               \
-        pf_attn_body<HD, 1>(Q, kc, vt, out, M, S, H, n_rep, max_seq, scale, window);                                \
+        pf_attn_body<HD, 1>(Q, kc, vt, out, M, S, H, n_rep, max_seq, scale, window, etab);                          \
     }                                                                                                               \
     extern "C" __global__ void __launch_bounds__(256)                                                               \
     mc_pf_attn2_bfloat_hd##HD(const bf16_t* Q, const bf16_t* kc, const bf16_t* vt, bf16_t* out, uint32_t M, uint32_t S, \
-                              uint32_t H, uint32_t n_rep, uint32_t max_seq, float scale, uint32_t window)         \
+                              uint32_t H, uint32_t n_rep, uint32_t max_seq, float scale, uint32_t window,         \
+                              const float* etab)                                                                    \
     {                                                                                                               \
-        pf_attn_body<HD, 2>(Q, kc, vt, out, M, S, H, n_rep, max_seq, scale, window);                                \
+        pf_attn_body<HD, 2>(Q, kc, vt, out, M, S, H, n_rep, max_seq, scale, window, etab);                          \
     }
 MC_PF_ATTN(32)
 MC_PF_ATTN(64)
@@ -1392,7 +1484,7 @@ mc_pf_rope_cache_parts_bfloat(const float* part, uint32_t splits, uint32_t M, bf
 }
 // w1|w3 partials -> act(a) * b (mc_pf_act_mul_bfloat with the reduce in front); ffn a multiple of 4
 extern "C" __global__ void
-mc_pf_act_mul_parts_bfloat(const float* part, uint32_t splits, uint32_t M, bf16_t* out, uint32_t ffn, int32_t gelu)
+mc_pf_act_mul_parts_bfloat(const float* part, uint32_t splits, uint32_t M, bf16_t* out, uint32_t ffn, int32_t gelu, const float* etab)
 {
     const uint32_t j0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4, r = blockIdx.y;
     if (j0 >= ffn) return;
@@ -1403,7 +1495,7 @@ mc_pf_act_mul_parts_bfloat(const float* part, uint32_t splits, uint32_t M, bf16_
     auto one = [&](float a, float b) {
         a = bf2f(f2bf(a));
         b = bf2f(f2bf(b));
-        const float g = gelu ? BF::rt(pf_gelu_f(a)) : pf_silu_T<BF>(a);
+        const float g = gelu ? BF::rt(pf_gelu_f(a)) : pf_silu_T<BF>(a, etab);
         return g * b;
     };
     const float o0 = one(lo.x, lo.y), o1 = one(lo.z, lo.w), o2 = one(hi.x, hi.y), o3 = one(hi.z, hi.w);

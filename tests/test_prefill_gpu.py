@@ -368,3 +368,59 @@ def test_split_k_reduce_folded_into_the_consumers_is_bit_identical(acc, n, monke
         parity.exact(out["1"][2][layer], out["0"][2][layer], f"hidden[{layer}]")
         parity.exact(out["1"][3][layer][0], out["0"][3][layer][0], f"K[{layer}]")
         parity.exact(out["1"][3][layer][1], out["0"][3][layer][1], f"V[{layer}]")
+
+
+def test_exp_table_holds_the_rounded_double_exp_of_every_bfloat16_and_the_lds_window_reads_it_back(acc):
+    """prefill_kernels.hip: the prompt pass takes exp of bfloat16 values (scores, silu arguments) from a 65536-entry table
+    built with the same exp_precise the kernels used inline.  (a) every entry is the correctly rounded exp the oracle
+    computes ((float)exp((double)x), oracle/mc_oracle.py softmax / silu); (b) the attention's 8192-entry LDS window
+    with clamped magnitude bits returns the table's value for EVERY bfloat16 bit pattern (NaNs pass through)."""
+    import metalchat_amd as mc
+
+    tab = acc.alloc(65536 * 4)
+    out = acc.alloc(65536 * 4)
+    mc.KernelTask(acc.load("mc_exp_table_bfloat"), (65536, 1, 1), (256, 1, 1), [tab])()
+    mc.KernelTask(acc.load("mc_pf_exp_window_bfloat"), (8 * 256, 1, 1), (256, 1, 1), [tab, out])()
+    acc.wait()
+    t = tab.download(np.float32, 65536)
+    w = out.download(np.float32, 65536)
+    x = (np.arange(65536, dtype=np.uint32) << 16).view(np.float32)
+    with np.errstate(over="ignore", under="ignore", invalid="ignore"):
+        want = np.exp(x.astype(np.float64)).astype(np.float32)
+    nan = np.isnan(x)
+    assert np.array_equal(t[~nan].view(np.uint32), want[~nan].view(np.uint32))
+    assert np.isnan(t[nan]).all()
+    assert np.array_equal(w[~nan].view(np.uint32), t[~nan].view(np.uint32))
+    assert np.array_equal(w[nan].view(np.uint32), x[nan].view(np.uint32))
+    assert t[0xFF80] == 0.0 and t[0x7F80] == np.inf and t[0] == 1.0 and t[0x8000] == 1.0
+
+
+@pytest.mark.parametrize("fmt,quant,group", [(2, "i4", 128), (1, "i8", 32), (0, None, 0)])
+@pytest.mark.parametrize("n", [256, 300])
+def test_activation_in_the_gemm_epilogue_is_bit_identical_to_the_separate_launch(acc, n, fmt, quant, group, monkeypatch):
+    """From 256 rows on an unsplit w1|w3 GEMM finishes silu(a) * b in its epilogue (prefill_kernels.hip pf_gemm_big_body, EPI 3:
+    neighbouring lanes hold the pair) and mc_pf_act_mul never launches.  Same roundings in the same order: every tap is the
+    same bits with MC_PF_ACT_EPI=0, and both agree with the oracle like any prompt (test_prompt_lengths_around_the_tile_edges
+    runs through this epilogue)."""
+    import metalchat_amd as mc
+
+    cfg = mg.tiny_cfg(BF16, dim=256, n_heads=4, n_kv_heads=2, head_dim=64, ffn_dim=768, n_layers=2, vocab=384, max_seq_len=320)
+    weights = mg.make_model(cfg, seed=89, quant=quant, group=group or 32)
+    tokens = np.random.default_rng(n).integers(0, cfg["vocab"], n).tolist()
+    out = {}
+    for epi in ("1", "0"):
+        monkeypatch.setenv("MC_PF_ACT_EPI", epi)
+        dec = mc.Decoder(acc, **mg.decoder_kwargs(cfg, weight_format=fmt, group_size=group))
+        dec.load_model(weights)
+        dec.set_taps(True)
+        dec.launch_log(True)
+        tok = dec.prefill(tokens, 0)
+        names = set(dec.launched())
+        fused = [x for x in names if x.endswith("_e3")]
+        assert (len(fused) == 1 and not [x for x in names if "act_mul" in x]) if epi == "1" else (not fused and [x for x in names if "act_mul" in x]), sorted(names)
+        out[epi] = (tok, dec.logits().copy(), [dec.hidden(layer).copy() for layer in range(cfg["n_layers"])])
+        dec.release()
+    assert out["1"][0] == out["0"][0]
+    parity.exact(out["1"][1], out["0"][1], "logits, activation in the epilogue vs its own launch")
+    for layer in range(cfg["n_layers"]):
+        parity.exact(out["1"][2][layer], out["0"][2][layer], f"hidden[{layer}]")
