@@ -1053,13 +1053,15 @@ pf_attn_body(const bf16_t* Q, const bf16_t* kc, const bf16_t* vt, bf16_t* out, u
     __shared__ float inv_sum[NH][16];
     // exp of a score (a bfloat16 value; -inf where masked -> 0) from the LDS window of the table: filled here, first used behind
     // the barrier in front of pass 1
-    // (one head per workgroup -- the kernel of short prompts and of head_dim 256 -- gathers from the table in global memory instead:
-    //  filling the window costs 1.4 us per launch, more than the few exponentials of an 8-row prompt ever did)
+    // (one head per workgroup -- the kernel of short prompts and of head_dim 256 -- keeps the inline exponential: at 8 rows the
+    //  few exponentials cost nothing, filling the window costs 1.4 us per launch (6.3 -> 7.7 us), and gathering from the table in
+    //  global memory costs more still (8.6 us: the weight stream of a short prompt has flushed the table out of L2 by the next
+    //  layer, and each gather is then a dependent trip to HBM))
     constexpr bool WIN = NH > 1;
     __shared__ __attribute__((aligned(16))) float ewin[WIN ? 2 * pf_exp_window::N : 4];
     const pf_exp_window ewl{ewin};
     if (WIN) ewl.fill(etab);
-    auto ew = [&](float x) { return WIN ? ewl(x) : pf_exp_tab(etab, x); };
+    auto ew = [&](float x) { return WIN ? ewl(x) : exp_precise(x); };
     __shared__ __attribute__((aligned(16))) bf16_t pl[NH][4][16 * 40]; // 16 rows x 32 keys, rows padded to 80 bytes
     constexpr uint32_t OD = HD < 128 ? HD : 128; // output columns reduced per phase
     __shared__ float osum[4][16][OD + 1];
