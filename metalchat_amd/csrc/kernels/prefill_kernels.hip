@@ -1058,6 +1058,7 @@ pf_attn_body(const bf16_t* Q, const bf16_t* kc, const bf16_t* vt, bf16_t* out, u
     //  global memory costs more still (8.6 us: the weight stream of a short prompt has flushed the table out of L2 by the next
     //  layer, and each gather is then a dependent trip to HBM))
     constexpr bool WIN = NH > 1;
+    constexpr bool PRE = NH > 1; // K fragments one tile ahead (with the inline fp64 exponential the address registers do not fit: SGPR spills)
     __shared__ __attribute__((aligned(16))) float ewin[WIN ? 2 * pf_exp_window::N : 4];
     const pf_exp_window ewl{ewin};
     if (WIN) ewl.fill(etab);
@@ -1105,7 +1106,9 @@ pf_attn_body(const bf16_t* Q, const bf16_t* kc, const bf16_t* vt, bf16_t* out, u
             for (int i = 0; i < 4; i++) {
                 const uint32_t r = r0 + lg * 4 + i;
                 const float sc = T::rt(T::rt(acc[i]) * scale);
-                sv[j][i] = (int(r < M) & int(key < S) & int(pf_visible(r, key, S, M, window))) ? sc : -INFINITY;
+                const bool vis = NH > 1 ? bool(int(r < M) & int(key < S) & int(pf_visible(r, key, S, M, window)))
+                                        : (r < M && key < S && pf_visible(r, key, S, M, window));
+                sv[j][i] = vis ? sc : -INFINITY;
             }
         }
     };
@@ -1117,17 +1120,19 @@ pf_attn_body(const bf16_t* Q, const bf16_t* kc, const bf16_t* vt, bf16_t* out, u
         for (int i = 0; i < 4; i++) rsum[j][i] = 0.0f;
     {
         uint4 k0[DK], k1[DK];
-        load_k((b_lo + wave) * 32, k0);
+        if (PRE) load_k((b_lo + wave) * 32, k0);
         if (WIN) __syncthreads(); // the exp window is filled
         for (uint32_t b = b_lo + wave; b <= b_hi; b += 4) {
             float sv[NH][4];
-            load_k(b * 32 + 16, k1);
+            if (PRE) load_k(b * 32 + 16, k1);
+            else load_k(b * 32, k0);
             score_tile(b * 32, k0, sv);
 #pragma unroll
             for (int j = 0; j < NH; j++)
 #pragma unroll
                 for (int i = 0; i < 4; i++) rsum[j][i] += ew(sv[j][i]);
-            load_k((b + 4) * 32, k0); // (past the range: clamped to the last key, never used)
+            if (PRE) load_k((b + 4) * 32, k0); // (past the range: clamped to the last key, never used)
+            else load_k(b * 32 + 16, k1);
             score_tile(b * 32 + 16, k1, sv);
 #pragma unroll
             for (int j = 0; j < NH; j++)
@@ -1164,16 +1169,34 @@ pf_attn_body(const bf16_t* Q, const bf16_t* kc, const bf16_t* vt, bf16_t* out, u
 #pragma unroll
         for (uint32_t t = 0; t < DT; t++) oacc[j][t] = pf_f32x4{0, 0, 0, 0};
     uint4 k0[DK], k1[DK];
-    load_k((b_lo + wave) * 32, k0);
+    if (PRE) load_k((b_lo + wave) * 32, k0);
+    // V fragments of a block: eight at a time in flight, requested together and then multiplied (left to itself hipcc issues load -
+    // wait - multiply per fragment as soon as anything around the loop changes).  VTOP (two heads, head_dim <= 128: the registers are
+    // there): the block's eight are requested before its scores are computed, so their latency hides behind the exponentials
+    constexpr uint32_t VG = DT < 8 ? DT : 8;
+    constexpr bool VTOP = PRE && DT <= 8;
     for (uint32_t b = b_lo + wave; b <= b_hi; b += 4) {
+        const uint32_t c = b * 32 + kg;
+        const uint32_t vm = c + 8 <= max_seq ? 0xFFFFFFFFu : 0u, cc = c + 8 <= max_seq ? c : max_seq - 8;
+        const bf16_t* vp = vbase + (size_t)l15 * max_seq + cc;
+        uint4 vbs[VG];
+        if (VTOP) {
+#pragma unroll
+            for (uint32_t t = 0; t < VG; t++) {
+                vbs[t] = *reinterpret_cast<const uint4*>(vp);
+                vp += (size_t)16 * max_seq;
+            }
+        }
 #pragma unroll
         for (uint32_t half = 0; half < 2; half++) {
             float sv[NH][4];
             if (half == 0) {
-                load_k(b * 32 + 16, k1);
+                if (PRE) load_k(b * 32 + 16, k1);
+                else load_k(b * 32, k0);
                 score_tile(b * 32, k0, sv);
             } else {
-                load_k((b + 4) * 32, k0); // (past the range: clamped to the last key, never used)
+                if (PRE) load_k((b + 4) * 32, k0); // (past the range: clamped to the last key, never used)
+                else load_k(b * 32 + 16, k1);
                 score_tile(b * 32 + 16, k1, sv);
             }
 #pragma unroll
@@ -1198,15 +1221,22 @@ pf_attn_body(const bf16_t* Q, const bf16_t* kc, const bf16_t* vt, bf16_t* out, u
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const uint32_t c = b * 32 + kg;
 #pragma unroll
-        for (uint32_t t = 0; t < DT; t++) {
-            const uint32_t vm = c + 8 <= max_seq ? 0xFFFFFFFFu : 0u;
-            uint4 vb = *reinterpret_cast<const uint4*>(vbase + (size_t)(t * 16 + l15) * max_seq + (c + 8 <= max_seq ? c : max_seq - 8));
-            vb = make_uint4(vb.x & vm, vb.y & vm, vb.z & vm, vb.w & vm);
+        for (uint32_t t0 = 0; t0 < DT; t0 += VG) {
+            if (!VTOP) {
 #pragma unroll
-            for (int j = 0; j < NH; j++)
-                oacc[j][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(pf_bf16x8, pa[j]), __builtin_bit_cast(pf_bf16x8, vb), oacc[j][t], 0, 0, 0);
+                for (uint32_t t = 0; t < VG; t++) {
+                    vbs[t] = *reinterpret_cast<const uint4*>(vp);
+                    vp += (size_t)16 * max_seq;
+                }
+            }
+#pragma unroll
+            for (uint32_t t = 0; t < VG; t++) {
+                const uint4 vb = make_uint4(vbs[t].x & vm, vbs[t].y & vm, vbs[t].z & vm, vbs[t].w & vm);
+#pragma unroll
+                for (int j = 0; j < NH; j++)
+                    oacc[j][t0 + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(pf_bf16x8, pa[j]), __builtin_bit_cast(pf_bf16x8, vb), oacc[j][t0 + t], 0, 0, 0);
+            }
         }
     }
 #pragma unroll
