@@ -1460,6 +1460,16 @@ struct mc_decoder {
                     const char* heads_env = getenv("MC_PF_ATTN_HEADS");
                     const bool enough = (unsigned)((M + 15) / 16) * (unsigned)(H / 2) >= 2u * (unsigned)dev->prop.multiProcessorCount;
                     const bool two = (H / KV) % 2 == 0 && hd <= 128 && (heads_env ? atoi(heads_env) == 2 : enough);
+                    // four query heads per workgroup (head_dim 128, 360 registers: one workgroup per CU): at 1024 rows and more
+                    // the launch is bound by the K / V fragments its waves pull out of L2 (1.6 GB per layer at 2048 rows, ~ 6 TB/s),
+                    // and four heads per fragment halve them again: 2048 rows 44.5 -> 42.6 ms, 1024: 22.75 -> 22.3, 512: 11.8 -> 11.7
+                    const bool four = (H / KV) % 4 == 0 && hd == 128 &&
+                                      (heads_env ? atoi(heads_env) == 4
+                                                 : (unsigned)((M + 15) / 16) * (unsigned)(H / 4) >= (unsigned)dev->prop.multiProcessorCount);
+                    if (four)
+                        return launch("mc_pf_attn4_bfloat_hd128", (M + 15) / 16, H / 4, 1, 256, 0,
+                                      pack(pf_q, L.kc, L.vt, pf_att, (uint32_t)M, (uint32_t)S, (uint32_t)H, (uint32_t)(H / KV),
+                                           (uint32_t)cfg.max_seq_len, scale_T, win, (const void*)pf_etab));
                     return launch(std::string(two ? "mc_pf_attn2_bfloat_hd" : "mc_pf_attn_bfloat_hd") + std::to_string(hd), (M + 15) / 16, two ? H / 2 : H, 1, 256, 0,
                                   pack(pf_q, L.kc, L.vt, pf_att, (uint32_t)M, (uint32_t)S, (uint32_t)H, (uint32_t)(H / KV),
                                        (uint32_t)cfg.max_seq_len, scale_T, win, (const void*)pf_etab));

@@ -1257,6 +1257,182 @@ pf_attn_body(const bf16_t* Q, const bf16_t* kc, const bf16_t* vt, bf16_t* out, u
             }
         }
 }
+// ---- the two-head kernel, scores TRANSPOSED (round 4).  pf_attn_body computes S = Q K^T, whose C layout gives a lane four ROWS of
+// one key; P V wants a lane to hold eight KEYS of one row, so every block of probabilities went through LDS (16 two-byte stores, two
+// fences, a 16-byte read per head) and every per-row quantity (sum, 1/sum) was held four times.  Here the same two fragments enter the
+// MFMA the other way round -- A = K, B = Q -- and C is S^T: lane (l15, lg) holds four keys of row r0 + l15.  With the keys of a
+// 32-key block dealt to its two tiles in groups of four (load_k below) those are keys 8 lg .. + 3 and 8 lg + 4 .. + 7: the eight k
+// slots of that lane's A operand for P V, in order.  P never leaves registers, the row sum is one value per lane and head, and a block that the causal
+// mask, the window and the bounds leave whole (all but the diagonal ones) skips the per-element mask.  Same roundings as
+// pf_attn_body: s = T(T(q.k) scale), e = exp(s) (table), p = T(e * 1/sum), out = T(sum of the four waves' P V).
+template <uint32_t HD, int NH>
+__device__ __forceinline__ void
+pf_attn_kt_body(const bf16_t* Q, const bf16_t* kc, const bf16_t* vt, bf16_t* out, uint32_t M, uint32_t S, uint32_t H,
+                uint32_t n_rep, uint32_t max_seq, float scale, uint32_t window, const float* etab)
+{
+    using T = BF;
+    constexpr uint32_t DT = HD / 16, DK = HD / 32;
+    __shared__ float wsum[NH][4][16];
+    __shared__ float inv_sum[NH][16];
+    __shared__ __attribute__((aligned(16))) float ewin[2 * pf_exp_window::N];
+    const pf_exp_window ew{ewin};
+    ew.fill(etab);
+    constexpr uint32_t OD = HD < 128 ? HD : 128; // output columns reduced per phase
+    __shared__ float osum[4][16][OD + 1];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t l15 = lane & 15, lg = lane >> 4, kg = lg * 8;
+    const uint32_t r0 = blockIdx.x * 16, h0 = blockIdx.y * NH, kv = h0 / n_rep;
+    const bf16_t* kbase = kc + (size_t)kv * max_seq * HD;
+    const bf16_t* vbase = vt + (size_t)kv * HD * max_seq;
+    const uint32_t sq = S - M, rlast = min(r0 + 15, M - 1);
+    uint32_t clo = sq, chi = sq + rlast;
+    if (window && r0 + 1 > window) clo = sq + (r0 + 1 - window);
+    const uint32_t b_lo = clo / 32, b_hi = chi / 32;
+    const uint32_t r = r0 + l15; // this lane's row
+    // Q fragments of the row block (the B operand of S^T: lane (l15, lg) holds Q[r][32 d + 8 lg ..])
+    uint4 qa[NH][DK];
+    {
+        const uint32_t qr = min(r, M - 1);
+#pragma unroll
+        for (int j = 0; j < NH; j++)
+#pragma unroll
+            for (uint32_t d = 0; d < DK; d++)
+                qa[j][d] = *reinterpret_cast<const uint4*>(Q + ((size_t)qr * H + h0 + j) * HD + d * 32 + kg);
+    }
+    // The two tiles of a 32-key block take its keys in groups of four: tile h holds keys blk + 8 g + 4 h + (0..3), g = 0..3, as its
+    // rows m = 4 g + (0..3).  In the C layout lane (l15, lg) then holds keys blk + 8 lg + 4 h + i -- both tiles together the eight
+    // CONSECUTIVE keys blk + 8 lg .. + 7, the natural k slots of the P V operand (V stays one 16-byte load per lane and tile).
+    auto load_k = [&](uint32_t blk, uint32_t h, uint4 (&kb)[DK]) {
+        const uint32_t key = blk + 8 * (l15 >> 2) + 4 * h + (l15 & 3), keyc = key < S ? key : S - 1;
+#pragma unroll
+        for (uint32_t d = 0; d < DK; d++) kb[d] = *reinterpret_cast<const uint4*>(kbase + (size_t)keyc * HD + d * 32 + kg);
+    };
+    // sv[j][i] = masked, scaled score of (row r, key blk + 8 lg + 4 h + i) for head j
+    auto score_tile = [&](uint32_t blk, uint32_t h, const uint4 (&kb)[DK], float (&sv)[NH][4]) {
+        // whole block visible (wave-uniform): rows and keys in range, the last key at or below the first row's diagonal, the first
+        // key at or above the chunk's start, the last row inside the first key's window
+        const bool full = r0 + 15 < M && blk + 31 < S && blk >= sq && blk + 31 - sq <= r0 && (!window || r0 + 15 < window + (blk - sq));
+#pragma unroll
+        for (int j = 0; j < NH; j++) {
+            pf_f32x4 acc = {0, 0, 0, 0};
+#pragma unroll
+            for (uint32_t d = 0; d < DK; d++)
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(pf_bf16x8, kb[d]), __builtin_bit_cast(pf_bf16x8, qa[j][d]), acc, 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; i++) sv[j][i] = T::rt(T::rt(acc[i]) * scale);
+        }
+        if (!full) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const uint32_t key = blk + lg * 8 + h * 4 + i;
+                const bool vis = bool(int(r < M) & int(key < S) & int(pf_visible(r, key, S, M, window)));
+#pragma unroll
+                for (int j = 0; j < NH; j++) sv[j][i] = vis ? sv[j][i] : -INFINITY;
+            }
+        }
+    };
+    // ---- pass 1: exp row sums (one row per lane: its four keys of every tile, then the four lane groups, then the four waves)
+    float rsum[NH];
+#pragma unroll
+    for (int j = 0; j < NH; j++) rsum[j] = 0.0f;
+    uint4 k0[DK], k1[DK];
+    load_k((b_lo + wave) * 32, 0, k0);
+    __syncthreads(); // the exp window is filled
+    for (uint32_t b = b_lo + wave; b <= b_hi; b += 4) {
+        float sv[NH][4];
+        load_k(b * 32, 1, k1);
+        score_tile(b * 32, 0, k0, sv);
+#pragma unroll
+        for (int j = 0; j < NH; j++) rsum[j] += (ew(sv[j][0]) + ew(sv[j][1])) + (ew(sv[j][2]) + ew(sv[j][3]));
+        load_k((b + 4) * 32, 0, k0); // (past the range: clamped to the last key, never used)
+        score_tile(b * 32, 1, k1, sv);
+#pragma unroll
+        for (int j = 0; j < NH; j++) rsum[j] += (ew(sv[j][0]) + ew(sv[j][1])) + (ew(sv[j][2]) + ew(sv[j][3]));
+    }
+#pragma unroll
+    for (int j = 0; j < NH; j++) {
+        float e = rsum[j];
+        e += __shfl_xor(e, 16, 64);
+        e += __shfl_xor(e, 32, 64);
+        if (lg == 0) wsum[j][wave][l15] = e;
+    }
+    __syncthreads();
+    if (threadIdx.x < 16 * NH) {
+        const uint32_t j = threadIdx.x / 16, rr = threadIdx.x % 16;
+        inv_sum[j][rr] = 1.0f / ((wsum[j][0][rr] + wsum[j][1][rr]) + (wsum[j][2][rr] + wsum[j][3][rr]));
+    }
+    __syncthreads();
+    float inv[NH];
+#pragma unroll
+    for (int j = 0; j < NH; j++) inv[j] = inv_sum[j][l15];
+    // ---- pass 2: probabilities (T) x V
+    pf_f32x4 oacc[NH][DT];
+#pragma unroll
+    for (int j = 0; j < NH; j++)
+#pragma unroll
+        for (uint32_t t = 0; t < DT; t++) oacc[j][t] = pf_f32x4{0, 0, 0, 0};
+    load_k((b_lo + wave) * 32, 0, k0);
+    constexpr uint32_t VG = DT < 8 ? DT : 8;
+    for (uint32_t b = b_lo + wave; b <= b_hi; b += 4) {
+        // V fragments of the block (keys b 32 + 8 lg .. + 7: the slots of this lane's A operand), the first VG of them requested
+        // before the scores are computed.  Past max_seq: clamped address, masked to zero.
+        const uint32_t c = b * 32 + kg;
+        const uint32_t vm = c + 8 <= max_seq ? 0xFFFFFFFFu : 0u;
+        const bf16_t* vp = vbase + (size_t)l15 * max_seq + (c + 8 <= max_seq ? c : max_seq - 8);
+        uint4 vbs[VG];
+#pragma unroll
+        for (uint32_t t = 0; t < VG; t++) vbs[t] = *reinterpret_cast<const uint4*>(vp + (size_t)t * 16 * max_seq);
+        uint4 pa[NH];
+        {
+            float sv[NH][4];
+            load_k(b * 32, 1, k1);
+            score_tile(b * 32, 0, k0, sv);
+#pragma unroll
+            for (int j = 0; j < NH; j++) {
+                pa[j].x = pack_bf16x2(T::rt(ew(sv[j][0]) * inv[j]), T::rt(ew(sv[j][1]) * inv[j]));
+                pa[j].y = pack_bf16x2(T::rt(ew(sv[j][2]) * inv[j]), T::rt(ew(sv[j][3]) * inv[j]));
+            }
+            load_k((b + 4) * 32, 0, k0); // (past the range: clamped to the last key, never used)
+            score_tile(b * 32, 1, k1, sv);
+#pragma unroll
+            for (int j = 0; j < NH; j++) {
+                pa[j].z = pack_bf16x2(T::rt(ew(sv[j][0]) * inv[j]), T::rt(ew(sv[j][1]) * inv[j]));
+                pa[j].w = pack_bf16x2(T::rt(ew(sv[j][2]) * inv[j]), T::rt(ew(sv[j][3]) * inv[j]));
+            }
+        }
+#pragma unroll
+        for (uint32_t t0 = 0; t0 < DT; t0 += VG) {
+            if (t0) {
+#pragma unroll
+                for (uint32_t t = 0; t < VG; t++) vbs[t] = *reinterpret_cast<const uint4*>(vp + (size_t)(t0 + t) * 16 * max_seq);
+            }
+#pragma unroll
+            for (uint32_t t = 0; t < VG; t++) {
+                const uint4 vb = make_uint4(vbs[t].x & vm, vbs[t].y & vm, vbs[t].z & vm, vbs[t].w & vm);
+#pragma unroll
+                for (int j = 0; j < NH; j++)
+                    oacc[j][t0 + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(pf_bf16x8, pa[j]), __builtin_bit_cast(pf_bf16x8, vb), oacc[j][t0 + t], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NH; j++)
+#pragma unroll
+        for (uint32_t ph = 0; ph < HD / OD; ph++) {
+            if (ph || j) __syncthreads();
+#pragma unroll
+            for (uint32_t t = 0; t < OD / 16; t++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) osum[wave][lg * 4 + i][t * 16 + l15] = oacc[j][ph * (OD / 16) + t][i];
+            __syncthreads();
+            for (uint32_t e = threadIdx.x; e < 16 * OD; e += blockDim.x) {
+                const uint32_t rr = e / OD, d = e % OD, ro = r0 + rr;
+                if (ro < M)
+                    out[((size_t)ro * H + h0 + j) * HD + ph * OD + d] =
+                        T::st((osum[0][rr][d] + osum[1][rr][d]) + (osum[2][rr][d] + osum[3][rr][d]));
+            }
+        }
+}
 #define MC_PF_ATTN(HD)                                                                                              \
     extern "C" __global__ void __launch_bounds__(256)                                                               \
     mc_pf_attn_bfloat_hd##HD(const bf16_t* Q, const bf16_t* kc, const bf16_t* vt, bf16_t* out, uint32_t M, uint32_t S, \
@@ -1270,12 +1446,18 @@ pf_attn_body(const bf16_t* Q, const bf16_t* kc, const bf16_t* vt, bf16_t* out, u
                               uint32_t H, uint32_t n_rep, uint32_t max_seq, float scale, uint32_t window,         \
                               const float* etab)                                                                    \
     {                                                                                                               \
-        pf_attn_body<HD, 2>(Q, kc, vt, out, M, S, H, n_rep, max_seq, scale, window, etab);                          \
+        pf_attn_kt_body<HD, 2>(Q, kc, vt, out, M, S, H, n_rep, max_seq, scale, window, etab);                       \
     }
 MC_PF_ATTN(32)
 MC_PF_ATTN(64)
 MC_PF_ATTN(128)
 MC_PF_ATTN(256)
+extern "C" __global__ void __launch_bounds__(256)
+mc_pf_attn4_bfloat_hd128(const bf16_t* Q, const bf16_t* kc, const bf16_t* vt, bf16_t* out, uint32_t M, uint32_t S, uint32_t H, uint32_t n_rep,
+                         uint32_t max_seq, float scale, uint32_t window, const float* etab)
+{
+    pf_attn_kt_body<128, 4>(Q, kc, vt, out, M, S, H, n_rep, max_seq, scale, window, etab);
+}
 
 // (A 64-row variant -- four waves sharing every K / V tile through LDS, each wave owning 16 rows --
 // was built and measured: 2.6 vs 2.1 ms at M = 512 and 66 vs 61 ms whole-prompt at M = 2048.  The

@@ -66,7 +66,7 @@ def test_decode_and_reference_kernels_present(symbols):
               # the prompt pass on the quad-interleaved weight copy and its consumers with the split-K reduce inside (round 4)
               "mc_pf2_repack_i4", "mc_pf2_gemm_i4_bfloat", "mc_pf_rope_cache_parts_bfloat", "mc_pf_act_mul_parts_bfloat",
               "mc_pf_rmsnorm_parts_bfloat", "mc_pf_splitk_reduce_bfloat",
-              "mc_exp_table_bfloat", "mc_pf_exp_window_bfloat",  # exp of a bfloat16 by table (prompt attention, silu)
+              "mc_exp_table_bfloat", "mc_pf_exp_window_bfloat", "mc_pf_attn2_bfloat_hd128", "mc_pf_attn4_bfloat_hd128",  # exp of a bfloat16 by table (prompt attention, silu)
               "mc_test_hold_cu"):
         assert k in symbols, k
     # the reference's own kernel names (ABI part 1, kernel/kernel.h:30-90)

@@ -22,7 +22,7 @@ def tol(dt):
     return (1e-4, 1.0) if dt == F32 else (7.8e-3, 0.7)
 
 
-def check_against_oracle(acc, cfg, weights, dec_over, tokens, start_pos=0, window=0, follow=3, warm=()):
+def check_against_oracle(acc, cfg, weights, dec_over, tokens, start_pos=0, window=0, follow=3, warm=(), expect_kernel=None):
     import metalchat_amd as mc
 
     dt = cfg["dtype"]
@@ -35,7 +35,12 @@ def check_against_oracle(acc, cfg, weights, dec_over, tokens, start_pos=0, windo
         om.step(t, p)
         dec.step(t, p)
     otok, ologits = om.forward(tokens, start_pos, window)
+    if expect_kernel:
+        dec.launch_log(True)
     gtok = dec.prefill(tokens, start_pos, window)
+    if expect_kernel:
+        assert expect_kernel in set(dec.launched()), sorted(set(dec.launched()))
+        dec.launch_log(False)
     for layer in range(0, cfg["n_layers"]):
         parity.check(dt, dec.hidden(layer), om.hidden(layer), rel=rel, max_ulp=2, max_frac=frac,
                      what=f"prefill hidden[{layer}] (last row)")
@@ -424,3 +429,57 @@ def test_activation_in_the_gemm_epilogue_is_bit_identical_to_the_separate_launch
     parity.exact(out["1"][1], out["0"][1], "logits, activation in the epilogue vs its own launch")
     for layer in range(cfg["n_layers"]):
         parity.exact(out["1"][2][layer], out["0"][2][layer], f"hidden[{layer}]")
+
+
+# ---- the two-head prompt attention (mc_pf_attn2_bfloat_hd*: transposed scores, P in registers, exp from the LDS window).  The
+# decoder takes it when the grid fills the chip (>= 2 workgroups per CU: 512 rows of a 32-head model); MC_PF_ATTN_HEADS=2 takes it
+# on the small models the oracle can follow.
+@pytest.mark.parametrize("n", [2, 17, 100, 300])
+def test_two_head_prompt_attention_matches_oracle(acc, n, monkeypatch):
+    monkeypatch.setenv("MC_PF_ATTN_HEADS", "2")
+    cfg = mg.tiny_cfg(BF16, max_seq_len=320)  # head_dim 32, 8 heads on 2 kv heads
+    weights = mg.make_model(cfg, seed=91, quant="i4", group=32)
+    tokens = np.random.default_rng(n).integers(0, cfg["vocab"], n).tolist()
+    check_against_oracle(acc, cfg, weights, dict(weight_format=2, group_size=32), tokens, follow=1, expect_kernel="mc_pf_attn2_bfloat_hd32")
+
+
+@pytest.mark.parametrize("hd,heads,kv,nh", [(64, 4, 2, 2), (128, 8, 2, 2), (128, 8, 2, 4), (128, 4, 1, 4)])
+def test_two_head_prompt_attention_head_dims(acc, hd, heads, kv, nh, monkeypatch):
+    """... and the four-head form of head_dim 128 (mc_pf_attn4_bfloat_hd128: the decoder's choice from 512 rows of Llama-3-8B on)"""
+    monkeypatch.setenv("MC_PF_ATTN_HEADS", str(nh))
+    cfg = mg.tiny_cfg(BF16, dim=256, n_heads=heads, n_kv_heads=kv, head_dim=hd, max_seq_len=192)
+    weights = mg.make_model(cfg, seed=92, quant="i4", group=32)
+    tokens = np.random.default_rng(hd).integers(0, cfg["vocab"], 150).tolist()
+    check_against_oracle(acc, cfg, weights, dict(weight_format=2, group_size=32), tokens, follow=1, expect_kernel=f"mc_pf_attn{nh}_bfloat_hd{hd}")
+
+
+def test_four_head_prompt_attention_sliding_window_and_second_chunk(acc, monkeypatch):
+    monkeypatch.setenv("MC_PF_ATTN_HEADS", "4")
+    cfg = mg.tiny_cfg(BF16, family=1, dim=256, n_heads=4, n_kv_heads=1, head_dim=128, n_layers=2, rope_sliding_theta=10000.0,
+                      sliding_stride=2, max_seq_len=320)
+    weights = mg.make_model(cfg, seed=93, quant="i4", group=32)
+    tokens = np.random.default_rng(12).integers(0, cfg["vocab"], 270).tolist()
+    check_against_oracle(acc, cfg, weights, dict(weight_format=2, group_size=32), tokens, window=37, follow=1, expect_kernel="mc_pf_attn4_bfloat_hd128")
+    cfg = mg.tiny_cfg(BF16, dim=256, n_heads=8, n_kv_heads=2, head_dim=128, max_seq_len=96)
+    weights = mg.make_model(cfg, seed=94, quant="i4", group=32)
+    rng = np.random.default_rng(13)
+    warm = rng.integers(0, cfg["vocab"], 21).tolist()
+    tokens = rng.integers(0, cfg["vocab"], 40).tolist()
+    check_against_oracle(acc, cfg, weights, dict(weight_format=2, group_size=32), tokens, start_pos=21, warm=warm, expect_kernel="mc_pf_attn4_bfloat_hd128")
+
+
+def test_two_head_prompt_attention_sliding_window_and_second_chunk(acc, monkeypatch):
+    monkeypatch.setenv("MC_PF_ATTN_HEADS", "2")
+    # gemma3 block, window 37 over 270 rows: tiles left of the window, whole tiles, the two diagonals
+    cfg = mg.tiny_cfg(BF16, family=1, n_layers=2, rope_sliding_theta=10000.0, sliding_stride=2,
+                      attn_scale=float(1.0 / np.sqrt(48.0)), max_seq_len=320)
+    weights = mg.make_model(cfg, seed=80, quant="i4", group=32)
+    tokens = np.random.default_rng(10).integers(0, cfg["vocab"], 270).tolist()
+    check_against_oracle(acc, cfg, weights, dict(weight_format=2, group_size=32), tokens, window=37, follow=1, expect_kernel="mc_pf_attn2_bfloat_hd32")
+    # a chunk at start_pos > 0 attends to its own rows only (nn/attention.h:283-299): the columns of the earlier context are masked
+    cfg = mg.tiny_cfg(BF16, max_seq_len=96)
+    weights = mg.make_model(cfg, seed=75, quant="i4", group=32)
+    rng = np.random.default_rng(7)
+    warm = rng.integers(0, cfg["vocab"], 21).tolist()
+    tokens = rng.integers(0, cfg["vocab"], 40).tolist()
+    check_against_oracle(acc, cfg, weights, dict(weight_format=2, group_size=32), tokens, start_pos=21, warm=warm, expect_kernel="mc_pf_attn2_bfloat_hd32")
