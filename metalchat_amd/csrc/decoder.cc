@@ -21,10 +21,71 @@
 #include <unordered_map>
 #include <algorithm>
 #include <memory>
+#include <dlfcn.h>
+#include <tuple>
+#include <cstdio>
+#include <hipblaslt/hipblaslt.h> // types and prototypes only: the library is opened with dlopen when a long prompt first asks for it
 
 using namespace mcimpl;
 
 namespace {
+
+// The ROCm library GEMM behind the prompt pass of LONG prompts (gemm_lib below).  A plain bfloat16 GEMM with fp32 sums is what
+// hipBLASLt exists for; the hand-written prompt kernels stay for everything the library is not better at (prefill_kernels.hip).
+struct blaslt_api {
+    void* handle = nullptr;
+    bool tried = false, ok = false;
+    decltype(&hipblasLtCreate) Create = nullptr;
+    decltype(&hipblasLtDestroy) Destroy = nullptr;
+    decltype(&hipblasLtMatmulDescCreate) DescCreate = nullptr;
+    decltype(&hipblasLtMatmulDescDestroy) DescDestroy = nullptr;
+    decltype(&hipblasLtMatmulDescSetAttribute) DescSet = nullptr;
+    decltype(&hipblasLtMatrixLayoutCreate) LayoutCreate = nullptr;
+    decltype(&hipblasLtMatrixLayoutDestroy) LayoutDestroy = nullptr;
+    decltype(&hipblasLtMatmulPreferenceCreate) PrefCreate = nullptr;
+    decltype(&hipblasLtMatmulPreferenceDestroy) PrefDestroy = nullptr;
+    decltype(&hipblasLtMatmulPreferenceSetAttribute) PrefSet = nullptr;
+    decltype(&hipblasLtMatmulAlgoGetHeuristic) Heuristic = nullptr;
+    decltype(&hipblasLtMatmul) Matmul = nullptr;
+};
+blaslt_api&
+blaslt()
+{
+    static blaslt_api api;
+    if (api.tried) return api;
+    api.tried = true;
+    for (const char* name : {"libhipblaslt.so.1", "libhipblaslt.so", "/opt/rocm/lib/libhipblaslt.so"}) {
+        api.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (api.handle) break;
+    }
+    if (!api.handle) return api;
+    bool all = true;
+#define MC_LT_SYM(field, sym) \
+    api.field = reinterpret_cast<decltype(api.field)>(dlsym(api.handle, sym)); \
+    all = all && api.field != nullptr;
+    MC_LT_SYM(Create, "hipblasLtCreate")
+    MC_LT_SYM(Destroy, "hipblasLtDestroy")
+    MC_LT_SYM(DescCreate, "hipblasLtMatmulDescCreate")
+    MC_LT_SYM(DescDestroy, "hipblasLtMatmulDescDestroy")
+    MC_LT_SYM(DescSet, "hipblasLtMatmulDescSetAttribute")
+    MC_LT_SYM(LayoutCreate, "hipblasLtMatrixLayoutCreate")
+    MC_LT_SYM(LayoutDestroy, "hipblasLtMatrixLayoutDestroy")
+    MC_LT_SYM(PrefCreate, "hipblasLtMatmulPreferenceCreate")
+    MC_LT_SYM(PrefDestroy, "hipblasLtMatmulPreferenceDestroy")
+    MC_LT_SYM(PrefSet, "hipblasLtMatmulPreferenceSetAttribute")
+    MC_LT_SYM(Heuristic, "hipblasLtMatmulAlgoGetHeuristic")
+    MC_LT_SYM(Matmul, "hipblasLtMatmul")
+#undef MC_LT_SYM
+    api.ok = all;
+    return api;
+}
+// one multiplication shape of gemm_lib: Y[M][N] = X[M][K] Wd[N][K]^T
+struct blaslt_plan {
+    hipblasLtMatmulDesc_t desc = nullptr;
+    hipblasLtMatrixLayout_t a = nullptr, b = nullptr, c = nullptr;
+    hipblasLtMatmulHeuristicResult_t algo{};
+    bool usable = false, tried = false;
+};
 
 constexpr int PB = 64; // cache slots per attention-scores workgroup (decode_kernels.hip)
 
@@ -46,6 +107,8 @@ struct linear_w {
     std::vector<uint8_t> scales_host; // shadow of the quad-interleaved scale buffer (load path only)
     void* wq2 = nullptr;      // int4: the quad-interleaved copy short prompts multiply from (prefill_kernels.hip mc_pf2_*), built on demand
     uint64_t wq2_gen = 0;     // ... from the weights of this generation (mc_decoder::weights_gen)
+    void* wd = nullptr;       // int4 / int8: the dequantised bfloat16 copy [out][in] long prompts multiply by in the library GEMM (gemm_lib), built on demand
+    uint64_t wd_gen = 0;
     // quantization::lora_adaptor(s) of the matrices fused here (quantization/lora.h:17-53): the A
     // matrices stacked [nseg*rank][in] (a T-format GEMV of its own), B in fused row order
     // [out][nseg*rank] with zeros outside each row's own adaptor columns, a = T(A x) in lora_vec
@@ -179,6 +242,13 @@ struct mc_decoder {
     const void* pending_pn = nullptr; // gemma3: postnorm_args the next pre-norm GEMV has to apply to `proj`
     uint64_t weights_gen = 1;  // bumped whenever weight rows change: the derived copies (linear_w::wq2) are rebuilt
     bool pf2_on = true;        // MC_PF2: short prompts from the quad-interleaved copy
+    bool pf_lib_on = true;     // MC_PF_BLASLT: long prompts' large GEMMs in hipBLASLt on a dequantised bfloat16 copy of the matrix (gemm_lib)
+    bool pf_lib_force = false;
+    hipblasLtHandle_t lt = nullptr;
+    void* lt_ws = nullptr;
+    static constexpr size_t lt_ws_bytes = 64u << 20;
+    std::map<std::tuple<int, int, int, int>, blaslt_plan> lt_plans;
+    int lt_calls = 0; // library multiplications issued (mc_decoder_launch_log names them "hipblasLtMatmul")
     bool pf_fold_on = true;    // MC_PF_FOLD: the split-K reduce of a prompt GEMM inside the kernel that consumes its rows
     bool lazy_pick = false;    // inside mc_decoder_generate: the pick of a token is folded by the NEXT token's embedding launch
     bool lazy_pick_on = true;  // MC_LAZY_PICK
@@ -319,6 +389,13 @@ struct mc_decoder {
         (void)hipSetDevice(dev->ordinal);
         drop_graph();
         for (void* p : allocs) (void)hipFree(p);
+        for (auto& kv : lt_plans) {
+            blaslt_plan& pl = kv.second;
+            if (pl.desc) (void)blaslt().DescDestroy(pl.desc);
+            for (hipblasLtMatrixLayout_t l : {pl.a, pl.b, pl.c})
+                if (l) (void)blaslt().LayoutDestroy(l);
+        }
+        if (lt) (void)blaslt().Destroy(lt);
         if (err_evt) (void)hipEventDestroy(err_evt);
         if (err_host) (void)hipHostFree(err_host);
     }
@@ -1280,6 +1357,92 @@ struct mc_decoder {
                       pack((const void*)pf_part, Y, epi == 1 ? res : (const void*)nullptr, (uint32_t)M, (uint32_t)L.out, splits, la,
                            (const void*)L.lora_b, (uint32_t)L.lora_cols, L.lora_scale));
     }
+    // ---- the library GEMM of long prompts
+    // Measured on MI355X (tools/blaslt_probe.py, profiles/r04_blaslt_probe.log; WBITS=16 tools/prefill_bench.py): the hand-written
+    // tiled GEMM reaches 600-725 TFLOP/s with AND without its dequantisation (plain bfloat weights: 180 us for w1|w3 at 512 rows
+    // against 168 with int4) -- its ceiling is the tile loop, not the exact arithmetic -- while hipBLASLt multiplies the same shapes
+    // at 1.1-1.36 PFLOP/s once a launch has >= 128 tiles of 256 x 256 (w1|w3 from 512 rows on, every matrix of Llama-3-8B from 2048
+    // rows on) and at 600-750 below that, where the split-K kernels here are faster.  The operand is Wd = T(T(q) T(s)), the very
+    // values the prompt kernels hold in LDS, kept as a bfloat16 copy [out][in] (2 bytes per weight more HBM: 14 GB for Llama-3-8B
+    // of 288); sums are fp32, rounded to T once (linear.h:70-81) -- only the order of the fp32 additions differs from the kernels'.
+    // Any failure of the library (absent, no algorithm, an error status) switches the path off: the prompt kernels take over.
+    bool
+    lib_ok(const linear_w& L, int M) const
+    {
+        if (!pf_lib_on || tb != 2 || L.lora_cols || getenv("MC_PF_SMALL_GEMM")) return false;
+        if (L.fmt != MC_WFMT_T && (L.in % 16 != 0 || (L.group && (L.group & (L.group - 1)) != 0))) return false;
+        if (L.in % 8 != 0 || L.out % 8 != 0) return false;
+        if (pf_lib_force) return true; // (MC_PF_BLASLT=2: every prompt GEMM that can, whatever its size -- how the tests reach it on small models)
+        return M >= 256 && (size_t)((L.out + 255) / 256) * (size_t)((M + 255) / 256) >= 128;
+    }
+    mc_status
+    ensure_wd(const linear_w& Lc, const void** wd)
+    {
+        linear_w& L = const_cast<linear_w&>(Lc);
+        if (L.fmt == MC_WFMT_T) {
+            *wd = L.w;
+            return MC_OK;
+        }
+        if (!(L.wd && L.wd_gen == weights_gen)) {
+            if (!L.wd) {
+                mc_status s = alloc(&L.wd, (size_t)L.out * L.in * 2, false);
+                if (s != MC_OK) return s;
+            }
+            mc_status s = launch(L.fmt == MC_WFMT_I4 ? "mc_pf_dequant_rows_i4_bfloat" : "mc_pf_dequant_rows_i8_bfloat", (L.in / 16 + 255) / 256,
+                                 L.out, 1, 256, 0, pack((const void*)L.w, (const void*)L.scales, L.wd, (uint32_t)L.out, (uint32_t)L.in, (uint32_t)L.group));
+            if (s != MC_OK) return s;
+            L.wd_gen = weights_gen;
+        }
+        *wd = L.wd;
+        return MC_OK;
+    }
+    // Y[M][out] (bfloat16, or fp32 when f32_out) = X[M][in] Wd^T on the decoder's stream.  false: the library path is off now
+    bool
+    gemm_lib(const linear_w& L, const void* X, void* Y, int M, bool f32_out)
+    {
+        blaslt_api& api = blaslt();
+        auto off = [&](const char* why) {
+            pf_lib_on = false;
+            if (getenv("MC_PF_BLASLT_VERBOSE")) fprintf(stderr, "metalchat_hip: hipBLASLt path switched off: %s\n", why);
+            return false;
+        };
+        if (!api.ok) return off("library or symbols not found");
+        if (!lt && api.Create(&lt) != HIPBLAS_STATUS_SUCCESS) {
+            lt = nullptr;
+            return off("hipblasLtCreate");
+        }
+        if (!lt_ws && alloc(&lt_ws, lt_ws_bytes, false) != MC_OK) return off("workspace");
+        const void* wd = nullptr;
+        if (ensure_wd(L, &wd) != MC_OK) return off("dequantised copy");
+        blaslt_plan& pl = lt_plans[std::make_tuple(L.out, L.in, M, f32_out ? 1 : 0)];
+        if (!pl.tried) {
+            pl.tried = true;
+            // row-major Y[M][N] is column-major N x M: Y' = op(A) op(B) with A = Wd ([N][K] row-major = K x N column-major, transposed)
+            // and B = X ([M][K] row-major = K x M column-major)
+            const hipblasOperation_t ta = HIPBLAS_OP_T, tb_ = HIPBLAS_OP_N;
+            bool good = api.DescCreate(&pl.desc, HIPBLAS_COMPUTE_32F, HIP_R_32F) == HIPBLAS_STATUS_SUCCESS;
+            good = good && api.DescSet(pl.desc, HIPBLASLT_MATMUL_DESC_TRANSA, &ta, sizeof(ta)) == HIPBLAS_STATUS_SUCCESS;
+            good = good && api.DescSet(pl.desc, HIPBLASLT_MATMUL_DESC_TRANSB, &tb_, sizeof(tb_)) == HIPBLAS_STATUS_SUCCESS;
+            good = good && api.LayoutCreate(&pl.a, HIP_R_16BF, (uint64_t)L.in, (uint64_t)L.out, (int64_t)L.in) == HIPBLAS_STATUS_SUCCESS;
+            good = good && api.LayoutCreate(&pl.b, HIP_R_16BF, (uint64_t)L.in, (uint64_t)M, (int64_t)L.in) == HIPBLAS_STATUS_SUCCESS;
+            good = good && api.LayoutCreate(&pl.c, f32_out ? HIP_R_32F : HIP_R_16BF, (uint64_t)L.out, (uint64_t)M, (int64_t)L.out) == HIPBLAS_STATUS_SUCCESS;
+            hipblasLtMatmulPreference_t pref = nullptr;
+            good = good && api.PrefCreate(&pref) == HIPBLAS_STATUS_SUCCESS;
+            const uint64_t wsb = lt_ws_bytes;
+            good = good && api.PrefSet(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &wsb, sizeof(wsb)) == HIPBLAS_STATUS_SUCCESS;
+            int found = 0;
+            good = good && api.Heuristic(lt, pl.desc, pl.a, pl.b, pl.c, pl.c, pref, 1, &pl.algo, &found) == HIPBLAS_STATUS_SUCCESS && found > 0;
+            if (pref) (void)api.PrefDestroy(pref);
+            pl.usable = good;
+        }
+        if (!pl.usable) return off("no algorithm for a shape");
+        const float one = 1.0f, zero = 0.0f;
+        if (api.Matmul(lt, pl.desc, &one, wd, pl.a, X, pl.b, &zero, Y, pl.c, Y, pl.c, &pl.algo.algo, lt_ws, lt_ws_bytes, stream) != HIPBLAS_STATUS_SUCCESS)
+            return off("hipblasLtMatmul");
+        lt_calls++;
+        if (log_on) launch_log.push_back("hipblasLtMatmul");
+        return true;
+    }
     // A prompt GEMM that splits K, stopped at its fp32 partial sums (pf_part, [splits][M][out]): the kernel that consumes the rows
     // adds them itself (prefill_kernels.hip mc_pf_*_parts_bfloat) and the reduce launch is saved.  false: this matrix at this M
     // does not split (or carries an adaptor, or T = float): the caller takes gemm().
@@ -1288,6 +1451,25 @@ struct mc_decoder {
     {
         *st = MC_OK;
         if (!pf_fold_on || tb != 2 || L.lora_cols || getenv("MC_PF_SMALL_GEMM")) return false;
+        if (lib_ok(L, M)) {
+            // the library GEMM leaves its fp32 sums as the ONE partial the consumers add up
+            const size_t need1 = (size_t)M * L.out;
+            if (need1 > pf_part_elems) {
+                const hipError_t e = hipStreamSynchronize(stream);
+                if (e != hipSuccess) {
+                    *st = hip_fail(e, "hipStreamSynchronize");
+                    return true;
+                }
+                release((void**)&pf_part);
+                *st = alloc((void**)&pf_part, need1 * 4, false);
+                if (*st != MC_OK) return true;
+                pf_part_elems = need1;
+            }
+            if (gemm_lib(L, X, pf_part, M, true)) {
+                *splits_out = 1;
+                return true;
+            }
+        }
         const bool small = pf2_ok(L, M);
         unsigned splits = 1, ktper = 0;
         if (small) pf2_split(L, splits, ktper);
@@ -1341,6 +1523,7 @@ struct mc_decoder {
         // every bf16 prompt takes the pipelined 128 x 128 MFMA tiling: a short prompt is bound by the
         // weight stream, and the unpipelined 64 x 64 tile (kept for T = float, the parity path) needed
         // 32-42 ms for 8-64 rows where this one needs 5
+        if (epi == 0 && lib_ok(L, M) && gemm_lib(L, X, Y, M, false)) return MC_OK;
         const bool big = tb == 2 && !getenv("MC_PF_SMALL_GEMM");
         const std::string f = L.fmt == MC_WFMT_I4 ? "i4_" : (L.fmt == MC_WFMT_I8 ? "i8_" : "w_");
         const void* la = L.lora_cols ? pf_lora : nullptr;
@@ -1511,10 +1694,11 @@ struct mc_decoder {
             // table of exponentials rides in `res`).  MC_PF_ACT_EPI=0: the separate launch
             const bool act_epi_on = !(getenv("MC_PF_ACT_EPI") && atoi(getenv("MC_PF_ACT_EPI")) == 0);
             const bool act_epi = act_epi_on && tb == 2 && !gemma && !L.w13.lora_cols && !getenv("MC_PF_SMALL_GEMM") && !pf2_ok(L.w13, M) &&
-                                 gemm_row_tile(M) == 256 && gemm_splits(L.w13, M) == 1 && !(getenv("MC_PF_DEPTH") && atoi(getenv("MC_PF_DEPTH")) == 1);
+                                 gemm_row_tile(M) == 256 && gemm_splits(L.w13, M) == 1 && !(getenv("MC_PF_DEPTH") && atoi(getenv("MC_PF_DEPTH")) == 1) &&
+                                 !lib_ok(L.w13, M); // (the library GEMM + the separate activation launch: 94 + 12 us against 166 at 512 rows)
             if (act_epi) {
                 s = timed("gemm_w13_act", [&] { return gemm(L.w13, 3, pf_xn, pf_g, pf_etab, M); });
-            } else if (cfg.ffn_dim % 4 == 0 && gemm_to_parts(L.w13, pf_xn, M, &sp, &gs)) {
+            } else if (cfg.ffn_dim % 4 == 0 && !lib_ok(L.w13, M) && gemm_to_parts(L.w13, pf_xn, M, &sp, &gs)) { // (library: bfloat16 rows out, half the bytes of fp32 partials)
                 if (gs != MC_OK) return gs;
                 s = timed("act_mul", [&] { return launch("mc_pf_act_mul_parts_" + tname, (cfg.ffn_dim / 4 + 255) / 256 + 1, M, 1, 256, 0,
                            pack((const void*)pf_part, sp, (uint32_t)M, pf_g, (uint32_t)cfg.ffn_dim, (int32_t)(gemma ? 1 : 0), (const void*)pf_etab)); });
@@ -1632,6 +1816,10 @@ mc_decoder_create(mc_device* dev, mc_library* lib, mc_queue* q, const mc_decoder
     if (const char* e = getenv("MC_ATTN_QKN")) d->attn_qkn_on = atoi(e) != 0;
     if (const char* e = getenv("MC_LAZY_PICK")) d->lazy_pick_on = atoi(e) != 0;
     if (const char* e = getenv("MC_PF2")) d->pf2_on = atoi(e) != 0;
+    if (const char* e = getenv("MC_PF_BLASLT")) {
+        d->pf_lib_on = atoi(e) != 0;
+        d->pf_lib_force = atoi(e) == 2;
+    }
     if (const char* e = getenv("MC_PF_FOLD")) d->pf_fold_on = atoi(e) != 0;
     if (const char* e = getenv("MC_ATTN_T2")) d->attn_t2_on = atoi(e) != 0;
     if (const char* e = getenv("MC_ATTN_FUSED_WGS")) d->attn_fused_max_wgs_per_cu = (unsigned)std::max(1, std::min(4, atoi(e)));

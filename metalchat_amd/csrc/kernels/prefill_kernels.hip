@@ -786,6 +786,55 @@ MC_PF_GEMM_BIG_D(mc_pf_gemm128_w_bfloat_d2_e0, PF_W_T, 0, 2)
 MC_PF_GEMM_BIG_D(mc_pf_gemm128_w_bfloat_d2_e1, PF_W_T, 1, 2)
 MC_PF_GEMM_BIG_D(mc_pf_gemm128_w_bfloat_d2_e2, PF_W_T, 2, 2)
 
+// ------------------------------------------------------------------------------------------ a dequantised copy of a matrix
+// Wd[row][k] = T(T(q) * T(s)) (kernel/mul.metal:78-82) as plain bfloat16 rows [N][K] -- bit for bit the values pf_gemm_body's W tile
+// holds -- built once per matrix (decoder.cc ensure_wd): the operand LONG prompts multiply by in a library GEMM (hipBLASLt;
+// decoder.cc gemm_lib says when).  Thread -> 16 consecutive k of row blockIdx.y; K is a multiple of 16.
+template <int WF>
+__device__ __forceinline__ void
+pf_dequant_rows_body(const void* __restrict__ wp, const void* __restrict__ sp, bf16_t* __restrict__ out, uint32_t N, uint32_t K, uint32_t group)
+{
+    using T = BF;
+    const uint32_t kabs = (blockIdx.x * blockDim.x + threadIdx.x) * 16, gr = blockIdx.y;
+    if (kabs >= K || gr >= N) return;
+    const uint32_t ngroups = group ? K / group : 1;
+    const uint32_t glog = group ? 31u - __builtin_clz(group) : 31u;
+    bf16_t* dst = out + (size_t)gr * K + kabs;
+    if (WF == PF_W_I8) {
+        const int8_t* src = static_cast<const int8_t*>(wp) + (size_t)gr * K + kabs;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const float sc = T::rt(pf_scale<WF, T>(sp, gr, group ? (kabs + i) >> glog : 0, ngroups));
+            dst[i] = T::st((float)src[i] * sc);
+        }
+    } else {
+        // 16 weights = two dwords; nibble p of a dword is weight {0,2,4,6,1,3,5,7}[p]
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(static_cast<const char*>(wp) + (size_t)gr * (K / 2) + kabs / 2);
+#pragma unroll
+        for (int d = 0; d < 2; d++) {
+            const uint32_t v = src[d];
+#pragma unroll
+            for (int p = 0; p < 8; p++) {
+                const int wi = (p < 4) ? 2 * p : 2 * (p - 4) + 1;
+                const int q = (int)((v >> (4 * p)) & 0xF) - 8;
+                const uint32_t kq = kabs + 8 * d + wi;
+                const float sc = T::rt(pf_scale<WF, T>(sp, gr, group ? kq >> glog : 0, ngroups));
+                dst[8 * d + wi] = T::st((float)q * sc);
+            }
+        }
+    }
+}
+extern "C" __global__ void
+mc_pf_dequant_rows_i4_bfloat(const void* wp, const void* sp, bf16_t* out, uint32_t N, uint32_t K, uint32_t group)
+{
+    pf_dequant_rows_body<PF_W_I4>(wp, sp, out, N, K, group);
+}
+extern "C" __global__ void
+mc_pf_dequant_rows_i8_bfloat(const void* wp, const void* sp, bf16_t* out, uint32_t N, uint32_t K, uint32_t group)
+{
+    pf_dequant_rows_body<PF_W_I8>(wp, sp, out, N, K, group);
+}
+
 // y = T(sum_z partial[z]) (+ adaptation) (+ residual): the epilogue of a split-K GEMM
 extern "C" __global__ void
 mc_pf_splitk_reduce_bfloat(const float* part, bf16_t* Y, const bf16_t* res, uint32_t M, uint32_t N, uint32_t splits,

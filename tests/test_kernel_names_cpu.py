@@ -67,6 +67,7 @@ def test_decode_and_reference_kernels_present(symbols):
               "mc_pf2_repack_i4", "mc_pf2_gemm_i4_bfloat", "mc_pf_rope_cache_parts_bfloat", "mc_pf_act_mul_parts_bfloat",
               "mc_pf_rmsnorm_parts_bfloat", "mc_pf_splitk_reduce_bfloat",
               "mc_exp_table_bfloat", "mc_pf_exp_window_bfloat", "mc_pf_attn2_bfloat_hd128", "mc_pf_attn4_bfloat_hd128",  # exp of a bfloat16 by table (prompt attention, silu)
+              "mc_pf_dequant_rows_i4_bfloat", "mc_pf_dequant_rows_i8_bfloat",  # the dequantised copy long prompts multiply by in the library GEMM
               "mc_test_hold_cu"):
         assert k in symbols, k
     # the reference's own kernel names (ABI part 1, kernel/kernel.h:30-90)

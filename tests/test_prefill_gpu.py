@@ -483,3 +483,53 @@ def test_two_head_prompt_attention_sliding_window_and_second_chunk(acc, monkeypa
     warm = rng.integers(0, cfg["vocab"], 21).tolist()
     tokens = rng.integers(0, cfg["vocab"], 40).tolist()
     check_against_oracle(acc, cfg, weights, dict(weight_format=2, group_size=32), tokens, start_pos=21, warm=warm, expect_kernel="mc_pf_attn2_bfloat_hd32")
+
+
+# ---- the library GEMM of long prompts (decoder.cc gemm_lib: hipBLASLt on the dequantised bfloat16 copy of a matrix).  The decoder
+# takes it where a launch has >= 128 tiles of 256 x 256 (w1|w3 of Llama-3-8B from 512 rows on); MC_PF_BLASLT=2 takes it for every
+# prompt GEMM that can, which is how the models the oracle can follow reach it.
+@pytest.mark.parametrize("quant,fmt,group", [("i4", 2, 32), ("i4", 2, 128), ("i8", 1, 32), (None, 0, 0)])
+@pytest.mark.parametrize("n", [21, 300])
+def test_library_gemm_of_long_prompts_matches_oracle(acc, n, quant, fmt, group, monkeypatch):
+    """The operand is Wd = T(T(q) T(s)) (kernel/mul.metal:78-82) as a bfloat16 copy, the sums are fp32, rounded to T once
+    (nn/linear.h:70-81): the same bounds as every other prompt path, through bfloat16 rows out (w1|w3) and through the fp32
+    rows the consumers of a split GEMM add up (wq|wk|wv, wo, w2)."""
+    monkeypatch.setenv("MC_PF_BLASLT", "2")
+    cfg = mg.tiny_cfg(BF16, dim=256, n_heads=4, n_kv_heads=2, head_dim=64, ffn_dim=768, n_layers=2, vocab=384, max_seq_len=320)
+    weights = mg.make_model(cfg, seed=97, quant=quant, group=group or 32)
+    tokens = np.random.default_rng(n + fmt).integers(0, cfg["vocab"], n).tolist()
+    check_against_oracle(acc, cfg, weights, dict(weight_format=fmt, group_size=group), tokens, follow=2, expect_kernel="hipblasLtMatmul")
+
+
+def test_library_gemm_is_the_decoders_choice_only_where_a_launch_has_enough_tiles(acc, monkeypatch):
+    """512 rows on a model with a 16384-row w1|w3: that GEMM alone goes to the library (128 tiles of 256 x 256), the others keep
+    the prompt kernels; the token and the rows agree with the kernels-only prompt (MC_PF_BLASLT=0) like two orders of the same
+    fp32 sums; and new weights rebuild the dequantised copy."""
+    import metalchat_amd as mc
+
+    cfg = mg.tiny_cfg(BF16, dim=512, n_heads=4, n_kv_heads=2, head_dim=128, ffn_dim=8192, n_layers=2, vocab=512, max_seq_len=512)
+    weights = mg.make_model(cfg, seed=98, quant="i4", group=128)
+    tokens = np.random.default_rng(5).integers(0, cfg["vocab"], 512).tolist()
+    out = {}
+    for lib in ("1", "0"):
+        monkeypatch.setenv("MC_PF_BLASLT", lib)
+        dec = mc.Decoder(acc, **mg.decoder_kwargs(cfg, weight_format=2, group_size=128))
+        dec.load_model(weights)
+        dec.set_taps(True)
+        dec.launch_log(True)
+        tok = dec.prefill(tokens, 0)
+        names = dec.launched()
+        n_lib = sum(1 for x in names if x == "hipblasLtMatmul")
+        assert n_lib == (cfg["n_layers"] if lib == "1" else 0), sorted(set(names))
+        if lib == "1":
+            assert sum(1 for x in names if x.startswith("mc_pf_dequant_rows_i4")) == cfg["n_layers"]
+            assert not [x for x in names if x.endswith("_e3")] and [x for x in names if "act_mul" in x]
+            dec.launch_log(True)
+            dec.prefill(tokens, 0)      # the copy exists now
+            assert not [x for x in dec.launched() if x.startswith("mc_pf_dequant_rows")]
+        out[lib] = (tok, dec.logits().copy(), [dec.hidden(layer).copy() for layer in range(cfg["n_layers"])])
+        dec.release()
+    rel, frac = tol(BF16)
+    for layer in range(cfg["n_layers"]):
+        parity.check(BF16, out["1"][2][layer], out["0"][2][layer], rel=rel, max_ulp=2, max_frac=frac, what=f"hidden[{layer}], library vs kernels")
+    parity.check(BF16, out["1"][1], out["0"][1], rel=rel, max_ulp=2, max_frac=frac, what="logits, library vs kernels")

@@ -1,5 +1,5 @@
 """Time-to-first-token of the prompt pass on the BASELINE model shape (tuning aid).
-usage: python tools/prefill_bench.py [len ...]"""
+usage: [WBITS=4|8|16] python tools/prefill_bench.py [len ...]   (16: plain bfloat weights -- what the tiled GEMM does without its dequantisation)"""
 import sys
 import time
 
@@ -14,7 +14,8 @@ lens = [int(a) for a in sys.argv[1:]] or [128, 512, 2048]
 acc = mc.HardwareAccelerator(path=os.environ.get("MC_HSACO"))
 dec = mc.Decoder(acc, dtype=mc.BF16, dim=4096, n_heads=32, n_kv_heads=8, head_dim=128, ffn_dim=14336, n_layers=32,
                  vocab=128256, max_seq_len=2048, rope_theta=500000.0, norm_eps=1e-5, attn_scale=128 ** -0.5,
-                 weight_format=mc.WFMT_I4, group_size=128)
+                 weight_format={"4": mc.WFMT_I4, "8": mc.WFMT_I8, "16": mc.WFMT_T}[os.environ.get("WBITS", "4")],
+                 group_size=0 if os.environ.get("WBITS") == "16" else 128)
 dec.init_synthetic(1)
 rng = np.random.default_rng(0)
 for n in lens:
