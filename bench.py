@@ -552,9 +552,18 @@ def main():
         lin_params = m["n_layers"] * (m["dim"] * m["n_heads"] * m["head_dim"] * 2
                                       + 2 * m["dim"] * m["n_kv_heads"] * m["head_dim"]
                                       + 3 * m["dim"] * m["ffn_dim"])
+        # which of its GEMMs went to the ROCm library (decoder.cc gemm_lib: launches with >= 128 tiles of 256 x 256 multiply a
+        # dequantised bfloat16 copy of the matrix in hipBLASLt; the others are the hand-written prompt kernels) -- from the launch log
+        dec.launch_log(True)
+        dec.prefill(ptoks, 0)
+        acc.wait()
+        pnames = dec.launched()
+        dec.launch_log(False)
         out["prompt_pass"] = {"tokens": plen, "ms": pms, "tokens_per_s": plen / (pms * 1e-3),
                               "linear_TFLOPs": 2.0 * lin_params * plen / (pms * 1e-3) / 1e12,
-                              "mfma_peak_TFLOPs": 2500.0}
+                              "mfma_peak_TFLOPs": 2500.0,
+                              "gemm_launches": {"hipBLASLt": pnames.count("hipblasLtMatmul"),
+                                                "hand_written": sum(1 for x in pnames if x.startswith("mc_pf_gemm") or x.startswith("mc_pf2_gemm"))}}
     if rank == 0 and world == 1 and not args.no_other_configs and args.model == "llama3-8b":
         if pipe is None:
             dec.release()
