@@ -533,3 +533,13 @@ def test_library_gemm_is_the_decoders_choice_only_where_a_launch_has_enough_tile
     for layer in range(cfg["n_layers"]):
         parity.check(BF16, out["1"][2][layer], out["0"][2][layer], rel=rel, max_ulp=2, max_frac=frac, what=f"hidden[{layer}], library vs kernels")
     parity.check(BF16, out["1"][1], out["0"][1], rel=rel, max_ulp=2, max_frac=frac, what="logits, library vs kernels")
+
+
+def test_library_gemm_under_a_gemma3_block(acc, monkeypatch):
+    """gemma3 (gelu, post-norms, sliding window: nn/gemma.h:110-137): the plain-store GEMMs of its block through the library"""
+    monkeypatch.setenv("MC_PF_BLASLT", "2")
+    cfg = mg.tiny_cfg(BF16, family=1, n_layers=2, rope_sliding_theta=10000.0, sliding_stride=2,
+                      attn_scale=float(1.0 / np.sqrt(48.0)), max_seq_len=320)
+    weights = mg.make_model(cfg, seed=99, quant="i4", group=32)
+    tokens = np.random.default_rng(12).integers(0, cfg["vocab"], 270).tolist()
+    check_against_oracle(acc, cfg, weights, dict(weight_format=2, group_size=32), tokens, window=37, follow=1, expect_kernel="hipblasLtMatmul")
