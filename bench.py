@@ -552,7 +552,7 @@ def main():
         lin_params = m["n_layers"] * (m["dim"] * m["n_heads"] * m["head_dim"] * 2
                                       + 2 * m["dim"] * m["n_kv_heads"] * m["head_dim"]
                                       + 3 * m["dim"] * m["ffn_dim"])
-        # which of its GEMMs went to the ROCm library (decoder.cc gemm_lib: launches with >= 128 tiles of 256 x 256 multiply a
+        # which of its GEMMs went to the ROCm library (decoder.cc gemm_lib: launches with >= 48 tiles of 256 x 256 multiply a
         # dequantised bfloat16 copy of the matrix in hipBLASLt; the others are the hand-written prompt kernels) -- from the launch log
         dec.launch_log(True)
         dec.prefill(ptoks, 0)

@@ -244,7 +244,7 @@ struct mc_decoder {
     bool pf2_on = true;        // MC_PF2: short prompts from the quad-interleaved copy
     bool pf_lib_on = true;     // MC_PF_BLASLT: long prompts' large GEMMs in hipBLASLt on a dequantised bfloat16 copy of the matrix (gemm_lib)
     bool pf_lib_force = false;
-    int pf_lib_tiles = 128;    // MC_PF_BLASLT_TILES: the fewest 256 x 256 tiles of a launch the library takes (measured: tools/blaslt_probe.py)
+    int pf_lib_tiles = 48;     // MC_PF_BLASLT_TILES: the fewest 256 x 256 tiles of a launch the library takes (swept on whole prompts: profiles/r04_prefill_blaslt.log)
     hipblasLtHandle_t lt = nullptr;
     void* lt_ws = nullptr;
     static constexpr size_t lt_ws_bytes = 64u << 20;
@@ -1362,8 +1362,9 @@ struct mc_decoder {
     // Measured on MI355X (tools/blaslt_probe.py, profiles/r04_blaslt_probe.log; WBITS=16 tools/prefill_bench.py): the hand-written
     // tiled GEMM reaches 600-725 TFLOP/s with AND without its dequantisation (plain bfloat weights: 180 us for w1|w3 at 512 rows
     // against 168 with int4) -- its ceiling is the tile loop, not the exact arithmetic -- while hipBLASLt multiplies the same shapes
-    // at 1.1-1.36 PFLOP/s once a launch has >= 128 tiles of 256 x 256 (w1|w3 from 512 rows on, every matrix of Llama-3-8B from 2048
-    // rows on) and at 600-750 below that, where the split-K kernels here are faster.  The operand is Wd = T(T(q) T(s)), the very
+    // at 1.1-1.36 PFLOP/s once a launch has >= 128 tiles of 256 x 256 and at 600-750 with 32-48 of them, where the split-K kernels
+    // here are as fast or faster.  The threshold was then swept on whole prompts of 256-1536 rows (profiles/r04_prefill_blaslt.log):
+    // 48 tiles is the best or equal at every length (w1|w3 from 256 rows on, wq|wk|wv from 512, every matrix of Llama-3-8B from 768).  The operand is Wd = T(T(q) T(s)), the very
     // values the prompt kernels hold in LDS, kept as a bfloat16 copy [out][in] (2 bytes per weight more HBM: 14 GB for Llama-3-8B
     // of 288); sums are fp32, rounded to T once (linear.h:70-81) -- only the order of the fp32 additions differs from the kernels'.
     // Any failure of the library (absent, no algorithm, an error status) switches the path off: the prompt kernels take over.

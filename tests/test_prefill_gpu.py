@@ -486,7 +486,7 @@ def test_two_head_prompt_attention_sliding_window_and_second_chunk(acc, monkeypa
 
 
 # ---- the library GEMM of long prompts (decoder.cc gemm_lib: hipBLASLt on the dequantised bfloat16 copy of a matrix).  The decoder
-# takes it where a launch has >= 128 tiles of 256 x 256 (w1|w3 of Llama-3-8B from 512 rows on); MC_PF_BLASLT=2 takes it for every
+# takes it where a launch has >= 48 tiles of 256 x 256 (w1|w3 of Llama-3-8B from 256 rows on, every matrix from 768); MC_PF_BLASLT=2 takes it for every
 # prompt GEMM that can, which is how the models the oracle can follow reach it.
 @pytest.mark.parametrize("quant,fmt,group", [("i4", 2, 32), ("i4", 2, 128), ("i8", 1, 32), (None, 0, 0)])
 @pytest.mark.parametrize("n", [21, 300])
@@ -502,7 +502,7 @@ def test_library_gemm_of_long_prompts_matches_oracle(acc, n, quant, fmt, group, 
 
 
 def test_library_gemm_is_the_decoders_choice_only_where_a_launch_has_enough_tiles(acc, monkeypatch):
-    """512 rows on a model with a 16384-row w1|w3: that GEMM alone goes to the library (128 tiles of 256 x 256), the others keep
+    """512 rows on a model with a 16384-row w1|w3: that GEMM alone goes to the library (128 tiles of 256 x 256 >= 48; the others have 2-8), the others keep
     the prompt kernels; the token and the rows agree with the kernels-only prompt (MC_PF_BLASLT=0) like two orders of the same
     fp32 sums; and new weights rebuild the dequantised copy."""
     import metalchat_amd as mc
