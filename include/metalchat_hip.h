@@ -237,6 +237,10 @@ mc_status mc_decoder_step(mc_decoder* d, int32_t token, int32_t start_pos, const
  * rotated left by len and the chunk takes the last len rows (len <= max_seq_len, "sink_cache: requested length ... is
  * larger than the cache size" otherwise).  A chunk that starts inside the cache and ends outside is an error, as it
  * is in the reference (its cache slice runs out of range).
+ * Long prompts: a GEMM launch with >= 48 tiles of 256 x 256 (MC_PF_BLASLT_TILES) multiplies a dequantised bfloat16 copy of the
+ * matrix -- Wd = T(T(q) T(s)), kernel/mul.metal:78-82, 2 bytes per weight more device memory, built on first use -- in the ROCm
+ * library GEMM (libhipblaslt, opened with dlopen on first use; MC_PF_BLASLT=0 or an absent library: the prompt kernels alone).
+ * Same operand values, fp32 sums rounded to T once (nn/linear.h:70-81); the first such prompt of a process also pays the library's start-up.
  * mc_decoder_prefill_stage is the same pass on ONE STAGE of a layer pipeline: the first stage takes `tokens`, a later
  * stage the [len][dim] hidden rows of the previous one (`rows_in`, device memory); *rows_out (device memory, valid
  * until the next prompt pass) receives this stage's rows; the last stage runs the head and fills *next_token. */
