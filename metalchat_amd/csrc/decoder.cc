@@ -244,6 +244,7 @@ struct mc_decoder {
     bool pf2_on = true;        // MC_PF2: short prompts from the quad-interleaved copy
     bool pf_lib_on = true;     // MC_PF_BLASLT: long prompts' large GEMMs in hipBLASLt on a dequantised bfloat16 copy of the matrix (gemm_lib)
     bool pf_lib_force = false;
+    int pf_lib_rows = 256;     // MC_PF_BLASLT_ROWS: the shortest prompt chunk whose GEMMs may take the library
     int pf_lib_tiles = 48;     // MC_PF_BLASLT_TILES: the fewest 256 x 256 tiles of a launch the library takes (swept on whole prompts: profiles/r04_prefill_blaslt.log)
     hipblasLtHandle_t lt = nullptr;
     void* lt_ws = nullptr;
@@ -1375,7 +1376,7 @@ struct mc_decoder {
         if (L.fmt != MC_WFMT_T && (L.in % 16 != 0 || (L.group && (L.group & (L.group - 1)) != 0))) return false;
         if (L.in % 8 != 0 || L.out % 8 != 0) return false;
         if (pf_lib_force) return true; // (MC_PF_BLASLT=2: every prompt GEMM that can, whatever its size -- how the tests reach it on small models)
-        return M >= 256 && (size_t)((L.out + 255) / 256) * (size_t)((M + 255) / 256) >= (size_t)pf_lib_tiles;
+        return M >= pf_lib_rows && (size_t)((L.out + 255) / 256) * (size_t)((M + 255) / 256) >= (size_t)pf_lib_tiles;
     }
     mc_status
     ensure_wd(const linear_w& Lc, const void** wd)
@@ -1822,6 +1823,7 @@ mc_decoder_create(mc_device* dev, mc_library* lib, mc_queue* q, const mc_decoder
         d->pf_lib_on = atoi(e) != 0;
         d->pf_lib_force = atoi(e) == 2;
     }
+    if (const char* e = getenv("MC_PF_BLASLT_ROWS")) d->pf_lib_rows = std::max(1, atoi(e));
     if (const char* e = getenv("MC_PF_BLASLT_TILES")) d->pf_lib_tiles = std::max(1, atoi(e));
     if (const char* e = getenv("MC_PF_FOLD")) d->pf_fold_on = atoi(e) != 0;
     if (const char* e = getenv("MC_ATTN_T2")) d->attn_t2_on = atoi(e) != 0;
