@@ -244,7 +244,8 @@ struct mc_decoder {
     bool pf2_on = true;        // MC_PF2: short prompts from the quad-interleaved copy
     bool pf_lib_on = true;     // MC_PF_BLASLT: long prompts' large GEMMs in hipBLASLt on a dequantised bfloat16 copy of the matrix (gemm_lib)
     bool pf_lib_force = false;
-    int pf_lib_rows = 256;     // MC_PF_BLASLT_ROWS: the shortest prompt chunk whose GEMMs may take the library
+    int pf_lib_rows = 160;     // MC_PF_BLASLT_ROWS: the shortest prompt chunk whose GEMMs may take the library (measured: 128 rows 5.01 ms without against
+                               // 5.38 with, 160 rows 6.83 / 5.96, 192: 6.91 / 6.33, 224: 7.08 / 6.44 -- profiles/r04_prefill_blaslt.log)
     int pf_lib_tiles = 48;     // MC_PF_BLASLT_TILES: the fewest 256 x 256 tiles of a launch the library takes (swept on whole prompts: profiles/r04_prefill_blaslt.log)
     hipblasLtHandle_t lt = nullptr;
     void* lt_ws = nullptr;
