@@ -244,6 +244,9 @@ struct mc_decoder {
     bool pf2_on = true;        // MC_PF2: short prompts from the quad-interleaved copy
     bool pf_lib_on = true;     // MC_PF_BLASLT: long prompts' large GEMMs in hipBLASLt on a dequantised bfloat16 copy of the matrix (gemm_lib)
     bool pf_lib_force = false;
+    bool pf_lib_tune = false;  // MC_PF_BLASLT_TUNE=1: the fastest of the heuristic's first eight algorithms, timed once per shape, instead of its first
+                               // (measured: inside the noise -- 512 rows 10.13 / 9.91 ms without, 10.04 / 10.00 with; 2048 rows 32.92 / 33.52, 32.55 / 32.92 --
+                               // and a timed choice would make the order of the fp32 additions differ from run to run: off)
     int pf_lib_rows = 160;     // MC_PF_BLASLT_ROWS: the shortest prompt chunk whose GEMMs may take the library (measured: 128 rows 5.01 ms without against
                                // 5.38 with, 160 rows 6.83 / 5.96, 192: 6.91 / 6.33, 224: 7.08 / 6.44 -- profiles/r04_prefill_blaslt.log)
     int pf_lib_tiles = 48;     // MC_PF_BLASLT_TILES: the fewest 256 x 256 tiles of a launch the library takes (swept on whole prompts: profiles/r04_prefill_blaslt.log)
@@ -1435,8 +1438,44 @@ struct mc_decoder {
             const uint64_t wsb = lt_ws_bytes;
             good = good && api.PrefSet(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &wsb, sizeof(wsb)) == HIPBLAS_STATUS_SUCCESS;
             int found = 0;
-            good = good && api.Heuristic(lt, pl.desc, pl.a, pl.b, pl.c, pl.c, pref, 1, &pl.algo, &found) == HIPBLAS_STATUS_SUCCESS && found > 0;
+            constexpr int NCAND = 8;
+            hipblasLtMatmulHeuristicResult_t cand[NCAND] = {};
+            good = good && api.Heuristic(lt, pl.desc, pl.a, pl.b, pl.c, pl.c, pref, pf_lib_tune ? NCAND : 1, cand, &found) == HIPBLAS_STATUS_SUCCESS && found > 0;
             if (pref) (void)api.PrefDestroy(pref);
+            if (good) pl.algo = cand[0];
+            if (good && found > 1) {
+                // the heuristic's first answer is not always the fastest kernel for a shape: each candidate multiplies THIS call's
+                // operands once to warm up and three times between two events (the rows it leaves are the rows any of them leaves
+                // up to the order of the fp32 additions; the last run below is the chosen one's)
+                hipEvent_t e0 = nullptr, e1 = nullptr;
+                if (hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
+                    const float one = 1.0f, zero = 0.0f;
+                    float best = 0.0f;
+                    int best_i = -1;
+                    for (int i = 0; i < found; i++) {
+                        if (cand[i].workspaceSize > lt_ws_bytes) continue;
+                        bool ran = true;
+                        for (int r = 0; r < 4 && ran; r++) {
+                            if (r == 1) (void)hipEventRecord(e0, stream);
+                            ran = api.Matmul(lt, pl.desc, &one, wd, pl.a, X, pl.b, &zero, Y, pl.c, Y, pl.c, &cand[i].algo, lt_ws, lt_ws_bytes, stream) == HIPBLAS_STATUS_SUCCESS;
+                        }
+                        float ms = 0.0f;
+                        if (!ran || hipEventRecord(e1, stream) != hipSuccess || hipEventSynchronize(e1) != hipSuccess ||
+                            hipEventElapsedTime(&ms, e0, e1) != hipSuccess)
+                            continue;
+                        if (best_i < 0 || ms < best) {
+                            best = ms;
+                            best_i = i;
+                        }
+                    }
+                    if (best_i >= 0) pl.algo = cand[best_i];
+                    if (getenv("MC_PF_BLASLT_VERBOSE"))
+                        fprintf(stderr, "metalchat_hip: hipBLASLt %d x %d x %d%s: candidate %d of %d, %.1f us\n", M, L.out, L.in, f32_out ? " (fp32 rows)" : "",
+                                best_i, found, best * 1e3f / 3.0f);
+                }
+                if (e0) (void)hipEventDestroy(e0);
+                if (e1) (void)hipEventDestroy(e1);
+            }
             pl.usable = good;
         }
         if (!pl.usable) return off("no algorithm for a shape");
@@ -1824,6 +1863,7 @@ mc_decoder_create(mc_device* dev, mc_library* lib, mc_queue* q, const mc_decoder
         d->pf_lib_on = atoi(e) != 0;
         d->pf_lib_force = atoi(e) == 2;
     }
+    if (const char* e = getenv("MC_PF_BLASLT_TUNE")) d->pf_lib_tune = atoi(e) != 0;
     if (const char* e = getenv("MC_PF_BLASLT_ROWS")) d->pf_lib_rows = std::max(1, atoi(e));
     if (const char* e = getenv("MC_PF_BLASLT_TILES")) d->pf_lib_tiles = std::max(1, atoi(e));
     if (const char* e = getenv("MC_PF_FOLD")) d->pf_fold_on = atoi(e) != 0;
