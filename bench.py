@@ -538,7 +538,7 @@ def main():
                          "launches_per_token": ln_all},
         }
         # informational (not `value`): the prompt pass that precedes decoding -- time to first token
-        # for a 512-token prompt through mc_decoder_prefill (dequant-once MFMA GEMMs), measured
+        # for a 512-token prompt through mc_decoder_prefill (dequant-once MFMA GEMMs; hipBLASLt for its large launches), measured
         # after the timed region on the same decoder; the first call allocates and is not timed
         plen = min(512, S)
         ptoks = np.random.default_rng(1).integers(0, m["vocab"], plen)
