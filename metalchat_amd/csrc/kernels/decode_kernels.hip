@@ -43,28 +43,6 @@ derive_state(step_state* st, int32_t max_seq, int32_t pre_len)
     st->epoch += 1;
 }
 
-// Test aid (tests/test_fallback_gpu.py): a workgroup that HOLDS its compute unit -- it declares (nearly) all of a CU's 160 KiB of
-// LDS, which keeps every kernel that uses LDS off that CU -- until *release != 0 or `ticks` of the 100 MHz clock have
-// passed (a bounded spin: the grid drains by itself).  What another process or stream on the same GPU does to a launch that
-// needs its workgroups resident together.
-extern "C" __global__ void
-mc_test_hold_cu(const uint32_t* release, uint32_t* started, unsigned long long ticks)
-{
-    constexpr uint32_t N = (160 * 1024 - 1024) / 4;
-    __shared__ uint32_t hold_lds[N];
-    // (an index the compiler cannot know: an array of which one word is used is shrunk to that word)
-    hold_lds[(release[0] + threadIdx.x * 631u + (uint32_t)ticks) % N] = threadIdx.x;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        if (hold_lds[(uint32_t)(ticks >> 3) % N] == 0xFFFFFFFFu) started[1] = 1;
-        atomicAdd(started, 1u);
-        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-        while (__hip_atomic_load(release, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0 && __builtin_amdgcn_s_memrealtime() - t0 < ticks)
-            __builtin_amdgcn_s_sleep(64);
-    }
-    __syncthreads();
-}
-
 // start a step at an explicit (token, pos).  token < 0 keeps the token left by the argmax.
 extern "C" __global__ void
 mc_step_set(step_state* st, int32_t token, int32_t pos, int32_t max_seq, int32_t pre_len,
@@ -640,7 +618,7 @@ mc_attn_pv_reduce_float(const float* __restrict__ parts, float* __restrict__ out
 // XCD a workgroup lands (workgroups with equal blockIdx.x % 8 share an XCD in practice: the ranges of one kv head sit
 // together, so most hand-offs stay inside one L2 -- for speed only).  tag = step epoch * 256 + layer + 1: unique per
 // launch (the epoch counts steps since the decoder was created and is never reset), so a granule of an earlier launch is
-// never mistaken for this one's and nothing has to be cleared between launches.  Every wait is bounded (2 s of
+// never mistaken for this one's and nothing has to be cleared between launches.  Every wait is bounded (50 ms of
 // s_memrealtime): on expiry the launch sets state.err and carries on with what it has; later waits see the flag and do not
 // wait at all, and the host reports it (mc_decoder_generate / _step return MC_ERR_RUNTIME).  The grid must be co-resident:
 // the host takes this path only while nsplit * n_kv <= 4 workgroups per CU.

@@ -4,7 +4,7 @@
 // XCD a workgroup lands.  tag = step epoch * 256 + a number that is unique inside the token (layer + 1, or 128 + layer for the
 // second hand-off buffer of a layer): the epoch counts steps since the decoder was created and is never reset, so a granule of
 // an earlier launch is never mistaken for this one's and nothing has to be cleared between launches.  Every wait is bounded
-// (2 s of s_memrealtime): on expiry the launch sets state.err and carries on with what it has; later waits see the flag and do
+// (50 ms of s_memrealtime -- a launch is ~ 15 us, so 3000 x its length; round 4: 2 s): on expiry the launch sets state.err and carries on with what it has; later waits see the flag and do
 // not wait at all, and the host reports it (mc_decoder_generate / _step return MC_ERR_RUNTIME).  A launch whose workgroups wait
 // for one another must be co-resident: the host guarantees it (decoder.cc attn_fused(), attn_wo_fused(), chain_ok()).
 #pragma once
@@ -76,6 +76,9 @@ granule_look_dual(const unsigned long long* slow, size_t fast_off, uint32_t look
 }
 
 // one round of a bounded wait: false = keep waiting.  `ok` is wave-uniform.
+#ifndef MC_HANDOFF_BOUND_TICKS
+#define MC_HANDOFF_BOUND_TICKS 5000000ull // 50 ms at 100 MHz
+#endif
 struct handoff_wait {
     unsigned long long t0;
     uint32_t spins;
@@ -90,7 +93,7 @@ struct handoff_wait {
         __builtin_amdgcn_s_sleep(MC_HANDOFF_SLEEP);
         if ((++spins & 63u) != 0) return false;
         if (__hip_atomic_load((gu32_t*)&st->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return true;
-        if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { // 2 s at 100 MHz
+        if (__builtin_amdgcn_s_memrealtime() - t0 > MC_HANDOFF_BOUND_TICKS) {
             __hip_atomic_store((gu32_t*)&st->err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return true;
         }

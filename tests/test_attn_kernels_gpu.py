@@ -140,7 +140,7 @@ def test_two_launch_attention_matches_the_oracle(acc, H, KV, hd, max_seq, n):
 
 
 def test_a_hand_off_whose_producers_never_run_gives_up_and_reports(acc):
-    """The waits inside a launch are bounded (handoff.h: 2 s of s_memrealtime, then state.err is set and every later wait of the
+    """The waits inside a launch are bounded (handoff.h: 50 ms of s_memrealtime, then state.err is set and every later wait of the
     token returns at once).  Here half of the workgroups of mc_attn_fused_bfloat are simply not launched: the others wait for
     partial denominators nobody will publish, must come back within the bound with the error word set (what
     mc_decoder_step / _generate turn into MC_ERR_RUNTIME, decoder.cc check_handoffs) -- and the same buffers serve a complete
@@ -175,7 +175,7 @@ def test_a_hand_off_whose_producers_never_run_gives_up_and_reports(acc):
     took = time.perf_counter() - t0
     err = int(state.download(np.int32, 12)[10]) & 0xFFFFFFFF
     assert err != 0, "the launch must report the hand-off it gave up on"
-    assert 1.0 < took < 8.0, f"bounded wait: {took:.2f} s"
+    assert 0.04 < took < 0.4, f"bounded wait: {took:.3f} s"
     # the next step (a new epoch): complete grid, same granule buffers, a clean state
     state = state_buffer(acc, n, 2)
     launch(state, nsplit * KV)

@@ -10,6 +10,7 @@ import pytest
 import parity
 from test_context_gpu import FULL_WIDTH, SEED, random_cache
 import modelgen as mg
+import testkernels
 
 pytestmark = pytest.mark.gpu
 BF16 = 0
@@ -40,7 +41,7 @@ def test_a_step_whose_handoffs_give_up_is_repeated_without_them(monkeypatch):
     import metalchat_amd as mc
 
     acc = mc.HardwareAccelerator(ordinal=0)
-    acc2 = mc.HardwareAccelerator(ordinal=0)   # a second queue: the "other user" of the GPU
+    acc2 = mc.HardwareAccelerator(path=testkernels.build(), ordinal=0)   # a second queue with the test-only code object: the "other user" of the GPU
     cfg = dict(dtype=BF16, n_layers=2, vocab=2048, norm_eps=1e-5, max_seq_len=2048, **FULL_WIDTH["llama3-8b"])
     kw = mg.decoder_kwargs(cfg, weight_format=mc.WFMT_I4, group_size=128)
     n = 100
@@ -64,14 +65,15 @@ def test_a_step_whose_handoffs_give_up_is_repeated_without_them(monkeypatch):
     dec = fresh()
     dec.launch_log(True)
  
-    release, started, nhold = hold_most_of_the_chip(acc2, 6.0)
+    release, started, nhold = hold_most_of_the_chip(acc2, 3.0)
     try:
         t0 = time.perf_counter()
         tok = dec.step(5, n)                      # most of the hand-off launch's workgroups cannot start: it gives up, the step is repeated
         took = time.perf_counter() - t0
-        print(f"step under a held chip: {took:.2f} s, fall-backs {dec.handoff_fallbacks()}, launched {sorted(set(dec.launched()))}")
+        print(f"step under a held chip: {took:.3f} s, fall-backs {dec.handoff_fallbacks()}, launched {sorted(set(dec.launched()))}")
         assert dec.handoff_fallbacks() == 1
-        assert 1.0 < took < 5.5, f"bounded wait + one repetition, the chip still held: {took:.2f} s"
+        # (handoff.h: every wait gives up after 50 ms -- VERDICT r04 item 5: "the first step returns in < 0.3 s")
+        assert 0.04 < took < 0.3, f"bounded wait (50 ms) + one repetition, the chip still held: {took:.3f} s"
         names = dec.launched()
         assert any(x.startswith("mc_attn_qkv_wo_") or x.startswith("mc_attn_wo_") for x in names), sorted(set(names))
         assert "mc_attn_scores_bfloat" in names and "mc_attn_pv_bfloat" in names, sorted(set(names))
@@ -94,7 +96,7 @@ def test_a_chain_whose_handoffs_give_up_is_repeated_without_them(monkeypatch):
     import metalchat_amd as mc
 
     acc = mc.HardwareAccelerator(ordinal=0)
-    acc2 = mc.HardwareAccelerator(ordinal=0)
+    acc2 = mc.HardwareAccelerator(path=testkernels.build(), ordinal=0)
     cfg = dict(dtype=BF16, n_layers=2, vocab=2048, norm_eps=1e-5, max_seq_len=2048, **FULL_WIDTH["llama3-8b"])
     kw = mg.decoder_kwargs(cfg, weight_format=mc.WFMT_I4, group_size=128)
     monkeypatch.setenv("MC_ATTN_FUSED", "0")
@@ -105,7 +107,7 @@ def test_a_chain_whose_handoffs_give_up_is_repeated_without_them(monkeypatch):
     monkeypatch.delenv("MC_ATTN_FUSED")
     dec = mc.Decoder(acc, **kw)
     dec.init_synthetic(SEED)
-    release, started, nhold = hold_most_of_the_chip(acc2, 5.0)
+    release, started, nhold = hold_most_of_the_chip(acc2, 3.0)
     try:
         got = list(dec.generate(3, 0, 12))   # stays inside the cache: repeated from the state in front of the call
         assert dec.handoff_fallbacks() == 1
