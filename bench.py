@@ -358,7 +358,45 @@ def run_other_configs(mc, acc, np):
             dec.release()
         except Exception as e:  # an informational leg must not take the headline down
             out.append(dict(config=name, error=str(e)[:200]))
+    out.append(run_local_pipeline_70b(mc, acc, np))
     return out
+
+
+def run_local_pipeline_70b(mc, acc, np, world=8):
+    """BASELINE configs[4] as far as ONE GPU can show it: Llama-3-70B int4 g128 cut into `world` stages of
+    80 / world layers (include/metalchat/nn/llama.h:123-126), all of them on this device in this process -- mc_pipeline_create_local:
+    the launches of every stage are the RCCL transport's, a hop is a device-to-device copy of the hidden row behind an event instead
+    of ncclSend / ncclRecv.  Next to the single-stage 70B number above it prices the pipeline's bookkeeping (7 row hops + the token
+    hop per token); it says nothing about xGMI."""
+    name = f"Llama-3-70B int4 g128 layer-pipelined pp{world}, all stages sharing this GPU (device-to-device hops), S=2048 (configs[4])"
+    try:
+        m = MODELS["llama3-70b"]
+        S, K = 2048, 32
+        stages = []
+        for r in range(world):
+            b, e = mc.pipeline_layer_range(r, world, m["n_layers"])
+            d = mc.Decoder(acc, dtype=mc.BF16, family=mc.FAMILY_LLAMA3, max_seq_len=S, attn_scale=float(1.0 / np.sqrt(m["head_dim"])),
+                           layer_begin=b, layer_end=e, weight_format=mc.WFMT_I4, group_size=128, use_graph=0, **m)
+            d.init_synthetic(7)
+            stages.append(d)
+        pipe = mc.Pipeline.local(stages)
+        start = S - K - 8
+        tok = int(pipe.generate(1, start, 8)[-1])
+        acc.wait()
+        t0 = time.perf_counter()
+        pipe.generate(tok, start + 8, K)
+        acc.wait()
+        dt = time.perf_counter() - t0
+        pipe.release()
+        for d in stages:
+            d.release()
+        ab = algorithmic_bytes(m, 4, 128, S, 2)
+        tps = K / dt
+        return dict(config=name, tokens_per_s=tps, ms_per_token=dt / K * 1e3, tokens=K, layers_per_stage=m["n_layers"] // world,
+                    algorithmic_bytes=ab["total"], frac_of_hbm_peak=ab["total"] * tps / 1e9 / HBM_PEAK_GBS,
+                    hop_transport="device-to-device copy behind an event", hipgraph=False)
+    except Exception as e:
+        return dict(config=name, error=str(e)[:200])
 
 
 def build_70b_stage(mc, acc, np, args, rank, world):
@@ -474,10 +512,20 @@ def main():
         tok = int(gen(tok, fill, W)[-1])
     sync_all()
     t0 = time.perf_counter()
-    gen(tok, fill + W, K)
+    tok = int(gen(tok, fill + W, K)[-1])
     sync_all()
     dt = time.perf_counter() - t0
     tmax = sync_all(dt)
+    # Two more chains of the same K tokens, continuing past position seq_len (the sink ring turns: every token still attends to
+    # max_seq_len rows, the same traffic): `value` stays the FIRST chain -- steps x ms_per_step is the region the driver can check --
+    # and `value_spread` says how far apart three identical chains of this process land
+    chain_tps = [K / tmax]
+    for c in (1, 2):
+        sync_all()
+        t0 = time.perf_counter()
+        tok = int(gen(tok, fill + W + c * K, K)[-1])
+        sync_all()
+        chain_tps.append(K / sync_all(time.perf_counter() - t0))
 
     ab = algorithmic_bytes(m, args.wbits, args.group, S, tbytes)
     tok_s = K / tmax
@@ -485,6 +533,7 @@ def main():
         "metric": "decode tokens/s (batch=1) + achieved HBM GB/s vs roofline, int4 Llama-3-8B",
         "value": tok_s, "unit": "tokens/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": 1e3 * tmax / K, "higher_is_better": True,
+        "value_spread": [min(chain_tps), max(chain_tps)], "chains_tokens_per_s": chain_tps,
         "scaling": "strong", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"{args.model} int{args.wbits} (group={args.group}) batch=1 greedy decode, "
@@ -538,12 +587,16 @@ def main():
                          "launches_per_token": ln_all},
         }
         # informational (not `value`): the prompt pass that precedes decoding -- time to first token
-        # for a 512-token prompt through mc_decoder_prefill (dequant-once MFMA GEMMs; hipBLASLt for its large launches), measured
-        # after the timed region on the same decoder; the first call allocates and is not timed
+        # for a 512-token prompt through mc_decoder_prefill (hand-written MFMA GEMMs on the decode weight layout, dequantised once per
+        # tile in LDS), measured after the timed region on the same decoder; `first_call_ms` is the first prompt of the process
+        # (allocations included), `ms` the mean of the next three, `extra_hbm_bytes` what derived weight copies hold afterwards
         plen = min(512, S)
         ptoks = np.random.default_rng(1).integers(0, m["vocab"], plen)
-        dec.prefill(ptoks, 0)
         acc.wait()
+        t0 = time.perf_counter()
+        dec.prefill(ptoks, 0)   # the FIRST prompt of the process: row buffers allocated, the table of exponentials built
+        acc.wait()
+        first_ms = (time.perf_counter() - t0) * 1e3
         t0 = time.perf_counter()
         for _ in range(3):
             dec.prefill(ptoks, 0)
@@ -559,7 +612,8 @@ def main():
         acc.wait()
         pnames = dec.launched()
         dec.launch_log(False)
-        out["prompt_pass"] = {"tokens": plen, "ms": pms, "tokens_per_s": plen / (pms * 1e-3),
+        out["prompt_pass"] = {"tokens": plen, "ms": pms, "first_call_ms": first_ms, "extra_hbm_bytes": dec.derived_weight_bytes(),
+                              "tokens_per_s": plen / (pms * 1e-3),
                               "linear_TFLOPs": 2.0 * lin_params * plen / (pms * 1e-3) / 1e12,
                               "mfma_peak_TFLOPs": 2500.0,
                               "gemm_launches": {"hipBLASLt": pnames.count("hipblasLtMatmul"),

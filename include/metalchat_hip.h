@@ -335,6 +335,11 @@ mc_status mc_decoder_gemv_kernel_name(mc_decoder* d, const char* which, char* bu
  * MC_ERR_RUNTIME ("... repeat the call") -- the reference delivers a GPU execution error the same way, through the future that
  * is waited for (src/kernel_thread.cc:134-144). */
 int32_t mc_decoder_handoff_fallbacks(const mc_decoder* d);
+/* HBM bytes this decoder holds in DERIVED copies of its weights, built on demand by the prompt pass: the quad-interleaved int4 copy
+ * short prompts stream from (+ 0.5 byte per weight) and -- only with the opt-in library GEMM, MC_PF_BLASLT=1 -- the dequantised
+ * bfloat16 copy (+ 2 bytes per weight).  0 until a prompt has asked for one.  The reference materialises the dequantised matrix on
+ * every call (quantization/lora.h:115-117); the default path here never does. */
+size_t mc_decoder_derived_weight_bytes(const mc_decoder* d);
 /* Test aid: record the host names of every kernel the decoder launches from now on (enable = 1 clears the log and
  * drops a captured token graph, whose replay would launch without passing here; 0 stops recording).
  * mc_decoder_launch_log_read copies the newline-separated names and returns the bytes needed (terminator included).

@@ -2553,6 +2553,25 @@ mc_decoder_handoff_fallbacks(const mc_decoder* d)
     return d ? d->handoff_fallbacks : 0;
 }
 
+size_t
+mc_decoder_derived_weight_bytes(const mc_decoder* d)
+{
+    if (!d) return 0;
+    size_t n = 0;
+    auto one = [&](const linear_w& L) {
+        if (L.wq2) n += (size_t)((L.out + 15) / 16) * (size_t)(L.in / 128) * 1024;
+        if (L.wd) n += (size_t)L.out * L.in * 2;
+    };
+    for (const layer_w& L : d->layers) {
+        one(L.qkv);
+        one(L.wo);
+        one(L.w13);
+        one(L.w2);
+    }
+    one(d->output);
+    return n;
+}
+
 void*
 mc_decoder_hidden_out(mc_decoder* d)
 {

@@ -16,9 +16,9 @@
 //     of 128 bytes, 16-byte chunk c of row r at position c ^ ((r >> 1) & 7) -- conflict-free for the fragment reads by the bank rule
 //     of ds_read_b128 (MI355X_MICROARCH.md, LDS).  Filled by LDS-DMA (buffer_load ... lds, 16 bytes per lane): the destination is linear
 //     per wave instruction (8 rows), the swizzle sits on the SOURCE address; rows past M or N read as zeros (the buffer's bounds).
-//   * one half tile is staged per phase, by the group that is not multiplying, into the image whose last reader finished a phase
-//     earlier; `s_waitcnt vmcnt(4)` at the end of every reading phase leaves ONE half tile of the wave in flight across the barrier;
-//     a half tile is read three phases after it was requested at the earliest (~ 0.7 us).
+//   * one half tile is staged per phase, by the group that is not multiplying, into a ring of half-tile slots; a counted
+//     `s_waitcnt vmcnt(N)` at the end of every reading phase leaves the wave's youngest requests in flight across the barrier; a half
+//     tile is read 3 (8 slots) or 5 (10 slots: all 160 KiB) phases after it was requested at the earliest.
 //
 //   phase p = 4 t + q of K tile t        group 0                         group 1                       staged (by the reading group)
 //     q = 0                              read (t, k 0-31)                multiply (t - 1, k 32-63)      W rows 0-127 of tile t + 1
@@ -30,8 +30,23 @@
 
 #include "common.h"
 
+#include <type_traits>
+
 namespace mc {
 namespace g8 {
+
+// byte k of a dword -> float in one full-rate instruction (hipcc builds v_bfe_u32 + v_cvt_f32_u32 otherwise)
+template <int K_>
+__device__ __forceinline__ float
+ubyte_f32(uint32_t v)
+{
+    float d;
+    if (K_ == 0) asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(d) : "v"(v));
+    if (K_ == 1) asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(d) : "v"(v));
+    if (K_ == 2) asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(d) : "v"(v));
+    if (K_ == 3) asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(d) : "v"(v));
+    return d;
+}
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -77,12 +92,18 @@ struct args {
     uint32_t M, N, K, group;
 };
 
-template <int WF, int EPI, typename ActFn>
+// NS: half-tile slots of the LDS ring (8 = two images of a K tile, 128 KiB; 10 = all 160 KiB: every request goes out two phases
+// earlier).  DIAG (lab builds): 1 = nothing is staged inside the loop (what the LDS reads, the MFMAs and the barriers take alone),
+// 2 = no MFMAs (what the staging and the reads take alone).
+template <int WF, int EPI, int NS = 8, int DIAG = 0, typename ActFn>
 __device__ __forceinline__ void
 body(const args& a, ActFn&& act)
 {
-    static_assert(WF == W_T, "quantised operands: pf_gemm8_q.h");
-    __shared__ __attribute__((aligned(1024))) char lds_[LDS_BYTES];
+    static_assert(NS == 8 || NS == 10, "slots");
+    static_assert(WF == W_T || NS == 8, "the quantised loop's schedule is written for two images");
+    constexpr int D = NS - 8;                  // phases a request goes out earlier than the two-image schedule's
+    constexpr int LEAD = 1 + D;                // events of tile 1 the prologue requests behind tile 0 (the loop's phase p requests event 4 + LEAD + p)
+    __shared__ __attribute__((aligned(1024))) char lds_[NS * HALF_BYTES];
     lds_char* const lds = (lds_char*)lds_;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t grp = wave >> 2, wq = wave & 3u; // group; X half = grp, W half = wq >> 1, its rows (wq & 1) * 64 ..
@@ -96,8 +117,14 @@ body(const args& a, ActFn&& act)
     const uint32_t tbeg = EPI == E_PART ? blockIdx.z * tper : 0u;
     const uint32_t T = tbeg < TT ? min(tper, TT - tbeg) : 0u;
 
-    // ---- staging: a half tile = 16 wave instructions of 8 rows x 128 bytes; the four waves of the staging group take four each
-    // (instruction i of wave wq: rows (4 wq + i) 8 .. + 7).  Lane l: row l >> 3, position l & 7 of the row, i.e. source chunk
+    // ---- staging.  EVENTS: half tile c (0 = X rows 0-127, 1 = W rows 0-127, 2 = W rows 128-255, 3 = X rows 128-255) of K tile u is
+    // event 4 u + c and lives in ring slot (4 u + c) % NS.  Tile 0 and the first LEAD events of tile 1 are requested in the prologue;
+    // phase p of the loop requests event 4 + LEAD + p = p + NS - 3, by the group that reads in that phase: event e goes out in phase
+    // e - NS + 3 and is first read in phase >= 4 (e / 4), i.e. 3 + D phases later at the earliest (the W hi and X hi events).  A slot is
+    // free again when its event's last reader is done: X lo of tile u after phase 4 u + 2, the other three after 4 u + 3 -- and event
+    // e + NS, the slot's next tenant, is requested in phase e + 3: 4 u + 3 for the X lo of tile u (e = 4 u), >= 4 u + 4 for the others.
+    // A half tile = 16 wave instructions of 8 rows x 128 bytes; the four waves of the staging group take four each (instruction i
+    // of wave wq: rows (4 wq + i) 8 .. + 7).  Lane l: row l >> 3, position l & 7 of the row, i.e. source chunk
     // (l & 7) ^ ((row >> 1) & 7) = (l & 7) ^ (((i & 1) * 4 + (l >> 4)) & 7).  The LDS-DMA is inline asm: hipcc then neither counts it
     // nor waits vmcnt(0) in front of every LDS read that might alias its destination (it did, with the builtin: the loop drained the
     // queue twelve times per phase) -- the waits are counted by hand below.
@@ -110,13 +137,15 @@ body(const args& a, ActFn&& act)
     const uint32_t sc0 = ((lane & 7u) ^ (lane >> 4)) * 16u;              // even instructions; odd ones: ^ 64
     const uint32_t xv0 = (m0 + srow) * K * 2u + sc0, wv0 = (n0 + srow) * K * 2u + sc0;
     const uint32_t lds0 = (uint32_t)(uintptr_t)lds + wq * 4096u;
-    // half: 0 / 1 = X rows 0-127 / 128-255, 2 / 3 = W rows 0-127 / 128-255 (wave-uniform); t: K tile of this workgroup's range
-    auto stage = [&](uint32_t img, uint32_t half, uint32_t t) {
+    // event e (wave-uniform): tile e / 4 of this workgroup's K range, half tile e % 4
+    auto stage = [&](uint32_t e) {
+        const uint32_t u = e >> 2, c = e & 3u;
         // (a tile past the end of the K range: the last one again -- what it writes is never read, and the loop keeps its counted waits)
-        const uint32_t k0 = (tbeg + (t < T ? t : T - 1u)) * BK;
-        const uint32_t dst = lds0 + img * IMG_BYTES + half * HALF_BYTES;
-        const bool isw = half >= 2u;
-        const uint32_t base = (isw ? wv0 : xv0) + ((half & 1u) * 128u) * K * 2u + k0 * 2u;
+        const uint32_t k0 = (tbeg + (u < T ? u : T - 1u)) * BK;
+        const uint32_t dst = lds0 + (e % (uint32_t)NS) * HALF_BYTES;
+        const bool isw = c == 1u || c == 2u;
+        const uint32_t hi = c >> 1; // (rows 128-255 of the operand: c = 2, 3)
+        const uint32_t base = (isw ? wv0 : xv0) + (hi * 128u) * K * 2u + k0 * 2u;
         const u32x4 rs = isw ? wrs : xrs; // (scalar selects: the descriptor stays in SGPRs)
 #pragma unroll
         for (uint32_t i = 0; i < 4; i++) {
@@ -132,14 +161,17 @@ body(const args& a, ActFn&& act)
     // ---- fragments: 16 bytes of row (16 j + l15) of a half tile, k = 32 ks + 8 lg .. + 7: chunk 4 ks + lg at position ^ (l15 >> 1)
     const uint32_t f0 = l15 * 128u + ((lg ^ (l15 >> 1)) & 7u) * 16u;
     const uint32_t f1 = l15 * 128u + (((4u + lg) ^ (l15 >> 1)) & 7u) * 16u;
-    const uint32_t wbase = (2u + (wq >> 1)) * HALF_BYTES + (wq & 1u) * 8192u, xbase = grp * HALF_BYTES;
+    const uint32_t wsub = (wq & 1u) * 8192u;
     u32x4 wf[4], xf[8];
-    auto read_frags = [&](uint32_t img, uint32_t ks) {
-        lds_char* p = lds + img * IMG_BYTES + (ks ? f1 : f0);
+    // tile t: the W half of this wave is event 4 t + 1 + (wq >> 1), its X half event 4 t + 3 grp
+    auto read_frags = [&](uint32_t t, uint32_t ks) {
+        const uint32_t ws = (4u * t + 1u + (wq >> 1)) % (uint32_t)NS, xs = (4u * t + 3u * grp) % (uint32_t)NS;
+        lds_char* pw = lds + ws * HALF_BYTES + wsub + (ks ? f1 : f0);
+        lds_char* px = lds + xs * HALF_BYTES + (ks ? f1 : f0);
 #pragma unroll
-        for (int j = 0; j < 4; j++) wf[j] = *(const __attribute__((address_space(3))) u32x4*)(p + wbase + j * 2048);
+        for (int j = 0; j < 4; j++) wf[j] = *(const __attribute__((address_space(3))) u32x4*)(pw + j * 2048);
 #pragma unroll
-        for (int i = 0; i < 8; i++) xf[i] = *(const __attribute__((address_space(3))) u32x4*)(p + xbase + i * 2048);
+        for (int i = 0; i < 8; i++) xf[i] = *(const __attribute__((address_space(3))) u32x4*)(px + i * 2048);
     };
     f32x4 acc[8][4];
 #pragma unroll
@@ -147,6 +179,13 @@ body(const args& a, ActFn&& act)
 #pragma unroll
         for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     auto multiply = [&] {
+        if constexpr (DIAG == 2) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) asm volatile("" ::"v"(xf[i]));
+#pragma unroll
+            for (int j = 0; j < 4; j++) asm volatile("" ::"v"(wf[j]));
+            return;
+        }
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int i = 0; i < 8; i++)
@@ -155,10 +194,11 @@ body(const args& a, ActFn&& act)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[j]), __builtin_bit_cast(bf16x8, xf[i]), acc[i][j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
     };
-    // end of a phase in which this wave read and staged: its fragment reads done (the half tile may be overwritten a phase later),
-    // all but its youngest half tile landed
+    // end of a phase in which this wave read and staged: its fragment reads done (the slot may be overwritten a phase later), all
+    // but its youngest 1 + D / 2 half tiles landed
     auto end_read = [&] {
-        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        if constexpr (D == 0) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
     };
@@ -167,31 +207,144 @@ body(const args& a, ActFn&& act)
         __builtin_amdgcn_sched_barrier(0);
     };
 
+    if constexpr (WF != W_T) {
+        // ---- quantised W (int4 / int8 rows of the decode GEMV's layout): X travels as above, in QUARTERS (64 rows: two LDS-DMAs per
+        // wave and phase); a W quarter (64 rows x 64 k = the rows ONE wave position wq multiplies) is loaded to registers -- 8 (int4) or
+        // 16 (int8) bytes per lane: row lane / 4 of the wave's 16, weights 16 (lane % 4) .. + 15 of the tile -- by the group that reads,
+        // and two of its reading phases later dequantised EXACTLY (Wd = T(T(q) T(s)), kernel/mul.metal:78-82: one conversion, one fma
+        // and half a pack per weight; (n - 8) s and q s are exact in fp32) and written into the W slot with two 16-byte LDS stores: ~ 50
+        // vector instructions per wave and phase, issued by the group that is NOT multiplying.  Per phase p = 4 t + 2 ks + grp:
+        //     X quarter j = (p + 5) % 4 of tile (p + 5) / 4 (X lo rows 0-63, 64-127, X hi rows 0-63, 64-127) requested;
+        //     W quarter r = p % 4 of tile p / 4 + 1 dequantised and written (its slot's last reader -- tile p / 4 - 1 -- finished a phase
+        //     ago at the latest; its first reader comes in phase 4 (p / 4 + 1) at the earliest); W quarter (p + 2) % 4 of tile (p + 2) / 4 + 1
+        //     requested.  One wait per phase: `vmcnt(2)` behind the two new LDS-DMAs = everything of the previous reading phase landed.
+        const uint32_t K2 = WF == W_I4 ? K / 2u : K;                       // bytes per W row
+        const uint32_t RUNB = WF == W_I4 ? 8u : 16u;                       // bytes of a lane's 16 weights
+        const uint32_t ngroups = a.group ? K / a.group : 1u, glog = a.group ? 31u - (uint32_t)__builtin_clz(a.group) : 31u;
+        const u32x4 qrs = rsrc_of(a.w, (size_t)N * K2), srs = rsrc_of(a.scales, (size_t)((N + 3u) / 4u) * ngroups * 8u);
+        const uint32_t wrow16 = wq * 16u + (lane >> 2);                    // the lane's row inside a W quarter
+        const uint32_t qv0 = (n0 + wrow16) * K2 + (lane & 3u) * RUNB;      // + (64 r) K2 + k0 bytes
+        const uint32_t sv0 = (((n0 >> 2) + 4u * wq + (lane >> 4)) * ngroups * 4u + ((lane >> 2) & 3u)) * 2u; // + (16 r ngroups + g) 8
+        const uint32_t ww0 = wrow16 * 128u + (((2u * (lane & 3u)) ^ ((lane >> 3) & 7u)) * 16u); // first chunk; the second: ^ 16
+        typedef typename std::conditional<WF == W_I4, u32x2, u32x4>::type wraw_t;
+        wraw_t wraw;
+        uint32_t sraw;
+        auto stage_xq = [&](uint32_t u, uint32_t j) { // X quarter j of tile u
+            const uint32_t c = (j >> 1) ? 3u : 0u, qh = j & 1u;
+            const uint32_t k0 = (tbeg + (u < T ? u : T - 1u)) * BK;
+            const uint32_t dst = lds0 - wq * 2048u + ((4u * u + c) % 8u) * HALF_BYTES + qh * 8192u; // (lds0 carries wq * 4096: a wave's share of a QUARTER is 2 KiB)
+            const uint32_t base = xv0 - (wq * 16u) * K * 2u + ((j >> 1) * 128u + qh * 64u) * K * 2u + k0 * 2u; // (xv0: row wq * 32 + lane / 8 -> wq * 16 + lane / 8)
+#pragma unroll
+            for (uint32_t i = 0; i < 2; i++) {
+                const uint32_t vo = (base + i * 8u * K * 2u) ^ (i * 64u);
+                uint32_t keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep)
+                             : "s"(dst + i * 1024u), "v"(vo), "s"(xrs)
+                             : "memory");
+            }
+        };
+        auto load_wq = [&](uint32_t u, uint32_t r) { // W quarter r of tile u into wraw / sraw (asm: counted by hand)
+            const uint32_t k0 = (tbeg + (u < T ? u : T - 1u)) * BK;
+            const uint32_t vo = qv0 + (64u * r) * K2 + (WF == W_I4 ? k0 / 2u : k0);
+            const uint32_t so = sv0 + (16u * r * ngroups + (a.group ? k0 >> glog : 0u)) * 8u;
+            if constexpr (WF == W_I4) asm volatile("buffer_load_dwordx2 %0, %1, %2, 0 offen" : "=v"(wraw) : "v"(vo), "s"(qrs) : "memory");
+            else asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(wraw) : "v"(vo), "s"(qrs) : "memory");
+            asm volatile("buffer_load_ushort %0, %1, %2, 0 offen" : "=v"(sraw) : "v"(so), "s"(srs) : "memory");
+        };
+        auto write_wq = [&](uint32_t u, uint32_t r) { // wraw / sraw -> the W slot of tile u, rows 64 (r & 1) .. of half r >> 1
+            const float sc = __uint_as_float(sraw << 16);
+            uint32_t o[8];
+            if constexpr (WF == W_I4) {
+                const float c8 = -8.0f * sc;
+                const uint32_t v[2] = {wraw.x, wraw.y};
+#pragma unroll
+                for (int d = 0; d < 2; d++) {
+                    // nibble p of a dword = weight {0,2,4,6,1,3,5,7}[p] of its 8-run: byte b of lo / hi = nibble 2 b / 2 b + 1
+                    const uint32_t lo = v[d] & 0x0F0F0F0Fu, hi = (v[d] >> 4) & 0x0F0F0F0Fu;
+                    o[4 * d + 0] = pack_bf16x2(__builtin_fmaf(ubyte_f32<0>(lo), sc, c8), __builtin_fmaf(ubyte_f32<2>(lo), sc, c8));
+                    o[4 * d + 1] = pack_bf16x2(__builtin_fmaf(ubyte_f32<0>(hi), sc, c8), __builtin_fmaf(ubyte_f32<2>(hi), sc, c8));
+                    o[4 * d + 2] = pack_bf16x2(__builtin_fmaf(ubyte_f32<1>(lo), sc, c8), __builtin_fmaf(ubyte_f32<3>(lo), sc, c8));
+                    o[4 * d + 3] = pack_bf16x2(__builtin_fmaf(ubyte_f32<1>(hi), sc, c8), __builtin_fmaf(ubyte_f32<3>(hi), sc, c8));
+                }
+            } else {
+                // a byte b = q as int8: b ^ 0x80 = q + 128 as an unsigned byte, (q + 128) s - 128 s = q s exactly (<= 16 significant bits)
+                const float c128 = -128.0f * sc;
+                const uint32_t v[4] = {wraw.x ^ 0x80808080u, wraw.y ^ 0x80808080u, wraw.z ^ 0x80808080u, wraw.w ^ 0x80808080u};
+#pragma unroll
+                for (int d = 0; d < 4; d++) {
+                    o[2 * d + 0] = pack_bf16x2(__builtin_fmaf(ubyte_f32<0>(v[d]), sc, c128), __builtin_fmaf(ubyte_f32<1>(v[d]), sc, c128));
+                    o[2 * d + 1] = pack_bf16x2(__builtin_fmaf(ubyte_f32<2>(v[d]), sc, c128), __builtin_fmaf(ubyte_f32<3>(v[d]), sc, c128));
+                }
+            }
+            lds_char* dst = lds + ((4u * u + 1u + (r >> 1)) % 8u) * HALF_BYTES + (r & 1u) * 8192u + ww0;
+            *(__attribute__((address_space(3))) u32x4*)dst = u32x4{o[0], o[1], o[2], o[3]};
+            *(__attribute__((address_space(3))) u32x4*)((lds_char*)((uint32_t)(uintptr_t)dst ^ 16u)) = u32x4{o[4], o[5], o[6], o[7]};
+        };
+        if (T != 0) {
+            // ---- prologue: X of tile 0 (every wave its share of the four quarters: both groups issue the same instructions), W of
+            // tile 0 (group 0: quarters 0 and 2, group 1: 1 and 3), then what phases -1 and -2 / -1 of the table would have requested
+#pragma unroll
+            for (uint32_t j = 0; j < 4; j++) stage_xq(0u, j);
+            load_wq(0u, grp);
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(wraw), "+v"(sraw)::"memory");
+            write_wq(0u, grp);
+            load_wq(0u, 2u + grp);
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(wraw), "+v"(sraw)::"memory");
+            write_wq(0u, 2u + grp);
+            stage_xq(1u, 0u);
+            load_wq(1u, grp);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            if (grp != 0) __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            auto read_step = [&](uint32_t t, uint32_t ks) {
+                const uint32_t p = 4u * t + 2u * ks + grp;
+                read_frags(t, ks);
+                stage_xq((p + 5u) >> 2, (p + 5u) & 3u);
+                asm volatile("s_waitcnt vmcnt(2)" : "+v"(wraw), "+v"(sraw)::"memory"); // the previous reading phase's requests landed
+                write_wq((p >> 2) + 1u, p & 3u);
+                __builtin_amdgcn_sched_barrier(0); // (the registers are read before the next load is issued into them)
+                load_wq(((p + 2u) >> 2) + 1u, (p + 2u) & 3u);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            for (uint32_t t = 0; t < T; t++) {
+                read_step(t, 0);
+                multiply();
+                end_mul();
+                read_step(t, 1);
+                multiply();
+                end_mul();
+            }
+            if (grp == 0) __builtin_amdgcn_s_barrier();
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(wraw), "+v"(sraw)::"memory");
+        }
+    } else
     if (T != 0) {
-        // ---- prologue: tile 0 whole and X lo of tile 1, every wave its quarter of each half tile (both groups issue the same
-        // instructions here: the same bytes twice, once per launch)
-        stage(0, 2, 0);
-        stage(0, 3, 0);
-        stage(0, 0, 0);
-        stage(0, 1, 0);
-        stage(1, 0, 1);
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); // tile 0 landed (this wave's share), X lo of tile 1 in flight
+        // ---- prologue: tile 0 and the first LEAD events of tile 1, every wave its quarter of each half tile (both groups issue the
+        // same instructions here: the same bytes twice, once per launch)
+#pragma unroll
+        for (uint32_t e = 0; e < 4u + LEAD; e++) stage(e);
+        if constexpr (D == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); // tile 0 landed (this wave's share)
+        else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         // ONE instruction stream for both groups; group 1 runs it one barrier -- one phase -- behind group 0 (and group 0 passes one
-        // more barrier at the end), so that wherever group 0 multiplies group 1 reads and stages, and the other way round.  What a
-        // wave stages in its two reading phases of tile t is the table's column for ITS group.
+        // more barrier at the end), so that wherever group 0 multiplies group 1 reads and stages, and the other way round: the
+        // stream's reading step (t, ks) is phase 4 t + 2 ks for group 0 and 4 t + 2 ks + 1 for group 1.
         if (grp != 0) __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         for (uint32_t t = 0; t < T; t++) {
-            const uint32_t img = t & 1u, nimg = img ^ 1u;
-            read_frags(img, 0);
-            stage(nimg, 2u + grp, t + 1);                      // group 0: W lo, group 1: W hi of tile t + 1
+            read_frags(t, 0);
+            if (DIAG != 1) stage(4u + LEAD + 4u * t + grp);
             end_read();
             multiply();
             end_mul();
-            read_frags(img, 1);
-            stage(grp ? img : nimg, grp ? 0u : 1u, t + 1 + grp); // group 0: X hi of tile t + 1, group 1: X lo of tile t + 2
+            read_frags(t, 1);
+            if (DIAG != 1) stage(4u + LEAD + 4u * t + 2u + grp);
             end_read();
             multiply();
             end_mul();

@@ -139,6 +139,7 @@ def capi() -> C.CDLL:
                                        C.POINTER(i32)]),
         "mc_decoder_gemv_kernel_name": (i32, [vp, C.c_char_p, C.c_char_p, sz]),
         "mc_decoder_handoff_fallbacks": (i32, [vp]),
+        "mc_decoder_derived_weight_bytes": (C.c_size_t, [vp]),
         "mc_decoder_launch_log": (i32, [vp, i32]),
         "mc_decoder_launch_log_read": (sz, [vp, C.c_char_p, sz]),
         "mc_decoder_weight_ptrs": (i32, [vp, i32, C.c_char_p, pvp, pvp, C.POINTER(i32),
@@ -715,6 +716,10 @@ class Decoder:
         buf = C.create_string_buffer(256)
         _check(capi().mc_decoder_gemv_kernel_name(self._h, which.encode(), buf, 256))
         return buf.value.decode()
+
+    def derived_weight_bytes(self) -> int:
+        """HBM held by derived copies of the weights (mc_decoder_derived_weight_bytes)."""
+        return int(capi().mc_decoder_derived_weight_bytes(self._h))
 
     def handoff_fallbacks(self) -> int:
         """how often an in-launch hand-off gave up and the decoder fell back to launches that need no co-residency"""
