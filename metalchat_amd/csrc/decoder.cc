@@ -242,7 +242,9 @@ struct mc_decoder {
     const void* pending_pn = nullptr; // gemma3: postnorm_args the next pre-norm GEMV has to apply to `proj`
     uint64_t weights_gen = 1;  // bumped whenever weight rows change: the derived copies (linear_w::wq2) are rebuilt
     bool pf2_on = true;        // MC_PF2: short prompts from the quad-interleaved copy
-    bool pf_lib_on = true;     // MC_PF_BLASLT: long prompts' large GEMMs in hipBLASLt on a dequantised bfloat16 copy of the matrix (gemm_lib)
+    bool pf_g8_on = true;      // MC_PF_GEMM8: prompts of pf_g8_rows rows and more take the 256 x 256 ping-pong GEMM (kernels/pf_gemm8.h)
+    int pf_g8_rows = 384;      // MC_PF_GEMM8_ROWS (measured round 5: 256 rows 7.42 ms with, 7.06 without -- one row of tiles leaves half the chip idle; 512 rows 10.13 against 11.66)
+    bool pf_lib_on = false;    // MC_PF_BLASLT=1 (opt-in since round 5, a comparison aid): long prompts' large GEMMs in hipBLASLt on a dequantised bfloat16 copy of the matrix (gemm_lib)
     bool pf_lib_force = false;
     bool pf_lib_tune = false;  // MC_PF_BLASLT_TUNE=1: the fastest of the heuristic's first eight algorithms, timed once per shape, instead of its first
                                // (measured: inside the noise -- 512 rows 10.13 / 9.91 ms without, 10.04 / 10.00 with; 2048 rows 32.92 / 33.52, 32.55 / 32.92 --
@@ -1363,6 +1365,34 @@ struct mc_decoder {
                       pack((const void*)pf_part, Y, epi == 1 ? res : (const void*)nullptr, (uint32_t)M, (uint32_t)L.out, splits, la,
                            (const void*)L.lora_b, (uint32_t)L.lora_cols, L.lora_scale));
     }
+    // ---- the 256 x 256 ping-pong GEMM (round 5, kernels/pf_gemm8.h): bfloat16 rows, no adaptor, K in whole tiles of 64, scale groups
+    // of whole 16-runs; from pf_g8_rows rows on (below that the 128-row tiles keep more workgroups busy)
+    bool
+    g8_ok(const linear_w& L, int M) const
+    {
+        if (!pf_g8_on || tb != 2 || L.lora_cols || M < pf_g8_rows || getenv("MC_PF_SMALL_GEMM")) return false;
+        if (L.in % 64 != 0 || L.out % 4 != 0) return false;
+        if (L.fmt != MC_WFMT_T && L.group && (L.group < 32 || (L.group & (L.group - 1)) != 0)) return false;
+        if ((size_t)L.out * L.in * 2 > 0xFFFFFFFFull || (size_t)M * L.in * 2 > 0xFFFFFFFFull) return false; // (32-bit buffer offsets)
+        return true;
+    }
+    // K ranges of a launch: one round of workgroups on the chip at most, eight K tiles per range at least
+    unsigned
+    g8_splits(const linear_w& L, int M) const
+    {
+        const unsigned tiles = ((L.out + 255) / 256) * ((M + 255) / 256), cus = (unsigned)dev->prop.multiProcessorCount;
+        unsigned splits = 1;
+        while (splits < 16 && tiles * splits * 2 <= cus && (unsigned)L.in / 64u / (splits * 2) >= 8u) splits *= 2;
+        return getenv("MC_PF_NO_SPLITK") ? 1u : splits;
+    }
+    mc_status
+    g8_launch(const linear_w& L, int epi, const void* X, void* Y, const void* res, int M, unsigned splits)
+    {
+        const std::string f = L.fmt == MC_WFMT_I4 ? "i4" : (L.fmt == MC_WFMT_I8 ? "i8" : "w");
+        return launch("mc_pf_gemm8_" + f + "_bfloat_e" + std::to_string(epi), (L.out + 255) / 256, (M + 255) / 256, splits, 512, 0,
+                      pack(L.w, L.scales, X, Y, res, (uint32_t)M, (uint32_t)L.out, (uint32_t)L.in, (uint32_t)L.group, (const void*)nullptr,
+                           (const void*)nullptr, (uint32_t)0, 0.0f));
+    }
     // ---- the library GEMM of long prompts
     // Measured on MI355X (tools/blaslt_probe.py, profiles/r04_blaslt_probe.log; WBITS=16 tools/prefill_bench.py): the hand-written
     // tiled GEMM reaches 600-725 TFLOP/s with AND without its dequantisation (plain bfloat weights: 180 us for w1|w3 at 512 rows
@@ -1513,10 +1543,10 @@ struct mc_decoder {
                 return true;
             }
         }
-        const bool small = pf2_ok(L, M);
+        const bool small = pf2_ok(L, M), g8 = !small && g8_ok(L, M);
         unsigned splits = 1, ktper = 0;
         if (small) pf2_split(L, splits, ktper);
-        else splits = gemm_splits(L, M);
+        else splits = g8 ? g8_splits(L, M) : gemm_splits(L, M);
         if (splits < 2) return false;
         const size_t need = (size_t)splits * M * L.out;
         if (need > pf_part_elems) {
@@ -1531,6 +1561,10 @@ struct mc_decoder {
             pf_part_elems = need;
         }
         *splits_out = splits;
+        if (g8) {
+            *st = g8_launch(L, 2, X, pf_part, nullptr, M, splits);
+            return true;
+        }
         if (small) {
             *st = ensure_pf2(L);
             if (*st != MC_OK) return true;
@@ -1567,6 +1601,23 @@ struct mc_decoder {
         // weight stream, and the unpipelined 64 x 64 tile (kept for T = float, the parity path) needed
         // 32-42 ms for 8-64 rows where this one needs 5
         if (epi == 0 && lib_ok(L, M) && gemm_lib(L, X, Y, M, false)) return MC_OK;
+        if (g8_ok(L, M) && !(pf2_ok(L, M) && epi != 2)) {
+            const unsigned splits = epi == 3 ? 1u : g8_splits(L, M);
+            if (splits == 1) return g8_launch(L, epi, X, Y, res, M, 1);
+            const size_t need = (size_t)splits * M * L.out;
+            if (need > pf_part_elems) {
+                MC_HIP(hipStreamSynchronize(stream));
+                release((void**)&pf_part);
+                mc_status s = alloc((void**)&pf_part, need * 4, false);
+                if (s != MC_OK) return s;
+                pf_part_elems = need;
+            }
+            mc_status s = g8_launch(L, 2, X, pf_part, nullptr, M, splits);
+            if (s != MC_OK) return s;
+            return launch("mc_pf_splitk_reduce_" + tname, (L.out + 255) / 256, M, 1, 256, 0,
+                          pack((const void*)pf_part, Y, epi == 1 ? res : (const void*)nullptr, (uint32_t)M, (uint32_t)L.out, splits, (const void*)nullptr,
+                               (const void*)nullptr, (uint32_t)0, 0.0f));
+        }
         const bool big = tb == 2 && !getenv("MC_PF_SMALL_GEMM");
         const std::string f = L.fmt == MC_WFMT_I4 ? "i4_" : (L.fmt == MC_WFMT_I8 ? "i8_" : "w_");
         const void* la = L.lora_cols ? pf_lora : nullptr;
@@ -1737,8 +1788,9 @@ struct mc_decoder {
             // table of exponentials rides in `res`).  MC_PF_ACT_EPI=0: the separate launch
             const bool act_epi_on = !(getenv("MC_PF_ACT_EPI") && atoi(getenv("MC_PF_ACT_EPI")) == 0);
             const bool act_epi = act_epi_on && tb == 2 && !gemma && !L.w13.lora_cols && !getenv("MC_PF_SMALL_GEMM") && !pf2_ok(L.w13, M) &&
-                                 gemm_row_tile(M) == 256 && gemm_splits(L.w13, M) == 1 && !(getenv("MC_PF_DEPTH") && atoi(getenv("MC_PF_DEPTH")) == 1) &&
-                                 !lib_ok(L.w13, M); // (the library GEMM + the separate activation launch: 94 + 12 us against 166 at 512 rows)
+                                 (g8_ok(L.w13, M) ? g8_splits(L.w13, M) == 1 && cfg.ffn_dim % 2 == 0
+                                                  : gemm_row_tile(M) == 256 && gemm_splits(L.w13, M) == 1 && !(getenv("MC_PF_DEPTH") && atoi(getenv("MC_PF_DEPTH")) == 1)) &&
+                                 !lib_ok(L.w13, M); // (the opt-in library GEMM + the separate activation launch)
             if (act_epi) {
                 s = timed("gemm_w13_act", [&] { return gemm(L.w13, 3, pf_xn, pf_g, pf_etab, M); });
             } else if (cfg.ffn_dim % 4 == 0 && !lib_ok(L.w13, M) && gemm_to_parts(L.w13, pf_xn, M, &sp, &gs)) { // (library: bfloat16 rows out, half the bytes of fp32 partials)
@@ -1859,6 +1911,8 @@ mc_decoder_create(mc_device* dev, mc_library* lib, mc_queue* q, const mc_decoder
     if (const char* e = getenv("MC_ATTN_QKN")) d->attn_qkn_on = atoi(e) != 0;
     if (const char* e = getenv("MC_LAZY_PICK")) d->lazy_pick_on = atoi(e) != 0;
     if (const char* e = getenv("MC_PF2")) d->pf2_on = atoi(e) != 0;
+    if (const char* e = getenv("MC_PF_GEMM8")) d->pf_g8_on = atoi(e) != 0;
+    if (const char* e = getenv("MC_PF_GEMM8_ROWS")) d->pf_g8_rows = std::max(1, atoi(e));
     if (const char* e = getenv("MC_PF_BLASLT")) {
         d->pf_lib_on = atoi(e) != 0;
         d->pf_lib_force = atoi(e) == 2;

@@ -59,6 +59,9 @@ constexpr uint32_t HALF_BYTES = 128 * BK * 2;     // 16 KiB: 128 rows of 128 byt
 constexpr uint32_t IMG_BYTES = 4 * HALF_BYTES;    // X lo, X hi, W lo, W hi
 constexpr uint32_t LDS_BYTES = 2 * IMG_BYTES;     // 128 KiB
 
+#ifndef MC_G8_INTERLEAVE
+#define MC_G8_INTERLEAVE 1 // the multiplying phase of the quantised loop: MFMAs and the dequantisation's vector instructions interleaved by sched_group_barrier
+#endif
 enum { W_T = 0, W_I8 = 1, W_I4 = 2 };
 enum { E_STORE = 0, E_RES = 1, E_PART = 2, E_ACT = 3 };
 
@@ -178,7 +181,7 @@ body(const args& a, ActFn&& act)
     for (int i = 0; i < 8; i++)
 #pragma unroll
         for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    auto multiply = [&] {
+    auto multiply = [&](bool prio = true) {
         if constexpr (DIAG == 2) {
 #pragma unroll
             for (int i = 0; i < 8; i++) asm volatile("" ::"v"(xf[i]));
@@ -186,13 +189,13 @@ body(const args& a, ActFn&& act)
             for (int j = 0; j < 4; j++) asm volatile("" ::"v"(wf[j]));
             return;
         }
-        __builtin_amdgcn_s_setprio(1);
+        if (prio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int i = 0; i < 8; i++)
 #pragma unroll
             for (int j = 0; j < 4; j++)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[j]), __builtin_bit_cast(bf16x8, xf[i]), acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
+        if (prio) __builtin_amdgcn_s_setprio(0);
     };
     // end of a phase in which this wave read and staged: its fragment reads done (the slot may be overwritten a phase later), all
     // but its youngest 1 + D / 2 half tiles landed
@@ -224,11 +227,13 @@ body(const args& a, ActFn&& act)
         const u32x4 qrs = rsrc_of(a.w, (size_t)N * K2), srs = rsrc_of(a.scales, (size_t)((N + 3u) / 4u) * ngroups * 8u);
         const uint32_t wrow16 = wq * 16u + (lane >> 2);                    // the lane's row inside a W quarter
         const uint32_t qv0 = (n0 + wrow16) * K2 + (lane & 3u) * RUNB;      // + (64 r) K2 + k0 bytes
-        const uint32_t sv0 = (((n0 >> 2) + 4u * wq + (lane >> 4)) * ngroups * 4u + ((lane >> 2) & 3u)) * 2u; // + (16 r ngroups + g) 8
+        // (+ (16 r ngroups + g) 8 per quarter; g = group of the tile's first weight, the lane's 16-run may lie in a later one when group < 64)
+        const uint32_t sv0 = (((n0 >> 2) + 4u * wq + (lane >> 4)) * ngroups * 4u + ((lane >> 2) & 3u)) * 2u +
+                             (a.group ? (((lane & 3u) * 16u) >> glog) * 8u : 0u);
         const uint32_t ww0 = wrow16 * 128u + (((2u * (lane & 3u)) ^ ((lane >> 3) & 7u)) * 16u); // first chunk; the second: ^ 16
         typedef typename std::conditional<WF == W_I4, u32x2, u32x4>::type wraw_t;
-        wraw_t wraw;
-        uint32_t sraw;
+        wraw_t wA, wB;
+        uint32_t sA, sB;
         auto stage_xq = [&](uint32_t u, uint32_t j) { // X quarter j of tile u
             const uint32_t c = (j >> 1) ? 3u : 0u, qh = j & 1u;
             const uint32_t k0 = (tbeg + (u < T ? u : T - 1u)) * BK;
@@ -244,7 +249,8 @@ body(const args& a, ActFn&& act)
                              : "memory");
             }
         };
-        auto load_wq = [&](uint32_t u, uint32_t r) { // W quarter r of tile u into wraw / sraw (asm: counted by hand)
+        // W quarter wp % 4 of tile wp / 4 + 1 (the quarter that is WRITTEN in phase wp) into a register set (asm: counted by hand)
+        auto load_wq = [&](uint32_t u, uint32_t r, wraw_t& wraw, uint32_t& sraw) {
             const uint32_t k0 = (tbeg + (u < T ? u : T - 1u)) * BK;
             const uint32_t vo = qv0 + (64u * r) * K2 + (WF == W_I4 ? k0 / 2u : k0);
             const uint32_t so = sv0 + (16u * r * ngroups + (a.group ? k0 >> glog : 0u)) * 8u;
@@ -252,7 +258,7 @@ body(const args& a, ActFn&& act)
             else asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(wraw) : "v"(vo), "s"(qrs) : "memory");
             asm volatile("buffer_load_ushort %0, %1, %2, 0 offen" : "=v"(sraw) : "v"(so), "s"(srs) : "memory");
         };
-        auto write_wq = [&](uint32_t u, uint32_t r) { // wraw / sraw -> the W slot of tile u, rows 64 (r & 1) .. of half r >> 1
+        auto write_wq = [&](uint32_t u, uint32_t r, const wraw_t& wraw, uint32_t sraw) { // -> the W slot of tile u, rows 64 (r & 1) .. of half r >> 1
             const float sc = __uint_as_float(sraw << 16);
             uint32_t o[8];
             if constexpr (WF == W_I4) {
@@ -283,44 +289,69 @@ body(const args& a, ActFn&& act)
         };
         if (T != 0) {
             // ---- prologue: X of tile 0 (every wave its share of the four quarters: both groups issue the same instructions), W of
-            // tile 0 (group 0: quarters 0 and 2, group 1: 1 and 3), then what phases -1 and -2 / -1 of the table would have requested
+            // tile 0 (group 0: quarters 0 and 2, group 1: 1 and 3), the quarter of phase 0 -- in which nobody multiplies yet -- by group
+            // 1, then what phase -1 would have requested: an X quarter, and the W quarter this wave writes in its first multiplying phase
 #pragma unroll
             for (uint32_t j = 0; j < 4; j++) stage_xq(0u, j);
-            load_wq(0u, grp);
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(wraw), "+v"(sraw)::"memory");
-            write_wq(0u, grp);
-            load_wq(0u, 2u + grp);
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(wraw), "+v"(sraw)::"memory");
-            write_wq(0u, 2u + grp);
+            load_wq(0u, grp, wA, sA);
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(wA), "+v"(sA)::"memory");
+            write_wq(0u, grp, wA, sA);
+            __builtin_amdgcn_sched_barrier(0);
+            load_wq(0u, 2u + grp, wA, sA);
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(wA), "+v"(sA)::"memory");
+            write_wq(0u, 2u + grp, wA, sA);
+            __builtin_amdgcn_sched_barrier(0);
+            if (grp != 0) {
+                load_wq(1u, 0u, wA, sA);
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(wA), "+v"(sA)::"memory");
+                write_wq(1u, 0u, wA, sA);
+            }
+            __builtin_amdgcn_sched_barrier(0);
             stage_xq(1u, 0u);
-            load_wq(1u, grp);
+            load_wq(1u, 1u + grp, wB, sB);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
             if (grp != 0) __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
-            auto read_step = [&](uint32_t t, uint32_t ks) {
+            // a reading step of the stream: phase p.  `ld`: the register set loaded here (for the quarter written in phase p + 3),
+            // `keep`: the other one, loaded in the wave's previous reading phase and consumed in the multiplying phase that follows
+            auto read_step = [&](uint32_t t, uint32_t ks, wraw_t& wld, uint32_t& sld, wraw_t& wkeep, uint32_t& skeep) {
                 const uint32_t p = 4u * t + 2u * ks + grp;
                 read_frags(t, ks);
                 stage_xq((p + 5u) >> 2, (p + 5u) & 3u);
-                asm volatile("s_waitcnt vmcnt(2)" : "+v"(wraw), "+v"(sraw)::"memory"); // the previous reading phase's requests landed
-                write_wq((p >> 2) + 1u, p & 3u);
-                __builtin_amdgcn_sched_barrier(0); // (the registers are read before the next load is issued into them)
-                load_wq(((p + 2u) >> 2) + 1u, (p + 2u) & 3u);
+                load_wq(((p + 3u) >> 2) + 1u, (p + 3u) & 3u, wld, sld);
+                asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" : "+v"(wkeep), "+v"(skeep)::"memory"); // the previous reading phase's requests landed
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            // a multiplying step: phase p + 1 behind reading step p; the W quarter of this phase from `w`, `sc`
+            auto mul_step = [&](uint32_t t, uint32_t ks, const wraw_t& w, uint32_t sc) {
+                const uint32_t p = 4u * t + 2u * ks + grp + 1u;
+                __builtin_amdgcn_s_setprio(1);
+                write_wq((p >> 2) + 1u, p & 3u, w, sc);
+                multiply(false); // (s_setprio is a scheduling fence: with it around the MFMAs alone they stay behind all the vector work)
+#if MC_G8_INTERLEAVE
+                // one MFMA, then two of the dequantisation's vector instructions, ...
+#pragma unroll
+                for (int i = 0; i < 32; i++) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                }
+#endif
+                __builtin_amdgcn_s_setprio(0);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
             };
             for (uint32_t t = 0; t < T; t++) {
-                read_step(t, 0);
-                multiply();
-                end_mul();
-                read_step(t, 1);
-                multiply();
-                end_mul();
+                read_step(t, 0, wA, sA, wB, sB);
+                mul_step(t, 0, wB, sB);
+                read_step(t, 1, wB, sB, wA, sA);
+                mul_step(t, 1, wA, sA);
             }
             if (grp == 0) __builtin_amdgcn_s_barrier();
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(wraw), "+v"(sraw)::"memory");
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(wA), "+v"(sA), "+v"(wB), "+v"(sB)::"memory");
         }
     } else
     if (T != 0) {

@@ -786,6 +786,29 @@ MC_PF_GEMM_BIG_D(mc_pf_gemm128_w_bfloat_d2_e0, PF_W_T, 0, 2)
 MC_PF_GEMM_BIG_D(mc_pf_gemm128_w_bfloat_d2_e1, PF_W_T, 1, 2)
 MC_PF_GEMM_BIG_D(mc_pf_gemm128_w_bfloat_d2_e2, PF_W_T, 2, 2)
 
+// ------------------------------------------------------------------------------------------ GEMM, prompts of 256 rows and more (round 5)
+// pf_gemm8.h: 256 x 256 tiles, two wave groups alternating between the LDS and the matrix pipe, LDS-DMA staging, quantised W
+// dequantised in the loop.  mc_pf_gemm8_{i4,i8,w}_bfloat_e{0: store, 1: + residual, 2: fp32 partial sums of a K range (split-K),
+// 3: silu(w1 x) * (w3 x) of the fused w1|w3 matrix}; the argument list of the mc_pf_gemm256_* kernels.
+#include "pf_gemm8.h"
+#define MC_PF_GEMM8(NAME, WF, EPI)                                                                                            \
+    extern "C" __global__ void __launch_bounds__(512)                                                                         \
+    NAME(const void* w, const void* scales, const bf16_t* X, bf16_t* Y, const bf16_t* res, uint32_t M, uint32_t N, uint32_t K, \
+         uint32_t group, const bf16_t* la, const bf16_t* lb, uint32_t lora_rank, float lora_scale)                            \
+    {                                                                                                                         \
+        const g8::args a{w, scales, X, Y, res, M, N, K, group};                                                               \
+        const float* etab = reinterpret_cast<const float*>(res);                                                              \
+        g8::body<WF, EPI>(a, [etab](float x, float y) { return pf_silu_T<BF>(x, etab) * y; });                                \
+    }
+#define MC_PF_GEMM8_SET(F, WF)                          \
+    MC_PF_GEMM8(mc_pf_gemm8_##F##_bfloat_e0, WF, g8::E_STORE) \
+    MC_PF_GEMM8(mc_pf_gemm8_##F##_bfloat_e1, WF, g8::E_RES)   \
+    MC_PF_GEMM8(mc_pf_gemm8_##F##_bfloat_e2, WF, g8::E_PART)  \
+    MC_PF_GEMM8(mc_pf_gemm8_##F##_bfloat_e3, WF, g8::E_ACT)
+MC_PF_GEMM8_SET(i4, g8::W_I4)
+MC_PF_GEMM8_SET(i8, g8::W_I8)
+MC_PF_GEMM8_SET(w, g8::W_T)
+
 // ------------------------------------------------------------------------------------------ a dequantised copy of a matrix
 // Wd[row][k] = T(T(q) * T(s)) (kernel/mul.metal:78-82) as plain bfloat16 rows [N][K] -- bit for bit the values pf_gemm_body's W tile
 // holds -- built once per matrix (decoder.cc ensure_wd): the operand LONG prompts multiply by in a library GEMM (hipBLASLt;

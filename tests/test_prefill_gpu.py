@@ -485,8 +485,45 @@ def test_two_head_prompt_attention_sliding_window_and_second_chunk(acc, monkeypa
     check_against_oracle(acc, cfg, weights, dict(weight_format=2, group_size=32), tokens, start_pos=21, warm=warm, expect_kernel="mc_pf_attn2_bfloat_hd32")
 
 
+# ---- the 256 x 256 ping-pong GEMM of long prompts (kernels/pf_gemm8.h, decoder.cc g8_ok: from 384 rows on; MC_PF_GEMM8_ROWS lowers the
+# gate so that shorter prompts of the models the oracle can follow reach it too).  Kernel-level parity: tests/test_gemm8_gpu.py.
+@pytest.mark.parametrize("quant,fmt,group", [("i4", 2, 32), ("i4", 2, 128), ("i8", 1, 32), (None, 0, 0)])
+@pytest.mark.parametrize("n,gate", [(400, None), (300, "192"), (257, "192")])
+def test_long_prompts_take_the_ping_pong_gemm_and_match_the_oracle(acc, n, gate, quant, fmt, group, monkeypatch):
+    """Every linear of the block through mc_pf_gemm8_*: wq|wk|wv / wo / w2 with a plain store or residual (these models are too
+    narrow to split K), w1|w3 with silu * mul in its epilogue; no copy of the weights is built (mc_decoder_derived_weight_bytes
+    stays 0) and the library is never called."""
+    import metalchat_amd as mc
+
+    if gate:
+        monkeypatch.setenv("MC_PF_GEMM8_ROWS", gate)
+    cfg = mg.tiny_cfg(BF16, dim=256, n_heads=4, n_kv_heads=2, head_dim=64, ffn_dim=768, n_layers=2, vocab=384, max_seq_len=448)
+    weights = mg.make_model(cfg, seed=101, quant=quant, group=group or 32)
+    tokens = np.random.default_rng(n + fmt).integers(0, cfg["vocab"], n).tolist()
+    f = {2: "i4", 1: "i8", 0: "w"}[fmt]
+    check_against_oracle(acc, cfg, weights, dict(weight_format=fmt, group_size=group), tokens, follow=2, expect_kernel=f"mc_pf_gemm8_{f}_bfloat_e3")
+    dec = mc.Decoder(acc, **mg.decoder_kwargs(cfg, weight_format=fmt, group_size=group))
+    dec.load_model(weights)
+    dec.launch_log(True)
+    dec.prefill(tokens, 0)
+    names = dec.launched()
+    assert not [x for x in names if x.startswith("mc_pf_gemm") and not x.startswith("mc_pf_gemm8_")], sorted(set(names))
+    assert "hipblasLtMatmul" not in names and not [x for x in names if x.startswith("mc_pf_dequant_rows")]
+    assert dec.derived_weight_bytes() == 0
+    dec.release()
+
+
+def test_wide_long_prompt_splits_k_in_the_ping_pong_gemm(acc):
+    """K = 2048 with two column tiles: the 256 x 256 GEMM splits K (mc_pf_gemm8_*_e2) and the consumers add the fp32 partial sums"""
+    cfg = mg.tiny_cfg(BF16, dim=2048, n_heads=4, n_kv_heads=1, head_dim=128, ffn_dim=512, n_layers=1, vocab=256, max_seq_len=400)
+    weights = mg.make_model(cfg, seed=102, quant="i4", group=128)
+    tokens = np.random.default_rng(3).integers(0, cfg["vocab"], 390).tolist()
+    check_against_oracle(acc, cfg, weights, dict(weight_format=2, group_size=128), tokens, follow=1, expect_kernel="mc_pf_gemm8_i4_bfloat_e2")
+
+
 # ---- the library GEMM of long prompts (decoder.cc gemm_lib: hipBLASLt on the dequantised bfloat16 copy of a matrix).  The decoder
-# takes it where a launch has >= 48 tiles of 256 x 256 (w1|w3 of Llama-3-8B from 256 rows on, every matrix from 768); MC_PF_BLASLT=2 takes it for every
+# takes it -- ONLY when asked to, MC_PF_BLASLT=1: an opt-in comparison since round 5, the default path builds no dequantised copy --
+# where a launch has >= 48 tiles of 256 x 256 (w1|w3 of Llama-3-8B from 256 rows on, every matrix from 768); MC_PF_BLASLT=2 takes it for every
 # prompt GEMM that can, which is how the models the oracle can follow reach it.
 @pytest.mark.parametrize("quant,fmt,group", [("i4", 2, 32), ("i4", 2, 128), ("i8", 1, 32), (None, 0, 0)])
 @pytest.mark.parametrize("n", [21, 300])
