@@ -242,6 +242,7 @@ struct mc_decoder {
     const void* pending_pn = nullptr; // gemma3: postnorm_args the next pre-norm GEMV has to apply to `proj`
     uint64_t weights_gen = 1;  // bumped whenever weight rows change: the derived copies (linear_w::wq2) are rebuilt
     bool pf2_on = true;        // MC_PF2: short prompts from the quad-interleaved copy
+    bool kv_virtual_on = true; // MC_KV_VIRTUAL: fewer than 8 kv heads launched as 8 virtual ones where wq|wk|wv is inside the attention launch (kv_virtual_shift)
     bool pf_g8_on = true;      // MC_PF_GEMM8: prompts of pf_g8_rows rows and more take the 256 x 256 ping-pong GEMM (kernels/pf_gemm8.h)
     int pf_g8_rows = 384;      // MC_PF_GEMM8_ROWS (measured round 5: 256 rows 7.42 ms with, 7.06 without -- one row of tiles leaves half the chip idle; 512 rows 10.13 against 11.66)
     bool pf_lib_on = false;    // MC_PF_BLASLT=1 (opt-in since round 5, a comparison aid): long prompts' large GEMMs in hipBLASLt on a dequantised bfloat16 copy of the matrix (gemm_lib)
@@ -745,6 +746,16 @@ struct mc_decoder {
                L.qkv.out == (cfg.n_heads + 2 * cfg.n_kv_heads) * hd && pg >= 64 && pg <= 512;
     }
 
+    // VIRTUAL kv heads of the launches with wq|wk|wv inside (decode_kernels.hip attn_fused_bf, kv_shift): a model with 1, 2 or 4 kv heads is
+    // launched as 8 heads of n_rep / (8 / KV) query heads each, 8 / KV of them on one cache head -- a workgroup on every CU, a virtual
+    // head's ranges on one XCD.  Returns log2 of the heads per cache head (0: the real heads).
+    int
+    kv_virtual_shift() const
+    {
+        const int KV = cfg.n_kv_heads, n_rep = cfg.n_heads / KV;
+        if (!kv_virtual_on || KV >= 8 || 8 % KV != 0 || n_rep % (8 / KV) != 0) return 0;
+        return KV == 4 ? 1 : (KV == 2 ? 2 : 3);
+    }
     // ... the same launch for PLAIN bfloat weights (mc_attn_qkv_wo_w_bfloat_hd64_k4_q4: Llama-3.2-1B, the reference's default model):
     // rows of 4 KiB (K = 2048), at most ONE row pair per wave in either GEMV phase
     bool
@@ -752,8 +763,9 @@ struct mc_decoder {
     {
         if (!attn_qkv_on || !attn_wo_on || !attn_qkv_g || !attn_fused() || tb != 2 || cfg.family == MC_FAMILY_GEMMA3) return false;
         if (L.qkv.fmt != MC_WFMT_T || L.wo.fmt != MC_WFMT_T || L.qkv.lora_cols || L.wo.lora_cols || occ_wo_w == 0) return false;
-        const int hd = cfg.head_dim, n_rep = cfg.n_heads / cfg.n_kv_heads, pg = (n_rep + 2) * hd / 2;
-        const unsigned grid = (unsigned)(nsplit * cfg.n_kv_heads);
+        const int sh = kv_virtual_shift();
+        const int hd = cfg.head_dim, n_rep = (cfg.n_heads / cfg.n_kv_heads) >> sh, pg = (n_rep + 2) * hd / 2;
+        const unsigned grid = (unsigned)(nsplit * (cfg.n_kv_heads << sh));
         return hd == 64 && L.wo.in == 2048 && L.qkv.in == 2048 && L.wo.in == cfg.n_heads * hd && L.wo.out % 2 == 0 &&
                L.qkv.out == (cfg.n_heads + 2 * cfg.n_kv_heads) * hd && grid <= (unsigned)dev->prop.multiProcessorCount &&
                pg % nsplit == 0 && pg / nsplit <= 8 && n_rep <= 16 && pg >= 64 && pg <= 512 && (unsigned)L.wo.out / 2 <= 8u * grid;
@@ -985,16 +997,19 @@ struct mc_decoder {
             if (qkv_in) {
                 // attention_norm, wq|wk|wv, rope, cache write, scores, softmax, P.V, wo + residual (transformer.h:130-133,
                 // attention.h:170-205) in ONE launch: every hand-off but the last stays inside one kv head
+                // (plain weights: fewer than 8 kv heads are launched as 8 virtual ones, kv_virtual_shift)
+                const int vsh = qkv_w_in ? kv_virtual_shift() : 0;
+                const bool vfast = vsh ? handoff_fast : handoff_fast_here();
                 s = launch(qkv_w_in ? std::string("mc_attn_qkv_wo_w_bfloat_hd64_k4_q4")
                                     : "mc_attn_qkv_wo_i4_" + tname + "_hd" + std::to_string(hd) + "_k" + std::to_string(L.wo.in / 2048) + "_q" +
                                           std::to_string(L.qkv.in / 2048),
-                           (unsigned)(nsplit * KV), 1, 1, 512, 0,
+                           (unsigned)(nsplit * (KV << vsh)), 1, 1, 512, 0,
                            pack((const void*)L.kc, (const void*)L.vt, attn_out, attn_psum_g, attn_slab_g, attn_row_g, attn_qkv_g, state,
-                                (uint32_t)n_rep, (uint32_t)KV, (uint32_t)cfg.max_seq_len, scale_T, (uint32_t)nsplit, (uint32_t)(li + 1),
+                                (uint32_t)(n_rep >> vsh), (uint32_t)(KV << vsh), (uint32_t)cfg.max_seq_len, scale_T, (uint32_t)nsplit, (uint32_t)(li + 1),
                                 (const void*)L.wo.w, (const void*)L.wo.scales, x, hidden, (uint32_t)L.wo.out, (uint32_t)L.wo.group,
                                 (const void*)L.attention_norm, (const void*)L.qkv.w, (const void*)L.qkv.scales,
                                 (const float*)rope_cos[L.rope_table], (const float*)rope_sin[L.rope_table], cfg.norm_eps, mu,
-                                (uint32_t)(handoff_fast_here() ? 1 : 0), (void*)nullptr));
+                                (uint32_t)(vfast ? 1 : 0), (void*)nullptr, (uint32_t)vsh));
                 if (s != MC_OK) return s;
             } else if (!gemma) {
                 // attention_norm + wq|wk|wv + rope + cache write in ONE launch
@@ -1911,6 +1926,7 @@ mc_decoder_create(mc_device* dev, mc_library* lib, mc_queue* q, const mc_decoder
     if (const char* e = getenv("MC_ATTN_QKN")) d->attn_qkn_on = atoi(e) != 0;
     if (const char* e = getenv("MC_LAZY_PICK")) d->lazy_pick_on = atoi(e) != 0;
     if (const char* e = getenv("MC_PF2")) d->pf2_on = atoi(e) != 0;
+    if (const char* e = getenv("MC_KV_VIRTUAL")) d->kv_virtual_on = atoi(e) != 0;
     if (const char* e = getenv("MC_PF_GEMM8")) d->pf_g8_on = atoi(e) != 0;
     if (const char* e = getenv("MC_PF_GEMM8_ROWS")) d->pf_g8_rows = std::max(1, atoi(e));
     if (const char* e = getenv("MC_PF_BLASLT")) {
@@ -1963,7 +1979,7 @@ mc_decoder_create(mc_device* dev, mc_library* lib, mc_queue* q, const mc_decoder
         A(d->attn_psum_g, (size_t)H * d->nsplit * 8 * 2);
         A(d->attn_slab_g, (size_t)H * hd * d->nsplit * 8 * 2);
         A(d->attn_row_g, (size_t)H * hd / 2 * 8);
-        A(d->attn_qkv_g, (size_t)(H + 2 * KV) * hd / 2 * 8 * 2);
+        A(d->attn_qkv_g, (size_t)(H + 2 * std::max(KV, 8)) * hd / 2 * 8 * 2); // (virtual kv heads: a K and a V row per virtual head)
     }
     A(d->taps, (size_t)(d->n_own + 1) * dim * tb);
     A(d->state, sizeof(step_state_h));

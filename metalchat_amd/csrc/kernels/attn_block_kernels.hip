@@ -70,6 +70,7 @@ struct qkv_in_launch {
     char* xs;     // the row in LDS (padded for the transposed reads: gemv.h Q_M4D)
     float* red;   // 16 floats of scratch
     uint32_t n_rep, KV, max_seq, nsplit, group, layer_tag, fastpath;
+    uint32_t kv_shift; // virtual kv heads (decode_kernels.hip attn_fused_bf): n_rep and KV are the VIRTUAL counts, cache head = kv >> kv_shift
     float eps, mu;
     unsigned long long* tl;
     // ---- what at_start() leaves for before_scores()
@@ -86,8 +87,8 @@ struct qkv_in_launch {
     // packed pair (gemv.h EPI_QKV_ROPE: q heads, k heads, v heads; rotation partners adjacent) of pair j of kv head `kv`
     __device__ __forceinline__ uint32_t pp_of(uint32_t kv, uint32_t j) const
     {
-        const uint32_t hq = n_rep * HALF, H = n_rep * KV;
-        return j < hq ? kv * hq + j : (j < hq + HALF ? H * HALF + kv * HALF + (j - hq) : (H + KV) * HALF + kv * HALF + (j - hq - HALF));
+        const uint32_t hq = n_rep * HALF, H = n_rep * KV, kvc = kv >> kv_shift, KVC = KV >> kv_shift; // (the K and V rows of the CACHE head)
+        return j < hq ? kv * hq + j : (j < hq + HALF ? H * HALF + kvc * HALF + (j - hq) : (H + KVC) * HALF + kvc * HALF + (j - hq - HALF));
     }
     // The deal of the workgroup's PW pairs over its eight waves.  Waves w and w + 4 share SIMD w, and a wave alone on its SIMD
     // multiplies at ~ 60 % of the rate two reach together (MFMA and VALU issue overlap only ACROSS waves), so
@@ -302,8 +303,8 @@ struct qkv_in_launch {
             if (j < hq + HALF) {
                 const float x1 = BF::rt(my_a), x2 = BF::rt(my_b);
                 const bf16_t o1 = BF::st(eo_c * x1 - eo_s * x2), o2 = BF::st(eo_s * x1 + eo_c * x2);
-                if (j >= hq) {
-                    gS_p dst = (gS_p)kc + ((size_t)kv * max_seq + slot) * HD;
+                if (j >= hq) { // (virtual heads of one cache head write the same bits to the same place)
+                    gS_p dst = (gS_p)kc + ((size_t)(kv >> kv_shift) * max_seq + slot) * HD;
                     dst[j - hq] = o1;
                     dst[j - hq + HALF] = o2;
                 }
@@ -311,8 +312,8 @@ struct qkv_in_launch {
             } else {
                 const uint32_t d = 2u * (j - hq - HALF);
                 const bf16_t va = BF::st(my_a), vb = BF::st(my_b);
-                ((gS_p)vt)[((size_t)kv * HD + d) * max_seq + slot] = va;
-                ((gS_p)vt)[((size_t)kv * HD + d + 1) * max_seq + slot] = vb;
+                ((gS_p)vt)[((size_t)(kv >> kv_shift) * HD + d) * max_seq + slot] = va;
+                ((gS_p)vt)[((size_t)(kv >> kv_shift) * HD + d + 1) * max_seq + slot] = vb;
                 g = (uint32_t)va | ((uint32_t)vb << 16);
             }
             unsigned long long* gp = qkv_g + (size_t)kv * PG + j;
@@ -361,7 +362,8 @@ attn_wo_body(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const 
              // QN != 0: the hidden row is `res`; its norm weight, the packed wq|wk|wv matrix and its scales, the rope tables, the
              // granules of hand-off Q
              const void* __restrict__ qnorm_w = nullptr, const void* __restrict__ qkv_w = nullptr, const void* __restrict__ qkv_s = nullptr,
-             const float* fcos = nullptr, const float* fsin = nullptr, unsigned long long* qkv_g = nullptr, float eps = 0.0f, float mu = 0.0f)
+             const float* fcos = nullptr, const float* fsin = nullptr, unsigned long long* qkv_g = nullptr, float eps = 0.0f, float mu = 0.0f,
+             uint32_t kv_shift = 0)
 {
     constexpr uint32_t K = WB ? 512u * LNCH : 2048u * LNCH;
     constexpr uint32_t CHUNK_LDS = 2048 * 2 / 16 * 17;  // a chunk of the row in LDS: 16 bytes of padding per 256 (gemv.h Q_M4D)
@@ -382,7 +384,7 @@ attn_wo_body(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const 
         qx.xp = res; qx.normp = qnorm_w; qx.qw = qkv_w; qx.qs = qkv_s; qx.fcos = fcos; qx.fsin = fsin;
         qx.kc = const_cast<bf16_t*>(kc); qx.vt = const_cast<bf16_t*>(vt); qx.qkv_g = qkv_g; qx.st = st; qx.xs = xs; qx.red = qred;
         qx.n_rep = n_rep; qx.KV = KV; qx.max_seq = max_seq; qx.nsplit = nsplit; qx.group = group; qx.layer_tag = layer_tag;
-        qx.fastpath = fastpath; qx.eps = eps; qx.mu = mu; qx.tl = tl;
+        qx.fastpath = fastpath; qx.eps = eps; qx.mu = mu; qx.tl = tl; qx.kv_shift = kv_shift;
         qx.at_start();
     }
 
@@ -460,7 +462,7 @@ attn_wo_body(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const 
     };
     constexpr int TL_STRIDE = QN ? 16 : 8, TL_BASE = QN ? 3 : 0;
     if constexpr (QN != 0) {
-        attn_fused_bf<HD, 1, 8>(q, kc, vt, psum_g, slab_g, st, n_rep, KV, max_seq, scale, nsplit, layer_tag, tl, publish, request_wo, fastpath, qx);
+        attn_fused_bf<HD, 1, 8>(q, kc, vt, psum_g, slab_g, st, n_rep, KV, max_seq, scale, nsplit, layer_tag, tl, publish, request_wo, fastpath, qx, kv_shift);
     } else {
         attn_fused_bf<HD, 1, 8>(q, kc, vt, psum_g, slab_g, st, n_rep, KV, max_seq, scale, nsplit, layer_tag, tl, publish, request_wo, fastpath);
     }
@@ -590,11 +592,11 @@ attn_wo_body(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const 
          unsigned long long* row_g, unsigned long long* qkv_g, step_state* st, uint32_t n_rep, uint32_t n_kv, uint32_t max_seq,         \
          float scale, uint32_t nsplit, uint32_t layer_tag, const void* wo_w, const void* wo_s, const bf16_t* x, bf16_t* y,              \
          uint32_t out_rows, uint32_t group, const void* qnorm_w, const void* qkv_w, const void* qkv_s, const float* fcos, const float* fsin, float eps,    \
-         float mu, uint32_t fastpath, unsigned long long* tl)                                                                            \
+         float mu, uint32_t fastpath, unsigned long long* tl, uint32_t kv_shift)                                                         \
     {                                                                                                                                    \
         attn_wo_body<HD, LNCH, QN>(nullptr, kc, vt, attn_out, psum_g, slab_g, row_g, st, n_rep, n_kv, max_seq, scale, nsplit, layer_tag, \
                                    wo_w, wo_s, x, y, out_rows, group, 1u, fastpath, tl, qnorm_w, qkv_w, qkv_s, fcos, fsin,               \
-                                   qkv_g, eps, mu);                                                                                      \
+                                   qkv_g, eps, mu, kv_shift);                                                                            \
     }
 // mc_attn_qkv_wo_i4_bfloat_hd{head_dim}_k{KiB per Wo row}_q{KiB per wq|wk|wv row}
 MC_ATTN_QKV_WO(mc_attn_qkv_wo_i4_bfloat_hd128_k2_q2, 128, 2, 2)  // Llama-3-8B: dim 4096, 32 heads x 128
@@ -605,11 +607,11 @@ MC_ATTN_QKV_WO(mc_attn_qkv_wo_i4_bfloat_hd128_k2_q2, 128, 2, 2)  // Llama-3-8B: 
          unsigned long long* row_g, unsigned long long* qkv_g, step_state* st, uint32_t n_rep, uint32_t n_kv, uint32_t max_seq,         \
          float scale, uint32_t nsplit, uint32_t layer_tag, const void* wo_w, const void* wo_s, const bf16_t* x, bf16_t* y,              \
          uint32_t out_rows, uint32_t group, const void* qnorm_w, const void* qkv_w, const void* qkv_s, const float* fcos, const float* fsin, float eps,    \
-         float mu, uint32_t fastpath, unsigned long long* tl)                                                                            \
+         float mu, uint32_t fastpath, unsigned long long* tl, uint32_t kv_shift)                                                         \
     {                                                                                                                                    \
         attn_wo_body<HD, LNCH, QN, 1>(nullptr, kc, vt, attn_out, psum_g, slab_g, row_g, st, n_rep, n_kv, max_seq, scale, nsplit, layer_tag, \
                                       wo_w, wo_s, x, y, out_rows, group, 1u, fastpath, tl, qnorm_w, qkv_w, qkv_s, fcos, fsin,            \
-                                      qkv_g, eps, mu);                                                                                   \
+                                      qkv_g, eps, mu, kv_shift);                                                                         \
     }
 MC_ATTN_QKV_WO_W(mc_attn_qkv_wo_w_bfloat_hd64_k4_q4, 64, 4, 4)  // Llama-3.2-1B: dim 2048, 32 heads x 64, bf16 weights
 

@@ -783,8 +783,13 @@ __device__ __forceinline__ void
 attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const bf16_t* __restrict__ vt,
               unsigned long long* psum_g, unsigned long long* slab_g, step_state* st, uint32_t n_rep, uint32_t KV, uint32_t max_seq,
               float scale, uint32_t nsplit, uint32_t layer_tag, unsigned long long* tl, OnChunk&& on_chunk, BehindScores&& behind_scores,
-              uint32_t fastpath, QSrc qsrc = QSrc())
+              uint32_t fastpath, QSrc qsrc = QSrc(), uint32_t kv_shift = 0)
 {
+    // kv_shift != 0 (round 5, mc_attn_qkv_wo_*): VIRTUAL kv heads.  A model with fewer than 8 kv heads (TinyLlama: 4 x 8 query heads)
+    // leaves half the chip without a workgroup and its heads' ranges on two XCDs each; launched as 8 heads of n_rep / 2 query heads --
+    // virtual head v = query heads v n_rep' .. + n_rep' - 1 (their natural numbering), cache head v >> kv_shift -- every CU has a
+    // workgroup, every virtual head's ranges share an XCD, and the K / V tiles of a cache head are read once per virtual head (2 x
+    // 2.1 MB of a 92 MB layer).  Only the cache ADDRESSES know: kvc below.
     // fastpath != 0: hand-offs A and B publish every granule twice and look at the XCD-local copy first (handoff.h, round 4); the
     // buffers are then twice as long, the `fast` words behind the `slow` ones
     const size_t psum_fast = (size_t)KV * n_rep * nsplit, slab_fast = (size_t)KV * nsplit * n_rep * HD;
@@ -814,6 +819,7 @@ attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t col = lane & 15, c = lane >> 4;
     const uint32_t p_begin = split * PBW;
+    const uint32_t kvc = kv >> kv_shift; // the cache head
     // ---- 1. the K tiles and the queries: requested before anything is waited for -- the step state included (a range past
     // kv_len reads slots nobody uses: their products are masked below)
     qsrc.before_tiles();
@@ -827,7 +833,7 @@ attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const
 #pragma unroll
         for (int t = 0; t < T; t++) {
             const uint32_t pos = p_begin + t * PB + wave * 16 + col;
-            const bf16_t* kbase = kc + ((((size_t)kv * max_seq + (pos < max_seq ? pos : max_seq - 1)) * HD + c * 8) & live);
+            const bf16_t* kbase = kc + ((((size_t)kvc * max_seq + (pos < max_seq ? pos : max_seq - 1)) * HD + c * 8) & live);
 #pragma unroll
             for (int ks = 0; ks < KS; ks++) kb[t][ks] = *reinterpret_cast<const uint4*>(kbase + ks * 32);
         }
@@ -835,7 +841,7 @@ attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const
 #pragma unroll
         for (int t = 0; t < T; t++) {
             const uint32_t pos = p_begin + t * PB + wave * 16 + col;
-            const bf16_t* kbase = kc + ((size_t)kv * max_seq + (pos < max_seq ? pos : max_seq - 1)) * HD;
+            const bf16_t* kbase = kc + ((size_t)kvc * max_seq + (pos < max_seq ? pos : max_seq - 1)) * HD;
 #pragma unroll
             for (int ks = 0; ks < KS; ks++) kb[t][ks] = *reinterpret_cast<const uint4*>(kbase + ks * 32 + c * 8);
         }
@@ -853,7 +859,7 @@ attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const
 #pragma unroll
             for (int b = 0; b < NB; b++) {
                 const uint32_t db = wave + NW * b;
-                const bf16_t* vrow = vt + ((size_t)kv * HD + (db < (uint32_t)NDB ? db : 0u) * 16 + col) * max_seq;
+                const bf16_t* vrow = vt + ((size_t)kvc * HD + (db < (uint32_t)NDB ? db : 0u) * 16 + col) * max_seq;
 #pragma unroll
                 for (int u = 0; u < 2; u++) {
                     const uint32_t p0 = p_begin + t * PB + u * 32 + c * 8;

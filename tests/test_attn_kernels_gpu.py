@@ -247,7 +247,7 @@ def test_attention_and_wo_in_one_launch_matches_the_oracle(acc, shape, n, fast):
 
 @pytest.mark.parametrize("fast", [1, 0])
 @pytest.mark.parametrize("n", [2048, 1000, 1, 65])
-@pytest.mark.parametrize("shape", ["llama3-8b-int4", "llama3.2-1b-bf16"])
+@pytest.mark.parametrize("shape", ["llama3-8b-int4", "llama3.2-1b-bf16", "tinyllama-bf16"])
 def test_norm_qkv_rope_attention_and_wo_in_one_launch_matches_the_oracle(acc, n, fast, shape):
     """`mc_attn_qkv_wo_i4_bfloat_hd128_k2_q2` (attn_block_kernels.hip qkv_in_launch: attention_norm, wq|wk|wv, RoPE, the cache
     write, the decode attention, Wo and the residual of one block -- nn/transformer.h:130-133, nn/attention.h:170-205 -- the kernel
@@ -261,8 +261,12 @@ def test_norm_qkv_rope_attention_and_wo_in_one_launch_matches_the_oracle(acc, n,
 
     # (the second shape: `mc_attn_qkv_wo_w_bfloat_hd64_k4_q4`, the same launch for PLAIN bfloat weights -- nn::linear, Llama-3.2-1B,
     #  the reference's default model, src/llama.cc:19-31)
+    # (the third: TinyLlama's 4 kv heads x 8 query heads, launched as 8 VIRTUAL kv heads of 4 query heads -- kv_shift = 1, round 5,
+    #  decode_kernels.hip attn_fused_bf: two virtual heads read one cache head and write its new row, the same bits, twice)
     int4 = shape == "llama3-8b-int4"
-    H, KV, hd, dim, max_seq = (32, 8, 128, 4096, 2048) if int4 else (32, 8, 64, 2048, 2048)
+    H, KV, hd, dim, max_seq = (32, 8, 128, 4096, 2048) if int4 else (32, 4 if shape == "tinyllama-bf16" else 8, 64, 2048, 2048)
+    vsh = 1 if shape == "tinyllama-bf16" else 0
+    KVV = KV << vsh
     half = hd // 2
     cfg = mg.tiny_cfg(BF16, dim=dim, n_heads=H, n_kv_heads=KV, head_dim=hd, ffn_dim=256, n_layers=1, vocab=64, max_seq_len=max_seq)
     w = mg.make_model(cfg, seed=303, quant="i4" if int4 else None, group=128)
@@ -304,7 +308,7 @@ def test_norm_qkv_rope_attention_and_wo_in_one_launch_matches_the_oracle(acc, n,
     psum = acc.to_device(np.zeros(2 * H * nsplit, np.uint64))
     slab = acc.to_device(np.zeros(2 * H * hd * nsplit, np.uint64))
     row_g = acc.to_device(np.zeros(H * hd // 2, np.uint64))
-    qkv_g = acc.to_device(np.zeros(2 * (H + 2 * KV) * hd // 2, np.uint64))
+    qkv_g = acc.to_device(np.zeros(2 * (H + 2 * KVV) * hd // 2, np.uint64))
     attn_out = acc.alloc(H * hd * 2)
     nw = acc.to_device(lw["attention_norm"])
     cb, sb = acc.to_device(fcos.reshape(-1)), acc.to_device(fsin.reshape(-1))
@@ -316,10 +320,11 @@ def test_norm_qkv_rope_attention_and_wo_in_one_launch_matches_the_oracle(acc, n,
         st = np.zeros(12, np.int32)
         st[2], st[3], st[6], st[9] = n, slot, rrow, epoch
         state = acc.to_device(st)
-        mc.KernelTask(kern, (nsplit * KV * 512, 1, 1), (512, 1, 1),
-                      [kc, vt, attn_out, psum, slab, row_g, qkv_g, state, np.uint32(n_rep), np.uint32(KV), np.uint32(max_seq),
+        mc.KernelTask(kern, (nsplit * KVV * 512, 1, 1), (512, 1, 1),
+                      [kc, vt, attn_out, psum, slab, row_g, qkv_g, state, np.uint32(n_rep >> vsh), np.uint32(KVV), np.uint32(max_seq),
                        np.float32(scale), np.uint32(nsplit), np.uint32(layer_tag), W(wo_p), W(wo_s), hb, hb, np.uint32(dim),
-                       np.uint32(128 if int4 else 0), nw, W(qk_p), W(qk_s), cb, sb, np.float32(1e-5), np.float32(0.0), np.uint32(fast), None])()
+                       np.uint32(128 if int4 else 0), nw, W(qk_p), W(qk_s), cb, sb, np.float32(1e-5), np.float32(0.0), np.uint32(fast), None,
+                       np.uint32(vsh)])()
         acc.wait()
         assert int(state.download(np.int32, 12)[10]) == 0, "a hand-off of the launch gave up"
         kgot = kc.download(np.uint16, KV * max_seq * hd).reshape(KV, max_seq, hd)

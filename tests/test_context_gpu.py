@@ -222,8 +222,11 @@ def test_tinyllama_1b_shapes_end_to_end(acc, dtype):
                          max_ulp=3, max_frac=0.8, what=f"tinyllama S=2048 dt{dtype}", launched=names)
     assert agree >= 7
     if dtype == BF16:
-        assert {"mc_gemv_w_bfloat_ling4_p1_e4", "mc_attn_fused_bfloat", "mc_gemv_w_bfloat_ling4_p0_e1", "mc_gemv_w_bfloat_ling4_p1_e2", "mc_gemv_w_bfloat_ling11_p0_e1",
+        # (round 5: three launches per block -- the 4 kv heads as 8 virtual ones inside mc_attn_qkv_wo_w_*,
+        #  test_tinyllama_takes_the_one_launch_block_as_eight_virtual_kv_heads below holds that form next to the five launches)
+        assert {"mc_attn_qkv_wo_w_bfloat_hd64_k4_q4", "mc_gemv_w_bfloat_ling4_p1_e2", "mc_gemv_w_bfloat_ling11_p0_e1",
                 "mc_gemv_w_bfloat_ling4_p1_e5"} <= names, sorted(names)
+        assert not {"mc_gemv_w_bfloat_ling4_p1_e4", "mc_attn_fused_bfloat", "mc_gemv_w_bfloat_ling4_p0_e1"} & names, sorted(names)
 
 
 def test_llama32_1b_shapes_take_the_one_launch_block_with_plain_weights(acc, monkeypatch):
@@ -259,6 +262,44 @@ def test_llama32_1b_shapes_take_the_one_launch_block_with_plain_weights(acc, mon
         dec.release()
     assert out["1"][0] == out["0"][0]
     parity.check(BF16, out["1"][1], out["0"][1], rel=7.8e-3, max_ulp=2, max_frac=0.6, what="one-launch block vs five launches, logits")
+
+
+def test_tinyllama_takes_the_one_launch_block_as_eight_virtual_kv_heads(acc, monkeypatch):
+    # BASELINE configs[0] (TinyLlama-1.1B: 4 kv heads x 8 query heads of 64, plain bfloat weights): the three-launch layer of
+    # Llama-3.2-1B with the 4 kv heads launched as 8 VIRTUAL ones of 4 query heads each (round 5, decoder.cc kv_virtual_shift;
+    # decode_kernels.hip attn_fused_bf kv_shift) -- against the oracle at S = 2048 and at position 40 with injected caches, and next
+    # to the five-launch form (MC_KV_VIRTUAL=0): the same tokens, logits within the suite's bound, the same cache rows bit for bit.
+    import metalchat_amd as mc
+
+    cfg = dict(dtype=BF16, family=0, n_layers=2, vocab=32000, max_seq_len=2048, norm_eps=1e-5, dim=2048, n_heads=32,
+               n_kv_heads=4, head_dim=64, ffn_dim=5632, rope_theta=10000.0, attn_scale=64 ** -0.5)
+    weights = t_weights_model(cfg, SEED)
+    names = set()
+    agree = run_injected(acc, cfg, weights, 2044, 8, dict(weight_format=mc.WFMT_T, group_size=0), rel_logits=7.8e-3,
+                         max_ulp=3, max_frac=0.8, what="tinyllama S=2048, virtual kv heads", launched=names)
+    assert agree >= 7
+    assert "mc_attn_qkv_wo_w_bfloat_hd64_k4_q4" in names and "mc_gemv_w_bfloat_ling4_p1_e4" not in names, sorted(names)
+    agree = run_injected(acc, cfg, weights, 40, 8, dict(weight_format=mc.WFMT_T, group_size=0), rel_logits=7.8e-3,
+                         max_ulp=3, max_frac=0.8, what="tinyllama at position 40 (all but one range of the launch empty)")
+    assert agree >= 7
+    out = {}
+    for form in ("1", "0"):
+        monkeypatch.setenv("MC_KV_VIRTUAL", form)
+        dec = mc.Decoder(acc, **mg.decoder_kwargs(cfg, weight_format=mc.WFMT_T, group_size=0))
+        dec.init_synthetic(SEED)
+        for layer in range(cfg["n_layers"]):
+            k, v = random_cache(cfg, 1500, 300 + layer)
+            dec.import_kv(layer, k, v)
+        dec.launch_log(True)
+        toks = list(dec.generate(9, 1500, 12))
+        assert ("mc_attn_qkv_wo_w_bfloat_hd64_k4_q4" in set(dec.launched())) == (form == "1"), sorted(set(dec.launched()))
+        out[form] = (toks, dec.logits().copy(), dec.export_kv(0))
+        dec.release()
+    assert out["1"][0] == out["0"][0]
+    parity.check(BF16, out["1"][1], out["0"][1], rel=7.8e-3, max_ulp=2, max_frac=0.6, what="virtual kv heads vs five launches, logits")
+    # layer 0's cache rows do not depend on any attention: the rows the one-launch block wrote (twice each) are the GEMV's
+    parity.exact(out["1"][2][0], out["0"][2][0], "K rows of layer 0")
+    parity.exact(out["1"][2][1], out["0"][2][1], "V rows of layer 0")
 
 
 def test_llama3_70b_widths_one_block(acc):

@@ -56,7 +56,7 @@ for epoch in (1, 2, 3):
                       [kc, vt, attn_out, psum, slab, row_g, qkv_g, state, np.uint32(n_rep), np.uint32(KV), np.uint32(S), np.float32(hd ** -0.5),
                        np.uint32(nsplit), np.uint32(i + 1), W(wo[i & 1][0]), W(wo[i & 1][1]), hidden, hidden, np.uint32(dim), np.uint32(128),
                        norm_w, W(qkv[i & 1][0]), W(qkv[i & 1][1]), fcos, fsin, np.float32(1e-5), np.float32(0.0), np.uint32(FAST),
-                       acc.wrap(tl.device_ptr + i * WGS * 128, WGS * 128)])()
+                       acc.wrap(tl.device_ptr + i * WGS * 128, WGS * 128), np.uint32(0)])()
     ms = acc.timer_end_ms()
     acc.wait()
     t = tl.download(np.uint64, N * WGS * 16).reshape(N, WGS, 16).astype(np.int64)
