@@ -243,6 +243,8 @@ struct mc_decoder {
     uint64_t weights_gen = 1;  // bumped whenever weight rows change: the derived copies (linear_w::wq2) are rebuilt
     bool pf2_on = true;        // MC_PF2: short prompts from the quad-interleaved copy
     bool kv_virtual_on = true; // MC_KV_VIRTUAL: fewer than 8 kv heads launched as 8 virtual ones where wq|wk|wv is inside the attention launch (kv_virtual_shift)
+    bool pf_attn8_on = true;   // MC_PF_ATTN8: the prompt attention with K / V tiles through LDS, from pf_attn8_rows rows on
+    int pf_attn8_rows = 1024;  // MC_PF_ATTN8_ROWS
     bool pf_g8_on = true;      // MC_PF_GEMM8: prompts of pf_g8_rows rows and more take the 256 x 256 ping-pong GEMM (kernels/pf_gemm8.h)
     int pf_g8_rows = 384;      // MC_PF_GEMM8_ROWS (measured round 5: 256 rows 7.42 ms with, 7.06 without -- one row of tiles leaves half the chip idle; 512 rows 10.13 against 11.66)
     bool pf_lib_on = false;    // MC_PF_BLASLT=1 (opt-in since round 5, a comparison aid): long prompts' large GEMMs in hipBLASLt on a dequantised bfloat16 copy of the matrix (gemm_lib)
@@ -1758,6 +1760,18 @@ struct mc_decoder {
                     const bool four = (H / KV) % 4 == 0 && hd == 128 &&
                                       (heads_env ? atoi(heads_env) == 4
                                                  : (unsigned)((M + 15) / 16) * (unsigned)(H / 4) >= (unsigned)dev->prop.multiProcessorCount);
+                    // long prompts (round 5): K / V tiles through LDS, 32 rows x 4 heads per workgroup (prefill_kernels.hip pf_attn_lds_body)
+                    const bool eight = (H / KV) % 4 == 0 && hd == 128 && cfg.max_seq_len % 8 == 0 &&
+                                       (heads_env ? atoi(heads_env) == 8 : (pf_attn8_on && M >= pf_attn8_rows));
+                    // (row tiles of 32 rows, dealt in pairs -- tile x with tile (last - x): equal work under the causal mask -- when the
+                    //  pairs still cover the CUs; MC_PF_ATTN8_PAIR=0 / 1 forces either)
+                    const unsigned ntl = (unsigned)(M + 31) / 32u;
+                    const char* pair_env = getenv("MC_PF_ATTN8_PAIR");
+                    const bool pair = pair_env ? atoi(pair_env) != 0 : ((ntl + 1u) / 2u) * (unsigned)(H / 4) >= (unsigned)dev->prop.multiProcessorCount;
+                    if (eight)
+                        return launch("mc_pf_attn8_bfloat_hd128", pair ? (ntl + 1u) / 2u : ntl, H / 4, 1, 512, 0,
+                                      pack(pf_q, L.kc, L.vt, pf_att, (uint32_t)M, (uint32_t)S, (uint32_t)H, (uint32_t)(H / KV),
+                                           (uint32_t)cfg.max_seq_len, scale_T, win, (const void*)pf_etab));
                     if (four)
                         return launch("mc_pf_attn4_bfloat_hd128", (M + 15) / 16, H / 4, 1, 256, 0,
                                       pack(pf_q, L.kc, L.vt, pf_att, (uint32_t)M, (uint32_t)S, (uint32_t)H, (uint32_t)(H / KV),
@@ -1927,6 +1941,8 @@ mc_decoder_create(mc_device* dev, mc_library* lib, mc_queue* q, const mc_decoder
     if (const char* e = getenv("MC_LAZY_PICK")) d->lazy_pick_on = atoi(e) != 0;
     if (const char* e = getenv("MC_PF2")) d->pf2_on = atoi(e) != 0;
     if (const char* e = getenv("MC_KV_VIRTUAL")) d->kv_virtual_on = atoi(e) != 0;
+    if (const char* e = getenv("MC_PF_ATTN8")) d->pf_attn8_on = atoi(e) != 0;
+    if (const char* e = getenv("MC_PF_ATTN8_ROWS")) d->pf_attn8_rows = std::max(1, atoi(e));
     if (const char* e = getenv("MC_PF_GEMM8")) d->pf_g8_on = atoi(e) != 0;
     if (const char* e = getenv("MC_PF_GEMM8_ROWS")) d->pf_g8_rows = std::max(1, atoi(e));
     if (const char* e = getenv("MC_PF_BLASLT")) {

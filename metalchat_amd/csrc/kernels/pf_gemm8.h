@@ -54,7 +54,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) char lds_char;
 
-constexpr uint32_t BM = 256, BN = 256, BK = 64;
+constexpr uint32_t BN = 256, BK = 64; // (rows of X per tile: the body's BM, 256 or 128)
 constexpr uint32_t HALF_BYTES = 128 * BK * 2;     // 16 KiB: 128 rows of 128 bytes
 constexpr uint32_t IMG_BYTES = 4 * HALF_BYTES;    // X lo, X hi, W lo, W hi
 constexpr uint32_t LDS_BYTES = 2 * IMG_BYTES;     // 128 KiB
@@ -98,12 +98,18 @@ struct args {
 // NS: half-tile slots of the LDS ring (8 = two images of a K tile, 128 KiB; 10 = all 160 KiB: every request goes out two phases
 // earlier).  DIAG (lab builds): 1 = nothing is staged inside the loop (what the LDS reads, the MFMAs and the barriers take alone),
 // 2 = no MFMAs (what the staging and the reads take alone).
-template <int WF, int EPI, int NS = 8, int DIAG = 0, typename ActFn>
+// BM: rows of X per tile.  256: the tile above.  128 (mc_pf_gemm8h_*): every wave 64 x 64 outputs, the X half tiles 64 rows -- for the
+// launches whose 256-row tiles would be too few for the chip: twice the workgroups before K is split, i.e. half the fp32 partial sums
+// written and read back (a 512-row prompt of Llama-3-8B moved 368 MB of them per block with 256-row tiles).
+template <int WF, int EPI, int NS = 8, int DIAG = 0, int BM = 256, typename ActFn>
 __device__ __forceinline__ void
 body(const args& a, ActFn&& act)
 {
     static_assert(NS == 8 || NS == 10, "slots");
     static_assert(WF == W_T || NS == 8, "the quantised loop's schedule is written for two images");
+    static_assert(BM == 256 || (BM == 128 && NS == 8), "rows of X per tile");
+    constexpr int MI = BM / 32;              // 16-row tiles of X per wave
+    constexpr uint32_t NXI = BM / 64;        // LDS-DMAs per wave of an X half tile (BM / 2 rows)
     constexpr int D = NS - 8;                  // phases a request goes out earlier than the two-image schedule's
     constexpr int LEAD = 1 + D;                // events of tile 1 the prologue requests behind tile 0 (the loop's phase p requests event 4 + LEAD + p)
     __shared__ __attribute__((aligned(1024))) char lds_[NS * HALF_BYTES];
@@ -136,22 +142,23 @@ body(const args& a, ActFn&& act)
         return u32x4{(uint32_t)v, (uint32_t)(v >> 32), (uint32_t)min(bytes, (size_t)0xFFFFFFFFu), 0x00020000u};
     };
     const u32x4 xrs = rsrc_of(a.X, (size_t)M * K * 2), wrs = rsrc_of(a.w, (size_t)N * K * 2);
-    const uint32_t srow = wq * 32u + (lane >> 3);                       // row of instruction 0 inside the half tile
+    const uint32_t srow = wq * 32u + (lane >> 3);                       // row of instruction 0 inside a W half tile (X: wq BM / 8 + ...)
     const uint32_t sc0 = ((lane & 7u) ^ (lane >> 4)) * 16u;              // even instructions; odd ones: ^ 64
-    const uint32_t xv0 = (m0 + srow) * K * 2u + sc0, wv0 = (n0 + srow) * K * 2u + sc0;
-    const uint32_t lds0 = (uint32_t)(uintptr_t)lds + wq * 4096u;
+    const uint32_t xv0 = (m0 + wq * (BM / 8u) + (lane >> 3)) * K * 2u + sc0, wv0 = (n0 + srow) * K * 2u + sc0;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)lds + wq * 4096u, lds0x = (uint32_t)(uintptr_t)lds + wq * (NXI * 1024u);
     // event e (wave-uniform): tile e / 4 of this workgroup's K range, half tile e % 4
     auto stage = [&](uint32_t e) {
         const uint32_t u = e >> 2, c = e & 3u;
         // (a tile past the end of the K range: the last one again -- what it writes is never read, and the loop keeps its counted waits)
         const uint32_t k0 = (tbeg + (u < T ? u : T - 1u)) * BK;
-        const uint32_t dst = lds0 + (e % (uint32_t)NS) * HALF_BYTES;
         const bool isw = c == 1u || c == 2u;
-        const uint32_t hi = c >> 1; // (rows 128-255 of the operand: c = 2, 3)
-        const uint32_t base = (isw ? wv0 : xv0) + (hi * 128u) * K * 2u + k0 * 2u;
+        const uint32_t dst = (isw ? lds0 : lds0x) + (e % (uint32_t)NS) * HALF_BYTES;
+        const uint32_t hi = c >> 1; // (the upper half of the operand's rows: c = 2, 3)
+        const uint32_t base = (isw ? wv0 : xv0) + (hi * (isw ? 128u : BM / 2u)) * K * 2u + k0 * 2u;
         const u32x4 rs = isw ? wrs : xrs; // (scalar selects: the descriptor stays in SGPRs)
 #pragma unroll
         for (uint32_t i = 0; i < 4; i++) {
+            if (BM == 128 && i >= NXI && !isw) break; // (wave-uniform: an X half tile of 64 rows is two instructions per wave)
             const uint32_t vo = (base + i * 8u * K * 2u) ^ ((i & 1u) * 64u);
             uint32_t keep;
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
@@ -165,7 +172,7 @@ body(const args& a, ActFn&& act)
     const uint32_t f0 = l15 * 128u + ((lg ^ (l15 >> 1)) & 7u) * 16u;
     const uint32_t f1 = l15 * 128u + (((4u + lg) ^ (l15 >> 1)) & 7u) * 16u;
     const uint32_t wsub = (wq & 1u) * 8192u;
-    u32x4 wf[4], xf[8];
+    u32x4 wf[4], xf[MI];
     // tile t: the W half of this wave is event 4 t + 1 + (wq >> 1), its X half event 4 t + 3 grp
     auto read_frags = [&](uint32_t t, uint32_t ks) {
         const uint32_t ws = (4u * t + 1u + (wq >> 1)) % (uint32_t)NS, xs = (4u * t + 3u * grp) % (uint32_t)NS;
@@ -174,24 +181,24 @@ body(const args& a, ActFn&& act)
 #pragma unroll
         for (int j = 0; j < 4; j++) wf[j] = *(const __attribute__((address_space(3))) u32x4*)(pw + j * 2048);
 #pragma unroll
-        for (int i = 0; i < 8; i++) xf[i] = *(const __attribute__((address_space(3))) u32x4*)(px + i * 2048);
+        for (int i = 0; i < MI; i++) xf[i] = *(const __attribute__((address_space(3))) u32x4*)(px + i * 2048);
     };
-    f32x4 acc[8][4];
+    f32x4 acc[MI][4];
 #pragma unroll
-    for (int i = 0; i < 8; i++)
+    for (int i = 0; i < MI; i++)
 #pragma unroll
         for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     auto multiply = [&](bool prio = true) {
         if constexpr (DIAG == 2) {
 #pragma unroll
-            for (int i = 0; i < 8; i++) asm volatile("" ::"v"(xf[i]));
+            for (int i = 0; i < MI; i++) asm volatile("" ::"v"(xf[i]));
 #pragma unroll
             for (int j = 0; j < 4; j++) asm volatile("" ::"v"(wf[j]));
             return;
         }
         if (prio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int i = 0; i < 8; i++)
+        for (int i = 0; i < MI; i++)
 #pragma unroll
             for (int j = 0; j < 4; j++)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[j]), __builtin_bit_cast(bf16x8, xf[i]), acc[i][j], 0, 0, 0);
@@ -199,9 +206,15 @@ body(const args& a, ActFn&& act)
     };
     // end of a phase in which this wave read and staged: its fragment reads done (the slot may be overwritten a phase later), all
     // but its youngest 1 + D / 2 half tiles landed
-    auto end_read = [&] {
-        if constexpr (D == 0) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    // (BM = 128, two images: the youngest half tile is a W one -- four instructions -- behind the reading step of k 0-31 and an X one --
+    //  two -- behind that of k 32-63)
+    auto end_read = [&](uint32_t ks) {
+        if constexpr (D != 0) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        else if constexpr (BM == 256) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        else {
+            if (ks == 0) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+        }
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
     };
@@ -231,17 +244,21 @@ body(const args& a, ActFn&& act)
         const uint32_t sv0 = (((n0 >> 2) + 4u * wq + (lane >> 4)) * ngroups * 4u + ((lane >> 2) & 3u)) * 2u +
                              (a.group ? (((lane & 3u) * 16u) >> glog) * 8u : 0u);
         const uint32_t ww0 = wrow16 * 128u + (((2u * (lane & 3u)) ^ ((lane >> 3) & 7u)) * 16u); // first chunk; the second: ^ 16
+        constexpr uint32_t NXQ = BM / 128; // LDS-DMAs per wave of an X quarter
         typedef typename std::conditional<WF == W_I4, u32x2, u32x4>::type wraw_t;
         wraw_t wA, wB;
         uint32_t sA, sB;
         auto stage_xq = [&](uint32_t u, uint32_t j) { // X quarter j of tile u
             const uint32_t c = (j >> 1) ? 3u : 0u, qh = j & 1u;
             const uint32_t k0 = (tbeg + (u < T ? u : T - 1u)) * BK;
-            const uint32_t dst = lds0 - wq * 2048u + ((4u * u + c) % 8u) * HALF_BYTES + qh * 8192u; // (lds0 carries wq * 4096: a wave's share of a QUARTER is 2 KiB)
-            const uint32_t base = xv0 - (wq * 16u) * K * 2u + ((j >> 1) * 128u + qh * 64u) * K * 2u + k0 * 2u; // (xv0: row wq * 32 + lane / 8 -> wq * 16 + lane / 8)
+            // (a quarter = BM / 4 rows; a wave's share of it: BM / 16 rows = NXQ instructions, NXQ KiB)
+            const uint32_t dst = (uint32_t)(uintptr_t)lds + wq * (NXQ * 1024u) + ((4u * u + c) % 8u) * HALF_BYTES + qh * (BM * 32u);
+            const uint32_t base = (m0 + wq * (BM / 16u) + (lane >> 3)) * K * 2u + sc0 + ((j >> 1) * (BM / 2u) + qh * (BM / 4u)) * K * 2u + k0 * 2u;
 #pragma unroll
-            for (uint32_t i = 0; i < 2; i++) {
-                const uint32_t vo = (base + i * 8u * K * 2u) ^ (i * 64u);
+            for (uint32_t i = 0; i < NXQ; i++) {
+                // (the source chunk's swizzle (row >> 1) & 7: + 4 on every second group of 8 rows -- instruction 1 of a wave, and with
+                //  32-row quarters, BM = 128, the odd waves' only instruction)
+                const uint32_t vo = (base + i * 8u * K * 2u) ^ (((i + (BM == 128 ? wq : 0u)) & 1u) * 64u);
                 uint32_t keep;
                 asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
                              : "=&s"(keep)
@@ -321,7 +338,9 @@ body(const args& a, ActFn&& act)
                 read_frags(t, ks);
                 stage_xq((p + 5u) >> 2, (p + 5u) & 3u);
                 load_wq(((p + 3u) >> 2) + 1u, (p + 3u) & 3u, wld, sld);
-                asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" : "+v"(wkeep), "+v"(skeep)::"memory"); // the previous reading phase's requests landed
+                // the previous reading phase's requests landed (in flight: this phase's NXQ LDS-DMAs and two loads)
+                if constexpr (BM == 256) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" : "+v"(wkeep), "+v"(skeep)::"memory");
+                else asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" : "+v"(wkeep), "+v"(skeep)::"memory");
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
             };
@@ -334,9 +353,9 @@ body(const args& a, ActFn&& act)
 #if MC_G8_INTERLEAVE
                 // one MFMA, then two of the dequantisation's vector instructions, ...
 #pragma unroll
-                for (int i = 0; i < 32; i++) {
+                for (int i = 0; i < 4 * MI; i++) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, BM == 256 ? 2 : 4, 0);
                 }
 #endif
                 __builtin_amdgcn_s_setprio(0);
@@ -359,8 +378,10 @@ body(const args& a, ActFn&& act)
         // same instructions here: the same bytes twice, once per launch)
 #pragma unroll
         for (uint32_t e = 0; e < 4u + LEAD; e++) stage(e);
-        if constexpr (D == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); // tile 0 landed (this wave's share)
-        else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        // tile 0 landed (this wave's share); in flight: X lo of tile 1 (D = 0), + W lo and W hi of tile 1 (D = 2)
+        if constexpr (D != 0) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else if constexpr (BM == 256) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         // ONE instruction stream for both groups; group 1 runs it one barrier -- one phase -- behind group 0 (and group 0 passes one
@@ -371,12 +392,12 @@ body(const args& a, ActFn&& act)
         for (uint32_t t = 0; t < T; t++) {
             read_frags(t, 0);
             if (DIAG != 1) stage(4u + LEAD + 4u * t + grp);
-            end_read();
+            end_read(0);
             multiply();
             end_mul();
             read_frags(t, 1);
             if (DIAG != 1) stage(4u + LEAD + 4u * t + 2u + grp);
-            end_read();
+            end_read(1);
             multiply();
             end_mul();
         }
@@ -385,9 +406,9 @@ body(const args& a, ActFn&& act)
     }
 
     // ---- epilogue: lane (l15, lg) holds, in acc[i][j][r], row m = 16 i + l15 of the wave's 128, column n = 16 j + 4 lg + r of its 64
-    const uint32_t mw = m0 + grp * 128u + l15, nw = n0 + wq * 64u + lg * 4u;
+    const uint32_t mw = m0 + grp * (BM / 2u) + l15, nw = n0 + wq * 64u + lg * 4u;
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
+    for (int i = 0; i < MI; i++) {
         const uint32_t m = mw + 16u * i;
         if (m >= M) continue;
 #pragma unroll

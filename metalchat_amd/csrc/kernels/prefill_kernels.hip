@@ -791,20 +791,24 @@ MC_PF_GEMM_BIG_D(mc_pf_gemm128_w_bfloat_d2_e2, PF_W_T, 2, 2)
 // dequantised in the loop.  mc_pf_gemm8_{i4,i8,w}_bfloat_e{0: store, 1: + residual, 2: fp32 partial sums of a K range (split-K),
 // 3: silu(w1 x) * (w3 x) of the fused w1|w3 matrix}; the argument list of the mc_pf_gemm256_* kernels.
 #include "pf_gemm8.h"
-#define MC_PF_GEMM8(NAME, WF, EPI)                                                                                            \
+#define MC_PF_GEMM8(NAME, WF, EPI, BM)                                                                                          \
     extern "C" __global__ void __launch_bounds__(512)                                                                         \
     NAME(const void* w, const void* scales, const bf16_t* X, bf16_t* Y, const bf16_t* res, uint32_t M, uint32_t N, uint32_t K, \
          uint32_t group, const bf16_t* la, const bf16_t* lb, uint32_t lora_rank, float lora_scale)                            \
     {                                                                                                                         \
         const g8::args a{w, scales, X, Y, res, M, N, K, group};                                                               \
         const float* etab = reinterpret_cast<const float*>(res);                                                              \
-        g8::body<WF, EPI>(a, [etab](float x, float y) { return pf_silu_T<BF>(x, etab) * y; });                                \
+        g8::body<WF, EPI, 8, 0, BM>(a, [etab](float x, float y) { return pf_silu_T<BF>(x, etab) * y; });                      \
     }
+// (128 rows of X per tile -- g8::body's BM = 128, twice the workgroups before K is split -- was built for the launches whose 256-row
+//  tiles are too few for the chip, parity-green in the lab build (tools/gemm8) and NOT faster with quantised weights: the dequantisation
+//  per phase stays what it is while the MFMAs halve -- 512 x 4096 x 4096 int4: 33.0 us with 4 K ranges against 32.7 for the 256-row tile;
+//  512 x 6144 x 4096: 51.2 with 2 ranges against ~ 44 with 4; profiles/r05_gemm8_lab_bm128.log.  Not instantiated here.)
 #define MC_PF_GEMM8_SET(F, WF)                          \
-    MC_PF_GEMM8(mc_pf_gemm8_##F##_bfloat_e0, WF, g8::E_STORE) \
-    MC_PF_GEMM8(mc_pf_gemm8_##F##_bfloat_e1, WF, g8::E_RES)   \
-    MC_PF_GEMM8(mc_pf_gemm8_##F##_bfloat_e2, WF, g8::E_PART)  \
-    MC_PF_GEMM8(mc_pf_gemm8_##F##_bfloat_e3, WF, g8::E_ACT)
+    MC_PF_GEMM8(mc_pf_gemm8_##F##_bfloat_e0, WF, g8::E_STORE, 256) \
+    MC_PF_GEMM8(mc_pf_gemm8_##F##_bfloat_e1, WF, g8::E_RES, 256)   \
+    MC_PF_GEMM8(mc_pf_gemm8_##F##_bfloat_e2, WF, g8::E_PART, 256)  \
+    MC_PF_GEMM8(mc_pf_gemm8_##F##_bfloat_e3, WF, g8::E_ACT, 256)
 MC_PF_GEMM8_SET(i4, g8::W_I4)
 MC_PF_GEMM8_SET(i8, g8::W_I8)
 MC_PF_GEMM8_SET(w, g8::W_T)
@@ -1529,6 +1533,226 @@ mc_pf_attn4_bfloat_hd128(const bf16_t* Q, const bf16_t* kc, const bf16_t* vt, bf
                          uint32_t max_seq, float scale, uint32_t window, const float* etab)
 {
     pf_attn_kt_body<128, 4>(Q, kc, vt, out, M, S, H, n_rep, max_seq, scale, window, etab);
+}
+
+// ---- long prompts (round 5): K and V tiles through LDS, 32 rows x 4 heads per workgroup, row tiles in pairs (mc_pf_attn8_bfloat_hd128).
+// pf_attn_kt_body's waves pull every K / V fragment they multiply out of L2 themselves (one fragment serves the 4 heads x 16 rows of ITS
+// workgroup: 1.6 GB per layer at 2048 rows), and its grid is one workgroup per 16 rows, whatever their number of keys.  Here a workgroup
+// is 8 waves = 4 heads x 2 x 16 rows: a tile of 64 keys (K: 64 rows of 256 bytes; V: the 128 rows of 128 bytes of the transposed cache)
+// is brought in ONCE by LDS-DMA (buffer_load ... lds, as kernels/pf_gemm8.h: the destination linear per instruction, the bank swizzle on
+// the source address) for all 128 (head, row) pairs of the workgroup -- half the bytes per row -- into one of two images, one barrier per
+// tile; every wave owns whole rows (one 16-row block of one head), so there is no sum across waves at the end.  A workgroup takes TWO row
+// tiles, p and (last - p): the causal triangle gives row tile p about p + 1 key tiles, so every workgroup of the launch has the same
+// number of key tiles to within one -- 256 equal workgroups at 2048 rows of Llama-3-8B, one per CU.
+// The arithmetic is pf_attn_kt_body's, operation for operation: S^T = K Q^T on the MFMA (a lane holds four keys of one row), s = T(T(q.k)
+// scale), e = exp(s) from the table's LDS window, the row sum over the lane's keys, then the four lane groups, p = T(e * 1/sum) straight into
+// the A operand of P V.  Only the ORDER of the fp32 additions differs (keys in sequence instead of four interleaved quarters).
+// (First build: 64 rows per workgroup, one row tile each: correct at once and no faster than pf_attn_kt_body -- 34.8 against 35.1 ms per
+//  2048-token prompt: the launch lasted what its heaviest workgroup took, twice the mean, and the per-score vector work -- two roundings,
+//  the table lookup, the product with 1/sum: ~ 17 instructions in pass 2 -- is what a wave's time goes to, not the K / V bytes.)
+template <uint32_t HD, int NH>
+__device__ __forceinline__ void
+pf_attn_lds_body(const bf16_t* Q, const bf16_t* kc, const bf16_t* vt, bf16_t* out, uint32_t M, uint32_t S, uint32_t H, uint32_t n_rep,
+                 uint32_t max_seq, float scale, uint32_t window, const float* etab)
+{
+    using T = BF;
+    static_assert(HD == 128 && NH == 4, "8 waves = 4 heads x 2 x 16 rows; K rows of 256 bytes");
+    constexpr uint32_t DT = HD / 16, DK = HD / 32, KT = 64, RT = 32;
+    constexpr uint32_t KB = KT * HD * 2, VB = HD * KT * 2, IMG = KB + VB; // 16 KiB + 16 KiB
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) char lds_char;
+    __shared__ __attribute__((aligned(1024))) char lds_[2 * IMG + 2 * pf_exp_window::N * 4]; // (ONE array: cdna_hip_programming.md s.5)
+    lds_char* const lds = (lds_char*)lds_;
+    const pf_exp_window ew{reinterpret_cast<float*>(lds_ + 2 * IMG)};
+    ew.fill(etab);
+    const uint32_t lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t l15 = lane & 15, lg = lane >> 4, kg = lg * 8;
+    const uint32_t h0 = blockIdx.y * NH, kv = h0 / n_rep, hh = h0 + (wave & 3u);
+    const uint32_t sq = S - M, NTL = (M + RT - 1u) / RT;
+    // ---- staging (inline asm: hipcc neither counts an LDS-DMA nor may it wait vmcnt(0) in front of every LDS read for it)
+    auto rsrc_of = [](const void* p, size_t bytes) {
+        const uint64_t v = (uint64_t)p;
+        return u32x4{(uint32_t)v, (uint32_t)(v >> 32), (uint32_t)bytes, 0x00020000u};
+    };
+    const u32x4 krs = rsrc_of(kc + (size_t)kv * max_seq * HD, (size_t)max_seq * HD * 2);   // keys past max_seq read as zeros
+    const u32x4 vrs = rsrc_of(vt + (size_t)kv * HD * max_seq, (size_t)HD * max_seq * 2);
+    // K: instruction i of wave w = keys 8 w + 4 i + (lane >> 4) of the tile, position lane & 15 of the 256-byte row holds source chunk
+    //    (lane & 15) ^ sK, sK = 4 ((key >> 3) & 3) + (key & 3) -- the lane's l15 when the fragment is read (below): conflict-free
+    // V: instruction i of wave w = rows (dims) 16 w + 8 i + (lane >> 3), position lane & 7 holds chunk (lane & 7) ^ ((row >> 1) & 7)
+    const uint32_t kvo = (8u * wave + (lane >> 4)) * (HD * 2u) + (((lane & 15u) ^ (4u * (wave & 3u) + (lane >> 4))) * 16u);
+    const uint32_t vvo = (16u * wave + (lane >> 3)) * (max_seq * 2u) + (((lane & 7u) ^ (lane >> 4)) * 16u);
+    const uint32_t ldsw = (uint32_t)(uintptr_t)lds + wave * 2048u;
+    auto dma = [&](uint32_t dst, uint32_t vo, const u32x4& rs) {
+        uint32_t keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "s"(dst), "v"(vo), "s"(rs)
+                     : "memory");
+    };
+    auto stage = [&](uint32_t t, bool with_v) { // tile t (keys 64 t ..) into image t & 1
+        const uint32_t img = (t & 1u) * IMG, key0 = t * KT;
+        dma(ldsw + img, kvo + key0 * (HD * 2u), krs);
+        dma(ldsw + img + 1024u, kvo + (key0 + 4u) * (HD * 2u), krs);
+        if (with_v) {
+            dma(ldsw + img + KB, vvo + key0 * 2u, vrs);
+            dma(ldsw + img + KB + 1024u, (vvo + 8u * (max_seq * 2u) + key0 * 2u) ^ 64u, vrs);
+        }
+    };
+    __syncthreads(); // the exp window is filled
+    // the launch's row tiles: workgroup x takes tile x and tile NTL - 1 - x (gridDim.x = ceil(NTL / 2): equal work under the causal
+    // mask), or tile x alone (gridDim.x = NTL)
+    const bool paired = gridDim.x < NTL;
+    for (uint32_t which = 0; which < 2; which++) {
+        const uint32_t rt = which ? NTL - 1u - blockIdx.x : blockIdx.x;
+        if (which && (!paired || rt == blockIdx.x)) break; // (wave-uniform)
+        const uint32_t r0 = rt * RT, rs0 = r0 + 16u * (wave >> 2), r = rs0 + l15; // this wave: head hh, rows rs0 .. rs0 + 15; the lane's row
+        const uint32_t rlast = min(r0 + RT - 1u, M - 1u);
+        uint32_t clo = sq, chi = sq + rlast;
+        if (window && r0 + 1 > window) clo = sq + (r0 + 1 - window);
+        const uint32_t t_lo = clo / KT, t_hi = chi / KT;
+        // ---- Q fragments of the wave's row block (the B operand of S^T: lane (l15, lg) holds Q[row][32 d + 8 lg ..])
+        uint4 qa[DK];
+        {
+            const uint32_t qr = min(r, M - 1u);
+#pragma unroll
+            for (uint32_t d = 0; d < DK; d++) qa[d] = *reinterpret_cast<const uint4*>(Q + ((size_t)qr * H + hh) * HD + d * 32 + kg);
+        }
+        // K fragment of tile image `img`: 32-key block bb, sub-tile h: keys 32 bb + 8 (l15 >> 2) + 4 h + (l15 & 3) (pf_attn_kt_body load_k)
+        auto read_k = [&](uint32_t img, uint32_t bb, uint32_t h, uint4 (&kb)[DK]) {
+            lds_char* p = lds + img + (32u * bb + 8u * (l15 >> 2) + 4u * h + (l15 & 3u)) * (HD * 2u);
+#pragma unroll
+            for (uint32_t d = 0; d < DK; d++) {
+                const u32x4 v = *(const __attribute__((address_space(3))) u32x4*)(p + (((d * 4u + lg) ^ l15) * 16u));
+                kb[d] = make_uint4(v.x, v.y, v.z, v.w);
+            }
+        };
+        // sb[0] | sb[1] = the BITS of the four masked scores T(T(q.k) scale) of (row r, keys blk + 8 lg + 4 h + 0 .. 3), two to a dword.
+        // (Two values per conversion instruction and no way back to float: the table is indexed by the bits -- 3 vector
+        //  instructions per score instead of 5 for the two roundings; -inf = 0xFF80 where masked.)
+        auto score_tile = [&](uint32_t blk, uint32_t h, const uint4 (&kb)[DK], uint32_t (&sb)[2]) {
+            const bool full = rs0 + 15 < M && blk + 31 < S && blk >= sq && blk + 31 - sq <= rs0 && (!window || rs0 + 15 < window + (blk - sq));
+            pf_f32x4 acc = {0, 0, 0, 0};
+#pragma unroll
+            for (uint32_t d = 0; d < DK; d++)
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(pf_bf16x8, kb[d]), __builtin_bit_cast(pf_bf16x8, qa[d]), acc, 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const uint32_t t2 = pack_bf16x2(acc[2 * j], acc[2 * j + 1]); // T(q.k)
+                sb[j] = pack_bf16x2(__uint_as_float(t2 << 16) * scale, __uint_as_float(t2 & 0xFFFF0000u) * scale);
+            }
+            if (!full) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const uint32_t key = blk + lg * 8 + h * 4 + i;
+                    const bool vis = bool(int(r < M) & int(key < S) & int(pf_visible(r, key, S, M, window)));
+                    const uint32_t keep = (i & 1) ? 0x0000FFFFu : 0xFFFF0000u, ninf = (i & 1) ? 0xFF800000u : 0x0000FF80u;
+                    sb[i >> 1] = vis ? sb[i >> 1] : ((sb[i >> 1] & keep) | ninf);
+                }
+            }
+        };
+        // exp of a score given by its bits: pf_exp_window::operator() on the bits (the same entry of the same table)
+        auto exp_bits = [&](uint32_t b) {
+            const uint32_t a_ = b & 0x7FFFu;
+            const float e = ew.w[min(max(a_, pf_exp_window::LO), pf_exp_window::HI - 1u) - pf_exp_window::LO + (b >> 15) * pf_exp_window::N];
+            return a_ > 0x7F80u ? __uint_as_float(b << 16) : e;
+        };
+        // does 32-key block blk hold a key any row of the wave's block may see?  (wave-uniform: whole blocks above the diagonal or
+        // below the window are skipped -- their exponentials are exact zeros)
+        auto relevant = [&](uint32_t blk) {
+            const uint32_t rl = min(rs0 + 15u, M - 1u);
+            if (rs0 >= M || blk > sq + rl) return false;
+            if (window && rs0 + 1 > window && blk + 31 < sq + (rs0 + 1 - window)) return false;
+            return true;
+        };
+        auto tile_begin = [&](uint32_t t, bool with_v) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's share of tile t landed
+            __builtin_amdgcn_s_barrier();                     // ... everybody's; and everybody is done with the other image
+            __builtin_amdgcn_sched_barrier(0);
+            if (t < t_hi) stage(t + 1u, with_v);
+        };
+        // ---- pass 1: exp row sums
+        float rsum = 0.0f;
+        __builtin_amdgcn_s_barrier(); // (everybody is done with the images of the row tile before)
+        __builtin_amdgcn_sched_barrier(0);
+        stage(t_lo, false);
+        // (four independent chains per tile -- both 32-key blocks and both sub-tiles as straight-line code where the whole tile is in
+        //  sight -- were built too: 33.97 against 33.05 ms per 2048-token prompt, 152 registers against 114: not kept)
+        for (uint32_t t = t_lo; t <= t_hi; t++) {
+            tile_begin(t, false);
+            const uint32_t img = (t & 1u) * IMG;
+#pragma unroll
+            for (uint32_t bb = 0; bb < 2; bb++) {
+                const uint32_t blk = t * KT + 32u * bb;
+                if (!relevant(blk)) continue;
+#pragma unroll
+                for (uint32_t h = 0; h < 2; h++) {
+                    uint4 kb[DK];
+                    read_k(img, bb, h, kb);
+                    uint32_t sb[2];
+                    score_tile(blk, h, kb, sb);
+                    rsum += (exp_bits(sb[0] & 0xFFFFu) + exp_bits(sb[0] >> 16)) + (exp_bits(sb[1] & 0xFFFFu) + exp_bits(sb[1] >> 16));
+                }
+            }
+        }
+        rsum += __shfl_xor(rsum, 16, 64);
+        rsum += __shfl_xor(rsum, 32, 64);
+        const float inv = 1.0f / rsum;
+        // ---- pass 2: probabilities (T) x V
+        pf_f32x4 oacc[DT];
+#pragma unroll
+        for (uint32_t t = 0; t < DT; t++) oacc[t] = pf_f32x4{0, 0, 0, 0};
+        __builtin_amdgcn_s_barrier(); // (everybody is done with pass 1's last image before it is staged again)
+        __builtin_amdgcn_sched_barrier(0);
+        stage(t_lo, true);
+        for (uint32_t t = t_lo; t <= t_hi; t++) {
+            tile_begin(t, true);
+            const uint32_t img = (t & 1u) * IMG;
+#pragma unroll
+            for (uint32_t bb = 0; bb < 2; bb++) {
+                const uint32_t blk = t * KT + 32u * bb;
+                if (!relevant(blk)) continue;
+                uint4 pa;
+#pragma unroll
+                for (uint32_t h = 0; h < 2; h++) {
+                    uint4 kb[DK];
+                    read_k(img, bb, h, kb);
+                    uint32_t sb[2];
+                    score_tile(blk, h, kb, sb);
+                    const uint32_t a = pack_bf16x2(exp_bits(sb[0] & 0xFFFFu) * inv, exp_bits(sb[0] >> 16) * inv);
+                    const uint32_t b = pack_bf16x2(exp_bits(sb[1] & 0xFFFFu) * inv, exp_bits(sb[1] >> 16) * inv);
+                    if (h == 0) {
+                        pa.x = a;
+                        pa.y = b;
+                    } else {
+                        pa.z = a;
+                        pa.w = b;
+                    }
+                }
+                // V fragments of the block: rows (dims) 16 t + l15 of the transposed tile, keys 32 bb + 8 lg .. + 7 = chunk 4 bb + lg
+                lds_char* vp = lds + img + KB + l15 * 128u + ((((4u * bb + lg) ^ (l15 >> 1)) & 7u) * 16u);
+#pragma unroll
+                for (uint32_t t2 = 0; t2 < DT; t2++) {
+                    const u32x4 v = *(const __attribute__((address_space(3))) u32x4*)(vp + t2 * 2048u);
+                    const uint4 vb = make_uint4(v.x, v.y, v.z, v.w);
+                    oacc[t2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(pf_bf16x8, pa), __builtin_bit_cast(pf_bf16x8, vb), oacc[t2], 0, 0, 0);
+                }
+            }
+        }
+        // ---- the rows: lane (l15, lg) holds out[rs0 + 4 lg + i][hh][16 t + l15]
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t ro = rs0 + 4u * lg + i;
+            if (ro >= M) continue;
+#pragma unroll
+            for (uint32_t t2 = 0; t2 < DT; t2++) out[((size_t)ro * H + hh) * HD + t2 * 16 + l15] = T::st(oacc[t2][i]);
+        }
+    }
+}
+extern "C" __global__ void __launch_bounds__(512)
+mc_pf_attn8_bfloat_hd128(const bf16_t* Q, const bf16_t* kc, const bf16_t* vt, bf16_t* out, uint32_t M, uint32_t S, uint32_t H, uint32_t n_rep,
+                         uint32_t max_seq, float scale, uint32_t window, const float* etab)
+{
+    pf_attn_lds_body<128, 4>(Q, kc, vt, out, M, S, H, n_rep, max_seq, scale, window, etab);
 }
 
 // (A 64-row variant -- four waves sharing every K / V tile through LDS, each wave owning 16 rows --

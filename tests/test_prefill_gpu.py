@@ -453,6 +453,38 @@ def test_two_head_prompt_attention_head_dims(acc, hd, heads, kv, nh, monkeypatch
     check_against_oracle(acc, cfg, weights, dict(weight_format=2, group_size=32), tokens, follow=1, expect_kernel=f"mc_pf_attn{nh}_bfloat_hd{hd}")
 
 
+@pytest.mark.parametrize("n", [2, 31, 33, 64, 65, 130, 300, 448])
+def test_prompt_attention_through_lds_tiles_matches_oracle(acc, n, monkeypatch):
+    """mc_pf_attn8_bfloat_hd128 (round 5: K / V tiles of 64 keys through LDS by LDS-DMA, 64 rows x 4 heads per workgroup -- the prompt
+    attention of 1024 rows and more; MC_PF_ATTN_HEADS=8 takes it on the models the oracle can follow): rows below, at and above one
+    row tile and one key tile, a ragged last tile, GQA 4 and 8; row tiles one per workgroup and in pairs (tile x with tile last - x: an
+    odd count leaves the middle one alone)."""
+    monkeypatch.setenv("MC_PF_ATTN_HEADS", "8")
+    for heads, kvh in ((8, 2), (8, 1)):
+        monkeypatch.setenv("MC_PF_ATTN8_PAIR", "1" if kvh == 2 else "0")
+        cfg = mg.tiny_cfg(BF16, dim=256, n_heads=heads, n_kv_heads=kvh, head_dim=128, ffn_dim=512, n_layers=2, vocab=384, max_seq_len=448)
+        weights = mg.make_model(cfg, seed=131 + kvh, quant="i4", group=128)
+        tokens = np.random.default_rng(n + kvh).integers(0, cfg["vocab"], n).tolist()
+        check_against_oracle(acc, cfg, weights, dict(weight_format=2, group_size=128), tokens, follow=1, expect_kernel="mc_pf_attn8_bfloat_hd128")
+
+
+def test_prompt_attention_through_lds_tiles_sliding_window_and_second_chunk(acc, monkeypatch):
+    """... under gemma3's sliding window (whole key tiles below the window are skipped) and for a chunk behind an earlier context (the
+    reference's mask leaves the earlier columns at -inf: nn/attention.h:283-321)"""
+    monkeypatch.setenv("MC_PF_ATTN_HEADS", "8")
+    monkeypatch.setenv("MC_PF_ATTN8_PAIR", "1")
+    cfg = mg.tiny_cfg(BF16, family=1, dim=256, n_heads=4, n_kv_heads=1, head_dim=128, ffn_dim=512, n_layers=2, rope_sliding_theta=10000.0,
+                      sliding_stride=2, attn_scale=float(1.0 / np.sqrt(48.0)), max_seq_len=320)
+    weights = mg.make_model(cfg, seed=133, quant="i4", group=32)
+    tokens = np.random.default_rng(14).integers(0, cfg["vocab"], 270).tolist()
+    check_against_oracle(acc, cfg, weights, dict(weight_format=2, group_size=32), tokens, window=37, follow=1, expect_kernel="mc_pf_attn8_bfloat_hd128")
+    cfg = mg.tiny_cfg(BF16, dim=256, n_heads=4, n_kv_heads=1, head_dim=128, ffn_dim=512, n_layers=1, vocab=384, max_seq_len=320)
+    weights = mg.make_model(cfg, seed=134, quant="i4", group=32)
+    warm = np.random.default_rng(15).integers(0, cfg["vocab"], 21).tolist()
+    tokens = np.random.default_rng(16).integers(0, cfg["vocab"], 150).tolist()
+    check_against_oracle(acc, cfg, weights, dict(weight_format=2, group_size=32), tokens, start_pos=21, warm=warm, expect_kernel="mc_pf_attn8_bfloat_hd128")
+
+
 def test_four_head_prompt_attention_sliding_window_and_second_chunk(acc, monkeypatch):
     monkeypatch.setenv("MC_PF_ATTN_HEADS", "4")
     cfg = mg.tiny_cfg(BF16, family=1, dim=256, n_heads=4, n_kv_heads=1, head_dim=128, n_layers=2, rope_sliding_theta=10000.0,

@@ -43,7 +43,7 @@ def quad_scales(sc):
     return np.ascontiguousarray(sc.reshape(-1, 4, G).transpose(0, 2, 1)).reshape(-1)
 
 
-def quant_case(lab, rng, fmt, M, N, K, group, reps):
+def quant_case(lab, rng, fmt, M, N, K, group, reps, pre="gemm8", bm=256, splits=1):
     X = to_bf16(rng.uniform(-1, 1, (M, K)))
     qmax = 7 if fmt == "i4" else 127
     q = rng.integers(-qmax - 1, qmax + 1, (N, K))
@@ -53,14 +53,17 @@ def quant_case(lab, rng, fmt, M, N, K, group, reps):
     wb = lab.to_device(pack_i4(q) if fmt == "i4" else q.astype(np.int8).reshape(-1).view(np.uint8))
     sb = lab.to_device(quad_scales(sc))
     xb = lab.to_device(X.reshape(-1))
-    yb = lab.to_device(np.zeros(M * N, np.uint16))
-    kern = lab.load(f"mc_pf_gemm8_{fmt}_bfloat_e0")
-    nx, ny = (N + 255) // 256, (M + 255) // 256
-    task = mc.KernelTask(kern, (nx * 512, ny, 1), (512, 1, 1),
+    yb = lab.to_device(np.zeros(M * N * (1 if splits == 1 else 2 * splits), np.uint16))
+    kern = lab.load(f"mc_pf_{pre}_{fmt}_bfloat_e{0 if splits == 1 else 2}")
+    nx, ny = (N + 255) // 256, (M + bm - 1) // bm
+    task = mc.KernelTask(kern, (nx * 512, ny, splits), (512, 1, 1),
                          [wb, sb, xb, yb, None, np.uint32(M), np.uint32(N), np.uint32(K), np.uint32(group), None, None, np.uint32(0), np.float32(0)])
     task()
     lab.wait()
-    Y = yb.download(np.uint16, M * N).reshape(M, N)
+    if splits == 1:
+        Y = yb.download(np.uint16, M * N).reshape(M, N)
+    else:
+        Y = to_bf16(yb.download(np.float32, splits * M * N).reshape(splits, M, N).sum(0))
     rows = sorted(set([0, 1, 63, 64, 127, 128, 255, 256 % M, M - 1, M // 2] + list(rng.integers(0, M, 6))))
     ref = from_bf16(X[rows]).astype(np.float64) @ wd.astype(np.float64).T
     got = from_bf16(Y[rows]).astype(np.float64)
@@ -74,7 +77,7 @@ def quant_case(lab, rng, fmt, M, N, K, group, reps):
         task()
     lab.wait()
     us = (time.perf_counter() - t0) / reps * 1e6
-    print(f"{M:5d} x {N:6d} x {K:6d}  gemm8 {fmt} g{group:<4d}   {us:9.1f} us  {2.0 * M * N * K / us / 1e6:8.1f} TFLOP/s   max rel err {err.max():.2e}  bad {bad}", flush=True)
+    print(f"{M:5d} x {N:6d} x {K:6d}  {pre} {fmt} g{group:<4d} x{splits}  {us:9.1f} us  {2.0 * M * N * K / us / 1e6:8.1f} TFLOP/s   max rel err {err.max():.2e}  bad {bad}", flush=True)
 
 
 def main():
@@ -105,6 +108,9 @@ def main():
         if args.quant:
             for fmt in args.quant.split(","):
                 quant_case(lab, rng, fmt, M, N, K, 128 if K % 128 == 0 else 32, args.reps)
+                for sp in (1, 2, 4):
+                    if (K // 64) % sp == 0 and (sp == 1 or fmt == "i4"):
+                        quant_case(lab, rng, fmt, M, N, K, 128 if K % 128 == 0 else 32, args.reps, "gemm8h", 128, sp)
         X = to_bf16(rng.uniform(-1, 1, (M, K)))
         W = to_bf16(rng.uniform(-1, 1, (N, K)))
         variants = [(lab, k_new, "gemm8", 256, True)]
