@@ -246,6 +246,7 @@ struct mc_decoder {
     bool pf_attn8_on = true;   // MC_PF_ATTN8: the prompt attention with K / V tiles through LDS, from pf_attn8_rows rows on
     int pf_attn8_rows = 1024;  // MC_PF_ATTN8_ROWS
     bool pf_g8_on = true;      // MC_PF_GEMM8: prompts of pf_g8_rows rows and more take the 256 x 256 ping-pong GEMM (kernels/pf_gemm8.h)
+    int pf_g8_max_splits = 16, pf_g8_min_ktiles = 8; // MC_PF_GEMM8_MAXSPLIT, MC_PF_GEMM8_MINKT: K ranges of a launch (g8_splits)
     int pf_g8_rows = 384;      // MC_PF_GEMM8_ROWS (measured round 5: 256 rows 7.42 ms with, 7.06 without -- one row of tiles leaves half the chip idle; 512 rows 10.13 against 11.66)
     bool pf_lib_on = false;    // MC_PF_BLASLT=1 (opt-in since round 5, a comparison aid): long prompts' large GEMMs in hipBLASLt on a dequantised bfloat16 copy of the matrix (gemm_lib)
     bool pf_lib_force = false;
@@ -1399,7 +1400,7 @@ struct mc_decoder {
     {
         const unsigned tiles = ((L.out + 255) / 256) * ((M + 255) / 256), cus = (unsigned)dev->prop.multiProcessorCount;
         unsigned splits = 1;
-        while (splits < 16 && tiles * splits * 2 <= cus && (unsigned)L.in / 64u / (splits * 2) >= 8u) splits *= 2;
+        while (splits < (unsigned)pf_g8_max_splits && tiles * splits * 2 <= cus && (unsigned)L.in / 64u / (splits * 2) >= (unsigned)pf_g8_min_ktiles) splits *= 2;
         return getenv("MC_PF_NO_SPLITK") ? 1u : splits;
     }
     mc_status
@@ -1945,6 +1946,8 @@ mc_decoder_create(mc_device* dev, mc_library* lib, mc_queue* q, const mc_decoder
     if (const char* e = getenv("MC_PF_ATTN8_ROWS")) d->pf_attn8_rows = std::max(1, atoi(e));
     if (const char* e = getenv("MC_PF_GEMM8")) d->pf_g8_on = atoi(e) != 0;
     if (const char* e = getenv("MC_PF_GEMM8_ROWS")) d->pf_g8_rows = std::max(1, atoi(e));
+    if (const char* e = getenv("MC_PF_GEMM8_MAXSPLIT")) d->pf_g8_max_splits = std::max(1, atoi(e));
+    if (const char* e = getenv("MC_PF_GEMM8_MINKT")) d->pf_g8_min_ktiles = std::max(1, atoi(e));
     if (const char* e = getenv("MC_PF_BLASLT")) {
         d->pf_lib_on = atoi(e) != 0;
         d->pf_lib_force = atoi(e) == 2;
