@@ -197,11 +197,15 @@ struct qkv_in_launch {
                 ss += b * b;
             }
             const float wsum_ = wave_sum_dpp(WB && tid >= NPK ? 0.0f : ss);
+#if MC_ABL_NORM_NOXWAVE
+            float tot = wsum_ * 8.0f; // (ablation build, gemv.h: timing only)
+#else
             if (lane == 0) red[wave] = wsum_;
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // (LDS only: the first pairs stay in flight)
             float tot = 0.0f;
 #pragma unroll
             for (int i = 0; i < 8; i++) tot += red[i];
+#endif
             const float inv = 1.0f / sqrtf(tot / (float)KQ + eps);
             uint32_t o[4];
 #pragma unroll

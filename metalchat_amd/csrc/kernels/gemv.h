@@ -25,6 +25,9 @@
 // registers so the next tile's loads are in flight while the current one is dequantised.
 // HBM-bound: algorithmic bytes per output row = in*bits/8 + (in/group)*scale_bytes.
 #pragma once
+#ifndef MC_ABL_NORM_NOXWAVE
+#define MC_ABL_NORM_NOXWAVE 0
+#endif
 
 #include "common.h"
 
@@ -1652,11 +1655,18 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
                 for (int i = 0; i < NXP; i++) put(i, normalise_l(h[i], nr[i], inv2));
             } else if (PRO == PRO_RMSNORM) {
                 const float wsum_ = wave_sum_dpp(sumsq_l(xr));
+#if MC_ABL_NORM_NOXWAVE
+                // ABLATION (round 5; wrong numbers, timing only): what the prologue would cost if the row's sum of
+                // squares needed no exchange across the workgroup's waves -- the upper bound of what partial sums left by the
+                // PRODUCER of the row could save (each wave would still add up the partials it loads: this wave sum)
+                float tot = wsum_ * (float)LWAVES;
+#else
                 if (lane == 0) red[wave] = wsum_;
                 __syncthreads();
                 float tot = 0.0f;
 #pragma unroll
                 for (uint32_t i = 0; i < (uint32_t)LWAVES; i++) tot += red[i];
+#endif
                 const float inv = 1.0f / sqrtf(tot / (float)in + eps);
 #pragma unroll
                 for (int i = 0; i < NXP; i++) put(i, normalise_l(xr[i], nr[i], inv));
