@@ -54,8 +54,23 @@ blaslt()
     static blaslt_api api;
     if (api.tried) return api;
     api.tried = true;
-    for (const char* name : {"libhipblaslt.so.1", "libhipblaslt.so", "/opt/rocm/lib/libhipblaslt.so"}) {
-        api.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+    // The copy that sits next to the libamdhip64 THIS library is linked against, first: a process that has also loaded another ROCm
+    // stack (the torch wheel carries private copies of libamdhip64 / libhipblaslt: tests/ckptgen.py imports torch) would otherwise get
+    // that stack's libhipblaslt by its soname -- a second HIP runtime that knows nothing of this one's streams (found in round 5: the
+    // process died in hipblasLtCreate once the library stopped being loaded by the first long prompt of the test session).
+    std::vector<std::string> names;
+    Dl_info info;
+    if (dladdr(reinterpret_cast<void*>(&hipGetDevice), &info) && info.dli_fname) {
+        std::string dir(info.dli_fname);
+        const size_t slash = dir.rfind('/');
+        if (slash != std::string::npos) names.push_back(dir.substr(0, slash) + "/libhipblaslt.so.1");
+    }
+    for (const char* n : {"/opt/rocm/lib/libhipblaslt.so.1", "libhipblaslt.so.1", "libhipblaslt.so"}) names.push_back(n);
+    // RTLD_DEEPBIND: the library's HIP calls bind to ITS OWN dependency chain -- the libamdhip64 of this process's first ROCm stack, found
+    // by soname among the loaded objects -- before the global scope, where an `import torch` has put the wheel's private HIP runtime
+    // ("no ROCm-capable device is detected" from inside hipblasLtCreate, and an exit(1), otherwise).
+    for (const std::string& name : names) {
+        api.handle = dlopen(name.c_str(), RTLD_NOW | RTLD_LOCAL | RTLD_DEEPBIND);
         if (api.handle) break;
     }
     if (!api.handle) return api;

@@ -101,14 +101,21 @@ struct args {
 // BM: rows of X per tile.  256: the tile above.  128 (mc_pf_gemm8h_*): every wave 64 x 64 outputs, the X half tiles 64 rows -- for the
 // launches whose 256-row tiles would be too few for the chip: twice the workgroups before K is split, i.e. half the fp32 partial sums
 // written and read back (a 512-row prompt of Llama-3-8B moved 368 MB of them per block with 256-row tiles).
-template <int WF, int EPI, int NS = 8, int DIAG = 0, int BM = 256, typename ActFn>
+// MF: the MFMA -- 16: v_mfma_f32_16x16x32_bf16 (32 per phase and wave), 32: v_mfma_f32_32x32x16_bf16 (16 per phase: the same matrix-pipe
+// time from half the instructions, i.e. half the issue-port cycles the MFMAs hold -- what the quantised loop's dequantisation competes for).
+template <int WF, int EPI, int NS = 8, int DIAG = 0, int BM = 256, int MF = 16, typename ActFn>
 __device__ __forceinline__ void
 body(const args& a, ActFn&& act)
 {
     static_assert(NS == 8 || NS == 10, "slots");
     static_assert(WF == W_T || NS == 8, "the quantised loop's schedule is written for two images");
     static_assert(BM == 256 || (BM == 128 && NS == 8), "rows of X per tile");
-    constexpr int MI = BM / 32;              // 16-row tiles of X per wave
+    static_assert(MF == 16 || MF == 32, "MFMA shape");
+    constexpr int MI = BM / (2 * MF);        // MF-row tiles of X per wave (its BM / 2 rows)
+    constexpr int NI = 64 / MF;              // MF-row tiles of W per wave (its 64 rows)
+    constexpr int KS = MF == 16 ? 1 : 2;     // MFMA k-steps per 32-deep phase
+    constexpr int AR = MF == 16 ? 4 : 16;    // accumulator registers per tile
+    typedef float accv __attribute__((ext_vector_type(AR)));
     constexpr uint32_t NXI = BM / 64;        // LDS-DMAs per wave of an X half tile (BM / 2 rows)
     constexpr int D = NS - 8;                  // phases a request goes out earlier than the two-image schedule's
     constexpr int LEAD = 1 + D;                // events of tile 1 the prologue requests behind tile 0 (the loop's phase p requests event 4 + LEAD + p)
@@ -169,39 +176,59 @@ body(const args& a, ActFn&& act)
     };
 
     // ---- fragments: 16 bytes of row (16 j + l15) of a half tile, k = 32 ks + 8 lg .. + 7: chunk 4 ks + lg at position ^ (l15 >> 1)
-    const uint32_t f0 = l15 * 128u + ((lg ^ (l15 >> 1)) & 7u) * 16u;
-    const uint32_t f1 = l15 * 128u + (((4u + lg) ^ (l15 >> 1)) & 7u) * 16u;
+    // (32 x 32 x 16: lane (r = lane & 31, h = lane >> 5) holds row r, k = 16 kk + 8 h .. + 7 of k-step kk: chunk 4 ks + 2 kk + h.  The same
+    //  positions are conflict-free: rows 0-3, 12-15 and 20-27 of one chunk -- a lane group of ds_read_b128 -- have (r >> 1) & 7 = 0 0 1 1 6 6 7 7
+    //  2 2 3 3 4 4 5 5 in both row parities)
+    const uint32_t l31 = lane & 31, lh = lane >> 5;
+    const uint32_t frow = MF == 16 ? l15 : l31, fsw = frow >> 1;
+    auto fpos = [&](uint32_t ks, uint32_t kk) { // byte offset of the lane's fragment of k-step (ks, kk) inside its tile of MF rows
+        const uint32_t chunk = MF == 16 ? 4u * ks + lg : 4u * ks + 2u * kk + lh;
+        return frow * 128u + ((chunk ^ fsw) & 7u) * 16u;
+    };
+    const uint32_t f0 = fpos(0, 0), f1 = fpos(1, 0), f0b = fpos(0, 1), f1b = fpos(1, 1);
     const uint32_t wsub = (wq & 1u) * 8192u;
-    u32x4 wf[4], xf[MI];
+    u32x4 wf[NI][KS], xf[MI][KS];
     // tile t: the W half of this wave is event 4 t + 1 + (wq >> 1), its X half event 4 t + 3 grp
     auto read_frags = [&](uint32_t t, uint32_t ks) {
         const uint32_t ws = (4u * t + 1u + (wq >> 1)) % (uint32_t)NS, xs = (4u * t + 3u * grp) % (uint32_t)NS;
-        lds_char* pw = lds + ws * HALF_BYTES + wsub + (ks ? f1 : f0);
-        lds_char* px = lds + xs * HALF_BYTES + (ks ? f1 : f0);
+        lds_char* pw = lds + ws * HALF_BYTES + wsub;
+        lds_char* px = lds + xs * HALF_BYTES;
 #pragma unroll
-        for (int j = 0; j < 4; j++) wf[j] = *(const __attribute__((address_space(3))) u32x4*)(pw + j * 2048);
+        for (int kk = 0; kk < KS; kk++) {
+            const uint32_t f = ks ? (kk ? f1b : f1) : (kk ? f0b : f0);
 #pragma unroll
-        for (int i = 0; i < MI; i++) xf[i] = *(const __attribute__((address_space(3))) u32x4*)(px + i * 2048);
+            for (int j = 0; j < NI; j++) wf[j][kk] = *(const __attribute__((address_space(3))) u32x4*)(pw + f + j * (MF * 128));
+#pragma unroll
+            for (int i = 0; i < MI; i++) xf[i][kk] = *(const __attribute__((address_space(3))) u32x4*)(px + f + i * (MF * 128));
+        }
     };
-    f32x4 acc[MI][4];
+    accv acc[MI][NI];
 #pragma unroll
     for (int i = 0; i < MI; i++)
 #pragma unroll
-        for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NI; j++)
+#pragma unroll
+            for (int e = 0; e < AR; e++) acc[i][j][e] = 0.0f;
     auto multiply = [&](bool prio = true) {
         if constexpr (DIAG == 2) {
 #pragma unroll
-            for (int i = 0; i < MI; i++) asm volatile("" ::"v"(xf[i]));
+            for (int i = 0; i < MI; i++) asm volatile("" ::"v"(xf[i][0]), "v"(xf[i][KS - 1]));
 #pragma unroll
-            for (int j = 0; j < 4; j++) asm volatile("" ::"v"(wf[j]));
+            for (int j = 0; j < NI; j++) asm volatile("" ::"v"(wf[j][0]), "v"(wf[j][KS - 1]));
             return;
         }
         if (prio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int i = 0; i < MI; i++)
+        for (int kk = 0; kk < KS; kk++)
 #pragma unroll
-            for (int j = 0; j < 4; j++)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[j]), __builtin_bit_cast(bf16x8, xf[i]), acc[i][j], 0, 0, 0);
+            for (int i = 0; i < MI; i++)
+#pragma unroll
+                for (int j = 0; j < NI; j++) {
+                    if constexpr (MF == 16)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[j][kk]), __builtin_bit_cast(bf16x8, xf[i][kk]), acc[i][j], 0, 0, 0);
+                    else
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[j][kk]), __builtin_bit_cast(bf16x8, xf[i][kk]), acc[i][j], 0, 0, 0);
+                }
         if (prio) __builtin_amdgcn_s_setprio(0);
     };
     // end of a phase in which this wave read and staged: its fragment reads done (the slot may be overwritten a phase later), all
@@ -353,9 +380,9 @@ body(const args& a, ActFn&& act)
 #if MC_G8_INTERLEAVE
                 // one MFMA, then two of the dequantisation's vector instructions, ...
 #pragma unroll
-                for (int i = 0; i < 4 * MI; i++) {
+                for (int i = 0; i < MI * NI * KS; i++) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, BM == 256 ? 2 : 4, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, (BM == 256 ? 2 : 4) * (MF == 16 ? 1 : 2), 0);
                 }
 #endif
                 __builtin_amdgcn_s_setprio(0);
@@ -405,35 +432,39 @@ body(const args& a, ActFn&& act)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
 
-    // ---- epilogue: lane (l15, lg) holds, in acc[i][j][r], row m = 16 i + l15 of the wave's 128, column n = 16 j + 4 lg + r of its 64
-    const uint32_t mw = m0 + grp * (BM / 2u) + l15, nw = n0 + wq * 64u + lg * 4u;
+    // ---- epilogue.  16 x 16 x 32: lane (l15, lg) holds, in acc[i][j][r], row m = 16 i + l15 of the wave's rows, column n = 16 j + 4 lg + r of its
+    // 64.  32 x 32 x 16: lane (l31, lh) holds, in acc[i][j][4 g + r], row 32 i + l31, column 32 j + 8 g + 4 lh + r.  Either way four consecutive
+    // columns of one row per group of four registers.
+    const uint32_t mw = m0 + grp * (BM / 2u) + frow, nw = n0 + wq * 64u + (MF == 16 ? lg : lh) * 4u;
 #pragma unroll
     for (int i = 0; i < MI; i++) {
-        const uint32_t m = mw + 16u * i;
+        const uint32_t m = mw + (uint32_t)MF * i;
         if (m >= M) continue;
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const uint32_t n = nw + 16u * j;
-            if (n >= N) continue; // (N is a multiple of 4: the host's condition)
-            const f32x4 v = acc[i][j];
-            if constexpr (EPI == E_PART) {
-                *reinterpret_cast<f32x4*>(static_cast<float*>(a.Y) + ((size_t)blockIdx.z * M + m) * N + n) = v;
-            } else if constexpr (EPI == E_ACT) {
-                // columns (2 c, 2 c + 1) of the fused w1|w3 output are the pair (w1 x, w3 x) of output column c
-                const float o0 = act(BF::rt(v[0]), BF::rt(v[1])), o1 = act(BF::rt(v[2]), BF::rt(v[3]));
-                *reinterpret_cast<uint32_t*>(static_cast<bf16_t*>(a.Y) + (size_t)m * (N / 2) + (n >> 1)) = pack_bf16x2(o0, o1);
-            } else {
-                float o[4] = {BF::rt(v[0]), BF::rt(v[1]), BF::rt(v[2]), BF::rt(v[3])};
-                if constexpr (EPI == E_RES) {
-                    const u32x2 r = *reinterpret_cast<const u32x2*>(static_cast<const bf16_t*>(a.res) + (size_t)m * N + n);
-                    o[0] = __uint_as_float(r.x << 16) + o[0];
-                    o[1] = __uint_as_float(r.x & 0xFFFF0000u) + o[1];
-                    o[2] = __uint_as_float(r.y << 16) + o[2];
-                    o[3] = __uint_as_float(r.y & 0xFFFF0000u) + o[3];
+        for (int j = 0; j < NI; j++)
+#pragma unroll
+            for (int g = 0; g < AR / 4; g++) {
+                const uint32_t n = nw + (uint32_t)MF * j + 8u * g;
+                if (n >= N) continue; // (N is a multiple of 4: the host's condition)
+                const f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                if constexpr (EPI == E_PART) {
+                    *reinterpret_cast<f32x4*>(static_cast<float*>(a.Y) + ((size_t)blockIdx.z * M + m) * N + n) = v;
+                } else if constexpr (EPI == E_ACT) {
+                    // columns (2 c, 2 c + 1) of the fused w1|w3 output are the pair (w1 x, w3 x) of output column c
+                    const float o0 = act(BF::rt(v[0]), BF::rt(v[1])), o1 = act(BF::rt(v[2]), BF::rt(v[3]));
+                    *reinterpret_cast<uint32_t*>(static_cast<bf16_t*>(a.Y) + (size_t)m * (N / 2) + (n >> 1)) = pack_bf16x2(o0, o1);
+                } else {
+                    float o[4] = {BF::rt(v[0]), BF::rt(v[1]), BF::rt(v[2]), BF::rt(v[3])};
+                    if constexpr (EPI == E_RES) {
+                        const u32x2 r = *reinterpret_cast<const u32x2*>(static_cast<const bf16_t*>(a.res) + (size_t)m * N + n);
+                        o[0] = __uint_as_float(r.x << 16) + o[0];
+                        o[1] = __uint_as_float(r.x & 0xFFFF0000u) + o[1];
+                        o[2] = __uint_as_float(r.y << 16) + o[2];
+                        o[3] = __uint_as_float(r.y & 0xFFFF0000u) + o[3];
+                    }
+                    *reinterpret_cast<u32x2*>(static_cast<bf16_t*>(a.Y) + (size_t)m * N + n) = u32x2{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
                 }
-                *reinterpret_cast<u32x2*>(static_cast<bf16_t*>(a.Y) + (size_t)m * N + n) = u32x2{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
             }
-        }
     }
 }
 

@@ -4,13 +4,14 @@
 using namespace mc;
 #define G8(NAME, WF, EPI) G8X(NAME, WF, EPI, 8, 0)
 #define G8X(NAME, WF, EPI, NS, DIAG) G8Y(NAME, WF, EPI, NS, DIAG, 256)
-#define G8Y(NAME, WF, EPI, NS, DIAG, BM)                                                                                                   \
+#define G8Y(NAME, WF, EPI, NS, DIAG, BM) G8Z(NAME, WF, EPI, NS, DIAG, BM, 16)
+#define G8Z(NAME, WF, EPI, NS, DIAG, BM, MF)                                                                                                   \
     extern "C" __global__ void __launch_bounds__(512)                                                                         \
     NAME(const void* w, const void* scales, const bf16_t* X, bf16_t* Y, const bf16_t* res, uint32_t M, uint32_t N, uint32_t K, \
          uint32_t group, const bf16_t* la, const bf16_t* lb, uint32_t lora_rank, float lora_scale)                            \
     {                                                                                                                         \
         g8::args a{w, scales, X, Y, res, M, N, K, group};                                                                     \
-        g8::body<WF, EPI, NS, DIAG, BM>(a, [](float x, float y) { return x * y; });                                                         \
+        g8::body<WF, EPI, NS, DIAG, BM, MF>(a, [](float x, float y) { return x * y; });                                                         \
     }
 G8(mc_pf_gemm8_w_bfloat_e0, g8::W_T, g8::E_STORE)
 G8(mc_pf_gemm8_w_bfloat_e2, g8::W_T, g8::E_PART)
@@ -25,3 +26,7 @@ G8Y(mc_pf_gemm8h_w_bfloat_e2, g8::W_T, g8::E_PART, 8, 0, 128)
 G8Y(mc_pf_gemm8h_i4_bfloat_e0, g8::W_I4, g8::E_STORE, 8, 0, 128)
 G8Y(mc_pf_gemm8h_i8_bfloat_e0, g8::W_I8, g8::E_STORE, 8, 0, 128)
 G8Y(mc_pf_gemm8h_i4_bfloat_e2, g8::W_I4, g8::E_PART, 8, 0, 128)
+G8Z(mc_pf_gemm8_w_bfloat_e0_mf32, g8::W_T, g8::E_STORE, 8, 0, 256, 32)
+G8Z(mc_pf_gemm8x_i4_bfloat_e0, g8::W_I4, g8::E_STORE, 8, 0, 256, 32)
+G8Z(mc_pf_gemm8x_i8_bfloat_e0, g8::W_I8, g8::E_STORE, 8, 0, 256, 32)
+G8Z(mc_pf_gemm8x_i4_bfloat_e2, g8::W_I4, g8::E_PART, 8, 0, 256, 32)

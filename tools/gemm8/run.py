@@ -88,6 +88,7 @@ def main():
     ap.add_argument("--shapes", default="512x28672x4096,2048x28672x4096,512x6144x4096,512x4096x4096,512x4096x14336,300x768x256,1024x28672x4096")
     ap.add_argument("--no-old", action="store_true")
     ap.add_argument("--no-splitk", action="store_true")
+    ap.add_argument("--bm128", action="store_true", help="the 128-row tile variants too (gemm8h)")
     ap.add_argument("--quant", default="i4,i8", help="quantised-W variants to run per shape")
     ap.add_argument("--extra", default="ns8,nostage,nomfma", help="lab variants of --kernel: suffixes")
     args = ap.parse_args()
@@ -108,9 +109,11 @@ def main():
         if args.quant:
             for fmt in args.quant.split(","):
                 quant_case(lab, rng, fmt, M, N, K, 128 if K % 128 == 0 else 32, args.reps)
-                for sp in (1, 2, 4):
-                    if (K // 64) % sp == 0 and (sp == 1 or fmt == "i4"):
-                        quant_case(lab, rng, fmt, M, N, K, 128 if K % 128 == 0 else 32, args.reps, "gemm8h", 128, sp)
+                if args.bm128:
+                    for sp in (1, 2, 4):
+                        if (K // 64) % sp == 0 and (sp == 1 or fmt == "i4"):
+                            quant_case(lab, rng, fmt, M, N, K, 128 if K % 128 == 0 else 32, args.reps, "gemm8h", 128, sp)
+                quant_case(lab, rng, fmt, M, N, K, 128 if K % 128 == 0 else 32, args.reps, "gemm8x", 256, 1)   # 32 x 32 x 16 MFMAs
         X = to_bf16(rng.uniform(-1, 1, (M, K)))
         W = to_bf16(rng.uniform(-1, 1, (N, K)))
         variants = [(lab, k_new, "gemm8", 256, True)]
