@@ -257,6 +257,7 @@ struct mc_decoder {
     const void* pending_pn = nullptr; // gemma3: postnorm_args the next pre-norm GEMV has to apply to `proj`
     uint64_t weights_gen = 1;  // bumped whenever weight rows change: the derived copies (linear_w::wq2) are rebuilt
     bool pf2_on = true;        // MC_PF2: short prompts from the quad-interleaved copy
+    bool attn_i8_on = true;    // MC_ATTN_I8: int8 wq|wk|wv and Wo inside the attention launch (attn_qkv_wo_i8_tiles)
     bool kv_virtual_on = true; // MC_KV_VIRTUAL: fewer than 8 kv heads launched as 8 virtual ones where wq|wk|wv is inside the attention launch (kv_virtual_shift)
     bool pf_attn8_on = true;   // MC_PF_ATTN8: the prompt attention with K / V tiles through LDS, from pf_attn8_rows rows on
     int pf_attn8_rows = 1024;  // MC_PF_ATTN8_ROWS
@@ -308,7 +309,7 @@ struct mc_decoder {
     hipEvent_t err_evt = nullptr;
     bool err_pending = false;
     int handoff_fallbacks = 0;
-    int occ_fused = -1, occ_wo = -1, occ_wo_w = -1;   // co-resident workgroups per CU of the hand-off launches (the occupancy API's answer; -1: not asked yet)
+    int occ_fused = -1, occ_wo = -1, occ_wo_w = -1, occ_wo_i8 = -1;   // co-resident workgroups per CU of the hand-off launches (the occupancy API's answer; -1: not asked yet)
     bool handoff_fast = true;    // MC_HANDOFF_FAST=0: hand-offs A and B through the fabric only (A/B; handoff.h "the XCD-local fast path")
     bool attn_wo_on = true;      // MC_ATTN_WO=0: the Wo GEMV as a launch of its own behind the one-launch attention (A/B, parity)
     bool attn_fused_on = true;   // MC_ATTN_FUSED=0: scores and P.V as two launches (A/B, parity)
@@ -700,6 +701,7 @@ struct mc_decoder {
         const int hd = cfg.head_dim, k = cfg.n_heads * hd / 2048;
         occ_wo = ask("mc_attn_wo_i4_bfloat_hd" + std::to_string(hd) + "_k" + std::to_string(k), 512);
         occ_wo_w = hd == 64 ? ask("mc_attn_qkv_wo_w_bfloat_hd64_k4_q4", 512) : 0;
+        occ_wo_i8 = hd == 128 ? ask("mc_attn_qkv_wo_i8_bfloat_hd128_k4_q4_t4", 512) : 0;
         (void)hipGetLastError();
     }
     // a hand-off gave up: report nothing yet, make the NEXT launches independent of co-residency
@@ -787,6 +789,29 @@ struct mc_decoder {
         return hd == 64 && L.wo.in == 2048 && L.qkv.in == 2048 && L.wo.in == cfg.n_heads * hd && L.wo.out % 2 == 0 &&
                L.qkv.out == (cfg.n_heads + 2 * cfg.n_kv_heads) * hd && grid <= (unsigned)dev->prop.multiProcessorCount &&
                pg % nsplit == 0 && pg / nsplit <= 8 && n_rep <= 16 && pg >= 64 && pg <= 512 && (unsigned)L.wo.out / 2 <= 8u * grid;
+    }
+
+    // ... the same launch for INT8 weights (round 5, mc_attn_qkv_wo_i8_bfloat_hd128_k4_q4_t{1,4}: Llama-3-8B int8): rows of 4 KiB (K = 4096),
+    // one 512-thread workgroup per CU -- 64-slot ranges up to S = 2048 (t1), 256-slot ranges at S = 8192 (t4: 32 ranges x 8 kv heads).
+    // Returns the 64-slot tiles per scoring wave (1 or 4), 0 = not this form.
+    int
+    attn_qkv_wo_i8_tiles(const layer_w& L) const
+    {
+        if (!attn_qkv_on || !attn_wo_on || !attn_i8_on || !attn_fused_on || !attn_qkv_g || !attn_psum_g || tb != 2 || n_own > 254 || cfg.family == MC_FAMILY_GEMMA3) return 0;
+        if (L.qkv.fmt != MC_WFMT_I8 || L.wo.fmt != MC_WFMT_I8 || L.qkv.lora_cols || L.wo.lora_cols || occ_wo_i8 == 0) return 0;
+        auto group_ok = [](const linear_w& W) { return W.group == 0 || (W.group >= 16 && (W.group & (W.group - 1)) == 0); };
+        if (!group_ok(L.qkv) || !group_ok(L.wo) || L.qkv.group != L.wo.group) return 0;
+        const int hd = cfg.head_dim, n_rep = cfg.n_heads / cfg.n_kv_heads, pg = (n_rep + 2) * hd / 2;
+        if (hd != 128 || L.wo.in != 4096 || L.qkv.in != 4096 || L.wo.in != cfg.n_heads * hd || L.wo.out % 2 != 0 ||
+            L.qkv.out != (cfg.n_heads + 2 * cfg.n_kv_heads) * hd || cfg.n_kv_heads % 8 != 0 || n_rep > 16)
+            return 0;
+        for (int t : {1, 4}) {
+            if (nsplit % t) continue;
+            const int ns = nsplit / t;
+            const unsigned grid = (unsigned)(ns * cfg.n_kv_heads);
+            if (grid <= (unsigned)dev->prop.multiProcessorCount && pg % ns == 0 && pg / ns <= 16 && (unsigned)L.wo.out / 2 <= 8u * grid) return t;
+        }
+        return 0;
     }
 
     // dynamic LDS of a linear-order int4 GEMV (gemv(): the padded row, the scratch, the parked sums of eight waves)
@@ -1010,7 +1035,8 @@ struct mc_decoder {
         for (int li = 0; li < n_own; li++) {
             layer_w& L = layers[li];
             const bool qkv_w_in = attn_qkv_wo_w_fused(L);
-            const bool qkv_in = qkv_w_in || attn_qkv_wo_fused(L);
+            const int i8_tiles = qkv_w_in ? 0 : attn_qkv_wo_i8_tiles(L);
+            const bool qkv_in = qkv_w_in || i8_tiles || attn_qkv_wo_fused(L);
             bool qkn_in = false;
             if (qkv_in) {
                 // attention_norm, wq|wk|wv, rope, cache write, scores, softmax, P.V, wo + residual (transformer.h:130-133,
@@ -1018,12 +1044,15 @@ struct mc_decoder {
                 // (plain weights: fewer than 8 kv heads are launched as 8 virtual ones, kv_virtual_shift)
                 const int vsh = qkv_w_in ? kv_virtual_shift() : 0;
                 const bool vfast = vsh ? handoff_fast : handoff_fast_here();
+                // (int8: ranges of 64 i8_tiles slots -- nsplit / i8_tiles of them per kv head)
+                const int ns = i8_tiles ? nsplit / i8_tiles : nsplit;
                 s = launch(qkv_w_in ? std::string("mc_attn_qkv_wo_w_bfloat_hd64_k4_q4")
+                           : i8_tiles ? "mc_attn_qkv_wo_i8_bfloat_hd128_k4_q4_t" + std::to_string(i8_tiles)
                                     : "mc_attn_qkv_wo_i4_" + tname + "_hd" + std::to_string(hd) + "_k" + std::to_string(L.wo.in / 2048) + "_q" +
                                           std::to_string(L.qkv.in / 2048),
-                           (unsigned)(nsplit * (KV << vsh)), 1, 1, 512, 0,
+                           (unsigned)(ns * (KV << vsh)), 1, 1, 512, 0,
                            pack((const void*)L.kc, (const void*)L.vt, attn_out, attn_psum_g, attn_slab_g, attn_row_g, attn_qkv_g, state,
-                                (uint32_t)(n_rep >> vsh), (uint32_t)(KV << vsh), (uint32_t)cfg.max_seq_len, scale_T, (uint32_t)nsplit, (uint32_t)(li + 1),
+                                (uint32_t)(n_rep >> vsh), (uint32_t)(KV << vsh), (uint32_t)cfg.max_seq_len, scale_T, (uint32_t)ns, (uint32_t)(li + 1),
                                 (const void*)L.wo.w, (const void*)L.wo.scales, x, hidden, (uint32_t)L.wo.out, (uint32_t)L.wo.group,
                                 (const void*)L.attention_norm, (const void*)L.qkv.w, (const void*)L.qkv.scales,
                                 (const float*)rope_cos[L.rope_table], (const float*)rope_sin[L.rope_table], cfg.norm_eps, mu,
@@ -1957,6 +1986,7 @@ mc_decoder_create(mc_device* dev, mc_library* lib, mc_queue* q, const mc_decoder
     if (const char* e = getenv("MC_LAZY_PICK")) d->lazy_pick_on = atoi(e) != 0;
     if (const char* e = getenv("MC_PF2")) d->pf2_on = atoi(e) != 0;
     if (const char* e = getenv("MC_KV_VIRTUAL")) d->kv_virtual_on = atoi(e) != 0;
+    if (const char* e = getenv("MC_ATTN_I8")) d->attn_i8_on = atoi(e) != 0;
     if (const char* e = getenv("MC_PF_ATTN8")) d->pf_attn8_on = atoi(e) != 0;
     if (const char* e = getenv("MC_PF_ATTN8_ROWS")) d->pf_attn8_rows = std::max(1, atoi(e));
     if (const char* e = getenv("MC_PF_GEMM8")) d->pf_g8_on = atoi(e) != 0;
@@ -2852,6 +2882,7 @@ mc_decoder_gemv_kernel_name(mc_decoder* d, const char* which, char* buf, size_t 
         const linear_w& wo = d->layers[0].wo;
         d->query_occupancy();
         name = d->attn_qkv_wo_w_fused(d->layers[0]) ? std::string("mc_attn_qkv_wo_w_bfloat_hd64_k4_q4")
+               : d->attn_qkv_wo_i8_tiles(d->layers[0]) ? "mc_attn_qkv_wo_i8_bfloat_hd128_k4_q4_t" + std::to_string(d->attn_qkv_wo_i8_tiles(d->layers[0]))
                : d->attn_qkv_wo_fused(d->layers[0]) ? "mc_attn_qkv_wo_i4_" + d->tname + "_hd" + std::to_string(d->cfg.head_dim) + "_k" + std::to_string(wo.in / 2048) +
                                                          "_q" + std::to_string(d->layers[0].qkv.in / 2048)
                : d->attn_wo_fused(wo) ? "mc_attn_wo_i4_" + d->tname + "_hd" + std::to_string(d->cfg.head_dim) + "_k" + std::to_string(wo.in / 2048)

@@ -49,14 +49,19 @@ using namespace mc::gemv;
 // rows of QN KiB hold 512 QN weights, no scales, the row in LDS in natural order, a row multiplied packet by packet with
 // v_dot2_f32_bf16 as gemv.h mac<WF_T> does, one pair per wave at most.  Every difference is a compile-time branch: the int4
 // instantiation is the code it was.
+// WB = 2 (round 5, mc_attn_qkv_wo_i8_bfloat_*): int8 weights (quantization::linear at 8 bits) -- rows of QN KiB hold 1024 QN weights, one
+// bfloat scale per row and group, the row in LDS in natural order, a packet of 16 weights dequantised and multiplied as gemv.h
+// mac<Q_EXACT> (Wd = T(T(q) T(s)) per weight, fp32 sums by v_dot2c); up to two pairs per wave.  The stand-alone int8 kernels multiply on
+// the matrix pipe (gemv.h mac8b_n): the same products in another order -- parity with the oracle, not identity with those launches.
 template <int HD, int QN, int WB = 0>
 struct qkv_in_launch {
-    static_assert(WB ? QN == 4 : QN == 2, "at most one 16-byte packet of the hidden row per thread (K = 4096 int4 / 2048 bfloat, 512 threads)");
+    static_assert(WB ? QN == 4 : QN == 2, "at most one 16-byte packet of the hidden row per thread (K = 4096 int4 / int8, 2048 bfloat; 512 threads)");
     static constexpr bool LDS = true, PIN_V = true;
     static constexpr int TL_STRIDE = 16, TL_BASE = 3; // stamps: 0 start, 1 row staged, 2 pairs published, 3.. attn_fused_bf's 0..
-    static constexpr uint32_t KQ = WB ? 512u * QN : 2048u * QN, ROWBQ = 1024u * QN, CHUNK_LDS = 2048 * 2 / 16 * 17, HALF = HD / 2;
+    static constexpr uint32_t KQ = WB == 1 ? 512u * QN : (WB == 2 ? 1024u * QN : 2048u * QN), ROWBQ = 1024u * QN, CHUNK_LDS = 2048 * 2 / 16 * 17, HALF = HD / 2;
     static constexpr uint32_t NPK = KQ / 8; // 16-byte packets of the hidden row
-    static constexpr int PMAXQ = WB ? 1 : 2;
+    static constexpr uint32_t WPK = WB == 1 ? 8u : (WB == 2 ? 16u : 32u); // weights of a lane's 16-byte packet
+    static constexpr int PMAXQ = WB == 1 ? 1 : 2;
     typedef const __attribute__((address_space(3))) bf16_t* lds_row;
     typedef __attribute__((address_space(3))) bf16_t* lds_row_w;
     typedef uint32_t rowv4 __attribute__((ext_vector_type(4)));
@@ -116,11 +121,11 @@ struct qkv_in_launch {
                 const rowv4 v = __builtin_nontemporal_load(reinterpret_cast<const rowv4*>(wrow + (((size_t)rr * ROWBQ + c * 1024) & lm64)));
                 ww[i][rr][c] = make_uint4(v.x, v.y, v.z, v.w);
             }
-        if constexpr (WB == 0) {
+        if constexpr (WB != 1) {
             const char* srow = static_cast<const char*>(qs) + (((size_t)(pp >> 1) * ngroups) * 4 + (pp & 1u) * 2) * 2;
 #pragma unroll
             for (int c = 0; c < QN; c++) {
-                const uint32_t g = group ? ((2048u * c + 32u * lane) >> glog) : 0u;
+                const uint32_t g = group ? ((64u * WPK * c + WPK * lane) >> glog) : 0u;
                 wsc[i][c] = *reinterpret_cast<const uint32_t*>(srow + ((g * 8u) & lm));
             }
         }
@@ -154,7 +159,7 @@ struct qkv_in_launch {
     {
         const uint32_t tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
         // the row first (gemv.h, the build-time prologue of the linear-order kernels), the step state behind it
-        const uint32_t pk = WB ? tid & (NPK - 1u) : tid; // (bfloat weights: 256 packets, threads 256.. read them again and add nothing)
+        const uint32_t pk = WB == 1 ? tid & (NPK - 1u) : tid; // (bfloat weights: 256 packets, threads 256.. read them again and add nothing)
         xr = reinterpret_cast<const rowv4*>(xp)[pk];
         nr = reinterpret_cast<const rowv4*>(normp)[pk];
         stamp(0);
@@ -196,7 +201,7 @@ struct qkv_in_launch {
                 ss += a * a;
                 ss += b * b;
             }
-            const float wsum_ = wave_sum_dpp(WB && tid >= NPK ? 0.0f : ss);
+            const float wsum_ = wave_sum_dpp(WB == 1 && tid >= NPK ? 0.0f : ss);
 #if MC_ABL_NORM_NOXWAVE
             float tot = wsum_ * 8.0f; // (ablation build, gemv.h: timing only)
 #else
@@ -223,8 +228,12 @@ struct qkv_in_launch {
         // then the shared pair; its address waits for the step state: asked for in at_start() that wait sat in the middle of
         // the weight requests)
         if constexpr (PMAXQ > 1) {
-            if (shared) request_shared_row();   // (wave-uniform, and the same for every wave of the launch: no wave's loads
-            else request_pair(PMAXQ - 1);       //  are "behind a branch" that another path of ITS OWN code does not take)
+            if constexpr (WB == 0) {
+                if (shared) request_shared_row();   // (wave-uniform, and the same for every wave of the launch: no wave's loads
+                else request_pair(PMAXQ - 1);       //  are "behind a branch" that another path of ITS OWN code does not take)
+            } else {
+                request_pair(PMAXQ - 1);
+            }
         }
         typedef const __attribute__((address_space(1))) float* gfloat_p;
         const uint32_t li = min(lane, cnt ? cnt - 1u : 0u), jm = li < full ? j0 + li : js;
@@ -241,8 +250,18 @@ struct qkv_in_launch {
         const uint32_t lane_tr = (((lane >> 4) * 4 + (lane & 3)) * 17 + ((lane >> 2) & 3) * 4) * 16;
         const m4b_lane m4bk = m4b_lane_consts(lane);
         typedef __attribute__((address_space(3))) mf_s4 lds_s4;
-        uint2 x[QN][8];
-        if constexpr (WB == 0) {
+        uint2 x[QN][WB == 2 ? 4 : 8];
+        if constexpr (WB == 2) {
+            // (int8: the lane's packet c of a row is weights 16 (64 c + lane) .. + 15: 32 bytes of the row in LDS)
+#pragma unroll
+            for (int c = 0; c < QN; c++) {
+                const uint4 v0 = *reinterpret_cast<const uint4*>(xs + (size_t)(c * 64 + lane) * 32), v1 = *reinterpret_cast<const uint4*>(xs + (size_t)(c * 64 + lane) * 32 + 16);
+                x[c][0] = make_uint2(v0.x, v0.y);
+                x[c][1] = make_uint2(v0.z, v0.w);
+                x[c][2] = make_uint2(v1.x, v1.y);
+                x[c][3] = make_uint2(v1.z, v1.w);
+            }
+        } else if constexpr (WB == 0) {
 #pragma unroll
             for (int c = 0; c < QN; c++) {
                 lds_s4* xt = (lds_s4*)(xs + c * CHUNK_LDS + lane_tr);
@@ -260,7 +279,20 @@ struct qkv_in_launch {
         }
         // one row: QN packets into one accumulator, the lane's own element, one wave sum (the stand-alone kernel's order)
         auto row_sum = [&](const uint4 (&w)[QN], const uint32_t (&sc)[QN], uint32_t hi) {
-            if constexpr (WB != 0) {
+            if constexpr (WB == 2) {
+                float a = 0.0f; // gemv.h mac<Q_EXACT> for int8 on bfloat rows, packets in order, one wave sum
+#pragma unroll
+                for (int c = 0; c < QN; c++) {
+                    xregs<BF, 16> xr;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        xr.v[2 * e] = x[c][e].x;
+                        xr.v[2 * e + 1] = x[c][e].y;
+                    }
+                    mac<Q_EXACT>(a, w[c], asf(hi ? (sc[c] & 0xFFFF0000u) : (sc[c] << 16)), xr, 0.0f, static_cast<fmt<WF_I8, BF>*>(nullptr));
+                }
+                return wave_sum_dpp(a);
+            } else if constexpr (WB != 0) {
                 float a = 0.0f; // gemv.h mac<WF_T>: four v_dot2_f32_bf16 per packet, packets in order, one wave sum
 #pragma unroll
                 for (int c = 0; c < QN; c++) {
@@ -356,7 +388,8 @@ struct qkv_in_launch {
 
 // LNCH = KiB of packed weights per Wo row (K = H * hd = 2048 LNCH); QN != 0: wq|wk|wv (rows of QN KiB) in this launch too -- qx
 // WB = 1: plain bfloat weights for Wo and wq|wk|wv (rows of LNCH / QN KiB = 512 LNCH / 512 QN weights; qkv_in_launch above)
-template <int HD, int LNCH, int QN = 0, int WB = 0>
+// TT: 64-slot score tiles per scoring wave (attn_fused_bf's T): 1 = 64 cache slots per workgroup, 4 = 256 (S = 8192 with one workgroup per CU)
+template <int HD, int LNCH, int QN = 0, int WB = 0, int TT = 1>
 __device__ __forceinline__ void
 attn_wo_body(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const bf16_t* __restrict__ vt, bf16_t* __restrict__ attn_out,
              unsigned long long* psum_g, unsigned long long* slab_g, unsigned long long* row_g, step_state* st, uint32_t n_rep,
@@ -369,11 +402,12 @@ attn_wo_body(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const 
              const float* fcos = nullptr, const float* fsin = nullptr, unsigned long long* qkv_g = nullptr, float eps = 0.0f, float mu = 0.0f,
              uint32_t kv_shift = 0)
 {
-    constexpr uint32_t K = WB ? 512u * LNCH : 2048u * LNCH;
+    constexpr uint32_t K = WB == 1 ? 512u * LNCH : (WB == 2 ? 1024u * LNCH : 2048u * LNCH);
+    constexpr uint32_t WPK = WB == 1 ? 8u : (WB == 2 ? 16u : 32u); // weights of a lane's 16-byte packet
     constexpr uint32_t CHUNK_LDS = 2048 * 2 / 16 * 17;  // a chunk of the row in LDS: 16 bytes of padding per 256 (gemv.h Q_M4D)
     constexpr uint32_t ROWB = 1024u * LNCH;              // bytes of weights per row
     // (QN != 0: the hidden row of the wq|wk|wv phase first, the attention row of the Wo phase later: hand-off C lies between them)
-    __shared__ __attribute__((aligned(16))) char xs[(LNCH > QN ? LNCH : QN) * (WB ? 1024u : CHUNK_LDS)];
+    __shared__ __attribute__((aligned(16))) char xs[(LNCH > QN ? LNCH : QN) * (WB == 1 ? 1024u : (WB == 2 ? 2048u : CHUNK_LDS))];
     __shared__ float qred[QN ? 16 : 1];
     __shared__ __attribute__((aligned(16))) bf16_t qkv_rows[QN ? 18 * HD : 8]; // queries of up to 16 heads, the K row, the V row
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -396,7 +430,7 @@ attn_wo_body(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const 
     // host takes this kernel only then).  Their weights are requested BEHIND the scores (attn_fused_bf's hook): at the start of the
     // launch they queue in front of the K tile in the CU's memory pipe (measured: 720 tokens/s against 732 with the Wo GEMV as a
     // launch of its own); behind the scores the hand-offs of the attention cover them.
-    constexpr int PMAX = WB ? 1 : 2; // (bfloat weights: a pair is 2 LNCH KiB = 32 registers at LNCH = 4)
+    constexpr int PMAX = WB ? 1 : 2; // (bfloat / int8 weights: a pair is 2 LNCH KiB = 32 registers at LNCH = 4)
     const uint32_t NP = out_rows / 2;
     uint32_t pb, pe;
     static_assert(MC_LIN_FAVOUR < 63, "with at most 16 pairs per workgroup (the host's condition) no wave may get a third");
@@ -442,12 +476,12 @@ attn_wo_body(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const 
                     const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow + (((size_t)r * ROWB + c * 1024) & lm64)));
                     ww[i][r][c] = make_uint4(v.x, v.y, v.z, v.w);
                 }
-            if constexpr (WB == 0) {
+            if constexpr (WB != 1) {
                 // scales: row quads [ceil(out / 4)][ngroups][4] bf16 (gemv.h); the dword (rows 2 pr, 2 pr + 1) of the lane's group
                 const char* srow = static_cast<const char*>(wo_s) + (((size_t)(pr >> 1) * ngroups) * 4 + (pr & 1u) * 2) * 2;
 #pragma unroll
                 for (int c = 0; c < LNCH; c++) {
-                    const uint32_t g = group ? ((2048u * c + 32u * lane) >> glog) : 0u;
+                    const uint32_t g = group ? ((64u * WPK * c + WPK * lane) >> glog) : 0u;
                     ws[i][c] = *reinterpret_cast<const uint32_t*>(srow + ((g * 8u) & lm));
                 }
             }
@@ -466,8 +500,9 @@ attn_wo_body(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const 
     };
     constexpr int TL_STRIDE = QN ? 16 : 8, TL_BASE = QN ? 3 : 0;
     if constexpr (QN != 0) {
-        attn_fused_bf<HD, 1, 8>(q, kc, vt, psum_g, slab_g, st, n_rep, KV, max_seq, scale, nsplit, layer_tag, tl, publish, request_wo, fastpath, qx, kv_shift);
+        attn_fused_bf<HD, TT, 8>(q, kc, vt, psum_g, slab_g, st, n_rep, KV, max_seq, scale, nsplit, layer_tag, tl, publish, request_wo, fastpath, qx, kv_shift);
     } else {
+        static_assert(QN != 0 || TT == 1, "wide ranges: with wq|wk|wv in the launch only");
         attn_fused_bf<HD, 1, 8>(q, kc, vt, psum_g, slab_g, st, n_rep, KV, max_seq, scale, nsplit, layer_tag, tl, publish, request_wo, fastpath);
     }
     // tl != null (tools/attn_wo_timeline.py only): thread 0 of every workgroup leaves s_memrealtime stamps of its phases
@@ -536,7 +571,17 @@ attn_wo_body(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const 
         float rsum[2];
 #pragma unroll
         for (int r = 0; r < 2; r++) {
-            if constexpr (WB != 0) {
+            if constexpr (WB == 2) {
+                float a = 0.0f; // gemv.h mac<Q_EXACT> for int8: packets in order, one wave sum
+#pragma unroll
+                for (int c = 0; c < LNCH; c++) {
+                    xregs<BF, 16> xr;
+                    xr.load(xs + (size_t)(c * 64 + lane) * 32, 0);
+                    const uint32_t raw = ws[i][c];
+                    mac<Q_EXACT>(a, ww[i][r][c], asf(r ? (raw & 0xFFFF0000u) : (raw << 16)), xr, 0.0f, static_cast<fmt<WF_I8, BF>*>(nullptr));
+                }
+                rsum[r] = wave_sum_dpp(a);
+            } else if constexpr (WB != 0) {
                 float a = 0.0f; // gemv.h mac<WF_T>: four v_dot2_f32_bf16 per packet, packets in order, one wave sum
 #pragma unroll
                 for (int c = 0; c < LNCH; c++) {
@@ -618,6 +663,21 @@ MC_ATTN_QKV_WO(mc_attn_qkv_wo_i4_bfloat_hd128_k2_q2, 128, 2, 2)  // Llama-3-8B: 
                                       qkv_g, eps, mu, kv_shift);                                                                         \
     }
 MC_ATTN_QKV_WO_W(mc_attn_qkv_wo_w_bfloat_hd64_k4_q4, 64, 4, 4)  // Llama-3.2-1B: dim 2048, 32 heads x 64, bf16 weights
+// ... with int8 weights: mc_attn_qkv_wo_i8_bfloat_hd{head_dim}_k{KiB per Wo row}_q{KiB per wq|wk|wv row}_t{64-slot tiles per scoring wave}
+#define MC_ATTN_QKV_WO_I8(NAME, HD, LNCH, QN, TT)                                                                                         \
+    extern "C" __global__ void __launch_bounds__(512)                                                                                    \
+    NAME(const bf16_t* kc, const bf16_t* vt, bf16_t* attn_out, unsigned long long* psum_g, unsigned long long* slab_g,                  \
+         unsigned long long* row_g, unsigned long long* qkv_g, step_state* st, uint32_t n_rep, uint32_t n_kv, uint32_t max_seq,         \
+         float scale, uint32_t nsplit, uint32_t layer_tag, const void* wo_w, const void* wo_s, const bf16_t* x, bf16_t* y,              \
+         uint32_t out_rows, uint32_t group, const void* qnorm_w, const void* qkv_w, const void* qkv_s, const float* fcos, const float* fsin, float eps,    \
+         float mu, uint32_t fastpath, unsigned long long* tl, uint32_t kv_shift)                                                         \
+    {                                                                                                                                    \
+        attn_wo_body<HD, LNCH, QN, 2, TT>(nullptr, kc, vt, attn_out, psum_g, slab_g, row_g, st, n_rep, n_kv, max_seq, scale, nsplit,     \
+                                          layer_tag, wo_w, wo_s, x, y, out_rows, group, 1u, fastpath, tl, qnorm_w, qkv_w, qkv_s, fcos,   \
+                                          fsin, qkv_g, eps, mu, kv_shift);                                                               \
+    }
+MC_ATTN_QKV_WO_I8(mc_attn_qkv_wo_i8_bfloat_hd128_k4_q4_t1, 128, 4, 4, 1)  // Llama-3-8B int8, S <= 2048
+MC_ATTN_QKV_WO_I8(mc_attn_qkv_wo_i8_bfloat_hd128_k4_q4_t4, 128, 4, 4, 4)  // ... S = 8192: 256-slot ranges, one workgroup per CU
 
 // mc_attn_wo_i4_bfloat_hd{head_dim}_k{KiB per Wo row}
 MC_ATTN_WO(mc_attn_wo_i4_bfloat_hd128_k2, 128, 2)  // Llama-3-8B: 32 heads x 128

@@ -873,7 +873,8 @@ attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const
     constexpr bool V_LATE = QSrc::LDS && !QSrc::PIN_V;
     if constexpr (!V_LATE) request_v();
     if constexpr (QSrc::LDS) {
-        static_assert(T == 1, "queries computed in the launch: 64-slot ranges");
+        // (T > 1, round 5: wider ranges -- mc_attn_qkv_wo_i8_*_t4, S = 8192 with one 512-thread workgroup per CU; every tile of the
+        //  step's slot is patched below)
         // the tile requests stay HERE, in front of the phase that computes the queries (a value used on a never-taken path cannot
         // be sunk past the branch, and is not waited for on the path that is taken)
         uint32_t never;
@@ -884,10 +885,14 @@ attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const
             //  against 12.1 + 5.0 for the two launches it replaces)
             if constexpr (QSrc::PIN_V) {
 #pragma unroll
-                for (int b = 0; b < NB; b++) asm volatile("" ::"v"(vb[0][b][0].x), "v"(vb[0][b][1].w));
+                for (int t = 0; t < T; t++)
+#pragma unroll
+                    for (int b = 0; b < NB; b++) asm volatile("" ::"v"(vb[t][b][0].x), "v"(vb[t][b][1].w));
             }
 #pragma unroll
-            for (int ks = 0; ks < KS; ks++) asm volatile("" ::"v"(kb[0][ks].x));
+            for (int t = 0; t < T; t++)
+#pragma unroll
+                for (int ks = 0; ks < KS; ks++) asm volatile("" ::"v"(kb[t][ks].x));
         }
         qsrc.before_scores();
     }
@@ -907,10 +912,12 @@ attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const
     if constexpr (QSrc::LDS) {
         // the step's own row: its slot of the K tile comes from LDS (q_from_hbm's note); its column of the V tile in front of P.V
         ws = (uint32_t)st->write_slot;
-        if (scorer && p_begin + wave * 16 + col == ws) {
 #pragma unroll
-            for (int ks = 0; ks < KS; ks++) kb[0][ks] = *(const __attribute__((address_space(3))) uint4*)(qsrc.k_s + ks * 32 + c * 8);
-        }
+        for (int t = 0; t < T; t++)
+            if (scorer && p_begin + t * PB + wave * 16 + col == ws) {
+#pragma unroll
+                for (int ks = 0; ks < KS; ks++) kb[t][ks] = *(const __attribute__((address_space(3))) uint4*)(qsrc.k_s + ks * 32 + c * 8);
+            }
     }
     const uint32_t S = (uint32_t)st->kv_len;
     const uint32_t tag = st->epoch * 256u + layer_tag;
@@ -1039,15 +1046,17 @@ attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const
                 const uint32_t db = wave + NW * b;
                 const uint32_t vnew = (uint32_t)qsrc.v_s[(db < (uint32_t)NDB ? db : 0u) * 16 + col];
 #pragma unroll
+                for (int t = 0; t < T; t++)
+#pragma unroll
                 for (int u = 0; u < 2; u++) {
-                    const uint32_t e = ws - (p_begin + u * 32 + c * 8); // element of the lane's eight slots, if < 8
-                    uint32_t w4[4] = {vb[0][b][u].x, vb[0][b][u].y, vb[0][b][u].z, vb[0][b][u].w};
+                    const uint32_t e = ws - (p_begin + t * PB + u * 32 + c * 8); // element of the lane's eight slots, if < 8
+                    uint32_t w4[4] = {vb[t][b][u].x, vb[t][b][u].y, vb[t][b][u].z, vb[t][b][u].w};
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
                         const uint32_t lo = (w4[i] & 0xFFFF0000u) | vnew, hi = (w4[i] & 0x0000FFFFu) | (vnew << 16);
                         w4[i] = e == 2u * i ? lo : (e == 2u * i + 1u ? hi : w4[i]);
                     }
-                    vb[0][b][u] = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+                    vb[t][b][u] = make_uint4(w4[0], w4[1], w4[2], w4[3]);
                 }
             }
         }

@@ -247,7 +247,7 @@ def test_attention_and_wo_in_one_launch_matches_the_oracle(acc, shape, n, fast):
 
 @pytest.mark.parametrize("fast", [1, 0])
 @pytest.mark.parametrize("n", [2048, 1000, 1, 65])
-@pytest.mark.parametrize("shape", ["llama3-8b-int4", "llama3.2-1b-bf16", "tinyllama-bf16"])
+@pytest.mark.parametrize("shape", ["llama3-8b-int4", "llama3.2-1b-bf16", "tinyllama-bf16", "llama3-8b-int8", "llama3-8b-int8-8192"])
 def test_norm_qkv_rope_attention_and_wo_in_one_launch_matches_the_oracle(acc, n, fast, shape):
     """`mc_attn_qkv_wo_i4_bfloat_hd128_k2_q2` (attn_block_kernels.hip qkv_in_launch: attention_norm, wq|wk|wv, RoPE, the cache
     write, the decode attention, Wo and the residual of one block -- nn/transformer.h:130-133, nn/attention.h:170-205 -- the kernel
@@ -263,21 +263,27 @@ def test_norm_qkv_rope_attention_and_wo_in_one_launch_matches_the_oracle(acc, n,
     #  the reference's default model, src/llama.cc:19-31)
     # (the third: TinyLlama's 4 kv heads x 8 query heads, launched as 8 VIRTUAL kv heads of 4 query heads -- kv_shift = 1, round 5,
     #  decode_kernels.hip attn_fused_bf: two virtual heads read one cache head and write its new row, the same bits, twice)
+    # (the fourth and fifth: int8 weights, round 5 -- `mc_attn_qkv_wo_i8_bfloat_hd128_k4_q4_t1` with 64-slot ranges and `_t4` with 256-slot
+    #  ranges at max_seq_len 8192, where the cache is filled up to n x 4 rows so that ranges are full, ragged and empty as in the others)
     int4 = shape == "llama3-8b-int4"
-    H, KV, hd, dim, max_seq = (32, 8, 128, 4096, 2048) if int4 else (32, 4 if shape == "tinyllama-bf16" else 8, 64, 2048, 2048)
+    int8 = shape.startswith("llama3-8b-int8")
+    tiles = 4 if shape == "llama3-8b-int8-8192" else 1
+    H, KV, hd, dim, max_seq = (32, 8, 128, 4096, 2048 * tiles) if (int4 or int8) else (32, 4 if shape == "tinyllama-bf16" else 8, 64, 2048, 2048)
+    if tiles == 4:
+        n = n * 4
     vsh = 1 if shape == "tinyllama-bf16" else 0
     KVV = KV << vsh
     half = hd // 2
     cfg = mg.tiny_cfg(BF16, dim=dim, n_heads=H, n_kv_heads=KV, head_dim=hd, ffn_dim=256, n_layers=1, vocab=64, max_seq_len=max_seq)
-    w = mg.make_model(cfg, seed=303, quant="i4" if int4 else None, group=128)
-    dec = mc.Decoder(acc, **(mg.decoder_kwargs(cfg, weight_format=mc.WFMT_I4, group_size=128) if int4 else mg.decoder_kwargs(cfg)))
+    w = mg.make_model(cfg, seed=303, quant="i4" if int4 else ("i8" if int8 else None), group=128)
+    dec = mc.Decoder(acc, **(mg.decoder_kwargs(cfg, weight_format=mc.WFMT_I4 if int4 else mc.WFMT_I8, group_size=128) if (int4 or int8) else mg.decoder_kwargs(cfg)))
     dec.load_model(w)
     lw = w["layers"][0]
     wo_p, wo_s, rows, inf, _ = dec.weight_ptrs(0, "wo")
     qk_p, qk_s, qrows, qinf, _ = dec.weight_ptrs(0, "qkv")
     assert (rows, inf, qrows, qinf) == (dim, H * hd, (H + 2 * KV) * hd, dim)
     rng = np.random.default_rng(1000 + n)
-    n_rep, nsplit = H // KV, max_seq // PB
+    n_rep, nsplit = H // KV, max_seq // (PB * tiles)
     slot, rrow, nrows = n - 1, 5, 8            # the step writes slot n - 1 and reads n slots
     x = dyadic_row(rng, dim)
     k = mo.encode(BF16, rng.normal(0, 0.4, (n, KV, hd)).astype(np.float32))
@@ -312,7 +318,7 @@ def test_norm_qkv_rope_attention_and_wo_in_one_launch_matches_the_oracle(acc, n,
     attn_out = acc.alloc(H * hd * 2)
     nw = acc.to_device(lw["attention_norm"])
     cb, sb = acc.to_device(fcos.reshape(-1)), acc.to_device(fsin.reshape(-1))
-    kern = acc.load("mc_attn_qkv_wo_i4_bfloat_hd128_k2_q2" if int4 else "mc_attn_qkv_wo_w_bfloat_hd64_k4_q4")
+    kern = acc.load("mc_attn_qkv_wo_i4_bfloat_hd128_k2_q2" if int4 else (f"mc_attn_qkv_wo_i8_bfloat_hd128_k4_q4_t{tiles}" if int8 else "mc_attn_qkv_wo_w_bfloat_hd64_k4_q4"))
     W = lambda p_: acc.wrap(p_, 1 << 40) if p_ else None
     for epoch, layer_tag in ((1, 1), (1, 2), (9, 200)):
         hb = acc.to_device(x)                  # read as the block input and the residual, overwritten IN PLACE, as the decoder launches it
@@ -323,7 +329,7 @@ def test_norm_qkv_rope_attention_and_wo_in_one_launch_matches_the_oracle(acc, n,
         mc.KernelTask(kern, (nsplit * KVV * 512, 1, 1), (512, 1, 1),
                       [kc, vt, attn_out, psum, slab, row_g, qkv_g, state, np.uint32(n_rep >> vsh), np.uint32(KVV), np.uint32(max_seq),
                        np.float32(scale), np.uint32(nsplit), np.uint32(layer_tag), W(wo_p), W(wo_s), hb, hb, np.uint32(dim),
-                       np.uint32(128 if int4 else 0), nw, W(qk_p), W(qk_s), cb, sb, np.float32(1e-5), np.float32(0.0), np.uint32(fast), None,
+                       np.uint32(128 if (int4 or int8) else 0), nw, W(qk_p), W(qk_s), cb, sb, np.float32(1e-5), np.float32(0.0), np.uint32(fast), None,
                        np.uint32(vsh)])()
         acc.wait()
         assert int(state.download(np.int32, 12)[10]) == 0, "a hand-off of the launch gave up"
