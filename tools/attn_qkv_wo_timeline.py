@@ -5,7 +5,8 @@ argument, null in the product): Llama-3-8B shapes, a full cache of 2048 slots, t
   0 start  1 hidden row normalised and staged  2 the wave's wq|wk|wv pairs published  11 hand-off Q done (queries, K / V row in LDS)
   4 scores + exp done  5 hand-off A done  6 P.V done  7 partial rows published  8 hand-off B + reduce done
   9 hand-off C done, attention row staged  10 Wo pairs stored
-usage: [MC_HANDOFF_FAST=0] attn_qkv_wo_timeline.py [launches=32]"""
+usage: [MC_HANDOFF_FAST=0] [FMT=i8 [TILES=4]] attn_qkv_wo_timeline.py [launches=32]
+FMT=i8: mc_attn_qkv_wo_i8_bfloat_hd128_k4_q4_t{TILES} (round 5): TILES = 1 at S = 2048, 4 at S = 8192 (256-slot ranges)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -16,12 +17,14 @@ import modelgen as mg
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 FAST = int(os.environ.get("MC_HANDOFF_FAST", "1"))
-H, KV, hd, S, dim = 32, 8, 128, 2048, 4096
-n_rep, nsplit = H // KV, S // 64
+I8 = os.environ.get("FMT") == "i8"
+TILES = int(os.environ.get("TILES", "4")) if I8 else 1
+H, KV, hd, S, dim = 32, 8, 128, 2048 * TILES, 4096
+n_rep, nsplit = H // KV, S // (64 * TILES)
 acc = mc.HardwareAccelerator()
 cfg = dict(dtype=0, n_layers=2, vocab=2048, norm_eps=1e-5, max_seq_len=S, family=0, dim=dim, n_heads=H, n_kv_heads=KV, head_dim=hd, ffn_dim=1024,
            rope_theta=500000.0, attn_scale=hd ** -0.5)
-dec = mc.Decoder(acc, **mg.decoder_kwargs(cfg, weight_format=mc.WFMT_I4, group_size=128))
+dec = mc.Decoder(acc, **mg.decoder_kwargs(cfg, weight_format=mc.WFMT_I8 if I8 else mc.WFMT_I4, group_size=128))
 dec.init_synthetic(7)
 wo = [dec.weight_ptrs(l, "wo") for l in (0, 1)]
 qkv = [dec.weight_ptrs(l, "qkv") for l in (0, 1)]
@@ -39,7 +42,7 @@ row_g = acc.to_device(np.zeros(H * hd // 2, np.uint64))
 qkv_g = acc.to_device(np.zeros(2 * (H + 2 * KV) * hd // 2, np.uint64))
 WGS = nsplit * KV
 tl = acc.alloc(N * WGS * 16 * 8)
-k = acc.load("mc_attn_qkv_wo_i4_bfloat_hd128_k2_q2")
+k = acc.load(f"mc_attn_qkv_wo_i8_bfloat_hd128_k4_q4_t{TILES}" if I8 else "mc_attn_qkv_wo_i4_bfloat_hd128_k2_q2")
 W = lambda p: acc.wrap(p, 1 << 40)
 order = [0, 1, 2, 11, 4, 5, 6, 7, 8, 9, 10]
 names = ["start -> row staged", "wq|wk|wv pairs + rope + publish", "hand-off Q", "scores + exp", "hand-off A (denominators)", "P.V",
