@@ -297,6 +297,8 @@ struct mc_decoder {
     unsigned long long* attn_slab_g = nullptr; // [KV][nsplit][n_rep][hd] fp32 partial P.V sums
     unsigned long long* attn_row_g = nullptr;  // [H * hd / 2]          the finished attention row, two bf16 per granule (mc_attn_wo_*)
     unsigned long long* attn_qkv_g = nullptr;  // [KV][(n_rep + 2) hd / 2] the step's rotated queries and K / V row, two bf16 per granule (mc_attn_qkv_wo_*)
+    bool attn_qkv_qkn_on = true; // MC_ATTN_QKV_QKN=0: gemma3's wq|wk|wv GEMV as a launch of its own in front of mc_attn_wo_qkn_* (A/B, parity)
+    bool attn_wo_qkn_on = true;  // MC_ATTN_WO_QKN=0: gemma3's q/k-norm + rope + cache write + attention as mc_attn_fused_qkn_T, Wo as a GEMV of its own (A/B, parity)
     bool attn_qkn_on = true;     // MC_ATTN_QKN=0: gemma3's q/k-norm + rope + cache write as a launch of their own (mc_rope_kv_T) in front of the attention (A/B, parity)
     bool attn_qkv_on = true;     // MC_ATTN_QKV=0: wq|wk|wv as a launch of its own in front of mc_attn_wo_* (A/B, parity)
     // ---- what happens when an in-launch hand-off gives up (its workgroups were not resident together: another stream or process
@@ -309,7 +311,7 @@ struct mc_decoder {
     hipEvent_t err_evt = nullptr;
     bool err_pending = false;
     int handoff_fallbacks = 0;
-    int occ_fused = -1, occ_wo = -1, occ_wo_w = -1, occ_wo_i8 = -1;   // co-resident workgroups per CU of the hand-off launches (the occupancy API's answer; -1: not asked yet)
+    int occ_fused = -1, occ_wo = -1, occ_wo_w = -1, occ_wo_i8 = -1, occ_wo_qkn = -1, occ_qkv_qkn = -1;   // co-resident workgroups per CU of the hand-off launches (the occupancy API's answer; -1: not asked yet)
     bool handoff_fast = true;    // MC_HANDOFF_FAST=0: hand-offs A and B through the fabric only (A/B; handoff.h "the XCD-local fast path")
     bool attn_wo_on = true;      // MC_ATTN_WO=0: the Wo GEMV as a launch of its own behind the one-launch attention (A/B, parity)
     bool attn_fused_on = true;   // MC_ATTN_FUSED=0: scores and P.V as two launches (A/B, parity)
@@ -702,6 +704,8 @@ struct mc_decoder {
         occ_wo = ask("mc_attn_wo_i4_bfloat_hd" + std::to_string(hd) + "_k" + std::to_string(k), 512);
         occ_wo_w = hd == 64 ? ask("mc_attn_qkv_wo_w_bfloat_hd64_k4_q4", 512) : 0;
         occ_wo_i8 = hd == 128 ? ask("mc_attn_qkv_wo_i8_bfloat_hd128_k4_q4_t4", 512) : 0;
+        occ_wo_qkn = hd == 256 ? ask("mc_attn_wo_qkn_i4_bfloat_hd256_k2_t2", 512) : 0;
+        occ_qkv_qkn = hd == 256 ? ask("mc_attn_qkv_wo_qkn_i4_bfloat_hd256_k2_p2_t2", 512) : 0;
         (void)hipGetLastError();
     }
     // a hand-off gave up: report nothing yet, make the NEXT launches independent of co-residency
@@ -728,6 +732,35 @@ struct mc_decoder {
         // (one 512-thread workgroup per CU: the kernels hold up to 132 VGPRs, two such workgroups would not be resident together)
         return built && wo.in == cfg.n_heads * hd && (unsigned)wo.out / 2 <= 2u * 8u * (unsigned)(nsplit * cfg.n_kv_heads) &&
                (unsigned)(nsplit * cfg.n_kv_heads) <= (unsigned)dev->prop.multiProcessorCount;
+    }
+
+    // gemma3 (round 5): q_norm / k_norm + rotation + cache write + attention + Wo in ONE launch from the raw wq|wk|wv rows
+    // (mc_attn_wo_qkn_i4_bfloat_hd256_k2_t{1,2}: one 512-thread workgroup per CU, ranges of 64 or 128 slots -- Gemma-7B's 16 kv heads at
+    // S = 2048 are 16 x 16).  Returns the 64-slot tiles per range, 0: not this form.
+    int
+    attn_wo_qkn_tiles(const linear_w& wo) const
+    {
+        if (!attn_wo_qkn_on || !attn_wo_on || !attn_qkn_on || !attn_fused_on || !attn_psum_g || !attn_row_g || tb != 2 || n_own > 254) return 0;
+        if (cfg.family != MC_FAMILY_GEMMA3 || cfg.head_dim != 256 || occ_wo_qkn == 0 || !lin_ok(wo) || wo.lora_cols || wo.out % 2 != 0) return 0;
+        if (wo.in != 4096 || wo.in != cfg.n_heads * cfg.head_dim || cfg.n_heads / cfg.n_kv_heads > 16) return 0;
+        for (int tiles = 1; tiles <= 2; tiles *= 2) {
+            if (nsplit % tiles != 0 || cfg.max_seq_len % (64 * tiles) != 0) continue;
+            const unsigned grid = (unsigned)(nsplit / tiles * cfg.n_kv_heads);
+            if (grid <= (unsigned)dev->prop.multiProcessorCount && (unsigned)wo.out / 2 <= 2u * 8u * grid) return tiles;
+        }
+        return 0;
+    }
+
+    // ... with wq|wk|wv and the block's norms in the launch too (mc_attn_qkv_wo_qkn_i4_bfloat_hd256_k2_p{1,2}_t2, attn_block_kernels.hip
+    // qkv_qkn_in_launch): rows of 1.5 KiB (K = 3072), the kv head's (n_rep + 2) hd / 2 rotation pairs dealt evenly over its ranges, at most
+    // three per wave, one thread per pair in the hand-off
+    bool
+    attn_qkv_wo_qkn_ok(const layer_w& L) const
+    {
+        if (!attn_qkv_qkn_on || !attn_qkv_on || !attn_qkv_g || occ_qkv_qkn == 0 || attn_wo_qkn_tiles(L.wo) != 2) return false;
+        if (!lin_split_ok(L.qkv) || L.qkv.lora_cols || L.qkv.in != 3072 || cfg.dim != 3072 || L.qkv.group != L.wo.group) return false;
+        const int hd = cfg.head_dim, n_rep = cfg.n_heads / cfg.n_kv_heads, pg = (n_rep + 2) * hd / 2, ns = nsplit / 2;
+        return L.qkv.out == (cfg.n_heads + 2 * cfg.n_kv_heads) * hd && pg <= 512 && pg % ns == 0 && pg / ns <= 24;
     }
 
     // The XCD-local fast path of hand-offs A / B / Q (handoff.h) pays where the workgroups of one kv head CAN share an XCD: they
@@ -1037,7 +1070,8 @@ struct mc_decoder {
             const bool qkv_w_in = attn_qkv_wo_w_fused(L);
             const int i8_tiles = qkv_w_in ? 0 : attn_qkv_wo_i8_tiles(L);
             const bool qkv_in = qkv_w_in || i8_tiles || attn_qkv_wo_fused(L);
-            bool qkn_in = false;
+            bool qkn_in = false, gq = false;
+            int qkn_wo = 0;
             if (qkv_in) {
                 // attention_norm, wq|wk|wv, rope, cache write, scores, softmax, P.V, wo + residual (transformer.h:130-133,
                 // attention.h:170-205) in ONE launch: every hand-off but the last stays inside one kv head
@@ -1063,6 +1097,30 @@ struct mc_decoder {
                 // (transformer.h:130, attention.h:170-177)
                 s = gemv(L.qkv, 1, 4, x, qkv, L.qkv_epi, L.attention_norm, mu);
                 if (s != MC_OK) return s;
+            } else if ((gq = attn_qkv_wo_qkn_ok(L))) {
+                // gemma3, ONE launch from the row handed to the block to Wo's output: (the previous block's ffn post-norm + residual,)
+                // attention_norm, wq|wk|wv, q_norm / k_norm, rope, cache write, scores, softmax, P.V, wo (transformer.h:126-133,
+                // attention.h:170-205); the attention post-norm and its residual are the w1|w3 GEMV's prologue (or mc_rmsnorm_row below)
+                postnorm_args_h h{};
+                if (pending_pn) {
+                    const auto it = pn_host.find(pending_pn);
+                    if (it == pn_host.end()) return fail(MC_ERR_RUNTIME, "attention block: unknown post-norm descriptor");
+                    h = it->second;
+                }
+                const int ns = nsplit / 2;
+                s = launch(std::string("mc_attn_qkv_wo_qkn_i4_") + tname + "_hd256_k2_p" + (pending_pn ? "2" : "1") + "_t2", (unsigned)(ns * KV), 1, 1, 512, 0,
+                           pack((const void*)L.kc, (const void*)L.vt, attn_out, attn_psum_g, attn_slab_g, attn_row_g, attn_qkv_g, state,
+                                (uint32_t)n_rep, (uint32_t)KV, (uint32_t)cfg.max_seq_len, scale_T, (uint32_t)ns, (uint32_t)(li + 1),
+                                (const void*)L.wo.w, (const void*)L.wo.scales, pending_pn ? (const void*)proj : x, proj, (uint32_t)L.wo.out,
+                                (uint32_t)L.wo.group, (const void*)L.attention_norm, (const void*)L.qkv.w, (const void*)L.qkv.scales,
+                                (const float*)rope_cos[L.rope_table], (const float*)rope_sin[L.rope_table], cfg.norm_eps, mu,
+                                (uint32_t)(handoff_fast_here() ? 1 : 0), (void*)nullptr, (const void*)L.q_norm, (const void*)L.k_norm,
+                                (const void*)h.post_w, (const void*)h.res, (void*)h.h_out));
+                if (s != MC_OK) return s;
+                if (pending_pn) {
+                    pending_pn = nullptr;
+                    x = hidden;
+                }
             } else {
                 // gemma3 normalises q and k per head before the rotation (attention.h:174-175):
                 // that needs whole heads, so rope + cache write stay a launch of their own
@@ -1078,8 +1136,9 @@ struct mc_decoder {
                 if (s != MC_OK) return s;
                 // q_norm / k_norm + rope + cache write: inside the one-launch attention where that is what follows
                 // (mc_attn_fused_qkn_bfloat, decode_kernels.hip q_from_qkv_rows), a launch of their own otherwise
-                qkn_in = attn_qkn_on && tb == 2 && (hd == 128 || hd == 256) && attn_fused() && !attn_wo_fused(L.wo);
-                if (!qkn_in) {
+                qkn_wo = attn_wo_qkn_tiles(L.wo);
+                qkn_in = !qkn_wo && attn_qkn_on && tb == 2 && (hd == 128 || hd == 256) && attn_fused() && !attn_wo_fused(L.wo);
+                if (!qkn_in && !qkn_wo) {
                     s = launch("mc_rope_kv_" + tname, H + 2 * KV, 1, 1, hd / 2, 0,
                                pack(qkv, q_rot, L.kc, L.vt, rope_cos[L.rope_table], rope_sin[L.rope_table],
                                     L.q_norm, L.k_norm, state, (uint32_t)H, (uint32_t)KV, (uint32_t)hd,
@@ -1088,6 +1147,28 @@ struct mc_decoder {
                 }
             }
             if (qkv_in) {
+            } else if (gq) {
+                if (!fuse_pn) {
+                    s = launch("mc_rmsnorm_row_" + tname, 1, 1, 1, 1024, 0,
+                               pack(proj, L.attention_post_norm, x, hidden, (uint32_t)dim, cfg.norm_eps, mu));
+                    if (s != MC_OK) return s;
+                }
+            } else if (qkn_wo) {
+                // q_norm / k_norm, rope, cache write, scores, softmax, P.V, wo (attention.h:170-205) in ONE launch; the post-norm and the
+                // residual are the next GEMV's prologue (or mc_rmsnorm_row below)
+                const int ns = nsplit / qkn_wo;
+                s = launch("mc_attn_wo_qkn_i4_" + tname + "_hd256_k2_t" + std::to_string(qkn_wo), (unsigned)(ns * KV), 1, 1, 512, 0,
+                           pack((const void*)qkv, (const void*)L.kc, (const void*)L.vt, attn_out, attn_psum_g, attn_slab_g, attn_row_g, state,
+                                (uint32_t)n_rep, (uint32_t)KV, (uint32_t)cfg.max_seq_len, scale_T, (uint32_t)ns, (uint32_t)(li + 1),
+                                (const void*)L.wo.w, (const void*)L.wo.scales, (const void*)nullptr, proj, (uint32_t)L.wo.out, (uint32_t)L.wo.group,
+                                (uint32_t)0, (uint32_t)(handoff_fast_here() ? 1 : 0), (void*)nullptr, (const void*)L.q_norm, (const void*)L.k_norm,
+                                (const float*)rope_cos[L.rope_table], (const float*)rope_sin[L.rope_table], cfg.norm_eps, mu));
+                if (s != MC_OK) return s;
+                if (!fuse_pn) {
+                    s = launch("mc_rmsnorm_row_" + tname, 1, 1, 1, 1024, 0,
+                               pack(proj, L.attention_post_norm, x, hidden, (uint32_t)dim, cfg.norm_eps, mu));
+                    if (s != MC_OK) return s;
+                }
             } else if (attn_wo_fused(L.wo)) {
                 // scores, softmax, P.V, wo + residual  (attention.h:191-205, transformer.h:132-133) in ONE launch
                 s = launch("mc_attn_wo_i4_" + tname + "_hd" + std::to_string(hd) + "_k" + std::to_string(L.wo.in / 2048),
@@ -1983,6 +2064,8 @@ mc_decoder_create(mc_device* dev, mc_library* lib, mc_queue* q, const mc_decoder
     if (const char* e = getenv("MC_HANDOFF_FAST")) d->handoff_fast = atoi(e) != 0;
     if (const char* e = getenv("MC_ATTN_QKV")) d->attn_qkv_on = atoi(e) != 0;
     if (const char* e = getenv("MC_ATTN_QKN")) d->attn_qkn_on = atoi(e) != 0;
+    if (const char* e = getenv("MC_ATTN_WO_QKN")) d->attn_wo_qkn_on = atoi(e) != 0;
+    if (const char* e = getenv("MC_ATTN_QKV_QKN")) d->attn_qkv_qkn_on = atoi(e) != 0;
     if (const char* e = getenv("MC_LAZY_PICK")) d->lazy_pick_on = atoi(e) != 0;
     if (const char* e = getenv("MC_PF2")) d->pf2_on = atoi(e) != 0;
     if (const char* e = getenv("MC_KV_VIRTUAL")) d->kv_virtual_on = atoi(e) != 0;

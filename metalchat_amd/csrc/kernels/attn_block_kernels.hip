@@ -386,10 +386,298 @@ struct qkv_in_launch {
     }
 };
 
+
+// ------------------------------------------------------------------------------------------
+// gemma3 (round 5, mc_attn_qkv_wo_qkn_*): wq|wk|wv of a gemma3 block INSIDE the attention launch -- what qkv_in_launch does for Llama, with
+// the three things gemma3 adds (include/metalchat/nn/gemma.h:110-137, nn/attention.h:170-177, nn/transformer.h:126-141):
+//   * rows of 1.5 KiB (K = 3072, Gemma-7B): a rotation pair of rows is one 3 KiB SUPER ROW swept against the hidden row staged
+//     twice in LDS ([x, x]) -- gemv.h LSPLIT, the arithmetic of mc_gemv_i4_bfloat_lin3s_p{1,2}_e0 addition for addition: one accumulator
+//     per 1 KiB packet, the middle packet split between the two rows by a lane mask, one wave sum per row;
+//   * P2: the previous linear's post-norm, its residual add and this block's pre-norm in the prologue (gemv.h PRO_POSTNORM: h = T(res +
+//     T((mu + post_w) x rsqrt(mean(x^2) + eps))), left in HBM by workgroup 0; row = T((mu + norm_w) h rsqrt(mean(h^2) + eps)));
+//   * q_norm / k_norm over WHOLE heads before the rotation: the pairs are handed over RAW (T(row sum), as the GEMV's plain store leaves
+//     them) and every workgroup of the kv head normalises and rotates the 2 hd values it gathered -- thread t holds pair t of the
+//     head's (n_rep + 2) hd / 2, i.e. exactly the (head, j) that mc_rope_kv_T / q_from_qkv_rows give thread t: the same wave_sum tree,
+//     the wave sums added in wave order; the workgroup whose range holds the step's slot writes the K row and the V column.
+// At most three pairs per wave (Gemma-7B at S = 2048: 384 pairs per kv head over 16 ranges x 8 waves), (n_rep + 2) hd / 2 <= 512.
+template <int HD, int P2>
+struct qkv_qkn_in_launch {
+    static_assert(HD == 256, "gemma3 with head_dim 256 (hd / 2 threads per head are whole waves)");
+    static constexpr bool LDS = true, PIN_V = true;
+    static constexpr int TL_STRIDE = 16, TL_BASE = 3; // stamps: 0 start, 1 row staged, 2 pairs published, 3.. attn_fused_bf's 0.., 11 rows normalised
+    static constexpr uint32_t KQ = 3072u, NPK = KQ / 8, ROWB2 = 3072u, CHUNK_LDS = 2048 * 2 / 16 * 17, HALF = HD / 2, WPH = HALF / 64;
+    static constexpr int PMAXQ = 3, NCH = 3;
+    typedef const __attribute__((address_space(3))) bf16_t* lds_row;
+    typedef __attribute__((address_space(3))) bf16_t* lds_row_w;
+    typedef uint32_t rowv4 __attribute__((ext_vector_type(4)));
+    lds_row q_s, k_s, v_s;
+    // ---- what the launch was given
+    const void *xp, *normp, *postp, *resp, *qw, *qs;
+    void* h_out;
+    const bf16_t *q_norm, *k_norm;
+    const float *fcos, *fsin;
+    bf16_t *kc, *vt;
+    unsigned long long* qkv_g;
+    step_state* st;
+    char* xs;   // [x, x] in LDS: three chunks of 2048, padded for the transposed reads
+    float* red; // 32 floats of scratch
+    uint32_t n_rep, KV, max_seq, nsplit, group, layer_tag, fastpath, split_slots;
+    float eps, mu;
+    unsigned long long* tl;
+    // ---- what at_start() leaves for the later phases
+    rowv4 xr, nr, pwr, rrr;
+    uint4 ww[PMAXQ][NCH];
+    uint32_t wsc[PMAXQ][NCH];
+    uint32_t nq0, nq1, nk0, nk1; // (the norm weights' bits, zero-extended: 2-byte members of a policy passed by value went through scratch)
+    float pc, ps;
+    uint32_t j0, full, slot, tag, rrow_;
+
+    __device__ __forceinline__ void stamp(int i) const
+    {
+        if (tl && threadIdx.x == 0) tl[(size_t)blockIdx.x * TL_STRIDE + i] = __builtin_amdgcn_s_memrealtime();
+    }
+    // packed pair of pair j of kv head `kv`: q heads of the group, then its k head, then its v head (rotation partners adjacent)
+    __device__ __forceinline__ uint32_t pp_of(uint32_t kv, uint32_t j) const
+    {
+        const uint32_t hq = n_rep * HALF, H = n_rep * KV;
+        return j < hq ? kv * hq + j : (j < hq + HALF ? H * HALF + kv * HALF + (j - hq) : (H + KV) * HALF + kv * HALF + (j - hq - HALF));
+    }
+    // (gemv.h LSPLIT) the lane's 32 weights of packet c belong to the super row's SECOND row when they lie past 3072
+    static __device__ __forceinline__ bool second_half(int c, uint32_t lane) { return 2048u * (uint32_t)c + 32u * lane >= 3072u; }
+    // pair i of the wave: its 3 KiB of weights and the scales of the lane's groups (every load unconditional; a pair the wave does not
+    // have reads one broadcast line: masks, not selects -- gemv.h ltile)
+    __device__ __forceinline__ void request_pair(int i)
+    {
+        const uint32_t lane = threadIdx.x & 63, kv = blockIdx.x % KV;
+        const uint32_t glog = group ? 31u - __builtin_clz(group) : 31u, ngroups = group ? KQ >> glog : 1u;
+        const uint32_t lm = 0u - (uint32_t)((uint32_t)i < full ? 1u : 0u);
+        const uint64_t lm64 = ((uint64_t)lm << 32) | lm;
+        const uint32_t pp = pp_of(kv, j0 + i) & lm;
+        const char* wrow = static_cast<const char*>(qw) + (((uint64_t)pp * ROWB2) & lm64) + ((lane * 16) & lm);
+#pragma unroll
+        for (int c = 0; c < NCH; c++) {
+            const rowv4 v = __builtin_nontemporal_load(reinterpret_cast<const rowv4*>(wrow + (((size_t)c * 1024) & lm64)));
+            ww[i][c] = make_uint4(v.x, v.y, v.z, v.w);
+        }
+        // scales: row quads [ceil(out / 4)][ngroups][4] bf16; the dword (rows 2 pp, 2 pp + 1) of the lane's group
+        const char* srow = static_cast<const char*>(qs) + (((size_t)(pp >> 1) * ngroups) * 4 + (pp & 1u) * 2) * 2;
+#pragma unroll
+        for (int c = 0; c < NCH; c++) {
+            const uint32_t ks = 2048u * (uint32_t)c + 32u * lane, k = ks >= KQ ? ks - KQ : ks;
+            const uint32_t g = group ? (k >> glog) : 0u;
+            wsc[i][c] = *reinterpret_cast<const uint32_t*>(srow + ((g * 8u) & lm));
+        }
+    }
+    __device__ __forceinline__ void at_start()
+    {
+        const uint32_t tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const uint32_t pk = min(tid, NPK - 1u); // (384 packets: threads 384.. read the last one again and add nothing)
+        xr = reinterpret_cast<const rowv4*>(xp)[pk];
+        nr = reinterpret_cast<const rowv4*>(normp)[pk];
+        if constexpr (P2 != 0) {
+            pwr = reinterpret_cast<const rowv4*>(postp)[pk];
+            rrr = reinterpret_cast<const rowv4*>(resp)[pk];
+        }
+        stamp(0);
+        const __attribute__((address_space(1))) int32_t* stp = (const __attribute__((address_space(1))) int32_t*)st;
+        slot = (uint32_t)stp[3];
+        rrow_ = (uint32_t)stp[6];
+        tag = (uint32_t)stp[9] * 256u + layer_tag;
+        const uint32_t j = tid % HALF;
+        nq0 = q_norm[j]; nq1 = q_norm[j + HALF];
+        nk0 = k_norm[j]; nk1 = k_norm[j + HALF];
+        asm volatile("s_barrier" ::: "memory"); // (the row's requests stay ahead of the weight requests in the CU's memory pipe)
+        const uint32_t split = blockIdx.x / KV;
+        const uint32_t PG = (n_rep + 2u) * HALF, PW = PG / nsplit, e = PW >> 3, r = PW & 7u;
+        full = e + (wave < r ? 1u : 0u);
+        j0 = split * PW + wave * e + min(wave, r);
+        request_pair(0);
+    }
+    __device__ __forceinline__ void before_tiles()
+    {
+        const uint32_t tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const bool live = tid < NPK;
+        // ---- the prologue of mc_gemv_i4_bfloat_lin3s_p{1,2}_* (gemv.h, the build-time prologue): the same sums in the same order
+        auto sumsq = [&](const rowv4& v) {
+            const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
+            float s1 = 0.0f;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const float a = asf(vv[e] << 16), b = asf(vv[e] & 0xFFFF0000u);
+                s1 += a * a;
+                s1 += b * b;
+            }
+            return live ? s1 : 0.0f;
+        };
+        auto normalise = [&](const rowv4& v, const rowv4& w, float inv) {
+            const uint32_t vv[4] = {v.x, v.y, v.z, v.w}, wv[4] = {w.x, w.y, w.z, w.w};
+            uint32_t o[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const float a = (mu + asf(wv[e] << 16)) * asf(vv[e] << 16) * inv;
+                const float b = (mu + asf(wv[e] & 0xFFFF0000u)) * asf(vv[e] & 0xFFFF0000u) * inv;
+                o[e] = pack_bf16x2(a, b);
+            }
+            return rowv4{o[0], o[1], o[2], o[3]};
+        };
+        rowv4 row;
+        {
+            const float w1 = wave_sum_dpp(sumsq(xr));
+            if (lane == 0) red[wave] = w1;
+            lds_barrier(); // (LDS only: the first pairs stay in flight)
+            float tot = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 8; i++) tot += red[i];
+            const float inv1 = 1.0f / sqrtf(tot / (float)KQ + eps);
+            if constexpr (P2 != 0) {
+                const rowv4 y = normalise(xr, pwr, inv1);
+                const uint32_t aa[4] = {rrr.x, rrr.y, rrr.z, rrr.w}, bb[4] = {y.x, y.y, y.z, y.w};
+                uint32_t o[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+                    o[e] = pack_bf16x2(asf(aa[e] << 16) + asf(bb[e] << 16), asf(aa[e] & 0xFFFF0000u) + asf(bb[e] & 0xFFFF0000u));
+                const rowv4 h = live ? rowv4{o[0], o[1], o[2], o[3]} : rowv4{0, 0, 0, 0};
+                if (blockIdx.x == 0 && live) ((__attribute__((address_space(1))) rowv4*)h_out)[tid] = h;
+                const float w2 = wave_sum_dpp(sumsq(h));
+                if (lane == 0) red[16 + wave] = w2;
+                lds_barrier(); // (not __syncthreads(): behind workgroup 0's store it would wait for every pair requested so far)
+                float tot2 = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 8; i++) tot2 += red[16 + i];
+                const float inv2 = 1.0f / sqrtf(tot2 / (float)KQ + eps);
+                row = normalise(h, nr, inv2);
+            } else {
+                row = normalise(xr, nr, inv1);
+            }
+        }
+        if (live) { // the row twice, [x, x]; packet p sits in slot p + p / 16
+            rowv4* xl = reinterpret_cast<rowv4*>(xs);
+            xl[tid + (tid >> 4)] = row;
+            xl[(NPK + tid) + ((NPK + tid) >> 4)] = row;
+        }
+        lds_barrier();
+        stamp(1);
+        // ---- the rest of the wave's pairs, then the table row of this thread's rotation (its address waits for the step state)
+        request_pair(1);
+        request_pair(2);
+        typedef const __attribute__((address_space(1))) float* gfloat_p;
+        pc = ((gfloat_p)fcos)[(size_t)rrow_ * HALF + tid % HALF];
+        ps = ((gfloat_p)fsin)[(size_t)rrow_ * HALF + tid % HALF];
+    }
+    __device__ __forceinline__ void before_scores()
+    {
+        const uint32_t tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const uint32_t kv = blockIdx.x % KV, split = blockIdx.x / KV;
+        const uint32_t PG = (n_rep + 2u) * HALF;
+        // ---- the wave's super rows from registers (mc_gemv_i4_bfloat_lin3s_*'s arithmetic)
+        const uint32_t lane_tr = (((lane >> 4) * 4 + (lane & 3)) * 17 + ((lane >> 2) & 3) * 4) * 16;
+        const m4b_lane m4bk = m4b_lane_consts(lane);
+        typedef __attribute__((address_space(3))) mf_s4 lds_s4;
+        uint2 x[NCH][8];
+#pragma unroll
+        for (int c = 0; c < NCH; c++) {
+            lds_s4* xt = (lds_s4*)(xs + c * CHUNK_LDS + lane_tr);
+#pragma unroll
+            for (int e = 0; e < 8; e++) x[c][e] = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16(xt + e));
+        }
+        float my_a = 0.0f, my_b = 0.0f;
+#pragma unroll
+        for (int i = 0; i < PMAXQ; i++) {
+            if ((uint32_t)i >= full) break;
+            float m[NCH];
+#pragma unroll
+            for (int c = 0; c < NCH; c++) {
+                const uint32_t dw = wsc[i][c];
+                const uint32_t sfl = second_half(c, lane) ? (dw & 0xFFFF0000u) : (dw << 16);
+                mf_f4 one[1] = {mf_f4{0, 0, 0, 0}};
+                mac4b_n<1>(one, ww[i][c], m4b_prepare(sfl, m4bk), x[c]);
+                const uint32_t e = lane & 3;
+                m[c] = e == 0 ? one[0][0] : (e == 1 ? one[0][1] : (e == 2 ? one[0][2] : one[0][3]));
+            }
+            // packets 0 and 2 are whole rows' worth, the middle one is the first row's in lanes 0..31 and the second row's in lanes 32..63
+            const float fa = wave_sum_dpp((m[0] + (lane < 32 ? m[1] : 0.0f)) * 0x1p37f);
+            const float fb = wave_sum_dpp((m[2] + (lane < 32 ? 0.0f : m[1])) * 0x1p37f);
+            if (lane == (uint32_t)i) {
+                my_a = fa;
+                my_b = fb;
+            }
+        }
+        // ---- the pair RAW (the plain store of the GEMV: T(row sum)) as ONE granule to the workgroups of this kv head (hand-off Q)
+        if (lane < full) {
+            const uint32_t j = j0 + lane;
+            const uint32_t g = (uint32_t)BF::st(my_a) | ((uint32_t)BF::st(my_b) << 16);
+            unsigned long long* gp = qkv_g + (size_t)kv * PG + j;
+            if (fastpath) granule_store_dual(gp, (size_t)KV * PG, tag, g);
+            else granule_store(gp, tag, g);
+        }
+        stamp(2);
+        // ---- hand-off Q: thread t gathers pair t of this kv head
+        unsigned long long g = 0ull;
+        if (wave * 64u < PG) {
+            const unsigned long long* gp = qkv_g + (size_t)kv * PG + min(tid, PG - 1u);
+            handoff_wait w;
+            for (uint32_t look = 0;; look++) {
+                g = fastpath ? granule_look_dual(gp, (size_t)KV * PG, look) : granule_load(gp);
+                const bool ok = (uint32_t)(g >> 32) == tag;
+                if (__all(ok) || w.expired(st, 0xD0000000u | layer_tag)) break;
+            }
+        }
+        // ---- q_norm / k_norm + rotation of the head this thread's pair belongs to (mc_rope_kv_T / q_from_qkv_rows::one_pass: thread
+        // (head hl, pair j) = thread hl * hd / 2 + j), the V pairs as they are; the cache rows by the workgroup whose range holds the slot
+        {
+            const uint32_t hl = tid / HALF, j = tid % HALF;
+            const bool is_q = hl < n_rep, live = hl < n_rep + 1u, is_v = hl == n_rep + 1u;
+            const bool writer = slot / split_slots == split;
+            float x1 = asf((uint32_t)g << 16), x2 = asf((uint32_t)g & 0xFFFF0000u);
+            if (!live) x1 = x2 = 0.0f;
+            const float v = wave_sum(x1 * x1 + x2 * x2);
+            if (lane == 0) red[24 + wave] = v;
+            lds_barrier();
+            float tot = 0.0f;
+#pragma unroll
+            for (uint32_t i = 0; i < WPH; i++) tot += red[24 + (tid / HALF) * WPH + i];
+            const float inv = 1.0f / sqrtf(tot / (float)HD + eps);
+            x1 = BF::rt((mu + bf2f((bf16_t)(is_q ? nq0 : nk0))) * x1 * inv);
+            x2 = BF::rt((mu + bf2f((bf16_t)(is_q ? nq1 : nk1))) * x2 * inv);
+            const bf16_t o1 = BF::st(pc * x1 - ps * x2), o2 = BF::st(ps * x1 + pc * x2);
+            lds_row_w qw_ = (lds_row_w)q_s;
+            if (live) {
+                qw_[hl * HD + j] = o1; // (the K row sits behind the n_rep query heads: k_s = q_s + n_rep * HD)
+                qw_[hl * HD + j + HALF] = o2;
+                if (!is_q && writer) {
+                    typedef __attribute__((address_space(1))) bf16_t* gS_p;
+                    gS_p dst = (gS_p)kc + ((size_t)kv * max_seq + slot) * HD;
+                    dst[j] = o1;
+                    dst[j + HALF] = o2;
+                }
+            } else if (is_v) {
+                const bf16_t va = (bf16_t)(g & 0xFFFFu), vb = (bf16_t)((g >> 16) & 0xFFFFu);
+                *(__attribute__((address_space(3))) uint32_t*)(qw_ + (n_rep + 1u) * HD + 2u * j) = (uint32_t)g;
+                if (writer) {
+                    typedef __attribute__((address_space(1))) bf16_t* gS_p;
+                    ((gS_p)vt)[((size_t)kv * HD + 2u * j) * max_seq + slot] = va;
+                    ((gS_p)vt)[((size_t)kv * HD + 2u * j + 1u) * max_seq + slot] = vb;
+                }
+            }
+        }
+        lds_barrier(); // (behind the cache write: __syncthreads() would drain the vector-memory counter, i.e. wait for the tiles)
+        stamp(11);
+    }
+};
+
 // LNCH = KiB of packed weights per Wo row (K = H * hd = 2048 LNCH); QN != 0: wq|wk|wv (rows of QN KiB) in this launch too -- qx
 // WB = 1: plain bfloat weights for Wo and wq|wk|wv (rows of LNCH / QN KiB = 512 LNCH / 512 QN weights; qkv_in_launch above)
 // TT: 64-slot score tiles per scoring wave (attn_fused_bf's T): 1 = 64 cache slots per workgroup, 4 = 256 (S = 8192 with one workgroup per CU)
-template <int HD, int LNCH, int QN = 0, int WB = 0, int TT = 1>
+// QKN = 1 (round 5, mc_attn_wo_qkn_*: gemma3): `q` holds the RAW wq|wk|wv rows of the step (the GEMV's plain store); q_norm / k_norm, the rotation
+// and the cache write happen in this launch (decode_kernels.hip q_from_qkv_rows<HD, 512>) -- `qnorm_w` = q_norm, `qkv_w` = k_norm
+// QKN = 2 / 3 (mc_attn_qkv_wo_qkn_*): gemma3 with wq|wk|wv in the launch too (qkv_qkn_in_launch above; 3: the post-norm prologue) -- `res` = the
+// row handed to the block, `qnorm_w` = attention_norm, `gx` = the pointers gemma3 adds
+struct gemma_extra {
+    const void *post_w, *res_row; // (QKN = 3) the previous linear's post-norm and the residual it adds to
+    void* h_out;                  // (QKN = 3) where workgroup 0 leaves that hidden row
+    const bf16_t *q_norm, *k_norm;
+};
+template <int HD, int LNCH, int QN = 0, int WB = 0, int TT = 1, int QKN = 0>
 __device__ __forceinline__ void
 attn_wo_body(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const bf16_t* __restrict__ vt, bf16_t* __restrict__ attn_out,
              unsigned long long* psum_g, unsigned long long* slab_g, unsigned long long* row_g, step_state* st, uint32_t n_rep,
@@ -400,16 +688,18 @@ attn_wo_body(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const 
              // granules of hand-off Q
              const void* __restrict__ qnorm_w = nullptr, const void* __restrict__ qkv_w = nullptr, const void* __restrict__ qkv_s = nullptr,
              const float* fcos = nullptr, const float* fsin = nullptr, unsigned long long* qkv_g = nullptr, float eps = 0.0f, float mu = 0.0f,
-             uint32_t kv_shift = 0)
+             uint32_t kv_shift = 0, gemma_extra gx = gemma_extra())
 {
     constexpr uint32_t K = WB == 1 ? 512u * LNCH : (WB == 2 ? 1024u * LNCH : 2048u * LNCH);
     constexpr uint32_t WPK = WB == 1 ? 8u : (WB == 2 ? 16u : 32u); // weights of a lane's 16-byte packet
     constexpr uint32_t CHUNK_LDS = 2048 * 2 / 16 * 17;  // a chunk of the row in LDS: 16 bytes of padding per 256 (gemv.h Q_M4D)
     constexpr uint32_t ROWB = 1024u * LNCH;              // bytes of weights per row
     // (QN != 0: the hidden row of the wq|wk|wv phase first, the attention row of the Wo phase later: hand-off C lies between them)
-    __shared__ __attribute__((aligned(16))) char xs[(LNCH > QN ? LNCH : QN) * (WB == 1 ? 1024u : (WB == 2 ? 2048u : CHUNK_LDS))];
-    __shared__ float qred[QN ? 16 : 1];
-    __shared__ __attribute__((aligned(16))) bf16_t qkv_rows[QN ? 18 * HD : 8]; // queries of up to 16 heads, the K row, the V row
+    constexpr int QCH = QKN >= 2 ? 3 : QN; // chunks of the row of the wq|wk|wv phase (gemma3: [x, x] = three chunks of 2048)
+    __shared__ __attribute__((aligned(16))) char xs[(LNCH > QCH ? LNCH : QCH) * (WB == 1 ? 1024u : (WB == 2 ? 2048u : CHUNK_LDS))];
+    static_assert(QN == 0 || QKN == 0, "one source of the step's queries");
+    __shared__ float qred[(QN || QKN) ? 32 : 1];
+    __shared__ __attribute__((aligned(16))) bf16_t qkv_rows[(QN || QKN) ? 18 * HD : 8]; // queries of up to 16 heads, the K row, the V row
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // (QN != 0) the hidden row and the wave's wq|wk|wv pairs are requested by the first instructions of the launch
     typedef qkv_in_launch<HD, QN ? QN : (WB ? 4 : 2), WB> qx_t;
@@ -424,6 +714,31 @@ attn_wo_body(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const 
         qx.n_rep = n_rep; qx.KV = KV; qx.max_seq = max_seq; qx.nsplit = nsplit; qx.group = group; qx.layer_tag = layer_tag;
         qx.fastpath = fastpath; qx.eps = eps; qx.mu = mu; qx.tl = tl; qx.kv_shift = kv_shift;
         qx.at_start();
+    }
+    typedef qkv_qkn_in_launch<(QKN >= 2 ? HD : 256), QKN == 3> qg_t;
+    qg_t qg;
+    if constexpr (QKN >= 2) {
+        typedef typename qg_t::lds_row lds_row;
+        qg.q_s = (lds_row)qkv_rows;
+        qg.k_s = (lds_row)qkv_rows + n_rep * HD;
+        qg.v_s = (lds_row)qkv_rows + (n_rep + 1u) * HD;
+        qg.xp = res; qg.normp = qnorm_w; qg.postp = gx.post_w; qg.resp = gx.res_row; qg.h_out = gx.h_out; qg.qw = qkv_w; qg.qs = qkv_s;
+        qg.q_norm = gx.q_norm; qg.k_norm = gx.k_norm; qg.fcos = fcos; qg.fsin = fsin; qg.kc = const_cast<bf16_t*>(kc); qg.vt = const_cast<bf16_t*>(vt);
+        qg.qkv_g = qkv_g; qg.st = st; qg.xs = xs; qg.red = qred; qg.n_rep = n_rep; qg.KV = KV; qg.max_seq = max_seq; qg.nsplit = nsplit;
+        qg.group = group; qg.layer_tag = layer_tag; qg.fastpath = fastpath; qg.split_slots = 64u * TT; qg.eps = eps; qg.mu = mu; qg.tl = tl;
+        qg.at_start();
+    }
+    typedef q_from_qkv_rows<(QKN == 1 ? HD : 128), 512> qn_t;
+    qn_t qn;
+    if constexpr (QKN == 1) {
+        typedef typename qn_t::lds_row lds_row;
+        qn.q_s = (lds_row)qkv_rows;
+        qn.k_s = (lds_row)qkv_rows + n_rep * HD;
+        qn.v_s = (lds_row)qkv_rows + (n_rep + 1u) * HD;
+        qn.red = qred; qn.qkv = q; qn.q_norm = static_cast<const bf16_t*>(qnorm_w); qn.k_norm = static_cast<const bf16_t*>(qkv_w);
+        qn.fcos = fcos; qn.fsin = fsin; qn.kc = const_cast<bf16_t*>(kc); qn.vt = const_cast<bf16_t*>(vt); qn.st = st; qn.n_rep = n_rep; qn.KV = KV;
+        qn.max_seq = max_seq; qn.split_slots = 64u * TT; qn.eps = eps; qn.mu = mu;
+        qn.at_start();
     }
 
     // ---- the Wo row pairs of this wave: contiguous spans dealt as the linear-order kernels deal theirs, at most PMAX each (the
@@ -454,7 +769,10 @@ attn_wo_body(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const 
 #endif
     auto request_wo = [&](int point) {
         const bool poller = wave < n_rep; // (attn_fused_bf: head = wave, wave + NW, ... gathers the denominators of hand-off A)
-        if (QN != 0 && MC_QKV_WO_REQ_EARLY == 1) {
+#ifndef MC_QKN_WO_EARLY
+#define MC_QKN_WO_EARLY 0 // 1 (tuning): the gemma3 form requests its Wo pairs in front of the scores
+#endif
+        if ((QN != 0 && MC_QKV_WO_REQ_EARLY == 1) || (QKN == 1 && MC_QKN_WO_EARLY == 1)) {
             if (point != -1) return;
         } else if (QN != 0 && MC_QKV_WO_REQ_EARLY == 2) {
             // the waves that compute no scores ask in front of them (they are idle there), the others behind hand-off A
@@ -498,11 +816,15 @@ attn_wo_body(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const 
             if ((col & 1u) == 0) granule_store(row_g + ((size_t)head * HD + db * 16 + col) / 2, epoch_tag, pack_bf16x2(v, vn));
         }
     };
-    constexpr int TL_STRIDE = QN ? 16 : 8, TL_BASE = QN ? 3 : 0;
+    constexpr int TL_STRIDE = (QN || QKN >= 2) ? 16 : 8, TL_BASE = (QN || QKN >= 2) ? 3 : 0;
     if constexpr (QN != 0) {
         attn_fused_bf<HD, TT, 8>(q, kc, vt, psum_g, slab_g, st, n_rep, KV, max_seq, scale, nsplit, layer_tag, tl, publish, request_wo, fastpath, qx, kv_shift);
+    } else if constexpr (QKN >= 2) {
+        attn_fused_bf<HD, TT, 8>(nullptr, kc, vt, psum_g, slab_g, st, n_rep, KV, max_seq, scale, nsplit, layer_tag, tl, publish, request_wo, fastpath, qg);
+    } else if constexpr (QKN != 0) {
+        attn_fused_bf<HD, TT, 8>(nullptr, kc, vt, psum_g, slab_g, st, n_rep, KV, max_seq, scale, nsplit, layer_tag, tl, publish, request_wo, fastpath, qn);
     } else {
-        static_assert(QN != 0 || TT == 1, "wide ranges: with wq|wk|wv in the launch only");
+        static_assert(QN != 0 || TT == 1, "wide ranges: with the step's rows in LDS only (every tile of the step's slot is patched from there)");
         attn_fused_bf<HD, 1, 8>(q, kc, vt, psum_g, slab_g, st, n_rep, KV, max_seq, scale, nsplit, layer_tag, tl, publish, request_wo, fastpath);
     }
     // tl != null (tools/attn_wo_timeline.py only): thread 0 of every workgroup leaves s_memrealtime stamps of its phases
@@ -678,6 +1000,41 @@ MC_ATTN_QKV_WO_W(mc_attn_qkv_wo_w_bfloat_hd64_k4_q4, 64, 4, 4)  // Llama-3.2-1B:
     }
 MC_ATTN_QKV_WO_I8(mc_attn_qkv_wo_i8_bfloat_hd128_k4_q4_t1, 128, 4, 4, 1)  // Llama-3-8B int8, S <= 2048
 MC_ATTN_QKV_WO_I8(mc_attn_qkv_wo_i8_bfloat_hd128_k4_q4_t4, 128, 4, 4, 4)  // ... S = 8192: 256-slot ranges, one workgroup per CU
+
+// ... gemma3 (round 5): q_norm / k_norm + rotation + cache write (mc_rope_kv_T) + attention + Wo in one launch, from the raw wq|wk|wv rows:
+// mc_attn_wo_qkn_i4_bfloat_hd{head_dim}_k{KiB per Wo row}_t{64-slot tiles per scoring wave}
+#define MC_ATTN_WO_QKN(NAME, HD, LNCH, TT)                                                                                               \
+    extern "C" __global__ void __launch_bounds__(512)                                                                                    \
+    NAME(const bf16_t* qkv, const bf16_t* kc, const bf16_t* vt, bf16_t* attn_out, unsigned long long* psum_g, unsigned long long* slab_g, \
+         unsigned long long* row_g, step_state* st, uint32_t n_rep, uint32_t n_kv, uint32_t max_seq, float scale, uint32_t nsplit,      \
+         uint32_t layer_tag, const void* wo_w, const void* wo_s, const bf16_t* res, bf16_t* y, uint32_t out_rows, uint32_t group,       \
+         uint32_t has_res, uint32_t fastpath, unsigned long long* tl, const bf16_t* q_norm, const bf16_t* k_norm, const float* fcos,     \
+         const float* fsin, float eps, float mu)                                                                                         \
+    {                                                                                                                                    \
+        attn_wo_body<HD, LNCH, 0, 0, TT, 1>(qkv, kc, vt, attn_out, psum_g, slab_g, row_g, st, n_rep, n_kv, max_seq, scale, nsplit,       \
+                                            layer_tag, wo_w, wo_s, res, y, out_rows, group, has_res, fastpath, tl, q_norm, k_norm,       \
+                                            nullptr, fcos, fsin, nullptr, eps, mu);                                                      \
+    }
+// ... and with wq|wk|wv in the launch (qkv_qkn_in_launch): mc_attn_qkv_wo_qkn_i4_bfloat_hd{head_dim}_k{KiB per Wo row}_p{1: pre-norm, 2: post-norm +
+// residual + pre-norm}_t{tiles}; rows of 1.5 KiB (K = 3072)
+#define MC_ATTN_QKV_WO_QKN(NAME, HD, LNCH, P, TT)                                                                                        \
+    extern "C" __global__ void __launch_bounds__(512)                                                                                    \
+    NAME(const bf16_t* kc, const bf16_t* vt, bf16_t* attn_out, unsigned long long* psum_g, unsigned long long* slab_g,                  \
+         unsigned long long* row_g, unsigned long long* qkv_g, step_state* st, uint32_t n_rep, uint32_t n_kv, uint32_t max_seq,         \
+         float scale, uint32_t nsplit, uint32_t layer_tag, const void* wo_w, const void* wo_s, const bf16_t* x, bf16_t* y,              \
+         uint32_t out_rows, uint32_t group, const void* norm_w, const void* qkv_w, const void* qkv_s, const float* fcos,                \
+         const float* fsin, float eps, float mu, uint32_t fastpath, unsigned long long* tl, const bf16_t* q_norm, const bf16_t* k_norm, \
+         const void* post_w, const void* res_row, void* h_out)                                                                           \
+    {                                                                                                                                    \
+        attn_wo_body<HD, LNCH, 0, 0, TT, 1 + P>(nullptr, kc, vt, attn_out, psum_g, slab_g, row_g, st, n_rep, n_kv, max_seq, scale,       \
+                                                nsplit, layer_tag, wo_w, wo_s, x, y, out_rows, group, 0u, fastpath, tl, norm_w, qkv_w,   \
+                                                qkv_s, fcos, fsin, qkv_g, eps, mu, 0u,                                                   \
+                                                gemma_extra{post_w, res_row, h_out, q_norm, k_norm});                                    \
+    }
+MC_ATTN_QKV_WO_QKN(mc_attn_qkv_wo_qkn_i4_bfloat_hd256_k2_p1_t2, 256, 2, 1, 2)  // Gemma-7B at S = 2048: the first block (or parity taps)
+MC_ATTN_QKV_WO_QKN(mc_attn_qkv_wo_qkn_i4_bfloat_hd256_k2_p2_t2, 256, 2, 2, 2)  // ... every other block
+MC_ATTN_WO_QKN(mc_attn_wo_qkn_i4_bfloat_hd256_k2_t1, 256, 2, 1)  // Gemma-7B shapes up to S = 1024
+MC_ATTN_WO_QKN(mc_attn_wo_qkn_i4_bfloat_hd256_k2_t2, 256, 2, 2)  // ... S = 2048: 16 ranges of 128 slots x 16 kv heads = one workgroup per CU
 
 // mc_attn_wo_i4_bfloat_hd{head_dim}_k{KiB per Wo row}
 MC_ATTN_WO(mc_attn_wo_i4_bfloat_hd128_k2, 128, 2)  // Llama-3-8B: 32 heads x 128

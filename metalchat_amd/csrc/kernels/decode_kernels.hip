@@ -658,10 +658,13 @@ struct q_from_hbm {
 // rope_kv_body: the same thread <-> pair mapping, the same wave_sum tree, the wave sums added in wave order -- and the
 // workgroup whose range holds the step's slot writes the K row and the V column to the cache for the steps to come.
 // NT: threads of the workgroup (256: mc_attn_fused_qkn_T; 512: with the Wo GEMV in the launch, mc_attn_wo_qkn_*); `red` holds NT / 64 floats
+#ifndef MC_QKN_PIN_V
+#define MC_QKN_PIN_V 0 // 1 (tuning): the 512-thread form requests its V tiles in front of the norms too
+#endif
 template <int HD, int NT = 256>
 struct q_from_qkv_rows {
     static_assert(HD == 128 || HD == 256, "hd / 2 threads per head are whole waves");
-    static constexpr bool LDS = true, PIN_V = false;
+    static constexpr bool LDS = true, PIN_V = NT == 512 && MC_QKN_PIN_V != 0;
     static constexpr int TL_STRIDE = 8, TL_BASE = 0;
     static constexpr uint32_t HALF = HD / 2, HPP = NT / HALF, WPH = HALF / 64; // heads per pass of the NT threads, waves per head
     typedef const __attribute__((address_space(3))) bf16_t* lds_row;

@@ -344,3 +344,197 @@ def test_norm_qkv_rope_attention_and_wo_in_one_launch_matches_the_oracle(acc, n,
         parity.check(BF16, hb.download(np.uint16, dim), ref.reshape(-1), rel=4e-3, max_ulp=2, max_frac=0.3, scale_aware=True,
                      what=f"norm + wq|wk|wv + rope + attention + Wo + residual in one launch, n{n} tag ({epoch}, {layer_tag})")
     dec.release()
+
+
+@pytest.mark.parametrize("fast", [1, 0])
+@pytest.mark.parametrize("tiles,n", [(2, 2048), (2, 1000), (2, 1), (2, 129), (1, 1024), (1, 65)])
+def test_gemma_norms_rope_attention_and_wo_in_one_launch_matches_the_oracle(acc, tiles, n, fast):
+    """`mc_attn_wo_qkn_i4_bfloat_hd256_k2_t{1,2}` (round 5; attn_block_kernels.hip attn_wo_body with decode_kernels.hip q_from_qkv_rows<256, 512>):
+    gemma3's q_norm / k_norm over whole heads, the rotation, the cache write (nn/attention.h:170-177), the decode attention and Wo WITHOUT a
+    residual (nn/attention.h:191-205; the block's post-norm adds it, nn/transformer.h:132-133) in one launch from the RAW wq|wk|wv rows,
+    launched BY NAME on Gemma-7B's shapes (16 heads x 256, 16 kv heads; ranges of 64 tiles slots: 128 at S = 2048 so that the launch is one
+    workgroup per CU) against the oracle's kernels composed as the reference composes them: rmsnorm per head (mu = 1), rope at the step's
+    table row, the rows appended to the cache, the attention of test_one_launch_attention_matches_the_oracle, hadamard_broadcast + bmm for Wo."""
+    import metalchat_amd as mc
+
+    H, KV, hd, dim = 16, 16, 256, 3072
+    max_seq, half = 1024 * tiles, hd // 2
+    cfg = mg.tiny_cfg(BF16, dim=dim, n_heads=H, n_kv_heads=KV, head_dim=hd, ffn_dim=256, n_layers=1, vocab=64, max_seq_len=max_seq)
+    w = mg.make_model(cfg, seed=91, quant="i4", group=128)
+    dec = mc.Decoder(acc, **mg.decoder_kwargs(cfg, weight_format=mc.WFMT_I4, group_size=128))
+    dec.load_model(w)
+    wo_p, wo_s, rows, inf, _ = dec.weight_ptrs(0, "wo")
+    assert (rows, inf) == (dim, H * hd)
+    rng = np.random.default_rng(4000 + n + tiles)
+    n_rep, nsplit = H // KV, max_seq // (PB * tiles)
+    slot, rrow, nrows, eps = n - 1, 3, 6, 1e-6
+    q0 = mo.encode(BF16, rng.normal(0, 1.5, (H, hd)).astype(np.float32))
+    k0 = mo.encode(BF16, rng.normal(0, 0.7, (KV, hd)).astype(np.float32))
+    v0 = mo.encode(BF16, rng.normal(0, 0.5, (KV, hd)).astype(np.float32))
+    qw = mo.encode(BF16, rng.uniform(-0.3, 0.4, hd).astype(np.float32))
+    kw = mo.encode(BF16, rng.uniform(-0.3, 0.4, hd).astype(np.float32))
+    k = mo.encode(BF16, rng.normal(0, 0.4, (n, KV, hd)).astype(np.float32))
+    v = mo.encode(BF16, rng.normal(0, 0.5, (n, KV, hd)).astype(np.float32))
+    fcos, fsin = np.zeros((nrows, half), np.float32), np.zeros((nrows, half), np.float32)
+    L = mo.layout
+    mo.rope_freqs(L(fcos.shape), fcos, L(fsin.shape), fsin, hd, 0, 10000.0)
+    scale = float(mo.from_bf16(mo.to_bf16(np.array([hd ** -0.5], np.float32)))[0])
+    # ---- the oracle's composition
+    qn, kn = np.zeros_like(q0), np.zeros_like(k0)
+    mo.rmsnorm(BF16, L(q0.shape), qn, L(q0.shape), q0, L((hd,)), qw, eps, 1.0)
+    mo.rmsnorm(BF16, L(k0.shape), kn, L(k0.shape), k0, L((hd,)), kw, eps, 1.0)
+    q1, k1 = np.zeros_like(qn), np.zeros_like(kn)
+    mo.rope(BF16, L(qn.shape), q1, L(qn.shape), qn, L(fcos.shape), fcos, L(fsin.shape), fsin, 1, H, rrow)
+    mo.rope(BF16, L(kn.shape), k1, L(kn.shape), kn, L(fcos.shape), fcos, L(fsin.shape), fsin, 1, KV, rrow)
+    k[slot], v[slot] = k1, v0
+    att = oracle_attention(q1, k, v, n_rep, scale)
+    proj = oracle_linear(BF16, w["layers"][0]["wo"], att.reshape(1, 1, -1)).reshape(-1)
+    # ---- the launch: raw rows as the wq|wk|wv GEMV stores them (q and k heads with the rotation's partners adjacent: [2 j] = natural [j],
+    # [2 j + 1] = natural [j + hd / 2]; v natural), the cache with garbage in the step's slot
+    def packed(a):
+        o = np.zeros_like(a)
+        o[:, 0::2], o[:, 1::2] = a[:, :half], a[:, half:]
+        return o
+    raw = acc.to_device(np.concatenate([packed(q0).reshape(-1), packed(k0).reshape(-1), v0.reshape(-1)]))
+    kpast, vpast = k.copy(), v.copy()
+    kpast[slot] = mo.encode(BF16, rng.normal(0, 30, (KV, hd)).astype(np.float32))
+    vpast[slot] = mo.encode(BF16, rng.normal(0, 30, (KV, hd)).astype(np.float32))
+    kc, vt = device_caches(acc, kpast, vpast, max_seq)
+    psum = acc.to_device(np.zeros(2 * H * nsplit, np.uint64))
+    slab = acc.to_device(np.zeros(2 * H * hd * nsplit, np.uint64))
+    row_g = acc.to_device(np.zeros(H * hd // 2, np.uint64))
+    attn_out = acc.alloc(H * hd * 2)
+    qwb, kwb = acc.to_device(qw), acc.to_device(kw)
+    cb, sb = acc.to_device(fcos.reshape(-1)), acc.to_device(fsin.reshape(-1))
+    kern = acc.load(f"mc_attn_wo_qkn_i4_bfloat_hd256_k2_t{tiles}")
+    W = lambda p_: acc.wrap(p_, 1 << 40)
+    for epoch, layer_tag in ((1, 1), (1, 2), (9, 200)):
+        yb = acc.to_device(np.full(dim, 0x7FC0, np.uint16))
+        attn_out.upload(np.zeros(H * hd, np.uint16))
+        st = np.zeros(12, np.int32)
+        st[2], st[3], st[6], st[9] = n, slot, rrow, epoch
+        state = acc.to_device(st)
+        mc.KernelTask(kern, (nsplit * KV * 512, 1, 1), (512, 1, 1),
+                      [raw, kc, vt, attn_out, psum, slab, row_g, state, np.uint32(n_rep), np.uint32(KV), np.uint32(max_seq), np.float32(scale),
+                       np.uint32(nsplit), np.uint32(layer_tag), W(wo_p), W(wo_s), None, yb, np.uint32(dim), np.uint32(128), np.uint32(0), np.uint32(fast), None,
+                       qwb, kwb, cb, sb, np.float32(eps), np.float32(1.0)])()
+        acc.wait()
+        assert int(state.download(np.int32, 12)[10]) == 0, "a hand-off of the launch gave up"
+        kgot = kc.download(np.uint16, KV * max_seq * hd).reshape(KV, max_seq, hd)
+        vgot = vt.download(np.uint16, KV * hd * max_seq).reshape(KV, hd, max_seq)
+        parity.check(BF16, kgot[:, slot].reshape(-1), k1.reshape(-1), rel=3e-3, max_ulp=2, max_frac=0.2, what=f"K row the launch wrote (k_norm + rotation), n{n}")
+        parity.exact(vgot[:, :, slot], v0, "V row the launch wrote")
+        if n > 1:
+            parity.exact(kgot[:, : slot], kpast[: slot].transpose(1, 0, 2), "the earlier K rows are untouched")
+        parity.check(BF16, attn_out.download(np.uint16, H * hd), att.reshape(-1), rel=4e-3, max_ulp=2, max_frac=0.3, scale_aware=True,
+                     what=f"attention row of the one launch, t{tiles} n{n} tag ({epoch}, {layer_tag})")
+        parity.check(BF16, yb.download(np.uint16, dim), proj, rel=4e-3, max_ulp=2, max_frac=0.3, scale_aware=True,
+                     what=f"q/k-norm + rope + attention + Wo in one launch, t{tiles} n{n} tag ({epoch}, {layer_tag})")
+    dec.release()
+
+
+@pytest.mark.parametrize("fast", [1, 0])
+@pytest.mark.parametrize("n", [2048, 1000, 1, 129])
+@pytest.mark.parametrize("post", [0, 1])
+def test_gemma_block_from_the_row_to_wo_in_one_launch_matches_the_oracle(acc, post, n, fast):
+    """`mc_attn_qkv_wo_qkn_i4_bfloat_hd256_k2_p{1,2}_t2` (round 5; attn_block_kernels.hip qkv_qkn_in_launch): a gemma3 block from the row it
+    is handed to Wo's output in ONE launch at Gemma-7B's widths (K = 3072: rows of 1.5 KiB; 16 heads x 256, 16 kv heads; S = 2048 as 16 ranges
+    of 128 slots) -- `_p2_`: the previous linear's post-norm + the residual add, left in HBM (nn/transformer.h:138-139), then attention_norm,
+    wq|wk|wv, q_norm / k_norm, rope, the cache write, the decode attention and Wo (nn/transformer.h:130-133, nn/attention.h:170-205);
+    `_p1_`: from attention_norm on -- launched BY NAME against the oracle's kernels composed as the reference composes them.  The row is
+    dyadic (its first normalisation is then the oracle's bit for bit, test_lin_kernels_gpu.py)."""
+    import metalchat_amd as mc
+    from test_lin_kernels_gpu import dyadic_row
+
+    H, KV, hd, dim, max_seq, tiles = 16, 16, 256, 3072, 2048, 2
+    half = hd // 2
+    cfg = mg.tiny_cfg(BF16, family=1, dim=dim, n_heads=H, n_kv_heads=KV, head_dim=hd, ffn_dim=256, n_layers=1, vocab=64, max_seq_len=max_seq,
+                      rope_theta=10000.0, norm_eps=1e-6)
+    w = mg.make_model(cfg, seed=515, quant="i4", group=128)
+    dec = mc.Decoder(acc, **mg.decoder_kwargs(cfg, weight_format=mc.WFMT_I4, group_size=128))
+    dec.load_model(w)
+    lw = w["layers"][0]
+    wo_p, wo_s, rows, inf, _ = dec.weight_ptrs(0, "wo")
+    qk_p, qk_s, qrows, qinf, _ = dec.weight_ptrs(0, "qkv")
+    assert (rows, inf, qrows, qinf) == (dim, H * hd, (H + 2 * KV) * hd, dim)
+    rng = np.random.default_rng(7000 + n + post)
+    n_rep, nsplit = H // KV, max_seq // (PB * tiles)
+    slot, rrow, nrows, eps, mu = n - 1, 4, 6, 1e-6, 1.0
+    L = mo.layout
+    x = dyadic_row(rng, dim)
+
+    def norm(v, wgt):
+        out = np.zeros((1, v.size), np.uint16)
+        mo.rmsnorm(BF16, L((1, v.size)), out, L((1, v.size)), v.reshape(1, -1), L((v.size,)), wgt, eps, mu)
+        return out.reshape(-1)
+
+    if post:
+        res = mo.encode(BF16, rng.normal(0, 1, dim).astype(np.float32))
+        y = norm(x, lw["ffn_post_norm"])
+        h = np.zeros((1, dim), np.uint16)
+        mo.add(BF16, L((1, dim)), h, L((1, dim)), res.reshape(1, -1), L((1, dim)), y.reshape(1, -1))
+        h = h.reshape(-1)
+    else:
+        res, h = None, x
+    xn = norm(h, lw["attention_norm"])
+    q0 = oracle_linear(BF16, lw["wq"], xn.reshape(1, 1, -1)).reshape(H, hd)
+    k0 = oracle_linear(BF16, lw["wk"], xn.reshape(1, 1, -1)).reshape(KV, hd)
+    v0 = oracle_linear(BF16, lw["wv"], xn.reshape(1, 1, -1)).reshape(KV, hd)
+    qn, kn = np.zeros_like(q0), np.zeros_like(k0)
+    mo.rmsnorm(BF16, L(q0.shape), qn, L(q0.shape), q0, L((hd,)), lw["q_norm"], eps, mu)
+    mo.rmsnorm(BF16, L(k0.shape), kn, L(k0.shape), k0, L((hd,)), lw["k_norm"], eps, mu)
+    fcos, fsin = np.zeros((nrows, half), np.float32), np.zeros((nrows, half), np.float32)
+    mo.rope_freqs(L(fcos.shape), fcos, L(fsin.shape), fsin, hd, 0, 10000.0)
+    q1, k1 = np.zeros_like(qn), np.zeros_like(kn)
+    mo.rope(BF16, L(qn.shape), q1, L(qn.shape), qn, L(fcos.shape), fcos, L(fsin.shape), fsin, 1, H, rrow)
+    mo.rope(BF16, L(kn.shape), k1, L(kn.shape), kn, L(fcos.shape), fcos, L(fsin.shape), fsin, 1, KV, rrow)
+    k = mo.encode(BF16, rng.normal(0, 0.4, (n, KV, hd)).astype(np.float32))
+    v = mo.encode(BF16, rng.normal(0, 0.5, (n, KV, hd)).astype(np.float32))
+    k[slot], v[slot] = k1, v0
+    scale = float(mo.from_bf16(mo.to_bf16(np.array([hd ** -0.5], np.float32)))[0])
+    att = oracle_attention(q1, k, v, n_rep, scale)
+    proj = oracle_linear(BF16, lw["wo"], att.reshape(1, 1, -1)).reshape(-1)
+    # ---- the launch
+    kpast, vpast = k.copy(), v.copy()
+    kpast[slot] = mo.encode(BF16, rng.normal(0, 30, (KV, hd)).astype(np.float32))
+    vpast[slot] = mo.encode(BF16, rng.normal(0, 30, (KV, hd)).astype(np.float32))
+    kc, vt = device_caches(acc, kpast, vpast, max_seq)
+    psum = acc.to_device(np.zeros(2 * H * nsplit, np.uint64))
+    slab = acc.to_device(np.zeros(2 * H * hd * nsplit, np.uint64))
+    row_g = acc.to_device(np.zeros(H * hd // 2, np.uint64))
+    qkv_g = acc.to_device(np.zeros(2 * (H + 2 * KV) * hd // 2, np.uint64))
+    attn_out = acc.alloc(H * hd * 2)
+    nw, qnb, knb = acc.to_device(lw["attention_norm"]), acc.to_device(lw["q_norm"]), acc.to_device(lw["k_norm"])
+    pwb = acc.to_device(lw["ffn_post_norm"]) if post else None
+    resb = acc.to_device(res) if post else None
+    cb, sb = acc.to_device(fcos.reshape(-1)), acc.to_device(fsin.reshape(-1))
+    kern = acc.load(f"mc_attn_qkv_wo_qkn_i4_bfloat_hd256_k2_p{1 + post}_t2")
+    W = lambda p_: acc.wrap(p_, 1 << 40)
+    for epoch, layer_tag in ((1, 1), (1, 2), (9, 200)):
+        xb = acc.to_device(x)
+        yb = acc.to_device(np.full(dim, 0x7FC0, np.uint16))
+        hb = acc.to_device(np.full(dim, 0x7FC0, np.uint16)) if post else None
+        attn_out.upload(np.zeros(H * hd, np.uint16))
+        st = np.zeros(12, np.int32)
+        st[2], st[3], st[6], st[9] = n, slot, rrow, epoch
+        state = acc.to_device(st)
+        mc.KernelTask(kern, (nsplit * KV * 512, 1, 1), (512, 1, 1),
+                      [kc, vt, attn_out, psum, slab, row_g, qkv_g, state, np.uint32(n_rep), np.uint32(KV), np.uint32(max_seq), np.float32(scale),
+                       np.uint32(nsplit), np.uint32(layer_tag), W(wo_p), W(wo_s), xb, yb, np.uint32(dim), np.uint32(128), nw, W(qk_p), W(qk_s), cb, sb,
+                       np.float32(eps), np.float32(mu), np.uint32(fast), None, qnb, knb, pwb, resb, hb])()
+        acc.wait()
+        assert int(state.download(np.int32, 12)[10]) == 0, "a hand-off of the launch gave up"
+        if post:
+            parity.check(BF16, hb.download(np.uint16, dim), h, rel=2e-3, max_ulp=1, max_frac=0.02, what=f"the hidden row workgroup 0 leaves (post-norm + residual), n{n}")
+        kgot = kc.download(np.uint16, KV * max_seq * hd).reshape(KV, max_seq, hd)
+        vgot = vt.download(np.uint16, KV * hd * max_seq).reshape(KV, hd, max_seq)
+        parity.check(BF16, kgot[:, slot].reshape(-1), k1.reshape(-1), rel=4e-3, max_ulp=2, max_frac=0.3, scale_aware=True, what=f"K row the launch wrote, p{1 + post} n{n}")
+        parity.check(BF16, vgot[:, :, slot].reshape(-1), v0.reshape(-1), rel=3e-3, max_ulp=2 if post else 1, max_frac=0.3 if post else 0.05, scale_aware=True,
+                     what=f"V row the launch wrote, p{1 + post} n{n}")
+        if n > 1:
+            parity.exact(kgot[:, : slot], kpast[: slot].transpose(1, 0, 2), "the earlier K rows are untouched")
+        parity.check(BF16, attn_out.download(np.uint16, H * hd), att.reshape(-1), rel=4e-3, max_ulp=2, max_frac=0.3, scale_aware=True,
+                     what=f"attention row of the one launch, p{1 + post} n{n} tag ({epoch}, {layer_tag})")
+        parity.check(BF16, yb.download(np.uint16, dim), proj, rel=4e-3, max_ulp=2, max_frac=0.3, scale_aware=True,
+                     what=f"norms + wq|wk|wv + q/k-norm + rope + attention + Wo in one launch, p{1 + post} n{n} tag ({epoch}, {layer_tag})")
+    dec.release()

@@ -21,7 +21,7 @@ I8 = os.environ.get("FMT") == "i8"
 TILES = int(os.environ.get("TILES", "4")) if I8 else 1
 H, KV, hd, S, dim = 32, 8, 128, 2048 * TILES, 4096
 n_rep, nsplit = H // KV, S // (64 * TILES)
-acc = mc.HardwareAccelerator()
+acc = mc.HardwareAccelerator(path=os.environ.get("MC_HSACO"))
 cfg = dict(dtype=0, n_layers=2, vocab=2048, norm_eps=1e-5, max_seq_len=S, family=0, dim=dim, n_heads=H, n_kv_heads=KV, head_dim=hd, ffn_dim=1024,
            rope_theta=500000.0, attn_scale=hd ** -0.5)
 dec = mc.Decoder(acc, **mg.decoder_kwargs(cfg, weight_format=mc.WFMT_I8 if I8 else mc.WFMT_I4, group_size=128))
