@@ -56,7 +56,7 @@ using namespace mc::gemv;
 template <int HD, int QN, int WB = 0>
 struct qkv_in_launch {
     static_assert(WB ? QN == 4 : QN == 2, "at most one 16-byte packet of the hidden row per thread (K = 4096 int4 / int8, 2048 bfloat; 512 threads)");
-    static constexpr bool LDS = true, PIN_V = true;
+    static constexpr bool LDS = true, PIN_V = true, STAGED = false;
     static constexpr int TL_STRIDE = 16, TL_BASE = 3; // stamps: 0 start, 1 row staged, 2 pairs published, 3.. attn_fused_bf's 0..
     static constexpr uint32_t KQ = WB == 1 ? 512u * QN : (WB == 2 ? 1024u * QN : 2048u * QN), ROWBQ = 1024u * QN, CHUNK_LDS = 2048 * 2 / 16 * 17, HALF = HD / 2;
     static constexpr uint32_t NPK = KQ / 8; // 16-byte packets of the hidden row
@@ -403,7 +403,18 @@ struct qkv_in_launch {
 template <int HD, int P2>
 struct qkv_qkn_in_launch {
     static_assert(HD == 256, "gemma3 with head_dim 256 (hd / 2 threads per head are whole waves)");
-    static constexpr bool LDS = true, PIN_V = true;
+#ifndef MC_GQ_PIN_V
+#define MC_GQ_PIN_V 1 // 0 (tuning): the V tiles requested behind the wq|wk|wv phase instead of in front of it
+#endif
+#ifndef MC_GQ_STAGED
+#define MC_GQ_STAGED 1 // 0 (tuning): the K / V tiles requested up front, in front of the wq|wk|wv phase
+#endif
+#ifndef MC_GQ_V_STEP
+#define MC_GQ_V_STEP 3 // the V tiles: 2 = behind the last pair's multiplication, 3 = behind the polls of hand-off Q (a wave's loads return in
+                       // order: polls behind 8 KB of V tiles per wave see their granules only when those have arrived)
+#endif
+    static constexpr bool LDS = true, PIN_V = MC_GQ_PIN_V != 0, STAGED = MC_GQ_STAGED != 0;
+    static constexpr int V_STEP = MC_GQ_V_STEP;
     static constexpr int TL_STRIDE = 16, TL_BASE = 3; // stamps: 0 start, 1 row staged, 2 pairs published, 3.. attn_fused_bf's 0.., 11 rows normalised
     static constexpr uint32_t KQ = 3072u, NPK = KQ / 8, ROWB2 = 3072u, CHUNK_LDS = 2048 * 2 / 16 * 17, HALF = HD / 2, WPH = HALF / 64;
     static constexpr int PMAXQ = 3, NCH = 3;
@@ -564,7 +575,11 @@ struct qkv_qkn_in_launch {
         pc = ((gfloat_p)fcos)[(size_t)rrow_ * HALF + tid % HALF];
         ps = ((gfloat_p)fsin)[(size_t)rrow_ * HALF + tid % HALF];
     }
-    __device__ __forceinline__ void before_scores()
+    __device__ __forceinline__ void before_scores() { before_scores([](int) {}); }
+    // tiles(step): attn_fused_bf's tile requests (STAGED), placed behind the multiplication of pair `step`: the memory pipe stays full
+    // while the wave is never held at issue for long
+    template <typename Tiles>
+    __device__ __forceinline__ void before_scores(Tiles&& tiles)
     {
         const uint32_t tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
         const uint32_t kv = blockIdx.x % KV, split = blockIdx.x / KV;
@@ -583,7 +598,7 @@ struct qkv_qkn_in_launch {
         float my_a = 0.0f, my_b = 0.0f;
 #pragma unroll
         for (int i = 0; i < PMAXQ; i++) {
-            if ((uint32_t)i >= full) break;
+            if ((uint32_t)i < full) { // (wave-uniform; no load inside)
             float m[NCH];
 #pragma unroll
             for (int c = 0; c < NCH; c++) {
@@ -601,6 +616,11 @@ struct qkv_qkn_in_launch {
                 my_a = fa;
                 my_b = fb;
             }
+            }
+#ifdef MC_GQ_STAMPS
+            stamp(12 + i);
+#endif
+            tiles(i);
         }
         // ---- the pair RAW (the plain store of the GEMV: T(row sum)) as ONE granule to the workgroups of this kv head (hand-off Q)
         if (lane < full) {
@@ -622,6 +642,7 @@ struct qkv_qkn_in_launch {
                 if (__all(ok) || w.expired(st, 0xD0000000u | layer_tag)) break;
             }
         }
+        tiles(PMAXQ);
         // ---- q_norm / k_norm + rotation of the head this thread's pair belongs to (mc_rope_kv_T / q_from_qkv_rows::one_pass: thread
         // (head hl, pair j) = thread hl * hd / 2 + j), the V pairs as they are; the cache rows by the workgroup whose range holds the slot
         {

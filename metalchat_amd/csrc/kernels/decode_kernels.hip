@@ -642,7 +642,7 @@ mc_attn_pv_reduce_float(const float* __restrict__ parts, float* __restrict__ out
 // (LDS); the tile registers of the step's slot are then patched from there (the cache row itself is written by the workgroup
 // that computed it, for the steps to come: whatever a tile load found in that slot is never used).
 struct q_from_hbm {
-    static constexpr bool LDS = false, PIN_V = false;
+    static constexpr bool LDS = false, PIN_V = false, STAGED = false;
     static constexpr int TL_STRIDE = 8, TL_BASE = 0;
     typedef const __attribute__((address_space(3))) bf16_t* lds_row; // (LDS address space: a generic pointer would make these flat loads)
     lds_row q_s = nullptr, k_s = nullptr, v_s = nullptr;
@@ -664,7 +664,7 @@ struct q_from_hbm {
 template <int HD, int NT = 256>
 struct q_from_qkv_rows {
     static_assert(HD == 128 || HD == 256, "hd / 2 threads per head are whole waves");
-    static constexpr bool LDS = true, PIN_V = NT == 512 && MC_QKN_PIN_V != 0;
+    static constexpr bool LDS = true, PIN_V = NT == 512 && MC_QKN_PIN_V != 0, STAGED = false;
     static constexpr int TL_STRIDE = 8, TL_BASE = 0;
     static constexpr uint32_t HALF = HD / 2, HPP = NT / HALF, WPH = HALF / 64; // heads per pass of the NT threads, waves per head
     typedef const __attribute__((address_space(3))) bf16_t* lds_row;
@@ -828,17 +828,24 @@ attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const
     qsrc.before_tiles();
     uint4 kb[T][KS];
     const bool scorer = NW == 4 || wave < 4; // (waves 4 .. NW - 1 compute no scores: no K tile, no queries)
-    if constexpr (QSrc::LDS) {
-        // (every load of the launch unconditional: with one load behind a branch hipcc waits vmcnt(0) wherever it waits -- the
-        //  rmsnorm of the wq|wk|wv phase would sit behind every tile of the launch.  Waves that compute no scores read one
-        //  broadcast line of the cache: masks, not selects -- gemv.h ltile)
+    // STAGED (round 5, qkv_qkn_in_launch): a wave stalls at ISSUE once the CU's memory pipe is full, so tiles requested up front -- 128 KB per
+    // CU at head_dim 256 with 128-slot ranges -- hold the wave's own arithmetic back until most of them have ARRIVED (the first row pair of
+    // the wq|wk|wv phase was multiplied 5 us after its weights were in).  Such a policy is handed the requests and places them between
+    // its own phases: step t < T = the K tile t, step QSrc::V_STEP = the V tiles (when PIN_V).
+    // (every load of the launch unconditional: with one load behind a branch hipcc waits vmcnt(0) wherever it waits -- the
+    //  rmsnorm of the wq|wk|wv phase would sit behind every tile of the launch.  Waves that compute no scores read one
+    //  broadcast line of the cache: masks, not selects -- gemv.h ltile)
+    auto request_k_lds = [&](int t) {
         const size_t live = (size_t)0 - (size_t)(scorer ? 1 : 0);
+        const uint32_t pos = p_begin + t * PB + wave * 16 + col;
+        const bf16_t* kbase = kc + ((((size_t)kvc * max_seq + (pos < max_seq ? pos : max_seq - 1)) * HD + c * 8) & live);
 #pragma unroll
-        for (int t = 0; t < T; t++) {
-            const uint32_t pos = p_begin + t * PB + wave * 16 + col;
-            const bf16_t* kbase = kc + ((((size_t)kvc * max_seq + (pos < max_seq ? pos : max_seq - 1)) * HD + c * 8) & live);
+        for (int ks = 0; ks < KS; ks++) kb[t][ks] = *reinterpret_cast<const uint4*>(kbase + ks * 32);
+    };
+    if constexpr (QSrc::LDS) {
+        if constexpr (!QSrc::STAGED) {
 #pragma unroll
-            for (int ks = 0; ks < KS; ks++) kb[t][ks] = *reinterpret_cast<const uint4*>(kbase + ks * 32);
+            for (int t = 0; t < T; t++) request_k_lds(t);
         }
     } else if (scorer) {
 #pragma unroll
@@ -874,8 +881,31 @@ attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const
     //  tile requested BEHIND it: its barriers are opaque to the compiler, so requests written in front of them stay there, and
     //  its first wait -- for the table row, the launch's youngest load -- then waits for the V tile as well)
     constexpr bool V_LATE = QSrc::LDS && !QSrc::PIN_V;
-    if constexpr (!V_LATE) request_v();
-    if constexpr (QSrc::LDS) {
+    if constexpr (!V_LATE && !QSrc::STAGED) request_v();
+    if constexpr (QSrc::LDS && QSrc::STAGED) {
+        qsrc.before_scores([&](int step) {
+            asm volatile("" ::: "memory"); // (the requests stay between the policy's phases: no load moves across)
+#pragma unroll
+            for (int t = 0; t < T; t++)
+                if (step == t) request_k_lds(t);
+            if (step == QSrc::V_STEP && !V_LATE) request_v();
+            asm volatile("" ::: "memory");
+        });
+        uint32_t never;
+        asm volatile("s_mov_b32 %0, 0" : "=s"(never));
+        if (never) {
+            if constexpr (QSrc::PIN_V) {
+#pragma unroll
+                for (int t = 0; t < T; t++)
+#pragma unroll
+                    for (int b = 0; b < NB; b++) asm volatile("" ::"v"(vb[t][b][0].x), "v"(vb[t][b][1].w));
+            }
+#pragma unroll
+            for (int t = 0; t < T; t++)
+#pragma unroll
+                for (int ks = 0; ks < KS; ks++) asm volatile("" ::"v"(kb[t][ks].x));
+        }
+    } else if constexpr (QSrc::LDS) {
         // (T > 1, round 5: wider ranges -- mc_attn_qkv_wo_i8_*_t4, S = 8192 with one 512-thread workgroup per CU; every tile of the
         //  step's slot is patched below)
         // the tile requests stay HERE, in front of the phase that computes the queries (a value used on a never-taken path cannot
@@ -1064,6 +1094,11 @@ attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const
             }
         }
         // ---- 4. P.V over the range's slots: A = T(e * inv) from LDS (softmax.metal:84-86), B = the V tiles
+        // (round 5: no select per element -- ~ 60 of a step's ~ 100 instructions, and the P.V of a wide range is VALU time: 1.76 us for the
+        //  eight steps of Gemma-7B's 128-slot ranges.  Slots past kv_len hold e = 0 (the scores wrote it), so T(0 * inv) is the 0 the
+        //  select gave; rows past n_rep of the numerator buffer were never written and must not reach the MFMA as NaNs: those lanes
+        //  read row 0 instead and multiply by their inv = 0 -- rows of the A operand nobody reads the results of)
+        const uint32_t erow = (col < n_rep ? col : 0u) * (uint32_t)ES;
 #pragma unroll
         for (int t = 0; t < T; t++)
 #pragma unroll
@@ -1071,18 +1106,12 @@ attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const
                 if (wave + NW * b >= (uint32_t)NDB) continue;
 #pragma unroll
                 for (int u = 0; u < 2; u++) {
-                    const uint32_t p0 = p_begin + t * PB + u * 32 + c * 8;
-                    const float4 e0 = *reinterpret_cast<const float4*>(ebuf + col * ES + t * PB + u * 32 + c * 8);
-                    const float4 e1 = *reinterpret_cast<const float4*>(ebuf + col * ES + t * PB + u * 32 + c * 8 + 4);
+                    const float4 e0 = *reinterpret_cast<const float4*>(ebuf + erow + t * PB + u * 32 + c * 8);
+                    const float4 e1 = *reinterpret_cast<const float4*>(ebuf + erow + t * PB + u * 32 + c * 8 + 4);
                     const float e[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
                     uint32_t wv[4];
 #pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        // (rows past n_rep of the numerator buffer were never written: they must not reach the MFMA as NaNs)
-                        const float pa = (col < n_rep && p0 + 2 * j < S) ? e[2 * j] * inv : 0.0f;
-                        const float pb = (col < n_rep && p0 + 2 * j + 1 < S) ? e[2 * j + 1] * inv : 0.0f;
-                        wv[j] = pack_bf16x2(pa, pb);
-                    }
+                    for (int j = 0; j < 4; j++) wv[j] = pack_bf16x2(e[2 * j] * inv, e[2 * j + 1] * inv);
                     const uint4 pa4 = make_uint4(wv[0], wv[1], wv[2], wv[3]);
                     oacc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, pa4), __builtin_bit_cast(bf16x8_t, vb[t][b][u]), oacc[b], 0, 0, 0);
                 }
