@@ -53,10 +53,27 @@ using namespace mc::gemv;
 // bfloat scale per row and group, the row in LDS in natural order, a packet of 16 weights dequantised and multiplied as gemv.h
 // mac<Q_EXACT> (Wd = T(T(q) T(s)) per weight, fp32 sums by v_dot2c); up to two pairs per wave.  The stand-alone int8 kernels multiply on
 // the matrix pipe (gemv.h mac8b_n): the same products in another order -- parity with the oracle, not identity with those launches.
-template <int HD, int QN, int WB = 0>
+// STG (round 5): where the K / V tile requests of the attention go.  0: in front of the wq|wk|wv phase (round 4).  A wave stalls at ISSUE once
+// the CU's memory pipe is full, so requests written in front of the multiplications hold those back until most of the bytes have
+// arrived (decode_kernels.hip attn_fused_bf, STAGED); 1: the K tile behind the first pair's multiplication, the V tile behind the second;
+// 2: ... the V tile behind the polls of hand-off Q (a wave's loads return in order: polls behind its V tile see their granules when
+// that has arrived).  Same box, alternating (tools/ab_hsaco.sh, tools/configs_run.py; 3-4 rounds each): Llama-3-8B int4 800.0 -> 808.9 tokens/s
+// with 1 (789.2 with 2); int8 at S = 8192 502.0 -> 507.8 with 2 (501.5 with 1); plain bfloat weights (one pair per wave: one phase) 1513 ->
+// 1503 with 2 on TinyLlama: left at 0.
+#ifndef MC_QX_STG_I4
+#define MC_QX_STG_I4 1
+#endif
+#ifndef MC_QX_STG_I8
+#define MC_QX_STG_I8 2
+#endif
+#ifndef MC_QX_STG_W
+#define MC_QX_STG_W 0
+#endif
+template <int HD, int QN, int WB = 0, int STG = (WB == 0 ? MC_QX_STG_I4 : (WB == 1 ? MC_QX_STG_W : MC_QX_STG_I8))>
 struct qkv_in_launch {
     static_assert(WB ? QN == 4 : QN == 2, "at most one 16-byte packet of the hidden row per thread (K = 4096 int4 / int8, 2048 bfloat; 512 threads)");
-    static constexpr bool LDS = true, PIN_V = true, STAGED = false;
+    static constexpr bool LDS = true, PIN_V = true, STAGED = STG != 0;
+    static constexpr int K_STEPS = WB == 1 ? 1 : 2, V_STEP = STG == 2 ? K_STEPS : K_STEPS - 1; // (the polls are step K_STEPS)
     static constexpr int TL_STRIDE = 16, TL_BASE = 3; // stamps: 0 start, 1 row staged, 2 pairs published, 3.. attn_fused_bf's 0..
     static constexpr uint32_t KQ = WB == 1 ? 512u * QN : (WB == 2 ? 1024u * QN : 2048u * QN), ROWBQ = 1024u * QN, CHUNK_LDS = 2048 * 2 / 16 * 17, HALF = HD / 2;
     static constexpr uint32_t NPK = KQ / 8; // 16-byte packets of the hidden row
@@ -241,7 +258,9 @@ struct qkv_in_launch {
         eo_c = ((gfloat_p)fcos)[(size_t)rrow_ * HALF + jj];
         eo_s = ((gfloat_p)fsin)[(size_t)rrow_ * HALF + jj];
     }
-    __device__ __forceinline__ void before_scores()
+    __device__ __forceinline__ void before_scores() { before_scores([](int) {}); }
+    template <typename Tiles>
+    __device__ __forceinline__ void before_scores(Tiles&& tiles)
     {
         const uint32_t tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
         const uint32_t kv = blockIdx.x % KV;
@@ -314,12 +333,15 @@ struct qkv_in_launch {
         float my_a = 0.0f, my_b = 0.0f;
 #pragma unroll
         for (int i = 0; i < PMAXQ; i++) {
-            if ((uint32_t)i >= full) break;
-            const float ra = row_sum(ww[i][0], wsc[i], 0u), rb = row_sum(ww[i][1], wsc[i], 1u);
-            if (lane == (uint32_t)i) {
-                my_a = ra;
-                my_b = rb;
+            if (!STAGED && (uint32_t)i >= full) break;
+            if ((uint32_t)i < full) { // (wave-uniform; no load inside)
+                const float ra = row_sum(ww[i][0], wsc[i], 0u), rb = row_sum(ww[i][1], wsc[i], 1u);
+                if (lane == (uint32_t)i) {
+                    my_a = ra;
+                    my_b = rb;
+                }
             }
+            if constexpr (STAGED) tiles(i);
         }
         if (shared) { // (wave-uniform, and uniform over the workgroup: the barrier below is reached by every wave or by none)
             const float rs = row_sum(ww[PMAXQ - 1][0], wsc[PMAXQ - 1], sh_row);
@@ -358,15 +380,18 @@ struct qkv_in_launch {
         }
         stamp(2);
         // ---- hand-off Q: the PG pairs of this kv head into LDS (thread t: pair t), natural order
+        unsigned long long g = 0ull;
         if (wave * 64u < PG) {
             const unsigned long long* gp = qkv_g + (size_t)kv * PG + min(tid, PG - 1u);
-            unsigned long long g = 0ull;
             handoff_wait w;
             for (uint32_t look = 0;; look++) {
                 g = fastpath ? granule_look_dual(gp, (size_t)KV * PG, look) : granule_load(gp);
                 const bool ok = (uint32_t)(g >> 32) == tag;
                 if (__all(ok) || w.expired(st, 0xD0000000u | layer_tag)) break;
             }
+        }
+        if constexpr (STAGED) tiles(PMAXQ);
+        {
             if (tid < PG) {
                 const uint32_t hq = n_rep * HALF;
                 const bf16_t lo = (bf16_t)(g & 0xFFFFu), hi = (bf16_t)((g >> 16) & 0xFFFFu);
@@ -414,7 +439,7 @@ struct qkv_qkn_in_launch {
                        // order: polls behind 8 KB of V tiles per wave see their granules only when those have arrived)
 #endif
     static constexpr bool LDS = true, PIN_V = MC_GQ_PIN_V != 0, STAGED = MC_GQ_STAGED != 0;
-    static constexpr int V_STEP = MC_GQ_V_STEP;
+    static constexpr int V_STEP = MC_GQ_V_STEP, K_STEPS = 3;
     static constexpr int TL_STRIDE = 16, TL_BASE = 3; // stamps: 0 start, 1 row staged, 2 pairs published, 3.. attn_fused_bf's 0.., 11 rows normalised
     static constexpr uint32_t KQ = 3072u, NPK = KQ / 8, ROWB2 = 3072u, CHUNK_LDS = 2048 * 2 / 16 * 17, HALF = HD / 2, WPH = HALF / 64;
     static constexpr int PMAXQ = 3, NCH = 3;

@@ -831,7 +831,7 @@ attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const
     // STAGED (round 5, qkv_qkn_in_launch): a wave stalls at ISSUE once the CU's memory pipe is full, so tiles requested up front -- 128 KB per
     // CU at head_dim 256 with 128-slot ranges -- hold the wave's own arithmetic back until most of them have ARRIVED (the first row pair of
     // the wq|wk|wv phase was multiplied 5 us after its weights were in).  Such a policy is handed the requests and places them between
-    // its own phases: step t < T = the K tile t, step QSrc::V_STEP = the V tiles (when PIN_V).
+    // its own phases (K_STEPS of them that multiply): step t = the K tile t, step QSrc::V_STEP = the V tiles (when PIN_V).
     // (every load of the launch unconditional: with one load behind a branch hipcc waits vmcnt(0) wherever it waits -- the
     //  rmsnorm of the wq|wk|wv phase would sit behind every tile of the launch.  Waves that compute no scores read one
     //  broadcast line of the cache: masks, not selects -- gemv.h ltile)
@@ -886,8 +886,8 @@ attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const
         qsrc.before_scores([&](int step) {
             asm volatile("" ::: "memory"); // (the requests stay between the policy's phases: no load moves across)
 #pragma unroll
-            for (int t = 0; t < T; t++)
-                if (step == t) request_k_lds(t);
+            for (int t = 0; t < T; t++) // (tile t behind phase t; what is left of a wide range behind the policy's last phase)
+                if (step == (t < QSrc::K_STEPS ? t : QSrc::K_STEPS - 1)) request_k_lds(t);
             if (step == QSrc::V_STEP && !V_LATE) request_v();
             asm volatile("" ::: "memory");
         });
