@@ -297,6 +297,11 @@ struct mc_decoder {
     unsigned long long* attn_slab_g = nullptr; // [KV][nsplit][n_rep][hd] fp32 partial P.V sums
     unsigned long long* attn_row_g = nullptr;  // [H * hd / 2]          the finished attention row, two bf16 per granule (mc_attn_wo_*)
     unsigned long long* attn_qkv_g = nullptr;  // [KV][(n_rep + 2) hd / 2] the step's rotated queries and K / V row, two bf16 per granule (mc_attn_qkv_wo_*)
+    // MC_ATTN_QKV_ONLY=1: the 70B shapes' wq|wk|wv GEMV inside the attention launch (mc_attn_qkv_i4_bfloat_hd128_q4).  Built in round 5 as VERDICT r04
+    // item 2 (iv) asked, bit for bit the two launches, and NOT faster: 21.25 us against 11.65 + 9.04 in the trace (profiles/r05_kernel_stats_70b_qkvin.csv),
+    // 127.4 / 127.1 against 128.0 / 127.9 tokens/s alternating on one box -- 160 KB of wq|wk|wv per workgroup are 7 us of multiplication in front of
+    // the first hand-off, which is what the GEMV launch lasts.  Off by default.
+    bool attn_qkv_only_on = false;
     bool attn_qkv_qkn_on = true; // MC_ATTN_QKV_QKN=0: gemma3's wq|wk|wv GEMV as a launch of its own in front of mc_attn_wo_qkn_* (A/B, parity)
     bool attn_wo_qkn_on = true;  // MC_ATTN_WO_QKN=0: gemma3's q/k-norm + rope + cache write + attention as mc_attn_fused_qkn_T, Wo as a GEMV of its own (A/B, parity)
     bool attn_qkn_on = true;     // MC_ATTN_QKN=0: gemma3's q/k-norm + rope + cache write as a launch of their own (mc_rope_kv_T) in front of the attention (A/B, parity)
@@ -311,7 +316,7 @@ struct mc_decoder {
     hipEvent_t err_evt = nullptr;
     bool err_pending = false;
     int handoff_fallbacks = 0;
-    int occ_fused = -1, occ_wo = -1, occ_wo_w = -1, occ_wo_i8 = -1, occ_wo_qkn = -1, occ_qkv_qkn = -1;   // co-resident workgroups per CU of the hand-off launches (the occupancy API's answer; -1: not asked yet)
+    int occ_fused = -1, occ_wo = -1, occ_wo_w = -1, occ_wo_i8 = -1, occ_wo_qkn = -1, occ_qkv_qkn = -1, occ_qkv_only = -1;   // co-resident workgroups per CU of the hand-off launches (the occupancy API's answer; -1: not asked yet)
     bool handoff_fast = true;    // MC_HANDOFF_FAST=0: hand-offs A and B through the fabric only (A/B; handoff.h "the XCD-local fast path")
     bool attn_wo_on = true;      // MC_ATTN_WO=0: the Wo GEMV as a launch of its own behind the one-launch attention (A/B, parity)
     bool attn_fused_on = true;   // MC_ATTN_FUSED=0: scores and P.V as two launches (A/B, parity)
@@ -706,6 +711,7 @@ struct mc_decoder {
         occ_wo_i8 = hd == 128 ? ask("mc_attn_qkv_wo_i8_bfloat_hd128_k4_q4_t4", 512) : 0;
         occ_wo_qkn = hd == 256 ? ask("mc_attn_wo_qkn_i4_bfloat_hd256_k2_t2", 512) : 0;
         occ_qkv_qkn = hd == 256 ? ask("mc_attn_qkv_wo_qkn_i4_bfloat_hd256_k2_p2_t2", 512) : 0;
+        occ_qkv_only = hd == 128 ? ask("mc_attn_qkv_i4_bfloat_hd128_q4", 512) : 0;
         (void)hipGetLastError();
     }
     // a hand-off gave up: report nothing yet, make the NEXT launches independent of co-residency
@@ -797,6 +803,18 @@ struct mc_decoder {
         const bool built = hd == 128 && L.wo.in == 4096 && L.qkv.in == 4096;
         return built && L.qkv.group == L.wo.group && pg % nsplit == 0 && pg / nsplit <= 16 && n_rep <= 16 &&
                L.qkv.out == (cfg.n_heads + 2 * cfg.n_kv_heads) * hd && pg >= 64 && pg <= 512;
+    }
+
+    // ... WITHOUT Wo (round 5, mc_attn_qkv_i4_bfloat_hd128_q4: Llama-3-70B -- its Wo rows of 4 KiB stay a GEMV, attn_wo_fused): rows of 4 KiB for
+    // wq|wk|wv too (K = 8192), up to three pairs per wave, the kv head's pairs gathered in two passes of 512
+    bool
+    attn_qkv_only_ok(const layer_w& L) const
+    {
+        if (!attn_qkv_on || !attn_qkv_only_on || !attn_qkv_g || !attn_fused() || tb != 2 || cfg.family == MC_FAMILY_GEMMA3 || occ_qkv_only == 0) return false;
+        if (!lin_ok(L.qkv) || L.qkv.lora_cols || L.qkv.in != 8192 || cfg.dim != 8192 || cfg.head_dim != 128 || cfg.n_kv_heads % 8 != 0) return false;
+        const int hd = cfg.head_dim, n_rep = cfg.n_heads / cfg.n_kv_heads, pg = (n_rep + 2) * hd / 2;
+        return (unsigned)(nsplit * cfg.n_kv_heads) <= (unsigned)dev->prop.multiProcessorCount && n_rep <= 16 && pg <= 1024 && pg % nsplit == 0 &&
+               pg / nsplit <= 24 && pg / nsplit >= 8 && L.qkv.out == (cfg.n_heads + 2 * cfg.n_kv_heads) * hd;
     }
 
     // VIRTUAL kv heads of the launches with wq|wk|wv inside (decode_kernels.hip attn_fused_bf, kv_shift): a model with 1, 2 or 4 kv heads is
@@ -1070,7 +1088,7 @@ struct mc_decoder {
             const bool qkv_w_in = attn_qkv_wo_w_fused(L);
             const int i8_tiles = qkv_w_in ? 0 : attn_qkv_wo_i8_tiles(L);
             const bool qkv_in = qkv_w_in || i8_tiles || attn_qkv_wo_fused(L);
-            bool qkn_in = false, gq = false;
+            bool qkn_in = false, gq = false, q_only = false;
             int qkn_wo = 0;
             if (qkv_in) {
                 // attention_norm, wq|wk|wv, rope, cache write, scores, softmax, P.V, wo + residual (transformer.h:130-133,
@@ -1091,6 +1109,18 @@ struct mc_decoder {
                                 (const void*)L.attention_norm, (const void*)L.qkv.w, (const void*)L.qkv.scales,
                                 (const float*)rope_cos[L.rope_table], (const float*)rope_sin[L.rope_table], cfg.norm_eps, mu,
                                 (uint32_t)(vfast ? 1 : 0), (void*)nullptr, (uint32_t)vsh));
+                if (s != MC_OK) return s;
+            } else if (!gemma && (q_only = attn_qkv_only_ok(L))) {
+                // attention_norm, wq|wk|wv, rope, cache write, scores, softmax, P.V (transformer.h:130, attention.h:170-203) in ONE launch;
+                // Wo + residual from the finished row below
+                s = launch("mc_attn_qkv_i4_" + tname + "_hd128_q4", (unsigned)(nsplit * KV), 1, 1, 512, 0,
+                           pack((const void*)L.kc, (const void*)L.vt, attn_out, attn_psum_g, attn_slab_g, attn_qkv_g, state, (uint32_t)n_rep,
+                                (uint32_t)KV, (uint32_t)cfg.max_seq_len, scale_T, (uint32_t)nsplit, (uint32_t)(li + 1), x, (uint32_t)L.qkv.group,
+                                (const void*)L.attention_norm, (const void*)L.qkv.w, (const void*)L.qkv.scales,
+                                (const float*)rope_cos[L.rope_table], (const float*)rope_sin[L.rope_table], cfg.norm_eps, mu,
+                                (uint32_t)(handoff_fast_here() ? 1 : 0), (void*)nullptr));
+                if (s != MC_OK) return s;
+                s = gemv(L.wo, 0, 1, attn_out, hidden, x, nullptr, mu);
                 if (s != MC_OK) return s;
             } else if (!gemma) {
                 // attention_norm + wq|wk|wv + rope + cache write in ONE launch
@@ -1146,7 +1176,7 @@ struct mc_decoder {
                     if (s != MC_OK) return s;
                 }
             }
-            if (qkv_in) {
+            if (qkv_in || q_only) {
             } else if (gq) {
                 if (!fuse_pn) {
                     s = launch("mc_rmsnorm_row_" + tname, 1, 1, 1, 1024, 0,
@@ -2066,6 +2096,7 @@ mc_decoder_create(mc_device* dev, mc_library* lib, mc_queue* q, const mc_decoder
     if (const char* e = getenv("MC_ATTN_QKN")) d->attn_qkn_on = atoi(e) != 0;
     if (const char* e = getenv("MC_ATTN_WO_QKN")) d->attn_wo_qkn_on = atoi(e) != 0;
     if (const char* e = getenv("MC_ATTN_QKV_QKN")) d->attn_qkv_qkn_on = atoi(e) != 0;
+    if (const char* e = getenv("MC_ATTN_QKV_ONLY")) d->attn_qkv_only_on = atoi(e) != 0;
     if (const char* e = getenv("MC_LAZY_PICK")) d->lazy_pick_on = atoi(e) != 0;
     if (const char* e = getenv("MC_PF2")) d->pf2_on = atoi(e) != 0;
     if (const char* e = getenv("MC_KV_VIRTUAL")) d->kv_virtual_on = atoi(e) != 0;

@@ -71,14 +71,18 @@ using namespace mc::gemv;
 #endif
 template <int HD, int QN, int WB = 0, int STG = (WB == 0 ? MC_QX_STG_I4 : (WB == 1 ? MC_QX_STG_W : MC_QX_STG_I8))>
 struct qkv_in_launch {
-    static_assert(WB ? QN == 4 : QN == 2, "at most one 16-byte packet of the hidden row per thread (K = 4096 int4 / int8, 2048 bfloat; 512 threads)");
+    // (WB = 0, QN = 4 -- round 5, mc_attn_qkv_i4_bfloat_hd128_q4: Llama-3-70B's rows of 4 KiB (K = 8192): two packets of the hidden row per
+    //  thread, up to THREE pairs per wave (20 per workgroup), 640 pairs per kv head gathered in two passes)
+    static_assert(WB ? QN == 4 : (QN == 2 || QN == 4), "K = 4096 / 8192 int4, 4096 int8, 2048 bfloat; 512 threads");
+    static constexpr bool WIDE = WB == 0 && QN == 4;
     static constexpr bool LDS = true, PIN_V = true, STAGED = STG != 0;
-    static constexpr int K_STEPS = WB == 1 ? 1 : 2, V_STEP = STG == 2 ? K_STEPS : K_STEPS - 1; // (the polls are step K_STEPS)
+    static constexpr int K_STEPS = WB == 1 ? 1 : (WIDE ? 3 : 2), V_STEP = STG == 2 ? K_STEPS : K_STEPS - 1; // (the polls are step K_STEPS)
     static constexpr int TL_STRIDE = 16, TL_BASE = 3; // stamps: 0 start, 1 row staged, 2 pairs published, 3.. attn_fused_bf's 0..
     static constexpr uint32_t KQ = WB == 1 ? 512u * QN : (WB == 2 ? 1024u * QN : 2048u * QN), ROWBQ = 1024u * QN, CHUNK_LDS = 2048 * 2 / 16 * 17, HALF = HD / 2;
     static constexpr uint32_t NPK = KQ / 8; // 16-byte packets of the hidden row
     static constexpr uint32_t WPK = WB == 1 ? 8u : (WB == 2 ? 16u : 32u); // weights of a lane's 16-byte packet
-    static constexpr int PMAXQ = WB == 1 ? 1 : 2;
+    static constexpr int PMAXQ = WB == 1 ? 1 : (WIDE ? 3 : 2);
+    static constexpr int NXP = WIDE ? 2 : 1; // packets of the hidden row per thread
     typedef const __attribute__((address_space(3))) bf16_t* lds_row;
     typedef __attribute__((address_space(3))) bf16_t* lds_row_w;
     typedef uint32_t rowv4 __attribute__((ext_vector_type(4)));
@@ -96,7 +100,7 @@ struct qkv_in_launch {
     float eps, mu;
     unsigned long long* tl;
     // ---- what at_start() leaves for before_scores()
-    rowv4 xr, nr;
+    rowv4 xr[NXP], nr[NXP];
     uint4 ww[PMAXQ][2][QN];
     uint32_t wsc[PMAXQ][QN];
     float eo_c, eo_s;
@@ -177,8 +181,11 @@ struct qkv_in_launch {
         const uint32_t tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
         // the row first (gemv.h, the build-time prologue of the linear-order kernels), the step state behind it
         const uint32_t pk = WB == 1 ? tid & (NPK - 1u) : tid; // (bfloat weights: 256 packets, threads 256.. read them again and add nothing)
-        xr = reinterpret_cast<const rowv4*>(xp)[pk];
-        nr = reinterpret_cast<const rowv4*>(normp)[pk];
+#pragma unroll
+        for (int i = 0; i < NXP; i++) {
+            xr[i] = reinterpret_cast<const rowv4*>(xp)[pk + 512u * i];
+            nr[i] = reinterpret_cast<const rowv4*>(normp)[pk + 512u * i];
+        }
         stamp(0);
         const __attribute__((address_space(1))) int32_t* stp = (const __attribute__((address_space(1))) int32_t*)st;
         slot = (uint32_t)stp[3];
@@ -187,7 +194,7 @@ struct qkv_in_launch {
         asm volatile("s_barrier" ::: "memory"); // (the row's requests stay ahead of the weight requests in the CU's memory pipe)
         const uint32_t split = blockIdx.x / KV;
         const uint32_t PG = (n_rep + 2u) * HALF, PW = PG / nsplit, e = PW >> 3, r = PW & 7u;
-        if (MC_QKV_ROW_DEAL && WB == 0 && r == 4u && e + 1u <= (uint32_t)PMAXQ) {
+        if (MC_QKV_ROW_DEAL && !WIDE && WB == 0 && r == 4u && e + 1u <= (uint32_t)PMAXQ) {
             const uint32_t w4 = wave & 3u;
             full = e;
             j0 = split * PW + (wave < 4u ? w4 * (e + 1u) : 4u * (e + 1u) + w4 * e);
@@ -210,13 +217,19 @@ struct qkv_in_launch {
         const uint32_t tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
         // ---- rmsnorm on the way into LDS (kernel/rmsnorm.metal:52-95; the additions in the stand-alone kernel's order)
         {
-            const uint32_t vv[4] = {xr.x, xr.y, xr.z, xr.w}, wv[4] = {nr.x, nr.y, nr.z, nr.w};
+            // (gemv.h, the build-time prologue: a sum per packet, the packets' sums added in order)
             float ss = 0.0f;
 #pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const float a = asf(vv[e] << 16), b = asf(vv[e] & 0xFFFF0000u);
-                ss += a * a;
-                ss += b * b;
+            for (int i = 0; i < NXP; i++) {
+                const uint32_t vv[4] = {xr[i].x, xr[i].y, xr[i].z, xr[i].w};
+                float s1 = 0.0f;
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const float a = asf(vv[e] << 16), b = asf(vv[e] & 0xFFFF0000u);
+                    s1 += a * a;
+                    s1 += b * b;
+                }
+                ss += s1;
             }
             const float wsum_ = wave_sum_dpp(WB == 1 && tid >= NPK ? 0.0f : ss);
 #if MC_ABL_NORM_NOXWAVE
@@ -229,22 +242,30 @@ struct qkv_in_launch {
             for (int i = 0; i < 8; i++) tot += red[i];
 #endif
             const float inv = 1.0f / sqrtf(tot / (float)KQ + eps);
-            uint32_t o[4];
 #pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const float a = (mu + asf(wv[e] << 16)) * asf(vv[e] << 16) * inv;
-                const float b = (mu + asf(wv[e] & 0xFFFF0000u)) * asf(vv[e] & 0xFFFF0000u) * inv;
-                o[e] = pack_bf16x2(a, b);
+            for (int i = 0; i < NXP; i++) {
+                const uint32_t vv[4] = {xr[i].x, xr[i].y, xr[i].z, xr[i].w}, wv[4] = {nr[i].x, nr[i].y, nr[i].z, nr[i].w};
+                uint32_t o[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const float a = (mu + asf(wv[e] << 16)) * asf(vv[e] << 16) * inv;
+                    const float b = (mu + asf(wv[e] & 0xFFFF0000u)) * asf(vv[e] & 0xFFFF0000u) * inv;
+                    o[e] = pack_bf16x2(a, b);
+                }
+                const uint32_t p = tid + 512u * i;
+                if constexpr (WB == 0) reinterpret_cast<rowv4*>(xs)[p + (p >> 4)] = rowv4{o[0], o[1], o[2], o[3]}; // (packet p sits in slot p + p / 16)
+                else if (tid < NPK) reinterpret_cast<rowv4*>(xs)[tid] = rowv4{o[0], o[1], o[2], o[3]};              // (natural order)
             }
-            if constexpr (WB == 0) reinterpret_cast<rowv4*>(xs)[tid + (tid >> 4)] = rowv4{o[0], o[1], o[2], o[3]}; // (packet p sits in slot p + p / 16)
-            else if (tid < NPK) reinterpret_cast<rowv4*>(xs)[tid] = rowv4{o[0], o[1], o[2], o[3]};                  // (natural order)
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         stamp(1);
         // ---- the rest of the wave's rows and the rotation of the pair this lane will finish (lane i < cnt: whole pair j0 + i,
         // then the shared pair; its address waits for the step state: asked for in at_start() that wait sat in the middle of
         // the weight requests)
-        if constexpr (PMAXQ > 1) {
+        if constexpr (WIDE) {
+            request_pair(1);
+            request_pair(2);
+        } else if constexpr (PMAXQ > 1) {
             if constexpr (WB == 0) {
                 if (shared) request_shared_row();   // (wave-uniform, and the same for every wave of the launch: no wave's loads
                 else request_pair(PMAXQ - 1);       //  are "behind a branch" that another path of ITS OWN code does not take)
@@ -380,29 +401,36 @@ struct qkv_in_launch {
         }
         stamp(2);
         // ---- hand-off Q: the PG pairs of this kv head into LDS (thread t: pair t), natural order
-        unsigned long long g = 0ull;
-        if (wave * 64u < PG) {
-            const unsigned long long* gp = qkv_g + (size_t)kv * PG + min(tid, PG - 1u);
-            handoff_wait w;
-            for (uint32_t look = 0;; look++) {
-                g = fastpath ? granule_look_dual(gp, (size_t)KV * PG, look) : granule_load(gp);
-                const bool ok = (uint32_t)(g >> 32) == tag;
-                if (__all(ok) || w.expired(st, 0xD0000000u | layer_tag)) break;
+        constexpr int NPASS = WIDE ? 2 : 1; // (up to 512 NPASS pairs per kv head)
+        unsigned long long g[NPASS];
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ps++) {
+            g[ps] = 0ull;
+            if (512u * ps + wave * 64u < PG) {
+                const unsigned long long* gp = qkv_g + (size_t)kv * PG + min(512u * ps + tid, PG - 1u);
+                handoff_wait w;
+                for (uint32_t look = 0;; look++) {
+                    g[ps] = fastpath ? granule_look_dual(gp, (size_t)KV * PG, look) : granule_load(gp);
+                    const bool ok = (uint32_t)(g[ps] >> 32) == tag;
+                    if (__all(ok) || w.expired(st, 0xD0000000u | layer_tag)) break;
+                }
             }
         }
         if constexpr (STAGED) tiles(PMAXQ);
-        {
-            if (tid < PG) {
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ps++) {
+            const uint32_t t = 512u * ps + tid;
+            if (t < PG) {
                 const uint32_t hq = n_rep * HALF;
-                const bf16_t lo = (bf16_t)(g & 0xFFFFu), hi = (bf16_t)((g >> 16) & 0xFFFFu);
+                const bf16_t lo = (bf16_t)(g[ps] & 0xFFFFu), hi = (bf16_t)((g[ps] >> 16) & 0xFFFFu);
                 lds_row_w qw_ = (lds_row_w)q_s;
-                if (tid < hq + HALF) { // q heads of the group, then its k head: [head][HD], element jj and jj + HD / 2
-                    const uint32_t hl = tid / HALF, jj = tid % HALF;
+                if (t < hq + HALF) { // q heads of the group, then its k head: [head][HD], element jj and jj + HD / 2
+                    const uint32_t hl = t / HALF, jj = t % HALF;
                     qw_[hl * HD + jj] = lo;
                     qw_[hl * HD + jj + HALF] = hi;
                 } else { // v: elements 2 jj, 2 jj + 1
-                    const uint32_t jj = tid - hq - HALF;
-                    *(__attribute__((address_space(3))) uint32_t*)(qw_ + (n_rep + 1u) * HD + 2u * jj) = (uint32_t)g;
+                    const uint32_t jj = t - hq - HALF;
+                    *(__attribute__((address_space(3))) uint32_t*)(qw_ + (n_rep + 1u) * HD + 2u * jj) = (uint32_t)g[ps];
                 }
             }
         }
@@ -1017,6 +1045,46 @@ attn_wo_body(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const 
     }
 // mc_attn_qkv_wo_i4_bfloat_hd{head_dim}_k{KiB per Wo row}_q{KiB per wq|wk|wv row}
 MC_ATTN_QKV_WO(mc_attn_qkv_wo_i4_bfloat_hd128_k2_q2, 128, 2, 2)  // Llama-3-8B: dim 4096, 32 heads x 128
+// ... WITHOUT Wo (round 5, Llama-3-70B: 64 heads x 128 make Wo rows of 4 KiB -- two pairs per wave are 64 registers requested behind the
+// scores, measured slower than the GEMV twice, above): attention_norm + wq|wk|wv (rows of 4 KiB, K = 8192) + rope + cache write + the decode
+// attention in one launch, the row left in HBM for the Wo GEMV: mc_attn_qkv_i4_bfloat_hd{head_dim}_q{KiB per wq|wk|wv row}
+template <int HD, int QN>
+__device__ __forceinline__ void
+attn_qkv_body(const bf16_t* kc, const bf16_t* vt, bf16_t* attn_out, unsigned long long* psum_g, unsigned long long* slab_g, unsigned long long* qkv_g,
+              step_state* st, uint32_t n_rep, uint32_t KV, uint32_t max_seq, float scale, uint32_t nsplit, uint32_t layer_tag, const bf16_t* x,
+              uint32_t group, const void* norm_w, const void* qkv_w, const void* qkv_s, const float* fcos, const float* fsin, float eps, float mu,
+              uint32_t fastpath, unsigned long long* tl)
+{
+    constexpr uint32_t CHUNK_LDS = 2048 * 2 / 16 * 17;
+    __shared__ __attribute__((aligned(16))) char xs[QN * CHUNK_LDS];
+    __shared__ float qred[16];
+    __shared__ __attribute__((aligned(16))) bf16_t qkv_rows[18 * HD];
+    typedef qkv_in_launch<HD, QN, 0> qx_t;
+    typedef typename qx_t::lds_row lds_row;
+    qx_t qx;
+    qx.q_s = (lds_row)qkv_rows;
+    qx.k_s = (lds_row)qkv_rows + n_rep * HD;
+    qx.v_s = (lds_row)qkv_rows + (n_rep + 1u) * HD;
+    qx.xp = x; qx.normp = norm_w; qx.qw = qkv_w; qx.qs = qkv_s; qx.fcos = fcos; qx.fsin = fsin;
+    qx.kc = const_cast<bf16_t*>(kc); qx.vt = const_cast<bf16_t*>(vt); qx.qkv_g = qkv_g; qx.st = st; qx.xs = xs; qx.red = qred;
+    qx.n_rep = n_rep; qx.KV = KV; qx.max_seq = max_seq; qx.nsplit = nsplit; qx.group = group; qx.layer_tag = layer_tag;
+    qx.fastpath = fastpath; qx.eps = eps; qx.mu = mu; qx.tl = tl; qx.kv_shift = 0;
+    qx.at_start();
+    // one rounding of the fp32 sum (bmm.metal:80): the attention row the Wo GEMV reads
+    auto store = [&](uint32_t head, uint32_t db, uint32_t col, float v) {
+        if ((threadIdx.x & 63) < 16) attn_out[(size_t)head * HD + db * 16 + col] = f2bf(v);
+    };
+    attn_fused_bf<HD, 1, 8>(nullptr, kc, vt, psum_g, slab_g, st, n_rep, KV, max_seq, scale, nsplit, layer_tag, tl, store, [](int) {}, fastpath, qx, 0u);
+}
+extern "C" __global__ void __launch_bounds__(512)
+mc_attn_qkv_i4_bfloat_hd128_q4(const bf16_t* kc, const bf16_t* vt, bf16_t* attn_out, unsigned long long* psum_g, unsigned long long* slab_g,
+                               unsigned long long* qkv_g, step_state* st, uint32_t n_rep, uint32_t n_kv, uint32_t max_seq, float scale, uint32_t nsplit,
+                               uint32_t layer_tag, const bf16_t* x, uint32_t group, const void* norm_w, const void* qkv_w, const void* qkv_s,
+                               const float* fcos, const float* fsin, float eps, float mu, uint32_t fastpath, unsigned long long* tl)
+{
+    attn_qkv_body<128, 4>(kc, vt, attn_out, psum_g, slab_g, qkv_g, st, n_rep, n_kv, max_seq, scale, nsplit, layer_tag, x, group, norm_w, qkv_w, qkv_s,
+                          fcos, fsin, eps, mu, fastpath, tl);
+}
 // ... with plain bfloat weights (nn::linear): mc_attn_qkv_wo_w_bfloat_hd{head_dim}_k{KiB per Wo row}_q{KiB per wq|wk|wv row}
 #define MC_ATTN_QKV_WO_W(NAME, HD, LNCH, QN)                                                                                              \
     extern "C" __global__ void __launch_bounds__(512)                                                                                    \

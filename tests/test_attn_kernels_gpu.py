@@ -538,3 +538,75 @@ def test_gemma_block_from_the_row_to_wo_in_one_launch_matches_the_oracle(acc, po
         parity.check(BF16, yb.download(np.uint16, dim), proj, rel=4e-3, max_ulp=2, max_frac=0.3, scale_aware=True,
                      what=f"norms + wq|wk|wv + q/k-norm + rope + attention + Wo in one launch, p{1 + post} n{n} tag ({epoch}, {layer_tag})")
     dec.release()
+
+
+@pytest.mark.parametrize("fast", [1, 0])
+@pytest.mark.parametrize("n", [2048, 1000, 1, 65])
+def test_llama3_70b_norm_qkv_rope_and_attention_in_one_launch_matches_the_oracle(acc, n, fast):
+    """`mc_attn_qkv_i4_bfloat_hd128_q4` (round 5; attn_block_kernels.hip attn_qkv_body): attention_norm, wq|wk|wv on rows of 4 KiB (K = 8192), RoPE,
+    the cache write and the decode attention of a Llama-3-70B block (64 heads x 128, 8 kv heads of 8 query heads: 640 rotation pairs per kv
+    head, 20 per workgroup, gathered in two passes) in ONE launch, the attention row left in HBM for the Wo GEMV -- nn/transformer.h:130,
+    nn/attention.h:170-203 -- launched BY NAME against the oracle's kernels composed as the reference composes them."""
+    import metalchat_amd as mc
+    from test_lin_kernels_gpu import dyadic_row, oracle_rmsnorm
+
+    H, KV, hd, dim, max_seq = 64, 8, 128, 8192, 2048
+    half = hd // 2
+    cfg = mg.tiny_cfg(BF16, dim=dim, n_heads=H, n_kv_heads=KV, head_dim=hd, ffn_dim=256, n_layers=1, vocab=64, max_seq_len=max_seq)
+    w = mg.make_model(cfg, seed=707, quant="i4", group=128)
+    dec = mc.Decoder(acc, **mg.decoder_kwargs(cfg, weight_format=mc.WFMT_I4, group_size=128))
+    dec.load_model(w)
+    lw = w["layers"][0]
+    qk_p, qk_s, qrows, qinf, _ = dec.weight_ptrs(0, "qkv")
+    assert (qrows, qinf) == ((H + 2 * KV) * hd, dim)
+    rng = np.random.default_rng(2000 + n)
+    n_rep, nsplit = H // KV, max_seq // PB
+    slot, rrow, nrows = n - 1, 5, 8
+    x = dyadic_row(rng, dim)
+    k = mo.encode(BF16, rng.normal(0, 0.4, (n, KV, hd)).astype(np.float32))
+    v = mo.encode(BF16, rng.normal(0, 0.5, (n, KV, hd)).astype(np.float32))
+    fcos, fsin = np.zeros((nrows, half), np.float32), np.zeros((nrows, half), np.float32)
+    L = mo.layout
+    mo.rope_freqs(L(fcos.shape), fcos, L(fsin.shape), fsin, hd, 0, 500000.0)
+    scale = float(mo.from_bf16(mo.to_bf16(np.array([hd ** -0.5], np.float32)))[0])
+    xn = oracle_rmsnorm(x, lw["attention_norm"])
+    q0 = oracle_linear(BF16, lw["wq"], xn.reshape(1, 1, -1)).reshape(H, hd)
+    k0 = oracle_linear(BF16, lw["wk"], xn.reshape(1, 1, -1)).reshape(KV, hd)
+    v0 = oracle_linear(BF16, lw["wv"], xn.reshape(1, 1, -1)).reshape(KV, hd)
+    q1, k1 = np.zeros_like(q0), np.zeros_like(k0)
+    mo.rope(BF16, L(q0.shape), q1, L(q0.shape), q0, L(fcos.shape), fcos, L(fsin.shape), fsin, 1, H, rrow)
+    mo.rope(BF16, L(k0.shape), k1, L(k0.shape), k0, L(fcos.shape), fcos, L(fsin.shape), fsin, 1, KV, rrow)
+    k[slot], v[slot] = k1, v0
+    att = oracle_attention(q1, k, v, n_rep, scale)
+    kpast, vpast = k.copy(), v.copy()
+    kpast[slot] = mo.encode(BF16, rng.normal(0, 30, (KV, hd)).astype(np.float32))
+    vpast[slot] = mo.encode(BF16, rng.normal(0, 30, (KV, hd)).astype(np.float32))
+    kc, vt = device_caches(acc, kpast, vpast, max_seq)
+    psum = acc.to_device(np.zeros(2 * H * nsplit, np.uint64))
+    slab = acc.to_device(np.zeros(2 * H * hd * nsplit, np.uint64))
+    qkv_g = acc.to_device(np.zeros(2 * (H + 2 * KV) * hd // 2, np.uint64))
+    attn_out = acc.alloc(H * hd * 2)
+    nw = acc.to_device(lw["attention_norm"])
+    cb, sb = acc.to_device(fcos.reshape(-1)), acc.to_device(fsin.reshape(-1))
+    kern = acc.load("mc_attn_qkv_i4_bfloat_hd128_q4")
+    W = lambda p_: acc.wrap(p_, 1 << 40)
+    xb = acc.to_device(x)
+    for epoch, layer_tag in ((1, 1), (1, 2), (9, 200)):
+        attn_out.upload(np.zeros(H * hd, np.uint16))
+        st = np.zeros(12, np.int32)
+        st[2], st[3], st[6], st[9] = n, slot, rrow, epoch
+        state = acc.to_device(st)
+        mc.KernelTask(kern, (nsplit * KV * 512, 1, 1), (512, 1, 1),
+                      [kc, vt, attn_out, psum, slab, qkv_g, state, np.uint32(n_rep), np.uint32(KV), np.uint32(max_seq), np.float32(scale), np.uint32(nsplit),
+                       np.uint32(layer_tag), xb, np.uint32(128), nw, W(qk_p), W(qk_s), cb, sb, np.float32(1e-5), np.float32(0.0), np.uint32(fast), None])()
+        acc.wait()
+        assert int(state.download(np.int32, 12)[10]) == 0, "a hand-off of the launch gave up"
+        kgot = kc.download(np.uint16, KV * max_seq * hd).reshape(KV, max_seq, hd)
+        vgot = vt.download(np.uint16, KV * hd * max_seq).reshape(KV, hd, max_seq)
+        parity.check(BF16, kgot[:, slot].reshape(-1), k1.reshape(-1), rel=3e-3, max_ulp=2, max_frac=0.2, what=f"K row the launch wrote (GEMV + rotation), n{n}")
+        parity.check(BF16, vgot[:, :, slot].reshape(-1), v0.reshape(-1), rel=2e-3, max_ulp=1, max_frac=0.05, what=f"V row the launch wrote, n{n}")
+        if n > 1:
+            parity.exact(kgot[:, : slot], kpast[: slot].transpose(1, 0, 2), "the earlier K rows are untouched")
+        parity.check(BF16, attn_out.download(np.uint16, H * hd), att.reshape(-1), rel=4e-3, max_ulp=2, max_frac=0.3, scale_aware=True,
+                     what=f"attention row of the one launch, n{n} tag ({epoch}, {layer_tag})")
+    dec.release()
