@@ -328,7 +328,8 @@ def run_other_configs(mc, acc, np):
     """The other BASELINE.json configurations, briefly, on this one GPU (informational, driver-observed): each
     builds its own decoder, STARTS at position seq_len - tokens - 8 (the earlier cache rows are zero: the context
     is not decoded, the KV / weight traffic per token is what the position implies) and times `tokens` chained
-    greedy tokens after 8 warm-up tokens."""
+    greedy tokens after 64 warm-up tokens (8 read 2 % low against tools/configs_run.py, which decodes the whole context
+    first: the chip has not reached its clocks behind a weight fill)."""
     cases = [
         ("TinyLlama-1.1B bf16 weights, S=2048 (configs[0] on the GPU)", "tinyllama-1.1b", 16, 0, 2048, 128, 0, mc.FAMILY_LLAMA3),
         ("Llama-3-8B int8 g128, S=8192, 64 of the tokens past max_seq_len (configs[2])", "llama3-8b", 8, 128, 8192, 64, 64, mc.FAMILY_LLAMA3),
@@ -344,11 +345,12 @@ def run_other_configs(mc, acc, np):
                              weight_format={4: mc.WFMT_I4, 8: mc.WFMT_I8, 16: mc.WFMT_T}[wbits], group_size=group,
                              use_graph=1, **extra, **m)
             dec.init_synthetic(7)
-            start = S - K - 8
-            tok = int(dec.generate(1, start, 8)[-1])
+            WARM = 64
+            start = S - K - WARM
+            tok = int(dec.generate(1, start, WARM)[-1])
             acc.wait()
             t0 = time.perf_counter()
-            dec.generate(tok, start + 8, K + past)
+            dec.generate(tok, start + WARM, K + past)
             acc.wait()
             dt = time.perf_counter() - t0
             ab = algorithmic_bytes(m, wbits, group or 1, S, 2)
@@ -380,11 +382,12 @@ def run_local_pipeline_70b(mc, acc, np, world=8):
             d.init_synthetic(7)
             stages.append(d)
         pipe = mc.Pipeline.local(stages)
-        start = S - K - 8
-        tok = int(pipe.generate(1, start, 8)[-1])
+        WARM = 32
+        start = S - K - WARM
+        tok = int(pipe.generate(1, start, WARM)[-1])
         acc.wait()
         t0 = time.perf_counter()
-        pipe.generate(tok, start + 8, K)
+        pipe.generate(tok, start + WARM, K)
         acc.wait()
         dt = time.perf_counter() - t0
         pipe.release()
