@@ -75,6 +75,10 @@ struct qkv_in_launch {
     //  thread, up to THREE pairs per wave (20 per workgroup), 640 pairs per kv head gathered in two passes)
     static_assert(WB ? QN == 4 : (QN == 2 || QN == 4), "K = 4096 / 8192 int4, 4096 int8, 2048 bfloat; 512 threads");
     static constexpr bool WIDE = WB == 0 && QN == 4;
+#ifndef MC_I8_SCORER_WAVES
+#define MC_I8_SCORER_WAVES 8 // (int8, wide ranges) all eight waves compute scores: decode_kernels.hip attn_fused_bf SW; 507.7 -> 517.9 tokens/s same box, three alternating runs
+#endif
+    static constexpr int SCORER_WAVES = WB == 2 ? MC_I8_SCORER_WAVES : 4;
     static constexpr bool LDS = true, PIN_V = true, STAGED = STG != 0;
     static constexpr int K_STEPS = WB == 1 ? 1 : (WIDE ? 3 : 2), V_STEP = STG == 2 ? K_STEPS : K_STEPS - 1; // (the polls are step K_STEPS)
     static constexpr int TL_STRIDE = 16, TL_BASE = 3; // stamps: 0 start, 1 row staged, 2 pairs published, 3.. attn_fused_bf's 0..
@@ -456,6 +460,9 @@ struct qkv_in_launch {
 template <int HD, int P2>
 struct qkv_qkn_in_launch {
     static_assert(HD == 256, "gemma3 with head_dim 256 (hd / 2 threads per head are whole waves)");
+#ifndef MC_GQ_SCORER_WAVES
+#define MC_GQ_SCORER_WAVES 8 // one 16-slot tile per wave on all eight waves (q_from_qkv_rows<., 512> says the same, MC_QKN_SCORER_WAVES: the two forms stay bit for bit); 657 -> 666 tokens/s same box, three alternating runs
+#endif
 #ifndef MC_GQ_PIN_V
 #define MC_GQ_PIN_V 1 // 0 (tuning): the V tiles requested behind the wq|wk|wv phase instead of in front of it
 #endif
@@ -468,6 +475,7 @@ struct qkv_qkn_in_launch {
 #endif
     static constexpr bool LDS = true, PIN_V = MC_GQ_PIN_V != 0, STAGED = MC_GQ_STAGED != 0;
     static constexpr int V_STEP = MC_GQ_V_STEP, K_STEPS = 3;
+    static constexpr int SCORER_WAVES = MC_GQ_SCORER_WAVES;
     static constexpr int TL_STRIDE = 16, TL_BASE = 3; // stamps: 0 start, 1 row staged, 2 pairs published, 3.. attn_fused_bf's 0.., 11 rows normalised
     static constexpr uint32_t KQ = 3072u, NPK = KQ / 8, ROWB2 = 3072u, CHUNK_LDS = 2048 * 2 / 16 * 17, HALF = HD / 2, WPH = HALF / 64;
     static constexpr int PMAXQ = 3, NCH = 3;

@@ -19,6 +19,7 @@
 // RoPE is applied before caching, so slot order does not matter.
 #include "common.h"
 #include "handoff.h"
+#include <type_traits>
 
 using namespace mc;
 
@@ -665,6 +666,10 @@ template <int HD, int NT = 256>
 struct q_from_qkv_rows {
     static_assert(HD == 128 || HD == 256, "hd / 2 threads per head are whole waves");
     static constexpr bool LDS = true, PIN_V = NT == 512 && MC_QKN_PIN_V != 0, STAGED = false;
+#ifndef MC_QKN_SCORER_WAVES
+#define MC_QKN_SCORER_WAVES 8
+#endif
+    static constexpr int SCORER_WAVES = NT == 512 ? MC_QKN_SCORER_WAVES : 4;
     static constexpr int TL_STRIDE = 8, TL_BASE = 0;
     static constexpr uint32_t HALF = HD / 2, HPP = NT / HALF, WPH = HALF / 64; // heads per pass of the NT threads, waves per head
     typedef const __attribute__((address_space(3))) bf16_t* lds_row;
@@ -778,6 +783,11 @@ struct q_from_qkv_rows {
         lds_barrier();
     }
 };
+// (a query-source policy may ask for eight scoring waves: `static constexpr int SCORER_WAVES = 8` -- attn_fused_bf, SW)
+template <typename Q, typename = void>
+struct scorer_waves_of { static constexpr int value = 4; };
+template <typename Q>
+struct scorer_waves_of<Q, std::void_t<decltype(Q::SCORER_WAVES)>> { static constexpr int value = Q::SCORER_WAVES; };
 // PADKV: the kv heads may be dealt with a stride of the next multiple of 8 (`fastpath` bit 1, below) -- only the launches that
 // are the attention alone are built with it: in a launch with GEMV phases behind the attention the early exit it needs would
 // put every load of those phases "behind a branch" (hipcc then waits vmcnt(0) wherever it waits)
@@ -805,8 +815,15 @@ attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const
     constexpr int NDB = HD / 16;                // 16-column blocks of the output
     constexpr int NB = NDB >= NW ? NDB / NW : 1; // ... per wave
     constexpr uint32_t PBW = PB * T;            // cache slots per workgroup
+    // SW (round 5): waves that compute scores.  4 (round 3 .. ): waves 0-3, T tiles of 16 slots each -- slot t * 64 + wave * 16 + col.  8 (a policy that
+    // asks for it, wide ranges of an eight-wave workgroup: mc_attn_qkv_wo_i8_*_t4): all eight waves, T / 2 tiles each -- slot t * 128 + wave * 16 +
+    // col: the scores of a 256-slot range 2.7 -> 1.4 us.  The tile sums of a wave are added in tile order, the waves' sums pairwise in wave
+    // order, as below; the numerators land in the same places of the buffer.
+    constexpr int SW = (NW == 8 && T >= 2 && scorer_waves_of<QSrc>::value == 8) ? 8 : 4;
+    constexpr int TS = T * 4 / SW;              // score tiles per scoring wave
+    constexpr uint32_t PBS = 16u * SW;          // slots per round of the scoring waves
     constexpr int ES = PBW + 4;                 // numerator row stride in LDS (floats): 16 rows read 32 bytes apart in the banks
-    __shared__ float wsum[4][16];
+    __shared__ float wsum[SW][16];
     __shared__ float inv_s[16];
     __shared__ __attribute__((aligned(16))) float ebuf[16 * ES];
 
@@ -826,8 +843,8 @@ attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const
     // ---- 1. the K tiles and the queries: requested before anything is waited for -- the step state included (a range past
     // kv_len reads slots nobody uses: their products are masked below)
     qsrc.before_tiles();
-    uint4 kb[T][KS];
-    const bool scorer = NW == 4 || wave < 4; // (waves 4 .. NW - 1 compute no scores: no K tile, no queries)
+    uint4 kb[TS][KS];
+    const bool scorer = NW == 4 || wave < (uint32_t)SW; // (waves SW .. NW - 1 compute no scores: no K tile, no queries)
     // STAGED (round 5, qkv_qkn_in_launch): a wave stalls at ISSUE once the CU's memory pipe is full, so tiles requested up front -- 128 KB per
     // CU at head_dim 256 with 128-slot ranges -- hold the wave's own arithmetic back until most of them have ARRIVED (the first row pair of
     // the wq|wk|wv phase was multiplied 5 us after its weights were in).  Such a policy is handed the requests and places them between
@@ -837,7 +854,7 @@ attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const
     //  broadcast line of the cache: masks, not selects -- gemv.h ltile)
     auto request_k_lds = [&](int t) {
         const size_t live = (size_t)0 - (size_t)(scorer ? 1 : 0);
-        const uint32_t pos = p_begin + t * PB + wave * 16 + col;
+        const uint32_t pos = p_begin + t * PBS + wave * 16 + col;
         const bf16_t* kbase = kc + ((((size_t)kvc * max_seq + (pos < max_seq ? pos : max_seq - 1)) * HD + c * 8) & live);
 #pragma unroll
         for (int ks = 0; ks < KS; ks++) kb[t][ks] = *reinterpret_cast<const uint4*>(kbase + ks * 32);
@@ -845,12 +862,12 @@ attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const
     if constexpr (QSrc::LDS) {
         if constexpr (!QSrc::STAGED) {
 #pragma unroll
-            for (int t = 0; t < T; t++) request_k_lds(t);
+            for (int t = 0; t < TS; t++) request_k_lds(t);
         }
     } else if (scorer) {
 #pragma unroll
-        for (int t = 0; t < T; t++) {
-            const uint32_t pos = p_begin + t * PB + wave * 16 + col;
+        for (int t = 0; t < TS; t++) {
+            const uint32_t pos = p_begin + t * PBS + wave * 16 + col;
             const bf16_t* kbase = kc + ((size_t)kvc * max_seq + (pos < max_seq ? pos : max_seq - 1)) * HD;
 #pragma unroll
             for (int ks = 0; ks < KS; ks++) kb[t][ks] = *reinterpret_cast<const uint4*>(kbase + ks * 32 + c * 8);
@@ -886,7 +903,7 @@ attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const
         qsrc.before_scores([&](int step) {
             asm volatile("" ::: "memory"); // (the requests stay between the policy's phases: no load moves across)
 #pragma unroll
-            for (int t = 0; t < T; t++) // (tile t behind phase t; what is left of a wide range behind the policy's last phase)
+            for (int t = 0; t < TS; t++) // (tile t behind phase t; what is left of a wide range behind the policy's last phase)
                 if (step == (t < QSrc::K_STEPS ? t : QSrc::K_STEPS - 1)) request_k_lds(t);
             if (step == QSrc::V_STEP && !V_LATE) request_v();
             asm volatile("" ::: "memory");
@@ -901,7 +918,7 @@ attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const
                     for (int b = 0; b < NB; b++) asm volatile("" ::"v"(vb[t][b][0].x), "v"(vb[t][b][1].w));
             }
 #pragma unroll
-            for (int t = 0; t < T; t++)
+            for (int t = 0; t < TS; t++)
 #pragma unroll
                 for (int ks = 0; ks < KS; ks++) asm volatile("" ::"v"(kb[t][ks].x));
         }
@@ -923,7 +940,7 @@ attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const
                     for (int b = 0; b < NB; b++) asm volatile("" ::"v"(vb[t][b][0].x), "v"(vb[t][b][1].w));
             }
 #pragma unroll
-            for (int t = 0; t < T; t++)
+            for (int t = 0; t < TS; t++)
 #pragma unroll
                 for (int ks = 0; ks < KS; ks++) asm volatile("" ::"v"(kb[t][ks].x));
         }
@@ -946,8 +963,8 @@ attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const
         // the step's own row: its slot of the K tile comes from LDS (q_from_hbm's note); its column of the V tile in front of P.V
         ws = (uint32_t)st->write_slot;
 #pragma unroll
-        for (int t = 0; t < T; t++)
-            if (scorer && p_begin + t * PB + wave * 16 + col == ws) {
+        for (int t = 0; t < TS; t++)
+            if (scorer && p_begin + t * PBS + wave * 16 + col == ws) {
 #pragma unroll
                 for (int ks = 0; ks < KS; ks++) kb[t][ks] = *(const __attribute__((address_space(3))) uint4*)(qsrc.k_s + ks * 32 + c * 8);
             }
@@ -978,8 +995,8 @@ attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const
         float esum[4] = {0.f, 0.f, 0.f, 0.f}; // per m: this lane group's running sum over the wave's tiles
         if (scorer) {
 #pragma unroll
-        for (int t = 0; t < T; t++) {
-            const uint32_t pos = p_begin + t * PB + wave * 16 + col;
+        for (int t = 0; t < TS; t++) {
+            const uint32_t pos = p_begin + t * PBS + wave * 16 + col;
             f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < KS; ks++)
@@ -998,7 +1015,7 @@ attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const
                     sc = BF::rt(sc * scale);
                     e = exp_precise(sc);
                 }
-                ebuf[head * ES + t * PB + wave * 16 + col] = e;
+                ebuf[head * ES + t * PBS + wave * 16 + col] = e;
                 e += __shfl_xor(e, 1, 64);
                 e += __shfl_xor(e, 2, 64);
                 e += __shfl_xor(e, 4, 64);
@@ -1035,7 +1052,8 @@ attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const
         stamp(1);
         // ---- 3. hand-off A: this range's partial denominators out, the kv head's denominators in
         if (threadIdx.x < n_rep) {
-            const float tot = (wsum[0][threadIdx.x] + wsum[1][threadIdx.x]) + (wsum[2][threadIdx.x] + wsum[3][threadIdx.x]);
+            float tot = (wsum[0][threadIdx.x] + wsum[1][threadIdx.x]) + (wsum[2][threadIdx.x] + wsum[3][threadIdx.x]);
+            if constexpr (SW == 8) tot = tot + ((wsum[4][threadIdx.x] + wsum[5][threadIdx.x]) + (wsum[6][threadIdx.x] + wsum[7][threadIdx.x]));
             unsigned long long* gp = psum_g + (size_t)(kv * n_rep + threadIdx.x) * nsplit + split;
             if (fastpath) granule_store_dual(gp, psum_fast, tag, __float_as_uint(tot));
             else granule_store(gp, tag, __float_as_uint(tot));
