@@ -347,7 +347,7 @@ def test_norm_qkv_rope_attention_and_wo_in_one_launch_matches_the_oracle(acc, n,
 
 
 @pytest.mark.parametrize("fast", [1, 0])
-@pytest.mark.parametrize("tiles,n", [(2, 2048), (2, 1000), (2, 1), (2, 129), (1, 1024), (1, 65)])
+@pytest.mark.parametrize("tiles,n", [(2, 2048), (2, 1000), (2, 1), (2, 129), (2, 40), (2, 200), (1, 1024), (1, 65)])   # (the step's slot in every 32-slot group of a range)
 def test_gemma_norms_rope_attention_and_wo_in_one_launch_matches_the_oracle(acc, tiles, n, fast):
     """`mc_attn_wo_qkn_i4_bfloat_hd256_k2_t{1,2}` (round 5; attn_block_kernels.hip attn_wo_body with decode_kernels.hip q_from_qkv_rows<256, 512>):
     gemma3's q_norm / k_norm over whole heads, the rotation, the cache write (nn/attention.h:170-177), the decode attention and Wo WITHOUT a
@@ -434,7 +434,7 @@ def test_gemma_norms_rope_attention_and_wo_in_one_launch_matches_the_oracle(acc,
 
 
 @pytest.mark.parametrize("fast", [1, 0])
-@pytest.mark.parametrize("n", [2048, 1000, 1, 129])
+@pytest.mark.parametrize("n", [2048, 1000, 1, 129, 40, 200])   # (the step's slot in every 32-slot group of a 128-slot range)
 @pytest.mark.parametrize("post", [0, 1])
 def test_gemma_block_from_the_row_to_wo_in_one_launch_matches_the_oracle(acc, post, n, fast):
     """`mc_attn_qkv_wo_qkn_i4_bfloat_hd256_k2_p{1,2}_t2` (round 5; attn_block_kernels.hip qkv_qkn_in_launch): a gemma3 block from the row it
