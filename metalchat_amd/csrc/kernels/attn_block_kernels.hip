@@ -59,7 +59,7 @@ using namespace mc::gemv;
 // 2: ... the V tile behind the polls of hand-off Q (a wave's loads return in order: polls behind its V tile see their granules when
 // that has arrived).  Same box, alternating (tools/ab_hsaco.sh, tools/configs_run.py; 3-4 rounds each): Llama-3-8B int4 800.0 -> 808.9 tokens/s
 // with 1 (789.2 with 2); int8 at S = 8192 502.0 -> 507.8 with 2 (501.5 with 1); plain bfloat weights (one pair per wave: one phase) 1513 ->
-// 1503 with 2 on TinyLlama: left at 0.
+// 1503 with 2 on TinyLlama, 1527 -> 1526 with 1 (four alternating runs): left at 0.
 #ifndef MC_QX_STG_I4
 #define MC_QX_STG_I4 1
 #endif
