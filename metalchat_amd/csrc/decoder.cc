@@ -763,9 +763,10 @@ struct mc_decoder {
     bool
     attn_qkv_wo_qkn_ok(const layer_w& L) const
     {
-        if (!attn_qkv_qkn_on || !attn_qkv_on || !attn_qkv_g || occ_qkv_qkn == 0 || attn_wo_qkn_tiles(L.wo) != 2) return false;
+        const int tiles = attn_wo_qkn_tiles(L.wo);
+        if (!attn_qkv_qkn_on || !attn_qkv_on || !attn_qkv_g || occ_qkv_qkn == 0 || tiles == 0) return false;
         if (!lin_split_ok(L.qkv) || L.qkv.lora_cols || L.qkv.in != 3072 || cfg.dim != 3072 || L.qkv.group != L.wo.group) return false;
-        const int hd = cfg.head_dim, n_rep = cfg.n_heads / cfg.n_kv_heads, pg = (n_rep + 2) * hd / 2, ns = nsplit / 2;
+        const int hd = cfg.head_dim, n_rep = cfg.n_heads / cfg.n_kv_heads, pg = (n_rep + 2) * hd / 2, ns = nsplit / tiles;
         return L.qkv.out == (cfg.n_heads + 2 * cfg.n_kv_heads) * hd && pg <= 512 && pg % ns == 0 && pg / ns <= 24;
     }
 
@@ -1137,8 +1138,9 @@ struct mc_decoder {
                     if (it == pn_host.end()) return fail(MC_ERR_RUNTIME, "attention block: unknown post-norm descriptor");
                     h = it->second;
                 }
-                const int ns = nsplit / 2;
-                s = launch(std::string("mc_attn_qkv_wo_qkn_i4_") + tname + "_hd256_k2_p" + (pending_pn ? "2" : "1") + "_t2", (unsigned)(ns * KV), 1, 1, 512, 0,
+                const int tiles = attn_wo_qkn_tiles(L.wo), ns = nsplit / tiles;
+                s = launch(std::string("mc_attn_qkv_wo_qkn_i4_") + tname + "_hd256_k2_p" + (pending_pn ? "2" : "1") + "_t" + std::to_string(tiles),
+                           (unsigned)(ns * KV), 1, 1, 512, 0,
                            pack((const void*)L.kc, (const void*)L.vt, attn_out, attn_psum_g, attn_slab_g, attn_row_g, attn_qkv_g, state,
                                 (uint32_t)n_rep, (uint32_t)KV, (uint32_t)cfg.max_seq_len, scale_T, (uint32_t)ns, (uint32_t)(li + 1),
                                 (const void*)L.wo.w, (const void*)L.wo.scales, pending_pn ? (const void*)proj : x, proj, (uint32_t)L.wo.out,

@@ -1153,6 +1153,8 @@ MC_ATTN_QKV_WO_I8(mc_attn_qkv_wo_i8_bfloat_hd128_k4_q4_t4, 128, 4, 4, 4)  // ...
                                                 qkv_s, fcos, fsin, qkv_g, eps, mu, 0u,                                                   \
                                                 gemma_extra{post_w, res_row, h_out, q_norm, k_norm});                                    \
     }
+MC_ATTN_QKV_WO_QKN(mc_attn_qkv_wo_qkn_i4_bfloat_hd256_k2_p1_t1, 256, 2, 1, 1)  // Gemma-7B at S = 1024 (16 ranges of 64 slots): the first block (or parity taps)
+MC_ATTN_QKV_WO_QKN(mc_attn_qkv_wo_qkn_i4_bfloat_hd256_k2_p2_t1, 256, 2, 2, 1)  // ... every other block
 MC_ATTN_QKV_WO_QKN(mc_attn_qkv_wo_qkn_i4_bfloat_hd256_k2_p1_t2, 256, 2, 1, 2)  // Gemma-7B at S = 2048: the first block (or parity taps)
 MC_ATTN_QKV_WO_QKN(mc_attn_qkv_wo_qkn_i4_bfloat_hd256_k2_p2_t2, 256, 2, 2, 2)  // ... every other block
 MC_ATTN_WO_QKN(mc_attn_wo_qkn_i4_bfloat_hd256_k2_t1, 256, 2, 1)  // Gemma-7B shapes up to S = 1024

@@ -434,10 +434,10 @@ def test_gemma_norms_rope_attention_and_wo_in_one_launch_matches_the_oracle(acc,
 
 
 @pytest.mark.parametrize("fast", [1, 0])
-@pytest.mark.parametrize("n", [2048, 1000, 1, 129, 40, 200])   # (the step's slot in every 32-slot group of a 128-slot range)
+@pytest.mark.parametrize("n,tiles", [(2048, 2), (1000, 2), (1, 2), (129, 2), (40, 2), (200, 2), (1024, 1), (70, 1)])   # (tiles = 2: the step's slot in every 32-slot group of a 128-slot range)
 @pytest.mark.parametrize("post", [0, 1])
-def test_gemma_block_from_the_row_to_wo_in_one_launch_matches_the_oracle(acc, post, n, fast):
-    """`mc_attn_qkv_wo_qkn_i4_bfloat_hd256_k2_p{1,2}_t2` (round 5; attn_block_kernels.hip qkv_qkn_in_launch): a gemma3 block from the row it
+def test_gemma_block_from_the_row_to_wo_in_one_launch_matches_the_oracle(acc, post, n, tiles, fast):
+    """`mc_attn_qkv_wo_qkn_i4_bfloat_hd256_k2_p{1,2}_t{1,2}` (round 5; attn_block_kernels.hip qkv_qkn_in_launch): a gemma3 block from the row it
     is handed to Wo's output in ONE launch at Gemma-7B's widths (K = 3072: rows of 1.5 KiB; 16 heads x 256, 16 kv heads; S = 2048 as 16 ranges
     of 128 slots) -- `_p2_`: the previous linear's post-norm + the residual add, left in HBM (nn/transformer.h:138-139), then attention_norm,
     wq|wk|wv, q_norm / k_norm, rope, the cache write, the decode attention and Wo (nn/transformer.h:130-133, nn/attention.h:170-205);
@@ -446,7 +446,7 @@ def test_gemma_block_from_the_row_to_wo_in_one_launch_matches_the_oracle(acc, po
     import metalchat_amd as mc
     from test_lin_kernels_gpu import dyadic_row
 
-    H, KV, hd, dim, max_seq, tiles = 16, 16, 256, 3072, 2048, 2
+    H, KV, hd, dim, max_seq = 16, 16, 256, 3072, 1024 * tiles   # (`_t1`: S = 1024 as 16 ranges of 64 slots)
     half = hd // 2
     cfg = mg.tiny_cfg(BF16, family=1, dim=dim, n_heads=H, n_kv_heads=KV, head_dim=hd, ffn_dim=256, n_layers=1, vocab=64, max_seq_len=max_seq,
                       rope_theta=10000.0, norm_eps=1e-6)
@@ -508,7 +508,7 @@ def test_gemma_block_from_the_row_to_wo_in_one_launch_matches_the_oracle(acc, po
     pwb = acc.to_device(lw["ffn_post_norm"]) if post else None
     resb = acc.to_device(res) if post else None
     cb, sb = acc.to_device(fcos.reshape(-1)), acc.to_device(fsin.reshape(-1))
-    kern = acc.load(f"mc_attn_qkv_wo_qkn_i4_bfloat_hd256_k2_p{1 + post}_t2")
+    kern = acc.load(f"mc_attn_qkv_wo_qkn_i4_bfloat_hd256_k2_p{1 + post}_t{tiles}")
     W = lambda p_: acc.wrap(p_, 1 << 40)
     for epoch, layer_tag in ((1, 1), (1, 2), (9, 200)):
         xb = acc.to_device(x)
