@@ -258,6 +258,7 @@ struct mc_decoder {
     uint64_t weights_gen = 1;  // bumped whenever weight rows change: the derived copies (linear_w::wq2) are rebuilt
     bool pf2_on = true;        // MC_PF2: short prompts from the quad-interleaved copy
     bool attn_i8_on = true;    // MC_ATTN_I8: int8 wq|wk|wv and Wo inside the attention launch (attn_qkv_wo_i8_tiles)
+    bool attn_i4_wide_on = true; // MC_ATTN_I4_WIDE: the int4 block with 128- / 256-slot ranges at S = 4096 / 8192 (attn_qkv_wo_i4_wide_tiles)
     bool kv_virtual_on = true; // MC_KV_VIRTUAL: fewer than 8 kv heads launched as 8 virtual ones where wq|wk|wv is inside the attention launch (kv_virtual_shift)
     bool pf_attn8_on = true;   // MC_PF_ATTN8: the prompt attention with K / V tiles through LDS, from pf_attn8_rows rows on
     int pf_attn8_rows = 1024;  // MC_PF_ATTN8_ROWS
@@ -316,7 +317,7 @@ struct mc_decoder {
     hipEvent_t err_evt = nullptr;
     bool err_pending = false;
     int handoff_fallbacks = 0;
-    int occ_fused = -1, occ_wo = -1, occ_wo_w = -1, occ_wo_i8 = -1, occ_wo_qkn = -1, occ_qkv_qkn = -1, occ_qkv_only = -1;   // co-resident workgroups per CU of the hand-off launches (the occupancy API's answer; -1: not asked yet)
+    int occ_fused = -1, occ_wo = -1, occ_wo_w = -1, occ_wo_i8 = -1, occ_wo_qkn = -1, occ_qkv_qkn = -1, occ_qkv_only = -1, occ_wo_i4_wide = -1;   // co-resident workgroups per CU of the hand-off launches (the occupancy API's answer; -1: not asked yet)
     bool handoff_fast = true;    // MC_HANDOFF_FAST=0: hand-offs A and B through the fabric only (A/B; handoff.h "the XCD-local fast path")
     bool attn_wo_on = true;      // MC_ATTN_WO=0: the Wo GEMV as a launch of its own behind the one-launch attention (A/B, parity)
     bool attn_fused_on = true;   // MC_ATTN_FUSED=0: scores and P.V as two launches (A/B, parity)
@@ -712,6 +713,7 @@ struct mc_decoder {
         occ_wo_qkn = hd == 256 ? ask("mc_attn_wo_qkn_i4_bfloat_hd256_k2_t2", 512) : 0;
         occ_qkv_qkn = hd == 256 ? ask("mc_attn_qkv_wo_qkn_i4_bfloat_hd256_k2_p2_t2", 512) : 0;
         occ_qkv_only = hd == 128 ? ask("mc_attn_qkv_i4_bfloat_hd128_q4", 512) : 0;
+        occ_wo_i4_wide = hd == 128 ? ask("mc_attn_qkv_wo_i4_bfloat_hd128_k2_q2_t4", 512) : 0;
         (void)hipGetLastError();
     }
     // a hand-off gave up: report nothing yet, make the NEXT launches independent of co-residency
@@ -862,6 +864,26 @@ struct mc_decoder {
             const int ns = nsplit / t;
             const unsigned grid = (unsigned)(ns * cfg.n_kv_heads);
             if (grid <= (unsigned)dev->prop.multiProcessorCount && pg % ns == 0 && pg / ns <= 16 && (unsigned)L.wo.out / 2 <= 8u * grid) return t;
+        }
+        return 0;
+    }
+
+    // ... the int4 launch with WIDE ranges (round 5, mc_attn_qkv_wo_i4_bfloat_hd128_k2_q2_t{2,4}): contexts whose 64-slot ranges are more workgroups
+    // than CUs -- Llama-3-8B at S = 4096 / 8192 -- as 128- / 256-slot ranges, one 512-thread workgroup per CU.  Returns the tiles (2 or 4), 0 = not this form.
+    int
+    attn_qkv_wo_i4_wide_tiles(const layer_w& L) const
+    {
+        if (!attn_qkv_on || !attn_wo_on || !attn_i4_wide_on || !attn_fused_on || !attn_qkv_g || !attn_psum_g || !attn_row_g || tb != 2 || n_own > 254) return 0;
+        if (cfg.family == MC_FAMILY_GEMMA3 || occ_wo_i4_wide == 0 || !lin_ok(L.wo) || !lin_ok(L.qkv) || L.qkv.lora_cols || L.wo.lora_cols) return 0;
+        const int hd = cfg.head_dim, n_rep = cfg.n_heads / cfg.n_kv_heads, pg = (n_rep + 2) * hd / 2;
+        if (hd != 128 || L.wo.in != 4096 || L.qkv.in != 4096 || L.wo.in != cfg.n_heads * hd || L.wo.out % 2 != 0 || L.qkv.group != L.wo.group ||
+            L.qkv.out != (cfg.n_heads + 2 * cfg.n_kv_heads) * hd || cfg.n_kv_heads % 8 != 0 || n_rep > 16)
+            return 0;
+        for (int t : {2, 4}) {
+            if (nsplit % t) continue;
+            const int ns = nsplit / t;
+            const unsigned grid = (unsigned)(ns * cfg.n_kv_heads);
+            if (grid <= (unsigned)dev->prop.multiProcessorCount && pg % ns == 0 && pg / ns <= 16 && pg >= 64 && (unsigned)L.wo.out / 2 <= 16u * grid) return t;
         }
         return 0;
     }
@@ -1088,7 +1110,9 @@ struct mc_decoder {
             layer_w& L = layers[li];
             const bool qkv_w_in = attn_qkv_wo_w_fused(L);
             const int i8_tiles = qkv_w_in ? 0 : attn_qkv_wo_i8_tiles(L);
-            const bool qkv_in = qkv_w_in || i8_tiles || attn_qkv_wo_fused(L);
+            const bool i4_in = !qkv_w_in && !i8_tiles && attn_qkv_wo_fused(L);
+            const int i4_tiles = (qkv_w_in || i8_tiles || i4_in) ? 0 : attn_qkv_wo_i4_wide_tiles(L);
+            const bool qkv_in = qkv_w_in || i8_tiles || i4_in || i4_tiles;
             bool qkn_in = false, gq = false, q_only = false;
             int qkn_wo = 0;
             if (qkv_in) {
@@ -1098,11 +1122,11 @@ struct mc_decoder {
                 const int vsh = qkv_w_in ? kv_virtual_shift() : 0;
                 const bool vfast = vsh ? handoff_fast : handoff_fast_here();
                 // (int8: ranges of 64 i8_tiles slots -- nsplit / i8_tiles of them per kv head)
-                const int ns = i8_tiles ? nsplit / i8_tiles : nsplit;
+                const int ns = i8_tiles ? nsplit / i8_tiles : (i4_tiles ? nsplit / i4_tiles : nsplit);
                 s = launch(qkv_w_in ? std::string("mc_attn_qkv_wo_w_bfloat_hd64_k4_q4")
                            : i8_tiles ? "mc_attn_qkv_wo_i8_bfloat_hd128_k4_q4_t" + std::to_string(i8_tiles)
                                     : "mc_attn_qkv_wo_i4_" + tname + "_hd" + std::to_string(hd) + "_k" + std::to_string(L.wo.in / 2048) + "_q" +
-                                          std::to_string(L.qkv.in / 2048),
+                                          std::to_string(L.qkv.in / 2048) + (i4_tiles ? "_t" + std::to_string(i4_tiles) : std::string()),
                            (unsigned)(ns * (KV << vsh)), 1, 1, 512, 0,
                            pack((const void*)L.kc, (const void*)L.vt, attn_out, attn_psum_g, attn_slab_g, attn_row_g, attn_qkv_g, state,
                                 (uint32_t)(n_rep >> vsh), (uint32_t)(KV << vsh), (uint32_t)cfg.max_seq_len, scale_T, (uint32_t)ns, (uint32_t)(li + 1),
@@ -2099,6 +2123,7 @@ mc_decoder_create(mc_device* dev, mc_library* lib, mc_queue* q, const mc_decoder
     if (const char* e = getenv("MC_ATTN_WO_QKN")) d->attn_wo_qkn_on = atoi(e) != 0;
     if (const char* e = getenv("MC_ATTN_QKV_QKN")) d->attn_qkv_qkn_on = atoi(e) != 0;
     if (const char* e = getenv("MC_ATTN_QKV_ONLY")) d->attn_qkv_only_on = atoi(e) != 0;
+    if (const char* e = getenv("MC_ATTN_I4_WIDE")) d->attn_i4_wide_on = atoi(e) != 0;
     if (const char* e = getenv("MC_LAZY_PICK")) d->lazy_pick_on = atoi(e) != 0;
     if (const char* e = getenv("MC_PF2")) d->pf2_on = atoi(e) != 0;
     if (const char* e = getenv("MC_KV_VIRTUAL")) d->kv_virtual_on = atoi(e) != 0;

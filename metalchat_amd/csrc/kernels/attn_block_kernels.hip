@@ -78,7 +78,7 @@ struct qkv_in_launch {
 #ifndef MC_I8_SCORER_WAVES
 #define MC_I8_SCORER_WAVES 8 // (int8, wide ranges) all eight waves compute scores: decode_kernels.hip attn_fused_bf SW; 507.7 -> 517.9 tokens/s same box, three alternating runs
 #endif
-    static constexpr int SCORER_WAVES = WB == 2 ? MC_I8_SCORER_WAVES : 4;
+    static constexpr int SCORER_WAVES = WB == 1 ? 4 : MC_I8_SCORER_WAVES; // (int4 / int8: wide ranges score on all eight waves; 64-slot ranges on four either way)
     static constexpr bool LDS = true, PIN_V = true, STAGED = STG != 0;
     static constexpr int K_STEPS = WB == 1 ? 1 : (WIDE ? 3 : 2), V_STEP = STG == 2 ? K_STEPS : K_STEPS - 1; // (the polls are step K_STEPS)
     static constexpr int TL_STRIDE = 16, TL_BASE = 3; // stamps: 0 start, 1 row staged, 2 pairs published, 3.. attn_fused_bf's 0..
@@ -1039,7 +1039,7 @@ attn_wo_body(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const 
                                wo_s, res, y, out_rows, group, has_res, fastpath, tl);                                                    \
     }
 // ... with wq|wk|wv in the launch too (qkv_in_launch above): one launch from the hidden row to the hidden row
-#define MC_ATTN_QKV_WO(NAME, HD, LNCH, QN)                                                                                                \
+#define MC_ATTN_QKV_WO(NAME, HD, LNCH, QN, TT)                                                                                            \
     extern "C" __global__ void __launch_bounds__(512)                                                                                    \
     NAME(const bf16_t* kc, const bf16_t* vt, bf16_t* attn_out, unsigned long long* psum_g, unsigned long long* slab_g,                  \
          unsigned long long* row_g, unsigned long long* qkv_g, step_state* st, uint32_t n_rep, uint32_t n_kv, uint32_t max_seq,         \
@@ -1047,12 +1047,15 @@ attn_wo_body(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const 
          uint32_t out_rows, uint32_t group, const void* qnorm_w, const void* qkv_w, const void* qkv_s, const float* fcos, const float* fsin, float eps,    \
          float mu, uint32_t fastpath, unsigned long long* tl, uint32_t kv_shift)                                                         \
     {                                                                                                                                    \
-        attn_wo_body<HD, LNCH, QN>(nullptr, kc, vt, attn_out, psum_g, slab_g, row_g, st, n_rep, n_kv, max_seq, scale, nsplit, layer_tag, \
-                                   wo_w, wo_s, x, y, out_rows, group, 1u, fastpath, tl, qnorm_w, qkv_w, qkv_s, fcos, fsin,               \
-                                   qkv_g, eps, mu, kv_shift);                                                                            \
+        attn_wo_body<HD, LNCH, QN, 0, TT>(nullptr, kc, vt, attn_out, psum_g, slab_g, row_g, st, n_rep, n_kv, max_seq, scale, nsplit,     \
+                                          layer_tag, wo_w, wo_s, x, y, out_rows, group, 1u, fastpath, tl, qnorm_w, qkv_w, qkv_s, fcos,   \
+                                          fsin, qkv_g, eps, mu, kv_shift);                                                               \
     }
 // mc_attn_qkv_wo_i4_bfloat_hd{head_dim}_k{KiB per Wo row}_q{KiB per wq|wk|wv row}
-MC_ATTN_QKV_WO(mc_attn_qkv_wo_i4_bfloat_hd128_k2_q2, 128, 2, 2)  // Llama-3-8B: dim 4096, 32 heads x 128
+MC_ATTN_QKV_WO(mc_attn_qkv_wo_i4_bfloat_hd128_k2_q2, 128, 2, 2, 1)  // Llama-3-8B: dim 4096, 32 heads x 128
+// ... with 128- and 256-slot ranges (round 5: contexts of 4096 and 8192 slots in one 512-thread workgroup per CU, as the int8 launch below): _t{tiles}
+MC_ATTN_QKV_WO(mc_attn_qkv_wo_i4_bfloat_hd128_k2_q2_t2, 128, 2, 2, 2)
+MC_ATTN_QKV_WO(mc_attn_qkv_wo_i4_bfloat_hd128_k2_q2_t4, 128, 2, 2, 4)
 // ... WITHOUT Wo (round 5, Llama-3-70B: 64 heads x 128 make Wo rows of 4 KiB -- two pairs per wave are 64 registers requested behind the
 // scores, measured slower than the GEMV twice, above): attention_norm + wq|wk|wv (rows of 4 KiB, K = 8192) + rope + cache write + the decode
 // attention in one launch, the row left in HBM for the Wo GEMV: mc_attn_qkv_i4_bfloat_hd{head_dim}_q{KiB per wq|wk|wv row}

@@ -166,6 +166,27 @@ def test_llama3_8b_int8_at_8192_with_automatic_context_ranges(acc, monkeypatch):
         assert ({"mc_gemv_i8_bfloat_ling4_p1_e4", "mc_gemv_i8_bfloat_ling4_p1_e2", "mc_gemv_i8_bfloat_ling14_p0_e1", "mc_gemv_i8_bfloat_ling4_p1_e5"} | attn) <= names, sorted(names)
 
 
+@pytest.mark.parametrize("S", [4096, 8192])
+def test_llama3_8b_int4_at_long_contexts_takes_the_three_launch_layer(acc, monkeypatch, S):
+    # round 5: the int4 block with 128- / 256-slot ranges (mc_attn_qkv_wo_i4_bfloat_hd128_k2_q2_t{2,4}: one 512-thread workgroup per CU at S = 4096 /
+    # 8192, where the 64-slot ranges are more workgroups than can wait for one another) against the oracle, near the end of the cache and past it
+    # (the ring turns); MC_ATTN_I4_WIDE=0: the launches of round 4 (the wq|wk|wv GEMV, mc_attn_fused_t2_bfloat or scores + P.V, the Wo GEMV)
+    import metalchat_amd as mc
+
+    cfg = dict(dtype=BF16, n_layers=1, vocab=2048, max_seq_len=S, norm_eps=1e-5, **FULL_WIDTH["llama3-8b"])
+    weights = synth_model(cfg, SEED)
+    kern = f"mc_attn_qkv_wo_i4_bfloat_hd128_k2_q2_t{S // 2048}"
+    for wide in ("1", "0"):
+        monkeypatch.setenv("MC_ATTN_I4_WIDE", wide)
+        names = set()
+        agree = run_injected(acc, cfg, weights, S - 7, 12, dict(weight_format=mc.WFMT_I4, group_size=128), rel_logits=5e-3, max_ulp=2, max_frac=0.7,
+                             what=f"8B int4 S={S} (MC_ATTN_I4_WIDE={wide})", launched=names)
+        assert agree >= 10
+        assert (kern in names) == (wide == "1"), sorted(names)
+        assert ("mc_gemv_i4_bfloat_lin2_p1_e4" in names) == (wide == "0"), sorted(names)
+        assert {"mc_gemv_i4_bfloat_lin2_p1_e2", "mc_gemv_i4_bfloat_lin7_p0_e1"} <= names, sorted(names)
+
+
 def test_llama3_8b_int8_three_launch_layer_at_short_and_mid_contexts(acc, monkeypatch):
     # ... the same block at S = 2048 (64-slot ranges: `_t1`) and S = 8192 (`_t4`), full and at position 300 (most ranges empty), and across
     # the end of the cache (the ring turns).  Full contexts: run_injected's bounds against the oracle.  Position 300: int8 on bfloat rows sits

@@ -60,6 +60,7 @@ def test_decode_and_reference_kernels_present(symbols):
               # ... with the Wo GEMV behind it (decoder.cc attn_wo_fused: head_dim x KiB per Wo row)
               "mc_attn_wo_i4_bfloat_hd128_k2", "mc_attn_wo_i4_bfloat_hd64_k1", "mc_attn_wo_i4_bfloat_hd256_k2",
               "mc_attn_qkv_wo_i4_bfloat_hd128_k2_q2",  # wq|wk|wv, attention and Wo in one launch (round 4)
+              "mc_attn_qkv_wo_i4_bfloat_hd128_k2_q2_t2", "mc_attn_qkv_wo_i4_bfloat_hd128_k2_q2_t4",  # ... 128- / 256-slot ranges (attn_qkv_wo_i4_wide_tiles)
               "mc_attn_qkv_wo_w_bfloat_hd64_k4_q4",    # ... for plain bfloat weights (decoder.cc attn_qkv_wo_w_fused)
               "mc_attn_qkv_i4_bfloat_hd128_q4",        # ... without Wo, rows of 4 KiB (Llama-3-70B; decoder.cc attn_qkv_only_ok)
               "mc_attn_qkv_wo_i8_bfloat_hd128_k4_q4_t1", "mc_attn_qkv_wo_i8_bfloat_hd128_k4_q4_t4",  # ... for int8 weights (attn_qkv_wo_i8_tiles)
