@@ -833,16 +833,25 @@ struct mc_decoder {
     // ... the same launch for PLAIN bfloat weights (mc_attn_qkv_wo_w_bfloat_hd64_k4_q4: Llama-3.2-1B, the reference's default model):
     // rows of 4 KiB (K = 2048), at most ONE row pair per wave in either GEMV phase
     bool
-    attn_qkv_wo_w_fused(const layer_w& L) const
+    attn_qkv_wo_w_fused(const layer_w& L) const { return attn_qkv_wo_w_tiles(L) != 0; }
+    // ... as the 64-slot tiles per range: 1 (S <= 2048), 2 or 4 (round 5: S = 4096 / 8192 with 128- / 256-slot ranges, mc_attn_qkv_wo_w_*_t{2,4}); 0 = not this form
+    int
+    attn_qkv_wo_w_tiles(const layer_w& L) const
     {
-        if (!attn_qkv_on || !attn_wo_on || !attn_qkv_g || !attn_fused() || tb != 2 || cfg.family == MC_FAMILY_GEMMA3) return false;
-        if (L.qkv.fmt != MC_WFMT_T || L.wo.fmt != MC_WFMT_T || L.qkv.lora_cols || L.wo.lora_cols || occ_wo_w == 0) return false;
+        if (!attn_qkv_on || !attn_wo_on || !attn_qkv_g || !attn_fused_on || !attn_psum_g || n_own > 254 || tb != 2 || cfg.family == MC_FAMILY_GEMMA3) return 0;
+        if (L.qkv.fmt != MC_WFMT_T || L.wo.fmt != MC_WFMT_T || L.qkv.lora_cols || L.wo.lora_cols || occ_wo_w == 0) return 0;
         const int sh = kv_virtual_shift();
         const int hd = cfg.head_dim, n_rep = (cfg.n_heads / cfg.n_kv_heads) >> sh, pg = (n_rep + 2) * hd / 2;
-        const unsigned grid = (unsigned)(nsplit * (cfg.n_kv_heads << sh));
-        return hd == 64 && L.wo.in == 2048 && L.qkv.in == 2048 && L.wo.in == cfg.n_heads * hd && L.wo.out % 2 == 0 &&
-               L.qkv.out == (cfg.n_heads + 2 * cfg.n_kv_heads) * hd && grid <= (unsigned)dev->prop.multiProcessorCount &&
-               pg % nsplit == 0 && pg / nsplit <= 8 && n_rep <= 16 && pg >= 64 && pg <= 512 && (unsigned)L.wo.out / 2 <= 8u * grid;
+        if (hd != 64 || L.wo.in != 2048 || L.qkv.in != 2048 || L.wo.in != cfg.n_heads * hd || L.wo.out % 2 != 0 ||
+            L.qkv.out != (cfg.n_heads + 2 * cfg.n_kv_heads) * hd || n_rep > 16 || pg < 64 || pg > 512)
+            return 0;
+        for (int t : {1, 2, 4}) {
+            if (nsplit % t || (t == 1 && !attn_fused()) || (t > 1 && !attn_i4_wide_on)) continue;
+            const int ns = nsplit / t;
+            const unsigned grid = (unsigned)(ns * (cfg.n_kv_heads << sh));
+            if (grid <= (unsigned)dev->prop.multiProcessorCount && pg % ns == 0 && pg / ns <= 8 && (unsigned)L.wo.out / 2 <= 8u * grid) return t;
+        }
+        return 0;
     }
 
     // ... the same launch for INT8 weights (round 5, mc_attn_qkv_wo_i8_bfloat_hd128_k4_q4_t{1,4}: Llama-3-8B int8): rows of 4 KiB (K = 4096),
@@ -859,7 +868,7 @@ struct mc_decoder {
         if (hd != 128 || L.wo.in != 4096 || L.qkv.in != 4096 || L.wo.in != cfg.n_heads * hd || L.wo.out % 2 != 0 ||
             L.qkv.out != (cfg.n_heads + 2 * cfg.n_kv_heads) * hd || cfg.n_kv_heads % 8 != 0 || n_rep > 16)
             return 0;
-        for (int t : {1, 4}) {
+        for (int t : {1, 2, 4}) {
             if (nsplit % t) continue;
             const int ns = nsplit / t;
             const unsigned grid = (unsigned)(ns * cfg.n_kv_heads);
@@ -1108,7 +1117,8 @@ struct mc_decoder {
         }
         for (int li = 0; li < n_own; li++) {
             layer_w& L = layers[li];
-            const bool qkv_w_in = attn_qkv_wo_w_fused(L);
+            const int w_tiles = attn_qkv_wo_w_tiles(L);
+            const bool qkv_w_in = w_tiles != 0;
             const int i8_tiles = qkv_w_in ? 0 : attn_qkv_wo_i8_tiles(L);
             const bool i4_in = !qkv_w_in && !i8_tiles && attn_qkv_wo_fused(L);
             const int i4_tiles = (qkv_w_in || i8_tiles || i4_in) ? 0 : attn_qkv_wo_i4_wide_tiles(L);
@@ -1122,8 +1132,8 @@ struct mc_decoder {
                 const int vsh = qkv_w_in ? kv_virtual_shift() : 0;
                 const bool vfast = vsh ? handoff_fast : handoff_fast_here();
                 // (int8: ranges of 64 i8_tiles slots -- nsplit / i8_tiles of them per kv head)
-                const int ns = i8_tiles ? nsplit / i8_tiles : (i4_tiles ? nsplit / i4_tiles : nsplit);
-                s = launch(qkv_w_in ? std::string("mc_attn_qkv_wo_w_bfloat_hd64_k4_q4")
+                const int ns = i8_tiles ? nsplit / i8_tiles : (i4_tiles ? nsplit / i4_tiles : (w_tiles ? nsplit / w_tiles : nsplit));
+                s = launch(qkv_w_in ? std::string("mc_attn_qkv_wo_w_bfloat_hd64_k4_q4") + (w_tiles > 1 ? "_t" + std::to_string(w_tiles) : std::string())
                            : i8_tiles ? "mc_attn_qkv_wo_i8_bfloat_hd128_k4_q4_t" + std::to_string(i8_tiles)
                                     : "mc_attn_qkv_wo_i4_" + tname + "_hd" + std::to_string(hd) + "_k" + std::to_string(L.wo.in / 2048) + "_q" +
                                           std::to_string(L.qkv.in / 2048) + (i4_tiles ? "_t" + std::to_string(i4_tiles) : std::string()),
@@ -3022,10 +3032,14 @@ mc_decoder_gemv_kernel_name(mc_decoder* d, const char* which, char* buf, size_t 
         if (d->layers.empty()) return fail(MC_ERR_INVALID_ARGUMENT, "mc_decoder_gemv_kernel_name: this stage owns no block");
         const linear_w& wo = d->layers[0].wo;
         d->query_occupancy();
-        name = d->attn_qkv_wo_w_fused(d->layers[0]) ? std::string("mc_attn_qkv_wo_w_bfloat_hd64_k4_q4")
-               : d->attn_qkv_wo_i8_tiles(d->layers[0]) ? "mc_attn_qkv_wo_i8_bfloat_hd128_k4_q4_t" + std::to_string(d->attn_qkv_wo_i8_tiles(d->layers[0]))
-               : d->attn_qkv_wo_fused(d->layers[0]) ? "mc_attn_qkv_wo_i4_" + d->tname + "_hd" + std::to_string(d->cfg.head_dim) + "_k" + std::to_string(wo.in / 2048) +
-                                                         "_q" + std::to_string(d->layers[0].qkv.in / 2048)
+        const layer_w& L0 = d->layers[0];
+        const int wt = d->attn_qkv_wo_w_tiles(L0), i4w = d->attn_qkv_wo_i4_wide_tiles(L0);
+        const std::string i4name = "mc_attn_qkv_wo_i4_" + d->tname + "_hd" + std::to_string(d->cfg.head_dim) + "_k" + std::to_string(wo.in / 2048) + "_q" +
+                                   std::to_string(L0.qkv.in / 2048);
+        name = wt ? std::string("mc_attn_qkv_wo_w_bfloat_hd64_k4_q4") + (wt > 1 ? "_t" + std::to_string(wt) : std::string())
+               : d->attn_qkv_wo_i8_tiles(L0) ? "mc_attn_qkv_wo_i8_bfloat_hd128_k4_q4_t" + std::to_string(d->attn_qkv_wo_i8_tiles(L0))
+               : d->attn_qkv_wo_fused(L0) ? i4name
+               : i4w ? i4name + "_t" + std::to_string(i4w)
                : d->attn_wo_fused(wo) ? "mc_attn_wo_i4_" + d->tname + "_hd" + std::to_string(d->cfg.head_dim) + "_k" + std::to_string(wo.in / 2048)
                : d->attn_fused()    ? "mc_attn_fused_" + d->tname
                : d->attn_fused_t2() ? "mc_attn_fused_t2_" + d->tname

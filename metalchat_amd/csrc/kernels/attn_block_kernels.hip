@@ -78,7 +78,7 @@ struct qkv_in_launch {
 #ifndef MC_I8_SCORER_WAVES
 #define MC_I8_SCORER_WAVES 8 // (int8, wide ranges) all eight waves compute scores: decode_kernels.hip attn_fused_bf SW; 507.7 -> 517.9 tokens/s same box, three alternating runs
 #endif
-    static constexpr int SCORER_WAVES = WB == 1 ? 4 : MC_I8_SCORER_WAVES; // (int4 / int8: wide ranges score on all eight waves; 64-slot ranges on four either way)
+    static constexpr int SCORER_WAVES = MC_I8_SCORER_WAVES; // (wide ranges score on all eight waves; 64-slot ranges on four either way)
     static constexpr bool LDS = true, PIN_V = true, STAGED = STG != 0;
     static constexpr int K_STEPS = WB == 1 ? 1 : (WIDE ? 3 : 2), V_STEP = STG == 2 ? K_STEPS : K_STEPS - 1; // (the polls are step K_STEPS)
     static constexpr int TL_STRIDE = 16, TL_BASE = 3; // stamps: 0 start, 1 row staged, 2 pairs published, 3.. attn_fused_bf's 0..
@@ -1097,7 +1097,7 @@ mc_attn_qkv_i4_bfloat_hd128_q4(const bf16_t* kc, const bf16_t* vt, bf16_t* attn_
                           fcos, fsin, eps, mu, fastpath, tl);
 }
 // ... with plain bfloat weights (nn::linear): mc_attn_qkv_wo_w_bfloat_hd{head_dim}_k{KiB per Wo row}_q{KiB per wq|wk|wv row}
-#define MC_ATTN_QKV_WO_W(NAME, HD, LNCH, QN)                                                                                              \
+#define MC_ATTN_QKV_WO_W(NAME, HD, LNCH, QN, TT)                                                                                          \
     extern "C" __global__ void __launch_bounds__(512)                                                                                    \
     NAME(const bf16_t* kc, const bf16_t* vt, bf16_t* attn_out, unsigned long long* psum_g, unsigned long long* slab_g,                  \
          unsigned long long* row_g, unsigned long long* qkv_g, step_state* st, uint32_t n_rep, uint32_t n_kv, uint32_t max_seq,         \
@@ -1105,11 +1105,13 @@ mc_attn_qkv_i4_bfloat_hd128_q4(const bf16_t* kc, const bf16_t* vt, bf16_t* attn_
          uint32_t out_rows, uint32_t group, const void* qnorm_w, const void* qkv_w, const void* qkv_s, const float* fcos, const float* fsin, float eps,    \
          float mu, uint32_t fastpath, unsigned long long* tl, uint32_t kv_shift)                                                         \
     {                                                                                                                                    \
-        attn_wo_body<HD, LNCH, QN, 1>(nullptr, kc, vt, attn_out, psum_g, slab_g, row_g, st, n_rep, n_kv, max_seq, scale, nsplit, layer_tag, \
-                                      wo_w, wo_s, x, y, out_rows, group, 1u, fastpath, tl, qnorm_w, qkv_w, qkv_s, fcos, fsin,            \
-                                      qkv_g, eps, mu, kv_shift);                                                                         \
+        attn_wo_body<HD, LNCH, QN, 1, TT>(nullptr, kc, vt, attn_out, psum_g, slab_g, row_g, st, n_rep, n_kv, max_seq, scale, nsplit,     \
+                                          layer_tag, wo_w, wo_s, x, y, out_rows, group, 1u, fastpath, tl, qnorm_w, qkv_w, qkv_s, fcos,   \
+                                          fsin, qkv_g, eps, mu, kv_shift);                                                               \
     }
-MC_ATTN_QKV_WO_W(mc_attn_qkv_wo_w_bfloat_hd64_k4_q4, 64, 4, 4)  // Llama-3.2-1B: dim 2048, 32 heads x 64, bf16 weights
+MC_ATTN_QKV_WO_W(mc_attn_qkv_wo_w_bfloat_hd64_k4_q4, 64, 4, 4, 1)  // Llama-3.2-1B: dim 2048, 32 heads x 64, bf16 weights
+MC_ATTN_QKV_WO_W(mc_attn_qkv_wo_w_bfloat_hd64_k4_q4_t2, 64, 4, 4, 2)  // ... S = 4096 (round 5: 128-slot ranges)
+MC_ATTN_QKV_WO_W(mc_attn_qkv_wo_w_bfloat_hd64_k4_q4_t4, 64, 4, 4, 4)  // ... S = 8192 (256-slot ranges)
 // ... with int8 weights: mc_attn_qkv_wo_i8_bfloat_hd{head_dim}_k{KiB per Wo row}_q{KiB per wq|wk|wv row}_t{64-slot tiles per scoring wave}
 #define MC_ATTN_QKV_WO_I8(NAME, HD, LNCH, QN, TT)                                                                                         \
     extern "C" __global__ void __launch_bounds__(512)                                                                                    \
@@ -1124,6 +1126,7 @@ MC_ATTN_QKV_WO_W(mc_attn_qkv_wo_w_bfloat_hd64_k4_q4, 64, 4, 4)  // Llama-3.2-1B:
                                           fsin, qkv_g, eps, mu, kv_shift);                                                               \
     }
 MC_ATTN_QKV_WO_I8(mc_attn_qkv_wo_i8_bfloat_hd128_k4_q4_t1, 128, 4, 4, 1)  // Llama-3-8B int8, S <= 2048
+MC_ATTN_QKV_WO_I8(mc_attn_qkv_wo_i8_bfloat_hd128_k4_q4_t2, 128, 4, 4, 2)  // ... S = 4096: 128-slot ranges
 MC_ATTN_QKV_WO_I8(mc_attn_qkv_wo_i8_bfloat_hd128_k4_q4_t4, 128, 4, 4, 4)  // ... S = 8192: 256-slot ranges, one workgroup per CU
 
 // ... gemma3 (round 5): q_norm / k_norm + rotation + cache write (mc_rope_kv_T) + attention + Wo in one launch, from the raw wq|wk|wv rows:

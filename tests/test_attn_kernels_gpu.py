@@ -248,7 +248,7 @@ def test_attention_and_wo_in_one_launch_matches_the_oracle(acc, shape, n, fast):
 @pytest.mark.parametrize("fast", [1, 0])
 @pytest.mark.parametrize("n", [2048, 1000, 1, 65])
 @pytest.mark.parametrize("shape", ["llama3-8b-int4", "llama3.2-1b-bf16", "tinyllama-bf16", "llama3-8b-int8", "llama3-8b-int8-8192", "llama3-8b-int4-4096",
-                                   "llama3-8b-int4-8192"])
+                                   "llama3-8b-int4-8192", "llama3-8b-int8-4096", "llama3.2-1b-bf16-8192", "tinyllama-bf16-4096"])
 def test_norm_qkv_rope_attention_and_wo_in_one_launch_matches_the_oracle(acc, n, fast, shape):
     """`mc_attn_qkv_wo_i4_bfloat_hd128_k2_q2` (attn_block_kernels.hip qkv_in_launch: attention_norm, wq|wk|wv, RoPE, the cache
     write, the decode attention, Wo and the residual of one block -- nn/transformer.h:130-133, nn/attention.h:170-205 -- the kernel
@@ -270,9 +270,10 @@ def test_norm_qkv_rope_attention_and_wo_in_one_launch_matches_the_oracle(acc, n,
     int4 = shape.startswith("llama3-8b-int4")
     int8 = shape.startswith("llama3-8b-int8")
     tiles = 4 if shape.endswith("-8192") else (2 if shape.endswith("-4096") else 1)
-    H, KV, hd, dim, max_seq = (32, 8, 128, 4096, 2048 * tiles) if (int4 or int8) else (32, 4 if shape == "tinyllama-bf16" else 8, 64, 2048, 2048)
+    # (... and the wide ranges of the int8 launch at S = 4096 and of the plain-bfloat launch: Llama-3.2-1B at 8192, TinyLlama's virtual heads at 4096)
+    H, KV, hd, dim, max_seq = (32, 8, 128, 4096, 2048 * tiles) if (int4 or int8) else (32, 4 if shape.startswith("tinyllama-bf16") else 8, 64, 2048, 2048 * tiles)
     n = n * tiles
-    vsh = 1 if shape == "tinyllama-bf16" else 0
+    vsh = 1 if shape.startswith("tinyllama-bf16") else 0
     KVV = KV << vsh
     half = hd // 2
     cfg = mg.tiny_cfg(BF16, dim=dim, n_heads=H, n_kv_heads=KV, head_dim=hd, ffn_dim=256, n_layers=1, vocab=64, max_seq_len=max_seq)
@@ -319,7 +320,7 @@ def test_norm_qkv_rope_attention_and_wo_in_one_launch_matches_the_oracle(acc, n,
     attn_out = acc.alloc(H * hd * 2)
     nw = acc.to_device(lw["attention_norm"])
     cb, sb = acc.to_device(fcos.reshape(-1)), acc.to_device(fsin.reshape(-1))
-    kern = acc.load("mc_attn_qkv_wo_i4_bfloat_hd128_k2_q2" + (f"_t{tiles}" if tiles > 1 else "") if int4 else (f"mc_attn_qkv_wo_i8_bfloat_hd128_k4_q4_t{tiles}" if int8 else "mc_attn_qkv_wo_w_bfloat_hd64_k4_q4"))
+    kern = acc.load("mc_attn_qkv_wo_i4_bfloat_hd128_k2_q2" + (f"_t{tiles}" if tiles > 1 else "") if int4 else (f"mc_attn_qkv_wo_i8_bfloat_hd128_k4_q4_t{tiles}" if int8 else "mc_attn_qkv_wo_w_bfloat_hd64_k4_q4" + (f"_t{tiles}" if tiles > 1 else "")))
     W = lambda p_: acc.wrap(p_, 1 << 40) if p_ else None
     for epoch, layer_tag in ((1, 1), (1, 2), (9, 200)):
         hb = acc.to_device(x)                  # read as the block input and the residual, overwritten IN PLACE, as the decoder launches it

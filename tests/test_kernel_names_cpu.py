@@ -63,7 +63,8 @@ def test_decode_and_reference_kernels_present(symbols):
               "mc_attn_qkv_wo_i4_bfloat_hd128_k2_q2_t2", "mc_attn_qkv_wo_i4_bfloat_hd128_k2_q2_t4",  # ... 128- / 256-slot ranges (attn_qkv_wo_i4_wide_tiles)
               "mc_attn_qkv_wo_w_bfloat_hd64_k4_q4",    # ... for plain bfloat weights (decoder.cc attn_qkv_wo_w_fused)
               "mc_attn_qkv_i4_bfloat_hd128_q4",        # ... without Wo, rows of 4 KiB (Llama-3-70B; decoder.cc attn_qkv_only_ok)
-              "mc_attn_qkv_wo_i8_bfloat_hd128_k4_q4_t1", "mc_attn_qkv_wo_i8_bfloat_hd128_k4_q4_t4",  # ... for int8 weights (attn_qkv_wo_i8_tiles)
+              "mc_attn_qkv_wo_i8_bfloat_hd128_k4_q4_t1", "mc_attn_qkv_wo_i8_bfloat_hd128_k4_q4_t2", "mc_attn_qkv_wo_i8_bfloat_hd128_k4_q4_t4",
+              "mc_attn_qkv_wo_w_bfloat_hd64_k4_q4_t2", "mc_attn_qkv_wo_w_bfloat_hd64_k4_q4_t4",   # wide ranges of the plain-bfloat launch (attn_qkv_wo_w_tiles)  # ... for int8 weights (attn_qkv_wo_i8_tiles)
               "mc_attn_fused_qkn_bfloat",              # gemma3: q/k-norm + rope + cache write inside the one-launch attention
               "mc_attn_wo_qkn_i4_bfloat_hd256_k2_t1", "mc_attn_wo_qkn_i4_bfloat_hd256_k2_t2",  # ... with Wo in the launch too (attn_wo_qkn_tiles)
               "mc_attn_qkv_wo_qkn_i4_bfloat_hd256_k2_p1_t2", "mc_attn_qkv_wo_qkn_i4_bfloat_hd256_k2_p2_t2",
