@@ -751,7 +751,7 @@ struct mc_decoder {
         if (!attn_wo_qkn_on || !attn_wo_on || !attn_qkn_on || !attn_fused_on || !attn_psum_g || !attn_row_g || tb != 2 || n_own > 254) return 0;
         if (cfg.family != MC_FAMILY_GEMMA3 || cfg.head_dim != 256 || occ_wo_qkn == 0 || !lin_ok(wo) || wo.lora_cols || wo.out % 2 != 0) return 0;
         if (wo.in != 4096 || wo.in != cfg.n_heads * cfg.head_dim || cfg.n_heads / cfg.n_kv_heads > 16) return 0;
-        for (int tiles = 1; tiles <= 2; tiles *= 2) {
+        for (int tiles = 1; tiles <= 4; tiles *= 2) { // (64-, 128-, 256-slot ranges: S = 1024, 2048, 4096 at Gemma-7B's 16 kv heads)
             if (nsplit % tiles != 0 || cfg.max_seq_len % (64 * tiles) != 0) continue;
             const unsigned grid = (unsigned)(nsplit / tiles * cfg.n_kv_heads);
             if (grid <= (unsigned)dev->prop.multiProcessorCount && (unsigned)wo.out / 2 <= 2u * 8u * grid) return tiles;

@@ -1163,8 +1163,11 @@ MC_ATTN_QKV_WO_QKN(mc_attn_qkv_wo_qkn_i4_bfloat_hd256_k2_p1_t1, 256, 2, 1, 1)  /
 MC_ATTN_QKV_WO_QKN(mc_attn_qkv_wo_qkn_i4_bfloat_hd256_k2_p2_t1, 256, 2, 2, 1)  // ... every other block
 MC_ATTN_QKV_WO_QKN(mc_attn_qkv_wo_qkn_i4_bfloat_hd256_k2_p1_t2, 256, 2, 1, 2)  // Gemma-7B at S = 2048: the first block (or parity taps)
 MC_ATTN_QKV_WO_QKN(mc_attn_qkv_wo_qkn_i4_bfloat_hd256_k2_p2_t2, 256, 2, 2, 2)  // ... every other block
+MC_ATTN_QKV_WO_QKN(mc_attn_qkv_wo_qkn_i4_bfloat_hd256_k2_p1_t4, 256, 2, 1, 4)  // Gemma-7B at S = 4096 (256-slot ranges)
+MC_ATTN_QKV_WO_QKN(mc_attn_qkv_wo_qkn_i4_bfloat_hd256_k2_p2_t4, 256, 2, 2, 4)
 MC_ATTN_WO_QKN(mc_attn_wo_qkn_i4_bfloat_hd256_k2_t1, 256, 2, 1)  // Gemma-7B shapes up to S = 1024
 MC_ATTN_WO_QKN(mc_attn_wo_qkn_i4_bfloat_hd256_k2_t2, 256, 2, 2)  // ... S = 2048: 16 ranges of 128 slots x 16 kv heads = one workgroup per CU
+MC_ATTN_WO_QKN(mc_attn_wo_qkn_i4_bfloat_hd256_k2_t4, 256, 2, 4)  // ... S = 4096
 
 // mc_attn_wo_i4_bfloat_hd{head_dim}_k{KiB per Wo row}
 MC_ATTN_WO(mc_attn_wo_i4_bfloat_hd128_k2, 128, 2)  // Llama-3-8B: 32 heads x 128

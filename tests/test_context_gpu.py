@@ -354,7 +354,7 @@ def test_llama32_1b_shapes_take_the_one_launch_block_with_plain_weights(acc, mon
     parity.check(BF16, out["1"][1], out["0"][1], rel=7.8e-3, max_ulp=2, max_frac=0.6, what="one-launch block vs five launches, logits")
 
 
-@pytest.mark.parametrize("shape,S", [("llama3.2-1b", 4096), ("tinyllama", 8192), ("llama3-8b-int8", 4096)])
+@pytest.mark.parametrize("shape,S", [("llama3.2-1b", 4096), ("tinyllama", 8192), ("llama3-8b-int8", 4096), ("gemma-7b", 4096)])
 def test_wide_ranges_keep_the_three_launch_layer_at_long_contexts(acc, monkeypatch, shape, S):
     # round 5: the one-launch blocks with 128- / 256-slot ranges (`_t2` / `_t4`) for plain bfloat weights (Llama-3.2-1B; TinyLlama as 8 virtual kv
     # heads) and int8 at S = 4096 -- against the oracle near the end of the cache and past it, and next to round 4's launches (MC_ATTN_I4_WIDE=0 /
@@ -365,6 +365,11 @@ def test_wide_ranges_keep_the_three_launch_layer_at_long_contexts(acc, monkeypat
         cfg = dict(dtype=BF16, n_layers=1, vocab=2048, max_seq_len=S, norm_eps=1e-5, **FULL_WIDTH["llama3-8b"])
         weights, fmt = synth_model(cfg, SEED, bits=8), dict(weight_format=mc.WFMT_I8, group_size=128)
         kern, off = f"mc_attn_qkv_wo_i8_bfloat_hd128_k4_q4_t{S // 2048}", {"MC_ATTN_I8": "0"}
+    elif shape == "gemma-7b":   # (the gemma3 block with 256-slot ranges: 16 ranges x 16 kv heads at S = 4096; `_p2_t4` by name in test_attn_kernels_gpu.py)
+        cfg = dict(dtype=BF16, n_layers=1, vocab=2048, max_seq_len=S, norm_eps=1e-5, dim=3072, n_heads=16, n_kv_heads=16, head_dim=256,
+                   ffn_dim=4096, family=1, rope_theta=10000.0, rope_sliding_theta=10000.0, sliding_stride=2, attn_scale=256 ** -0.5)
+        weights, fmt = synth_model(cfg, SEED), dict(weight_format=mc.WFMT_I4, group_size=128)
+        kern, off = "mc_attn_qkv_wo_qkn_i4_bfloat_hd256_k2_p1_t4", {"MC_ATTN_WO_QKN": "0"}
     else:
         cfg = dict(dtype=BF16, family=0, n_layers=2, vocab=32000, max_seq_len=S, norm_eps=1e-5, dim=2048, n_heads=32,
                    n_kv_heads=8 if shape == "llama3.2-1b" else 4, head_dim=64, ffn_dim=8192 if shape == "llama3.2-1b" else 5632,
@@ -373,7 +378,7 @@ def test_wide_ranges_keep_the_three_launch_layer_at_long_contexts(acc, monkeypat
         kern, off = f"mc_attn_qkv_wo_w_bfloat_hd64_k4_q4_t{S // 2048}", {"MC_ATTN_I4_WIDE": "0"}
     toks = {}
     for form in ("wide", "off"):
-        for k_ in ("MC_ATTN_I4_WIDE", "MC_ATTN_I8"):
+        for k_ in ("MC_ATTN_I4_WIDE", "MC_ATTN_I8", "MC_ATTN_WO_QKN"):
             monkeypatch.delenv(k_, raising=False)
         if form == "off":
             for k_, v_ in off.items():

@@ -68,7 +68,8 @@ def test_decode_and_reference_kernels_present(symbols):
               "mc_attn_fused_qkn_bfloat",              # gemma3: q/k-norm + rope + cache write inside the one-launch attention
               "mc_attn_wo_qkn_i4_bfloat_hd256_k2_t1", "mc_attn_wo_qkn_i4_bfloat_hd256_k2_t2",  # ... with Wo in the launch too (attn_wo_qkn_tiles)
               "mc_attn_qkv_wo_qkn_i4_bfloat_hd256_k2_p1_t2", "mc_attn_qkv_wo_qkn_i4_bfloat_hd256_k2_p2_t2",
-              "mc_attn_qkv_wo_qkn_i4_bfloat_hd256_k2_p1_t1", "mc_attn_qkv_wo_qkn_i4_bfloat_hd256_k2_p2_t1",  # ... and wq|wk|wv + the norms (attn_qkv_wo_qkn_ok)
+              "mc_attn_qkv_wo_qkn_i4_bfloat_hd256_k2_p1_t1", "mc_attn_qkv_wo_qkn_i4_bfloat_hd256_k2_p2_t1",
+              "mc_attn_qkv_wo_qkn_i4_bfloat_hd256_k2_p1_t4", "mc_attn_qkv_wo_qkn_i4_bfloat_hd256_k2_p2_t4", "mc_attn_wo_qkn_i4_bfloat_hd256_k2_t4",  # ... and wq|wk|wv + the norms (attn_qkv_wo_qkn_ok)
               "mc_attn_fused_t2_bfloat",               # 128-slot ranges (decoder.cc attn_fused_t2: S = 8192)
               # the prompt pass on the quad-interleaved weight copy and its consumers with the split-K reduce inside (round 4)
               "mc_pf2_repack_i4", "mc_pf2_gemm_i4_bfloat", "mc_pf_rope_cache_parts_bfloat", "mc_pf_act_mul_parts_bfloat",
