@@ -839,3 +839,38 @@ def test_gemma_7b_attention_block_with_wo_inside_against_the_two_launches(acc, m
     assert same >= len(out["wo", True][0]) - 2, same
     parity.exact(out["wo", True][1][0][0], out["sep", True][1][0][0], "K cache of the first block")
     parity.exact(out["wo", True][1][0][1], out["sep", True][1][0][1], "V cache of the first block")
+
+
+@pytest.mark.parametrize("shape", ["gemma-7b", "llama3-8b-int4-8192", "tinyllama-4096"])
+def test_graph_replay_of_the_round5_blocks_equals_eager_across_the_end_of_the_cache(acc, shape):
+    # The launches this round added to the default path -- the gemma3 block (mc_attn_qkv_wo_qkn_*: `_p1_` then `_p2_`), the int4 block with 256-slot
+    # ranges, the plain-bfloat block with 128-slot ranges on 8 virtual kv heads -- in mc_decoder_generate's hipGraph replay against the eager
+    # launches: the same 40 greedy tokens from 12 slots before the end of the cache on (the ring turns 28 times), the same last logits, bit for bit.
+    import metalchat_amd as mc
+
+    if shape == "gemma-7b":
+        cfg = dict(dtype=BF16, n_layers=2, vocab=2048, max_seq_len=2048, norm_eps=1e-5, dim=3072, n_heads=16, n_kv_heads=16, head_dim=256,
+                   ffn_dim=4096, family=1, rope_theta=10000.0, rope_sliding_theta=10000.0, sliding_stride=2, attn_scale=256 ** -0.5)
+        fmt, kern = dict(weight_format=mc.WFMT_I4, group_size=128), "mc_attn_qkv_wo_qkn_i4_bfloat_hd256_k2_p2_t2"
+    elif shape == "llama3-8b-int4-8192":
+        cfg = dict(dtype=BF16, n_layers=2, vocab=2048, max_seq_len=8192, norm_eps=1e-5, **FULL_WIDTH["llama3-8b"])
+        fmt, kern = dict(weight_format=mc.WFMT_I4, group_size=128), "mc_attn_qkv_wo_i4_bfloat_hd128_k2_q2_t4"
+    else:
+        cfg = dict(dtype=BF16, family=0, n_layers=2, vocab=32000, max_seq_len=4096, norm_eps=1e-5, dim=2048, n_heads=32, n_kv_heads=4, head_dim=64,
+                   ffn_dim=5632, rope_theta=10000.0, attn_scale=64 ** -0.5)
+        fmt, kern = dict(weight_format=mc.WFMT_T, group_size=0), "mc_attn_qkv_wo_w_bfloat_hd64_k4_q4_t2"
+    S = cfg["max_seq_len"]
+    out = {}
+    for graph in (0, 1):
+        dec = mc.Decoder(acc, **mg.decoder_kwargs(cfg, use_graph=graph, **fmt))
+        dec.init_synthetic(SEED)
+        for layer in range(cfg["n_layers"]):
+            k, v = random_cache(cfg, S - 12, 1100 + layer)
+            dec.import_kv(layer, k, v)
+        dec.launch_log(True)
+        toks = list(dec.generate(7, S - 12, 40))
+        assert kern in set(dec.launched()), sorted(set(dec.launched()))
+        out[graph] = (toks, dec.logits().copy())
+        dec.release()
+    assert out[0][0] == out[1][0], shape
+    parity.exact(out[0][1], out[1][1], f"{shape}: the last logits, graph replay vs eager")
