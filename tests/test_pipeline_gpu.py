@@ -162,3 +162,47 @@ def test_rccl_two_ranks_equal_single_stage(world):
     for r, (p, (o, e)) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, f"rank {r}: rc {p.returncode}\n{o[-2000:]}\n{e[-4000:]}"
     assert f"rccl {world} ranks ok" in outs[0][0]
+
+
+def test_local_pipeline_of_gemma_7b_shaped_blocks_equals_the_single_stage_bit_for_bit(acc):
+    """The gemma3 block in one launch (round 5, mc_attn_qkv_wo_qkn_*) at the seams of a layer pipeline: the first block of a later stage has no
+    post-norm in front of it (`_p1_` on the row the hop delivered), the last block of a stage leaves its ffn post-norm to mc_rmsnorm_row so that the
+    row can travel -- two stages of two Gemma-7B-wide blocks each against the single stage: tokens, logits and every cache bit for bit, across the
+    end of the cache."""
+    import metalchat_amd as mc
+    from test_context_gpu import SEED, random_cache
+
+    cfg = dict(dtype=BF16, n_layers=4, vocab=2048, max_seq_len=2048, norm_eps=1e-5, dim=3072, n_heads=16, n_kv_heads=16, head_dim=256,
+               ffn_dim=4096, family=1, rope_theta=10000.0, rope_sliding_theta=10000.0, sliding_stride=2, attn_scale=256 ** -0.5)
+    kw = mg.decoder_kwargs(cfg, weight_format=mc.WFMT_I4, group_size=128)
+    caches = [random_cache(cfg, 2040, 1300 + layer) for layer in range(cfg["n_layers"])]
+    single = mc.Decoder(acc, **kw)
+    single.init_synthetic(SEED)
+    for layer, (k, v) in enumerate(caches):
+        single.import_kv(layer, k, v)
+    single.launch_log(True)
+    want = list(single.generate(5, 2040, 20))
+    assert {"mc_attn_qkv_wo_qkn_i4_bfloat_hd256_k2_p1_t2", "mc_attn_qkv_wo_qkn_i4_bfloat_hd256_k2_p2_t2"} <= set(single.launched())
+    want_logits = single.logits().copy()
+    want_kv = [tuple(a.copy() for a in single.export_kv(layer)) for layer in range(cfg["n_layers"])]
+    single.release()
+    stages = []
+    for r in range(2):
+        lb, le = mc.pipeline_layer_range(r, 2, cfg["n_layers"])
+        d = mc.Decoder(acc, **dict(kw, layer_begin=lb, layer_end=le))
+        d.init_synthetic(SEED)
+        for layer in range(lb, le):
+            d.import_kv(layer, *caches[layer])
+        stages.append(d)
+    pipe = mc.Pipeline.local(stages)
+    got = list(pipe.generate(5, 2040, 20))
+    assert got == want
+    parity.exact(stages[-1].logits(), want_logits, "logits of the last token")
+    for r, d in enumerate(stages):
+        for layer in range(d.cfg["layer_begin"], d.cfg["layer_end"]):
+            gk, gv = d.export_kv(layer)
+            parity.exact(gk, want_kv[layer][0], f"stage {r} K[{layer}]")
+            parity.exact(gv, want_kv[layer][1], f"stage {r} V[{layer}]")
+    pipe.release()
+    for d in stages:
+        d.release()
