@@ -69,8 +69,20 @@ using namespace mc::gemv;
 #ifndef MC_QX_STG_W
 #define MC_QX_STG_W 0
 #endif
-template <int HD, int QN, int WB = 0, int STG = (WB == 0 ? MC_QX_STG_I4 : (WB == 1 ? MC_QX_STG_W : MC_QX_STG_I8))>
+// NOTE (round 6, mc_attn_qkv_wo_w13_*): a NINTH wave of the workgroup -- the run-ahead loader below -- joins every workgroup barrier of the launch; it learns
+// that a wave has reached barrier k from the LDS word `note_w`, which lane 0 of every arriving wave sets to k (asm ds_write: handoff.h).
+// Barrier 1 (at_start) is joined unconditionally and is what publishes the word's initial zero.
+constexpr int qx_stg_default(int WB) { return WB == 0 ? MC_QX_STG_I4 : (WB == 1 ? MC_QX_STG_W : MC_QX_STG_I8); }
+template <int HD, int QN, int WB = 0, int STG = qx_stg_default(WB), int NOTE = 0>
 struct qkv_in_launch {
+    static_assert(!NOTE || !MC_QKV_ROW_DEAL, "the loader counts the barriers of the whole-pair deal");
+    uint32_t note_w = 0; // (NOTE) byte offset of the word in LDS
+    __device__ __forceinline__ void note(int k) const
+    {
+        if constexpr (NOTE != 0) {
+            if ((threadIdx.x & 63) == 0) lds_poke(note_w, (uint32_t)k);
+        }
+    }
     // (WB = 0, QN = 4 -- round 5, mc_attn_qkv_i4_bfloat_hd128_q4: Llama-3-70B's rows of 4 KiB (K = 8192): two packets of the hidden row per
     //  thread, up to THREE pairs per wave (20 per workgroup), 640 pairs per kv head gathered in two passes)
     static_assert(WB ? QN == 4 : (QN == 2 || QN == 4), "K = 4096 / 8192 int4, 4096 int8, 2048 bfloat; 512 threads");
@@ -240,6 +252,7 @@ struct qkv_in_launch {
             float tot = wsum_ * 8.0f; // (ablation build, gemv.h: timing only)
 #else
             if (lane == 0) red[wave] = wsum_;
+            note(2);
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // (LDS only: the first pairs stay in flight)
             float tot = 0.0f;
 #pragma unroll
@@ -261,6 +274,7 @@ struct qkv_in_launch {
                 else if (tid < NPK) reinterpret_cast<rowv4*>(xs)[tid] = rowv4{o[0], o[1], o[2], o[3]};              // (natural order)
             }
         }
+        note(3);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         stamp(1);
         // ---- the rest of the wave's rows and the rotation of the pair this lane will finish (lane i < cnt: whole pair j0 + i,
@@ -438,6 +452,7 @@ struct qkv_in_launch {
                 }
             }
         }
+        note(4);
         __syncthreads();
         stamp(11);
     }
@@ -504,6 +519,7 @@ struct qkv_qkn_in_launch {
     float pc, ps;
     uint32_t j0, full, slot, tag, rrow_;
 
+    __device__ __forceinline__ void note(int) const {} // (attn_fused_bf: qkv_in_launch NOTE)
     __device__ __forceinline__ void stamp(int i) const
     {
         if (tl && threadIdx.x == 0) tl[(size_t)blockIdx.x * TL_STRIDE + i] = __builtin_amdgcn_s_memrealtime();
@@ -759,7 +775,9 @@ struct gemma_extra {
     void* h_out;                  // (QKN = 3) where workgroup 0 leaves that hidden row
     const bf16_t *q_norm, *k_norm;
 };
-template <int HD, int LNCH, int QN = 0, int WB = 0, int TT = 1, int QKN = 0>
+// CH = 1 (round 6, mc_attn_qkv_wo_w13_*): a phase follows in the same launch -- every stored pair of the output row is also published as a
+// {2 x bf16, tag} granule in `hid_g` (hand-off D), and the workgroup's barriers are noted for the loader wave (qkv_in_launch NOTE, `note_w`)
+template <int HD, int LNCH, int QN = 0, int WB = 0, int TT = 1, int QKN = 0, int CH = 0>
 __device__ __forceinline__ void
 attn_wo_body(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const bf16_t* __restrict__ vt, bf16_t* __restrict__ attn_out,
              unsigned long long* psum_g, unsigned long long* slab_g, unsigned long long* row_g, step_state* st, uint32_t n_rep,
@@ -770,8 +788,9 @@ attn_wo_body(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const 
              // granules of hand-off Q
              const void* __restrict__ qnorm_w = nullptr, const void* __restrict__ qkv_w = nullptr, const void* __restrict__ qkv_s = nullptr,
              const float* fcos = nullptr, const float* fsin = nullptr, unsigned long long* qkv_g = nullptr, float eps = 0.0f, float mu = 0.0f,
-             uint32_t kv_shift = 0, gemma_extra gx = gemma_extra())
+             uint32_t kv_shift = 0, gemma_extra gx = gemma_extra(), unsigned long long* hid_g = nullptr, uint32_t note_w = 0)
 {
+    static_assert(CH == 0 || (QN != 0 && QKN == 0 && WB == 0), "a chained phase: behind the int4 launch with wq|wk|wv inside");
     constexpr uint32_t K = WB == 1 ? 512u * LNCH : (WB == 2 ? 1024u * LNCH : 2048u * LNCH);
     constexpr uint32_t WPK = WB == 1 ? 8u : (WB == 2 ? 16u : 32u); // weights of a lane's 16-byte packet
     constexpr uint32_t CHUNK_LDS = 2048 * 2 / 16 * 17;  // a chunk of the row in LDS: 16 bytes of padding per 256 (gemv.h Q_M4D)
@@ -784,8 +803,9 @@ attn_wo_body(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const 
     __shared__ __attribute__((aligned(16))) bf16_t qkv_rows[(QN || QKN) ? 18 * HD : 8]; // queries of up to 16 heads, the K row, the V row
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // (QN != 0) the hidden row and the wave's wq|wk|wv pairs are requested by the first instructions of the launch
-    typedef qkv_in_launch<HD, QN ? QN : (WB ? 4 : 2), WB> qx_t;
+    typedef qkv_in_launch<HD, QN ? QN : (WB ? 4 : 2), WB, qx_stg_default(WB), CH> qx_t;
     qx_t qx;
+    qx.note_w = note_w;
     if constexpr (QN != 0) {
         typedef typename qx_t::lds_row lds_row;
         qx.q_s = (lds_row)qkv_rows;
@@ -963,6 +983,7 @@ attn_wo_body(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const 
             else *reinterpret_cast<uint32_t*>(xs + g * 4) = val[i]; // (natural order)
         }
     }
+    if constexpr (CH != 0) qx.note(7);
     __syncthreads();
     stamp(6);
 
@@ -1021,6 +1042,7 @@ attn_wo_body(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const 
                 vb = __uint_as_float(wres[i] & 0xFFFF0000u) + vb;
             }
             reinterpret_cast<uint32_t*>(y)[pb + i] = pack_bf16x2(va, vb);
+            if constexpr (CH != 0) granule_store(hid_g + pb + i, epoch_tag, pack_bf16x2(va, vb)); // hand-off D
         }
     }
     stamp(7);
@@ -1179,3 +1201,319 @@ MC_ATTN_WO(mc_attn_wo_i4_bfloat_hd128_k4, 128, 4)  // tuning builds (-DMC_ATTN_W
 #endif
 MC_ATTN_WO(mc_attn_wo_i4_bfloat_hd64_k1, 64, 1)    // 32 heads x 64
 MC_ATTN_WO(mc_attn_wo_i4_bfloat_hd256_k2, 256, 2)  // Gemma-7B shapes: 16 heads x 256
+
+// ------------------------------------------------------------------------------------------
+// Round 6: the attention block AND ffn_norm + w1|w3 + SiLU * mul (include/metalchat/nn/transformer.h:130-137, 53-59) in one launch, with a
+// RUN-AHEAD LOADER: mc_attn_qkv_wo_w13_i4_bfloat_hd128_k2_q2_f2.
+//
+// Why: the attention block lasts ~ 14 us for 30 MB -- four group synchronisations in a row, the HBM idle two thirds of the time --
+// and the w1|w3 GEMV behind it 12.5 us for 60.6 MB: a launch boundary, a prologue and a cold stream that starts only when the row
+// is there.  The weights of w1|w3 depend on nothing.  Round 3 chained the two phases with the first 4 KiB per wave requested before
+// the row arrived and lost (tools/experiments/README.md): a chained phase gains what it has on chip BEFORE its row arrives.  Here a
+// NINTH wave of the workgroup does nothing but bring the workgroup's first NLP row pairs of w1|w3 (4 KiB each: 112 KiB of the CU's
+// 224) into a static LDS image by LDS-DMA (global_load_lds_dwordx4 nt: no registers, a vmcnt queue of its own -- the eight waves'
+// polls and tiles never wait behind it in THEIR in-order return), trickled at ~ 9 GB/s per CU from the moment the queries are out
+// until the hidden row comes back (MI355X_MICROARCH.md: ldsdma-fill, prefetch-credit, gather-pass "thin the loader while its CU
+// gathers").  When hand-off D delivers the row, 112 KiB wait in LDS and 64 KiB in the eight waves' registers (two pairs each, requested
+// in front of the wait as round 3 did); 48 KiB per CU are left to stream behind the multiplications.
+//
+// The loader and the barriers: s_barrier counts every live wave of the workgroup, so the loader JOINS each of the block's barriers.
+// It learns that a wave has reached barrier k from an LDS word (qkv_in_launch NOTE; tools/ldr_lab.hip: joined <= 0.04 us after the first
+// arrival, the eight waves' phases unchanged) and issues one pair per look in between; behind the last barrier of the Wo phase it
+// issues what is left, waits for everything to land (s_waitcnt vmcnt(0)), joins the two barriers of the w1|w3 prologue -- the first
+// of them is what makes the image visible to the eight waves -- and ends: a wave that has terminated no longer counts.
+//
+// Numerics: bit for bit the two launches it replaces.  The attention block is the same code (attn_wo_body, CH = 1: its Wo epilogue
+// also publishes the pair as a granule).  The w1|w3 phase is mc_gemv_i4_bfloat_lin2_p1_e2's arithmetic: thread t holds packet t of the
+// hidden row (granules 4 t .. 4 t + 3), per-thread sum of squares, wave_sum_dpp, the eight wave sums in wave order, the normalised
+// row staged in the padded order; a pair = tiles (row 0 chunk 0, row 0 chunk 1, row 1 chunk 0, row 1 chunk 1) through mac4b_n<1>
+// into one accumulator per row, the lane's own element, one wave sum times 2^37, the epilogue of gemv.h finish_pair (EPI_SILU_MUL).  An
+// LDS-DMA deposits lane l's 16 bytes of a 1 KiB tile at byte 16 l of its slot, so ds_read_b128 at 16 l returns exactly the
+// registers global_load_dwordx4 would have filled.  Which wave multiplies a pair, and from where, does not change a bit of it.
+// ------------------------------------------------------------------------------------------
+namespace {
+
+#ifndef MC_LDR_NLA
+#define MC_LDR_NLA 4 // pairs of each of waves 0-3 (8 of w1|w3's 56 per workgroup) that wait in LDS
+#endif
+#ifndef MC_LDR_NLB
+#define MC_LDR_NLB 3 // ... of each of waves 4-7 (6 pairs)
+#endif
+#ifndef MC_LDR_START
+#define MC_LDR_START 4 // the loader's first request goes out behind this barrier of the block (4: hand-off Q done, the queries are out;
+                       // the wq|wk|wv phase in front of it is HBM-bound by itself)
+#endif
+#ifndef MC_LDR_PACE
+#define MC_LDR_PACE 4 // x 64 cycles between two looks of the loader (one pair per look: ~ 0.45 us, tools/ldr_lab.hip)
+#endif
+#ifndef MC_LDR_TAIL_PACE
+#define MC_LDR_TAIL_PACE 2 // ... behind the last barrier of the Wo phase (the row is on its way: nothing of this CU polls HBM-side data but hand-off D)
+#endif
+static_assert(MC_LDR_NLA >= MC_LDR_NLB && MC_LDR_NLA <= 8 && MC_LDR_NLB >= 0, "the early wave of a SIMD holds at least as many pairs in LDS as the late one");
+constexpr uint32_t LDR_NLP = 4u * MC_LDR_NLA + 4u * MC_LDR_NLB; // pairs in the LDS image
+// image slot of pair i of wave w: pairs are brought in round robin over the waves, every wave's first pair first
+__device__ __forceinline__ uint32_t ldr_slot(uint32_t w, uint32_t i)
+{
+    return i < (uint32_t)MC_LDR_NLB ? 8u * i + w : 8u * MC_LDR_NLB + 4u * (i - MC_LDR_NLB) + w;
+}
+// stamps (tl2 != null: tools/attn_w13_timeline.py), per workgroup, s_memrealtime:
+//   0 loader behind barrier 1   1 .. 28 pair n - 1 requested   30 everything landed   31 loader done
+//   32 Wo done (thread 0)   33 hand-off D: row gathered   34 row staged   35 first two streamed pairs multiplied   36 LDS pairs multiplied   37 stored
+constexpr int TL2_STRIDE = 40;
+
+template <int HD, int LNCH, int QN>
+__device__ __forceinline__ void
+attn_qkv_wo_w13_body(const bf16_t* kc, const bf16_t* vt, bf16_t* attn_out, unsigned long long* psum_g, unsigned long long* slab_g, unsigned long long* row_g,
+                     unsigned long long* qkv_g, step_state* st, uint32_t n_rep, uint32_t KV, uint32_t max_seq, float scale, uint32_t nsplit, uint32_t layer_tag,
+                     const void* wo_w, const void* wo_s, const bf16_t* x, bf16_t* y, uint32_t out_rows, uint32_t group, const void* qnorm_w,
+                     const void* qkv_w, const void* qkv_s, const float* fcos, const float* fsin, float eps, float mu, uint32_t fastpath,
+                     unsigned long long* tl, unsigned long long* hid_g, const void* __restrict__ w13_w, const void* __restrict__ w13_s,
+                     const void* __restrict__ ffn_norm, bf16_t* __restrict__ gate, uint32_t ffn_rows, uint32_t ffn_group, unsigned long long* tl2)
+{
+    static_assert(QN == 2 && LNCH == 2, "dim 4096: rows of 2 KiB for wq|wk|wv and w1|w3, one packet of the hidden row per thread");
+    constexpr uint32_t CHUNK_LDS = 2048 * 2 / 16 * 17, ROWB = 2048u, FN = 2, KF = 4096u;
+    __shared__ __attribute__((aligned(16))) char ring[LDR_NLP * 4096u];
+    __shared__ __attribute__((aligned(16))) char xs13[FN * CHUNK_LDS];
+    __shared__ float red13[16];
+    __shared__ uint32_t ldr_words[4];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t note_w = lds_off(&ldr_words[0]);
+    unsigned long long* mytl = tl2 ? tl2 + (size_t)blockIdx.x * TL2_STRIDE : nullptr;
+    const uint32_t NP = ffn_rows / 2;
+    typedef const void __attribute__((address_space(1))) gvoid_t;
+    typedef __attribute__((address_space(3))) void lds_void_t;
+
+    if (wave == 8) {
+        // ================= the loader
+        if (lane == 0) lds_poke(note_w, 0u);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // barrier 1 (qkv_in_launch at_start): unconditional
+        if (mytl && lane == 0) mytl[0] = __builtin_amdgcn_s_memrealtime();
+        // the barriers of this workgroup: 2, 3 (rmsnorm, row staged), 4 (hand-off Q), 5, 6 (scores, hand-off A: ranges below kv_len only), 7 (hand-off C)
+        const __attribute__((address_space(1))) int32_t* stp = (const __attribute__((address_space(1))) int32_t*)st;
+        const uint32_t kv_len = (uint32_t)stp[2], split = blockIdx.x / KV;
+        const bool active = split * 64u < kv_len;
+        uint32_t n = 0, next = 2, spins = 0;
+        auto request = [&](uint32_t n_) {
+            uint32_t w, i;
+            if (n_ < 8u * MC_LDR_NLB) { i = n_ >> 3; w = n_ & 7u; }
+            else { i = MC_LDR_NLB + ((n_ - 8u * MC_LDR_NLB) >> 2); w = (n_ - 8u * MC_LDR_NLB) & 3u; }
+            uint32_t pb, pe;
+            lin_deal<8>(NP, w, 8u, pb, pe);
+            const uint32_t pr = min(pb + i, NP - 1u); // (a wave with fewer pairs than the image gives it: the consumers never read the slot)
+            const char* src = static_cast<const char*>(w13_w) + (size_t)pr * (2u * ROWB) + lane * 16u;
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+                __builtin_amdgcn_global_load_lds((gvoid_t*)(src + t * 1024), (lds_void_t*)(ring + n_ * 4096u + t * 1024u), 16, 0, 2 /* nt */);
+            if (mytl && lane == 0) mytl[1 + n_] = __builtin_amdgcn_s_memrealtime();
+        };
+        // (bounded like every wait of the launch: 2^22 looks of >= 0.1 us; a workgroup that never reaches its barriers has hung already)
+        while (next <= 7u && spins < (1u << 22)) {
+            const uint32_t f = __builtin_amdgcn_readfirstlane(lds_peek(note_w));
+            if (f >= next) {
+                asm volatile("s_barrier" ::: "memory");
+                next++;
+                if (!active && next == 5u) next = 7u;
+                continue;
+            }
+            if (n < LDR_NLP && next > (uint32_t)MC_LDR_START) request(n++);
+            __builtin_amdgcn_s_sleep(MC_LDR_PACE);
+            spins++;
+        }
+        while (n < LDR_NLP) {
+            request(n++);
+            __builtin_amdgcn_s_sleep(MC_LDR_TAIL_PACE);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (mytl && lane == 0) mytl[30] = __builtin_amdgcn_s_memrealtime();
+        asm volatile("s_barrier" ::: "memory"); // barrier 8: the image is in LDS for the eight waves
+        asm volatile("s_barrier" ::: "memory"); // barrier 9: the row is staged
+        if (mytl && lane == 0) {
+            mytl[31] = __builtin_amdgcn_s_memrealtime();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        return;
+    }
+
+    // ================= the eight waves: the attention block ...
+    attn_wo_body<HD, LNCH, QN, 0, 1, 0, 1>(nullptr, kc, vt, attn_out, psum_g, slab_g, row_g, st, n_rep, KV, max_seq, scale, nsplit, layer_tag, wo_w, wo_s, x, y,
+                                           out_rows, group, 1u, fastpath, tl, qnorm_w, qkv_w, qkv_s, fcos, fsin, qkv_g, eps, mu, 0u, gemma_extra(), hid_g, note_w);
+    auto stamp2 = [&](int i) {
+        if (mytl && tid == 0) mytl[i] = __builtin_amdgcn_s_memrealtime();
+    };
+    stamp2(32);
+    // ================= ... and ffn_norm + w1|w3 + SiLU * mul
+    typedef uint32_t rowv4 __attribute__((ext_vector_type(4)));
+    uint32_t pb, pe;
+    lin_deal<8>(NP, wave, 8u, pb, pe);
+    const uint32_t cnt = pe - pb;                                                  // pairs of this wave (the host: at most 8)
+    const uint32_t nl = min(wave < 4 ? (uint32_t)MC_LDR_NLA : (uint32_t)MC_LDR_NLB, cnt); // ... of them in the LDS image: pairs pb .. pb + nl - 1
+    const uint32_t ps = pb + nl;                                                   // ... the rest streamed: ps .. pe - 1 (the host: at most 4)
+    const uint32_t glog = ffn_group ? 31u - __builtin_clz(ffn_group) : 31u, ngroups = ffn_group ? KF >> glog : 1u;
+    const char* wbase = static_cast<const char*>(w13_w);
+    const char* sbase = static_cast<const char*>(w13_s);
+    // (every load unconditional: masks, not selects -- gemv.h ltile.  A pair the wave does not have reads one broadcast line)
+    auto req_pair = [&](uint4 (&dst)[4], uint32_t pr, bool live) {
+        const uint32_t lm = 0u - (uint32_t)live;
+        const uint64_t lm64 = ((uint64_t)lm << 32) | lm;
+        const char* a = wbase + (((uint64_t)pr * (2u * ROWB)) & lm64) + ((lane * 16u) & lm);
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const rowv4 v = __builtin_nontemporal_load(reinterpret_cast<const rowv4*>(a + ((t * 1024u) & lm)));
+            dst[t] = make_uint4(v.x, v.y, v.z, v.w);
+        }
+    };
+    // scales of pair pr: half a row quad ([ngroups][4] bf16 per four rows) per chunk; the lane's 32 weights of chunk c sit in group (2048 c + 32 lane) / group
+    auto req_scales = [&](uint32_t (&q)[FN], uint32_t pr, bool live) {
+        const uint64_t ub = (((uint64_t)(pr >> 1) * ngroups) * 4 + (pr & 1u) * 2) * 2;
+        const uint32_t lm = 0u - (uint32_t)live;
+        const char* a = sbase + (ub & (((uint64_t)lm << 32) | lm));
+#pragma unroll
+        for (int c = 0; c < (int)FN; c++) {
+            const uint32_t g = ffn_group ? ((2048u * (uint32_t)c + 32u * lane) >> glog) : 0u;
+            q[c] = *reinterpret_cast<const uint32_t*>(a + ((g * 8u) & lm));
+        }
+    };
+    // ---- in front of the wait: the norm weights, every pair's scales, the first two streamed pairs (8 KiB per wave in registers)
+    const rowv4 nr = reinterpret_cast<const rowv4*>(ffn_norm)[tid];
+    uint32_t scl[MC_LDR_NLA][FN], scs[4][FN];
+#pragma unroll
+    for (int i = 0; i < MC_LDR_NLA; i++) req_scales(scl[i], pb + i, (uint32_t)i < nl);
+#pragma unroll
+    for (int i = 0; i < 4; i++) req_scales(scs[i], ps + i, ps + i < pe);
+    uint4 sr[2][4];
+    req_pair(sr[0], ps, ps < pe);
+    req_pair(sr[1], ps + 1, ps + 1 < pe);
+    // ---- hand-off D: the hidden row the Wo phases of ALL workgroups finished; thread t gathers packet t = granules 4 t .. 4 t + 3
+    // (one watched granule and ~ 0.4 us between looks while the row is not there, then one sweep: hand-off C)
+    const uint32_t epoch_tag = st->epoch * 256u + layer_tag;
+    rowv4 xr;
+    {
+        uint32_t val[4];
+        handoff_wait w;
+        for (;;) {
+            const bool seen = (uint32_t)(granule_load(hid_g + 4u * tid + 3u) >> 32) == epoch_tag;
+            if (__all(seen) || w.expired(st, 0xE0000000u | layer_tag)) break;
+            __builtin_amdgcn_s_sleep(MC_HANDOFF_C_SLEEP);
+        }
+        for (;;) {
+            bool ok = true;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const unsigned long long g = granule_load(hid_g + 4u * tid + i);
+                ok = ok && (uint32_t)(g >> 32) == epoch_tag;
+                val[i] = (uint32_t)g;
+            }
+            if (__all(ok) || w.expired(st, 0xE0000000u | layer_tag)) break;
+        }
+        xr = rowv4{val[0], val[1], val[2], val[3]};
+    }
+    stamp2(33);
+    // ---- ffn_norm on the way into LDS (kernel/rmsnorm.metal:52-95; gemv.h, the build-time prologue: the same additions in the same order)
+    {
+        const uint32_t vv[4] = {xr.x, xr.y, xr.z, xr.w};
+        float s1 = 0.0f;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const float a = asf(vv[e] << 16), b = asf(vv[e] & 0xFFFF0000u);
+            s1 += a * a;
+            s1 += b * b;
+        }
+        float ss = 0.0f;
+        ss += s1;
+        const float wsum_ = wave_sum_dpp(ss);
+        if (lane == 0) red13[wave] = wsum_;
+        lds_barrier(); // barrier 8 (with the loader: its image has landed)
+        float tot = 0.0f;
+#pragma unroll
+        for (uint32_t i = 0; i < 8u; i++) tot += red13[i];
+        const float inv = 1.0f / sqrtf(tot / (float)KF + eps);
+        const uint32_t wv[4] = {nr.x, nr.y, nr.z, nr.w};
+        uint32_t o[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const float a = (mu + asf(wv[e] << 16)) * asf(vv[e] << 16) * inv;
+            const float b = (mu + asf(wv[e] & 0xFFFF0000u)) * asf(vv[e] & 0xFFFF0000u) * inv;
+            o[e] = pack_bf16x2(a, b);
+        }
+        reinterpret_cast<rowv4*>(xs13)[tid + (tid >> 4)] = rowv4{o[0], o[1], o[2], o[3]}; // (packet p sits in slot p + p / 16)
+    }
+    lds_barrier(); // barrier 9
+    stamp2(34);
+    // ---- the row's transposed gather (gemv.h Q_M4D), once per wave
+    const uint32_t lane_tr = (((lane >> 4) * 4 + (lane & 3)) * 17 + ((lane >> 2) & 3) * 4) * 16;
+    const m4b_lane m4bk = m4b_lane_consts(lane);
+    typedef __attribute__((address_space(3))) mf_s4 lds_s4;
+    uint2 xq[FN][8];
+#pragma unroll
+    for (int c = 0; c < (int)FN; c++) {
+        lds_s4* xt = (lds_s4*)(xs13 + c * CHUNK_LDS + lane_tr);
+#pragma unroll
+        for (int e = 0; e < 8; e++) xq[c][e] = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16(xt + e));
+    }
+    // one pair: its four tiles in the linear-order kernel's order (gemv.h do_pair: tile t = row t / 2, chunk t % 2)
+    float my_a = 0.0f, my_b = 0.0f;
+    auto pair_sums = [&](const uint4 (&tile)[4], const uint32_t (&sc)[FN], uint32_t i) {
+        float rs[2];
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            mf_f4 acc[1] = {mf_f4{0, 0, 0, 0}};
+#pragma unroll
+            for (int c = 0; c < (int)FN; c++) {
+                const uint32_t raw = sc[c];
+                mac4b_n<1>(acc, tile[2 * r + c], m4b_prepare(r ? (raw & 0xFFFF0000u) : (raw << 16), m4bk), xq[c]);
+            }
+            const uint32_t e = lane & 3;
+            const float mine = e == 0 ? acc[0][0] : (e == 1 ? acc[0][1] : (e == 2 ? acc[0][2] : acc[0][3]));
+            rs[r] = wave_sum_dpp(mine) * 0x1p37f; // 2^M4B_Q: the sum was formed at 2^-Q (mac4b_n)
+        }
+        if (lane == i) {
+            my_a = rs[0];
+            my_b = rs[1];
+        }
+    };
+    // ---- the first two streamed pairs from registers; their slots take the last two
+    if (ps < pe) pair_sums(sr[0], scs[0], nl);           // (wave-uniform; no load inside)
+    req_pair(sr[0], ps + 2, ps + 2 < pe);
+    if (ps + 1 < pe) pair_sums(sr[1], scs[1], nl + 1u);
+    req_pair(sr[1], ps + 3, ps + 3 < pe);
+    stamp2(35);
+    // ---- the pairs that waited in LDS
+    typedef const __attribute__((address_space(3))) uint4* lds_u4;
+#pragma unroll
+    for (int i = 0; i < MC_LDR_NLA; i++) {
+        if ((uint32_t)i < nl) { // (wave-uniform; LDS reads only)
+            lds_u4 src = (lds_u4)(ring + ldr_slot(wave, (uint32_t)i) * 4096u + lane * 16u);
+            uint4 tile[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) tile[t] = src[t * 64];
+            pair_sums(tile, scl[i], (uint32_t)i);
+        }
+    }
+    stamp2(36);
+    // ---- the last streamed pairs
+    if (ps + 2 < pe) pair_sums(sr[0], scs[2], nl + 2u);
+    if (ps + 3 < pe) pair_sums(sr[1], scs[3], nl + 3u);
+    // ---- the epilogue of gemv.h finish_pair (EPI_SILU_MUL), one lane per pair: out[j] = T(silu(T(w1 x)) * T(w3 x))
+    if (lane < cnt) {
+        const float ga = BF::rt(my_a), gb = BF::rt(my_b);
+        const float g = mc::gemv::silu_T<BF>(ga);
+        gate[pb + lane] = BF::st(g * gb);
+    }
+    stamp2(37);
+}
+
+} // namespace
+
+// mc_attn_qkv_wo_w13_i4_bfloat_hd{head_dim}_k{KiB per Wo row}_q{KiB per wq|wk|wv row}_f{KiB per w1|w3 row}: 576 threads (eight waves + the loader)
+extern "C" __global__ void __launch_bounds__(576)
+mc_attn_qkv_wo_w13_i4_bfloat_hd128_k2_q2_f2(const bf16_t* kc, const bf16_t* vt, bf16_t* attn_out, unsigned long long* psum_g, unsigned long long* slab_g,
+                                            unsigned long long* row_g, unsigned long long* qkv_g, step_state* st, uint32_t n_rep, uint32_t n_kv, uint32_t max_seq,
+                                            float scale, uint32_t nsplit, uint32_t layer_tag, const void* wo_w, const void* wo_s, const bf16_t* x, bf16_t* y,
+                                            uint32_t out_rows, uint32_t group, const void* qnorm_w, const void* qkv_w, const void* qkv_s, const float* fcos,
+                                            const float* fsin, float eps, float mu, uint32_t fastpath, unsigned long long* tl, unsigned long long* hid_g,
+                                            const void* w13_w, const void* w13_s, const void* ffn_norm, bf16_t* gate, uint32_t ffn_rows, uint32_t ffn_group,
+                                            unsigned long long* tl2)
+{
+    attn_qkv_wo_w13_body<128, 2, 2>(kc, vt, attn_out, psum_g, slab_g, row_g, qkv_g, st, n_rep, n_kv, max_seq, scale, nsplit, layer_tag, wo_w, wo_s, x, y, out_rows,
+                                    group, qnorm_w, qkv_w, qkv_s, fcos, fsin, eps, mu, fastpath, tl, hid_g, w13_w, w13_s, ffn_norm, gate, ffn_rows, ffn_group, tl2);
+}
