@@ -813,8 +813,8 @@ struct mc_decoder {
     }
 
     // ... AND ffn_norm + w1|w3 + act*mul as the next phase of that launch (round 6, mc_attn_qkv_wo_w13_i4_bfloat_hd128_k2_q2_f2, attn_block_kernels.hip): a ninth
-    // wave of every workgroup brings 28 of the workgroup's w1|w3 row pairs into LDS while the eight wait through the attention's hand-offs.  The built
-    // shape only: dim 4096, exactly one workgroup per CU and 56 pairs of 2 KiB rows per workgroup (8 / 6 per wave: gemv.h lin_deal), llama blocks, no adaptor
+    // wave of every workgroup brings 32 of the workgroup's w1|w3 row pairs into LDS while the eight wait through the attention's hand-offs.  The built
+    // shape only: dim 4096, exactly one workgroup per CU and 56 pairs of 2 KiB rows per workgroup (7 per wave), llama blocks, no adaptor
     bool
     attn_qkv_wo_w13_ok(const layer_w& L) const
     {

@@ -1233,33 +1233,34 @@ MC_ATTN_WO(mc_attn_wo_i4_bfloat_hd256_k2, 256, 2)  // Gemma-7B shapes: 16 heads 
 // ------------------------------------------------------------------------------------------
 namespace {
 
-#ifndef MC_LDR_NLA
-#define MC_LDR_NLA 4 // pairs of each of waves 0-3 (8 of w1|w3's 56 per workgroup) that wait in LDS
-#endif
-#ifndef MC_LDR_NLB
-#define MC_LDR_NLB 3 // ... of each of waves 4-7 (6 pairs)
+#ifndef MC_LDR_NL
+#define MC_LDR_NL 4 // pairs of every wave (7 of w1|w3's 56 per workgroup) that wait in LDS: 32 x 4 KiB = 128 KiB of the CU's 224
 #endif
 #ifndef MC_LDR_START
 #define MC_LDR_START 4 // the loader's first request goes out behind this barrier of the block (4: hand-off Q done, the queries are out;
                        // the wq|wk|wv phase in front of it is HBM-bound by itself)
 #endif
 #ifndef MC_LDR_PACE
-#define MC_LDR_PACE 4 // x 64 cycles between two looks of the loader (one pair per look: ~ 0.45 us, tools/ldr_lab.hip)
+#define MC_LDR_PACE 2 // x 64 cycles between two looks of the loader (MC_LDR_BURST pairs per look)
+#endif
+#ifndef MC_LDR_BURST
+#define MC_LDR_BURST 1 // pairs (4 KiB each) requested per look
 #endif
 #ifndef MC_LDR_TAIL_PACE
-#define MC_LDR_TAIL_PACE 2 // ... behind the last barrier of the Wo phase (the row is on its way: nothing of this CU polls HBM-side data but hand-off D)
+#define MC_LDR_TAIL_PACE 1 // ... behind the last barrier of the Wo phase (the row is on its way: nothing of this CU polls HBM-side data but hand-off D)
 #endif
-static_assert(MC_LDR_NLA >= MC_LDR_NLB && MC_LDR_NLA <= 8 && MC_LDR_NLB >= 0, "the early wave of a SIMD holds at least as many pairs in LDS as the late one");
-constexpr uint32_t LDR_NLP = 4u * MC_LDR_NLA + 4u * MC_LDR_NLB; // pairs in the LDS image
-// image slot of pair i of wave w: pairs are brought in round robin over the waves, every wave's first pair first
-__device__ __forceinline__ uint32_t ldr_slot(uint32_t w, uint32_t i)
-{
-    return i < (uint32_t)MC_LDR_NLB ? 8u * i + w : 8u * MC_LDR_NLB + 4u * (i - MC_LDR_NLB) + w;
-}
+constexpr uint32_t LDR_PW = 7;                      // pairs per wave of the w1|w3 phase (the host: 56 per workgroup)
+constexpr uint32_t LDR_NLP = 8u * MC_LDR_NL;        // pairs in the LDS image
+constexpr uint32_t LDR_NS = LDR_PW - MC_LDR_NL;     // pairs per wave streamed into registers behind hand-off D
+static_assert(MC_LDR_NL >= 1 && MC_LDR_NL <= 7 && LDR_NS <= 3, "at most three streamed pairs per wave (48 registers)");
+// The deal of the w1|w3 phase: wave w multiplies pairs 56 wg + 7 w .. + 6 -- an EVEN deal, not gemv.h lin_deal's (8, 6): that one evens out the
+// two waves of a SIMD when the first of them arrives 2 us before the second (a launch's ramp); here both have been resident for 14 us.  Who
+// multiplies a pair does not change a bit of it.  Image slot of pair i of wave w: round robin over the waves, every wave's first pair first.
+__device__ __forceinline__ uint32_t ldr_slot(uint32_t w, uint32_t i) { return 8u * i + w; }
 // stamps (tl2 != null: tools/attn_w13_timeline.py), per workgroup, s_memrealtime:
-//   0 loader behind barrier 1   1 .. 28 pair n - 1 requested   30 everything landed   31 loader done
-//   32 Wo done (thread 0)   33 hand-off D: row gathered   34 row staged   35 first two streamed pairs multiplied   36 LDS pairs multiplied   37 stored
-constexpr int TL2_STRIDE = 40;
+//   0 loader behind barrier 1   1 .. 32 pair n - 1 requested   33 everything landed   34 loader done
+//   40 Wo done (thread 0)   41 hand-off D: row gathered   42 row staged   43 LDS pairs multiplied   44 streamed pairs multiplied, stored
+constexpr int TL2_STRIDE = 48;
 
 template <int HD, int LNCH, int QN>
 __device__ __forceinline__ void
@@ -1279,7 +1280,7 @@ attn_qkv_wo_w13_body(const bf16_t* kc, const bf16_t* vt, bf16_t* attn_out, unsig
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t note_w = lds_off(&ldr_words[0]);
     unsigned long long* mytl = tl2 ? tl2 + (size_t)blockIdx.x * TL2_STRIDE : nullptr;
-    const uint32_t NP = ffn_rows / 2;
+    const uint32_t pb_wg = blockIdx.x * (8u * LDR_PW); // (the host: ffn_rows == 2 * 56 * gridDim.x)
     typedef const void __attribute__((address_space(1))) gvoid_t;
     typedef __attribute__((address_space(3))) void lds_void_t;
 
@@ -1293,14 +1294,10 @@ attn_qkv_wo_w13_body(const bf16_t* kc, const bf16_t* vt, bf16_t* attn_out, unsig
         const uint32_t kv_len = (uint32_t)stp[2], split = blockIdx.x / KV;
         const bool active = split * 64u < kv_len;
         uint32_t n = 0, next = 2, spins = 0;
+        const char* src0 = static_cast<const char*>(w13_w) + (size_t)pb_wg * (2u * ROWB) + lane * 16u;
         auto request = [&](uint32_t n_) {
-            uint32_t w, i;
-            if (n_ < 8u * MC_LDR_NLB) { i = n_ >> 3; w = n_ & 7u; }
-            else { i = MC_LDR_NLB + ((n_ - 8u * MC_LDR_NLB) >> 2); w = (n_ - 8u * MC_LDR_NLB) & 3u; }
-            uint32_t pb, pe;
-            lin_deal<8>(NP, w, 8u, pb, pe);
-            const uint32_t pr = min(pb + i, NP - 1u); // (a wave with fewer pairs than the image gives it: the consumers never read the slot)
-            const char* src = static_cast<const char*>(w13_w) + (size_t)pr * (2u * ROWB) + lane * 16u;
+            // image slot n_ = pair n_ / 8 of wave n_ % 8 = pair 7 (n_ % 8) + n_ / 8 of the workgroup
+            const char* src = src0 + (size_t)(LDR_PW * (n_ & 7u) + (n_ >> 3)) * (2u * ROWB);
 #pragma unroll
             for (int t = 0; t < 4; t++)
                 __builtin_amdgcn_global_load_lds((gvoid_t*)(src + t * 1024), (lds_void_t*)(ring + n_ * 4096u + t * 1024u), 16, 0, 2 /* nt */);
@@ -1315,7 +1312,11 @@ attn_qkv_wo_w13_body(const bf16_t* kc, const bf16_t* vt, bf16_t* attn_out, unsig
                 if (!active && next == 5u) next = 7u;
                 continue;
             }
-            if (n < LDR_NLP && next > (uint32_t)MC_LDR_START) request(n++);
+            if (next > (uint32_t)MC_LDR_START) {
+#pragma unroll
+                for (int b = 0; b < MC_LDR_BURST; b++)
+                    if (n < LDR_NLP) request(n++);
+            }
             __builtin_amdgcn_s_sleep(MC_LDR_PACE);
             spins++;
         }
@@ -1324,11 +1325,11 @@ attn_qkv_wo_w13_body(const bf16_t* kc, const bf16_t* vt, bf16_t* attn_out, unsig
             __builtin_amdgcn_s_sleep(MC_LDR_TAIL_PACE);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (mytl && lane == 0) mytl[30] = __builtin_amdgcn_s_memrealtime();
+        if (mytl && lane == 0) mytl[33] = __builtin_amdgcn_s_memrealtime();
         asm volatile("s_barrier" ::: "memory"); // barrier 8: the image is in LDS for the eight waves
         asm volatile("s_barrier" ::: "memory"); // barrier 9: the row is staged
         if (mytl && lane == 0) {
-            mytl[31] = __builtin_amdgcn_s_memrealtime();
+            mytl[34] = __builtin_amdgcn_s_memrealtime();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         return;
@@ -1340,49 +1341,38 @@ attn_qkv_wo_w13_body(const bf16_t* kc, const bf16_t* vt, bf16_t* attn_out, unsig
     auto stamp2 = [&](int i) {
         if (mytl && tid == 0) mytl[i] = __builtin_amdgcn_s_memrealtime();
     };
-    stamp2(32);
+    stamp2(40);
     // ================= ... and ffn_norm + w1|w3 + SiLU * mul
     typedef uint32_t rowv4 __attribute__((ext_vector_type(4)));
-    uint32_t pb, pe;
-    lin_deal<8>(NP, wave, 8u, pb, pe);
-    const uint32_t cnt = pe - pb;                                                  // pairs of this wave (the host: at most 8)
-    const uint32_t nl = min(wave < 4 ? (uint32_t)MC_LDR_NLA : (uint32_t)MC_LDR_NLB, cnt); // ... of them in the LDS image: pairs pb .. pb + nl - 1
-    const uint32_t ps = pb + nl;                                                   // ... the rest streamed: ps .. pe - 1 (the host: at most 4)
+    const uint32_t pb = pb_wg + LDR_PW * wave; // pairs pb .. pb + 6: the first MC_LDR_NL in the LDS image, the rest streamed
+    const uint32_t ps = pb + MC_LDR_NL;
     const uint32_t glog = ffn_group ? 31u - __builtin_clz(ffn_group) : 31u, ngroups = ffn_group ? KF >> glog : 1u;
     const char* wbase = static_cast<const char*>(w13_w);
     const char* sbase = static_cast<const char*>(w13_s);
-    // (every load unconditional: masks, not selects -- gemv.h ltile.  A pair the wave does not have reads one broadcast line)
-    auto req_pair = [&](uint4 (&dst)[4], uint32_t pr, bool live) {
-        const uint32_t lm = 0u - (uint32_t)live;
-        const uint64_t lm64 = ((uint64_t)lm << 32) | lm;
-        const char* a = wbase + (((uint64_t)pr * (2u * ROWB)) & lm64) + ((lane * 16u) & lm);
+    auto req_pair = [&](uint4 (&dst)[4], uint32_t pr) {
+        const char* a = wbase + (uint64_t)pr * (2u * ROWB) + lane * 16u;
 #pragma unroll
         for (int t = 0; t < 4; t++) {
-            const rowv4 v = __builtin_nontemporal_load(reinterpret_cast<const rowv4*>(a + ((t * 1024u) & lm)));
+            const rowv4 v = __builtin_nontemporal_load(reinterpret_cast<const rowv4*>(a + t * 1024u));
             dst[t] = make_uint4(v.x, v.y, v.z, v.w);
         }
     };
     // scales of pair pr: half a row quad ([ngroups][4] bf16 per four rows) per chunk; the lane's 32 weights of chunk c sit in group (2048 c + 32 lane) / group
-    auto req_scales = [&](uint32_t (&q)[FN], uint32_t pr, bool live) {
-        const uint64_t ub = (((uint64_t)(pr >> 1) * ngroups) * 4 + (pr & 1u) * 2) * 2;
-        const uint32_t lm = 0u - (uint32_t)live;
-        const char* a = sbase + (ub & (((uint64_t)lm << 32) | lm));
+    auto req_scales = [&](uint32_t (&q)[FN], uint32_t pr) {
+        const char* a = sbase + (((uint64_t)(pr >> 1) * ngroups) * 4 + (pr & 1u) * 2) * 2;
 #pragma unroll
         for (int c = 0; c < (int)FN; c++) {
             const uint32_t g = ffn_group ? ((2048u * (uint32_t)c + 32u * lane) >> glog) : 0u;
-            q[c] = *reinterpret_cast<const uint32_t*>(a + ((g * 8u) & lm));
+            q[c] = *reinterpret_cast<const uint32_t*>(a + g * 8u);
         }
     };
-    // ---- in front of the wait: the norm weights, every pair's scales, the first two streamed pairs (8 KiB per wave in registers)
+    // ---- in front of the wait: the norm weights and every pair's scales (a few hundred bytes per wave: the polls of hand-off D return behind
+    // them -- a wave's vector-memory results return in issue order -- so the 12 KiB of the streamed pairs are NOT requested here: the first
+    // build did, and the row was seen 4.1 us after the last Wo store instead of ~ 3)
     const rowv4 nr = reinterpret_cast<const rowv4*>(ffn_norm)[tid];
-    uint32_t scl[MC_LDR_NLA][FN], scs[4][FN];
+    uint32_t scl[LDR_PW][FN];
 #pragma unroll
-    for (int i = 0; i < MC_LDR_NLA; i++) req_scales(scl[i], pb + i, (uint32_t)i < nl);
-#pragma unroll
-    for (int i = 0; i < 4; i++) req_scales(scs[i], ps + i, ps + i < pe);
-    uint4 sr[2][4];
-    req_pair(sr[0], ps, ps < pe);
-    req_pair(sr[1], ps + 1, ps + 1 < pe);
+    for (int i = 0; i < (int)LDR_PW; i++) req_scales(scl[i], pb + i);
     // ---- hand-off D: the hidden row the Wo phases of ALL workgroups finished; thread t gathers packet t = granules 4 t .. 4 t + 3
     // (one watched granule and ~ 0.4 us between looks while the row is not there, then one sweep: hand-off C)
     const uint32_t epoch_tag = st->epoch * 256u + layer_tag;
@@ -1407,7 +1397,11 @@ attn_qkv_wo_w13_body(const bf16_t* kc, const bf16_t* vt, bf16_t* attn_out, unsig
         }
         xr = rowv4{val[0], val[1], val[2], val[3]};
     }
-    stamp2(33);
+    stamp2(41);
+    // ---- the streamed pairs: requested now, multiplied last -- the LDS pairs' multiplications (~ 3.6 us) cover their way in
+    uint4 sr[LDR_NS ? LDR_NS : 1][4];
+#pragma unroll
+    for (int i = 0; i < (int)LDR_NS; i++) req_pair(sr[i], ps + i);
     // ---- ffn_norm on the way into LDS (kernel/rmsnorm.metal:52-95; gemv.h, the build-time prologue: the same additions in the same order)
     {
         const uint32_t vv[4] = {xr.x, xr.y, xr.z, xr.w};
@@ -1438,7 +1432,7 @@ attn_qkv_wo_w13_body(const bf16_t* kc, const bf16_t* vt, bf16_t* attn_out, unsig
         reinterpret_cast<rowv4*>(xs13)[tid + (tid >> 4)] = rowv4{o[0], o[1], o[2], o[3]}; // (packet p sits in slot p + p / 16)
     }
     lds_barrier(); // barrier 9
-    stamp2(34);
+    stamp2(42);
     // ---- the row's transposed gather (gemv.h Q_M4D), once per wave
     const uint32_t lane_tr = (((lane >> 4) * 4 + (lane & 3)) * 17 + ((lane >> 2) & 3) * 4) * 16;
     const m4b_lane m4bk = m4b_lane_consts(lane);
@@ -1471,35 +1465,27 @@ attn_qkv_wo_w13_body(const bf16_t* kc, const bf16_t* vt, bf16_t* attn_out, unsig
             my_b = rs[1];
         }
     };
-    // ---- the first two streamed pairs from registers; their slots take the last two
-    if (ps < pe) pair_sums(sr[0], scs[0], nl);           // (wave-uniform; no load inside)
-    req_pair(sr[0], ps + 2, ps + 2 < pe);
-    if (ps + 1 < pe) pair_sums(sr[1], scs[1], nl + 1u);
-    req_pair(sr[1], ps + 3, ps + 3 < pe);
-    stamp2(35);
     // ---- the pairs that waited in LDS
     typedef const __attribute__((address_space(3))) uint4* lds_u4;
 #pragma unroll
-    for (int i = 0; i < MC_LDR_NLA; i++) {
-        if ((uint32_t)i < nl) { // (wave-uniform; LDS reads only)
-            lds_u4 src = (lds_u4)(ring + ldr_slot(wave, (uint32_t)i) * 4096u + lane * 16u);
-            uint4 tile[4];
+    for (int i = 0; i < MC_LDR_NL; i++) {
+        lds_u4 src = (lds_u4)(ring + ldr_slot(wave, (uint32_t)i) * 4096u + lane * 16u);
+        uint4 tile[4];
 #pragma unroll
-            for (int t = 0; t < 4; t++) tile[t] = src[t * 64];
-            pair_sums(tile, scl[i], (uint32_t)i);
-        }
+        for (int t = 0; t < 4; t++) tile[t] = src[t * 64];
+        pair_sums(tile, scl[i], (uint32_t)i);
     }
-    stamp2(36);
-    // ---- the last streamed pairs
-    if (ps + 2 < pe) pair_sums(sr[0], scs[2], nl + 2u);
-    if (ps + 3 < pe) pair_sums(sr[1], scs[3], nl + 3u);
+    stamp2(43);
+    // ---- the streamed pairs
+#pragma unroll
+    for (int i = 0; i < (int)LDR_NS; i++) pair_sums(sr[i], scl[MC_LDR_NL + i], (uint32_t)(MC_LDR_NL + i));
     // ---- the epilogue of gemv.h finish_pair (EPI_SILU_MUL), one lane per pair: out[j] = T(silu(T(w1 x)) * T(w3 x))
-    if (lane < cnt) {
+    if (lane < LDR_PW) {
         const float ga = BF::rt(my_a), gb = BF::rt(my_b);
         const float g = mc::gemv::silu_T<BF>(ga);
         gate[pb + lane] = BF::st(g * gb);
     }
-    stamp2(37);
+    stamp2(44);
 }
 
 } // namespace

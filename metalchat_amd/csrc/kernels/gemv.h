@@ -1518,7 +1518,11 @@ body(const void* __restrict__ wp, const void* __restrict__ sp, const void* __res
                     continue;
                 }
                 const u32x4* ap = reinterpret_cast<const u32x4*>(a + p * 1024 + lo);
-                const u32x4 v = __builtin_nontemporal_load(ap); // (weights are read once per token)
+#ifndef MC_LIN_PLAIN_LOADS
+#define MC_LIN_PLAIN_LOADS 0 // 1 (tools/mall_probe.py only): default-policy weight loads, which the Infinity Cache keeps -- how fast would a launch be
+                             // whose weights a background prefetcher had brought there?
+#endif
+                const u32x4 v = MC_LIN_PLAIN_LOADS ? *ap : __builtin_nontemporal_load(ap); // (weights are read once per token)
                 dst[p] = make_uint4(v.x, v.y, v.z, v.w);
             }
         };

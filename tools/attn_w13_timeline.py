@@ -5,8 +5,8 @@ matrices of a synthetic decoder of L layers (L x 92 MB of weights: more than the
 layer tags; s_memrealtime stamps (100 MHz) of every workgroup:
   block (tl, thread 0):   0 start  1 row staged  2 wq|wk|wv pairs published  11 hand-off Q  4 scores  5 hand-off A  6 P.V  7 partials published
                           8 hand-off B + reduce  9 hand-off C, attention row staged  10 Wo pairs stored
-  chain (tl2):            0 loader behind barrier 1   1 .. 28 pair n - 1 requested   30 everything landed   31 loader done
-                          32 Wo done  33 hand-off D: hidden row gathered  34 row staged  35 two streamed pairs multiplied  36 LDS pairs multiplied  37 stored
+  chain (tl2):            0 loader behind barrier 1   1 .. 32 pair n - 1 requested   33 everything landed   34 loader done
+                          40 Wo done  41 hand-off D: hidden row gathered  42 row staged  43 LDS pairs multiplied  44 streamed pairs multiplied, stored
 usage: attn_w13_timeline.py [launches=32] [layers=8]     (MC_HSACO: a tuning build of the code object)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -45,7 +45,8 @@ hid_g = acc.to_device(np.zeros(dim // 2, np.uint64))
 qkv_g = acc.to_device(np.zeros(2 * (H + 2 * KV) * hd // 2, np.uint64))
 gate = acc.alloc(ffn * 2)
 tl = acc.alloc(N * WGS * 16 * 8)
-tl2 = acc.alloc(N * WGS * 40 * 8)
+TL2 = 48
+tl2 = acc.alloc(N * WGS * TL2 * 8)
 k_chain = acc.load("mc_attn_qkv_wo_w13_i4_bfloat_hd128_k2_q2_f2")
 k_block = acc.load("mc_attn_qkv_wo_i4_bfloat_hd128_k2_q2")
 k_w13 = acc.load("mc_gemv_i4_bfloat_lin2_p1_e2")
@@ -69,7 +70,7 @@ def run(form, stamps):
         l = i % L
         tlp = acc.wrap(tl.device_ptr + i * WGS * 128, WGS * 128) if stamps else None
         if form == "chain":
-            t2 = acc.wrap(tl2.device_ptr + i * WGS * 320, WGS * 320) if stamps else None
+            t2 = acc.wrap(tl2.device_ptr + i * WGS * TL2 * 8, WGS * TL2 * 8) if stamps else None
             mc.KernelTask(k_chain, (WGS * 576, 1, 1), (576, 1, 1),
                           block_args(i, tlp) + [hid_g, W(w13[l][0]), W(w13[l][1]), norm_w, gate, np.uint32(2 * ffn), np.uint32(128), t2])()
         else:
@@ -92,11 +93,11 @@ for epoch in range(1, 9):
     if stamps:
         tl.upload(np.zeros(N * WGS * 16, np.uint64))
         if form == "chain":
-            tl2.upload(np.zeros(N * WGS * 40, np.uint64))
+            tl2.upload(np.zeros(N * WGS * TL2, np.uint64))
     us = run(form, stamps)
     if stamps and form == "chain":
         t = tl.download(np.uint64, N * WGS * 16).reshape(N, WGS, 16).astype(np.int64)
-        t2 = tl2.download(np.uint64, N * WGS * 40).reshape(N, WGS, 40).astype(np.int64)
+        t2 = tl2.download(np.uint64, N * WGS * TL2).reshape(N, WGS, TL2).astype(np.int64)
     if stamps and form == "two":
         tb = tl.download(np.uint64, N * WGS * 16).reshape(N, WGS, 16).astype(np.int64)
     g = gate.download(np.uint16, ffn)
@@ -129,17 +130,16 @@ for i in (1, N // 2, N - 1):
         return f"min {d.min():6.2f} median {np.median(d):6.2f} max {d.max():6.2f}"
     print(f" launch {i}:")
     print(f"   loader behind barrier 1        {col(t2, 0)}")
-    for n in (1, 8, 16, 24, 28):
+    for n in (1, 8, 16, 24, 32):
         print(f"   pair {n - 1:2d} requested ({n * 4:3d} KiB)   {col(t2, n)}")
-    print(f"   image landed (112 KiB)          {col(t2, 30)}")
-    print(f"   Wo pairs stored                 {col(t2, 32)}")
-    print(f"   hand-off D: row gathered        {col(t2, 33)}")
-    print(f"   row normalised and staged       {col(t2, 34)}")
-    print(f"   first two streamed pairs done   {col(t2, 35)}")
-    print(f"   LDS pairs done                  {col(t2, 36)}")
-    print(f"   all stored                      {col(t2, 37)}")
+    print(f"   image landed (128 KiB)          {col(t2, 33)}")
+    print(f"   Wo pairs stored                 {col(t2, 40)}")
+    print(f"   hand-off D: row gathered        {col(t2, 41)}")
+    print(f"   row normalised and staged       {col(t2, 42)}")
+    print(f"   LDS pairs done                  {col(t2, 43)}")
+    print(f"   streamed pairs done, stored     {col(t2, 44)}")
     # bytes requested by the loaders over time: a histogram in 1 us bins (chip-wide MB)
-    req = ((t2[i, :, 1:29] - s0) / 100.0).ravel()
+    req = ((t2[i, :, 1:33] - s0) / 100.0).ravel()
     hist, _ = np.histogram(req, bins=np.arange(0, 26, 1.0))
     print("   loader requests per us (MB, chip-wide): " + " ".join(f"{x * 4096 / 1e6:4.1f}" for x in hist))
 dec.release()
