@@ -717,7 +717,7 @@ struct mc_decoder {
         occ_qkv_qkn = hd == 256 ? ask("mc_attn_qkv_wo_qkn_i4_bfloat_hd256_k2_p2_t2", 512) : 0;
         occ_qkv_only = hd == 128 ? ask("mc_attn_qkv_i4_bfloat_hd128_q4", 512) : 0;
         occ_wo_i4_wide = hd == 128 ? ask("mc_attn_qkv_wo_i4_bfloat_hd128_k2_q2_t4", 512) : 0;
-        occ_w13 = hd == 128 ? ask("mc_attn_qkv_wo_w13_i4_bfloat_hd128_k2_q2_f2", 576) : 0;
+        occ_w13 = hd == 128 ? ask("mc_attn_qkv_wo_w13_i4_bfloat_hd128_k2_q2_f2", 512) : 0;
         (void)hipGetLastError();
     }
     // a hand-off gave up: report nothing yet, make the NEXT launches independent of co-residency
@@ -812,8 +812,8 @@ struct mc_decoder {
                L.qkv.out == (cfg.n_heads + 2 * cfg.n_kv_heads) * hd && pg >= 64 && pg <= 512;
     }
 
-    // ... AND ffn_norm + w1|w3 + act*mul as the next phase of that launch (round 6, mc_attn_qkv_wo_w13_i4_bfloat_hd128_k2_q2_f2, attn_block_kernels.hip): a ninth
-    // wave of every workgroup brings 32 of the workgroup's w1|w3 row pairs into LDS while the eight wait through the attention's hand-offs.  The built
+    // ... AND ffn_norm + w1|w3 + act*mul as the next phase of that launch (round 6, mc_attn_qkv_wo_w13_i4_bfloat_hd128_k2_q2_f2, attn_block_kernels.hip): behind
+    // the Wo phase half the waves of every workgroup fetch their w1|w3 row pairs into registers while the other half waits for the hidden row.  The built
     // shape only: dim 4096, exactly one workgroup per CU and 56 pairs of 2 KiB rows per workgroup (7 per wave), llama blocks, no adaptor
     bool
     attn_qkv_wo_w13_ok(const layer_w& L) const
@@ -1143,8 +1143,8 @@ struct mc_decoder {
             int qkn_wo = 0;
             const bool chain13 = i4_in && attn_qkv_wo_w13_ok(L);
             if (chain13) {
-                // ... and ffn_norm, w1|w3, act*mul (transformer.h:135-137, 53-59) too: the block up to the gate row in ONE launch of eight waves + a loader
-                s = launch("mc_attn_qkv_wo_w13_i4_" + tname + "_hd128_k2_q2_f2", (unsigned)(nsplit * KV), 1, 1, 576, 0,
+                // ... and ffn_norm, w1|w3, act*mul (transformer.h:135-137, 53-59) too: the block up to the gate row in ONE launch
+                s = launch("mc_attn_qkv_wo_w13_i4_" + tname + "_hd128_k2_q2_f2", (unsigned)(nsplit * KV), 1, 1, 512, 0,
                            pack((const void*)L.kc, (const void*)L.vt, attn_out, attn_psum_g, attn_slab_g, attn_row_g, attn_qkv_g, state,
                                 (uint32_t)n_rep, (uint32_t)KV, (uint32_t)cfg.max_seq_len, scale_T, (uint32_t)nsplit, (uint32_t)(li + 1),
                                 (const void*)L.wo.w, (const void*)L.wo.scales, x, hidden, (uint32_t)L.wo.out, (uint32_t)L.wo.group,

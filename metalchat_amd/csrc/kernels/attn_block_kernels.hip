@@ -1203,64 +1203,63 @@ MC_ATTN_WO(mc_attn_wo_i4_bfloat_hd64_k1, 64, 1)    // 32 heads x 64
 MC_ATTN_WO(mc_attn_wo_i4_bfloat_hd256_k2, 256, 2)  // Gemma-7B shapes: 16 heads x 256
 
 // ------------------------------------------------------------------------------------------
-// Round 6: the attention block AND ffn_norm + w1|w3 + SiLU * mul (include/metalchat/nn/transformer.h:130-137, 53-59) in one launch, with a
-// RUN-AHEAD LOADER: mc_attn_qkv_wo_w13_i4_bfloat_hd128_k2_q2_f2.
+// Round 6: the attention block AND ffn_norm + w1|w3 + SiLU * mul (include/metalchat/nn/transformer.h:130-137, 53-59) in one launch:
+// mc_attn_qkv_wo_w13_i4_bfloat_hd128_k2_q2_f2.
 //
-// Why: the attention block lasts ~ 14 us for 30 MB -- four group synchronisations in a row, the HBM idle two thirds of the time --
-// and the w1|w3 GEMV behind it 12.5 us for 60.6 MB: a launch boundary, a prologue and a cold stream that starts only when the row
-// is there.  The weights of w1|w3 depend on nothing.  Round 3 chained the two phases with the first 4 KiB per wave requested before
-// the row arrived and lost (tools/experiments/README.md): a chained phase gains what it has on chip BEFORE its row arrives.  Here a
-// NINTH wave of the workgroup does nothing but bring the workgroup's first NLP row pairs of w1|w3 (4 KiB each: 112 KiB of the CU's
-// 224) into a static LDS image by LDS-DMA (global_load_lds_dwordx4 nt: no registers, a vmcnt queue of its own -- the eight waves'
-// polls and tiles never wait behind it in THEIR in-order return), trickled at ~ 9 GB/s per CU from the moment the queries are out
-// until the hidden row comes back (MI355X_MICROARCH.md: ldsdma-fill, prefetch-credit, gather-pass "thin the loader while its CU
-// gathers").  When hand-off D delivers the row, 112 KiB wait in LDS and 64 KiB in the eight waves' registers (two pairs each, requested
-// in front of the wait as round 3 did); 48 KiB per CU are left to stream behind the multiplications.
+// Why: the w1|w3 GEMV behind the attention block lasts 12.5 us for 60.6 MB -- a launch boundary, a prologue and a cold stream that starts only
+// when the row is there -- and its weights depend on nothing.  Round 3 chained the two phases with 4 KiB per wave requested before the row
+// arrived and lost (tools/experiments/README.md).  Round 6 first built the verdict's form: a NINTH wave per workgroup filling an LDS image of
+// 28 - 32 row pairs by LDS-DMA while the eight wait through the attention's hand-offs, joined to the block's barriers through an LDS word
+// (git history: commits "run-ahead LDS-DMA loader wave", "Loader wave v2"; profiles/r06_chain_loader_wave_v{1,2}_*: parity green, the loader
+// ahead of the row, 750 / 712 against 808 / 815 tokens/s same box).  What its timelines showed decides this form:
+//   * trickled at ~ 2 TB/s chip-wide the loader leaves the attention's hand-offs alone but has 64 KiB per CU when Wo is done; at 5 TB/s the
+//     image is complete in time and hand-offs B and C take 1 - 3 us longer (the price sits in the polling CU's own memory queue);
+//   * hand-off D -- the hidden row from 2048 Wo pairs on 256 CUs to every CU -- takes ~ 4 us after the LAST Wo store whatever is loaded;
+//   * with every weight on chip the eight waves need 6.6 us for the workgroup's 56 pairs: the exact dequantisation (245 issue slots per pair,
+//     two waves per SIMD) is the floor, not the stream -- so nothing has to be on chip before Wo is done: hand-off D's 4 us bring ~ 100 KiB
+//     per CU and the multiplications' 6.6 us cover the other 124.
+// So: no loader wave, no LDS image, nothing requested during the attention phases.  Behind the Wo phase waves 4-7 of every workgroup (the
+// FETCHERS) request their seven pairs -- 28 KiB per wave, into registers -- and dequantise the first of them (gemv.h m4b_dequant: everything
+// that does not need the row) while waves 0-3 (the POLLERS) wait for hand-off D, two packets of the row per thread; a wave's vector-memory
+// results return in issue order, so the pollers request THEIR pairs only when the row is in and multiply them as they arrive.
 //
-// The loader and the barriers: s_barrier counts every live wave of the workgroup, so the loader JOINS each of the block's barriers.
-// It learns that a wave has reached barrier k from an LDS word (qkv_in_launch NOTE; tools/ldr_lab.hip: joined <= 0.04 us after the first
-// arrival, the eight waves' phases unchanged) and issues one pair per look in between; behind the last barrier of the Wo phase it
-// issues what is left, waits for everything to land (s_waitcnt vmcnt(0)), joins the two barriers of the w1|w3 prologue -- the first
-// of them is what makes the image visible to the eight waves -- and ends: a wave that has terminated no longer counts.
-//
-// Numerics: bit for bit the two launches it replaces.  The attention block is the same code (attn_wo_body, CH = 1: its Wo epilogue
-// also publishes the pair as a granule).  The w1|w3 phase is mc_gemv_i4_bfloat_lin2_p1_e2's arithmetic: thread t holds packet t of the
-// hidden row (granules 4 t .. 4 t + 3), per-thread sum of squares, wave_sum_dpp, the eight wave sums in wave order, the normalised
-// row staged in the padded order; a pair = tiles (row 0 chunk 0, row 0 chunk 1, row 1 chunk 0, row 1 chunk 1) through mac4b_n<1>
-// into one accumulator per row, the lane's own element, one wave sum times 2^37, the epilogue of gemv.h finish_pair (EPI_SILU_MUL).  An
-// LDS-DMA deposits lane l's 16 bytes of a 1 KiB tile at byte 16 l of its slot, so ds_read_b128 at 16 l returns exactly the
-// registers global_load_dwordx4 would have filled.  Which wave multiplies a pair, and from where, does not change a bit of it.
+// Numerics: bit for bit the two launches it replaces.  The attention block is the same code (attn_wo_body, CH = 1: its Wo epilogue also
+// publishes the pair as a granule).  The w1|w3 phase is mc_gemv_i4_bfloat_lin2_p1_e2's arithmetic: packet p's sum of squares formed by one
+// thread, the sums of packets 64 v .. 64 v + 63 added by wave_sum_dpp in lane order (v = 0 .. 7: the stand-alone kernel's eight waves), the
+// eight sums in order, the normalised row staged in the padded order; a pair = tiles (row 0 chunk 0, row 0 chunk 1, row 1 chunk 0, row 1
+// chunk 1) through mac4b_n<1> (m4b_dequant + m4b_dot: the same instructions) into one accumulator per row, the lane's own element, one
+// wave sum times 2^37, the epilogue of gemv.h finish_pair (EPI_SILU_MUL).  Which wave multiplies a pair does not change a bit of it.
 // ------------------------------------------------------------------------------------------
 namespace {
 
-#ifndef MC_LDR_NL
-#define MC_LDR_NL 4 // pairs of every wave (7 of w1|w3's 56 per workgroup) that wait in LDS: 32 x 4 KiB = 128 KiB of the CU's 224
+#ifndef MC_W13_PREDEQ
+#define MC_W13_PREDEQ 1 // the fetchers dequantise their first pair while the pollers wait for hand-off D (64 registers)
 #endif
-#ifndef MC_LDR_START
-#define MC_LDR_START 4 // the loader's first request goes out behind this barrier of the block (4: hand-off Q done, the queries are out;
-                       // the wq|wk|wv phase in front of it is HBM-bound by itself)
-#endif
-#ifndef MC_LDR_PACE
-#define MC_LDR_PACE 2 // x 64 cycles between two looks of the loader (MC_LDR_BURST pairs per look)
-#endif
-#ifndef MC_LDR_BURST
-#define MC_LDR_BURST 1 // pairs (4 KiB each) requested per look
-#endif
-#ifndef MC_LDR_TAIL_PACE
-#define MC_LDR_TAIL_PACE 1 // ... behind the last barrier of the Wo phase (the row is on its way: nothing of this CU polls HBM-side data but hand-off D)
-#endif
-constexpr uint32_t LDR_PW = 7;                      // pairs per wave of the w1|w3 phase (the host: 56 per workgroup)
-constexpr uint32_t LDR_NLP = 8u * MC_LDR_NL;        // pairs in the LDS image
-constexpr uint32_t LDR_NS = LDR_PW - MC_LDR_NL;     // pairs per wave streamed into registers behind hand-off D
-static_assert(MC_LDR_NL >= 1 && MC_LDR_NL <= 7 && LDR_NS <= 3, "at most three streamed pairs per wave (48 registers)");
-// The deal of the w1|w3 phase: wave w multiplies pairs 56 wg + 7 w .. + 6 -- an EVEN deal, not gemv.h lin_deal's (8, 6): that one evens out the
-// two waves of a SIMD when the first of them arrives 2 us before the second (a launch's ramp); here both have been resident for 14 us.  Who
-// multiplies a pair does not change a bit of it.  Image slot of pair i of wave w: round robin over the waves, every wave's first pair first.
-__device__ __forceinline__ uint32_t ldr_slot(uint32_t w, uint32_t i) { return 8u * i + w; }
+constexpr uint32_t W13_PW = 7; // pairs per wave of the w1|w3 phase (the host: 56 per workgroup) -- an EVEN deal, not gemv.h lin_deal's (8, 6):
+                               // that one evens out the two waves of a SIMD when the first arrives 2 us before the second (a launch's ramp)
 // stamps (tl2 != null: tools/attn_w13_timeline.py), per workgroup, s_memrealtime:
-//   0 loader behind barrier 1   1 .. 32 pair n - 1 requested   33 everything landed   34 loader done
-//   40 Wo done (thread 0)   41 hand-off D: row gathered   42 row staged   43 LDS pairs multiplied   44 streamed pairs multiplied, stored
+//   40 Wo done (thread 0)   41 hand-off D: row gathered (thread 0)   42 row staged   43 a fetcher's (wave 4) last pair landed   44 wave 0 stored   45 wave 4 stored
 constexpr int TL2_STRIDE = 48;
+
+typedef uint32_t w13_v4 __attribute__((ext_vector_type(4)));
+// Loads the compiler does not count (its own counted waits stay exact for ITS loads; these are waited for by hand, below)
+__device__ __forceinline__ void w13_load16(w13_v4& dst, const void* p)
+{
+    asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(dst) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void w13_load4(uint32_t& dst, const void* p)
+{
+    asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+}
+// everything but the N youngest vector-memory operations of this wave has completed; the values pass THROUGH the wait, so no use of them can be scheduled in front of it
+template <int N> __device__ __forceinline__ void w13_wait(w13_v4& a, w13_v4& b, w13_v4& c, w13_v4& d)
+{
+    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N) : "memory");
+}
+template <int N> __device__ __forceinline__ void w13_wait(uint32_t& a)
+{
+    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(a) : "n"(N) : "memory");
+}
 
 template <int HD, int LNCH, int QN>
 __device__ __forceinline__ void
@@ -1271,171 +1270,140 @@ attn_qkv_wo_w13_body(const bf16_t* kc, const bf16_t* vt, bf16_t* attn_out, unsig
                      unsigned long long* tl, unsigned long long* hid_g, const void* __restrict__ w13_w, const void* __restrict__ w13_s,
                      const void* __restrict__ ffn_norm, bf16_t* __restrict__ gate, uint32_t ffn_rows, uint32_t ffn_group, unsigned long long* tl2)
 {
-    static_assert(QN == 2 && LNCH == 2, "dim 4096: rows of 2 KiB for wq|wk|wv and w1|w3, one packet of the hidden row per thread");
+    static_assert(QN == 2 && LNCH == 2, "dim 4096: rows of 2 KiB for wq|wk|wv and w1|w3");
     constexpr uint32_t CHUNK_LDS = 2048 * 2 / 16 * 17, ROWB = 2048u, FN = 2, KF = 4096u;
-    __shared__ __attribute__((aligned(16))) char ring[LDR_NLP * 4096u];
+    constexpr int PW = (int)W13_PW;
     __shared__ __attribute__((aligned(16))) char xs13[FN * CHUNK_LDS];
     __shared__ float red13[16];
-    __shared__ uint32_t ldr_words[4];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t note_w = lds_off(&ldr_words[0]);
     unsigned long long* mytl = tl2 ? tl2 + (size_t)blockIdx.x * TL2_STRIDE : nullptr;
-    const uint32_t pb_wg = blockIdx.x * (8u * LDR_PW); // (the host: ffn_rows == 2 * 56 * gridDim.x)
-    typedef const void __attribute__((address_space(1))) gvoid_t;
-    typedef __attribute__((address_space(3))) void lds_void_t;
 
-    if (wave == 8) {
-        // ================= the loader
-        if (lane == 0) lds_poke(note_w, 0u);
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // barrier 1 (qkv_in_launch at_start): unconditional
-        if (mytl && lane == 0) mytl[0] = __builtin_amdgcn_s_memrealtime();
-        // the barriers of this workgroup: 2, 3 (rmsnorm, row staged), 4 (hand-off Q), 5, 6 (scores, hand-off A: ranges below kv_len only), 7 (hand-off C)
-        const __attribute__((address_space(1))) int32_t* stp = (const __attribute__((address_space(1))) int32_t*)st;
-        const uint32_t kv_len = (uint32_t)stp[2], split = blockIdx.x / KV;
-        const bool active = split * 64u < kv_len;
-        uint32_t n = 0, next = 2, spins = 0;
-        const char* src0 = static_cast<const char*>(w13_w) + (size_t)pb_wg * (2u * ROWB) + lane * 16u;
-        auto request = [&](uint32_t n_) {
-            // image slot n_ = pair n_ / 8 of wave n_ % 8 = pair 7 (n_ % 8) + n_ / 8 of the workgroup
-            const char* src = src0 + (size_t)(LDR_PW * (n_ & 7u) + (n_ >> 3)) * (2u * ROWB);
-#pragma unroll
-            for (int t = 0; t < 4; t++)
-                __builtin_amdgcn_global_load_lds((gvoid_t*)(src + t * 1024), (lds_void_t*)(ring + n_ * 4096u + t * 1024u), 16, 0, 2 /* nt */);
-            if (mytl && lane == 0) mytl[1 + n_] = __builtin_amdgcn_s_memrealtime();
-        };
-        // (bounded like every wait of the launch: 2^22 looks of >= 0.1 us; a workgroup that never reaches its barriers has hung already)
-        while (next <= 7u && spins < (1u << 22)) {
-            const uint32_t f = __builtin_amdgcn_readfirstlane(lds_peek(note_w));
-            if (f >= next) {
-                asm volatile("s_barrier" ::: "memory");
-                next++;
-                if (!active && next == 5u) next = 7u;
-                continue;
-            }
-            if (next > (uint32_t)MC_LDR_START) {
-#pragma unroll
-                for (int b = 0; b < MC_LDR_BURST; b++)
-                    if (n < LDR_NLP) request(n++);
-            }
-            __builtin_amdgcn_s_sleep(MC_LDR_PACE);
-            spins++;
-        }
-        while (n < LDR_NLP) {
-            request(n++);
-            __builtin_amdgcn_s_sleep(MC_LDR_TAIL_PACE);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (mytl && lane == 0) mytl[33] = __builtin_amdgcn_s_memrealtime();
-        asm volatile("s_barrier" ::: "memory"); // barrier 8: the image is in LDS for the eight waves
-        asm volatile("s_barrier" ::: "memory"); // barrier 9: the row is staged
-        if (mytl && lane == 0) {
-            mytl[34] = __builtin_amdgcn_s_memrealtime();
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        return;
-    }
-
-    // ================= the eight waves: the attention block ...
+    // ================= the attention block ...
     attn_wo_body<HD, LNCH, QN, 0, 1, 0, 1>(nullptr, kc, vt, attn_out, psum_g, slab_g, row_g, st, n_rep, KV, max_seq, scale, nsplit, layer_tag, wo_w, wo_s, x, y,
-                                           out_rows, group, 1u, fastpath, tl, qnorm_w, qkv_w, qkv_s, fcos, fsin, qkv_g, eps, mu, 0u, gemma_extra(), hid_g, note_w);
-    auto stamp2 = [&](int i) {
-        if (mytl && tid == 0) mytl[i] = __builtin_amdgcn_s_memrealtime();
+                                           out_rows, group, 1u, fastpath, tl, qnorm_w, qkv_w, qkv_s, fcos, fsin, qkv_g, eps, mu, 0u, gemma_extra(), hid_g);
+    auto stamp2 = [&](int i, uint32_t t) {
+        if (mytl && tid == t) mytl[i] = __builtin_amdgcn_s_memrealtime();
     };
-    stamp2(40);
+    stamp2(40, 0);
     // ================= ... and ffn_norm + w1|w3 + SiLU * mul
-    typedef uint32_t rowv4 __attribute__((ext_vector_type(4)));
-    const uint32_t pb = pb_wg + LDR_PW * wave; // pairs pb .. pb + 6: the first MC_LDR_NL in the LDS image, the rest streamed
-    const uint32_t ps = pb + MC_LDR_NL;
+    const bool poller = wave < 4u;
+    const uint32_t pb = blockIdx.x * (8u * W13_PW) + W13_PW * wave; // pairs pb .. pb + 6 (the host: ffn_rows == 2 * 56 * gridDim.x)
     const uint32_t glog = ffn_group ? 31u - __builtin_clz(ffn_group) : 31u, ngroups = ffn_group ? KF >> glog : 1u;
-    const char* wbase = static_cast<const char*>(w13_w);
-    const char* sbase = static_cast<const char*>(w13_s);
-    auto req_pair = [&](uint4 (&dst)[4], uint32_t pr) {
-        const char* a = wbase + (uint64_t)pr * (2u * ROWB) + lane * 16u;
-#pragma unroll
-        for (int t = 0; t < 4; t++) {
-            const rowv4 v = __builtin_nontemporal_load(reinterpret_cast<const rowv4*>(a + t * 1024u));
-            dst[t] = make_uint4(v.x, v.y, v.z, v.w);
-        }
-    };
-    // scales of pair pr: half a row quad ([ngroups][4] bf16 per four rows) per chunk; the lane's 32 weights of chunk c sit in group (2048 c + 32 lane) / group
-    auto req_scales = [&](uint32_t (&q)[FN], uint32_t pr) {
-        const char* a = sbase + (((uint64_t)(pr >> 1) * ngroups) * 4 + (pr & 1u) * 2) * 2;
-#pragma unroll
-        for (int c = 0; c < (int)FN; c++) {
-            const uint32_t g = ffn_group ? ((2048u * (uint32_t)c + 32u * lane) >> glog) : 0u;
-            q[c] = *reinterpret_cast<const uint32_t*>(a + g * 8u);
-        }
-    };
-    // ---- in front of the wait: the norm weights and every pair's scales (a few hundred bytes per wave: the polls of hand-off D return behind
-    // them -- a wave's vector-memory results return in issue order -- so the 12 KiB of the streamed pairs are NOT requested here: the first
-    // build did, and the row was seen 4.1 us after the last Wo store instead of ~ 3)
-    const rowv4 nr = reinterpret_cast<const rowv4*>(ffn_norm)[tid];
-    uint32_t scl[LDR_PW][FN];
-#pragma unroll
-    for (int i = 0; i < (int)LDR_PW; i++) req_scales(scl[i], pb + i);
-    // ---- hand-off D: the hidden row the Wo phases of ALL workgroups finished; thread t gathers packet t = granules 4 t .. 4 t + 3
-    // (one watched granule and ~ 0.4 us between looks while the row is not there, then one sweep: hand-off C)
+    // ---- hand-off D (pollers): the hidden row the Wo phases of ALL workgroups finished; thread t < 256 gathers packets t and t + 256 =
+    // granules 4 p .. 4 p + 3 each (one watched granule and ~ 0.4 us between looks while the row is not there, then one sweep: hand-off C)
     const uint32_t epoch_tag = st->epoch * 256u + layer_tag;
-    rowv4 xr;
-    {
-        uint32_t val[4];
+    w13_v4 xr[2] = {w13_v4{0, 0, 0, 0}, w13_v4{0, 0, 0, 0}};
+    if (poller) { // (wave-uniform; every load inside is waited for inside)
+        uint32_t val[8];
         handoff_wait w;
         for (;;) {
-            const bool seen = (uint32_t)(granule_load(hid_g + 4u * tid + 3u) >> 32) == epoch_tag;
+            const bool seen = (uint32_t)(granule_load(hid_g + 4u * (tid + 256u) + 3u) >> 32) == epoch_tag;
             if (__all(seen) || w.expired(st, 0xE0000000u | layer_tag)) break;
             __builtin_amdgcn_s_sleep(MC_HANDOFF_C_SLEEP);
         }
         for (;;) {
             bool ok = true;
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const unsigned long long g = granule_load(hid_g + 4u * tid + i);
+            for (int i = 0; i < 8; i++) {
+                const unsigned long long g = granule_load(hid_g + 4u * (tid + 256u * (i >> 2)) + (i & 3));
                 ok = ok && (uint32_t)(g >> 32) == epoch_tag;
                 val[i] = (uint32_t)g;
             }
             if (__all(ok) || w.expired(st, 0xE0000000u | layer_tag)) break;
         }
-        xr = rowv4{val[0], val[1], val[2], val[3]};
+        xr[0] = w13_v4{val[0], val[1], val[2], val[3]};
+        xr[1] = w13_v4{val[4], val[5], val[6], val[7]};
     }
-    stamp2(41);
-    // ---- the streamed pairs: requested now, multiplied last -- the LDS pairs' multiplications (~ 3.6 us) cover their way in
-    uint4 sr[LDR_NS ? LDR_NS : 1][4];
+    stamp2(41, 0);
+    // ---- every wave's requests, in ONE place (the fetchers reach it ~ 4 us before the pollers): the norm weights of the packets this thread
+    // stages, the scales of its wave's pairs, the pairs.  None of it is visible to the compiler's wait counting: waited for by hand.
+    w13_v4 nr[2];
+    uint32_t scl[PW][FN];
+    w13_v4 wreg[PW][4];
+    {
+        const char* np_ = static_cast<const char*>(ffn_norm) + (size_t)(tid & 255u) * 16u;
+        w13_load16(nr[0], np_);
+        w13_load16(nr[1], np_ + 256 * 16);
+        // scales of pair pr: half a row quad ([ngroups][4] bf16 per four rows) per chunk; the lane's 32 weights of chunk c sit in group (2048 c + 32 lane) / group
 #pragma unroll
-    for (int i = 0; i < (int)LDR_NS; i++) req_pair(sr[i], ps + i);
+        for (int i = 0; i < PW; i++) {
+            const uint32_t pr = pb + (uint32_t)i;
+            const char* a = static_cast<const char*>(w13_s) + (((uint64_t)(pr >> 1) * ngroups) * 4 + (pr & 1u) * 2) * 2;
+#pragma unroll
+            for (int c = 0; c < (int)FN; c++) {
+                const uint32_t g = ffn_group ? ((2048u * (uint32_t)c + 32u * lane) >> glog) : 0u;
+                w13_load4(scl[i][c], a + g * 8u);
+            }
+        }
+        const char* wb = static_cast<const char*>(w13_w) + (uint64_t)pb * (2u * ROWB) + lane * 16u;
+#pragma unroll
+        for (int i = 0; i < PW; i++)
+#pragma unroll
+            for (int t = 0; t < 4; t++) w13_load16(wreg[i][t], wb + (size_t)i * (2u * ROWB) + t * 1024u);
+    }
+    // (issued behind this point: nothing until the epilogue's store -- the counts below are exact)
+    constexpr int NW = PW * 4; // weight loads, the youngest
+    const m4b_lane m4bk = m4b_lane_consts(lane);
+    // ---- the fetchers' first pair, dequantised while the pollers wait (the pollers dequantise theirs behind the row, as they must)
+    uint2 dq[MC_W13_PREDEQ ? 4 : 1][8];
+    if (MC_W13_PREDEQ && !poller) {
+        w13_wait<NW>(scl[0][0]);
+        w13_wait<NW>(scl[0][1]);
+        w13_wait<NW - 4>(wreg[0][0], wreg[0][1], wreg[0][2], wreg[0][3]);
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const uint32_t raw = scl[0][t & 1];
+            const w13_v4 v = wreg[0][t];
+            m4b_dequant(dq[MC_W13_PREDEQ ? t : 0], make_uint4(v.x, v.y, v.z, v.w), m4b_prepare((t >> 1) ? (raw & 0xFFFF0000u) : (raw << 16), m4bk));
+        }
+    }
     // ---- ffn_norm on the way into LDS (kernel/rmsnorm.metal:52-95; gemv.h, the build-time prologue: the same additions in the same order)
     {
-        const uint32_t vv[4] = {xr.x, xr.y, xr.z, xr.w};
-        float s1 = 0.0f;
+        float s1[2];
 #pragma unroll
-        for (int e = 0; e < 4; e++) {
-            const float a = asf(vv[e] << 16), b = asf(vv[e] & 0xFFFF0000u);
-            s1 += a * a;
-            s1 += b * b;
+        for (int q = 0; q < 2; q++) {
+            const uint32_t vv[4] = {xr[q].x, xr[q].y, xr[q].z, xr[q].w};
+            float s = 0.0f;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const float a = asf(vv[e] << 16), b = asf(vv[e] & 0xFFFF0000u);
+                s += a * a;
+                s += b * b;
+            }
+            float ss = 0.0f;
+            ss += s;
+            s1[q] = wave_sum_dpp(ss);
         }
-        float ss = 0.0f;
-        ss += s1;
-        const float wsum_ = wave_sum_dpp(ss);
-        if (lane == 0) red13[wave] = wsum_;
-        lds_barrier(); // barrier 8 (with the loader: its image has landed)
+        if (poller && lane == 0) { // the stand-alone kernel's wave v holds packets 64 v .. 64 v + 63
+            red13[wave] = s1[0];
+            red13[4u + wave] = s1[1];
+        }
+        lds_barrier();
         float tot = 0.0f;
 #pragma unroll
         for (uint32_t i = 0; i < 8u; i++) tot += red13[i];
         const float inv = 1.0f / sqrtf(tot / (float)KF + eps);
-        const uint32_t wv[4] = {nr.x, nr.y, nr.z, nr.w};
-        uint32_t o[4];
+        if (poller) {
+            w13_wait<NW + 2 * PW>(nr[0], nr[1], nr[0], nr[1]);
 #pragma unroll
-        for (int e = 0; e < 4; e++) {
-            const float a = (mu + asf(wv[e] << 16)) * asf(vv[e] << 16) * inv;
-            const float b = (mu + asf(wv[e] & 0xFFFF0000u)) * asf(vv[e] & 0xFFFF0000u) * inv;
-            o[e] = pack_bf16x2(a, b);
+            for (int q = 0; q < 2; q++) {
+                const uint32_t vv[4] = {xr[q].x, xr[q].y, xr[q].z, xr[q].w}, wv[4] = {nr[q].x, nr[q].y, nr[q].z, nr[q].w};
+                uint32_t o[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const float a = (mu + asf(wv[e] << 16)) * asf(vv[e] << 16) * inv;
+                    const float b = (mu + asf(wv[e] & 0xFFFF0000u)) * asf(vv[e] & 0xFFFF0000u) * inv;
+                    o[e] = pack_bf16x2(a, b);
+                }
+                const uint32_t p = tid + 256u * (uint32_t)q;
+                reinterpret_cast<w13_v4*>(xs13)[p + (p >> 4)] = w13_v4{o[0], o[1], o[2], o[3]}; // (packet p sits in slot p + p / 16)
+            }
         }
-        reinterpret_cast<rowv4*>(xs13)[tid + (tid >> 4)] = rowv4{o[0], o[1], o[2], o[3]}; // (packet p sits in slot p + p / 16)
     }
-    lds_barrier(); // barrier 9
-    stamp2(42);
+    lds_barrier();
+    stamp2(42, 0);
     // ---- the row's transposed gather (gemv.h Q_M4D), once per wave
     const uint32_t lane_tr = (((lane >> 4) * 4 + (lane & 3)) * 17 + ((lane >> 2) & 3) * 4) * 16;
-    const m4b_lane m4bk = m4b_lane_consts(lane);
     typedef __attribute__((address_space(3))) mf_s4 lds_s4;
     uint2 xq[FN][8];
 #pragma unroll
@@ -1444,54 +1412,58 @@ attn_qkv_wo_w13_body(const bf16_t* kc, const bf16_t* vt, bf16_t* attn_out, unsig
 #pragma unroll
         for (int e = 0; e < 8; e++) xq[c][e] = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16(xt + e));
     }
-    // one pair: its four tiles in the linear-order kernel's order (gemv.h do_pair: tile t = row t / 2, chunk t % 2)
+    // ---- the wave's pairs as they arrive: four tiles each, in the linear-order kernel's order (gemv.h do_pair: tile t = row t / 2, chunk t % 2)
     float my_a = 0.0f, my_b = 0.0f;
-    auto pair_sums = [&](const uint4 (&tile)[4], const uint32_t (&sc)[FN], uint32_t i) {
+    w13_wait<NW>(scl[0][0]); // (the scales are older than every weight load)
+    auto pair_step = [&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        w13_wait<NW - 4 * (i + 1)>(wreg[i][0], wreg[i][1], wreg[i][2], wreg[i][3]);
+        if (i == PW - 1) stamp2(43, 256);
         float rs[2];
 #pragma unroll
         for (int r = 0; r < 2; r++) {
             mf_f4 acc[1] = {mf_f4{0, 0, 0, 0}};
 #pragma unroll
             for (int c = 0; c < (int)FN; c++) {
-                const uint32_t raw = sc[c];
-                mac4b_n<1>(acc, tile[2 * r + c], m4b_prepare(r ? (raw & 0xFFFF0000u) : (raw << 16), m4bk), xq[c]);
+                if (MC_W13_PREDEQ && i == 0 && !poller) { // (wave-uniform)
+                    m4b_dot(acc[0], dq[MC_W13_PREDEQ ? 2 * r + c : 0], xq[c]);
+                } else {
+                    const uint32_t raw = scl[i][c];
+                    const w13_v4 v = wreg[i][2 * r + c];
+                    mac4b_n<1>(acc, make_uint4(v.x, v.y, v.z, v.w), m4b_prepare(r ? (raw & 0xFFFF0000u) : (raw << 16), m4bk), xq[c]);
+                }
             }
             const uint32_t e = lane & 3;
             const float mine = e == 0 ? acc[0][0] : (e == 1 ? acc[0][1] : (e == 2 ? acc[0][2] : acc[0][3]));
             rs[r] = wave_sum_dpp(mine) * 0x1p37f; // 2^M4B_Q: the sum was formed at 2^-Q (mac4b_n)
         }
-        if (lane == i) {
+        if (lane == (uint32_t)i) {
             my_a = rs[0];
             my_b = rs[1];
         }
     };
-    // ---- the pairs that waited in LDS
-    typedef const __attribute__((address_space(3))) uint4* lds_u4;
-#pragma unroll
-    for (int i = 0; i < MC_LDR_NL; i++) {
-        lds_u4 src = (lds_u4)(ring + ldr_slot(wave, (uint32_t)i) * 4096u + lane * 16u);
-        uint4 tile[4];
-#pragma unroll
-        for (int t = 0; t < 4; t++) tile[t] = src[t * 64];
-        pair_sums(tile, scl[i], (uint32_t)i);
-    }
-    stamp2(43);
-    // ---- the streamed pairs
-#pragma unroll
-    for (int i = 0; i < (int)LDR_NS; i++) pair_sums(sr[i], scl[MC_LDR_NL + i], (uint32_t)(MC_LDR_NL + i));
+    static_assert(PW == 7, "the steps below");
+    pair_step(std::integral_constant<int, 0>{});
+    pair_step(std::integral_constant<int, 1>{});
+    pair_step(std::integral_constant<int, 2>{});
+    pair_step(std::integral_constant<int, 3>{});
+    pair_step(std::integral_constant<int, 4>{});
+    pair_step(std::integral_constant<int, 5>{});
+    pair_step(std::integral_constant<int, 6>{});
     // ---- the epilogue of gemv.h finish_pair (EPI_SILU_MUL), one lane per pair: out[j] = T(silu(T(w1 x)) * T(w3 x))
-    if (lane < LDR_PW) {
+    if (lane < W13_PW) {
         const float ga = BF::rt(my_a), gb = BF::rt(my_b);
         const float g = mc::gemv::silu_T<BF>(ga);
         gate[pb + lane] = BF::st(g * gb);
     }
-    stamp2(44);
+    stamp2(44, 0);
+    stamp2(45, 256);
 }
 
 } // namespace
 
-// mc_attn_qkv_wo_w13_i4_bfloat_hd{head_dim}_k{KiB per Wo row}_q{KiB per wq|wk|wv row}_f{KiB per w1|w3 row}: 576 threads (eight waves + the loader)
-extern "C" __global__ void __launch_bounds__(576)
+// mc_attn_qkv_wo_w13_i4_bfloat_hd{head_dim}_k{KiB per Wo row}_q{KiB per wq|wk|wv row}_f{KiB per w1|w3 row}
+extern "C" __global__ void __launch_bounds__(512)
 mc_attn_qkv_wo_w13_i4_bfloat_hd128_k2_q2_f2(const bf16_t* kc, const bf16_t* vt, bf16_t* attn_out, unsigned long long* psum_g, unsigned long long* slab_g,
                                             unsigned long long* row_g, unsigned long long* qkv_g, step_state* st, uint32_t n_rep, uint32_t n_kv, uint32_t max_seq,
                                             float scale, uint32_t nsplit, uint32_t layer_tag, const void* wo_w, const void* wo_s, const bf16_t* x, bf16_t* y,

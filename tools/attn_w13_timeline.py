@@ -5,8 +5,8 @@ matrices of a synthetic decoder of L layers (L x 92 MB of weights: more than the
 layer tags; s_memrealtime stamps (100 MHz) of every workgroup:
   block (tl, thread 0):   0 start  1 row staged  2 wq|wk|wv pairs published  11 hand-off Q  4 scores  5 hand-off A  6 P.V  7 partials published
                           8 hand-off B + reduce  9 hand-off C, attention row staged  10 Wo pairs stored
-  chain (tl2):            0 loader behind barrier 1   1 .. 32 pair n - 1 requested   33 everything landed   34 loader done
-                          40 Wo done  41 hand-off D: hidden row gathered  42 row staged  43 LDS pairs multiplied  44 streamed pairs multiplied, stored
+  chain (tl2):            40 Wo done (thread 0)  41 hand-off D: hidden row gathered (thread 0)  42 row staged  43 a fetcher's (wave 4) last pair landed
+                          44 wave 0 stored  45 wave 4 stored
 usage: attn_w13_timeline.py [launches=32] [layers=8]     (MC_HSACO: a tuning build of the code object)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -71,7 +71,7 @@ def run(form, stamps):
         tlp = acc.wrap(tl.device_ptr + i * WGS * 128, WGS * 128) if stamps else None
         if form == "chain":
             t2 = acc.wrap(tl2.device_ptr + i * WGS * TL2 * 8, WGS * TL2 * 8) if stamps else None
-            mc.KernelTask(k_chain, (WGS * 576, 1, 1), (576, 1, 1),
+            mc.KernelTask(k_chain, (WGS * 512, 1, 1), (512, 1, 1),
                           block_args(i, tlp) + [hid_g, W(w13[l][0]), W(w13[l][1]), norm_w, gate, np.uint32(2 * ffn), np.uint32(128), t2])()
         else:
             mc.KernelTask(k_block, (WGS * 512, 1, 1), (512, 1, 1), block_args(i, tlp) + [np.uint32(0)])()
@@ -124,22 +124,15 @@ for i in (1, N // 2, N - 1):
     print(f" launch {i}: " + "; ".join(row) + f"; last Wo store after the first start {ea:.2f}|{eb:.2f}")
 print("\n-- chain launch (epoch 7 stamps): microseconds after the first workgroup's start")
 for i in (1, N // 2, N - 1):
-    s0 = t2[i, :, 0].min()
+    s0 = t[i, :, 0].min()
     def col(a, j):
         d = (a[i, :, j] - s0) / 100.0
         return f"min {d.min():6.2f} median {np.median(d):6.2f} max {d.max():6.2f}"
     print(f" launch {i}:")
-    print(f"   loader behind barrier 1        {col(t2, 0)}")
-    for n in (1, 8, 16, 24, 32):
-        print(f"   pair {n - 1:2d} requested ({n * 4:3d} KiB)   {col(t2, n)}")
-    print(f"   image landed (128 KiB)          {col(t2, 33)}")
-    print(f"   Wo pairs stored                 {col(t2, 40)}")
-    print(f"   hand-off D: row gathered        {col(t2, 41)}")
-    print(f"   row normalised and staged       {col(t2, 42)}")
-    print(f"   LDS pairs done                  {col(t2, 43)}")
-    print(f"   streamed pairs done, stored     {col(t2, 44)}")
-    # bytes requested by the loaders over time: a histogram in 1 us bins (chip-wide MB)
-    req = ((t2[i, :, 1:33] - s0) / 100.0).ravel()
-    hist, _ = np.histogram(req, bins=np.arange(0, 26, 1.0))
-    print("   loader requests per us (MB, chip-wide): " + " ".join(f"{x * 4096 / 1e6:4.1f}" for x in hist))
+    print(f"   Wo pairs stored (thread 0)       {col(t2, 40)}")
+    print(f"   hand-off D: row gathered         {col(t2, 41)}")
+    print(f"   row normalised and staged        {col(t2, 42)}")
+    print(f"   wave 4: last pair landed         {col(t2, 43)}")
+    print(f"   wave 0 (poller) stored           {col(t2, 44)}")
+    print(f"   wave 4 (fetcher) stored          {col(t2, 45)}")
 dec.release()
