@@ -69,20 +69,8 @@ using namespace mc::gemv;
 #ifndef MC_QX_STG_W
 #define MC_QX_STG_W 0
 #endif
-// NOTE (round 6, mc_attn_qkv_wo_w13_*): a NINTH wave of the workgroup -- the run-ahead loader below -- joins every workgroup barrier of the launch; it learns
-// that a wave has reached barrier k from the LDS word `note_w`, which lane 0 of every arriving wave sets to k (asm ds_write: handoff.h).
-// Barrier 1 (at_start) is joined unconditionally and is what publishes the word's initial zero.
-constexpr int qx_stg_default(int WB) { return WB == 0 ? MC_QX_STG_I4 : (WB == 1 ? MC_QX_STG_W : MC_QX_STG_I8); }
-template <int HD, int QN, int WB = 0, int STG = qx_stg_default(WB), int NOTE = 0>
+template <int HD, int QN, int WB = 0, int STG = (WB == 0 ? MC_QX_STG_I4 : (WB == 1 ? MC_QX_STG_W : MC_QX_STG_I8))>
 struct qkv_in_launch {
-    static_assert(!NOTE || !MC_QKV_ROW_DEAL, "the loader counts the barriers of the whole-pair deal");
-    uint32_t note_w = 0; // (NOTE) byte offset of the word in LDS
-    __device__ __forceinline__ void note(int k) const
-    {
-        if constexpr (NOTE != 0) {
-            if ((threadIdx.x & 63) == 0) lds_poke(note_w, (uint32_t)k);
-        }
-    }
     // (WB = 0, QN = 4 -- round 5, mc_attn_qkv_i4_bfloat_hd128_q4: Llama-3-70B's rows of 4 KiB (K = 8192): two packets of the hidden row per
     //  thread, up to THREE pairs per wave (20 per workgroup), 640 pairs per kv head gathered in two passes)
     static_assert(WB ? QN == 4 : (QN == 2 || QN == 4), "K = 4096 / 8192 int4, 4096 int8, 2048 bfloat; 512 threads");
@@ -252,7 +240,6 @@ struct qkv_in_launch {
             float tot = wsum_ * 8.0f; // (ablation build, gemv.h: timing only)
 #else
             if (lane == 0) red[wave] = wsum_;
-            note(2);
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // (LDS only: the first pairs stay in flight)
             float tot = 0.0f;
 #pragma unroll
@@ -274,7 +261,6 @@ struct qkv_in_launch {
                 else if (tid < NPK) reinterpret_cast<rowv4*>(xs)[tid] = rowv4{o[0], o[1], o[2], o[3]};              // (natural order)
             }
         }
-        note(3);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         stamp(1);
         // ---- the rest of the wave's rows and the rotation of the pair this lane will finish (lane i < cnt: whole pair j0 + i,
@@ -452,7 +438,6 @@ struct qkv_in_launch {
                 }
             }
         }
-        note(4);
         __syncthreads();
         stamp(11);
     }
@@ -519,7 +504,6 @@ struct qkv_qkn_in_launch {
     float pc, ps;
     uint32_t j0, full, slot, tag, rrow_;
 
-    __device__ __forceinline__ void note(int) const {} // (attn_fused_bf: qkv_in_launch NOTE)
     __device__ __forceinline__ void stamp(int i) const
     {
         if (tl && threadIdx.x == 0) tl[(size_t)blockIdx.x * TL_STRIDE + i] = __builtin_amdgcn_s_memrealtime();
@@ -775,9 +759,7 @@ struct gemma_extra {
     void* h_out;                  // (QKN = 3) where workgroup 0 leaves that hidden row
     const bf16_t *q_norm, *k_norm;
 };
-// CH = 1 (round 6, mc_attn_qkv_wo_w13_*): a phase follows in the same launch -- every stored pair of the output row is also published as a
-// {2 x bf16, tag} granule in `hid_g` (hand-off D), and the workgroup's barriers are noted for the loader wave (qkv_in_launch NOTE, `note_w`)
-template <int HD, int LNCH, int QN = 0, int WB = 0, int TT = 1, int QKN = 0, int CH = 0>
+template <int HD, int LNCH, int QN = 0, int WB = 0, int TT = 1, int QKN = 0>
 __device__ __forceinline__ void
 attn_wo_body(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const bf16_t* __restrict__ vt, bf16_t* __restrict__ attn_out,
              unsigned long long* psum_g, unsigned long long* slab_g, unsigned long long* row_g, step_state* st, uint32_t n_rep,
@@ -788,9 +770,8 @@ attn_wo_body(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const 
              // granules of hand-off Q
              const void* __restrict__ qnorm_w = nullptr, const void* __restrict__ qkv_w = nullptr, const void* __restrict__ qkv_s = nullptr,
              const float* fcos = nullptr, const float* fsin = nullptr, unsigned long long* qkv_g = nullptr, float eps = 0.0f, float mu = 0.0f,
-             uint32_t kv_shift = 0, gemma_extra gx = gemma_extra(), unsigned long long* hid_g = nullptr, uint32_t note_w = 0)
+             uint32_t kv_shift = 0, gemma_extra gx = gemma_extra())
 {
-    static_assert(CH == 0 || (QN != 0 && QKN == 0 && WB == 0), "a chained phase: behind the int4 launch with wq|wk|wv inside");
     constexpr uint32_t K = WB == 1 ? 512u * LNCH : (WB == 2 ? 1024u * LNCH : 2048u * LNCH);
     constexpr uint32_t WPK = WB == 1 ? 8u : (WB == 2 ? 16u : 32u); // weights of a lane's 16-byte packet
     constexpr uint32_t CHUNK_LDS = 2048 * 2 / 16 * 17;  // a chunk of the row in LDS: 16 bytes of padding per 256 (gemv.h Q_M4D)
@@ -803,9 +784,8 @@ attn_wo_body(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const 
     __shared__ __attribute__((aligned(16))) bf16_t qkv_rows[(QN || QKN) ? 18 * HD : 8]; // queries of up to 16 heads, the K row, the V row
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // (QN != 0) the hidden row and the wave's wq|wk|wv pairs are requested by the first instructions of the launch
-    typedef qkv_in_launch<HD, QN ? QN : (WB ? 4 : 2), WB, qx_stg_default(WB), CH> qx_t;
+    typedef qkv_in_launch<HD, QN ? QN : (WB ? 4 : 2), WB> qx_t;
     qx_t qx;
-    qx.note_w = note_w;
     if constexpr (QN != 0) {
         typedef typename qx_t::lds_row lds_row;
         qx.q_s = (lds_row)qkv_rows;
@@ -983,7 +963,6 @@ attn_wo_body(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const 
             else *reinterpret_cast<uint32_t*>(xs + g * 4) = val[i]; // (natural order)
         }
     }
-    if constexpr (CH != 0) qx.note(7);
     __syncthreads();
     stamp(6);
 
@@ -1042,7 +1021,6 @@ attn_wo_body(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const 
                 vb = __uint_as_float(wres[i] & 0xFFFF0000u) + vb;
             }
             reinterpret_cast<uint32_t*>(y)[pb + i] = pack_bf16x2(va, vb);
-            if constexpr (CH != 0) granule_store(hid_g + pb + i, epoch_tag, pack_bf16x2(va, vb)); // hand-off D
         }
     }
     stamp(7);
@@ -1201,277 +1179,3 @@ MC_ATTN_WO(mc_attn_wo_i4_bfloat_hd128_k4, 128, 4)  // tuning builds (-DMC_ATTN_W
 #endif
 MC_ATTN_WO(mc_attn_wo_i4_bfloat_hd64_k1, 64, 1)    // 32 heads x 64
 MC_ATTN_WO(mc_attn_wo_i4_bfloat_hd256_k2, 256, 2)  // Gemma-7B shapes: 16 heads x 256
-
-// ------------------------------------------------------------------------------------------
-// Round 6: the attention block AND ffn_norm + w1|w3 + SiLU * mul (include/metalchat/nn/transformer.h:130-137, 53-59) in one launch:
-// mc_attn_qkv_wo_w13_i4_bfloat_hd128_k2_q2_f2.
-//
-// Why: the w1|w3 GEMV behind the attention block lasts 12.5 us for 60.6 MB -- a launch boundary, a prologue and a cold stream that starts only
-// when the row is there -- and its weights depend on nothing.  Round 3 chained the two phases with 4 KiB per wave requested before the row
-// arrived and lost (tools/experiments/README.md).  Round 6 first built the verdict's form: a NINTH wave per workgroup filling an LDS image of
-// 28 - 32 row pairs by LDS-DMA while the eight wait through the attention's hand-offs, joined to the block's barriers through an LDS word
-// (git history: commits "run-ahead LDS-DMA loader wave", "Loader wave v2"; profiles/r06_chain_loader_wave_v{1,2}_*: parity green, the loader
-// ahead of the row, 750 / 712 against 808 / 815 tokens/s same box).  What its timelines showed decides this form:
-//   * trickled at ~ 2 TB/s chip-wide the loader leaves the attention's hand-offs alone but has 64 KiB per CU when Wo is done; at 5 TB/s the
-//     image is complete in time and hand-offs B and C take 1 - 3 us longer (the price sits in the polling CU's own memory queue);
-//   * hand-off D -- the hidden row from 2048 Wo pairs on 256 CUs to every CU -- takes ~ 4 us after the LAST Wo store whatever is loaded;
-//   * with every weight on chip the eight waves need 6.6 us for the workgroup's 56 pairs: the exact dequantisation (245 issue slots per pair,
-//     two waves per SIMD) is the floor, not the stream -- so nothing has to be on chip before Wo is done: hand-off D's 4 us bring ~ 100 KiB
-//     per CU and the multiplications' 6.6 us cover the other 124.
-// So: no loader wave, no LDS image, nothing requested during the attention phases.  Behind the Wo phase waves 4-7 of every workgroup (the
-// FETCHERS) request their seven pairs -- 28 KiB per wave, into registers -- and dequantise the first of them (gemv.h m4b_dequant: everything
-// that does not need the row) while waves 0-3 (the POLLERS) wait for hand-off D, two packets of the row per thread; a wave's vector-memory
-// results return in issue order, so the pollers request THEIR pairs only when the row is in and multiply them as they arrive.
-//
-// Numerics: bit for bit the two launches it replaces.  The attention block is the same code (attn_wo_body, CH = 1: its Wo epilogue also
-// publishes the pair as a granule).  The w1|w3 phase is mc_gemv_i4_bfloat_lin2_p1_e2's arithmetic: packet p's sum of squares formed by one
-// thread, the sums of packets 64 v .. 64 v + 63 added by wave_sum_dpp in lane order (v = 0 .. 7: the stand-alone kernel's eight waves), the
-// eight sums in order, the normalised row staged in the padded order; a pair = tiles (row 0 chunk 0, row 0 chunk 1, row 1 chunk 0, row 1
-// chunk 1) through mac4b_n<1> (m4b_dequant + m4b_dot: the same instructions) into one accumulator per row, the lane's own element, one
-// wave sum times 2^37, the epilogue of gemv.h finish_pair (EPI_SILU_MUL).  Which wave multiplies a pair does not change a bit of it.
-// ------------------------------------------------------------------------------------------
-namespace {
-
-#ifndef MC_W13_PREDEQ
-#define MC_W13_PREDEQ 1 // the fetchers dequantise their first pair while the pollers wait for hand-off D (64 registers)
-#endif
-constexpr uint32_t W13_PW = 7; // pairs per wave of the w1|w3 phase (the host: 56 per workgroup) -- an EVEN deal, not gemv.h lin_deal's (8, 6):
-                               // that one evens out the two waves of a SIMD when the first arrives 2 us before the second (a launch's ramp)
-// stamps (tl2 != null: tools/attn_w13_timeline.py), per workgroup, s_memrealtime:
-//   40 Wo done (thread 0)   41 hand-off D: row gathered (thread 0)   42 row staged   43 a fetcher's (wave 4) last pair landed   44 wave 0 stored   45 wave 4 stored
-constexpr int TL2_STRIDE = 48;
-
-typedef uint32_t w13_v4 __attribute__((ext_vector_type(4)));
-// Loads the compiler does not count (its own counted waits stay exact for ITS loads; these are waited for by hand, below)
-__device__ __forceinline__ void w13_load16(w13_v4& dst, const void* p)
-{
-    asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(dst) : "v"(p) : "memory");
-}
-__device__ __forceinline__ void w13_load4(uint32_t& dst, const void* p)
-{
-    asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
-}
-// everything but the N youngest vector-memory operations of this wave has completed; the values pass THROUGH the wait, so no use of them can be scheduled in front of it
-template <int N> __device__ __forceinline__ void w13_wait(w13_v4& a, w13_v4& b, w13_v4& c, w13_v4& d)
-{
-    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N) : "memory");
-}
-template <int N> __device__ __forceinline__ void w13_wait(uint32_t& a)
-{
-    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(a) : "n"(N) : "memory");
-}
-
-template <int HD, int LNCH, int QN>
-__device__ __forceinline__ void
-attn_qkv_wo_w13_body(const bf16_t* kc, const bf16_t* vt, bf16_t* attn_out, unsigned long long* psum_g, unsigned long long* slab_g, unsigned long long* row_g,
-                     unsigned long long* qkv_g, step_state* st, uint32_t n_rep, uint32_t KV, uint32_t max_seq, float scale, uint32_t nsplit, uint32_t layer_tag,
-                     const void* wo_w, const void* wo_s, const bf16_t* x, bf16_t* y, uint32_t out_rows, uint32_t group, const void* qnorm_w,
-                     const void* qkv_w, const void* qkv_s, const float* fcos, const float* fsin, float eps, float mu, uint32_t fastpath,
-                     unsigned long long* tl, unsigned long long* hid_g, const void* __restrict__ w13_w, const void* __restrict__ w13_s,
-                     const void* __restrict__ ffn_norm, bf16_t* __restrict__ gate, uint32_t ffn_rows, uint32_t ffn_group, unsigned long long* tl2)
-{
-    static_assert(QN == 2 && LNCH == 2, "dim 4096: rows of 2 KiB for wq|wk|wv and w1|w3");
-    constexpr uint32_t CHUNK_LDS = 2048 * 2 / 16 * 17, ROWB = 2048u, FN = 2, KF = 4096u;
-    constexpr int PW = (int)W13_PW;
-    __shared__ __attribute__((aligned(16))) char xs13[FN * CHUNK_LDS];
-    __shared__ float red13[16];
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    unsigned long long* mytl = tl2 ? tl2 + (size_t)blockIdx.x * TL2_STRIDE : nullptr;
-
-    // ================= the attention block ...
-    attn_wo_body<HD, LNCH, QN, 0, 1, 0, 1>(nullptr, kc, vt, attn_out, psum_g, slab_g, row_g, st, n_rep, KV, max_seq, scale, nsplit, layer_tag, wo_w, wo_s, x, y,
-                                           out_rows, group, 1u, fastpath, tl, qnorm_w, qkv_w, qkv_s, fcos, fsin, qkv_g, eps, mu, 0u, gemma_extra(), hid_g);
-    auto stamp2 = [&](int i, uint32_t t) {
-        if (mytl && tid == t) mytl[i] = __builtin_amdgcn_s_memrealtime();
-    };
-    stamp2(40, 0);
-    // ================= ... and ffn_norm + w1|w3 + SiLU * mul
-    const bool poller = wave < 4u;
-    const uint32_t pb = blockIdx.x * (8u * W13_PW) + W13_PW * wave; // pairs pb .. pb + 6 (the host: ffn_rows == 2 * 56 * gridDim.x)
-    const uint32_t glog = ffn_group ? 31u - __builtin_clz(ffn_group) : 31u, ngroups = ffn_group ? KF >> glog : 1u;
-    // ---- hand-off D (pollers): the hidden row the Wo phases of ALL workgroups finished; thread t < 256 gathers packets t and t + 256 =
-    // granules 4 p .. 4 p + 3 each (one watched granule and ~ 0.4 us between looks while the row is not there, then one sweep: hand-off C)
-    const uint32_t epoch_tag = st->epoch * 256u + layer_tag;
-    w13_v4 xr[2] = {w13_v4{0, 0, 0, 0}, w13_v4{0, 0, 0, 0}};
-    if (poller) { // (wave-uniform; every load inside is waited for inside)
-        uint32_t val[8];
-        handoff_wait w;
-        for (;;) {
-            const bool seen = (uint32_t)(granule_load(hid_g + 4u * (tid + 256u) + 3u) >> 32) == epoch_tag;
-            if (__all(seen) || w.expired(st, 0xE0000000u | layer_tag)) break;
-            __builtin_amdgcn_s_sleep(MC_HANDOFF_C_SLEEP);
-        }
-        for (;;) {
-            bool ok = true;
-#pragma unroll
-            for (int i = 0; i < 8; i++) {
-                const unsigned long long g = granule_load(hid_g + 4u * (tid + 256u * (i >> 2)) + (i & 3));
-                ok = ok && (uint32_t)(g >> 32) == epoch_tag;
-                val[i] = (uint32_t)g;
-            }
-            if (__all(ok) || w.expired(st, 0xE0000000u | layer_tag)) break;
-        }
-        xr[0] = w13_v4{val[0], val[1], val[2], val[3]};
-        xr[1] = w13_v4{val[4], val[5], val[6], val[7]};
-    }
-    stamp2(41, 0);
-    // ---- every wave's requests, in ONE place (the fetchers reach it ~ 4 us before the pollers): the norm weights of the packets this thread
-    // stages, the scales of its wave's pairs, the pairs.  None of it is visible to the compiler's wait counting: waited for by hand.
-    w13_v4 nr[2];
-    uint32_t scl[PW][FN];
-    w13_v4 wreg[PW][4];
-    {
-        const char* np_ = static_cast<const char*>(ffn_norm) + (size_t)(tid & 255u) * 16u;
-        w13_load16(nr[0], np_);
-        w13_load16(nr[1], np_ + 256 * 16);
-        // scales of pair pr: half a row quad ([ngroups][4] bf16 per four rows) per chunk; the lane's 32 weights of chunk c sit in group (2048 c + 32 lane) / group
-#pragma unroll
-        for (int i = 0; i < PW; i++) {
-            const uint32_t pr = pb + (uint32_t)i;
-            const char* a = static_cast<const char*>(w13_s) + (((uint64_t)(pr >> 1) * ngroups) * 4 + (pr & 1u) * 2) * 2;
-#pragma unroll
-            for (int c = 0; c < (int)FN; c++) {
-                const uint32_t g = ffn_group ? ((2048u * (uint32_t)c + 32u * lane) >> glog) : 0u;
-                w13_load4(scl[i][c], a + g * 8u);
-            }
-        }
-        const char* wb = static_cast<const char*>(w13_w) + (uint64_t)pb * (2u * ROWB) + lane * 16u;
-#pragma unroll
-        for (int i = 0; i < PW; i++)
-#pragma unroll
-            for (int t = 0; t < 4; t++) w13_load16(wreg[i][t], wb + (size_t)i * (2u * ROWB) + t * 1024u);
-    }
-    // (issued behind this point: nothing until the epilogue's store -- the counts below are exact)
-    constexpr int NW = PW * 4; // weight loads, the youngest
-    const m4b_lane m4bk = m4b_lane_consts(lane);
-    // ---- the fetchers' first pair, dequantised while the pollers wait (the pollers dequantise theirs behind the row, as they must)
-    uint2 dq[MC_W13_PREDEQ ? 4 : 1][8];
-    if (MC_W13_PREDEQ && !poller) {
-        w13_wait<NW>(scl[0][0]);
-        w13_wait<NW>(scl[0][1]);
-        w13_wait<NW - 4>(wreg[0][0], wreg[0][1], wreg[0][2], wreg[0][3]);
-#pragma unroll
-        for (int t = 0; t < 4; t++) {
-            const uint32_t raw = scl[0][t & 1];
-            const w13_v4 v = wreg[0][t];
-            m4b_dequant(dq[MC_W13_PREDEQ ? t : 0], make_uint4(v.x, v.y, v.z, v.w), m4b_prepare((t >> 1) ? (raw & 0xFFFF0000u) : (raw << 16), m4bk));
-        }
-    }
-    // ---- ffn_norm on the way into LDS (kernel/rmsnorm.metal:52-95; gemv.h, the build-time prologue: the same additions in the same order)
-    {
-        float s1[2];
-#pragma unroll
-        for (int q = 0; q < 2; q++) {
-            const uint32_t vv[4] = {xr[q].x, xr[q].y, xr[q].z, xr[q].w};
-            float s = 0.0f;
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const float a = asf(vv[e] << 16), b = asf(vv[e] & 0xFFFF0000u);
-                s += a * a;
-                s += b * b;
-            }
-            float ss = 0.0f;
-            ss += s;
-            s1[q] = wave_sum_dpp(ss);
-        }
-        if (poller && lane == 0) { // the stand-alone kernel's wave v holds packets 64 v .. 64 v + 63
-            red13[wave] = s1[0];
-            red13[4u + wave] = s1[1];
-        }
-        lds_barrier();
-        float tot = 0.0f;
-#pragma unroll
-        for (uint32_t i = 0; i < 8u; i++) tot += red13[i];
-        const float inv = 1.0f / sqrtf(tot / (float)KF + eps);
-        if (poller) {
-            w13_wait<NW + 2 * PW>(nr[0], nr[1], nr[0], nr[1]);
-#pragma unroll
-            for (int q = 0; q < 2; q++) {
-                const uint32_t vv[4] = {xr[q].x, xr[q].y, xr[q].z, xr[q].w}, wv[4] = {nr[q].x, nr[q].y, nr[q].z, nr[q].w};
-                uint32_t o[4];
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    const float a = (mu + asf(wv[e] << 16)) * asf(vv[e] << 16) * inv;
-                    const float b = (mu + asf(wv[e] & 0xFFFF0000u)) * asf(vv[e] & 0xFFFF0000u) * inv;
-                    o[e] = pack_bf16x2(a, b);
-                }
-                const uint32_t p = tid + 256u * (uint32_t)q;
-                reinterpret_cast<w13_v4*>(xs13)[p + (p >> 4)] = w13_v4{o[0], o[1], o[2], o[3]}; // (packet p sits in slot p + p / 16)
-            }
-        }
-    }
-    lds_barrier();
-    stamp2(42, 0);
-    // ---- the row's transposed gather (gemv.h Q_M4D), once per wave
-    const uint32_t lane_tr = (((lane >> 4) * 4 + (lane & 3)) * 17 + ((lane >> 2) & 3) * 4) * 16;
-    typedef __attribute__((address_space(3))) mf_s4 lds_s4;
-    uint2 xq[FN][8];
-#pragma unroll
-    for (int c = 0; c < (int)FN; c++) {
-        lds_s4* xt = (lds_s4*)(xs13 + c * CHUNK_LDS + lane_tr);
-#pragma unroll
-        for (int e = 0; e < 8; e++) xq[c][e] = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16(xt + e));
-    }
-    // ---- the wave's pairs as they arrive: four tiles each, in the linear-order kernel's order (gemv.h do_pair: tile t = row t / 2, chunk t % 2)
-    float my_a = 0.0f, my_b = 0.0f;
-    w13_wait<NW>(scl[0][0]); // (the scales are older than every weight load)
-    auto pair_step = [&](auto ic) {
-        constexpr int i = decltype(ic)::value;
-        w13_wait<NW - 4 * (i + 1)>(wreg[i][0], wreg[i][1], wreg[i][2], wreg[i][3]);
-        if (i == PW - 1) stamp2(43, 256);
-        float rs[2];
-#pragma unroll
-        for (int r = 0; r < 2; r++) {
-            mf_f4 acc[1] = {mf_f4{0, 0, 0, 0}};
-#pragma unroll
-            for (int c = 0; c < (int)FN; c++) {
-                if (MC_W13_PREDEQ && i == 0 && !poller) { // (wave-uniform)
-                    m4b_dot(acc[0], dq[MC_W13_PREDEQ ? 2 * r + c : 0], xq[c]);
-                } else {
-                    const uint32_t raw = scl[i][c];
-                    const w13_v4 v = wreg[i][2 * r + c];
-                    mac4b_n<1>(acc, make_uint4(v.x, v.y, v.z, v.w), m4b_prepare(r ? (raw & 0xFFFF0000u) : (raw << 16), m4bk), xq[c]);
-                }
-            }
-            const uint32_t e = lane & 3;
-            const float mine = e == 0 ? acc[0][0] : (e == 1 ? acc[0][1] : (e == 2 ? acc[0][2] : acc[0][3]));
-            rs[r] = wave_sum_dpp(mine) * 0x1p37f; // 2^M4B_Q: the sum was formed at 2^-Q (mac4b_n)
-        }
-        if (lane == (uint32_t)i) {
-            my_a = rs[0];
-            my_b = rs[1];
-        }
-    };
-    static_assert(PW == 7, "the steps below");
-    pair_step(std::integral_constant<int, 0>{});
-    pair_step(std::integral_constant<int, 1>{});
-    pair_step(std::integral_constant<int, 2>{});
-    pair_step(std::integral_constant<int, 3>{});
-    pair_step(std::integral_constant<int, 4>{});
-    pair_step(std::integral_constant<int, 5>{});
-    pair_step(std::integral_constant<int, 6>{});
-    // ---- the epilogue of gemv.h finish_pair (EPI_SILU_MUL), one lane per pair: out[j] = T(silu(T(w1 x)) * T(w3 x))
-    if (lane < W13_PW) {
-        const float ga = BF::rt(my_a), gb = BF::rt(my_b);
-        const float g = mc::gemv::silu_T<BF>(ga);
-        gate[pb + lane] = BF::st(g * gb);
-    }
-    stamp2(44, 0);
-    stamp2(45, 256);
-}
-
-} // namespace
-
-// mc_attn_qkv_wo_w13_i4_bfloat_hd{head_dim}_k{KiB per Wo row}_q{KiB per wq|wk|wv row}_f{KiB per w1|w3 row}
-extern "C" __global__ void __launch_bounds__(512)
-mc_attn_qkv_wo_w13_i4_bfloat_hd128_k2_q2_f2(const bf16_t* kc, const bf16_t* vt, bf16_t* attn_out, unsigned long long* psum_g, unsigned long long* slab_g,
-                                            unsigned long long* row_g, unsigned long long* qkv_g, step_state* st, uint32_t n_rep, uint32_t n_kv, uint32_t max_seq,
-                                            float scale, uint32_t nsplit, uint32_t layer_tag, const void* wo_w, const void* wo_s, const bf16_t* x, bf16_t* y,
-                                            uint32_t out_rows, uint32_t group, const void* qnorm_w, const void* qkv_w, const void* qkv_s, const float* fcos,
-                                            const float* fsin, float eps, float mu, uint32_t fastpath, unsigned long long* tl, unsigned long long* hid_g,
-                                            const void* w13_w, const void* w13_s, const void* ffn_norm, bf16_t* gate, uint32_t ffn_rows, uint32_t ffn_group,
-                                            unsigned long long* tl2)
-{
-    attn_qkv_wo_w13_body<128, 2, 2>(kc, vt, attn_out, psum_g, slab_g, row_g, qkv_g, st, n_rep, n_kv, max_seq, scale, nsplit, layer_tag, wo_w, wo_s, x, y, out_rows,
-                                    group, qnorm_w, qkv_w, qkv_s, fcos, fsin, eps, mu, fastpath, tl, hid_g, w13_w, w13_s, ffn_norm, gate, ffn_rows, ffn_group, tl2);
-}

@@ -650,7 +650,6 @@ struct q_from_hbm {
     __device__ __forceinline__ void at_start() {}
     __device__ __forceinline__ void before_tiles() {}
     __device__ __forceinline__ void before_scores() {}
-    __device__ __forceinline__ void note(int) const {}
 };
 
 // gemma3 (include/metalchat/nn/attention.h:170-177): q_norm / k_norm over whole heads, then the rotation, then the cache write --
@@ -696,7 +695,6 @@ struct q_from_qkv_rows {
     //  write below -- drains the vector-memory counter too, i.e. waits for the V tile in front of the scores: the launch then
     //  lasted 20.9 us against 11.9 + 4.9 for the two launches it replaces)
     static __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-    __device__ __forceinline__ void note(int) const {} // (attn_fused_bf: the barriers a loader wave must join -- qkv_in_launch NOTE)
     __device__ __forceinline__ const bf16_t* head_row(uint32_t kv, uint32_t hc) const
     {
         return qkv + (size_t)(hc < n_rep ? kv * n_rep + hc : n_rep * KV + kv) * HD;
@@ -1029,7 +1027,6 @@ attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const
         for (uint32_t m = 0; m < 4; m++)
             if (m < nm && col == 0) wsum[wave][4 * m + c] = esum[m];
         }
-        qsrc.note(5); // (a policy with a loader wave beside the eight: the barrier below is its fifth)
         if constexpr (T > 1) {
             // wide ranges: the V tiles (32 KB and more per workgroup) are REQUESTED here, behind the scores and in front of hand-off
             // A, whose wait then covers their latency (sunk behind it, as hipcc leaves them, P.V waited 3.2 us at S = 8192).  A value
@@ -1087,7 +1084,6 @@ attn_fused_bf(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const
     }
     behind_scores(1);
     if (active) {
-        qsrc.note(6);
         if constexpr (T > 1 || QSrc::LDS) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         else __syncthreads();
         stamp(2);

@@ -75,24 +75,6 @@ granule_look_dual(const unsigned long long* slow, size_t fast_off, uint32_t look
     return granule_load(handoff_slow_look(look) ? slow : slow + fast_off);
 }
 
-// ---- LDS words shared with a wave that issues LDS-DMA (attn_block_kernels.hip, the run-ahead loader of mc_attn_qkv_wo_w13_*): touched
-// through these asm forms ONLY -- a compiler-visible ds_read / ds_write next to an LDS-DMA makes hipcc drain the DMA first
-// (s_waitcnt vmcnt(0)), which would serialise the loader (tools/lds_stream_lab.hip, tools/ldr_lab.hip).  Addresses are byte offsets into LDS.
-typedef __attribute__((address_space(3))) char lds_char_t;
-__device__ __forceinline__ uint32_t lds_off(const void* p) { return (uint32_t)(uintptr_t)(lds_char_t*)p; }
-__device__ __forceinline__ uint32_t
-lds_peek(uint32_t a)
-{
-    uint32_t r;
-    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(r) : "v"(a) : "memory");
-    return r;
-}
-__device__ __forceinline__ void
-lds_poke(uint32_t a, uint32_t v)
-{
-    asm volatile("ds_write_b32 %0, %1" ::"v"(a), "v"(v) : "memory");
-}
-
 // one round of a bounded wait: false = keep waiting.  `ok` is wave-uniform.
 #ifndef MC_HANDOFF_BOUND_TICKS
 #define MC_HANDOFF_BOUND_TICKS 5000000ull // 50 ms at 100 MHz
