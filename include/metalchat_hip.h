@@ -329,12 +329,18 @@ mc_status mc_decoder_time_gemv(mc_decoder* d, const char* which, int32_t repeats
  * time_gemv("qkv") measure stand-alone launches).  Launches nothing. */
 mc_status mc_decoder_gemv_kernel_name(mc_decoder* d, const char* which, char* buf, size_t cap);
 /* How often an in-launch hand-off of the decode attention gave up (its workgroups were not resident together: another stream or
- * process held part of the chip) and the decoder fell back, for good, to the launches that need no co-residency.  A step
+ * process held part of the chip) and the decoder fell back to the launches that need no co-residency.  A step
  * (mc_decoder_step with a token read back) and a chain that stays inside the cache (mc_decoder_generate, start_pos + n <=
  * max_seq_len) are repeated on those launches and succeed; anywhere else the call that finds the flag fails with
  * MC_ERR_RUNTIME ("... repeat the call") -- the reference delivers a GPU execution error the same way, through the future that
  * is waited for (src/kernel_thread.cc:134-144). */
 int32_t mc_decoder_handoff_fallbacks(const mc_decoder* d);
+/* The fall-back is temporary: after 256 tokens decoded without a hand-off launch (MC_HANDOFF_REARM=<tokens>, 0 = never) the decoder takes
+ * the one-launch blocks again; every further fall-back doubles that distance, so a chip that is shared for good settles on the launches
+ * that need no co-residency.  mc_decoder_handoff_rearms: how often that happened; mc_decoder_handoffs_active: 1 while the decoder uses the
+ * hand-off launches, 0 while it is degraded (a caller that wants to know why its tokens got slower asks here). */
+int32_t mc_decoder_handoff_rearms(const mc_decoder* d);
+int32_t mc_decoder_handoffs_active(const mc_decoder* d);
 /* HBM bytes this decoder holds in DERIVED copies of its weights, built on demand by the prompt pass: the quad-interleaved int4 copy
  * short prompts stream from (+ 0.5 byte per weight) and -- only with the opt-in library GEMM, MC_PF_BLASLT=1 -- the dequantised
  * bfloat16 copy (+ 2 bytes per weight).  0 until a prompt has asked for one.  The reference materialises the dequantised matrix on

@@ -317,6 +317,22 @@ struct mc_decoder {
     hipEvent_t err_evt = nullptr;
     bool err_pending = false;
     int handoff_fallbacks = 0;
+    // ... and the fall-back is TEMPORARY (round 6): one transient stall (another stream holding CUs for 50 ms, a profiler pass) must not cost every
+    // later token the one-launch blocks.  After `rearm_after` tokens without a hand-off launch the decoder takes them again (mc_decoder_handoff_rearms counts);
+    // every further fall-back doubles the distance (a chip that is shared for good settles on the launches that need no co-residency), MC_HANDOFF_REARM=0: never
+    bool attn_fused_cfg = true;  // what the configuration asked for (MC_ATTN_FUSED)
+    int rearm_after = 256, clean_tokens = 0, handoff_rearms = 0;
+    void
+    note_clean_tokens(int n)
+    {
+        if (attn_fused_on || !attn_fused_cfg || rearm_after <= 0) return;
+        clean_tokens += n;
+        if (clean_tokens < rearm_after) return;
+        attn_fused_on = true;
+        clean_tokens = 0;
+        handoff_rearms++;
+        drop_graph(); // (captured with the launches that need no co-residency)
+    }
     int occ_fused = -1, occ_wo = -1, occ_wo_w = -1, occ_wo_i8 = -1, occ_wo_qkn = -1, occ_qkv_qkn = -1, occ_qkv_only = -1, occ_wo_i4_wide = -1;   // co-resident workgroups per CU of the hand-off launches (the occupancy API's answer; -1: not asked yet)
     bool handoff_fast = true;    // MC_HANDOFF_FAST=0: hand-offs A and B through the fabric only (A/B; handoff.h "the XCD-local fast path")
     bool attn_wo_on = true;      // MC_ATTN_WO=0: the Wo GEMV as a launch of its own behind the one-launch attention (A/B, parity)
@@ -725,6 +741,8 @@ struct mc_decoder {
         attn_fused_on = false; // (attn_wo_fused and attn_qkv_wo_fused need attn_fused)
         drop_graph();
         handoff_fallbacks++;
+        clean_tokens = 0;
+        if (handoff_fallbacks > 1 && rearm_after > 0 && rearm_after < (1 << 24)) rearm_after *= 2;
     }
 
     // ... with the Wo GEMV and its residual in the same launch (attn_block_kernels.hip): int4 weights on bfloat rows with scale
@@ -846,7 +864,8 @@ struct mc_decoder {
             L.qkv.out != (cfg.n_heads + 2 * cfg.n_kv_heads) * hd || n_rep > 16 || pg < 64 || pg > 512)
             return 0;
         for (int t : {1, 2, 4}) {
-            if (nsplit % t || (t == 1 && !attn_fused()) || (t > 1 && !attn_i4_wide_on)) continue;
+            // (wide ranges of a cache that is not whole ranges long -- S = 4040 -- would leave a ragged last range: the kernels clamp and mask it, no test covers it)
+            if (nsplit % t || (t > 1 && cfg.max_seq_len % (64 * t)) || (t == 1 && !attn_fused()) || (t > 1 && !attn_i4_wide_on)) continue;
             const int ns = nsplit / t;
             const unsigned grid = (unsigned)(ns * (cfg.n_kv_heads << sh));
             if (grid <= (unsigned)dev->prop.multiProcessorCount && pg % ns == 0 && pg / ns <= 8 && (unsigned)L.wo.out / 2 <= 8u * grid) return t;
@@ -869,7 +888,7 @@ struct mc_decoder {
             L.qkv.out != (cfg.n_heads + 2 * cfg.n_kv_heads) * hd || cfg.n_kv_heads % 8 != 0 || n_rep > 16)
             return 0;
         for (int t : {1, 2, 4}) {
-            if (nsplit % t) continue;
+            if (nsplit % t || (t > 1 && cfg.max_seq_len % (64 * t))) continue; // (whole ranges only: attn_qkv_wo_w_tiles)
             const int ns = nsplit / t;
             const unsigned grid = (unsigned)(ns * cfg.n_kv_heads);
             if (grid <= (unsigned)dev->prop.multiProcessorCount && pg % ns == 0 && pg / ns <= 16 && (unsigned)L.wo.out / 2 <= 8u * grid) return t;
@@ -889,7 +908,7 @@ struct mc_decoder {
             L.qkv.out != (cfg.n_heads + 2 * cfg.n_kv_heads) * hd || cfg.n_kv_heads % 8 != 0 || n_rep > 16)
             return 0;
         for (int t : {2, 4}) {
-            if (nsplit % t) continue;
+            if (nsplit % t || cfg.max_seq_len % (64 * t)) continue; // (whole ranges only: attn_qkv_wo_w_tiles)
             const int ns = nsplit / t;
             const unsigned grid = (unsigned)(ns * cfg.n_kv_heads);
             if (grid <= (unsigned)dev->prop.multiProcessorCount && pg % ns == 0 && pg / ns <= 16 && pg >= 64 && (unsigned)L.wo.out / 2 <= 16u * grid) return t;
@@ -2126,6 +2145,8 @@ mc_decoder_create(mc_device* dev, mc_library* lib, mc_queue* q, const mc_decoder
     if (const char* e = getenv("MC_GEMV_LIN")) d->gemv_lin = atoi(e) != 0;
     if (const char* e = getenv("MC_PV_FOLD")) d->pv_fold_on = atoi(e) != 0;
     if (const char* e = getenv("MC_ATTN_FUSED")) d->attn_fused_on = atoi(e) != 0;
+    d->attn_fused_cfg = d->attn_fused_on;
+    if (const char* e = getenv("MC_HANDOFF_REARM")) d->rearm_after = std::max(0, atoi(e));
     if (const char* e = getenv("MC_ATTN_WO")) d->attn_wo_on = atoi(e) != 0;
     if (const char* e = getenv("MC_HANDOFF_FAST")) d->handoff_fast = atoi(e) != 0;
     if (const char* e = getenv("MC_ATTN_QKV")) d->attn_qkv_on = atoi(e) != 0;
@@ -2649,13 +2670,17 @@ mc_decoder_step(mc_decoder* d, int32_t token, int32_t start_pos, const void* hid
             // nobody waits for this step: its flag is copied out behind it and looked at by the calls that follow (poll_pending_err)
             // and by every call that synchronises (check_err_synced); a set flag makes THAT call fail and latches the decoder
             if (handoffs) d->note_err_async();
+            d->note_clean_tokens(1);
             return MC_OK;
         }
         step_state_h st;
         MC_HIP(hipMemcpyAsync(&st, d->state, sizeof st, hipMemcpyDeviceToHost, d->stream));
         MC_HIP(hipStreamSynchronize(d->stream));
         *next_token = st.token;
-        if (!st.err) return MC_OK;
+        if (!st.err) {
+            d->note_clean_tokens(1);
+            return MC_OK;
+        }
         if (attempt > 0 || !handoffs) return d->check_handoffs(st);
         // the step again, from the state in front of it: its cache row goes to the same slot, every other row is untouched
         d->handoff_failed();
@@ -2820,7 +2845,10 @@ mc_decoder_generate(mc_decoder* d, int32_t first_token, int32_t start_pos, int32
     step_state_h st;
     MC_HIP(hipMemcpyAsync(&st, d->state, sizeof st, hipMemcpyDeviceToHost, d->stream));
     MC_HIP(hipStreamSynchronize(d->stream));
-    if (!st.err) return MC_OK;
+    if (!st.err) {
+        d->note_clean_tokens(n);
+        return MC_OK;
+    }
     // A hand-off gave up somewhere in the chain.  While the ring has not turned inside this call every row the chain wrote sits
     // behind kv_len of the state in front of it: the call is repeated from there, exactly, on the launches that need no
     // co-residency.  Past max_seq_len the failed chain has overwritten rows its own first steps attend to: reported instead.
@@ -2836,6 +2864,18 @@ int32_t
 mc_decoder_handoff_fallbacks(const mc_decoder* d)
 {
     return d ? d->handoff_fallbacks : 0;
+}
+
+int32_t
+mc_decoder_handoff_rearms(const mc_decoder* d)
+{
+    return d ? d->handoff_rearms : 0;
+}
+
+int32_t
+mc_decoder_handoffs_active(const mc_decoder* d)
+{
+    return d && d->attn_fused_on ? 1 : 0;
 }
 
 size_t
@@ -3460,6 +3500,7 @@ mc_pipeline_generate(mc_pipeline* p, int32_t first_token, int32_t start_pos, int
             MC_HIP(hipStreamSynchronize(d->stream));
             s = d->check_handoffs(st);
             if (s != MC_OK) return s;
+            d->note_clean_tokens(n);
         }
         return MC_OK;
     }
@@ -3490,7 +3531,9 @@ mc_pipeline_generate(mc_pipeline* p, int32_t first_token, int32_t start_pos, int
     step_state_h st;
     MC_HIP(hipMemcpyAsync(&st, d->state, sizeof st, hipMemcpyDeviceToHost, d->stream));
     MC_HIP(hipStreamSynchronize(d->stream));
-    return d->check_handoffs(st);
+    s = d->check_handoffs(st);
+    if (s == MC_OK) d->note_clean_tokens(n);
+    return s;
 }
 
 // The prompt pass through the pipeline: the [len][dim] hidden rows hop stage to stage, the last stage's pick returns

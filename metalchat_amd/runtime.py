@@ -139,6 +139,8 @@ def capi() -> C.CDLL:
                                        C.POINTER(i32)]),
         "mc_decoder_gemv_kernel_name": (i32, [vp, C.c_char_p, C.c_char_p, sz]),
         "mc_decoder_handoff_fallbacks": (i32, [vp]),
+        "mc_decoder_handoff_rearms": (i32, [vp]),
+        "mc_decoder_handoffs_active": (i32, [vp]),
         "mc_decoder_derived_weight_bytes": (C.c_size_t, [vp]),
         "mc_decoder_launch_log": (i32, [vp, i32]),
         "mc_decoder_launch_log_read": (sz, [vp, C.c_char_p, sz]),
@@ -724,6 +726,13 @@ class Decoder:
     def handoff_fallbacks(self) -> int:
         """how often an in-launch hand-off gave up and the decoder fell back to launches that need no co-residency"""
         return int(capi().mc_decoder_handoff_fallbacks(self._h))
+
+    def handoff_rearms(self) -> int:
+        """how often the decoder went BACK to the hand-off launches after a fall-back (256 clean tokens, doubling; MC_HANDOFF_REARM)"""
+        return int(capi().mc_decoder_handoff_rearms(self._h))
+
+    def handoffs_active(self) -> bool:
+        return bool(capi().mc_decoder_handoffs_active(self._h))
 
     def launch_log(self, enable: bool = True):
         """start (and clear) / stop recording the names of the kernels this decoder launches"""

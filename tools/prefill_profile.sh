@@ -1,6 +1,6 @@
 #!/bin/bash
-# Runs ON THE GPU BOX: kernel durations of one prompt length through rocprofv3 (eager launches).  usage: tools/prefill_profile.sh r05 512 [env...]
-R=${1:-r05}; N=${2:-512}; shift 2
+# Runs ON THE GPU BOX: kernel durations of one prompt length through rocprofv3 (eager launches).  usage: tools/prefill_profile.sh r06 512 [env...]
+R=${1:-r06}; N=${2:-512}; shift $(( $# < 2 ? $# : 2 ))
 OUT=/root/repo/gpurun_out; mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
 for kv in "$@"; do export "$kv"; done
