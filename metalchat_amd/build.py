@@ -20,7 +20,7 @@ SO = os.path.join(LIB, "libmetalchat_hip.so")
 
 KERNEL_SOURCES = [os.path.join(CSRC, "kernels", f) for f in (
     "metalchat_kernels.hip", "ref_kernels.hip", "gemv_kernels.hip", "decode_kernels.hip", "attn_block_kernels.hip",
-    "synth_kernels.hip", "sampler_kernels.hip", "prefill_kernels.hip", "common.h", "handoff.h", "gemv.h", "synth.h", "pf_gemm8.h")]
+    "synth_kernels.hip", "sampler_kernels.hip", "prefill_kernels.hip", "common.h", "handoff.h", "gemv.h", "gemv_ksplit.h", "synth.h", "pf_gemm8.h")]
 HOST_SOURCES = [os.path.join(CSRC, f) for f in ("backend.cc", "decoder.cc", "model_io.cc", "text.cc", "json_min.h", "backend_impl.h")] + [
     os.path.join(CSRC, "kernels", "synth.h"),
     os.path.join(os.path.dirname(HERE), "include", "metalchat_hip.h")]

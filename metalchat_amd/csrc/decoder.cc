@@ -306,6 +306,7 @@ struct mc_decoder {
     bool attn_qkv_qkn_on = true; // MC_ATTN_QKV_QKN=0: gemma3's wq|wk|wv GEMV as a launch of its own in front of mc_attn_wo_qkn_* (A/B, parity)
     bool attn_wo_qkn_on = true;  // MC_ATTN_WO_QKN=0: gemma3's q/k-norm + rope + cache write + attention as mc_attn_fused_qkn_T, Wo as a GEMV of its own (A/B, parity)
     bool attn_qkn_on = true;     // MC_ATTN_QKN=0: gemma3's q/k-norm + rope + cache write as a launch of their own (mc_rope_kv_T) in front of the attention (A/B, parity)
+    bool lin_k4_on = true;       // MC_LIN_K4=0: Gemma-7B's w2 on the one-pair-per-wave kernel (mc_gemv_i4_bfloat_lin12_*) instead of the K-split one (A/B, parity)
     bool attn_qkv_on = true;     // MC_ATTN_QKV=0: wq|wk|wv as a launch of its own in front of mc_attn_wo_* (A/B, parity)
     // ---- what happens when an in-launch hand-off gives up (its workgroups were not resident together: another stream or process
     // holds part of the chip).  The launch sets state.err and completes; the host then LATCHES the decoder onto the launches
@@ -1034,8 +1035,13 @@ struct mc_decoder {
             if (wgs > cap) wgs = cap;
             if (wgs > cus) wgs = wgs / cus * cus;
         }
+        // long rows, few of them (Gemma-7B's w2: 1536 pairs of 12 KiB rows = one pair per wave on 192 CUs): the K range of a pair over four waves of a
+        // workgroup on EVERY CU (gemv_ksplit.h) -- at most eight pairs per workgroup, plain store or residual add, no adaptor
+        const unsigned cus_ = (unsigned)dev->prop.multiProcessorCount;
+        const bool k4 = lin && lin_k4_on && nch == 12 && pro == 0 && (epi == 0 || epi == 1) && !L.lora_cols && lin_waves == 8 &&
+                        (unsigned)L.out / 2 >= 4u * cus_ && ((unsigned)L.out / 2 + cus_ - 1) / cus_ <= 8u;
         if (lin) {
-            name += "_lin" + std::to_string(nch);
+            name += "_lin" + std::to_string(nch) + (k4 ? "k4" : "");
             // ONE workgroup of eight waves per CU: the activation row is staged once per CU and, with the raw barrier
             // between the row requests and the first weight requests (gemv.h MC_GEMV_XBAR), always ahead of the weight
             // stream in the CU's in-order memory pipe (w1|w3: 16.2 us against 17.3 with two four-wave workgroups)
@@ -1050,6 +1056,7 @@ struct mc_decoder {
             wgs = (np + waves - 1) / waves;
             if (wgs > cap) wgs = cap;
             if (wgs > cus) wgs = wgs / cus * cus;
+            if (k4) wgs = cus;
         }
         else if (lins) {}
         else if (m4) name += m4d ? "_m4d" : "_m4";
@@ -2150,6 +2157,7 @@ mc_decoder_create(mc_device* dev, mc_library* lib, mc_queue* q, const mc_decoder
     if (const char* e = getenv("MC_ATTN_WO")) d->attn_wo_on = atoi(e) != 0;
     if (const char* e = getenv("MC_HANDOFF_FAST")) d->handoff_fast = atoi(e) != 0;
     if (const char* e = getenv("MC_ATTN_QKV")) d->attn_qkv_on = atoi(e) != 0;
+    if (const char* e = getenv("MC_LIN_K4")) d->lin_k4_on = atoi(e) != 0;
     if (const char* e = getenv("MC_ATTN_QKN")) d->attn_qkn_on = atoi(e) != 0;
     if (const char* e = getenv("MC_ATTN_WO_QKN")) d->attn_wo_qkn_on = atoi(e) != 0;
     if (const char* e = getenv("MC_ATTN_QKV_QKN")) d->attn_qkv_qkn_on = atoi(e) != 0;

@@ -6,6 +6,7 @@
 //       4 = wq|wk|wv with RoPE + sink-cache write (`res` carries a qkv_epilogue*)
 //   lora_rank != 0: the row results also take the LoRA adaptation T(T(B a) * scale), a = T(A x)
 #include "gemv.h"
+#include "gemv_ksplit.h"
 
 using namespace mc;
 using namespace mc::gemv;
@@ -104,6 +105,17 @@ MC_GEMV_LIN_SET(mc_gemv_i4_bfloat_lin2, MC_LIN2_CFG)   // K = 4096
 MC_GEMV_LIN_SET(mc_gemv_i4_bfloat_lin4, MC_LIN4_CFG)   // K = 8192
 MC_GEMV_LIN_SET(mc_gemv_i4_bfloat_lin7, MC_LIN7_CFG)   // K = 14336
 MC_GEMV_LIN_SET(mc_gemv_i4_bfloat_lin12, MC_LIN12_CFG) // K = 24576 (Gemma-7B's w2)
+// ... with the K range of a pair cut over four waves of the workgroup (gemv_ksplit.h, round 6): mc_gemv_i4_bfloat_lin12k4_p0_e{0,1}
+#define MC_GEMV_K4(NAME, NCH, EPI)                                                                \
+    extern "C" __global__ void __launch_bounds__(512)                                             \
+    NAME(const void* w, const void* scales, const void* x, void* y, const void* res,             \
+         const void* norm_w, uint32_t out_rows, uint32_t in, uint32_t group, float eps, float mu, \
+         const void* lora_a, const void* lora_b, uint32_t lora_rank, float lora_scale)            \
+    {                                                                                             \
+        body_ksplit4<NCH, EPI>(w, scales, x, y, res, out_rows, group);                            \
+    }
+MC_GEMV_K4(mc_gemv_i4_bfloat_lin12k4_p0_e0, 12, 0)
+MC_GEMV_K4(mc_gemv_i4_bfloat_lin12k4_p0_e1, 12, 1)
 // K = 3072 (Gemma-7B's QKV and w1|w3): rows of 1.5 KiB, two to a 3 KiB super row (gemv.h LSPLIT)
 #define MC_GEMV_LINS(NAME, PRO, EPI)                                                              \
     extern "C" __global__ void __launch_bounds__(64 * MC_LIN_WAVES)                               \

@@ -9,8 +9,24 @@ if ROOT not in sys.path:
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
+def pytest_addoption(parser):
+    parser.addoption("--runslow", action="store_true", default=False,
+                     help="also run the GPU cases marked `slow` (contexts and paths no BASELINE config names; MC_RUN_SLOW=1 does the same)")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: a GPU case outside the BASELINE configs (wide ranges at other contexts, the opt-in library GEMM): "
+                                       "skipped unless --runslow / MC_RUN_SLOW=1, so that `-m gpu` stays inside the driver's step limit")
+
+
+def pytest_collection_modifyitems(config, items):
+    if config.getoption("--runslow") or os.environ.get("MC_RUN_SLOW") == "1":
+        return
+    skip = pytest.mark.skip(reason="slow: outside the BASELINE configs (--runslow or MC_RUN_SLOW=1)")
+    for item in items:
+        if "slow" in item.keywords:
+            item.add_marker(skip)
 
 
 @pytest.fixture(scope="session")

@@ -326,7 +326,7 @@ def test_end_to_end_against_the_oracle_at_full_width(acc, name):
 def test_int8_long_context_against_the_oracle_at_full_width(acc, monkeypatch):
     # BASELINE configs[2] territory: int8-held weights, a long context.  One Llama-3-8B-wide block,
     # max_seq_len 4096 with P.V forced into 4 ranges of cache slots + the reduce launch (the layout a
-    # context of 8192 slots takes by itself), a 600-token prompt
+    # context of 8192 slots takes by itself), a 320-token prompt (two row tiles of the prompt GEMM; 600 tokens cost the oracle 55 s)
     # through the prompt pass (128 x 128 MFMA GEMMs on int8 weights, split-K) and decode steps behind
     # it -- all against the oracle on the regenerated weights.
     import metalchat_amd as mc
@@ -338,12 +338,12 @@ def test_int8_long_context_against_the_oracle_at_full_width(acc, monkeypatch):
     om = mo.Model(cfg, weights)
     dec = mc.Decoder(acc, **mg.decoder_kwargs(cfg, weight_format=mc.WFMT_I8, group_size=128))
     dec.init_synthetic(SEED)
-    n = 600
+    n = 320
     ptoks = np.random.default_rng(4).integers(0, cfg["vocab"], n)
     otok, ologits = om.forward(ptoks, 0, 0)
     gtok = dec.prefill(ptoks, 0)
-    # 600 rows feed each other through attention: measured 0.006 vector-wise and up to 2.5 scaled bf16
-    # steps on single logits (0.005 / 2.05 at 100 rows)
+    # the rows feed each other through attention: measured 0.006 vector-wise and up to 2.5 scaled bf16
+    # steps on single logits at 600 rows (0.005 / 2.05 at 100 rows)
     parity.check(BF16, dec.logits(), ologits, rel=7.8e-3, max_ulp=3, max_frac=0.9, what="int8 prompt logits")
     gk, gv = dec.export_kv(0)
     ok, ov = om.kv(0)

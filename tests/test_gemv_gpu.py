@@ -222,7 +222,7 @@ def test_gemv_lora_adaptation_term(acc, holder, dt):
     assert not np.array_equal(plain, got)
 
 
-@pytest.mark.parametrize("group", [128, 256])
+@pytest.mark.parametrize("group", [128, pytest.param(256, marks=pytest.mark.slow)])   # (BASELINE's group; 256: the same sweep, 16 s)
 def test_gemv_matrix_pipe_dequant_is_exact_for_every_weight(acc, holder, group):
     """Q_M4D dequantises on v_mfma_f32_4x4x4_16b_bf16 and gathers the activations through
     ds_read_b64_tr_b16.  A one-hot row x = e_k makes y[o] = Wd[o, k], so every position of the

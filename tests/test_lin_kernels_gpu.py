@@ -418,3 +418,54 @@ def test_gemma_post_norm_prologue(acc, models, family):
     got = launch(acc, kname(family, 2, 3), wptr, sptr, x, rows // 2, rows, K, grp(family), norm=nw, wgs=5, lds=lds_bytes(family, K), mu=mu, **pn)
     parity.exact(hb.download(np.uint16, K), h.reshape(-1), f"{family} p2_e3 hidden row")
     parity.check(BF16, got, ref.reshape(-1), rel=3e-3, max_ulp=2, max_frac=0.3, what=f"{family} p2_e3")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Round 6: long rows, few of them -- the K range of a row pair over four waves of a workgroup (gemv_ksplit.h, mc_gemv_i4_bfloat_lin12k4_p0_e{0,1}:
+# Gemma-7B's w2).  The per-weight arithmetic is the linear-order kernels'; a row's fp32 sum is four chains of three chunks added in quarter
+# order instead of one chain of twelve: the bound of `_lin3s_` against the classic family (one bf16 step, <= 1 % of the outputs).
+K4 = "i4_lin12k4"
+
+
+def k4_lds():
+    return lds_bytes("i4_lin12", 24576)
+
+
+def test_ksplit_store_and_residual_epilogues_match_the_oracle(acc, models):
+    cfg, w, dec = models.get("i4_lin12", "w2")
+    K = 24576
+    spec = w["layers"][0]["w2"]
+    rng = np.random.default_rng(21)
+    x = mo.encode(BF16, rng.normal(0, 1, K).astype(np.float32))
+    res = mo.encode(BF16, rng.normal(0, 1, 256).astype(np.float32))
+    wptr, sptr, rows, inf, ng = dec.weight_ptrs(0, "w2")
+    ref = oracle_linear(BF16, spec, x)
+    ref_res = np.zeros((1, 256), np.uint16)
+    mo.add(BF16, mo.layout((1, 256)), ref_res, mo.layout((1, 256)), res.reshape(1, -1), mo.layout((1, 256)), ref.reshape(1, -1))
+    lin = launch(acc, kname("i4_lin12", 0, 0), wptr, sptr, x, rows, rows, K, GROUP, wgs=16, lds=k4_lds())
+    # 128 row pairs: 16 workgroups (8 pairs each: four per half), 21 (7 and 6: halves of 4 + 3 and 3 + 3), 32 (4), 40 (4 and 3), 128 (one: half 1 idle)
+    for wgs in (16, 21, 32, 40, 128):
+        got = launch(acc, kname(K4, 0, 0), wptr, sptr, x, rows, rows, K, GROUP, wgs=wgs, lds=k4_lds())
+        strict(got, ref, f"{K4} p0_e0 wgs {wgs}")
+        r = parity.check(BF16, got, lin, rel=1e-3, max_ulp=1, max_frac=0.01, scale_aware=False, what=f"{K4} vs lin12, wgs {wgs}")
+        got = launch(acc, kname(K4, 0, 1), wptr, sptr, x, rows, rows, K, GROUP, res=res, wgs=wgs, lds=k4_lds())
+        strict(got, ref_res.reshape(-1), f"{K4} p0_e1 wgs {wgs}")
+
+
+def test_ksplit_one_hot_rows_return_every_weight_bit_for_bit(acc, models):
+    cfg, w, dec = models.get("i4_lin12", "w2")
+    K = 24576
+    spec = w["layers"][0]["w2"]
+    wptr, sptr, rows, inf, ng = dec.weight_ptrs(0, "w2")
+    wd = np.zeros((rows, K), np.uint16)
+    sc = np.ascontiguousarray(spec["scales"].reshape(-1), np.float32)
+    mo.hadamard_broadcast(BF16, 1, mo.layout((rows * ng, GROUP)), wd, mo.layout((rows * ng, GROUP)), spec["weight"], mo.layout((rows * ng,)), sc)
+    rows_used = 60   # 30 pairs over 4 workgroups: 8, 8, 7, 7 -- halves of 4 + 4 and 4 + 3
+    ks = one_hot_columns(K, 2048)
+    xb = acc.alloc(K * 2)
+    for k in ks[::3] + [6143, 6144, 12287, 12288, 18431, 18432]:   # (every third column of the sweep, and the quarters' edges)
+        x = np.zeros(K, np.uint16)
+        x[k] = 0x3F80  # 1.0: three of a row's four quarter sums are exact zeros
+        xb.upload(x)
+        got = launch(acc, kname(K4, 0, 0), wptr, sptr, xb, rows_used, rows_used, K, GROUP, wgs=4, lds=k4_lds())
+        assert np.array_equal(got, wd[:rows_used, k]), f"{K4} column {k}: rows {np.flatnonzero(got != wd[:rows_used, k])[:8]}"

@@ -572,6 +572,7 @@ def test_wide_long_prompt_splits_k_in_the_ping_pong_gemm(acc):
     check_against_oracle(acc, cfg, weights, dict(weight_format=2, group_size=128), tokens, follow=1, expect_kernel="mc_pf_gemm8_i4_bfloat_e2")
 
 
+@pytest.mark.slow   # (hipBLASLt is opt-in since round 5, MC_PF_BLASLT=1: a comparison aid, not the product path)
 # ---- the library GEMM of long prompts (decoder.cc gemm_lib: hipBLASLt on the dequantised bfloat16 copy of a matrix).  The decoder
 # takes it -- ONLY when asked to, MC_PF_BLASLT=1: an opt-in comparison since round 5, the default path builds no dequantised copy --
 # where a launch has >= 48 tiles of 256 x 256 (w1|w3 of Llama-3-8B from 256 rows on, every matrix from 768); MC_PF_BLASLT=2 takes it for every
@@ -591,6 +592,7 @@ def test_library_gemm_of_long_prompts_matches_oracle(acc, n, quant, fmt, group, 
     check_against_oracle(acc, cfg, weights, dict(weight_format=fmt, group_size=group), tokens, follow=2, expect_kernel="hipblasLtMatmul")
 
 
+@pytest.mark.slow   # (hipBLASLt is opt-in since round 5, MC_PF_BLASLT=1: a comparison aid, not the product path)
 def test_library_gemm_is_the_decoders_choice_only_where_a_launch_has_enough_tiles(acc, monkeypatch, request):
     """512 rows on a model with a 16384-row w1|w3: that GEMM alone goes to the library (128 tiles of 256 x 256 >= 48; the others have 2-8), the others keep
     the prompt kernels; the token and the rows agree with the kernels-only prompt (MC_PF_BLASLT=0) like two orders of the same
@@ -628,6 +630,7 @@ def test_library_gemm_is_the_decoders_choice_only_where_a_launch_has_enough_tile
     parity.check(BF16, out["1"][1], out["0"][1], rel=rel, max_ulp=2, max_frac=frac, what="logits, library vs kernels")
 
 
+@pytest.mark.slow   # (hipBLASLt is opt-in since round 5, MC_PF_BLASLT=1: a comparison aid, not the product path)
 def test_library_gemm_under_a_gemma3_block(acc, monkeypatch, request):
     """gemma3 (gelu, post-norms, sliding window: nn/gemma.h:110-137): the plain-store GEMMs of its block through the library"""
     if in_torch_free_child(request):
