@@ -297,6 +297,9 @@ struct mc_decoder {
     unsigned long long* attn_psum_g = nullptr; // [H][nsplit]            partial softmax denominators
     unsigned long long* attn_slab_g = nullptr; // [KV][nsplit][n_rep][hd] fp32 partial P.V sums
     unsigned long long* attn_row_g = nullptr;  // [H * hd / 2]          the finished attention row, two bf16 per granule (mc_attn_wo_*)
+    unsigned long long* attn_hid_g = nullptr;  // [dim / 2]             the hidden row behind Wo, for the w1|w3 phase of mc_attn_qkv_wo_w13_w_* (hand-off D)
+    bool chain_w13_on = true;    // MC_CHAIN_W13=0: ffn_norm + w1|w3 + act*mul as a launch of its own behind the plain-weight attention block (A/B, parity)
+    int occ_w13 = -1;
     unsigned long long* attn_qkv_g = nullptr;  // [KV][(n_rep + 2) hd / 2] the step's rotated queries and K / V row, two bf16 per granule (mc_attn_qkv_wo_*)
     // MC_ATTN_QKV_ONLY=1: the 70B shapes' wq|wk|wv GEMV inside the attention launch (mc_attn_qkv_i4_bfloat_hd128_q4).  Built in round 5 as VERDICT r04
     // item 2 (iv) asked, bit for bit the two launches, and NOT faster: 21.25 us against 11.65 + 9.04 in the trace (profiles/r05_kernel_stats_70b_qkvin.csv),
@@ -731,6 +734,7 @@ struct mc_decoder {
         occ_qkv_qkn = hd == 256 ? ask("mc_attn_qkv_wo_qkn_i4_bfloat_hd256_k2_p2_t2", 512) : 0;
         occ_qkv_only = hd == 128 ? ask("mc_attn_qkv_i4_bfloat_hd128_q4", 512) : 0;
         occ_wo_i4_wide = hd == 128 ? ask("mc_attn_qkv_wo_i4_bfloat_hd128_k2_q2_t4", 512) : 0;
+        occ_w13 = hd == 64 ? ask("mc_attn_qkv_wo_w13_w_bfloat_hd64_k4_q4_f5", 512) : 0;
         (void)hipGetLastError();
     }
     // a hand-off gave up: report nothing yet, make the NEXT launches independent of co-residency
@@ -872,6 +876,22 @@ struct mc_decoder {
             if (grid <= (unsigned)dev->prop.multiProcessorCount && pg % ns == 0 && pg / ns <= 8 && (unsigned)L.wo.out / 2 <= 8u * grid) return t;
         }
         return 0;
+    }
+
+    // ... AND ffn_norm + w1|w3 + act*mul as the next phase of that launch (round 6, mc_attn_qkv_wo_w13_w_bfloat_hd64_k4_q4_f{4,5}, attn_block_kernels.hip):
+    // behind the Wo phase half the waves of every workgroup fetch w1|w3 row pairs into registers while the other half waits for the hidden row.
+    // 64-slot ranges, exactly one workgroup per CU, w1|w3 plain bfloat with K = 2048, no adaptor.  Returns the pairs per fetcher wave (4 or 5), 0 = no.
+    int
+    attn_qkv_wo_w13_w_fetch(const layer_w& L) const
+    {
+        if (!chain_w13_on || !attn_hid_g || occ_w13 <= 0 || attn_qkv_wo_w_tiles(L) != 1 || L.w13.fmt != MC_WFMT_T || L.w13.lora_cols) return 0;
+        const unsigned grid = (unsigned)(nsplit * (cfg.n_kv_heads << kv_virtual_shift()));
+        if (cfg.dim != 2048 || L.w13.in != 2048 || L.w13.out % 2 || grid != (unsigned)dev->prop.multiProcessorCount || lin_waves != 8) return 0;
+        const unsigned nb = ((unsigned)L.w13.out / 2 + grid - 1) / grid; // pairs of the fullest workgroup
+        // (the fetchers F each -- what hand-off D's ~ 4 us bring in --, the pollers the rest, at most F each: TinyLlama's 22 = 4 x 4 + (2, 2, 1, 1),
+        //  Llama-3.2-1B's 32 = 4 x 5 + 4 x 3)
+        const unsigned f = nb > 24u ? 5u : 4u;
+        return nb <= 8u * f && nb >= 4u * f ? (int)f : 0;
     }
 
     // ... the same launch for INT8 weights (round 5, mc_attn_qkv_wo_i8_bfloat_hd128_k4_q4_t{1,4}: Llama-3-8B int8): rows of 4 KiB (K = 4096),
@@ -1151,7 +1171,20 @@ struct mc_decoder {
             const bool qkv_in = qkv_w_in || i8_tiles || i4_in || i4_tiles;
             bool qkn_in = false, gq = false, q_only = false;
             int qkn_wo = 0;
-            if (qkv_in) {
+            const int chain_f = w_tiles == 1 ? attn_qkv_wo_w13_w_fetch(L) : 0;
+            if (chain_f) {
+                // ... and ffn_norm, w1|w3, act*mul (transformer.h:135-137, 53-59) too: the block up to the gate row in ONE launch
+                const int vsh = kv_virtual_shift();
+                s = launch("mc_attn_qkv_wo_w13_w_bfloat_hd64_k4_q4_f" + std::to_string(chain_f), (unsigned)(nsplit * (KV << vsh)), 1, 1, 512, 0,
+                           pack((const void*)L.kc, (const void*)L.vt, attn_out, attn_psum_g, attn_slab_g, attn_row_g, attn_qkv_g, state,
+                                (uint32_t)(n_rep >> vsh), (uint32_t)(KV << vsh), (uint32_t)cfg.max_seq_len, scale_T, (uint32_t)nsplit, (uint32_t)(li + 1),
+                                (const void*)L.wo.w, (const void*)L.wo.scales, x, hidden, (uint32_t)L.wo.out, (uint32_t)L.wo.group,
+                                (const void*)L.attention_norm, (const void*)L.qkv.w, (const void*)L.qkv.scales,
+                                (const float*)rope_cos[L.rope_table], (const float*)rope_sin[L.rope_table], cfg.norm_eps, mu,
+                                (uint32_t)((vsh ? handoff_fast : handoff_fast_here()) ? 1 : 0), (void*)nullptr, (uint32_t)vsh, attn_hid_g,
+                                (const void*)L.w13.w, (const void*)L.ffn_norm, gate, (uint32_t)L.w13.out, (void*)nullptr));
+                if (s != MC_OK) return s;
+            } else if (qkv_in) {
                 // attention_norm, wq|wk|wv, rope, cache write, scores, softmax, P.V, wo + residual (transformer.h:130-133,
                 // attention.h:170-205) in ONE launch: every hand-off but the last stays inside one kv head
                 // (plain weights: fewer than 8 kv heads are launched as 8 virtual ones, kv_virtual_shift)
@@ -1344,7 +1377,9 @@ struct mc_decoder {
             }
             }
             // ffn_norm + w1|w3 + act*mul           (transformer.h:135-137, 53-59)
-            if (gemma && fuse_pn) {
+            if (chain_f) {
+                s = MC_OK; // (a phase of the launch above)
+            } else if (gemma && fuse_pn) {
                 // attention post-norm + residual (-> hidden_b) + ffn_norm in the prologue
                 s = gemv(L.w13, 2, 3, proj, gate, L.pn_attn, L.ffn_norm, mu);
             } else {
@@ -2158,6 +2193,7 @@ mc_decoder_create(mc_device* dev, mc_library* lib, mc_queue* q, const mc_decoder
     if (const char* e = getenv("MC_HANDOFF_FAST")) d->handoff_fast = atoi(e) != 0;
     if (const char* e = getenv("MC_ATTN_QKV")) d->attn_qkv_on = atoi(e) != 0;
     if (const char* e = getenv("MC_LIN_K4")) d->lin_k4_on = atoi(e) != 0;
+    if (const char* e = getenv("MC_CHAIN_W13")) d->chain_w13_on = atoi(e) != 0;
     if (const char* e = getenv("MC_ATTN_QKN")) d->attn_qkn_on = atoi(e) != 0;
     if (const char* e = getenv("MC_ATTN_WO_QKN")) d->attn_wo_qkn_on = atoi(e) != 0;
     if (const char* e = getenv("MC_ATTN_QKV_QKN")) d->attn_qkv_qkn_on = atoi(e) != 0;
@@ -2223,6 +2259,7 @@ mc_decoder_create(mc_device* dev, mc_library* lib, mc_queue* q, const mc_decoder
         A(d->attn_psum_g, (size_t)H * d->nsplit * 8 * 2);
         A(d->attn_slab_g, (size_t)H * hd * d->nsplit * 8 * 2);
         A(d->attn_row_g, (size_t)H * hd / 2 * 8);
+        A(d->attn_hid_g, (size_t)dim / 2 * 8);
         A(d->attn_qkv_g, (size_t)(H + 2 * std::max(KV, 8)) * hd / 2 * 8 * 2); // (virtual kv heads: a K and a V row per virtual head)
     }
     A(d->taps, (size_t)(d->n_own + 1) * dim * tb);

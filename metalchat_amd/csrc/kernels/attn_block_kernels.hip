@@ -759,7 +759,9 @@ struct gemma_extra {
     void* h_out;                  // (QKN = 3) where workgroup 0 leaves that hidden row
     const bf16_t *q_norm, *k_norm;
 };
-template <int HD, int LNCH, int QN = 0, int WB = 0, int TT = 1, int QKN = 0>
+// CH = 1 (round 6, mc_attn_qkv_wo_w13_w_*): a phase follows in the same launch -- every stored pair of the output row is also published as a
+// {2 x bf16, tag} granule in `hid_g` (hand-off D)
+template <int HD, int LNCH, int QN = 0, int WB = 0, int TT = 1, int QKN = 0, int CH = 0>
 __device__ __forceinline__ void
 attn_wo_body(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const bf16_t* __restrict__ vt, bf16_t* __restrict__ attn_out,
              unsigned long long* psum_g, unsigned long long* slab_g, unsigned long long* row_g, step_state* st, uint32_t n_rep,
@@ -770,8 +772,9 @@ attn_wo_body(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const 
              // granules of hand-off Q
              const void* __restrict__ qnorm_w = nullptr, const void* __restrict__ qkv_w = nullptr, const void* __restrict__ qkv_s = nullptr,
              const float* fcos = nullptr, const float* fsin = nullptr, unsigned long long* qkv_g = nullptr, float eps = 0.0f, float mu = 0.0f,
-             uint32_t kv_shift = 0, gemma_extra gx = gemma_extra())
+             uint32_t kv_shift = 0, gemma_extra gx = gemma_extra(), unsigned long long* hid_g = nullptr)
 {
+    static_assert(CH == 0 || (QN != 0 && QKN == 0), "a chained phase: behind a llama launch with wq|wk|wv inside");
     constexpr uint32_t K = WB == 1 ? 512u * LNCH : (WB == 2 ? 1024u * LNCH : 2048u * LNCH);
     constexpr uint32_t WPK = WB == 1 ? 8u : (WB == 2 ? 16u : 32u); // weights of a lane's 16-byte packet
     constexpr uint32_t CHUNK_LDS = 2048 * 2 / 16 * 17;  // a chunk of the row in LDS: 16 bytes of padding per 256 (gemv.h Q_M4D)
@@ -1021,6 +1024,7 @@ attn_wo_body(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const 
                 vb = __uint_as_float(wres[i] & 0xFFFF0000u) + vb;
             }
             reinterpret_cast<uint32_t*>(y)[pb + i] = pack_bf16x2(va, vb);
+            if constexpr (CH != 0) granule_store(hid_g + pb + i, epoch_tag, pack_bf16x2(va, vb)); // hand-off D
         }
     }
     stamp(7);
@@ -1179,3 +1183,224 @@ MC_ATTN_WO(mc_attn_wo_i4_bfloat_hd128_k4, 128, 4)  // tuning builds (-DMC_ATTN_W
 #endif
 MC_ATTN_WO(mc_attn_wo_i4_bfloat_hd64_k1, 64, 1)    // 32 heads x 64
 MC_ATTN_WO(mc_attn_wo_i4_bfloat_hd256_k2, 256, 2)  // Gemma-7B shapes: 16 heads x 256
+
+// ------------------------------------------------------------------------------------------
+// Round 6: the attention block AND ffn_norm + w1|w3 + SiLU * mul (include/metalchat/nn/transformer.h:130-137, 53-59) in one launch, for PLAIN
+// bfloat weights (nn::linear; TinyLlama-1.1B, Llama-3.2-1B): mc_attn_qkv_wo_w13_w_bfloat_hd64_k4_q4_f{4,5}.
+//
+// The same chain was built three ways for the int4 headline first and lost every time (tools/experiments/README.md, round 6): with every weight
+// on chip the exact int4 dequantisation alone takes the eight waves 6.6 - 8 us per workgroup, as long as the stand-alone launch needs to stream
+// the matrix beside it.  Plain bfloat weights have no such floor -- four v_dot2_f32_bf16 per 16-byte packet -- so here a chained phase costs
+// what it cannot have on chip when the row arrives, and the stand-alone launch's boundary + prologue + cold start (~ 3 us of its 9.6) go.
+// What those builds' timelines taught is how to spend hand-off D's ~ 4 us (the hidden row from 1024 Wo pairs on 256 CUs to every CU):
+//   * nothing is requested during the attention phases (a loader beside them sits in the polling CUs' own memory queues);
+//   * behind the Wo phase waves 4-7 (the FETCHERS) request their F row pairs -- 8 KiB each, into registers -- and poll nothing, while waves 0-3
+//     (the POLLERS) wait for the row; a wave's vector-memory results return in issue order, so the pollers request their pairs only
+//     when the row is in, and multiply them as they arrive; the fetchers' F pairs are then long in;
+//   * the loads of this phase are inline asm with hand-counted waits: one request site for both kinds of wave (reached at different
+//     times), no load behind a branch.
+//
+// Numerics: bit for bit the two launches it replaces.  The attention block is the same code (attn_wo_body, CH = 1: its Wo epilogue also
+// publishes the pair as a granule).  The w1|w3 phase is mc_gemv_w_bfloat_ling4_p1_e2's arithmetic (gemv.h LGEN): packet p's sum of squares
+// formed by one thread (p < 256), the sums of packets 64 v .. 64 v + 63 added by wave_sum_dpp in lane order, the eight wave sums in order
+// (the last four are zeros there too), the normalised row staged in natural order; a row = its four packets in order through four
+// v_dot2_f32_bf16 each into ONE fp32 sum, one wave sum; the epilogue of gemv.h finish_pair (EPI_SILU_MUL).  Which wave multiplies a pair
+// does not change a bit of it.
+// ------------------------------------------------------------------------------------------
+namespace {
+
+// stamps (tl2 != null: tools/attn_w13_timeline.py), per workgroup, s_memrealtime:
+//   40 Wo done (thread 0)   41 hand-off D: row gathered (thread 0)   42 row staged   44 wave 0 (poller) stored   45 wave 4 (fetcher) stored
+constexpr int TL2_STRIDE = 48;
+
+typedef uint32_t w13_v4 __attribute__((ext_vector_type(4)));
+// Loads the compiler does not count (its own counted waits stay exact for ITS loads; these are waited for by hand, below)
+__device__ __forceinline__ void w13_load16(w13_v4& dst, const void* p)
+{
+    asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(dst) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void w13_load16_plain(w13_v4& dst, const void* p)
+{
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+}
+// everything but the N youngest vector-memory operations of this wave has completed; the values pass THROUGH the wait, so no use of them can be scheduled in front of it
+template <int N> __device__ __forceinline__ void w13_wait(w13_v4& a, w13_v4& b, w13_v4& c, w13_v4& d)
+{
+    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N) : "memory");
+}
+template <int N> __device__ __forceinline__ void w13_wait(w13_v4& a)
+{
+    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(a) : "n"(N) : "memory");
+}
+
+// F: pairs of each fetcher wave; the pollers share what is left of the workgroup's pairs (the host: at most F each)
+template <int HD, int F>
+__device__ __forceinline__ void
+attn_qkv_wo_w13_w_body(const bf16_t* kc, const bf16_t* vt, bf16_t* attn_out, unsigned long long* psum_g, unsigned long long* slab_g, unsigned long long* row_g,
+                       unsigned long long* qkv_g, step_state* st, uint32_t n_rep, uint32_t KV, uint32_t max_seq, float scale, uint32_t nsplit, uint32_t layer_tag,
+                       const void* wo_w, const void* wo_s, const bf16_t* x, bf16_t* y, uint32_t out_rows, uint32_t group, const void* qnorm_w,
+                       const void* qkv_w, const void* qkv_s, const float* fcos, const float* fsin, float eps, float mu, uint32_t fastpath,
+                       unsigned long long* tl, uint32_t kv_shift, unsigned long long* hid_g, const void* __restrict__ w13_w, const void* __restrict__ ffn_norm,
+                       bf16_t* __restrict__ gate, uint32_t ffn_rows, unsigned long long* tl2)
+{
+    constexpr uint32_t KF = 2048u, ROWB = 4096u; // dim 2048: rows of 4 KiB, 256 packets of the hidden row
+    constexpr int PK = 4;                        // packets (KiB) per row
+    __shared__ __attribute__((aligned(16))) char xs13[KF * 2];
+    __shared__ float red13[16];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    unsigned long long* mytl = tl2 ? tl2 + (size_t)blockIdx.x * TL2_STRIDE : nullptr;
+
+    // ================= the attention block ...
+    attn_wo_body<HD, 4, 4, 1, 1, 0, 1>(nullptr, kc, vt, attn_out, psum_g, slab_g, row_g, st, n_rep, KV, max_seq, scale, nsplit, layer_tag, wo_w, wo_s, x, y,
+                                       out_rows, group, 1u, fastpath, tl, qnorm_w, qkv_w, qkv_s, fcos, fsin, qkv_g, eps, mu, kv_shift, gemma_extra(), hid_g);
+    auto stamp2 = [&](int i, uint32_t t) {
+        if (mytl && tid == t) mytl[i] = __builtin_amdgcn_s_memrealtime();
+    };
+    stamp2(40, 0);
+    // ================= ... and ffn_norm + w1|w3 + SiLU * mul
+    const bool poller = wave < 4u;
+    // the workgroup's pairs: equal contiguous shares of the launch (a remainder to the first workgroups); the fetchers F each, the pollers the rest
+    const uint32_t NP = ffn_rows / 2, G = gridDim.x, wq_ = NP / G, wrem = NP - wq_ * G;
+    const uint32_t nb = wq_ + (blockIdx.x < wrem ? 1u : 0u), sb0 = blockIdx.x * wq_ + min(blockIdx.x, wrem);
+    const uint32_t nf = min(nb, 4u * (uint32_t)F), rest = nb - nf, w4 = wave & 3u;
+    const uint32_t pb = poller ? sb0 + nf + w4 * (rest >> 2) + min(w4, rest & 3u) : sb0 + min(nf, w4 * (uint32_t)F);
+    const uint32_t cnt = poller ? (rest >> 2) + (w4 < (rest & 3u) ? 1u : 0u) : min((uint32_t)F, nf - min(nf, w4 * (uint32_t)F));
+    // ---- hand-off D (pollers): the hidden row the Wo phases of ALL workgroups finished; thread t < 256 gathers packet t = granules 4 t .. 4 t + 3
+    // (one watched granule and ~ 0.4 us between looks while the row is not there, then one sweep: hand-off C)
+    const uint32_t epoch_tag = st->epoch * 256u + layer_tag;
+    w13_v4 xr = w13_v4{0, 0, 0, 0};
+    if (poller) { // (wave-uniform; every load inside is waited for inside)
+        uint32_t val[4];
+        handoff_wait w;
+        for (;;) {
+            const bool seen = (uint32_t)(granule_load(hid_g + 4u * tid + 3u) >> 32) == epoch_tag;
+            if (__all(seen) || w.expired(st, 0xE0000000u | layer_tag)) break;
+            __builtin_amdgcn_s_sleep(MC_HANDOFF_C_SLEEP);
+        }
+        for (;;) {
+            bool ok = true;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const unsigned long long g = granule_load(hid_g + 4u * tid + i);
+                ok = ok && (uint32_t)(g >> 32) == epoch_tag;
+                val[i] = (uint32_t)g;
+            }
+            if (__all(ok) || w.expired(st, 0xE0000000u | layer_tag)) break;
+        }
+        xr = w13_v4{val[0], val[1], val[2], val[3]};
+    }
+    stamp2(41, 0);
+    // ---- every wave's requests, in ONE place (the fetchers reach it ~ 4 us before the pollers): the norm weights of the packet this thread stages,
+    // the wave's pairs (a pair the wave does not have reads one broadcast line: masks, not selects)
+    w13_v4 nr;
+    w13_v4 wreg[F][2 * PK];
+    w13_load16_plain(nr, static_cast<const char*>(ffn_norm) + (size_t)(tid & 255u) * 16u);
+#pragma unroll
+    for (int i = 0; i < F; i++) {
+        const uint32_t lm = 0u - (uint32_t)((uint32_t)i < cnt ? 1u : 0u);
+        const uint64_t lm64 = ((uint64_t)lm << 32) | lm;
+        const char* a = static_cast<const char*>(w13_w) + (((uint64_t)(pb + (uint32_t)i) * 2u * ROWB) & lm64) + ((lane * 16u) & lm);
+#pragma unroll
+        for (int t = 0; t < 2 * PK; t++) w13_load16(wreg[i][t], a + ((t * 1024u) & lm));
+    }
+    // (issued behind this point: nothing until the epilogue's store -- the counts below are exact)
+    constexpr int NW = F * 2 * PK; // weight loads, the youngest
+    // ---- ffn_norm on the way into LDS (kernel/rmsnorm.metal:52-95; gemv.h LGEN, the build-time prologue: the same additions in the same order)
+    {
+        const uint32_t vv[4] = {xr.x, xr.y, xr.z, xr.w};
+        float s1 = 0.0f;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const float a = asf(vv[e] << 16), b = asf(vv[e] & 0xFFFF0000u);
+            s1 += a * a;
+            s1 += b * b;
+        }
+        float ss = 0.0f;
+        ss += poller ? s1 : 0.0f; // (the stand-alone kernel's threads 256 .. 511 add nothing)
+        const float wsum_ = wave_sum_dpp(ss);
+        if (lane == 0) red13[wave] = wsum_;
+        lds_barrier();
+        float tot = 0.0f;
+#pragma unroll
+        for (uint32_t i = 0; i < 8u; i++) tot += red13[i];
+        const float inv = 1.0f / sqrtf(tot / (float)KF + eps);
+        if (poller) {
+            w13_wait<NW>(nr);
+            const uint32_t wv[4] = {nr.x, nr.y, nr.z, nr.w};
+            uint32_t o[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const float a = (mu + asf(wv[e] << 16)) * asf(vv[e] << 16) * inv;
+                const float b = (mu + asf(wv[e] & 0xFFFF0000u)) * asf(vv[e] & 0xFFFF0000u) * inv;
+                o[e] = pack_bf16x2(a, b);
+            }
+            reinterpret_cast<w13_v4*>(xs13)[tid] = w13_v4{o[0], o[1], o[2], o[3]}; // (natural order)
+        }
+    }
+    lds_barrier();
+    stamp2(42, 0);
+    // ---- the lane's slices of the row, once per wave: packet 64 c + lane of chunk c
+    uint4 xq[PK];
+#pragma unroll
+    for (int c = 0; c < PK; c++) xq[c] = *reinterpret_cast<const uint4*>(xs13 + (size_t)(c * 64 + (int)lane) * 16);
+    // ---- the wave's pairs as they arrive: a row = its four packets in order (gemv.h mac<WF_T>: four v_dot2_f32_bf16 per packet), one wave sum
+    float my_a = 0.0f, my_b = 0.0f;
+    auto pair_step = [&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        w13_wait<NW - 2 * PK * (i + 1)>(wreg[i][0], wreg[i][1], wreg[i][2], wreg[i][3]);
+        w13_wait<NW - 2 * PK * (i + 1)>(wreg[i][4], wreg[i][5], wreg[i][6], wreg[i][7]);
+        if ((uint32_t)i < cnt) { // (wave-uniform; no load inside)
+            float rs[2];
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                float a = 0.0f;
+#pragma unroll
+                for (int c = 0; c < PK; c++) {
+                    const w13_v4 wv = wreg[i][PK * r + c];
+                    a = dot2(wv.x, xq[c].x, a);
+                    a = dot2(wv.y, xq[c].y, a);
+                    a = dot2(wv.z, xq[c].z, a);
+                    a = dot2(wv.w, xq[c].w, a);
+                }
+                rs[r] = wave_sum_dpp(a);
+            }
+            if (lane == (uint32_t)i) {
+                my_a = rs[0];
+                my_b = rs[1];
+            }
+        }
+    };
+    pair_step(std::integral_constant<int, 0>{});
+    if constexpr (F > 1) pair_step(std::integral_constant<int, 1>{});
+    if constexpr (F > 2) pair_step(std::integral_constant<int, 2>{});
+    if constexpr (F > 3) pair_step(std::integral_constant<int, 3>{});
+    if constexpr (F > 4) pair_step(std::integral_constant<int, 4>{});
+    static_assert(F >= 1 && F <= 5, "the steps above");
+    // ---- the epilogue of gemv.h finish_pair (EPI_SILU_MUL), one lane per pair: out[j] = T(silu(T(w1 x)) * T(w3 x))
+    if (lane < cnt) {
+        const float ga = BF::rt(my_a), gb = BF::rt(my_b);
+        const float g = mc::gemv::silu_T<BF>(ga);
+        gate[pb + lane] = BF::st(g * gb);
+    }
+    stamp2(44, 0);
+    stamp2(45, 256);
+}
+
+} // namespace
+
+// mc_attn_qkv_wo_w13_w_bfloat_hd{head_dim}_k{KiB per Wo row}_q{KiB per wq|wk|wv row}_f{pairs of w1|w3 per fetcher wave}
+#define MC_ATTN_QKV_WO_W13_W(NAME, HD, F)                                                                                                \
+    extern "C" __global__ void __launch_bounds__(512)                                                                                    \
+    NAME(const bf16_t* kc, const bf16_t* vt, bf16_t* attn_out, unsigned long long* psum_g, unsigned long long* slab_g,                  \
+         unsigned long long* row_g, unsigned long long* qkv_g, step_state* st, uint32_t n_rep, uint32_t n_kv, uint32_t max_seq,         \
+         float scale, uint32_t nsplit, uint32_t layer_tag, const void* wo_w, const void* wo_s, const bf16_t* x, bf16_t* y,              \
+         uint32_t out_rows, uint32_t group, const void* qnorm_w, const void* qkv_w, const void* qkv_s, const float* fcos, const float* fsin, float eps,    \
+         float mu, uint32_t fastpath, unsigned long long* tl, uint32_t kv_shift, unsigned long long* hid_g, const void* w13_w,           \
+         const void* ffn_norm, bf16_t* gate, uint32_t ffn_rows, unsigned long long* tl2)                                                 \
+    {                                                                                                                                    \
+        attn_qkv_wo_w13_w_body<HD, F>(kc, vt, attn_out, psum_g, slab_g, row_g, qkv_g, st, n_rep, n_kv, max_seq, scale, nsplit, layer_tag, wo_w, wo_s, x, y, \
+                                      out_rows, group, qnorm_w, qkv_w, qkv_s, fcos, fsin, eps, mu, fastpath, tl, kv_shift, hid_g, w13_w, ffn_norm, gate,   \
+                                      ffn_rows, tl2);                                                                                    \
+    }
+MC_ATTN_QKV_WO_W13_W(mc_attn_qkv_wo_w13_w_bfloat_hd64_k4_q4_f4, 64, 4) // TinyLlama-1.1B: 22 pairs per workgroup = 4 x 4 + (2, 2, 1, 1)
+MC_ATTN_QKV_WO_W13_W(mc_attn_qkv_wo_w13_w_bfloat_hd64_k4_q4_f5, 64, 5) // Llama-3.2-1B:   32 pairs per workgroup = 4 x 5 + 4 x 3

@@ -1,0 +1,119 @@
+"""Round 6: the attention block AND ffn_norm + w1|w3 + SiLU * mul in one launch for plain bfloat weights
+(mc_attn_qkv_wo_w13_w_bfloat_hd64_k4_q4_f{4,5}, attn_block_kernels.hip; MC_CHAIN_W13=0 switches it off) at TinyLlama-1.1B's (BASELINE configs[0]
+on the GPU: 4 kv heads as 8 virtual ones, 22 row pairs of w1|w3 per workgroup) and Llama-3.2-1B's (the reference's default model: 32 pairs) widths.
+
+  * against the oracle: S = 2048, kv_len 2045 .. 2048 and rolls past the end, and position 40 (all but one range of the launch empty);
+  * BIT FOR BIT the two launches it replaces (mc_attn_qkv_wo_w_bfloat_hd64_k4_q4 + mc_gemv_w_bfloat_ling4_p1_e2): hidden rows of every
+    block, logits, tokens, both blocks' caches, near an empty cache, at position 70 and across the end of a full one;
+  * graph replay == eager launches over a chain of tokens that crosses the end of the cache.
+"""
+import numpy as np
+import pytest
+
+import modelgen as mg
+import parity
+from test_context_gpu import random_cache, run_injected, t_weights_model
+from test_full_size_gpu import SEED
+
+pytestmark = pytest.mark.gpu
+BF16 = 0
+BLOCK = "mc_attn_qkv_wo_w_bfloat_hd64_k4_q4"
+W13 = "mc_gemv_w_bfloat_ling4_p1_e2"
+SHAPES = {
+    "tinyllama": (dict(n_kv_heads=4, ffn_dim=5632, rope_theta=10000.0), "mc_attn_qkv_wo_w13_w_bfloat_hd64_k4_q4_f4"),
+    "llama3.2-1b": (dict(n_kv_heads=8, ffn_dim=8192, rope_theta=500000.0), "mc_attn_qkv_wo_w13_w_bfloat_hd64_k4_q4_f5"),
+}
+
+
+def config(shape, **over):
+    cfg = dict(dtype=BF16, family=0, n_layers=2, vocab=32000, max_seq_len=2048, norm_eps=1e-5, dim=2048, n_heads=32, head_dim=64,
+               attn_scale=64 ** -0.5, **SHAPES[shape][0])
+    cfg.update(over)
+    return cfg
+
+
+@pytest.mark.parametrize("shape", list(SHAPES))
+def test_chained_block_against_the_oracle(acc, monkeypatch, shape):
+    import metalchat_amd as mc
+
+    monkeypatch.setenv("MC_CHAIN_W13", "1")
+    cfg = config(shape)
+    weights = t_weights_model(cfg, SEED)
+    names = set()
+    agree = run_injected(acc, cfg, weights, 2044, 8, dict(weight_format=mc.WFMT_T, group_size=0), rel_logits=7.8e-3,
+                         max_ulp=3, max_frac=0.8, what=f"{shape} S=2048, chained", launched=names)
+    assert agree >= 7
+    assert SHAPES[shape][1] in names and BLOCK not in names and W13 not in names, sorted(names)
+    if shape == "tinyllama":
+        # (position 40 with 8 query heads per kv head: EITHER form sits 3.1 scaled bf16 steps from the oracle on single elements of hidden[0] --
+        #  test_context_gpu.py::test_tinyllama_takes_the_one_launch_block_as_eight_virtual_kv_heads; the identity test below covers the position)
+        return
+    agree = run_injected(acc, cfg, weights, 40, 8, dict(weight_format=mc.WFMT_T, group_size=0), rel_logits=7.8e-3,
+                         max_ulp=3, max_frac=0.8, what=f"{shape} at position 40, chained")
+    assert agree >= 7
+
+
+@pytest.mark.parametrize("shape", list(SHAPES))
+def test_chained_block_equals_the_two_launches_bit_for_bit(acc, monkeypatch, shape):
+    import metalchat_amd as mc
+
+    cfg = config(shape, vocab=2048)
+    S = cfg["max_seq_len"]
+    out = {}
+    for form in ("chain", "three"):
+        monkeypatch.setenv("MC_CHAIN_W13", "1" if form == "chain" else "0")
+        dec = mc.Decoder(acc, **mg.decoder_kwargs(cfg, weight_format=mc.WFMT_T, group_size=0))
+        dec.init_synthetic(SEED)
+        dec.set_taps(True)
+        dec.launch_log(True)
+        rows = []
+        for n_inject in (2, 70, S - 4):
+            for layer in range(cfg["n_layers"]):
+                k, v = random_cache(cfg, n_inject, 700 + layer)
+                dec.import_kv(layer, k, v)
+            tok = 5
+            for i in range(8):
+                tok = dec.step(tok, n_inject + i)
+                rows.append((tok, dec.logits().copy(), np.stack([dec.hidden(l) for l in range(-1, cfg["n_layers"])])))
+        caches = [dec.export_kv(l) for l in range(cfg["n_layers"])]
+        names = set(dec.launched())
+        if form == "chain":
+            assert SHAPES[shape][1] in names and BLOCK not in names and W13 not in names, sorted(names)
+        else:
+            assert not [n for n in names if "_w13_" in n] and {BLOCK, W13} <= names, sorted(names)
+        assert dec.handoff_fallbacks() == 0
+        out[form] = (rows, caches)
+        dec.release()
+    for i, ((ta, la, ha), (tb_, lb, hb)) in enumerate(zip(out["chain"][0], out["three"][0])):
+        assert ta == tb_, i
+        parity.exact(ha, hb, f"{shape} step {i}: hidden rows, chained launch vs the two launches")
+        parity.exact(la, lb, f"{shape} step {i}: logits")
+    for l, ((ka, va), (kb, vb)) in enumerate(zip(out["chain"][1], out["three"][1])):
+        parity.exact(ka, kb, f"{shape} block {l}: K cache")
+        parity.exact(va, vb, f"{shape} block {l}: V cache")
+
+
+def test_chained_block_graph_replay_equals_eager_across_the_end_of_the_cache(acc, monkeypatch):
+    import metalchat_amd as mc
+
+    cfg = config("tinyllama", n_layers=3, vocab=4096)
+    S = cfg["max_seq_len"]
+    toks = {}
+    for form in ("chain-graph", "chain-eager", "three-graph"):
+        monkeypatch.setenv("MC_CHAIN_W13", "0" if form.startswith("three") else "1")
+        dec = mc.Decoder(acc, **mg.decoder_kwargs(cfg, weight_format=mc.WFMT_T, group_size=0))
+        dec.init_synthetic(SEED)
+        for layer in range(cfg["n_layers"]):
+            k, v = random_cache(cfg, S - 12, 900 + layer)
+            dec.import_kv(layer, k, v)
+        if form.endswith("graph"):
+            toks[form] = list(dec.generate(9, S - 12, 40))
+        else:
+            t, seq = 9, []
+            for i in range(40):
+                t = dec.step(t, S - 12 + i)
+                seq.append(t)
+            toks[form] = seq
+        assert dec.handoff_fallbacks() == 0
+        dec.release()
+    assert toks["chain-graph"] == toks["chain-eager"] == toks["three-graph"]
