@@ -3121,7 +3121,9 @@ mc_decoder_gemv_kernel_name(mc_decoder* d, const char* which, char* buf, size_t 
         const int wt = d->attn_qkv_wo_w_tiles(L0), i4w = d->attn_qkv_wo_i4_wide_tiles(L0);
         const std::string i4name = "mc_attn_qkv_wo_i4_" + d->tname + "_hd" + std::to_string(d->cfg.head_dim) + "_k" + std::to_string(wo.in / 2048) + "_q" +
                                    std::to_string(L0.qkv.in / 2048);
-        name = wt ? std::string("mc_attn_qkv_wo_w_bfloat_hd64_k4_q4") + (wt > 1 ? "_t" + std::to_string(wt) : std::string())
+        const int chf = wt == 1 ? d->attn_qkv_wo_w13_w_fetch(L0) : 0; // (round 6: ffn_norm + w1|w3 + act*mul in the launch too)
+        name = chf ? "mc_attn_qkv_wo_w13_w_bfloat_hd64_k4_q4_f" + std::to_string(chf)
+               : wt ? std::string("mc_attn_qkv_wo_w_bfloat_hd64_k4_q4") + (wt > 1 ? "_t" + std::to_string(wt) : std::string())
                : d->attn_qkv_wo_i8_tiles(L0) ? "mc_attn_qkv_wo_i8_bfloat_hd128_k4_q4_t" + std::to_string(d->attn_qkv_wo_i8_tiles(L0))
                : d->attn_qkv_wo_fused(L0) ? i4name
                : i4w ? i4name + "_t" + std::to_string(i4w)

@@ -1219,18 +1219,10 @@ __device__ __forceinline__ void w13_load16(w13_v4& dst, const void* p)
 {
     asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(dst) : "v"(p) : "memory");
 }
-__device__ __forceinline__ void w13_load16_plain(w13_v4& dst, const void* p)
-{
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
-}
 // everything but the N youngest vector-memory operations of this wave has completed; the values pass THROUGH the wait, so no use of them can be scheduled in front of it
 template <int N> __device__ __forceinline__ void w13_wait(w13_v4& a, w13_v4& b, w13_v4& c, w13_v4& d)
 {
     asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N) : "memory");
-}
-template <int N> __device__ __forceinline__ void w13_wait(w13_v4& a)
-{
-    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(a) : "n"(N) : "memory");
 }
 
 // F: pairs of each fetcher wave; the pollers share what is left of the workgroup's pairs (the host: at most F each)
@@ -1268,8 +1260,11 @@ attn_qkv_wo_w13_w_body(const bf16_t* kc, const bf16_t* vt, bf16_t* attn_out, uns
     // ---- hand-off D (pollers): the hidden row the Wo phases of ALL workgroups finished; thread t < 256 gathers packet t = granules 4 t .. 4 t + 3
     // (one watched granule and ~ 0.4 us between looks while the row is not there, then one sweep: hand-off C)
     const uint32_t epoch_tag = st->epoch * 256u + layer_tag;
-    w13_v4 xr = w13_v4{0, 0, 0, 0};
+    w13_v4 xr = w13_v4{0, 0, 0, 0}, nr = w13_v4{0, 0, 0, 0};
     if (poller) { // (wave-uniform; every load inside is waited for inside)
+        // the norm weights of the packet this thread stages: asked for in front of the wait (behind it they sat behind the workgroup's own
+        // weight requests: 2.2 us from the first sight of the row to "row staged", profiles/r06_chainw_timeline_tiny_first_build.log)
+        nr = reinterpret_cast<const w13_v4*>(ffn_norm)[tid];
         uint32_t val[4];
         handoff_wait w;
         for (;;) {
@@ -1290,11 +1285,9 @@ attn_qkv_wo_w13_w_body(const bf16_t* kc, const bf16_t* vt, bf16_t* attn_out, uns
         xr = w13_v4{val[0], val[1], val[2], val[3]};
     }
     stamp2(41, 0);
-    // ---- every wave's requests, in ONE place (the fetchers reach it ~ 4 us before the pollers): the norm weights of the packet this thread stages,
-    // the wave's pairs (a pair the wave does not have reads one broadcast line: masks, not selects)
-    w13_v4 nr;
+    // ---- every wave's requests, in ONE place (the fetchers reach it ~ 4 us before the pollers): the wave's pairs (a pair the wave does not
+    // have reads one broadcast line: masks, not selects)
     w13_v4 wreg[F][2 * PK];
-    w13_load16_plain(nr, static_cast<const char*>(ffn_norm) + (size_t)(tid & 255u) * 16u);
 #pragma unroll
     for (int i = 0; i < F; i++) {
         const uint32_t lm = 0u - (uint32_t)((uint32_t)i < cnt ? 1u : 0u);
@@ -1325,7 +1318,6 @@ attn_qkv_wo_w13_w_body(const bf16_t* kc, const bf16_t* vt, bf16_t* attn_out, uns
         for (uint32_t i = 0; i < 8u; i++) tot += red13[i];
         const float inv = 1.0f / sqrtf(tot / (float)KF + eps);
         if (poller) {
-            w13_wait<NW>(nr);
             const uint32_t wv[4] = {nr.x, nr.y, nr.z, nr.w};
             uint32_t o[4];
 #pragma unroll
