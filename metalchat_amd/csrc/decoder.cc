@@ -735,6 +735,8 @@ struct mc_decoder {
         occ_qkv_only = hd == 128 ? ask("mc_attn_qkv_i4_bfloat_hd128_q4", 512) : 0;
         occ_wo_i4_wide = hd == 128 ? ask("mc_attn_qkv_wo_i4_bfloat_hd128_k2_q2_t4", 512) : 0;
         occ_w13 = hd == 64 ? ask("mc_attn_qkv_wo_w13_w_bfloat_hd64_k4_q4_f5", 512) : 0;
+        // (one kernel per family is asked: the widest-range / most-register instantiation, which bounds the others -- every form is ONE 512-thread
+        //  workgroup per CU, so the answer that matters is "at least one")
         (void)hipGetLastError();
     }
     // a hand-off gave up: report nothing yet, make the NEXT launches independent of co-residency
@@ -766,7 +768,7 @@ struct mc_decoder {
     }
 
     // gemma3 (round 5): q_norm / k_norm + rotation + cache write + attention + Wo in ONE launch from the raw wq|wk|wv rows
-    // (mc_attn_wo_qkn_i4_bfloat_hd256_k2_t{1,2}: one 512-thread workgroup per CU, ranges of 64 or 128 slots -- Gemma-7B's 16 kv heads at
+    // (mc_attn_wo_qkn_i4_bfloat_hd256_k2_t{1,2,4}: one 512-thread workgroup per CU, ranges of 64, 128 or 256 slots -- Gemma-7B's 16 kv heads at
     // S = 2048 are 16 x 16).  Returns the 64-slot tiles per range, 0: not this form.
     int
     attn_wo_qkn_tiles(const linear_w& wo) const

@@ -474,7 +474,7 @@ def test_two_head_prompt_attention_head_dims(acc, hd, heads, kv, nh, monkeypatch
 
 @pytest.mark.parametrize("n", [2, 31, 33, 64, 65, 130, 300, 448])
 def test_prompt_attention_through_lds_tiles_matches_oracle(acc, n, monkeypatch):
-    """mc_pf_attn8_bfloat_hd128 (round 5: K / V tiles of 64 keys through LDS by LDS-DMA, 64 rows x 4 heads per workgroup -- the prompt
+    """mc_pf_attn8_bfloat_hd128 (round 5: K / V tiles of 64 keys through LDS by LDS-DMA, 32 rows x 4 heads per workgroup, row tiles in pairs -- the prompt
     attention of 1024 rows and more; MC_PF_ATTN_HEADS=8 takes it on the models the oracle can follow): rows below, at and above one
     row tile and one key tile, a ragged last tile, GQA 4 and 8; row tiles one per workgroup and in pairs (tile x with tile last - x: an
     odd count leaves the middle one alone)."""
