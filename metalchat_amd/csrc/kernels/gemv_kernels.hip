@@ -117,13 +117,17 @@ MC_GEMV_LIN_SET(mc_gemv_i4_bfloat_lin12, MC_LIN12_CFG) // K = 24576 (Gemma-7B's 
 MC_GEMV_K4(mc_gemv_i4_bfloat_lin12k4_p0_e0, 12, 0)
 MC_GEMV_K4(mc_gemv_i4_bfloat_lin12k4_p0_e1, 12, 1)
 // K = 3072 (Gemma-7B's QKV and w1|w3): rows of 1.5 KiB, two to a 3 KiB super row (gemv.h LSPLIT)
+#ifndef MC_LIN3S_RING
+#define MC_LIN3S_RING 3 // ring slots (KiB per wave in flight): 2, 3 or 6 (a quad of rows is six tiles).  Gemma-7B shapes, same box, alternating: 2 (rounds 4-5) 682.5 / 682.3,
+                        // 3: 691.2 / 695.4, 6: 692.0 / 690.4 tokens/s (profiles/r06_ab_lin3s_ring.log)
+#endif
 #define MC_GEMV_LINS(NAME, PRO, EPI)                                                              \
     extern "C" __global__ void __launch_bounds__(64 * MC_LIN_WAVES)                               \
     NAME(const void* w, const void* scales, const void* x, void* y, const void* res,             \
          const void* norm_w, uint32_t out_rows, uint32_t in, uint32_t group, float eps, float mu, \
          const void* lora_a, const void* lora_b, uint32_t lora_rank, float lora_scale)            \
     {                                                                                             \
-        body<WF_I4, BF, Q_M4D, PRO, EPI, 4, 3, 1, 2, MC_LIN_WAVES, 0, 1>(                       \
+        body<WF_I4, BF, Q_M4D, PRO, EPI, 4, 3, 1, MC_LIN3S_RING, MC_LIN_WAVES, 0, 1>(           \
             w, scales, x, y, res, norm_w, out_rows, in, group, eps, mu, lora_a, lora_b, lora_rank, lora_scale); \
     }
 #if MC_LIN_WAVES
