@@ -919,19 +919,6 @@ struct mc_decoder {
         return 0;
     }
 
-    // ... AND ffn_norm + w1|w3 + act*mul as the next phase of the int8 launch (round 6, mc_attn_qkv_wo_w13_i8_bfloat_hd128_k4_q4_t{1,2,4}): the plain-weight
-    // chain's form (attn_qkv_wo_w13_w_fetch) -- int8 GEMVs wait for memory too.  Exactly one workgroup per CU and 56 pairs of 4 KiB rows per workgroup
-    // (4 fetcher waves x 4 pairs in registers + 8 waves x 5 streamed behind the row), no adaptor.  Returns the block's tiles, 0 = no.
-    int
-    attn_qkv_wo_w13_i8_tiles(const layer_w& L) const
-    {
-        const int t = attn_qkv_wo_i8_tiles(L);
-        if (!t || !chain_w13_on || !attn_hid_g || L.w13.fmt != MC_WFMT_I8 || L.w13.lora_cols || ling_kib(L.w13) != 4) return 0;
-        const unsigned grid = (unsigned)(nsplit / t * cfg.n_kv_heads);
-        if (cfg.dim != 4096 || L.w13.in != 4096 || grid != (unsigned)dev->prop.multiProcessorCount || (unsigned)L.w13.out != 2u * 56u * grid || lin_waves != 8) return 0;
-        return (L.w13.group == 0 || (L.w13.group >= 16 && (L.w13.group & (L.w13.group - 1)) == 0)) ? t : 0;
-    }
-
     // ... the int4 launch with WIDE ranges (round 5, mc_attn_qkv_wo_i4_bfloat_hd128_k2_q2_t{2,4}): contexts whose 64-slot ranges are more workgroups
     // than CUs -- Llama-3-8B at S = 4096 / 8192 -- as 128- / 256-slot ranges, one 512-thread workgroup per CU.  Returns the tiles (2 or 4), 0 = not this form.
     int
@@ -1187,21 +1174,7 @@ struct mc_decoder {
             bool qkn_in = false, gq = false, q_only = false;
             int qkn_wo = 0;
             const int chain_f = w_tiles == 1 ? attn_qkv_wo_w13_w_fetch(L) : 0;
-            const int chain_i8 = i8_tiles ? attn_qkv_wo_w13_i8_tiles(L) : 0;
-            if (chain_i8) {
-                // int8: the block up to the gate row in ONE launch (attn_block_kernels.hip attn_qkv_wo_w13_i8_body)
-                const int ns = nsplit / chain_i8;
-                s = launch("mc_attn_qkv_wo_w13_i8_bfloat_hd128_k4_q4_t" + std::to_string(chain_i8), (unsigned)(ns * KV), 1, 1, 512, 0,
-                           pack((const void*)L.kc, (const void*)L.vt, attn_out, attn_psum_g, attn_slab_g, attn_row_g, attn_qkv_g, state,
-                                (uint32_t)n_rep, (uint32_t)KV, (uint32_t)cfg.max_seq_len, scale_T, (uint32_t)ns, (uint32_t)(li + 1),
-                                (const void*)L.wo.w, (const void*)L.wo.scales, x, hidden, (uint32_t)L.wo.out, (uint32_t)L.wo.group,
-                                (const void*)L.attention_norm, (const void*)L.qkv.w, (const void*)L.qkv.scales,
-                                (const float*)rope_cos[L.rope_table], (const float*)rope_sin[L.rope_table], cfg.norm_eps, mu,
-                                (uint32_t)(handoff_fast_here() ? 1 : 0), (void*)nullptr, (uint32_t)0, attn_hid_g,
-                                (const void*)L.w13.w, (const void*)L.w13.scales, (const void*)L.ffn_norm, gate, (uint32_t)L.w13.out, (uint32_t)L.w13.group,
-                                (void*)nullptr));
-                if (s != MC_OK) return s;
-            } else if (chain_f) {
+            if (chain_f) {
                 // ... and ffn_norm, w1|w3, act*mul (transformer.h:135-137, 53-59) too: the block up to the gate row in ONE launch
                 const int vsh = kv_virtual_shift();
                 s = launch("mc_attn_qkv_wo_w13_w_bfloat_hd64_k4_q4_f" + std::to_string(chain_f), (unsigned)(nsplit * (KV << vsh)), 1, 1, 512, 0,
@@ -1406,7 +1379,7 @@ struct mc_decoder {
             }
             }
             // ffn_norm + w1|w3 + act*mul           (transformer.h:135-137, 53-59)
-            if (chain_f || chain_i8) {
+            if (chain_f) {
                 s = MC_OK; // (a phase of the launch above)
             } else if (gemma && fuse_pn) {
                 // attention post-norm + residual (-> hidden_b) + ffn_norm in the prologue
@@ -3151,9 +3124,7 @@ mc_decoder_gemv_kernel_name(mc_decoder* d, const char* which, char* buf, size_t 
         const std::string i4name = "mc_attn_qkv_wo_i4_" + d->tname + "_hd" + std::to_string(d->cfg.head_dim) + "_k" + std::to_string(wo.in / 2048) + "_q" +
                                    std::to_string(L0.qkv.in / 2048);
         const int chf = wt == 1 ? d->attn_qkv_wo_w13_w_fetch(L0) : 0; // (round 6: ffn_norm + w1|w3 + act*mul in the launch too)
-        const int ch8 = wt ? 0 : d->attn_qkv_wo_w13_i8_tiles(L0);
-        name = ch8 ? "mc_attn_qkv_wo_w13_i8_bfloat_hd128_k4_q4_t" + std::to_string(ch8)
-               : chf ? "mc_attn_qkv_wo_w13_w_bfloat_hd64_k4_q4_f" + std::to_string(chf)
+        name = chf ? "mc_attn_qkv_wo_w13_w_bfloat_hd64_k4_q4_f" + std::to_string(chf)
                : wt ? std::string("mc_attn_qkv_wo_w_bfloat_hd64_k4_q4") + (wt > 1 ? "_t" + std::to_string(wt) : std::string())
                : d->attn_qkv_wo_i8_tiles(L0) ? "mc_attn_qkv_wo_i8_bfloat_hd128_k4_q4_t" + std::to_string(d->attn_qkv_wo_i8_tiles(L0))
                : d->attn_qkv_wo_fused(L0) ? i4name

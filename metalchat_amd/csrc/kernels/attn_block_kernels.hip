@@ -1396,265 +1396,3 @@ attn_qkv_wo_w13_w_body(const bf16_t* kc, const bf16_t* vt, bf16_t* attn_out, uns
     }
 MC_ATTN_QKV_WO_W13_W(mc_attn_qkv_wo_w13_w_bfloat_hd64_k4_q4_f4, 64, 4) // TinyLlama-1.1B: 22 pairs per workgroup = 4 x 4 + (2, 2, 1, 1)
 MC_ATTN_QKV_WO_W13_W(mc_attn_qkv_wo_w13_w_bfloat_hd64_k4_q4_f5, 64, 5) // Llama-3.2-1B:   32 pairs per workgroup = 4 x 5 + 4 x 3
-
-// ------------------------------------------------------------------------------------------
-// ... and for INT8 weights (quantization::linear at 8 bits; Llama-3-8B int8, BASELINE configs[2]): mc_attn_qkv_wo_w13_i8_bfloat_hd128_k4_q4_t{1,2,4}.
-// The int8 GEMVs wait for memory (w1|w3: 121 MB in 22 us; its matrix-pipe dequantisation, gemv.h mac8b_n, needs ~ 7 us of the SIMDs), so the
-// plain-weight chain's form carries over: behind the Wo phase waves 4-7 fetch F = 4 row pairs of 8 KiB each into registers and poll nothing,
-// waves 0-3 poll hand-off D; behind the row EVERY wave streams PS = 5 more pairs through the stand-alone kernel's ring of four 1 KiB packets
-// (56 = 4 x 4 + 8 x 5 pairs per workgroup: the host takes this form only for that count).
-//
-// Numerics: bit for bit the two launches it replaces.  The w1|w3 phase is mc_gemv_i8_bfloat_ling4_p1_e2's arithmetic (gemv.h LGEN, I8M): packet p's
-// sum of squares by one thread, the sums of packets 64 v .. 64 v + 63 by wave_sum_dpp, the eight sums in order, the normalised row staged in the
-// order mac8b_n's transposition wants (x_perm8); a row = its four packets in order through mac8b_n<1> into one accumulator, the lane's own
-// element times 2^37, one wave sum; the epilogue of gemv.h finish_pair (EPI_SILU_MUL).
-// ------------------------------------------------------------------------------------------
-namespace {
-
-template <int HD, int TT>
-__device__ __forceinline__ void
-attn_qkv_wo_w13_i8_body(const bf16_t* kc, const bf16_t* vt, bf16_t* attn_out, unsigned long long* psum_g, unsigned long long* slab_g, unsigned long long* row_g,
-                        unsigned long long* qkv_g, step_state* st, uint32_t n_rep, uint32_t KV, uint32_t max_seq, float scale, uint32_t nsplit, uint32_t layer_tag,
-                        const void* wo_w, const void* wo_s, const bf16_t* x, bf16_t* y, uint32_t out_rows, uint32_t group, const void* qnorm_w,
-                        const void* qkv_w, const void* qkv_s, const float* fcos, const float* fsin, float eps, float mu, uint32_t fastpath,
-                        unsigned long long* tl, uint32_t kv_shift, unsigned long long* hid_g, const void* __restrict__ w13_w, const void* __restrict__ w13_s,
-                        const void* __restrict__ ffn_norm, bf16_t* __restrict__ gate, uint32_t ffn_rows, uint32_t ffn_group, unsigned long long* tl2)
-{
-    constexpr uint32_t KF = 4096u, ROWB = 4096u, CHUNK = 1024u; // dim 4096: rows of 4 KiB, four packets of 1024 weights
-    constexpr int PK = 4, F = 4, PS = 5;
-    __shared__ __attribute__((aligned(16))) char xs13[KF * 2];
-    __shared__ float red13[16];
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    unsigned long long* mytl = tl2 ? tl2 + (size_t)blockIdx.x * TL2_STRIDE : nullptr;
-
-    // ================= the attention block ...
-    attn_wo_body<HD, 4, 4, 2, TT, 0, 1>(nullptr, kc, vt, attn_out, psum_g, slab_g, row_g, st, n_rep, KV, max_seq, scale, nsplit, layer_tag, wo_w, wo_s, x, y,
-                                        out_rows, group, 1u, fastpath, tl, qnorm_w, qkv_w, qkv_s, fcos, fsin, qkv_g, eps, mu, kv_shift, gemma_extra(), hid_g);
-    auto stamp2 = [&](int i, uint32_t t) {
-        if (mytl && tid == t) mytl[i] = __builtin_amdgcn_s_memrealtime();
-    };
-    stamp2(40, 0);
-    // ================= ... and ffn_norm + w1|w3 + SiLU * mul
-    const bool poller = wave < 4u;
-    const uint32_t sb0 = blockIdx.x * (uint32_t)(4 * F + 8 * PS);          // the workgroup's 56 pairs (the host: ffn_rows == 2 * 56 * gridDim.x)
-    const uint32_t pf0 = sb0 + (wave & 3u) * (uint32_t)F;                   // (fetchers) prefetched pairs pf0 .. pf0 + F - 1
-    const uint32_t ps0 = sb0 + 4u * (uint32_t)F + wave * (uint32_t)PS;      // streamed pairs ps0 .. ps0 + PS - 1 of every wave
-    const uint32_t glog = ffn_group ? 31u - __builtin_clz(ffn_group) : 31u, ngroups = ffn_group ? KF >> glog : 1u;
-    const char* wbase = static_cast<const char*>(w13_w);
-    const char* sbase = static_cast<const char*>(w13_s);
-    // ---- hand-off D (pollers): thread t < 256 gathers packets t and t + 256 = granules 4 p .. 4 p + 3 each
-    const uint32_t epoch_tag = st->epoch * 256u + layer_tag;
-    w13_v4 xr[2] = {w13_v4{0, 0, 0, 0}, w13_v4{0, 0, 0, 0}}, nr[2] = {w13_v4{0, 0, 0, 0}, w13_v4{0, 0, 0, 0}};
-    if (poller) { // (wave-uniform; every load inside is waited for inside)
-        nr[0] = reinterpret_cast<const w13_v4*>(ffn_norm)[tid];
-        nr[1] = reinterpret_cast<const w13_v4*>(ffn_norm)[tid + 256u];
-        uint32_t val[8];
-        handoff_wait w;
-        for (;;) {
-            const bool seen = (uint32_t)(granule_load(hid_g + 4u * (tid + 256u) + 3u) >> 32) == epoch_tag;
-            if (__all(seen) || w.expired(st, 0xE0000000u | layer_tag)) break;
-            __builtin_amdgcn_s_sleep(MC_HANDOFF_C_SLEEP);
-        }
-        for (;;) {
-            bool ok = true;
-#pragma unroll
-            for (int i = 0; i < 8; i++) {
-                const unsigned long long g = granule_load(hid_g + 4u * (tid + 256u * (i >> 2)) + (i & 3));
-                ok = ok && (uint32_t)(g >> 32) == epoch_tag;
-                val[i] = (uint32_t)g;
-            }
-            if (__all(ok) || w.expired(st, 0xE0000000u | layer_tag)) break;
-        }
-        xr[0] = w13_v4{val[0], val[1], val[2], val[3]};
-        xr[1] = w13_v4{val[4], val[5], val[6], val[7]};
-    }
-    stamp2(41, 0);
-    // ---- the fetchers' F pairs and their scales, in ONE place for every wave (a poller reads one broadcast line, behind the row: masks, not selects);
-    // inline asm: the compiler does not count these, they are waited for by hand once the row is staged (they were requested >= 4 us before)
-    w13_v4 wreg[F][2 * PK];
-    uint32_t wsc[F][PK];
-    {
-        const uint32_t lm = 0u - (uint32_t)(poller ? 0u : 1u);
-        const uint64_t lm64 = ((uint64_t)lm << 32) | lm;
-#pragma unroll
-        for (int i = 0; i < F; i++) {
-            const uint32_t pr = (pf0 + (uint32_t)i) & lm;
-            const char* a = wbase + (((uint64_t)pr * 2u * ROWB) & lm64) + ((lane * 16u) & lm);
-#pragma unroll
-            for (int t = 0; t < 2 * PK; t++) w13_load16(wreg[i][t], a + ((t * 1024u) & lm));
-            const char* s0 = sbase + (((((uint64_t)(pr >> 1) * ngroups) * 4 + (pr & 1u) * 2) * 2) & lm64);
-#pragma unroll
-            for (int c = 0; c < PK; c++) {
-                const uint32_t g = ffn_group ? ((CHUNK * (uint32_t)c + 16u * lane) >> glog) : 0u;
-                asm volatile("global_load_dword %0, %1, off" : "=v"(wsc[i][c]) : "v"(s0 + ((g * 8u) & lm)) : "memory");
-            }
-        }
-    }
-    // ---- ffn_norm on the way into LDS (kernel/rmsnorm.metal:52-95; gemv.h LGEN, the build-time prologue: the same additions in the same order)
-    {
-        float s1[2];
-#pragma unroll
-        for (int q = 0; q < 2; q++) {
-            const uint32_t vv[4] = {xr[q].x, xr[q].y, xr[q].z, xr[q].w};
-            float s = 0.0f;
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const float a = asf(vv[e] << 16), b = asf(vv[e] & 0xFFFF0000u);
-                s += a * a;
-                s += b * b;
-            }
-            float ss = 0.0f;
-            ss += s;
-            s1[q] = wave_sum_dpp(ss);
-        }
-        if (poller && lane == 0) { // the stand-alone kernel's wave v holds packets 64 v .. 64 v + 63
-            red13[wave] = s1[0];
-            red13[4u + wave] = s1[1];
-        }
-        lds_barrier();
-        float tot = 0.0f;
-#pragma unroll
-        for (uint32_t i = 0; i < 8u; i++) tot += red13[i];
-        const float inv = 1.0f / sqrtf(tot / (float)KF + eps);
-        if (poller) {
-            uint16_t* xh = reinterpret_cast<uint16_t*>(xs13);
-#pragma unroll
-            for (int q = 0; q < 2; q++) {
-                const uint32_t vv[4] = {xr[q].x, xr[q].y, xr[q].z, xr[q].w}, wv[4] = {nr[q].x, nr[q].y, nr[q].z, nr[q].w};
-                uint32_t o[4];
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    const float a = (mu + asf(wv[e] << 16)) * asf(vv[e] << 16) * inv;
-                    const float b = (mu + asf(wv[e] & 0xFFFF0000u)) * asf(vv[e] & 0xFFFF0000u) * inv;
-                    o[e] = pack_bf16x2(a, b);
-                }
-                // the order mac8b_n wants (gemv.h x_perm8): element n of the row = lane 4 b + e, dword d, byte p of its chunk
-                const uint32_t n0 = 8u * (tid + 256u * (uint32_t)q);
-#pragma unroll
-                for (int e2 = 0; e2 < 8; e2++) xh[x_perm8(n0 + e2)] = (uint16_t)(o[e2 / 2] >> (16 * (e2 & 1)));
-            }
-        }
-    }
-    lds_barrier();
-    stamp2(42, 0);
-    // ---- the lane's slices of the row, once per wave: 32 bytes of chunk c
-    xregs<BF, 16> gx[PK];
-#pragma unroll
-    for (int c = 0; c < PK; c++) gx[c].load(xs13 + (size_t)c * CHUNK * 2 + lane * 32u, 0);
-    const m4b_lane i8k = m4b_lane_consts<true>(lane);
-    // ---- everything requested by hand has landed (>= 4 us ago for a fetcher; a poller's broadcast line just now): one wait, the values pass through it
-#pragma unroll
-    for (int i = 0; i < F; i++) {
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(wreg[i][0]), "+v"(wreg[i][1]), "+v"(wreg[i][2]), "+v"(wreg[i][3]), "+v"(wreg[i][4]), "+v"(wreg[i][5]),
-                     "+v"(wreg[i][6]), "+v"(wreg[i][7]), "+v"(wsc[i][0]), "+v"(wsc[i][1]), "+v"(wsc[i][2]), "+v"(wsc[i][3])::"memory");
-    }
-    // ---- the streamed pairs: the stand-alone kernel's ring of four packets, refilled packet by packet; scales one pair ahead (compiler-counted loads
-    // from here on: nothing of the hand-made requests is in flight any more)
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    auto gload = [&](uint4& dst, uint32_t pr, uint32_t t, bool live) {
-        const uint64_t rb = ((uint64_t)pr * 2 + (uint64_t)(t / (uint32_t)PK)) * ROWB + (uint64_t)(t % (uint32_t)PK) * 1024;
-        const uint32_t lm = 0u - (uint32_t)live;
-        const char* a = wbase + (rb & (((uint64_t)lm << 32) | lm));
-        const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a + ((lane * 16u) & lm)));
-        dst = make_uint4(v.x, v.y, v.z, v.w);
-    };
-    auto gscales = [&](uint32_t (&q)[PK], uint32_t pr, bool live) {
-        const uint64_t ub = (((uint64_t)(pr >> 1) * ngroups) * 4 + (pr & 1u) * 2) * 2;
-        const uint32_t lm = 0u - (uint32_t)live;
-        const char* a = sbase + (ub & (((uint64_t)lm << 32) | lm));
-#pragma unroll
-        for (int c = 0; c < PK; c++) {
-            const uint32_t g = ffn_group ? ((CHUNK * (uint32_t)c + 16u * lane) >> glog) : 0u;
-            q[c] = *reinterpret_cast<const uint32_t*>(a + ((g * 8u) & lm));
-        }
-    };
-    uint4 gring[4];
-    uint32_t gsa[PK], gsb[PK];
-    gscales(gsa, ps0, true);
-#pragma unroll
-    for (int j = 0; j < 4; j++) gload(gring[j], ps0, (uint32_t)j, true);
-    // a row: four packets through mac8b_n<1> into one accumulator, the lane's own element at 2^-37, one wave sum (gemv.h pair_g, I8M)
-    float my_a = 0.0f, my_b = 0.0f;
-    mf_f4 acc4[1] = {mf_f4{0, 0, 0, 0}};
-    auto row_done = [&]() {
-        const uint32_t e = lane & 3;
-        const float accf = (e == 0 ? acc4[0][0] : (e == 1 ? acc4[0][1] : (e == 2 ? acc4[0][2] : acc4[0][3]))) * 0x1p37f;
-        acc4[0] = mf_f4{0, 0, 0, 0};
-        return wave_sum_dpp(accf);
-    };
-    // ---- the fetchers' pairs first, from registers, while the ring's first packets are on their way: lanes 0 .. F - 1 finish them
-    if (!poller) { // (wave-uniform; no load inside)
-#pragma unroll
-        for (int i = 0; i < F; i++) {
-            float rs[2];
-#pragma unroll
-            for (int r = 0; r < 2; r++) {
-#pragma unroll
-                for (int c = 0; c < PK; c++) {
-                    const uint32_t raw = wsc[i][c];
-                    const w13_v4 v = wreg[i][PK * r + c];
-                    mac8b_n<1>(acc4, make_uint4(v.x, v.y, v.z, v.w), m4b_prepare(r ? (raw & 0xFFFF0000u) : (raw << 16), i8k), gx[c]);
-                }
-                rs[r] = row_done();
-            }
-            if (lane == (uint32_t)i) {
-                my_a = rs[0];
-                my_b = rs[1];
-            }
-        }
-    }
-    // ---- the streamed pairs: lanes F .. F + PS - 1 finish them
-#pragma unroll
-    for (int p = 0; p < PS; p++) {
-        const uint32_t pr = ps0 + (uint32_t)p;
-        gscales(gsb, pr + 1, p + 1 < PS);
-        float rs[2] = {0.0f, 0.0f};
-#pragma unroll
-        for (int t = 0; t < 2 * PK; t++) {
-            const int r = t / PK, c = t % PK, slot = t % 4;
-            const uint32_t raw = gsa[c];
-            mac8b_n<1>(acc4, gring[slot], m4b_prepare(r ? (raw & 0xFFFF0000u) : (raw << 16), i8k), gx[c]);
-            if (t + 4 < 2 * PK) gload(gring[slot], pr, (uint32_t)(t + 4), true);
-            else gload(gring[slot], pr + 1, (uint32_t)(t + 4 - 2 * PK), p + 1 < PS);
-            if (c == PK - 1) rs[r] = row_done();
-        }
-        if (lane == (uint32_t)(F + p)) {
-            my_a = rs[0];
-            my_b = rs[1];
-        }
-#pragma unroll
-        for (int c = 0; c < PK; c++) gsa[c] = gsb[c];
-    }
-    // ---- the epilogue of gemv.h finish_pair (EPI_SILU_MUL), one lane per pair: out[j] = T(silu(T(w1 x)) * T(w3 x))
-    {
-        const bool mine = lane < (uint32_t)F ? !poller : lane < (uint32_t)(F + PS);
-        const uint32_t pair = lane < (uint32_t)F ? pf0 + lane : ps0 + (lane - (uint32_t)F);
-        if (mine) {
-            const float ga = BF::rt(my_a), gb = BF::rt(my_b);
-            const float g = mc::gemv::silu_T<BF>(ga);
-            gate[pair] = BF::st(g * gb);
-        }
-    }
-    stamp2(44, 0);
-    stamp2(45, 256);
-}
-
-} // namespace
-
-// mc_attn_qkv_wo_w13_i8_bfloat_hd{head_dim}_k{KiB per Wo row}_q{KiB per wq|wk|wv row}_t{64-slot tiles per scoring wave}
-#define MC_ATTN_QKV_WO_W13_I8(NAME, HD, TT)                                                                                              \
-    extern "C" __global__ void __launch_bounds__(512)                                                                                    \
-    NAME(const bf16_t* kc, const bf16_t* vt, bf16_t* attn_out, unsigned long long* psum_g, unsigned long long* slab_g,                  \
-         unsigned long long* row_g, unsigned long long* qkv_g, step_state* st, uint32_t n_rep, uint32_t n_kv, uint32_t max_seq,         \
-         float scale, uint32_t nsplit, uint32_t layer_tag, const void* wo_w, const void* wo_s, const bf16_t* x, bf16_t* y,              \
-         uint32_t out_rows, uint32_t group, const void* qnorm_w, const void* qkv_w, const void* qkv_s, const float* fcos, const float* fsin, float eps,    \
-         float mu, uint32_t fastpath, unsigned long long* tl, uint32_t kv_shift, unsigned long long* hid_g, const void* w13_w,           \
-         const void* w13_s, const void* ffn_norm, bf16_t* gate, uint32_t ffn_rows, uint32_t ffn_group, unsigned long long* tl2)          \
-    {                                                                                                                                    \
-        attn_qkv_wo_w13_i8_body<HD, TT>(kc, vt, attn_out, psum_g, slab_g, row_g, qkv_g, st, n_rep, n_kv, max_seq, scale, nsplit, layer_tag, wo_w, wo_s, x, y, \
-                                        out_rows, group, qnorm_w, qkv_w, qkv_s, fcos, fsin, eps, mu, fastpath, tl, kv_shift, hid_g, w13_w, w13_s, ffn_norm, \
-                                        gate, ffn_rows, ffn_group, tl2);                                                                 \
-    }
-MC_ATTN_QKV_WO_W13_I8(mc_attn_qkv_wo_w13_i8_bfloat_hd128_k4_q4_t1, 128, 1)  // Llama-3-8B int8, S = 2048
-MC_ATTN_QKV_WO_W13_I8(mc_attn_qkv_wo_w13_i8_bfloat_hd128_k4_q4_t2, 128, 2)  // ... S = 4096
-MC_ATTN_QKV_WO_W13_I8(mc_attn_qkv_wo_w13_i8_bfloat_hd128_k4_q4_t4, 128, 4)  // ... S = 8192 (BASELINE configs[2])

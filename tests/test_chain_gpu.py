@@ -13,7 +13,7 @@ import pytest
 import modelgen as mg
 import parity
 from test_context_gpu import random_cache, run_injected, t_weights_model
-from test_full_size_gpu import FULL_WIDTH, SEED, synth_model
+from test_full_size_gpu import SEED
 
 pytestmark = pytest.mark.gpu
 BF16 = 0
@@ -117,64 +117,3 @@ def test_chained_block_graph_replay_equals_eager_across_the_end_of_the_cache(acc
         assert dec.handoff_fallbacks() == 0
         dec.release()
     assert toks["chain-graph"] == toks["chain-eager"] == toks["three-graph"]
-
-
-# ---------------------------------------------------------------------------------------------------------------------
-# ... and for int8 weights (BASELINE configs[2]): mc_attn_qkv_wo_w13_i8_bfloat_hd128_k4_q4_t{1,4} -- 4 fetcher waves x 4 pairs in registers, every
-# wave 5 more pairs through the stand-alone kernel's ring behind the row
-I8_BLOCK = "mc_attn_qkv_wo_i8_bfloat_hd128_k4_q4_t"
-I8_CHAIN = "mc_attn_qkv_wo_w13_i8_bfloat_hd128_k4_q4_t"
-I8_W13 = "mc_gemv_i8_bfloat_ling4_p1_e2"
-
-
-def test_int8_chained_block_against_the_oracle_at_8192(acc, monkeypatch):
-    import metalchat_amd as mc
-
-    monkeypatch.setenv("MC_CHAIN_W13", "1")
-    cfg = dict(dtype=BF16, n_layers=1, vocab=2048, max_seq_len=8192, norm_eps=1e-5, **FULL_WIDTH["llama3-8b"])
-    weights = synth_model(cfg, SEED, bits=8)
-    names = set()
-    agree = run_injected(acc, cfg, weights, 8187, 10, dict(weight_format=mc.WFMT_I8, group_size=128),
-                         rel_logits=5e-3, max_ulp=2, max_frac=0.7, what="8B int8 S=8192, chained", launched=names)
-    assert agree >= 8
-    assert I8_CHAIN + "4" in names and I8_BLOCK + "4" not in names and I8_W13 not in names, sorted(names)
-
-
-@pytest.mark.parametrize("S", [2048, 8192])
-def test_int8_chained_block_equals_the_two_launches_bit_for_bit(acc, monkeypatch, S):
-    import metalchat_amd as mc
-
-    cfg = dict(dtype=BF16, n_layers=2, vocab=2048, max_seq_len=S, norm_eps=1e-5, **FULL_WIDTH["llama3-8b"])
-    t = str(S // 2048)
-    out = {}
-    for form in ("chain", "three"):
-        monkeypatch.setenv("MC_CHAIN_W13", "1" if form == "chain" else "0")
-        dec = mc.Decoder(acc, **mg.decoder_kwargs(cfg, weight_format=mc.WFMT_I8, group_size=128))
-        dec.init_synthetic(SEED)
-        dec.set_taps(True)
-        dec.launch_log(True)
-        rows = []
-        for n_inject in (2, 300, S - 4):
-            for layer in range(cfg["n_layers"]):
-                k, v = random_cache(cfg, n_inject, 700 + layer)
-                dec.import_kv(layer, k, v)
-            tok = 5
-            for i in range(8):
-                tok = dec.step(tok, n_inject + i)
-                rows.append((tok, dec.logits().copy(), np.stack([dec.hidden(l) for l in range(-1, cfg["n_layers"])])))
-        caches = [dec.export_kv(l) for l in range(cfg["n_layers"])]
-        names = set(dec.launched())
-        if form == "chain":
-            assert I8_CHAIN + t in names and I8_BLOCK + t not in names and I8_W13 not in names, sorted(names)
-        else:
-            assert not [n for n in names if "_w13_" in n] and {I8_BLOCK + t, I8_W13} <= names, sorted(names)
-        assert dec.handoff_fallbacks() == 0
-        out[form] = (rows, caches)
-        dec.release()
-    for i, ((ta, la, ha), (tb_, lb, hb)) in enumerate(zip(out["chain"][0], out["three"][0])):
-        assert ta == tb_, i
-        parity.exact(ha, hb, f"int8 S={S} step {i}: hidden rows, chained launch vs the two launches")
-        parity.exact(la, lb, f"int8 S={S} step {i}: logits")
-    for l, ((ka, va), (kb, vb)) in enumerate(zip(out["chain"][1], out["three"][1])):
-        parity.exact(ka, kb, f"int8 S={S} block {l}: K cache")
-        parity.exact(va, vb, f"int8 S={S} block {l}: V cache")
