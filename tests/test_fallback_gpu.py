@@ -52,19 +52,26 @@ def hold_most_of_the_chip(acc2, seconds):
     return release, started, nhold
 
 
-@pytest.mark.parametrize("shape", ["llama3-8b", "gemma-7b"])
+@pytest.mark.parametrize("shape", ["llama3-8b", "gemma-7b", "tinyllama"])
 def test_a_step_whose_handoffs_give_up_is_repeated_without_them(monkeypatch, shape):
     import metalchat_amd as mc
 
     acc, acc2 = two_queues()   # (acc2: the "other user" of the GPU)
+    wfmt, group = mc.WFMT_I4, 128
     if shape == "llama3-8b":
         cfg = dict(dtype=BF16, n_layers=2, vocab=2048, norm_eps=1e-5, max_seq_len=2048, **FULL_WIDTH["llama3-8b"])
+    elif shape == "tinyllama":
+        # (round 6: plain bfloat weights -- the launch that gives up carries ffn_norm + w1|w3 too, mc_attn_qkv_wo_w13_w_*: its hand-off D waits on rows
+        #  that never come; the step is repeated from the embedding on the launches that need no co-residency)
+        cfg = dict(dtype=BF16, family=0, n_layers=2, vocab=2048, max_seq_len=2048, norm_eps=1e-5, dim=2048, n_heads=32, n_kv_heads=4, head_dim=64,
+                   ffn_dim=5632, rope_theta=10000.0, attn_scale=64 ** -0.5)
+        wfmt, group = mc.WFMT_T, 0
     else:
         # (round 5: the gemma3 block in one launch, mc_attn_qkv_wo_qkn_* -- the launch that gives up has read its input row from the buffer
         #  its own Wo phase writes, and workgroup 0 may have left the hidden row: the step is repeated from the embedding, so neither shows)
         cfg = dict(dtype=BF16, n_layers=2, vocab=2048, max_seq_len=2048, norm_eps=1e-5, dim=3072, n_heads=16, n_kv_heads=16, head_dim=256,
                    ffn_dim=4096, family=1, rope_theta=10000.0, rope_sliding_theta=10000.0, sliding_stride=2, attn_scale=256 ** -0.5)
-    kw = mg.decoder_kwargs(cfg, weight_format=mc.WFMT_I4, group_size=128)
+    kw = mg.decoder_kwargs(cfg, weight_format=wfmt, group_size=group)
     n = 100
 
     def fresh():
