@@ -116,6 +116,26 @@ def pmc_traffic(kernel):
         return None
 
 
+def gemv_ablations(kernel):
+    """What bounds `kernel` as a launch of its own, from the newest committed ablation summary (profiles/rNN_gemv_ablations.json: the product build
+    next to a build without weight traffic and one without arithmetic, tools/mall_probe.py): informational, measured on another box than this run."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_gemv_ablations.json")))
+    if not files:
+        return None
+    try:
+        doc = json.load(open(files[-1]))
+        k = doc["kernels"].get(kernel)
+        if not k:
+            return None
+        b = k["bytes_per_launch"]
+        return dict(full_us=k["full_us"], compute_only_us=k["compute_only_us"], stream_only_us=k["stream_only_us"],
+                    stream_only_frac=b / (k["stream_only_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, file=os.path.relpath(files[-1], ROOT), git_head=doc.get("git_head"))
+    except Exception:
+        return None
+
+
 def usable_cores():
     """Host cores this process may actually use: the affinity mask, capped by the cgroup CPU quota (a container on
     a 256-core host is often given a fraction of it; an OpenMP team of one thread per HOST core then spends its
@@ -596,6 +616,8 @@ def main():
             "bound": "hbm", "kernel": f"{kname} (w1|w3 fused, per launch)", "achieved": achieved,
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": pmc_traffic(kname),
+            # (what bounds this kernel as a launch of its own: the same launch without arithmetic / without weight traffic, profiles/rNN_gemv_ablations.json)
+            "ablations": gemv_ablations(kname),
             "bytes_per_launch": by / ln, "avg_launch_us": per * 1e3,
             "other_gemvs": per_kind,
             "attention_kernel": attn_kernel,

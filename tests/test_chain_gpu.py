@@ -117,3 +117,26 @@ def test_chained_block_graph_replay_equals_eager_across_the_end_of_the_cache(acc
         assert dec.handoff_fallbacks() == 0
         dec.release()
     assert toks["chain-graph"] == toks["chain-eager"] == toks["three-graph"]
+
+
+def test_chained_block_over_a_long_chain_of_the_whole_model(acc, monkeypatch):
+    # all 22 blocks of TinyLlama-1.1B, 400 chained greedy tokens that cross the end of the cache (the sink ring turns 80 times): the same tokens and the same
+    # last logits as the three-launch layer, and no hand-off of the 8800 chained launches gives up
+    import metalchat_amd as mc
+
+    cfg = config("tinyllama", n_layers=22)
+    S = cfg["max_seq_len"]
+    out = {}
+    for form in ("chain", "three"):
+        monkeypatch.setenv("MC_CHAIN_W13", "1" if form == "chain" else "0")
+        dec = mc.Decoder(acc, **mg.decoder_kwargs(cfg, weight_format=mc.WFMT_T, group_size=0))
+        dec.init_synthetic(SEED)
+        for layer in range(cfg["n_layers"]):
+            k, v = random_cache(cfg, S - 320, 1100 + layer)
+            dec.import_kv(layer, k, v)
+        toks = list(dec.generate(11, S - 320, 400))
+        assert dec.handoff_fallbacks() == 0
+        out[form] = (toks, dec.logits().copy())
+        dec.release()
+    assert out["chain"][0] == out["three"][0]
+    parity.exact(out["chain"][1], out["three"][1], "last logits after 400 chained tokens")
