@@ -734,7 +734,7 @@ struct mc_decoder {
         occ_qkv_qkn = hd == 256 ? ask("mc_attn_qkv_wo_qkn_i4_bfloat_hd256_k2_p2_t2", 512) : 0;
         occ_qkv_only = hd == 128 ? ask("mc_attn_qkv_i4_bfloat_hd128_q4", 512) : 0;
         occ_wo_i4_wide = hd == 128 ? ask("mc_attn_qkv_wo_i4_bfloat_hd128_k2_q2_t4", 512) : 0;
-        occ_w13 = hd == 64 ? ask("mc_attn_qkv_wo_w13_w_bfloat_hd64_k4_q4_f5", 512) : 0;
+        occ_w13 = hd == 64 ? ask("mc_attn_qkv_wo_w13_w_bfloat_hd64_k4_q4_f4p4", 512) : 0;
         // (one kernel per family is asked: the widest-range / most-register instantiation, which bounds the others -- every form is ONE 512-thread
         //  workgroup per CU, so the answer that matters is "at least one")
         (void)hipGetLastError();
@@ -880,9 +880,9 @@ struct mc_decoder {
         return 0;
     }
 
-    // ... AND ffn_norm + w1|w3 + act*mul as the next phase of that launch (round 6, mc_attn_qkv_wo_w13_w_bfloat_hd64_k4_q4_f{4,5}, attn_block_kernels.hip):
+    // ... AND ffn_norm + w1|w3 + act*mul as the next phase of that launch (round 6, mc_attn_qkv_wo_w13_w_bfloat_hd64_k4_q4_f{3p3,4p4}, attn_block_kernels.hip):
     // behind the Wo phase half the waves of every workgroup fetch w1|w3 row pairs into registers while the other half waits for the hidden row.
-    // 64-slot ranges, exactly one workgroup per CU, w1|w3 plain bfloat with K = 2048, no adaptor.  Returns the pairs per fetcher wave (4 or 5), 0 = no.
+    // 64-slot ranges, exactly one workgroup per CU, w1|w3 plain bfloat with K = 2048, no adaptor.  Returns 10 F + P (pairs per fetcher wave, most pairs of a poller wave), 0 = no.
     int
     attn_qkv_wo_w13_w_fetch(const layer_w& L) const
     {
@@ -890,10 +890,14 @@ struct mc_decoder {
         const unsigned grid = (unsigned)(nsplit * (cfg.n_kv_heads << kv_virtual_shift()));
         if (cfg.dim != 2048 || L.w13.in != 2048 || L.w13.out % 2 || grid != (unsigned)dev->prop.multiProcessorCount || lin_waves != 8) return 0;
         const unsigned nb = ((unsigned)L.w13.out / 2 + grid - 1) / grid; // pairs of the fullest workgroup
-        // (the fetchers F each -- what hand-off D's ~ 4 us bring in --, the pollers the rest, at most F each: TinyLlama's 22 = 4 x 4 + (2, 2, 1, 1),
-        //  Llama-3.2-1B's 32 = 4 x 5 + 4 x 3)
-        const unsigned f = nb > 24u ? 5u : 4u;
-        return nb <= 8u * f && nb >= 4u * f ? (int)f : 0;
+        // (the fetchers F each, the pollers the rest, at most P each.  Returns 10 F + P.)
+        unsigned f = nb <= 24u ? 3u : 4u;
+        if (const char* e = getenv("MC_CHAIN_F")) f = (unsigned)atoi(e); // (tuning: tools/ab_case_multi.sh)
+        if (f < 1u || 4u * f > nb) return 0;
+        const unsigned p_ = (nb - 4u * f + 3u) / 4u; // the fullest poller
+        // built: f3p3 (22 pairs per workgroup: TinyLlama) and f4p4 (32: Llama-3.2-1B) -- the even deals, the measured best (attn_block_kernels.hip)
+        const unsigned pcap = f == 3u ? 3u : (f == 4u ? 4u : 0u);
+        return pcap && p_ <= pcap ? (int)(10u * f + pcap) : 0;
     }
 
     // ... the same launch for INT8 weights (round 5, mc_attn_qkv_wo_i8_bfloat_hd128_k4_q4_t{1,4}: Llama-3-8B int8): rows of 4 KiB (K = 4096),
@@ -1177,7 +1181,7 @@ struct mc_decoder {
             if (chain_f) {
                 // ... and ffn_norm, w1|w3, act*mul (transformer.h:135-137, 53-59) too: the block up to the gate row in ONE launch
                 const int vsh = kv_virtual_shift();
-                s = launch("mc_attn_qkv_wo_w13_w_bfloat_hd64_k4_q4_f" + std::to_string(chain_f), (unsigned)(nsplit * (KV << vsh)), 1, 1, 512, 0,
+                s = launch("mc_attn_qkv_wo_w13_w_bfloat_hd64_k4_q4_f" + std::to_string(chain_f / 10) + "p" + std::to_string(chain_f % 10), (unsigned)(nsplit * (KV << vsh)), 1, 1, 512, 0,
                            pack((const void*)L.kc, (const void*)L.vt, attn_out, attn_psum_g, attn_slab_g, attn_row_g, attn_qkv_g, state,
                                 (uint32_t)(n_rep >> vsh), (uint32_t)(KV << vsh), (uint32_t)cfg.max_seq_len, scale_T, (uint32_t)nsplit, (uint32_t)(li + 1),
                                 (const void*)L.wo.w, (const void*)L.wo.scales, x, hidden, (uint32_t)L.wo.out, (uint32_t)L.wo.group,
@@ -3124,7 +3128,7 @@ mc_decoder_gemv_kernel_name(mc_decoder* d, const char* which, char* buf, size_t 
         const std::string i4name = "mc_attn_qkv_wo_i4_" + d->tname + "_hd" + std::to_string(d->cfg.head_dim) + "_k" + std::to_string(wo.in / 2048) + "_q" +
                                    std::to_string(L0.qkv.in / 2048);
         const int chf = wt == 1 ? d->attn_qkv_wo_w13_w_fetch(L0) : 0; // (round 6: ffn_norm + w1|w3 + act*mul in the launch too)
-        name = chf ? "mc_attn_qkv_wo_w13_w_bfloat_hd64_k4_q4_f" + std::to_string(chf)
+        name = chf ? "mc_attn_qkv_wo_w13_w_bfloat_hd64_k4_q4_f" + std::to_string(chf / 10) + "p" + std::to_string(chf % 10)
                : wt ? std::string("mc_attn_qkv_wo_w_bfloat_hd64_k4_q4") + (wt > 1 ? "_t" + std::to_string(wt) : std::string())
                : d->attn_qkv_wo_i8_tiles(L0) ? "mc_attn_qkv_wo_i8_bfloat_hd128_k4_q4_t" + std::to_string(d->attn_qkv_wo_i8_tiles(L0))
                : d->attn_qkv_wo_fused(L0) ? i4name

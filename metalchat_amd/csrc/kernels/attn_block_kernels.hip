@@ -1225,8 +1225,8 @@ template <int N> __device__ __forceinline__ void w13_wait(w13_v4& a, w13_v4& b, 
     asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N) : "memory");
 }
 
-// F: pairs of each fetcher wave; the pollers share what is left of the workgroup's pairs (the host: at most F each)
-template <int HD, int F>
+// F: pairs of each fetcher wave; the pollers share what is left of the workgroup's pairs (the host: at most P each)
+template <int HD, int F, int P>
 __device__ __forceinline__ void
 attn_qkv_wo_w13_w_body(const bf16_t* kc, const bf16_t* vt, bf16_t* attn_out, unsigned long long* psum_g, unsigned long long* slab_g, unsigned long long* row_g,
                        unsigned long long* qkv_g, step_state* st, uint32_t n_rep, uint32_t KV, uint32_t max_seq, float scale, uint32_t nsplit, uint32_t layer_tag,
@@ -1237,6 +1237,7 @@ attn_qkv_wo_w13_w_body(const bf16_t* kc, const bf16_t* vt, bf16_t* attn_out, uns
 {
     constexpr uint32_t KF = 2048u, ROWB = 4096u; // dim 2048: rows of 4 KiB, 256 packets of the hidden row
     constexpr int PK = 4;                        // packets (KiB) per row
+    constexpr int PM = F > P ? F : P;            // pairs a wave may hold
     __shared__ __attribute__((aligned(16))) char xs13[KF * 2];
     __shared__ float red13[16];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1287,9 +1288,9 @@ attn_qkv_wo_w13_w_body(const bf16_t* kc, const bf16_t* vt, bf16_t* attn_out, uns
     stamp2(41, 0);
     // ---- every wave's requests, in ONE place (the fetchers reach it ~ 4 us before the pollers): the wave's pairs (a pair the wave does not
     // have reads one broadcast line: masks, not selects)
-    w13_v4 wreg[F][2 * PK];
+    w13_v4 wreg[PM][2 * PK];
 #pragma unroll
-    for (int i = 0; i < F; i++) {
+    for (int i = 0; i < PM; i++) {
         const uint32_t lm = 0u - (uint32_t)((uint32_t)i < cnt ? 1u : 0u);
         const uint64_t lm64 = ((uint64_t)lm << 32) | lm;
         const char* a = static_cast<const char*>(w13_w) + (((uint64_t)(pb + (uint32_t)i) * 2u * ROWB) & lm64) + ((lane * 16u) & lm);
@@ -1297,7 +1298,7 @@ attn_qkv_wo_w13_w_body(const bf16_t* kc, const bf16_t* vt, bf16_t* attn_out, uns
         for (int t = 0; t < 2 * PK; t++) w13_load16(wreg[i][t], a + ((t * 1024u) & lm));
     }
     // (issued behind this point: nothing until the epilogue's store -- the counts below are exact)
-    constexpr int NW = F * 2 * PK; // weight loads, the youngest
+    constexpr int NW = PM * 2 * PK; // weight loads, the youngest
     // ---- ffn_norm on the way into LDS (kernel/rmsnorm.metal:52-95; gemv.h LGEN, the build-time prologue: the same additions in the same order)
     {
         const uint32_t vv[4] = {xr.x, xr.y, xr.z, xr.w};
@@ -1363,11 +1364,12 @@ attn_qkv_wo_w13_w_body(const bf16_t* kc, const bf16_t* vt, bf16_t* attn_out, uns
         }
     };
     pair_step(std::integral_constant<int, 0>{});
-    if constexpr (F > 1) pair_step(std::integral_constant<int, 1>{});
-    if constexpr (F > 2) pair_step(std::integral_constant<int, 2>{});
-    if constexpr (F > 3) pair_step(std::integral_constant<int, 3>{});
-    if constexpr (F > 4) pair_step(std::integral_constant<int, 4>{});
-    static_assert(F >= 1 && F <= 5, "the steps above");
+    if constexpr (PM > 1) pair_step(std::integral_constant<int, 1>{});
+    if constexpr (PM > 2) pair_step(std::integral_constant<int, 2>{});
+    if constexpr (PM > 3) pair_step(std::integral_constant<int, 3>{});
+    if constexpr (PM > 4) pair_step(std::integral_constant<int, 4>{});
+    if constexpr (PM > 5) pair_step(std::integral_constant<int, 5>{});
+    static_assert(F >= 1 && PM <= 6, "the steps above");
     // ---- the epilogue of gemv.h finish_pair (EPI_SILU_MUL), one lane per pair: out[j] = T(silu(T(w1 x)) * T(w3 x))
     if (lane < cnt) {
         const float ga = BF::rt(my_a), gb = BF::rt(my_b);
@@ -1380,8 +1382,8 @@ attn_qkv_wo_w13_w_body(const bf16_t* kc, const bf16_t* vt, bf16_t* attn_out, uns
 
 } // namespace
 
-// mc_attn_qkv_wo_w13_w_bfloat_hd{head_dim}_k{KiB per Wo row}_q{KiB per wq|wk|wv row}_f{pairs of w1|w3 per fetcher wave}
-#define MC_ATTN_QKV_WO_W13_W(NAME, HD, F)                                                                                                \
+// mc_attn_qkv_wo_w13_w_bfloat_hd{head_dim}_k{KiB per Wo row}_q{KiB per wq|wk|wv row}_f{pairs of w1|w3 per fetcher wave}p{most pairs of a poller wave}
+#define MC_ATTN_QKV_WO_W13_W(NAME, HD, F, P)                                                                                             \
     extern "C" __global__ void __launch_bounds__(512)                                                                                    \
     NAME(const bf16_t* kc, const bf16_t* vt, bf16_t* attn_out, unsigned long long* psum_g, unsigned long long* slab_g,                  \
          unsigned long long* row_g, unsigned long long* qkv_g, step_state* st, uint32_t n_rep, uint32_t n_kv, uint32_t max_seq,         \
@@ -1390,9 +1392,12 @@ attn_qkv_wo_w13_w_body(const bf16_t* kc, const bf16_t* vt, bf16_t* attn_out, uns
          float mu, uint32_t fastpath, unsigned long long* tl, uint32_t kv_shift, unsigned long long* hid_g, const void* w13_w,           \
          const void* ffn_norm, bf16_t* gate, uint32_t ffn_rows, unsigned long long* tl2)                                                 \
     {                                                                                                                                    \
-        attn_qkv_wo_w13_w_body<HD, F>(kc, vt, attn_out, psum_g, slab_g, row_g, qkv_g, st, n_rep, n_kv, max_seq, scale, nsplit, layer_tag, wo_w, wo_s, x, y, \
-                                      out_rows, group, qnorm_w, qkv_w, qkv_s, fcos, fsin, eps, mu, fastpath, tl, kv_shift, hid_g, w13_w, ffn_norm, gate,   \
-                                      ffn_rows, tl2);                                                                                    \
+        attn_qkv_wo_w13_w_body<HD, F, P>(kc, vt, attn_out, psum_g, slab_g, row_g, qkv_g, st, n_rep, n_kv, max_seq, scale, nsplit, layer_tag, wo_w, wo_s, x, y, \
+                                         out_rows, group, qnorm_w, qkv_w, qkv_s, fcos, fsin, eps, mu, fastpath, tl, kv_shift, hid_g, w13_w, ffn_norm, gate, \
+                                         ffn_rows, tl2);                                                                                 \
     }
-MC_ATTN_QKV_WO_W13_W(mc_attn_qkv_wo_w13_w_bfloat_hd64_k4_q4_f4, 64, 4) // TinyLlama-1.1B: 22 pairs per workgroup = 4 x 4 + (2, 2, 1, 1)
-MC_ATTN_QKV_WO_W13_W(mc_attn_qkv_wo_w13_w_bfloat_hd64_k4_q4_f5, 64, 5) // Llama-3.2-1B:   32 pairs per workgroup = 4 x 5 + 4 x 3
+// How many pairs the fetchers take decides how long hand-off D lasts (its polls drain behind them in the CU's memory queue) against how much is left to
+// stream behind it.  Same box, alternating, tokens/s: TinyLlama (22 pairs per workgroup) F = 1 / 2 / 3 / 4 / 5: 1498 / 1534 / 1578-1603 / 1560-1567 / 1507-1520;
+// Llama-3.2-1B (32 pairs) F = 2 / 3 / 4 / 5: 1620 / 1650 / 1661 / 1643 (profiles/r06_ab_chain_f*.log) -- the even deal wins: every wave the same number of pairs.
+MC_ATTN_QKV_WO_W13_W(mc_attn_qkv_wo_w13_w_bfloat_hd64_k4_q4_f3p3, 64, 3, 3) // TinyLlama-1.1B: 22 pairs per workgroup = 4 x 3 + (3, 3, 2, 2)
+MC_ATTN_QKV_WO_W13_W(mc_attn_qkv_wo_w13_w_bfloat_hd64_k4_q4_f4p4, 64, 4, 4) // Llama-3.2-1B:   32 pairs per workgroup = 4 x 4 + 4 x 4

@@ -1,5 +1,5 @@
 """Round 6: the attention block AND ffn_norm + w1|w3 + SiLU * mul in one launch for plain bfloat weights
-(mc_attn_qkv_wo_w13_w_bfloat_hd64_k4_q4_f{4,5}, attn_block_kernels.hip; MC_CHAIN_W13=0 switches it off) at TinyLlama-1.1B's (BASELINE configs[0]
+(mc_attn_qkv_wo_w13_w_bfloat_hd64_k4_q4_f{3p3,4p4}, attn_block_kernels.hip; MC_CHAIN_W13=0 switches it off) at TinyLlama-1.1B's (BASELINE configs[0]
 on the GPU: 4 kv heads as 8 virtual ones, 22 row pairs of w1|w3 per workgroup) and Llama-3.2-1B's (the reference's default model: 32 pairs) widths.
 
   * against the oracle: S = 2048, kv_len 2045 .. 2048 and rolls past the end, and position 40 (all but one range of the launch empty);
@@ -20,8 +20,8 @@ BF16 = 0
 BLOCK = "mc_attn_qkv_wo_w_bfloat_hd64_k4_q4"
 W13 = "mc_gemv_w_bfloat_ling4_p1_e2"
 SHAPES = {
-    "tinyllama": (dict(n_kv_heads=4, ffn_dim=5632, rope_theta=10000.0), "mc_attn_qkv_wo_w13_w_bfloat_hd64_k4_q4_f4"),
-    "llama3.2-1b": (dict(n_kv_heads=8, ffn_dim=8192, rope_theta=500000.0), "mc_attn_qkv_wo_w13_w_bfloat_hd64_k4_q4_f5"),
+    "tinyllama": (dict(n_kv_heads=4, ffn_dim=5632, rope_theta=10000.0), "mc_attn_qkv_wo_w13_w_bfloat_hd64_k4_q4_f3p3"),
+    "llama3.2-1b": (dict(n_kv_heads=8, ffn_dim=8192, rope_theta=500000.0), "mc_attn_qkv_wo_w13_w_bfloat_hd64_k4_q4_f4p4"),
 }
 
 

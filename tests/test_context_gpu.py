@@ -316,7 +316,7 @@ def test_tinyllama_1b_shapes_end_to_end(acc, dtype):
         # (round 5: three launches per block -- the 4 kv heads as 8 virtual ones inside mc_attn_qkv_wo_w_*,
         #  test_tinyllama_takes_the_one_launch_block_as_eight_virtual_kv_heads below holds that form next to the five launches)
         # (round 6: TWO launches per block -- ffn_norm + w1|w3 + act*mul is a phase of the attention launch, mc_attn_qkv_wo_w13_w_*: tests/test_chain_gpu.py)
-        assert {"mc_attn_qkv_wo_w13_w_bfloat_hd64_k4_q4_f4", "mc_gemv_w_bfloat_ling11_p0_e1", "mc_gemv_w_bfloat_ling4_p1_e5"} <= names, sorted(names)
+        assert {"mc_attn_qkv_wo_w13_w_bfloat_hd64_k4_q4_f3p3", "mc_gemv_w_bfloat_ling11_p0_e1", "mc_gemv_w_bfloat_ling4_p1_e5"} <= names, sorted(names)
         assert "mc_gemv_w_bfloat_ling4_p1_e2" not in names and "mc_attn_qkv_wo_w_bfloat_hd64_k4_q4" not in names, sorted(names)
         assert not {"mc_gemv_w_bfloat_ling4_p1_e4", "mc_attn_fused_bfloat", "mc_gemv_w_bfloat_ling4_p0_e1"} & names, sorted(names)
 
@@ -335,7 +335,7 @@ def test_llama32_1b_shapes_take_the_one_launch_block_with_plain_weights(acc, mon
     agree = run_injected(acc, cfg, weights, 2044, 8, dict(weight_format=mc.WFMT_T, group_size=0), rel_logits=7.8e-3,
                          max_ulp=3, max_frac=0.8, what="llama3.2-1b S=2048", launched=names)
     assert agree >= 7
-    assert "mc_attn_qkv_wo_w13_w_bfloat_hd64_k4_q4_f5" in names and "mc_gemv_w_bfloat_ling4_p1_e4" not in names, sorted(names)   # (round 6: + w1|w3)
+    assert "mc_attn_qkv_wo_w13_w_bfloat_hd64_k4_q4_f4p4" in names and "mc_gemv_w_bfloat_ling4_p1_e4" not in names, sorted(names)   # (round 6: + w1|w3)
     agree = run_injected(acc, cfg, weights, 40, 8, dict(weight_format=mc.WFMT_T, group_size=0), rel_logits=7.8e-3,
                          max_ulp=3, max_frac=0.8, what="llama3.2-1b at position 40 (all but one range of the launch empty)")
     assert agree >= 7
@@ -349,7 +349,7 @@ def test_llama32_1b_shapes_take_the_one_launch_block_with_plain_weights(acc, mon
             dec.import_kv(layer, k, v)
         dec.launch_log(True)
         toks = list(dec.generate(9, 1500, 12))
-        assert ("mc_attn_qkv_wo_w13_w_bfloat_hd64_k4_q4_f5" in set(dec.launched())) == (form == "1")
+        assert ("mc_attn_qkv_wo_w13_w_bfloat_hd64_k4_q4_f4p4" in set(dec.launched())) == (form == "1")
         out[form] = (toks, dec.logits().copy())
         dec.release()
     assert out["1"][0] == out["0"][0]
@@ -406,7 +406,7 @@ def test_tinyllama_takes_the_one_launch_block_as_eight_virtual_kv_heads(acc, mon
     agree = run_injected(acc, cfg, weights, 2044, 8, dict(weight_format=mc.WFMT_T, group_size=0), rel_logits=7.8e-3,
                          max_ulp=3, max_frac=0.8, what="tinyllama S=2048, virtual kv heads", launched=names)
     assert agree >= 7
-    assert "mc_attn_qkv_wo_w13_w_bfloat_hd64_k4_q4_f4" in names and "mc_gemv_w_bfloat_ling4_p1_e4" not in names, sorted(names)   # (round 6: + w1|w3)
+    assert "mc_attn_qkv_wo_w13_w_bfloat_hd64_k4_q4_f3p3" in names and "mc_gemv_w_bfloat_ling4_p1_e4" not in names, sorted(names)   # (round 6: + w1|w3)
     out = {}
     for form in ("1", "0"):
         monkeypatch.setenv("MC_KV_VIRTUAL", form)
@@ -417,7 +417,7 @@ def test_tinyllama_takes_the_one_launch_block_as_eight_virtual_kv_heads(acc, mon
             dec.import_kv(layer, k, v)
         dec.launch_log(True)
         toks = list(dec.generate(9, 1500, 12))
-        assert ("mc_attn_qkv_wo_w13_w_bfloat_hd64_k4_q4_f4" in set(dec.launched())) == (form == "1"), sorted(set(dec.launched()))
+        assert ("mc_attn_qkv_wo_w13_w_bfloat_hd64_k4_q4_f3p3" in set(dec.launched())) == (form == "1"), sorted(set(dec.launched()))
         out[form] = (toks, dec.logits().copy(), dec.export_kv(0))
         dec.release()
     assert out["1"][0] == out["0"][0]

@@ -62,7 +62,7 @@ def test_decode_and_reference_kernels_present(symbols):
               "mc_attn_qkv_wo_i4_bfloat_hd128_k2_q2",  # wq|wk|wv, attention and Wo in one launch (round 4)
               "mc_attn_qkv_wo_i4_bfloat_hd128_k2_q2_t2", "mc_attn_qkv_wo_i4_bfloat_hd128_k2_q2_t4",  # ... 128- / 256-slot ranges (attn_qkv_wo_i4_wide_tiles)
               "mc_attn_qkv_wo_w_bfloat_hd64_k4_q4",    # ... for plain bfloat weights (decoder.cc attn_qkv_wo_w_fused)
-              "mc_attn_qkv_wo_w13_w_bfloat_hd64_k4_q4_f4", "mc_attn_qkv_wo_w13_w_bfloat_hd64_k4_q4_f5",  # ... + ffn_norm + w1|w3 + act*mul (round 6: attn_qkv_wo_w13_w_fetch)
+              "mc_attn_qkv_wo_w13_w_bfloat_hd64_k4_q4_f3p3", "mc_attn_qkv_wo_w13_w_bfloat_hd64_k4_q4_f4p4",  # ... + ffn_norm + w1|w3 + act*mul (round 6: attn_qkv_wo_w13_w_fetch)
               "mc_gemv_i4_bfloat_lin12k4_p0_e0", "mc_gemv_i4_bfloat_lin12k4_p0_e1",  # Gemma-7B's w2: the K range of a pair over four waves (gemv_ksplit.h)
               "mc_attn_qkv_i4_bfloat_hd128_q4",        # ... without Wo, rows of 4 KiB (Llama-3-70B; decoder.cc attn_qkv_only_ok)
               "mc_attn_qkv_wo_i8_bfloat_hd128_k4_q4_t1", "mc_attn_qkv_wo_i8_bfloat_hd128_k4_q4_t2", "mc_attn_qkv_wo_i8_bfloat_hd128_k4_q4_t4",

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Where a launch of mc_attn_qkv_wo_w13_w_bfloat_hd64_k4_q4_f{4,5} (round 6: the plain-weight attention block + ffn_norm + w1|w3 + SiLU * mul in one
+"""Where a launch of mc_attn_qkv_wo_w13_w_bfloat_hd64_k4_q4_f{3p3,4p4} (round 6: the plain-weight attention block + ffn_norm + w1|w3 + SiLU * mul in one
 launch) spends its time, next to the two launches it replaces on the same buffers.  TinyLlama-1.1B (MODEL=tinyllama: 4 kv heads as 8 virtual ones,
 ffn 5632) or Llama-3.2-1B (MODEL=llama32: 8 kv heads, ffn 8192) shapes, a full cache of 2048 slots, the matrices of a synthetic decoder of L layers,
 launches back to back with consecutive layer tags; s_memrealtime stamps (100 MHz) of every workgroup:
@@ -18,7 +18,7 @@ import modelgen as mg
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 L = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 TINY = os.environ.get("MODEL", "tinyllama") == "tinyllama"
-H, KVR, hd, S, dim, ffn, F = (32, 4, 64, 2048, 2048, 5632, 4) if TINY else (32, 8, 64, 2048, 2048, 8192, 5)
+H, KVR, hd, S, dim, ffn, F = (32, 4, 64, 2048, 2048, 5632, "3p3") if TINY else (32, 8, 64, 2048, 2048, 8192, "4p4")
 VSH = 1 if TINY else 0                      # virtual kv heads (decoder.cc kv_virtual_shift)
 KV, n_rep, nsplit = KVR << VSH, (H // KVR) >> VSH, S // 64
 WGS = nsplit * KV
