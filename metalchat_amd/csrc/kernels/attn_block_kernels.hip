@@ -1186,7 +1186,7 @@ MC_ATTN_WO(mc_attn_wo_i4_bfloat_hd256_k2, 256, 2)  // Gemma-7B shapes: 16 heads 
 
 // ------------------------------------------------------------------------------------------
 // Round 6: the attention block AND ffn_norm + w1|w3 + SiLU * mul (include/metalchat/nn/transformer.h:130-137, 53-59) in one launch, for PLAIN
-// bfloat weights (nn::linear; TinyLlama-1.1B, Llama-3.2-1B): mc_attn_qkv_wo_w13_w_bfloat_hd64_k4_q4_f{4,5}.
+// bfloat weights (nn::linear; TinyLlama-1.1B, Llama-3.2-1B): mc_attn_qkv_wo_w13_w_bfloat_hd64_k4_q4_f{3p3,4p4}.
 //
 // The same chain was built three ways for the int4 headline first and lost every time (tools/experiments/README.md, round 6): with every weight
 // on chip the exact int4 dequantisation alone takes the eight waves 6.6 - 8 us per workgroup, as long as the stand-alone launch needs to stream
