@@ -262,6 +262,12 @@ struct mc_decoder {
     bool kv_virtual_on = true; // MC_KV_VIRTUAL: fewer than 8 kv heads launched as 8 virtual ones where wq|wk|wv is inside the attention launch (kv_virtual_shift)
     bool pf_attn8_on = true;   // MC_PF_ATTN8: the prompt attention with K / V tiles through LDS, from pf_attn8_rows rows on
     int pf_attn8_rows = 1024;  // MC_PF_ATTN8_ROWS
+    int pf_plain_mode = -1;    // MC_PF_PLAIN_COPY: 1 = the 256 x 256 prompt GEMM multiplies quantised matrices from their dequantised bfloat16 copy (linear_w::wd, built on
+                               // first use, 2 bytes per weight more HBM: the very values the quantised loop stages in LDS, same loop, same sums bit for bit -- without
+                               // the dequantisation that competes with the MFMAs for the issue port), 0 = from the quantised rows; unset = 1 iff the copies of every
+                               // block's matrices fit an eighth of the device's memory (Llama-3-8B: 14 of 288 GB, yes; 70B: 137 GB, no)
+    bool pf_plain_on = false;  // ... resolved when the first long prompt arrives (plain_copy_ok)
+    bool pf_plain_known = false;
     bool pf_g8_on = true;      // MC_PF_GEMM8: prompts of pf_g8_rows rows and more take the 256 x 256 ping-pong GEMM (kernels/pf_gemm8.h)
     int pf_g8_max_splits = 16, pf_g8_min_ktiles = 8; // MC_PF_GEMM8_MAXSPLIT, MC_PF_GEMM8_MINKT: K ranges of a launch (g8_splits)
     int pf_g8_rows = 384;      // MC_PF_GEMM8_ROWS (measured round 5: 256 rows 7.42 ms with, 7.06 without -- one row of tiles leaves half the chip idle; 512 rows 10.13 against 11.66)
@@ -1661,9 +1667,40 @@ struct mc_decoder {
         while (splits < (unsigned)pf_g8_max_splits && tiles * splits * 2 <= cus && (unsigned)L.in / 64u / (splits * 2) >= (unsigned)pf_g8_min_ktiles) splits *= 2;
         return getenv("MC_PF_NO_SPLITK") ? 1u : splits;
     }
+    // the quantised matrices of long prompts as dequantised bfloat16 copies (pf_plain_mode above)
+    bool
+    plain_copy_ok()
+    {
+        if (!pf_plain_known) {
+            pf_plain_known = true;
+            if (pf_plain_mode >= 0) pf_plain_on = pf_plain_mode != 0;
+            else {
+                size_t need = 0;
+                auto one = [&](const linear_w& L) {
+                    if (L.fmt != MC_WFMT_T) need += (size_t)L.out * L.in * 2;
+                };
+                for (const layer_w& L : layers) {
+                    one(L.qkv);
+                    one(L.wo);
+                    one(L.w13);
+                    one(L.w2);
+                }
+                pf_plain_on = need > 0 && need <= dev->prop.totalGlobalMem / 8;
+            }
+        }
+        return pf_plain_on;
+    }
     mc_status
     g8_launch(const linear_w& L, int epi, const void* X, void* Y, const void* res, int M, unsigned splits)
     {
+        if (L.fmt != MC_WFMT_T && plain_copy_ok()) {
+            const void* wd = nullptr;
+            if (ensure_wd(L, &wd) == MC_OK)
+                return launch("mc_pf_gemm8_w_bfloat_e" + std::to_string(epi), (L.out + 255) / 256, (M + 255) / 256, splits, 512, 0,
+                              pack(wd, (const void*)nullptr, X, Y, res, (uint32_t)M, (uint32_t)L.out, (uint32_t)L.in, (uint32_t)0, (const void*)nullptr,
+                                   (const void*)nullptr, (uint32_t)0, 0.0f));
+            pf_plain_on = false; // (no memory for the copy: the quantised rows from here on)
+        }
         const std::string f = L.fmt == MC_WFMT_I4 ? "i4" : (L.fmt == MC_WFMT_I8 ? "i8" : "w");
         return launch("mc_pf_gemm8_" + f + "_bfloat_e" + std::to_string(epi), (L.out + 255) / 256, (M + 255) / 256, splits, 512, 0,
                       pack(L.w, L.scales, X, Y, res, (uint32_t)M, (uint32_t)L.out, (uint32_t)L.in, (uint32_t)L.group, (const void*)nullptr,
@@ -2212,6 +2249,7 @@ mc_decoder_create(mc_device* dev, mc_library* lib, mc_queue* q, const mc_decoder
     if (const char* e = getenv("MC_PF_ATTN8")) d->pf_attn8_on = atoi(e) != 0;
     if (const char* e = getenv("MC_PF_ATTN8_ROWS")) d->pf_attn8_rows = std::max(1, atoi(e));
     if (const char* e = getenv("MC_PF_GEMM8")) d->pf_g8_on = atoi(e) != 0;
+    if (const char* e = getenv("MC_PF_PLAIN_COPY")) d->pf_plain_mode = atoi(e) != 0 ? 1 : 0;
     if (const char* e = getenv("MC_PF_GEMM8_ROWS")) d->pf_g8_rows = std::max(1, atoi(e));
     if (const char* e = getenv("MC_PF_GEMM8_MAXSPLIT")) d->pf_g8_max_splits = std::max(1, atoi(e));
     if (const char* e = getenv("MC_PF_GEMM8_MINKT")) d->pf_g8_min_ktiles = std::max(1, atoi(e));

@@ -538,20 +538,27 @@ def test_two_head_prompt_attention_sliding_window_and_second_chunk(acc, monkeypa
 
 # ---- the 256 x 256 ping-pong GEMM of long prompts (kernels/pf_gemm8.h, decoder.cc g8_ok: from 384 rows on; MC_PF_GEMM8_ROWS lowers the
 # gate so that shorter prompts of the models the oracle can follow reach it too).  Kernel-level parity: tests/test_gemm8_gpu.py.
-@pytest.mark.parametrize("quant,fmt,group", [("i4", 2, 32), ("i4", 2, 128), ("i8", 1, 32), (None, 0, 0)])
+@pytest.mark.parametrize("quant,fmt,group,copy", [("i4", 2, 32, "0"), ("i4", 2, 128, "0"), ("i8", 1, 32, "0"), (None, 0, 0, None),
+                                                  ("i4", 2, 128, None), ("i8", 1, 32, None)])
 @pytest.mark.parametrize("n,gate", [(400, None), (300, "192"), (257, "192")])
-def test_long_prompts_take_the_ping_pong_gemm_and_match_the_oracle(acc, n, gate, quant, fmt, group, monkeypatch):
+def test_long_prompts_take_the_ping_pong_gemm_and_match_the_oracle(acc, n, gate, quant, fmt, group, copy, monkeypatch):
     """Every linear of the block through mc_pf_gemm8_*: wq|wk|wv / wo / w2 with a plain store or residual (these models are too
-    narrow to split K), w1|w3 with silu * mul in its epilogue; no copy of the weights is built (mc_decoder_derived_weight_bytes
-    stays 0) and the library is never called."""
+    narrow to split K), w1|w3 with silu * mul in its epilogue; the library is never called.  Quantised matrices multiply from their
+    dequantised bfloat16 copies (round 6, decoder.cc plain_copy_ok: the default where the copies fit an eighth of the device's memory --
+    mc_pf_gemm8_w_* on linear_w::wd) or, with MC_PF_PLAIN_COPY=0, from the quantised rows (no copy: mc_decoder_derived_weight_bytes stays 0)."""
     import metalchat_amd as mc
 
     if gate:
         monkeypatch.setenv("MC_PF_GEMM8_ROWS", gate)
+    if copy is not None:
+        monkeypatch.setenv("MC_PF_PLAIN_COPY", copy)
+    else:
+        monkeypatch.delenv("MC_PF_PLAIN_COPY", raising=False)
     cfg = mg.tiny_cfg(BF16, dim=256, n_heads=4, n_kv_heads=2, head_dim=64, ffn_dim=768, n_layers=2, vocab=384, max_seq_len=448)
     weights = mg.make_model(cfg, seed=101, quant=quant, group=group or 32)
     tokens = np.random.default_rng(n + fmt).integers(0, cfg["vocab"], n).tolist()
-    f = {2: "i4", 1: "i8", 0: "w"}[fmt]
+    copied = fmt != 0 and copy is None
+    f = "w" if copied else {2: "i4", 1: "i8", 0: "w"}[fmt]
     check_against_oracle(acc, cfg, weights, dict(weight_format=fmt, group_size=group), tokens, follow=2, expect_kernel=f"mc_pf_gemm8_{f}_bfloat_e3")
     dec = mc.Decoder(acc, **mg.decoder_kwargs(cfg, weight_format=fmt, group_size=group))
     dec.load_model(weights)
@@ -559,17 +566,69 @@ def test_long_prompts_take_the_ping_pong_gemm_and_match_the_oracle(acc, n, gate,
     dec.prefill(tokens, 0)
     names = dec.launched()
     assert not [x for x in names if x.startswith("mc_pf_gemm") and not x.startswith("mc_pf_gemm8_")], sorted(set(names))
-    assert "hipblasLtMatmul" not in names and not [x for x in names if x.startswith("mc_pf_dequant_rows")]
-    assert dec.derived_weight_bytes() == 0
+    assert "hipblasLtMatmul" not in names
+    lin_weights = cfg["n_layers"] * (cfg["dim"] * (cfg["n_heads"] + 2 * cfg["n_kv_heads"]) * cfg["head_dim"] + cfg["n_heads"] * cfg["head_dim"] * cfg["dim"]
+                                     + 3 * cfg["dim"] * cfg["ffn_dim"])
+    if copied:
+        assert not [x for x in names if x.startswith("mc_pf_gemm8_i")], sorted(set(names))
+        assert len([x for x in names if x.startswith("mc_pf_dequant_rows")]) == 4 * cfg["n_layers"]
+        assert dec.derived_weight_bytes() == 2 * lin_weights
+        dec.launch_log(True)
+        dec.prefill(tokens, 0)   # the copies are built once
+        assert not [x for x in dec.launched() if x.startswith("mc_pf_dequant_rows")]
+    else:
+        assert not [x for x in names if x.startswith("mc_pf_dequant_rows")]
+        assert dec.derived_weight_bytes() == 0
     dec.release()
 
 
-def test_wide_long_prompt_splits_k_in_the_ping_pong_gemm(acc):
+@pytest.mark.parametrize("quant,fmt,group", [("i4", 2, 128), ("i4", 2, 32), ("i8", 1, 32)])
+def test_the_dequantised_copy_changes_no_bit_of_a_long_prompt(acc, quant, fmt, group, monkeypatch):
+    """MC_PF_PLAIN_COPY=1 against =0: the copy holds Wd = T(T(q) T(s)), the values the quantised loop stages in LDS, and mc_pf_gemm8_w_* is the
+    same loop -- hidden rows of every block, logits, the next tokens and both caches are equal bit for bit."""
+    import metalchat_amd as mc
+
+    cfg = mg.tiny_cfg(BF16, dim=2048, n_heads=4, n_kv_heads=1, head_dim=128, ffn_dim=1024, n_layers=2, vocab=512, max_seq_len=448)
+    weights = mg.make_model(cfg, seed=105, quant=quant, group=group)
+    tokens = np.random.default_rng(9).integers(0, cfg["vocab"], 400).tolist()
+    out = {}
+    for copy in ("1", "0"):
+        monkeypatch.setenv("MC_PF_PLAIN_COPY", copy)
+        dec = mc.Decoder(acc, **mg.decoder_kwargs(cfg, weight_format=fmt, group_size=group))
+        dec.load_model(weights)
+        dec.set_taps(True)
+        dec.launch_log(True)
+        tok = dec.prefill(tokens, 0)
+        names = set(dec.launched())
+        assert bool([x for x in names if x.startswith("mc_pf_gemm8_w_")]) == (copy == "1"), sorted(names)
+        assert bool([x for x in names if x.startswith("mc_pf_gemm8_i")]) == (copy == "0"), sorted(names)
+        rows = [np.stack([dec.hidden(l) for l in range(cfg["n_layers"])]), dec.logits().copy()]
+        toks = [tok]
+        for i in range(4):
+            toks.append(dec.step(toks[-1], len(tokens) + i))
+        out[copy] = (toks, rows, dec.logits().copy(), [dec.export_kv(l) for l in range(cfg["n_layers"])])
+        dec.release()
+    assert out["1"][0] == out["0"][0]
+    parity.exact(out["1"][1][0], out["0"][1][0], "hidden rows of the prompt, copy vs quantised rows")
+    parity.exact(out["1"][1][1], out["0"][1][1], "logits of the prompt")
+    parity.exact(out["1"][2], out["0"][2], "logits after four more tokens")
+    for l, ((ka, va), (kb, vb)) in enumerate(zip(out["1"][3], out["0"][3])):
+        parity.exact(ka, kb, f"block {l}: K cache")
+        parity.exact(va, vb, f"block {l}: V cache")
+
+
+@pytest.mark.parametrize("copy", ["0", None])
+def test_wide_long_prompt_splits_k_in_the_ping_pong_gemm(acc, copy, monkeypatch):
     """K = 2048 with two column tiles: the 256 x 256 GEMM splits K (mc_pf_gemm8_*_e2) and the consumers add the fp32 partial sums"""
+    if copy is not None:
+        monkeypatch.setenv("MC_PF_PLAIN_COPY", copy)
+    else:
+        monkeypatch.delenv("MC_PF_PLAIN_COPY", raising=False)
     cfg = mg.tiny_cfg(BF16, dim=2048, n_heads=4, n_kv_heads=1, head_dim=128, ffn_dim=512, n_layers=1, vocab=256, max_seq_len=400)
     weights = mg.make_model(cfg, seed=102, quant="i4", group=128)
     tokens = np.random.default_rng(3).integers(0, cfg["vocab"], 390).tolist()
-    check_against_oracle(acc, cfg, weights, dict(weight_format=2, group_size=128), tokens, follow=1, expect_kernel="mc_pf_gemm8_i4_bfloat_e2")
+    check_against_oracle(acc, cfg, weights, dict(weight_format=2, group_size=128), tokens, follow=1,
+                         expect_kernel="mc_pf_gemm8_i4_bfloat_e2" if copy == "0" else "mc_pf_gemm8_w_bfloat_e2")
 
 
 @pytest.mark.slow   # (hipBLASLt is opt-in since round 5, MC_PF_BLASLT=1: a comparison aid, not the product path)
