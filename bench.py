@@ -627,8 +627,8 @@ def main():
                          "launches_per_token": ln_all},
         }
         # informational (not `value`): the prompt pass that precedes decoding -- time to first token
-        # for a 512-token prompt through mc_decoder_prefill (hand-written MFMA GEMMs on the decode weight layout, dequantised once per
-        # tile in LDS), measured after the timed region on the same decoder; `first_call_ms` is the first prompt of the process
+        # for a 512-token prompt through mc_decoder_prefill (hand-written MFMA GEMMs; since round 6 on a dequantised bfloat16 copy of each quantised
+        # matrix, built in the first call -- `extra_hbm_bytes` -- where it fits an eighth of the device: DESIGN.md section 7), measured after the timed region on the same decoder; `first_call_ms` is the first prompt of the process
         # (allocations included), `ms` the mean of the next three, `extra_hbm_bytes` what derived weight copies hold afterwards
         plen = min(512, S)
         ptoks = np.random.default_rng(1).integers(0, m["vocab"], plen)

@@ -1685,7 +1685,9 @@ struct mc_decoder {
                     one(L.w13);
                     one(L.w2);
                 }
-                pf_plain_on = need > 0 && need <= dev->prop.totalGlobalMem / 8;
+                size_t free_b = 0, total_b = 0;
+                if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
+                pf_plain_on = need > 0 && need <= dev->prop.totalGlobalMem / 8 && need <= free_b / 2; // (and half of what is free NOW: other decoders share the device)
             }
         }
         return pf_plain_on;

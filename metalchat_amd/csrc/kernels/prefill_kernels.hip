@@ -803,7 +803,10 @@ MC_PF_GEMM_BIG_D(mc_pf_gemm128_w_bfloat_d2_e2, PF_W_T, 2, 2)
 // (128 rows of X per tile -- g8::body's BM = 128, twice the workgroups before K is split -- was built for the launches whose 256-row
 //  tiles are too few for the chip, parity-green in the lab build (tools/gemm8) and NOT faster with quantised weights: the dequantisation
 //  per phase stays what it is while the MFMAs halve -- 512 x 4096 x 4096 int4: 33.0 us with 4 K ranges against 32.7 for the 256-row tile;
-//  512 x 6144 x 4096: 51.2 with 2 ranges against ~ 44 with 4; profiles/r05_gemm8_lab_bm128.log.  Not instantiated here.)
+//  512 x 6144 x 4096: 51.2 with 2 ranges against ~ 44 with 4; profiles/r05_gemm8_lab_bm128.log.  Round 6 tried it again on the dequantised copies
+//  (no dequantisation left in the loop), 128-row tiles with HALF the K ranges = the same workgroups and half the fp32 partial sums: a 512-token prompt
+//  10.44 - 10.51 ms against 9.88 (1024: 18.0 against 16.4; profiles/r06_pf_gemm8h2_ab.log) -- a workgroup stages the W tile for half the outputs.
+//  Not instantiated here.)
 #define MC_PF_GEMM8_SET(F, WF)                          \
     MC_PF_GEMM8(mc_pf_gemm8_##F##_bfloat_e0, WF, g8::E_STORE, 256) \
     MC_PF_GEMM8(mc_pf_gemm8_##F##_bfloat_e1, WF, g8::E_RES, 256)   \
@@ -2023,8 +2026,10 @@ mc_pf_rmsnorm_parts_bfloat(const float* part, uint32_t splits, uint32_t M, const
     float hv[4][8];
     uint4 wv[4];
     float ss = 0.0f;
+    const uint32_t rounds = (npk + bd - 1) / bd; // (uniform: a round no thread has a packet in is not loaded at all -- dim 4096 on 256 threads: two of the four)
 #pragma unroll
     for (int i = 0; i < 4; i++) {
+        if ((uint32_t)i >= rounds) break;
         const uint32_t pk = threadIdx.x + i * bd, pc = pk < npk ? pk : npk - 1;
         const uint4 rv = reinterpret_cast<const uint4*>(res + base)[pc];
         wv[i] = reinterpret_cast<const uint4*>(w)[pc];
