@@ -270,7 +270,9 @@ struct mc_decoder {
     bool pf_plain_known = false;
     bool pf_g8_on = true;      // MC_PF_GEMM8: prompts of pf_g8_rows rows and more take the 256 x 256 ping-pong GEMM (kernels/pf_gemm8.h)
     int pf_g8_max_splits = 16, pf_g8_min_ktiles = 8; // MC_PF_GEMM8_MAXSPLIT, MC_PF_GEMM8_MINKT: K ranges of a launch (g8_splits)
-    int pf_g8_rows = 384;      // MC_PF_GEMM8_ROWS (measured round 5: 256 rows 7.42 ms with, 7.06 without -- one row of tiles leaves half the chip idle; 512 rows 10.13 against 11.66)
+    int pf_g8_rows = 257;      // MC_PF_GEMM8_ROWS: from TWO row tiles on (round 5 measured 256 rows 7.42 ms with, 7.06 without -- one row of tiles leaves half the chip idle -- and 512 rows
+                               // 10.13 against 11.66, and set 384; round 6, on the dequantised copies: 256 rows 6.87 without against 7.65 with, 320 rows 11.2 against 8.95, 383: 11.3 against 9.2 --
+                               // profiles/r06_pf_rows_ab.log)
     bool pf_lib_on = false;    // MC_PF_BLASLT=1 (opt-in since round 5, a comparison aid): long prompts' large GEMMs in hipBLASLt on a dequantised bfloat16 copy of the matrix (gemm_lib)
     bool pf_lib_force = false;
     bool pf_lib_tune = false;  // MC_PF_BLASLT_TUNE=1: the fastest of the heuristic's first eight algorithms, timed once per shape, instead of its first

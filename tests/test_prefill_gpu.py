@@ -536,11 +536,11 @@ def test_two_head_prompt_attention_sliding_window_and_second_chunk(acc, monkeypa
     check_against_oracle(acc, cfg, weights, dict(weight_format=2, group_size=32), tokens, start_pos=21, warm=warm, expect_kernel="mc_pf_attn2_bfloat_hd32")
 
 
-# ---- the 256 x 256 ping-pong GEMM of long prompts (kernels/pf_gemm8.h, decoder.cc g8_ok: from 384 rows on; MC_PF_GEMM8_ROWS lowers the
+# ---- the 256 x 256 ping-pong GEMM of long prompts (kernels/pf_gemm8.h, decoder.cc g8_ok: from 257 rows on, two row tiles; MC_PF_GEMM8_ROWS lowers the
 # gate so that shorter prompts of the models the oracle can follow reach it too).  Kernel-level parity: tests/test_gemm8_gpu.py.
 @pytest.mark.parametrize("quant,fmt,group,copy", [("i4", 2, 32, "0"), ("i4", 2, 128, "0"), ("i8", 1, 32, "0"), (None, 0, 0, None),
                                                   ("i4", 2, 128, None), ("i8", 1, 32, None)])
-@pytest.mark.parametrize("n,gate", [(400, None), (300, "192"), (257, "192")])
+@pytest.mark.parametrize("n,gate", [(400, None), (300, None), (257, None), (200, "192")])
 def test_long_prompts_take_the_ping_pong_gemm_and_match_the_oracle(acc, n, gate, quant, fmt, group, copy, monkeypatch):
     """Every linear of the block through mc_pf_gemm8_*: wq|wk|wv / wo / w2 with a plain store or residual (these models are too
     narrow to split K), w1|w3 with silu * mul in its epilogue; the library is never called.  Quantised matrices multiply from their
