@@ -1704,6 +1704,7 @@ struct mc_decoder {
                               pack(wd, (const void*)nullptr, X, Y, res, (uint32_t)M, (uint32_t)L.out, (uint32_t)L.in, (uint32_t)0, (const void*)nullptr,
                                    (const void*)nullptr, (uint32_t)0, 0.0f));
             pf_plain_on = false; // (no memory for the copy: the quantised rows from here on)
+            (void)hipGetLastError(); // (the failed allocation's residue: RCCL reads it between its own calls)
         }
         const std::string f = L.fmt == MC_WFMT_I4 ? "i4" : (L.fmt == MC_WFMT_I8 ? "i8" : "w");
         return launch("mc_pf_gemm8_" + f + "_bfloat_e" + std::to_string(epi), (L.out + 255) / 256, (M + 255) / 256, splits, 512, 0,
