@@ -342,9 +342,11 @@ int32_t mc_decoder_handoff_fallbacks(const mc_decoder* d);
 int32_t mc_decoder_handoff_rearms(const mc_decoder* d);
 int32_t mc_decoder_handoffs_active(const mc_decoder* d);
 /* HBM bytes this decoder holds in DERIVED copies of its weights, built on demand by the prompt pass: the quad-interleaved int4 copy
- * short prompts stream from (+ 0.5 byte per weight) and -- only with the opt-in library GEMM, MC_PF_BLASLT=1 -- the dequantised
- * bfloat16 copy (+ 2 bytes per weight).  0 until a prompt has asked for one.  The reference materialises the dequantised matrix on
- * every call (quantization/lora.h:115-117); the default path here never does. */
+ * short prompts stream from (+ 0.5 byte per weight) and the dequantised bfloat16 copy Wd = T(T(q) T(s)) that prompts of 257 rows and
+ * more multiply by (+ 2 bytes per weight; built per matrix on first use where the copies of the decoder's blocks fit an eighth of the
+ * device's memory and half of what is free -- MC_PF_PLAIN_COPY=1 / 0 forces / forbids; without it the same GEMM dequantises inside its
+ * loop, bit for bit the same rows).  0 until a prompt has asked for one.  The reference materialises the dequantised matrix on every
+ * call (quantization/lora.h:115-117); here it is built once and rebuilt when the weights change. */
 size_t mc_decoder_derived_weight_bytes(const mc_decoder* d);
 /* Test aid: record the host names of every kernel the decoder launches from now on (enable = 1 clears the log and
  * drops a captured token graph, whose replay would launch without passing here; 0 stops recording).
