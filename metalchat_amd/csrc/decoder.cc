@@ -268,6 +268,7 @@ struct mc_decoder {
                                // block's matrices fit an eighth of the device's memory (Llama-3-8B: 14 of 288 GB, yes; 70B: 137 GB, no)
     bool pf_plain_on = false;  // ... resolved when the first long prompt arrives (plain_copy_ok)
     bool pf_plain_known = false;
+    bool pf_rope_pack = true;  // MC_PF_ROPE_PACK (prefill: the rope + cache launch with four rotation pairs per thread)
     bool pf_g8_on = true;      // MC_PF_GEMM8: prompts of pf_g8_rows rows and more take the 256 x 256 ping-pong GEMM (kernels/pf_gemm8.h)
     int pf_g8_max_splits = 16, pf_g8_min_ktiles = 8; // MC_PF_GEMM8_MAXSPLIT, MC_PF_GEMM8_MINKT: K ranges of a launch (g8_splits)
     int pf_g8_rows = 257;      // MC_PF_GEMM8_ROWS: from TWO row tiles on (round 5 measured 256 rows 7.42 ms with, 7.06 without -- one row of tiles leaves half the chip idle -- and 512 rows
@@ -2029,8 +2030,19 @@ struct mc_decoder {
                 if (s != MC_OK) return s;
             }
             xn_ready = false;
+            // rope + cache write: four rotation pairs per thread where the block has no q / k norms (prefill_kernels.hip pf_rope_cache_v4_body: a
+            // quarter of the waves of the one-pair launch, which is bound by the rate waves start at); MC_PF_ROPE_PACK=0: the launch of rounds 1-5
+            const bool rope_v4 = pf_rope_pack && tb == 2 && !L.q_norm && !L.k_norm && hd % 8 == 0 && hd <= 2048 && 2048 % hd == 0;
+            const unsigned rope_per = rope_v4 ? 2048u / (unsigned)hd : 1u; // heads of a row per workgroup of 256 threads
+            const unsigned rope_gx = ((unsigned)(H + 2 * KV) * (unsigned)M + rope_per - 1) / rope_per;
             if (gemm_to_parts(L.qkv, pf_xn, M, &sp, &gs)) {
                 if (gs != MC_OK) return gs;
+                if (rope_v4)
+                    s = timed("rope_cache", [&] { return launch("mc_pf_rope_cache_parts_v4_bfloat", rope_gx, 1, 1, 256, 0,
+                               pack((const void*)pf_part, sp, (uint32_t)M, pf_q, L.kc, L.vt, rope_cos[L.rope_table], rope_sin[L.rope_table],
+                                    (uint32_t)H, (uint32_t)KV, (uint32_t)hd, (uint32_t)cfg.max_seq_len, (uint32_t)start_pos,
+                                    (uint32_t)(rope_pos - rope_start))); });
+                else
                 s = timed("rope_cache", [&] { return launch("mc_pf_rope_cache_parts_" + tname, H + 2 * KV, M, 1, hd / 2, 0,
                            pack((const void*)pf_part, sp, (uint32_t)M, pf_q, L.kc, L.vt, rope_cos[L.rope_table], rope_sin[L.rope_table], L.q_norm,
                                 L.k_norm, (uint32_t)H, (uint32_t)KV, (uint32_t)hd, (uint32_t)cfg.max_seq_len,
@@ -2038,6 +2050,11 @@ struct mc_decoder {
             } else {
                 s = timed("gemm_qkv", [&] { return gemm(L.qkv, 0, pf_xn, pf_qkv, nullptr, M); });
                 if (s != MC_OK) return s;
+                if (rope_v4)
+                    s = timed("rope_cache", [&] { return launch("mc_pf_rope_cache_v4_bfloat", rope_gx, 1, 1, 256, 0,
+                               pack(pf_qkv, pf_q, L.kc, L.vt, rope_cos[L.rope_table], rope_sin[L.rope_table], (uint32_t)H, (uint32_t)KV, (uint32_t)hd,
+                                    (uint32_t)cfg.max_seq_len, (uint32_t)start_pos, (uint32_t)(rope_pos - rope_start), (uint32_t)M)); });
+                else
                 s = timed("rope_cache", [&] { return launch("mc_pf_rope_cache_" + tname, H + 2 * KV, M, 1, hd / 2, 0,
                            pack(pf_qkv, pf_q, L.kc, L.vt, rope_cos[L.rope_table], rope_sin[L.rope_table], L.q_norm,
                                 L.k_norm, (uint32_t)H, (uint32_t)KV, (uint32_t)hd, (uint32_t)cfg.max_seq_len,
@@ -2254,6 +2271,7 @@ mc_decoder_create(mc_device* dev, mc_library* lib, mc_queue* q, const mc_decoder
     if (const char* e = getenv("MC_PF_ATTN8")) d->pf_attn8_on = atoi(e) != 0;
     if (const char* e = getenv("MC_PF_ATTN8_ROWS")) d->pf_attn8_rows = std::max(1, atoi(e));
     if (const char* e = getenv("MC_PF_GEMM8")) d->pf_g8_on = atoi(e) != 0;
+    if (const char* e = getenv("MC_PF_ROPE_PACK")) d->pf_rope_pack = atoi(e) != 0;
     if (const char* e = getenv("MC_PF_PLAIN_COPY")) d->pf_plain_mode = atoi(e) != 0 ? 1 : 0;
     if (const char* e = getenv("MC_PF_GEMM8_ROWS")) d->pf_g8_rows = std::max(1, atoi(e));
     if (const char* e = getenv("MC_PF_GEMM8_MAXSPLIT")) d->pf_g8_max_splits = std::max(1, atoi(e));

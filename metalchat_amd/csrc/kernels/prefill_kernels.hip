@@ -1995,6 +1995,68 @@ mc_pf_rope_cache_parts_bfloat(const float* part, uint32_t splits, uint32_t M, bf
     dst[j] = o1;
     dst[j + half] = o2;
 }
+// ---- rope + cache write, four rotation pairs per thread (round 6).  mc_pf_rope_cache{,_parts}_bfloat launch one WAVE per head of a row
+// (hd / 2 threads, a pair each): 98 304 one-wave workgroups at 2048 rows of Llama-3-8B take 24.9 us whatever they do (q and k skipped: 23.2, v
+// skipped: 24.2; four of them per workgroup: the same) -- the rate waves START at, not bytes (50 MB: ~ 10 us).  Here a thread takes 16 bytes of
+// the row -- four pairs (2j, 2j + 1), j = 4 l .. 4 l + 3, of a q or k head, eight elements of a v head --, a head is hd / 8 lanes, a workgroup
+// of 256 threads 2048 / hd heads: a quarter of the waves.  Every element goes through the operations of pf_rope_cache_body /
+// mc_pf_rope_cache_parts_bfloat: bit for bit the same q rows and caches.  Without q / k norms only (their sums would be formed in another
+// order: gemma3 and qwen3 keep the launch above); bfloat rows.  SPLITS = true: the rows are fp32 partial sums [z][M][(H + 2 KV) hd] of the
+// wq|wk|wv GEMM (pf_part_sum8: T(sum over z, in z order)).
+template <bool SPLITS>
+__device__ __forceinline__ void
+pf_rope_cache_v4_body(const void* rows, uint32_t splits, uint32_t M, bf16_t* q_out, bf16_t* kc, bf16_t* vt, const float* fcos, const float* fsin,
+                      uint32_t H, uint32_t KV, uint32_t hd, uint32_t max_seq, uint32_t start_pos, uint32_t rope_row0)
+{
+    const uint32_t half = hd / 2, lpu = hd / 8, nb = H + 2 * KV, NQ = nb * hd;
+    const uint32_t unit = blockIdx.x * (blockDim.x / lpu) + threadIdx.x / lpu, l = threadIdx.x % lpu;
+    if (unit >= nb * M) return;
+    const uint32_t b = unit % nb, r = unit / nb, slot = start_pos + r;
+    // the unit's head in the row: q heads, then k heads, then v heads (the fused matrix's row order)
+    const size_t src = (size_t)r * NQ + (size_t)b * hd + 8 * l;
+    float x[8];
+    if (SPLITS) {
+        pf_part_sum8(static_cast<const float*>(rows), splits, (size_t)M * NQ, src, x);
+#pragma unroll
+        for (int i = 0; i < 8; i++) x[i] = bf2f(f2bf(x[i]));
+    } else {
+        const uint4 v = *reinterpret_cast<const uint4*>(static_cast<const bf16_t*>(rows) + src);
+        const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 8; i++) x[i] = __uint_as_float((i & 1) ? (d[i >> 1] & 0xFFFF0000u) : (d[i >> 1] << 16));
+    }
+    if (b >= H + KV) {
+        bf16_t* dst = vt + (size_t)(b - H - KV) * hd * max_seq + slot;
+#pragma unroll
+        for (int i = 0; i < 8; i++) dst[(size_t)(8 * l + i) * max_seq] = f2bf(x[i]);
+        return;
+    }
+    const size_t tr = (size_t)(rope_row0 + r) * half + 4 * l;
+    const float4 c4 = *reinterpret_cast<const float4*>(fcos + tr), s4 = *reinterpret_cast<const float4*>(fsin + tr);
+    const float c[4] = {c4.x, c4.y, c4.z, c4.w}, s[4] = {s4.x, s4.y, s4.z, s4.w};
+    float o1[4], o2[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const float x1 = x[2 * i], x2 = x[2 * i + 1];
+        o1[i] = BF::rt(c[i] * x1 - s[i] * x2);
+        o2[i] = BF::rt(s[i] * x1 + c[i] * x2);
+    }
+    bf16_t* dst = (b < H ? q_out + ((size_t)r * H + b) * hd : kc + ((size_t)(b - H) * max_seq + slot) * hd) + 4 * l;
+    *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16x2(o1[0], o1[1]), pack_bf16x2(o1[2], o1[3]));
+    *reinterpret_cast<uint2*>(dst + half) = make_uint2(pack_bf16x2(o2[0], o2[1]), pack_bf16x2(o2[2], o2[3]));
+}
+extern "C" __global__ void __launch_bounds__(256)
+mc_pf_rope_cache_v4_bfloat(const bf16_t* qkv, bf16_t* q_out, bf16_t* kc, bf16_t* vt, const float* fcos, const float* fsin, uint32_t H, uint32_t KV,
+                           uint32_t hd, uint32_t max_seq, uint32_t start_pos, uint32_t rope_row0, uint32_t M)
+{
+    pf_rope_cache_v4_body<false>(qkv, 1, M, q_out, kc, vt, fcos, fsin, H, KV, hd, max_seq, start_pos, rope_row0);
+}
+extern "C" __global__ void __launch_bounds__(256)
+mc_pf_rope_cache_parts_v4_bfloat(const float* part, uint32_t splits, uint32_t M, bf16_t* q_out, bf16_t* kc, bf16_t* vt, const float* fcos,
+                                 const float* fsin, uint32_t H, uint32_t KV, uint32_t hd, uint32_t max_seq, uint32_t start_pos, uint32_t rope_row0)
+{
+    pf_rope_cache_v4_body<true>(part, splits, M, q_out, kc, vt, fcos, fsin, H, KV, hd, max_seq, start_pos, rope_row0);
+}
 // w1|w3 partials -> act(a) * b (mc_pf_act_mul_bfloat with the reduce in front); ffn a multiple of 4
 extern "C" __global__ void
 mc_pf_act_mul_parts_bfloat(const float* part, uint32_t splits, uint32_t M, bf16_t* out, uint32_t ffn, int32_t gelu, const float* etab)

@@ -582,6 +582,42 @@ def test_long_prompts_take_the_ping_pong_gemm_and_match_the_oracle(acc, n, gate,
     dec.release()
 
 
+@pytest.mark.parametrize("family,hd,n", [(0, 128, 300), (0, 128, 37), (1, 128, 300), (1, 256, 300), (1, 256, 37), (0, 64, 300)])
+def test_packed_rope_launch_changes_no_bit(acc, family, hd, n, monkeypatch):
+    """Round 6: mc_pf_rope_cache{,_parts}_v4_bfloat give a thread four rotation pairs (a quarter of the waves: the one-pair launch was bound by the
+    rate waves start at) where the block has no q / k norms.  MC_PF_ROPE_PACK=0 is the launch of rounds 1-5: logits, tokens and both caches are
+    equal bit for bit; gemma3 (family 1: q / k norms) keeps the old launch either way."""
+    import metalchat_amd as mc
+
+    over = dict(family=family, dim=256, n_heads=4, n_kv_heads=2, head_dim=hd, ffn_dim=512, n_layers=2, vocab=384, max_seq_len=320)
+    if family == 1:
+        over.update(rope_sliding_theta=10000.0, sliding_stride=2)
+    cfg = mg.tiny_cfg(BF16, **over)
+    weights = mg.make_model(cfg, seed=107, quant="i4", group=32)
+    tokens = np.random.default_rng(n + hd).integers(0, cfg["vocab"], n).tolist()
+    out = {}
+    for pack in ("1", "0"):
+        monkeypatch.setenv("MC_PF_ROPE_PACK", pack)
+        dec = mc.Decoder(acc, **mg.decoder_kwargs(cfg, weight_format=2, group_size=32))
+        dec.load_model(weights)
+        dec.launch_log(True)
+        toks = [dec.prefill(tokens, 0)]
+        names = set(dec.launched())
+        dec.launch_log(False)
+        assert bool([x for x in names if "rope_cache" in x and "_v4_" in x]) == (pack == "1" and family == 0), sorted(names)
+        lg = dec.logits().copy()
+        for i in range(3):
+            toks.append(dec.step(toks[-1], n + i))
+        out[pack] = (toks, lg, dec.logits().copy(), [dec.export_kv(l) for l in range(cfg["n_layers"])])
+        dec.release()
+    assert out["1"][0] == out["0"][0]
+    parity.exact(out["1"][1], out["0"][1], "logits of the prompt, packed vs one unit per workgroup")
+    parity.exact(out["1"][2], out["0"][2], "logits three tokens later")
+    for l, ((ka, va), (kb, vb)) in enumerate(zip(out["1"][3], out["0"][3])):
+        parity.exact(ka, kb, f"block {l}: K cache")
+        parity.exact(va, vb, f"block {l}: V cache")
+
+
 @pytest.mark.parametrize("quant,fmt,group", [("i4", 2, 128), ("i4", 2, 32), ("i8", 1, 32)])
 def test_the_dequantised_copy_changes_no_bit_of_a_long_prompt(acc, quant, fmt, group, monkeypatch):
     """MC_PF_PLAIN_COPY=1 against =0: the copy holds Wd = T(T(q) T(s)), the values the quantised loop stages in LDS, and mc_pf_gemm8_w_* is the
