@@ -2034,7 +2034,8 @@ struct mc_decoder {
             // quarter of the waves of the one-pair launch, which is bound by the rate waves start at); MC_PF_ROPE_PACK=0: the launch of rounds 1-5
             const bool rope_v4 = pf_rope_pack && tb == 2 && !L.q_norm && !L.k_norm && hd % 8 == 0 && hd <= 2048 && 2048 % hd == 0;
             const unsigned rope_per = rope_v4 ? 2048u / (unsigned)hd : 1u; // heads of a row per workgroup of 256 threads
-            const unsigned rope_gx = ((unsigned)(H + 2 * KV) * (unsigned)M + rope_per - 1) / rope_per;
+            const unsigned rope_gx = rope_v4 ? ((unsigned)(H + KV) * (unsigned)M + rope_per - 1) / rope_per + (unsigned)KV * (((unsigned)M + 15u) / 16u) // q / k units, then v tiles of 16 rows
+                                             : 0u;
             if (gemm_to_parts(L.qkv, pf_xn, M, &sp, &gs)) {
                 if (gs != MC_OK) return gs;
                 if (rope_v4)

@@ -2003,34 +2003,46 @@ mc_pf_rope_cache_parts_bfloat(const float* part, uint32_t splits, uint32_t M, bf
 // mc_pf_rope_cache_parts_bfloat: bit for bit the same q rows and caches.  Without q / k norms only (their sums would be formed in another
 // order: gemma3 and qwen3 keep the launch above); bfloat rows.  SPLITS = true: the rows are fp32 partial sums [z][M][(H + 2 KV) hd] of the
 // wq|wk|wv GEMM (pf_part_sum8: T(sum over z, in z order)).
+// The TRANSPOSED V cache ([kv][d][slot]) is written by workgroups of their own, behind the q / k ones in the grid: 16 rows of one kv head, thread
+// (i = t % 16, g = t / 16) takes elements 8 g .. 8 g + 7 of row r0 + i -- for each of its eight stores the 16 threads of a g write 16 CONSECUTIVE
+// slots of one d (32 bytes) where a thread per element wrote 2 bytes every 4 KB.
 template <bool SPLITS>
 __device__ __forceinline__ void
 pf_rope_cache_v4_body(const void* rows, uint32_t splits, uint32_t M, bf16_t* q_out, bf16_t* kc, bf16_t* vt, const float* fcos, const float* fsin,
                       uint32_t H, uint32_t KV, uint32_t hd, uint32_t max_seq, uint32_t start_pos, uint32_t rope_row0)
 {
-    const uint32_t half = hd / 2, lpu = hd / 8, nb = H + 2 * KV, NQ = nb * hd;
-    const uint32_t unit = blockIdx.x * (blockDim.x / lpu) + threadIdx.x / lpu, l = threadIdx.x % lpu;
-    if (unit >= nb * M) return;
-    const uint32_t b = unit % nb, r = unit / nb, slot = start_pos + r;
-    // the unit's head in the row: q heads, then k heads, then v heads (the fused matrix's row order)
-    const size_t src = (size_t)r * NQ + (size_t)b * hd + 8 * l;
-    float x[8];
-    if (SPLITS) {
-        pf_part_sum8(static_cast<const float*>(rows), splits, (size_t)M * NQ, src, x);
+    const uint32_t half = hd / 2, lpu = hd / 8, nb = H + KV, NQ = (H + 2 * KV) * hd, per = blockDim.x / lpu;
+    const uint32_t gq = (nb * M + per - 1) / per; // workgroups of q / k units; behind them KV * ceil(M / 16) of v tiles
+    auto load8 = [&](size_t src, float (&x)[8]) {
+        if (SPLITS) {
+            pf_part_sum8(static_cast<const float*>(rows), splits, (size_t)M * NQ, src, x);
 #pragma unroll
-        for (int i = 0; i < 8; i++) x[i] = bf2f(f2bf(x[i]));
-    } else {
-        const uint4 v = *reinterpret_cast<const uint4*>(static_cast<const bf16_t*>(rows) + src);
-        const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+            for (int i = 0; i < 8; i++) x[i] = bf2f(f2bf(x[i]));
+        } else {
+            const uint4 v = *reinterpret_cast<const uint4*>(static_cast<const bf16_t*>(rows) + src);
+            const uint32_t d[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-        for (int i = 0; i < 8; i++) x[i] = __uint_as_float((i & 1) ? (d[i >> 1] & 0xFFFF0000u) : (d[i >> 1] << 16));
-    }
-    if (b >= H + KV) {
-        bf16_t* dst = vt + (size_t)(b - H - KV) * hd * max_seq + slot;
+            for (int i = 0; i < 8; i++) x[i] = __uint_as_float((i & 1) ? (d[i >> 1] & 0xFFFF0000u) : (d[i >> 1] << 16));
+        }
+    };
+    if (blockIdx.x >= gq) {
+        const uint32_t vb = blockIdx.x - gq, kv = vb % KV, r = (vb / KV) * 16 + (threadIdx.x & 15u);
+        if (r >= M) return;
+        bf16_t* dst = vt + (size_t)kv * hd * max_seq + start_pos + r;
+        for (uint32_t g = threadIdx.x >> 4; g < lpu; g += blockDim.x >> 4) {
+            float x[8];
+            load8((size_t)r * NQ + (size_t)(nb + kv) * hd + 8 * g, x);
 #pragma unroll
-        for (int i = 0; i < 8; i++) dst[(size_t)(8 * l + i) * max_seq] = f2bf(x[i]);
+            for (int i = 0; i < 8; i++) dst[(size_t)(8 * g + i) * max_seq] = f2bf(x[i]);
+        }
         return;
     }
+    const uint32_t unit = blockIdx.x * per + threadIdx.x / lpu, l = threadIdx.x % lpu;
+    if (unit >= nb * M) return;
+    const uint32_t b = unit % nb, r = unit / nb, slot = start_pos + r;
+    // the unit's head in the row: q heads, then k heads (the fused matrix's row order)
+    float x[8];
+    load8((size_t)r * NQ + (size_t)b * hd + 8 * l, x);
     const size_t tr = (size_t)(rope_row0 + r) * half + 4 * l;
     const float4 c4 = *reinterpret_cast<const float4*>(fcos + tr), s4 = *reinterpret_cast<const float4*>(fsin + tr);
     const float c[4] = {c4.x, c4.y, c4.z, c4.w}, s[4] = {s4.x, s4.y, s4.z, s4.w};
