@@ -582,7 +582,7 @@ def test_long_prompts_take_the_ping_pong_gemm_and_match_the_oracle(acc, n, gate,
     dec.release()
 
 
-@pytest.mark.parametrize("family,hd,n", [(0, 128, 300), (0, 128, 37), (1, 128, 300), (1, 256, 300), (1, 256, 37), (0, 64, 300)])
+@pytest.mark.parametrize("family,hd,n", [(0, 128, 300), (0, 128, 37), (1, 128, 300), (1, 256, 300), (1, 256, 37), (0, 64, 300), (0, 256, 300), (0, 256, 21), (0, 32, 70)])
 def test_packed_rope_launch_changes_no_bit(acc, family, hd, n, monkeypatch):
     """Round 6: mc_pf_rope_cache{,_parts}_v4_bfloat give a thread four rotation pairs (a quarter of the waves: the one-pair launch was bound by the
     rate waves start at) where the block has no q / k norms.  MC_PF_ROPE_PACK=0 is the launch of rounds 1-5: logits, tokens and both caches are
