@@ -384,6 +384,7 @@ struct mc_decoder {
          *pf_q = nullptr, *pf_att = nullptr, *pf_g2 = nullptr, *pf_g = nullptr, *pf_probs = nullptr;
     int32_t* pf_tokens = nullptr;
     float* pf_etab = nullptr; // exp_precise of every bfloat16 value (prefill_kernels.hip mc_exp_table_bfloat), 256 KiB
+    float* pf_gtab = nullptr; // gemma: T(gelu) of every bfloat16 value (mc_gelu_table_bfloat), 256 KiB; MC_PF_GELU_TABLE=0: none (the fp64 tanh per element)
     void* pf_lora = nullptr;
     size_t pf_lora_elems = 0;
     float* pf_part = nullptr; // split-K partial sums [splits][M][N]
@@ -1555,6 +1556,12 @@ struct mc_decoder {
             s = launch("mc_exp_table_bfloat", 256, 1, 1, 256, 0, pack(pf_etab));
             if (s != MC_OK) return s;
         }
+        if (tb == 2 && cfg.family == MC_FAMILY_GEMMA3 && !pf_gtab && !(getenv("MC_PF_GELU_TABLE") && atoi(getenv("MC_PF_GELU_TABLE")) == 0)) {
+            s = alloc((void**)&pf_gtab, 65536 * sizeof(float), false);
+            if (s != MC_OK) return s;
+            s = launch("mc_gelu_table_bfloat", 256, 1, 1, 256, 0, pack(pf_gtab));
+            if (s != MC_OK) return s;
+        }
         const size_t need = (tb == 2 && !pf_two_pass) ? 0 : (size_t)H * M * S;
         if (need > pf_probs_elems) {
             MC_HIP(hipStreamSynchronize(stream));
@@ -1921,7 +1928,7 @@ struct mc_decoder {
         // 32-42 ms for 8-64 rows where this one needs 5
         if (epi == 0 && lib_ok(L, M) && gemm_lib(L, X, Y, M, false)) return MC_OK;
         if (g8_ok(L, M) && !(pf2_ok(L, M) && epi != 2)) {
-            const unsigned splits = epi == 3 ? 1u : g8_splits(L, M);
+            const unsigned splits = epi >= 3 ? 1u : g8_splits(L, M);
             if (splits == 1) return g8_launch(L, epi, X, Y, res, M, 1);
             const size_t need = (size_t)splits * M * L.out;
             if (need > pf_part_elems) {
@@ -2030,9 +2037,10 @@ struct mc_decoder {
                 if (s != MC_OK) return s;
             }
             xn_ready = false;
-            // rope + cache write: four rotation pairs per thread where the block has no q / k norms (prefill_kernels.hip pf_rope_cache_v4_body: a
-            // quarter of the waves of the one-pair launch, which is bound by the rate waves start at); MC_PF_ROPE_PACK=0: the launch of rounds 1-5
-            const bool rope_v4 = pf_rope_pack && tb == 2 && !L.q_norm && !L.k_norm && hd % 8 == 0 && hd <= 2048 && 2048 % hd == 0;
+            // rope + cache write: four rotation pairs per thread (prefill_kernels.hip pf_rope_cache_v4_body: a quarter of the waves of the one-pair
+            // launch, which is bound by the rate waves start at, and the transposed V cache written 16 slots at a time); MC_PF_ROPE_PACK=0: the launch of rounds 1-5
+            const bool rope_v4 = pf_rope_pack && tb == 2 && hd % 8 == 0 && hd <= 2048 && 2048 % hd == 0 &&
+                                 ((!L.q_norm && !L.k_norm) || hd == 128 || hd == 256); // (q / k norms: the head sizes whose sum order the kernel reproduces)
             const unsigned rope_per = rope_v4 ? 2048u / (unsigned)hd : 1u; // heads of a row per workgroup of 256 threads
             const unsigned rope_gx = rope_v4 ? ((unsigned)(H + KV) * (unsigned)M + rope_per - 1) / rope_per + (unsigned)KV * (((unsigned)M + 15u) / 16u) // q / k units, then v tiles of 16 rows
                                              : 0u;
@@ -2042,7 +2050,7 @@ struct mc_decoder {
                     s = timed("rope_cache", [&] { return launch("mc_pf_rope_cache_parts_v4_bfloat", rope_gx, 1, 1, 256, 0,
                                pack((const void*)pf_part, sp, (uint32_t)M, pf_q, L.kc, L.vt, rope_cos[L.rope_table], rope_sin[L.rope_table],
                                     (uint32_t)H, (uint32_t)KV, (uint32_t)hd, (uint32_t)cfg.max_seq_len, (uint32_t)start_pos,
-                                    (uint32_t)(rope_pos - rope_start))); });
+                                    (uint32_t)(rope_pos - rope_start), L.q_norm, L.k_norm, cfg.norm_eps, mu)); });
                 else
                 s = timed("rope_cache", [&] { return launch("mc_pf_rope_cache_parts_" + tname, H + 2 * KV, M, 1, hd / 2, 0,
                            pack((const void*)pf_part, sp, (uint32_t)M, pf_q, L.kc, L.vt, rope_cos[L.rope_table], rope_sin[L.rope_table], L.q_norm,
@@ -2054,7 +2062,8 @@ struct mc_decoder {
                 if (rope_v4)
                     s = timed("rope_cache", [&] { return launch("mc_pf_rope_cache_v4_bfloat", rope_gx, 1, 1, 256, 0,
                                pack(pf_qkv, pf_q, L.kc, L.vt, rope_cos[L.rope_table], rope_sin[L.rope_table], (uint32_t)H, (uint32_t)KV, (uint32_t)hd,
-                                    (uint32_t)cfg.max_seq_len, (uint32_t)start_pos, (uint32_t)(rope_pos - rope_start), (uint32_t)M)); });
+                                    (uint32_t)cfg.max_seq_len, (uint32_t)start_pos, (uint32_t)(rope_pos - rope_start), (uint32_t)M, L.q_norm, L.k_norm,
+                                    cfg.norm_eps, mu)); });
                 else
                 s = timed("rope_cache", [&] { return launch("mc_pf_rope_cache_" + tname, H + 2 * KV, M, 1, hd / 2, 0,
                            pack(pf_qkv, pf_q, L.kc, L.vt, rope_cos[L.rope_table], rope_sin[L.rope_table], L.q_norm,
@@ -2135,21 +2144,23 @@ struct mc_decoder {
             // silu(w1 x) * (w3 x) in the epilogue of an unsplit 256-row GEMM (prefill_kernels.hip pf_gemm_big_body EPI 3; the
             // table of exponentials rides in `res`).  MC_PF_ACT_EPI=0: the separate launch
             const bool act_epi_on = !(getenv("MC_PF_ACT_EPI") && atoi(getenv("MC_PF_ACT_EPI")) == 0);
-            const bool act_epi = act_epi_on && tb == 2 && !gemma && !L.w13.lora_cols && !getenv("MC_PF_SMALL_GEMM") && !pf2_ok(L.w13, M) &&
-                                 (g8_ok(L.w13, M) ? g8_splits(L.w13, M) == 1 && cfg.ffn_dim % 2 == 0
-                                                  : gemm_row_tile(M) == 256 && gemm_splits(L.w13, M) == 1 && !(getenv("MC_PF_DEPTH") && atoi(getenv("MC_PF_DEPTH")) == 1)) &&
+            // (gemma: gelu from the table of round 6 -- the 256 x 256 GEMM's e4 epilogue only; without the table the separate launch with its fp64 tanh)
+            const bool act_epi = act_epi_on && tb == 2 && !L.w13.lora_cols && !getenv("MC_PF_SMALL_GEMM") && !pf2_ok(L.w13, M) &&
+                                 (g8_ok(L.w13, M) ? g8_splits(L.w13, M) == 1 && cfg.ffn_dim % 2 == 0 && (!gemma || pf_gtab)
+                                                  : !gemma && gemm_row_tile(M) == 256 && gemm_splits(L.w13, M) == 1 && !(getenv("MC_PF_DEPTH") && atoi(getenv("MC_PF_DEPTH")) == 1)) &&
                                  !lib_ok(L.w13, M); // (the opt-in library GEMM + the separate activation launch)
+            const void* act_tab = gemma ? (const void*)pf_gtab : (const void*)pf_etab; // (gelu without a table: nullptr, the kernels evaluate it)
             if (act_epi) {
-                s = timed("gemm_w13_act", [&] { return gemm(L.w13, 3, pf_xn, pf_g, pf_etab, M); });
+                s = timed("gemm_w13_act", [&] { return gemm(L.w13, gemma ? 4 : 3, pf_xn, pf_g, act_tab, M); });
             } else if (cfg.ffn_dim % 4 == 0 && !lib_ok(L.w13, M) && gemm_to_parts(L.w13, pf_xn, M, &sp, &gs)) { // (library: bfloat16 rows out, half the bytes of fp32 partials)
                 if (gs != MC_OK) return gs;
                 s = timed("act_mul", [&] { return launch("mc_pf_act_mul_parts_" + tname, (cfg.ffn_dim / 4 + 255) / 256 + 1, M, 1, 256, 0,
-                           pack((const void*)pf_part, sp, (uint32_t)M, pf_g, (uint32_t)cfg.ffn_dim, (int32_t)(gemma ? 1 : 0), (const void*)pf_etab)); });
+                           pack((const void*)pf_part, sp, (uint32_t)M, pf_g, (uint32_t)cfg.ffn_dim, (int32_t)(gemma ? 1 : 0), act_tab)); });
             } else {
                 s = timed("gemm_w13", [&] { return gemm(L.w13, 0, pf_xn, pf_g2, nullptr, M); });
                 if (s != MC_OK) return s;
                 s = timed("act_mul", [&] { return launch("mc_pf_act_mul_" + tname, (cfg.ffn_dim / act_pp + 255) / 256 + 1, M, 1, 256, 0,
-                           tb == 2 ? pack(pf_g2, pf_g, (uint32_t)cfg.ffn_dim, (int32_t)(gemma ? 1 : 0), (const void*)pf_etab)
+                           tb == 2 ? pack(pf_g2, pf_g, (uint32_t)cfg.ffn_dim, (int32_t)(gemma ? 1 : 0), act_tab)
                                    : pack(pf_g2, pf_g, (uint32_t)cfg.ffn_dim, (int32_t)(gemma ? 1 : 0))); });
             }
             if (s != MC_OK) return s;

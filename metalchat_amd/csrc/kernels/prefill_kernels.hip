@@ -173,6 +173,16 @@ pf_exp_tab(const float* tab, float x) // x a bfloat16 value
 {
     return tab[__float_as_uint(x) >> 16];
 }
+// (round 6) The same for gemma's activation: T(gelu(a)) of a bfloat16 a is one of 65536 values, and pf_gelu_f is an fp64 tanh per element
+// -- mc_pf_act_mul_bfloat took 247 us per block on 2048 rows of Gemma-7B's shapes, 1.2 TB/s.  mc_gelu_table_bfloat evaluates
+// T(pf_gelu_f(value)) once per bfloat16 value (built when the first prompt of a gemma decoder arrives): tab[bits] IS that value.
+__device__ __forceinline__ float pf_gelu_f(float x);
+extern "C" __global__ void
+mc_gelu_table_bfloat(float* tab)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 65536u) tab[i] = BF::rt(pf_gelu_f(__uint_as_float(i << 16)));
+}
 // The window: |x| in [2^-25, 2^7) -- 32 binades x 128 mantissas x 2 signs = 8192 floats, 32 KiB.  Below it exp(x) rounds to 1.0f
 // (like exp(+-2^-25), the first entries), above it exp(x) is inf or 0 (like the last entries; -inf, the masked score, included):
 // clamping the magnitude bits into the window gives the table's value for every bfloat16 that is not a NaN, and a NaN is passed
@@ -232,7 +242,8 @@ pf_act_mul_body(const typename T::S* in, typename T::S* out, uint32_t ffn, int32
     const uint32_t j0 = (blockIdx.x * blockDim.x + threadIdx.x) * PP, r = blockIdx.y;
     if (j0 >= ffn) return;
     auto one = [&](float a, float b) {
-        const float g = gelu ? T::rt(pf_gelu_f(a)) : pf_silu_T<T>(a, etab);
+        // (gelu: `etab` is the table of T(gelu) where the caller has one -- bfloat rows)
+        const float g = gelu ? (T::bytes == 2 && etab ? pf_exp_tab(etab, a) : T::rt(pf_gelu_f(a))) : pf_silu_T<T>(a, etab);
         return g * b;
     };
     if (ffn % PP == 0) {
@@ -807,11 +818,23 @@ MC_PF_GEMM_BIG_D(mc_pf_gemm128_w_bfloat_d2_e2, PF_W_T, 2, 2)
 //  (no dequantisation left in the loop), 128-row tiles with HALF the K ranges = the same workgroups and half the fp32 partial sums: a 512-token prompt
 //  10.44 - 10.51 ms against 9.88 (1024: 18.0 against 16.4; profiles/r06_pf_gemm8h2_ab.log) -- a workgroup stages the W tile for half the outputs.
 //  Not instantiated here.)
+// e4 (round 6): gelu(w1 x) * (w3 x) -- gemma's activation in the epilogue, T(gelu) of the bfloat16 w1 x looked up in mc_gelu_table_bfloat's table
+// (which rides in `res` as e3's table of exponentials does)
+#define MC_PF_GEMM8_GELU(NAME, WF)                                                                                            \
+    extern "C" __global__ void __launch_bounds__(512)                                                                         \
+    NAME(const void* w, const void* scales, const bf16_t* X, bf16_t* Y, const bf16_t* res, uint32_t M, uint32_t N, uint32_t K, \
+         uint32_t group, const bf16_t* la, const bf16_t* lb, uint32_t lora_rank, float lora_scale)                            \
+    {                                                                                                                         \
+        const g8::args a{w, scales, X, Y, res, M, N, K, group};                                                               \
+        const float* gtab = reinterpret_cast<const float*>(res);                                                              \
+        g8::body<WF, g8::E_ACT, 8, 0, 256>(a, [gtab](float x, float y) { return pf_exp_tab(gtab, x) * y; });                  \
+    }
 #define MC_PF_GEMM8_SET(F, WF)                          \
     MC_PF_GEMM8(mc_pf_gemm8_##F##_bfloat_e0, WF, g8::E_STORE, 256) \
     MC_PF_GEMM8(mc_pf_gemm8_##F##_bfloat_e1, WF, g8::E_RES, 256)   \
     MC_PF_GEMM8(mc_pf_gemm8_##F##_bfloat_e2, WF, g8::E_PART, 256)  \
-    MC_PF_GEMM8(mc_pf_gemm8_##F##_bfloat_e3, WF, g8::E_ACT, 256)
+    MC_PF_GEMM8(mc_pf_gemm8_##F##_bfloat_e3, WF, g8::E_ACT, 256)   \
+    MC_PF_GEMM8_GELU(mc_pf_gemm8_##F##_bfloat_e4, WF)
 MC_PF_GEMM8_SET(i4, g8::W_I4)
 MC_PF_GEMM8_SET(i8, g8::W_I8)
 MC_PF_GEMM8_SET(w, g8::W_T)
@@ -2000,8 +2023,8 @@ mc_pf_rope_cache_parts_bfloat(const float* part, uint32_t splits, uint32_t M, bf
 // skipped: 24.2; four of them per workgroup: the same) -- the rate waves START at, not bytes (50 MB: ~ 10 us).  Here a thread takes 16 bytes of
 // the row -- four pairs (2j, 2j + 1), j = 4 l .. 4 l + 3, of a q or k head, eight elements of a v head --, a head is hd / 8 lanes, a workgroup
 // of 256 threads 2048 / hd heads: a quarter of the waves.  Every element goes through the operations of pf_rope_cache_body /
-// mc_pf_rope_cache_parts_bfloat: bit for bit the same q rows and caches.  Without q / k norms only (their sums would be formed in another
-// order: gemma3 and qwen3 keep the launch above); bfloat rows.  SPLITS = true: the rows are fp32 partial sums [z][M][(H + 2 KV) hd] of the
+// mc_pf_rope_cache_parts_bfloat: bit for bit the same q rows and caches -- the q / k norms of gemma3 and qwen3 included (head_dim 128 / 256: the
+// butterfly of the one-pair launch over the pairs of a head, reproduced addition for addition below); bfloat rows.  SPLITS = true: the rows are fp32 partial sums [z][M][(H + 2 KV) hd] of the
 // wq|wk|wv GEMM (pf_part_sum8: T(sum over z, in z order)).
 // The TRANSPOSED V cache ([kv][d][slot]) is written by workgroups of their own, behind the q / k ones in the grid: 16 rows of one kv head, thread
 // (i = t % 16, g = t / 16) takes elements 8 g .. 8 g + 7 of row r0 + i -- for each of its eight stores the 16 threads of a g write 16 CONSECUTIVE
@@ -2009,7 +2032,8 @@ mc_pf_rope_cache_parts_bfloat(const float* part, uint32_t splits, uint32_t M, bf
 template <bool SPLITS>
 __device__ __forceinline__ void
 pf_rope_cache_v4_body(const void* rows, uint32_t splits, uint32_t M, bf16_t* q_out, bf16_t* kc, bf16_t* vt, const float* fcos, const float* fsin,
-                      uint32_t H, uint32_t KV, uint32_t hd, uint32_t max_seq, uint32_t start_pos, uint32_t rope_row0)
+                      uint32_t H, uint32_t KV, uint32_t hd, uint32_t max_seq, uint32_t start_pos, uint32_t rope_row0, const bf16_t* q_norm,
+                      const bf16_t* k_norm, float eps, float mu)
 {
     const uint32_t half = hd / 2, lpu = hd / 8, nb = H + KV, NQ = (H + 2 * KV) * hd, per = blockDim.x / lpu;
     const uint32_t gq = (nb * M + per - 1) / per; // workgroups of q / k units; behind them KV * ceil(M / 16) of v tiles
@@ -2043,6 +2067,33 @@ pf_rope_cache_v4_body(const void* rows, uint32_t splits, uint32_t M, bf16_t* q_o
     // the unit's head in the row: q heads, then k heads (the fused matrix's row order)
     float x[8];
     load8((size_t)r * NQ + (size_t)b * hd + 8 * l, x);
+    const bf16_t* nw = b < H ? q_norm : k_norm;
+    if (nw) {
+        // q / k norm (gemma3, qwen3; head_dim 128 or 256: decoder.cc).  The one-pair launch sums x1^2 + x2^2 of pair j over the head with a butterfly
+        // over the bits of j, 32 first (wave_sum), and at head_dim 256 adds its two waves' sums last (block_sum).  Pair j = 4 l + i lives in lane l:
+        // bits 5 .. 2 of j are lane distances 8 .. 1, bits 1 and 0 are inside the lane, bit 6 is lane distance 16 -- the same additions in the same
+        // order (both partners of a step add the same two values), so the same sum to the bit.
+        float p[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) p[i] = x[2 * i] * x[2 * i] + x[2 * i + 1] * x[2 * i + 1];
+#pragma unroll
+        for (int off = 8; off >= 1; off >>= 1)
+#pragma unroll
+            for (int i = 0; i < 4; i++) p[i] += __shfl_xor(p[i], off, 64);
+        const float q0 = p[0] + p[2], q1 = p[1] + p[3];
+        float tot = q0 + q1;
+        if (lpu == 32) tot += __shfl_xor(tot, 16, 64);
+        const float inv = 1.0f / sqrtf(tot / (float)hd + eps);
+        const uint2 wa = *reinterpret_cast<const uint2*>(nw + 4 * l), wb = *reinterpret_cast<const uint2*>(nw + half + 4 * l);
+        const uint32_t da[2] = {wa.x, wa.y}, db[2] = {wb.x, wb.y};
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const float w1 = __uint_as_float((i & 1) ? (da[i >> 1] & 0xFFFF0000u) : (da[i >> 1] << 16));
+            const float w2 = __uint_as_float((i & 1) ? (db[i >> 1] & 0xFFFF0000u) : (db[i >> 1] << 16));
+            x[2 * i] = BF::rt((mu + w1) * x[2 * i] * inv);
+            x[2 * i + 1] = BF::rt((mu + w2) * x[2 * i + 1] * inv);
+        }
+    }
     const size_t tr = (size_t)(rope_row0 + r) * half + 4 * l;
     const float4 c4 = *reinterpret_cast<const float4*>(fcos + tr), s4 = *reinterpret_cast<const float4*>(fsin + tr);
     const float c[4] = {c4.x, c4.y, c4.z, c4.w}, s[4] = {s4.x, s4.y, s4.z, s4.w};
@@ -2059,15 +2110,17 @@ pf_rope_cache_v4_body(const void* rows, uint32_t splits, uint32_t M, bf16_t* q_o
 }
 extern "C" __global__ void __launch_bounds__(256)
 mc_pf_rope_cache_v4_bfloat(const bf16_t* qkv, bf16_t* q_out, bf16_t* kc, bf16_t* vt, const float* fcos, const float* fsin, uint32_t H, uint32_t KV,
-                           uint32_t hd, uint32_t max_seq, uint32_t start_pos, uint32_t rope_row0, uint32_t M)
+                           uint32_t hd, uint32_t max_seq, uint32_t start_pos, uint32_t rope_row0, uint32_t M, const bf16_t* q_norm, const bf16_t* k_norm,
+                           float eps, float mu)
 {
-    pf_rope_cache_v4_body<false>(qkv, 1, M, q_out, kc, vt, fcos, fsin, H, KV, hd, max_seq, start_pos, rope_row0);
+    pf_rope_cache_v4_body<false>(qkv, 1, M, q_out, kc, vt, fcos, fsin, H, KV, hd, max_seq, start_pos, rope_row0, q_norm, k_norm, eps, mu);
 }
 extern "C" __global__ void __launch_bounds__(256)
 mc_pf_rope_cache_parts_v4_bfloat(const float* part, uint32_t splits, uint32_t M, bf16_t* q_out, bf16_t* kc, bf16_t* vt, const float* fcos,
-                                 const float* fsin, uint32_t H, uint32_t KV, uint32_t hd, uint32_t max_seq, uint32_t start_pos, uint32_t rope_row0)
+                                 const float* fsin, uint32_t H, uint32_t KV, uint32_t hd, uint32_t max_seq, uint32_t start_pos, uint32_t rope_row0,
+                                 const bf16_t* q_norm, const bf16_t* k_norm, float eps, float mu)
 {
-    pf_rope_cache_v4_body<true>(part, splits, M, q_out, kc, vt, fcos, fsin, H, KV, hd, max_seq, start_pos, rope_row0);
+    pf_rope_cache_v4_body<true>(part, splits, M, q_out, kc, vt, fcos, fsin, H, KV, hd, max_seq, start_pos, rope_row0, q_norm, k_norm, eps, mu);
 }
 // w1|w3 partials -> act(a) * b (mc_pf_act_mul_bfloat with the reduce in front); ffn a multiple of 4
 extern "C" __global__ void
@@ -2082,7 +2135,7 @@ mc_pf_act_mul_parts_bfloat(const float* part, uint32_t splits, uint32_t M, bf16_
     auto one = [&](float a, float b) {
         a = bf2f(f2bf(a));
         b = bf2f(f2bf(b));
-        const float g = gelu ? BF::rt(pf_gelu_f(a)) : pf_silu_T<BF>(a, etab);
+        const float g = gelu ? (etab ? pf_exp_tab(etab, a) : BF::rt(pf_gelu_f(a))) : pf_silu_T<BF>(a, etab);
         return g * b;
     };
     const float o0 = one(lo.x, lo.y), o1 = one(lo.z, lo.w), o2 = one(hi.x, hi.y), o3 = one(hi.z, hi.w);

@@ -80,8 +80,9 @@ def test_decode_and_reference_kernels_present(symbols):
               "mc_pf_dequant_rows_i4_bfloat", "mc_pf_dequant_rows_i8_bfloat"):  # the dequantised copy the opt-in library GEMM multiplies by
         assert k in symbols, k
     # the 256 x 256 ping-pong GEMM of long prompts (kernels/pf_gemm8.h, decoder.cc g8_launch)
+    assert "mc_gelu_table_bfloat" in symbols
     for f in ("i4", "i8", "w"):
-        for e in range(4):
+        for e in range(5):   # (e4, round 6: gemma's gelu(w1 x) * (w3 x) from the table)
             assert f"mc_pf_gemm8_{f}_bfloat_e{e}" in symbols
     # test aids live in a code object of their own (tests/kernels/): the product code object carries none
     assert not [k for k in symbols if k.startswith("mc_test_")], [k for k in symbols if k.startswith("mc_test_")]

@@ -582,11 +582,71 @@ def test_long_prompts_take_the_ping_pong_gemm_and_match_the_oracle(acc, n, gate,
     dec.release()
 
 
+def test_gelu_table_is_the_function_for_every_bfloat16(acc):
+    """Round 6: mc_gelu_table_bfloat's table IS T(gelu) of every bfloat16 value -- mc_pf_act_mul_bfloat over all 65536 values as `a` (b = 1) with the
+    table and with the fp64 tanh per element give the same rows (NaN inputs aside: their payloads are not compared)."""
+    import metalchat_amd as mc
+
+    a = np.arange(65536, dtype=np.uint32).astype(np.uint16)
+    pairs = np.empty(2 * 65536, np.uint16)
+    pairs[0::2] = a
+    pairs[1::2] = 0x3F80   # b = 1.0
+    inp = acc.to_device(pairs)
+    tab = acc.alloc(65536 * 4)
+    mc.KernelTask(acc.load("mc_gelu_table_bfloat"), (256 * 256, 1, 1), (256, 1, 1), [tab])()
+    outs = []
+    for t in (tab, None):
+        out = acc.to_device(np.zeros(65536, np.uint16))
+        mc.KernelTask(acc.load("mc_pf_act_mul_bfloat"), ((65536 // 4 // 256 + 1) * 256, 1, 1), (256, 1, 1), [inp, out, np.uint32(65536), np.int32(1), t])()
+        acc.wait()
+        outs.append(out.download(np.uint16, 65536))
+    finite = (a & 0x7F80) != 0x7F80
+    nan_in = ((a & 0x7F80) == 0x7F80) & ((a & 0x007F) != 0)
+    assert np.array_equal(outs[0][~nan_in], outs[1][~nan_in])
+    assert finite.sum() == 65536 - 256 and nan_in.sum() == 254
+    t32 = tab.download(np.float32, 65536)
+    assert t32[0x3F80] == 0.83984375 and t32[0] == 0.0   # gelu(1) = 0.8412 -> 0.83984375 as a bfloat16; gelu(0) = 0
+
+
+@pytest.mark.parametrize("quant,fmt,group,copy", [("i4", 2, 32, None), ("i4", 2, 32, "0"), (None, 0, 0, None)])
+def test_gemma_long_prompt_takes_the_gelu_epilogue(acc, quant, fmt, group, copy, monkeypatch):
+    """gemma3 blocks, 300 rows: w1|w3 with gelu(w1 x) * (w3 x) in the epilogue of the 256 x 256 GEMM (mc_pf_gemm8_*_e4, T(gelu) from the table) --
+    against the oracle, and bit for bit MC_PF_GELU_TABLE=0 (no table: the GEMM stores both halves and mc_pf_act_mul_bfloat evaluates the fp64 tanh)."""
+    import metalchat_amd as mc
+
+    if copy is not None:
+        monkeypatch.setenv("MC_PF_PLAIN_COPY", copy)
+    cfg = mg.tiny_cfg(BF16, family=1, dim=256, n_heads=4, n_kv_heads=2, head_dim=64, ffn_dim=768, n_layers=2, vocab=384, max_seq_len=320,
+                      rope_sliding_theta=10000.0, sliding_stride=2)
+    weights = mg.make_model(cfg, seed=141, quant=quant, group=group or 32)
+    tokens = np.random.default_rng(41).integers(0, cfg["vocab"], 300).tolist()
+    f = "w" if (fmt == 0 or copy is None) else "i4"
+    check_against_oracle(acc, cfg, weights, dict(weight_format=fmt, group_size=group), tokens, follow=2, expect_kernel=f"mc_pf_gemm8_{f}_bfloat_e4")
+    out = {}
+    for table in ("1", "0"):
+        monkeypatch.setenv("MC_PF_GELU_TABLE", table)
+        dec = mc.Decoder(acc, **mg.decoder_kwargs(cfg, weight_format=fmt, group_size=group))
+        dec.load_model(weights)
+        dec.launch_log(True)
+        tok = dec.prefill(tokens, 0)
+        names = set(dec.launched())
+        assert bool([x for x in names if x.endswith("_e4")]) == (table == "1"), sorted(names)
+        assert ("mc_pf_act_mul_bfloat" in names) == (table == "0"), sorted(names)
+        out[table] = (tok, dec.logits().copy(), [dec.export_kv(l) for l in range(cfg["n_layers"])])
+        dec.release()
+    assert out["1"][0] == out["0"][0]
+    parity.exact(out["1"][1], out["0"][1], "logits of the prompt, gelu from the table vs the fp64 tanh")
+    for l, ((ka, va), (kb, vb)) in enumerate(zip(out["1"][2], out["0"][2])):
+        parity.exact(ka, kb, f"block {l}: K cache")
+        parity.exact(va, vb, f"block {l}: V cache")
+
+
 @pytest.mark.parametrize("family,hd,n", [(0, 128, 300), (0, 128, 37), (1, 128, 300), (1, 256, 300), (1, 256, 37), (0, 64, 300), (0, 256, 300), (0, 256, 21), (0, 32, 70)])
 def test_packed_rope_launch_changes_no_bit(acc, family, hd, n, monkeypatch):
     """Round 6: mc_pf_rope_cache{,_parts}_v4_bfloat give a thread four rotation pairs (a quarter of the waves: the one-pair launch was bound by the
-    rate waves start at) where the block has no q / k norms.  MC_PF_ROPE_PACK=0 is the launch of rounds 1-5: logits, tokens and both caches are
-    equal bit for bit; gemma3 (family 1: q / k norms) keeps the old launch either way."""
+    rate waves start at) and write the transposed V cache 16 slots at a time.  MC_PF_ROPE_PACK=0 is the launch of rounds 1-5: logits, tokens and
+    both caches are equal bit for bit -- with gemma3's q / k norms too (family 1; head_dim 128 and 256, where the sum over a head is the old
+    launch's butterfly addition for addition)."""
     import metalchat_amd as mc
 
     over = dict(family=family, dim=256, n_heads=4, n_kv_heads=2, head_dim=hd, ffn_dim=512, n_layers=2, vocab=384, max_seq_len=320)
@@ -604,7 +664,7 @@ def test_packed_rope_launch_changes_no_bit(acc, family, hd, n, monkeypatch):
         toks = [dec.prefill(tokens, 0)]
         names = set(dec.launched())
         dec.launch_log(False)
-        assert bool([x for x in names if "rope_cache" in x and "_v4_" in x]) == (pack == "1" and family == 0), sorted(names)
+        assert bool([x for x in names if "rope_cache" in x and "_v4_" in x]) == (pack == "1"), sorted(names)
         lg = dec.logits().copy()
         for i in range(3):
             toks.append(dec.step(toks[-1], n + i))
