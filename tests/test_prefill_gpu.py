@@ -582,6 +582,19 @@ def test_long_prompts_take_the_ping_pong_gemm_and_match_the_oracle(acc, n, gate,
     dec.release()
 
 
+@pytest.mark.parametrize("family,kvh,n,window", [(1, 4, 270, 37), (1, 4, 40, 0), (1, 2, 129, 0), (1, 4, 300, 0)])
+def test_head_dim_256_prompt_attention(acc, family, kvh, n, window):
+    """head_dim 256 (Gemma-7B: as many kv heads as query heads): mc_pf_attn_bfloat_hd256 against the oracle -- gemma3's sliding window, a short
+    prompt, a long one, GQA 2."""
+    over = dict(family=family, dim=256, n_heads=4, n_kv_heads=kvh, head_dim=256, ffn_dim=512, n_layers=2, vocab=384, max_seq_len=320)
+    if family == 1:
+        over.update(rope_sliding_theta=10000.0, sliding_stride=2)
+    cfg = mg.tiny_cfg(BF16, **over)
+    weights = mg.make_model(cfg, seed=151, quant="i4", group=32)
+    tokens = np.random.default_rng(n).integers(0, cfg["vocab"], n).tolist()
+    check_against_oracle(acc, cfg, weights, dict(weight_format=2, group_size=32), tokens, window=window, follow=2, expect_kernel="mc_pf_attn_bfloat_hd256")
+
+
 def test_gelu_table_is_the_function_for_every_bfloat16(acc):
     """Round 6: mc_gelu_table_bfloat's table IS T(gelu) of every bfloat16 value -- mc_pf_act_mul_bfloat over all 65536 values as `a` (b = 1) with the
     table and with the fp64 tanh per element give the same rows (NaN inputs aside: their payloads are not compared)."""
