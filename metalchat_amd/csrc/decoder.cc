@@ -262,6 +262,7 @@ struct mc_decoder {
     bool kv_virtual_on = true; // MC_KV_VIRTUAL: fewer than 8 kv heads launched as 8 virtual ones where wq|wk|wv is inside the attention launch (kv_virtual_shift)
     bool pf_attn8_on = true;   // MC_PF_ATTN8: the prompt attention with K / V tiles through LDS, from pf_attn8_rows rows on
     int pf_attn8_rows = 1024;  // MC_PF_ATTN8_ROWS
+    int pf_attn8_rows256 = 513; // MC_PF_ATTN8_ROWS256 (head_dim 256: mc_pf_attn8_bfloat_hd256; Gemma-7B shapes: 2048 rows 35.5 against 44.4 ms, 1024: 19.0 against 21.3, 512: equal, 256: 9.0 against 8.85)
     int pf_plain_mode = -1;    // MC_PF_PLAIN_COPY: 1 = the 256 x 256 prompt GEMM multiplies quantised matrices from their dequantised bfloat16 copy (linear_w::wd, built on
                                // first use, 2 bytes per weight more HBM: the very values the quantised loop stages in LDS, same loop, same sums bit for bit -- without
                                // the dequantisation that competes with the MFMAs for the issue port), 0 = from the quantised rows; unset = 1 iff the copies of every
@@ -2096,6 +2097,16 @@ struct mc_decoder {
                     const unsigned ntl = (unsigned)(M + 31) / 32u;
                     const char* pair_env = getenv("MC_PF_ATTN8_PAIR");
                     const bool pair = pair_env ? atoi(pair_env) != 0 : ((ntl + 1u) / 2u) * (unsigned)(H / 4) >= (unsigned)dev->prop.multiProcessorCount;
+                    // head_dim 256 (round 6; Gemma-7B: a kv head per query head): the same K / V tiles through LDS for 64 rows of ONE head, four waves
+                    // (MC_PF_ATTN8_ROWS256: from how many rows; MC_PF_ATTN_HEADS=1: never)
+                    const bool eight256 = hd == 256 && cfg.max_seq_len % 8 == 0 && (heads_env ? atoi(heads_env) == 8 : (pf_attn8_on && M >= pf_attn8_rows256));
+                    if (eight256) {
+                        const unsigned ntl64 = (unsigned)(M + 63) / 64u;
+                        const bool pair64 = pair_env ? atoi(pair_env) != 0 : ((ntl64 + 1u) / 2u) * (unsigned)H >= (unsigned)dev->prop.multiProcessorCount;
+                        return launch("mc_pf_attn8_bfloat_hd256", pair64 ? (ntl64 + 1u) / 2u : ntl64, H, 1, 256, 0,
+                                      pack(pf_q, L.kc, L.vt, pf_att, (uint32_t)M, (uint32_t)S, (uint32_t)H, (uint32_t)(H / KV),
+                                           (uint32_t)cfg.max_seq_len, scale_T, win, (const void*)pf_etab));
+                    }
                     if (eight)
                         return launch("mc_pf_attn8_bfloat_hd128", pair ? (ntl + 1u) / 2u : ntl, H / 4, 1, 512, 0,
                                       pack(pf_q, L.kc, L.vt, pf_att, (uint32_t)M, (uint32_t)S, (uint32_t)H, (uint32_t)(H / KV),
@@ -2282,6 +2293,7 @@ mc_decoder_create(mc_device* dev, mc_library* lib, mc_queue* q, const mc_decoder
     if (const char* e = getenv("MC_ATTN_I8")) d->attn_i8_on = atoi(e) != 0;
     if (const char* e = getenv("MC_PF_ATTN8")) d->pf_attn8_on = atoi(e) != 0;
     if (const char* e = getenv("MC_PF_ATTN8_ROWS")) d->pf_attn8_rows = std::max(1, atoi(e));
+    if (const char* e = getenv("MC_PF_ATTN8_ROWS256")) d->pf_attn8_rows256 = std::max(1, atoi(e));
     if (const char* e = getenv("MC_PF_GEMM8")) d->pf_g8_on = atoi(e) != 0;
     if (const char* e = getenv("MC_PF_ROPE_PACK")) d->pf_rope_pack = atoi(e) != 0;
     if (const char* e = getenv("MC_PF_PLAIN_COPY")) d->pf_plain_mode = atoi(e) != 0 ? 1 : 0;

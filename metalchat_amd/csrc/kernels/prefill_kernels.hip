@@ -1576,15 +1576,20 @@ mc_pf_attn4_bfloat_hd128(const bf16_t* Q, const bf16_t* kc, const bf16_t* vt, bf
 // (First build: 64 rows per workgroup, one row tile each: correct at once and no faster than pf_attn_kt_body -- 34.8 against 35.1 ms per
 //  2048-token prompt: the launch lasted what its heaviest workgroup took, twice the mean, and the per-score vector work -- two roundings,
 //  the table lookup, the product with 1/sum: ~ 17 instructions in pass 2 -- is what a wave's time goes to, not the K / V bytes.)
-template <uint32_t HD, int NH>
+// (round 6) NW waves = NH heads x NW / NH blocks of 16 rows: <128, 4, 8> is the kernel above; <256, 1, 4> (mc_pf_attn8_bfloat_hd256) is head_dim 256
+// with a kv head per query head (Gemma-7B): four waves = 64 rows of ONE head share a tile of 64 keys (K rows of 512 bytes: 32 KiB, V: 256 rows of
+// 128 bytes) -- mc_pf_attn_bfloat_hd256 pulled 3.2 GB of fragments per block at 2048 rows, one 16-row block at a time.
+template <uint32_t HD, int NH, int NW>
 __device__ __forceinline__ void
 pf_attn_lds_body(const bf16_t* Q, const bf16_t* kc, const bf16_t* vt, bf16_t* out, uint32_t M, uint32_t S, uint32_t H, uint32_t n_rep,
                  uint32_t max_seq, float scale, uint32_t window, const float* etab)
 {
     using T = BF;
-    static_assert(HD == 128 && NH == 4, "8 waves = 4 heads x 2 x 16 rows; K rows of 256 bytes");
-    constexpr uint32_t DT = HD / 16, DK = HD / 32, KT = 64, RT = 32;
-    constexpr uint32_t KB = KT * HD * 2, VB = HD * KT * 2, IMG = KB + VB; // 16 KiB + 16 KiB
+    static_assert((HD == 128 && NH == 4 && NW == 8) || (HD == 256 && NH == 1 && NW == 4), "waves = heads x blocks of 16 rows; K rows of 256 or 512 bytes");
+    constexpr uint32_t DT = HD / 16, DK = HD / 32, KT = 64, RT = 16 * (NW / NH);
+    constexpr uint32_t KB = KT * HD * 2, VB = HD * KT * 2, IMG = KB + VB; // 16 + 16 KiB (head_dim 128), 32 + 32 KiB (256)
+    constexpr uint32_t KI = KB / 1024 / NW, VI = VB / 1024 / NW;         // 1 KiB LDS-DMAs per wave and tile: K, V
+    constexpr uint32_t KPI = 1024 / (HD * 2);                             // keys per K instruction (4 or 2)
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     typedef __attribute__((address_space(3))) char lds_char;
     __shared__ __attribute__((aligned(1024))) char lds_[2 * IMG + 2 * pf_exp_window::N * 4]; // (ONE array: cdna_hip_programming.md s.5)
@@ -1593,7 +1598,7 @@ pf_attn_lds_body(const bf16_t* Q, const bf16_t* kc, const bf16_t* vt, bf16_t* ou
     ew.fill(etab);
     const uint32_t lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t l15 = lane & 15, lg = lane >> 4, kg = lg * 8;
-    const uint32_t h0 = blockIdx.y * NH, kv = h0 / n_rep, hh = h0 + (wave & 3u);
+    const uint32_t h0 = blockIdx.y * NH, kv = h0 / n_rep, hh = h0 + (wave % NH);
     const uint32_t sq = S - M, NTL = (M + RT - 1u) / RT;
     // ---- staging (inline asm: hipcc neither counts an LDS-DMA nor may it wait vmcnt(0) in front of every LDS read for it)
     auto rsrc_of = [](const void* p, size_t bytes) {
@@ -1602,12 +1607,23 @@ pf_attn_lds_body(const bf16_t* Q, const bf16_t* kc, const bf16_t* vt, bf16_t* ou
     };
     const u32x4 krs = rsrc_of(kc + (size_t)kv * max_seq * HD, (size_t)max_seq * HD * 2);   // keys past max_seq read as zeros
     const u32x4 vrs = rsrc_of(vt + (size_t)kv * HD * max_seq, (size_t)HD * max_seq * 2);
-    // K: instruction i of wave w = keys 8 w + 4 i + (lane >> 4) of the tile, position lane & 15 of the 256-byte row holds source chunk
-    //    (lane & 15) ^ sK, sK = 4 ((key >> 3) & 3) + (key & 3) -- the lane's l15 when the fragment is read (below): conflict-free
-    // V: instruction i of wave w = rows (dims) 16 w + 8 i + (lane >> 3), position lane & 7 holds chunk (lane & 7) ^ ((row >> 1) & 7)
-    const uint32_t kvo = (8u * wave + (lane >> 4)) * (HD * 2u) + (((lane & 15u) ^ (4u * (wave & 3u) + (lane >> 4))) * 16u);
-    const uint32_t vvo = (16u * wave + (lane >> 3)) * (max_seq * 2u) + (((lane & 7u) ^ (lane >> 4)) * 16u);
-    const uint32_t ldsw = (uint32_t)(uintptr_t)lds + wave * 2048u;
+    // K: instruction i of wave w = keys (KI w + i) KPI + lane / (64 / KPI) of the tile; position p = lane % (64 / KPI) of the row holds source
+    //    chunk p ^ sK in its low four bits, sK = 4 ((key >> 3) & 3) + (key & 3) -- the lane's l15 when the fragment is read (below): conflict-free
+    // V: instruction i of wave w = rows (dims) 8 (VI w + i) + (lane >> 3), position lane & 7 holds chunk (lane & 7) ^ ((row >> 1) & 7)
+    // The destination is linear: key k at k * 2 HD bytes of the K image, dim d at d * 128 bytes of the V image.
+    uint32_t kvo[KI], vvo[VI];
+#pragma unroll
+    for (uint32_t i = 0; i < KI; i++) {
+        const uint32_t key = (KI * wave + i) * KPI + lane / (64u / KPI), pch = lane % (64u / KPI);
+        const uint32_t sk = 4u * ((key >> 3) & 3u) + (key & 3u);
+        kvo[i] = key * (HD * 2u) + (((pch & ~15u) | ((pch & 15u) ^ sk)) * 16u);
+    }
+#pragma unroll
+    for (uint32_t i = 0; i < VI; i++) {
+        const uint32_t row = 8u * (VI * wave + i) + (lane >> 3);
+        vvo[i] = row * (max_seq * 2u) + (((lane & 7u) ^ ((row >> 1) & 7u)) * 16u);
+    }
+    const uint32_t ldsk = (uint32_t)(uintptr_t)lds + wave * (KI * 1024u), ldsv = (uint32_t)(uintptr_t)lds + KB + wave * (VI * 1024u);
     auto dma = [&](uint32_t dst, uint32_t vo, const u32x4& rs) {
         uint32_t keep;
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
@@ -1617,11 +1633,11 @@ pf_attn_lds_body(const bf16_t* Q, const bf16_t* kc, const bf16_t* vt, bf16_t* ou
     };
     auto stage = [&](uint32_t t, bool with_v) { // tile t (keys 64 t ..) into image t & 1
         const uint32_t img = (t & 1u) * IMG, key0 = t * KT;
-        dma(ldsw + img, kvo + key0 * (HD * 2u), krs);
-        dma(ldsw + img + 1024u, kvo + (key0 + 4u) * (HD * 2u), krs);
+#pragma unroll
+        for (uint32_t i = 0; i < KI; i++) dma(ldsk + img + i * 1024u, kvo[i] + key0 * (HD * 2u), krs);
         if (with_v) {
-            dma(ldsw + img + KB, vvo + key0 * 2u, vrs);
-            dma(ldsw + img + KB + 1024u, (vvo + 8u * (max_seq * 2u) + key0 * 2u) ^ 64u, vrs);
+#pragma unroll
+            for (uint32_t i = 0; i < VI; i++) dma(ldsv + img + i * 1024u, vvo[i] + key0 * 2u, vrs);
         }
     };
     __syncthreads(); // the exp window is filled
@@ -1631,7 +1647,7 @@ pf_attn_lds_body(const bf16_t* Q, const bf16_t* kc, const bf16_t* vt, bf16_t* ou
     for (uint32_t which = 0; which < 2; which++) {
         const uint32_t rt = which ? NTL - 1u - blockIdx.x : blockIdx.x;
         if (which && (!paired || rt == blockIdx.x)) break; // (wave-uniform)
-        const uint32_t r0 = rt * RT, rs0 = r0 + 16u * (wave >> 2), r = rs0 + l15; // this wave: head hh, rows rs0 .. rs0 + 15; the lane's row
+        const uint32_t r0 = rt * RT, rs0 = r0 + 16u * (wave / NH), r = rs0 + l15; // this wave: head hh, rows rs0 .. rs0 + 15; the lane's row
         const uint32_t rlast = min(r0 + RT - 1u, M - 1u);
         uint32_t clo = sq, chi = sq + rlast;
         if (window && r0 + 1 > window) clo = sq + (r0 + 1 - window);
@@ -1778,7 +1794,13 @@ extern "C" __global__ void __launch_bounds__(512)
 mc_pf_attn8_bfloat_hd128(const bf16_t* Q, const bf16_t* kc, const bf16_t* vt, bf16_t* out, uint32_t M, uint32_t S, uint32_t H, uint32_t n_rep,
                          uint32_t max_seq, float scale, uint32_t window, const float* etab)
 {
-    pf_attn_lds_body<128, 4>(Q, kc, vt, out, M, S, H, n_rep, max_seq, scale, window, etab);
+    pf_attn_lds_body<128, 4, 8>(Q, kc, vt, out, M, S, H, n_rep, max_seq, scale, window, etab);
+}
+extern "C" __global__ void __launch_bounds__(256)
+mc_pf_attn8_bfloat_hd256(const bf16_t* Q, const bf16_t* kc, const bf16_t* vt, bf16_t* out, uint32_t M, uint32_t S, uint32_t H, uint32_t n_rep,
+                         uint32_t max_seq, float scale, uint32_t window, const float* etab)
+{
+    pf_attn_lds_body<256, 1, 4>(Q, kc, vt, out, M, S, H, n_rep, max_seq, scale, window, etab);
 }
 
 // (A 64-row variant -- four waves sharing every K / V tile through LDS, each wave owning 16 rows --

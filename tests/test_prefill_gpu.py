@@ -582,17 +582,25 @@ def test_long_prompts_take_the_ping_pong_gemm_and_match_the_oracle(acc, n, gate,
     dec.release()
 
 
-@pytest.mark.parametrize("family,kvh,n,window", [(1, 4, 270, 37), (1, 4, 40, 0), (1, 2, 129, 0), (1, 4, 300, 0)])
-def test_head_dim_256_prompt_attention(acc, family, kvh, n, window):
-    """head_dim 256 (Gemma-7B: as many kv heads as query heads): mc_pf_attn_bfloat_hd256 against the oracle -- gemma3's sliding window, a short
-    prompt, a long one, GQA 2."""
+@pytest.mark.parametrize("family,kvh,n,window,pair", [(1, 4, 270, 37, "1"), (1, 4, 40, 0, None), (1, 2, 129, 0, "0"), (1, 4, 300, 0, "1"), (1, 4, 300, 0, "0"),
+                                                       (1, 4, 65, 0, "1"), (1, 4, 193, 5, "1")])
+def test_head_dim_256_prompt_attention(acc, family, kvh, n, window, pair, monkeypatch):
+    """head_dim 256 (Gemma-7B: as many kv heads as query heads) against the oracle -- gemma3's sliding window, a short prompt, long ones, GQA 2.
+    Round 6: mc_pf_attn8_bfloat_hd256 (pf_attn_lds_body<256, 1, 4>: 64 rows of one head share K / V tiles of 64 keys through LDS, row tiles single
+    and in pairs) from 513 rows on (MC_PF_ATTN8_ROWS256 lowers the gate for these small models); below that, and with MC_PF_ATTN_HEADS=1, the round-1 kernel -- same token, same bounds."""
     over = dict(family=family, dim=256, n_heads=4, n_kv_heads=kvh, head_dim=256, ffn_dim=512, n_layers=2, vocab=384, max_seq_len=320)
     if family == 1:
         over.update(rope_sliding_theta=10000.0, sliding_stride=2)
     cfg = mg.tiny_cfg(BF16, **over)
     weights = mg.make_model(cfg, seed=151, quant="i4", group=32)
     tokens = np.random.default_rng(n).integers(0, cfg["vocab"], n).tolist()
-    check_against_oracle(acc, cfg, weights, dict(weight_format=2, group_size=32), tokens, window=window, follow=2, expect_kernel="mc_pf_attn_bfloat_hd256")
+    if pair is not None:
+        monkeypatch.setenv("MC_PF_ATTN8_PAIR", pair)
+        monkeypatch.setenv("MC_PF_ATTN8_ROWS256", "64")
+    check_against_oracle(acc, cfg, weights, dict(weight_format=2, group_size=32), tokens, window=window, follow=2,
+                         expect_kernel="mc_pf_attn8_bfloat_hd256" if pair is not None else "mc_pf_attn_bfloat_hd256")
+    monkeypatch.setenv("MC_PF_ATTN_HEADS", "1")
+    check_against_oracle(acc, cfg, weights, dict(weight_format=2, group_size=32), tokens, window=window, follow=1, expect_kernel="mc_pf_attn_bfloat_hd256")
 
 
 def test_gelu_table_is_the_function_for_every_bfloat16(acc):
