@@ -262,6 +262,7 @@ struct mc_decoder {
     bool kv_virtual_on = true; // MC_KV_VIRTUAL: fewer than 8 kv heads launched as 8 virtual ones where wq|wk|wv is inside the attention launch (kv_virtual_shift)
     bool pf_attn8_on = true;   // MC_PF_ATTN8: the prompt attention with K / V tiles through LDS, from pf_attn8_rows rows on
     int pf_attn8_rows = 1024;  // MC_PF_ATTN8_ROWS
+    int pf_attn8_rows64 = 1793; // MC_PF_ATTN8_ROWS64 (head_dim 64: mc_pf_attn8_bfloat_hd64_h{8,4}; TinyLlama 2048 rows 8.35 against 8.95 ms, Llama-3.2-1B 6.57 against 7.0; 1536 - 1792 rows equal, 1024: 5.1 against 4.9 -- profiles/r06_pf_hd64_attn8_ab.log)
     int pf_attn8_rows256 = 513; // MC_PF_ATTN8_ROWS256 (head_dim 256: mc_pf_attn8_bfloat_hd256; Gemma-7B shapes: 2048 rows 35.5 against 44.4 ms, 1024: 19.0 against 21.3, 512: equal, 256: 9.0 against 8.85)
     int pf_plain_mode = -1;    // MC_PF_PLAIN_COPY: 1 = the 256 x 256 prompt GEMM multiplies quantised matrices from their dequantised bfloat16 copy (linear_w::wd, built on
                                // first use, 2 bytes per weight more HBM: the very values the quantised loop stages in LDS, same loop, same sums bit for bit -- without
@@ -2107,6 +2108,16 @@ struct mc_decoder {
                                       pack(pf_q, L.kc, L.vt, pf_att, (uint32_t)M, (uint32_t)S, (uint32_t)H, (uint32_t)(H / KV),
                                            (uint32_t)cfg.max_seq_len, scale_T, win, (const void*)pf_etab));
                     }
+                    // head_dim 64 (round 6; TinyLlama-1.1B: 8 query heads per kv head, Llama-3.2-1B: 4): 8 heads x 16 rows or 4 heads x 32 rows per workgroup
+                    const unsigned nh64 = (H / KV) % 8 == 0 ? 8u : ((H / KV) % 4 == 0 ? 4u : 0u);
+                    const bool eight64 = hd == 64 && nh64 && cfg.max_seq_len % 8 == 0 && (heads_env ? atoi(heads_env) == 8 : (pf_attn8_on && M >= pf_attn8_rows64));
+                    if (eight64) {
+                        const unsigned rt64 = 128u / nh64, ntl = ((unsigned)M + rt64 - 1u) / rt64;
+                        const bool pr = pair_env ? atoi(pair_env) != 0 : ((ntl + 1u) / 2u) * ((unsigned)H / nh64) >= (unsigned)dev->prop.multiProcessorCount;
+                        return launch(nh64 == 8 ? "mc_pf_attn8_bfloat_hd64_h8" : "mc_pf_attn8_bfloat_hd64_h4", pr ? (ntl + 1u) / 2u : ntl, (unsigned)H / nh64, 1, 512, 0,
+                                      pack(pf_q, L.kc, L.vt, pf_att, (uint32_t)M, (uint32_t)S, (uint32_t)H, (uint32_t)(H / KV),
+                                           (uint32_t)cfg.max_seq_len, scale_T, win, (const void*)pf_etab));
+                    }
                     if (eight)
                         return launch("mc_pf_attn8_bfloat_hd128", pair ? (ntl + 1u) / 2u : ntl, H / 4, 1, 512, 0,
                                       pack(pf_q, L.kc, L.vt, pf_att, (uint32_t)M, (uint32_t)S, (uint32_t)H, (uint32_t)(H / KV),
@@ -2293,6 +2304,7 @@ mc_decoder_create(mc_device* dev, mc_library* lib, mc_queue* q, const mc_decoder
     if (const char* e = getenv("MC_ATTN_I8")) d->attn_i8_on = atoi(e) != 0;
     if (const char* e = getenv("MC_PF_ATTN8")) d->pf_attn8_on = atoi(e) != 0;
     if (const char* e = getenv("MC_PF_ATTN8_ROWS")) d->pf_attn8_rows = std::max(1, atoi(e));
+    if (const char* e = getenv("MC_PF_ATTN8_ROWS64")) d->pf_attn8_rows64 = std::max(1, atoi(e));
     if (const char* e = getenv("MC_PF_ATTN8_ROWS256")) d->pf_attn8_rows256 = std::max(1, atoi(e));
     if (const char* e = getenv("MC_PF_GEMM8")) d->pf_g8_on = atoi(e) != 0;
     if (const char* e = getenv("MC_PF_ROPE_PACK")) d->pf_rope_pack = atoi(e) != 0;

@@ -1578,14 +1578,18 @@ mc_pf_attn4_bfloat_hd128(const bf16_t* Q, const bf16_t* kc, const bf16_t* vt, bf
 //  the table lookup, the product with 1/sum: ~ 17 instructions in pass 2 -- is what a wave's time goes to, not the K / V bytes.)
 // (round 6) NW waves = NH heads x NW / NH blocks of 16 rows: <128, 4, 8> is the kernel above; <256, 1, 4> (mc_pf_attn8_bfloat_hd256) is head_dim 256
 // with a kv head per query head (Gemma-7B): four waves = 64 rows of ONE head share a tile of 64 keys (K rows of 512 bytes: 32 KiB, V: 256 rows of
-// 128 bytes) -- mc_pf_attn_bfloat_hd256 pulled 3.2 GB of fragments per block at 2048 rows, one 16-row block at a time.
+// 128 bytes) -- mc_pf_attn_bfloat_hd256 pulled 3.2 GB of fragments per block at 2048 rows, one 16-row block at a time.  <64, 8, 8> and <64, 4, 8>
+// (mc_pf_attn8_bfloat_hd64_h8 / _h4) are head_dim 64 with eight or four query heads per kv head (TinyLlama-1.1B, Llama-3.2-1B): the eight waves of a
+// workgroup are 8 heads x 16 rows or 4 heads x 32 rows on one tile (K rows of 128 bytes: the swizzle flips three bits of the chunk index, not four).
 template <uint32_t HD, int NH, int NW>
 __device__ __forceinline__ void
 pf_attn_lds_body(const bf16_t* Q, const bf16_t* kc, const bf16_t* vt, bf16_t* out, uint32_t M, uint32_t S, uint32_t H, uint32_t n_rep,
                  uint32_t max_seq, float scale, uint32_t window, const float* etab)
 {
     using T = BF;
-    static_assert((HD == 128 && NH == 4 && NW == 8) || (HD == 256 && NH == 1 && NW == 4), "waves = heads x blocks of 16 rows; K rows of 256 or 512 bytes");
+    static_assert((HD == 128 && NH == 4 && NW == 8) || (HD == 256 && NH == 1 && NW == 4) || (HD == 64 && (NH == 4 || NH == 8) && NW == 8),
+                  "waves = heads x blocks of 16 rows; K rows of 128, 256 or 512 bytes");
+    constexpr uint32_t SW = HD >= 128 ? 15u : HD / 8 - 1u; // the K rows' swizzle: the low bits of the 16-byte chunk index that the key's sK flips
     constexpr uint32_t DT = HD / 16, DK = HD / 32, KT = 64, RT = 16 * (NW / NH);
     constexpr uint32_t KB = KT * HD * 2, VB = HD * KT * 2, IMG = KB + VB; // 16 + 16 KiB (head_dim 128), 32 + 32 KiB (256)
     constexpr uint32_t KI = KB / 1024 / NW, VI = VB / 1024 / NW;         // 1 KiB LDS-DMAs per wave and tile: K, V
@@ -1616,7 +1620,7 @@ pf_attn_lds_body(const bf16_t* Q, const bf16_t* kc, const bf16_t* vt, bf16_t* ou
     for (uint32_t i = 0; i < KI; i++) {
         const uint32_t key = (KI * wave + i) * KPI + lane / (64u / KPI), pch = lane % (64u / KPI);
         const uint32_t sk = 4u * ((key >> 3) & 3u) + (key & 3u);
-        kvo[i] = key * (HD * 2u) + (((pch & ~15u) | ((pch & 15u) ^ sk)) * 16u);
+        kvo[i] = key * (HD * 2u) + (((pch & ~SW) | ((pch & SW) ^ (sk & SW))) * 16u);
     }
 #pragma unroll
     for (uint32_t i = 0; i < VI; i++) {
@@ -1664,7 +1668,7 @@ pf_attn_lds_body(const bf16_t* Q, const bf16_t* kc, const bf16_t* vt, bf16_t* ou
             lds_char* p = lds + img + (32u * bb + 8u * (l15 >> 2) + 4u * h + (l15 & 3u)) * (HD * 2u);
 #pragma unroll
             for (uint32_t d = 0; d < DK; d++) {
-                const u32x4 v = *(const __attribute__((address_space(3))) u32x4*)(p + (((d * 4u + lg) ^ l15) * 16u));
+                const u32x4 v = *(const __attribute__((address_space(3))) u32x4*)(p + (((d * 4u + lg) ^ (l15 & SW)) * 16u));
                 kb[d] = make_uint4(v.x, v.y, v.z, v.w);
             }
         };
@@ -1795,6 +1799,18 @@ mc_pf_attn8_bfloat_hd128(const bf16_t* Q, const bf16_t* kc, const bf16_t* vt, bf
                          uint32_t max_seq, float scale, uint32_t window, const float* etab)
 {
     pf_attn_lds_body<128, 4, 8>(Q, kc, vt, out, M, S, H, n_rep, max_seq, scale, window, etab);
+}
+extern "C" __global__ void __launch_bounds__(512)
+mc_pf_attn8_bfloat_hd64_h8(const bf16_t* Q, const bf16_t* kc, const bf16_t* vt, bf16_t* out, uint32_t M, uint32_t S, uint32_t H, uint32_t n_rep,
+                           uint32_t max_seq, float scale, uint32_t window, const float* etab)
+{
+    pf_attn_lds_body<64, 8, 8>(Q, kc, vt, out, M, S, H, n_rep, max_seq, scale, window, etab);
+}
+extern "C" __global__ void __launch_bounds__(512)
+mc_pf_attn8_bfloat_hd64_h4(const bf16_t* Q, const bf16_t* kc, const bf16_t* vt, bf16_t* out, uint32_t M, uint32_t S, uint32_t H, uint32_t n_rep,
+                           uint32_t max_seq, float scale, uint32_t window, const float* etab)
+{
+    pf_attn_lds_body<64, 4, 8>(Q, kc, vt, out, M, S, H, n_rep, max_seq, scale, window, etab);
 }
 extern "C" __global__ void __launch_bounds__(256)
 mc_pf_attn8_bfloat_hd256(const bf16_t* Q, const bf16_t* kc, const bf16_t* vt, bf16_t* out, uint32_t M, uint32_t S, uint32_t H, uint32_t n_rep,

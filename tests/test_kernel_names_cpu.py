@@ -76,7 +76,7 @@ def test_decode_and_reference_kernels_present(symbols):
               # the prompt pass on the quad-interleaved weight copy and its consumers with the split-K reduce inside (round 4)
               "mc_pf2_repack_i4", "mc_pf2_gemm_i4_bfloat", "mc_pf_rope_cache_parts_bfloat", "mc_pf_rope_cache_v4_bfloat", "mc_pf_rope_cache_parts_v4_bfloat", "mc_pf_act_mul_parts_bfloat",
               "mc_pf_rmsnorm_parts_bfloat", "mc_pf_splitk_reduce_bfloat",
-              "mc_exp_table_bfloat", "mc_pf_exp_window_bfloat", "mc_pf_attn2_bfloat_hd128", "mc_pf_attn4_bfloat_hd128", "mc_pf_attn8_bfloat_hd128", "mc_pf_attn8_bfloat_hd256",  # exp of a bfloat16 by table (prompt attention, silu)
+              "mc_exp_table_bfloat", "mc_pf_exp_window_bfloat", "mc_pf_attn2_bfloat_hd128", "mc_pf_attn4_bfloat_hd128", "mc_pf_attn8_bfloat_hd128", "mc_pf_attn8_bfloat_hd256", "mc_pf_attn8_bfloat_hd64_h8", "mc_pf_attn8_bfloat_hd64_h4",  # exp of a bfloat16 by table (prompt attention, silu)
               "mc_pf_dequant_rows_i4_bfloat", "mc_pf_dequant_rows_i8_bfloat"):  # the dequantised copy the opt-in library GEMM multiplies by
         assert k in symbols, k
     # the 256 x 256 ping-pong GEMM of long prompts (kernels/pf_gemm8.h, decoder.cc g8_launch)

@@ -603,6 +603,27 @@ def test_head_dim_256_prompt_attention(acc, family, kvh, n, window, pair, monkey
     check_against_oracle(acc, cfg, weights, dict(weight_format=2, group_size=32), tokens, window=window, follow=1, expect_kernel="mc_pf_attn_bfloat_hd256")
 
 
+@pytest.mark.parametrize("family,heads,kvh,n,window,pair", [(0, 8, 1, 300, 0, "1"), (0, 8, 1, 300, 0, "0"), (0, 8, 2, 300, 0, "1"), (0, 8, 2, 270, 0, "0"),
+                                                             (1, 8, 1, 270, 37, "1"), (1, 8, 2, 193, 5, "1"), (0, 16, 2, 65, 0, "1"), (0, 8, 2, 129, 0, None)])
+def test_head_dim_64_prompt_attention_through_lds_tiles(acc, family, heads, kvh, n, window, pair, monkeypatch):
+    """Round 6: head_dim 64 with eight or four query heads per kv head (TinyLlama-1.1B, Llama-3.2-1B) -- mc_pf_attn8_bfloat_hd64_h8 / _h4
+    (pf_attn_lds_body<64, 8, 8> / <64, 4, 8>: K rows of 128 bytes, eight waves = 8 heads x 16 rows or 4 heads x 32 rows on one K / V tile) against the
+    oracle: single row tiles and pairs, gemma3's sliding window, ragged last tiles; MC_PF_ATTN_HEADS=2 (the two-head kernel of round 4) within the same bounds."""
+    over = dict(family=family, dim=256, n_heads=heads, n_kv_heads=kvh, head_dim=64, ffn_dim=512, n_layers=2, vocab=384, max_seq_len=320)
+    if family == 1:
+        over.update(rope_sliding_theta=10000.0, sliding_stride=2)
+    cfg = mg.tiny_cfg(BF16, **over)
+    weights = mg.make_model(cfg, seed=161, quant="i4", group=32)
+    tokens = np.random.default_rng(n + heads).integers(0, cfg["vocab"], n).tolist()
+    monkeypatch.setenv("MC_PF_ATTN8_ROWS64", "64")   # (the product's gate sits where the kernel starts to pay on TinyLlama's widths)
+    if pair is not None:
+        monkeypatch.setenv("MC_PF_ATTN8_PAIR", pair)
+    kern = "mc_pf_attn8_bfloat_hd64_h8" if heads // kvh % 8 == 0 else "mc_pf_attn8_bfloat_hd64_h4"
+    check_against_oracle(acc, cfg, weights, dict(weight_format=2, group_size=32), tokens, window=window, follow=2, expect_kernel=kern)
+    monkeypatch.setenv("MC_PF_ATTN_HEADS", "2")
+    check_against_oracle(acc, cfg, weights, dict(weight_format=2, group_size=32), tokens, window=window, follow=1, expect_kernel="mc_pf_attn2_bfloat_hd64")
+
+
 def test_gelu_table_is_the_function_for_every_bfloat16(acc):
     """Round 6: mc_gelu_table_bfloat's table IS T(gelu) of every bfloat16 value -- mc_pf_act_mul_bfloat over all 65536 values as `a` (b = 1) with the
     table and with the fp64 tanh per element give the same rows (NaN inputs aside: their payloads are not compared)."""

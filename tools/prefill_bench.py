@@ -1,5 +1,5 @@
 """Time-to-first-token of the prompt pass on the BASELINE model shape (tuning aid).
-usage: [WBITS=4|8|16] [MODEL=llama3-8b|gemma] python tools/prefill_bench.py [len ...]   (16: plain bfloat weights -- what the tiled GEMM does without its
+usage: [WBITS=4|8|16] [MODEL=llama3-8b|gemma|tinyllama|llama32] python tools/prefill_bench.py [len ...]   (16: plain bfloat weights -- what the tiled GEMM does without its
 dequantisation; gemma: Gemma-7B shapes with the gemma3 block, BASELINE configs[3])"""
 import sys
 import time
@@ -14,7 +14,11 @@ import metalchat_amd as mc
 lens = [int(a) for a in sys.argv[1:]] or [128, 512, 2048]
 acc = mc.HardwareAccelerator(path=os.environ.get("MC_HSACO"))
 GEMMA = os.environ.get("MODEL", "llama3-8b") == "gemma"
-shape = (dict(dim=3072, n_heads=16, n_kv_heads=16, head_dim=256, ffn_dim=24576, n_layers=28, vocab=256000, rope_theta=10000.0, attn_scale=256 ** -0.5,
+TINY = os.environ.get("MODEL", "llama3-8b") == "tinyllama"   # (BASELINE configs[0]: WBITS=16 for its bfloat16 weights)
+L32 = os.environ.get("MODEL", "llama3-8b") == "llama32"      # (Llama-3.2-1B, the reference's default model: WBITS=16)
+shape = (dict(dim=2048, n_heads=32, n_kv_heads=4, head_dim=64, ffn_dim=5632, n_layers=22, vocab=32000, rope_theta=10000.0, attn_scale=64 ** -0.5) if TINY else
+         dict(dim=2048, n_heads=32, n_kv_heads=8, head_dim=64, ffn_dim=8192, n_layers=16, vocab=128256, rope_theta=500000.0, attn_scale=64 ** -0.5) if L32 else
+         dict(dim=3072, n_heads=16, n_kv_heads=16, head_dim=256, ffn_dim=24576, n_layers=28, vocab=256000, rope_theta=10000.0, attn_scale=256 ** -0.5,
               family=mc.FAMILY_GEMMA3, rope_sliding_theta=10000.0, sliding_stride=6) if GEMMA else
          dict(dim=4096, n_heads=32, n_kv_heads=8, head_dim=128, ffn_dim=14336, n_layers=32, vocab=128256, rope_theta=500000.0, attn_scale=128 ** -0.5))
 VOCAB, PARAMS = shape["vocab"], shape["n_layers"] * (shape["dim"] * shape["head_dim"] * (2 * shape["n_heads"] + 2 * shape["n_kv_heads"]) + 3 * shape["dim"] * shape["ffn_dim"])
