@@ -2141,7 +2141,15 @@ struct mc_decoder {
                                 (uint32_t)hd, (uint32_t)cfg.max_seq_len, win)); });
                 if (s != MC_OK) return s;
             }
-            if (L.attention_post_norm) {
+            // gemma3's post norms: the reduce of a split Wo / w2, the post norm with the residual and the next norm in one launch
+            // (prefill_kernels.hip mc_pf_rmsnorm2_parts_bfloat; MC_PF_NORM2=0: the three launches)
+            const bool norm2 = fold_norm && tb == 2 && !(getenv("MC_PF_NORM2") && atoi(getenv("MC_PF_NORM2")) == 0);
+            if (L.attention_post_norm && norm2 && gemm_to_parts(L.wo, pf_att, M, &sp, &gs)) {
+                if (gs != MC_OK) return gs;
+                s = timed("norm", [&] { return launch("mc_pf_rmsnorm2_parts_bfloat", M, 1, 1, 256, 0,
+                           pack((const void*)pf_part, sp, (uint32_t)M, (const void*)pf_x, pf_h, (const void*)L.attention_post_norm, (const void*)L.ffn_norm,
+                                pf_xn, (uint32_t)dim, cfg.norm_eps, mu)); });
+            } else if (L.attention_post_norm) {
                 s = timed("gemm_wo", [&] { return gemm(L.wo, 0, pf_att, pf_proj, nullptr, M); });
                 if (s != MC_OK) return s;
                 s = norm_rows(pf_proj, L.attention_post_norm, pf_x, pf_h, M, mu);
@@ -2186,7 +2194,15 @@ struct mc_decoder {
                                    : pack(pf_g2, pf_g, (uint32_t)cfg.ffn_dim, (int32_t)(gemma ? 1 : 0))); });
             }
             if (s != MC_OK) return s;
-            if (L.ffn_post_norm) {
+            if (L.ffn_post_norm && norm2 && gemm_to_parts(L.w2, pf_g, M, &sp, &gs)) {
+                if (gs != MC_OK) return gs;
+                // x = T(h + post_norm(T(sum))) -> pf_x (the block's output), and the NEXT block's attention norm of it -> pf_xn
+                const void* wn = li + 1 < n_own ? (const void*)layers[li + 1].attention_norm : (const void*)nullptr;
+                s = timed("norm", [&] { return launch("mc_pf_rmsnorm2_parts_bfloat", M, 1, 1, 256, 0,
+                           pack((const void*)pf_part, sp, (uint32_t)M, (const void*)pf_h, pf_x, (const void*)L.ffn_post_norm, wn, pf_xn, (uint32_t)dim,
+                                cfg.norm_eps, mu)); });
+                xn_ready = wn != nullptr;
+            } else if (L.ffn_post_norm) {
                 s = timed("gemm_w2", [&] { return gemm(L.w2, 0, pf_g, pf_proj, nullptr, M); });
                 if (s != MC_OK) return s;
                 s = norm_rows(pf_proj, L.ffn_post_norm, pf_h, pf_x, M, mu);

@@ -2056,6 +2056,66 @@ mc_pf_rope_cache_parts_bfloat(const float* part, uint32_t splits, uint32_t M, bf
     dst[j] = o1;
     dst[j + half] = o2;
 }
+// gemma3's blocks put a norm between the projection and the residual (attention_post_norm, ffn_post_norm): Wo / w2 partials -> p = T(sum)
+// -> h = T(res + T((mu + w_post) p / rms(p))) (written: the next residual) -> rmsnorm(h) with w_next (round 6: mc_pf_splitk_reduce_bfloat +
+// mc_pf_rmsnorm_bfloat with a residual + mc_pf_rmsnorm_bfloat in one launch; w_next null: the last block, no second norm).  Every element goes
+// through those three kernels' operations, and both sums of squares are formed as pf_rmsnorm_body forms them (a thread's packets in order, then
+// block_sum): bit for bit their rows.  One workgroup of 256 threads per row, dim a multiple of 8 and at most 8192.
+extern "C" __global__ void
+mc_pf_rmsnorm2_parts_bfloat(const float* part, uint32_t splits, uint32_t M, const bf16_t* res, bf16_t* h_out, const bf16_t* w_post, const bf16_t* w_next,
+                            bf16_t* y, uint32_t dim, float eps, float mu)
+{
+    __shared__ float red[16];
+    const size_t base = (size_t)blockIdx.x * dim, zs = (size_t)M * dim;
+    const uint32_t npk = dim / 8, bd = blockDim.x, rounds = (npk + bd - 1) / bd;
+    float pv[4][8], hv[4][8];
+    auto elem = [](const uint4& v, int j) -> float {
+        const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+        return __uint_as_float((j & 1) ? (d[j >> 1] & 0xFFFF0000u) : (d[j >> 1] << 16));
+    };
+    float ss = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        if ((uint32_t)i >= rounds) break;
+        const uint32_t pk = threadIdx.x + i * bd, pc = pk < npk ? pk : npk - 1;
+        pf_part_sum8(part, splits, zs, base + 8 * pc, pv[i]);
+#pragma unroll
+        for (int j = 0; j < 8; j++) pv[i][j] = bf2f(f2bf(pv[i][j])); // mc_pf_splitk_reduce_bfloat: T(sum), the row the first norm reads
+        if (pk < npk)
+#pragma unroll
+            for (int j = 0; j < 8; j++) ss += pv[i][j] * pv[i][j];
+    }
+    const float inv1 = 1.0f / sqrtf(block_sum(ss, red) / (float)dim + eps);
+    ss = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        if ((uint32_t)i >= rounds) break;
+        const uint32_t pk = threadIdx.x + i * bd, pc = pk < npk ? pk : npk - 1;
+        const uint4 wv = reinterpret_cast<const uint4*>(w_post)[pc], rv = reinterpret_cast<const uint4*>(res + base)[pc];
+#pragma unroll
+        for (int j = 0; j < 8; j++) hv[i][j] = bf2f(f2bf(elem(rv, j) + BF::rt((mu + elem(wv, j)) * pv[i][j] * inv1))); // the row the second norm reads
+        if (pk < npk) {
+            reinterpret_cast<uint4*>(h_out + base)[pk] = make_uint4(pack_bf16x2(hv[i][0], hv[i][1]), pack_bf16x2(hv[i][2], hv[i][3]),
+                                                                     pack_bf16x2(hv[i][4], hv[i][5]), pack_bf16x2(hv[i][6], hv[i][7]));
+#pragma unroll
+            for (int j = 0; j < 8; j++) ss += hv[i][j] * hv[i][j];
+        }
+    }
+    if (!w_next) return; // (uniform)
+    const float inv2 = 1.0f / sqrtf(block_sum(ss, red) / (float)dim + eps);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        if ((uint32_t)i >= rounds) break;
+        const uint32_t pk = threadIdx.x + i * bd;
+        if (pk >= npk) continue;
+        const uint4 wv = reinterpret_cast<const uint4*>(w_next)[pk];
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) o[j] = BF::rt((mu + elem(wv, j)) * hv[i][j] * inv2);
+        reinterpret_cast<uint4*>(y + base)[pk] = make_uint4(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7]));
+    }
+}
+
 // ---- rope + cache write, four rotation pairs per thread (round 6).  mc_pf_rope_cache{,_parts}_bfloat launch one WAVE per head of a row
 // (hd / 2 threads, a pair each): 98 304 one-wave workgroups at 2048 rows of Llama-3-8B take 24.9 us whatever they do (q and k skipped: 23.2, v
 // skipped: 24.2; four of them per workgroup: the same) -- the rate waves START at, not bytes (50 MB: ~ 10 us).  Here a thread takes 16 bytes of

@@ -75,7 +75,7 @@ def test_decode_and_reference_kernels_present(symbols):
               "mc_attn_fused_t2_bfloat",               # 128-slot ranges (decoder.cc attn_fused_t2: S = 8192)
               # the prompt pass on the quad-interleaved weight copy and its consumers with the split-K reduce inside (round 4)
               "mc_pf2_repack_i4", "mc_pf2_gemm_i4_bfloat", "mc_pf_rope_cache_parts_bfloat", "mc_pf_rope_cache_v4_bfloat", "mc_pf_rope_cache_parts_v4_bfloat", "mc_pf_act_mul_parts_bfloat",
-              "mc_pf_rmsnorm_parts_bfloat", "mc_pf_splitk_reduce_bfloat",
+              "mc_pf_rmsnorm_parts_bfloat", "mc_pf_rmsnorm2_parts_bfloat", "mc_pf_splitk_reduce_bfloat",
               "mc_exp_table_bfloat", "mc_pf_exp_window_bfloat", "mc_pf_attn2_bfloat_hd128", "mc_pf_attn4_bfloat_hd128", "mc_pf_attn8_bfloat_hd128", "mc_pf_attn8_bfloat_hd256", "mc_pf_attn8_bfloat_hd64_h8", "mc_pf_attn8_bfloat_hd64_h4",  # exp of a bfloat16 by table (prompt attention, silu)
               "mc_pf_dequant_rows_i4_bfloat", "mc_pf_dequant_rows_i8_bfloat"):  # the dequantised copy the opt-in library GEMM multiplies by
         assert k in symbols, k

@@ -624,6 +624,39 @@ def test_head_dim_64_prompt_attention_through_lds_tiles(acc, family, heads, kvh,
     check_against_oracle(acc, cfg, weights, dict(weight_format=2, group_size=32), tokens, window=window, follow=1, expect_kernel="mc_pf_attn2_bfloat_hd64")
 
 
+def test_gemma_post_norms_fold_into_the_consumer_of_a_split_gemm(acc, monkeypatch):
+    """gemma3 blocks wide enough for Wo and w2 to split K: mc_pf_rmsnorm2_parts_bfloat sums the fp32 partials, applies the post norm with the
+    residual and the next norm in one launch -- against the oracle, and bit for bit MC_PF_NORM2=0 (mc_pf_splitk_reduce_bfloat + two
+    mc_pf_rmsnorm_bfloat): logits, tokens, caches."""
+    import metalchat_amd as mc
+
+    cfg = mg.tiny_cfg(BF16, family=1, dim=2048, n_heads=8, n_kv_heads=2, head_dim=128, ffn_dim=1024, n_layers=2, vocab=512, max_seq_len=448,
+                      rope_sliding_theta=10000.0, sliding_stride=2)
+    weights = mg.make_model(cfg, seed=171, quant="i4", group=128)
+    tokens = np.random.default_rng(71).integers(0, cfg["vocab"], 400).tolist()
+    check_against_oracle(acc, cfg, weights, dict(weight_format=2, group_size=128), tokens, follow=2, expect_kernel="mc_pf_rmsnorm2_parts_bfloat")
+    out = {}
+    for fold in ("1", "0"):
+        monkeypatch.setenv("MC_PF_NORM2", fold)
+        dec = mc.Decoder(acc, **mg.decoder_kwargs(cfg, weight_format=2, group_size=128))
+        dec.load_model(weights)
+        dec.launch_log(True)
+        toks = [dec.prefill(tokens, 0)]
+        names = dec.launched()
+        assert names.count("mc_pf_rmsnorm2_parts_bfloat") == (2 * cfg["n_layers"] if fold == "1" else 0), sorted(set(names))
+        lg = dec.logits().copy()
+        for i in range(3):
+            toks.append(dec.step(toks[-1], len(tokens) + i))
+        out[fold] = (toks, lg, dec.logits().copy(), [dec.export_kv(l) for l in range(cfg["n_layers"])])
+        dec.release()
+    assert out["1"][0] == out["0"][0]
+    parity.exact(out["1"][1], out["0"][1], "logits of the prompt, folded post norms vs three launches")
+    parity.exact(out["1"][2], out["0"][2], "logits three tokens later")
+    for l, ((ka, va), (kb, vb)) in enumerate(zip(out["1"][3], out["0"][3])):
+        parity.exact(ka, kb, f"block {l}: K cache")
+        parity.exact(va, vb, f"block {l}: V cache")
+
+
 def test_gelu_table_is_the_function_for_every_bfloat16(acc):
     """Round 6: mc_gelu_table_bfloat's table IS T(gelu) of every bfloat16 value -- mc_pf_act_mul_bfloat over all 65536 values as `a` (b = 1) with the
     table and with the fp64 tanh per element give the same rows (NaN inputs aside: their payloads are not compared)."""
