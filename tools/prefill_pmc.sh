@@ -10,6 +10,6 @@ for G in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 S
   rm -rf /tmp/pq
   rocprofv3 --pmc $G --output-format csv -d /tmp/pq -- python3 /root/repo/tools/prefill_bench.py $N > /dev/null 2> /tmp/pq.err
   echo "== $N rows: $G" >> $LOG
-  for K in mc_pf_gemm8_i4_bfloat_e3 mc_pf_gemm8_i4_bfloat_e2 mc_pf_gemm8_i4_bfloat_e0 mc_pf_attn8_bfloat mc_pf_attn4_bfloat; do python3 /root/repo/tools/pmc_summary.py /tmp/pq $K 2>/dev/null >> $LOG; done
+  for K in mc_pf_gemm8_w_bfloat_e3 mc_pf_gemm8_w_bfloat_e2 mc_pf_gemm8_w_bfloat_e0 mc_pf_gemm8_i4_bfloat_e3 mc_pf_gemm8_i4_bfloat_e2 mc_pf_gemm8_i4_bfloat_e0 mc_pf_attn8_bfloat mc_pf_attn4_bfloat; do python3 /root/repo/tools/pmc_summary.py /tmp/pq $K 2>/dev/null >> $LOG; done
 done
 cat $LOG
