@@ -1,5 +1,5 @@
 """Time-to-first-token of the prompt pass on the BASELINE model shape (tuning aid).
-usage: [WBITS=4|8|16] [MODEL=llama3-8b|gemma|tinyllama|llama32] python tools/prefill_bench.py [len ...]   (16: plain bfloat weights -- what the tiled GEMM does without its
+usage: [S=max_seq_len] [WBITS=4|8|16] [MODEL=llama3-8b|gemma|tinyllama|llama32] python tools/prefill_bench.py [len ...]   (16: plain bfloat weights -- what the tiled GEMM does without its
 dequantisation; gemma: Gemma-7B shapes with the gemma3 block, BASELINE configs[3])"""
 import sys
 import time
@@ -22,7 +22,7 @@ shape = (dict(dim=2048, n_heads=32, n_kv_heads=4, head_dim=64, ffn_dim=5632, n_l
               family=mc.FAMILY_GEMMA3, rope_sliding_theta=10000.0, sliding_stride=6) if GEMMA else
          dict(dim=4096, n_heads=32, n_kv_heads=8, head_dim=128, ffn_dim=14336, n_layers=32, vocab=128256, rope_theta=500000.0, attn_scale=128 ** -0.5))
 VOCAB, PARAMS = shape["vocab"], shape["n_layers"] * (shape["dim"] * shape["head_dim"] * (2 * shape["n_heads"] + 2 * shape["n_kv_heads"]) + 3 * shape["dim"] * shape["ffn_dim"])
-dec = mc.Decoder(acc, dtype=mc.BF16, max_seq_len=2048, norm_eps=1e-5,
+dec = mc.Decoder(acc, dtype=mc.BF16, max_seq_len=int(os.environ.get("S", "2048")), norm_eps=1e-5,
                  weight_format={"4": mc.WFMT_I4, "8": mc.WFMT_I8, "16": mc.WFMT_T}[os.environ.get("WBITS", "4")],
                  group_size=0 if os.environ.get("WBITS") == "16" else 128, **shape)
 dec.init_synthetic(1)
